@@ -1,0 +1,113 @@
+"""FASTA/FASTQ reading and the byte encoding the distance kernels see.
+
+Behaviour follows apples/fasta2dic.py:
+* record name = header up to the first space (fasta2dic.py:17);
+* the last character of every line is dropped unconditionally (``l[:-1]``,
+  fasta2dic.py:13,20,22), so a final line without a newline loses a base;
+* sequences are upper-cased, or with masking lower-case -> '-' (fasta2dic.py:50,63-67);
+* letters outside the alphabet -> '-': nt ``BDEFHIJKLMNOPQRSUVWXYZ``, aa ``BJOUXZ``
+  (fasta2dic.py:58-61); every other byte passes through as an ordinary symbol.
+
+Instead of ``{name: ndarray('S1')}`` the build keeps one dense ``uint8[N, L]``
+matrix plus a name list (dict semantics: a repeated name keeps its first
+position and the last sequence).
+"""
+import numpy as np
+
+
+def read_records(fp):
+    """Yield ``(name, seq)`` for FASTA records and ``(name, seq)`` for FASTQ ones."""
+    last = None
+    while True:
+        if not last:
+            for line in fp:
+                if line[0] in '>@':
+                    last = line[:-1]
+                    break
+        if not last:
+            break
+        name = last[1:].partition(' ')[0]
+        parts = []
+        last = None
+        for line in fp:
+            if line[0] in '@+>':
+                last = line[:-1]
+                break
+            parts.append(line[:-1])
+        if not last or last[0] != '+':
+            yield name, ''.join(parts)
+            if not last:
+                break
+        else:  # FASTQ: skip the quality block
+            seq = ''.join(parts)
+            got = 0
+            complete = False
+            for line in fp:
+                got += len(line) - 1
+                if got >= len(seq):
+                    last = None
+                    complete = True
+                    yield name, seq
+                    break
+            if not complete:
+                yield name, seq
+                break
+
+
+def _translation(prot_flag, mask_flag):
+    tab = np.arange(256, dtype=np.uint8)
+    lower = np.frombuffer(b'abcdefghijklmnopqrstuvwxyz', dtype=np.uint8)
+    if mask_flag:
+        tab[lower] = ord('-')
+    else:
+        tab[lower] = lower - 32
+    invalid = b'BJOUXZ' if prot_flag else b'BDEFHIJKLMNOPQRSUVWXYZ'
+    inv = np.zeros(256, dtype=bool)
+    inv[np.frombuffer(invalid, dtype=np.uint8)] = True
+    tab[inv[tab]] = ord('-')
+    return tab
+
+
+def encode_sequence(seq, prot_flag, mask_flag):
+    """str -> uint8 array in the reference's byte encoding."""
+    raw = np.frombuffer(seq.encode(), dtype=np.uint8)
+    return _translation(prot_flag, mask_flag)[raw]
+
+
+class Alignment:
+    """Names + dense ``uint8[N, L]`` matrix (row r is ``names[r]``)."""
+
+    def __init__(self, names, seqs):
+        self.names = list(names)
+        self.seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        self.index = {n: i for i, n in enumerate(self.names)}
+
+    def __len__(self):
+        return len(self.names)
+
+    @property
+    def length(self):
+        return self.seqs.shape[1] if self.seqs.ndim == 2 else 0
+
+
+def read_alignment(path, prot_flag, mask_flag):
+    """FASTA file -> :class:`Alignment` (apples/fasta2dic.py:42-72)."""
+    tab = _translation(prot_flag, mask_flag)
+    order = {}
+    rows = []
+    with open(path) as f:
+        for name, seq in read_records(f):
+            enc = tab[np.frombuffer(seq.encode(), dtype=np.uint8)]
+            if name in order:
+                rows[order[name]] = enc
+            else:
+                order[name] = len(rows)
+                rows.append(enc)
+    if not rows:
+        return Alignment([], np.zeros((0, 0), dtype=np.uint8))
+    L = len(rows[0])
+    for n, r in zip(order, rows):
+        if len(r) != L:
+            raise ValueError('sequence %s has length %d, expected %d (alignment rows must be equal length)'
+                             % (n, len(r), L))
+    return Alignment(list(order), np.vstack(rows))

@@ -1,0 +1,161 @@
+"""Seeded synthetic inputs: backbone tree, simulated alignment, queries.
+
+Deterministic from (seed, N, L, Q, alphabet).  Used by bench.py, the parity
+tests and the golden generator; nothing here is on the placement hot path.
+
+* Tree: N leaves ``t0..``, random-join binary topology (repeatedly join two
+  random roots), branch lengths Exp(mean 0.01).
+* Alignment: uniform root sequence evolved down every edge with per-site
+  substitution probability 3/4(1-exp(-4t/3)) (nt, JC69) or 19/20(1-exp(-20t/19))
+  (aa, Poisson), substitutions uniform over the other letters; then 5 % of the
+  sites of every sequence -> '-'.
+* Queries: random leaf edge, attached at its midpoint, pendant Exp(0.01).
+"""
+import numpy as np
+
+from .tree import parse_newick
+
+NT = np.frombuffer(b'ACGT', dtype=np.uint8)
+AA = np.frombuffer(b'ARNDCQEGHILKMFPSTWYV', dtype=np.uint8)
+
+
+def random_tree_newick(n_leaves, seed=1, mean_len=0.01):
+    """Random-join binary tree as a Newick string (iterative, O(N))."""
+    rng = np.random.default_rng(seed)
+    # node table: children of internal nodes; leaves 0..n-1
+    left = []
+    right = []
+    roots = list(range(n_leaves))
+    nxt = n_leaves
+    picks = rng.random(2 * n_leaves)
+    pi = 0
+    while len(roots) > 1:
+        i = int(picks[pi] * len(roots)); pi += 1
+        roots[i], roots[-1] = roots[-1], roots[i]
+        a = roots.pop()
+        j = int(picks[pi] * len(roots)); pi += 1
+        roots[j], roots[-1] = roots[-1], roots[j]
+        b = roots.pop()
+        left.append(a)
+        right.append(b)
+        roots.append(nxt)
+        nxt += 1
+    total = nxt
+    lens = rng.exponential(mean_len, size=total)
+    # iterative Newick emission
+    out = []
+    stack = [(roots[0], 0)]
+    while stack:
+        v, st = stack.pop()
+        if v < n_leaves:
+            out.append('t%d:%.6f' % (v, lens[v]))
+            continue
+        k = v - n_leaves
+        if st == 0:
+            out.append('(')
+            stack.append((v, 1))
+            stack.append((left[k], 0))
+        elif st == 1:
+            out.append(',')
+            stack.append((v, 2))
+            stack.append((right[k], 0))
+        else:
+            if v == roots[0]:
+                out.append(')')
+            else:
+                out.append('):%.6f' % lens[v])
+    out.append(';')
+    return ''.join(out)
+
+
+def _sub_prob(t, n_states):
+    k = n_states / (n_states - 1.0)
+    return (1.0 - 1.0 / n_states) * (1.0 - np.exp(-k * t))
+
+
+def _evolve(idx, t, n_states, rng):
+    """idx: int8 state array; returns a mutated copy after time t."""
+    p = _sub_prob(t, n_states)
+    hit = rng.random(idx.shape[0]) < p
+    nh = int(hit.sum())
+    out = idx.copy()
+    if nh:
+        out[hit] = (idx[hit] + rng.integers(1, n_states, size=nh)) % n_states
+    return out
+
+
+class SynthData:
+    pass
+
+
+def make_dataset(n_leaves, length, n_queries, protein=False, seed_tree=1, seed_aln=5, seed_query=3,
+                 gap_rate=0.05, mean_len=0.01):
+    """Returns an object with: newick, tree, ref_names, ref_seqs uint8[N,L] (rows in
+    leaf order), query_names, query_seqs uint8[Q,L], query_leaf (true sister leaf)."""
+    alphabet = AA if protein else NT
+    ns = len(alphabet)
+    newick = random_tree_newick(n_leaves, seed_tree, mean_len)
+    tree = parse_newick(newick)
+    rng = np.random.default_rng(seed_aln)
+    n = tree.n_nodes
+    states = np.empty((n, length), dtype=np.int8)
+    states[tree.root] = rng.integers(0, ns, size=length)
+    for v in range(n - 2, -1, -1):  # parents (larger ids) first
+        states[v] = _evolve(states[tree.parent[v]], tree.edge_len[v], ns, rng)
+    leaves = tree.leaves
+    ref = alphabet[states[leaves]]
+    gaps = rng.random(ref.shape) < gap_rate
+    ref[gaps] = ord('-')
+    ref_names = [tree.labels[v] for v in leaves]
+
+    rq = np.random.default_rng(seed_query)
+    q_leaf = rq.integers(0, len(leaves), size=n_queries)
+    q_pend = rq.exponential(mean_len, size=n_queries)
+    qs = np.empty((n_queries, length), dtype=np.uint8)
+    for i in range(n_queries):
+        v = leaves[q_leaf[i]]
+        mid = _evolve(states[tree.parent[v]], tree.edge_len[v] / 2.0, ns, rq)
+        s = _evolve(mid, q_pend[i], ns, rq)
+        row = alphabet[s]
+        row[rq.random(length) < gap_rate] = ord('-')
+        qs[i] = row
+    d = SynthData()
+    d.newick = newick
+    d.tree = tree
+    d.ref_names = ref_names
+    d.ref_seqs = np.ascontiguousarray(ref)
+    d.query_names = ['q%d' % i for i in range(n_queries)]
+    d.query_seqs = qs
+    d.query_leaf = q_leaf
+    d.query_pendant = q_pend
+    return d
+
+
+def noisy_distance_rows(tree, query_leaf, query_pendant, rows, seed_noise=7, rel_sd=0.05, floor=1e-4):
+    """``-d`` style input (C5): for the queries in ``rows``, true path distance from the
+    attachment point to every leaf x (1 + rel_sd N(0,1)), floored.  float64[len(rows), n_leaves],
+    columns in leaf order."""
+    n = tree.n_nodes
+    leaves = tree.leaves
+    out = np.empty((len(rows), len(leaves)), dtype=np.float64)
+    for k, qi in enumerate(rows):
+        rng = np.random.default_rng([seed_noise, int(qi)])
+        v = int(leaves[query_leaf[qi]])
+        # distance from the midpoint of v's edge to every node: walk up, then sweep down
+        dist = np.full(n, -1.0)
+        half = tree.edge_len[v] / 2.0
+        dist[v] = half
+        up = half
+        u = v
+        while tree.parent[u] >= 0:
+            u2 = int(tree.parent[u])
+            up = up + (tree.edge_len[u] if u != v else 0.0)
+            dist[u2] = up
+            u = u2
+        for w in range(n - 2, -1, -1):
+            if dist[w] < 0:
+                dist[w] = dist[tree.parent[w]] + tree.edge_len[w]
+        true = dist[leaves] + query_pendant[qi]
+        noisy = true * (1.0 + rel_sd * rng.standard_normal(len(leaves)))
+        out[k] = np.maximum(noisy, floor)
+    return out

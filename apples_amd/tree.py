@@ -1,0 +1,198 @@
+"""Backbone tree as flat arrays (the layout the HIP kernels read).
+
+Replaces the treeswift objects the reference walks (apples/prepareTree.py:24-36)
+with struct-of-arrays indexed by ``edge_index``:
+
+* node id == ``edge_index`` == 0-based left-to-right post-order number
+  (apples/util.py:57-69), so children < parent and the root is ``n_nodes - 1``;
+* ``level`` == BFS depth, root 0 (apples/util.py:72-88);
+* children in file order as CSR (``child_off``/``child_idx``) -- the order the
+  reference accumulates S/R sums in (apples/OLS.py:36, 59).
+
+Newick reader follows the contract in SURVEY.md Appendix B: ``[&R]`` prefix ->
+rooted, labels may be quoted, ``[...]`` comments dropped, lengths via float().
+"""
+import re
+
+import numpy as np
+
+_TOKEN = re.compile(r"\(|\)|,|;|:|'(?:[^']|'')*'|\[[^\]]*\]|[^(),:;\[\]']+")
+
+
+class Tree:
+    """Array form of the backbone tree.  All arrays have length ``n_nodes``."""
+
+    def __init__(self, parent, edge_len, has_len, labels, child_off, child_idx, level, is_rooted):
+        self.parent = parent  # int32, -1 for the root
+        self.edge_len = edge_len  # float64, 0.0 where has_len is False
+        self.has_len = has_len  # bool: edge length present in the Newick
+        self.labels = labels  # list[str|None]
+        self.child_off = child_off  # int32[n_nodes+1]
+        self.child_idx = child_idx  # int32[n_nodes-1], file order
+        self.level = level  # int32
+        self.is_rooted = is_rooted
+        self.n_nodes = len(parent)
+        self.root = self.n_nodes - 1
+        nchild = np.diff(child_off)
+        self.is_leaf = nchild == 0
+        self.leaves = np.nonzero(self.is_leaf)[0].astype(np.int32)  # ascending id == left-to-right
+        # leaf label -> node id (apples/prepareTree.py:32-34; later duplicates overwrite)
+        self.name_to_node = {}
+        for v in self.leaves:
+            self.name_to_node[labels[v]] = int(v)
+
+    @property
+    def n_leaves(self):
+        return len(self.leaves)
+
+    def children(self, v):
+        return self.child_idx[self.child_off[v]:self.child_off[v + 1]]
+
+
+def parse_newick(text):
+    """Parse one Newick tree string into a :class:`Tree`."""
+    text = text.strip()
+    is_rooted = False
+    if text.startswith('[&R]'):
+        is_rooted = True
+        text = text[4:].lstrip()
+    elif text.startswith('[&U]'):
+        text = text[4:].lstrip()
+
+    # creation-order (pre-order) temporary nodes
+    t_parent = [-1]
+    t_label = [None]
+    t_len = [None]
+    t_children = [[]]
+    cur = 0
+    expect_len = False
+    done = False
+    for m in _TOKEN.finditer(text):
+        tok = m.group(0)
+        c = tok[0]
+        if expect_len:
+            if c in '(),;' or c == '[':
+                raise ValueError('malformed Newick: missing branch length before %r' % tok)
+            t_len[cur] = float(tok.strip())
+            expect_len = False
+            continue
+        if c == '(':
+            t_parent.append(cur)
+            t_label.append(None)
+            t_len.append(None)
+            t_children.append([])
+            t_children[cur].append(len(t_parent) - 1)
+            cur = len(t_parent) - 1
+        elif c == ',':
+            par = t_parent[cur]
+            if par < 0:
+                raise ValueError('malformed Newick: comma at top level')
+            t_parent.append(par)
+            t_label.append(None)
+            t_len.append(None)
+            t_children.append([])
+            t_children[par].append(len(t_parent) - 1)
+            cur = len(t_parent) - 1
+        elif c == ')':
+            cur = t_parent[cur]
+            if cur < 0:
+                raise ValueError('malformed Newick: unbalanced parentheses')
+        elif c == ':':
+            expect_len = True
+        elif c == ';':
+            done = True
+            break
+        elif c == '[':
+            continue  # comment
+        elif c == "'":
+            t_label[cur] = tok[1:-1].replace("''", "'")
+        else:
+            s = tok.strip()
+            if s:
+                t_label[cur] = s
+    if not done and cur != 0:
+        raise ValueError('malformed Newick: unexpected end of input')
+    if cur != 0:
+        raise ValueError('malformed Newick: unbalanced parentheses')
+
+    n = len(t_parent)
+    # iterative left-to-right post-order numbering (apples/util.py:65-69)
+    post = np.empty(n, dtype=np.int64)
+    counter = 0
+    stack = [(0, 0)]
+    while stack:
+        v, i = stack.pop()
+        ch = t_children[v]
+        if i < len(ch):
+            stack.append((v, i + 1))
+            stack.append((ch[i], 0))
+        else:
+            post[v] = counter
+            counter += 1
+
+    parent = np.full(n, -1, dtype=np.int32)
+    edge_len = np.zeros(n, dtype=np.float64)
+    has_len = np.zeros(n, dtype=bool)
+    labels = [None] * n
+    nchild = np.zeros(n, dtype=np.int64)
+    for v in range(n):
+        p = post[v]
+        if t_parent[v] >= 0:
+            parent[p] = post[t_parent[v]]
+        if t_len[v] is not None:
+            edge_len[p] = t_len[v]
+            has_len[p] = True
+        labels[p] = t_label[v]
+        nchild[p] = len(t_children[v])
+    child_off = np.zeros(n + 1, dtype=np.int32)
+    child_off[1:] = np.cumsum(nchild)
+    child_idx = np.empty(max(n - 1, 0), dtype=np.int32)
+    for v in range(n):
+        p = post[v]
+        o = child_off[p]
+        for k, c in enumerate(t_children[v]):
+            child_idx[o + k] = post[c]
+    # BFS depth; parents have larger ids, so a descending sweep sees parents first
+    level = np.zeros(n, dtype=np.int32)
+    for v in range(n - 2, -1, -1):
+        level[v] = level[parent[v]] + 1
+    return Tree(parent, edge_len, has_len, labels, child_off, child_idx, level, is_rooted)
+
+
+def read_tree(path):
+    with open(path) as f:
+        return parse_newick(f.read())
+
+
+def _len_str(x):
+    # apples/jutil.py:80-87 -- integral floats print as ints, others as str(float)
+    if float(x).is_integer():
+        return str(int(x))
+    return str(float(x))
+
+
+def extended_newick(tree):
+    """Newick with ``{edge_index}`` after every non-root node (apples/jutil.py:22-96)."""
+    strs = [None] * tree.n_nodes
+    for v in range(tree.n_nodes):  # ascending id is a post-order
+        ch = tree.children(v)
+        if len(ch) == 0:
+            strs[v] = '' if tree.labels[v] is None else str(tree.labels[v])
+        else:
+            out = ['(']
+            for c in ch:
+                out.append(strs[c])
+                if tree.has_len[c]:
+                    out.append(':%s' % _len_str(tree.edge_len[c]))
+                out.append('{%d}' % c)
+                out.append(',')
+                strs[c] = None
+            out.pop()
+            out.append(')')
+            if tree.labels[v] is not None:
+                out.append(str(tree.labels[v]))
+            strs[v] = ''.join(out)
+    s = strs[tree.root]
+    if tree.is_rooted:
+        return '[&R] %s;' % s
+    return '%s;' % s
