@@ -1,0 +1,756 @@
+// C ABI of libapples_hip.so: context, uploads, batch driver, timing.  See include/apples_hip.h.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "common.h"
+
+thread_local std::string g_create_error;
+
+namespace {
+
+template <typename T>
+int dev_alloc(apples_ctx *ctx, T **p, int64_t n) {
+    *p = nullptr;
+    if (n <= 0) n = 1;
+    HIP_TRY(ctx, hipMalloc((void **)p, (size_t)n * sizeof(T)));
+    return 0;
+}
+
+template <typename T>
+int dev_upload(apples_ctx *ctx, T **p, const T *h, int64_t n) {
+    if (dev_alloc(ctx, p, n)) return 1;
+    if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(*p, h, (size_t)n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+void dev_free(void *p) {
+    if (p) (void)hipFree(p);
+}
+
+int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// BLOSUM45-derived dissimilarities (FastTree2's table, the data apples/distance.py:12-415 reads);
+// supplied by the host in params? No: it is part of the algorithm, so it is compiled in via
+// blosum45_table.inc, generated from apples_amd/data/blosum45_dist.txt by the build script.
+const double kBlosum45[400] = {
+#include "blosum45_table.inc"
+};
+
+int upload_tree(apples_ctx *ctx, const apples_tree *t) {
+    DevTree &d = ctx->tree;
+    d.n_nodes = t->n_nodes;
+    int h = 0;
+    for (int i = 0; i < t->n_nodes; ++i) h = std::max(h, t->level[i]);
+    d.height = h;
+    if (dev_upload(ctx, &d.parent, t->parent, t->n_nodes)) return 1;
+    if (dev_upload(ctx, &d.edge_len, t->edge_len, t->n_nodes)) return 1;
+    if (dev_upload(ctx, &d.child_off, t->child_off, t->n_nodes + 1)) return 1;
+    if (dev_upload(ctx, &d.child_idx, t->child_idx, std::max(t->n_nodes - 1, 1))) return 1;
+    if (dev_upload(ctx, &d.level, t->level, t->n_nodes)) return 1;
+    return 0;
+}
+
+// sort keys so that deeper leaves come first; rows that are not tree leaves go last
+std::vector<int32_t> level_order(const int32_t *node, int64_t n, const std::vector<int32_t> &level) {
+    std::vector<int32_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
+        int la = node[a] >= 0 ? level[node[a]] : -1;
+        int lb = node[b] >= 0 ? level[node[b]] : -1;
+        return la > lb;
+    });
+    return idx;
+}
+
+int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignment *al) {
+    DevAlign &a = ctx->aln;
+    a.n_rows = al->n_rows;
+    a.n_refs = al->n_refs;
+    a.L = al->length;
+    a.W = (a.L + 31) / 32;
+    a.G = (a.W + 3) / 4;
+    a.slots_pad = round_up(std::max<int64_t>(a.n_rows, 1), APPLES_TPB);
+    if (a.L <= 0 || a.L > 65535) { ctx->err = "alignment length must be in [1, 65535]"; return 1; }
+    if (al->n_refs > al->n_rows) { ctx->err = "n_refs > n_rows"; return 1; }
+    std::vector<int32_t> level(t->level, t->level + t->n_nodes);
+    for (int64_t r = 0; r < a.n_refs; ++r)
+        if (al->row_node[r] >= t->n_nodes) { ctx->err = "row_node out of range"; return 1; }
+    std::vector<int32_t> ord = level_order(al->row_node, a.n_refs, level);
+    a.slot_row.assign(a.n_rows, 0);
+    a.row_slot.assign(a.n_rows, 0);
+    for (int64_t s = 0; s < a.n_refs; ++s) { a.slot_row[s] = ord[s]; a.row_slot[ord[s]] = (int32_t)s; }
+    for (int64_t r = a.n_refs; r < a.n_rows; ++r) { a.slot_row[r] = (int32_t)r; a.row_slot[r] = (int32_t)r; }
+    std::vector<int32_t> slot_node(a.n_refs), slot_level(a.n_refs);
+    for (int64_t s = 0; s < a.n_refs; ++s) {
+        int nd = al->row_node[a.slot_row[s]];
+        slot_node[s] = nd;
+        slot_level[s] = nd >= 0 ? level[nd] : -1;
+    }
+    // clusters
+    std::vector<int32_t> rep_slot, rep_moff, mem_slot, slot_rep(a.n_refs, -1), slot_mpos(a.n_refs, 0);
+    if (al->rep_row == nullptr) {
+        a.n_reps = a.n_refs;
+        a.all_singleton = true;
+        rep_slot.resize(a.n_reps); rep_moff.resize(a.n_reps + 1); mem_slot.resize(a.n_reps);
+        for (int64_t j = 0; j < a.n_reps; ++j) {
+            rep_slot[j] = a.row_slot[j]; rep_moff[j] = (int32_t)j; mem_slot[j] = a.row_slot[j];
+            slot_rep[a.row_slot[j]] = (int32_t)j;
+        }
+        rep_moff[a.n_reps] = (int32_t)a.n_reps;
+    } else {
+        a.n_reps = al->n_reps;
+        a.all_singleton = true;
+        rep_slot.resize(a.n_reps); rep_moff.assign(al->member_off, al->member_off + a.n_reps + 1);
+        mem_slot.resize(rep_moff[a.n_reps]);
+        for (int64_t j = 0; j < a.n_reps; ++j) {
+            if (al->rep_row[j] < 0 || al->rep_row[j] >= a.n_rows) { ctx->err = "rep_row out of range"; return 1; }
+            rep_slot[j] = a.row_slot[al->rep_row[j]];
+            int cnt = rep_moff[j + 1] - rep_moff[j];
+            if (cnt != 1 || al->member_row[rep_moff[j]] != al->rep_row[j]) a.all_singleton = false;
+            for (int m = rep_moff[j]; m < rep_moff[j + 1]; ++m) {
+                int r = al->member_row[m];
+                if (r < 0 || r >= a.n_refs) { ctx->err = "member_row out of range"; return 1; }
+                mem_slot[m] = a.row_slot[r];
+                slot_rep[a.row_slot[r]] = (int32_t)j;
+                slot_mpos[a.row_slot[r]] = m - rep_moff[j];
+            }
+        }
+        for (int64_t s = 0; s < a.n_refs; ++s)
+            if (slot_rep[s] < 0) { ctx->err = "every reference row must belong to exactly one cluster"; return 1; }
+        if (a.all_singleton && a.n_reps != a.n_refs) a.all_singleton = false;
+    }
+    if (dev_upload(ctx, &a.slot_node, slot_node.data(), a.n_refs)) return 1;
+    if (dev_upload(ctx, &a.slot_level, slot_level.data(), a.n_refs)) return 1;
+    if (dev_upload(ctx, &a.slot_rep, slot_rep.data(), a.n_refs)) return 1;
+    if (dev_upload(ctx, &a.slot_mpos, slot_mpos.data(), a.n_refs)) return 1;
+    if (dev_upload(ctx, &a.rep_slot, rep_slot.data(), a.n_reps)) return 1;
+    if (dev_upload(ctx, &a.rep_moff, rep_moff.data(), a.n_reps + 1)) return 1;
+    if (dev_upload(ctx, &a.mem_slot, mem_slot.data(), (int64_t)mem_slot.size())) return 1;
+
+    // rows in slot order -> device, then pack on the device
+    std::vector<uint8_t> stage((size_t)a.n_rows * a.L);
+    for (int64_t s = 0; s < a.n_rows; ++s)
+        memcpy(stage.data() + (size_t)s * a.L, al->rows + (size_t)a.slot_row[s] * a.L, a.L);
+    if (dev_upload(ctx, &a.raw, stage.data(), (int64_t)stage.size())) return 1;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // stage goes out of scope
+
+    if (ctx->params.model == APPLES_SCOREDIST) {
+        int Lpad = (a.L + 15) / 16 * 16;
+        if (dev_alloc(ctx, &a.aa_idx, (int64_t)(Lpad / 16) * a.slots_pad * 16)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(a.aa_idx, 20, (size_t)(Lpad / 16) * a.slots_pad * 16, ctx->stream));
+        if (launch_pack_aa(ctx, a.raw, a.n_rows, a.L, a.aa_idx, a.slots_pad, false)) return 1;
+        a.planes = 0;
+        double tab[21 * 21];
+        for (int i = 0; i < 21; ++i)
+            for (int j = 0; j < 21; ++j) tab[i * 21 + j] = (i < 20 && j < 20) ? kBlosum45[i * 20 + j] : 0.0;
+        if (dev_upload(ctx, &ctx->blosum, tab, 21 * 21)) return 1;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        int *d_exotic = nullptr;
+        if (dev_alloc(ctx, &d_exotic, 1)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(d_exotic, 0, sizeof(int), ctx->stream));
+        a.planes = 2;
+        int64_t words = (int64_t)a.G * 3 * a.slots_pad;
+        if (dev_alloc(ctx, &a.packed, words)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(a.packed, 0, (size_t)words * sizeof(uint4), ctx->stream));
+        if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 2, a.packed, a.slots_pad, false, d_exotic)) return 1;
+        int exotic = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&exotic, d_exotic, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (exotic) {  // symbols beyond ACGT-: keep the raw byte in 8 planes
+            dev_free(a.packed);
+            a.planes = 8;
+            words = (int64_t)a.G * 9 * a.slots_pad;
+            if (dev_alloc(ctx, &a.packed, words)) return 1;
+            HIP_TRY(ctx, hipMemsetAsync(a.packed, 0, (size_t)words * sizeof(uint4), ctx->stream));
+            if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 8, a.packed, a.slots_pad, false, d_exotic)) return 1;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        dev_free(d_exotic);
+    }
+    return 0;
+}
+
+int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond ACGT-: widen the reference
+    DevAlign &a = ctx->aln;
+    if (a.planes == 8) return 0;
+    int *d_exotic = nullptr;
+    if (dev_alloc(ctx, &d_exotic, 1)) return 1;
+    dev_free(a.packed);
+    a.planes = 8;
+    int64_t words = (int64_t)a.G * 9 * a.slots_pad;
+    if (dev_alloc(ctx, &a.packed, words)) return 1;
+    HIP_TRY(ctx, hipMemsetAsync(a.packed, 0, (size_t)words * sizeof(uint4), ctx->stream));
+    if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 8, a.packed, a.slots_pad, false, d_exotic)) return 1;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(d_exotic);
+    // existing query blocks were packed with 2 planes: repack them
+    for (auto &qb : ctx->blocks) {
+        if (!qb.live || qb.planes == 8) continue;
+        dev_free(qb.packed);
+        int64_t w = qb.n_pad * a.G * 9;
+        if (dev_alloc(ctx, &qb.packed, w)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(qb.packed, 0, (size_t)w * sizeof(uint4), ctx->stream));
+        int *d_ex2 = nullptr;
+        if (dev_alloc(ctx, &d_ex2, 1)) return 1;
+        if (launch_pack_rows(ctx, qb.raw, qb.n, a.L, 8, qb.packed, 0, true, d_ex2)) return 1;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        dev_free(d_ex2);
+        qb.planes = 8;
+    }
+    return 0;
+}
+
+void free_workspace(Workspace &w) {
+    dev_free(w.dist); dev_free(w.counts); dev_free(w.obs_node); dev_free(w.obs_dist); dev_free(w.cnt_gt);
+    dev_free(w.n_obs); dev_free(w.map); dev_free(w.order); dev_free(w.grp_off); dev_free(w.S); dev_free(w.R);
+    dev_free(w.xe);
+    w = Workspace();
+}
+
+// workspaces for `members` rows/columns per query
+int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t want_batch, bool need_dist,
+                     bool need_counts, bool need_xe) {
+    Workspace &w = ctx->ws;
+    const DevTree &t = ctx->tree;
+    int64_t batch = want_batch;
+    if (ctx->params.max_batch > 0) batch = std::min(batch, (int64_t)ctx->params.max_batch);
+    // bound the per-batch buffers to ~6 GiB
+    int64_t per_q = stride * 8 + members * 12 + (int64_t)(t.height + 2) * 4 + (need_counts ? stride * 4 : 0);
+    int64_t cap = std::max<int64_t>(32, ((int64_t)6 << 30) / std::max<int64_t>(per_q, 1));
+    batch = std::min(batch, cap);
+    batch = round_up(std::max<int64_t>(batch, 1), 32);
+    bool regrow = batch > w.batch || members > w.obs_cap || stride > w.stride || (need_counts && !w.counts) || (need_xe && !w.xe) ||
+                  (need_dist && !w.dist);
+    if (!regrow) return 0;
+    batch = std::max(batch, w.batch);
+    int64_t obs_cap = std::max(members, w.obs_cap);
+    stride = std::max(stride, w.stride);
+    bool had_xe = w.xe != nullptr, had_counts = w.counts != nullptr;
+    free_workspace(w);
+    w.batch = batch;
+    w.obs_cap = obs_cap;
+    w.stride = stride;
+    if (dev_alloc(ctx, &w.dist, batch * std::max<int64_t>(stride, 1))) return 1;
+    if (need_counts || had_counts)
+        if (dev_alloc(ctx, &w.counts, batch * std::max<int64_t>(stride, 1))) return 1;
+    if (dev_alloc(ctx, &w.obs_node, batch * obs_cap)) return 1;
+    if (dev_alloc(ctx, &w.obs_dist, batch * obs_cap)) return 1;
+    if (dev_alloc(ctx, &w.cnt_gt, batch * (int64_t)(t.height + 2))) return 1;
+    if (dev_alloc(ctx, &w.n_obs, batch)) return 1;
+    // sweep scratch: one slice per persistent workgroup, bounded to ~48 GiB in total
+    int64_t per_wg = (int64_t)t.n_nodes * (4 + 4 + 48 + 48 + ((need_xe || had_xe) ? 40 : 0)) + (t.height + 4) * 4;
+    int64_t wgs = std::min<int64_t>(1024, std::max<int64_t>(8, ((int64_t)48 << 30) / std::max<int64_t>(per_wg, 1)));
+    w.sweep_wgs = (int)wgs;
+    if (dev_alloc(ctx, &w.map, wgs * t.n_nodes)) return 1;
+    HIP_TRY(ctx, hipMemsetAsync(w.map, 0, (size_t)wgs * t.n_nodes * 4, ctx->stream));
+    if (dev_alloc(ctx, &w.order, wgs * t.n_nodes)) return 1;
+    if (dev_alloc(ctx, &w.grp_off, wgs * (int64_t)(t.height + 4))) return 1;
+    if (dev_alloc(ctx, &w.S, wgs * t.n_nodes * 6)) return 1;
+    if (dev_alloc(ctx, &w.R, wgs * t.n_nodes * 6)) return 1;
+    if (need_xe || had_xe)
+        if (dev_alloc(ctx, &w.xe, wgs * t.n_nodes * 5)) return 1;
+    return 0;
+}
+
+int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t *self_row, QueryBlock *qb) {
+    DevAlign &a = ctx->aln;
+    qb->n = n;
+    qb->n_pad = round_up(std::max<int64_t>(n, 1), 32);
+    if (dev_upload(ctx, &qb->raw, queries, n * a.L)) return 1;
+    std::vector<int32_t> self(std::max<int64_t>(n, 1), -1);
+    if (self_row)
+        for (int64_t i = 0; i < n; ++i) {
+            if (self_row[i] >= a.n_refs) { ctx->err = "self_row out of range"; return 1; }
+            self[i] = self_row[i] >= 0 ? a.row_slot[self_row[i]] : -1;
+        }
+    if (dev_upload(ctx, &qb->self_slot, self.data(), (int64_t)self.size())) return 1;
+    if (dev_alloc(ctx, &qb->out, std::max<int64_t>(n, 1))) return 1;
+    if (ctx->params.model == APPLES_SCOREDIST) {
+        int Lpad = (a.L + 15) / 16 * 16;
+        if (dev_alloc(ctx, &qb->aa_idx, qb->n_pad * Lpad)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(qb->aa_idx, 20, (size_t)qb->n_pad * Lpad, ctx->stream));
+        if (launch_pack_aa(ctx, qb->raw, n, a.L, qb->aa_idx, 0, true)) return 1;
+    } else {
+        int *d_exotic = nullptr;
+        if (dev_alloc(ctx, &d_exotic, 1)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(d_exotic, 0, sizeof(int), ctx->stream));
+        int planes = a.planes;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int64_t w = qb->n_pad * a.G * (planes + 1);
+            if (dev_alloc(ctx, &qb->packed, w)) return 1;
+            HIP_TRY(ctx, hipMemsetAsync(qb->packed, 0, (size_t)w * sizeof(uint4), ctx->stream));
+            if (launch_pack_rows(ctx, qb->raw, n, a.L, planes, qb->packed, 0, true, d_exotic)) return 1;
+            int exotic = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&exotic, d_exotic, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (planes == 2 && exotic) {
+                dev_free(qb->packed);
+                qb->packed = nullptr;
+                if (repack_to_bytes(ctx)) return 1;
+                planes = 8;
+                continue;
+            }
+            break;
+        }
+        qb->planes = planes;
+        dev_free(d_exotic);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    qb->live = true;
+    return 0;
+}
+
+void free_block(QueryBlock *qb) {
+    dev_free(qb->raw); dev_free(qb->packed); dev_free(qb->aa_idx); dev_free(qb->self_slot); dev_free(qb->out);
+    *qb = QueryBlock();
+}
+
+struct PhaseTimer {
+    apples_ctx *ctx;
+    double acc[APPLES_T_COUNT] = {};
+    void begin(int k) { (void)hipEventRecord(ctx->ev[2 * (k & 3)], ctx->stream); }
+    void end(int k) { (void)hipEventRecord(ctx->ev[2 * (k & 3) + 1], ctx->stream); pending[k & 3] = true; kind[k & 3] = k; }
+    bool pending[4] = {false, false, false, false};
+    int kind[4] = {0, 0, 0, 0};
+    void flush() {
+        for (int i = 0; i < 4; ++i)
+            if (pending[i]) {
+                (void)hipEventSynchronize(ctx->ev[2 * i + 1]);
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]);
+                acc[kind[i]] += ms;
+                pending[i] = false;
+            }
+    }
+};
+
+SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t q0) {
+    const DevAlign &a = ctx->aln;
+    Workspace &w = ctx->ws;
+    SelectArgs s{};
+    s.dist = w.dist; s.stride = a.slots_pad; s.gather = nullptr;
+    s.slot_node = a.slot_node; s.slot_level = a.slot_level; s.slot_rep = a.slot_rep; s.slot_mpos = a.slot_mpos;
+    s.rep_slot = a.rep_slot; s.rep_moff = a.rep_moff; s.mem_slot = a.mem_slot;
+    s.n_members = a.n_refs; s.n_reps = a.n_reps; s.all_singleton = a.all_singleton ? 1 : 0; s.table_mode = 0;
+    s.self_slot = qb.self_slot + q0;
+    s.thr = ctx->params.filt_threshold; s.baseobs = ctx->params.base_observation; s.height = ctx->tree.height;
+    s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
+    s.out = qb.out + q0;
+    return s;
+}
+
+SweepArgs sweep_args(apples_ctx *ctx, apples_placement *out, bool keep_edges) {
+    Workspace &w = ctx->ws;
+    SweepArgs s{};
+    s.tree = ctx->tree;
+    s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
+    s.map = w.map; s.order = w.order; s.grp_off = w.grp_off; s.S = w.S; s.R = w.R; s.xe = w.xe;
+    s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
+    s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
+    s.out = out;
+    return s;
+}
+
+int dist_tile_for(int64_t nq) { return nq >= 32 ? 32 : (nq >= 16 ? 16 : (nq >= 8 ? 8 : (nq >= 4 ? 4 : 1))); }
+
+int run_block(apples_ctx *ctx, QueryBlock &qb) {
+    const DevAlign &a = ctx->aln;
+    bool hybrid = ctx->params.criterion == APPLES_HYBRID;
+    if (ensure_workspace(ctx, a.n_refs, a.slots_pad, qb.n, true, false, hybrid)) return 1;
+    Workspace &w = ctx->ws;
+    PhaseTimer pt{ctx};
+    hipEvent_t e_start, e_stop;
+    HIP_TRY(ctx, hipEventCreate(&e_start));
+    HIP_TRY(ctx, hipEventCreate(&e_stop));
+    HIP_TRY(ctx, hipEventRecord(e_start, ctx->stream));
+    int launches = 0;
+    for (int64_t q0 = 0; q0 < qb.n; q0 += w.batch) {
+        int64_t nq = std::min(w.batch, qb.n - q0);
+        pt.flush();
+        pt.begin(APPLES_T_DIST);
+        if (ctx->params.model == APPLES_SCOREDIST) {
+            if (launch_scoredist(ctx, qb, q0, nq, w.dist, nullptr)) return 1;
+        } else {
+            if (launch_counts(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, nullptr)) return 1;
+        }
+        pt.end(APPLES_T_DIST);
+        ++launches;
+        pt.begin(APPLES_T_SELECT);
+        if (launch_select(ctx, select_args_alignment(ctx, qb, q0), nq)) return 1;
+        pt.end(APPLES_T_SELECT);
+        pt.begin(APPLES_T_SWEEP);
+        if (launch_sweep(ctx, sweep_args(ctx, qb.out + q0, false), nq, w.sweep_wgs)) return 1;
+        pt.end(APPLES_T_SWEEP);
+    }
+    HIP_TRY(ctx, hipEventRecord(e_stop, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(e_stop));
+    pt.flush();
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e_start, e_stop);
+    (void)hipEventDestroy(e_start);
+    (void)hipEventDestroy(e_stop);
+    for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = pt.acc[i];
+    ctx->t_ms[APPLES_T_TOTAL] = ms;
+    ctx->t_ms[APPLES_T_DIST_LAUNCHES] = launches;
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *apples_last_error(const apples_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, const apples_params *params, int device,
+                      apples_ctx **out) {
+    *out = nullptr;
+    apples_ctx *ctx = new apples_ctx();
+    auto fail = [&]() {
+        g_create_error = ctx->err;
+        apples_ctx_destroy(ctx);
+        return 1;
+    };
+    ctx->device = device;
+    ctx->params = *params;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        ctx->err = "no HIP device available: the APPLES hot path needs an MI355X (there is no CPU fallback)";
+        return fail();
+    }
+    if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return fail(); }
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return fail(); }
+    for (int i = 0; i < 8; ++i)
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return fail(); }
+    if (tree->n_nodes < 2) { ctx->err = "tree needs at least two nodes"; return fail(); }
+    if (upload_tree(ctx, tree)) return fail();
+    if (aln) {
+        if (setup_alignment(ctx, tree, aln)) return fail();
+        ctx->has_aln = true;
+    }
+    if (apples_set_params(ctx, params)) return fail();
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "context upload failed"; return fail(); }
+    *out = ctx;
+    return 0;
+}
+
+int apples_set_params(apples_ctx *ctx, const apples_params *params) {
+    int model = ctx->params.model;
+    if (ctx->has_aln && params->model != model) { ctx->err = "the distance model is fixed at context creation"; return 1; }
+    ctx->params = *params;
+    ctx->params.jc_lut = nullptr;
+    if (params->jc_lut && params->jc_lut_len > 0) {
+        int64_t L = ctx->has_aln ? ctx->aln.L : 0;
+        int64_t need = (L + 1) * (L + 2) / 2;
+        if (ctx->has_aln && params->jc_lut_len < need) { ctx->err = "jc_lut too short for this alignment length"; return 1; }
+        dev_free(ctx->jc_lut);
+        ctx->jc_lut = nullptr;
+        if (dev_upload(ctx, &ctx->jc_lut, params->jc_lut, params->jc_lut_len)) return 1;
+        ctx->jc_lut_len = params->jc_lut_len;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        dev_free(ctx->jc_lut);
+        ctx->jc_lut = nullptr;
+        ctx->jc_lut_len = 0;
+    }
+    return 0;
+}
+
+void apples_ctx_destroy(apples_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &qb : ctx->blocks) free_block(&qb);
+    free_workspace(ctx->ws);
+    DevTree &t = ctx->tree;
+    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level);
+    DevAlign &a = ctx->aln;
+    dev_free(a.raw); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.slot_node); dev_free(a.slot_level);
+    dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
+    dev_free(ctx->jc_lut); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
+    dev_free(ctx->d_col_level);
+    for (int i = 0; i < 8; ++i)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int apples_queries_upload(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries, const int32_t *self_row,
+                          int64_t *handle) {
+    if (!ctx->has_aln) { ctx->err = "context has no alignment"; return 1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t slot = ctx->blocks.size();
+    for (size_t i = 0; i < ctx->blocks.size(); ++i)
+        if (!ctx->blocks[i].live) { slot = i; break; }
+    if (slot == ctx->blocks.size()) ctx->blocks.emplace_back();
+    QueryBlock qb;
+    if (make_block(ctx, queries, n_queries, self_row, &qb)) { free_block(&qb); return 1; }
+    ctx->blocks[slot] = qb;
+    *handle = (int64_t)slot;
+    return 0;
+}
+
+int apples_queries_free(apples_ctx *ctx, int64_t handle) {
+    if (handle < 0 || handle >= (int64_t)ctx->blocks.size() || !ctx->blocks[handle].live) { ctx->err = "bad handle"; return 1; }
+    free_block(&ctx->blocks[handle]);
+    return 0;
+}
+
+int apples_place_resident(apples_ctx *ctx, int64_t handle) {
+    if (handle < 0 || handle >= (int64_t)ctx->blocks.size() || !ctx->blocks[handle].live) { ctx->err = "bad handle"; return 1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return run_block(ctx, ctx->blocks[handle]);
+}
+
+int apples_fetch_placements(apples_ctx *ctx, int64_t handle, apples_placement *out) {
+    if (handle < 0 || handle >= (int64_t)ctx->blocks.size() || !ctx->blocks[handle].live) { ctx->err = "bad handle"; return 1; }
+    QueryBlock &qb = ctx->blocks[handle];
+    HIP_TRY(ctx, hipMemcpyAsync(out, qb.out, (size_t)qb.n * sizeof(apples_placement), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int apples_place_from_sequences(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries, const int32_t *self_row,
+                                apples_placement *out) {
+    if (n_queries == 0) return 0;
+    int64_t h;
+    if (apples_queries_upload(ctx, queries, n_queries, self_row, &h)) return 1;
+    int rc = apples_place_resident(ctx, h);
+    if (!rc) rc = apples_fetch_placements(ctx, h, out);
+    free_block(&ctx->blocks[h]);
+    return rc;
+}
+
+int apples_distances_resident(apples_ctx *ctx, int64_t handle, int32_t query_tile) {
+    if (handle < 0 || handle >= (int64_t)ctx->blocks.size() || !ctx->blocks[handle].live) { ctx->err = "bad handle"; return 1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    QueryBlock &qb = ctx->blocks[handle];
+    const DevAlign &a = ctx->aln;
+    if (ensure_workspace(ctx, a.n_refs, a.slots_pad, qb.n, true, false, false)) return 1;
+    Workspace &w = ctx->ws;
+    PhaseTimer pt{ctx};
+    int launches = 0;
+    for (int64_t q0 = 0; q0 < qb.n; q0 += w.batch) {
+        int64_t nq = std::min(w.batch, qb.n - q0);
+        pt.flush();
+        pt.begin(APPLES_T_DIST);
+        if (ctx->params.model == APPLES_SCOREDIST) {
+            if (launch_scoredist(ctx, qb, q0, nq, w.dist, nullptr)) return 1;
+        } else {
+            if (launch_counts(ctx, qb, q0, nq, query_tile > 0 ? query_tile : dist_tile_for(nq), w.dist, nullptr)) return 1;
+        }
+        pt.end(APPLES_T_DIST);
+        ++launches;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    pt.flush();
+    for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = pt.acc[i];
+    ctx->t_ms[APPLES_T_TOTAL] = pt.acc[APPLES_T_DIST];
+    ctx->t_ms[APPLES_T_DIST_LAUNCHES] = launches;
+    return 0;
+}
+
+int apples_distances(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries, uint32_t *out_counts, double *out_dist) {
+    if (!ctx->has_aln) { ctx->err = "context has no alignment"; return 1; }
+    if (n_queries == 0) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const DevAlign &a = ctx->aln;
+    int64_t h;
+    if (apples_queries_upload(ctx, queries, n_queries, nullptr, &h)) return 1;
+    QueryBlock &qb = ctx->blocks[h];
+    int rc = ensure_workspace(ctx, a.n_refs, a.slots_pad, n_queries, true, out_counts != nullptr, false);
+    Workspace &w = ctx->ws;
+    std::vector<double> hd;
+    std::vector<uint32_t> hc;
+    for (int64_t q0 = 0; !rc && q0 < qb.n; q0 += w.batch) {
+        int64_t nq = std::min(w.batch, qb.n - q0);
+        if (ctx->params.model == APPLES_SCOREDIST) rc = launch_scoredist(ctx, qb, q0, nq, w.dist, out_counts ? w.counts : nullptr);
+        else rc = launch_counts(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, out_counts ? w.counts : nullptr);
+        if (rc) break;
+        hd.resize((size_t)nq * a.slots_pad);
+        if (hipMemcpyAsync(hd.data(), w.dist, hd.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "copy back failed"; rc = 1; break; }
+        if (out_counts) {
+            hc.resize((size_t)nq * a.slots_pad);
+            if (hipMemcpyAsync(hc.data(), w.counts, hc.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "copy back failed"; rc = 1; break; }
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "distance kernel failed"; rc = 1; break; }
+        for (int64_t q = 0; q < nq; ++q)
+            for (int64_t s = 0; s < a.n_rows; ++s) {
+                int64_t r = a.slot_row[s];
+                if (out_dist) out_dist[(q0 + q) * a.n_rows + r] = hd[(size_t)q * a.slots_pad + s];
+                if (out_counts) {
+                    uint32_t c = hc[(size_t)q * a.slots_pad + s];
+                    if (ctx->params.model == APPLES_SCOREDIST) {
+                        out_counts[((q0 + q) * a.n_rows + r) * 2] = 0;
+                        out_counts[((q0 + q) * a.n_rows + r) * 2 + 1] = c;
+                    } else {
+                        out_counts[((q0 + q) * a.n_rows + r) * 2] = c >> 16;
+                        out_counts[((q0 + q) * a.n_rows + r) * 2 + 1] = c & 0xffffu;
+                    }
+                }
+            }
+    }
+    free_block(&ctx->blocks[h]);
+    return rc;
+}
+
+int apples_place_from_distances(apples_ctx *ctx, const double *dist, int64_t n_queries, int64_t n_cols,
+                                const int32_t *col_node, const int32_t *self_col, apples_placement *out) {
+    if (n_queries == 0) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const DevTree &t = ctx->tree;
+    // column layout (cached while the caller keeps passing the same col_node)
+    bool same = ctx->dcols == n_cols && (int64_t)ctx->h_col_node.size() == n_cols &&
+                std::equal(col_node, col_node + n_cols, ctx->h_col_node.begin());
+    std::vector<int32_t> level(t.n_nodes);
+    std::vector<int32_t> &perm = ctx->h_col_perm;
+    if (!same) {
+        HIP_TRY(ctx, hipMemcpy(level.data(), t.level, (size_t)t.n_nodes * 4, hipMemcpyDeviceToHost));
+        for (int64_t c = 0; c < n_cols; ++c)
+            if (col_node[c] >= t.n_nodes) { ctx->err = "col_node out of range"; return 1; }
+        perm = level_order(col_node, n_cols, level);
+        std::vector<int32_t> s_node(n_cols), s_level(n_cols);
+        for (int64_t s = 0; s < n_cols; ++s) {
+            int nd = col_node[perm[s]];
+            s_node[s] = nd;
+            s_level[s] = nd >= 0 ? level[nd] : -1;
+        }
+        dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node); dev_free(ctx->d_col_level);
+        if (dev_upload(ctx, &ctx->d_col_perm, perm.data(), n_cols)) return 1;
+        if (dev_upload(ctx, &ctx->d_col_node, s_node.data(), n_cols)) return 1;
+        if (dev_upload(ctx, &ctx->d_col_level, s_level.data(), n_cols)) return 1;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->h_col_node.assign(col_node, col_node + n_cols);
+        ctx->dcols = n_cols;
+    }
+    std::vector<int32_t> col_slot(n_cols);
+    for (int64_t s = 0; s < n_cols; ++s) col_slot[perm[s]] = (int32_t)s;
+    bool hybrid = ctx->params.criterion == APPLES_HYBRID;
+    if (ensure_workspace(ctx, n_cols, n_cols, n_queries, true, false, hybrid)) return 1;
+    Workspace &w = ctx->ws;
+    apples_placement *d_out = nullptr;
+    int32_t *d_self = nullptr;
+    if (dev_alloc(ctx, &d_out, w.batch)) return 1;
+    if (dev_alloc(ctx, &d_self, w.batch)) return 1;
+    PhaseTimer pt{ctx};
+    int rc = 0;
+    for (int64_t q0 = 0; q0 < n_queries && !rc; q0 += w.batch) {
+        int64_t nq = std::min(w.batch, n_queries - q0);
+        std::vector<int32_t> self(nq, -1);
+        if (self_col)
+            for (int64_t i = 0; i < nq; ++i)
+                if (self_col[q0 + i] >= 0 && self_col[q0 + i] < n_cols) self[i] = col_slot[self_col[q0 + i]];
+        if (hipMemcpyAsync(d_self, self.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(w.dist, dist + q0 * n_cols, (size_t)nq * n_cols * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "upload of the distance table failed"; rc = 1; break; }
+        SelectArgs s{};
+        s.dist = w.dist; s.stride = n_cols; s.gather = ctx->d_col_perm;
+        s.slot_node = ctx->d_col_node; s.slot_level = ctx->d_col_level; s.slot_rep = nullptr; s.slot_mpos = nullptr;
+        s.rep_slot = nullptr; s.rep_moff = nullptr; s.mem_slot = nullptr;
+        s.n_members = n_cols; s.n_reps = n_cols; s.all_singleton = 1; s.table_mode = 1; s.self_slot = d_self;
+        s.thr = ctx->params.filt_threshold; s.baseobs = ctx->params.base_observation; s.height = t.height;
+        s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
+        s.out = d_out;
+        pt.flush();
+        pt.begin(APPLES_T_SELECT);
+        rc = launch_select(ctx, s, nq);
+        pt.end(APPLES_T_SELECT);
+        if (rc) break;
+        pt.begin(APPLES_T_SWEEP);
+        rc = launch_sweep(ctx, sweep_args(ctx, d_out, false), nq, w.sweep_wgs);
+        pt.end(APPLES_T_SWEEP);
+        if (rc) break;
+        if (hipMemcpyAsync(out + q0, d_out, (size_t)nq * sizeof(apples_placement), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "placement kernels failed"; rc = 1; break; }
+    }
+    pt.flush();
+    for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = pt.acc[i];
+    ctx->t_ms[APPLES_T_TOTAL] = pt.acc[APPLES_T_SELECT] + pt.acc[APPLES_T_SWEEP];
+    dev_free(d_out);
+    dev_free(d_self);
+    return rc;
+}
+
+int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *obs_dist, int32_t n_obs, uint8_t *valid,
+                       double *S, double *R, double *x, double *err, int32_t *lca, apples_placement *out) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const DevTree &t = ctx->tree;
+    if (n_obs < 2) { ctx->err = "need at least two observed leaves"; return 1; }
+    std::vector<int32_t> level(t.n_nodes);
+    HIP_TRY(ctx, hipMemcpy(level.data(), t.level, (size_t)t.n_nodes * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n_obs; ++i)
+        if (obs_node[i] < 0 || obs_node[i] >= t.n_nodes) { ctx->err = "obs_node out of range"; return 1; }
+    std::vector<int32_t> ord = level_order(obs_node, n_obs, level);
+    std::vector<int32_t> s_node(n_obs);
+    std::vector<double> s_dist(n_obs);
+    for (int i = 0; i < n_obs; ++i) { s_node[i] = obs_node[ord[i]]; s_dist[i] = obs_dist[ord[i]]; }
+    std::vector<int32_t> cg(t.height + 2);
+    for (int l = -1; l <= t.height; ++l) {
+        int c = 0;
+        for (int i = 0; i < n_obs; ++i) c += level[s_node[i]] > l;
+        cg[l + 1] = c;
+    }
+    if (ensure_workspace(ctx, std::max<int64_t>(n_obs, ctx->ws.obs_cap), std::max<int64_t>(n_obs, 1), 1, true, false, true)) return 1;
+    Workspace &w = ctx->ws;
+    apples_placement *d_out = nullptr;
+    if (dev_alloc(ctx, &d_out, 1)) return 1;
+    apples_placement init{};
+    init.n_obs = n_obs;
+    HIP_TRY(ctx, hipMemcpy(d_out, &init, sizeof(init), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(w.obs_node, s_node.data(), (size_t)n_obs * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(w.obs_dist, s_dist.data(), (size_t)n_obs * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(w.cnt_gt, cg.data(), cg.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(w.n_obs, &n_obs, 4, hipMemcpyHostToDevice));
+    if (launch_sweep(ctx, sweep_args(ctx, d_out, true), 1, 1)) { dev_free(d_out); return 1; }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    apples_placement res;
+    HIP_TRY(ctx, hipMemcpy(&res, d_out, sizeof(res), hipMemcpyDeviceToHost));
+    dev_free(d_out);
+    if (out) *out = res;
+    int V = res.n_valid;
+    std::vector<int32_t> order(V);
+    std::vector<double> hS((size_t)V * 6), hR((size_t)V * 6), hx((size_t)V * 5);
+    HIP_TRY(ctx, hipMemcpy(order.data(), w.order, (size_t)V * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hS.data(), w.S, hS.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hR.data(), w.R, hR.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hx.data(), w.xe, hx.size() * 8, hipMemcpyDeviceToHost));
+    if (lca) HIP_TRY(ctx, hipMemcpy(lca, w.grp_off + t.height + 3, 4, hipMemcpyDeviceToHost));
+    if (valid) memset(valid, 0, t.n_nodes);
+    for (int i = 0; i < V; ++i) {
+        int v = order[i];
+        if (valid) valid[v] = 1;
+        if (S) memcpy(S + (size_t)v * 6, &hS[(size_t)i * 6], 48);
+        if (R) memcpy(R + (size_t)v * 6, &hR[(size_t)i * 6], 48);
+        if (x) memcpy(x + (size_t)v * 4, &hx[(size_t)i * 5], 32);
+        if (err) err[v] = hx[(size_t)i * 5 + 4];
+    }
+    return 0;
+}
+
+int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n) {
+    for (int i = 0; i < n && i < APPLES_T_COUNT; ++i) ms[i] = ctx->t_ms[i];
+    return n < APPLES_T_COUNT ? n : APPLES_T_COUNT;
+}
+
+const char *apples_describe(apples_ctx *ctx) {
+    hipDeviceProp_t prop;
+    char buf[1024];
+    const char *name = "?";
+    int cus = 0;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) { name = prop.name; cus = prop.multiProcessorCount; }
+    const DevAlign &a = ctx->aln;
+    snprintf(buf, sizeof buf,
+             "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"n_rows\": %lld, "
+             "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
+             "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"jc_lut\": %d}",
+             name, cus, ctx->tree.n_nodes, ctx->tree.height, (long long)a.n_rows, (long long)a.n_refs,
+             (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
+             (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.sweep_wgs,
+             ctx->jc_lut ? 1 : 0);
+    ctx->desc = buf;
+    return ctx->desc.c_str();
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+// Shared declarations of libapples_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/apples_hip.h"
+
+#define APPLES_TPB 256  // threads per workgroup in every kernel: 4 wave64
+
+struct DevTree {
+    int32_t n_nodes = 0;
+    int32_t height = 0;  // max level
+    int32_t *parent = nullptr;
+    double *edge_len = nullptr;
+    int32_t *child_off = nullptr;
+    int32_t *child_idx = nullptr;
+    int32_t *level = nullptr;
+};
+
+// Slot = physical position of an alignment row on the device.  Member slots [0, n_refs) are the
+// reference rows sorted by tree level, deepest first (rows that are not tree leaves last);
+// consensus slots follow.  Sorting by level lets the selection kernel's ordered compaction
+// hand the sweep kernel its leaves already grouped by level.
+struct DevAlign {
+    int64_t n_rows = 0, n_refs = 0, n_reps = 0;
+    int64_t slots_pad = 0;  // n_rows rounded up to a multiple of APPLES_TPB
+    int32_t L = 0, W = 0, G = 0;  // sites, 32-site words, groups of 4 words
+    int32_t planes = 0;           // code planes in the packed layout: 2 (ACGT fast path) or 8 (raw byte)
+    bool all_singleton = true;
+    uint8_t *raw = nullptr;       // [n_rows*L] bytes in slot order (kept for lazy repacking / scoredist)
+    uint4 *packed = nullptr;      // [G][planes+1][slots_pad] uint4 = 4 consecutive 32-site words
+    uint8_t *aa_idx = nullptr;    // scoredist: [Lpad16/16][slots_pad][16] residue indices 0..19, 20 = gap
+    int32_t *slot_node = nullptr; // [n_refs] tree node or -1
+    int32_t *slot_level = nullptr;// [n_refs] level or -1
+    int32_t *slot_rep = nullptr;  // [n_refs] representative index of the member's cluster
+    int32_t *slot_mpos = nullptr; // [n_refs] position inside its cluster
+    int32_t *rep_slot = nullptr;  // [n_reps] slot holding the representative's sequence
+    int32_t *rep_moff = nullptr;  // [n_reps+1]
+    int32_t *mem_slot = nullptr;  // members in stored order, as slots
+    std::vector<int32_t> row_slot;  // host: row -> slot
+    std::vector<int32_t> slot_row;  // host: slot -> row
+};
+
+struct QueryBlock {
+    int64_t n = 0, n_pad = 0;
+    uint8_t *raw = nullptr;       // [n*L]
+    uint4 *packed = nullptr;      // [n_pad][G][planes+1] uint4
+    uint8_t *aa_idx = nullptr;    // [n_pad][Lpad16]
+    int32_t *self_slot = nullptr; // [n]
+    apples_placement *out = nullptr;  // [n] device
+    int planes = 0;
+    bool live = false;
+};
+
+struct Workspace {
+    int64_t batch = 0;            // queries per device batch
+    int64_t stride = 0;           // row stride of dist/counts
+    double *dist = nullptr;       // [batch][slots_pad] fp64 distances in slot order
+    uint32_t *counts = nullptr;   // [batch][slots_pad] (mism<<16|valid), only when requested
+    int32_t *obs_node = nullptr;  // [batch][obs_cap]
+    double *obs_dist = nullptr;   // [batch][obs_cap]
+    int32_t *cnt_gt = nullptr;    // [batch][height+2]: #observed leaves with level > l, at index l+1
+    int32_t *n_obs = nullptr;     // [batch] emitted observed leaves (tree leaves, self removed)
+    int64_t obs_cap = 0;
+    // sweep scratch, one slice per persistent workgroup
+    int32_t sweep_wgs = 0;
+    int32_t *map = nullptr;       // [wgs][n_nodes] node -> order index + 1 (0 = not in subtree)
+    int32_t *order = nullptr;     // [wgs][n_nodes] node ids grouped by level, deepest first
+    int32_t *grp_off = nullptr;   // [wgs][height+3]
+    double *S = nullptr;          // [wgs][n_nodes][6]
+    double *R = nullptr;          // [wgs][n_nodes][6]
+    double *xe = nullptr;         // [wgs][n_nodes][5] x_1,x_2,x_1_neg,x_2_neg,err (HYBRID / inspection)
+};
+
+struct apples_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string desc;
+    apples_params params{};
+    DevTree tree;
+    DevAlign aln;
+    bool has_aln = false;
+    double *jc_lut = nullptr;
+    int64_t jc_lut_len = 0;
+    double *blosum = nullptr;  // 21x21 table (row/col 20 = gap -> 0)
+    Workspace ws;
+    std::vector<QueryBlock> blocks;
+    // -d path: column layout cache
+    int64_t dcols = 0;
+    int32_t *d_col_perm = nullptr;   // [n_cols] slot -> column, level-sorted
+    int32_t *d_col_node = nullptr;   // [n_cols] slot -> node
+    int32_t *d_col_level = nullptr;
+    std::vector<int32_t> h_col_node;
+    std::vector<int32_t> h_col_perm;
+    // timing
+    hipEvent_t ev[8] = {};
+    double t_ms[APPLES_T_COUNT] = {};
+};
+
+extern thread_local std::string g_create_error;
+
+#define HIP_TRY(ctx, call)                                                                            \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess) {                                                                      \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                          \
+            return 1;                                                                                 \
+        }                                                                                             \
+    } while (0)
+
+// ---- kernels' host launchers (defined in the .hip files) -----------------------------------------
+// pack.hip
+int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, int planes, uint4 *d_out,
+                     int64_t slots_pad, bool query_layout, int *d_exotic);
+int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, int64_t slots_pad,
+                   bool query_layout);
+// dist.hip
+int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
+                  uint32_t *d_counts);
+int launch_scoredist(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *d_dist,
+                     uint32_t *d_counts);
+// select.hip
+struct SelectArgs {
+    const double *dist;       // [nq][stride]
+    int64_t stride;
+    const int32_t *gather;    // slot -> column (distance-table path) or nullptr
+    const int32_t *slot_node, *slot_level, *slot_rep, *slot_mpos, *rep_slot, *rep_moff, *mem_slot;
+    int64_t n_members, n_reps;
+    int all_singleton;
+    int table_mode;           // 1: -d semantics (rows not in the tree are ignored entirely)
+    const int32_t *self_slot; // [nq] or nullptr
+    double thr;
+    int baseobs;
+    int height;
+    int32_t *obs_node; double *obs_dist; int64_t obs_cap; int32_t *cnt_gt; int32_t *n_obs;
+    apples_placement *out;    // [nq]
+};
+int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
+// sweep.hip
+struct SweepArgs {
+    DevTree tree;
+    const int32_t *obs_node; const double *obs_dist; int64_t obs_cap; const int32_t *cnt_gt; const int32_t *n_obs;
+    int32_t *map, *order, *grp_off; double *S, *R, *xe;
+    int method, criterion, negative;
+    int keep_edges;           // store per-edge x/err (inspection or HYBRID)
+    apples_placement *out;
+};
+int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs);

@@ -1,0 +1,163 @@
+// Distance kernels: one fp64 distance per (query, alignment row).
+//
+// JC69 (apples/distance.py:718-745): per pair two integers, valid = #sites where neither is '-',
+// mism = #valid sites whose bytes differ; then p = mism/valid and -0.75*ln(1 - 4p/3).  The integer
+// part is bit-plane arithmetic: per 32 sites  M = qM & rM ; X = OR_p(qC_p ^ rC_p) ; mism += popc(X & M).
+// A thread owns one reference row (coalesced 16 B/lane reads of the plane-major layout), a
+// workgroup owns 256 rows x TQ queries; the query words are wave-uniform, so they come through
+// the scalar cache and occupy SGPRs, not LDS.  HBM traffic per launch is the packed reference
+// once per query tile plus 8 B per pair of output.  No MFMA: this is popcount, not a contraction.
+#include "common.h"
+
+__device__ __forceinline__ double jc69_from_counts(uint32_t mism, uint32_t valid, int L, double overlap,
+                                                   const double *__restrict__ lut) {
+    if (lut) return lut[(int64_t)valid * (valid + 1) / 2 + mism];
+    // apples/distance.py:735-745, literal order
+    if (valid == 0 || (double)valid / (double)L < overlap) return -1.0;
+    double p = (double)mism * 1.0 / (double)valid;
+    if (p - 2.220446049250313e-16 < 0) return 0.0;
+    double loc = 1 - (4 * p / 3);
+    if (0 >= loc) return -1.0;
+    return -0.75 * log(loc);
+}
+
+template <int P, int TQ>
+__global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ refp, const uint4 *__restrict__ qp,
+                                                     double *__restrict__ dist, uint32_t *__restrict__ counts,
+                                                     int64_t n_slots, int64_t slots_pad, int G, int64_t nq, int L,
+                                                     double overlap, const double *__restrict__ lut) {
+    const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    const int64_t q0 = (int64_t)blockIdx.y * TQ;
+    uint32_t nv[TQ], nm[TQ];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) nv[t] = nm[t] = 0;
+    for (int g = 0; g < G; ++g) {
+        const uint4 *rp = refp + ((int64_t)g * (P + 1)) * slots_pad + slot;
+        uint4 rm = rp[0];
+        uint4 rc[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) rc[p] = rp[(int64_t)(1 + p) * slots_pad];
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            const uint4 *qq = qp + ((q0 + t) * G + g) * (P + 1);  // wave-uniform address
+            uint4 qm = qq[0];
+            uint4 x = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                uint4 qc = qq[1 + p];
+                x.x |= qc.x ^ rc[p].x; x.y |= qc.y ^ rc[p].y; x.z |= qc.z ^ rc[p].z; x.w |= qc.w ^ rc[p].w;
+            }
+            uint32_t m0 = qm.x & rm.x, m1 = qm.y & rm.y, m2 = qm.z & rm.z, m3 = qm.w & rm.w;
+            nv[t] += __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+            nm[t] += __popc(x.x & m0) + __popc(x.y & m1) + __popc(x.z & m2) + __popc(x.w & m3);
+        }
+    }
+    if (slot >= n_slots) return;
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+        if (q0 + t < nq) {
+            int64_t o = (q0 + t) * slots_pad + slot;
+            if (dist) dist[o] = jc69_from_counts(nm[t], nv[t], L, overlap, lut);
+            if (counts) counts[o] = (nm[t] << 16) | nv[t];
+        }
+    }
+}
+
+template <int P>
+static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
+                             uint32_t *d_counts) {
+    const DevAlign &a = ctx->aln;
+    const uint4 *qp = qb.packed + q0 * a.G * (P + 1);
+    const double *lut = ctx->jc_lut;
+    dim3 block(APPLES_TPB);
+#define LAUNCH(TQ)                                                                                                  \
+    hipLaunchKernelGGL((k_jc69<P, TQ>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)), \
+                       block, 0, ctx->stream, a.packed, qp, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,  \
+                       ctx->params.overlap_frac, lut)
+    if (tile >= 32) LAUNCH(32);
+    else if (tile >= 16) LAUNCH(16);
+    else if (tile >= 8) LAUNCH(8);
+    else if (tile >= 4) LAUNCH(4);
+    else LAUNCH(1);
+#undef LAUNCH
+}
+
+int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
+                  uint32_t *d_counts) {
+    if (nq == 0) return 0;
+    if (ctx->aln.planes == 2) launch_jc69_tile<2>(ctx, qb, q0, nq, tile, d_dist, d_counts);
+    else launch_jc69_tile<8>(ctx, qb, q0, nq, tile, d_dist, d_counts);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// scoredist (apples/distance.py:681-715): valid as above; tot = sum over sites of T[q_s][r_s] with
+// T = BLOSUM45 dissimilarities extended by a zero gap row/column; r = 1 - tot/valid; r <= 0 -> -1;
+// else -ln(r)*1.3.  The 21x21 fp64 table sits in LDS; for one query site all lanes index the same
+// 21-entry row with their own residue, i.e. 21 consecutive 8-byte words: conflict-free ds_read_b64.
+// Sites are summed left to right in fp64 (the reference's order is whatever BLAS ddot does, so
+// this path is tolerance-checked, not bit-checked).
+template <int TQ>
+__global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restrict__ refa, const uint8_t *__restrict__ qa,
+                                                          const double *__restrict__ table, double *__restrict__ dist,
+                                                          uint32_t *__restrict__ counts, int64_t n_slots,
+                                                          int64_t slots_pad, int Lpad, int L, int64_t nq, double overlap) {
+    __shared__ double T[21 * 21];
+    for (int i = threadIdx.x; i < 21 * 21; i += APPLES_TPB) T[i] = table[i];
+    __syncthreads();
+    const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    const int64_t q0 = (int64_t)blockIdx.y * TQ;
+    double tot[TQ];
+    uint32_t nv[TQ];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) { tot[t] = 0.0; nv[t] = 0; }
+    const int n16 = Lpad / 16;
+    for (int s16 = 0; s16 < n16; ++s16) {
+        uint4 rw = *reinterpret_cast<const uint4 *>(refa + ((int64_t)s16 * slots_pad + slot) * 16);
+        uint32_t r[4] = {rw.x, rw.y, rw.z, rw.w};
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            uint4 qw = *reinterpret_cast<const uint4 *>(qa + (q0 + t) * (int64_t)Lpad + s16 * 16);  // uniform
+            uint32_t q[4] = {qw.x, qw.y, qw.z, qw.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                uint32_t qi = (q[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                uint32_t ri = (r[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                if (qi != 20u) {  // wave-uniform branch: a query gap adds nothing for any row
+                    tot[t] += T[qi * 21 + ri];
+                    nv[t] += (ri != 20u);
+                }
+            }
+        }
+    }
+    if (slot >= n_slots) return;
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+        if (q0 + t < nq) {
+            int64_t o = (q0 + t) * slots_pad + slot;
+            uint32_t valid = nv[t];
+            double d;
+            if (valid == 0 || (double)valid / (double)L < overlap) d = -1.0;
+            else {
+                double r1 = 1 - tot[t] / (double)valid;
+                if (0 >= r1) d = -1.0;
+                else d = -log(r1) * 1.3;
+            }
+            if (dist) dist[o] = d;
+            if (counts) counts[o] = valid;
+        }
+    }
+}
+
+int launch_scoredist(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *d_dist,
+                     uint32_t *d_counts) {
+    if (nq == 0) return 0;
+    const DevAlign &a = ctx->aln;
+    int Lpad = (a.L + 15) / 16 * 16;
+    constexpr int TQ = 8;
+    hipLaunchKernelGGL((k_scoredist<TQ>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)),
+                       dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, qb.aa_idx + q0 * Lpad, ctx->blosum, d_dist, d_counts,
+                       a.n_rows, a.slots_pad, Lpad, a.L, nq, ctx->params.overlap_frac);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

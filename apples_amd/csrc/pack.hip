@@ -1,0 +1,136 @@
+// Packing kernels: the reference's 1-byte-per-site rows (apples/fasta2dic.py:71) -> device layouts.
+//
+// Bit-plane layout (JC69 path): sites are cut into 32-site words, 4 words form a group g.
+// Per row: a gap plane M (bit = site is not '-') and P code planes.  P = 2 is the ACGT fast
+// path (code = (byte >> 1) & 3: A=0 C=1 T=2 G=3); P = 8 keeps the raw byte, so "any other byte
+// is an ordinary symbol" (distance.py:733 compares bytes) holds for every input.
+//   reference rows : packed[(g*(P+1) + plane) * slots_pad + slot]   (uint4; a wave reads 1 KiB)
+//   query rows     : packed[(q*G + g) * (P+1) + plane]              (uint4; wave-uniform reads)
+#include "common.h"
+
+template <int P>
+__global__ __launch_bounds__(APPLES_TPB) void k_pack_rows(const uint8_t *__restrict__ raw, int64_t n_rows, int L, int G,
+                                                          uint4 *__restrict__ out, int64_t slots_pad, int query_layout,
+                                                          int *__restrict__ exotic) {
+    int64_t row = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    int g = blockIdx.y;
+    if (row >= n_rows) return;
+    const uint8_t *src = raw + row * (int64_t)L;
+    uint32_t m[4] = {0, 0, 0, 0};
+    uint32_t c[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[p][k] = 0;
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int base = (g * 4 + k) * 32;
+        for (int i = 0; i < 32; ++i) {
+            int site = base + i;
+            if (site >= L) break;
+            uint32_t b = src[site];
+            uint32_t nd = (b != (uint32_t)'-');
+            m[k] |= nd << i;
+            if (P == 2) {
+                uint32_t code = (b >> 1) & 3u;
+                bad |= nd & !(b == 'A' || b == 'C' || b == 'G' || b == 'T');
+                c[0][k] |= ((code & 1u) & nd) << i;
+                c[1][k] |= ((code >> 1) & nd) << i;
+            } else {
+#pragma unroll
+                for (int p = 0; p < P; ++p) c[p][k] |= (((b >> p) & 1u) & nd) << i;
+            }
+        }
+    }
+    if (bad) atomicOr(exotic, 1);
+    if (query_layout) {
+        uint4 *dst = out + (row * G + g) * (P + 1);
+        dst[0] = make_uint4(m[0], m[1], m[2], m[3]);
+#pragma unroll
+        for (int p = 0; p < P; ++p) dst[1 + p] = make_uint4(c[p][0], c[p][1], c[p][2], c[p][3]);
+    } else {
+        out[((int64_t)g * (P + 1) + 0) * slots_pad + row] = make_uint4(m[0], m[1], m[2], m[3]);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            out[((int64_t)g * (P + 1) + 1 + p) * slots_pad + row] = make_uint4(c[p][0], c[p][1], c[p][2], c[p][3]);
+    }
+}
+
+int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, int planes, uint4 *d_out,
+                     int64_t slots_pad, bool query_layout, int *d_exotic) {
+    if (n_rows == 0) return 0;
+    int G = ctx->aln.G;
+    dim3 grid((unsigned)((n_rows + APPLES_TPB - 1) / APPLES_TPB), (unsigned)G);
+    if (planes == 2)
+        hipLaunchKernelGGL(k_pack_rows<2>, grid, dim3(APPLES_TPB), 0, ctx->stream, d_raw, n_rows, L, G, d_out, slots_pad,
+                           query_layout ? 1 : 0, d_exotic);
+    else
+        hipLaunchKernelGGL(k_pack_rows<8>, grid, dim3(APPLES_TPB), 0, ctx->stream, d_raw, n_rows, L, G, d_out, slots_pad,
+                           query_layout ? 1 : 0, d_exotic);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// scoredist layout: residue index per site, a2i of apples/distance.py:418-678 (ARNDCQEGHILKMFPSTWYV
+// both cases -> 0..19, every other byte -> 0) with '-' -> 20 (a zero row/column of the table, so
+// gapped sites add +0.0 exactly as nondash*BLOSUM45[...] does at distance.py:706).
+//   reference rows : aa[(s16 * slots_pad + slot) * 16 + k]    s16 = site / 16
+//   query rows     : aa[q * Lpad + site]
+__device__ __forceinline__ uint8_t aa_index(uint8_t b) {
+    switch (b) {
+        case 'A': case 'a': return 0;
+        case 'R': case 'r': return 1;
+        case 'N': case 'n': return 2;
+        case 'D': case 'd': return 3;
+        case 'C': case 'c': return 4;
+        case 'Q': case 'q': return 5;
+        case 'E': case 'e': return 6;
+        case 'G': case 'g': return 7;
+        case 'H': case 'h': return 8;
+        case 'I': case 'i': return 9;
+        case 'L': case 'l': return 10;
+        case 'K': case 'k': return 11;
+        case 'M': case 'm': return 12;
+        case 'F': case 'f': return 13;
+        case 'P': case 'p': return 14;
+        case 'S': case 's': return 15;
+        case 'T': case 't': return 16;
+        case 'W': case 'w': return 17;
+        case 'Y': case 'y': return 18;
+        case 'V': case 'v': return 19;
+        case '-': return 20;
+        default: return 0;
+    }
+}
+
+__global__ __launch_bounds__(APPLES_TPB) void k_pack_aa(const uint8_t *__restrict__ raw, int64_t n_rows, int L, int Lpad,
+                                                        uint8_t *__restrict__ out, int64_t slots_pad, int query_layout) {
+    int64_t row = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    int s16 = blockIdx.y;
+    if (row >= n_rows) return;
+    const uint8_t *src = raw + row * (int64_t)L;
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int site = s16 * 16 + k;
+        uint32_t v = site < L ? aa_index(src[site]) : 20u;
+        w[k >> 2] |= v << (8 * (k & 3));
+    }
+    uint4 val = make_uint4(w[0], w[1], w[2], w[3]);
+    if (query_layout)
+        *reinterpret_cast<uint4 *>(out + row * (int64_t)Lpad + s16 * 16) = val;
+    else
+        *reinterpret_cast<uint4 *>(out + ((int64_t)s16 * slots_pad + row) * 16) = val;
+}
+
+int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, int64_t slots_pad,
+                   bool query_layout) {
+    if (n_rows == 0) return 0;
+    int Lpad = (L + 15) / 16 * 16;
+    dim3 grid((unsigned)((n_rows + APPLES_TPB - 1) / APPLES_TPB), (unsigned)(Lpad / 16));
+    hipLaunchKernelGGL(k_pack_aa, grid, dim3(APPLES_TPB), 0, ctx->stream, d_raw, n_rows, L, Lpad, d_out, slots_pad,
+                       query_layout ? 1 : 0);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

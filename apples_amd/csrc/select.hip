@@ -1,0 +1,236 @@
+// Observed-set selection: which references a query keeps (one workgroup per query).
+//
+// Alignment input, apples/Reference.py:138-154: valid representatives are popped in ascending
+// (distance, index) order; a cluster is expanded while d <= threshold OR fewer than `baseobs`
+// valid member distances have been collected; the first representative failing both stops the
+// walk.  Data-parallel restatement: accept every representative with 0 <= d <= thr; if that
+// leaves obs_num < baseobs, keep accepting the smallest remaining (d, i) until it does not.
+// The accepted set is therefore {d <= thr} U {(d, i) <= cut}, and only `cut` has to be stored.
+//
+// Distance-table input, apples/PoolQueryWorker.py:44-59: stable sort by distance, names not in
+// the tree and negatives skipped, the `baseobs` nearest always kept, later ones only if <= thr:
+// the same rule with every column its own cluster and i = column index.
+//
+// Then (PoolQueryWorker.py:63-98): drop the query's own entry, first zero distance in dict
+// order -> exact placement, <= 2 distances -> unplaceable.  Survivors are written with an
+// ordered compaction in slot order; slots are sorted by tree level, deepest first, so the sweep
+// kernel receives its leaves grouped by level together with the per-level offsets cnt_gt.
+#include "common.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ bool key_lt(double d1, int i1, double d2, int i2) { return d1 < d2 || (d1 == d2 && i1 < i2); }
+__device__ __forceinline__ bool key_le(double d1, int i1, double d2, int i2) { return d1 < d2 || (d1 == d2 && i1 <= i2); }
+
+__device__ __forceinline__ double shfl_down_f64(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_down(lo, delta, WAVE);
+    hi = __shfl_down(hi, delta, WAVE);
+    return __hiloint2double(hi, lo);
+}
+
+// block-wide sum of an int; result valid in every thread
+__device__ int block_sum(int v, int *sh /*[4+]*/) {
+    for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+    int w = threadIdx.x / WAVE;
+    __syncthreads();
+    if ((threadIdx.x & (WAVE - 1)) == 0) sh[w] = v;
+    __syncthreads();
+    int s = 0;
+    for (int k = 0; k < APPLES_TPB / WAVE; ++k) s += sh[k];
+    return s;
+}
+
+// block-wide lexicographic arg-min over (d, i, j); result valid in every thread
+__device__ void block_argmin3(double &d, int &i, int &j, double *shd, int *shi, int *shj) {
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+        double d2 = shfl_down_f64(d, o);
+        int i2 = __shfl_down(i, o, WAVE);
+        int j2 = __shfl_down(j, o, WAVE);
+        if (d2 < d || (d2 == d && (i2 < i || (i2 == i && j2 < j)))) { d = d2; i = i2; j = j2; }
+    }
+    int w = threadIdx.x / WAVE;
+    __syncthreads();
+    if ((threadIdx.x & (WAVE - 1)) == 0) { shd[w] = d; shi[w] = i; shj[w] = j; }
+    __syncthreads();
+    d = shd[0]; i = shi[0]; j = shj[0];
+    for (int k = 1; k < APPLES_TPB / WAVE; ++k) {
+        double d2 = shd[k]; int i2 = shi[k], j2 = shj[k];
+        if (d2 < d || (d2 == d && (i2 < i || (i2 == i && j2 < j)))) { d = d2; i = i2; j = j2; }
+    }
+}
+
+// exclusive prefix sum of a 0/1 flag across the block; returns this thread's offset, total in *tot
+__device__ int block_excl_scan(int flag, int *sh /*[4+]*/, int *tot) {
+    unsigned long long mask = __ballot(flag);
+    int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    int pre = __popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) sh[w] = __popcll(mask);
+    __syncthreads();
+    int base = 0, t = 0;
+    for (int k = 0; k < APPLES_TPB / WAVE; ++k) {
+        if (k < w) base += sh[k];
+        t += sh[k];
+    }
+    *tot = t;
+    return base + pre;
+}
+
+#define INF_D __longlong_as_double(0x7ff0000000000000LL)
+
+__global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
+    __shared__ int sh_i[8];
+    __shared__ int sh_j[8];
+    __shared__ double sh_d[8];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const double *row = a.dist + q * a.stride;
+    const int32_t *gather = a.gather;
+    const int64_t nm = a.n_members;
+    const int self = a.self_slot ? a.self_slot[q] : -1;
+    const double thr = a.thr;
+    const bool single = a.all_singleton != 0;
+    const bool table = a.table_mode != 0;
+#define DIST(s) (gather ? row[gather[(s)]] : row[(s)])
+    // representative index used to break distance ties: heap of (d, i) at Reference.py:143, or the
+    // column position for the stable sort at PoolQueryWorker.py:51
+#define SLOT_KEYIDX(s) (table ? gather[(s)] : a.slot_rep[(s)])
+
+    // ---- pass A: observations inside the threshold ------------------------------------------------
+    int cnt = 0;
+    if (single) {
+        for (int64_t s = tid; s < nm; s += APPLES_TPB) {
+            if (table && a.slot_node[s] < 0) continue;
+            double d = DIST(s);
+            if (d >= 0 && d <= thr) cnt++;
+        }
+    } else {
+        for (int64_t j = tid; j < a.n_reps; j += APPLES_TPB) {
+            double d = DIST(a.rep_slot[j]);
+            if (d >= 0 && d <= thr)
+                for (int m = a.rep_moff[j]; m < a.rep_moff[j + 1]; ++m) cnt += !(DIST(a.mem_slot[m]) < 0);
+        }
+    }
+    int obs = block_sum(cnt, sh_i);
+
+    // ---- top-up: smallest (d, i) beyond the threshold until baseobs observations -------------------
+    double cut_d = -INF_D;
+    int cut_i = -1;
+    while (obs < a.baseobs) {
+        double bd = INF_D;
+        int bi = 0x7fffffff, bj = 0;
+        if (single) {
+            for (int64_t s = tid; s < nm; s += APPLES_TPB) {
+                if (table && a.slot_node[s] < 0) continue;
+                double d = DIST(s);
+                if (d >= 0 && d > thr) {
+                    int i = SLOT_KEYIDX(s);
+                    if (key_lt(cut_d, cut_i, d, i) && key_lt(d, i, bd, bi)) { bd = d; bi = i; }
+                }
+            }
+        } else {
+            for (int64_t j = tid; j < a.n_reps; j += APPLES_TPB) {
+                double d = DIST(a.rep_slot[j]);
+                if (d >= 0 && d > thr && key_lt(cut_d, cut_i, d, (int)j) && key_lt(d, (int)j, bd, bi)) { bd = d; bi = (int)j; }
+            }
+        }
+        block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
+        if (bi == 0x7fffffff) break;  // nothing left
+        cut_d = bd;
+        cut_i = bi;
+        if (single) obs += 1;
+        else {
+            int c = 0;
+            for (int m = a.rep_moff[bi] + tid; m < a.rep_moff[bi + 1]; m += APPLES_TPB) c += !(DIST(a.mem_slot[m]) < 0);
+            obs += block_sum(c, sh_i);
+        }
+    }
+
+    // ---- pass B: ordered compaction of the observed leaves -----------------------------------------
+    int32_t *o_node = a.obs_node + q * a.obs_cap;
+    double *o_dist = a.obs_dist + q * a.obs_cap;
+    int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
+    int base = 0;      // emitted so far
+    int n_total = 0;   // len(obs_dist) after the self entry is removed
+    // first zero distance in dict order: min over (d_rep, rep index, member position)
+    double z_d = INF_D;
+    int z_i = 0x7fffffff, z_p = 0x7fffffff, z_node = -2;
+    for (int64_t s0 = 0; s0 <= nm; s0 += APPLES_TPB) {
+        int64_t s = s0 + tid;
+        int emit = 0, node = -1;
+        double dm = -1.0;
+        if (s < nm) {
+            node = a.slot_node[s];
+            dm = DIST(s);
+            bool in_dict;
+            double drep;
+            int ri, mp;
+            if (single) {
+                drep = dm; ri = SLOT_KEYIDX(s); mp = 0;
+                in_dict = (dm >= 0) && (dm <= thr || key_le(dm, ri, cut_d, cut_i));
+                if (table && node < 0) in_dict = false;
+            } else {
+                ri = a.slot_rep[s]; mp = a.slot_mpos[s];
+                drep = DIST(a.rep_slot[ri]);
+                in_dict = (drep >= 0) && (drep <= thr || key_le(drep, ri, cut_d, cut_i)) && !(dm < 0);
+            }
+            if (in_dict && (int)s != self) {
+                n_total++;
+                if (dm == 0 && (drep < z_d || (drep == z_d && (ri < z_i || (ri == z_i && mp < z_p))))) {
+                    z_d = drep; z_i = ri; z_p = mp; z_node = node;
+                }
+                emit = node >= 0;
+            }
+        }
+        int tot;
+        int pre = base + block_excl_scan(emit, sh_i, &tot);
+        if (emit) { o_node[pre] = node; o_dist[pre] = dm; }
+        if (s <= nm) {  // level boundaries (virtual end slot nm has level -1)
+            int lv = (s < nm) ? a.slot_level[s] : -1;
+            int lprev = (s == 0) ? a.height + 1 : a.slot_level[s - 1];
+            for (int l = lv; l < lprev; ++l) cg[l + 1] = pre;
+        }
+        base += tot;
+    }
+    n_total = block_sum(n_total, sh_i);
+    // pack (z_i, z_p) is not needed beyond ordering; carry the node through a second reduction
+    double zd = z_d; int zi = z_i, zp = z_p;
+    block_argmin3(zd, zi, zp, sh_d, sh_i, sh_j);
+    __shared__ int sh_znode;
+    if (tid == 0) sh_znode = -2;
+    __syncthreads();
+    if (z_node != -2 && z_d == zd && z_i == zi && z_p == zp) sh_znode = z_node;
+    __syncthreads();
+
+    if (tid == 0) {
+        apples_placement p;
+        p.edge = 0; p.flags = 0; p.error = 0.0; p.distal = 0.0; p.pendant = 0.0; p.n_obs = n_total; p.n_valid = 0;
+        int n_emit = base;
+        if (zi != 0x7fffffff) {
+            p.flags = APPLES_F_EXACT | APPLES_F_PENDANT_INT;
+            p.edge = sh_znode;
+            if (sh_znode < 0) { p.flags |= APPLES_F_ZERO_NOT_IN_TREE; p.edge = -1; }
+            n_emit = 0;
+        } else if (n_total <= 2) {
+            p.flags = APPLES_F_INSUFFICIENT | APPLES_F_PENDANT_INT;
+            p.edge = -1;
+            n_emit = 0;
+        } else if (n_emit < 2) {
+            p.flags = APPLES_F_DEGENERATE | APPLES_F_PENDANT_INT;
+            p.edge = -1;
+            n_emit = 0;
+        }
+        a.out[q] = p;
+        a.n_obs[q] = n_emit;  // 0 = nothing for the sweep to do
+    }
+#undef DIST
+#undef SLOT_KEYIDX
+}
+
+int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(k_select, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

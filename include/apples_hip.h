@@ -1,0 +1,169 @@
+/*
+ * apples_hip.h -- C ABI of the MI355X-native APPLES hot path (libapples_hip.so).
+ *
+ * The reference (balabanmetin/apples, pure Python) has no FFI layer; its seams are Python
+ * call signatures.  Each entry point below names the reference interface it
+ * replaces (file:line relative to the reference tree).  Plain C: int status returns
+ * (0 = ok), caller-owned contiguous buffers, one opaque context per device, no globals.
+ * A context is thread-compatible: one host thread at a time.
+ *
+ *   seam B1  pool.starmap(PoolQueryWorker.runquery, queries)      run_apples.py:94-102
+ *   seam B2  Reference.get_obs_dist / dist_function               apples/Reference.py:22-29,117-157
+ *   seam B3  Algorithm.dp_frag / placement_per_edge / placement   apples/Algorithm.py:16-101
+ */
+#ifndef APPLES_HIP_H
+#define APPLES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct apples_ctx apples_ctx;
+
+/* -m / --method (apples/PoolQueryWorker.py:104-111: anything else means OLS) */
+enum { APPLES_OLS = 0, APPLES_FM = 1, APPLES_BME = 2, APPLES_BE = 3 };
+/* -c / --criterion (apples/Algorithm.py:76-91: anything else means MLSE) */
+enum { APPLES_MLSE = 0, APPLES_ME = 1, APPLES_HYBRID = 2 };
+/* distance model: jc69 (apples/distance.py:718-745) or scoredist (:681-715), chosen by -p
+ * as in apples/Reference.py:22-25 */
+enum { APPLES_JC69 = 0, APPLES_SCOREDIST = 1 };
+
+/* Backbone tree as arrays indexed by edge_index = left-to-right post-order number
+ * (apples/util.py:57-69); level = BFS depth (apples/util.py:72-88); children in file order. */
+typedef struct {
+    int32_t n_nodes;
+    const int32_t *parent;    /* [n_nodes], -1 for the root (= n_nodes-1) */
+    const double *edge_len;   /* [n_nodes] */
+    const int32_t *child_off; /* [n_nodes+1] CSR */
+    const int32_t *child_idx; /* [n_nodes-1] */
+    const int32_t *level;     /* [n_nodes] */
+} apples_tree;
+
+/* Reference alignment in the reference's own encoding: 1 byte per site, '-' = gap, any other
+ * byte an ordinary symbol (apples/fasta2dic.py:56-71).  Rows 0..n_refs-1 are the reference
+ * sequences (Reference.refs, apples/Reference.py:19); rows n_refs..n_rows-1 are consensus
+ * sequences of multi-member clusters.  Clusters (Reference.representatives,
+ * apples/Reference.py:107) in representative order i: rep_row[i] = row holding the
+ * representative sequence, members = member_row[member_off[i]..member_off[i+1]) in stored
+ * order.  rep_row == NULL means every reference is its own singleton cluster in row order
+ * (apples/PoolRepresentativeWorker.py:99-101). */
+typedef struct {
+    int64_t n_rows;
+    int64_t n_refs;
+    int32_t length;           /* L */
+    const uint8_t *rows;      /* [n_rows * L] row-major */
+    const int32_t *row_node;  /* [n_refs] tree node of each reference row, -1 if not a leaf of the tree */
+    int64_t n_reps;
+    const int32_t *rep_row;   /* [n_reps] or NULL */
+    const int32_t *member_off;/* [n_reps+1] or NULL */
+    const int32_t *member_row;/* [member_off[n_reps]] or NULL */
+} apples_alignment;
+
+/* Options that reach the per-query worker (apples/OptionsRun.py, apples/OptionsBasic.py). */
+typedef struct {
+    int32_t model;            /* APPLES_JC69 | APPLES_SCOREDIST (-p) */
+    int32_t method;           /* -m */
+    int32_t criterion;        /* -c */
+    int32_t negative_branch;  /* -n */
+    double filt_threshold;    /* -f (default 0.2) */
+    int32_t base_observation; /* -b (default 25) */
+    double overlap_frac;      /* -V (default 0.001) */
+    /* Optional JC69 table: jc_lut[valid*(valid+1)/2 + mism] = distance for the integer pair,
+     * valid in [0, L]; lets the host fill it with numpy's own log so distances carry the
+     * reference's bits.  NULL: the kernel evaluates -0.75*log(1-4p/3) itself. */
+    const double *jc_lut;
+    int64_t jc_lut_len;
+    int64_t max_batch;        /* queries per device batch; 0 = choose from free memory */
+} apples_params;
+
+/* One placement = the p row runquery returns, [edge_num, likelihood(error), 1, distal, pendant]
+ * (apples/Algorithm.py:98-101, apples/PoolQueryWorker.py:36-37,74,88,119-125). */
+typedef struct {
+    int32_t edge;             /* edge_index; -1 = cannot be placed (fewer than 3 distances) */
+    uint32_t flags;           /* APPLES_F_* */
+    double error;
+    double distal;            /* edge_length - x_2 */
+    double pendant;           /* x_1 */
+    int32_t n_obs;            /* len(obs_dist) the worker saw (after removing the query's own entry) */
+    int32_t n_valid;          /* Subtree.num_nodes (apples/Subtree.py:42) */
+} apples_placement;
+
+#define APPLES_F_EXACT        1u  /* a zero distance: p = [edge,0,1,0,0] (PoolQueryWorker.py:72-75) */
+#define APPLES_F_INSUFFICIENT 2u  /* len(obs_dist) <= 2 (PoolQueryWorker.py:97-98), edge = -1 */
+#define APPLES_F_MISPLACED    4u  /* potential_misplacement_flag (Algorithm.py:94-97) */
+#define APPLES_F_PENDANT_INT  8u  /* x_1 is the clamped Python int 0, printed "0" not "0.0" (util.py:32-50) */
+#define APPLES_F_ZERO_NOT_IN_TREE 16u /* zero distance to a reference that is not a tree leaf: the
+                                         reference raises KeyError (PoolQueryWorker.py:74) */
+#define APPLES_F_DEGENERATE  32u  /* >=3 distances but fewer than two of them on tree leaves */
+
+/* Build a context on HIP device `device`: uploads the tree, packs the alignment into the
+ * bit-plane layout, allocates workspaces.  `aln` may be NULL for a distance-table-only context
+ * (run_apples.py -d).  Replaces prepareTree + ReducedReference construction state that
+ * PoolQueryWorker.set_class_attributes injects (apples/PoolQueryWorker.py:17-24). */
+int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, const apples_params *params,
+                      int device, apples_ctx **out);
+void apples_ctx_destroy(apples_ctx *ctx);
+/* Message for the last non-zero status on this context (or creation failure when ctx == NULL). */
+const char *apples_last_error(const apples_ctx *ctx);
+
+/* Change the per-query options without rebuilding the context (tree/alignment stay resident). */
+int apples_set_params(apples_ctx *ctx, const apples_params *params);
+
+/* Seam B2, element kernel: dist_function(query, row) for every row (apples/Reference.py:22-25).
+ * queries: [n_queries * L] bytes.  out_counts (nullable): [n_queries * n_rows * 2] uint32 pairs
+ * (mismatches, valid) -- jc69's two integers (apples/distance.py:733-737); for scoredist the
+ * pair is (0, valid).  out_dist (nullable): [n_queries * n_rows] fp64, -1.0 = missing. */
+int apples_distances(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries,
+                     uint32_t *out_counts, double *out_dist);
+
+/* Seam B1, alignment input: runquery(name, seq, None) for a block of queries
+ * (apples/PoolQueryWorker.py:28-141 = get_obs_dist -> Subtree -> dp_frag -> placement_per_edge
+ * -> placement).  self_row[q] = reference row whose name equals the query's name when that
+ * name is a tree leaf (the entry runquery deletes, PoolQueryWorker.py:63-66), else -1;
+ * NULL = none. */
+int apples_place_from_sequences(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries,
+                                const int32_t *self_row, apples_placement *out);
+
+/* Seam B1, distance-table input (run_apples.py -d): runquery(name, None, obs_dist).
+ * dist: [n_queries * n_cols] fp64 in the table's column order, <0 = missing
+ * (apples/PoolQueryWorker.py:44-59); col_node[c] = tree leaf of column c or -1 when the name
+ * is not in the tree; self_col as self_row above. */
+int apples_place_from_distances(apples_ctx *ctx, const double *dist, int64_t n_queries, int64_t n_cols,
+                                const int32_t *col_node, const int32_t *self_col, apples_placement *out);
+
+/* Seam B3 for inspection/parity: per-edge results of the sweep for ONE observed set.
+ * obs_node/obs_dist: n_obs observed leaves (tree node ids) and their distances.  Outputs are
+ * indexed by edge_index over [0, n_nodes): valid (0/1), S[6], R[6] (tuple order as in
+ * apples/OLS.py:27-33, FM.py:21-27, BE.py:11-17, BME.py:11-17), x[4] = x_1,x_2,x_1_neg,x_2_neg
+ * (apples/util.py:51-54), err = error_per_edge.  Any output pointer may be NULL. */
+int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *obs_dist, int32_t n_obs,
+                       uint8_t *valid, double *S, double *R, double *x, double *err, int32_t *lca,
+                       apples_placement *out);
+
+/* ---- device-resident variants used by bench.py (inputs already in HBM when timing starts) ---- */
+/* Upload and pack a block of queries; returns a handle owned by the context. */
+int apples_queries_upload(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries,
+                          const int32_t *self_row, int64_t *handle);
+int apples_queries_free(apples_ctx *ctx, int64_t handle);
+/* One pass of the hot path over an uploaded block; placements stay on the device until fetched. */
+int apples_place_resident(apples_ctx *ctx, int64_t handle);
+int apples_fetch_placements(apples_ctx *ctx, int64_t handle, apples_placement *out);
+/* Distance kernel alone over an uploaded block (roofline measurement); results stay on device. */
+int apples_distances_resident(apples_ctx *ctx, int64_t handle, int32_t query_tile);
+
+/* Per-kernel device time of the most recent apples_place_* / apples_distances* call, measured
+ * with HIP events on the context's stream.  ms[APPLES_T_*]; n = number of entries filled. */
+enum { APPLES_T_PACK = 0, APPLES_T_DIST = 1, APPLES_T_SELECT = 2, APPLES_T_SWEEP = 3, APPLES_T_TOTAL = 4,
+       APPLES_T_DIST_LAUNCHES = 5, APPLES_T_COUNT = 6 };
+int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n);
+
+/* Introspection: device name, packed layout, workspace sizes (JSON text, owned by ctx). */
+const char *apples_describe(apples_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APPLES_HIP_H */

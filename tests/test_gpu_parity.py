@@ -1,0 +1,269 @@
+"""Parity of the HIP path (through the C ABI) against the golden fixtures the reference produced
+and against the CPU oracle on the same seeded inputs.  Needs an MI355X: run with -m gpu."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import DATA, GOLD, ROOT, assert_prow, load_json, read_dismat
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import apples_oracle as orc  # noqa: E402
+
+from apples_amd import synth  # noqa: E402
+from apples_amd.engine import Engine, placement_row, F_EXACT, F_INSUFFICIENT  # noqa: E402
+from apples_amd.fasta import read_alignment  # noqa: E402
+from apples_amd.tree import read_tree  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def c1():
+    tree = read_tree(os.path.join(DATA, 'backbone.nwk'))
+    ref = read_alignment(os.path.join(DATA, 'ref.fa'), False, False)
+    qry = read_alignment(os.path.join(DATA, 'query.fa'), False, False)
+    nodes = np.array([tree.name_to_node.get(n, -1) for n in ref.names], np.int32)
+    return tree, ref, qry, nodes
+
+
+@pytest.fixture(scope='module')
+def eng_c1(c1):
+    tree, ref, qry, nodes = c1
+    e = Engine(tree, ref.seqs, nodes, method='OLS')
+    yield e
+    e.close()
+
+
+def test_jc69_counts_and_distances(c1, eng_c1):
+    tree, ref, qry, nodes = c1
+    counts, dist = eng_c1.distances(qry.seqs)
+    g = np.load(os.path.join(GOLD, 'g1_jc69_data.npz'))
+    want = np.array([[orc.pair_counts(q, r) for r in ref.seqs] for q in qry.seqs], dtype=np.uint32)
+    assert np.array_equal(counts, want)  # integers: bit exact
+    np.testing.assert_allclose(dist, g['dist'], rtol=1e-6, atol=0)  # north_star tolerance
+    # with the numpy-filled table the device hands out the host's own log bits
+    host = np.array([[orc.jc69(q, r, 0.001) for r in ref.seqs] for q in qry.seqs])
+    assert np.array_equal(dist, host)
+
+
+def test_jc69_edge_cases_and_byte_symbols():
+    g = np.load(os.path.join(GOLD, 'g1_jc69_synth.npz'))
+    a, b = g['a'], g['b']
+    tree = read_tree(os.path.join(DATA, 'small_backbone.nwk'))
+    for V, key in ((0.001, 'jc69_V0.001'), (0.5, 'jc69_V0.5')):
+        # rows of `b` act as the reference; '*' and '?' force the 8-plane raw-byte layout
+        e = Engine(tree, b, np.full(len(b), -1, np.int32), method='OLS', overlap=V)
+        assert e.describe()['code_planes'] == 8
+        counts, dist = e.distances(a)
+        for i in range(len(a)):
+            assert tuple(counts[i, i]) == orc.pair_counts(a[i], b[i])
+            w = g[key][i]
+            assert (dist[i, i] == w) or abs(dist[i, i] - w) <= 1e-6 * abs(w)
+        e.close()
+    # ACGT- only -> 2-plane fast path; a later query block with '*' widens the context lazily
+    keep = [i for i in range(len(b)) if not (set(b[i].tobytes()) - set(b'ACGT-'))]
+    e = Engine(tree, b[keep], np.full(len(keep), -1, np.int32), method='OLS')
+    assert e.describe()['code_planes'] == 2
+    c1_, d1 = e.distances(a[:8])      # rows 0..7 of `a` are plain
+    c2_, d2 = e.distances(a[8:10])    # row 8 carries '*'
+    assert e.describe()['code_planes'] == 8
+    c3_, d3 = e.distances(a[:8])
+    assert np.array_equal(c1_, c3_) and np.array_equal(d1, d3)
+    for qi in range(8, 10):
+        for k, ri in enumerate(keep):
+            assert tuple(c2_[qi - 8, k]) == orc.pair_counts(a[qi], b[ri])
+    e.close()
+
+
+def test_jc69_device_log_without_table(c1):
+    tree, ref, qry, nodes = c1
+    e = Engine(tree, ref.seqs, nodes, method='OLS', use_lut=False)
+    _, dist = e.distances(qry.seqs, want_counts=False)
+    g = np.load(os.path.join(GOLD, 'g1_jc69_data.npz'))
+    np.testing.assert_allclose(dist, g['dist'], rtol=1e-12, atol=0)
+    e.close()
+
+
+def test_scoredist_against_golden():
+    g = np.load(os.path.join(GOLD, 'g1_scoredist_synth.npz'))
+    a, b = g['a'], g['b']
+    tree = read_tree(os.path.join(DATA, 'small_backbone.nwk'))
+    for V, key in ((0.001, 'scoredist_V0.001'), (0.5, 'scoredist_V0.5')):
+        e = Engine(tree, b, np.full(len(b), -1, np.int32), protein=True, overlap=V)
+        counts, dist = e.distances(a)
+        got = np.array([dist[i, i] for i in range(len(a))])
+        want = g[key]
+        assert np.array_equal(got < 0, want < 0)
+        assert np.array_equal(np.signbit(got), np.signbit(want))  # identical pair -> -0.0
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-15)
+        seq = np.array([orc.scoredist_sequential(a[i], b[i], V) for i in range(len(a))])
+        np.testing.assert_allclose(got, seq, rtol=1e-14, atol=1e-15)  # same summation order as the kernel
+        for i in range(len(a)):
+            assert counts[i, i, 1] == orc.pair_counts(a[i], b[i])[1]
+        e.close()
+
+
+METHODS = ('OLS', 'FM', 'BME', 'BE')
+
+
+def test_sweep_per_edge_against_golden(c1):
+    """S/R tuples, 2x2 solutions and residuals of every candidate edge (G3)."""
+    tree, ref, qry, nodes = c1
+    g = np.load(os.path.join(GOLD, 'g3_per_edge.npz'))
+    e = Engine(tree, None, method='OLS')
+    for qi in range(3):
+        names = [str(x) for x in g['q%d_obs_names' % qi]]
+        on = np.array([tree.name_to_node[k] for k in names], np.int32)
+        od = g['q%d_obs_dist' % qi]
+        for m in METHODS:
+            e.set_options(method=m)
+            r = e.sweep_edges(on, od)
+            key = 'q%d_%s_' % (qi, m)
+            edges = g[key + 'edge']
+            assert np.array_equal(np.nonzero(r['valid'])[0], edges)
+            assert r['lca'] == int(g[key + 'lca']) and r['placement']['n_valid'] == int(g[key + 'num_nodes'])
+            # same IEEE operations in the same order: bit identical
+            assert np.array_equal(r['S'][edges], g[key + 'S']), (qi, m)
+            assert np.array_equal(r['R'][edges], g[key + 'R']), (qi, m)
+            assert np.array_equal(r['x'][edges], g[key + 'x']), (qi, m)
+            # residual: x*x here vs libm pow in the reference (<= 1 ulp per square)
+            scale = np.abs(g[key + 'S']).max() + np.abs(g[key + 'R']).max()
+            assert np.max(np.abs(r['err'][edges] - g[key + 'err'])) <= 1e-13 * scale
+            assert np.mean(r['err'][edges] == g[key + 'err']) > 0.9
+    e.close()
+
+
+def _rows(eng, seqs, self_rows=None):
+    return [placement_row(p) for p in eng.place_sequences(seqs, self_rows)]
+
+
+def test_placements_alignment_golden(c1):
+    tree, ref, qry, nodes = c1
+    g = load_json('g4_placements.json')
+    eng = Engine(tree, ref.seqs, nodes)
+    for case in g['aln']:
+        if case.get('clusters') == 'clades':
+            continue
+        eng.set_options(method=case['m'], criterion=case['c'], negative=case['n'], threshold=case['f'],
+                        baseobs=case['b'])
+        got = _rows(eng, qry.seqs)
+        for row, w in zip(got, case['p']):
+            assert_prow(row, w['p'], ctx='aln %s/%s/n=%s/f=%s %s' % (case['m'], case['c'], case['n'], case['f'], w['n']))
+    eng.close()
+
+
+def test_placements_clustered_reference_golden(c1):
+    tree, ref, qry, nodes = c1
+    reps = load_json('g2_selection.json')['clade_clusters']
+    cons, rep_row, moff, mrow = [], [], [0], []
+    for r in reps:
+        if len(r['members']) == 1 and ref.seqs[ref.index[r['members'][0]]].tobytes().decode() == r['cons']:
+            rep_row.append(ref.index[r['members'][0]])
+        else:
+            rep_row.append(len(ref) + len(cons))
+            cons.append(np.frombuffer(r['cons'].encode(), np.uint8))
+        mrow += [ref.index[m] for m in r['members']]
+        moff.append(len(mrow))
+    clusters = (np.array(cons, np.uint8).reshape(-1, ref.length), rep_row, moff, mrow)
+    eng = Engine(tree, ref.seqs, nodes, clusters=clusters)
+    assert eng.describe()['all_singleton'] == 0
+    g = load_json('g4_placements.json')
+    n = 0
+    for case in g['aln']:
+        if case.get('clusters') != 'clades':
+            continue
+        eng.set_options(method=case['m'], criterion=case['c'], negative=case['n'], threshold=case['f'], baseobs=case['b'])
+        for row, w in zip(_rows(eng, qry.seqs), case['p']):
+            assert_prow(row, w['p'], ctx='clades %s %s' % (case['m'], w['n']))
+        n += 1
+    assert n == 2
+    # the observed set itself, against get_obs_dist's dict (G2): compare through n_obs
+    sel = load_json('g2_selection.json')
+    for case in sel['cases']:
+        if case['clusters'] != 'clades':
+            continue
+        eng.set_options(method='OLS', threshold=case['f'], baseobs=case['b'])
+        p = eng.place_sequences(qry.seqs[qry.index[case['query']]][None, :])[0]
+        assert p['n_obs'] == len(case['obs']), case
+    eng.close()
+
+
+def test_placements_distance_table_golden(c1):
+    tree, ref, qry, nodes = c1
+    g = load_json('g4_placements.json')
+    rows = list(read_dismat(os.path.join(DATA, 'dist.mat')))
+    cols = list(rows[0][1])
+    D = np.array([[r[1][c] for c in cols] for r in rows])
+    col_nodes = np.array([tree.name_to_node.get(c, -1) for c in cols], np.int32)
+    eng = Engine(tree, None)
+    for case in g['dist']:
+        eng.set_options(method=case['m'], threshold=case['f'], baseobs=case['b'])
+        got = [placement_row(p) for p in eng.place_distances(D, col_nodes)]
+        for row, w in zip(got, case['p']):
+            assert_prow(row, w['p'], ctx='-d %s f=%s %s' % (case['m'], case['f'], w['n']))
+    eng.close()
+    stree = read_tree(os.path.join(DATA, 'small_backbone.nwk'))
+    srows = list(read_dismat(os.path.join(DATA, 'small_dist.mat')))
+    scols = list(srows[0][1])
+    sD = np.array([[r[1][c] for c in scols] for r in srows])
+    eng = Engine(stree, None)
+    for case in g['small']:
+        eng.set_options(method=case['m'])
+        got = [placement_row(p) for p in eng.place_distances(sD, [stree.name_to_node[c] for c in scols])]
+        assert got[0][0] == 3
+        for row, w in zip(got, case['p']):
+            assert_prow(row, w['p'], ctx='small %s' % case['m'])
+    eng.close()
+
+
+def test_edge_cases_golden(c1):
+    tree, ref, qry, nodes = c1
+    g = load_json('g4_placements.json')['edge_cases']
+    L = ref.length
+    allgap = np.full(L, ord('-'), np.uint8)
+    names = ['allgap', ref.names[0], 'copy_of_second', 'allgap2', 'normal']
+    assert names == g['names']
+    seqs = np.vstack([allgap, ref.seqs[0], ref.seqs[1], allgap, qry.seqs[0]])
+    # runquery drops the query's own entry when its name is a backbone leaf (PoolQueryWorker.py:63-66)
+    self_rows = np.array([ref.index[n] if (n in ref.index and n in tree.name_to_node) else -1 for n in names], np.int32)
+    eng = Engine(tree, ref.seqs, nodes, method='OLS')
+    out = eng.place_sequences(seqs, self_rows)
+    assert out[0]['flags'] & F_INSUFFICIENT and out[2]['flags'] & F_EXACT and out[3]['flags'] & F_INSUFFICIENT
+    for p, w in zip(out, g['results']):
+        assert_prow(placement_row(p), w['p'], ctx='edge case %s' % w['n'])
+    eng.close()
+
+
+@pytest.mark.parametrize('label', ['nt_OLS', 'aa_FM'])
+def test_synthetic_alignment_golden(label):
+    g = load_json('g6_synthetic.json')[label]
+    d = synth.make_dataset(g['N'], g['L'], g['Q'], protein=g['protein'])
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, protein=g['protein'], method=g['m'], threshold=g['f'], baseobs=g['b'])
+    out = eng.place_sequences(d.query_seqs)
+    ties = 0
+    for i, p in enumerate(out):
+        assert p['n_obs'] == g['n_obs'][i]
+        w, bs = g['p'][i], g['best_second'][i]
+        row = placement_row(p)
+        if row[0] != w['p'][0] and bs is not None and abs(bs[1] - bs[0]) <= 1e-12 * max(abs(bs[0]), 1e-300):
+            ties += 1  # documented tie class
+            continue
+        assert_prow(row, w['p'], ctx='%s q%d' % (label, i))
+    assert ties <= 2
+    eng.close()
+
+
+@pytest.mark.parametrize('m', ['BME', 'OLS'])
+def test_synthetic_distance_table_golden(m):
+    g = load_json('g6_synthetic.json')['dmat_' + m]
+    d = synth.make_dataset(g['N'], 500, g['Q'])
+    D = synth.noisy_distance_rows(d.tree, d.query_leaf, d.query_pendant, list(range(g['Q'])))
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, None, method=m, threshold=g['f'], baseobs=g['b'])
+    out = eng.place_distances(D, nodes)
+    for i, p in enumerate(out):
+        assert_prow(placement_row(p), g['p'][i]['p'], ctx='dmat %s q%d' % (m, i))
+    eng.close()
