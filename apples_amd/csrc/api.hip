@@ -512,6 +512,12 @@ int apples_fetch_placements(apples_ctx *ctx, int64_t handle, apples_placement *o
     return 0;
 }
 
+int apples_placements_device_ptr(apples_ctx *ctx, int64_t handle, void **ptr) {
+    if (handle < 0 || handle >= (int64_t)ctx->blocks.size() || !ctx->blocks[handle].live) { ctx->err = "bad handle"; return 1; }
+    *ptr = ctx->blocks[handle].out;
+    return 0;
+}
+
 int apples_place_from_sequences(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries, const int32_t *self_row,
                                 apples_placement *out) {
     if (n_queries == 0) return 0;

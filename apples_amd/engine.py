@@ -24,7 +24,7 @@ PLACEMENT_DTYPE = np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'),
 EXPORTS = ['apples_ctx_create', 'apples_ctx_destroy', 'apples_last_error', 'apples_set_params', 'apples_distances',
            'apples_place_from_sequences', 'apples_place_from_distances', 'apples_sweep_edges',
            'apples_queries_upload', 'apples_queries_free', 'apples_place_resident', 'apples_fetch_placements',
-           'apples_distances_resident', 'apples_last_timing', 'apples_describe']
+           'apples_distances_resident', 'apples_placements_device_ptr', 'apples_last_timing', 'apples_describe']
 
 
 class _Tree(C.Structure):
@@ -74,6 +74,7 @@ def load_library():
     lib.apples_place_resident.argtypes = [C.c_void_p, C.c_int64]
     lib.apples_fetch_placements.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     lib.apples_distances_resident.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+    lib.apples_placements_device_ptr.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     lib.apples_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     _lib = lib
     return lib
@@ -272,6 +273,11 @@ class Engine:
         out = np.zeros(n, PLACEMENT_DTYPE)
         self._check(self.lib.apples_fetch_placements(self.ctx, handle, _ptr(out)))
         return out
+
+    def placements_device_ptr(self, handle):
+        p = C.c_void_p()
+        self._check(self.lib.apples_placements_device_ptr(self.ctx, handle, C.byref(p)))
+        return p.value
 
     def distances_resident(self, handle, query_tile=0):
         self._check(self.lib.apples_distances_resident(self.ctx, handle, int(query_tile)))

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the APPLES per-query hot path on MI355X (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|small] [--no-cpu]
+
+A step = one pass of the hot path (distance vector -> observed-set selection -> least-squares
+sweep -> best edge) over one block of synthetic queries whose packed form, together with the
+packed reference alignment and the tree, is already resident in HBM.  value = query
+placements/s for the whole job.  For N > 1 (launched by torch.distributed.run, one rank per GPU)
+every rank places its own shard of the same size (weak scaling, no collective in the data path)
+and the placements are gathered to rank 0 with one RCCL gather inside the timed region.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, algorithmic bytes / HIP-event
+time) and `cpu_baseline` (the CPU restatement of the reference path -- per-query
+numpy/Python worker under a fork pool, as run_apples.py:101-102 -- timed on this host's cores on
+a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (leaves, L, queries per GPU, protein, method, threshold)   -- BASELINE.json configs
+    'c2': (10000, 1000, 10000, False, 'OLS', 0.2),
+    'c3': (200000, 1000, 100000, False, 'OLS', 0.2),
+    'c4': (50000, 500, 50000, True, 'FM', 0.2),
+    'small': (2000, 500, 2048, False, 'OLS', 0.2),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def cpu_baseline(ds, protein, method, threshold, target_cpu_seconds=20.0):
+    """Time the oracle's pool driver on a bounded, seeded sample of the same queries."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import apples_oracle as orc
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    kw = dict(protein=protein, method=method, criterion='MLSE', threshold=threshold, baseobs=25, overlap=0.001)
+    t0 = time.time()
+    orc.run_pool(ds.tree, ds.ref_names, ds.ref_seqs, ds.query_names[:1], ds.query_seqs[:1], threads=1, **kw)
+    t1 = max(time.time() - t0, 1e-3)
+    n = int(min(len(ds.query_names), max(cores, min(4 * cores, target_cpu_seconds / t1))))
+    t0 = time.time()
+    orc.run_pool(ds.tree, ds.ref_names, ds.ref_seqs, ds.query_names[:n], ds.query_seqs[:n], threads=cores, **kw)
+    dt = time.time() - t0
+    return {'value': n / dt, 'unit': 'queries/s', 'cores': cores, 'kind': 'port',
+            'sample': 'first %d of the %d synthetic queries, %d-process fork pool, %.1f s wall (%.2f s for one query on '
+                      'one core)' % (n, len(ds.query_names), cores, dt, t1)}
+
+
+def load_traffic(workload, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d[workload][kernel]['hbm_bytes_per_launch']
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--queries', type=int, default=0, help='override queries per GPU')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from apples_amd import synth
+    from apples_amd.engine import Engine
+
+    n_leaves, L, Q, protein, method, thr = WORKLOADS[args.workload]
+    if args.queries:
+        Q = args.queries
+    # every rank holds the same backbone + reference; queries are rank-specific shards
+    ds = synth.make_dataset(n_leaves, L, Q, protein=protein, seed_query=3 + rank)
+    nodes = np.array([ds.tree.name_to_node[n] for n in ds.ref_names], np.int32)
+    eng = Engine(ds.tree, ds.ref_seqs, nodes, protein=protein, method=method, criterion='MLSE', threshold=thr,
+                 baseobs=25, overlap=0.001, device=local_rank)
+    handle, nq = eng.upload_queries(ds.query_seqs)
+
+    gather_buf = None
+    if world > 1:
+        class _DevArray:  # zero-copy view of the device-resident placement structs
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
+        res = torch.as_tensor(_DevArray(eng.placements_device_ptr(handle), nq * 40), device='cuda')
+        gather_buf = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
+
+    def step():
+        eng.place_resident(handle)  # returns after the stream has drained
+        if world > 1:
+            dist.gather(res, gather_buf, dst=0)  # the end-of-run gather (replaces starmap's pickle return)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    phases = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0}
+    launches = 0
+    for _ in range(args.steps):
+        step()
+        t = eng.timing()
+        for k in phases:
+            phases[k] += t[k]
+        launches += t['dist_launches']
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    out = eng.fetch(handle, nq)
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * nq / (dt / args.steps)
+        rows = eng.n_rows
+        placed = out['n_valid'] > 0
+        mean_v = float(np.mean(out['n_valid'][placed] + 1)) if placed.any() else 0.0
+        per_step = {k: v / args.steps for k, v in phases.items()}
+        # algorithmic bytes per step: distance N_rows*(L+8)+L per query; sweep 332*V per query
+        dist_bytes = nq * (rows * (L + 8) + L)
+        sweep_bytes = 332.0 * float(np.sum(out['n_valid'][placed] + 1))
+        kernels = {
+            'jc69_distance' if not protein else 'scoredist_distance': (dist_bytes, per_step['dist_ms']),
+            'lsq_sweep': (sweep_bytes, per_step['sweep_ms']),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][1])
+        n_launch = max(launches / args.steps, 1) if dom != 'lsq_sweep' else max(launches / args.steps, 1)
+        achieved = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9 if kernels[dom][1] > 0 else 0.0
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(args.workload, dom),
+                    'launches_per_step': n_launch, 'avg_launch_ms': kernels[dom][1] / n_launch,
+                    'algorithmic_bytes_per_launch': kernels[dom][0] / n_launch,
+                    'per_kernel_ms_per_step': per_step,
+                    'all_kernels_GBps': {k: (v[0] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in kernels.items()}}
+        cpu = None
+        if world == 1 and not args.no_cpu:
+            cpu = cpu_baseline(ds, protein, method, thr)
+        line = {
+            'metric': 'query placements/sec (whole node)', 'value': value, 'unit': 'queries/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s: synthetic %d-leaf backbone, L=%d %s, %d queries per GPU, %s/%s, -f %.1f -b 25, '
+                                   'all-singleton clusters' % (args.workload, n_leaves, L, 'aa' if protein else 'nt', nq,
+                                                              method, 'scoredist' if protein else 'JC69', thr),
+                       'n_ref': n_leaves, 'L': L, 'queries_per_gpu': nq, 'method': method,
+                       'mean_observed': float(np.mean(out['n_obs'])), 'mean_swept_nodes': mean_v,
+                       'placed': int(placed.sum()), 'parallelism': 'query-sharded x%d' % world},
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        if cpu:
+            line['speedup_vs_cpu_baseline'] = value / cpu['value']
+        print(json.dumps(line), flush=True)
+    eng.free_queries(handle)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -151,6 +151,10 @@ int apples_queries_free(apples_ctx *ctx, int64_t handle);
 /* One pass of the hot path over an uploaded block; placements stay on the device until fetched. */
 int apples_place_resident(apples_ctx *ctx, int64_t handle);
 int apples_fetch_placements(apples_ctx *ctx, int64_t handle, apples_placement *out);
+/* Device address of the block's placement array (n_queries apples_placement structs), for
+ * zero-copy hand-off to a collective (the end-of-run RCCL gather that replaces starmap's pickle
+ * return, run_apples.py:101-102). */
+int apples_placements_device_ptr(apples_ctx *ctx, int64_t handle, void **ptr);
 /* Distance kernel alone over an uploaded block (roofline measurement); results stay on device. */
 int apples_distances_resident(apples_ctx *ctx, int64_t handle, int32_t query_tile);
 

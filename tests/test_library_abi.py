@@ -1,0 +1,72 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/apples_hip.h declares; struct layouts agree between C and the ctypes mirror."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from helpers import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'apples_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(apples_[a-z_]+)\s*\(', text)))
+
+
+def test_header_declares_the_documented_entry_points():
+    syms = _declared_symbols()
+    for s in ('apples_ctx_create', 'apples_ctx_destroy', 'apples_distances', 'apples_place_from_sequences',
+              'apples_place_from_distances', 'apples_last_error'):
+        assert s in syms
+
+
+def test_library_builds_loads_and_exports_every_symbol():
+    from apples_amd import build, engine
+    lib_path = build.build(verbose=False)
+    assert os.path.exists(lib_path)
+    lib = ctypes.CDLL(lib_path)
+    for s in _declared_symbols():
+        assert hasattr(lib, s), 'missing export %s' % s
+    assert sorted(engine.EXPORTS) == _declared_symbols()
+    engine.load_library()
+
+
+def test_placement_struct_layout_matches_header():
+    from apples_amd.engine import PLACEMENT_DTYPE
+    assert PLACEMENT_DTYPE.itemsize == 40
+    assert [PLACEMENT_DTYPE.fields[n][1] for n in PLACEMENT_DTYPE.names] == [0, 4, 8, 16, 24, 32, 36]
+
+
+def test_missing_gpu_fails_loudly():
+    """No silent CPU path: without a device the context constructor raises."""
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from apples_amd.tree import parse_newick\n"
+            "from apples_amd.engine import Engine\n"
+            "t = parse_newick('((A:0.1,B:0.2):0.25,(C:0.3,(D:0.2,E:0.2):0.2):0.25);')\n"
+            "try:\n"
+            "    Engine(t, None)\n"
+            "except RuntimeError as e:\n"
+            "    print('RAISED', e)\n" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='-1', ROCR_VISIBLE_DEVICES='')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=300)
+    assert 'RAISED' in out.stdout, out.stdout + out.stderr
+
+
+def test_jc69_table_matches_reference_expression():
+    """The host-filled JC69 table equals the oracle's scalar evaluation for every integer pair."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import apples_oracle as orc
+    from apples_amd.engine import jc69_lut
+    for L, V in ((37, 0.001), (64, 0.5)):
+        lut = jc69_lut(L, V)
+        assert len(lut) == (L + 1) * (L + 2) // 2
+        for valid in range(L + 1):
+            for mism in range(valid + 1):
+                want = orc.jc69_from_counts(mism, valid, L, V)
+                got = lut[valid * (valid + 1) // 2 + mism]
+                assert got == want and np.signbit(got) == np.signbit(want), (mism, valid)
