@@ -1,0 +1,115 @@
+"""Batch form of PoolQueryWorker.runquery (apples/PoolQueryWorker.py:28-141): what
+``pool.starmap(queryworker.runquery, queries)`` returns (run_apples.py:94-102), computed by the
+HIP engine on one or more MI355X devices."""
+import logging
+import sys
+import threading
+
+import numpy as np
+
+from .engine import (Engine, placement_row, F_EXACT, F_INSUFFICIENT, F_MISPLACED, F_ZERO_NOT_IN_TREE, F_DEGENERATE)
+
+
+def _shards(n, parts):
+    """Contiguous blocks, rank r gets [r*n/parts, (r+1)*n/parts) -- input order is preserved by
+    construction, as starmap does."""
+    return [(r * n // parts, (r + 1) * n // parts) for r in range(parts)]
+
+
+class QueryWorker:
+    """State injected once (PoolQueryWorker.set_class_attributes, PoolQueryWorker.py:17-24)."""
+
+    def __init__(self, tree, options, reference=None, devices=(0,)):
+        self.tree = tree
+        self.options = options
+        self.reference = reference
+        self.devices = list(devices)
+        self._engines = {}
+
+    def _engine(self, device):
+        if device not in self._engines:
+            o = self.options
+            kw = dict(protein=o.protein_seqs, method=o.method_name, criterion=o.criterion_name,
+                      negative=bool(o.negative_branch), threshold=o.filt_threshold,
+                      baseobs=o.base_observation_threshold, overlap=o.minimum_alignment_overlap, device=device)
+            if self.reference is not None:
+                aln = self.reference.aln
+                nodes = np.array([self.tree.name_to_node.get(n, -1) for n in aln.names], np.int32)
+                self._engines[device] = Engine(self.tree, aln.seqs, nodes, clusters=self.reference.cluster_arrays(), **kw)
+            else:
+                self._engines[device] = Engine(self.tree, None, **kw)
+        return self._engines[device]
+
+    def close(self):
+        for e in self._engines.values():
+            e.close()
+        self._engines = {}
+
+    def _run_sharded(self, n, fn):
+        """fn(engine, lo, hi) -> placement array for queries [lo, hi); one host thread per device."""
+        parts = _shards(n, len(self.devices))
+        outs = [None] * len(parts)
+        errs = []
+
+        def work(k):
+            try:
+                lo, hi = parts[k]
+                outs[k] = fn(self._engine(self.devices[k]), lo, hi)
+            except Exception as e:  # an exception in any worker aborts the run, as starmap does
+                errs.append(e)
+
+        if len(parts) == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(k,)) for k in range(len(parts))]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        if errs:
+            raise errs[0]
+        return np.concatenate(outs) if outs else np.zeros(0)
+
+    # ------------------------------------------------------------------ alignment input
+    def run_sequences(self, names, seqs):
+        aln = self.reference.aln
+        # the entry runquery deletes: query name is a backbone leaf and names a reference row (:63-66)
+        self_rows = np.array([aln.index.get(n, -1) if n in self.tree.name_to_node else -1 for n in names], np.int32)
+        out = self._run_sharded(len(names), lambda eng, lo, hi: eng.place_sequences(seqs[lo:hi], self_rows[lo:hi]))
+        return self._to_jplace(names, out)
+
+    # ------------------------------------------------------------------ distance-table input
+    def run_distances(self, names, cols, D):
+        col_nodes = np.array([self.tree.name_to_node.get(c, -1) for c in cols], np.int32)
+        col_index = {c: i for i, c in enumerate(cols)}
+        self_cols = np.array([col_index.get(n, -1) if n in self.tree.name_to_node else -1 for n in names], np.int32)
+        out = self._run_sharded(len(names), lambda eng, lo, hi: eng.place_distances(D[lo:hi], col_nodes, self_cols[lo:hi]))
+        return self._to_jplace(names, out)
+
+    # ------------------------------------------------------------------ result assembly
+    def _to_jplace(self, names, out):
+        results = []
+        for name, p in zip(names, out):
+            flags = int(p['flags'])
+            if name in self.tree.name_to_node:
+                logging.warning('The query named %s exists in the backbone. Changing its name to %s-query.' % (name, name))
+                name = name + '-query'
+            if flags & F_ZERO_NOT_IN_TREE:
+                raise KeyError('query %s has a zero distance to a reference that is not a leaf of the backbone tree'
+                               % name)
+            if flags & F_DEGENERATE:
+                raise ValueError('query %s: fewer than two of its observed references are leaves of the backbone tree'
+                                 % name)
+            row = placement_row(p)
+            if flags & F_INSUFFICIENT:
+                sys.stderr.write('Taxon {} cannot be placed. At least three non-infinity distances '
+                                 'should be observed to place a taxon. '
+                                 'Consequently, this taxon is ignored (no output).\n'.format(name))
+            elif not (flags & F_EXACT) and (flags & F_MISPLACED):
+                ignored = ''
+                if self.options.exclude_intplace:
+                    row[0] = -1
+                    ignored = ' Consequently, this sequence is ignored (no output).'
+                logging.warning('Best placement for query sequence %s has zero pendant edge length and placed at an '
+                                'internal node with a non-zero least squares error. This is a potential misplacement.%s'
+                                % (name, ignored))
+            results.append({'placements': [{'p': [row], 'n': [name]}]})
+        return results

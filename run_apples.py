@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's run_apples.py on its per-query hot path: same flags, same jplace,
+placements computed on MI355X.  Backbone branch re-estimation (FastTree) and
+APPLES database pickles are outside this build: the tree is taken as given (-D semantics)."""
+import logging
+import re
+import sys
+import time
+
+import numpy as np
+
+from apples_amd.fasta import read_alignment
+from apples_amd.jplace import dumps, finish, join_jplace
+from apples_amd.options import options_config
+from apples_amd.reference import ReducedReference, read_treecluster
+from apples_amd.tree import extended_newick, read_tree
+from apples_amd.worker import QueryWorker
+
+
+def read_dismat(f):
+    """Header: whitespace-split names after the first field; rows: name then floats
+    (run_apples.py:43-54).  Returns (query names, column names, float64 matrix)."""
+    tags = re.split(r'\s+', f.readline().rstrip())[1:]
+    cols, seen = [], {}
+    for t in tags:  # dict(zip(tags, ...)): a repeated name keeps its first position, last value
+        if t not in seen:
+            seen[t] = len(cols)
+            cols.append(t)
+    names, rows = [], []
+    for line in f.readlines():
+        d = re.split(r'\s+', line.strip())
+        names.append(d[0])
+        row = np.full(len(cols), -1.0)
+        for t, v in zip(tags, d[1:]):
+            row[seen[t]] = float(v)
+        rows.append(row)
+    return names, cols, (np.vstack(rows) if rows else np.zeros((0, len(cols))))
+
+
+def main(argv=None):
+    startb = time.time()
+    options, _ = options_config(argv)
+    if options.reestimate_backbone and not options.dist_fp:
+        logging.warning('Backbone branch lengths are used as given: FastTree re-estimation is not part of this '
+                        'build (equivalent to -D).')
+    start = time.time()
+    tree = read_tree(options.tree_fp)
+    newick = extended_newick(tree)
+    logging.info('[%s] Tree is parsed and preprocessed in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))
+
+    ngpu = options.num_gpus
+    if ngpu <= 0:
+        import ctypes
+        from apples_amd.engine import load_library
+        load_library()
+        hip = ctypes.CDLL('libamdhip64.so')
+        n = ctypes.c_int(0)
+        hip.hipGetDeviceCount(ctypes.byref(n))
+        ngpu = max(n.value, 1)
+    devices = list(range(ngpu))
+
+    if options.dist_fp:
+        with open(options.dist_fp) as f:
+            names, cols, D = read_dismat(f)
+        worker = QueryWorker(tree, options, None, devices)
+        startq = time.time()
+        results = worker.run_distances(names, cols, D)
+    else:
+        start = time.time()
+        ref = read_alignment(options.ref_fp, options.protein_seqs, False)  # reference rows are never masked
+        clusters = read_treecluster(options.clusters_fp) if options.clusters_fp else None
+        reference = ReducedReference(ref, options.protein_seqs, clusters)
+        logging.info('[%s] Reduced reference is prepared in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))
+        if options.query_fp:
+            q = read_alignment(options.query_fp, options.protein_seqs, options.mask_lowconfidence)
+            qnames, qseqs = q.names, q.seqs
+        else:
+            ext = read_alignment(options.extended_ref_fp, options.protein_seqs, options.mask_lowconfidence)
+            keep = [i for i, n in enumerate(ext.names) if n not in ref.index]
+            qnames, qseqs = [ext.names[i] for i in keep], ext.seqs[keep]
+        worker = QueryWorker(tree, options, reference, devices)
+        startq = time.time()
+        results = worker.run_sequences(qnames, qseqs)
+    logging.info('[%s] Processed all queries in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - startq))
+    worker.close()
+
+    result = finish(join_jplace(results), newick, sys.argv if argv is None else ['run_apples.py'] + list(argv))
+    text = dumps(result)
+    if options.output_fp:
+        with open(options.output_fp, 'w') as f:
+            f.write(text)
+    else:
+        sys.stdout.write(text)
+    logging.warning('[%s] APPLES finished in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - startb))
+
+
+if __name__ == '__main__':
+    main()

@@ -447,8 +447,58 @@ def g6():
     jdump(out, 'g6_synthetic.json')
 
 
+# ============================================================================= G7 whole-CLI runs
+def g7():
+    """Run the reference's own run_apples.py end to end (treeswift stand-in registered above, and
+    a stub TreeCluster.py on PATH that labels every leaf '-1' = all-singleton clusters)."""
+    import runpy
+    import stat
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    stub = os.path.join(tmp, 'TreeCluster.py')
+    with open(stub, 'w') as f:
+        f.write('#!%s\nimport sys\nsys.path.insert(0, %r)\nfrom apples_amd.tree import read_tree\n'
+                'a = sys.argv\nt = read_tree(a[a.index("-i") + 1])\n'
+                'out = open(a[a.index("-o") + 1], "w")\nout.write("SequenceName\\tClusterNumber\\n")\n'
+                '[out.write("%%s\\t-1\\n" %% t.labels[v]) for v in t.leaves]\nout.close()\n' % (sys.executable, ROOT))
+    os.chmod(stub, os.stat(stub).st_mode | stat.S_IEXEC)
+    os.environ['PATH'] = tmp + os.pathsep + os.environ['PATH']
+    runs = {
+        'aln_OLS': ['-s', os.path.join(DATA, 'ref.fa'), '-q', os.path.join(DATA, 'query.fa'), '-t',
+                    os.path.join(DATA, 'backbone.nwk'), '-m', 'OLS', '-D', '-T', '2'],
+        'aln_default': ['-s', os.path.join(DATA, 'ref.fa'), '-q', os.path.join(DATA, 'query.fa'), '-t',
+                        os.path.join(DATA, 'backbone.nwk'), '-D', '-T', '2'],
+        'dist_default': ['-d', os.path.join(DATA, 'dist.mat'), '-t', os.path.join(DATA, 'backbone.nwk'), '-T', '2'],
+        'small_BME': ['-d', os.path.join(DATA, 'small_dist.mat'), '-t', os.path.join(DATA, 'small_backbone.nwk'),
+                      '-m', 'BME', '-T', '1'],
+    }
+    for label, args in runs.items():
+        outp = os.path.join(HERE, 'g7_cli_%s.jplace' % label)
+        old = sys.argv
+        sys.argv = ['run_apples.py'] + args + ['-o', outp]
+        try:
+            runpy.run_path(os.path.join(REF, 'run_apples.py'), run_name='__main__')
+        except RuntimeError as e:  # set_start_method may only be called once per process
+            if 'context has already been set' not in str(e):
+                raise
+            import multiprocessing as mp
+            orig = mp.set_start_method
+            mp.set_start_method = lambda *a, **k: None
+            try:
+                runpy.run_path(os.path.join(REF, 'run_apples.py'), run_name='__main__')
+            finally:
+                mp.set_start_method = orig
+        finally:
+            sys.argv = old
+        # keep the fixture location-independent
+        j = json.load(open(outp))
+        j['metadata']['invocation'] = 'run_apples.py ' + ' '.join(a.replace(DATA + os.sep, 'data/') for a in args)
+        with open(outp, 'w') as f:
+            f.write(json.dumps(j, sort_keys=True, indent=4) + '\n')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
     for w in which:
         print('generating', w, flush=True)
         globals()[w]()

@@ -1,0 +1,55 @@
+"""End-to-end drop-in check: this build's run_apples.py against jplace files written by the
+REFERENCE's run_apples.py (tests/golden/g7_cli_*.jplace).  Needs an MI355X."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import DATA, GOLD, ROOT, assert_prow
+
+pytestmark = pytest.mark.gpu
+
+RUNS = {
+    'aln_OLS': ['-s', 'ref.fa', '-q', 'query.fa', '-t', 'backbone.nwk', '-m', 'OLS', '-D', '-T', '2'],
+    'aln_default': ['-s', 'ref.fa', '-q', 'query.fa', '-t', 'backbone.nwk', '-D', '-T', '2'],
+    'dist_default': ['-d', 'dist.mat', '-t', 'backbone.nwk', '-T', '2'],
+    'small_BME': ['-d', 'small_dist.mat', '-t', 'small_backbone.nwk', '-m', 'BME', '-T', '1'],
+}
+
+
+@pytest.mark.parametrize('label', sorted(RUNS))
+def test_cli_matches_reference_jplace(label, tmp_path):
+    args = [a if a.startswith('-') or not os.path.exists(os.path.join(DATA, a)) else os.path.join(DATA, a)
+            for a in RUNS[label]]
+    out = tmp_path / 'out.jplace'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_apples.py')] + args + ['-o', str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = json.load(open(out))
+    want = json.load(open(os.path.join(GOLD, 'g7_cli_%s.jplace' % label)))
+    assert list(got) == list(want) == ['fields', 'metadata', 'placements', 'tree', 'version']
+    assert got['fields'] == want['fields'] and got['version'] == want['version'] and got['tree'] == want['tree']
+    assert [p['n'] for p in got['placements']] == [p['n'] for p in want['placements']]
+    for g, w in zip(got['placements'], want['placements']):
+        assert_prow(g['p'][0], w['p'][0], ctx='%s %s' % (label, w['n'][0]))
+    # text-level layout: sort_keys + indent=4 + trailing newline (run_apples.py:116-117)
+    text = open(out).read()
+    assert text.endswith('}\n') and text.startswith('{\n    "fields": [')
+
+
+def test_cli_stdout_and_extended_reference(tmp_path):
+    ext = tmp_path / 'ext.fa'
+    with open(ext, 'w') as f:
+        f.write(open(os.path.join(DATA, 'ref.fa')).read())
+        f.write(open(os.path.join(DATA, 'query.fa')).read())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_apples.py'), '-s', os.path.join(DATA, 'ref.fa'), '-x',
+                        str(ext), '-t', os.path.join(DATA, 'backbone.nwk'), '-m', 'OLS', '-D'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)
+    want = json.load(open(os.path.join(GOLD, 'g7_cli_aln_OLS.jplace')))
+    assert [p['n'] for p in got['placements']] == [p['n'] for p in want['placements']]
+    for g, w in zip(got['placements'], want['placements']):
+        assert_prow(g['p'][0], w['p'][0])

