@@ -45,7 +45,9 @@ def cpu_baseline(ds, protein, method, threshold, target_cpu_seconds=20.0):
     t0 = time.time()
     orc.run_pool(ds.tree, ds.ref_names, ds.ref_seqs, ds.query_names[:1], ds.query_seqs[:1], threads=1, **kw)
     t1 = max(time.time() - t0, 1e-3)
-    n = int(min(len(ds.query_names), max(cores, min(4 * cores, target_cpu_seconds / t1))))
+    # enough queries that every core gets several (pool start-up is inside the reference's own
+    # "Processed all queries" timer, run_apples.py:93-104), bounded to ~20-60 s of CPU work
+    n = int(min(len(ds.query_names), max(4 * cores, min(16 * cores, target_cpu_seconds / t1))))
     t0 = time.time()
     orc.run_pool(ds.tree, ds.ref_names, ds.ref_seqs, ds.query_names[:n], ds.query_seqs[:n], threads=cores, **kw)
     dt = time.time() - t0
@@ -100,18 +102,18 @@ def main():
                  baseobs=25, overlap=0.001, device=local_rank)
     handle, nq = eng.upload_queries(ds.query_seqs)
 
-    gather_buf = None
     if world > 1:
         class _DevArray:  # zero-copy view of the device-resident placement structs
             def __init__(self, ptr, nbytes):
                 self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
         res = torch.as_tensor(_DevArray(eng.placements_device_ptr(handle), nq * 40), device='cuda')
-        gather_buf = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
+        from apples_amd.distributed import gather_bytes
 
     def step():
         eng.place_resident(handle)  # returns after the stream has drained
         if world > 1:
-            dist.gather(res, gather_buf, dst=0)  # the end-of-run gather (replaces starmap's pickle return)
+            # the end-of-run gather over RCCL/xGMI (replaces starmap's pickle return)
+            gather_bytes(res, rank, world, dist)
 
     def sync():
         if world > 1:
