@@ -1,6 +1,7 @@
 // C ABI of libapples_hip.so: context, uploads, batch driver, timing.  See include/apples_hip.h.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -49,6 +50,19 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
     if (dev_upload(ctx, &d.child_off, t->child_off, t->n_nodes + 1)) return 1;
     if (dev_upload(ctx, &d.child_idx, t->child_idx, std::max(t->n_nodes - 1, 1))) return 1;
     if (dev_upload(ctx, &d.level, t->level, t->n_nodes)) return 1;
+    std::vector<NodeRec> rec(t->n_nodes);
+    for (int i = 0; i < t->n_nodes; ++i) {
+        NodeRec &r = rec[i];
+        r.parent = t->parent[i];
+        r.child_off = t->child_off[i];
+        r.nchild = t->child_off[i + 1] - t->child_off[i];
+        r.c0 = r.nchild > 0 ? t->child_idx[r.child_off] : -1;
+        r.c1 = r.nchild > 1 ? t->child_idx[r.child_off + 1] : -1;
+        r.level = t->level[i];
+        r.e = t->edge_len[i];
+    }
+    if (dev_upload(ctx, &d.rec, rec.data(), t->n_nodes)) return 1;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -203,11 +217,32 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
     return 0;
 }
 
+void free_sweep(Workspace::Sweep &sw) {
+    dev_free(sw.map); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
+    sw = Workspace::Sweep();
+}
+
 void free_workspace(Workspace &w) {
     dev_free(w.dist); dev_free(w.counts); dev_free(w.obs_node); dev_free(w.obs_dist); dev_free(w.cnt_gt);
-    dev_free(w.n_obs); dev_free(w.map); dev_free(w.order); dev_free(w.grp_off); dev_free(w.S); dev_free(w.R);
-    dev_free(w.xe);
+    dev_free(w.n_obs); dev_free(w.overflow_list); dev_free(w.overflow_count);
+    free_sweep(w.small);
+    free_sweep(w.big);
     w = Workspace();
+}
+
+int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg, int64_t cap, bool xe) {
+    const DevTree &t = ctx->tree;
+    sw.wgs = wgs;
+    sw.teams = (int64_t)wgs * teams_per_wg;
+    sw.cap = cap;
+    if (dev_alloc(ctx, &sw.map, sw.teams * t.n_nodes)) return 1;
+    HIP_TRY(ctx, hipMemsetAsync(sw.map, 0, (size_t)sw.teams * t.n_nodes * 4, ctx->stream));
+    if (dev_alloc(ctx, &sw.grp_off, sw.teams * (int64_t)(t.height + 4))) return 1;
+    HIP_TRY(ctx, hipMalloc(&sw.A, (size_t)sw.teams * (cap + 1) * 64));
+    HIP_TRY(ctx, hipMalloc(&sw.B, (size_t)sw.teams * (cap + 1) * 64));
+    if (xe)
+        if (dev_alloc(ctx, &sw.xe, sw.teams * cap * 5)) return 1;
+    return 0;
 }
 
 // workspaces for `members` rows/columns per query
@@ -219,16 +254,16 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     if (ctx->params.max_batch > 0) batch = std::min(batch, (int64_t)ctx->params.max_batch);
     // bound the per-batch buffers to ~6 GiB
     int64_t per_q = stride * 8 + members * 12 + (int64_t)(t.height + 2) * 4 + (need_counts ? stride * 4 : 0);
-    int64_t cap = std::max<int64_t>(32, ((int64_t)6 << 30) / std::max<int64_t>(per_q, 1));
-    batch = std::min(batch, cap);
+    int64_t capq = std::max<int64_t>(32, ((int64_t)6 << 30) / std::max<int64_t>(per_q, 1));
+    batch = std::min(batch, capq);
     batch = round_up(std::max<int64_t>(batch, 1), 32);
-    bool regrow = batch > w.batch || members > w.obs_cap || stride > w.stride || (need_counts && !w.counts) || (need_xe && !w.xe) ||
-                  (need_dist && !w.dist);
+    bool regrow = batch > w.batch || members > w.obs_cap || stride > w.stride || (need_counts && !w.counts) ||
+                  (need_xe && !w.big.xe) || (need_dist && !w.dist);
     if (!regrow) return 0;
     batch = std::max(batch, w.batch);
     int64_t obs_cap = std::max(members, w.obs_cap);
     stride = std::max(stride, w.stride);
-    bool had_xe = w.xe != nullptr, had_counts = w.counts != nullptr;
+    bool xe = need_xe || w.big.xe != nullptr, had_counts = w.counts != nullptr;
     free_workspace(w);
     w.batch = batch;
     w.obs_cap = obs_cap;
@@ -240,18 +275,24 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     if (dev_alloc(ctx, &w.obs_dist, batch * obs_cap)) return 1;
     if (dev_alloc(ctx, &w.cnt_gt, batch * (int64_t)(t.height + 2))) return 1;
     if (dev_alloc(ctx, &w.n_obs, batch)) return 1;
-    // sweep scratch: one slice per persistent workgroup, bounded to ~48 GiB in total
-    int64_t per_wg = (int64_t)t.n_nodes * (4 + 4 + 48 + 48 + ((need_xe || had_xe) ? 40 : 0)) + (t.height + 4) * 4;
-    int64_t wgs = std::min<int64_t>(1024, std::max<int64_t>(8, ((int64_t)48 << 30) / std::max<int64_t>(per_wg, 1)));
-    w.sweep_wgs = (int)wgs;
-    if (dev_alloc(ctx, &w.map, wgs * t.n_nodes)) return 1;
-    HIP_TRY(ctx, hipMemsetAsync(w.map, 0, (size_t)wgs * t.n_nodes * 4, ctx->stream));
-    if (dev_alloc(ctx, &w.order, wgs * t.n_nodes)) return 1;
-    if (dev_alloc(ctx, &w.grp_off, wgs * (int64_t)(t.height + 4))) return 1;
-    if (dev_alloc(ctx, &w.S, wgs * t.n_nodes * 6)) return 1;
-    if (dev_alloc(ctx, &w.R, wgs * t.n_nodes * 6)) return 1;
-    if (need_xe || had_xe)
-        if (dev_alloc(ctx, &w.xe, wgs * t.n_nodes * 5)) return 1;
+    if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
+    if (dev_alloc(ctx, &w.overflow_count, 1)) return 1;
+    // small teams: one wavefront per query, up to 8 workgroups (32 waves) per CU on 256 CUs;
+    // map is n_nodes ints per team (<= ~8 GiB in total), order/S/R share ~16 GiB
+    int64_t nn = t.n_nodes;
+    int64_t teams = std::min<int64_t>(8192, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
+    teams = std::min<int64_t>(teams, round_up(batch, 4));
+    if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
+    int wgs_small = (int)std::max<int64_t>(1, teams / 4);
+    int64_t per_node = 64 + 64 + (xe ? 40 : 0);
+    int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
+    if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, xe)) return 1;
+    // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
+    int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 4;
+    int64_t big_max = getenv("APPLES_SWEEP_BIG_WGS") ? atoi(getenv("APPLES_SWEEP_BIG_WGS")) : 512;
+    int wgs_big = (int)std::min<int64_t>(big_max, std::max<int64_t>(4, ((int64_t)24 << 30) / std::max<int64_t>(per_wg, 1)));
+    wgs_big = (int)std::min<int64_t>(wgs_big, batch);
+    if (alloc_sweep(ctx, w.big, wgs_big, 1, nn, xe)) return 1;
     return 0;
 }
 
@@ -342,16 +383,37 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     return s;
 }
 
-SweepArgs sweep_args(apples_ctx *ctx, apples_placement *out, bool keep_edges) {
+SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placement *out, bool keep_edges) {
     Workspace &w = ctx->ws;
     SweepArgs s{};
     s.tree = ctx->tree;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
-    s.map = w.map; s.order = w.order; s.grp_off = w.grp_off; s.S = w.S; s.R = w.R; s.xe = w.xe;
+    s.map = sw.map; s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
+    s.cap = sw.cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
     s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
+    s.work_list = nullptr; s.work_count = nullptr;
+    s.overflow_list = w.overflow_list; s.overflow_count = w.overflow_count;
     s.out = out;
     return s;
+}
+
+// The sweep for one device batch: wavefront-sized teams first, then workgroup-sized teams with
+// full-size scratch for the queries whose induced subtree did not fit (usually none).
+int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq) {
+    Workspace &w = ctx->ws;
+    HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), ctx->stream));
+    static const int small_team = getenv("APPLES_SWEEP_TEAM") ? atoi(getenv("APPLES_SWEEP_TEAM")) : 64;  // tuning knob
+    SweepArgs b = sweep_args(ctx, w.big, out, false);
+    if (small_team == 64) {
+        if (launch_sweep(ctx, sweep_args(ctx, w.small, out, false), nq, w.small.wgs, 64)) return 1;
+        b.work_list = w.overflow_list;
+        b.work_count = w.overflow_count;
+    }
+    b.overflow_list = nullptr;  // a big team's scratch holds the whole tree: it cannot overflow
+    b.overflow_count = nullptr;
+    if (launch_sweep(ctx, b, nq, w.big.wgs, 256)) return 1;
+    return 0;
 }
 
 int dist_tile_for(int64_t nq) { return nq >= 32 ? 32 : (nq >= 16 ? 16 : (nq >= 8 ? 8 : (nq >= 4 ? 4 : 1))); }
@@ -382,7 +444,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
         if (launch_select(ctx, select_args_alignment(ctx, qb, q0), nq)) return 1;
         pt.end(APPLES_T_SELECT);
         pt.begin(APPLES_T_SWEEP);
-        if (launch_sweep(ctx, sweep_args(ctx, qb.out + q0, false), nq, w.sweep_wgs)) return 1;
+        if (run_sweep(ctx, qb.out + q0, nq)) return 1;
         pt.end(APPLES_T_SWEEP);
     }
     HIP_TRY(ctx, hipEventRecord(e_stop, ctx->stream));
@@ -465,7 +527,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     for (auto &qb : ctx->blocks) free_block(&qb);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
-    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level);
+    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec);
     DevAlign &a = ctx->aln;
     dev_free(a.raw); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
@@ -665,7 +727,7 @@ int apples_place_from_distances(apples_ctx *ctx, const double *dist, int64_t n_q
         pt.end(APPLES_T_SELECT);
         if (rc) break;
         pt.begin(APPLES_T_SWEEP);
-        rc = launch_sweep(ctx, sweep_args(ctx, d_out, false), nq, w.sweep_wgs);
+        rc = run_sweep(ctx, d_out, nq);
         pt.end(APPLES_T_SWEEP);
         if (rc) break;
         if (hipMemcpyAsync(out + q0, d_out, (size_t)nq * sizeof(apples_placement), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -709,7 +771,7 @@ int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *o
     HIP_TRY(ctx, hipMemcpy(w.obs_dist, s_dist.data(), (size_t)n_obs * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.cnt_gt, cg.data(), cg.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.n_obs, &n_obs, 4, hipMemcpyHostToDevice));
-    if (launch_sweep(ctx, sweep_args(ctx, d_out, true), 1, 1)) { dev_free(d_out); return 1; }
+    if (launch_sweep(ctx, sweep_args(ctx, w.big, d_out, true), 1, 1, 256)) { dev_free(d_out); return 1; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     apples_placement res;
     HIP_TRY(ctx, hipMemcpy(&res, d_out, sizeof(res), hipMemcpyDeviceToHost));
@@ -717,12 +779,18 @@ int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *o
     if (out) *out = res;
     int V = res.n_valid;
     std::vector<int32_t> order(V);
-    std::vector<double> hS((size_t)V * 6), hR((size_t)V * 6), hx((size_t)V * 5);
-    HIP_TRY(ctx, hipMemcpy(order.data(), w.order, (size_t)V * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(hS.data(), w.S, hS.size() * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(hR.data(), w.R, hR.size() * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(hx.data(), w.xe, hx.size() * 8, hipMemcpyDeviceToHost));
-    if (lca) HIP_TRY(ctx, hipMemcpy(lca, w.grp_off + t.height + 3, 4, hipMemcpyDeviceToHost));
+    std::vector<double> hS((size_t)V * 6), hR((size_t)V * 6), hx((size_t)V * 5), ha((size_t)V * 8), hb((size_t)V * 8);
+    HIP_TRY(ctx, hipMemcpy(ha.data(), w.big.A, ha.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hb.data(), w.big.B, hb.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hx.data(), w.big.xe, hx.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < V; ++i) {
+        memcpy(&hS[(size_t)i * 6], &ha[(size_t)i * 8], 48);
+        memcpy(&hR[(size_t)i * 6], &hb[(size_t)i * 8], 48);
+        int32_t nd;
+        memcpy(&nd, reinterpret_cast<const char *>(&ha[(size_t)i * 8]) + 56, 4);
+        order[i] = nd;
+    }
+    if (lca) HIP_TRY(ctx, hipMemcpy(lca, w.big.grp_off + t.height + 3, 4, hipMemcpyDeviceToHost));
     if (valid) memset(valid, 0, t.n_nodes);
     for (int i = 0; i < V; ++i) {
         int v = order[i];
@@ -750,11 +818,11 @@ const char *apples_describe(apples_ctx *ctx) {
     snprintf(buf, sizeof buf,
              "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"n_rows\": %lld, "
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
-             "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"jc_lut\": %d}",
+             "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d}",
              name, cus, ctx->tree.n_nodes, ctx->tree.height, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
-             (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.sweep_wgs,
-             ctx->jc_lut ? 1 : 0);
+             (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
+             (long long)ctx->ws.small.cap, ctx->ws.big.wgs, ctx->jc_lut ? 1 : 0);
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

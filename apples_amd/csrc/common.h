@@ -10,6 +10,16 @@
 
 #define APPLES_TPB 256  // threads per workgroup in every kernel: 4 wave64
 
+// Tree constants of one node in one 32-byte record (one memory transaction per visit).
+struct __attribute__((aligned(32))) NodeRec {
+    int32_t parent;     // -1 for the root
+    int32_t c0, c1;     // first two children in file order (-1 if absent)
+    int32_t nchild;
+    int32_t child_off;  // into child_idx (all children, for polytomies)
+    int32_t level;
+    double e;           // edge length
+};
+
 struct DevTree {
     int32_t n_nodes = 0;
     int32_t height = 0;  // max level
@@ -18,6 +28,7 @@ struct DevTree {
     int32_t *child_off = nullptr;
     int32_t *child_idx = nullptr;
     int32_t *level = nullptr;
+    NodeRec *rec = nullptr;
 };
 
 // Slot = physical position of an alignment row on the device.  Member slots [0, n_refs) are the
@@ -65,14 +76,19 @@ struct Workspace {
     int32_t *cnt_gt = nullptr;    // [batch][height+2]: #observed leaves with level > l, at index l+1
     int32_t *n_obs = nullptr;     // [batch] emitted observed leaves (tree leaves, self removed)
     int64_t obs_cap = 0;
-    // sweep scratch, one slice per persistent workgroup
-    int32_t sweep_wgs = 0;
-    int32_t *map = nullptr;       // [wgs][n_nodes] node -> order index + 1 (0 = not in subtree)
-    int32_t *order = nullptr;     // [wgs][n_nodes] node ids grouped by level, deepest first
-    int32_t *grp_off = nullptr;   // [wgs][height+3]
-    double *S = nullptr;          // [wgs][n_nodes][6]
-    double *R = nullptr;          // [wgs][n_nodes][6]
-    double *xe = nullptr;         // [wgs][n_nodes][5] x_1,x_2,x_1_neg,x_2_neg,err (HYBRID / inspection)
+    // sweep scratch.  Small teams (one wavefront per query): `cap` nodes each; big teams (one
+    // workgroup per query, for subtrees beyond cap): n_nodes each.
+    struct Sweep {
+        int32_t wgs = 0;          // workgroups of the launch
+        int64_t teams = 0, cap = 0;
+        int32_t *map = nullptr;   // [teams][n_nodes] node -> compact index + 1 (0 = not in subtree)
+        int32_t *grp_off = nullptr; // [teams][height+4] level groups in compact order, deepest first
+        void *A = nullptr;        // [teams][cap+1] ARec (64 B): S tuple, edge length, node, leaf flag
+        void *B = nullptr;        // [teams][cap+1] BRec (64 B): R tuple, first two valid children
+        double *xe = nullptr;     // [teams][cap][5] x_1,x_2,x_1_neg,x_2_neg,err (HYBRID / inspection)
+    } small, big;
+    int32_t *overflow_list = nullptr;  // [batch]
+    int32_t *overflow_count = nullptr; // [1]
 };
 
 struct apples_ctx {
@@ -144,9 +160,14 @@ int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 struct SweepArgs {
     DevTree tree;
     const int32_t *obs_node; const double *obs_dist; int64_t obs_cap; const int32_t *cnt_gt; const int32_t *n_obs;
-    int32_t *map, *order, *grp_off; double *S, *R, *xe;
+    int32_t *map, *grp_off; void *A, *B; double *xe;
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
+    int64_t cap;              // nodes of order/S/R/xe scratch per team
+    const int32_t *work_list; // queries to process (nullptr = 0..nq-1)
+    const int32_t *work_count;// device count of work_list entries (nullptr = nq)
+    int32_t *overflow_list;   // queries whose subtree exceeded `cap`
+    int32_t *overflow_count;
     apples_placement *out;
 };
-int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs);
+int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team);

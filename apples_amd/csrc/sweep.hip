@@ -14,6 +14,14 @@
 // of that level (contiguous in the level-sorted obs list) plus the parents claimed from level
 // l+1; the loop stops when a level holds a single node and no shallower leaves remain.
 //
+// Data layout (the kernel is bound by scattered memory transactions, so everything a visit
+// needs sits in one aligned record): NodeRec (32 B, tree constant: parent, first two children,
+// edge length); per team and per subtree node, in compact order of discovery, ARec (64 B: S
+// tuple, edge length, node id, leaf flag) and BRec (64 B: R tuple, compact indices of the first
+// two valid children).  The top-down pass is parent-centric: a node reads its valid children's
+// ARecs, forms each child's R (siblings in file order, then its own lifted R), solves that
+// child's 2x2 system and residual, and stores R only for children that are internal.
+//
 // Bit parity: fp64, compiled with -ffp-contract=off; every sum is taken in the order of the
 // cited source line, children/siblings in file order and the parent term last.
 // `x ** 2` is libm pow in the reference and x*x here (<= 1 ulp apart).
@@ -138,12 +146,19 @@ __device__ __forceinline__ double shfl_down_f64s(double v, int delta) {
     return __hiloint2double(hi, lo);
 }
 
-// block-wide lexicographic arg-min over (key, id); NaN keys never win
-__device__ void block_argmin(double &d, int &i, double *shd, int *shi) {
+// team-wide lexicographic arg-min over (key, id); NaN keys never win.  A team is one wavefront
+// (TEAM == 64: shuffles only) or the whole workgroup (TEAM == 256: shuffles + LDS).
+template <int TEAM>
+__device__ void team_argmin(double &d, int &i, double *shd, int *shi) {
     for (int o = WAVE / 2; o > 0; o >>= 1) {
         double d2 = shfl_down_f64s(d, o);
         int i2 = __shfl_down(i, o, WAVE);
         if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; }
+    }
+    if (TEAM == WAVE) {
+        d = __hiloint2double(__shfl(__double2hiint(d), 0, WAVE), __shfl(__double2loint(d), 0, WAVE));
+        i = __shfl(i, 0, WAVE);
+        return;
     }
     int w = threadIdx.x / WAVE;
     __syncthreads();
@@ -156,22 +171,72 @@ __device__ void block_argmin(double &d, int &i, double *shd, int *shi) {
     }
 }
 
-template <int M>
+// Make the team's global/LDS writes visible to the whole team.  One wavefront executes its memory
+// instructions in order, so a wavefront-scope fence is enough; a workgroup needs the barrier.
+template <int TEAM>
+__device__ __forceinline__ void team_sync() {
+    if (TEAM == WAVE) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    else __syncthreads();
+}
+
+struct __attribute__((aligned(64))) ARec {
+    double S[6];
+    double e;
+    int32_t node;
+    int32_t leaf;
+};
+struct __attribute__((aligned(64))) BRec {
+    double R[6];
+    int32_t k0, k1, nk, pad;
+};
+
+// valid children of node v (tree record nr) in file order -> compact indices; returns their number
+// and the first two in k[0], k[1]
+__device__ __forceinline__ int valid_kids2(const NodeRec &nr, const int32_t *__restrict__ map,
+                                           const int32_t *__restrict__ child_idx, int *k) {
+    int nk = 0;
+    k[0] = k[1] = -1;
+    if (nr.nchild <= 2) {
+        if (nr.nchild >= 1) { int m = map[nr.c0]; if (m > 0) k[nk++] = m - 1; }
+        if (nr.nchild >= 2) { int m = map[nr.c1]; if (m > 0) k[nk++] = m - 1; }
+    } else {
+        for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
+            int m = map[child_idx[ci]];
+            if (m > 0) { if (nk < 2) k[nk] = m - 1; ++nk; }
+        }
+    }
+    return nk;
+}
+
+// One team = TEAM threads working on one query: a wavefront (TEAM == 64, four independent teams
+// per workgroup; the level loops need no s_barrier) or the whole workgroup (TEAM == 256).  Queries
+// whose subtree does not fit a team's scratch (`cap` nodes) are appended to an overflow list that
+// a second launch with full-size scratch takes.
+template <int M, int TEAM>
 __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
-    __shared__ int sh_cnt[3];
+    constexpr int TEAMS_PER_WG = APPLES_TPB / TEAM;
+    constexpr bool BME = (M == APPLES_BME);
+    __shared__ int sh_cnt_all[TEAMS_PER_WG][4];
     __shared__ double sh_d[4];
     __shared__ int sh_i[4];
-    const int tid = threadIdx.x;
+    const int team_in_wg = threadIdx.x / TEAM;
+    const int tid = threadIdx.x % TEAM;
+    int *sh_cnt = sh_cnt_all[team_in_wg];
     const DevTree &T = a.tree;
+    const NodeRec *__restrict__ NR = T.rec;
     const int64_t nn = T.n_nodes;
-    int32_t *map = a.map + (int64_t)blockIdx.x * nn;
-    int32_t *order = a.order + (int64_t)blockIdx.x * nn;
-    int32_t *grp_off = a.grp_off + (int64_t)blockIdx.x * (T.height + 4);
-    double *Sb = a.S + (int64_t)blockIdx.x * nn * 6;
-    double *Rb = a.R + (int64_t)blockIdx.x * nn * 6;
-    double *xe = a.xe ? a.xe + (int64_t)blockIdx.x * nn * 5 : nullptr;
+    const int64_t cap = a.cap;  // scratch capacity of this launch's teams, in nodes
+    const int64_t team = (int64_t)blockIdx.x * TEAMS_PER_WG + team_in_wg;
+    const int64_t n_teams = (int64_t)gridDim.x * TEAMS_PER_WG;
+    int32_t *map = a.map + team * nn;
+    ARec *A = reinterpret_cast<ARec *>(a.A) + team * (cap + 1);
+    BRec *B = reinterpret_cast<BRec *>(a.B) + team * (cap + 1);
+    int32_t *grp_off = a.grp_off + team * (T.height + 4);
+    double *xe = a.xe ? a.xe + team * cap * 5 : nullptr;
+    const int64_t n_work = a.work_count ? *a.work_count : nq;
 
-    for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
+    for (int64_t w = team; w < n_work; w += n_teams) {
+        const int64_t q = a.work_list ? a.work_list[w] : w;
         const int n = a.n_obs[q];
         if (n == 0) continue;
         const int32_t *o_node = a.obs_node + q * a.obs_cap;
@@ -181,137 +246,215 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
         // ------------------------------------------------------------ bottom-up: mark + S values
         int lvl = T.level[o_node[0]];
         int base = 0, n_par = 0, G = 0, lca = -1, lca_claimed = 0;
+        bool overflow = false;
         if (tid < 3) sh_cnt[tid] = 0;
-        __syncthreads();
+        team_sync<TEAM>();
         while (true) {
             const int lo = cg[lvl + 1], hi = cg[lvl];  // observed leaves of this level: obs[lo, hi)
             const int n_lvl = n_par + (hi - lo);
             if (n_lvl == 1 && hi == n) {  // one node left in the frontier: the LCA (Subtree.py:36-43)
-                if (n_par == 1) { lca = order[base]; lca_claimed = 1; }
+                if (n_par == 1) { lca = A[base].node; lca_claimed = 1; }
                 else lca = o_node[lo];
                 break;
             }
+            if (cap < nn && (int64_t)base + 2 * (int64_t)n_lvl > cap) { overflow = true; break; }
             if (tid == 0) { grp_off[G] = base; sh_cnt[(G + 1) % 3] = 0; }
             int *next_cnt = &sh_cnt[G % 3];
-            for (int k = tid; k < n_lvl; k += APPLES_TPB) {
+            for (int k = tid; k < n_lvl; k += TEAM) {
                 const int idx = base + k;
-                double acc[6];
-                int v;
+                ARec ar;
+                NodeRec nr;
                 if (k >= n_par) {
                     const int j = lo + (k - n_par);
-                    v = o_node[j];
-                    order[idx] = v;
-                    map[v] = idx + 1;
-                    leaf_tuple<M>(o_dist[j], acc);
+                    ar.node = o_node[j];
+                    nr = NR[ar.node];
+                    map[ar.node] = idx + 1;
+                    leaf_tuple<M>(o_dist[j], ar.S);
+                    ar.leaf = 1;
                 } else {
-                    v = order[idx];
+                    ar.node = A[idx].node;
+                    nr = NR[ar.node];
+                    ar.leaf = 0;
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) acc[c] = 0;
-                    const int c0 = T.child_off[v], c1 = T.child_off[v + 1];
-                    double coef = 1.0;
-                    if (M == APPLES_BME) {  // apples/BME.py:20
-                        int nv = 0;
-                        for (int ci = c0; ci < c1; ++ci) nv += map[T.child_idx[ci]] > 0;
-                        coef = 1.0 / (double)nv;
-                    }
-                    for (int ci = c0; ci < c1; ++ci) {
-                        const int c = T.child_idx[ci];
-                        const int mc = map[c];
-                        if (mc > 0) {
-                            double s[6], t[6];
-                            const double *sp = Sb + (int64_t)(mc - 1) * 6;
+                    for (int c = 0; c < 6; ++c) ar.S[c] = 0;
+                    int kk[2];
+                    const int nk = valid_kids2(nr, map, T.child_idx, kk);
+                    const double coef = BME ? 1.0 / (double)nk : 1.0;  // apples/BME.py:20
+                    if (nr.nchild <= 2) {
 #pragma unroll
-                            for (int x = 0; x < 6; ++x) s[x] = sp[x];
-                            lift<M>(s, T.edge_len[c], t);
+                        for (int z = 0; z < 2; ++z) {
+                            if (z < nk) {
+                                const ARec &cr = A[kk[z]];
+                                double s[6], t[6];
 #pragma unroll
-                            for (int x = 0; x < 6; ++x) acc[x] += (M == APPLES_BME) ? coef * t[x] : t[x];
+                                for (int x = 0; x < 6; ++x) s[x] = cr.S[x];
+                                lift<M>(s, cr.e, t);
+#pragma unroll
+                                for (int x = 0; x < 6; ++x) ar.S[x] += BME ? coef * t[x] : t[x];
+                            }
+                        }
+                    } else {
+                        for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
+                            const int mc = map[T.child_idx[ci]];
+                            if (mc > 0) {
+                                const ARec &cr = A[mc - 1];
+                                double s[6], t[6];
+#pragma unroll
+                                for (int x = 0; x < 6; ++x) s[x] = cr.S[x];
+                                lift<M>(s, cr.e, t);
+#pragma unroll
+                                for (int x = 0; x < 6; ++x) ar.S[x] += BME ? coef * t[x] : t[x];
+                            }
                         }
                     }
+                    BRec &br = B[idx];
+                    br.k0 = kk[0]; br.k1 = kk[1]; br.nk = nk;
                 }
-                double *sp = Sb + (int64_t)idx * 6;
-#pragma unroll
-                for (int x = 0; x < 6; ++x) sp[x] = acc[x];
-                const int p = T.parent[v];
+                ar.e = nr.e;
+                A[idx] = ar;
+                if (ar.leaf) B[idx].nk = 0;
+                const int p = nr.parent;
                 if (p >= 0 && atomicCAS(&map[p], 0, -1) == 0) {
                     const int nidx = base + n_lvl + atomicAdd(next_cnt, 1);
-                    order[nidx] = p;
+                    A[nidx].node = p;
                     map[p] = nidx + 1;
                 }
             }
-            __syncthreads();
+            team_sync<TEAM>();
             n_par = *next_cnt;
             base += n_lvl;
             ++G;
             --lvl;
         }
-        const int V = base;  // Subtree.num_nodes
-        if (tid == 0) grp_off[G] = V;
-        __syncthreads();
+        if (overflow) {  // hand the query to the big-team launch; undo this team's marks first
+            team_sync<TEAM>();
+            for (int idx = tid; idx < base + n_par; idx += TEAM) map[A[idx].node] = 0;
+            if (tid == 0) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
+            team_sync<TEAM>();
+            continue;
+        }
+        const int V = base;  // Subtree.num_nodes; the LCA's record sits at index V
+        if (tid == 0) {
+            grp_off[G] = V;
+            grp_off[G + 1] = V + 1;
+            int kk[2];
+            const NodeRec nr = NR[lca];
+            A[V].node = lca;
+            B[V].nk = valid_kids2(nr, map, T.child_idx, kk);
+            B[V].k0 = kk[0]; B[V].k1 = kk[1];
+        }
+        team_sync<TEAM>();
 
-        // ------------------------------------------------------------ top-down: R values, solve, residual
+        // ------------------------------------------------------------ top-down, parent-centric:
+        // a node forms R for each valid child (all_R_values), solves it (placement_per_edge) and
+        // evaluates its residual (error_per_edge)
         double best_key = INF_D;
         int best_v = 0x7fffffff;
-        for (int g = G - 1; g >= 0; --g) {
+        Sol best_sol;
+        double best_e = 0;
+        best_sol.x1 = best_sol.x2 = best_sol.err = 0; best_sol.x1_int = 0; best_sol.x1n = best_sol.x2n = 0;
+        for (int g = G; g >= 1; --g) {
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
-            for (int idx = g0 + tid; idx < g1; idx += APPLES_TPB) {
-                const int v = order[idx];
-                const int p = T.parent[v];
-                double acc[6];
+            for (int idx = g0 + tid; idx < g1; idx += TEAM) {
+                const BRec br = B[idx];
+                if (br.nk == 0) continue;  // an observed leaf
+                const bool is_lca = (idx == V);
+                double rp[6], ep = 0;
+                if (!is_lca) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) acc[c] = 0;
-                const int c0 = T.child_off[p], c1 = T.child_off[p + 1];
-                double coef = 1.0;
-                if (M == APPLES_BME) {  // apples/BME.py:36-37
-                    int ns = (p != lca) ? 1 : 0;
+                    for (int x = 0; x < 6; ++x) rp[x] = br.R[x];
+                    ep = A[idx].e;
+                }
+                const int pnode = A[idx].node;
+                const NodeRec nr = NR[pnode];
+                // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
+                const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + br.nk - 1) : 1.0;
+                double plift[6];
+                if (!is_lca) lift<M>(rp, ep, plift);
+                if (nr.nchild <= 2) {
+                    ARec kid[2];
+                    kid[0] = A[br.k0];
+                    if (br.nk > 1) kid[1] = A[br.k1];
+#pragma unroll
+                    for (int z = 0; z < 2; ++z) {
+                        if (z < br.nk) {
+                            double acc[6];
+#pragma unroll
+                            for (int x = 0; x < 6; ++x) acc[x] = 0;
+                            if (br.nk > 1) {  // the one valid sibling (apples/OLS.py:59-69)
+                                double t[6];
+                                lift<M>(kid[1 - z].S, kid[1 - z].e, t);
+#pragma unroll
+                                for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * t[x] : t[x];
+                            }
+                            if (!is_lca) {  // parent term last (apples/OLS.py:70-80)
+#pragma unroll
+                                for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
+                            }
+                            const int cidx = z == 0 ? br.k0 : br.k1;
+                            Sol r = solve_edge<M>(kid[z].S, acc, kid[z].e, a.negative);
+                            if (!kid[z].leaf || a.keep_edges) {
+#pragma unroll
+                                for (int x = 0; x < 6; ++x) B[cidx].R[x] = acc[x];
+                            }
+                            if (a.keep_edges) {
+                                double *xp = xe + (int64_t)cidx * 5;
+                                xp[0] = r.x1; xp[1] = r.x2; xp[2] = r.x1n; xp[3] = r.x2n; xp[4] = r.err;
+                            }
+                            const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
+                            if (key < best_key || (key == best_key && kid[z].node < best_v)) {
+                                best_key = key; best_v = kid[z].node; best_sol = r; best_e = kid[z].e;
+                            }
+                        }
+                    }
+                } else {  // polytomy: children through the CSR list
+                    const int c0 = nr.child_off, c1 = nr.child_off + nr.nchild;
                     for (int ci = c0; ci < c1; ++ci) {
-                        const int c = T.child_idx[ci];
-                        ns += (c != v) && (map[c] > 0);
+                        const int mc = map[T.child_idx[ci]];
+                        if (mc <= 0) continue;
+                        double acc[6];
+#pragma unroll
+                        for (int x = 0; x < 6; ++x) acc[x] = 0;
+                        for (int cj = c0; cj < c1; ++cj) {
+                            if (cj == ci) continue;
+                            const int ms = map[T.child_idx[cj]];
+                            if (ms > 0) {
+                                const ARec &sr = A[ms - 1];
+                                double s[6], t[6];
+#pragma unroll
+                                for (int x = 0; x < 6; ++x) s[x] = sr.S[x];
+                                lift<M>(s, sr.e, t);
+#pragma unroll
+                                for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * t[x] : t[x];
+                            }
+                        }
+                        if (!is_lca) {
+#pragma unroll
+                            for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
+                        }
+                        const ARec kr = A[mc - 1];
+                        Sol r = solve_edge<M>(kr.S, acc, kr.e, a.negative);
+                        if (!kr.leaf || a.keep_edges) {
+#pragma unroll
+                            for (int x = 0; x < 6; ++x) B[mc - 1].R[x] = acc[x];
+                        }
+                        if (a.keep_edges) {
+                            double *xp = xe + (int64_t)(mc - 1) * 5;
+                            xp[0] = r.x1; xp[1] = r.x2; xp[2] = r.x1n; xp[3] = r.x2n; xp[4] = r.err;
+                        }
+                        const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
+                        if (key < best_key || (key == best_key && kr.node < best_v)) {
+                            best_key = key; best_v = kr.node; best_sol = r; best_e = kr.e;
+                        }
                     }
-                    coef = 1.0 / (double)ns;
                 }
-                for (int ci = c0; ci < c1; ++ci) {
-                    const int c = T.child_idx[ci];
-                    if (c == v) continue;
-                    const int mc = map[c];
-                    if (mc > 0) {
-                        double s[6], t[6];
-                        const double *sp = Sb + (int64_t)(mc - 1) * 6;
-#pragma unroll
-                        for (int x = 0; x < 6; ++x) s[x] = sp[x];
-                        lift<M>(s, T.edge_len[c], t);
-#pragma unroll
-                        for (int x = 0; x < 6; ++x) acc[x] += (M == APPLES_BME) ? coef * t[x] : t[x];
-                    }
-                }
-                if (p != lca) {  // parent is valid: add its R lifted over its edge (apples/OLS.py:70-80)
-                    double s[6], t[6];
-                    const double *rp = Rb + (int64_t)(map[p] - 1) * 6;
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) s[x] = rp[x];
-                    lift<M>(s, T.edge_len[p], t);
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) acc[x] += (M == APPLES_BME) ? coef * t[x] : t[x];
-                }
-                double *rp = Rb + (int64_t)idx * 6;
-#pragma unroll
-                for (int x = 0; x < 6; ++x) rp[x] = acc[x];
-                double s[6];
-                const double *sp = Sb + (int64_t)idx * 6;
-#pragma unroll
-                for (int x = 0; x < 6; ++x) s[x] = sp[x];
-                Sol r = solve_edge<M>(s, acc, T.edge_len[v], a.negative);
-                if (a.keep_edges) {
-                    double *xp = xe + (int64_t)idx * 5;
-                    xp[0] = r.x1; xp[1] = r.x2; xp[2] = r.x1n; xp[3] = r.x2n; xp[4] = r.err;
-                }
-                const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
-                if (key < best_key || (key == best_key && v < best_v)) { best_key = key; best_v = v; }
             }
-            __syncthreads();
+            team_sync<TEAM>();
         }
 
         // ------------------------------------------------------------ selection (apples/Algorithm.py:74-91)
         int win;
+        const int my_best = best_v;
         if (a.criterion == APPLES_HYBRID) {
             // nsmallest(floor(log2(num_nodes))) by error (stable = ties to the smaller edge_index),
             // then the first minimum of x_1 among them in that order
@@ -323,62 +466,83 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
             for (int r = 0; r < kk; ++r) {
                 double ke = INF_D;
                 int kv = 0x7fffffff;
-                for (int idx = tid; idx < V; idx += APPLES_TPB) {
+                for (int idx = tid; idx < V; idx += TEAM) {
                     const double e = xe[(int64_t)idx * 5 + 4];
-                    const int v = order[idx];
+                    const int v = A[idx].node;
                     const bool after = (e > last_e) || (e == last_e && v > last_v);
                     if (after && (e < ke || (e == ke && v < kv))) { ke = e; kv = v; }
                 }
-                block_argmin(ke, kv, sh_d, sh_i);
+                team_argmin<TEAM>(ke, kv, sh_d, sh_i);
                 if (kv == 0x7fffffff) break;
                 last_e = ke; last_v = kv;
                 const double x1 = xe[(int64_t)(map[kv] - 1) * 5 + 0];
                 if (win < 0 || x1 < bx) { bx = x1; win = kv; }
             }
+            if (win >= 0 && tid == 0) {  // rebuild the winner's solution from the stored per-edge values
+                const int widx = map[win] - 1;
+                const double *xp = xe + (int64_t)widx * 5;
+                best_sol.x1 = xp[0]; best_sol.x2 = xp[1]; best_sol.err = xp[4];
+                // the clamped pendant is the int 0 exactly when the clamp replaced a non-zero value or
+                // the value the solver kept is itself not the unclamped one (apples/util.py:32-50)
+                ARec wr = A[widx];
+                double rr[6];
+#pragma unroll
+                for (int x = 0; x < 6; ++x) rr[x] = B[widx].R[x];
+                best_sol = solve_edge<M>(wr.S, rr, wr.e, a.negative);
+                best_e = wr.e;
+            }
         } else {
-            block_argmin(best_key, best_v, sh_d, sh_i);
+            team_argmin<TEAM>(best_key, best_v, sh_d, sh_i);
             win = best_v;
         }
 
-        if (tid == 0) {
-            apples_placement pl = a.out[q];
-            pl.n_valid = V;
-            if (win < 0 || win == 0x7fffffff) {
+        const bool writer = (a.criterion == APPLES_HYBRID) ? (tid == 0) : (my_best == win && win != 0x7fffffff);
+        if (win < 0 || win == 0x7fffffff) {
+            if (tid == 0) {
+                apples_placement pl = a.out[q];
+                pl.n_valid = V;
                 pl.edge = -1;
                 pl.flags |= APPLES_F_DEGENERATE | APPLES_F_PENDANT_INT;
-            } else {
-                const int idx = map[win] - 1;
-                double s[6], r6[6];
-#pragma unroll
-                for (int x = 0; x < 6; ++x) { s[x] = Sb[(int64_t)idx * 6 + x]; r6[x] = Rb[(int64_t)idx * 6 + x]; }
-                const double e = T.edge_len[win];
-                Sol r = solve_edge<M>(s, r6, e, a.negative);
-                pl.edge = win;
-                pl.error = r.err;
-                pl.distal = e - r.x2;
-                pl.pendant = r.x1;
-                pl.flags = 0;
-                if (r.x1_int) pl.flags |= APPLES_F_PENDANT_INT;
-                if (r.x1 == 0 && r.err > 0 && (r.x2 == 0 || r.x2 == e)) pl.flags |= APPLES_F_MISPLACED;
+                a.out[q] = pl;
             }
+        } else if (writer) {
+            apples_placement pl = a.out[q];
+            pl.n_valid = V;
+            pl.edge = win;
+            pl.error = best_sol.err;
+            pl.distal = best_e - best_sol.x2;
+            pl.pendant = best_sol.x1;
+            pl.flags = 0;
+            if (best_sol.x1_int) pl.flags |= APPLES_F_PENDANT_INT;
+            if (best_sol.x1 == 0 && best_sol.err > 0 && (best_sol.x2 == 0 || best_sol.x2 == best_e)) pl.flags |= APPLES_F_MISPLACED;
             a.out[q] = pl;
-            grp_off[T.height + 3] = lca;
         }
-        __syncthreads();
+        if (tid == 0) grp_off[T.height + 3] = lca;
+        team_sync<TEAM>();
         // ------------------------------------------------------------ unroll_changes (Subtree.py:72-76)
-        for (int idx = tid; idx < V + lca_claimed; idx += APPLES_TPB) map[order[idx]] = 0;
-        __syncthreads();
+        for (int idx = tid; idx < V + lca_claimed; idx += TEAM) map[A[idx].node] = 0;
+        team_sync<TEAM>();
     }
 }
 
-int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs) {
-    if (nq == 0) return 0;
-    dim3 grid((unsigned)(nq < wgs ? nq : wgs)), block(APPLES_TPB);
+template <int TEAM>
+static void launch_sweep_team(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs) {
+    dim3 grid((unsigned)wgs), block(APPLES_TPB);
     switch (a.method) {
-        case APPLES_FM: hipLaunchKernelGGL(k_sweep<APPLES_FM>, grid, block, 0, ctx->stream, a, nq); break;
-        case APPLES_BME: hipLaunchKernelGGL(k_sweep<APPLES_BME>, grid, block, 0, ctx->stream, a, nq); break;
-        case APPLES_BE: hipLaunchKernelGGL(k_sweep<APPLES_BE>, grid, block, 0, ctx->stream, a, nq); break;
-        default: hipLaunchKernelGGL(k_sweep<APPLES_OLS>, grid, block, 0, ctx->stream, a, nq); break;
+        case APPLES_FM: hipLaunchKernelGGL((k_sweep<APPLES_FM, TEAM>), grid, block, 0, ctx->stream, a, nq); break;
+        case APPLES_BME: hipLaunchKernelGGL((k_sweep<APPLES_BME, TEAM>), grid, block, 0, ctx->stream, a, nq); break;
+        case APPLES_BE: hipLaunchKernelGGL((k_sweep<APPLES_BE, TEAM>), grid, block, 0, ctx->stream, a, nq); break;
+        default: hipLaunchKernelGGL((k_sweep<APPLES_OLS, TEAM>), grid, block, 0, ctx->stream, a, nq); break;
+    }
+}
+
+int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team) {
+    if (nq == 0) return 0;
+    if (team == 64) {
+        int64_t need = (nq + 3) / 4;
+        launch_sweep_team<64>(ctx, a, nq, (int)(need < wgs ? need : wgs));
+    } else {
+        launch_sweep_team<256>(ctx, a, nq, (int)(nq < wgs ? nq : wgs));
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
