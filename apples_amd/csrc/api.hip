@@ -224,7 +224,8 @@ void free_sweep(Workspace::Sweep &sw) {
 
 void free_workspace(Workspace &w) {
     dev_free(w.dist); dev_free(w.counts); dev_free(w.obs_node); dev_free(w.obs_dist); dev_free(w.cnt_gt);
-    dev_free(w.n_obs); dev_free(w.overflow_list); dev_free(w.overflow_count);
+    dev_free(w.n_obs); dev_free(w.overflow_list); dev_free(w.overflow_count); dev_free(w.route_list); dev_free(w.route_count); dev_free(w.seg_slot); dev_free(w.seg_cnt);
+    dev_free(w.dist_slow); dev_free(w.slow_list); dev_free(w.slow_count);
     free_sweep(w.small);
     free_sweep(w.big);
     w = Workspace();
@@ -247,23 +248,26 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
 
 // workspaces for `members` rows/columns per query
 int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t want_batch, bool need_dist,
-                     bool need_counts, bool need_xe) {
+                     bool need_counts, bool need_xe, bool need_fused = false) {
     Workspace &w = ctx->ws;
     const DevTree &t = ctx->tree;
     int64_t batch = want_batch;
     if (ctx->params.max_batch > 0) batch = std::min(batch, (int64_t)ctx->params.max_batch);
-    // bound the per-batch buffers to ~6 GiB
-    int64_t per_q = stride * 8 + members * 12 + (int64_t)(t.height + 2) * 4 + (need_counts ? stride * 4 : 0);
-    int64_t capq = std::max<int64_t>(32, ((int64_t)6 << 30) / std::max<int64_t>(per_q, 1));
+    // bound the per-batch buffers to ~32 GiB (the card has 288 GB; larger batches amortise the
+    // sweep's tail and the kernel boundaries)
+    int64_t per_q = stride * 8 + members * 12 + (int64_t)(t.height + 2) * 4 + (need_counts ? stride * 4 : 0) +
+                    (need_fused ? stride * 12 + stride / 16 : 0);
+    int64_t capq = std::max<int64_t>(32, ((int64_t)32 << 30) / std::max<int64_t>(per_q, 1));
     batch = std::min(batch, capq);
     batch = round_up(std::max<int64_t>(batch, 1), 32);
     bool regrow = batch > w.batch || members > w.obs_cap || stride > w.stride || (need_counts && !w.counts) ||
-                  (need_xe && !w.big.xe) || (need_dist && !w.dist);
+                  (need_xe && !w.big.xe) || (need_dist && !w.dist) || (need_fused && !w.seg_slot);
     if (!regrow) return 0;
     batch = std::max(batch, w.batch);
     int64_t obs_cap = std::max(members, w.obs_cap);
     stride = std::max(stride, w.stride);
     bool xe = need_xe || w.big.xe != nullptr, had_counts = w.counts != nullptr;
+    bool fused = need_fused || w.seg_slot != nullptr;
     free_workspace(w);
     w.batch = batch;
     w.obs_cap = obs_cap;
@@ -275,6 +279,15 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     if (dev_alloc(ctx, &w.obs_dist, batch * obs_cap)) return 1;
     if (dev_alloc(ctx, &w.cnt_gt, batch * (int64_t)(t.height + 2))) return 1;
     if (dev_alloc(ctx, &w.n_obs, batch)) return 1;
+    if (fused) {
+        if (dev_alloc(ctx, &w.seg_slot, batch * std::max<int64_t>(stride, 1))) return 1;
+        if (dev_alloc(ctx, &w.seg_cnt, batch * std::max<int64_t>(stride / 64, 1))) return 1;
+        if (dev_alloc(ctx, &w.dist_slow, batch * std::max<int64_t>(stride, 1))) return 1;
+        if (dev_alloc(ctx, &w.slow_list, batch)) return 1;
+        if (dev_alloc(ctx, &w.slow_count, 1)) return 1;
+    }
+    if (dev_alloc(ctx, &w.route_list, batch)) return 1;
+    if (dev_alloc(ctx, &w.route_count, 1)) return 1;
     if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
     if (dev_alloc(ctx, &w.overflow_count, 1)) return 1;
     // small teams: one wavefront per query, up to 8 workgroups (32 waves) per CU on 256 CUs;
@@ -368,6 +381,12 @@ struct PhaseTimer {
     }
 };
 
+// observed-leaf count above which a query goes straight to a workgroup-sized sweep team
+int big_threshold() {
+    static const int v = getenv("APPLES_BIG_THRESHOLD") ? atoi(getenv("APPLES_BIG_THRESHOLD")) : 4096;
+    return v;
+}
+
 SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t q0) {
     const DevAlign &a = ctx->aln;
     Workspace &w = ctx->ws;
@@ -380,6 +399,9 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     s.thr = ctx->params.filt_threshold; s.baseobs = ctx->params.base_observation; s.height = ctx->tree.height;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.out = qb.out + q0;
+    s.big_threshold = big_threshold(); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+    s.seg_slot = w.seg_slot; s.seg_cnt = w.seg_cnt; s.node_level = ctx->tree.level;
+    s.slow_list = w.slow_list; s.slow_count = w.slow_count; s.qlist = nullptr; s.qcount = nullptr;
     return s;
 }
 
@@ -392,7 +414,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.cap = sw.cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
     s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
-    s.work_list = nullptr; s.work_count = nullptr;
+    s.work_list = nullptr; s.work_count = nullptr; s.big_threshold = big_threshold();
     s.overflow_list = w.overflow_list; s.overflow_count = w.overflow_count;
     s.out = out;
     return s;
@@ -402,16 +424,25 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
 // full-size scratch for the queries whose induced subtree did not fit (usually none).
 int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq) {
     Workspace &w = ctx->ws;
-    HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), ctx->stream));
     static const int small_team = getenv("APPLES_SWEEP_TEAM") ? atoi(getenv("APPLES_SWEEP_TEAM")) : 64;  // tuning knob
     SweepArgs b = sweep_args(ctx, w.big, out, false);
-    if (small_team == 64) {
-        if (launch_sweep(ctx, sweep_args(ctx, w.small, out, false), nq, w.small.wgs, 64)) return 1;
-        b.work_list = w.overflow_list;
-        b.work_count = w.overflow_count;
-    }
     b.overflow_list = nullptr;  // a big team's scratch holds the whole tree: it cannot overflow
     b.overflow_count = nullptr;
+    if (small_team != 64) return launch_sweep(ctx, b, nq, w.big.wgs, 256);
+    // queries the selection kernel routed to big teams (many observed leaves) run on a second
+    // stream, concurrently with the wavefront-sized teams that take everything else
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sel, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_sel, 0));
+    b.work_list = w.route_list;
+    b.work_count = w.route_count;
+    if (launch_sweep(ctx, b, nq, w.big.wgs, 256, ctx->stream2)) return 1;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_big, ctx->stream2));
+    HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), ctx->stream));
+    if (launch_sweep(ctx, sweep_args(ctx, w.small, out, false), nq, w.small.wgs, 64)) return 1;
+    // whatever did not fit a small team's scratch (usually nothing)
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_big, 0));
+    b.work_list = w.overflow_list;
+    b.work_count = w.overflow_count;
     if (launch_sweep(ctx, b, nq, w.big.wgs, 256)) return 1;
     return 0;
 }
@@ -421,7 +452,11 @@ int dist_tile_for(int64_t nq) { return nq >= 32 ? 32 : (nq >= 16 ? 16 : (nq >= 8
 int run_block(apples_ctx *ctx, QueryBlock &qb) {
     const DevAlign &a = ctx->aln;
     bool hybrid = ctx->params.criterion == APPLES_HYBRID;
-    if (ensure_workspace(ctx, a.n_refs, a.slots_pad, qb.n, true, false, hybrid)) return 1;
+    // fused path: threshold compaction in the distance kernel's epilogue; only queries that need
+    // the top-up rule get full distance rows
+    static const bool no_fuse = getenv("APPLES_NO_FUSE") != nullptr;  // tuning/diagnostic knob
+    const bool fused = !no_fuse && a.all_singleton && ctx->params.model == APPLES_JC69;
+    if (ensure_workspace(ctx, a.n_refs, a.slots_pad, qb.n, true, false, hybrid, fused)) return 1;
     Workspace &w = ctx->ws;
     PhaseTimer pt{ctx};
     hipEvent_t e_start, e_stop;
@@ -432,17 +467,36 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
     for (int64_t q0 = 0; q0 < qb.n; q0 += w.batch) {
         int64_t nq = std::min(w.batch, qb.n - q0);
         pt.flush();
-        pt.begin(APPLES_T_DIST);
-        if (ctx->params.model == APPLES_SCOREDIST) {
-            if (launch_scoredist(ctx, qb, q0, nq, w.dist, nullptr)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(w.route_count, 0, sizeof(int32_t), ctx->stream));
+        if (fused) {
+            HIP_TRY(ctx, hipMemsetAsync(w.slow_count, 0, sizeof(int32_t), ctx->stream));
+            pt.begin(APPLES_T_DIST);
+            if (launch_counts_fused(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, w.seg_slot, w.seg_cnt)) return 1;
+            pt.end(APPLES_T_DIST);
+            ++launches;
+            pt.begin(APPLES_T_SELECT);
+            SelectArgs sa = select_args_alignment(ctx, qb, q0);
+            if (launch_select_fast(ctx, sa, nq)) return 1;
+            // top-up path for the queries k_select_fast listed: full rows, then the general selection
+            if (launch_counts_listed(ctx, qb, q0, nq, w.slow_list, w.slow_count, w.dist_slow)) return 1;
+            sa.dist = w.dist_slow;
+            sa.qlist = w.slow_list;
+            sa.qcount = w.slow_count;
+            if (launch_select(ctx, sa, nq)) return 1;
+            pt.end(APPLES_T_SELECT);
         } else {
-            if (launch_counts(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, nullptr)) return 1;
+            pt.begin(APPLES_T_DIST);
+            if (ctx->params.model == APPLES_SCOREDIST) {
+                if (launch_scoredist(ctx, qb, q0, nq, w.dist, nullptr)) return 1;
+            } else {
+                if (launch_counts(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, nullptr)) return 1;
+            }
+            pt.end(APPLES_T_DIST);
+            ++launches;
+            pt.begin(APPLES_T_SELECT);
+            if (launch_select(ctx, select_args_alignment(ctx, qb, q0), nq)) return 1;
+            pt.end(APPLES_T_SELECT);
         }
-        pt.end(APPLES_T_DIST);
-        ++launches;
-        pt.begin(APPLES_T_SELECT);
-        if (launch_select(ctx, select_args_alignment(ctx, qb, q0), nq)) return 1;
-        pt.end(APPLES_T_SELECT);
         pt.begin(APPLES_T_SWEEP);
         if (run_sweep(ctx, qb.out + q0, nq)) return 1;
         pt.end(APPLES_T_SWEEP);
@@ -484,7 +538,9 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         return fail();
     }
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return fail(); }
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return fail(); }
+    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_sel, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return fail(); }
     for (int i = 0; i < 8; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return fail(); }
     if (tree->n_nodes < 2) { ctx->err = "tree needs at least two nodes"; return fail(); }
@@ -524,6 +580,7 @@ int apples_set_params(apples_ctx *ctx, const apples_params *params) {
 void apples_ctx_destroy(apples_ctx *ctx) {
     if (!ctx) return;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     for (auto &qb : ctx->blocks) free_block(&qb);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
@@ -535,6 +592,9 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     dev_free(ctx->d_col_level);
     for (int i = 0; i < 8; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ev_sel) (void)hipEventDestroy(ctx->ev_sel);
+    if (ctx->ev_big) (void)hipEventDestroy(ctx->ev_big);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -721,6 +781,8 @@ int apples_place_from_distances(apples_ctx *ctx, const double *dist, int64_t n_q
         s.thr = ctx->params.filt_threshold; s.baseobs = ctx->params.base_observation; s.height = t.height;
         s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
         s.out = d_out;
+        s.big_threshold = big_threshold(); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+        if (hipMemsetAsync(w.route_count, 0, sizeof(int32_t), ctx->stream) != hipSuccess) { ctx->err = "memset failed"; rc = 1; break; }
         pt.flush();
         pt.begin(APPLES_T_SELECT);
         rc = launch_select(ctx, s, nq);

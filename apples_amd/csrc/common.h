@@ -87,6 +87,13 @@ struct Workspace {
         void *B = nullptr;        // [teams][cap+1] BRec (64 B): R tuple, first two valid children
         double *xe = nullptr;     // [teams][cap][5] x_1,x_2,x_1_neg,x_2_neg,err (HYBRID / inspection)
     } small, big;
+    int32_t *seg_slot = nullptr;       // [batch][stride] fused path: slots of the kept entries
+    int32_t *seg_cnt = nullptr;        // [batch][stride/64]
+    double *dist_slow = nullptr;       // [batch][stride] full rows for the top-up path
+    int32_t *slow_list = nullptr;      // [batch]
+    int32_t *slow_count = nullptr;     // [1]
+    int32_t *route_list = nullptr;     // [batch] queries routed to big teams by the selection kernel
+    int32_t *route_count = nullptr;    // [1]
     int32_t *overflow_list = nullptr;  // [batch]
     int32_t *overflow_count = nullptr; // [1]
 };
@@ -94,6 +101,8 @@ struct Workspace {
 struct apples_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // big-team sweep of the routed queries, concurrent with the small teams
+    hipEvent_t ev_sel = nullptr, ev_big = nullptr;
     std::string err;
     std::string desc;
     apples_params params{};
@@ -154,8 +163,21 @@ struct SelectArgs {
     int height;
     int32_t *obs_node; double *obs_dist; int64_t obs_cap; int32_t *cnt_gt; int32_t *n_obs;
     apples_placement *out;    // [nq]
+    // fused fast path (k_jc69 MODE 1 -> k_select_fast)
+    const int32_t *seg_slot, *seg_cnt;  // [nq][stride], [nq][stride/64]
+    const int32_t *node_level;          // tree level by node id
+    int32_t *slow_list, *slow_count;    // queries that need the top-up rule
+    int big_threshold;                  // n_obs above this -> straight to the big-team sweep list
+    int32_t *overflow_list, *overflow_count;
+    // listed mode of k_select: block r handles query qlist[r] with distances in row r
+    const int32_t *qlist, *qcount;
 };
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
+int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
+int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
+                        int32_t *seg_slot, int32_t *seg_cnt);
+int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
+                         const int32_t *qcount, double *d_dist);
 // sweep.hip
 struct SweepArgs {
     DevTree tree;
@@ -164,10 +186,11 @@ struct SweepArgs {
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
     int64_t cap;              // nodes of order/S/R/xe scratch per team
+    int big_threshold;        // small teams skip queries with more observed leaves (already listed for big teams)
     const int32_t *work_list; // queries to process (nullptr = 0..nq-1)
     const int32_t *work_count;// device count of work_list entries (nullptr = nq)
     int32_t *overflow_list;   // queries whose subtree exceeded `cap`
     int32_t *overflow_count;
     apples_placement *out;
 };
-int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team);
+int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team, hipStream_t stream = nullptr);

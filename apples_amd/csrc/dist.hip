@@ -21,16 +21,32 @@ __device__ __forceinline__ double jc69_from_counts(uint32_t mism, uint32_t valid
     return -0.75 * log(loc);
 }
 
-template <int P, int TQ>
+// MODE 0: full rows  -> dist[q][slot] (and counts) for queries q0..q0+nq-1 of the block
+// MODE 1: fused      -> only entries with 0 <= d <= thr are kept: every wavefront (64 consecutive
+//                       slots = one segment) writes them, in slot order, at the start of its segment
+//                       of seg_slot/seg_d and their number to seg_cnt[q][segment]
+// MODE 2: listed     -> full rows for the queries named by qlist[0..*qcount) (top-up path); row r of
+//                       dist belongs to qlist[r]
+template <int P, int TQ, int MODE>
 __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ refp, const uint4 *__restrict__ qp,
                                                      double *__restrict__ dist, uint32_t *__restrict__ counts,
                                                      int64_t n_slots, int64_t slots_pad, int G, int64_t nq, int L,
-                                                     double overlap, const double *__restrict__ lut) {
+                                                     double overlap, const double *__restrict__ lut, double thr,
+                                                     int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
+                                                     const int32_t *__restrict__ qlist,
+                                                     const int32_t *__restrict__ qcount) {
     const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
     const int64_t q0 = (int64_t)blockIdx.y * TQ;
+    if (MODE == 2) {
+        nq = *qcount;
+        if (q0 >= nq) return;
+    }
     uint32_t nv[TQ], nm[TQ];
 #pragma unroll
     for (int t = 0; t < TQ; ++t) nv[t] = nm[t] = 0;
+    int64_t qi[TQ];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) qi[t] = (MODE == 2) ? (int64_t)qlist[(q0 + t < nq) ? q0 + t : q0] : q0 + t;
     for (int g = 0; g < G; ++g) {
         const uint4 *rp = refp + ((int64_t)g * (P + 1)) * slots_pad + slot;
         uint4 rm = rp[0];
@@ -39,7 +55,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
         for (int p = 0; p < P; ++p) rc[p] = rp[(int64_t)(1 + p) * slots_pad];
 #pragma unroll
         for (int t = 0; t < TQ; ++t) {
-            const uint4 *qq = qp + ((q0 + t) * G + g) * (P + 1);  // wave-uniform address
+            const uint4 *qq = qp + (qi[t] * G + g) * (P + 1);  // wave-uniform address
             uint4 qm = qq[0];
             uint4 x = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -52,6 +68,27 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
             nm[t] += __popc(x.x & m0) + __popc(x.y & m1) + __popc(x.z & m2) + __popc(x.w & m3);
         }
     }
+    if (MODE == 1) {
+        const int lane = threadIdx.x & 63;
+        const int64_t seg = slot >> 6;
+        const int64_t n_seg = slots_pad >> 6;
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            if (q0 + t < nq) {  // wave-uniform
+                double d = -1.0;
+                if (slot < n_slots) d = jc69_from_counts(nm[t], nv[t], L, overlap, lut);
+                const bool keep = d >= 0 && d <= thr;
+                const unsigned long long m = __ballot(keep);
+                if (keep) {
+                    const int64_t o = (q0 + t) * slots_pad + seg * 64 + __popcll(m & ((1ull << lane) - 1ull));
+                    seg_slot[o] = (int32_t)slot;
+                    dist[o] = d;
+                }
+                if (lane == 0) seg_cnt[(q0 + t) * n_seg + seg] = __popcll(m);
+            }
+        }
+        return;
+    }
     if (slot >= n_slots) return;
 #pragma unroll
     for (int t = 0; t < TQ; ++t) {
@@ -63,17 +100,18 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
     }
 }
 
-template <int P>
+template <int P, int MODE>
 static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
-                             uint32_t *d_counts) {
+                             uint32_t *d_counts, int32_t *seg_slot, int32_t *seg_cnt, const int32_t *qlist,
+                             const int32_t *qcount) {
     const DevAlign &a = ctx->aln;
     const uint4 *qp = qb.packed + q0 * a.G * (P + 1);
     const double *lut = ctx->jc_lut;
     dim3 block(APPLES_TPB);
-#define LAUNCH(TQ)                                                                                                  \
-    hipLaunchKernelGGL((k_jc69<P, TQ>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)), \
-                       block, 0, ctx->stream, a.packed, qp, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,  \
-                       ctx->params.overlap_frac, lut)
+#define LAUNCH(TQ)                                                                                                   \
+    hipLaunchKernelGGL((k_jc69<P, TQ, MODE>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)), \
+                       block, 0, ctx->stream, a.packed, qp, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,   \
+                       ctx->params.overlap_frac, lut, ctx->params.filt_threshold, seg_slot, seg_cnt, qlist, qcount)
     if (tile >= 32) LAUNCH(32);
     else if (tile >= 16) LAUNCH(16);
     else if (tile >= 8) LAUNCH(8);
@@ -85,8 +123,29 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
 int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
                   uint32_t *d_counts) {
     if (nq == 0) return 0;
-    if (ctx->aln.planes == 2) launch_jc69_tile<2>(ctx, qb, q0, nq, tile, d_dist, d_counts);
-    else launch_jc69_tile<8>(ctx, qb, q0, nq, tile, d_dist, d_counts);
+    if (ctx->aln.planes == 2) launch_jc69_tile<2, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
+    else launch_jc69_tile<8, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// fused threshold compaction (MODE 1): see k_select_fast for the consumer
+int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
+                        int32_t *seg_slot, int32_t *seg_cnt) {
+    if (nq == 0) return 0;
+    if (ctx->aln.planes == 2) launch_jc69_tile<2, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
+    else launch_jc69_tile<8, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// full rows for a device-side list of queries of the block starting at q0 (MODE 2); the grid covers
+// nq_max list entries and tiles beyond *qcount exit at once
+int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
+                         const int32_t *qcount, double *d_dist) {
+    if (nq_max == 0) return 0;
+    if (ctx->aln.planes == 2) launch_jc69_tile<2, 2>(ctx, qb, q0, nq_max, 32, d_dist, nullptr, nullptr, nullptr, qlist, qcount);
+    else launch_jc69_tile<8, 2>(ctx, qb, q0, nq_max, 32, d_dist, nullptr, nullptr, nullptr, qlist, qcount);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -83,9 +83,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
     __shared__ double sh_d[8];
-    const int64_t q = blockIdx.x;
+    // listed mode (top-up path): block r handles query qlist[r], whose distances are row r
+    if (a.qcount && (int64_t)blockIdx.x >= *a.qcount) return;
+    const int64_t q = a.qlist ? a.qlist[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
-    const double *row = a.dist + q * a.stride;
+    const double *row = a.dist + (int64_t)blockIdx.x * a.stride;
     const int32_t *gather = a.gather;
     const int64_t nm = a.n_members;
     const int self = a.self_slot ? a.self_slot[q] : -1;
@@ -115,35 +117,64 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     int obs = block_sum(cnt, sh_i);
 
     // ---- top-up: smallest (d, i) beyond the threshold until baseobs observations -------------------
+    // Each thread first caches the KL smallest candidates of its own strided slice (one pass over
+    // the row); every round then takes the block-wide minimum of the cache heads.  A thread whose
+    // cache runs dry while its slice holds more candidates refills it with another pass over its
+    // slice only.
     double cut_d = -INF_D;
     int cut_i = -1;
-    while (obs < a.baseobs) {
-        double bd = INF_D;
-        int bi = 0x7fffffff, bj = 0;
-        if (single) {
-            for (int64_t s = tid; s < nm; s += APPLES_TPB) {
-                if (table && a.slot_node[s] < 0) continue;
-                double d = DIST(s);
-                if (d >= 0 && d > thr) {
-                    int i = SLOT_KEYIDX(s);
-                    if (key_lt(cut_d, cut_i, d, i) && key_lt(d, i, bd, bi)) { bd = d; bi = i; }
+    if (obs < a.baseobs) {
+        constexpr int KL = 4;
+        double cd[KL];
+        int ci[KL];
+        int head = 0, filled = 0;
+        bool more = true;  // the slice may hold candidates beyond the cached ones
+        const int64_t n_items = single ? nm : a.n_reps;
+        auto refill = [&](double lo_d, int lo_i) {
+            filled = 0;
+            head = 0;
+            int seen = 0;
+            for (int64_t s = tid; s < n_items; s += APPLES_TPB) {
+                double d;
+                int i;
+                if (single) {
+                    if (table && a.slot_node[s] < 0) continue;
+                    d = DIST(s);
+                    i = SLOT_KEYIDX(s);
+                } else {
+                    d = DIST(a.rep_slot[s]);
+                    i = (int)s;
+                }
+                if (!(d >= 0 && d > thr) || !key_lt(lo_d, lo_i, d, i)) continue;
+                ++seen;
+                // insertion into the sorted cache (ascending)
+                int pos = filled < KL ? filled : KL;
+                while (pos > 0 && key_lt(d, i, cd[pos - 1], ci[pos - 1])) --pos;
+                if (pos < KL) {
+                    for (int k = (filled < KL ? filled : KL - 1); k > pos; --k) { cd[k] = cd[k - 1]; ci[k] = ci[k - 1]; }
+                    cd[pos] = d; ci[pos] = i;
+                    if (filled < KL) ++filled;
                 }
             }
-        } else {
-            for (int64_t j = tid; j < a.n_reps; j += APPLES_TPB) {
-                double d = DIST(a.rep_slot[j]);
-                if (d >= 0 && d > thr && key_lt(cut_d, cut_i, d, (int)j) && key_lt(d, (int)j, bd, bi)) { bd = d; bi = (int)j; }
+            more = seen > filled;
+        };
+        refill(cut_d, cut_i);
+        while (obs < a.baseobs) {
+            if (head == filled && more) refill(cut_d, cut_i);
+            double bd = head < filled ? cd[head] : INF_D;
+            int bi = head < filled ? ci[head] : 0x7fffffff, bj = 0;
+            const int mine = bi;
+            block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
+            if (bi == 0x7fffffff) break;  // nothing left
+            if (mine == bi && head < filled) ++head;
+            cut_d = bd;
+            cut_i = bi;
+            if (single) obs += 1;
+            else {
+                int c = 0;
+                for (int m = a.rep_moff[bi] + tid; m < a.rep_moff[bi + 1]; m += APPLES_TPB) c += !(DIST(a.mem_slot[m]) < 0);
+                obs += block_sum(c, sh_i);
             }
-        }
-        block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
-        if (bi == 0x7fffffff) break;  // nothing left
-        cut_d = bd;
-        cut_i = bi;
-        if (single) obs += 1;
-        else {
-            int c = 0;
-            for (int m = a.rep_moff[bi] + tid; m < a.rep_moff[bi + 1]; m += APPLES_TPB) c += !(DIST(a.mem_slot[m]) < 0);
-            obs += block_sum(c, sh_i);
         }
     }
 
@@ -223,9 +254,148 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
         }
         a.out[q] = p;
         a.n_obs[q] = n_emit;  // 0 = nothing for the sweep to do
+        if (n_emit > a.big_threshold && a.overflow_list) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
     }
 #undef DIST
 #undef SLOT_KEYIDX
+}
+
+// exclusive prefix sum of an int across the block; returns this thread's offset, total in *tot
+__device__ int block_excl_scan_int(int v, int *sh /*[4+]*/, int *tot) {
+    int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    int incl = v;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        int t = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == WAVE - 1) sh[w] = incl;
+    __syncthreads();
+    int base = 0, t = 0;
+    for (int k = 0; k < APPLES_TPB / WAVE; ++k) {
+        if (k < w) base += sh[k];
+        t += sh[k];
+    }
+    *tot = t;
+    return base + incl - v;
+}
+
+// Fast selection for all-singleton alignment input: consumes the segments the fused distance
+// kernel wrote (k_jc69 MODE 1: per 64-slot segment, the entries with 0 <= d <= thr in slot order).
+// If they number fewer than `baseobs` the query needs the top-up rule of Reference.py:144 and is
+// pushed to the slow list (full rows + k_select).  Otherwise the observed dict is exactly those
+// entries: drop the query's own row, find the first zero (smallest representative index, since all
+// zero keys tie on d = 0), count, and compact the tree leaves in slot order (= level order).
+__global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
+    __shared__ int sh_i[8];
+    __shared__ int sh_j[8];
+    __shared__ double sh_d[8];
+    __shared__ int sh_pref[APPLES_TPB + 1];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t n_seg = a.stride >> 6;
+    const int32_t *cnt = a.seg_cnt + q * n_seg;
+    const int32_t *sslot = a.seg_slot + q * a.stride;
+    const double *sd = a.dist + q * a.stride;
+    const int self = a.self_slot ? a.self_slot[q] : -1;
+    int c = 0;
+    for (int64_t s = tid; s < n_seg; s += APPLES_TPB) c += cnt[s];
+    const int total = block_sum(c, sh_i);
+    if (total < a.baseobs) {
+        if (tid == 0) {
+            a.slow_list[atomicAdd(a.slow_count, 1)] = (int32_t)q;
+            a.n_obs[q] = 0;
+        }
+        return;
+    }
+    int32_t *o_node = a.obs_node + q * a.obs_cap;
+    double *o_dist = a.obs_dist + q * a.obs_cap;
+    int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
+    int base = 0, n_total = 0;
+    int z_i = 0x7fffffff, z_node = -2;
+    for (int64_t s0 = 0; s0 < n_seg; s0 += APPLES_TPB) {
+        const int64_t s = s0 + tid;
+        const int my = s < n_seg ? cnt[s] : 0;
+        int chunk_total;
+        const int pre = block_excl_scan_int(my, sh_i, &chunk_total);
+        sh_pref[tid] = pre;
+        if (tid == 0) sh_pref[APPLES_TPB] = chunk_total;
+        __syncthreads();
+        // flat loop over this chunk's entries, in order
+        for (int e0 = 0; e0 < chunk_total; e0 += APPLES_TPB) {
+            const int e = e0 + tid;
+            int emit = 0, node = -1;
+            double d = 0;
+            if (e < chunk_total) {
+                int lo = 0, hi = APPLES_TPB;  // last segment whose prefix <= e
+                while (hi - lo > 1) {
+                    int mid = (lo + hi) >> 1;
+                    if (sh_pref[mid] <= e) lo = mid; else hi = mid;
+                }
+                const int64_t src = (s0 + lo) * 64 + (e - sh_pref[lo]);
+                const int slot = sslot[src];
+                d = sd[src];
+                if (slot != self) {
+                    ++n_total;
+                    node = a.slot_node[slot];
+                    if (d == 0) {
+                        const int ri = a.slot_rep[slot];
+                        if (ri < z_i) { z_i = ri; z_node = node; }
+                    }
+                    emit = node >= 0;
+                }
+            }
+            int tot;
+            const int pos = base + block_excl_scan(emit, sh_j, &tot);
+            if (emit) { o_node[pos] = node; o_dist[pos] = d; }
+            base += tot;
+        }
+        __syncthreads();
+    }
+    n_total = block_sum(n_total, sh_i);
+    double zd = 0; int zi = z_i, zp = 0;
+    block_argmin3(zd, zi, zp, sh_d, sh_i, sh_j);
+    __shared__ int sh_znode;
+    if (tid == 0) sh_znode = -2;
+    __syncthreads();
+    if (z_i == zi && zi != 0x7fffffff) sh_znode = z_node;
+    __syncthreads();
+    const int n_emit = base;
+    // per-level offsets into the level-sorted list (the sweep's cnt_gt)
+    for (int i = tid; i <= n_emit; i += APPLES_TPB) {
+        const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
+        const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
+        for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
+    }
+    if (tid == 0) {
+        apples_placement p;
+        p.edge = 0; p.flags = 0; p.error = 0.0; p.distal = 0.0; p.pendant = 0.0; p.n_obs = n_total; p.n_valid = 0;
+        int ne = n_emit;
+        if (zi != 0x7fffffff) {
+            p.flags = APPLES_F_EXACT | APPLES_F_PENDANT_INT;
+            p.edge = sh_znode;
+            if (sh_znode < 0) { p.flags |= APPLES_F_ZERO_NOT_IN_TREE; p.edge = -1; }
+            ne = 0;
+        } else if (n_total <= 2) {
+            p.flags = APPLES_F_INSUFFICIENT | APPLES_F_PENDANT_INT;
+            p.edge = -1;
+            ne = 0;
+        } else if (ne < 2) {
+            p.flags = APPLES_F_DEGENERATE | APPLES_F_PENDANT_INT;
+            p.edge = -1;
+            ne = 0;
+        }
+        a.out[q] = p;
+        a.n_obs[q] = ne;
+        if (ne > a.big_threshold && a.overflow_list) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
+    }
+}
+
+int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(k_select_fast, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
 }
 
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {

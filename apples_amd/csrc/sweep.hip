@@ -239,6 +239,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
         const int64_t q = a.work_list ? a.work_list[w] : w;
         const int n = a.n_obs[q];
         if (n == 0) continue;
+        if (TEAM == WAVE && !a.work_list && n > a.big_threshold) continue;  // listed for a workgroup-sized team
         const int32_t *o_node = a.obs_node + q * a.obs_cap;
         const double *o_dist = a.obs_dist + q * a.obs_cap;
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
@@ -526,23 +527,24 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
 }
 
 template <int TEAM>
-static void launch_sweep_team(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs) {
+static void launch_sweep_team(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st) {
     dim3 grid((unsigned)wgs), block(APPLES_TPB);
     switch (a.method) {
-        case APPLES_FM: hipLaunchKernelGGL((k_sweep<APPLES_FM, TEAM>), grid, block, 0, ctx->stream, a, nq); break;
-        case APPLES_BME: hipLaunchKernelGGL((k_sweep<APPLES_BME, TEAM>), grid, block, 0, ctx->stream, a, nq); break;
-        case APPLES_BE: hipLaunchKernelGGL((k_sweep<APPLES_BE, TEAM>), grid, block, 0, ctx->stream, a, nq); break;
-        default: hipLaunchKernelGGL((k_sweep<APPLES_OLS, TEAM>), grid, block, 0, ctx->stream, a, nq); break;
+        case APPLES_FM: hipLaunchKernelGGL((k_sweep<APPLES_FM, TEAM>), grid, block, 0, st, a, nq); break;
+        case APPLES_BME: hipLaunchKernelGGL((k_sweep<APPLES_BME, TEAM>), grid, block, 0, st, a, nq); break;
+        case APPLES_BE: hipLaunchKernelGGL((k_sweep<APPLES_BE, TEAM>), grid, block, 0, st, a, nq); break;
+        default: hipLaunchKernelGGL((k_sweep<APPLES_OLS, TEAM>), grid, block, 0, st, a, nq); break;
     }
 }
 
-int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team) {
+int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team, hipStream_t stream) {
     if (nq == 0) return 0;
+    hipStream_t st = stream ? stream : ctx->stream;
     if (team == 64) {
         int64_t need = (nq + 3) / 4;
-        launch_sweep_team<64>(ctx, a, nq, (int)(need < wgs ? need : wgs));
+        launch_sweep_team<64>(ctx, a, nq, (int)(need < wgs ? need : wgs), st);
     } else {
-        launch_sweep_team<256>(ctx, a, nq, (int)(nq < wgs ? nq : wgs));
+        launch_sweep_team<256>(ctx, a, nq, (int)(nq < wgs ? nq : wgs), st);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

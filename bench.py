@@ -57,7 +57,9 @@ def cpu_baseline(ds, protein, method, threshold, target_cpu_seconds=20.0):
 
 
 def load_traffic(workload, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes."""
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+    (profiles/pmc_summary.json, written by scripts/pmc_to_traffic.py from separate --pmc runs of
+    this same command; FETCH_SIZE/WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)."""
     path = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
     try:
         with open(path) as f:
