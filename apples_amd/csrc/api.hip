@@ -217,6 +217,12 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
     return 0;
 }
 
+// observed-leaf count above which a query goes straight to a workgroup-sized sweep team
+int big_threshold() {
+    static const int v = getenv("APPLES_BIG_THRESHOLD") ? atoi(getenv("APPLES_BIG_THRESHOLD")) : 4096;
+    return v;
+}
+
 void free_sweep(Workspace::Sweep &sw) {
     dev_free(sw.map); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
     sw = Workspace::Sweep();
@@ -231,18 +237,19 @@ void free_workspace(Workspace &w) {
     w = Workspace();
 }
 
-int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg, int64_t cap, bool xe) {
+int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg, int64_t cap, int64_t leaf_cap, bool xe) {
     const DevTree &t = ctx->tree;
     sw.wgs = wgs;
     sw.teams = (int64_t)wgs * teams_per_wg;
     sw.cap = cap;
+    sw.leaf_cap = leaf_cap;
     if (dev_alloc(ctx, &sw.map, sw.teams * t.n_nodes)) return 1;
     HIP_TRY(ctx, hipMemsetAsync(sw.map, 0, (size_t)sw.teams * t.n_nodes * 4, ctx->stream));
     if (dev_alloc(ctx, &sw.grp_off, sw.teams * (int64_t)(t.height + 4))) return 1;
     HIP_TRY(ctx, hipMalloc(&sw.A, (size_t)sw.teams * (cap + 1) * 64));
     HIP_TRY(ctx, hipMalloc(&sw.B, (size_t)sw.teams * (cap + 1) * 64));
     if (xe)
-        if (dev_alloc(ctx, &sw.xe, sw.teams * cap * 5)) return 1;
+        if (dev_alloc(ctx, &sw.xe, sw.teams * (cap + leaf_cap) * 11)) return 1;
     return 0;
 }
 
@@ -297,15 +304,15 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
-    int64_t per_node = 64 + 64 + (xe ? 40 : 0);
+    int64_t per_node = 64 + 64 + (xe ? 2 * 88 : 0);
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
-    if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, xe)) return 1;
+    if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold())), xe)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
     int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 4;
     int64_t big_max = getenv("APPLES_SWEEP_BIG_WGS") ? atoi(getenv("APPLES_SWEEP_BIG_WGS")) : 512;
     int wgs_big = (int)std::min<int64_t>(big_max, std::max<int64_t>(4, ((int64_t)24 << 30) / std::max<int64_t>(per_wg, 1)));
     wgs_big = (int)std::min<int64_t>(wgs_big, batch);
-    if (alloc_sweep(ctx, w.big, wgs_big, 1, nn, xe)) return 1;
+    if (alloc_sweep(ctx, w.big, wgs_big, 1, nn, members, xe)) return 1;
     return 0;
 }
 
@@ -381,12 +388,6 @@ struct PhaseTimer {
     }
 };
 
-// observed-leaf count above which a query goes straight to a workgroup-sized sweep team
-int big_threshold() {
-    static const int v = getenv("APPLES_BIG_THRESHOLD") ? atoi(getenv("APPLES_BIG_THRESHOLD")) : 4096;
-    return v;
-}
-
 SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t q0) {
     const DevAlign &a = ctx->aln;
     Workspace &w = ctx->ws;
@@ -412,6 +413,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.map = sw.map; s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
     s.cap = sw.cap;
+    s.leaf_cap = sw.leaf_cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
     s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
     s.work_list = nullptr; s.work_count = nullptr; s.big_threshold = big_threshold();
@@ -447,7 +449,13 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq) {
     return 0;
 }
 
-int dist_tile_for(int64_t nq) { return nq >= 32 ? 32 : (nq >= 16 ? 16 : (nq >= 8 ? 8 : (nq >= 4 ? 4 : 1))); }
+int dist_tile_for(int64_t nq) {
+    static const int forced = getenv("APPLES_DIST_TILE") ? atoi(getenv("APPLES_DIST_TILE")) : 0;  // tuning knob
+    if (forced > 0) return forced;
+    // 16 queries per reference pass: 32 accumulators + 12 reference words stay within 96 VGPRs
+    // (5 waves/SIMD); 32 queries per pass spill the epilogue to 150 VGPRs and run slower
+    return nq >= 16 ? 16 : (nq >= 8 ? 8 : (nq >= 4 ? 4 : 1));
+}
 
 int run_block(apples_ctx *ctx, QueryBlock &qb) {
     const DevAlign &a = ctx->aln;
@@ -568,11 +576,29 @@ int apples_set_params(apples_ctx *ctx, const apples_params *params) {
         ctx->jc_lut = nullptr;
         if (dev_upload(ctx, &ctx->jc_lut, params->jc_lut, params->jc_lut_len)) return 1;
         ctx->jc_lut_len = params->jc_lut_len;
+        dev_free(ctx->jc_mmax);
+        ctx->jc_mmax = nullptr;
+        if (ctx->has_aln) {  // integer form of 0 <= d <= threshold, valid only if the table is monotone in mism
+            std::vector<int32_t> mmax(L + 1, -1);
+            bool monotone = true;
+            for (int64_t v = 0; v <= L; ++v) {
+                const double *row = params->jc_lut + v * (v + 1) / 2;
+                int last = -1;
+                for (int64_t m = 0; m <= v; ++m)
+                    if (row[m] >= 0 && row[m] <= params->filt_threshold) last = (int)m;
+                for (int64_t m = 0; m <= last; ++m)
+                    if (!(row[m] >= 0 && row[m] <= params->filt_threshold)) monotone = false;
+                mmax[v] = last;
+            }
+            if (monotone && dev_upload(ctx, &ctx->jc_mmax, mmax.data(), L + 1)) return 1;
+        }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     } else {
         dev_free(ctx->jc_lut);
         ctx->jc_lut = nullptr;
         ctx->jc_lut_len = 0;
+        dev_free(ctx->jc_mmax);
+        ctx->jc_mmax = nullptr;
     }
     return 0;
 }
@@ -588,7 +614,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevAlign &a = ctx->aln;
     dev_free(a.raw); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
-    dev_free(ctx->jc_lut); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
+    dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);
     for (int i = 0; i < 8; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -840,19 +866,40 @@ int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *o
     dev_free(d_out);
     if (out) *out = res;
     int V = res.n_valid;
-    std::vector<int32_t> order(V);
-    std::vector<double> hS((size_t)V * 6), hR((size_t)V * 6), hx((size_t)V * 5), ha((size_t)V * 8), hb((size_t)V * 8);
-    HIP_TRY(ctx, hipMemcpy(ha.data(), w.big.A, ha.size() * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(hb.data(), w.big.B, hb.size() * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(hx.data(), w.big.xe, hx.size() * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < V; ++i) {
-        memcpy(&hS[(size_t)i * 6], &ha[(size_t)i * 8], 48);
-        memcpy(&hR[(size_t)i * 6], &hb[(size_t)i * 8], 48);
-        int32_t nd;
-        memcpy(&nd, reinterpret_cast<const char *>(&ha[(size_t)i * 8]) + 56, 4);
-        order[i] = nd;
-    }
+    int32_t VI = 0;
+    HIP_TRY(ctx, hipMemcpy(&VI, w.big.grp_off + t.height + 2, 4, hipMemcpyDeviceToHost));
     if (lca) HIP_TRY(ctx, hipMemcpy(lca, w.big.grp_off + t.height + 3, 4, hipMemcpyDeviceToHost));
+    // internal nodes: compact records; observed leaves: rebuilt from the level-sorted list
+    std::vector<int32_t> order(V);
+    std::vector<double> hS((size_t)V * 6), hR((size_t)V * 6), hx((size_t)V * 5), ha((size_t)std::max(VI, 1) * 8);
+    std::vector<double> hxi((size_t)std::max(VI, 1) * 11), hxl((size_t)n_obs * 11);
+    HIP_TRY(ctx, hipMemcpy(ha.data(), w.big.A, (size_t)VI * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hxi.data(), w.big.xe, (size_t)VI * 88, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hxl.data(), w.big.xe + (size_t)w.big.cap * 11, (size_t)n_obs * 88, hipMemcpyDeviceToHost));
+    std::vector<int32_t> level_h;
+    for (int i = 0; i < V; ++i) {
+        const double *xr;
+        if (i < VI) {
+            memcpy(&hS[(size_t)i * 6], &ha[(size_t)i * 8], 48);
+            int32_t nd;
+            memcpy(&nd, reinterpret_cast<const char *>(&ha[(size_t)i * 8]) + 56, 4);
+            order[i] = nd;
+            xr = &hxi[(size_t)i * 11];
+        } else {
+            int j = i - VI;
+            order[i] = s_node[j];
+            double D = s_dist[j];
+            double *S6 = &hS[(size_t)i * 6];
+            S6[0] = 1; S6[1] = 0; S6[2] = 0; S6[3] = 0;
+            int m = ctx->params.method;
+            if (m == APPLES_FM) { S6[4] = 1.0 / D; S6[5] = 1.0 / (D * D); }
+            else if (m == APPLES_BE) { S6[4] = D; S6[5] = 1.0 / D; }
+            else { S6[4] = D * D; S6[5] = D; }
+            xr = &hxl[(size_t)j * 11];
+        }
+        memcpy(&hx[(size_t)i * 5], xr, 40);
+        memcpy(&hR[(size_t)i * 6], xr + 5, 48);
+    }
     if (valid) memset(valid, 0, t.n_nodes);
     for (int i = 0; i < V; ++i) {
         int v = order[i];

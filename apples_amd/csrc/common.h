@@ -58,7 +58,7 @@ struct DevAlign {
 struct QueryBlock {
     int64_t n = 0, n_pad = 0;
     uint8_t *raw = nullptr;       // [n*L]
-    uint4 *packed = nullptr;      // [n_pad][G][planes+1] uint4
+    uint4 *packed = nullptr;      // [n_pad/16][G][16][planes+1] uint4
     uint8_t *aa_idx = nullptr;    // [n_pad][Lpad16]
     int32_t *self_slot = nullptr; // [n]
     apples_placement *out = nullptr;  // [n] device
@@ -80,7 +80,7 @@ struct Workspace {
     // workgroup per query, for subtrees beyond cap): n_nodes each.
     struct Sweep {
         int32_t wgs = 0;          // workgroups of the launch
-        int64_t teams = 0, cap = 0;
+        int64_t teams = 0, cap = 0, leaf_cap = 0;
         int32_t *map = nullptr;   // [teams][n_nodes] node -> compact index + 1 (0 = not in subtree)
         int32_t *grp_off = nullptr; // [teams][height+4] level groups in compact order, deepest first
         void *A = nullptr;        // [teams][cap+1] ARec (64 B): S tuple, edge length, node, leaf flag
@@ -111,6 +111,7 @@ struct apples_ctx {
     bool has_aln = false;
     double *jc_lut = nullptr;
     int64_t jc_lut_len = 0;
+    int32_t *jc_mmax = nullptr;  // [L+1] largest mismatch count with 0 <= lut <= threshold, per valid count
     double *blosum = nullptr;  // 21x21 table (row/col 20 = gap -> 0)
     Workspace ws;
     std::vector<QueryBlock> blocks;
@@ -185,7 +186,8 @@ struct SweepArgs {
     int32_t *map, *grp_off; void *A, *B; double *xe;
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
-    int64_t cap;              // nodes of order/S/R/xe scratch per team
+    int64_t cap;              // internal nodes of A/B/xe scratch per team
+    int64_t leaf_cap;         // observed leaves a team's xe area can hold beyond `cap`
     int big_threshold;        // small teams skip queries with more observed leaves (already listed for big teams)
     const int32_t *work_list; // queries to process (nullptr = 0..nq-1)
     const int32_t *work_count;// device count of work_list entries (nullptr = nq)

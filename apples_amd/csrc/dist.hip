@@ -7,6 +7,8 @@
 // workgroup owns 256 rows x TQ queries; the query words are wave-uniform, so they come through
 // the scalar cache and occupy SGPRs, not LDS.  HBM traffic per launch is the packed reference
 // once per query tile plus 8 B per pair of output.  No MFMA: this is popcount, not a contraction.
+#include <cstdlib>
+
 #include "common.h"
 
 __device__ __forceinline__ double jc69_from_counts(uint32_t mism, uint32_t valid, int L, double overlap,
@@ -21,20 +23,29 @@ __device__ __forceinline__ double jc69_from_counts(uint32_t mism, uint32_t valid
     return -0.75 * log(loc);
 }
 
+// popcount with the instruction's own accumulate operand (D = popc(S0) + S1); hipcc otherwise emits
+// v_bcnt ..., 0 followed by separate adds
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 // MODE 0: full rows  -> dist[q][slot] (and counts) for queries q0..q0+nq-1 of the block
 // MODE 1: fused      -> only entries with 0 <= d <= thr are kept: every wavefront (64 consecutive
 //                       slots = one segment) writes them, in slot order, at the start of its segment
 //                       of seg_slot/seg_d and their number to seg_cnt[q][segment]
 // MODE 2: listed     -> full rows for the queries named by qlist[0..*qcount) (top-up path); row r of
 //                       dist belongs to qlist[r]
-template <int P, int TQ, int MODE>
+template <int P, int TQ, int MODE, bool ASM>
 __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ refp, const uint4 *__restrict__ qp,
                                                      double *__restrict__ dist, uint32_t *__restrict__ counts,
                                                      int64_t n_slots, int64_t slots_pad, int G, int64_t nq, int L,
                                                      double overlap, const double *__restrict__ lut, double thr,
                                                      int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
                                                      const int32_t *__restrict__ qlist,
-                                                     const int32_t *__restrict__ qcount) {
+                                                     const int32_t *__restrict__ qcount,
+                                                     const int32_t *__restrict__ mmax) {
     const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
     const int64_t q0 = (int64_t)blockIdx.y * TQ;
     if (MODE == 2) {
@@ -53,31 +64,72 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
         uint4 rc[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) rc[p] = rp[(int64_t)(1 + p) * slots_pad];
+        // query words are wave-uniform (scalar loads).  Software pipeline: the words of the next
+        // CH queries are requested before the current CH are consumed, so the scalar-cache latency
+        // hides behind ~50 VALU instructions instead of stalling every query.
+        constexpr int CH = (TQ >= 2) ? 2 : 1;
+        uint4 cur[CH][P + 1], nxt[CH][P + 1];
 #pragma unroll
-        for (int t = 0; t < TQ; ++t) {
-            const uint4 *qq = qp + (qi[t] * G + g) * (P + 1);  // wave-uniform address
-            uint4 qm = qq[0];
-            uint4 x = make_uint4(0, 0, 0, 0);
+        for (int c = 0; c < CH; ++c) {
+            const uint4 *qq = qp + (((qi[c] >> 4) * G + g) * 16 + (qi[c] & 15)) * (P + 1);
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                uint4 qc = qq[1 + p];
-                x.x |= qc.x ^ rc[p].x; x.y |= qc.y ^ rc[p].y; x.z |= qc.z ^ rc[p].z; x.w |= qc.w ^ rc[p].w;
+            for (int p = 0; p <= P; ++p) cur[c][p] = qq[p];
+        }
+#pragma unroll
+        for (int t0 = 0; t0 < TQ; t0 += CH) {
+            if (t0 + CH < TQ) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int64_t qn = qi[(t0 + CH + c) < TQ ? (t0 + CH + c) : 0];
+                    const uint4 *qq = qp + (((qn >> 4) * G + g) * 16 + (qn & 15)) * (P + 1);
+#pragma unroll
+                    for (int p = 0; p <= P; ++p) nxt[c][p] = qq[p];
+                }
             }
-            uint32_t m0 = qm.x & rm.x, m1 = qm.y & rm.y, m2 = qm.z & rm.z, m3 = qm.w & rm.w;
-            nv[t] += __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
-            nm[t] += __popc(x.x & m0) + __popc(x.y & m1) + __popc(x.z & m2) + __popc(x.w & m3);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int t = t0 + c;
+                uint4 qm = cur[c][0];
+                uint4 x = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    uint4 qc = cur[c][1 + p];
+                    x.x |= qc.x ^ rc[p].x; x.y |= qc.y ^ rc[p].y; x.z |= qc.z ^ rc[p].z; x.w |= qc.w ^ rc[p].w;
+                }
+                uint32_t m0 = qm.x & rm.x, m1 = qm.y & rm.y, m2 = qm.z & rm.z, m3 = qm.w & rm.w;
+                if (ASM) {
+                    nv[t] = bcnt_acc(m3, bcnt_acc(m2, bcnt_acc(m1, bcnt_acc(m0, nv[t]))));
+                    nm[t] = bcnt_acc(x.w & m3, bcnt_acc(x.z & m2, bcnt_acc(x.y & m1, bcnt_acc(x.x & m0, nm[t]))));
+                } else {
+                    nv[t] += __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+                    nm[t] += __popc(x.x & m0) + __popc(x.y & m1) + __popc(x.z & m2) + __popc(x.w & m3);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int p = 0; p <= P; ++p) cur[c][p] = nxt[c][p];
         }
     }
     if (MODE == 1) {
         const int lane = threadIdx.x & 63;
-        const int64_t seg = slot >> 6;
+        // the segment index is wave-uniform: keep it (and the row offsets built on it) in SGPRs
+        const int64_t seg = __builtin_amdgcn_readfirstlane((int)(slot >> 6));
         const int64_t n_seg = slots_pad >> 6;
 #pragma unroll
         for (int t = 0; t < TQ; ++t) {
             if (q0 + t < nq) {  // wave-uniform
+                // 0 <= d <= thr decided on the integers when the host supplied the table: mmax[valid] is
+                // the largest mismatch count whose tabulated distance passes (d is monotone in mism)
                 double d = -1.0;
-                if (slot < n_slots) d = jc69_from_counts(nm[t], nv[t], L, overlap, lut);
-                const bool keep = d >= 0 && d <= thr;
+                bool keep;
+                if (mmax) {
+                    keep = slot < n_slots && (int)nm[t] <= mmax[nv[t]];
+                    if (keep) d = lut[(int64_t)nv[t] * (nv[t] + 1) / 2 + nm[t]];
+                } else {
+                    if (slot < n_slots) d = jc69_from_counts(nm[t], nv[t], L, overlap, lut);
+                    keep = d >= 0 && d <= thr;
+                }
                 const unsigned long long m = __ballot(keep);
                 if (keep) {
                     const int64_t o = (q0 + t) * slots_pad + seg * 64 + __popcll(m & ((1ull << lane) - 1ull));
@@ -86,6 +138,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
                 }
                 if (lane == 0) seg_cnt[(q0 + t) * n_seg + seg] = __popcll(m);
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the 32 epilogues from being interleaved (VGPR pressure)
         }
         return;
     }
@@ -97,6 +150,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
             if (dist) dist[o] = jc69_from_counts(nm[t], nv[t], L, overlap, lut);
             if (counts) counts[o] = (nm[t] << 16) | nv[t];
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -105,19 +159,25 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
                              uint32_t *d_counts, int32_t *seg_slot, int32_t *seg_cnt, const int32_t *qlist,
                              const int32_t *qcount) {
     const DevAlign &a = ctx->aln;
-    const uint4 *qp = qb.packed + q0 * a.G * (P + 1);
+    const uint4 *qp = qb.packed + q0 * a.G * (P + 1);  // q0 is a multiple of 32: whole 16-query tiles
     const double *lut = ctx->jc_lut;
     dim3 block(APPLES_TPB);
+    static const bool use_asm = getenv("APPLES_NO_BCNT_ASM") == nullptr;  // tuning knob (default: accumulate form)
+    static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
+    const int32_t *mmax = no_mmax ? nullptr : ctx->jc_mmax;
 #define LAUNCH(TQ)                                                                                                   \
-    hipLaunchKernelGGL((k_jc69<P, TQ, MODE>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)), \
+    if (use_asm) LAUNCH2(TQ, true); else LAUNCH2(TQ, false)
+#define LAUNCH2(TQ, A)                                                                                               \
+    hipLaunchKernelGGL((k_jc69<P, TQ, MODE, A>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)), \
                        block, 0, ctx->stream, a.packed, qp, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,   \
-                       ctx->params.overlap_frac, lut, ctx->params.filt_threshold, seg_slot, seg_cnt, qlist, qcount)
+                       ctx->params.overlap_frac, lut, ctx->params.filt_threshold, seg_slot, seg_cnt, qlist, qcount, mmax)
     if (tile >= 32) LAUNCH(32);
     else if (tile >= 16) LAUNCH(16);
     else if (tile >= 8) LAUNCH(8);
     else if (tile >= 4) LAUNCH(4);
     else LAUNCH(1);
 #undef LAUNCH
+#undef LAUNCH2
 }
 
 int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,

@@ -5,7 +5,9 @@
 // path (code = (byte >> 1) & 3: A=0 C=1 T=2 G=3); P = 8 keeps the raw byte, so "any other byte
 // is an ordinary symbol" (distance.py:733 compares bytes) holds for every input.
 //   reference rows : packed[(g*(P+1) + plane) * slots_pad + slot]   (uint4; a wave reads 1 KiB)
-//   query rows     : packed[(q*G + g) * (P+1) + plane]              (uint4; wave-uniform reads)
+//   query rows     : packed[(((q/16)*G + g)*16 + q%16) * (P+1) + plane]   (uint4; wave-uniform reads:
+//                    for one word group the 16 queries of a tile are contiguous, so several
+//                    queries arrive per scalar load)
 #include "common.h"
 
 template <int P>
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_pack_rows(const uint8_t *__restr
     }
     if (bad) atomicOr(exotic, 1);
     if (query_layout) {
-        uint4 *dst = out + (row * G + g) * (P + 1);
+        uint4 *dst = out + (((row >> 4) * G + g) * 16 + (row & 15)) * (P + 1);
         dst[0] = make_uint4(m[0], m[1], m[2], m[3]);
 #pragma unroll
         for (int p = 0; p < P; ++p) dst[1 + p] = make_uint4(c[p][0], c[p][1], c[p][2], c[p][3]);

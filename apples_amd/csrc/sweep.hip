@@ -14,13 +14,15 @@
 // of that level (contiguous in the level-sorted obs list) plus the parents claimed from level
 // l+1; the loop stops when a level holds a single node and no shallower leaves remain.
 //
-// Data layout (the kernel is bound by scattered memory transactions, so everything a visit
-// needs sits in one aligned record): NodeRec (32 B, tree constant: parent, first two children,
-// edge length); per team and per subtree node, in compact order of discovery, ARec (64 B: S
-// tuple, edge length, node id, leaf flag) and BRec (64 B: R tuple, compact indices of the first
-// two valid children).  The top-down pass is parent-centric: a node reads its valid children's
-// ARecs, forms each child's R (siblings in file order, then its own lifted R), solves that
-// child's 2x2 system and residual, and stores R only for children that are internal.
+// Data layout (the kernel is bound by HBM/L2 misses on scattered 64-byte records, so records are
+// few and whole): NodeRec (32 B, tree constant: parent, first two children, edge length); per
+// team and per INTERNAL subtree node, in compact order of discovery, ARec (64 B: S tuple, edge
+// length, node id) and BRec (64 B: R tuple, descriptors of the first two valid children).
+// Observed leaves get no record: a leaf is named by its position j in the query's level-sorted
+// observation list (map[leaf] = -(j+2), child descriptor < 0) and its tuple is rebuilt from the
+// distance whenever a parent needs it.  The top-down pass is parent-centric: a node forms each
+// valid child's R (siblings in file order, then its own lifted R), solves that child's 2x2
+// system and residual, and stores R only for children that are internal.
 //
 // Bit parity: fp64, compiled with -ffp-contract=off; every sum is taken in the order of the
 // cited source line, children/siblings in file order and the parent term last.
@@ -183,35 +185,65 @@ struct __attribute__((aligned(64))) ARec {
     double S[6];
     double e;
     int32_t node;
-    int32_t leaf;
+    int32_t pad;
 };
 struct __attribute__((aligned(64))) BRec {
     double R[6];
-    int32_t k0, k1, nk, pad;
+    int32_t k0, k1, nk, poly;  // child descriptors: > 0 internal (compact index + 1), <= -2 leaf (-(j+2))
 };
 
-// valid children of node v (tree record nr) in file order -> compact indices; returns their number
-// and the first two in k[0], k[1]
+#define XE_STRIDE 11  // x_1, x_2, x_1_neg, x_2_neg, err, R[6]  (HYBRID / inspection only)
+
+// valid children of a node (tree record nr) in file order -> descriptors; returns their number and
+// the first two in k[0], k[1]
 __device__ __forceinline__ int valid_kids2(const NodeRec &nr, const int32_t *__restrict__ map,
                                            const int32_t *__restrict__ child_idx, int *k) {
     int nk = 0;
-    k[0] = k[1] = -1;
+    k[0] = k[1] = 0;
     if (nr.nchild <= 2) {
-        if (nr.nchild >= 1) { int m = map[nr.c0]; if (m > 0) k[nk++] = m - 1; }
-        if (nr.nchild >= 2) { int m = map[nr.c1]; if (m > 0) k[nk++] = m - 1; }
+        if (nr.nchild >= 1) { int m = map[nr.c0]; if (m != 0) k[nk++] = m; }
+        if (nr.nchild >= 2) { int m = map[nr.c1]; if (m != 0) k[nk++] = m; }
     } else {
         for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
             int m = map[child_idx[ci]];
-            if (m > 0) { if (nk < 2) k[nk] = m - 1; ++nk; }
+            if (m != 0) { if (nk < 2) k[nk] = m; ++nk; }
         }
     }
     return nk;
 }
 
+struct Kid {
+    double S[6];
+    double e;
+    int32_t node;
+    int32_t leaf;
+};
+
+// a child's S tuple, edge length and node id from its descriptor
+template <int M>
+__device__ __forceinline__ void load_kid(int kd, const ARec *__restrict__ A, const NodeRec *__restrict__ NR,
+                                         const int32_t *__restrict__ o_node, const double *__restrict__ o_dist,
+                                         Kid &k) {
+    if (kd > 0) {
+        const ARec &r = A[kd - 1];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) k.S[x] = r.S[x];
+        k.e = r.e;
+        k.node = r.node;
+        k.leaf = 0;
+    } else {
+        const int j = -kd - 2;
+        k.node = o_node[j];
+        leaf_tuple<M>(o_dist[j], k.S);
+        k.e = NR[k.node].e;
+        k.leaf = 1;
+    }
+}
+
 // One team = TEAM threads working on one query: a wavefront (TEAM == 64, four independent teams
 // per workgroup; the level loops need no s_barrier) or the whole workgroup (TEAM == 256).  Queries
-// whose subtree does not fit a team's scratch (`cap` nodes) are appended to an overflow list that
-// a second launch with full-size scratch takes.
+// whose subtree does not fit a team's scratch (`cap` internal nodes) are appended to an overflow
+// list that a second launch with full-size scratch takes.
 template <int M, int TEAM>
 __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
     constexpr int TEAMS_PER_WG = APPLES_TPB / TEAM;
@@ -219,20 +251,25 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
     __shared__ int sh_cnt_all[TEAMS_PER_WG][4];
     __shared__ double sh_d[4];
     __shared__ int sh_i[4];
+    // per-wavefront staging area for 64 ARecs: records are built one per lane but stored to HBM as
+    // whole 1-KiB rows (4 store instructions per 64 records instead of 256 16-byte partial writes)
+    __shared__ uint4 sh_stage[APPLES_TPB / WAVE][WAVE * 4];
+    uint4 *stage = sh_stage[threadIdx.x / WAVE];
+    const int lane = threadIdx.x & (WAVE - 1);
     const int team_in_wg = threadIdx.x / TEAM;
     const int tid = threadIdx.x % TEAM;
     int *sh_cnt = sh_cnt_all[team_in_wg];
     const DevTree &T = a.tree;
     const NodeRec *__restrict__ NR = T.rec;
     const int64_t nn = T.n_nodes;
-    const int64_t cap = a.cap;  // scratch capacity of this launch's teams, in nodes
+    const int64_t cap = a.cap;  // scratch capacity of this launch's teams, in internal nodes
     const int64_t team = (int64_t)blockIdx.x * TEAMS_PER_WG + team_in_wg;
     const int64_t n_teams = (int64_t)gridDim.x * TEAMS_PER_WG;
     int32_t *map = a.map + team * nn;
     ARec *A = reinterpret_cast<ARec *>(a.A) + team * (cap + 1);
     BRec *B = reinterpret_cast<BRec *>(a.B) + team * (cap + 1);
     int32_t *grp_off = a.grp_off + team * (T.height + 4);
-    double *xe = a.xe ? a.xe + team * cap * 5 : nullptr;
+    double *xe = a.xe ? a.xe + team * (cap + a.leaf_cap) * XE_STRIDE : nullptr;
     const int64_t n_work = a.work_count ? *a.work_count : nq;
 
     for (int64_t w = team; w < n_work; w += n_teams) {
@@ -252,30 +289,41 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
         team_sync<TEAM>();
         while (true) {
             const int lo = cg[lvl + 1], hi = cg[lvl];  // observed leaves of this level: obs[lo, hi)
-            const int n_lvl = n_par + (hi - lo);
-            if (n_lvl == 1 && hi == n) {  // one node left in the frontier: the LCA (Subtree.py:36-43)
+            const int n_leaf = hi - lo;
+            if (n_par + n_leaf == 1 && hi == n) {  // one node left in the frontier: the LCA (Subtree.py:36-43)
                 if (n_par == 1) { lca = A[base].node; lca_claimed = 1; }
                 else lca = o_node[lo];
                 break;
             }
-            if (cap < nn && (int64_t)base + 2 * (int64_t)n_lvl > cap) { overflow = true; break; }
+            if (cap < nn && (int64_t)base + 2 * (int64_t)n_par + n_leaf > cap) { overflow = true; break; }
             if (tid == 0) { grp_off[G] = base; sh_cnt[(G + 1) % 3] = 0; }
             int *next_cnt = &sh_cnt[G % 3];
-            for (int k = tid; k < n_lvl; k += TEAM) {
+            const int next_base = base + n_par;
+            // (a) observed leaves of this level: name them in the map and claim their parents
+            for (int k = tid; k < n_leaf; k += TEAM) {
+                const int j = lo + k;
+                const int v = o_node[j];
+                map[v] = -(j + 2);
+                const int p = NR[v].parent;
+                if (p >= 0 && atomicCAS(&map[p], 0, -1) == 0) {
+                    const int nidx = next_base + atomicAdd(next_cnt, 1);
+                    A[nidx].node = p;
+                    map[p] = nidx + 1;
+                }
+            }
+            // (b) internal nodes of this level (claimed from the level below): S tuple from the valid
+            // children in file order, then claim the parent
+            for (int k0 = 0; k0 < n_par; k0 += TEAM) {  // team-uniform trip count
+                const int k = k0 + tid;
                 const int idx = base + k;
+                const bool active = k < n_par;
                 ARec ar;
-                NodeRec nr;
-                if (k >= n_par) {
-                    const int j = lo + (k - n_par);
-                    ar.node = o_node[j];
-                    nr = NR[ar.node];
-                    map[ar.node] = idx + 1;
-                    leaf_tuple<M>(o_dist[j], ar.S);
-                    ar.leaf = 1;
-                } else {
+                int parent = -1;
+                if (active) {
                     ar.node = A[idx].node;
-                    nr = NR[ar.node];
-                    ar.leaf = 0;
+                    ar.pad = 0;
+                    const NodeRec nr = NR[ar.node];
+                    parent = nr.parent;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) ar.S[c] = 0;
                     int kk[2];
@@ -285,11 +333,10 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
 #pragma unroll
                         for (int z = 0; z < 2; ++z) {
                             if (z < nk) {
-                                const ARec &cr = A[kk[z]];
-                                double s[6], t[6];
-#pragma unroll
-                                for (int x = 0; x < 6; ++x) s[x] = cr.S[x];
-                                lift<M>(s, cr.e, t);
+                                Kid kd;
+                                load_kid<M>(kk[z], A, NR, o_node, o_dist, kd);
+                                double t[6];
+                                lift<M>(kd.S, kd.e, t);
 #pragma unroll
                                 for (int x = 0; x < 6; ++x) ar.S[x] += BME ? coef * t[x] : t[x];
                             }
@@ -297,52 +344,66 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
                     } else {
                         for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
                             const int mc = map[T.child_idx[ci]];
-                            if (mc > 0) {
-                                const ARec &cr = A[mc - 1];
-                                double s[6], t[6];
-#pragma unroll
-                                for (int x = 0; x < 6; ++x) s[x] = cr.S[x];
-                                lift<M>(s, cr.e, t);
+                            if (mc != 0) {
+                                Kid kd;
+                                load_kid<M>(mc, A, NR, o_node, o_dist, kd);
+                                double t[6];
+                                lift<M>(kd.S, kd.e, t);
 #pragma unroll
                                 for (int x = 0; x < 6; ++x) ar.S[x] += BME ? coef * t[x] : t[x];
                             }
                         }
                     }
                     BRec &br = B[idx];
-                    br.k0 = kk[0]; br.k1 = kk[1]; br.nk = nk;
+                    br.k0 = kk[0]; br.k1 = kk[1]; br.nk = nk; br.poly = nr.nchild > 2;
+                    ar.e = nr.e;
+                    // stage the record; its 64 bytes leave as part of a 1-KiB row below
+                    const uint4 *src = reinterpret_cast<const uint4 *>(&ar);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) stage[lane * 4 + x] = src[x];
                 }
-                ar.e = nr.e;
-                A[idx] = ar;
-                if (ar.leaf) B[idx].nk = 0;
-                const int p = nr.parent;
-                if (p >= 0 && atomicCAS(&map[p], 0, -1) == 0) {
-                    const int nidx = base + n_lvl + atomicAdd(next_cnt, 1);
-                    A[nidx].node = p;
-                    map[p] = nidx + 1;
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const int wave_k0 = k0 + (tid - lane);         // first record of this wavefront's 64
+                    const int n_here = n_par - wave_k0;            // records this wavefront holds (may be <= 0)
+                    uint4 *dst = reinterpret_cast<uint4 *>(&A[base + wave_k0]);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int c = x * WAVE + lane;             // 16-byte chunk of the 4-KiB block
+                        if ((c >> 2) < n_here) dst[c] = stage[c];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (active && parent >= 0 && atomicCAS(&map[parent], 0, -1) == 0) {
+                    const int nidx = next_base + atomicAdd(next_cnt, 1);
+                    A[nidx].node = parent;
+                    map[parent] = nidx + 1;
                 }
             }
             team_sync<TEAM>();
             n_par = *next_cnt;
-            base += n_lvl;
+            base = next_base;
             ++G;
             --lvl;
         }
         if (overflow) {  // hand the query to the big-team launch; undo this team's marks first
             team_sync<TEAM>();
             for (int idx = tid; idx < base + n_par; idx += TEAM) map[A[idx].node] = 0;
+            for (int j = tid; j < n; j += TEAM) map[o_node[j]] = 0;
             if (tid == 0) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
             team_sync<TEAM>();
             continue;
         }
-        const int V = base;  // Subtree.num_nodes; the LCA's record sits at index V
+        const int VI = base;      // internal valid nodes; the LCA's record sits at index VI
+        const int V = base + n;   // Subtree.num_nodes
         if (tid == 0) {
-            grp_off[G] = V;
-            grp_off[G + 1] = V + 1;
+            grp_off[G] = VI;
+            grp_off[G + 1] = VI + 1;
             int kk[2];
             const NodeRec nr = NR[lca];
-            A[V].node = lca;
-            B[V].nk = valid_kids2(nr, map, T.child_idx, kk);
-            B[V].k0 = kk[0]; B[V].k1 = kk[1];
+            A[VI].node = lca;
+            B[VI].nk = valid_kids2(nr, map, T.child_idx, kk);
+            B[VI].k0 = kk[0]; B[VI].k1 = kk[1]; B[VI].poly = nr.nchild > 2;
         }
         team_sync<TEAM>();
 
@@ -357,25 +418,39 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
         for (int g = G; g >= 1; --g) {
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
             for (int idx = g0 + tid; idx < g1; idx += TEAM) {
+                const bool is_lca = (idx == VI);
                 const BRec br = B[idx];
-                if (br.nk == 0) continue;  // an observed leaf
-                const bool is_lca = (idx == V);
                 double rp[6], ep = 0;
                 if (!is_lca) {
 #pragma unroll
                     for (int x = 0; x < 6; ++x) rp[x] = br.R[x];
                     ep = A[idx].e;
                 }
-                const int pnode = A[idx].node;
-                const NodeRec nr = NR[pnode];
                 // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
                 const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + br.nk - 1) : 1.0;
                 double plift[6];
                 if (!is_lca) lift<M>(rp, ep, plift);
-                if (nr.nchild <= 2) {
-                    ARec kid[2];
-                    kid[0] = A[br.k0];
-                    if (br.nk > 1) kid[1] = A[br.k1];
+                auto finish_kid = [&](int kd, const Kid &kid, const double *acc) {
+                    Sol r = solve_edge<M>(kid.S, acc, kid.e, a.negative);
+                    if (kd > 0) {
+#pragma unroll
+                        for (int x = 0; x < 6; ++x) B[kd - 1].R[x] = acc[x];
+                    }
+                    if (a.keep_edges) {
+                        double *xp = xe + (int64_t)(kd > 0 ? kd - 1 : cap + (-kd - 2)) * XE_STRIDE;
+                        xp[0] = r.x1; xp[1] = r.x2; xp[2] = r.x1n; xp[3] = r.x2n; xp[4] = r.err;
+#pragma unroll
+                        for (int x = 0; x < 6; ++x) xp[5 + x] = acc[x];
+                    }
+                    const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
+                    if (key < best_key || (key == best_key && kid.node < best_v)) {
+                        best_key = key; best_v = kid.node; best_sol = r; best_e = kid.e;
+                    }
+                };
+                if (!br.poly) {
+                    Kid kid[2];
+                    load_kid<M>(br.k0, A, NR, o_node, o_dist, kid[0]);
+                    if (br.nk > 1) load_kid<M>(br.k1, A, NR, o_node, o_dist, kid[1]);
 #pragma unroll
                     for (int z = 0; z < 2; ++z) {
                         if (z < br.nk) {
@@ -392,39 +467,26 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
 #pragma unroll
                                 for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
                             }
-                            const int cidx = z == 0 ? br.k0 : br.k1;
-                            Sol r = solve_edge<M>(kid[z].S, acc, kid[z].e, a.negative);
-                            if (!kid[z].leaf || a.keep_edges) {
-#pragma unroll
-                                for (int x = 0; x < 6; ++x) B[cidx].R[x] = acc[x];
-                            }
-                            if (a.keep_edges) {
-                                double *xp = xe + (int64_t)cidx * 5;
-                                xp[0] = r.x1; xp[1] = r.x2; xp[2] = r.x1n; xp[3] = r.x2n; xp[4] = r.err;
-                            }
-                            const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
-                            if (key < best_key || (key == best_key && kid[z].node < best_v)) {
-                                best_key = key; best_v = kid[z].node; best_sol = r; best_e = kid[z].e;
-                            }
+                            finish_kid(z == 0 ? br.k0 : br.k1, kid[z], acc);
                         }
                     }
                 } else {  // polytomy: children through the CSR list
+                    const NodeRec nr = NR[A[idx].node];
                     const int c0 = nr.child_off, c1 = nr.child_off + nr.nchild;
                     for (int ci = c0; ci < c1; ++ci) {
                         const int mc = map[T.child_idx[ci]];
-                        if (mc <= 0) continue;
+                        if (mc == 0) continue;
                         double acc[6];
 #pragma unroll
                         for (int x = 0; x < 6; ++x) acc[x] = 0;
                         for (int cj = c0; cj < c1; ++cj) {
                             if (cj == ci) continue;
                             const int ms = map[T.child_idx[cj]];
-                            if (ms > 0) {
-                                const ARec &sr = A[ms - 1];
-                                double s[6], t[6];
-#pragma unroll
-                                for (int x = 0; x < 6; ++x) s[x] = sr.S[x];
-                                lift<M>(s, sr.e, t);
+                            if (ms != 0) {
+                                Kid sk;
+                                load_kid<M>(ms, A, NR, o_node, o_dist, sk);
+                                double t[6];
+                                lift<M>(sk.S, sk.e, t);
 #pragma unroll
                                 for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * t[x] : t[x];
                             }
@@ -433,20 +495,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
 #pragma unroll
                             for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
                         }
-                        const ARec kr = A[mc - 1];
-                        Sol r = solve_edge<M>(kr.S, acc, kr.e, a.negative);
-                        if (!kr.leaf || a.keep_edges) {
-#pragma unroll
-                            for (int x = 0; x < 6; ++x) B[mc - 1].R[x] = acc[x];
-                        }
-                        if (a.keep_edges) {
-                            double *xp = xe + (int64_t)(mc - 1) * 5;
-                            xp[0] = r.x1; xp[1] = r.x2; xp[2] = r.x1n; xp[3] = r.x2n; xp[4] = r.err;
-                        }
-                        const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
-                        if (key < best_key || (key == best_key && kr.node < best_v)) {
-                            best_key = key; best_v = kr.node; best_sol = r; best_e = kr.e;
-                        }
+                        Kid kr;
+                        load_kid<M>(mc, A, NR, o_node, o_dist, kr);
+                        finish_kid(mc, kr, acc);
                     }
                 }
             }
@@ -458,39 +509,41 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
         const int my_best = best_v;
         if (a.criterion == APPLES_HYBRID) {
             // nsmallest(floor(log2(num_nodes))) by error (stable = ties to the smaller edge_index),
-            // then the first minimum of x_1 among them in that order
+            // then the first minimum of x_1 among them in that order.  Candidates: internal nodes
+            // (xe slot = compact index) and observed leaves (xe slot = cap + j).
             const int kk = 31 - __clz(V);
             double last_e = -INF_D;
             int last_v = -1;
             double bx = INF_D;
+            int win_slot = -1;
             win = -1;
             for (int r = 0; r < kk; ++r) {
                 double ke = INF_D;
                 int kv = 0x7fffffff;
-                for (int idx = tid; idx < V; idx += TEAM) {
-                    const double e = xe[(int64_t)idx * 5 + 4];
-                    const int v = A[idx].node;
+                for (int i = tid; i < V; i += TEAM) {
+                    const int64_t slot = i < VI ? i : cap + (i - VI);
+                    const int v = i < VI ? A[i].node : o_node[i - VI];
+                    const double e = xe[slot * XE_STRIDE + 4];
                     const bool after = (e > last_e) || (e == last_e && v > last_v);
                     if (after && (e < ke || (e == ke && v < kv))) { ke = e; kv = v; }
                 }
                 team_argmin<TEAM>(ke, kv, sh_d, sh_i);
                 if (kv == 0x7fffffff) break;
                 last_e = ke; last_v = kv;
-                const double x1 = xe[(int64_t)(map[kv] - 1) * 5 + 0];
-                if (win < 0 || x1 < bx) { bx = x1; win = kv; }
+                const int mk = map[kv];
+                const int64_t slot = mk > 0 ? mk - 1 : cap + (-mk - 2);
+                const double x1 = xe[slot * XE_STRIDE + 0];
+                if (win < 0 || x1 < bx) { bx = x1; win = kv; win_slot = (int)slot; }
             }
-            if (win >= 0 && tid == 0) {  // rebuild the winner's solution from the stored per-edge values
-                const int widx = map[win] - 1;
-                const double *xp = xe + (int64_t)widx * 5;
-                best_sol.x1 = xp[0]; best_sol.x2 = xp[1]; best_sol.err = xp[4];
-                // the clamped pendant is the int 0 exactly when the clamp replaced a non-zero value or
-                // the value the solver kept is itself not the unclamped one (apples/util.py:32-50)
-                ARec wr = A[widx];
+            if (win >= 0 && tid == 0) {  // rebuild the winner's solution from its stored R
+                const int mk = map[win];
+                Kid wk;
+                load_kid<M>(mk, A, NR, o_node, o_dist, wk);
                 double rr[6];
 #pragma unroll
-                for (int x = 0; x < 6; ++x) rr[x] = B[widx].R[x];
-                best_sol = solve_edge<M>(wr.S, rr, wr.e, a.negative);
-                best_e = wr.e;
+                for (int x = 0; x < 6; ++x) rr[x] = xe[(int64_t)win_slot * XE_STRIDE + 5 + x];
+                best_sol = solve_edge<M>(wk.S, rr, wk.e, a.negative);
+                best_e = wk.e;
             }
         } else {
             team_argmin<TEAM>(best_key, best_v, sh_d, sh_i);
@@ -518,10 +571,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
             if (best_sol.x1 == 0 && best_sol.err > 0 && (best_sol.x2 == 0 || best_sol.x2 == best_e)) pl.flags |= APPLES_F_MISPLACED;
             a.out[q] = pl;
         }
-        if (tid == 0) grp_off[T.height + 3] = lca;
+        if (tid == 0) { grp_off[T.height + 3] = lca; grp_off[T.height + 2] = VI; }
         team_sync<TEAM>();
         // ------------------------------------------------------------ unroll_changes (Subtree.py:72-76)
-        for (int idx = tid; idx < V + lca_claimed; idx += TEAM) map[A[idx].node] = 0;
+        for (int idx = tid; idx < VI + lca_claimed; idx += TEAM) map[A[idx].node] = 0;
+        for (int j = tid; j < n; j += TEAM) map[o_node[j]] = 0;
         team_sync<TEAM>();
     }
 }
