@@ -228,7 +228,24 @@ void free_sweep(Workspace::Sweep &sw) {
     sw = Workspace::Sweep();
 }
 
+void swap_bufs(Workspace &w) {
+    BatchBuf &a = w.alt;
+    std::swap(w.dist, a.dist); std::swap(w.counts, a.counts); std::swap(w.obs_node, a.obs_node);
+    std::swap(w.obs_dist, a.obs_dist); std::swap(w.cnt_gt, a.cnt_gt); std::swap(w.n_obs, a.n_obs);
+    std::swap(w.seg_slot, a.seg_slot); std::swap(w.seg_cnt, a.seg_cnt); std::swap(w.dist_slow, a.dist_slow);
+    std::swap(w.slow_list, a.slow_list); std::swap(w.slow_count, a.slow_count); std::swap(w.route_list, a.route_list);
+    std::swap(w.route_count, a.route_count); std::swap(w.overflow_list, a.overflow_list);
+    std::swap(w.overflow_count, a.overflow_count);
+}
+
 void free_workspace(Workspace &w) {
+    {
+        BatchBuf &a = w.alt;
+        dev_free(a.dist); dev_free(a.counts); dev_free(a.obs_node); dev_free(a.obs_dist); dev_free(a.cnt_gt);
+        dev_free(a.n_obs); dev_free(a.seg_slot); dev_free(a.seg_cnt); dev_free(a.dist_slow); dev_free(a.slow_list);
+        dev_free(a.slow_count); dev_free(a.route_list); dev_free(a.route_count); dev_free(a.overflow_list);
+        dev_free(a.overflow_count);
+    }
     dev_free(w.dist); dev_free(w.counts); dev_free(w.obs_node); dev_free(w.obs_dist); dev_free(w.cnt_gt);
     dev_free(w.n_obs); dev_free(w.overflow_list); dev_free(w.overflow_count); dev_free(w.route_list); dev_free(w.route_count); dev_free(w.seg_slot); dev_free(w.seg_cnt);
     dev_free(w.dist_slow); dev_free(w.slow_list); dev_free(w.slow_count);
@@ -255,7 +272,7 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
 
 // workspaces for `members` rows/columns per query
 int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t want_batch, bool need_dist,
-                     bool need_counts, bool need_xe, bool need_fused = false) {
+                     bool need_counts, bool need_xe, bool need_fused = false, bool need_alt = false) {
     Workspace &w = ctx->ws;
     const DevTree &t = ctx->tree;
     int64_t batch = want_batch;
@@ -264,39 +281,44 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     // sweep's tail and the kernel boundaries)
     int64_t per_q = stride * 8 + members * 12 + (int64_t)(t.height + 2) * 4 + (need_counts ? stride * 4 : 0) +
                     (need_fused ? stride * 12 + stride / 16 : 0);
-    int64_t capq = std::max<int64_t>(32, ((int64_t)32 << 30) / std::max<int64_t>(per_q, 1));
+    int64_t capq = std::max<int64_t>(32, ((int64_t)(need_alt ? 16 : 32) << 30) / std::max<int64_t>(per_q, 1));
     batch = std::min(batch, capq);
     batch = round_up(std::max<int64_t>(batch, 1), 32);
     bool regrow = batch > w.batch || members > w.obs_cap || stride > w.stride || (need_counts && !w.counts) ||
-                  (need_xe && !w.big.xe) || (need_dist && !w.dist) || (need_fused && !w.seg_slot);
+                  (need_xe && !w.big.xe) || (need_dist && !w.dist) || (need_fused && !w.seg_slot) || (need_alt && !w.has_alt);
     if (!regrow) return 0;
     batch = std::max(batch, w.batch);
     int64_t obs_cap = std::max(members, w.obs_cap);
     stride = std::max(stride, w.stride);
     bool xe = need_xe || w.big.xe != nullptr, had_counts = w.counts != nullptr;
     bool fused = need_fused || w.seg_slot != nullptr;
+    bool alt = need_alt || w.has_alt;
     free_workspace(w);
     w.batch = batch;
     w.obs_cap = obs_cap;
     w.stride = stride;
-    if (dev_alloc(ctx, &w.dist, batch * std::max<int64_t>(stride, 1))) return 1;
-    if (need_counts || had_counts)
-        if (dev_alloc(ctx, &w.counts, batch * std::max<int64_t>(stride, 1))) return 1;
-    if (dev_alloc(ctx, &w.obs_node, batch * obs_cap)) return 1;
-    if (dev_alloc(ctx, &w.obs_dist, batch * obs_cap)) return 1;
-    if (dev_alloc(ctx, &w.cnt_gt, batch * (int64_t)(t.height + 2))) return 1;
-    if (dev_alloc(ctx, &w.n_obs, batch)) return 1;
-    if (fused) {
-        if (dev_alloc(ctx, &w.seg_slot, batch * std::max<int64_t>(stride, 1))) return 1;
-        if (dev_alloc(ctx, &w.seg_cnt, batch * std::max<int64_t>(stride / 64, 1))) return 1;
-        if (dev_alloc(ctx, &w.dist_slow, batch * std::max<int64_t>(stride, 1))) return 1;
-        if (dev_alloc(ctx, &w.slow_list, batch)) return 1;
-        if (dev_alloc(ctx, &w.slow_count, 1)) return 1;
+    for (int set = 0; set < (alt ? 2 : 1); ++set) {
+        if (dev_alloc(ctx, &w.dist, batch * std::max<int64_t>(stride, 1))) return 1;
+        if (need_counts || had_counts)
+            if (dev_alloc(ctx, &w.counts, batch * std::max<int64_t>(stride, 1))) return 1;
+        if (dev_alloc(ctx, &w.obs_node, batch * obs_cap)) return 1;
+        if (dev_alloc(ctx, &w.obs_dist, batch * obs_cap)) return 1;
+        if (dev_alloc(ctx, &w.cnt_gt, batch * (int64_t)(t.height + 2))) return 1;
+        if (dev_alloc(ctx, &w.n_obs, batch)) return 1;
+        if (fused) {
+            if (dev_alloc(ctx, &w.seg_slot, batch * std::max<int64_t>(stride, 1))) return 1;
+            if (dev_alloc(ctx, &w.seg_cnt, batch * std::max<int64_t>(stride / 64, 1))) return 1;
+            if (dev_alloc(ctx, &w.dist_slow, batch * std::max<int64_t>(stride, 1))) return 1;
+            if (dev_alloc(ctx, &w.slow_list, batch)) return 1;
+            if (dev_alloc(ctx, &w.slow_count, 1)) return 1;
+        }
+        if (dev_alloc(ctx, &w.route_list, batch)) return 1;
+        if (dev_alloc(ctx, &w.route_count, 1)) return 1;
+        if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
+        if (dev_alloc(ctx, &w.overflow_count, 1)) return 1;
+        if (alt && set == 0) swap_bufs(w);
     }
-    if (dev_alloc(ctx, &w.route_list, batch)) return 1;
-    if (dev_alloc(ctx, &w.route_count, 1)) return 1;
-    if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
-    if (dev_alloc(ctx, &w.overflow_count, 1)) return 1;
+    w.has_alt = alt;
     // small teams: one wavefront per query, up to 8 workgroups (32 waves) per CU on 256 CUs;
     // map is n_nodes ints per team (<= ~8 GiB in total), order/S/R share ~16 GiB
     int64_t nn = t.n_nodes;
@@ -424,28 +446,33 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
 
 // The sweep for one device batch: wavefront-sized teams first, then workgroup-sized teams with
 // full-size scratch for the queries whose induced subtree did not fit (usually none).
-int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq) {
+// `st` = the stream the small-team sweep (and the final overflow launch) runs on; the caller has
+// made `st` wait for the selection kernel of this batch.
+int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st = nullptr) {
     Workspace &w = ctx->ws;
+    if (!st) st = ctx->stream;
     static const int small_team = getenv("APPLES_SWEEP_TEAM") ? atoi(getenv("APPLES_SWEEP_TEAM")) : 64;  // tuning knob
     SweepArgs b = sweep_args(ctx, w.big, out, false);
     b.overflow_list = nullptr;  // a big team's scratch holds the whole tree: it cannot overflow
     b.overflow_count = nullptr;
-    if (small_team != 64) return launch_sweep(ctx, b, nq, w.big.wgs, 256);
-    // queries the selection kernel routed to big teams (many observed leaves) run on a second
-    // stream, concurrently with the wavefront-sized teams that take everything else
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_sel, ctx->stream));
+    if (small_team != 64) return launch_sweep(ctx, b, nq, w.big.wgs, 256, st);
+    // queries the selection kernel routed to big teams (many observed leaves) run on stream2,
+    // concurrently with the wavefront-sized teams that take everything else
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_sel, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_sel, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_bigfree, 0));  // big scratch free again
     b.work_list = w.route_list;
     b.work_count = w.route_count;
     if (launch_sweep(ctx, b, nq, w.big.wgs, 256, ctx->stream2)) return 1;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_big, ctx->stream2));
-    HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), ctx->stream));
-    if (launch_sweep(ctx, sweep_args(ctx, w.small, out, false), nq, w.small.wgs, 64)) return 1;
+    HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), st));
+    if (launch_sweep(ctx, sweep_args(ctx, w.small, out, false), nq, w.small.wgs, 64, st)) return 1;
     // whatever did not fit a small team's scratch (usually nothing)
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_big, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_big, 0));
     b.work_list = w.overflow_list;
     b.work_count = w.overflow_count;
-    if (launch_sweep(ctx, b, nq, w.big.wgs, 256)) return 1;
+    if (launch_sweep(ctx, b, nq, w.big.wgs, 256, st)) return 1;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_bigfree, st));
     return 0;
 }
 
@@ -457,32 +484,49 @@ int dist_tile_for(int64_t nq) {
     return nq >= 16 ? 16 : (nq >= 8 ? 8 : (nq >= 4 ? 4 : 1));
 }
 
+// One pass of the hot path over a resident query block.  The block is cut into sub-batches that
+// flow through two streams: front = distance + selection, back = sweep; with two sets of batch
+// buffers the distance kernel of sub-batch i+1 (VALU-bound) overlaps the sweep of sub-batch i
+// (memory-latency-bound).
 int run_block(apples_ctx *ctx, QueryBlock &qb) {
     const DevAlign &a = ctx->aln;
     bool hybrid = ctx->params.criterion == APPLES_HYBRID;
     // fused path: threshold compaction in the distance kernel's epilogue; only queries that need
     // the top-up rule get full distance rows
-    static const bool no_fuse = getenv("APPLES_NO_FUSE") != nullptr;  // tuning/diagnostic knob
+    static const bool no_fuse = getenv("APPLES_NO_FUSE") != nullptr;  // tuning/diagnostic knobs
+    static const int n_pipe = getenv("APPLES_PIPELINE") ? atoi(getenv("APPLES_PIPELINE")) : 1;  // >1: measured slower (sweep and distance kernels contend), kept as a knob
     const bool fused = !no_fuse && a.all_singleton && ctx->params.model == APPLES_JC69;
-    if (ensure_workspace(ctx, a.n_refs, a.slots_pad, qb.n, true, false, hybrid, fused)) return 1;
+    const bool pipelined = n_pipe > 1 && qb.n >= 1024;
+    int64_t want = qb.n;
+    if (pipelined) want = round_up((qb.n + n_pipe - 1) / n_pipe, 32);
+    if (ensure_workspace(ctx, a.n_refs, a.slots_pad, want, true, false, hybrid, fused, pipelined)) return 1;
     Workspace &w = ctx->ws;
-    PhaseTimer pt{ctx};
+    const int64_t step = pipelined ? std::min<int64_t>(w.batch, want) : w.batch;
+    const int64_t n_sub = (qb.n + step - 1) / step;
+    hipStream_t front = ctx->stream, back = pipelined ? ctx->stream3 : ctx->stream;
+    std::vector<hipEvent_t> ev((size_t)n_sub * 6);
+    for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
     hipEvent_t e_start, e_stop;
     HIP_TRY(ctx, hipEventCreate(&e_start));
     HIP_TRY(ctx, hipEventCreate(&e_stop));
-    HIP_TRY(ctx, hipEventRecord(e_start, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(e_start, front));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_bigfree, front));
+    if (pipelined) HIP_TRY(ctx, hipStreamWaitEvent(back, e_start, 0));
     int launches = 0;
-    for (int64_t q0 = 0; q0 < qb.n; q0 += w.batch) {
-        int64_t nq = std::min(w.batch, qb.n - q0);
-        pt.flush();
-        HIP_TRY(ctx, hipMemsetAsync(w.route_count, 0, sizeof(int32_t), ctx->stream));
+    for (int64_t i = 0; i < n_sub; ++i) {
+        const int64_t q0 = i * step;
+        const int64_t nq = std::min(step, qb.n - q0);
+        const int set = (int)(i & 1);
+        if (pipelined && i > 0) swap_bufs(w);  // host view: w.* now names buffer set `set`
+        if (pipelined && i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_back[set], 0));  // set free again
+        hipEvent_t *e = &ev[(size_t)i * 6];
+        HIP_TRY(ctx, hipMemsetAsync(w.route_count, 0, sizeof(int32_t), front));
         if (fused) {
-            HIP_TRY(ctx, hipMemsetAsync(w.slow_count, 0, sizeof(int32_t), ctx->stream));
-            pt.begin(APPLES_T_DIST);
+            HIP_TRY(ctx, hipMemsetAsync(w.slow_count, 0, sizeof(int32_t), front));
+            HIP_TRY(ctx, hipEventRecord(e[0], front));
             if (launch_counts_fused(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, w.seg_slot, w.seg_cnt)) return 1;
-            pt.end(APPLES_T_DIST);
+            HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;
-            pt.begin(APPLES_T_SELECT);
             SelectArgs sa = select_args_alignment(ctx, qb, q0);
             if (launch_select_fast(ctx, sa, nq)) return 1;
             // top-up path for the queries k_select_fast listed: full rows, then the general selection
@@ -491,32 +535,49 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
             sa.qlist = w.slow_list;
             sa.qcount = w.slow_count;
             if (launch_select(ctx, sa, nq)) return 1;
-            pt.end(APPLES_T_SELECT);
+            HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else {
-            pt.begin(APPLES_T_DIST);
+            HIP_TRY(ctx, hipEventRecord(e[0], front));
             if (ctx->params.model == APPLES_SCOREDIST) {
                 if (launch_scoredist(ctx, qb, q0, nq, w.dist, nullptr)) return 1;
             } else {
                 if (launch_counts(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, nullptr)) return 1;
             }
-            pt.end(APPLES_T_DIST);
+            HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;
-            pt.begin(APPLES_T_SELECT);
             if (launch_select(ctx, select_args_alignment(ctx, qb, q0), nq)) return 1;
-            pt.end(APPLES_T_SELECT);
+            HIP_TRY(ctx, hipEventRecord(e[2], front));
         }
-        pt.begin(APPLES_T_SWEEP);
-        if (run_sweep(ctx, qb.out + q0, nq)) return 1;
-        pt.end(APPLES_T_SWEEP);
+        if (pipelined) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_front[set], front));
+            HIP_TRY(ctx, hipStreamWaitEvent(back, ctx->ev_front[set], 0));
+        }
+        HIP_TRY(ctx, hipEventRecord(e[3], back));
+        if (run_sweep(ctx, qb.out + q0, nq, back)) return 1;
+        HIP_TRY(ctx, hipEventRecord(e[4], back));
+        if (pipelined) HIP_TRY(ctx, hipEventRecord(ctx->ev_back[set], back));
     }
-    HIP_TRY(ctx, hipEventRecord(e_stop, ctx->stream));
+    if (pipelined) {
+        HIP_TRY(ctx, hipEventRecord(e_stop, back));
+        HIP_TRY(ctx, hipStreamWaitEvent(front, e_stop, 0));
+        if ((n_sub & 1) == 0) swap_bufs(w);  // leave the host view on set 0
+    }
+    HIP_TRY(ctx, hipEventRecord(e_stop, front));
     HIP_TRY(ctx, hipEventSynchronize(e_stop));
-    pt.flush();
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+    for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = 0;
+    for (int64_t i = 0; i < n_sub; ++i) {
+        hipEvent_t *e = &ev[(size_t)i * 6];
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e[0], e[1]); ctx->t_ms[APPLES_T_DIST] += ms;
+        (void)hipEventElapsedTime(&ms, e[1], e[2]); ctx->t_ms[APPLES_T_SELECT] += ms;
+        (void)hipEventElapsedTime(&ms, e[3], e[4]); ctx->t_ms[APPLES_T_SWEEP] += ms;
+    }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e_start, e_stop);
+    for (auto &e : ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(e_start);
     (void)hipEventDestroy(e_stop);
-    for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = pt.acc[i];
     ctx->t_ms[APPLES_T_TOTAL] = ms;
     ctx->t_ms[APPLES_T_DIST_LAUNCHES] = launches;
     HIP_TRY(ctx, hipGetLastError());
@@ -547,6 +608,12 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
     }
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return fail(); }
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
+        hipStreamCreate(&ctx->stream3) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_front[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_front[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_back[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_back[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_bigfree, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_sel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return fail(); }
     for (int i = 0; i < 8; ++i)
@@ -607,6 +674,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     if (!ctx) return;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     for (auto &qb : ctx->blocks) free_block(&qb);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
@@ -618,6 +686,12 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     dev_free(ctx->d_col_level);
     for (int i = 0; i < 8; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->ev_front[i]) (void)hipEventDestroy(ctx->ev_front[i]);
+        if (ctx->ev_back[i]) (void)hipEventDestroy(ctx->ev_back[i]);
+    }
+    if (ctx->ev_bigfree) (void)hipEventDestroy(ctx->ev_bigfree);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->ev_sel) (void)hipEventDestroy(ctx->ev_sel);
     if (ctx->ev_big) (void)hipEventDestroy(ctx->ev_big);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);

@@ -66,6 +66,15 @@ struct QueryBlock {
     bool live = false;
 };
 
+// per-batch buffers that exist twice so that the distance/selection kernels of batch i+1 overlap
+// the sweep of batch i (front stream vs back stream)
+struct BatchBuf {
+    double *dist = nullptr; uint32_t *counts = nullptr; int32_t *obs_node = nullptr; double *obs_dist = nullptr;
+    int32_t *cnt_gt = nullptr, *n_obs = nullptr, *seg_slot = nullptr, *seg_cnt = nullptr; double *dist_slow = nullptr;
+    int32_t *slow_list = nullptr, *slow_count = nullptr, *route_list = nullptr, *route_count = nullptr;
+    int32_t *overflow_list = nullptr, *overflow_count = nullptr;
+};
+
 struct Workspace {
     int64_t batch = 0;            // queries per device batch
     int64_t stride = 0;           // row stride of dist/counts
@@ -96,6 +105,8 @@ struct Workspace {
     int32_t *route_count = nullptr;    // [1]
     int32_t *overflow_list = nullptr;  // [batch]
     int32_t *overflow_count = nullptr; // [1]
+    BatchBuf alt;                      // the other buffer set (swapped in by the pipelined driver)
+    bool has_alt = false;
 };
 
 struct apples_ctx {
@@ -103,6 +114,8 @@ struct apples_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // big-team sweep of the routed queries, concurrent with the small teams
     hipEvent_t ev_sel = nullptr, ev_big = nullptr;
+    hipStream_t stream3 = nullptr;   // back stream: sweeps of batch i while the front stream works on batch i+1
+    hipEvent_t ev_front[2] = {}, ev_back[2] = {}, ev_bigfree = nullptr;
     std::string err;
     std::string desc;
     apples_params params{};

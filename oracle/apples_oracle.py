@@ -436,3 +436,33 @@ def run_pool(tree, ref_names, ref_seqs, query_names, query_seqs, protein=False, 
     ctx = mp.get_context('fork')
     with ctx.Pool(threads) as pool:
         return pool.starmap(_Worker.run, tasks)
+
+
+def _noop(_):
+    return 0
+
+
+def time_pool(tree, ref_names, ref_seqs, query_names, query_seqs, threads, **kw):
+    """Steady-state timing of the pool driver for bench.py's cpu_baseline: the fork pool is started
+    and warmed first (its start-up, which the reference's own "Processed all queries" timer includes,
+    is returned separately), then the starmap over the sample is timed.
+    Returns (seconds_steady, seconds_startup, results)."""
+    import multiprocessing as mp
+    import time
+    rows = {n: ref_seqs[i] for i, n in enumerate(ref_names)}
+    _Worker.tree = tree
+    _Worker.reps = [(ref_seqs[i], [n]) for i, n in enumerate(ref_names)]
+    _Worker.rows = rows
+    _Worker.dist_fn = scoredist if kw.get('protein') else jc69
+    _Worker.params = dict(threshold=kw.get('threshold', 0.2), baseobs=kw.get('baseobs', 25),
+                          overlap=kw.get('overlap', 0.001), method=kw.get('method', 'FM'),
+                          criterion=kw.get('criterion', 'MLSE'), negative=False, exclude=False)
+    tasks = [(n, query_seqs[i]) for i, n in enumerate(query_names)]
+    ctx = mp.get_context('fork')
+    t0 = time.time()
+    with ctx.Pool(threads) as pool:
+        pool.map(_noop, range(4 * threads))
+        t1 = time.time()
+        res = pool.starmap(_Worker.run, tasks)
+        t2 = time.time()
+    return t2 - t1, t1 - t0, res

@@ -120,3 +120,29 @@ def test_fused_and_full_row_selection_paths_agree(c2):
         outs.append(r.stdout)
     assert len(outs[0]) == 3 * 512 * 40
     assert outs[0] == outs[1] == outs[2] == outs[3]
+
+
+def test_device_resident_results_visible_to_torch_zero_copy():
+    """bench.py hands the device-resident placement structs to torch.distributed (RCCL gather)
+    through __cuda_array_interface__ without a host round trip: the view must alias the bytes that
+    apples_fetch_placements copies out.  Runs in a fresh process, as bench.py does."""
+    import subprocess
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from apples_amd import synth\n"
+            "from apples_amd.engine import Engine\n"
+            "from apples_amd.distributed import shard_bounds\n"
+            "d = synth.make_dataset(2000, 500, 256)\n"
+            "nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)\n"
+            "eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')\n"
+            "h, nq = eng.upload_queries(d.query_seqs)\n"
+            "eng.place_resident(h)\n"
+            "class V:\n"
+            "    def __init__(self, ptr, n):\n"
+            "        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}\n"
+            "view = torch.as_tensor(V(eng.placements_device_ptr(h), nq * 40), device='cuda')\n"
+            "want = eng.fetch(h, nq)\n"
+            "assert view.cpu().numpy().tobytes() == want.tobytes()\n"
+            "assert shard_bounds(nq, 1) == [(0, nq)]\n"
+            "print('ZEROCOPY_OK')\n" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
+    assert 'ZEROCOPY_OK' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
