@@ -153,8 +153,10 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
     if (ctx->params.model == APPLES_SCOREDIST) {
         int Lpad = (a.L + 15) / 16 * 16;
         if (dev_alloc(ctx, &a.aa_idx, (int64_t)(Lpad / 16) * a.slots_pad * 16)) return 1;
-        HIP_TRY(ctx, hipMemsetAsync(a.aa_idx, 20, (size_t)(Lpad / 16) * a.slots_pad * 16, ctx->stream));
-        if (launch_pack_aa(ctx, a.raw, a.n_rows, a.L, a.aa_idx, a.slots_pad, false)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(a.aa_idx, 160, (size_t)(Lpad / 16) * a.slots_pad * 16, ctx->stream));
+        if (dev_alloc(ctx, &a.aa_mask, (int64_t)(Lpad / 16) * a.slots_pad)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(a.aa_mask, 0, (size_t)(Lpad / 16) * a.slots_pad * 2, ctx->stream));
+        if (launch_pack_aa(ctx, a.raw, a.n_rows, a.L, a.aa_idx, a.aa_mask, a.slots_pad, false)) return 1;
         a.planes = 0;
         double tab[21 * 21];
         for (int i = 0; i < 21; ++i)
@@ -355,7 +357,9 @@ int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t
         int Lpad = (a.L + 15) / 16 * 16;
         if (dev_alloc(ctx, &qb->aa_idx, qb->n_pad * Lpad)) return 1;
         HIP_TRY(ctx, hipMemsetAsync(qb->aa_idx, 20, (size_t)qb->n_pad * Lpad, ctx->stream));
-        if (launch_pack_aa(ctx, qb->raw, n, a.L, qb->aa_idx, 0, true)) return 1;
+        if (dev_alloc(ctx, &qb->aa_mask, qb->n_pad * (Lpad / 16))) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(qb->aa_mask, 0, (size_t)qb->n_pad * (Lpad / 16) * 2, ctx->stream));
+        if (launch_pack_aa(ctx, qb->raw, n, a.L, qb->aa_idx, qb->aa_mask, 0, true)) return 1;
     } else {
         int *d_exotic = nullptr;
         if (dev_alloc(ctx, &d_exotic, 1)) return 1;
@@ -387,7 +391,7 @@ int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t
 }
 
 void free_block(QueryBlock *qb) {
-    dev_free(qb->raw); dev_free(qb->packed); dev_free(qb->aa_idx); dev_free(qb->self_slot); dev_free(qb->out);
+    dev_free(qb->raw); dev_free(qb->packed); dev_free(qb->aa_idx); dev_free(qb->aa_mask); dev_free(qb->self_slot); dev_free(qb->out);
     *qb = QueryBlock();
 }
 
@@ -680,7 +684,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.slot_node); dev_free(a.slot_level);
+    dev_free(a.raw); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

@@ -43,7 +43,8 @@ struct DevAlign {
     bool all_singleton = true;
     uint8_t *raw = nullptr;       // [n_rows*L] bytes in slot order (kept for lazy repacking / scoredist)
     uint4 *packed = nullptr;      // [G][planes+1][slots_pad] uint4 = 4 consecutive 32-site words
-    uint8_t *aa_idx = nullptr;    // scoredist: [Lpad16/16][slots_pad][16] residue indices 0..19, 20 = gap
+    uint8_t *aa_idx = nullptr;    // scoredist: [Lpad16/16][slots_pad][16] residue index * 8 (0..152, 160 = gap)
+    uint16_t *aa_mask = nullptr;  // scoredist: [Lpad16/16][slots_pad] bit k = site 16*s16+k is not a gap
     int32_t *slot_node = nullptr; // [n_refs] tree node or -1
     int32_t *slot_level = nullptr;// [n_refs] level or -1
     int32_t *slot_rep = nullptr;  // [n_refs] representative index of the member's cluster
@@ -59,7 +60,8 @@ struct QueryBlock {
     int64_t n = 0, n_pad = 0;
     uint8_t *raw = nullptr;       // [n*L]
     uint4 *packed = nullptr;      // [n_pad/16][G][16][planes+1] uint4
-    uint8_t *aa_idx = nullptr;    // [n_pad][Lpad16]
+    uint8_t *aa_idx = nullptr;    // [n_pad][Lpad16] residue index (20 = gap)
+    uint16_t *aa_mask = nullptr;  // [n_pad][Lpad16/16]
     int32_t *self_slot = nullptr; // [n]
     apples_placement *out = nullptr;  // [n] device
     int planes = 0;
@@ -155,8 +157,8 @@ extern thread_local std::string g_create_error;
 // pack.hip
 int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, int planes, uint4 *d_out,
                      int64_t slots_pad, bool query_layout, int *d_exotic);
-int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, int64_t slots_pad,
-                   bool query_layout);
+int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, uint16_t *d_mask,
+                   int64_t slots_pad, bool query_layout);
 // dist.hip
 int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
                   uint32_t *d_counts);

@@ -7,6 +7,7 @@
 // workgroup owns 256 rows x TQ queries; the query words are wave-uniform, so they come through
 // the scalar cache and occupy SGPRs, not LDS.  HBM traffic per launch is the packed reference
 // once per query tile plus 8 B per pair of output.  No MFMA: this is popcount, not a contraction.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -47,11 +48,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
                                                      const int32_t *__restrict__ qcount,
                                                      const int32_t *__restrict__ mmax) {
     const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
-    const int64_t q0 = (int64_t)blockIdx.y * TQ;
-    if (MODE == 2) {
-        nq = *qcount;
-        if (q0 >= nq) return;
-    }
+    if (MODE == 2) nq = *qcount;
+    // listed mode: the list length lives on the device, so a bounded grid.y loops over the tiles
+    for (int64_t q0 = (int64_t)blockIdx.y * TQ; q0 < nq; q0 += (MODE == 2 ? (int64_t)gridDim.y * TQ : nq)) {
     uint32_t nv[TQ], nm[TQ];
 #pragma unroll
     for (int t = 0; t < TQ; ++t) nv[t] = nm[t] = 0;
@@ -142,15 +141,17 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
         }
         return;
     }
-    if (slot >= n_slots) return;
+    if (slot < n_slots) {
 #pragma unroll
-    for (int t = 0; t < TQ; ++t) {
-        if (q0 + t < nq) {
-            int64_t o = (q0 + t) * slots_pad + slot;
-            if (dist) dist[o] = jc69_from_counts(nm[t], nv[t], L, overlap, lut);
-            if (counts) counts[o] = (nm[t] << 16) | nv[t];
+        for (int t = 0; t < TQ; ++t) {
+            if (q0 + t < nq) {
+                int64_t o = (q0 + t) * slots_pad + slot;
+                if (dist) dist[o] = jc69_from_counts(nm[t], nv[t], L, overlap, lut);
+                if (counts) counts[o] = (nm[t] << 16) | nv[t];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+    }
     }
 }
 
@@ -168,7 +169,8 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
 #define LAUNCH(TQ)                                                                                                   \
     if (use_asm) LAUNCH2(TQ, true); else LAUNCH2(TQ, false)
 #define LAUNCH2(TQ, A)                                                                                               \
-    hipLaunchKernelGGL((k_jc69<P, TQ, MODE, A>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)), \
+    hipLaunchKernelGGL((k_jc69<P, TQ, MODE, A>), dim3((unsigned)(a.slots_pad / APPLES_TPB),                          \
+                       (unsigned)(MODE == 2 ? std::min<int64_t>((nq + TQ - 1) / TQ, 8) : (nq + TQ - 1) / TQ)),         \
                        block, 0, ctx->stream, a.packed, qp, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,   \
                        ctx->params.overlap_frac, lut, ctx->params.filt_threshold, seg_slot, seg_cnt, qlist, qcount, mmax)
     if (tile >= 32) LAUNCH(32);
@@ -217,13 +219,15 @@ int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int6
 // Sites are summed left to right in fp64 (the reference's order is whatever BLAS ddot does, so
 // this path is tolerance-checked, not bit-checked).
 template <int TQ>
-__global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restrict__ refa, const uint8_t *__restrict__ qa,
+__global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
+                                                          const uint8_t *__restrict__ qa, const uint16_t *__restrict__ qm,
                                                           const double *__restrict__ table, double *__restrict__ dist,
                                                           uint32_t *__restrict__ counts, int64_t n_slots,
                                                           int64_t slots_pad, int Lpad, int L, int64_t nq, double overlap) {
     __shared__ double T[21 * 21];
     for (int i = threadIdx.x; i < 21 * 21; i += APPLES_TPB) T[i] = table[i];
     __syncthreads();
+    const char *Tb = reinterpret_cast<const char *>(T);
     const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
     const int64_t q0 = (int64_t)blockIdx.y * TQ;
     double tot[TQ];
@@ -232,21 +236,34 @@ __global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restr
     for (int t = 0; t < TQ; ++t) { tot[t] = 0.0; nv[t] = 0; }
     const int n16 = Lpad / 16;
     for (int s16 = 0; s16 < n16; ++s16) {
-        uint4 rw = *reinterpret_cast<const uint4 *>(refa + ((int64_t)s16 * slots_pad + slot) * 16);
-        uint32_t r[4] = {rw.x, rw.y, rw.z, rw.w};
+        // this row's 16 residues as table column byte offsets (index * 8), unpacked once per block of
+        // sites and reused for all TQ queries
+        const uint4 rw = *reinterpret_cast<const uint4 *>(refa + ((int64_t)s16 * slots_pad + slot) * 16);
+        const uint32_t rmask = refm[(int64_t)s16 * slots_pad + slot];
+        uint32_t r8[16];
+        const uint32_t rr[4] = {rw.x, rw.y, rw.z, rw.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r8[k] = (rr[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        // wave-uniform: the queries' residues select table rows (scalar arithmetic)
+        uint32_t qv[TQ][4];
 #pragma unroll
         for (int t = 0; t < TQ; ++t) {
-            uint4 qw = *reinterpret_cast<const uint4 *>(qa + (q0 + t) * (int64_t)Lpad + s16 * 16);  // uniform
-            uint32_t q[4] = {qw.x, qw.y, qw.z, qw.w};
+            const uint4 qw = *reinterpret_cast<const uint4 *>(qa + (q0 + t) * (int64_t)Lpad + s16 * 16);
+            qv[t][0] = qw.x; qv[t][1] = qw.y; qv[t][2] = qw.z; qv[t][3] = qw.w;
+            nv[t] += __popc(rmask & (uint32_t)qm[(q0 + t) * (int64_t)n16 + s16]);
+        }
+        // site-major: the TQ table reads of one site are independent, so they are in flight together;
+        // each query still sums its sites left to right
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                uint32_t qi = (q[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                uint32_t ri = (r[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                if (qi != 20u) {  // wave-uniform branch: a query gap adds nothing for any row
-                    tot[t] += T[qi * 21 + ri];
-                    nv[t] += (ri != 20u);
-                }
+        for (int k = 0; k < 16; ++k) {
+            double v[TQ];
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) {
+                const uint32_t qrow = ((qv[t][k >> 2] >> (8 * (k & 3))) & 0xffu) * 168u;  // 21 columns * 8 bytes
+                v[t] = *reinterpret_cast<const double *>(Tb + qrow + r8[k]);               // gap row/column = +0.0
             }
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) tot[t] += v[t];
         }
     }
     if (slot >= n_slots) return;
@@ -275,8 +292,9 @@ int launch_scoredist(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t 
     int Lpad = (a.L + 15) / 16 * 16;
     constexpr int TQ = 8;
     hipLaunchKernelGGL((k_scoredist<TQ>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)),
-                       dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, qb.aa_idx + q0 * Lpad, ctx->blosum, d_dist, d_counts,
-                       a.n_rows, a.slots_pad, Lpad, a.L, nq, ctx->params.overlap_frac);
+                       dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask, qb.aa_idx + q0 * Lpad,
+                       qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, d_dist, d_counts, a.n_rows, a.slots_pad, Lpad, a.L, nq,
+                       ctx->params.overlap_frac);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

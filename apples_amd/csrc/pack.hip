@@ -77,8 +77,10 @@ int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int 
 // scoredist layout: residue index per site, a2i of apples/distance.py:418-678 (ARNDCQEGHILKMFPSTWYV
 // both cases -> 0..19, every other byte -> 0) with '-' -> 20 (a zero row/column of the table, so
 // gapped sites add +0.0 exactly as nondash*BLOSUM45[...] does at distance.py:706).
-//   reference rows : aa[(s16 * slots_pad + slot) * 16 + k]    s16 = site / 16
-//   query rows     : aa[q * Lpad + site]
+//   reference rows : aa[(s16 * slots_pad + slot) * 16 + k] = index * 8 (the byte offset of the
+//                    table column, so the kernel adds it to a row base without scaling)
+//   query rows     : aa[q * Lpad + site] = index
+//   gap masks      : mask[s16 * slots_pad + slot] / mask[q * (Lpad/16) + s16]: bit k = site is not '-'
 __device__ __forceinline__ uint8_t aa_index(uint8_t b) {
     switch (b) {
         case 'A': case 'a': return 0;
@@ -107,32 +109,39 @@ __device__ __forceinline__ uint8_t aa_index(uint8_t b) {
 }
 
 __global__ __launch_bounds__(APPLES_TPB) void k_pack_aa(const uint8_t *__restrict__ raw, int64_t n_rows, int L, int Lpad,
-                                                        uint8_t *__restrict__ out, int64_t slots_pad, int query_layout) {
+                                                        uint8_t *__restrict__ out, uint16_t *__restrict__ mask,
+                                                        int64_t slots_pad, int query_layout) {
     int64_t row = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
     int s16 = blockIdx.y;
     if (row >= n_rows) return;
     const uint8_t *src = raw + row * (int64_t)L;
     uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t m = 0;
+    const uint32_t scale = query_layout ? 1u : 8u;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         int site = s16 * 16 + k;
         uint32_t v = site < L ? aa_index(src[site]) : 20u;
-        w[k >> 2] |= v << (8 * (k & 3));
+        m |= (uint32_t)(v != 20u) << k;
+        w[k >> 2] |= (v * scale) << (8 * (k & 3));
     }
     uint4 val = make_uint4(w[0], w[1], w[2], w[3]);
-    if (query_layout)
+    if (query_layout) {
         *reinterpret_cast<uint4 *>(out + row * (int64_t)Lpad + s16 * 16) = val;
-    else
+        mask[row * (int64_t)(Lpad / 16) + s16] = (uint16_t)m;
+    } else {
         *reinterpret_cast<uint4 *>(out + ((int64_t)s16 * slots_pad + row) * 16) = val;
+        mask[(int64_t)s16 * slots_pad + row] = (uint16_t)m;
+    }
 }
 
-int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, int64_t slots_pad,
-                   bool query_layout) {
+int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, uint16_t *d_mask,
+                   int64_t slots_pad, bool query_layout) {
     if (n_rows == 0) return 0;
     int Lpad = (L + 15) / 16 * 16;
     dim3 grid((unsigned)((n_rows + APPLES_TPB - 1) / APPLES_TPB), (unsigned)(Lpad / 16));
-    hipLaunchKernelGGL(k_pack_aa, grid, dim3(APPLES_TPB), 0, ctx->stream, d_raw, n_rows, L, Lpad, d_out, slots_pad,
-                       query_layout ? 1 : 0);
+    hipLaunchKernelGGL(k_pack_aa, grid, dim3(APPLES_TPB), 0, ctx->stream, d_raw, n_rows, L, Lpad, d_out, d_mask,
+                       slots_pad, query_layout ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

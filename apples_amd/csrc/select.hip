@@ -15,6 +15,8 @@
 // order -> exact placement, <= 2 distances -> unplaceable.  Survivors are written with an
 // ordered compaction in slot order; slots are sorted by tree level, deepest first, so the sweep
 // kernel receives its leaves grouped by level together with the per-level offsets cnt_gt.
+#include <algorithm>
+
 #include "common.h"
 
 #define WAVE 64
@@ -83,11 +85,13 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
     __shared__ double sh_d[8];
-    // listed mode (top-up path): block r handles query qlist[r], whose distances are row r
-    if (a.qcount && (int64_t)blockIdx.x >= *a.qcount) return;
-    const int64_t q = a.qlist ? a.qlist[blockIdx.x] : blockIdx.x;
+    // listed mode (top-up path): a fixed grid walks the device-side list; entry r names query
+    // qlist[r], whose distances are row r
+    const int64_t n_list = a.qcount ? (int64_t)*a.qcount : (int64_t)gridDim.x;
+    for (int64_t r = blockIdx.x; r < n_list; r += gridDim.x) {
+    const int64_t q = a.qlist ? a.qlist[r] : r;
     const int tid = threadIdx.x;
-    const double *row = a.dist + (int64_t)blockIdx.x * a.stride;
+    const double *row = a.dist + r * a.stride;
     const int32_t *gather = a.gather;
     const int64_t nm = a.n_members;
     const int self = a.self_slot ? a.self_slot[q] : -1;
@@ -256,6 +260,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
         a.n_obs[q] = n_emit;  // 0 = nothing for the sweep to do
         if (n_emit > a.big_threshold && a.overflow_list) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
     }
+    __syncthreads();  // shared scratch is reused by the next list entry
+    }
 #undef DIST
 #undef SLOT_KEYIDX
 }
@@ -400,7 +406,9 @@ int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
 
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
-    hipLaunchKernelGGL(k_select, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
+    // listed mode: the list length lives on the device, so a bounded grid loops over it
+    unsigned grid = a.qcount ? (unsigned)std::min<int64_t>(nq, 512) : (unsigned)nq;
+    hipLaunchKernelGGL(k_select, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
