@@ -391,7 +391,7 @@ int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t
 }
 
 void free_block(QueryBlock *qb) {
-    dev_free(qb->raw); dev_free(qb->packed); dev_free(qb->aa_idx); dev_free(qb->aa_mask); dev_free(qb->self_slot); dev_free(qb->out);
+    dev_free(qb->table); dev_free(qb->raw); dev_free(qb->packed); dev_free(qb->aa_idx); dev_free(qb->aa_mask); dev_free(qb->self_slot); dev_free(qb->out);
     *qb = QueryBlock();
 }
 
@@ -724,9 +724,12 @@ int apples_queries_free(apples_ctx *ctx, int64_t handle) {
     return 0;
 }
 
+static int run_table_block(apples_ctx *ctx, QueryBlock &qb);
+
 int apples_place_resident(apples_ctx *ctx, int64_t handle) {
     if (handle < 0 || handle >= (int64_t)ctx->blocks.size() || !ctx->blocks[handle].live) { ctx->err = "bad handle"; return 1; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->blocks[handle].table) return run_table_block(ctx, ctx->blocks[handle]);
     return run_block(ctx, ctx->blocks[handle]);
 }
 
@@ -828,35 +831,66 @@ int apples_distances(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries,
     return rc;
 }
 
+// column layout of a distance table: columns sorted by tree level (deepest first), cached while
+// the caller keeps passing the same col_node
+static int setup_columns(apples_ctx *ctx, int64_t n_cols, const int32_t *col_node) {
+    const DevTree &t = ctx->tree;
+    bool same = ctx->dcols == n_cols && (int64_t)ctx->h_col_node.size() == n_cols &&
+                std::equal(col_node, col_node + n_cols, ctx->h_col_node.begin());
+    if (same) return 0;
+    std::vector<int32_t> level(t.n_nodes);
+    HIP_TRY(ctx, hipMemcpy(level.data(), t.level, (size_t)t.n_nodes * 4, hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < n_cols; ++c)
+        if (col_node[c] >= t.n_nodes) { ctx->err = "col_node out of range"; return 1; }
+    std::vector<int32_t> &perm = ctx->h_col_perm;
+    perm = level_order(col_node, n_cols, level);
+    std::vector<int32_t> s_node(n_cols), s_level(n_cols);
+    for (int64_t s = 0; s < n_cols; ++s) {
+        int nd = col_node[perm[s]];
+        s_node[s] = nd;
+        s_level[s] = nd >= 0 ? level[nd] : -1;
+    }
+    dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node); dev_free(ctx->d_col_level);
+    if (dev_upload(ctx, &ctx->d_col_perm, perm.data(), n_cols)) return 1;
+    if (dev_upload(ctx, &ctx->d_col_node, s_node.data(), n_cols)) return 1;
+    if (dev_upload(ctx, &ctx->d_col_level, s_level.data(), n_cols)) return 1;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->h_col_node.assign(col_node, col_node + n_cols);
+    ctx->dcols = n_cols;
+    return 0;
+}
+
+// selection (table rule) + sweep over nq rows of a device-resident table in slot order; d_self = per-query own
+// column as a slot index or -1
+static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, int64_t n_cols, const int32_t *d_self,
+                           apples_placement *d_out, PhaseTimer &pt) {
+    Workspace &w = ctx->ws;
+    SelectArgs s{};
+    s.dist = d_rows; s.stride = n_cols; s.gather = nullptr;  // rows were permuted into slot order
+    s.slot_node = ctx->d_col_node; s.slot_level = ctx->d_col_level; s.slot_rep = ctx->d_col_perm;
+    s.node_level = ctx->tree.level;
+    s.n_members = n_cols; s.n_reps = n_cols; s.all_singleton = 1; s.table_mode = 1; s.self_slot = d_self;
+    s.thr = ctx->params.filt_threshold; s.baseobs = ctx->params.base_observation; s.height = ctx->tree.height;
+    s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
+    s.out = d_out;
+    s.big_threshold = big_threshold(); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+    HIP_TRY(ctx, hipMemsetAsync(w.route_count, 0, sizeof(int32_t), ctx->stream));
+    pt.flush();
+    pt.begin(APPLES_T_SELECT);
+    if (launch_select(ctx, s, nq)) return 1;
+    pt.end(APPLES_T_SELECT);
+    pt.begin(APPLES_T_SWEEP);
+    if (run_sweep(ctx, d_out, nq)) return 1;
+    pt.end(APPLES_T_SWEEP);
+    return 0;
+}
+
 int apples_place_from_distances(apples_ctx *ctx, const double *dist, int64_t n_queries, int64_t n_cols,
                                 const int32_t *col_node, const int32_t *self_col, apples_placement *out) {
     if (n_queries == 0) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const DevTree &t = ctx->tree;
-    // column layout (cached while the caller keeps passing the same col_node)
-    bool same = ctx->dcols == n_cols && (int64_t)ctx->h_col_node.size() == n_cols &&
-                std::equal(col_node, col_node + n_cols, ctx->h_col_node.begin());
-    std::vector<int32_t> level(t.n_nodes);
-    std::vector<int32_t> &perm = ctx->h_col_perm;
-    if (!same) {
-        HIP_TRY(ctx, hipMemcpy(level.data(), t.level, (size_t)t.n_nodes * 4, hipMemcpyDeviceToHost));
-        for (int64_t c = 0; c < n_cols; ++c)
-            if (col_node[c] >= t.n_nodes) { ctx->err = "col_node out of range"; return 1; }
-        perm = level_order(col_node, n_cols, level);
-        std::vector<int32_t> s_node(n_cols), s_level(n_cols);
-        for (int64_t s = 0; s < n_cols; ++s) {
-            int nd = col_node[perm[s]];
-            s_node[s] = nd;
-            s_level[s] = nd >= 0 ? level[nd] : -1;
-        }
-        dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node); dev_free(ctx->d_col_level);
-        if (dev_upload(ctx, &ctx->d_col_perm, perm.data(), n_cols)) return 1;
-        if (dev_upload(ctx, &ctx->d_col_node, s_node.data(), n_cols)) return 1;
-        if (dev_upload(ctx, &ctx->d_col_level, s_level.data(), n_cols)) return 1;
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->h_col_node.assign(col_node, col_node + n_cols);
-        ctx->dcols = n_cols;
-    }
+    if (setup_columns(ctx, n_cols, col_node)) return 1;
+    const std::vector<int32_t> &perm = ctx->h_col_perm;
     std::vector<int32_t> col_slot(n_cols);
     for (int64_t s = 0; s < n_cols; ++s) col_slot[perm[s]] = (int32_t)s;
     bool hybrid = ctx->params.criterion == APPLES_HYBRID;
@@ -864,8 +898,10 @@ int apples_place_from_distances(apples_ctx *ctx, const double *dist, int64_t n_q
     Workspace &w = ctx->ws;
     apples_placement *d_out = nullptr;
     int32_t *d_self = nullptr;
+    double *d_stage = nullptr;
     if (dev_alloc(ctx, &d_out, w.batch)) return 1;
     if (dev_alloc(ctx, &d_self, w.batch)) return 1;
+    if (dev_alloc(ctx, &d_stage, std::min<int64_t>(w.batch, n_queries) * n_cols)) return 1;
     PhaseTimer pt{ctx};
     int rc = 0;
     for (int64_t q0 = 0; q0 < n_queries && !rc; q0 += w.batch) {
@@ -875,26 +911,11 @@ int apples_place_from_distances(apples_ctx *ctx, const double *dist, int64_t n_q
             for (int64_t i = 0; i < nq; ++i)
                 if (self_col[q0 + i] >= 0 && self_col[q0 + i] < n_cols) self[i] = col_slot[self_col[q0 + i]];
         if (hipMemcpyAsync(d_self, self.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(w.dist, dist + q0 * n_cols, (size_t)nq * n_cols * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d_stage, dist + q0 * n_cols, (size_t)nq * n_cols * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "upload of the distance table failed"; rc = 1; break; }
-        SelectArgs s{};
-        s.dist = w.dist; s.stride = n_cols; s.gather = ctx->d_col_perm;
-        s.slot_node = ctx->d_col_node; s.slot_level = ctx->d_col_level; s.slot_rep = nullptr; s.slot_mpos = nullptr;
-        s.rep_slot = nullptr; s.rep_moff = nullptr; s.mem_slot = nullptr;
-        s.n_members = n_cols; s.n_reps = n_cols; s.all_singleton = 1; s.table_mode = 1; s.self_slot = d_self;
-        s.thr = ctx->params.filt_threshold; s.baseobs = ctx->params.base_observation; s.height = t.height;
-        s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
-        s.out = d_out;
-        s.big_threshold = big_threshold(); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
-        if (hipMemsetAsync(w.route_count, 0, sizeof(int32_t), ctx->stream) != hipSuccess) { ctx->err = "memset failed"; rc = 1; break; }
-        pt.flush();
-        pt.begin(APPLES_T_SELECT);
-        rc = launch_select(ctx, s, nq);
-        pt.end(APPLES_T_SELECT);
+        rc = launch_permute_cols(ctx, d_stage, w.dist, ctx->d_col_perm, nq, n_cols);
         if (rc) break;
-        pt.begin(APPLES_T_SWEEP);
-        rc = run_sweep(ctx, d_out, nq);
-        pt.end(APPLES_T_SWEEP);
+        rc = run_table_batch(ctx, w.dist, nq, n_cols, d_self, d_out, pt);
         if (rc) break;
         if (hipMemcpyAsync(out + q0, d_out, (size_t)nq * sizeof(apples_placement), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "placement kernels failed"; rc = 1; break; }
@@ -904,7 +925,70 @@ int apples_place_from_distances(apples_ctx *ctx, const double *dist, int64_t n_q
     ctx->t_ms[APPLES_T_TOTAL] = pt.acc[APPLES_T_SELECT] + pt.acc[APPLES_T_SWEEP];
     dev_free(d_out);
     dev_free(d_self);
+    dev_free(d_stage);
     return rc;
+}
+
+int apples_table_upload(apples_ctx *ctx, const double *dist, int64_t n_queries, int64_t n_cols, const int32_t *col_node,
+                        const int32_t *self_col, int64_t *handle) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (setup_columns(ctx, n_cols, col_node)) return 1;
+    const std::vector<int32_t> &perm = ctx->h_col_perm;
+    std::vector<int32_t> col_slot(n_cols);
+    for (int64_t s = 0; s < n_cols; ++s) col_slot[perm[s]] = (int32_t)s;
+    std::vector<int32_t> self(std::max<int64_t>(n_queries, 1), -1);
+    if (self_col)
+        for (int64_t i = 0; i < n_queries; ++i)
+            if (self_col[i] >= 0 && self_col[i] < n_cols) self[i] = col_slot[self_col[i]];
+    size_t slot = ctx->blocks.size();
+    for (size_t i = 0; i < ctx->blocks.size(); ++i)
+        if (!ctx->blocks[i].live) { slot = i; break; }
+    if (slot == ctx->blocks.size()) ctx->blocks.emplace_back();
+    QueryBlock qb;
+    qb.n = n_queries;
+    qb.n_cols = n_cols;
+    double *d_stage = nullptr;
+    if (dev_upload(ctx, &d_stage, dist, n_queries * n_cols) || dev_alloc(ctx, &qb.table, n_queries * n_cols) ||
+        dev_upload(ctx, &qb.self_slot, self.data(), (int64_t)self.size()) ||
+        dev_alloc(ctx, &qb.out, std::max<int64_t>(n_queries, 1)) ||
+        launch_permute_cols(ctx, d_stage, qb.table, ctx->d_col_perm, n_queries, n_cols)) {
+        dev_free(d_stage);
+        free_block(&qb);
+        return 1;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(d_stage);
+    qb.live = true;
+    ctx->blocks[slot] = qb;
+    *handle = (int64_t)slot;
+    return 0;
+}
+
+static int run_table_block(apples_ctx *ctx, QueryBlock &qb) {
+    bool hybrid = ctx->params.criterion == APPLES_HYBRID;
+    if (qb.n_cols != ctx->dcols) { ctx->err = "the column layout changed since this table was uploaded"; return 1; }
+    if (ensure_workspace(ctx, qb.n_cols, qb.n_cols, qb.n, false, false, hybrid)) return 1;
+    Workspace &w = ctx->ws;
+    PhaseTimer pt{ctx};
+    hipEvent_t e_start, e_stop;
+    HIP_TRY(ctx, hipEventCreate(&e_start));
+    HIP_TRY(ctx, hipEventCreate(&e_stop));
+    HIP_TRY(ctx, hipEventRecord(e_start, ctx->stream));
+    for (int64_t q0 = 0; q0 < qb.n; q0 += w.batch) {
+        int64_t nq = std::min(w.batch, qb.n - q0);
+        if (run_table_batch(ctx, qb.table + q0 * qb.n_cols, nq, qb.n_cols, qb.self_slot + q0, qb.out + q0, pt)) return 1;
+    }
+    HIP_TRY(ctx, hipEventRecord(e_stop, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(e_stop));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+    pt.flush();
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e_start, e_stop);
+    (void)hipEventDestroy(e_start);
+    (void)hipEventDestroy(e_stop);
+    for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = pt.acc[i];
+    ctx->t_ms[APPLES_T_TOTAL] = ms;
+    return 0;
 }
 
 int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *obs_dist, int32_t n_obs, uint8_t *valid,

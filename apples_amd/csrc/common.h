@@ -58,6 +58,8 @@ struct DevAlign {
 
 struct QueryBlock {
     int64_t n = 0, n_pad = 0;
+    double *table = nullptr;      // distance-table block: [n][n_cols] fp64 in slot order (columns sorted by level)
+    int64_t n_cols = 0;
     uint8_t *raw = nullptr;       // [n*L]
     uint4 *packed = nullptr;      // [n_pad/16][G][16][planes+1] uint4
     uint8_t *aa_idx = nullptr;    // [n_pad][Lpad16] residue index (20 = gap)
@@ -190,6 +192,7 @@ struct SelectArgs {
 };
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
+int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const int32_t *perm, int64_t nq, int64_t n_cols);
 int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
                         int32_t *seg_slot, int32_t *seg_cnt);
 int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,

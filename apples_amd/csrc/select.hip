@@ -16,6 +16,7 @@
 // ordered compaction in slot order; slots are sorted by tree level, deepest first, so the sweep
 // kernel receives its leaves grouped by level together with the per-level offsets cnt_gt.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -79,6 +80,26 @@ __device__ int block_excl_scan(int flag, int *sh /*[4+]*/, int *tot) {
     return base + pre;
 }
 
+// exclusive prefix sum of an int across the block; returns this thread's offset, total in *tot
+__device__ int block_excl_scan_int(int v, int *sh /*[4+]*/, int *tot) {
+    int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    int incl = v;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        int t = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == WAVE - 1) sh[w] = incl;
+    __syncthreads();
+    int base = 0, t = 0;
+    for (int k = 0; k < APPLES_TPB / WAVE; ++k) {
+        if (k < w) base += sh[k];
+        t += sh[k];
+    }
+    *tot = t;
+    return base + incl - v;
+}
+
 #define INF_D __longlong_as_double(0x7ff0000000000000LL)
 
 __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
@@ -101,33 +122,38 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
 #define DIST(s) (gather ? row[gather[(s)]] : row[(s)])
     // representative index used to break distance ties: heap of (d, i) at Reference.py:143, or the
     // column position for the stable sort at PoolQueryWorker.py:51
-#define SLOT_KEYIDX(s) (table ? gather[(s)] : a.slot_rep[(s)])
+#define SLOT_KEYIDX(s) (a.slot_rep[(s)])  // table input: slot_rep holds the column of the slot
 
-    // ---- pass A: observations inside the threshold ------------------------------------------------
-    int cnt = 0;
-    if (single) {
-        for (int64_t s = tid; s < nm; s += APPLES_TPB) {
-            if (table && a.slot_node[s] < 0) continue;
-            double d = DIST(s);
-            if (d >= 0 && d <= thr) cnt++;
-        }
-    } else {
+    // ---- pass A: observations inside the threshold (cluster input only; for singleton clusters the
+    // compaction pass below counts them itself and is simply repeated if the top-up rule applies) ----
+    int obs = 0;
+    bool have_obs = false, topped = false;
+    if (!single) {
+        int cnt = 0;
         for (int64_t j = tid; j < a.n_reps; j += APPLES_TPB) {
             double d = DIST(a.rep_slot[j]);
             if (d >= 0 && d <= thr)
                 for (int m = a.rep_moff[j]; m < a.rep_moff[j + 1]; ++m) cnt += !(DIST(a.mem_slot[m]) < 0);
         }
+        obs = block_sum(cnt, sh_i);
+        have_obs = true;
     }
-    int obs = block_sum(cnt, sh_i);
-
+    double cut_d = -INF_D;
+    int cut_i = -1;
+    int base = 0, n_total = 0;
+    double z_d = INF_D;
+    int z_i = 0x7fffffff, z_p = 0x7fffffff, z_node = -2;
+    int32_t *o_node = a.obs_node + q * a.obs_cap;
+    double *o_dist = a.obs_dist + q * a.obs_cap;
+    int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
+    for (int round = 0; round < 2; ++round) {
     // ---- top-up: smallest (d, i) beyond the threshold until baseobs observations -------------------
     // Each thread first caches the KL smallest candidates of its own strided slice (one pass over
     // the row); every round then takes the block-wide minimum of the cache heads.  A thread whose
     // cache runs dry while its slice holds more candidates refills it with another pass over its
     // slice only.
-    double cut_d = -INF_D;
-    int cut_i = -1;
-    if (obs < a.baseobs) {
+    if (have_obs && !topped && obs < a.baseobs) {
+        topped = true;
         constexpr int KL = 4;
         double cd[KL];
         int ci[KL];
@@ -182,52 +208,69 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
         }
     }
 
-    // ---- pass B: ordered compaction of the observed leaves -----------------------------------------
-    int32_t *o_node = a.obs_node + q * a.obs_cap;
-    double *o_dist = a.obs_dist + q * a.obs_cap;
-    int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
-    int base = 0;      // emitted so far
-    int n_total = 0;   // len(obs_dist) after the self entry is removed
+    // ---- pass B: ordered compaction of the observed leaves, 4 consecutive slots per thread ----------
+    base = 0;       // emitted so far
+    n_total = 0;    // len(obs_dist) after the self entry is removed
     // first zero distance in dict order: min over (d_rep, rep index, member position)
-    double z_d = INF_D;
-    int z_i = 0x7fffffff, z_p = 0x7fffffff, z_node = -2;
-    for (int64_t s0 = 0; s0 <= nm; s0 += APPLES_TPB) {
-        int64_t s = s0 + tid;
-        int emit = 0, node = -1;
-        double dm = -1.0;
-        if (s < nm) {
-            node = a.slot_node[s];
-            dm = DIST(s);
-            bool in_dict;
-            double drep;
-            int ri, mp;
-            if (single) {
-                drep = dm; ri = SLOT_KEYIDX(s); mp = 0;
-                in_dict = (dm >= 0) && (dm <= thr || key_le(dm, ri, cut_d, cut_i));
-                if (table && node < 0) in_dict = false;
-            } else {
-                ri = a.slot_rep[s]; mp = a.slot_mpos[s];
-                drep = DIST(a.rep_slot[ri]);
-                in_dict = (drep >= 0) && (drep <= thr || key_le(drep, ri, cut_d, cut_i)) && !(dm < 0);
-            }
-            if (in_dict && (int)s != self) {
-                n_total++;
-                if (dm == 0 && (drep < z_d || (drep == z_d && (ri < z_i || (ri == z_i && mp < z_p))))) {
-                    z_d = drep; z_i = ri; z_p = mp; z_node = node;
+    z_d = INF_D; z_i = 0x7fffffff; z_p = 0x7fffffff; z_node = -2;
+    int thr_cnt = 0;  // singleton input: entries with 0 <= d <= thr (the obs_num the top-up rule looks at)
+    constexpr int E = 4;
+    for (int64_t s0 = 0; s0 <= nm; s0 += (int64_t)APPLES_TPB * E) {
+        const int64_t sb = s0 + (int64_t)tid * E;
+        int emit[E], node[E];
+        double dm[E];
+        int n_emit_l = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int64_t s = sb + e;
+            emit[e] = 0; node[e] = -1; dm[e] = -1.0;
+            if (s < nm) {
+                node[e] = a.slot_node[s];
+                dm[e] = DIST(s);
+                bool in_dict;
+                double drep;
+                int ri, mp;
+                if (single) {
+                    drep = dm[e]; ri = SLOT_KEYIDX(s); mp = 0;
+                    const bool ok = (dm[e] >= 0) && !(table && node[e] < 0);
+                    thr_cnt += ok && dm[e] <= thr;
+                    in_dict = ok && (dm[e] <= thr || key_le(dm[e], ri, cut_d, cut_i));
+                } else {
+                    ri = a.slot_rep[s]; mp = a.slot_mpos[s];
+                    drep = DIST(a.rep_slot[ri]);
+                    in_dict = (drep >= 0) && (drep <= thr || key_le(drep, ri, cut_d, cut_i)) && !(dm[e] < 0);
                 }
-                emit = node >= 0;
+                if (in_dict && (int)s != self) {
+                    n_total++;
+                    if (dm[e] == 0 && (drep < z_d || (drep == z_d && (ri < z_i || (ri == z_i && mp < z_p))))) {
+                        z_d = drep; z_i = ri; z_p = mp; z_node = node[e];
+                    }
+                    emit[e] = node[e] >= 0;
+                }
             }
+            n_emit_l += emit[e];
         }
         int tot;
-        int pre = base + block_excl_scan(emit, sh_i, &tot);
-        if (emit) { o_node[pre] = node; o_dist[pre] = dm; }
-        if (s <= nm) {  // level boundaries (virtual end slot nm has level -1)
-            int lv = (s < nm) ? a.slot_level[s] : -1;
-            int lprev = (s == 0) ? a.height + 1 : a.slot_level[s - 1];
-            for (int l = lv; l < lprev; ++l) cg[l + 1] = pre;
+        int pos = base + block_excl_scan_int(n_emit_l, sh_i, &tot);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int64_t s = sb + e;
+            if (s <= nm) {  // level boundaries (virtual end slot nm has level -1)
+                int lv = (s < nm) ? a.slot_level[s] : -1;
+                int lprev = (s == 0) ? a.height + 1 : a.slot_level[s - 1];
+                for (int l = lv; l < lprev; ++l) cg[l + 1] = pos;
+            }
+            if (emit[e]) { o_node[pos] = node[e]; o_dist[pos] = dm[e]; ++pos; }
         }
         base += tot;
     }
+    if (!have_obs) {  // singleton input, first round: was the threshold set large enough?
+        obs = block_sum(thr_cnt, sh_i);
+        have_obs = true;
+        if (obs < a.baseobs) continue;  // no: apply the top-up rule and compact again
+    }
+    break;
+    }  // round
     n_total = block_sum(n_total, sh_i);
     // pack (z_i, z_p) is not needed beyond ordering; carry the node through a second reduction
     double zd = z_d; int zi = z_i, zp = z_p;
@@ -264,26 +307,6 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     }
 #undef DIST
 #undef SLOT_KEYIDX
-}
-
-// exclusive prefix sum of an int across the block; returns this thread's offset, total in *tot
-__device__ int block_excl_scan_int(int v, int *sh /*[4+]*/, int *tot) {
-    int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-    int incl = v;
-    for (int o = 1; o < WAVE; o <<= 1) {
-        int t = __shfl_up(incl, o, WAVE);
-        if (lane >= o) incl += t;
-    }
-    __syncthreads();
-    if (lane == WAVE - 1) sh[w] = incl;
-    __syncthreads();
-    int base = 0, t = 0;
-    for (int k = 0; k < APPLES_TPB / WAVE; ++k) {
-        if (k < w) base += sh[k];
-        t += sh[k];
-    }
-    *tot = t;
-    return base + incl - v;
 }
 
 // Fast selection for all-singleton alignment input: consumes the segments the fused distance
@@ -397,6 +420,24 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     }
 }
 
+// Distance-table rows arrive in the caller's column order; the selection and the sweep want them
+// in slot order (columns sorted by tree level).  One gather pass per uploaded block, after which
+// every later pass over the rows is a coalesced stream.
+__global__ __launch_bounds__(APPLES_TPB) void k_permute_cols(const double *__restrict__ in, double *__restrict__ out,
+                                                             const int32_t *__restrict__ perm, int64_t n_cols) {
+    const int64_t q = blockIdx.y;
+    const int64_t s = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    if (s < n_cols) out[q * n_cols + s] = in[q * n_cols + perm[s]];
+}
+
+int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const int32_t *perm, int64_t nq, int64_t n_cols) {
+    if (nq == 0 || n_cols == 0) return 0;
+    hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)((n_cols + APPLES_TPB - 1) / APPLES_TPB), (unsigned)nq), dim3(APPLES_TPB),
+                       0, ctx->stream, in, out, perm, n_cols);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
     hipLaunchKernelGGL(k_select_fast, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
@@ -404,11 +445,193 @@ int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     return 0;
 }
 
+
+// Selection for singleton clusters (alignment input whose top-up rule fired, or a distance table):
+// the row is streamed once, wavefront-parallel and without workgroup barriers -- each wavefront owns
+// a contiguous quarter of the slots, compacts its keepers with ballots into the start of its own
+// quarter of the output, and the four sparse pieces are then closed up.  If fewer than `baseobs`
+// entries pass the threshold the top-up rule computes a (d, i) cut and the row is streamed again.
+__global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
+    __shared__ int sh_i[8];
+    __shared__ int sh_j[8];
+    __shared__ double sh_d[8];
+    __shared__ int sh_wcnt[4];
+    __shared__ int sh_znode;
+    const int64_t n_list = a.qcount ? (int64_t)*a.qcount : (int64_t)gridDim.x;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const int64_t nm = a.n_members;
+    const double thr = a.thr;
+    const bool table = a.table_mode != 0;
+    // quarters aligned to 64 slots
+    const int64_t per = ((nm + 4 * WAVE - 1) / (4 * WAVE)) * WAVE;
+    const int64_t w_lo = std::min<int64_t>(nm, per * wv), w_hi = std::min<int64_t>(nm, per * (wv + 1));
+    for (int64_t r = blockIdx.x; r < n_list; r += gridDim.x) {
+        const int64_t q = a.qlist ? a.qlist[r] : r;
+        const double *row = a.dist + r * a.stride;
+        const int self = a.self_slot ? a.self_slot[q] : -1;
+        int32_t *o_node = a.obs_node + q * a.obs_cap;
+        double *o_dist = a.obs_dist + q * a.obs_cap;
+        int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
+        double cut_d = -INF_D;
+        int cut_i = -1;
+        int n_total = 0, thr_cnt = 0, n_emit = 0;
+        int z_i = 0x7fffffff, z_node = -2;
+        double z_d = INF_D;
+        for (int round = 0; round < 2; ++round) {
+            n_total = 0; thr_cnt = 0; z_i = 0x7fffffff; z_node = -2; z_d = INF_D;
+            int wbase = 0;  // keepers this wavefront has written (wave-uniform)
+            for (int64_t sb = w_lo; sb < w_hi; sb += 4 * WAVE) {  // wave-uniform trip count
+                // four independent loads per lane in flight before any of them is consumed
+                double dv[4];
+                int nv_[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t s = sb + u * WAVE + lane;
+                    dv[u] = s < w_hi ? row[s] : -1.0;
+                    nv_[u] = s < w_hi ? a.slot_node[s] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t s = sb + u * WAVE + lane;
+                    bool emit = false;
+                    const double d = dv[u];
+                    const int node = nv_[u];
+                    const bool ok = (s < w_hi) && (d >= 0) && !(table && node < 0);
+                    if (ok) {
+                        const bool in_thr = d <= thr;
+                        thr_cnt += in_thr;
+                        bool in_dict = in_thr;
+                        if (!in_thr && cut_i >= 0) in_dict = key_le(d, a.slot_rep[s], cut_d, cut_i);
+                        if (in_dict && (int)s != self) {
+                            ++n_total;
+                            if (d == 0) {
+                                const int ri = a.slot_rep[s];
+                                if (ri < z_i) { z_i = ri; z_node = node; z_d = 0; }
+                            }
+                            emit = node >= 0;
+                        }
+                    }
+                    const unsigned long long m = __ballot(emit);
+                    if (emit) {
+                        const int64_t o = w_lo + wbase + __popcll(m & ((1ull << lane) - 1ull));
+                        o_node[o] = node;
+                        o_dist[o] = d;
+                    }
+                    wbase += __popcll(m);
+                }
+            }
+            if (lane == 0) sh_wcnt[wv] = wbase;
+            const int obs = block_sum(thr_cnt, sh_i);  // (barriers inside also publish sh_wcnt)
+            if (round == 0 && obs < a.baseobs) {
+                // ---- top-up (Reference.py:144 / PoolQueryWorker.py:55): smallest (d, i) beyond the threshold
+                int have = obs;
+                constexpr int KL = 4;
+                double cd[KL];
+                int ci[KL];
+                int head = 0, filled = 0;
+                bool more = true;
+                auto refill = [&](double lo_d, int lo_i) {
+                    filled = 0; head = 0;
+                    int seen = 0;
+                    for (int64_t s = tid; s < nm; s += APPLES_TPB) {
+                        if (table && a.slot_node[s] < 0) continue;
+                        const double d = row[s];
+                        const int i = a.slot_rep[s];
+                        if (!(d >= 0 && d > thr) || !key_lt(lo_d, lo_i, d, i)) continue;
+                        ++seen;
+                        int pos = filled < KL ? filled : KL;
+                        while (pos > 0 && key_lt(d, i, cd[pos - 1], ci[pos - 1])) --pos;
+                        if (pos < KL) {
+                            for (int k = (filled < KL ? filled : KL - 1); k > pos; --k) { cd[k] = cd[k - 1]; ci[k] = ci[k - 1]; }
+                            cd[pos] = d; ci[pos] = i;
+                            if (filled < KL) ++filled;
+                        }
+                    }
+                    more = seen > filled;
+                };
+                refill(cut_d, cut_i);
+                while (have < a.baseobs) {
+                    if (head == filled && more) refill(cut_d, cut_i);
+                    double bd = head < filled ? cd[head] : INF_D;
+                    int bi = head < filled ? ci[head] : 0x7fffffff, bj = 0;
+                    const int mine = bi;
+                    block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
+                    if (bi == 0x7fffffff) break;
+                    if (mine == bi && head < filled) ++head;
+                    cut_d = bd; cut_i = bi;
+                    ++have;
+                }
+                if (cut_i >= 0) continue;  // stream again with the cut
+            }
+            break;
+        }
+        // ---- close up the four pieces: piece w starts at w_lo of wavefront w ----------------------------
+        __syncthreads();
+        int cnts[4], pre[4];
+        int acc = 0;
+        for (int k = 0; k < 4; ++k) { cnts[k] = sh_wcnt[k]; pre[k] = acc; acc += cnts[k]; }
+        n_emit = acc;
+        for (int k = 1; k < 4; ++k) {
+            const int64_t src = std::min<int64_t>(nm, per * k);
+            if (src == pre[k]) continue;
+            for (int c0 = 0; c0 < cnts[k]; c0 += APPLES_TPB) {  // moving down: read, barrier, write
+                const int c = c0 + tid;
+                int nd = 0;
+                double dd = 0;
+                if (c < cnts[k]) { nd = o_node[src + c]; dd = o_dist[src + c]; }
+                __syncthreads();
+                if (c < cnts[k]) { o_node[pre[k] + c] = nd; o_dist[pre[k] + c] = dd; }
+                __syncthreads();
+            }
+        }
+        n_total = block_sum(n_total, sh_i);
+        double zd = z_d; int zi = z_i, zp = 0;
+        block_argmin3(zd, zi, zp, sh_d, sh_i, sh_j);
+        if (tid == 0) sh_znode = -2;
+        __syncthreads();
+        if (z_i == zi && zi != 0x7fffffff) sh_znode = z_node;
+        __syncthreads();
+        // per-level offsets into the level-sorted list (the sweep's cnt_gt)
+        for (int i = tid; i <= n_emit; i += APPLES_TPB) {
+            const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
+            const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
+            for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
+        }
+        if (tid == 0) {
+            apples_placement p;
+            p.edge = 0; p.flags = 0; p.error = 0.0; p.distal = 0.0; p.pendant = 0.0; p.n_obs = n_total; p.n_valid = 0;
+            int ne = n_emit;
+            if (zi != 0x7fffffff) {
+                p.flags = APPLES_F_EXACT | APPLES_F_PENDANT_INT;
+                p.edge = sh_znode;
+                if (sh_znode < 0) { p.flags |= APPLES_F_ZERO_NOT_IN_TREE; p.edge = -1; }
+                ne = 0;
+            } else if (n_total <= 2) {
+                p.flags = APPLES_F_INSUFFICIENT | APPLES_F_PENDANT_INT;
+                p.edge = -1;
+                ne = 0;
+            } else if (ne < 2) {
+                p.flags = APPLES_F_DEGENERATE | APPLES_F_PENDANT_INT;
+                p.edge = -1;
+                ne = 0;
+            }
+            a.out[q] = p;
+            a.n_obs[q] = ne;
+            if (ne > a.big_threshold && a.overflow_list) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
+        }
+        __syncthreads();
+    }
+}
+
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
     // listed mode: the list length lives on the device, so a bounded grid loops over it
     unsigned grid = a.qcount ? (unsigned)std::min<int64_t>(nq, 512) : (unsigned)nq;
-    hipLaunchKernelGGL(k_select, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, a);
+    static const bool no_stream = getenv("APPLES_NO_STREAM_SELECT") != nullptr;  // diagnostic knob
+    if (a.all_singleton && !a.gather && !no_stream)  // singleton clusters, rows in slot order: barrier-free streaming form
+        hipLaunchKernelGGL(k_select_stream, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_select, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

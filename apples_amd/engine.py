@@ -23,7 +23,7 @@ PLACEMENT_DTYPE = np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'),
 
 EXPORTS = ['apples_ctx_create', 'apples_ctx_destroy', 'apples_last_error', 'apples_set_params', 'apples_distances',
            'apples_place_from_sequences', 'apples_place_from_distances', 'apples_sweep_edges',
-           'apples_queries_upload', 'apples_queries_free', 'apples_place_resident', 'apples_fetch_placements',
+           'apples_queries_upload', 'apples_table_upload', 'apples_queries_free', 'apples_place_resident', 'apples_fetch_placements',
            'apples_distances_resident', 'apples_placements_device_ptr', 'apples_last_timing', 'apples_describe']
 
 
@@ -70,6 +70,8 @@ def load_library():
                                                 C.c_void_p]
     lib.apples_sweep_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 7
     lib.apples_queries_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.apples_table_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_int64)]
     lib.apples_queries_free.argtypes = [C.c_void_p, C.c_int64]
     lib.apples_place_resident.argtypes = [C.c_void_p, C.c_int64]
     lib.apples_fetch_placements.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
@@ -262,6 +264,14 @@ class Engine:
         h = C.c_int64()
         self._check(self.lib.apples_queries_upload(self.ctx, _ptr(q), len(q), _ptr(sr), C.byref(h)))
         return h.value, len(q)
+
+    def upload_table(self, dist, col_nodes, self_cols=None):
+        d = np.ascontiguousarray(dist, np.float64)
+        cn = np.ascontiguousarray(col_nodes, np.int32)
+        sc = np.ascontiguousarray(self_cols, np.int32) if self_cols is not None else None
+        h = C.c_int64()
+        self._check(self.lib.apples_table_upload(self.ctx, _ptr(d), d.shape[0], d.shape[1], _ptr(cn), _ptr(sc), C.byref(h)))
+        return h.value, d.shape[0]
 
     def free_queries(self, handle):
         self._check(self.lib.apples_queries_free(self.ctx, handle))

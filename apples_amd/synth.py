@@ -159,3 +159,48 @@ def noisy_distance_rows(tree, query_leaf, query_pendant, rows, seed_noise=7, rel
         noisy = true * (1.0 + rel_sd * rng.standard_normal(len(leaves)))
         out[k] = np.maximum(noisy, floor)
     return out
+
+
+class TreeIndex:
+    """Root distances and leaf-rank ranges of every node (leaves in id order are contiguous per
+    subtree because node ids are post-order numbers)."""
+
+    def __init__(self, tree):
+        n = tree.n_nodes
+        self.rd = np.zeros(n)
+        for v in range(n - 2, -1, -1):
+            self.rd[v] = self.rd[tree.parent[v]] + tree.edge_len[v]
+        cnt = tree.is_leaf.astype(np.int64)
+        for v in range(n - 1):
+            cnt[tree.parent[v]] += cnt[v]
+        rank_end = np.cumsum(tree.is_leaf)  # leaves with id <= v
+        self.last = rank_end           # exclusive end of v's leaf-rank range
+        self.first = rank_end - cnt    # inclusive start
+        self.leaf_rd = self.rd[tree.leaves]
+
+
+def fast_distance_rows(tree, index, query_leaf, query_pendant, rows, seed_noise=7, rel_sd=0.05, floor=1e-4):
+    """Vectorised form of :func:`noisy_distance_rows` for benchmark-size inputs (C5): path distance
+    from the attachment point (midpoint of the sister leaf's edge) to every leaf via
+    rd(x) + rd(l) - 2 rd(lca), the lca being constant on O(depth) contiguous leaf-rank ranges.
+    Different noise stream than the per-query generator; not used for golden fixtures."""
+    leaves = tree.leaves
+    out = np.empty((len(rows), len(leaves)))
+    rng = np.random.default_rng([seed_noise, 12345])
+    for k, qi in enumerate(rows):
+        v = int(leaves[query_leaf[qi]])
+        half = tree.edge_len[v] / 2.0
+        rdx = index.rd[v] - half            # root distance of the attachment point
+        chain = []
+        u = int(tree.parent[v])
+        while u >= 0:
+            chain.append(u)
+            u = int(tree.parent[u])
+        lca_rd = np.empty(len(leaves))
+        for a in reversed(chain):           # root first; deeper ancestors overwrite their sub-ranges
+            lca_rd[index.first[a]:index.last[a]] = index.rd[a]
+        true = rdx + index.leaf_rd - 2.0 * lca_rd
+        true[index.first[v]] = half         # the sister leaf itself
+        true = true + query_pendant[qi]
+        out[k] = np.maximum(true * (1.0 + rel_sd * rng.standard_normal(len(leaves))), floor)
+    return out

@@ -32,6 +32,8 @@ WORKLOADS = {
     'c3': (200000, 1000, 100000, False, 'OLS', 0.2),
     'c4': (50000, 500, 50000, True, 'FM', 0.2),
     'small': (2000, 500, 2048, False, 'OLS', 0.2),
+    # C5: distance-table input (-d), least-squares-only path; L is irrelevant (no alignment)
+    'c5': (200000, 0, 100000, False, 'BME', 0.2),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
@@ -53,6 +55,21 @@ def cpu_baseline(ds, protein, method, threshold, target_cpu_seconds=20.0):
             'sample': 'first %d of the %d synthetic queries on a warmed %d-process fork pool: %.2f s steady state '
                       '(pool start-up %.1f s not counted; %.3f s for one query on one core)'
                       % (n, len(ds.query_names), cores, dt, startup, t1)}
+
+
+def cpu_baseline_table(ds, D, method, threshold, target_cpu_seconds=20.0):
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import apples_oracle as orc
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    t0 = time.time()
+    orc.time_pool_table(ds.tree, ds.ref_names, ds.query_names[:1], D[:1], 1, method=method, threshold=threshold)
+    t1 = max(time.time() - t0, 1e-3)
+    n = int(min(len(D), max(2 * cores, min(8 * cores, target_cpu_seconds / t1))))
+    dt, startup, _ = orc.time_pool_table(ds.tree, ds.ref_names, ds.query_names[:n], D[:n], cores, method=method,
+                                         threshold=threshold)
+    return {'value': n / dt, 'unit': 'queries/s', 'cores': cores, 'kind': 'port',
+            'sample': 'first %d table rows on a warmed %d-process fork pool: %.2f s steady state (start-up %.1f s not '
+                      'counted; %.3f s for one query on one core)' % (n, cores, dt, startup, t1)}
 
 
 def load_traffic(workload, kernel):
@@ -97,11 +114,20 @@ def main():
     if args.queries:
         Q = args.queries
     # every rank holds the same backbone + reference; queries are rank-specific shards
-    ds = synth.make_dataset(n_leaves, L, Q, protein=protein, seed_query=3 + rank)
+    table = args.workload == 'c5'
+    ds = synth.make_dataset(n_leaves, L if not table else 4, Q, protein=protein, seed_query=3 + rank)
     nodes = np.array([ds.tree.name_to_node[n] for n in ds.ref_names], np.int32)
-    eng = Engine(ds.tree, ds.ref_seqs, nodes, protein=protein, method=method, criterion='MLSE', threshold=thr,
-                 baseobs=25, overlap=0.001, device=local_rank)
-    handle, nq = eng.upload_queries(ds.query_seqs)
+    D = None
+    if table:
+        # noisy true path distances, generated in binary (never as text)
+        index = synth.TreeIndex(ds.tree)
+        D = synth.fast_distance_rows(ds.tree, index, ds.query_leaf, ds.query_pendant, list(range(Q)), seed_noise=7 + rank)
+        eng = Engine(ds.tree, None, method=method, criterion='MLSE', threshold=thr, baseobs=25, device=local_rank)
+        handle, nq = eng.upload_table(D, nodes)
+    else:
+        eng = Engine(ds.tree, ds.ref_seqs, nodes, protein=protein, method=method, criterion='MLSE', threshold=thr,
+                     baseobs=25, overlap=0.001, device=local_rank)
+        handle, nq = eng.upload_queries(ds.query_seqs)
 
     if world > 1:
         class _DevArray:  # zero-copy view of the device-resident placement structs
@@ -144,17 +170,18 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * nq / (dt / args.steps)
-        rows = eng.n_rows
+        rows = eng.n_rows if not table else n_leaves
         placed = out['n_valid'] > 0
         mean_v = float(np.mean(out['n_valid'][placed] + 1)) if placed.any() else 0.0
         per_step = {k: v / args.steps for k, v in phases.items()}
         # algorithmic bytes per step: distance N_rows*(L+8)+L per query; sweep 332*V per query
         dist_bytes = nq * (rows * (L + 8) + L)
         sweep_bytes = 332.0 * float(np.sum(out['n_valid'][placed] + 1))
-        kernels = {
-            'jc69_distance' if not protein else 'scoredist_distance': (dist_bytes, per_step['dist_ms']),
-            'lsq_sweep': (sweep_bytes, per_step['sweep_ms']),
-        }
+        kernels = {'lsq_sweep': (sweep_bytes, per_step['sweep_ms'])}
+        if table:  # the -d filter reads every table value once
+            kernels['table_select'] = (nq * rows * 8.0, per_step['select_ms'])
+        else:
+            kernels['jc69_distance' if not protein else 'scoredist_distance'] = (dist_bytes, per_step['dist_ms'])
         dom = max(kernels, key=lambda k: kernels[k][1])
         n_launch = max(launches / args.steps, 1) if dom != 'lsq_sweep' else max(launches / args.steps, 1)
         achieved = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9 if kernels[dom][1] > 0 else 0.0
@@ -166,15 +193,17 @@ def main():
                     'all_kernels_GBps': {k: (v[0] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in kernels.items()}}
         cpu = None
         if world == 1 and not args.no_cpu:
-            cpu = cpu_baseline(ds, protein, method, thr)
+            cpu = cpu_baseline_table(ds, D, method, thr) if table else cpu_baseline(ds, protein, method, thr)
         line = {
             'metric': 'query placements/sec (whole node)', 'value': value, 'unit': 'queries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%s: synthetic %d-leaf backbone, L=%d %s, %d queries per GPU, %s/%s, -f %.1f -b 25, '
-                                   'all-singleton clusters' % (args.workload, n_leaves, L, 'aa' if protein else 'nt', nq,
-                                                              method, 'scoredist' if protein else 'JC69', thr),
+            'config': {'workload': ('%s: synthetic %d-leaf backbone, -d distance-table input (noisy path distances, binary), '
+                                    '%d queries per GPU, %s, -f %.1f -b 25' % (args.workload, n_leaves, nq, method, thr)) if table
+                       else '%s: synthetic %d-leaf backbone, L=%d %s, %d queries per GPU, %s/%s, -f %.1f -b 25, '
+                       'all-singleton clusters' % (args.workload, n_leaves, L, 'aa' if protein else 'nt', nq,
+                                                  method, 'scoredist' if protein else 'JC69', thr),
                        'n_ref': n_leaves, 'L': L, 'queries_per_gpu': nq, 'method': method,
                        'mean_observed': float(np.mean(out['n_obs'])), 'mean_swept_nodes': mean_v,
                        'placed': int(placed.sum()), 'parallelism': 'query-sharded x%d' % world},

@@ -148,6 +148,10 @@ int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *o
 int apples_queries_upload(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries,
                           const int32_t *self_row, int64_t *handle);
 int apples_queries_free(apples_ctx *ctx, int64_t handle);
+/* Upload a distance table (run_apples.py -d input, as apples_place_from_distances takes it) and
+ * keep it resident; apples_place_resident / apples_fetch_placements then work on the handle. */
+int apples_table_upload(apples_ctx *ctx, const double *dist, int64_t n_queries, int64_t n_cols,
+                        const int32_t *col_node, const int32_t *self_col, int64_t *handle);
 /* One pass of the hot path over an uploaded block; placements stay on the device until fetched. */
 int apples_place_resident(apples_ctx *ctx, int64_t handle);
 int apples_fetch_placements(apples_ctx *ctx, int64_t handle, apples_placement *out);

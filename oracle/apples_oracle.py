@@ -466,3 +466,33 @@ def time_pool(tree, ref_names, ref_seqs, query_names, query_seqs, threads, **kw)
         res = pool.starmap(_Worker.run, tasks)
         t2 = time.time()
     return t2 - t1, t1 - t0, res
+
+
+class _TableWorker:
+    tree = None
+    cols = None
+    params = None
+
+    @classmethod
+    def run(cls, name, row):
+        p = cls.params
+        obs = valid_dists(dict(zip(cls.cols, row.tolist())), cls.tree.name_to_node, p['baseobs'], p['threshold'])
+        return runquery(cls.tree, name, obs, p['method'], p['criterion'], False, False)
+
+
+def time_pool_table(tree, col_names, query_names, D, threads, method='BME', criterion='MLSE', threshold=0.2, baseobs=25):
+    """Distance-table analogue of :func:`time_pool` (run_apples.py -d path)."""
+    import multiprocessing as mp
+    import time
+    _TableWorker.tree = tree
+    _TableWorker.cols = list(col_names)
+    _TableWorker.params = dict(method=method, criterion=criterion, threshold=threshold, baseobs=baseobs)
+    tasks = [(n, D[i]) for i, n in enumerate(query_names)]
+    ctx = mp.get_context('fork')
+    t0 = time.time()
+    with ctx.Pool(threads) as pool:
+        pool.map(_noop, range(4 * threads))
+        t1 = time.time()
+        res = pool.starmap(_TableWorker.run, tasks)
+        t2 = time.time()
+    return t2 - t1, t1 - t0, res

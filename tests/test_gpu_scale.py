@@ -146,3 +146,27 @@ def test_device_resident_results_visible_to_torch_zero_copy():
             "print('ZEROCOPY_OK')\n" % ROOT)
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
     assert 'ZEROCOPY_OK' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_resident_distance_table_matches_host_entry_point():
+    """apples_table_upload + apples_place_resident (the bench's C5 path) against
+    apples_place_from_distances and the C oracle on a 2000-leaf table."""
+    d = synth.make_dataset(2000, 8, 96)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ix = synth.TreeIndex(d.tree)
+    D = synth.fast_distance_rows(d.tree, ix, d.query_leaf, d.query_pendant, list(range(96)))
+    D[5, ::3] = -1.0           # missing values
+    D[6, :] = -1.0             # nothing observed
+    D[7, 10] = 0.0             # exact hit
+    for m in ('BME', 'FM'):
+        eng = Engine(d.tree, None, method=m)
+        a = eng.place_distances(D, nodes)
+        h, n = eng.upload_table(D, nodes)
+        eng.place_resident(h)
+        b = eng.fetch(h, n)
+        assert a.tobytes() == b.tobytes()
+        want = COracle(d.tree, method=m).place_distances(D, nodes)
+        _compare(b, want, None, d, nodes, 'table %s' % m)
+        assert b[6]['flags'] & F_INSUFFICIENT and b[7]['flags'] & F_EXACT
+        eng.free_queries(h)
+        eng.close()
