@@ -267,3 +267,52 @@ def test_synthetic_distance_table_golden(m):
     for i, p in enumerate(out):
         assert_prow(placement_row(p), g['p'][i]['p'], ctx='dmat %s q%d' % (m, i))
     eng.close()
+
+
+def test_polytomies_negative_and_zero_edges_against_c_oracle():
+    """data/prot/backbone.nwk: polytomies up to degree 42, 378 negative and 702 zero branch
+    lengths.  Exercises the CSR child paths of the sweep and util.solve2_2's branch table on
+    negative edge lengths, for every method and criterion, against the C oracle."""
+    from oracle_c import COracle
+    tree = read_tree(os.path.join(DATA, 'prot', 'backbone.nwk'))
+    assert np.diff(tree.child_off).max() >= 40 and (tree.edge_len < 0).sum() > 300
+    leaves = tree.leaves
+    rng = np.random.default_rng(5)
+    nq = 48
+    D = np.full((nq, len(leaves)), -1.0)
+    for i in range(nq):
+        k = [3, 4, 25, 200, 1500, len(leaves)][i % 6]
+        # observed leaves: a contiguous clade-like run plus scattered ones
+        start = rng.integers(0, len(leaves) - k + 1)
+        sel = np.unique(np.concatenate([np.arange(start, start + (k + 1) // 2),
+                                        rng.choice(len(leaves), size=k // 2, replace=False)]))
+        D[i, sel] = rng.uniform(0.01, 1.5, size=len(sel))
+    cols = leaves.astype(np.int32)
+    for m in METHODS:
+        for c in ('MLSE', 'ME', 'HYBRID'):
+            for neg in (False, True):
+                eng = Engine(tree, None, method=m, criterion=c, negative=neg, threshold=10.0, baseobs=5)
+                got = eng.place_distances(D, cols)
+                want = COracle(tree, method=m, criterion=c, negative=neg, threshold=10.0, baseobs=5).place_distances(D, cols)
+                assert np.array_equal(got['n_obs'], want['n_obs']) and np.array_equal(got['n_valid'], want['n_valid'])
+                bad = np.nonzero(got['edge'] != want['edge'])[0]
+                # zero-length edges make exact ties between an edge and its neighbours common here; accept a
+                # different edge only when the residuals agree to 1e-12 (tie class, SURVEY H1)
+                for b in bad:
+                    assert abs(got['error'][b] - want['error'][b]) <= 1e-12 * max(abs(want['error'][b]), 1e-30), (m, c, neg, b)
+                assert len(bad) <= nq // 4, (m, c, neg, len(bad))
+                same = got['edge'] == want['edge']
+                np.testing.assert_allclose(got['pendant'][same], want['pendant'][same], rtol=1e-6, atol=1e-12)
+                np.testing.assert_allclose(got['distal'][same], want['distal'][same], rtol=1e-6, atol=1e-12)
+                eng.close()
+    # per-edge arrays on one big observed set, bit for bit (S, R, x)
+    sel = np.nonzero(D[5] >= 0)[0]
+    for m in METHODS:
+        eng = Engine(tree, None, method=m)
+        r = eng.sweep_edges(cols[sel], D[5, sel])
+        w = COracle(tree, method=m).sweep_edges(cols[sel], D[5, sel])
+        assert np.array_equal(r['valid'], w['valid']) and r['lca'] == w['lca']
+        v = r['valid']
+        assert np.array_equal(r['S'][v], w['S'][v]) and np.array_equal(r['R'][v], w['R'][v])
+        assert np.array_equal(r['x'][v], w['x'][v])
+        eng.close()
