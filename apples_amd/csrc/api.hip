@@ -238,6 +238,7 @@ void swap_bufs(Workspace &w) {
     std::swap(w.slow_list, a.slow_list); std::swap(w.slow_count, a.slow_count); std::swap(w.route_list, a.route_list);
     std::swap(w.route_count, a.route_count); std::swap(w.overflow_list, a.overflow_list);
     std::swap(w.overflow_count, a.overflow_count);
+    std::swap(w.cls_list, a.cls_list); std::swap(w.cls_count, a.cls_count);
 }
 
 void free_workspace(Workspace &w) {
@@ -246,10 +247,11 @@ void free_workspace(Workspace &w) {
         dev_free(a.dist); dev_free(a.counts); dev_free(a.obs_node); dev_free(a.obs_dist); dev_free(a.cnt_gt);
         dev_free(a.n_obs); dev_free(a.seg_slot); dev_free(a.seg_cnt); dev_free(a.dist_slow); dev_free(a.slow_list);
         dev_free(a.slow_count); dev_free(a.route_list); dev_free(a.route_count); dev_free(a.overflow_list);
-        dev_free(a.overflow_count);
+        dev_free(a.overflow_count); dev_free(a.cls_list); dev_free(a.cls_count);
     }
     dev_free(w.dist); dev_free(w.counts); dev_free(w.obs_node); dev_free(w.obs_dist); dev_free(w.cnt_gt);
-    dev_free(w.n_obs); dev_free(w.overflow_list); dev_free(w.overflow_count); dev_free(w.route_list); dev_free(w.route_count); dev_free(w.seg_slot); dev_free(w.seg_cnt);
+    dev_free(w.n_obs); dev_free(w.overflow_list); dev_free(w.overflow_count); dev_free(w.route_list); dev_free(w.route_count);
+    dev_free(w.cls_list); dev_free(w.cls_count); dev_free(w.seg_slot); dev_free(w.seg_cnt);
     dev_free(w.dist_slow); dev_free(w.slow_list); dev_free(w.slow_count);
     free_sweep(w.small);
     free_sweep(w.big);
@@ -318,13 +320,17 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         if (dev_alloc(ctx, &w.route_count, 1)) return 1;
         if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
         if (dev_alloc(ctx, &w.overflow_count, 1)) return 1;
+        if (dev_alloc(ctx, &w.cls_list, 4 * batch)) return 1;
+        if (dev_alloc(ctx, &w.cls_count, 8)) return 1;
         if (alt && set == 0) swap_bufs(w);
     }
     w.has_alt = alt;
     // small teams: one wavefront per query, up to 8 workgroups (32 waves) per CU on 256 CUs;
     // map is n_nodes ints per team (<= ~8 GiB in total), order/S/R share ~16 GiB
     int64_t nn = t.n_nodes;
-    int64_t teams = std::min<int64_t>(8192, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
+    // (with the dynamic queue the rate is flat from 2 048 to 8 192 teams: the kernel is bound by HBM
+    // random-access traffic, not by latency; 4 096 keeps the scratch footprint moderate)
+    int64_t teams = std::min<int64_t>(4096, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
@@ -427,6 +433,7 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.out = qb.out + q0;
     s.big_threshold = big_threshold(); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+    s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     s.seg_slot = w.seg_slot; s.seg_cnt = w.seg_cnt; s.node_level = ctx->tree.level;
     s.slow_list = w.slow_list; s.slow_count = w.slow_count; s.qlist = nullptr; s.qcount = nullptr;
     return s;
@@ -443,6 +450,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
     s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
     s.work_list = nullptr; s.work_count = nullptr; s.big_threshold = big_threshold();
+    s.cls_list = nullptr; s.cls_count = nullptr; s.cls_stride = w.batch; s.cursor = w.cls_count + 4;
     s.overflow_list = w.overflow_list; s.overflow_count = w.overflow_count;
     s.out = out;
     return s;
@@ -459,7 +467,11 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     SweepArgs b = sweep_args(ctx, w.big, out, false);
     b.overflow_list = nullptr;  // a big team's scratch holds the whole tree: it cannot overflow
     b.overflow_count = nullptr;
-    if (small_team != 64) return launch_sweep(ctx, b, nq, w.big.wgs, 256, st);
+    b.cursor = w.cls_count + 5;
+    if (small_team != 64) {  // diagnostic mode: workgroup-sized teams for everything
+        b.cursor = w.cls_count + 4;
+        return launch_sweep(ctx, b, nq, w.big.wgs, 256, st);
+    }
     // queries the selection kernel routed to big teams (many observed leaves) run on stream2,
     // concurrently with the wavefront-sized teams that take everything else
     HIP_TRY(ctx, hipEventRecord(ctx->ev_sel, st));
@@ -470,11 +482,16 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     if (launch_sweep(ctx, b, nq, w.big.wgs, 256, ctx->stream2)) return 1;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_big, ctx->stream2));
     HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), st));
-    if (launch_sweep(ctx, sweep_args(ctx, w.small, out, false), nq, w.small.wgs, 64, st)) return 1;
+    SweepArgs sm = sweep_args(ctx, w.small, out, false);
+    sm.cls_list = w.cls_list;  // size-class queues written by the selection kernels, largest first
+    sm.cls_count = w.cls_count;
+    sm.cursor = w.cls_count + 4;
+    if (launch_sweep(ctx, sm, nq, w.small.wgs, 64, st)) return 1;
     // whatever did not fit a small team's scratch (usually nothing)
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_big, 0));
     b.work_list = w.overflow_list;
     b.work_count = w.overflow_count;
+    b.cursor = w.cls_count + 6;
     if (launch_sweep(ctx, b, nq, w.big.wgs, 256, st)) return 1;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_bigfree, st));
     return 0;
@@ -525,6 +542,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
         if (pipelined && i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_back[set], 0));  // set free again
         hipEvent_t *e = &ev[(size_t)i * 6];
         HIP_TRY(ctx, hipMemsetAsync(w.route_count, 0, sizeof(int32_t), front));
+        HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 8 * sizeof(int32_t), front));
         if (fused) {
             HIP_TRY(ctx, hipMemsetAsync(w.slow_count, 0, sizeof(int32_t), front));
             HIP_TRY(ctx, hipEventRecord(e[0], front));
@@ -874,7 +892,9 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.out = d_out;
     s.big_threshold = big_threshold(); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+    s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     HIP_TRY(ctx, hipMemsetAsync(w.route_count, 0, sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 8 * sizeof(int32_t), ctx->stream));
     pt.flush();
     pt.begin(APPLES_T_SELECT);
     if (launch_select(ctx, s, nq)) return 1;
@@ -1021,6 +1041,7 @@ int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *o
     HIP_TRY(ctx, hipMemcpy(w.obs_dist, s_dist.data(), (size_t)n_obs * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.cnt_gt, cg.data(), cg.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.n_obs, &n_obs, 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 8 * sizeof(int32_t), ctx->stream));
     if (launch_sweep(ctx, sweep_args(ctx, w.big, d_out, true), 1, 1, 256)) { dev_free(d_out); return 1; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     apples_placement res;

@@ -77,6 +77,7 @@ struct BatchBuf {
     int32_t *cnt_gt = nullptr, *n_obs = nullptr, *seg_slot = nullptr, *seg_cnt = nullptr; double *dist_slow = nullptr;
     int32_t *slow_list = nullptr, *slow_count = nullptr, *route_list = nullptr, *route_count = nullptr;
     int32_t *overflow_list = nullptr, *overflow_count = nullptr;
+    int32_t *cls_list = nullptr, *cls_count = nullptr;
 };
 
 struct Workspace {
@@ -109,6 +110,8 @@ struct Workspace {
     int32_t *route_count = nullptr;    // [1]
     int32_t *overflow_list = nullptr;  // [batch]
     int32_t *overflow_count = nullptr; // [1]
+    int32_t *cls_list = nullptr;       // [4][batch] placeable queries by size class, largest class first
+    int32_t *cls_count = nullptr;      // [8]: 4 class counts, then 3 dynamic-queue cursors (small / routed / overflow)
     BatchBuf alt;                      // the other buffer set (swapped in by the pipelined driver)
     bool has_alt = false;
 };
@@ -185,6 +188,8 @@ struct SelectArgs {
     const int32_t *seg_slot, *seg_cnt;  // [nq][stride], [nq][stride/64]
     const int32_t *node_level;          // tree level by node id
     int32_t *slow_list, *slow_count;    // queries that need the top-up rule
+    int32_t *cls_list, *cls_count;      // size-class work lists for the small-team sweep
+    int64_t cls_stride;
     int big_threshold;                  // n_obs above this -> straight to the big-team sweep list
     int32_t *overflow_list, *overflow_count;
     // listed mode of k_select: block r handles query qlist[r] with distances in row r
@@ -209,6 +214,10 @@ struct SweepArgs {
     int big_threshold;        // small teams skip queries with more observed leaves (already listed for big teams)
     const int32_t *work_list; // queries to process (nullptr = 0..nq-1)
     const int32_t *work_count;// device count of work_list entries (nullptr = nq)
+    const int32_t *cls_list;  // size-class lists (small teams): queue index -> query, largest class first
+    const int32_t *cls_count; // [4] class counts
+    int64_t cls_stride;
+    int32_t *cursor;          // dynamic work queue: teams take the next entry with one atomic add
     int32_t *overflow_list;   // queries whose subtree exceeded `cap`
     int32_t *overflow_count;
     apples_placement *out;

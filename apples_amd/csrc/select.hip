@@ -100,6 +100,17 @@ __device__ int block_excl_scan_int(int v, int *sh /*[4+]*/, int *tot) {
     return base + incl - v;
 }
 
+
+// a placeable query joins the work list of its size class; the sweep's teams take queries from the
+// largest class first (longest-processing-time order keeps the tail of the launch short)
+__device__ __forceinline__ void enlist(const SelectArgs &a, int64_t q, int ne) {
+    if (ne <= 0) return;
+    if (ne > a.big_threshold && a.overflow_list) { a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q; return; }
+    if (!a.cls_list) return;
+    const int k = ne > 1024 ? 0 : (ne > 512 ? 1 : (ne > 256 ? 2 : 3));
+    a.cls_list[k * a.cls_stride + atomicAdd(&a.cls_count[k], 1)] = (int32_t)q;
+}
+
 #define INF_D __longlong_as_double(0x7ff0000000000000LL)
 
 __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
         }
         a.out[q] = p;
         a.n_obs[q] = n_emit;  // 0 = nothing for the sweep to do
-        if (n_emit > a.big_threshold && a.overflow_list) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
+        enlist(a, q, n_emit);
     }
     __syncthreads();  // shared scratch is reused by the next list entry
     }
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
         }
         a.out[q] = p;
         a.n_obs[q] = ne;
-        if (ne > a.big_threshold && a.overflow_list) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
+        enlist(a, q, ne);
     }
 }
 
@@ -617,7 +628,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
             }
             a.out[q] = p;
             a.n_obs[q] = ne;
-            if (ne > a.big_threshold && a.overflow_list) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
+            enlist(a, q, ne);
         }
         __syncthreads();
     }

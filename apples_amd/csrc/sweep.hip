@@ -270,13 +270,37 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
     BRec *B = reinterpret_cast<BRec *>(a.B) + team * (cap + 1);
     int32_t *grp_off = a.grp_off + team * (T.height + 4);
     double *xe = a.xe ? a.xe + team * (cap + a.leaf_cap) * XE_STRIDE : nullptr;
-    const int64_t n_work = a.work_count ? *a.work_count : nq;
-
-    for (int64_t w = team; w < n_work; w += n_teams) {
-        const int64_t q = a.work_list ? a.work_list[w] : w;
+    // work queue: size-class lists written by the selection kernel (small teams), a device-side
+    // list (routed / overflow queries), or simply 0..nq-1
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int64_t n_work;
+    if (a.cls_list) {
+        c0 = a.cls_count[0]; c1 = a.cls_count[1]; c2 = a.cls_count[2]; c3 = a.cls_count[3];
+        n_work = (int64_t)c0 + c1 + c2 + c3;
+    } else {
+        n_work = a.work_count ? *a.work_count : nq;
+    }
+    (void)n_teams;
+    __shared__ int sh_w[TEAMS_PER_WG];
+    while (true) {
+        // dynamic scheduling: one atomic add per query, broadcast to the team
+        if (tid == 0) sh_w[team_in_wg] = atomicAdd(a.cursor, 1);
+        team_sync<TEAM>();
+        const int64_t w = sh_w[team_in_wg];
+        team_sync<TEAM>();
+        if (w >= n_work) break;
+        int64_t q;
+        if (a.cls_list) {
+            if (w < c0) q = a.cls_list[w];
+            else if (w < c0 + c1) q = a.cls_list[a.cls_stride + (w - c0)];
+            else if (w < (int64_t)c0 + c1 + c2) q = a.cls_list[2 * a.cls_stride + (w - c0 - c1)];
+            else q = a.cls_list[3 * a.cls_stride + (w - c0 - c1 - c2)];
+        } else {
+            q = a.work_list ? a.work_list[w] : w;
+        }
         const int n = a.n_obs[q];
         if (n == 0) continue;
-        if (TEAM == WAVE && !a.work_list && n > a.big_threshold) continue;  // listed for a workgroup-sized team
+        if (TEAM == WAVE && !a.work_list && !a.cls_list && n > a.big_threshold) continue;  // listed for a workgroup-sized team
         const int32_t *o_node = a.obs_node + q * a.obs_cap;
         const double *o_dist = a.obs_dist + q * a.obs_cap;
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
