@@ -51,8 +51,10 @@ def build_parser():
                  help='exclude queries placed on the internal nodes in jplace file')
     # this build
     p.add_option('--clusters', dest='clusters_fp', metavar='FILE',
-                 help='TreeCluster output (name<TAB>cluster) for the reduced reference; default: every reference '
-                      'is its own cluster')
+                 help='TreeCluster output (name<TAB>cluster) to use for the reduced reference instead of the '
+                      'built-in max-diameter clustering at 1.2 x the filter threshold')
+    p.add_option('--no-clusters', dest='no_clusters', action='store_true', default=False,
+                 help='every reference sequence is its own cluster (no reduced reference)')
     p.add_option('--gpus', dest='num_gpus', type=int, default=1, metavar='NUMBER',
                  help='number of MI355X devices to shard the queries over (0 = all visible)')
     return p

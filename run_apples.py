@@ -68,7 +68,17 @@ def main(argv=None):
     else:
         start = time.time()
         ref = read_alignment(options.ref_fp, options.protein_seqs, False)  # reference rows are never masked
-        clusters = read_treecluster(options.clusters_fp) if options.clusters_fp else None
+        if options.clusters_fp:
+            clusters = read_treecluster(options.clusters_fp)
+        elif options.no_clusters:
+            clusters = None
+        else:  # as the reference: max-diameter clusters at 1.2 x the filter threshold (Reference.py:87)
+            from apples_amd import treecluster
+            clusters = treecluster.grouped(tree, options.filt_threshold * 1.2)
+            in_aln = set(ref.names)
+            missing = [n for _, g in clusters for n in g if n not in in_aln]
+            if missing:
+                raise KeyError('backbone leaf %s has no sequence in the reference alignment' % missing[0])
         reference = ReducedReference(ref, options.protein_seqs, clusters)
         logging.info('[%s] Reduced reference is prepared in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))
         if options.query_fp:

@@ -456,11 +456,20 @@ def g7():
     import tempfile
     tmp = tempfile.mkdtemp()
     stub = os.path.join(tmp, 'TreeCluster.py')
+    # The reference shells out to TreeCluster.py (apples/Reference.py:87-88), which is not installed.
+    # The stand-in writes the table of this repo's own max-diameter clustering for the requested
+    # threshold (apples_amd/treecluster.py), or all singletons when APPLES_STUB_SINGLETONS is set, so
+    # the reference's cluster handling (consensus, heap expansion) runs on exactly the clusters the
+    # build uses.
     with open(stub, 'w') as f:
-        f.write('#!%s\nimport sys\nsys.path.insert(0, %r)\nfrom apples_amd.tree import read_tree\n'
-                'a = sys.argv\nt = read_tree(a[a.index("-i") + 1])\n'
-                'out = open(a[a.index("-o") + 1], "w")\nout.write("SequenceName\\tClusterNumber\\n")\n'
-                '[out.write("%%s\\t-1\\n" %% t.labels[v]) for v in t.leaves]\nout.close()\n' % (sys.executable, ROOT))
+        f.write('#!%s\nimport os, sys\nsys.path.insert(0, %r)\nfrom apples_amd.tree import read_tree\n'
+                'from apples_amd import treecluster\n'
+                'a = sys.argv\nt = read_tree(a[a.index("-i") + 1])\nout = a[a.index("-o") + 1]\n'
+                'if os.environ.get("APPLES_STUB_SINGLETONS"):\n'
+                '    f = open(out, "w"); f.write("SequenceName\\tClusterNumber\\n")\n'
+                '    [f.write("%%s\\t-1\\n" %% t.labels[v]) for v in t.leaves]; f.close()\n'
+                'else:\n'
+                '    treecluster.write_table(t, float(a[a.index("-t") + 1]), out)\n' % (sys.executable, ROOT))
     os.chmod(stub, os.stat(stub).st_mode | stat.S_IEXEC)
     os.environ['PATH'] = tmp + os.pathsep + os.environ['PATH']
     runs = {
@@ -468,12 +477,20 @@ def g7():
                     os.path.join(DATA, 'backbone.nwk'), '-m', 'OLS', '-D', '-T', '2'],
         'aln_default': ['-s', os.path.join(DATA, 'ref.fa'), '-q', os.path.join(DATA, 'query.fa'), '-t',
                         os.path.join(DATA, 'backbone.nwk'), '-D', '-T', '2'],
+        'aln_f03_b5_BME': ['-s', os.path.join(DATA, 'ref.fa'), '-q', os.path.join(DATA, 'query.fa'), '-t',
+                           os.path.join(DATA, 'backbone.nwk'), '-m', 'BME', '-f', '0.3', '-b', '5', '-D', '-T', '2'],
+        'aln_OLS_singletons': ['-s', os.path.join(DATA, 'ref.fa'), '-q', os.path.join(DATA, 'query.fa'), '-t',
+                               os.path.join(DATA, 'backbone.nwk'), '-m', 'OLS', '-D', '-T', '2'],
         'dist_default': ['-d', os.path.join(DATA, 'dist.mat'), '-t', os.path.join(DATA, 'backbone.nwk'), '-T', '2'],
         'small_BME': ['-d', os.path.join(DATA, 'small_dist.mat'), '-t', os.path.join(DATA, 'small_backbone.nwk'),
                       '-m', 'BME', '-T', '1'],
     }
     for label, args in runs.items():
         outp = os.path.join(HERE, 'g7_cli_%s.jplace' % label)
+        if label.endswith('_singletons'):
+            os.environ['APPLES_STUB_SINGLETONS'] = '1'
+        else:
+            os.environ.pop('APPLES_STUB_SINGLETONS', None)
         old = sys.argv
         sys.argv = ['run_apples.py'] + args + ['-o', outp]
         try:

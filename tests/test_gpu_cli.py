@@ -11,9 +11,16 @@ from helpers import DATA, GOLD, ROOT, assert_prow
 
 pytestmark = pytest.mark.gpu
 
+# The reference runs behind these fixtures consumed this repo's own cluster table through a
+# TreeCluster.py stand-in (tests/golden/make_goldens.py:g7), so cluster handling -- consensus
+# representatives, heap-ordered expansion -- is compared end to end.
 RUNS = {
     'aln_OLS': ['-s', 'ref.fa', '-q', 'query.fa', '-t', 'backbone.nwk', '-m', 'OLS', '-D', '-T', '2'],
     'aln_default': ['-s', 'ref.fa', '-q', 'query.fa', '-t', 'backbone.nwk', '-D', '-T', '2'],
+    'aln_f03_b5_BME': ['-s', 'ref.fa', '-q', 'query.fa', '-t', 'backbone.nwk', '-m', 'BME', '-f', '0.3', '-b', '5', '-D',
+                       '-T', '2'],
+    'aln_OLS_singletons': ['-s', 'ref.fa', '-q', 'query.fa', '-t', 'backbone.nwk', '-m', 'OLS', '-D', '-T', '2',
+                           '--no-clusters'],
     'dist_default': ['-d', 'dist.mat', '-t', 'backbone.nwk', '-T', '2'],
     'small_BME': ['-d', 'small_dist.mat', '-t', 'small_backbone.nwk', '-m', 'BME', '-T', '1'],
 }

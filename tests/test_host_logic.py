@@ -104,3 +104,44 @@ def test_shards_cover_in_order():
             assert sh[0][0] == 0 and sh[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
             assert max(h - l for l, h in sh) - min(h - l for l, h in sh) <= 1
+
+
+def test_max_diameter_clustering_properties():
+    """apples_amd/treecluster.py (TreeCluster 'max' method restated; parity unpinned): every leaf in
+    exactly one cluster, pairwise distances inside a cluster <= t, singletons labelled -1, grouping
+    as apples/Reference.py:93-100."""
+    import itertools
+    from apples_amd import treecluster as tc, synth
+    from apples_amd.tree import read_tree
+    for path, t in ((os.path.join(DATA, 'backbone.nwk'), 0.24), (os.path.join(DATA, 'prot', 'backbone.nwk'), 0.72)):
+        tree = read_tree(path)
+        clusters = tc.max_clusters(tree, t)
+        names = [n for c in clusters for n in c]
+        assert sorted(names) == sorted(tree.labels[v] for v in tree.leaves)
+        rd = synth.TreeIndex(tree).rd
+
+        def dist(a, b):
+            anc = set()
+            u = a
+            while u >= 0:
+                anc.add(u)
+                u = tree.parent[u]
+            u = b
+            while u not in anc:
+                u = tree.parent[u]
+            return rd[a] + rd[b] - 2 * rd[u]
+        if (tree.edge_len >= 0).all():  # the diameter guarantee presumes non-negative branch lengths
+            for c in clusters:
+                ids = [tree.name_to_node[n] for n in c][:25]
+                for a, b in itertools.combinations(ids, 2):
+                    assert dist(a, b) <= t + 1e-12
+        g = tc.grouped(tree, t)
+        assert [k for k, _ in g] == sorted(k for k, _ in g)  # ids sorted as strings
+        assert sum(len(m) for _, m in g) == tree.n_leaves
+        if any(len(c) == 1 for c in clusters):
+            assert g[0][0] == '-1'
+    # a huge threshold puts everything in one cluster; zero makes every leaf a singleton
+    tree = read_tree(os.path.join(DATA, 'small_backbone.nwk'))
+    assert tc.grouped(tree, 100.0) == [('1', ['A', 'B', 'C', 'D', 'E'])]
+    g0 = tc.grouped(tree, 0.0)  # members come in the order the sweep cut them off
+    assert len(g0) == 1 and g0[0][0] == '-1' and sorted(g0[0][1]) == ['A', 'B', 'C', 'D', 'E']
