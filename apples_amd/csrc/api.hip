@@ -472,28 +472,22 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
         b.cursor = w.cls_count + 4;
         return launch_sweep(ctx, b, nq, w.big.wgs, 256, st);
     }
-    // queries the selection kernel routed to big teams (many observed leaves) run on stream2,
-    // concurrently with the wavefront-sized teams that take everything else
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_sel, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_sel, 0));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_bigfree, 0));  // big scratch free again
+    // one launch: the first w.big.wgs workgroups first serve the queries the selection kernel
+    // routed to workgroup-sized teams (many observed leaves), then all workgroups split into
+    // wavefront-sized teams for the size-class queues
     b.work_list = w.route_list;
     b.work_count = w.route_count;
-    if (launch_sweep(ctx, b, nq, w.big.wgs, 256, ctx->stream2)) return 1;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_big, ctx->stream2));
     HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), st));
     SweepArgs sm = sweep_args(ctx, w.small, out, false);
     sm.cls_list = w.cls_list;  // size-class queues written by the selection kernels, largest first
     sm.cls_count = w.cls_count;
     sm.cursor = w.cls_count + 4;
-    if (launch_sweep(ctx, sm, nq, w.small.wgs, 64, st)) return 1;
+    if (launch_sweep_mixed(ctx, sm, b, nq, w.small.wgs, w.big.wgs, st)) return 1;
     // whatever did not fit a small team's scratch (usually nothing)
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_big, 0));
     b.work_list = w.overflow_list;
     b.work_count = w.overflow_count;
     b.cursor = w.cls_count + 6;
     if (launch_sweep(ctx, b, nq, w.big.wgs, 256, st)) return 1;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_bigfree, st));
     return 0;
 }
 
@@ -531,7 +525,6 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
     HIP_TRY(ctx, hipEventCreate(&e_start));
     HIP_TRY(ctx, hipEventCreate(&e_stop));
     HIP_TRY(ctx, hipEventRecord(e_start, front));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_bigfree, front));
     if (pipelined) HIP_TRY(ctx, hipStreamWaitEvent(back, e_start, 0));
     int launches = 0;
     for (int64_t i = 0; i < n_sub; ++i) {
@@ -586,7 +579,6 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
     }
     HIP_TRY(ctx, hipEventRecord(e_stop, front));
     HIP_TRY(ctx, hipEventSynchronize(e_stop));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = 0;
     for (int64_t i = 0; i < n_sub; ++i) {
         hipEvent_t *e = &ev[(size_t)i * 6];
@@ -629,6 +621,7 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         return fail();
     }
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return fail(); }
+    // stream2 is spare (the routed big-team sweep now shares one launch with the small teams)
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
         hipStreamCreate(&ctx->stream3) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_front[0], hipEventDisableTiming) != hipSuccess ||
@@ -1000,7 +993,6 @@ static int run_table_block(apples_ctx *ctx, QueryBlock &qb) {
     }
     HIP_TRY(ctx, hipEventRecord(e_stop, ctx->stream));
     HIP_TRY(ctx, hipEventSynchronize(e_stop));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     pt.flush();
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e_start, e_stop);

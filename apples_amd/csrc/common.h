@@ -223,3 +223,5 @@ struct SweepArgs {
     apples_placement *out;
 };
 int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team, hipStream_t stream = nullptr);
+int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,
+                       hipStream_t st);

@@ -28,6 +28,8 @@
 // cited source line, children/siblings in file order and the parent term last.
 // `x ** 2` is libm pow in the reference and x*x here (<= 1 ulp apart).
 // HBM-bound by design: ~60 fp64 flops against ~330 B per node; no MFMA.
+#include <algorithm>
+
 #include "common.h"
 
 #define WAVE 64
@@ -245,7 +247,7 @@ __device__ __forceinline__ void load_kid(int kd, const ARec *__restrict__ A, con
 // whose subtree does not fit a team's scratch (`cap` internal nodes) are appended to an overflow
 // list that a second launch with full-size scratch takes.
 template <int M, int TEAM>
-__global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
+__device__ void sweep_team(const SweepArgs &a, int64_t nq) {
     constexpr int TEAMS_PER_WG = APPLES_TPB / TEAM;
     constexpr bool BME = (M == APPLES_BME);
     __shared__ int sh_cnt_all[TEAMS_PER_WG][4];
@@ -602,6 +604,42 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
         for (int j = tid; j < n; j += TEAM) map[o_node[j]] = 0;
         team_sync<TEAM>();
     }
+}
+
+template <int M, int TEAM>
+__global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
+    sweep_team<M, TEAM>(a, nq);
+}
+
+// One launch for a whole batch: the first `n_big` workgroups first serve, as workgroup-sized teams
+// with full-size scratch, the queries the selection kernel routed to them (many observed leaves:
+// the longest jobs start first), then every workgroup splits into four wavefront-sized teams that
+// drain the size-class queues.
+template <int M>
+__global__ __launch_bounds__(APPLES_TPB) void k_sweep_mixed(SweepArgs small, SweepArgs big, int64_t nq, int n_big) {
+    if ((int)blockIdx.x < n_big) {
+        sweep_team<M, APPLES_TPB>(big, nq);
+        __syncthreads();
+    }
+    sweep_team<M, WAVE>(small, nq);
+}
+
+int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,
+                       hipStream_t st) {
+    if (nq == 0) return 0;
+    int64_t need = (nq + 3) / 4;
+    // every workgroup indexes the small teams' scratch by blockIdx.x, so the grid never exceeds `wgs`;
+    // big-team duty falls to the first min(n_big, grid) workgroups
+    dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(need, std::min<int64_t>(n_big, nq)), wgs)), block(APPLES_TPB);
+    if (n_big > (int)grid.x) n_big = (int)grid.x;
+    switch (small.method) {
+        case APPLES_FM: hipLaunchKernelGGL((k_sweep_mixed<APPLES_FM>), grid, block, 0, st, small, big, nq, n_big); break;
+        case APPLES_BME: hipLaunchKernelGGL((k_sweep_mixed<APPLES_BME>), grid, block, 0, st, small, big, nq, n_big); break;
+        case APPLES_BE: hipLaunchKernelGGL((k_sweep_mixed<APPLES_BE>), grid, block, 0, st, small, big, nq, n_big); break;
+        default: hipLaunchKernelGGL((k_sweep_mixed<APPLES_OLS>), grid, block, 0, st, small, big, nq, n_big); break;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
 }
 
 template <int TEAM>
