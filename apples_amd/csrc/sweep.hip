@@ -606,8 +606,12 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
     }
 }
 
+#ifndef APPLES_SWEEP_WAVES
+#define APPLES_SWEEP_WAVES 1
+#endif
+
 template <int M, int TEAM>
-__global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
+__global__ __launch_bounds__(APPLES_TPB, APPLES_SWEEP_WAVES) void k_sweep(SweepArgs a, int64_t nq) {
     sweep_team<M, TEAM>(a, nq);
 }
 
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sweep(SweepArgs a, int64_t nq) {
 // the longest jobs start first), then every workgroup splits into four wavefront-sized teams that
 // drain the size-class queues.
 template <int M>
-__global__ __launch_bounds__(APPLES_TPB) void k_sweep_mixed(SweepArgs small, SweepArgs big, int64_t nq, int n_big) {
+__global__ __launch_bounds__(APPLES_TPB, APPLES_SWEEP_WAVES) void k_sweep_mixed(SweepArgs small, SweepArgs big, int64_t nq, int n_big) {
     if ((int)blockIdx.x < n_big) {
         sweep_team<M, APPLES_TPB>(big, nq);
         __syncthreads();
