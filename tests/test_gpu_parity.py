@@ -316,3 +316,65 @@ def test_polytomies_negative_and_zero_edges_against_c_oracle():
         assert np.array_equal(r['S'][v], w['S'][v]) and np.array_equal(r['R'][v], w['R'][v])
         assert np.array_equal(r['x'][v], w['x'][v])
         eng.close()
+
+
+def _random_newick(rng, n_leaves, shape):
+    """Random rooted tree text: 'random' joins, 'caterpillar', or 'bushy' (polytomies), with a few
+    zero, tiny and missing branch lengths."""
+    def blen():
+        u = rng.random()
+        if u < 0.08:
+            return ':0'
+        if u < 0.12:
+            return ':%.3g' % (rng.random() * 1e-7)
+        return ':%.5f' % rng.exponential(0.05)
+    nodes = ['L%d%s' % (i, blen()) for i in range(n_leaves)]
+    if shape == 'caterpillar':
+        cur = nodes[0]
+        for nd in nodes[1:]:
+            cur = '(%s,%s)%s' % (cur, nd, blen())
+        return cur.rsplit(':', 1)[0] + ';'
+    while len(nodes) > 1:
+        k = 2 if shape == 'random' else int(rng.integers(2, 6))
+        k = min(k, len(nodes))
+        idx = sorted(rng.choice(len(nodes), size=k, replace=False), reverse=True)
+        kids = [nodes.pop(i) for i in idx]
+        nodes.append('(%s)%s' % (','.join(kids), blen()))
+    return nodes[0].rsplit(':', 1)[0] + ';'
+
+
+def test_random_trees_per_edge_bit_parity_with_c_oracle():
+    """Many small random trees (binary, caterpillar, polytomous; zero and tiny branch lengths) and
+    random observed sets of every size from 2 up: valid set, LCA, S, R and the 2x2 solutions must
+    equal the C oracle's bit for bit, placements edge for edge (ties resolved by residual)."""
+    from oracle_c import COracle
+    from apples_amd.tree import parse_newick
+    rng = np.random.default_rng(2024)
+    n_cases = 0
+    for shape in ('random', 'caterpillar', 'bushy'):
+        for n_leaves in (3, 4, 7, 16, 61, 200):
+            tree = parse_newick(_random_newick(rng, n_leaves, shape))
+            leaves = tree.leaves
+            eng = Engine(tree, None, method='OLS')
+            for m in METHODS:
+                eng.set_options(method=m, criterion='MLSE')
+                co = COracle(tree, method=m)
+                for k in sorted({2, 3, min(5, n_leaves), n_leaves // 2 + 1, n_leaves}):
+                    if k > n_leaves or k < 2:
+                        continue
+                    sel = np.sort(rng.choice(n_leaves, size=k, replace=False))
+                    D = rng.uniform(0.02, 1.0, size=k)
+                    r = eng.sweep_edges(leaves[sel], D)
+                    w = co.sweep_edges(leaves[sel], D)
+                    assert np.array_equal(r['valid'], w['valid']) and r['lca'] == w['lca'], (shape, n_leaves, m, k)
+                    v = r['valid']
+                    assert np.array_equal(r['S'][v], w['S'][v]), (shape, n_leaves, m, k)
+                    assert np.array_equal(r['R'][v], w['R'][v]), (shape, n_leaves, m, k)
+                    assert np.array_equal(r['x'][v], w['x'][v]), (shape, n_leaves, m, k)
+                    assert r['placement']['n_valid'] == w['placement']['n_valid']
+                    if r['placement']['edge'] != w['placement']['edge']:
+                        e1, e2 = r['err'][r['placement']['edge']], w['err'][w['placement']['edge']]
+                        assert abs(e1 - e2) <= 1e-12 * max(abs(e2), 1e-30), (shape, n_leaves, m, k)
+                    n_cases += 1
+            eng.close()
+    assert n_cases > 250
