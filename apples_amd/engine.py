@@ -110,7 +110,7 @@ def _ptr(a):
 class Engine:
     """One device context: resident tree + packed reference alignment + workspaces."""
 
-    LUT_MAX_LEN = 4096
+    LUT_MAX_LEN = 8192  # 33.6 M entries (268 MB) at most; longer alignments use the device log
 
     def __init__(self, tree, ref_seqs=None, ref_nodes=None, clusters=None, protein=False, method='FM',
                  criterion='MLSE', negative=False, threshold=0.2, baseobs=25, overlap=0.001, device=0,
