@@ -58,9 +58,11 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
         r.nchild = t->child_off[i + 1] - t->child_off[i];
         r.c0 = r.nchild > 0 ? t->child_idx[r.child_off] : -1;
         r.c1 = r.nchild > 1 ? t->child_idx[r.child_off + 1] : -1;
-        r.level = t->level[i];
+        r.prev_sib = -1;
         r.e = t->edge_len[i];
     }
+    for (int i = 0; i < t->n_nodes; ++i)
+        for (int c = t->child_off[i] + 1; c < t->child_off[i + 1]; ++c) rec[t->child_idx[c]].prev_sib = t->child_idx[c - 1];
     if (dev_upload(ctx, &d.rec, rec.data(), t->n_nodes)) return 1;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -449,6 +451,8 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.leaf_cap = sw.leaf_cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
     s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
+    static const int dbg = getenv("APPLES_SWEEP_DEBUG_PHASE") ? atoi(getenv("APPLES_SWEEP_DEBUG_PHASE")) : 0;
+    s.debug_phase = dbg;
     s.work_list = nullptr; s.work_count = nullptr; s.big_threshold = big_threshold();
     s.cls_list = nullptr; s.cls_count = nullptr; s.cls_stride = w.batch; s.cursor = w.cls_count + 4;
     s.overflow_list = w.overflow_list; s.overflow_count = w.overflow_count;

@@ -16,7 +16,7 @@ struct __attribute__((aligned(32))) NodeRec {
     int32_t c0, c1;     // first two children in file order (-1 if absent)
     int32_t nchild;
     int32_t child_off;  // into child_idx (all children, for polytomies)
-    int32_t level;
+    int32_t prev_sib;   // previous sibling in file order, -1 for a first child
     double e;           // edge length
 };
 
@@ -209,6 +209,7 @@ struct SweepArgs {
     int32_t *map, *grp_off; void *A, *B; double *xe;
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
+    int debug_phase;          // timing experiments only: 1 = stop after the bottom-up pass
     int64_t cap;              // internal nodes of A/B/xe scratch per team
     int64_t leaf_cap;         // observed leaves a team's xe area can hold beyond `cap`
     int big_threshold;        // small teams skip queries with more observed leaves (already listed for big teams)

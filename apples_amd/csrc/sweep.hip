@@ -313,6 +313,20 @@ __device__ __forceinline__ void load_kid(int kd, const ARec *__restrict__ A, con
     }
 }
 
+// Which child registers the parent in the compact order?  The first valid child in file order: a
+// node claims its parent iff none of its earlier siblings is in the subtree.  Deterministic, and a
+// plain load where an atomic compare-and-swap used to sit on every level's critical path.
+__device__ __forceinline__ bool claims_parent(const NodeRec &nr, const NodeRec *__restrict__ NR,
+                                              const int32_t *__restrict__ map) {
+    if (nr.parent < 0) return false;
+    int s = nr.prev_sib;
+    while (s >= 0) {
+        if (map[s] != 0) return false;
+        s = NR[s].prev_sib;
+    }
+    return true;
+}
+
 // One team = TEAM threads working on one query: a wavefront (TEAM == 64, four independent teams
 // per workgroup; the level loops need no s_barrier) or the whole workgroup (TEAM == 256).  Queries
 // whose subtree does not fit a team's scratch (`cap` internal nodes) are appended to an overflow
@@ -389,6 +403,10 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
         int base = 0, n_par = 0, G = 0, lca = -1, lca_claimed = 0;
         bool overflow = false;
         if (tid < 3) sh_cnt[tid] = 0;
+        // name every observed leaf in the map first: map[leaf] = -(j+2).  With that, "is my earlier
+        // sibling in the subtree?" is answerable inside a level step without atomics (an internal
+        // sibling was claimed one step earlier, a leaf sibling is marked here).
+        for (int j = tid; j < n; j += TEAM) map[o_node[j]] = -(j + 2);
         team_sync<TEAM>();
         while (true) {
             const int lo = cg[lvl + 1], hi = cg[lvl];  // observed leaves of this level: obs[lo, hi)
@@ -402,16 +420,15 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
             if (tid == 0) { grp_off[G] = base; sh_cnt[(G + 1) % 3] = 0; }
             int *next_cnt = &sh_cnt[G % 3];
             const int next_base = base + n_par;
-            // (a) observed leaves of this level: name them in the map and claim their parents
+            // (a) observed leaves of this level: the first valid child registers the parent
             for (int k = tid; k < n_leaf; k += TEAM) {
                 const int j = lo + k;
                 const int v = o_node[j];
-                map[v] = -(j + 2);
-                const int p = NR[v].parent;
-                if (p >= 0 && atomicCAS(&map[p], 0, -1) == 0) {
+                const NodeRec nr = NR[v];
+                if (claims_parent(nr, NR, map)) {
                     const int nidx = next_base + atomicAdd(next_cnt, 1);
-                    A[nidx].node = p;
-                    map[p] = nidx + 1;
+                    A[nidx].node = nr.parent;
+                    map[nr.parent] = nidx + 1;
                 }
             }
             // (b) internal nodes of this level (claimed from the level below): S tuple from the valid
@@ -422,11 +439,13 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                 const bool active = k < n_par;
                 ARec ar;
                 int parent = -1;
+                bool claimer = false;
                 if (active) {
                     ar.node = A[idx].node;
                     ar.pad = 0;
                     const NodeRec nr = NR[ar.node];
                     parent = nr.parent;
+                    claimer = claims_parent(nr, NR, map);
 #pragma unroll
                     for (int c = 0; c < 6; ++c) ar.S[c] = 0;
                     int kk[2];
@@ -477,7 +496,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (active && parent >= 0 && atomicCAS(&map[parent], 0, -1) == 0) {
+                if (claimer) {
                     const int nidx = next_base + atomicAdd(next_cnt, 1);
                     A[nidx].node = parent;
                     map[parent] = nidx + 1;
@@ -518,7 +537,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
         Sol best_sol;
         double best_e = 0;
         best_sol.x1 = best_sol.x2 = best_sol.err = 0; best_sol.x1_int = 0; best_sol.x1n = best_sol.x2n = 0;
-        for (int g = G; g >= 1; --g) {
+        for (int g = (a.debug_phase == 1 ? 0 : G); g >= 1; --g) {
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
             for (int idx = g0 + tid; idx < g1; idx += TEAM) {
                 const bool is_lca = (idx == VI);
