@@ -45,6 +45,8 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
     int h = 0;
     for (int i = 0; i < t->n_nodes; ++i) h = std::max(h, t->level[i]);
     d.height = h;
+    d.max_children = 0;
+    for (int i = 0; i < t->n_nodes; ++i) d.max_children = std::max(d.max_children, t->child_off[i + 1] - t->child_off[i]);
     if (dev_upload(ctx, &d.parent, t->parent, t->n_nodes)) return 1;
     if (dev_upload(ctx, &d.edge_len, t->edge_len, t->n_nodes)) return 1;
     if (dev_upload(ctx, &d.child_off, t->child_off, t->n_nodes + 1)) return 1;
@@ -228,7 +230,7 @@ int big_threshold() {
 }
 
 void free_sweep(Workspace::Sweep &sw) {
-    dev_free(sw.map); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
+    dev_free(sw.map); dev_free(sw.ver); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
     sw = Workspace::Sweep();
 }
 
@@ -269,10 +271,12 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
     if (dev_alloc(ctx, &sw.map, sw.teams * t.n_nodes)) return 1;
     HIP_TRY(ctx, hipMemsetAsync(sw.map, 0, (size_t)sw.teams * t.n_nodes * 4, ctx->stream));
     if (dev_alloc(ctx, &sw.grp_off, sw.teams * (int64_t)(t.height + 4))) return 1;
+    if (dev_alloc(ctx, &sw.ver, sw.teams)) return 1;
+    HIP_TRY(ctx, hipMemsetAsync(sw.ver, 0, (size_t)sw.teams * 4, ctx->stream));
     HIP_TRY(ctx, hipMalloc(&sw.A, (size_t)sw.teams * (cap + 1) * 64));
-    HIP_TRY(ctx, hipMalloc(&sw.B, (size_t)sw.teams * (cap + 1) * 64));
+    if (t.max_children > 2) HIP_TRY(ctx, hipMalloc(&sw.B, (size_t)sw.teams * (cap + 1) * 48));
     if (xe)
-        if (dev_alloc(ctx, &sw.xe, sw.teams * (cap + leaf_cap) * 11)) return 1;
+        if (dev_alloc(ctx, &sw.xe, sw.teams * (cap + leaf_cap) * 18)) return 1;
     return 0;
 }
 
@@ -336,7 +340,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
-    int64_t per_node = 64 + 64 + (xe ? 2 * 88 : 0);
+    int64_t per_node = 64 + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
     if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold())), xe)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
@@ -447,6 +451,9 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.tree = ctx->tree;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.map = sw.map; s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
+    s.map_ver = sw.ver;
+    s.map_bits = 1;
+    while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
     s.cap = sw.cap;
     s.leaf_cap = sw.leaf_cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
@@ -1051,19 +1058,19 @@ int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *o
     // internal nodes: compact records; observed leaves: rebuilt from the level-sorted list
     std::vector<int32_t> order(V);
     std::vector<double> hS((size_t)V * 6), hR((size_t)V * 6), hx((size_t)V * 5), ha((size_t)std::max(VI, 1) * 8);
-    std::vector<double> hxi((size_t)std::max(VI, 1) * 11), hxl((size_t)n_obs * 11);
+    std::vector<double> hxi((size_t)std::max(VI, 1) * 18), hxl((size_t)n_obs * 18);
     HIP_TRY(ctx, hipMemcpy(ha.data(), w.big.A, (size_t)VI * 64, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(hxi.data(), w.big.xe, (size_t)VI * 88, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(hxl.data(), w.big.xe + (size_t)w.big.cap * 11, (size_t)n_obs * 88, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hxi.data(), w.big.xe, (size_t)VI * 144, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hxl.data(), w.big.xe + (size_t)w.big.cap * 18, (size_t)n_obs * 144, hipMemcpyDeviceToHost));
     std::vector<int32_t> level_h;
     for (int i = 0; i < V; ++i) {
         const double *xr;
         if (i < VI) {
-            memcpy(&hS[(size_t)i * 6], &ha[(size_t)i * 8], 48);
+            memcpy(&hS[(size_t)i * 6], &hxi[(size_t)i * 18 + 11], 48);  // the record's tuple is R by now
             int32_t nd;
             memcpy(&nd, reinterpret_cast<const char *>(&ha[(size_t)i * 8]) + 56, 4);
             order[i] = nd;
-            xr = &hxi[(size_t)i * 11];
+            xr = &hxi[(size_t)i * 18];
         } else {
             int j = i - VI;
             order[i] = s_node[j];
@@ -1074,7 +1081,7 @@ int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *o
             if (m == APPLES_FM) { S6[4] = 1.0 / D; S6[5] = 1.0 / (D * D); }
             else if (m == APPLES_BE) { S6[4] = D; S6[5] = 1.0 / D; }
             else { S6[4] = D * D; S6[5] = D; }
-            xr = &hxl[(size_t)j * 11];
+            xr = &hxl[(size_t)j * 18];
         }
         memcpy(&hx[(size_t)i * 5], xr, 40);
         memcpy(&hR[(size_t)i * 6], xr + 5, 48);

@@ -23,6 +23,7 @@ struct __attribute__((aligned(32))) NodeRec {
 struct DevTree {
     int32_t n_nodes = 0;
     int32_t height = 0;  // max level
+    int32_t max_children = 0;
     int32_t *parent = nullptr;
     double *edge_len = nullptr;
     int32_t *child_off = nullptr;
@@ -95,11 +96,12 @@ struct Workspace {
     struct Sweep {
         int32_t wgs = 0;          // workgroups of the launch
         int64_t teams = 0, cap = 0, leaf_cap = 0;
-        int32_t *map = nullptr;   // [teams][n_nodes] node -> compact index + 1 (0 = not in subtree)
+        int32_t *map = nullptr;   // [teams][n_nodes] node -> tagged descriptor (sweep.hip NodeMap)
+        int32_t *ver = nullptr;   // [teams] last tag used in the team's map
         int32_t *grp_off = nullptr; // [teams][height+4] level groups in compact order, deepest first
-        void *A = nullptr;        // [teams][cap+1] ARec (64 B): S tuple, edge length, node, leaf flag
-        void *B = nullptr;        // [teams][cap+1] BRec (64 B): R tuple, first two valid children
-        double *xe = nullptr;     // [teams][cap][5] x_1,x_2,x_1_neg,x_2_neg,err (HYBRID / inspection)
+        void *A = nullptr;        // [teams][cap+1] Rec (64 B): S then R tuple, first two valid children, node
+        void *B = nullptr;        // [teams][cap+1][6] R values in waiting; trees with polytomies only
+        double *xe = nullptr;     // [teams][cap+leaf_cap][18] per-edge x, err, R, S (HYBRID / inspection)
     } small, big;
     int32_t *seg_slot = nullptr;       // [batch][stride] fused path: slots of the kept entries
     int32_t *seg_cnt = nullptr;        // [batch][stride/64]
@@ -207,6 +209,8 @@ struct SweepArgs {
     DevTree tree;
     const int32_t *obs_node; const double *obs_dist; int64_t obs_cap; const int32_t *cnt_gt; const int32_t *n_obs;
     int32_t *map, *grp_off; void *A, *B; double *xe;
+    int32_t *map_ver;         // [teams] version tags of the maps
+    int map_bits;             // payload bits of a map entry; the tag sits above them
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
     int debug_phase;          // timing experiments only: 1 = stop after the bottom-up pass

@@ -7,22 +7,24 @@
 //   placement_per_edge apples/OLS.py:83-97 + apples/util.py:6-54   -> fused into the top-down loop
 //   error_per_edge     apples/OLS.py:100-128 ... -> fused into the top-down loop
 //   placement          apples/Algorithm.py:62-101 -> wavefront/LDS arg-min over the candidates
-//   unroll_changes     apples/Subtree.py:72-76   -> map[] entries cleared
+//   unroll_changes     apples/Subtree.py:72-76   -> the team's map tag is incremented
 //
 // The reference pops the deepest frontier node, marks it valid and pushes its parent until one
 // node (the LCA) is left.  Level-synchronous form: the nodes at level l are the observed leaves
-// of that level (contiguous in the level-sorted obs list) plus the parents claimed from level
+// of that level (contiguous in the level-sorted obs list) plus the parents registered from level
 // l+1; the loop stops when a level holds a single node and no shallower leaves remain.
 //
-// Data layout (the kernel is bound by HBM/L2 misses on scattered 64-byte records, so records are
-// few and whole): NodeRec (32 B, tree constant: parent, first two children, edge length); per
-// team and per INTERNAL subtree node, in compact order of discovery, ARec (64 B: S tuple, edge
-// length, node id) and BRec (64 B: R tuple, descriptors of the first two valid children).
-// Observed leaves get no record: a leaf is named by its position j in the query's level-sorted
-// observation list (map[leaf] = -(j+2), child descriptor < 0) and its tuple is rebuilt from the
-// distance whenever a parent needs it.  The top-down pass is parent-centric: a node forms each
-// valid child's R (siblings in file order, then its own lifted R), solves that child's 2x2
-// system and residual, and stores R only for children that are internal.
+// Data layout (the kernel is bound by HBM/L2 misses on scattered 64-byte lines, so lines are few
+// and whole): NodeRec (32 B, tree constant: parent, first two children, previous sibling, edge
+// length); per team and per INTERNAL subtree node, in compact order of discovery, one Rec (64 B:
+// a tuple, descriptors of the first two valid children, node id).  The tuple is S after the
+// bottom-up pass and is overwritten with R by the node's parent on the way down.  Observed leaves
+// get no record: a leaf is named by its position j in the query's level-sorted observation list
+// (child descriptor -(j+2)) and its tuple is rebuilt from the distance whenever a parent needs it.
+// The top-down pass is parent-centric: a node forms each valid child's R (siblings in file order,
+// then its own lifted R), solves that child's 2x2 system and residual, and stores R only for
+// children that are internal.  The node -> descriptor map carries a per-query tag, so it is
+// never cleared.
 //
 // Bit parity: fp64, compiled with -ffp-contract=off; every sum is taken in the order of the
 // cited source line, children/siblings in file order and the parent term last.
@@ -254,74 +256,68 @@ __device__ __forceinline__ void team_sync() {
     else __syncthreads();
 }
 
-struct __attribute__((aligned(64))) ARec {
-    double S[6];
-    double e;
+// One 64-byte record per INTERNAL subtree node, in compact order of discovery.  T holds the node's
+// S tuple after the bottom-up pass; on the way down the parent overwrites it with the node's R
+// tuple (S is dead once the parent has formed the siblings' R values and solved this edge), so a
+// node costs one line of scratch, written once per pass.
+struct __attribute__((aligned(64))) Rec {
+    double T[6];
+    int32_t k0, k1;  // first two valid children: > 0 internal (compact index + 1), <= -2 leaf (-(j+2))
     int32_t node;
-    int32_t pad;
+    uint32_t meta;   // number of valid children | META_POLY | META_K0C1
 };
-struct __attribute__((aligned(64))) BRec {
-    double R[6];
-    int32_t k0, k1, nk, poly;  // child descriptors: > 0 internal (compact index + 1), <= -2 leaf (-(j+2))
-};
+#define META_POLY 0x40000000u  // more than two children in the tree: walk the CSR list
+#define META_K0C1 0x80000000u  // the only valid child is the node's second child
+#define META_NK 0x00ffffffu
 
-#define XE_STRIDE 11  // x_1, x_2, x_1_neg, x_2_neg, err, R[6]  (HYBRID / inspection only)
+#define XE_STRIDE 18  // x_1, x_2, x_1_neg, x_2_neg, err, R[6], S[6], x_1-is-int  (HYBRID / inspection only)
 
-// valid children of a node (tree record nr) in file order -> descriptors; returns their number and
-// the first two in k[0], k[1]
-__device__ __forceinline__ int valid_kids2(const NodeRec &nr, const int32_t *__restrict__ map,
-                                           const int32_t *__restrict__ child_idx, int *k) {
-    int nk = 0;
-    k[0] = k[1] = 0;
-    if (nr.nchild <= 2) {
-        if (nr.nchild >= 1) { int m = map[nr.c0]; if (m != 0) k[nk++] = m; }
-        if (nr.nchild >= 2) { int m = map[nr.c1]; if (m != 0) k[nk++] = m; }
-    } else {
-        for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
-            int m = map[child_idx[ci]];
-            if (m != 0) { if (nk < 2) k[nk] = m; ++nk; }
-        }
+// Per-team node -> descriptor table with a version tag in the high bits: an entry counts only if
+// its tag is the current query's, so nothing has to be cleared between queries
+// (unroll_changes, apples/Subtree.py:72-76, becomes a counter increment).
+struct NodeMap {
+    int32_t *m;
+    uint32_t ver;
+    int vb;
+    __device__ __forceinline__ int get(int v) const {
+        const uint32_t w = (uint32_t)m[v];
+        if ((w >> vb) != ver) return 0;
+        const uint32_t p = w & ((1u << vb) - 1u);
+        return (p & 1u) ? -(int)(p >> 1) - 1 : (int)(p >> 1);
     }
-    return nk;
-}
+    __device__ __forceinline__ void set_internal(int v, int idx) { m[v] = (int32_t)((ver << vb) | ((uint32_t)(idx + 1) << 1)); }
+    __device__ __forceinline__ void set_leaf(int v, int j) { m[v] = (int32_t)((ver << vb) | ((uint32_t)(j + 1) << 1) | 1u); }
+};
 
 struct Kid {
     double S[6];
     double e;
     int32_t node;
-    int32_t leaf;
 };
 
-// a child's S tuple, edge length and node id from its descriptor
+// a child's S tuple and edge length from its descriptor and node id
 template <int M>
-__device__ __forceinline__ void load_kid(int kd, const ARec *__restrict__ A, const NodeRec *__restrict__ NR,
-                                         const int32_t *__restrict__ o_node, const double *__restrict__ o_dist,
-                                         Kid &k) {
+__device__ __forceinline__ void load_kid(int kd, int node, const Rec *__restrict__ rec, const NodeRec *__restrict__ NR,
+                                         const double *__restrict__ o_dist, Kid &k) {
+    k.node = node;
+    k.e = NR[node].e;
     if (kd > 0) {
-        const ARec &r = A[kd - 1];
+        const Rec &r = rec[kd - 1];
 #pragma unroll
-        for (int x = 0; x < 6; ++x) k.S[x] = r.S[x];
-        k.e = r.e;
-        k.node = r.node;
-        k.leaf = 0;
+        for (int x = 0; x < 6; ++x) k.S[x] = r.T[x];
     } else {
-        const int j = -kd - 2;
-        k.node = o_node[j];
-        leaf_tuple<M>(o_dist[j], k.S);
-        k.e = NR[k.node].e;
-        k.leaf = 1;
+        leaf_tuple<M>(o_dist[-kd - 2], k.S);
     }
 }
 
 // Which child registers the parent in the compact order?  The first valid child in file order: a
 // node claims its parent iff none of its earlier siblings is in the subtree.  Deterministic, and a
-// plain load where an atomic compare-and-swap used to sit on every level's critical path.
-__device__ __forceinline__ bool claims_parent(const NodeRec &nr, const NodeRec *__restrict__ NR,
-                                              const int32_t *__restrict__ map) {
+// plain load where an atomic compare-and-swap would sit on every level's critical path.
+__device__ __forceinline__ bool claims_parent(const NodeRec &nr, const NodeRec *__restrict__ NR, const NodeMap &map) {
     if (nr.parent < 0) return false;
     int s = nr.prev_sib;
     while (s >= 0) {
-        if (map[s] != 0) return false;
+        if (map.get(s) != 0) return false;
         s = NR[s].prev_sib;
     }
     return true;
@@ -338,7 +334,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
     __shared__ int sh_cnt_all[TEAMS_PER_WG][4];
     __shared__ double sh_d[4];
     __shared__ int sh_i[4];
-    // per-wavefront staging area for 64 ARecs: records are built one per lane but stored to HBM as
+    // per-wavefront staging area for 64 records: they are built one per lane but stored to HBM as
     // whole 1-KiB rows (4 store instructions per 64 records instead of 256 16-byte partial writes)
     __shared__ uint4 sh_stage[APPLES_TPB / WAVE][WAVE * 4];
     uint4 *stage = sh_stage[threadIdx.x / WAVE];
@@ -357,10 +353,15 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
     const int64_t nn = T.n_nodes;
     const int64_t cap = a.cap;  // scratch capacity of this launch's teams, in internal nodes
     const int64_t team = (int64_t)blockIdx.x * TEAMS_PER_WG + team_in_wg;
-    const int64_t n_teams = (int64_t)gridDim.x * TEAMS_PER_WG;
-    int32_t *map = a.map + team * nn;
-    ARec *A = reinterpret_cast<ARec *>(a.A) + team * (cap + 1);
-    BRec *B = reinterpret_cast<BRec *>(a.B) + team * (cap + 1);
+    NodeMap map;
+    map.m = a.map + team * nn;
+    map.vb = a.map_bits;
+    map.ver = (uint32_t)a.map_ver[team];
+    const uint32_t ver_max = (1u << (32 - a.map_bits)) - 1u;
+    Rec *rec = reinterpret_cast<Rec *>(a.A) + team * (cap + 1);
+    // R values of a polytomy's children wait here until all of them are formed (in-place update
+    // would destroy sibling S values that are still needed); unused for binary trees
+    double *rtmp = a.B ? reinterpret_cast<double *>(a.B) + team * (cap + 1) * 6 : nullptr;
     int32_t *grp_off = a.grp_off + team * (T.height + 4);
     double *xe = a.xe ? a.xe + team * (cap + a.leaf_cap) * XE_STRIDE : nullptr;
     // work queue: size-class lists written by the selection kernel (small teams), a device-side
@@ -373,7 +374,6 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
     } else {
         n_work = a.work_count ? *a.work_count : nq;
     }
-    (void)n_teams;
     __shared__ int sh_w[TEAMS_PER_WG];
     while (true) {
         // dynamic scheduling: one atomic add per query, broadcast to the team
@@ -398,22 +398,30 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
         const double *o_dist = a.obs_dist + q * a.obs_cap;
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
 
+        // a fresh tag for this query's map entries; when the tags run out, wipe the table once
+        if (map.ver == ver_max) {
+            team_sync<TEAM>();
+            for (int64_t i = tid; i < nn; i += TEAM) map.m[i] = 0;
+            map.ver = 0;
+            team_sync<TEAM>();
+        }
+        ++map.ver;
+
         // ------------------------------------------------------------ bottom-up: mark + S values
         int lvl = T.level[o_node[0]];
-        int base = 0, n_par = 0, G = 0, lca = -1, lca_claimed = 0;
+        int base = 0, n_par = 0, G = 0, lca = -1;
         bool overflow = false;
         if (tid < 3) sh_cnt[tid] = 0;
-        // name every observed leaf in the map first: map[leaf] = -(j+2).  With that, "is my earlier
-        // sibling in the subtree?" is answerable inside a level step without atomics (an internal
-        // sibling was claimed one step earlier, a leaf sibling is marked here).
-        for (int j = tid; j < n; j += TEAM) map[o_node[j]] = -(j + 2);
+        // name every observed leaf in the map first: leaf j of the level-sorted list.  With that,
+        // "is my earlier sibling in the subtree?" is answerable inside a level step without atomics
+        // (an internal sibling was registered one step earlier, a leaf sibling is marked here).
+        for (int j = tid; j < n; j += TEAM) map.set_leaf(o_node[j], j);
         team_sync<TEAM>();
         while (true) {
             const int lo = cg[lvl + 1], hi = cg[lvl];  // observed leaves of this level: obs[lo, hi)
             const int n_leaf = hi - lo;
             if (n_par + n_leaf == 1 && hi == n) {  // one node left in the frontier: the LCA (Subtree.py:36-43)
-                if (n_par == 1) { lca = A[base].node; lca_claimed = 1; }
-                else lca = o_node[lo];
+                lca = (n_par == 1) ? rec[base].node : o_node[lo];
                 break;
             }
             if (cap < nn && (int64_t)base + 2 * (int64_t)n_par + n_leaf > cap) { overflow = true; break; }
@@ -422,65 +430,78 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
             const int next_base = base + n_par;
             // (a) observed leaves of this level: the first valid child registers the parent
             for (int k = tid; k < n_leaf; k += TEAM) {
-                const int j = lo + k;
-                const int v = o_node[j];
-                const NodeRec nr = NR[v];
+                const NodeRec nr = NR[o_node[lo + k]];
                 if (claims_parent(nr, NR, map)) {
                     const int nidx = next_base + atomicAdd(next_cnt, 1);
-                    A[nidx].node = nr.parent;
-                    map[nr.parent] = nidx + 1;
+                    rec[nidx].node = nr.parent;
+                    map.set_internal(nr.parent, nidx);
                 }
             }
-            // (b) internal nodes of this level (claimed from the level below): S tuple from the valid
-            // children in file order, then claim the parent
+            // (b) internal nodes of this level (registered from the level below): S tuple from the
+            // valid children in file order, then register the parent
             for (int k0 = 0; k0 < n_par; k0 += TEAM) {  // team-uniform trip count
                 const int k = k0 + tid;
                 const int idx = base + k;
                 const bool active = k < n_par;
-                ARec ar;
                 int parent = -1;
                 bool claimer = false;
                 if (active) {
-                    ar.node = A[idx].node;
-                    ar.pad = 0;
-                    const NodeRec nr = NR[ar.node];
+                    Rec r;
+                    r.node = rec[idx].node;
+                    const NodeRec nr = NR[r.node];
                     parent = nr.parent;
                     claimer = claims_parent(nr, NR, map);
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) ar.S[c] = 0;
-                    int kk[2];
-                    const int nk = valid_kids2(nr, map, T.child_idx, kk);
-                    const double coef = BME ? 1.0 / (double)nk : 1.0;  // apples/BME.py:20
+                    for (int c = 0; c < 6; ++c) r.T[c] = 0;
                     if (nr.nchild <= 2) {
+                        const int m0 = nr.nchild >= 1 ? map.get(nr.c0) : 0;
+                        const int m1 = nr.nchild >= 2 ? map.get(nr.c1) : 0;
+                        const int nk = (m0 != 0) + (m1 != 0);
+                        const double coef = BME ? 1.0 / (double)nk : 1.0;  // apples/BME.py:20
+                        r.k0 = m0 ? m0 : m1;
+                        r.k1 = (m0 && m1) ? m1 : 0;
+                        r.meta = (uint32_t)nk | ((!m0) ? META_K0C1 : 0u);
+                        const int n0 = m0 ? nr.c0 : nr.c1;
+                        {
+                            Kid kd;
+                            load_kid<M>(r.k0, n0, rec, NR, o_dist, kd);
+                            double t[6];
+                            lift<M>(kd.S, kd.e, t);
 #pragma unroll
-                        for (int z = 0; z < 2; ++z) {
-                            if (z < nk) {
-                                Kid kd;
-                                load_kid<M>(kk[z], A, NR, o_node, o_dist, kd);
-                                double t[6];
-                                lift<M>(kd.S, kd.e, t);
+                            for (int x = 0; x < 6; ++x) r.T[x] += BME ? coef * t[x] : t[x];
+                        }
+                        if (nk > 1) {
+                            Kid kd;
+                            load_kid<M>(r.k1, nr.c1, rec, NR, o_dist, kd);
+                            double t[6];
+                            lift<M>(kd.S, kd.e, t);
 #pragma unroll
-                                for (int x = 0; x < 6; ++x) ar.S[x] += BME ? coef * t[x] : t[x];
-                            }
+                            for (int x = 0; x < 6; ++x) r.T[x] += BME ? coef * t[x] : t[x];
                         }
                     } else {
+                        int nk = 0;
+                        r.k0 = r.k1 = 0;
                         for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
-                            const int mc = map[T.child_idx[ci]];
+                            const int mc = map.get(T.child_idx[ci]);
+                            if (mc != 0) { if (nk == 0) r.k0 = mc; else if (nk == 1) r.k1 = mc; ++nk; }
+                        }
+                        const double coef = BME ? 1.0 / (double)nk : 1.0;
+                        for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
+                            const int cn = T.child_idx[ci];
+                            const int mc = map.get(cn);
                             if (mc != 0) {
                                 Kid kd;
-                                load_kid<M>(mc, A, NR, o_node, o_dist, kd);
+                                load_kid<M>(mc, cn, rec, NR, o_dist, kd);
                                 double t[6];
                                 lift<M>(kd.S, kd.e, t);
 #pragma unroll
-                                for (int x = 0; x < 6; ++x) ar.S[x] += BME ? coef * t[x] : t[x];
+                                for (int x = 0; x < 6; ++x) r.T[x] += BME ? coef * t[x] : t[x];
                             }
                         }
+                        r.meta = (uint32_t)nk | META_POLY;
                     }
-                    BRec &br = B[idx];
-                    br.k0 = kk[0]; br.k1 = kk[1]; br.nk = nk; br.poly = nr.nchild > 2;
-                    ar.e = nr.e;
                     // stage the record; its 64 bytes leave as part of a 1-KiB row below
-                    const uint4 *src = reinterpret_cast<const uint4 *>(&ar);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(&r);
 #pragma unroll
                     for (int x = 0; x < 4; ++x) stage[lane * 4 + x] = src[x];
                 }
@@ -488,7 +509,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                 {
                     const int wave_k0 = k0 + (tid - lane);         // first record of this wavefront's 64
                     const int n_here = n_par - wave_k0;            // records this wavefront holds (may be <= 0)
-                    uint4 *dst = reinterpret_cast<uint4 *>(&A[base + wave_k0]);
+                    uint4 *dst = reinterpret_cast<uint4 *>(&rec[base + wave_k0]);
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
                         const int c = x * WAVE + lane;             // 16-byte chunk of the 4-KiB block
@@ -498,8 +519,8 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                 __builtin_amdgcn_wave_barrier();
                 if (claimer) {
                     const int nidx = next_base + atomicAdd(next_cnt, 1);
-                    A[nidx].node = parent;
-                    map[parent] = nidx + 1;
+                    rec[nidx].node = parent;
+                    map.set_internal(parent, nidx);
                 }
             }
             team_sync<TEAM>();
@@ -508,10 +529,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
             ++G;
             --lvl;
         }
-        if (overflow) {  // hand the query to the big-team launch; undo this team's marks first
-            team_sync<TEAM>();
-            for (int idx = tid; idx < base + n_par; idx += TEAM) map[A[idx].node] = 0;
-            for (int j = tid; j < n; j += TEAM) map[o_node[j]] = 0;
+        if (overflow) {  // hand the query to the big-team launch (this team's marks die with the tag)
             if (tid == 0) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
             team_sync<TEAM>();
             continue;
@@ -521,11 +539,25 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
         if (tid == 0) {
             grp_off[G] = VI;
             grp_off[G + 1] = VI + 1;
-            int kk[2];
             const NodeRec nr = NR[lca];
-            A[VI].node = lca;
-            B[VI].nk = valid_kids2(nr, map, T.child_idx, kk);
-            B[VI].k0 = kk[0]; B[VI].k1 = kk[1]; B[VI].poly = nr.nchild > 2;
+            Rec &r = rec[VI];
+            r.node = lca;
+            int nk = 0, k0 = 0, k1 = 0, first = -1;
+            if (nr.nchild <= 2) {
+                const int m0 = nr.nchild >= 1 ? map.get(nr.c0) : 0;
+                const int m1 = nr.nchild >= 2 ? map.get(nr.c1) : 0;
+                nk = (m0 != 0) + (m1 != 0);
+                k0 = m0 ? m0 : m1;
+                k1 = (m0 && m1) ? m1 : 0;
+                first = m0 ? 0 : 1;
+            } else {
+                for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
+                    const int mc = map.get(T.child_idx[ci]);
+                    if (mc != 0) { if (nk == 0) k0 = mc; else if (nk == 1) k1 = mc; ++nk; }
+                }
+            }
+            r.k0 = k0; r.k1 = k1;
+            r.meta = (uint32_t)nk | (nr.nchild > 2 ? META_POLY : 0u) | (first == 1 ? META_K0C1 : 0u);
         }
         team_sync<TEAM>();
 
@@ -541,46 +573,44 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
             for (int idx = g0 + tid; idx < g1; idx += TEAM) {
                 const bool is_lca = (idx == VI);
-                const BRec br = B[idx];
-                double rp[6], ep = 0;
-                if (!is_lca) {
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) rp[x] = br.R[x];
-                    ep = A[idx].e;
-                }
+                const Rec self = rec[idx];
+                const NodeRec nr = NR[self.node];
+                const int nk = (int)(self.meta & META_NK);
                 // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
-                const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + br.nk - 1) : 1.0;
+                const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
                 double plift[6];
-                if (!is_lca) lift<M>(rp, ep, plift);
-                auto finish_kid = [&](int kd, const Kid &kid, const double *acc) {
+                if (!is_lca) lift<M>(self.T, nr.e, plift);  // self.T is this node's R by now
+                auto finish_kid = [&](int kd, const Kid &kid, const double *acc, bool defer) {
                     Sol r = solve_edge<M>(kid.S, acc, kid.e, a.negative);
                     r.err = exact_err(r, lds_pow);  // the reference's `**2` bits (pruning it per edge was slower)
                     if (kd > 0) {
+                        double *dst = defer ? rtmp + (int64_t)(kd - 1) * 6 : rec[kd - 1].T;
 #pragma unroll
-                        for (int x = 0; x < 6; ++x) B[kd - 1].R[x] = acc[x];
+                        for (int x = 0; x < 6; ++x) dst[x] = acc[x];
                     }
                     if (a.keep_edges) {
                         double *xp = xe + (int64_t)(kd > 0 ? kd - 1 : cap + (-kd - 2)) * XE_STRIDE;
                         xp[0] = r.x1; xp[1] = r.x2; xp[2] = r.x1n; xp[3] = r.x2n; xp[4] = r.err;
 #pragma unroll
-                        for (int x = 0; x < 6; ++x) xp[5 + x] = acc[x];
+                        for (int x = 0; x < 6; ++x) { xp[5 + x] = acc[x]; xp[11 + x] = kid.S[x]; }
+                        xp[17] = r.x1_int ? 1.0 : 0.0;
                     }
                     const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
                     if (key < best_key || (key == best_key && kid.node < best_v)) {
                         best_key = key; best_v = kid.node; best_sol = r; best_e = kid.e;
                     }
                 };
-                if (!br.poly) {
+                if (!(self.meta & META_POLY)) {
                     Kid kid[2];
-                    load_kid<M>(br.k0, A, NR, o_node, o_dist, kid[0]);
-                    if (br.nk > 1) load_kid<M>(br.k1, A, NR, o_node, o_dist, kid[1]);
+                    if (nk > 0) load_kid<M>(self.k0, (self.meta & META_K0C1) ? nr.c1 : nr.c0, rec, NR, o_dist, kid[0]);
+                    if (nk > 1) load_kid<M>(self.k1, nr.c1, rec, NR, o_dist, kid[1]);
 #pragma unroll
                     for (int z = 0; z < 2; ++z) {
-                        if (z < br.nk) {
+                        if (z < nk) {
                             double acc[6];
 #pragma unroll
                             for (int x = 0; x < 6; ++x) acc[x] = 0;
-                            if (br.nk > 1) {  // the one valid sibling (apples/OLS.py:59-69)
+                            if (nk > 1) {  // the one valid sibling (apples/OLS.py:59-69)
                                 double t[6];
                                 lift<M>(kid[1 - z].S, kid[1 - z].e, t);
 #pragma unroll
@@ -590,24 +620,25 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
 #pragma unroll
                                 for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
                             }
-                            finish_kid(z == 0 ? br.k0 : br.k1, kid[z], acc);
+                            finish_kid(z == 0 ? self.k0 : self.k1, kid[z], acc, false);
                         }
                     }
                 } else {  // polytomy: children through the CSR list
-                    const NodeRec nr = NR[A[idx].node];
-                    const int c0 = nr.child_off, c1 = nr.child_off + nr.nchild;
-                    for (int ci = c0; ci < c1; ++ci) {
-                        const int mc = map[T.child_idx[ci]];
+                    const int cb = nr.child_off, ce = nr.child_off + nr.nchild;
+                    for (int ci = cb; ci < ce; ++ci) {
+                        const int cn = T.child_idx[ci];
+                        const int mc = map.get(cn);
                         if (mc == 0) continue;
                         double acc[6];
 #pragma unroll
                         for (int x = 0; x < 6; ++x) acc[x] = 0;
-                        for (int cj = c0; cj < c1; ++cj) {
+                        for (int cj = cb; cj < ce; ++cj) {
                             if (cj == ci) continue;
-                            const int ms = map[T.child_idx[cj]];
+                            const int sn = T.child_idx[cj];
+                            const int ms = map.get(sn);
                             if (ms != 0) {
                                 Kid sk;
-                                load_kid<M>(ms, A, NR, o_node, o_dist, sk);
+                                load_kid<M>(ms, sn, rec, NR, o_dist, sk);
                                 double t[6];
                                 lift<M>(sk.S, sk.e, t);
 #pragma unroll
@@ -619,8 +650,15 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                             for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
                         }
                         Kid kr;
-                        load_kid<M>(mc, A, NR, o_node, o_dist, kr);
-                        finish_kid(mc, kr, acc);
+                        load_kid<M>(mc, cn, rec, NR, o_dist, kr);
+                        finish_kid(mc, kr, acc, true);
+                    }
+                    for (int ci = cb; ci < ce; ++ci) {  // all siblings done: S -> R in place
+                        const int mc = map.get(T.child_idx[ci]);
+                        if (mc > 0) {
+#pragma unroll
+                            for (int x = 0; x < 6; ++x) rec[mc - 1].T[x] = rtmp[(int64_t)(mc - 1) * 6 + x];
+                        }
                     }
                 }
             }
@@ -645,7 +683,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                 int kv = 0x7fffffff;
                 for (int i = tid; i < V; i += TEAM) {
                     const int64_t slot = i < VI ? i : cap + (i - VI);
-                    const int v = i < VI ? A[i].node : o_node[i - VI];
+                    const int v = i < VI ? rec[i].node : o_node[i - VI];
                     const double e = xe[slot * XE_STRIDE + 4];
                     const bool after = (e > last_e) || (e == last_e && v > last_v);
                     if (after && (e < ke || (e == ke && v < kv))) { ke = e; kv = v; }
@@ -653,21 +691,16 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                 team_argmin<TEAM>(ke, kv, sh_d, sh_i);
                 if (kv == 0x7fffffff) break;
                 last_e = ke; last_v = kv;
-                const int mk = map[kv];
+                const int mk = map.get(kv);
                 const int64_t slot = mk > 0 ? mk - 1 : cap + (-mk - 2);
                 const double x1 = xe[slot * XE_STRIDE + 0];
                 if (win < 0 || x1 < bx) { bx = x1; win = kv; win_slot = (int)slot; }
             }
-            if (win >= 0 && tid == 0) {  // rebuild the winner's solution from its stored R
-                const int mk = map[win];
-                Kid wk;
-                load_kid<M>(mk, A, NR, o_node, o_dist, wk);
-                double rr[6];
-#pragma unroll
-                for (int x = 0; x < 6; ++x) rr[x] = xe[(int64_t)win_slot * XE_STRIDE + 5 + x];
-                best_sol = solve_edge<M>(wk.S, rr, wk.e, a.negative);
-                best_sol.err = exact_err(best_sol, lds_pow);
-                best_e = wk.e;
+            if (win >= 0 && tid == 0) {  // the winner's stored solution
+                const double *xp = xe + (int64_t)win_slot * XE_STRIDE;
+                best_sol.x1 = xp[0]; best_sol.x2 = xp[1]; best_sol.err = xp[4];
+                best_sol.x1_int = xp[17] != 0.0;
+                best_e = NR[win].e;
             }
         } else {
             team_argmin<TEAM>(best_key, best_v, sh_d, sh_i);
@@ -697,12 +730,10 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
         }
         if (tid == 0) { grp_off[T.height + 3] = lca; grp_off[T.height + 2] = VI; }
         team_sync<TEAM>();
-        // ------------------------------------------------------------ unroll_changes (Subtree.py:72-76)
-        for (int idx = tid; idx < VI + lca_claimed; idx += TEAM) map[A[idx].node] = 0;
-        for (int j = tid; j < n; j += TEAM) map[o_node[j]] = 0;
-        team_sync<TEAM>();
     }
+    if (tid == 0) a.map_ver[team] = (int32_t)map.ver;
 }
+
 
 #ifndef APPLES_SWEEP_WAVES
 #define APPLES_SWEEP_WAVES 1
