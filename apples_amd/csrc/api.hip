@@ -230,7 +230,7 @@ int big_threshold() {
 }
 
 void free_sweep(Workspace::Sweep &sw) {
-    dev_free(sw.map); dev_free(sw.ver); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
+    dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
     sw = Workspace::Sweep();
 }
 
@@ -272,6 +272,7 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
     HIP_TRY(ctx, hipMemsetAsync(sw.map, 0, (size_t)sw.teams * t.n_nodes * 4, ctx->stream));
     if (dev_alloc(ctx, &sw.grp_off, sw.teams * (int64_t)(t.height + 4))) return 1;
     if (dev_alloc(ctx, &sw.ver, sw.teams)) return 1;
+    if (dev_alloc(ctx, &sw.order, sw.teams * (cap + 1))) return 1;
     HIP_TRY(ctx, hipMemsetAsync(sw.ver, 0, (size_t)sw.teams * 4, ctx->stream));
     HIP_TRY(ctx, hipMalloc(&sw.A, (size_t)sw.teams * (cap + 1) * 64));
     if (t.max_children > 2) HIP_TRY(ctx, hipMalloc(&sw.B, (size_t)sw.teams * (cap + 1) * 48));
@@ -340,7 +341,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
-    int64_t per_node = 64 + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
+    int64_t per_node = 68 + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
     if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold())), xe)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
@@ -452,8 +453,10 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.map = sw.map; s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
     s.map_ver = sw.ver;
+    s.order = sw.order;
     s.map_bits = 1;
     while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
+    if (const char *e = getenv("APPLES_MAP_BITS")) s.map_bits = std::min(30, std::max(s.map_bits, atoi(e)));  // test knob: few tags, early wrap
     s.cap = sw.cap;
     s.leaf_cap = sw.leaf_cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;

@@ -98,6 +98,7 @@ struct Workspace {
         int64_t teams = 0, cap = 0, leaf_cap = 0;
         int32_t *map = nullptr;   // [teams][n_nodes] node -> tagged descriptor (sweep.hip NodeMap)
         int32_t *ver = nullptr;   // [teams] last tag used in the team's map
+        int32_t *order = nullptr; // [teams][cap+1] node ids in compact order
         int32_t *grp_off = nullptr; // [teams][height+4] level groups in compact order, deepest first
         void *A = nullptr;        // [teams][cap+1] Rec (64 B): S then R tuple, first two valid children, node
         void *B = nullptr;        // [teams][cap+1][6] R values in waiting; trees with polytomies only
@@ -210,6 +211,7 @@ struct SweepArgs {
     const int32_t *obs_node; const double *obs_dist; int64_t obs_cap; const int32_t *cnt_gt; const int32_t *n_obs;
     int32_t *map, *grp_off; void *A, *B; double *xe;
     int32_t *map_ver;         // [teams] version tags of the maps
+    int32_t *order;           // [teams][cap+1] node ids in compact order
     int map_bits;             // payload bits of a map entry; the tag sits above them
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)

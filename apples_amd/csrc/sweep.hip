@@ -359,6 +359,9 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
     map.ver = (uint32_t)a.map_ver[team];
     const uint32_t ver_max = (1u << (32 - a.map_bits)) - 1u;
     Rec *rec = reinterpret_cast<Rec *>(a.A) + team * (cap + 1);
+    // node ids in compact order: a registering child appends here (4 contiguous bytes) instead of
+    // touching the 64-byte line of a record that does not exist yet
+    int32_t *order = a.order + team * (cap + 1);
     // R values of a polytomy's children wait here until all of them are formed (in-place update
     // would destroy sibling S values that are still needed); unused for binary trees
     double *rtmp = a.B ? reinterpret_cast<double *>(a.B) + team * (cap + 1) * 6 : nullptr;
@@ -421,7 +424,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
             const int lo = cg[lvl + 1], hi = cg[lvl];  // observed leaves of this level: obs[lo, hi)
             const int n_leaf = hi - lo;
             if (n_par + n_leaf == 1 && hi == n) {  // one node left in the frontier: the LCA (Subtree.py:36-43)
-                lca = (n_par == 1) ? rec[base].node : o_node[lo];
+                lca = (n_par == 1) ? order[base] : o_node[lo];
                 break;
             }
             if (cap < nn && (int64_t)base + 2 * (int64_t)n_par + n_leaf > cap) { overflow = true; break; }
@@ -433,7 +436,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                 const NodeRec nr = NR[o_node[lo + k]];
                 if (claims_parent(nr, NR, map)) {
                     const int nidx = next_base + atomicAdd(next_cnt, 1);
-                    rec[nidx].node = nr.parent;
+                    order[nidx] = nr.parent;
                     map.set_internal(nr.parent, nidx);
                 }
             }
@@ -447,7 +450,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                 bool claimer = false;
                 if (active) {
                     Rec r;
-                    r.node = rec[idx].node;
+                    r.node = order[idx];
                     const NodeRec nr = NR[r.node];
                     parent = nr.parent;
                     claimer = claims_parent(nr, NR, map);
@@ -519,7 +522,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                 __builtin_amdgcn_wave_barrier();
                 if (claimer) {
                     const int nidx = next_base + atomicAdd(next_cnt, 1);
-                    rec[nidx].node = parent;
+                    order[nidx] = parent;
                     map.set_internal(parent, nidx);
                 }
             }

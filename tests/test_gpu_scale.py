@@ -66,6 +66,24 @@ def test_all_observed_stress_and_batching(c2):
     eng.close()
 
 
+def test_map_tags_wrap_around(c2, monkeypatch):
+    """The sweep's node map is never cleared between queries: entries carry a per-query tag and the
+    table is wiped only when the tags run out.  Force 3-bit tags and 8 teams so that every team
+    wraps dozens of times; placements must not change."""
+    d, nodes = c2
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    want = eng.place_sequences(d.query_seqs)
+    eng.close()
+    monkeypatch.setenv('APPLES_MAP_BITS', '29')
+    monkeypatch.setenv('APPLES_SWEEP_TEAMS', '8')
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    got = eng.place_sequences(d.query_seqs)
+    again = eng.place_sequences(d.query_seqs)
+    eng.close()
+    assert got.tobytes() == want.tobytes()
+    assert again.tobytes() == want.tobytes()
+
+
 def test_properties_at_full_c2_query_count(c2):
     """Size-independent properties on the whole pass: determinism across runs and batch sizes,
     permutation equivariance over queries, duplicates of reference rows place exactly."""
