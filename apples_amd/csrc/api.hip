@@ -77,7 +77,10 @@ std::vector<int32_t> level_order(const int32_t *node, int64_t n, const std::vect
     std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
         int la = node[a] >= 0 ? level[node[a]] : -1;
         int lb = node[b] >= 0 ? level[node[b]] : -1;
-        return la > lb;
+        if (la != lb) return la > lb;
+        // within a level by node id (= left to right in the tree): the sweep's per-level lists then
+        // come out in tree order and parents read their children's records nearly sequentially
+        return la >= 0 && node[a] < node[b];
     });
     return idx;
 }

@@ -323,6 +323,16 @@ __device__ __forceinline__ bool claims_parent(const NodeRec &nr, const NodeRec *
     return true;
 }
 
+// Position of a registering lane in the next level's list: lanes of a wavefront in lane order, one
+// LDS add per wavefront for the block of positions.  Must be reached by the whole wavefront.
+__device__ __forceinline__ int ordered_slot(bool claim, int lane, int *counter) {
+    const unsigned long long m = __ballot(claim);
+    int wb = 0;
+    if (lane == 0 && m) wb = atomicAdd(counter, __popcll(m));
+    wb = __shfl(wb, 0, WAVE);
+    return wb + __popcll(m & ((1ull << lane) - 1ull));
+}
+
 // One team = TEAM threads working on one query: a wavefront (TEAM == 64, four independent teams
 // per workgroup; the level loops need no s_barrier) or the whole workgroup (TEAM == 256).  Queries
 // whose subtree does not fit a team's scratch (`cap` internal nodes) are appended to an overflow
@@ -431,13 +441,24 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
             if (tid == 0) { grp_off[G] = base; sh_cnt[(G + 1) % 3] = 0; }
             int *next_cnt = &sh_cnt[G % 3];
             const int next_base = base + n_par;
-            // (a) observed leaves of this level: the first valid child registers the parent
-            for (int k = tid; k < n_leaf; k += TEAM) {
-                const NodeRec nr = NR[o_node[lo + k]];
-                if (claims_parent(nr, NR, map)) {
-                    const int nidx = next_base + atomicAdd(next_cnt, 1);
-                    order[nidx] = nr.parent;
-                    map.set_internal(nr.parent, nidx);
+            // (a) observed leaves of this level: the first valid child registers the parent.
+            // Registrations keep the order of the list they come from (ballot ranks, one LDS add per
+            // wavefront): leaves and records are in tree order within a level, so parents are too,
+            // and the gathers of children's records below and on the way down walk forward in memory
+            // instead of hopping at random.
+            for (int k0 = 0; k0 < n_leaf; k0 += TEAM) {  // team-uniform trip count
+                const int k = k0 + tid;
+                bool claimer = false;
+                int parent = -1;
+                if (k < n_leaf) {
+                    const NodeRec nr = NR[o_node[lo + k]];
+                    parent = nr.parent;
+                    claimer = claims_parent(nr, NR, map);
+                }
+                const int nidx = next_base + ordered_slot(claimer, lane, next_cnt);
+                if (claimer) {
+                    order[nidx] = parent;
+                    map.set_internal(parent, nidx);
                 }
             }
             // (b) internal nodes of this level (registered from the level below): S tuple from the
@@ -520,8 +541,8 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                const int nidx = next_base + ordered_slot(claimer, lane, next_cnt);
                 if (claimer) {
-                    const int nidx = next_base + atomicAdd(next_cnt, 1);
                     order[nidx] = parent;
                     map.set_internal(parent, nidx);
                 }
