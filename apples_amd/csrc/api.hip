@@ -52,19 +52,38 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
     if (dev_upload(ctx, &d.child_off, t->child_off, t->n_nodes + 1)) return 1;
     if (dev_upload(ctx, &d.child_idx, t->child_idx, std::max(t->n_nodes - 1, 1))) return 1;
     if (dev_upload(ctx, &d.level, t->level, t->n_nodes)) return 1;
+    // level-ordered bit space: level by level, internal nodes then leaves, each block in node-id
+    // order and aligned to a 64-bit word
+    std::vector<std::vector<int32_t>> lv_int(h + 1), lv_leaf(h + 1);
+    for (int i = 0; i < t->n_nodes; ++i)
+        (t->child_off[i + 1] > t->child_off[i] ? lv_int : lv_leaf)[t->level[i]].push_back(i);
+    std::vector<int32_t> lvlw(2 * (h + 1) + 1), lpos(t->n_nodes);
+    int32_t words = 0;
+    for (int l = 0; l <= h; ++l) {
+        lvlw[2 * l] = words;
+        for (size_t k = 0; k < lv_int[l].size(); ++k) lpos[lv_int[l][k]] = words * 64 + (int32_t)k;
+        words += (int32_t)((lv_int[l].size() + 63) / 64);
+        lvlw[2 * l + 1] = words;
+        for (size_t k = 0; k < lv_leaf[l].size(); ++k) lpos[lv_leaf[l][k]] = words * 64 + (int32_t)k;
+        words += (int32_t)((lv_leaf[l].size() + 63) / 64);
+    }
+    lvlw[2 * (h + 1)] = words;
+    d.bm_words = words;
+    std::vector<int32_t> lnode((size_t)std::max(words, 1) * 64, -1);
+    for (int i = 0; i < t->n_nodes; ++i) lnode[lpos[i]] = i;
+    if (dev_upload(ctx, &d.lvlw, lvlw.data(), (int64_t)lvlw.size())) return 1;
+    if (dev_upload(ctx, &d.lnode, lnode.data(), (int64_t)lnode.size())) return 1;
     std::vector<NodeRec> rec(t->n_nodes);
     for (int i = 0; i < t->n_nodes; ++i) {
         NodeRec &r = rec[i];
         r.parent = t->parent[i];
-        r.child_off = t->child_off[i];
         r.nchild = t->child_off[i + 1] - t->child_off[i];
-        r.c0 = r.nchild > 0 ? t->child_idx[r.child_off] : -1;
-        r.c1 = r.nchild > 1 ? t->child_idx[r.child_off + 1] : -1;
-        r.prev_sib = -1;
+        r.c0 = r.nchild > 0 ? t->child_idx[t->child_off[i]] : -1;
+        r.c1 = r.nchild > 1 ? t->child_idx[t->child_off[i] + 1] : -1;
+        r.lpos = lpos[i];
+        r.ppos = t->parent[i] >= 0 ? lpos[t->parent[i]] : -1;
         r.e = t->edge_len[i];
     }
-    for (int i = 0; i < t->n_nodes; ++i)
-        for (int c = t->child_off[i] + 1; c < t->child_off[i + 1]; ++c) rec[t->child_idx[c]].prev_sib = t->child_idx[c - 1];
     if (dev_upload(ctx, &d.rec, rec.data(), t->n_nodes)) return 1;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -233,7 +252,7 @@ int big_threshold() {
 }
 
 void free_sweep(Workspace::Sweep &sw) {
-    dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
+    dev_free(sw.bits); dev_free(sw.pre); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
     sw = Workspace::Sweep();
 }
 
@@ -271,12 +290,11 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
     sw.teams = (int64_t)wgs * teams_per_wg;
     sw.cap = cap;
     sw.leaf_cap = leaf_cap;
-    if (dev_alloc(ctx, &sw.map, sw.teams * t.n_nodes)) return 1;
-    HIP_TRY(ctx, hipMemsetAsync(sw.map, 0, (size_t)sw.teams * t.n_nodes * 4, ctx->stream));
+    if (!sweep_bits_in_lds(t)) {
+        if (dev_alloc(ctx, &sw.bits, sw.teams * (int64_t)t.bm_words)) return 1;
+        if (dev_alloc(ctx, &sw.pre, sw.teams * (int64_t)t.bm_words)) return 1;
+    }
     if (dev_alloc(ctx, &sw.grp_off, sw.teams * (int64_t)(t.height + 4))) return 1;
-    if (dev_alloc(ctx, &sw.ver, sw.teams)) return 1;
-    if (dev_alloc(ctx, &sw.order, sw.teams * (cap + 1))) return 1;
-    HIP_TRY(ctx, hipMemsetAsync(sw.ver, 0, (size_t)sw.teams * 4, ctx->stream));
     HIP_TRY(ctx, hipMalloc(&sw.A, (size_t)sw.teams * (cap + 1) * 64));
     if (t.max_children > 2) HIP_TRY(ctx, hipMalloc(&sw.B, (size_t)sw.teams * (cap + 1) * 48));
     if (xe)
@@ -340,15 +358,15 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     int64_t nn = t.n_nodes;
     // (with the dynamic queue the rate is flat from 2 048 to 8 192 teams: the kernel is bound by HBM
     // random-access traffic, not by latency; 4 096 keeps the scratch footprint moderate)
-    int64_t teams = std::min<int64_t>(4096, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
+    int64_t teams = 4096;
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
-    int64_t per_node = 68 + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
+    int64_t per_node = 64 + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
     if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold())), xe)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
-    int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 4;
+    int64_t per_wg = nn * per_node + (int64_t)t.bm_words * 12 + (t.height + 4) * 4;
     int64_t big_max = getenv("APPLES_SWEEP_BIG_WGS") ? atoi(getenv("APPLES_SWEEP_BIG_WGS")) : 512;
     int wgs_big = (int)std::min<int64_t>(big_max, std::max<int64_t>(4, ((int64_t)24 << 30) / std::max<int64_t>(per_wg, 1)));
     wgs_big = (int)std::min<int64_t>(wgs_big, batch);
@@ -454,12 +472,8 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     SweepArgs s{};
     s.tree = ctx->tree;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
-    s.map = sw.map; s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
-    s.map_ver = sw.ver;
-    s.order = sw.order;
-    s.map_bits = 1;
-    while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
-    if (const char *e = getenv("APPLES_MAP_BITS")) s.map_bits = std::min(30, std::max(s.map_bits, atoi(e)));  // test knob: few tags, early wrap
+    s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
+    s.bits = sw.bits; s.pre = sw.pre;
     s.cap = sw.cap;
     s.leaf_cap = sw.leaf_cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
@@ -710,7 +724,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     for (auto &qb : ctx->blocks) free_block(&qb);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
-    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec);
+    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode);
     DevAlign &a = ctx->aln;
     dev_free(a.raw); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);

@@ -15,8 +15,8 @@ struct __attribute__((aligned(32))) NodeRec {
     int32_t parent;     // -1 for the root
     int32_t c0, c1;     // first two children in file order (-1 if absent)
     int32_t nchild;
-    int32_t child_off;  // into child_idx (all children, for polytomies)
-    int32_t prev_sib;   // previous sibling in file order, -1 for a first child
+    int32_t lpos;       // position in the level-ordered bit space (sweep.hip NodeBits)
+    int32_t ppos;       // the parent's lpos (-1 for the root)
     double e;           // edge length
 };
 
@@ -30,6 +30,11 @@ struct DevTree {
     int32_t *child_idx = nullptr;
     int32_t *level = nullptr;
     NodeRec *rec = nullptr;
+    // level-ordered bit space of the sweep: per level one block for its internal nodes and one for
+    // its leaves (each in node-id order, each starting on a 64-bit word)
+    int32_t bm_words = 0;        // 64-bit words of the whole space
+    int32_t *lvlw = nullptr;     // [2*(height+1)+1] first word of level l's internal block at 2l, leaf block at 2l+1
+    int32_t *lnode = nullptr;    // [bm_words*64] node at a bit position (-1 = padding)
 };
 
 // Slot = physical position of an alignment row on the device.  Member slots [0, n_refs) are the
@@ -96,9 +101,8 @@ struct Workspace {
     struct Sweep {
         int32_t wgs = 0;          // workgroups of the launch
         int64_t teams = 0, cap = 0, leaf_cap = 0;
-        int32_t *map = nullptr;   // [teams][n_nodes] node -> tagged descriptor (sweep.hip NodeMap)
-        int32_t *ver = nullptr;   // [teams] last tag used in the team's map
-        int32_t *order = nullptr; // [teams][cap+1] node ids in compact order
+        unsigned long long *bits = nullptr; // [teams][bm_words] valid-node bits, when they do not fit in LDS
+        uint32_t *pre = nullptr;  // [teams][bm_words] per-word ranks within a block
         int32_t *grp_off = nullptr; // [teams][height+4] level groups in compact order, deepest first
         void *A = nullptr;        // [teams][cap+1] Rec (64 B): S then R tuple, first two valid children, node
         void *B = nullptr;        // [teams][cap+1][6] R values in waiting; trees with polytomies only
@@ -209,10 +213,9 @@ int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int6
 struct SweepArgs {
     DevTree tree;
     const int32_t *obs_node; const double *obs_dist; int64_t obs_cap; const int32_t *cnt_gt; const int32_t *n_obs;
-    int32_t *map, *grp_off; void *A, *B; double *xe;
-    int32_t *map_ver;         // [teams] version tags of the maps
-    int32_t *order;           // [teams][cap+1] node ids in compact order
-    int map_bits;             // payload bits of a map entry; the tag sits above them
+    int32_t *grp_off; void *A, *B; double *xe;
+    unsigned long long *bits; // [teams][bm_words] or nullptr: the bit space lives in LDS
+    uint32_t *pre;
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
     int debug_phase;          // timing experiments only: 1 = stop after the bottom-up pass
@@ -229,6 +232,7 @@ struct SweepArgs {
     int32_t *overflow_count;
     apples_placement *out;
 };
+bool sweep_bits_in_lds(const DevTree &t);  // the sweep's node bits fit in LDS (else per-team global scratch)
 int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team, hipStream_t stream = nullptr);
 int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,
                        hipStream_t st);

@@ -31,6 +31,7 @@
 // `x ** 2` is libm pow in the reference; pow2_libm below reproduces its bits.
 // HBM-bound by design: ~60 fp64 flops against ~330 B per node; no MFMA.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -272,22 +273,80 @@ struct __attribute__((aligned(64))) Rec {
 
 #define XE_STRIDE 18  // x_1, x_2, x_1_neg, x_2_neg, err, R[6], S[6], x_1-is-int  (HYBRID / inspection only)
 
-// Per-team node -> descriptor table with a version tag in the high bits: an entry counts only if
-// its tag is the current query's, so nothing has to be cleared between queries
-// (unroll_changes, apples/Subtree.py:72-76, becomes a counter increment).
-struct NodeMap {
-    int32_t *m;
-    uint32_t ver;
-    int vb;
-    __device__ __forceinline__ int get(int v) const {
-        const uint32_t w = (uint32_t)m[v];
-        if ((w >> vb) != ver) return 0;
-        const uint32_t p = w & ((1u << vb) - 1u);
-        return (p & 1u) ? -(int)(p >> 1) - 1 : (int)(p >> 1);
+// Which nodes are in the query's subtree: one bit per node in the tree's level-ordered bit space
+// (DevTree: per level a block for its internal nodes and a block for its leaves, each in node-id
+// order).  Because the level's records are created in that same order, a node's compact index is
+// the start of its level plus its rank inside the block, and an observed leaf's position in the
+// level-sorted observation list is the start of its level plus its rank: the rank (per-word
+// prefix count + popcount) replaces a node -> index table.  The space is a few KB for a 10^4-leaf
+// tree and lives in LDS; larger trees keep it in per-team global scratch.
+struct NodeBits {
+    unsigned long long *bm;
+    uint32_t *pre;  // per word: set bits of the same block in earlier words
+    // child descriptor of the node with tree record nc: > 0 internal (compact index + 1),
+    // <= -2 observed leaf (-(j+2)), 0 not in the subtree
+    __device__ __forceinline__ int desc(const NodeRec &nc, int base_int, int lo_leaf) const {
+        const int w = nc.lpos >> 6, b = nc.lpos & 63;
+        const unsigned long long word = bm[w];
+        if (!((word >> b) & 1ull)) return 0;
+        const int r = (int)pre[w] + __popcll(word & ((1ull << b) - 1ull));
+        return nc.nchild == 0 ? -(lo_leaf + r) - 2 : base_int + r + 1;
     }
-    __device__ __forceinline__ void set_internal(int v, int idx) { m[v] = (int32_t)((ver << vb) | ((uint32_t)(idx + 1) << 1)); }
-    __device__ __forceinline__ void set_leaf(int v, int j) { m[v] = (int32_t)((ver << vb) | ((uint32_t)(j + 1) << 1) | 1u); }
+    __device__ __forceinline__ void set(int lpos) const { atomicOr(&bm[lpos >> 6], 1ull << (lpos & 63)); }
 };
+
+// position of the k-th (0-based) set bit of x
+__device__ __forceinline__ int select64(unsigned long long x, int k) {
+    int pos = 0;
+    int c = __popc((uint32_t)x);
+    if (k >= c) { k -= c; x >>= 32; pos = 32; }
+    uint32_t v = (uint32_t)x;
+    c = __popc(v & 0xffffu); if (k >= c) { k -= c; v >>= 16; pos += 16; }
+    c = __popc(v & 0xffu);   if (k >= c) { k -= c; v >>= 8;  pos += 8; }
+    c = __popc(v & 0xfu);    if (k >= c) { k -= c; v >>= 4;  pos += 4; }
+    c = __popc(v & 0x3u);    if (k >= c) { k -= c; v >>= 2;  pos += 2; }
+    if (k >= (int)(v & 1u)) pos += 1;
+    return pos;
+}
+
+// bit position of the k-th node of the block occupying words [w0, w1): the last word whose prefix
+// count is <= k holds it
+__device__ __forceinline__ int kth_in_block(const NodeBits &nb, int w0, int w1, int k) {
+    int lo = w0, hi = w1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)nb.pre[mid] <= k) lo = mid; else hi = mid;
+    }
+    return lo * 64 + select64(nb.bm[lo], k - (int)nb.pre[lo]);
+}
+
+// per-word ranks of the block [w0, w1); returns the number of set bits.  One wavefront scans.
+template <int TEAM>
+__device__ int block_ranks(const NodeBits &nb, int w0, int w1, int tid, int *sh_slot) {
+    int run = 0;
+    if (TEAM == WAVE || tid < WAVE) {
+        const int lane = tid & (WAVE - 1);
+        for (int wb = w0; wb < w1; wb += WAVE) {
+            const int w = wb + lane;
+            const int c = (w < w1) ? __popcll(nb.bm[w]) : 0;
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const int t = __shfl_up(incl, o, WAVE);
+                if (lane >= o) incl += t;
+            }
+            if (w < w1) nb.pre[w] = (uint32_t)(run + incl - c);
+            run += __shfl(incl, WAVE - 1, WAVE);
+        }
+        if (TEAM != WAVE && tid == 0) *sh_slot = run;
+    }
+    if (TEAM != WAVE) {
+        __syncthreads();
+        run = *sh_slot;
+        __syncthreads();
+    }
+    return run;
+}
 
 struct Kid {
     double S[6];
@@ -295,12 +354,12 @@ struct Kid {
     int32_t node;
 };
 
-// a child's S tuple and edge length from its descriptor and node id
+// a child's S tuple from its descriptor; node id and edge length come from the tree record
 template <int M>
-__device__ __forceinline__ void load_kid(int kd, int node, const Rec *__restrict__ rec, const NodeRec *__restrict__ NR,
+__device__ __forceinline__ void load_kid(int kd, int node, double e, const Rec *__restrict__ rec,
                                          const double *__restrict__ o_dist, Kid &k) {
     k.node = node;
-    k.e = NR[node].e;
+    k.e = e;
     if (kd > 0) {
         const Rec &r = rec[kd - 1];
 #pragma unroll
@@ -310,68 +369,59 @@ __device__ __forceinline__ void load_kid(int kd, int node, const Rec *__restrict
     }
 }
 
-// Which child registers the parent in the compact order?  The first valid child in file order: a
-// node claims its parent iff none of its earlier siblings is in the subtree.  Deterministic, and a
-// plain load where an atomic compare-and-swap would sit on every level's critical path.
-__device__ __forceinline__ bool claims_parent(const NodeRec &nr, const NodeRec *__restrict__ NR, const NodeMap &map) {
-    if (nr.parent < 0) return false;
-    int s = nr.prev_sib;
-    while (s >= 0) {
-        if (map.get(s) != 0) return false;
-        s = NR[s].prev_sib;
-    }
-    return true;
-}
-
-// Position of a registering lane in the next level's list: lanes of a wavefront in lane order, one
-// LDS add per wavefront for the block of positions.  Must be reached by the whole wavefront.
-__device__ __forceinline__ int ordered_slot(bool claim, int lane, int *counter) {
-    const unsigned long long m = __ballot(claim);
-    int wb = 0;
-    if (lane == 0 && m) wb = atomicAdd(counter, __popcll(m));
-    wb = __shfl(wb, 0, WAVE);
-    return wb + __popcll(m & ((1ull << lane) - 1ull));
-}
-
 // One team = TEAM threads working on one query: a wavefront (TEAM == 64, four independent teams
 // per workgroup; the level loops need no s_barrier) or the whole workgroup (TEAM == 256).  Queries
 // whose subtree does not fit a team's scratch (`cap` internal nodes) are appended to an overflow
 // list that a second launch with full-size scratch takes.
-template <int M, int TEAM>
-__device__ void sweep_team(const SweepArgs &a, int64_t nq) {
-    constexpr int TEAMS_PER_WG = APPLES_TPB / TEAM;
-    constexpr bool BME = (M == APPLES_BME);
-    __shared__ int sh_cnt_all[TEAMS_PER_WG][4];
-    __shared__ double sh_d[4];
-    __shared__ int sh_i[4];
+// LDS of one workgroup (shared by the team shapes a kernel instantiates)
+struct SweepShared {
     // per-wavefront staging area for 64 records: they are built one per lane but stored to HBM as
     // whole 1-KiB rows (4 store instructions per 64 records instead of 256 16-byte partial writes)
-    __shared__ uint4 sh_stage[APPLES_TPB / WAVE][WAVE * 4];
-    uint4 *stage = sh_stage[threadIdx.x / WAVE];
-    const int lane = threadIdx.x & (WAVE - 1);
-    // libm pow tables (5 KiB) staged in LDS: two lookups per candidate edge would otherwise be ten
-    // scattered global loads
-    __shared__ double lds_pow[384 + 256];
-    for (int i = threadIdx.x; i < 384; i += APPLES_TPB) lds_pow[i] = (&kPowLogTab[0][0])[i];
-    for (int i = threadIdx.x; i < 256; i += APPLES_TPB) lds_pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
+    uint4 stage[APPLES_TPB / WAVE][WAVE * 4];
+    // libm pow tables (5 KiB): two lookups per candidate edge would otherwise be ten scattered
+    // global loads
+    double pow[384 + 256];
+    double d[4];
+    int cnt[APPLES_TPB / WAVE][4];
+    int i[4];
+    int w[APPLES_TPB / WAVE];
+};
+
+__device__ __forceinline__ void sweep_shared_init(SweepShared &sh) {
+    for (int i = threadIdx.x; i < 384; i += APPLES_TPB) sh.pow[i] = (&kPowLogTab[0][0])[i];
+    for (int i = threadIdx.x; i < 256; i += APPLES_TPB) sh.pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
     __syncthreads();
+}
+
+template <int M, int TEAM>
+__device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
+    constexpr int TEAMS_PER_WG = APPLES_TPB / TEAM;
+    constexpr bool BME = (M == APPLES_BME);
+    double *sh_d = sh.d;
+    int *sh_i = sh.i;
+    uint4 *stage = sh.stage[threadIdx.x / WAVE];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const double *lds_pow = sh.pow;
     const int team_in_wg = threadIdx.x / TEAM;
     const int tid = threadIdx.x % TEAM;
-    int *sh_cnt = sh_cnt_all[team_in_wg];
+    int *sh_cnt = sh.cnt[team_in_wg];
     const DevTree &T = a.tree;
     const NodeRec *__restrict__ NR = T.rec;
     const int64_t nn = T.n_nodes;
     const int64_t cap = a.cap;  // scratch capacity of this launch's teams, in internal nodes
     const int64_t team = (int64_t)blockIdx.x * TEAMS_PER_WG + team_in_wg;
-    NodeMap map;
-    map.m = a.map + team * nn;
-    map.vb = a.map_bits;
-    map.ver = (uint32_t)a.map_ver[team];
-    const uint32_t ver_max = (1u << (32 - a.map_bits)) - 1u;
+    NodeBits nb;
+    const int bm_words = T.bm_words;
+    if (a.bits) {
+        nb.bm = a.bits + team * bm_words;
+        nb.pre = a.pre + team * bm_words;
+    } else {  // dynamic LDS: [teams of this workgroup][bm_words] words, then the ranks
+        extern __shared__ unsigned long long dyn_lds[];
+        nb.bm = dyn_lds + (size_t)team_in_wg * bm_words;
+        nb.pre = reinterpret_cast<uint32_t *>(dyn_lds + (size_t)TEAMS_PER_WG * bm_words) + (size_t)team_in_wg * bm_words;
+    }
+    const int32_t *__restrict__ lvlw = T.lvlw;
     Rec *rec = reinterpret_cast<Rec *>(a.A) + team * (cap + 1);
-    // node ids in compact order: a registering child appends here (4 contiguous bytes) instead of
-    // touching the 64-byte line of a record that does not exist yet
-    int32_t *order = a.order + team * (cap + 1);
     // R values of a polytomy's children wait here until all of them are formed (in-place update
     // would destroy sibling S values that are still needed); unused for binary trees
     double *rtmp = a.B ? reinterpret_cast<double *>(a.B) + team * (cap + 1) * 6 : nullptr;
@@ -387,7 +437,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
     } else {
         n_work = a.work_count ? *a.work_count : nq;
     }
-    __shared__ int sh_w[TEAMS_PER_WG];
+    int *sh_w = sh.w;
     while (true) {
         // dynamic scheduling: one atomic add per query, broadcast to the team
         if (tid == 0) sh_w[team_in_wg] = atomicAdd(a.cursor, 1);
@@ -411,84 +461,60 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
         const double *o_dist = a.obs_dist + q * a.obs_cap;
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
 
-        // a fresh tag for this query's map entries; when the tags run out, wipe the table once
-        if (map.ver == ver_max) {
-            team_sync<TEAM>();
-            for (int64_t i = tid; i < nn; i += TEAM) map.m[i] = 0;
-            map.ver = 0;
-            team_sync<TEAM>();
-        }
-        ++map.ver;
-
         // ------------------------------------------------------------ bottom-up: mark + S values
-        int lvl = T.level[o_node[0]];
-        int base = 0, n_par = 0, G = 0, lca = -1;
+        for (int i = tid; i < bm_words; i += TEAM) nb.bm[i] = 0;  // unroll_changes of the previous query
+        team_sync<TEAM>();
+        // every observed leaf marks itself and its parent (a parent is in the subtree as soon as one
+        // child is; setting a bit twice is harmless, so nobody has to be "the" registering child)
+        for (int j = tid; j < n; j += TEAM) {
+            const NodeRec nr = NR[o_node[j]];
+            nb.set(nr.lpos);
+            if (nr.ppos >= 0 && n > 1) nb.set(nr.ppos);
+        }
+        const int lvl_first = T.level[o_node[0]];
+        int lvl = lvl_first;
+        int base = 0, kid_base = 0, n_par = 0, G = 0, lca = -1;
         bool overflow = false;
-        if (tid < 3) sh_cnt[tid] = 0;
-        // name every observed leaf in the map first: leaf j of the level-sorted list.  With that,
-        // "is my earlier sibling in the subtree?" is answerable inside a level step without atomics
-        // (an internal sibling was registered one step earlier, a leaf sibling is marked here).
-        for (int j = tid; j < n; j += TEAM) map.set_leaf(o_node[j], j);
         team_sync<TEAM>();
         while (true) {
             const int lo = cg[lvl + 1], hi = cg[lvl];  // observed leaves of this level: obs[lo, hi)
             const int n_leaf = hi - lo;
+            const int w0 = lvlw[2 * lvl], w1 = lvlw[2 * lvl + 1], w2 = lvlw[2 * lvl + 2];
+            // all children of this level's nodes have reported: rank the level's two blocks
+            n_par = block_ranks<TEAM>(nb, w0, w1, tid, &sh_cnt[0]);
+            block_ranks<TEAM>(nb, w1, w2, tid, &sh_cnt[0]);
+            team_sync<TEAM>();
             if (n_par + n_leaf == 1 && hi == n) {  // one node left in the frontier: the LCA (Subtree.py:36-43)
-                lca = (n_par == 1) ? order[base] : o_node[lo];
+                lca = (n_par == 1) ? T.lnode[kth_in_block(nb, w0, w1, 0)] : o_node[lo];
                 break;
             }
-            if (cap < nn && (int64_t)base + 2 * (int64_t)n_par + n_leaf > cap) { overflow = true; break; }
-            if (tid == 0) { grp_off[G] = base; sh_cnt[(G + 1) % 3] = 0; }
-            int *next_cnt = &sh_cnt[G % 3];
-            const int next_base = base + n_par;
-            // (a) observed leaves of this level: the first valid child registers the parent.
-            // Registrations keep the order of the list they come from (ballot ranks, one LDS add per
-            // wavefront): leaves and records are in tree order within a level, so parents are too,
-            // and the gathers of children's records below and on the way down walk forward in memory
-            // instead of hopping at random.
-            for (int k0 = 0; k0 < n_leaf; k0 += TEAM) {  // team-uniform trip count
-                const int k = k0 + tid;
-                bool claimer = false;
-                int parent = -1;
-                if (k < n_leaf) {
-                    const NodeRec nr = NR[o_node[lo + k]];
-                    parent = nr.parent;
-                    claimer = claims_parent(nr, NR, map);
-                }
-                const int nidx = next_base + ordered_slot(claimer, lane, next_cnt);
-                if (claimer) {
-                    order[nidx] = parent;
-                    map.set_internal(parent, nidx);
-                }
-            }
-            // (b) internal nodes of this level (registered from the level below): S tuple from the
-            // valid children in file order, then register the parent
+            if (cap < nn && (int64_t)base + n_par > cap) { overflow = true; break; }
+            if (tid == 0) grp_off[G] = base;
+            const int lo_kids = lvl + 2 <= T.height + 1 ? cg[lvl + 2] : 0;  // first observed leaf of the level below
+            // internal nodes of this level, in node-id order: S tuple from the valid children in
+            // file order, then tell the parent
             for (int k0 = 0; k0 < n_par; k0 += TEAM) {  // team-uniform trip count
                 const int k = k0 + tid;
-                const int idx = base + k;
                 const bool active = k < n_par;
-                int parent = -1;
-                bool claimer = false;
                 if (active) {
                     Rec r;
-                    r.node = order[idx];
+                    r.node = T.lnode[kth_in_block(nb, w0, w1, k)];
                     const NodeRec nr = NR[r.node];
-                    parent = nr.parent;
-                    claimer = claims_parent(nr, NR, map);
 #pragma unroll
                     for (int c = 0; c < 6; ++c) r.T[c] = 0;
                     if (nr.nchild <= 2) {
-                        const int m0 = nr.nchild >= 1 ? map.get(nr.c0) : 0;
-                        const int m1 = nr.nchild >= 2 ? map.get(nr.c1) : 0;
+                        NodeRec kr0, kr1;
+                        int m0 = 0, m1 = 0;
+                        if (nr.nchild >= 1) { kr0 = NR[nr.c0]; m0 = nb.desc(kr0, kid_base, lo_kids); }
+                        if (nr.nchild >= 2) { kr1 = NR[nr.c1]; m1 = nb.desc(kr1, kid_base, lo_kids); }
                         const int nk = (m0 != 0) + (m1 != 0);
                         const double coef = BME ? 1.0 / (double)nk : 1.0;  // apples/BME.py:20
                         r.k0 = m0 ? m0 : m1;
                         r.k1 = (m0 && m1) ? m1 : 0;
                         r.meta = (uint32_t)nk | ((!m0) ? META_K0C1 : 0u);
-                        const int n0 = m0 ? nr.c0 : nr.c1;
                         {
                             Kid kd;
-                            load_kid<M>(r.k0, n0, rec, NR, o_dist, kd);
+                            load_kid<M>(r.k0, m0 ? nr.c0 : nr.c1, m0 ? kr0.e : kr1.e, rec, o_dist, kd);
                             double t[6];
                             lift<M>(kd.S, kd.e, t);
 #pragma unroll
@@ -496,7 +522,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                         }
                         if (nk > 1) {
                             Kid kd;
-                            load_kid<M>(r.k1, nr.c1, rec, NR, o_dist, kd);
+                            load_kid<M>(r.k1, nr.c1, kr1.e, rec, o_dist, kd);
                             double t[6];
                             lift<M>(kd.S, kd.e, t);
 #pragma unroll
@@ -505,17 +531,19 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                     } else {
                         int nk = 0;
                         r.k0 = r.k1 = 0;
-                        for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
-                            const int mc = map.get(T.child_idx[ci]);
+                        const int cb = T.child_off[r.node], ce = cb + nr.nchild;
+                        for (int ci = cb; ci < ce; ++ci) {
+                            const int mc = nb.desc(NR[T.child_idx[ci]], kid_base, lo_kids);
                             if (mc != 0) { if (nk == 0) r.k0 = mc; else if (nk == 1) r.k1 = mc; ++nk; }
                         }
                         const double coef = BME ? 1.0 / (double)nk : 1.0;
-                        for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
+                        for (int ci = cb; ci < ce; ++ci) {
                             const int cn = T.child_idx[ci];
-                            const int mc = map.get(cn);
+                            const NodeRec cr = NR[cn];
+                            const int mc = nb.desc(cr, kid_base, lo_kids);
                             if (mc != 0) {
                                 Kid kd;
-                                load_kid<M>(mc, cn, rec, NR, o_dist, kd);
+                                load_kid<M>(mc, cn, cr.e, rec, o_dist, kd);
                                 double t[6];
                                 lift<M>(kd.S, kd.e, t);
 #pragma unroll
@@ -524,6 +552,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                         }
                         r.meta = (uint32_t)nk | META_POLY;
                     }
+                    if (nr.ppos >= 0) nb.set(nr.ppos);
                     // stage the record; its 64 bytes leave as part of a 1-KiB row below
                     const uint4 *src = reinterpret_cast<const uint4 *>(&r);
 #pragma unroll
@@ -541,15 +570,10 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                const int nidx = next_base + ordered_slot(claimer, lane, next_cnt);
-                if (claimer) {
-                    order[nidx] = parent;
-                    map.set_internal(parent, nidx);
-                }
             }
             team_sync<TEAM>();
-            n_par = *next_cnt;
-            base = next_base;
+            kid_base = base;
+            base += n_par;
             ++G;
             --lvl;
         }
@@ -567,16 +591,18 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
             Rec &r = rec[VI];
             r.node = lca;
             int nk = 0, k0 = 0, k1 = 0, first = -1;
+            const int klo = lvl + 2 <= T.height + 1 ? cg[lvl + 2] : 0;
             if (nr.nchild <= 2) {
-                const int m0 = nr.nchild >= 1 ? map.get(nr.c0) : 0;
-                const int m1 = nr.nchild >= 2 ? map.get(nr.c1) : 0;
+                const int m0 = nr.nchild >= 1 ? nb.desc(NR[nr.c0], kid_base, klo) : 0;
+                const int m1 = nr.nchild >= 2 ? nb.desc(NR[nr.c1], kid_base, klo) : 0;
                 nk = (m0 != 0) + (m1 != 0);
                 k0 = m0 ? m0 : m1;
                 k1 = (m0 && m1) ? m1 : 0;
                 first = m0 ? 0 : 1;
             } else {
-                for (int ci = nr.child_off; ci < nr.child_off + nr.nchild; ++ci) {
-                    const int mc = map.get(T.child_idx[ci]);
+                const int cb = T.child_off[lca];
+                for (int ci = cb; ci < cb + nr.nchild; ++ci) {
+                    const int mc = nb.desc(NR[T.child_idx[ci]], kid_base, klo);
                     if (mc != 0) { if (nk == 0) k0 = mc; else if (nk == 1) k1 = mc; ++nk; }
                 }
             }
@@ -593,7 +619,11 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
         Sol best_sol;
         double best_e = 0;
         best_sol.x1 = best_sol.x2 = best_sol.err = 0; best_sol.x1_int = 0; best_sol.x1n = best_sol.x2n = 0;
+#ifdef APPLES_BU_ONLY
+        for (int g = 0; g >= 1; --g) {
+#else
         for (int g = (a.debug_phase == 1 ? 0 : G); g >= 1; --g) {
+#endif
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
             for (int idx = g0 + tid; idx < g1; idx += TEAM) {
                 const bool is_lca = (idx == VI);
@@ -626,8 +656,11 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                 };
                 if (!(self.meta & META_POLY)) {
                     Kid kid[2];
-                    if (nk > 0) load_kid<M>(self.k0, (self.meta & META_K0C1) ? nr.c1 : nr.c0, rec, NR, o_dist, kid[0]);
-                    if (nk > 1) load_kid<M>(self.k1, nr.c1, rec, NR, o_dist, kid[1]);
+                    if (nk > 0) {
+                        const int n0 = (self.meta & META_K0C1) ? nr.c1 : nr.c0;
+                        load_kid<M>(self.k0, n0, NR[n0].e, rec, o_dist, kid[0]);
+                    }
+                    if (nk > 1) load_kid<M>(self.k1, nr.c1, NR[nr.c1].e, rec, o_dist, kid[1]);
 #pragma unroll
                     for (int z = 0; z < 2; ++z) {
                         if (z < nk) {
@@ -648,10 +681,12 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                         }
                     }
                 } else {  // polytomy: children through the CSR list
-                    const int cb = nr.child_off, ce = nr.child_off + nr.nchild;
+                    const int cb = T.child_off[self.node], ce = cb + nr.nchild;
+                    const int kb = grp_off[g - 1], klo = cg[lvl_first - g + 2];  // the children's level
                     for (int ci = cb; ci < ce; ++ci) {
                         const int cn = T.child_idx[ci];
-                        const int mc = map.get(cn);
+                        const NodeRec cr = NR[cn];
+                        const int mc = nb.desc(cr, kb, klo);
                         if (mc == 0) continue;
                         double acc[6];
 #pragma unroll
@@ -659,10 +694,11 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                         for (int cj = cb; cj < ce; ++cj) {
                             if (cj == ci) continue;
                             const int sn = T.child_idx[cj];
-                            const int ms = map.get(sn);
+                            const NodeRec sr = NR[sn];
+                            const int ms = nb.desc(sr, kb, klo);
                             if (ms != 0) {
                                 Kid sk;
-                                load_kid<M>(ms, sn, rec, NR, o_dist, sk);
+                                load_kid<M>(ms, sn, sr.e, rec, o_dist, sk);
                                 double t[6];
                                 lift<M>(sk.S, sk.e, t);
 #pragma unroll
@@ -674,11 +710,11 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                             for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
                         }
                         Kid kr;
-                        load_kid<M>(mc, cn, rec, NR, o_dist, kr);
+                        load_kid<M>(mc, cn, cr.e, rec, o_dist, kr);
                         finish_kid(mc, kr, acc, true);
                     }
                     for (int ci = cb; ci < ce; ++ci) {  // all siblings done: S -> R in place
-                        const int mc = map.get(T.child_idx[ci]);
+                        const int mc = nb.desc(NR[T.child_idx[ci]], kb, klo);
                         if (mc > 0) {
 #pragma unroll
                             for (int x = 0; x < 6; ++x) rec[mc - 1].T[x] = rtmp[(int64_t)(mc - 1) * 6 + x];
@@ -715,7 +751,8 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
                 team_argmin<TEAM>(ke, kv, sh_d, sh_i);
                 if (kv == 0x7fffffff) break;
                 last_e = ke; last_v = kv;
-                const int mk = map.get(kv);
+                const int kl = T.level[kv];
+                const int mk = nb.desc(NR[kv], grp_off[lvl_first - kl], cg[kl + 1]);
                 const int64_t slot = mk > 0 ? mk - 1 : cap + (-mk - 2);
                 const double x1 = xe[slot * XE_STRIDE + 0];
                 if (win < 0 || x1 < bx) { bx = x1; win = kv; win_slot = (int)slot; }
@@ -755,7 +792,6 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
         if (tid == 0) { grp_off[T.height + 3] = lca; grp_off[T.height + 2] = VI; }
         team_sync<TEAM>();
     }
-    if (tid == 0) a.map_ver[team] = (int32_t)map.ver;
 }
 
 
@@ -765,7 +801,9 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq) {
 
 template <int M, int TEAM>
 __global__ __launch_bounds__(APPLES_TPB, APPLES_SWEEP_WAVES) void k_sweep(SweepArgs a, int64_t nq) {
-    sweep_team<M, TEAM>(a, nq);
+    __shared__ SweepShared sh;
+    sweep_shared_init(sh);
+    sweep_team<M, TEAM>(a, nq, sh);
 }
 
 // One launch for a whole batch: the first `n_big` workgroups first serve, as workgroup-sized teams
@@ -774,11 +812,21 @@ __global__ __launch_bounds__(APPLES_TPB, APPLES_SWEEP_WAVES) void k_sweep(SweepA
 // drain the size-class queues.
 template <int M>
 __global__ __launch_bounds__(APPLES_TPB, APPLES_SWEEP_WAVES) void k_sweep_mixed(SweepArgs small, SweepArgs big, int64_t nq, int n_big) {
+    __shared__ SweepShared sh;
+    sweep_shared_init(sh);
     if ((int)blockIdx.x < n_big) {
-        sweep_team<M, APPLES_TPB>(big, nq);
+        sweep_team<M, APPLES_TPB>(big, nq, sh);
         __syncthreads();
     }
-    sweep_team<M, WAVE>(small, nq);
+    sweep_team<M, WAVE>(small, nq, sh);
+}
+
+bool sweep_bits_in_lds(const DevTree &t) {
+    if (getenv("APPLES_BITS_GLOBAL")) return false;  // test knob: exercise the big-tree layout on a small tree
+    return (size_t)4 * t.bm_words * 12 <= 40 * 1024;
+}
+static size_t dyn_lds_bytes(const DevTree &t, int teams_per_wg) {
+    return sweep_bits_in_lds(t) ? (size_t)teams_per_wg * t.bm_words * 12 : 0;
 }
 
 int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,
@@ -789,11 +837,12 @@ int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs 
     // big-team duty falls to the first min(n_big, grid) workgroups
     dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(need, std::min<int64_t>(n_big, nq)), wgs)), block(APPLES_TPB);
     if (n_big > (int)grid.x) n_big = (int)grid.x;
+    const size_t dyn = dyn_lds_bytes(small.tree, 4);
     switch (small.method) {
-        case APPLES_FM: hipLaunchKernelGGL((k_sweep_mixed<APPLES_FM>), grid, block, 0, st, small, big, nq, n_big); break;
-        case APPLES_BME: hipLaunchKernelGGL((k_sweep_mixed<APPLES_BME>), grid, block, 0, st, small, big, nq, n_big); break;
-        case APPLES_BE: hipLaunchKernelGGL((k_sweep_mixed<APPLES_BE>), grid, block, 0, st, small, big, nq, n_big); break;
-        default: hipLaunchKernelGGL((k_sweep_mixed<APPLES_OLS>), grid, block, 0, st, small, big, nq, n_big); break;
+        case APPLES_FM: hipLaunchKernelGGL((k_sweep_mixed<APPLES_FM>), grid, block, dyn, st, small, big, nq, n_big); break;
+        case APPLES_BME: hipLaunchKernelGGL((k_sweep_mixed<APPLES_BME>), grid, block, dyn, st, small, big, nq, n_big); break;
+        case APPLES_BE: hipLaunchKernelGGL((k_sweep_mixed<APPLES_BE>), grid, block, dyn, st, small, big, nq, n_big); break;
+        default: hipLaunchKernelGGL((k_sweep_mixed<APPLES_OLS>), grid, block, dyn, st, small, big, nq, n_big); break;
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -802,11 +851,12 @@ int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs 
 template <int TEAM>
 static void launch_sweep_team(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st) {
     dim3 grid((unsigned)wgs), block(APPLES_TPB);
+    const size_t dyn = dyn_lds_bytes(a.tree, APPLES_TPB / TEAM);
     switch (a.method) {
-        case APPLES_FM: hipLaunchKernelGGL((k_sweep<APPLES_FM, TEAM>), grid, block, 0, st, a, nq); break;
-        case APPLES_BME: hipLaunchKernelGGL((k_sweep<APPLES_BME, TEAM>), grid, block, 0, st, a, nq); break;
-        case APPLES_BE: hipLaunchKernelGGL((k_sweep<APPLES_BE, TEAM>), grid, block, 0, st, a, nq); break;
-        default: hipLaunchKernelGGL((k_sweep<APPLES_OLS, TEAM>), grid, block, 0, st, a, nq); break;
+        case APPLES_FM: hipLaunchKernelGGL((k_sweep<APPLES_FM, TEAM>), grid, block, dyn, st, a, nq); break;
+        case APPLES_BME: hipLaunchKernelGGL((k_sweep<APPLES_BME, TEAM>), grid, block, dyn, st, a, nq); break;
+        case APPLES_BE: hipLaunchKernelGGL((k_sweep<APPLES_BE, TEAM>), grid, block, dyn, st, a, nq); break;
+        default: hipLaunchKernelGGL((k_sweep<APPLES_OLS, TEAM>), grid, block, dyn, st, a, nq); break;
     }
 }
 

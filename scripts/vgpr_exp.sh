@@ -1,4 +1,4 @@
-for w in 1 4 5 6; do
+for w in 1 3 4; do
   rm -f apples_amd/csrc/sweep.o
   APPLES_EXTRA_HIPCC_FLAGS="-DAPPLES_SWEEP_WAVES=$w" python -m apples_amd.build > /dev/null 2>&1
   echo "== min waves/SIMD $w"

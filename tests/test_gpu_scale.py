@@ -66,16 +66,15 @@ def test_all_observed_stress_and_batching(c2):
     eng.close()
 
 
-def test_map_tags_wrap_around(c2, monkeypatch):
-    """The sweep's node map is never cleared between queries: entries carry a per-query tag and the
-    table is wiped only when the tags run out.  Force 3-bit tags and 8 teams so that every team
-    wraps dozens of times; placements must not change."""
+def test_node_bits_in_global_scratch(c2, monkeypatch):
+    """The sweep keeps its valid-node bits in LDS for trees of this size and in per-team global
+    scratch for big trees; force the big-tree layout here and compare."""
     d, nodes = c2
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
     want = eng.place_sequences(d.query_seqs)
     eng.close()
-    monkeypatch.setenv('APPLES_MAP_BITS', '29')
-    monkeypatch.setenv('APPLES_SWEEP_TEAMS', '8')
+    monkeypatch.setenv('APPLES_BITS_GLOBAL', '1')
+    monkeypatch.setenv('APPLES_SWEEP_TEAMS', '64')
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
     got = eng.place_sequences(d.query_seqs)
     again = eng.place_sequences(d.query_seqs)
