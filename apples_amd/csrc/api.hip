@@ -252,7 +252,7 @@ int big_threshold() {
 }
 
 void free_sweep(Workspace::Sweep &sw) {
-    dev_free(sw.bits); dev_free(sw.pre); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
+    dev_free(sw.bits); dev_free(sw.pre); dev_free(sw.lvl_rng); dev_free(sw.order); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
     sw = Workspace::Sweep();
 }
 
@@ -293,7 +293,10 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
     if (!sweep_bits_in_lds(t)) {
         if (dev_alloc(ctx, &sw.bits, sw.teams * (int64_t)t.bm_words)) return 1;
         if (dev_alloc(ctx, &sw.pre, sw.teams * (int64_t)t.bm_words)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(sw.bits, 0, (size_t)sw.teams * t.bm_words * 8, ctx->stream));
+        if (dev_alloc(ctx, &sw.order, sw.teams * (cap + 1))) return 1;
     }
+    if (dev_alloc(ctx, &sw.lvl_rng, sw.teams * (int64_t)(t.height + 2) * 4)) return 1;
     if (dev_alloc(ctx, &sw.grp_off, sw.teams * (int64_t)(t.height + 4))) return 1;
     HIP_TRY(ctx, hipMalloc(&sw.A, (size_t)sw.teams * (cap + 1) * 64));
     if (t.max_children > 2) HIP_TRY(ctx, hipMalloc(&sw.B, (size_t)sw.teams * (cap + 1) * 48));
@@ -362,7 +365,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
-    int64_t per_node = 64 + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
+    int64_t per_node = 68 + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
     if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold())), xe)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
@@ -473,7 +476,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.tree = ctx->tree;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
-    s.bits = sw.bits; s.pre = sw.pre;
+    s.bits = sw.bits; s.pre = sw.pre; s.lvl_rng = sw.lvl_rng; s.order = sw.order;
     s.cap = sw.cap;
     s.leaf_cap = sw.leaf_cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;

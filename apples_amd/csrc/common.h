@@ -103,6 +103,8 @@ struct Workspace {
         int64_t teams = 0, cap = 0, leaf_cap = 0;
         unsigned long long *bits = nullptr; // [teams][bm_words] valid-node bits, when they do not fit in LDS
         uint32_t *pre = nullptr;  // [teams][bm_words] per-word ranks within a block
+        int32_t *lvl_rng = nullptr; // [teams][height+2][4] dirty word ranges per processed level
+        int32_t *order = nullptr; // [teams][cap+1] bit positions of the level's nodes, in order (big trees)
         int32_t *grp_off = nullptr; // [teams][height+4] level groups in compact order, deepest first
         void *A = nullptr;        // [teams][cap+1] Rec (64 B): S then R tuple, first two valid children, node
         void *B = nullptr;        // [teams][cap+1][6] R values in waiting; trees with polytomies only
@@ -216,6 +218,8 @@ struct SweepArgs {
     int32_t *grp_off; void *A, *B; double *xe;
     unsigned long long *bits; // [teams][bm_words] or nullptr: the bit space lives in LDS
     uint32_t *pre;
+    int32_t *lvl_rng;         // [teams][height+2][4] dirty word ranges per processed level
+    int32_t *order;           // [teams][cap+1] (big trees)
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
     int debug_phase;          // timing experiments only: 1 = stop after the bottom-up pass

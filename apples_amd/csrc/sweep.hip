@@ -321,8 +321,10 @@ __device__ __forceinline__ int kth_in_block(const NodeBits &nb, int w0, int w1, 
 }
 
 // per-word ranks of the block [w0, w1); returns the number of set bits.  One wavefront scans.
+// With `order_out`, also lists the set bit positions in order (at most `limit` of them).
 template <int TEAM>
-__device__ int block_ranks(const NodeBits &nb, int w0, int w1, int tid, int *sh_slot) {
+__device__ int block_ranks(const NodeBits &nb, int w0, int w1, int tid, int *sh_slot, int32_t *order_out = nullptr,
+                           int64_t limit = 0) {
     int run = 0;
     if (TEAM == WAVE || tid < WAVE) {
         const int lane = tid & (WAVE - 1);
@@ -336,6 +338,11 @@ __device__ int block_ranks(const NodeBits &nb, int w0, int w1, int tid, int *sh_
                 if (lane >= o) incl += t;
             }
             if (w < w1) nb.pre[w] = (uint32_t)(run + incl - c);
+            if (order_out && c) {
+                unsigned long long x = nb.bm[w];
+                for (int64_t o = run + incl - c; x; x &= x - 1, ++o)
+                    if (o < limit) order_out[o] = w * 64 + __ffsll((long long)x) - 1;
+            }
             run += __shfl(incl, WAVE - 1, WAVE);
         }
         if (TEAM != WAVE && tid == 0) *sh_slot = run;
@@ -383,6 +390,7 @@ struct SweepShared {
     double pow[384 + 256];
     double d[4];
     int cnt[APPLES_TPB / WAVE][4];
+    int rng[APPLES_TPB / WAVE][4];  // dirty word ranges: this level's leaf block, the next level's internal block
     int i[4];
     int w[APPLES_TPB / WAVE];
 };
@@ -421,6 +429,16 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
         nb.pre = reinterpret_cast<uint32_t *>(dyn_lds + (size_t)TEAMS_PER_WG * bm_words) + (size_t)team_in_wg * bm_words;
     }
     const int32_t *__restrict__ lvlw = T.lvlw;
+    int *sh_rng = sh.rng[team_in_wg];
+    // dirty word ranges per processed level (internal block, leaf block): only those are ranked,
+    // searched and, after the query, cleared
+    int32_t *lvl_rng = a.lvl_rng + team * (int64_t)(T.height + 2) * 4;
+    // Two layouts.  Small trees: the bit space is a few KB of LDS, cleared and ranked in full, and
+    // the k-th node of a level is found by a search over the ranks.  Big trees: per-team global
+    // scratch; only the dirty word range of each level is ranked and cleared, and the ranking pass
+    // lists the level's nodes (a search would be a chain of global loads).
+    const bool gbits = a.bits != nullptr;
+    int32_t *order = gbits ? a.order + team * (cap + 1) : nullptr;
     Rec *rec = reinterpret_cast<Rec *>(a.A) + team * (cap + 1);
     // R values of a polytomy's children wait here until all of them are formed (in-place update
     // would destroy sibling S values that are still needed); unused for binary trees
@@ -462,30 +480,58 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
 
         // ------------------------------------------------------------ bottom-up: mark + S values
-        for (int i = tid; i < bm_words; i += TEAM) nb.bm[i] = 0;  // unroll_changes of the previous query
-        team_sync<TEAM>();
-        // every observed leaf marks itself and its parent (a parent is in the subtree as soon as one
-        // child is; setting a bit twice is harmless, so nobody has to be "the" registering child)
-        for (int j = tid; j < n; j += TEAM) {
-            const NodeRec nr = NR[o_node[j]];
-            nb.set(nr.lpos);
-            if (nr.ppos >= 0 && n > 1) nb.set(nr.ppos);
-        }
         const int lvl_first = T.level[o_node[0]];
         int lvl = lvl_first;
         int base = 0, kid_base = 0, n_par = 0, G = 0, lca = -1;
+        int imin = 0x7fffffff, imax = -1;  // dirty words of this level's internal block (big trees)
         bool overflow = false;
-        team_sync<TEAM>();
+        if (!gbits) {
+            for (int i = tid; i < bm_words; i += TEAM) nb.bm[i] = 0;  // unroll_changes of the previous query
+            team_sync<TEAM>();
+            // every observed leaf marks itself and its parent (a parent is in the subtree as soon as
+            // one child is; setting a bit twice is harmless, so nobody has to be "the" registering child)
+            for (int j = tid; j < n; j += TEAM) {
+                const NodeRec nr = NR[o_node[j]];
+                nb.set(nr.lpos);
+                if (nr.ppos >= 0 && n > 1) nb.set(nr.ppos);
+            }
+            team_sync<TEAM>();
+        }
         while (true) {
             const int lo = cg[lvl + 1], hi = cg[lvl];  // observed leaves of this level: obs[lo, hi)
             const int n_leaf = hi - lo;
-            const int w0 = lvlw[2 * lvl], w1 = lvlw[2 * lvl + 1], w2 = lvlw[2 * lvl + 2];
+            int w0, w1, wl0, wl1;  // words of this level's internal block and leaf block
+            if (gbits) {
+                if (tid == 0) { sh_rng[0] = 0x7fffffff; sh_rng[1] = -1; sh_rng[2] = 0x7fffffff; sh_rng[3] = -1; }
+                team_sync<TEAM>();
+                for (int k = tid; k < n_leaf; k += TEAM) {  // this level's leaves mark themselves and their parents
+                    const NodeRec nr = NR[o_node[lo + k]];
+                    nb.set(nr.lpos);
+                    atomicMin(&sh_rng[0], nr.lpos >> 6);
+                    atomicMax(&sh_rng[1], nr.lpos >> 6);
+                    if (nr.ppos >= 0 && n > 1) {
+                        nb.set(nr.ppos);
+                        atomicMin(&sh_rng[2], nr.ppos >> 6);
+                        atomicMax(&sh_rng[3], nr.ppos >> 6);
+                    }
+                }
+                team_sync<TEAM>();
+                const int lmin = sh_rng[0], lmax = sh_rng[1];
+                if (tid == 0) {
+                    int32_t *rg = lvl_rng + (int64_t)G * 4;
+                    rg[0] = imin; rg[1] = imax; rg[2] = lmin; rg[3] = lmax;
+                }
+                w0 = imax >= 0 ? imin : 0; w1 = imax + 1;
+                wl0 = lmax >= 0 ? lmin : 0; wl1 = lmax + 1;
+            } else {
+                w0 = lvlw[2 * lvl]; w1 = wl0 = lvlw[2 * lvl + 1]; wl1 = lvlw[2 * lvl + 2];
+            }
             // all children of this level's nodes have reported: rank the level's two blocks
-            n_par = block_ranks<TEAM>(nb, w0, w1, tid, &sh_cnt[0]);
-            block_ranks<TEAM>(nb, w1, w2, tid, &sh_cnt[0]);
+            n_par = w1 > w0 ? block_ranks<TEAM>(nb, w0, w1, tid, &sh_cnt[0], gbits ? order + base : nullptr, cap + 1 - base) : 0;
+            if (wl1 > wl0) block_ranks<TEAM>(nb, wl0, wl1, tid, &sh_cnt[0]);
             team_sync<TEAM>();
             if (n_par + n_leaf == 1 && hi == n) {  // one node left in the frontier: the LCA (Subtree.py:36-43)
-                lca = (n_par == 1) ? T.lnode[kth_in_block(nb, w0, w1, 0)] : o_node[lo];
+                lca = (n_par == 1) ? T.lnode[gbits ? order[base] : kth_in_block(nb, w0, w1, 0)] : o_node[lo];
                 break;
             }
             if (cap < nn && (int64_t)base + n_par > cap) { overflow = true; break; }
@@ -498,7 +544,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                 const bool active = k < n_par;
                 if (active) {
                     Rec r;
-                    r.node = T.lnode[kth_in_block(nb, w0, w1, k)];
+                    r.node = T.lnode[gbits ? order[base + k] : kth_in_block(nb, w0, w1, k)];
                     const NodeRec nr = NR[r.node];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) r.T[c] = 0;
@@ -552,7 +598,13 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         }
                         r.meta = (uint32_t)nk | META_POLY;
                     }
-                    if (nr.ppos >= 0) nb.set(nr.ppos);
+                    if (nr.ppos >= 0) {
+                        nb.set(nr.ppos);
+                        if (gbits) {
+                            atomicMin(&sh_rng[2], nr.ppos >> 6);
+                            atomicMax(&sh_rng[3], nr.ppos >> 6);
+                        }
+                    }
                     // stage the record; its 64 bytes leave as part of a 1-KiB row below
                     const uint4 *src = reinterpret_cast<const uint4 *>(&r);
 #pragma unroll
@@ -572,12 +624,31 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                 __builtin_amdgcn_wave_barrier();
             }
             team_sync<TEAM>();
+            if (gbits) {
+                imin = sh_rng[2]; imax = sh_rng[3];
+                team_sync<TEAM>();
+            }
             kid_base = base;
             base += n_par;
             ++G;
             --lvl;
         }
-        if (overflow) {  // hand the query to the big-team launch (this team's marks die with the tag)
+        // unroll_changes (Subtree.py:72-76), big trees: clear the dirty words of every level touched
+        auto clear_bits = [&](int levels, int xmin, int xmax) {
+            if (!gbits) return;
+            for (int g = 0; g < levels; ++g) {
+                const int32_t *rg = lvl_rng + (int64_t)g * 4;
+                if (rg[1] >= 0)  // (an empty range is [INT_MAX, -1])
+                    for (int w = rg[0] + tid; w <= rg[1]; w += TEAM) nb.bm[w] = 0;
+                if (rg[3] >= 0)
+                    for (int w = rg[2] + tid; w <= rg[3]; w += TEAM) nb.bm[w] = 0;
+            }
+            if (xmax >= 0)
+                for (int w = xmin + tid; w <= xmax; w += TEAM) nb.bm[w] = 0;
+        };
+        if (overflow) {  // hand the query to the big-team launch; undo this team's marks first
+            team_sync<TEAM>();
+            clear_bits(G + 1, sh_rng[2], sh_rng[3]);
             if (tid == 0) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
             team_sync<TEAM>();
             continue;
@@ -790,6 +861,8 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
             a.out[q] = pl;
         }
         if (tid == 0) { grp_off[T.height + 3] = lca; grp_off[T.height + 2] = VI; }
+        team_sync<TEAM>();
+        clear_bits(G + 1, 0, -1);
         team_sync<TEAM>();
     }
 }
