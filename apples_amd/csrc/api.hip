@@ -83,7 +83,18 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
         r.lpos = lpos[i];
         r.ppos = t->parent[i] >= 0 ? lpos[t->parent[i]] : -1;
         r.e = t->edge_len[i];
+        r.c0pos = r.c0 >= 0 ? lpos[r.c0] : -1;
+        r.c1pos = r.c1 >= 0 ? lpos[r.c1] : -1;
+        r.e0 = r.c0 >= 0 ? t->edge_len[r.c0] : 0.0;
+        r.e1 = r.c1 >= 0 ? t->edge_len[r.c1] : 0.0;
+        r.kleaf = 0;
+        if (r.c0 >= 0 && t->child_off[r.c0 + 1] == t->child_off[r.c0]) r.kleaf |= 1u;
+        if (r.c1 >= 0 && t->child_off[r.c1 + 1] == t->child_off[r.c1]) r.kleaf |= 2u;
+        r.pad = 0;
     }
+    std::vector<int32_t> npos((size_t)t->n_nodes * 2);
+    for (int i = 0; i < t->n_nodes; ++i) { npos[2 * (size_t)i] = rec[i].lpos; npos[2 * (size_t)i + 1] = rec[i].ppos; }
+    if (dev_upload(ctx, &d.npos, npos.data(), (int64_t)npos.size())) return 1;
     if (dev_upload(ctx, &d.rec, rec.data(), t->n_nodes)) return 1;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -252,7 +263,7 @@ int big_threshold() {
 }
 
 void free_sweep(Workspace::Sweep &sw) {
-    dev_free(sw.bits); dev_free(sw.pre); dev_free(sw.lvl_rng); dev_free(sw.order); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
+    dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
     sw = Workspace::Sweep();
 }
 
@@ -291,12 +302,12 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
     sw.cap = cap;
     sw.leaf_cap = leaf_cap;
     if (!sweep_bits_in_lds(t)) {
-        if (dev_alloc(ctx, &sw.bits, sw.teams * (int64_t)t.bm_words)) return 1;
-        if (dev_alloc(ctx, &sw.pre, sw.teams * (int64_t)t.bm_words)) return 1;
-        HIP_TRY(ctx, hipMemsetAsync(sw.bits, 0, (size_t)sw.teams * t.bm_words * 8, ctx->stream));
+        if (dev_alloc(ctx, &sw.map, sw.teams * (int64_t)t.n_nodes)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(sw.map, 0, (size_t)sw.teams * t.n_nodes * 4, ctx->stream));
+        if (dev_alloc(ctx, &sw.ver, sw.teams)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(sw.ver, 0, (size_t)sw.teams * 4, ctx->stream));
         if (dev_alloc(ctx, &sw.order, sw.teams * (cap + 1))) return 1;
     }
-    if (dev_alloc(ctx, &sw.lvl_rng, sw.teams * (int64_t)(t.height + 2) * 4)) return 1;
     if (dev_alloc(ctx, &sw.grp_off, sw.teams * (int64_t)(t.height + 4))) return 1;
     HIP_TRY(ctx, hipMalloc(&sw.A, (size_t)sw.teams * (cap + 1) * 64));
     if (t.max_children > 2) HIP_TRY(ctx, hipMalloc(&sw.B, (size_t)sw.teams * (cap + 1) * 48));
@@ -361,7 +372,8 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     int64_t nn = t.n_nodes;
     // (with the dynamic queue the rate is flat from 2 048 to 8 192 teams: the kernel is bound by HBM
     // random-access traffic, not by latency; 4 096 keeps the scratch footprint moderate)
-    int64_t teams = 4096;
+    // big trees keep a node map of n_nodes ints per team (<= ~8 GiB in total)
+    int64_t teams = sweep_bits_in_lds(t) ? 4096 : std::min<int64_t>(4096, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
@@ -369,7 +381,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
     if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold())), xe)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
-    int64_t per_wg = nn * per_node + (int64_t)t.bm_words * 12 + (t.height + 4) * 4;
+    int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 4;
     int64_t big_max = getenv("APPLES_SWEEP_BIG_WGS") ? atoi(getenv("APPLES_SWEEP_BIG_WGS")) : 512;
     int wgs_big = (int)std::min<int64_t>(big_max, std::max<int64_t>(4, ((int64_t)24 << 30) / std::max<int64_t>(per_wg, 1)));
     wgs_big = (int)std::min<int64_t>(wgs_big, batch);
@@ -476,7 +488,10 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.tree = ctx->tree;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
-    s.bits = sw.bits; s.pre = sw.pre; s.lvl_rng = sw.lvl_rng; s.order = sw.order;
+    s.map = sw.map; s.map_ver = sw.ver; s.order = sw.order;
+    s.map_bits = 1;
+    while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
+    if (const char *e = getenv("APPLES_MAP_BITS")) s.map_bits = std::min(30, std::max(s.map_bits, atoi(e)));  // test knob: few tags, early wrap
     s.cap = sw.cap;
     s.leaf_cap = sw.leaf_cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
@@ -727,7 +742,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     for (auto &qb : ctx->blocks) free_block(&qb);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
-    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode);
+    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.npos);
     DevAlign &a = ctx->aln;
     dev_free(a.raw); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);

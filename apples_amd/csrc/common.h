@@ -11,13 +11,20 @@
 #define APPLES_TPB 256  // threads per workgroup in every kernel: 4 wave64
 
 // Tree constants of one node in one 32-byte record (one memory transaction per visit).
-struct __attribute__((aligned(32))) NodeRec {
+// Tree constants of a node and what a parent needs to know about its first two children, in one
+// 64-byte line: the sweep's level steps are chains of dependent loads, and a separate load of the
+// children's records would add a link to every step.
+struct __attribute__((aligned(64))) NodeRec {
     int32_t parent;     // -1 for the root
     int32_t c0, c1;     // first two children in file order (-1 if absent)
     int32_t nchild;
     int32_t lpos;       // position in the level-ordered bit space (sweep.hip NodeBits)
     int32_t ppos;       // the parent's lpos (-1 for the root)
+    int32_t c0pos, c1pos; // the children's lpos
     double e;           // edge length
+    double e0, e1;      // the children's edge lengths
+    uint32_t kleaf;     // bit 0: c0 is a leaf, bit 1: c1 is a leaf
+    int32_t pad;
 };
 
 struct DevTree {
@@ -35,6 +42,7 @@ struct DevTree {
     int32_t bm_words = 0;        // 64-bit words of the whole space
     int32_t *lvlw = nullptr;     // [2*(height+1)+1] first word of level l's internal block at 2l, leaf block at 2l+1
     int32_t *lnode = nullptr;    // [bm_words*64] node at a bit position (-1 = padding)
+    int32_t *npos = nullptr;     // [n_nodes][2] lpos, ppos (what a leaf needs, without its 64-byte record)
 };
 
 // Slot = physical position of an alignment row on the device.  Member slots [0, n_refs) are the
@@ -101,10 +109,9 @@ struct Workspace {
     struct Sweep {
         int32_t wgs = 0;          // workgroups of the launch
         int64_t teams = 0, cap = 0, leaf_cap = 0;
-        unsigned long long *bits = nullptr; // [teams][bm_words] valid-node bits, when they do not fit in LDS
-        uint32_t *pre = nullptr;  // [teams][bm_words] per-word ranks within a block
-        int32_t *lvl_rng = nullptr; // [teams][height+2][4] dirty word ranges per processed level
-        int32_t *order = nullptr; // [teams][cap+1] bit positions of the level's nodes, in order (big trees)
+        uint32_t *map = nullptr;  // [teams][n_nodes] big trees: node -> tagged descriptor (sweep.hip NodeMap)
+        uint32_t *ver = nullptr;  // [teams] last tag used in the team's map
+        int32_t *order = nullptr; // [teams][cap+1] big trees: node ids in compact order
         int32_t *grp_off = nullptr; // [teams][height+4] level groups in compact order, deepest first
         void *A = nullptr;        // [teams][cap+1] Rec (64 B): S then R tuple, first two valid children, node
         void *B = nullptr;        // [teams][cap+1][6] R values in waiting; trees with polytomies only
@@ -216,10 +223,10 @@ struct SweepArgs {
     DevTree tree;
     const int32_t *obs_node; const double *obs_dist; int64_t obs_cap; const int32_t *cnt_gt; const int32_t *n_obs;
     int32_t *grp_off; void *A, *B; double *xe;
-    unsigned long long *bits; // [teams][bm_words] or nullptr: the bit space lives in LDS
-    uint32_t *pre;
-    int32_t *lvl_rng;         // [teams][height+2][4] dirty word ranges per processed level
-    int32_t *order;           // [teams][cap+1] (big trees)
+    uint32_t *map;            // big trees: [teams][n_nodes] tagged node map; nullptr = node bits in LDS
+    uint32_t *map_ver;        // [teams] version tags of the maps
+    int32_t *order;           // [teams][cap+1]
+    int map_bits;             // payload bits of a map entry; the tag sits above them
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
     int debug_phase;          // timing experiments only: 1 = stop after the bottom-up pass
@@ -236,7 +243,7 @@ struct SweepArgs {
     int32_t *overflow_count;
     apples_placement *out;
 };
-bool sweep_bits_in_lds(const DevTree &t);  // the sweep's node bits fit in LDS (else per-team global scratch)
+bool sweep_bits_in_lds(const DevTree &t);  // the sweep's node bits fit in LDS (else: tagged node map in global scratch)
 int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team, hipStream_t stream = nullptr);
 int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,
                        hipStream_t st);

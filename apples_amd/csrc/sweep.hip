@@ -7,24 +7,25 @@
 //   placement_per_edge apples/OLS.py:83-97 + apples/util.py:6-54   -> fused into the top-down loop
 //   error_per_edge     apples/OLS.py:100-128 ... -> fused into the top-down loop
 //   placement          apples/Algorithm.py:62-101 -> wavefront/LDS arg-min over the candidates
-//   unroll_changes     apples/Subtree.py:72-76   -> the team's map tag is incremented
+//   unroll_changes     apples/Subtree.py:72-76   -> the team's node bits are cleared / its map tag is incremented
 //
 // The reference pops the deepest frontier node, marks it valid and pushes its parent until one
 // node (the LCA) is left.  Level-synchronous form: the nodes at level l are the observed leaves
-// of that level (contiguous in the level-sorted obs list) plus the parents registered from level
+// of that level (contiguous in the level-sorted obs list) plus the parents reported from level
 // l+1; the loop stops when a level holds a single node and no shallower leaves remain.
 //
-// Data layout (the kernel is bound by HBM/L2 misses on scattered 64-byte lines, so lines are few
-// and whole): NodeRec (32 B, tree constant: parent, first two children, previous sibling, edge
-// length); per team and per INTERNAL subtree node, in compact order of discovery, one Rec (64 B:
-// a tuple, descriptors of the first two valid children, node id).  The tuple is S after the
-// bottom-up pass and is overwritten with R by the node's parent on the way down.  Observed leaves
-// get no record: a leaf is named by its position j in the query's level-sorted observation list
-// (child descriptor -(j+2)) and its tuple is rebuilt from the distance whenever a parent needs it.
-// The top-down pass is parent-centric: a node forms each valid child's R (siblings in file order,
-// then its own lifted R), solves that child's 2x2 system and residual, and stores R only for
-// children that are internal.  The node -> descriptor map carries a per-query tag, so it is
-// never cleared.
+// Data layout (the kernel is bound by HBM/L2 misses on scattered 64-byte lines and by the chain of
+// dependent loads in every level step, so lines are few and whole): NodeRec (64 B, tree constant:
+// the node and what a parent needs of its first two children); per team and per INTERNAL subtree
+// node, in compact order, one Rec (64 B: a tuple, descriptors of the first two valid children,
+// node id).  The tuple is S after the bottom-up pass and is overwritten with R by the node's
+// parent on the way down.  Observed leaves get no record: a leaf is named by its position j in
+// the query's level-sorted observation list (child descriptor -(j+2)) and its tuple is rebuilt
+// from the distance whenever a parent needs it.  The top-down pass is parent-centric: a node forms
+// each valid child's R (siblings in file order, then its own lifted R), solves that child's 2x2
+// system and residual, and stores R only for children that are internal.
+// Which nodes are in the subtree, and where their records are: NodeBits (LDS, trees up to ~50 k
+// nodes) or NodeMap (global scratch, bigger trees), see below.
 //
 // Bit parity: fp64, compiled with -ffp-contract=off; every sum is taken in the order of the
 // cited source line, children/siblings in file order and the parent term last.
@@ -285,15 +286,48 @@ struct NodeBits {
     uint32_t *pre;  // per word: set bits of the same block in earlier words
     // child descriptor of the node with tree record nc: > 0 internal (compact index + 1),
     // <= -2 observed leaf (-(j+2)), 0 not in the subtree
-    __device__ __forceinline__ int desc(const NodeRec &nc, int base_int, int lo_leaf) const {
-        const int w = nc.lpos >> 6, b = nc.lpos & 63;
+    __device__ __forceinline__ int desc_at(int lpos, bool leaf, int base_int, int lo_leaf) const {
+        const int w = lpos >> 6, b = lpos & 63;
         const unsigned long long word = bm[w];
         if (!((word >> b) & 1ull)) return 0;
         const int r = (int)pre[w] + __popcll(word & ((1ull << b) - 1ull));
-        return nc.nchild == 0 ? -(lo_leaf + r) - 2 : base_int + r + 1;
+        return leaf ? -(lo_leaf + r) - 2 : base_int + r + 1;
+    }
+    __device__ __forceinline__ int desc(const NodeRec &nc, int base_int, int lo_leaf) const {
+        return desc_at(nc.lpos, nc.nchild == 0, base_int, lo_leaf);
     }
     __device__ __forceinline__ void set(int lpos) const { atomicOr(&bm[lpos >> 6], 1ull << (lpos & 63)); }
 };
+
+// Big trees (the bit space would not fit in LDS): a per-team node -> descriptor table in global
+// scratch.  Entries carry the query's tag in their high bits, so the table is never cleared
+// between queries (unroll_changes becomes a counter increment; wiped once when the tags run out).
+struct NodeMap {
+    uint32_t *m;
+    uint32_t ver;
+    int vb;
+    __device__ __forceinline__ int get(int v) const {
+        const uint32_t w = m[v];
+        if ((w >> vb) != ver) return 0;
+        const uint32_t p = w & ((1u << vb) - 1u);
+        if (p == 0) return 0;  // claimed, index not stored yet: never read in that state
+        return (p & 1u) ? -(int)(p >> 1) - 1 : (int)(p >> 1);
+    }
+    __device__ __forceinline__ void set_internal(int v, int idx) const { m[v] = (ver << vb) | ((uint32_t)(idx + 1) << 1); }
+    __device__ __forceinline__ void set_leaf(int v, int j) const { m[v] = (ver << vb) | ((uint32_t)(j + 1) << 1) | 1u; }
+    // first child to report a parent in this query (tags only grow, so one atomic max decides)
+    __device__ __forceinline__ bool claim(int v) const { return atomicMax(&m[v], ver << vb) < (ver << vb); }
+};
+
+// Position of a registering lane in the next level's list: lanes of a wavefront in lane order, one
+// LDS add per wavefront for the block of positions.  Must be reached by the whole wavefront.
+__device__ __forceinline__ int ordered_slot(bool claim, int lane, int *counter) {
+    const unsigned long long m = __ballot(claim);
+    int wb = 0;
+    if (lane == 0 && m) wb = atomicAdd(counter, __popcll(m));
+    wb = __shfl(wb, 0, WAVE);
+    return wb + __popcll(m & ((1ull << lane) - 1ull));
+}
 
 // position of the k-th (0-based) set bit of x
 __device__ __forceinline__ int select64(unsigned long long x, int k) {
@@ -321,10 +355,8 @@ __device__ __forceinline__ int kth_in_block(const NodeBits &nb, int w0, int w1, 
 }
 
 // per-word ranks of the block [w0, w1); returns the number of set bits.  One wavefront scans.
-// With `order_out`, also lists the set bit positions in order (at most `limit` of them).
 template <int TEAM>
-__device__ int block_ranks(const NodeBits &nb, int w0, int w1, int tid, int *sh_slot, int32_t *order_out = nullptr,
-                           int64_t limit = 0) {
+__device__ int block_ranks(const NodeBits &nb, int w0, int w1, int tid, int *sh_slot) {
     int run = 0;
     if (TEAM == WAVE || tid < WAVE) {
         const int lane = tid & (WAVE - 1);
@@ -338,11 +370,6 @@ __device__ int block_ranks(const NodeBits &nb, int w0, int w1, int tid, int *sh_
                 if (lane >= o) incl += t;
             }
             if (w < w1) nb.pre[w] = (uint32_t)(run + incl - c);
-            if (order_out && c) {
-                unsigned long long x = nb.bm[w];
-                for (int64_t o = run + incl - c; x; x &= x - 1, ++o)
-                    if (o < limit) order_out[o] = w * 64 + __ffsll((long long)x) - 1;
-            }
             run += __shfl(incl, WAVE - 1, WAVE);
         }
         if (TEAM != WAVE && tid == 0) *sh_slot = run;
@@ -390,7 +417,6 @@ struct SweepShared {
     double pow[384 + 256];
     double d[4];
     int cnt[APPLES_TPB / WAVE][4];
-    int rng[APPLES_TPB / WAVE][4];  // dirty word ranges: this level's leaf block, the next level's internal block
     int i[4];
     int w[APPLES_TPB / WAVE];
 };
@@ -418,27 +444,32 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
     const int64_t nn = T.n_nodes;
     const int64_t cap = a.cap;  // scratch capacity of this launch's teams, in internal nodes
     const int64_t team = (int64_t)blockIdx.x * TEAMS_PER_WG + team_in_wg;
+    // Two ways to know which nodes are in the subtree.  Small trees: the level-ordered bit space,
+    // a few KB of LDS per team.  Big trees: the tagged node map in global scratch.
+    const bool umap = a.map != nullptr;
     NodeBits nb;
+    NodeMap map;
     const int bm_words = T.bm_words;
-    if (a.bits) {
-        nb.bm = a.bits + team * bm_words;
-        nb.pre = a.pre + team * bm_words;
+    int32_t *order = nullptr;  // big trees: node ids in compact order
+    if (umap) {
+        map.m = a.map + team * nn;
+        map.vb = a.map_bits;
+        map.ver = a.map_ver[team];
+        order = a.order + team * (cap + 1);
+        nb.bm = nullptr; nb.pre = nullptr;
     } else {  // dynamic LDS: [teams of this workgroup][bm_words] words, then the ranks
         extern __shared__ unsigned long long dyn_lds[];
         nb.bm = dyn_lds + (size_t)team_in_wg * bm_words;
         nb.pre = reinterpret_cast<uint32_t *>(dyn_lds + (size_t)TEAMS_PER_WG * bm_words) + (size_t)team_in_wg * bm_words;
+        map.m = nullptr; map.vb = 0; map.ver = 0;
     }
+    const uint32_t ver_max = umap ? (1u << (32 - a.map_bits)) - 1u : 0u;
     const int32_t *__restrict__ lvlw = T.lvlw;
-    int *sh_rng = sh.rng[team_in_wg];
-    // dirty word ranges per processed level (internal block, leaf block): only those are ranked,
-    // searched and, after the query, cleared
-    int32_t *lvl_rng = a.lvl_rng + team * (int64_t)(T.height + 2) * 4;
-    // Two layouts.  Small trees: the bit space is a few KB of LDS, cleared and ranked in full, and
-    // the k-th node of a level is found by a search over the ranks.  Big trees: per-team global
-    // scratch; only the dirty word range of each level is ranked and cleared, and the ranking pass
-    // lists the level's nodes (a search would be a chain of global loads).
-    const bool gbits = a.bits != nullptr;
-    int32_t *order = gbits ? a.order + team * (cap + 1) : nullptr;
+    const int2 *__restrict__ npos = reinterpret_cast<const int2 *>(T.npos);
+    // descriptor of node v (tree record position lpos / leaf flag), whichever layout is in use
+    auto desc_of = [&](int v, int lpos, bool leaf, int base_int, int lo_leaf) -> int {
+        return umap ? map.get(v) : nb.desc_at(lpos, leaf, base_int, lo_leaf);
+    };
     Rec *rec = reinterpret_cast<Rec *>(a.A) + team * (cap + 1);
     // R values of a polytomy's children wait here until all of them are formed (in-place update
     // would destroy sibling S values that are still needed); unused for binary trees
@@ -483,76 +514,80 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
         const int lvl_first = T.level[o_node[0]];
         int lvl = lvl_first;
         int base = 0, kid_base = 0, n_par = 0, G = 0, lca = -1;
-        int imin = 0x7fffffff, imax = -1;  // dirty words of this level's internal block (big trees)
         bool overflow = false;
-        if (!gbits) {
+        if (umap) {
+            // a fresh tag for this query's map entries; when the tags run out, wipe the table once
+            if (map.ver == ver_max) {
+                team_sync<TEAM>();
+                for (int64_t i = tid; i < nn; i += TEAM) map.m[i] = 0;
+                map.ver = 0;
+                team_sync<TEAM>();
+            }
+            ++map.ver;
+            if (tid < 3) sh_cnt[tid] = 0;
+            for (int j = tid; j < n; j += TEAM) map.set_leaf(o_node[j], j);
+        } else {
             for (int i = tid; i < bm_words; i += TEAM) nb.bm[i] = 0;  // unroll_changes of the previous query
             team_sync<TEAM>();
             // every observed leaf marks itself and its parent (a parent is in the subtree as soon as
             // one child is; setting a bit twice is harmless, so nobody has to be "the" registering child)
             for (int j = tid; j < n; j += TEAM) {
-                const NodeRec nr = NR[o_node[j]];
-                nb.set(nr.lpos);
-                if (nr.ppos >= 0 && n > 1) nb.set(nr.ppos);
+                const int2 np = npos[o_node[j]];
+                nb.set(np.x);
+                if (np.y >= 0 && n > 1) nb.set(np.y);
             }
-            team_sync<TEAM>();
         }
+        team_sync<TEAM>();
         while (true) {
             const int lo = cg[lvl + 1], hi = cg[lvl];  // observed leaves of this level: obs[lo, hi)
             const int n_leaf = hi - lo;
-            int w0, w1, wl0, wl1;  // words of this level's internal block and leaf block
-            if (gbits) {
-                if (tid == 0) { sh_rng[0] = 0x7fffffff; sh_rng[1] = -1; sh_rng[2] = 0x7fffffff; sh_rng[3] = -1; }
+            int w0 = 0, w1 = 0;
+            if (!umap) {
+                // all children of this level's nodes have reported: rank the level's two blocks
+                w0 = lvlw[2 * lvl]; w1 = lvlw[2 * lvl + 1];
+                const int wl1 = lvlw[2 * lvl + 2];
+                n_par = block_ranks<TEAM>(nb, w0, w1, tid, &sh_cnt[0]);
+                block_ranks<TEAM>(nb, w1, wl1, tid, &sh_cnt[0]);
                 team_sync<TEAM>();
-                for (int k = tid; k < n_leaf; k += TEAM) {  // this level's leaves mark themselves and their parents
-                    const NodeRec nr = NR[o_node[lo + k]];
-                    nb.set(nr.lpos);
-                    atomicMin(&sh_rng[0], nr.lpos >> 6);
-                    atomicMax(&sh_rng[1], nr.lpos >> 6);
-                    if (nr.ppos >= 0 && n > 1) {
-                        nb.set(nr.ppos);
-                        atomicMin(&sh_rng[2], nr.ppos >> 6);
-                        atomicMax(&sh_rng[3], nr.ppos >> 6);
-                    }
-                }
-                team_sync<TEAM>();
-                const int lmin = sh_rng[0], lmax = sh_rng[1];
-                if (tid == 0) {
-                    int32_t *rg = lvl_rng + (int64_t)G * 4;
-                    rg[0] = imin; rg[1] = imax; rg[2] = lmin; rg[3] = lmax;
-                }
-                w0 = imax >= 0 ? imin : 0; w1 = imax + 1;
-                wl0 = lmax >= 0 ? lmin : 0; wl1 = lmax + 1;
-            } else {
-                w0 = lvlw[2 * lvl]; w1 = wl0 = lvlw[2 * lvl + 1]; wl1 = lvlw[2 * lvl + 2];
             }
-            // all children of this level's nodes have reported: rank the level's two blocks
-            n_par = w1 > w0 ? block_ranks<TEAM>(nb, w0, w1, tid, &sh_cnt[0], gbits ? order + base : nullptr, cap + 1 - base) : 0;
-            if (wl1 > wl0) block_ranks<TEAM>(nb, wl0, wl1, tid, &sh_cnt[0]);
-            team_sync<TEAM>();
             if (n_par + n_leaf == 1 && hi == n) {  // one node left in the frontier: the LCA (Subtree.py:36-43)
-                lca = (n_par == 1) ? T.lnode[gbits ? order[base] : kth_in_block(nb, w0, w1, 0)] : o_node[lo];
+                lca = (n_par == 1) ? (umap ? order[base] : T.lnode[kth_in_block(nb, w0, w1, 0)]) : o_node[lo];
                 break;
             }
-            if (cap < nn && (int64_t)base + n_par > cap) { overflow = true; break; }
-            if (tid == 0) grp_off[G] = base;
+            if (cap < nn && (int64_t)base + (umap ? 2 * (int64_t)n_par + n_leaf : (int64_t)n_par) > cap) { overflow = true; break; }
+            if (tid == 0) { grp_off[G] = base; if (umap) sh_cnt[(G + 1) % 3] = 0; }
+            int *next_cnt = &sh_cnt[G % 3];
+            const int next_base = base + n_par;
+            if (umap) {  // observed leaves of this level: the first child to report registers the parent
+                for (int k0 = 0; k0 < n_leaf; k0 += TEAM) {  // team-uniform trip count
+                    const int k = k0 + tid;
+                    int parent = -1;
+                    bool claimer = false;
+                    if (k < n_leaf) {
+                        parent = NR[o_node[lo + k]].parent;
+                        claimer = parent >= 0 && map.claim(parent);
+                    }
+                    const int nidx = next_base + ordered_slot(claimer, lane, next_cnt);
+                    if (claimer) { order[nidx] = parent; map.set_internal(parent, nidx); }
+                }
+            }
             const int lo_kids = lvl + 2 <= T.height + 1 ? cg[lvl + 2] : 0;  // first observed leaf of the level below
             // internal nodes of this level, in node-id order: S tuple from the valid children in
             // file order, then tell the parent
             for (int k0 = 0; k0 < n_par; k0 += TEAM) {  // team-uniform trip count
                 const int k = k0 + tid;
                 const bool active = k < n_par;
+                int parent = -1;
                 if (active) {
                     Rec r;
-                    r.node = T.lnode[gbits ? order[base + k] : kth_in_block(nb, w0, w1, k)];
+                    r.node = umap ? order[base + k] : T.lnode[kth_in_block(nb, w0, w1, k)];
                     const NodeRec nr = NR[r.node];
+                    parent = nr.parent;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) r.T[c] = 0;
                     if (nr.nchild <= 2) {
-                        NodeRec kr0, kr1;
-                        int m0 = 0, m1 = 0;
-                        if (nr.nchild >= 1) { kr0 = NR[nr.c0]; m0 = nb.desc(kr0, kid_base, lo_kids); }
-                        if (nr.nchild >= 2) { kr1 = NR[nr.c1]; m1 = nb.desc(kr1, kid_base, lo_kids); }
+                        const int m0 = nr.nchild >= 1 ? desc_of(nr.c0, nr.c0pos, nr.kleaf & 1u, kid_base, lo_kids) : 0;
+                        const int m1 = nr.nchild >= 2 ? desc_of(nr.c1, nr.c1pos, nr.kleaf & 2u, kid_base, lo_kids) : 0;
                         const int nk = (m0 != 0) + (m1 != 0);
                         const double coef = BME ? 1.0 / (double)nk : 1.0;  // apples/BME.py:20
                         r.k0 = m0 ? m0 : m1;
@@ -560,7 +595,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         r.meta = (uint32_t)nk | ((!m0) ? META_K0C1 : 0u);
                         {
                             Kid kd;
-                            load_kid<M>(r.k0, m0 ? nr.c0 : nr.c1, m0 ? kr0.e : kr1.e, rec, o_dist, kd);
+                            load_kid<M>(r.k0, m0 ? nr.c0 : nr.c1, m0 ? nr.e0 : nr.e1, rec, o_dist, kd);
                             double t[6];
                             lift<M>(kd.S, kd.e, t);
 #pragma unroll
@@ -568,7 +603,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         }
                         if (nk > 1) {
                             Kid kd;
-                            load_kid<M>(r.k1, nr.c1, kr1.e, rec, o_dist, kd);
+                            load_kid<M>(r.k1, nr.c1, nr.e1, rec, o_dist, kd);
                             double t[6];
                             lift<M>(kd.S, kd.e, t);
 #pragma unroll
@@ -579,14 +614,14 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         r.k0 = r.k1 = 0;
                         const int cb = T.child_off[r.node], ce = cb + nr.nchild;
                         for (int ci = cb; ci < ce; ++ci) {
-                            const int mc = nb.desc(NR[T.child_idx[ci]], kid_base, lo_kids);
+                            const int mc = desc_of(T.child_idx[ci], npos[T.child_idx[ci]].x, NR[T.child_idx[ci]].nchild == 0, kid_base, lo_kids);
                             if (mc != 0) { if (nk == 0) r.k0 = mc; else if (nk == 1) r.k1 = mc; ++nk; }
                         }
                         const double coef = BME ? 1.0 / (double)nk : 1.0;
                         for (int ci = cb; ci < ce; ++ci) {
                             const int cn = T.child_idx[ci];
                             const NodeRec cr = NR[cn];
-                            const int mc = nb.desc(cr, kid_base, lo_kids);
+                            const int mc = desc_of(cn, cr.lpos, cr.nchild == 0, kid_base, lo_kids);
                             if (mc != 0) {
                                 Kid kd;
                                 load_kid<M>(mc, cn, cr.e, rec, o_dist, kd);
@@ -598,13 +633,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         }
                         r.meta = (uint32_t)nk | META_POLY;
                     }
-                    if (nr.ppos >= 0) {
-                        nb.set(nr.ppos);
-                        if (gbits) {
-                            atomicMin(&sh_rng[2], nr.ppos >> 6);
-                            atomicMax(&sh_rng[3], nr.ppos >> 6);
-                        }
-                    }
+                    if (!umap && nr.ppos >= 0) nb.set(nr.ppos);  // tell the parent
                     // stage the record; its 64 bytes leave as part of a 1-KiB row below
                     const uint4 *src = reinterpret_cast<const uint4 *>(&r);
 #pragma unroll
@@ -622,33 +651,20 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                if (umap) {
+                    const bool claimer = active && parent >= 0 && map.claim(parent);
+                    const int nidx = next_base + ordered_slot(claimer, lane, next_cnt);
+                    if (claimer) { order[nidx] = parent; map.set_internal(parent, nidx); }
+                }
             }
             team_sync<TEAM>();
-            if (gbits) {
-                imin = sh_rng[2]; imax = sh_rng[3];
-                team_sync<TEAM>();
-            }
             kid_base = base;
-            base += n_par;
+            base = next_base;
+            if (umap) n_par = *next_cnt;
             ++G;
             --lvl;
         }
-        // unroll_changes (Subtree.py:72-76), big trees: clear the dirty words of every level touched
-        auto clear_bits = [&](int levels, int xmin, int xmax) {
-            if (!gbits) return;
-            for (int g = 0; g < levels; ++g) {
-                const int32_t *rg = lvl_rng + (int64_t)g * 4;
-                if (rg[1] >= 0)  // (an empty range is [INT_MAX, -1])
-                    for (int w = rg[0] + tid; w <= rg[1]; w += TEAM) nb.bm[w] = 0;
-                if (rg[3] >= 0)
-                    for (int w = rg[2] + tid; w <= rg[3]; w += TEAM) nb.bm[w] = 0;
-            }
-            if (xmax >= 0)
-                for (int w = xmin + tid; w <= xmax; w += TEAM) nb.bm[w] = 0;
-        };
-        if (overflow) {  // hand the query to the big-team launch; undo this team's marks first
-            team_sync<TEAM>();
-            clear_bits(G + 1, sh_rng[2], sh_rng[3]);
+        if (overflow) {  // hand the query to the big-team launch (this team's marks die with the tag / the next clear)
             if (tid == 0) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
             team_sync<TEAM>();
             continue;
@@ -664,8 +680,8 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
             int nk = 0, k0 = 0, k1 = 0, first = -1;
             const int klo = lvl + 2 <= T.height + 1 ? cg[lvl + 2] : 0;
             if (nr.nchild <= 2) {
-                const int m0 = nr.nchild >= 1 ? nb.desc(NR[nr.c0], kid_base, klo) : 0;
-                const int m1 = nr.nchild >= 2 ? nb.desc(NR[nr.c1], kid_base, klo) : 0;
+                const int m0 = nr.nchild >= 1 ? desc_of(nr.c0, nr.c0pos, nr.kleaf & 1u, kid_base, klo) : 0;
+                const int m1 = nr.nchild >= 2 ? desc_of(nr.c1, nr.c1pos, nr.kleaf & 2u, kid_base, klo) : 0;
                 nk = (m0 != 0) + (m1 != 0);
                 k0 = m0 ? m0 : m1;
                 k1 = (m0 && m1) ? m1 : 0;
@@ -673,7 +689,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
             } else {
                 const int cb = T.child_off[lca];
                 for (int ci = cb; ci < cb + nr.nchild; ++ci) {
-                    const int mc = nb.desc(NR[T.child_idx[ci]], kid_base, klo);
+                    const int mc = desc_of(T.child_idx[ci], npos[T.child_idx[ci]].x, NR[T.child_idx[ci]].nchild == 0, kid_base, klo);
                     if (mc != 0) { if (nk == 0) k0 = mc; else if (nk == 1) k1 = mc; ++nk; }
                 }
             }
@@ -728,10 +744,10 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                 if (!(self.meta & META_POLY)) {
                     Kid kid[2];
                     if (nk > 0) {
-                        const int n0 = (self.meta & META_K0C1) ? nr.c1 : nr.c0;
-                        load_kid<M>(self.k0, n0, NR[n0].e, rec, o_dist, kid[0]);
+                        const bool second = (self.meta & META_K0C1) != 0;
+                        load_kid<M>(self.k0, second ? nr.c1 : nr.c0, second ? nr.e1 : nr.e0, rec, o_dist, kid[0]);
                     }
-                    if (nk > 1) load_kid<M>(self.k1, nr.c1, NR[nr.c1].e, rec, o_dist, kid[1]);
+                    if (nk > 1) load_kid<M>(self.k1, nr.c1, nr.e1, rec, o_dist, kid[1]);
 #pragma unroll
                     for (int z = 0; z < 2; ++z) {
                         if (z < nk) {
@@ -757,7 +773,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                     for (int ci = cb; ci < ce; ++ci) {
                         const int cn = T.child_idx[ci];
                         const NodeRec cr = NR[cn];
-                        const int mc = nb.desc(cr, kb, klo);
+                        const int mc = desc_of(cn, cr.lpos, cr.nchild == 0, kb, klo);
                         if (mc == 0) continue;
                         double acc[6];
 #pragma unroll
@@ -766,7 +782,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                             if (cj == ci) continue;
                             const int sn = T.child_idx[cj];
                             const NodeRec sr = NR[sn];
-                            const int ms = nb.desc(sr, kb, klo);
+                            const int ms = desc_of(sn, sr.lpos, sr.nchild == 0, kb, klo);
                             if (ms != 0) {
                                 Kid sk;
                                 load_kid<M>(ms, sn, sr.e, rec, o_dist, sk);
@@ -785,7 +801,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         finish_kid(mc, kr, acc, true);
                     }
                     for (int ci = cb; ci < ce; ++ci) {  // all siblings done: S -> R in place
-                        const int mc = nb.desc(NR[T.child_idx[ci]], kb, klo);
+                        const int mc = desc_of(T.child_idx[ci], npos[T.child_idx[ci]].x, NR[T.child_idx[ci]].nchild == 0, kb, klo);
                         if (mc > 0) {
 #pragma unroll
                             for (int x = 0; x < 6; ++x) rec[mc - 1].T[x] = rtmp[(int64_t)(mc - 1) * 6 + x];
@@ -823,7 +839,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                 if (kv == 0x7fffffff) break;
                 last_e = ke; last_v = kv;
                 const int kl = T.level[kv];
-                const int mk = nb.desc(NR[kv], grp_off[lvl_first - kl], cg[kl + 1]);
+                const int mk = desc_of(kv, npos[kv].x, NR[kv].nchild == 0, grp_off[lvl_first - kl], cg[kl + 1]);
                 const int64_t slot = mk > 0 ? mk - 1 : cap + (-mk - 2);
                 const double x1 = xe[slot * XE_STRIDE + 0];
                 if (win < 0 || x1 < bx) { bx = x1; win = kv; win_slot = (int)slot; }
@@ -862,9 +878,8 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
         }
         if (tid == 0) { grp_off[T.height + 3] = lca; grp_off[T.height + 2] = VI; }
         team_sync<TEAM>();
-        clear_bits(G + 1, 0, -1);
-        team_sync<TEAM>();
     }
+    if (umap && tid == 0) a.map_ver[team] = map.ver;
 }
 
 
@@ -895,7 +910,7 @@ __global__ __launch_bounds__(APPLES_TPB, APPLES_SWEEP_WAVES) void k_sweep_mixed(
 }
 
 bool sweep_bits_in_lds(const DevTree &t) {
-    if (getenv("APPLES_BITS_GLOBAL")) return false;  // test knob: exercise the big-tree layout on a small tree
+    if (getenv("APPLES_NODE_MAP")) return false;  // test knob: exercise the big-tree layout on a small tree
     return (size_t)4 * t.bm_words * 12 <= 40 * 1024;
 }
 static size_t dyn_lds_bytes(const DevTree &t, int teams_per_wg) {

@@ -66,15 +66,18 @@ def test_all_observed_stress_and_batching(c2):
     eng.close()
 
 
-def test_node_bits_in_global_scratch(c2, monkeypatch):
-    """The sweep keeps its valid-node bits in LDS for trees of this size and in per-team global
-    scratch for big trees; force the big-tree layout here and compare."""
+def test_big_tree_node_map_and_tag_wrap_around(c2, monkeypatch):
+    """Trees of this size keep the sweep's valid-node bits in LDS; big trees use a tagged node map
+    in global scratch that is never cleared between queries (the table is wiped only when the
+    tags run out).  Force that layout here, with 3-bit tags and 8 teams so that every team wraps
+    dozens of times; placements must not change."""
     d, nodes = c2
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
     want = eng.place_sequences(d.query_seqs)
     eng.close()
-    monkeypatch.setenv('APPLES_BITS_GLOBAL', '1')
-    monkeypatch.setenv('APPLES_SWEEP_TEAMS', '64')
+    monkeypatch.setenv('APPLES_NODE_MAP', '1')
+    monkeypatch.setenv('APPLES_MAP_BITS', '29')
+    monkeypatch.setenv('APPLES_SWEEP_TEAMS', '8')
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
     got = eng.place_sequences(d.query_seqs)
     again = eng.place_sequences(d.query_seqs)
