@@ -403,6 +403,21 @@ __device__ __forceinline__ void load_kid(int kd, int node, double e, const Rec *
     }
 }
 
+// the same, when the child level's records are still in the team's LDS staging area
+template <int M>
+__device__ __forceinline__ void load_kid_staged(int kd, int node, double e, const Rec *__restrict__ rec, const uint4 *tstage,
+                                                int kid_base, bool staged, const double *__restrict__ o_dist, Kid &k) {
+    if (staged && kd > 0) {
+        k.node = node;
+        k.e = e;
+        const double2 *p = reinterpret_cast<const double2 *>(tstage + (size_t)(kd - 1 - kid_base) * 4);
+        const double2 a = p[0], b = p[1], c = p[2];
+        k.S[0] = a.x; k.S[1] = a.y; k.S[2] = b.x; k.S[3] = b.y; k.S[4] = c.x; k.S[5] = c.y;
+    } else {
+        load_kid<M>(kd, node, e, rec, o_dist, k);
+    }
+}
+
 // One team = TEAM threads working on one query: a wavefront (TEAM == 64, four independent teams
 // per workgroup; the level loops need no s_barrier) or the whole workgroup (TEAM == 256).  Queries
 // whose subtree does not fit a team's scratch (`cap` internal nodes) are appended to an overflow
@@ -434,6 +449,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
     double *sh_d = sh.d;
     int *sh_i = sh.i;
     uint4 *stage = sh.stage[threadIdx.x / WAVE];
+    uint4 *tstage = TEAM == WAVE ? stage : &sh.stage[0][0];  // the team's staging area, one 64-byte slot per thread
     const int lane = threadIdx.x & (WAVE - 1);
     const double *lds_pow = sh.pow;
     const int team_in_wg = threadIdx.x / TEAM;
@@ -515,6 +531,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
         int lvl = lvl_first;
         int base = 0, kid_base = 0, n_par = 0, G = 0, lca = -1;
         bool overflow = false;
+        bool prev_staged = false;  // the level below fitted one pass: its records are still in LDS
         if (umap) {
             // a fresh tag for this query's map entries; when the tags run out, wipe the table once
             if (map.ver == ver_max) {
@@ -574,12 +591,15 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
             const int lo_kids = lvl + 2 <= T.height + 1 ? cg[lvl + 2] : 0;  // first observed leaf of the level below
             // internal nodes of this level, in node-id order: S tuple from the valid children in
             // file order, then tell the parent
+            // children's S tuples come from LDS when both levels are single-pass (the staging area
+            // still holds the level below, and nothing overwrites it before everybody has read)
+            const bool staged = prev_staged && n_par <= TEAM;
             for (int k0 = 0; k0 < n_par; k0 += TEAM) {  // team-uniform trip count
                 const int k = k0 + tid;
                 const bool active = k < n_par;
                 int parent = -1;
+                Rec r;
                 if (active) {
-                    Rec r;
                     r.node = umap ? order[base + k] : T.lnode[kth_in_block(nb, w0, w1, k)];
                     const NodeRec nr = NR[r.node];
                     parent = nr.parent;
@@ -595,7 +615,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         r.meta = (uint32_t)nk | ((!m0) ? META_K0C1 : 0u);
                         {
                             Kid kd;
-                            load_kid<M>(r.k0, m0 ? nr.c0 : nr.c1, m0 ? nr.e0 : nr.e1, rec, o_dist, kd);
+                            load_kid_staged<M>(r.k0, m0 ? nr.c0 : nr.c1, m0 ? nr.e0 : nr.e1, rec, tstage, kid_base, staged, o_dist, kd);
                             double t[6];
                             lift<M>(kd.S, kd.e, t);
 #pragma unroll
@@ -603,7 +623,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         }
                         if (nk > 1) {
                             Kid kd;
-                            load_kid<M>(r.k1, nr.c1, nr.e1, rec, o_dist, kd);
+                            load_kid_staged<M>(r.k1, nr.c1, nr.e1, rec, tstage, kid_base, staged, o_dist, kd);
                             double t[6];
                             lift<M>(kd.S, kd.e, t);
 #pragma unroll
@@ -634,6 +654,10 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         r.meta = (uint32_t)nk | META_POLY;
                     }
                     if (!umap && nr.ppos >= 0) nb.set(nr.ppos);  // tell the parent
+                }
+                if (staged) team_sync<TEAM>();  // everybody has read the level below
+                __builtin_amdgcn_wave_barrier();
+                if (active) {
                     // stage the record; its 64 bytes leave as part of a 1-KiB row below
                     const uint4 *src = reinterpret_cast<const uint4 *>(&r);
 #pragma unroll
@@ -658,6 +682,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                 }
             }
             team_sync<TEAM>();
+            prev_staged = n_par > 0 && n_par <= TEAM;
             kid_base = base;
             base = next_base;
             if (umap) n_par = *next_cnt;
