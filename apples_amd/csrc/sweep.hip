@@ -909,7 +909,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
 
 
 #ifndef APPLES_SWEEP_WAVES
-#define APPLES_SWEEP_WAVES 1
+#define APPLES_SWEEP_WAVES 2
 #endif
 
 template <int M, int TEAM>
