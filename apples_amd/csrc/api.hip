@@ -15,7 +15,14 @@ template <typename T>
 int dev_alloc(apples_ctx *ctx, T **p, int64_t n) {
     *p = nullptr;
     if (n <= 0) n = 1;
-    HIP_TRY(ctx, hipMalloc((void **)p, (size_t)n * sizeof(T)));
+    hipError_t e = hipMalloc((void **)p, (size_t)n * sizeof(T));
+    if (e != hipSuccess) {
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        ctx->err = std::string("hipMalloc of ") + std::to_string((size_t)n * sizeof(T)) + " bytes: " + hipGetErrorString(e) +
+                   " (" + std::to_string(fr >> 20) + " MiB free of " + std::to_string(tot >> 20) + ")";
+        return 1;
+    }
     return 0;
 }
 
