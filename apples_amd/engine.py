@@ -293,6 +293,19 @@ class Engine:
         self._check(self.lib.apples_distances_resident(self.ctx, handle, int(query_tile)))
 
 
+def placement_rows(out):
+    """Vectorised :func:`placement_row`: list of p rows for a placement array."""
+    flags = out['flags']
+    trivial = (flags & (F_EXACT | F_INSUFFICIENT | F_DEGENERATE)) != 0
+    pint = (flags & F_PENDANT_INT) != 0
+    edge = out['edge'].tolist()
+    err = out['error'].tolist()
+    dist = out['distal'].tolist()
+    pend = out['pendant'].tolist()
+    return [[e, 0, 1, 0, 0] if t else [e, er, 1, d, 0 if pi else pe]
+            for e, er, d, pe, t, pi in zip(edge, err, dist, pend, trivial.tolist(), pint.tolist())]
+
+
 def placement_row(p):
     """apples_placement -> the jplace p row with the reference's int/float leakage."""
     flags = int(p['flags'])

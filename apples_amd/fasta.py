@@ -90,8 +90,8 @@ class Alignment:
         return self.seqs.shape[1] if self.seqs.ndim == 2 else 0
 
 
-def read_alignment(path, prot_flag, mask_flag):
-    """FASTA file -> :class:`Alignment` (apples/fasta2dic.py:42-72)."""
+def _read_alignment_py(path, prot_flag, mask_flag):
+    """Record-by-record reader (the restatement the native scanner is tested against)."""
     tab = _translation(prot_flag, mask_flag)
     order = {}
     rows = []
@@ -111,3 +111,57 @@ def read_alignment(path, prot_flag, mask_flag):
             raise ValueError('sequence %s has length %d, expected %d (alignment rows must be equal length)'
                              % (n, len(r), L))
     return Alignment(list(order), np.vstack(rows))
+
+
+_io_lib = None
+
+
+def _load_io():
+    """libapples_io.so (include/apples_io.h), or None when it has not been built."""
+    global _io_lib
+    if _io_lib is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libapples_io.so')
+        if not os.path.exists(path):
+            _io_lib = False
+        else:
+            lib = ctypes.CDLL(path)
+            lib.apples_fasta_scan.restype = ctypes.c_int
+            lib.apples_fasta_scan.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_int64] + [ctypes.c_void_p] * 6
+            _io_lib = lib
+    return _io_lib or None
+
+
+def read_alignment(path, prot_flag, mask_flag):
+    """FASTA file -> :class:`Alignment` (apples/fasta2dic.py:42-72).  With libapples_io.so the file
+    image is scanned natively, every sequence written straight into its row of the dense matrix
+    (SURVEY 8f-2); repeated names, ragged input or a missing library take the record-by-record path."""
+    lib = _load_io()
+    if lib is None:
+        return _read_alignment_py(path, prot_flag, mask_flag)
+    import ctypes
+    tab = _translation(prot_flag, mask_flag)
+    with open(path, 'rb') as f:
+        data = np.frombuffer(f.read(), dtype=np.uint8)
+    n_rec = ctypes.c_int64(0)
+    length = ctypes.c_int64(0)
+    bad = ctypes.c_int64(-1)
+    bad_len = ctypes.c_int64(0)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.apples_fasta_scan(ptr(data), data.size, ptr(tab), None, 0, ctypes.byref(n_rec), ctypes.byref(length),
+                          None, None, ctypes.byref(bad), ctypes.byref(bad_len))
+    n, L = n_rec.value, length.value
+    if n == 0:
+        return Alignment([], np.zeros((0, 0), dtype=np.uint8))
+    mat = np.empty((n, L), dtype=np.uint8)
+    off = np.empty(n, dtype=np.int64)
+    ln = np.empty(n, dtype=np.int32)
+    rc = lib.apples_fasta_scan(ptr(data), data.size, ptr(tab), ptr(mat), n, ctypes.byref(n_rec), ctypes.byref(length),
+                               ptr(off), ptr(ln), ctypes.byref(bad), ctypes.byref(bad_len))
+    raw = data.tobytes() if n < 64 else memoryview(data)
+    names = [bytes(raw[o:o + k]).decode() for o, k in zip(off.tolist(), ln.tolist())]
+    if rc != 0 or len(set(names)) != n:
+        return _read_alignment_py(path, prot_flag, mask_flag)  # dict semantics / the reference's error
+    return Alignment(names, mat)

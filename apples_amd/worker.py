@@ -7,7 +7,7 @@ import threading
 
 import numpy as np
 
-from .engine import (Engine, placement_row, F_EXACT, F_INSUFFICIENT, F_MISPLACED, F_ZERO_NOT_IN_TREE, F_DEGENERATE)
+from .engine import (Engine, placement_rows, F_EXACT, F_INSUFFICIENT, F_MISPLACED, F_ZERO_NOT_IN_TREE, F_DEGENERATE)
 
 
 def _shards(n, parts):
@@ -69,47 +69,57 @@ class QueryWorker:
         return np.concatenate(outs) if outs else np.zeros(0)
 
     # ------------------------------------------------------------------ alignment input
-    def run_sequences(self, names, seqs):
+    def run_sequences(self, names, seqs, rows=False):
         aln = self.reference.aln
         # the entry runquery deletes: query name is a backbone leaf and names a reference row (:63-66)
         self_rows = np.array([aln.index.get(n, -1) if n in self.tree.name_to_node else -1 for n in names], np.int32)
         out = self._run_sharded(len(names), lambda eng, lo, hi: eng.place_sequences(seqs[lo:hi], self_rows[lo:hi]))
-        return self._to_jplace(names, out)
+        return self._rows(names, out) if rows else self._to_jplace(names, out)
 
     # ------------------------------------------------------------------ distance-table input
-    def run_distances(self, names, cols, D):
+    def run_distances(self, names, cols, D, rows=False):
         col_nodes = np.array([self.tree.name_to_node.get(c, -1) for c in cols], np.int32)
         col_index = {c: i for i, c in enumerate(cols)}
         self_cols = np.array([col_index.get(n, -1) if n in self.tree.name_to_node else -1 for n in names], np.int32)
         out = self._run_sharded(len(names), lambda eng, lo, hi: eng.place_distances(D[lo:hi], col_nodes, self_cols[lo:hi]))
-        return self._to_jplace(names, out)
+        return self._rows(names, out) if rows else self._to_jplace(names, out)
 
     # ------------------------------------------------------------------ result assembly
-    def _to_jplace(self, names, out):
-        results = []
-        for name, p in zip(names, out):
-            flags = int(p['flags'])
-            if name in self.tree.name_to_node:
+    def _rows(self, names, out):
+        """(names as printed, jplace p rows): the branches of runquery that are visible in the output
+        (PoolQueryWorker.py:63-70,83-88,119-130), flags first so that the common case stays vectorised."""
+        flags = out['flags']
+        zero_bad = np.nonzero(flags & F_ZERO_NOT_IN_TREE)[0]
+        degenerate = np.nonzero(flags & F_DEGENERATE)[0]
+        in_tree = self.tree.name_to_node
+        names = list(names)
+        for i, name in enumerate(names):
+            if name in in_tree:
                 logging.warning('The query named %s exists in the backbone. Changing its name to %s-query.' % (name, name))
-                name = name + '-query'
-            if flags & F_ZERO_NOT_IN_TREE:
-                raise KeyError('query %s has a zero distance to a reference that is not a leaf of the backbone tree'
-                               % name)
-            if flags & F_DEGENERATE:
-                raise ValueError('query %s: fewer than two of its observed references are leaves of the backbone tree'
-                                 % name)
-            row = placement_row(p)
-            if flags & F_INSUFFICIENT:
-                sys.stderr.write('Taxon {} cannot be placed. At least three non-infinity distances '
-                                 'should be observed to place a taxon. '
-                                 'Consequently, this taxon is ignored (no output).\n'.format(name))
-            elif not (flags & F_EXACT) and (flags & F_MISPLACED):
-                ignored = ''
-                if self.options.exclude_intplace:
-                    row[0] = -1
-                    ignored = ' Consequently, this sequence is ignored (no output).'
-                logging.warning('Best placement for query sequence %s has zero pendant edge length and placed at an '
-                                'internal node with a non-zero least squares error. This is a potential misplacement.%s'
-                                % (name, ignored))
-            results.append({'placements': [{'p': [row], 'n': [name]}]})
-        return results
+                names[i] = name + '-query'
+        # errors in input order, as the reference's starmap would raise the first one
+        if len(zero_bad) or len(degenerate):
+            i = min([int(x[0]) for x in (zero_bad, degenerate) if len(x)])
+            if flags[i] & F_ZERO_NOT_IN_TREE:
+                raise KeyError('query %s has a zero distance to a reference that is not a leaf of the backbone tree' % names[i])
+            raise ValueError('query %s: fewer than two of its observed references are leaves of the backbone tree' % names[i])
+        rows = placement_rows(out)
+        for i in np.nonzero(flags & F_INSUFFICIENT)[0]:
+            sys.stderr.write('Taxon {} cannot be placed. At least three non-infinity distances '
+                             'should be observed to place a taxon. '
+                             'Consequently, this taxon is ignored (no output).\n'.format(names[i]))
+        mis = np.nonzero(((flags & F_MISPLACED) != 0) & ((flags & (F_EXACT | F_INSUFFICIENT)) == 0))[0]
+        for i in mis:
+            ignored = ''
+            if self.options.exclude_intplace:
+                rows[i][0] = -1
+                ignored = ' Consequently, this sequence is ignored (no output).'
+            logging.warning('Best placement for query sequence %s has zero pendant edge length and placed at an '
+                            'internal node with a non-zero least squares error. This is a potential misplacement.%s'
+                            % (names[i], ignored))
+        return names, rows
+
+    def _to_jplace(self, names, out):
+        """One jplace dict per query, as runquery returns (PoolQueryWorker.py:36-37)."""
+        names, rows = self._rows(names, out)
+        return [{'placements': [{'p': [row], 'n': [name]}]} for name, row in zip(names, rows)]

@@ -10,7 +10,7 @@ import time
 import numpy as np
 
 from apples_amd.fasta import read_alignment
-from apples_amd.jplace import dumps, finish, join_jplace
+from apples_amd.jplace import iter_text, keep_mask
 from apples_amd.options import options_config
 from apples_amd.reference import ReducedReference, read_treecluster
 from apples_amd.tree import extended_newick, read_tree
@@ -64,7 +64,7 @@ def main(argv=None):
             names, cols, D = read_dismat(f)
         worker = QueryWorker(tree, options, None, devices)
         startq = time.time()
-        results = worker.run_distances(names, cols, D)
+        out_names, rows = worker.run_distances(names, cols, D, rows=True)
     else:
         start = time.time()
         ref = read_alignment(options.ref_fp, options.protein_seqs, False)  # reference rows are never masked
@@ -90,17 +90,19 @@ def main(argv=None):
             qnames, qseqs = [ext.names[i] for i in keep], ext.seqs[keep]
         worker = QueryWorker(tree, options, reference, devices)
         startq = time.time()
-        results = worker.run_sequences(qnames, qseqs)
+        out_names, rows = worker.run_sequences(qnames, qseqs, rows=True)
     logging.info('[%s] Processed all queries in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - startq))
     worker.close()
 
-    result = finish(join_jplace(results), newick, sys.argv if argv is None else ['run_apples.py'] + list(argv))
-    text = dumps(result)
+    # join_jplace + json.dumps(sort_keys=True, indent=4) of the reference (run_apples.py:106-118), streamed
+    keep = keep_mask([r[0] for r in rows])
+    text = iter_text(((n, r) for n, r, k in zip(out_names, rows, keep) if k), newick,
+                     sys.argv if argv is None else ['run_apples.py'] + list(argv))
+    f = open(options.output_fp, 'w') if options.output_fp else sys.stdout
+    for piece in text:
+        f.write(piece)
     if options.output_fp:
-        with open(options.output_fp, 'w') as f:
-            f.write(text)
-    else:
-        sys.stdout.write(text)
+        f.close()
     logging.warning('[%s] APPLES finished in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - startb))
 
 

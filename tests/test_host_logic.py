@@ -145,3 +145,123 @@ def test_max_diameter_clustering_properties():
     assert tc.grouped(tree, 100.0) == [('1', ['A', 'B', 'C', 'D', 'E'])]
     g0 = tc.grouped(tree, 0.0)  # members come in the order the sweep cut them off
     assert len(g0) == 1 and g0[0][0] == '-1' and sorted(g0[0][1]) == ['A', 'B', 'C', 'D', 'E']
+
+
+def _fake_placements(Q, seed, first_bad):
+    from apples_amd.engine import F_EXACT, F_PENDANT_INT, F_INSUFFICIENT, F_MISPLACED
+    dt = np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'), ('distal', '<f8'), ('pendant', '<f8'),
+                   ('n_obs', '<i4'), ('n_valid', '<i4')], align=True)
+    rng = np.random.default_rng(seed)
+    out = np.zeros(Q, dt)
+    out['edge'] = rng.integers(0, 19998, Q)
+    out['error'] = rng.random(Q) * 10.0 ** rng.integers(-20, 3, Q)
+    out['distal'] = rng.random(Q) * 0.01
+    out['pendant'] = rng.random(Q) * 0.01
+    kind = rng.integers(0, 10, Q)
+    out['flags'][kind == 0] = F_EXACT | F_PENDANT_INT
+    out['flags'][kind == 1] = F_PENDANT_INT
+    out['flags'][kind == 3] = F_PENDANT_INT | F_MISPLACED
+    bad = kind == 2
+    out['flags'][bad] = F_INSUFFICIENT | F_PENDANT_INT
+    out['edge'][bad] = -1
+    if first_bad:
+        out['flags'][0] = F_INSUFFICIENT | F_PENDANT_INT
+        out['edge'][0] = -1
+    return out
+
+
+@pytest.mark.parametrize('Q', [1, 2, 7, 3000])
+@pytest.mark.parametrize('first_bad', [False, True])
+def test_streaming_jplace_text_equals_json_dumps(Q, first_bad):
+    """The streaming writer and the vectorised row builder produce the bytes of the reference's
+    json.dumps(sort_keys=True, indent=4) over join_jplace's dict (run_apples.py:106-118), including
+    the keep-first quirk, int/float leakage, exponents and escaped names."""
+    from apples_amd.engine import placement_row, placement_rows
+    from apples_amd.jplace import dumps, finish, iter_text, join_jplace, keep_mask
+    out = _fake_placements(Q, Q + first_bad, first_bad)
+    names = ['q%d "x"\\ é' % i if i % 100 == 3 else 'q%d' % i for i in range(Q)]
+    tree_string = "('a b':1,b:2.5){1};"
+    res = [{'placements': [{'p': [placement_row(p)], 'n': [n]}]} for n, p in zip(names, out)]
+    want = dumps(finish(join_jplace(res), tree_string, ['run_apples.py', '-t', 'x y']))
+    rows = placement_rows(out)
+    assert rows == [placement_row(p) for p in out]
+    keep = keep_mask([r[0] for r in rows])
+    got = ''.join(iter_text(((n, r) for n, r, k in zip(names, rows, keep) if k), tree_string, ['run_apples.py', '-t', 'x y']))
+    assert got == want
+
+
+def test_worker_rows_rename_exclude_and_messages(capsys):
+    """Result assembly without a device: name collision rename, --exclude, the stderr line for
+    unplaceable queries (PoolQueryWorker.py:63-70,83-88,119-130)."""
+    from apples_amd.options import options_config
+    from apples_amd.tree import parse_newick
+    from apples_amd.worker import QueryWorker
+    tree = parse_newick('((a:1,b:1):1,(c:1,d:1):1);')
+    out = _fake_placements(40, 5, True)
+    names = ['a' if i == 4 else 'q%d' % i for i in range(40)]
+    for exclude in (False, True):
+        options, _ = options_config(['-t', 'x', '-s', 'y', '-q', 'z'] + (['--exclude'] if exclude else []))
+        w = QueryWorker(tree, options, None, [0])
+        got_names, rows = w._rows(names, out)
+        assert got_names[4] == 'a-query' and got_names[5] == 'q5'
+        from apples_amd.engine import F_MISPLACED, F_EXACT, F_INSUFFICIENT
+        mis = ((out['flags'] & F_MISPLACED) != 0) & ((out['flags'] & (F_EXACT | F_INSUFFICIENT)) == 0)
+        assert mis.any()
+        for i in np.nonzero(mis)[0]:
+            assert rows[i][0] == (-1 if exclude else int(out['edge'][i]))
+        err = capsys.readouterr().err
+        assert err.count('cannot be placed') == int(((out['flags'] & F_INSUFFICIENT) != 0).sum())
+        dicts = w._to_jplace(names, out)
+        capsys.readouterr()
+        assert [d['placements'][0]['p'][0] for d in dicts] == rows
+
+
+_FASTA_CASES = {
+    'plain': b'>a x y\nACGT\n>b\nAC-T\n',
+    'multiline': b'junk\n>a\nAC\nGT\n\n>b desc\nacgn\n',
+    'no_final_newline': b'>a\nACGT\n>b\nACGTT',
+    'crlf': b'>a\r\nACGT\r\n>b\r\nAC-T\r\n',
+    'cr_only': b'>a\rACGT\r>b\rAC-T\r',
+    'repeated_name': b'>a\nACGT\n>b\nAAAA\n>a\nTTTT\n',
+    'fastq': b'@a\nACGT\n+\nIIII\n@b\nAC-T\n+\nII\nII\n',
+    'fastq_truncated': b'@a\nACGT\n+\nII\n',
+    'fastq_at_in_quality': b'@a\nACGT\n+\n@III\n@b\nAC-T\n+\nIIII\n',
+    'headers_only': b'>a\n>b\n',
+    'header_last_unterminated': b'>a\nAC\n>',
+    'plus_last_unterminated': b'>a\nAC\n+',
+    'empty': b'',
+    'blank_lines': b'\n\n',
+    'ragged': b'>a\nACGT\n>b\nACG\n',
+    'empty_name': b'>\nAC\n> x\nGT\n',
+    'utf8_name': '>\u00e9\nAC\n>b\nGT\n'.encode(),
+    'tab_in_header': b'>a\tb c\nAC\n',
+    'other_symbols': b'>a\nA*?.\n>b\nbjou\n',
+}
+
+
+@pytest.mark.parametrize('case', sorted(_FASTA_CASES))
+def test_native_fasta_scan_matches_record_reader(case, tmp_path):
+    """libapples_io.so's scanner (include/apples_io.h) against the record-by-record restatement of
+    apples/fasta2dic.py:4-72, on the reader's quirks: dropped last characters, universal newlines,
+    FASTQ blocks, repeated names, ragged rows, both alphabets, masking on and off."""
+    from apples_amd import build, fasta
+    build.build_io(verbose=False)
+    fasta._io_lib = None
+    assert fasta._load_io() is not None
+    path = str(tmp_path / 'x.fa')
+    with open(path, 'wb') as f:
+        f.write(_FASTA_CASES[case])
+    for prot in (False, True):
+        for mask in (False, True):
+            try:
+                want, werr = fasta._read_alignment_py(path, prot, mask), None
+            except Exception as e:  # the reference's failure mode (unequal lengths) must be kept
+                want, werr = None, (type(e).__name__, str(e))
+            try:
+                got, gerr = fasta.read_alignment(path, prot, mask), None
+            except Exception as e:
+                got, gerr = None, (type(e).__name__, str(e))
+            assert werr == gerr
+            if want is not None:
+                assert want.names == got.names
+                assert np.array_equal(want.seqs, got.seqs)

@@ -9,8 +9,8 @@ import numpy as np
 from helpers import ROOT
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, 'include', 'apples_hip.h')).read()
+def _declared_symbols(header='apples_hip.h'):
+    text = open(os.path.join(ROOT, 'include', header)).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(apples_[a-z_]+)\s*\(', text)))
 
@@ -31,6 +31,20 @@ def test_library_builds_loads_and_exports_every_symbol():
         assert hasattr(lib, s), 'missing export %s' % s
     assert sorted(engine.EXPORTS) == _declared_symbols()
     engine.load_library()
+
+
+def test_io_library_builds_and_exports_every_symbol():
+    """include/apples_io.h: the host-side scanner library (plain g++, no device code)."""
+    from apples_amd import build
+    lib = ctypes.CDLL(build.build_io(verbose=False))
+    syms = _declared_symbols('apples_io.h')
+    assert syms == ['apples_fasta_scan']
+    for s in syms:
+        assert hasattr(lib, s), 'missing export %s' % s
+
+
+def test_every_header_in_include_is_covered():
+    assert sorted(os.listdir(os.path.join(ROOT, 'include'))) == ['apples_hip.h', 'apples_io.h']
 
 
 def test_placement_struct_layout_matches_header():
