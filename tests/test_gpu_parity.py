@@ -370,3 +370,32 @@ def test_random_trees_per_edge_bit_parity_with_c_oracle():
                     n_cases += 1
             eng.close()
     assert n_cases > 250
+
+
+def test_both_sweep_layouts_agree_on_polytomies(monkeypatch):
+    """The sweep knows which nodes are in a query's subtree either from a bit space in LDS (small
+    trees) or from a tagged node map in global scratch (big trees).  Same polytomous tree, same
+    observed sets, every method, HYBRID included (it looks nodes up again after the sweep): the two
+    layouts must return the same bytes."""
+    tree = read_tree(os.path.join(DATA, 'prot', 'backbone.nwk'))
+    leaves = tree.leaves
+    rng = np.random.default_rng(11)
+    nq = 36
+    D = np.full((nq, len(leaves)), -1.0)
+    for i in range(nq):
+        k = [3, 7, 60, 900, len(leaves)][i % 5]
+        sel = rng.choice(len(leaves), size=k, replace=False)
+        D[i, sel] = rng.uniform(0.01, 1.5, size=k)
+    cols = leaves.astype(np.int32)
+    for m, c in (('OLS', 'MLSE'), ('BME', 'HYBRID'), ('FM', 'ME'), ('BE', 'HYBRID')):
+        outs = []
+        for layout in ('bits', 'map'):
+            if layout == 'map':
+                monkeypatch.setenv('APPLES_NODE_MAP', '1')
+            else:
+                monkeypatch.delenv('APPLES_NODE_MAP', raising=False)
+            eng = Engine(tree, None, method=m, criterion=c, threshold=10.0, baseobs=5)
+            outs.append(eng.place_distances(D, cols))
+            eng.close()
+        assert outs[0].tobytes() == outs[1].tobytes(), (m, c)
+    monkeypatch.delenv('APPLES_NODE_MAP', raising=False)

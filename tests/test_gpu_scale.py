@@ -51,10 +51,14 @@ def test_c2_reference_size_against_c_oracle(c2, method, criterion):
     eng.close()
 
 
-def test_all_observed_stress_and_batching(c2):
-    """-f huge: every leaf observed (worst case for both kernels, V = 2N-2); also forces several
-    device batches and checks they agree with one big batch."""
+@pytest.mark.parametrize('layout', ['bits', 'map'])
+def test_all_observed_stress_and_batching(c2, layout, monkeypatch):
+    """-f huge: every leaf observed (worst case for both kernels, V = 2N-2; more than 4 096 observed
+    leaves send every query to the workgroup-sized teams); also forces several device batches and
+    checks they agree with one big batch.  Both node-lookup layouts of the sweep."""
     d, nodes = c2
+    if layout == 'map':
+        monkeypatch.setenv('APPLES_NODE_MAP', '1')
     nthreads = len(os.sched_getaffinity(0))
     co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', threshold=1e9, lut=jc69_lut(1000, 0.001), threads=nthreads)
     want = co.place_sequences(d.query_seqs[:96])
