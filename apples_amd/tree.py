@@ -59,12 +59,15 @@ def parse_newick(text):
     elif text.startswith('[&U]'):
         text = text[4:].lstrip()
 
-    # creation-order (pre-order) temporary nodes
+    # creation-order (= pre-order) temporary nodes; depth and subtree size come out of the token
+    # loop, so the post-order numbering below needs no traversal
     t_parent = [-1]
     t_label = [None]
     t_len = [None]
-    t_children = [[]]
+    t_depth = [0]
+    t_size = {}  # internal nodes only: nodes in the subtree, known when the ')' closes it
     cur = 0
+    depth = 0
     expect_len = False
     done = False
     for m in _TOKEN.finditer(text):
@@ -77,11 +80,11 @@ def parse_newick(text):
             expect_len = False
             continue
         if c == '(':
+            depth += 1
             t_parent.append(cur)
             t_label.append(None)
             t_len.append(None)
-            t_children.append([])
-            t_children[cur].append(len(t_parent) - 1)
+            t_depth.append(depth)
             cur = len(t_parent) - 1
         elif c == ',':
             par = t_parent[cur]
@@ -90,13 +93,14 @@ def parse_newick(text):
             t_parent.append(par)
             t_label.append(None)
             t_len.append(None)
-            t_children.append([])
-            t_children[par].append(len(t_parent) - 1)
+            t_depth.append(depth)
             cur = len(t_parent) - 1
         elif c == ')':
             cur = t_parent[cur]
             if cur < 0:
                 raise ValueError('malformed Newick: unbalanced parentheses')
+            depth -= 1
+            t_size[cur] = len(t_parent) - cur
         elif c == ':':
             expect_len = True
         elif c == ';':
@@ -116,46 +120,38 @@ def parse_newick(text):
         raise ValueError('malformed Newick: unbalanced parentheses')
 
     n = len(t_parent)
-    # iterative left-to-right post-order numbering (apples/util.py:65-69)
-    post = np.empty(n, dtype=np.int64)
-    counter = 0
-    stack = [(0, 0)]
-    while stack:
-        v, i = stack.pop()
-        ch = t_children[v]
-        if i < len(ch):
-            stack.append((v, i + 1))
-            stack.append((ch[i], 0))
-        else:
-            post[v] = counter
-            counter += 1
+    # left-to-right post-order number (apples/util.py:65-69) of the node created k-th (pre-order):
+    # k - depth + size - 1  (the nodes before it in pre-order that are not its ancestors, plus its
+    # own descendants)
+    pre_parent = np.array(t_parent, dtype=np.int64)
+    pre_depth = np.array(t_depth, dtype=np.int64)
+    size = np.ones(n, dtype=np.int64)
+    if t_size:
+        size[np.fromiter(t_size.keys(), dtype=np.int64, count=len(t_size))] = \
+            np.fromiter(t_size.values(), dtype=np.int64, count=len(t_size))
+    post = np.arange(n, dtype=np.int64) - pre_depth + size - 1
 
     parent = np.full(n, -1, dtype=np.int32)
+    nonroot = pre_parent >= 0
+    parent[post[nonroot]] = post[pre_parent[nonroot]]
+    lens = np.array([np.nan if x is None else x for x in t_len], dtype=np.float64)
+    given = np.array([x is not None for x in t_len], dtype=bool)
     edge_len = np.zeros(n, dtype=np.float64)
     has_len = np.zeros(n, dtype=bool)
+    edge_len[post[given]] = lens[given]
+    has_len[post] = given
     labels = [None] * n
-    nchild = np.zeros(n, dtype=np.int64)
-    for v in range(n):
-        p = post[v]
-        if t_parent[v] >= 0:
-            parent[p] = post[t_parent[v]]
-        if t_len[v] is not None:
-            edge_len[p] = t_len[v]
-            has_len[p] = True
-        labels[p] = t_label[v]
-        nchild[p] = len(t_children[v])
+    for p, lab in zip(post.tolist(), t_label):
+        labels[p] = lab
+    nchild = np.bincount(parent[parent >= 0], minlength=n)
     child_off = np.zeros(n + 1, dtype=np.int32)
     child_off[1:] = np.cumsum(nchild)
-    child_idx = np.empty(max(n - 1, 0), dtype=np.int32)
-    for v in range(n):
-        p = post[v]
-        o = child_off[p]
-        for k, c in enumerate(t_children[v]):
-            child_idx[o + k] = post[c]
-    # BFS depth; parents have larger ids, so a descending sweep sees parents first
+    # children in file order = creation order: sort the non-root nodes by (parent's number, creation order)
+    kids = np.nonzero(nonroot)[0]
+    order = kids[np.argsort(post[pre_parent[kids]], kind='stable')]
+    child_idx = post[order].astype(np.int32) if n > 1 else np.empty(0, dtype=np.int32)
     level = np.zeros(n, dtype=np.int32)
-    for v in range(n - 2, -1, -1):
-        level[v] = level[parent[v]] + 1
+    level[post] = pre_depth  # BFS depth (apples/util.py:72-88)
     return Tree(parent, edge_len, has_len, labels, child_off, child_idx, level, is_rooted)
 
 
