@@ -600,12 +600,20 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
             ++launches;
             SelectArgs sa = select_args_alignment(ctx, qb, q0);
             if (launch_select_fast(ctx, sa, nq)) return 1;
-            // top-up path for the queries k_select_fast listed: full rows, then the general selection
-            if (launch_counts_listed(ctx, qb, q0, nq, w.slow_list, w.slow_count, w.dist_slow)) return 1;
+            // top-up path for the queries k_select_fast listed: full rows + per-segment minima (in the
+            // rows of the fused buffers, which k_select_fast has consumed), then the `-b` nearest
+            static const bool no_topup = getenv("APPLES_NO_TOPUP_KERNEL") != nullptr;  // diagnostic knob
+            // (short rows are cheaper to stream twice than to rank: 2 x `-b` block arg-min rounds)
+            static const int64_t topup_min = getenv("APPLES_TOPUP_MIN_ROWS") ? atoll(getenv("APPLES_TOPUP_MIN_ROWS")) : 40000;
+            const bool topup = !no_topup && ctx->params.base_observation <= 256 && ctx->aln.n_refs >= topup_min;
+            if (launch_counts_listed(ctx, qb, q0, nq, w.slow_list, w.slow_count, w.dist_slow, topup ? w.dist : nullptr,
+                                     topup ? w.seg_slot : nullptr)) return 1;
             sa.dist = w.dist_slow;
             sa.qlist = w.slow_list;
             sa.qcount = w.slow_count;
-            if (launch_select(ctx, sa, nq)) return 1;
+            sa.segmin_d = w.dist;
+            sa.segmin_i = w.seg_slot;
+            if (topup ? launch_select_topup(ctx, sa, nq) : launch_select(ctx, sa, nq)) return 1;
             HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else {
             HIP_TRY(ctx, hipEventRecord(e[0], front));

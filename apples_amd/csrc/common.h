@@ -210,14 +210,17 @@ struct SelectArgs {
     int32_t *overflow_list, *overflow_count;
     // listed mode of k_select: block r handles query qlist[r] with distances in row r
     const int32_t *qlist, *qcount;
+    // top-up by segment minima (k_jc69 MODE 2 -> k_select_topup): [listed row][stride]
+    const double *segmin_d; const int32_t *segmin_i;
 };
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
+int launch_select_topup(apples_ctx *ctx, const SelectArgs &a, int64_t nq);  // listed queries, needs segmin_d/segmin_i; baseobs <= 256
 int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const int32_t *perm, int64_t nq, int64_t n_cols);
 int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
                         int32_t *seg_slot, int32_t *seg_cnt);
 int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
-                         const int32_t *qcount, double *d_dist);
+                         const int32_t *qcount, double *d_dist, double *segmin_d, int32_t *segmin_i);
 // sweep.hip
 struct SweepArgs {
     DevTree tree;

@@ -37,7 +37,9 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
 //                       slots = one segment) writes them, in slot order, at the start of its segment
 //                       of seg_slot/seg_d and their number to seg_cnt[q][segment]
 // MODE 2: listed     -> full rows for the queries named by qlist[0..*qcount) (top-up path); row r of
-//                       dist belongs to qlist[r]
+//                       dist belongs to qlist[r].  Also the smallest (d, representative index) key of
+//                       every 64-slot segment -> segmin_d/segmin_i[r][segment], so that the top-up
+//                       selection can find the `-b` nearest without streaming the row again
 template <int P, int TQ, int MODE, bool ASM>
 __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ refp, const uint4 *__restrict__ qp,
                                                      double *__restrict__ dist, uint32_t *__restrict__ counts,
@@ -46,7 +48,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
                                                      int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
                                                      const int32_t *__restrict__ qlist,
                                                      const int32_t *__restrict__ qcount,
-                                                     const int32_t *__restrict__ mmax) {
+                                                     const int32_t *__restrict__ mmax,
+                                                     const int32_t *__restrict__ slot_rep, double *__restrict__ segmin_d,
+                                                     int32_t *__restrict__ segmin_i) {
     const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
     if (MODE == 2) nq = *qcount;
     // listed mode: the list length lives on the device, so a bounded grid.y loops over the tiles
@@ -141,7 +145,34 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
         }
         return;
     }
-    if (slot < n_slots) {
+    if (MODE == 2 && segmin_d) {
+        const int lane = threadIdx.x & 63;
+        const int64_t seg = slot >> 6;
+        const int my_rep = slot < n_slots ? slot_rep[slot] : 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            if (q0 + t < nq) {  // wave-uniform
+                const int64_t o = (q0 + t) * slots_pad + slot;
+                double d = -1.0;
+                if (slot < n_slots) {
+                    d = jc69_from_counts(nm[t], nv[t], L, overlap, lut);
+                    dist[o] = d;
+                }
+                double kd = d >= 0 ? d : __longlong_as_double(0x7ff0000000000000LL);
+                int ki = d >= 0 ? my_rep : 0x7fffffff;
+                for (int sft = 32; sft > 0; sft >>= 1) {
+                    const double d2 = __hiloint2double(__shfl_down(__double2hiint(kd), sft, 64), __shfl_down(__double2loint(kd), sft, 64));
+                    const int i2 = __shfl_down(ki, sft, 64);
+                    if (d2 < kd || (d2 == kd && i2 < ki)) { kd = d2; ki = i2; }
+                }
+                if (lane == 0) {
+                    segmin_d[(q0 + t) * slots_pad + seg] = kd;
+                    segmin_i[(q0 + t) * slots_pad + seg] = ki;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (slot < n_slots) {
 #pragma unroll
         for (int t = 0; t < TQ; ++t) {
             if (q0 + t < nq) {
@@ -158,7 +189,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
 template <int P, int MODE>
 static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
                              uint32_t *d_counts, int32_t *seg_slot, int32_t *seg_cnt, const int32_t *qlist,
-                             const int32_t *qcount) {
+                             const int32_t *qcount, double *segmin_d = nullptr, int32_t *segmin_i = nullptr) {
     const DevAlign &a = ctx->aln;
     const uint4 *qp = qb.packed + q0 * a.G * (P + 1);  // q0 is a multiple of 32: whole 16-query tiles
     const double *lut = ctx->jc_lut;
@@ -172,7 +203,8 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
     hipLaunchKernelGGL((k_jc69<P, TQ, MODE, A>), dim3((unsigned)(a.slots_pad / APPLES_TPB),                          \
                        (unsigned)(MODE == 2 ? std::min<int64_t>((nq + TQ - 1) / TQ, 8) : (nq + TQ - 1) / TQ)),         \
                        block, 0, ctx->stream, a.packed, qp, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,   \
-                       ctx->params.overlap_frac, lut, ctx->params.filt_threshold, seg_slot, seg_cnt, qlist, qcount, mmax)
+                       ctx->params.overlap_frac, lut, ctx->params.filt_threshold, seg_slot, seg_cnt, qlist, qcount, mmax,    \
+                       a.slot_rep, segmin_d, segmin_i)
     if (tile >= 32) LAUNCH(32);
     else if (tile >= 16) LAUNCH(16);
     else if (tile >= 8) LAUNCH(8);
@@ -204,10 +236,10 @@ int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64
 // full rows for a device-side list of queries of the block starting at q0 (MODE 2); the grid covers
 // nq_max list entries and tiles beyond *qcount exit at once
 int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
-                         const int32_t *qcount, double *d_dist) {
+                         const int32_t *qcount, double *d_dist, double *segmin_d, int32_t *segmin_i) {
     if (nq_max == 0) return 0;
-    if (ctx->aln.planes == 2) launch_jc69_tile<2, 2>(ctx, qb, q0, nq_max, 32, d_dist, nullptr, nullptr, nullptr, qlist, qcount);
-    else launch_jc69_tile<8, 2>(ctx, qb, q0, nq_max, 32, d_dist, nullptr, nullptr, nullptr, qlist, qcount);
+    if (ctx->aln.planes == 2) launch_jc69_tile<2, 2>(ctx, qb, q0, nq_max, 32, d_dist, nullptr, nullptr, nullptr, qlist, qcount, segmin_d, segmin_i);
+    else launch_jc69_tile<8, 2>(ctx, qb, q0, nq_max, 32, d_dist, nullptr, nullptr, nullptr, qlist, qcount, segmin_d, segmin_i);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

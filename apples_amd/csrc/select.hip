@@ -634,6 +634,152 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
     }
 }
 
+// Top-up path of the fused pipeline (singleton clusters): a query with fewer than `-b` references
+// inside the threshold keeps exactly its `-b` nearest by (distance, index) -- everything inside the
+// threshold is among them.  The listed distance kernel left the smallest key of every 64-slot
+// segment next to the full row, and the `-b` nearest can only live in the `-b` segments with the
+// smallest minima: pick those, rank their <= 64 * b entries, write the survivors in slot order.
+// The row itself (n_members values) is never streamed.
+#define TOPUP_MAX_B 256
+__global__ __launch_bounds__(APPLES_TPB) void k_select_topup(SelectArgs a) {
+    __shared__ int sh_i[8];
+    __shared__ int sh_j[8];
+    __shared__ double sh_d[8];
+    __shared__ int sh_cand[TOPUP_MAX_B];
+    __shared__ int sh_sorted[TOPUP_MAX_B];
+    __shared__ int sh_znode;
+    const int64_t n_list = *a.qcount;
+    const int tid = threadIdx.x;
+    const int64_t nm = a.n_members;
+    const int n_seg = (int)((nm + 63) >> 6);
+    const int B = a.baseobs;
+    for (int64_t r = blockIdx.x; r < n_list; r += gridDim.x) {
+        const int64_t q = a.qlist[r];
+        const double *row = a.dist + r * a.stride;
+        const double *smd = a.segmin_d + r * a.stride;
+        const int32_t *smi = a.segmin_i + r * a.stride;
+        const int self = a.self_slot ? a.self_slot[q] : -1;
+        int32_t *o_node = a.obs_node + q * a.obs_cap;
+        double *o_dist = a.obs_dist + q * a.obs_cap;
+        int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
+        // ---- the B segments with the smallest minima, in key order
+        double last_d = -INF_D;
+        int last_i = -1;
+        int n_cand = 0;
+        for (int k = 0; k < B; ++k) {
+            double bd = INF_D;
+            int bi = 0x7fffffff, bs = 0;
+            for (int sgm = tid; sgm < n_seg; sgm += APPLES_TPB) {
+                const double d = smd[sgm];
+                const int i = smi[sgm];
+                if (i != 0x7fffffff && key_lt(last_d, last_i, d, i) && key_lt(d, i, bd, bi)) { bd = d; bi = i; bs = sgm; }
+            }
+            block_argmin3(bd, bi, bs, sh_d, sh_i, sh_j);
+            if (bi == 0x7fffffff) break;
+            if (tid == 0) sh_cand[k] = bs;
+            last_d = bd; last_i = bi;
+            ++n_cand;
+        }
+        __syncthreads();
+        // ---- the B smallest keys among the candidates' entries -> the cut (Reference.py:144-152)
+        const int n_ent = n_cand * 64;
+        double cut_d = -INF_D;
+        int cut_i = -1;
+        for (int k = 0; k < B; ++k) {
+            double bd = INF_D;
+            int bi = 0x7fffffff, bj = 0;
+            for (int e = tid; e < n_ent; e += APPLES_TPB) {
+                const int64_t s = (int64_t)sh_cand[e >> 6] * 64 + (e & 63);
+                if (s >= nm) continue;
+                const double d = row[s];
+                if (!(d >= 0)) continue;
+                const int i = a.slot_rep[s];
+                if (key_lt(cut_d, cut_i, d, i) && key_lt(d, i, bd, bi)) { bd = d; bi = i; }
+            }
+            block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
+            if (bi == 0x7fffffff) break;
+            cut_d = bd; cut_i = bi;
+        }
+        // ---- candidates in slot order
+        if (tid < n_cand) {
+            const int mine = sh_cand[tid];
+            int rank = 0;
+            for (int k = 0; k < n_cand; ++k) rank += sh_cand[k] < mine;
+            sh_sorted[rank] = mine;
+        }
+        __syncthreads();
+        int base = 0, n_total = 0;
+        int z_i = 0x7fffffff, z_node = -2;
+        for (int e0 = 0; e0 < n_ent; e0 += APPLES_TPB) {
+            const int e = e0 + tid;
+            int emit = 0, node = -1;
+            double d = 0;
+            if (e < n_ent) {
+                const int64_t s = (int64_t)sh_sorted[e >> 6] * 64 + (e & 63);
+                if (s < nm) {
+                    d = row[s];
+                    const int i = a.slot_rep[s];
+                    if (d >= 0 && key_le(d, i, cut_d, cut_i) && (int)s != self) {
+                        ++n_total;
+                        node = a.slot_node[s];
+                        if (d == 0 && i < z_i) { z_i = i; z_node = node; }
+                        emit = node >= 0;
+                    }
+                }
+            }
+            int tot;
+            const int pos = base + block_excl_scan(emit, sh_j, &tot);
+            if (emit) { o_node[pos] = node; o_dist[pos] = d; }
+            base += tot;
+        }
+        __syncthreads();
+        const int n_emit = base;
+        n_total = block_sum(n_total, sh_i);
+        double zd = 0; int zi = z_i, zp = 0;
+        block_argmin3(zd, zi, zp, sh_d, sh_i, sh_j);
+        if (tid == 0) sh_znode = -2;
+        __syncthreads();
+        if (z_i == zi && zi != 0x7fffffff) sh_znode = z_node;
+        __syncthreads();
+        // per-level offsets into the level-sorted list (the sweep's cnt_gt)
+        for (int i = tid; i <= n_emit; i += APPLES_TPB) {
+            const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
+            const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
+            for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
+        }
+        if (tid == 0) {
+            apples_placement p;
+            p.edge = 0; p.flags = 0; p.error = 0.0; p.distal = 0.0; p.pendant = 0.0; p.n_obs = n_total; p.n_valid = 0;
+            int ne = n_emit;
+            if (zi != 0x7fffffff) {
+                p.flags = APPLES_F_EXACT | APPLES_F_PENDANT_INT;
+                p.edge = sh_znode;
+                if (sh_znode < 0) { p.flags |= APPLES_F_ZERO_NOT_IN_TREE; p.edge = -1; }
+                ne = 0;
+            } else if (n_total <= 2) {
+                p.flags = APPLES_F_INSUFFICIENT | APPLES_F_PENDANT_INT;
+                p.edge = -1;
+                ne = 0;
+            } else if (ne < 2) {
+                p.flags = APPLES_F_DEGENERATE | APPLES_F_PENDANT_INT;
+                p.edge = -1;
+                ne = 0;
+            }
+            a.out[q] = p;
+            a.n_obs[q] = ne;
+            enlist(a, q, ne);
+        }
+        __syncthreads();
+    }
+}
+
+int launch_select_topup(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(k_select_topup, dim3((unsigned)std::min<int64_t>(nq, 1024)), dim3(APPLES_TPB), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
     // listed mode: the list length lives on the device, so a bounded grid loops over it

@@ -1,6 +1,6 @@
 """Exploratory C3-size run (200k leaves) with a reduced query count: kernel split + observed sizes."""
-import sys, time
-sys.path.insert(0, '.')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from apples_amd import synth
 from apples_amd.engine import Engine

@@ -121,7 +121,9 @@ def test_fused_and_full_row_selection_paths_agree(c2):
     """The fused path (threshold compaction in the distance epilogue + listed top-up) and the
     full-row path (APPLES_NO_FUSE=1) are two routes to the same observed sets: placements must be
     byte-identical, also when every query needs the top-up rule (tiny threshold) and when large
-    queries are routed to workgroup-sized sweep teams."""
+    queries are routed to workgroup-sized sweep teams.  The top-up rule itself has two forms
+    (streaming the full row, or ranking per-segment minima, the default for long rows): forced
+    here with APPLES_TOPUP_MIN_ROWS=0."""
     import subprocess
     d, nodes = c2
     code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
@@ -130,17 +132,18 @@ def test_fused_and_full_row_selection_paths_agree(c2):
             "d = synth.make_dataset(10000, 1000, 1536)\n"
             "nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)\n"
             "out = []\n"
-            "for thr, b in ((0.2, 25), (0.01, 25), (0.35, 40)):\n"
+            "for thr, b in ((0.2, 25), (0.01, 25), (0.35, 40), (0.02, 200)):\n"
             "    e = Engine(d.tree, d.ref_seqs, nodes, method='OLS', threshold=thr, baseobs=b)\n"
             "    out.append(e.place_sequences(d.query_seqs[:512]).tobytes()); e.close()\n"
             "sys.stdout.buffer.write(b''.join(out))\n" % ROOT)
     outs = []
-    for env in ({}, {'APPLES_NO_FUSE': '1'}, {'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_TEAM': '256'}):
+    for env in ({}, {'APPLES_NO_FUSE': '1'}, {'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_TEAM': '256'},
+                {'APPLES_TOPUP_MIN_ROWS': '0'}):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(r.stdout)
-    assert len(outs[0]) == 3 * 512 * 40
-    assert outs[0] == outs[1] == outs[2] == outs[3]
+    assert len(outs[0]) == 4 * 512 * 40
+    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4]
 
 
 def test_device_resident_results_visible_to_torch_zero_copy():
