@@ -142,19 +142,10 @@ __device__ __forceinline__ double pow2_libm(double x, const double *tab) {
 struct Sol {
     double x1, x2, x1n, x2n, err;
     int x1_int;
-    // residual terms, kept so that exact_err can swap the two squares for libm's pow bits
-    double A, B, D, E, F, up, dn, Rc, Sc;
 };
 
-// error_per_edge with the reference's `**2` bits: A + B + C + D + E + F, C = pow(up,2)*R + pow(dn,2)*S
-__device__ __forceinline__ double exact_err(const Sol &r, const double *tab) {
-    const double C = pow2_libm(r.up, tab) * r.Rc + pow2_libm(r.dn, tab) * r.Sc;
-    return r.A + r.B + C + r.D + r.E + r.F;
-}
-
-// placement_per_edge + util.solve2_2 + error_per_edge for one edge
 template <int M>
-__device__ __forceinline__ Sol solve_edge(const double *S, const double *R, double e, int negative) {
+__device__ __forceinline__ Sol solve_edge(const double *S, const double *R, double e, int negative, const double *pow_tab) {
     // which tuple slots play which role (apples/OLS.py:90-96, FM.py:86-92, BE.py:61-67, BME.py:64-70)
     constexpr int IA = (M == APPLES_OLS || M == APPLES_BME) ? 0 : 5;                     // a_11 = R? + S?
     constexpr int IC = (M == APPLES_OLS || M == APPLES_BME) ? 5 : (M == APPLES_FM ? 4 : 0);  // RD / R1_D / R
@@ -208,13 +199,12 @@ __device__ __forceinline__ Sol solve_edge(const double *S, const double *R, doub
     double dn = e + x1 - x2;  // path through the child side
     double A = R[JA] + S[JA];
     double B = 2 * up * R[JB] + 2 * dn * S[JB];
-    // plain squares here; exact_err() re-evaluates C with libm's pow bits (what the reference computes)
-    double C = (up * up) * R[JC] + (dn * dn) * S[JC];
+    // `x ** 2` is libm pow in the reference: same bits here
+    double C = pow2_libm(up, pow_tab) * R[JC] + pow2_libm(dn, pow_tab) * S[JC];
     double Dd = -2 * up * R[JD] - 2 * dn * S[JD];
     double E = -2 * R[JE] - 2 * S[JE];
     double F = R[JF] + S[JF];
     r.err = A + B + C + Dd + E + F;
-    r.A = A; r.B = B; r.D = Dd; r.E = E; r.F = F; r.up = up; r.dn = dn; r.Rc = R[JC]; r.Sc = S[JC];
     return r;
 }
 
@@ -747,8 +737,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                 double plift[6];
                 if (!is_lca) lift<M>(self.T, nr.e, plift);  // self.T is this node's R by now
                 auto finish_kid = [&](int kd, const Kid &kid, const double *acc, bool defer) {
-                    Sol r = solve_edge<M>(kid.S, acc, kid.e, a.negative);
-                    r.err = exact_err(r, lds_pow);  // the reference's `**2` bits (pruning it per edge was slower)
+                    const Sol r = solve_edge<M>(kid.S, acc, kid.e, a.negative, lds_pow);
                     if (kd > 0) {
                         double *dst = defer ? rtmp + (int64_t)(kd - 1) * 6 : rec[kd - 1].T;
 #pragma unroll
