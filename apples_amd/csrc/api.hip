@@ -446,6 +446,11 @@ int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t
         }
         qb->planes = planes;
         dev_free(d_exotic);
+        if (planes == 2 && dist_mfma_enabled()) {  // int8 operand image for the matrix-core distance kernel
+            const int64_t n128 = round_up(qb->n_pad, 128) + 128;  // a sub-batch may start at any multiple of 32
+            if (dev_alloc(ctx, &qb->qi8, n128 * a.W * 128)) return 1;
+            if (launch_expand_queries_i8(ctx, qb->raw, n, qb->qi8, n128)) return 1;
+        }
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     qb->live = true;
@@ -453,7 +458,7 @@ int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t
 }
 
 void free_block(QueryBlock *qb) {
-    dev_free(qb->table); dev_free(qb->raw); dev_free(qb->packed); dev_free(qb->aa_idx); dev_free(qb->aa_mask); dev_free(qb->self_slot); dev_free(qb->out);
+    dev_free(qb->table); dev_free(qb->raw); dev_free(qb->packed); dev_free(qb->qi8); dev_free(qb->aa_idx); dev_free(qb->aa_mask); dev_free(qb->self_slot); dev_free(qb->out);
     *qb = QueryBlock();
 }
 

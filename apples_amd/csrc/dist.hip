@@ -186,6 +186,196 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// int8 matrix-core form of the same counts (ACGT fast path, tiled case).  The bit-plane kernel above
+// is bound by VALU issue: 6 lane-ops per 32 sites and pair.  Counting is a bilinear form: give every
+// site a vector t in {(1,1,1),(1,-1,-1),(-1,1,-1),(-1,-1,1)} (the corners of a tetrahedron, one per
+// nucleotide; zero for a gap) and a validity flag v.  Then for a pair of rows
+//     sum t_r . t_q = 3*match - mism        sum v_r * v_q = valid = match + mism
+// so mism = (3*valid - sum t.t) / 4, exactly, in int32.  One v_mfma_i32_32x32x32_i8 covers 32 sites
+// of one component for a 32 x 32 block of pairs; the order of the 32 bytes inside a K chunk is
+// irrelevant as long as both operands use the same one (byte i = site i of the word).
+// Workgroup tile: 128 queries x 128 reference slots, four wavefronts of 64 x 64 (2 x 2 MFMA tiles,
+// two int32 accumulator sets).  Queries arrive pre-expanded (4 bytes/site, k_expand_queries_i8);
+// reference rows are expanded from their bit planes on the fly into LDS, behind the MFMAs.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+#define MF_RS 144  // LDS row stride in bytes: 4 components x 32 bytes + 16 (conflict-free 16-byte reads)
+
+// query rows -> int8 operand image: out[(q * W + w) * 128 + comp * 32 + i], comp = t1, t2, t3, v
+__global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_i8(const uint8_t *__restrict__ raw, int64_t n, int L, int W,
+                                                                  uint8_t *__restrict__ out, int64_t n_pad) {
+    const int64_t idx = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;  // one thread per (query, word, site)
+    const int64_t total = n_pad * W * 32;
+    if (idx >= total) return;
+    const int i = (int)(idx & 31);
+    const int64_t qw = idx >> 5;
+    const int w = (int)(qw % W);
+    const int64_t q = qw / W;
+    const int site = w * 32 + i;
+    int t1 = 0, t2 = 0, t3 = 0, v = 0;
+    if (q < n && site < L) {
+        const uint32_t b = raw[q * (int64_t)L + site];
+        if (b != (uint32_t)'-') {
+            const uint32_t code = (b >> 1) & 3u;  // as k_pack_rows<2>
+            v = 1;
+            t1 = (code & 2u) ? -1 : 1;
+            t2 = (code & 1u) ? -1 : 1;
+            t3 = (((code >> 1) ^ code) & 1u) ? -1 : 1;
+        }
+    }
+    uint8_t *o = out + qw * 128 + i;
+    o[0] = (uint8_t)t1; o[32] = (uint8_t)t2; o[64] = (uint8_t)t3; o[96] = (uint8_t)v;
+}
+
+// bit i of x -> least significant bit of byte i, four bits at a time (no carries: the partial
+// products land on distinct bit positions)
+__device__ __forceinline__ uint32_t spread4(uint32_t x) { return __umul24(x & 0xfu, 0x00204081u) & 0x01010101u; }
+// bytes 0/1 -> bytes 0x00/0xFF
+__device__ __forceinline__ uint32_t ffmask(uint32_t x) { return (x << 8) - x; }
+
+// 32 bytes of one component for one word: v bytes = validity bits; signed component = v | 0xFF where negative
+__device__ __forceinline__ void expand_comp(uint32_t m, uint32_t neg, bool is_signed, uint4 *dst) {
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t x = spread4(m >> (4 * k));
+        if (is_signed) x |= ffmask(spread4(neg >> (4 * k)));
+        o[k] = x;
+    }
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(APPLES_TPB) void k_jc69_mfma(const uint4 *__restrict__ refp, const uint8_t *__restrict__ qi8,
+                                                          double *__restrict__ dist, uint32_t *__restrict__ counts,
+                                                          int64_t n_slots, int64_t slots_pad, int G, int W, int64_t nq,
+                                                          int L, double overlap, const double *__restrict__ lut,
+                                                          double thr, int32_t *__restrict__ seg_slot,
+                                                          int32_t *__restrict__ seg_cnt, const int32_t *__restrict__ mmax) {
+    __shared__ __attribute__((aligned(16))) uint8_t Aq[128 * MF_RS];  // queries of the tile, one word
+    __shared__ __attribute__((aligned(16))) uint8_t Br[128 * MF_RS];  // reference slots of the tile, one word
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wq = wv >> 1, wr = wv & 1;
+    const int64_t r0 = (int64_t)blockIdx.x * 128, q0 = (int64_t)blockIdx.y * 128;
+    // loader roles
+    const int lrow = tid & 127, lpart = tid >> 7;       // reference row of the tile; components {t1,t2} or {t3,v}
+    const int lq = tid >> 1, lhalf = tid & 1;           // query of the tile; first or second 64 bytes of its 128
+    const uint8_t *qsrc = qi8 + ((q0 + lq) * (int64_t)W) * 128 + lhalf * 64;
+    v16i_t s1[2][2], s2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) { s1[i][j][x] = 0; s2[i][j][x] = 0; }
+    uint4 pm = make_uint4(0, 0, 0, 0), p0 = pm, p1 = pm;
+    for (int w = 0; w < W; ++w) {
+        if ((w & 3) == 0) {  // a new group of four words: this row's three planes
+            const int g = w >> 2;
+            const uint4 *rp = refp + ((int64_t)g * 3) * slots_pad + r0 + lrow;
+            pm = rp[0]; p0 = rp[slots_pad]; p1 = rp[2 * slots_pad];
+        }
+        const uint4 *qs = reinterpret_cast<const uint4 *>(qsrc + (int64_t)w * 128);
+        const uint4 qa = qs[0], qb = qs[1], qc = qs[2], qd = qs[3];
+        const int x = w & 3;
+        const uint32_t m = x == 0 ? pm.x : (x == 1 ? pm.y : (x == 2 ? pm.z : pm.w));
+        const uint32_t c0 = x == 0 ? p0.x : (x == 1 ? p0.y : (x == 2 ? p0.z : p0.w));
+        const uint32_t c1 = x == 0 ? p1.x : (x == 1 ? p1.y : (x == 2 ? p1.z : p1.w));
+        __syncthreads();  // the previous word's MFMAs have read the tiles
+        {
+            uint4 *bd = reinterpret_cast<uint4 *>(Br + lrow * MF_RS + lpart * 64);
+            if (lpart == 0) { expand_comp(m, c1, true, bd); expand_comp(m, c0, true, bd + 2); }
+            else { expand_comp(m, c0 ^ c1, true, bd); expand_comp(m, 0, false, bd + 2); }
+            uint4 *ad = reinterpret_cast<uint4 *>(Aq + lq * MF_RS + lhalf * 64);
+            ad[0] = qa; ad[1] = qb; ad[2] = qc; ad[3] = qd;
+        }
+        __syncthreads();
+        const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            v4i_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const v4i_t *>(Aq + (wq * 64 + i * 32 + fr) * MF_RS + c * 32 + fh * 16);
+                b[i] = *reinterpret_cast<const v4i_t *>(Br + (wr * 64 + i * 32 + fr) * MF_RS + c * 32 + fh * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (c < 3) s1[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], s1[i][j], 0, 0, 0);
+                    else s2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], s2[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // C layout of the 32x32 tiles: column (reference slot) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int fr = lane & 31, fh = lane >> 5;
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const int64_t q = q0 + wq * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * fh;
+                    const int64_t slot = r0 + wr * 64 + j * 32 + fr;
+                    if (q < nq && slot < n_slots) {
+                        const uint32_t valid = (uint32_t)s2[i][j][x];
+                        const uint32_t mism = (uint32_t)((3 * s2[i][j][x] - s1[i][j][x]) >> 2);
+                        const int64_t o = q * slots_pad + slot;
+                        if (dist) dist[o] = jc69_from_counts(mism, valid, L, overlap, lut);
+                        if (counts) counts[o] = (mism << 16) | valid;
+                    }
+                }
+        return;
+    }
+    // MODE 1: threshold test + per-segment compaction, the format k_select_fast reads.  This wavefront's
+    // 64 reference slots are one segment: column tile j = its lower or upper half.
+    const int64_t seg = (r0 + wr * 64) >> 6;
+    const int64_t n_seg = slots_pad >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+            const int64_t q = q0 + wq * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * fh;  // differs between the lane halves
+            bool keep[2];
+            double d[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t slot = r0 + wr * 64 + j * 32 + fr;
+                const uint32_t valid = (uint32_t)s2[i][j][x];
+                const uint32_t mism = (uint32_t)((3 * s2[i][j][x] - s1[i][j][x]) >> 2);
+                keep[j] = false;
+                d[j] = -1.0;
+                if (q < nq && slot < n_slots) {
+                    if (mmax) {
+                        keep[j] = (int)mism <= mmax[valid];
+                        if (keep[j]) d[j] = lut[(int64_t)valid * (valid + 1) / 2 + mism];
+                    } else {
+                        d[j] = jc69_from_counts(mism, valid, L, overlap, lut);
+                        keep[j] = d[j] >= 0 && d[j] <= thr;
+                    }
+                }
+            }
+            const unsigned long long b0 = __ballot(keep[0]), b1 = __ballot(keep[1]);
+            // this lane half's query: slots 0..31 of the segment from tile 0, 32..63 from tile 1
+            const unsigned long long segmask = ((b0 >> (32 * fh)) & 0xffffffffull) | (((b1 >> (32 * fh)) & 0xffffffffull) << 32);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (keep[j]) {
+                    const int pos = j * 32 + fr;
+                    const int64_t o = q * slots_pad + seg * 64 + __popcll(segmask & ((1ull << pos) - 1ull));
+                    seg_slot[o] = (int32_t)(r0 + wr * 64 + pos);
+                    dist[o] = d[j];
+                }
+            }
+            if (fr == 0 && q < nq) seg_cnt[q * n_seg + seg] = __popcll(segmask);
+        }
+}
+
 template <int P, int MODE>
 static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
                              uint32_t *d_counts, int32_t *seg_slot, int32_t *seg_cnt, const int32_t *qlist,
@@ -214,9 +404,38 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
 #undef LAUNCH2
 }
 
+bool dist_mfma_enabled() {
+    static const bool on = getenv("APPLES_DIST_MFMA") != nullptr;
+    return on;
+}
+
+int launch_expand_queries_i8(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad) {
+    const DevAlign &a = ctx->aln;
+    const int64_t total = n_pad * a.W * 32;
+    hipLaunchKernelGGL(k_expand_queries_i8, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0,
+                       ctx->stream, d_raw, n, a.L, a.W, d_out, n_pad);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+template <int MODE>
+static int launch_mfma(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *d_dist, uint32_t *d_counts,
+                       int32_t *seg_slot, int32_t *seg_cnt) {
+    const DevAlign &a = ctx->aln;
+    static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
+    dim3 grid((unsigned)(a.slots_pad / 128), (unsigned)((nq + 127) / 128));
+    hipLaunchKernelGGL((k_jc69_mfma<MODE>), grid, dim3(APPLES_TPB), 0, ctx->stream, a.packed,
+                       qb.qi8 + q0 * (int64_t)a.W * 128, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, a.W, nq, a.L,
+                       ctx->params.overlap_frac, ctx->jc_lut, ctx->params.filt_threshold, seg_slot, seg_cnt,
+                       no_mmax ? nullptr : ctx->jc_mmax);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
                   uint32_t *d_counts) {
     if (nq == 0) return 0;
+    if (qb.qi8 && ctx->aln.planes == 2) return launch_mfma<0>(ctx, qb, q0, nq, d_dist, d_counts, nullptr, nullptr);
     if (ctx->aln.planes == 2) launch_jc69_tile<2, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     else launch_jc69_tile<8, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     HIP_TRY(ctx, hipGetLastError());
@@ -227,6 +446,7 @@ int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq,
 int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
                         int32_t *seg_slot, int32_t *seg_cnt) {
     if (nq == 0) return 0;
+    if (qb.qi8 && ctx->aln.planes == 2) return launch_mfma<1>(ctx, qb, q0, nq, seg_d, nullptr, seg_slot, seg_cnt);
     if (ctx->aln.planes == 2) launch_jc69_tile<2, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
     else launch_jc69_tile<8, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
     HIP_TRY(ctx, hipGetLastError());
