@@ -447,7 +447,7 @@ int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t
         qb->planes = planes;
         dev_free(d_exotic);
         if (planes == 2 && dist_mfma_enabled()) {  // int8 operand image for the matrix-core distance kernel
-            const int64_t n128 = round_up(qb->n_pad, 128) + 128;  // a sub-batch may start at any multiple of 32
+            const int64_t n128 = round_up(qb->n_pad, 256) + 256;  // a sub-batch may start at any multiple of 32
             if (dev_alloc(ctx, &qb->qi8, n128 * a.W * 128)) return 1;
             if (launch_expand_queries_i8(ctx, qb->raw, n, qb->qi8, n128)) return 1;
         }
@@ -497,6 +497,7 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     s.seg_slot = w.seg_slot; s.seg_cnt = w.seg_cnt; s.node_level = ctx->tree.level;
     s.slow_list = w.slow_list; s.slow_count = w.slow_count; s.qlist = nullptr; s.qcount = nullptr;
+    s.seg_lut = nullptr;
     return s;
 }
 
@@ -610,7 +611,9 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
             HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;
             SelectArgs sa = select_args_alignment(ctx, qb, q0);
+            sa.seg_lut = fused_counts_format(ctx, qb) ? ctx->jc_lut : nullptr;
             if (launch_select_fast(ctx, sa, nq)) return 1;
+            sa.seg_lut = nullptr;
             // top-up path for the queries k_select_fast listed: full rows + per-segment minima (in the
             // rows of the fused buffers, which k_select_fast has consumed), then the `-b` nearest
             static const bool no_topup = getenv("APPLES_NO_TOPUP_KERNEL") != nullptr;  // diagnostic knob

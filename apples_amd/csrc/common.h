@@ -203,6 +203,7 @@ struct SelectArgs {
     apples_placement *out;    // [nq]
     // fused fast path (k_jc69 MODE 1 -> k_select_fast)
     const int32_t *seg_slot, *seg_cnt;  // [nq][stride], [nq][stride/64]
+    const double *seg_lut;              // non-null: the segments hold (valid << 32 | mism), distances are seg_lut[...]
     const int32_t *node_level;          // tree level by node id
     int32_t *slow_list, *slow_count;    // queries that need the top-up rule
     int32_t *cls_list, *cls_count;      // size-class work lists for the small-team sweep
@@ -219,6 +220,7 @@ int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_topup(apples_ctx *ctx, const SelectArgs &a, int64_t nq);  // listed queries, needs segmin_d/segmin_i; baseobs <= 256
 int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const int32_t *perm, int64_t nq, int64_t n_cols);
 bool dist_mfma_enabled();
+bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb);
 int launch_expand_queries_i8(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad);
 int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
                         int32_t *seg_slot, int32_t *seg_cnt);

@@ -195,8 +195,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
 // so mism = (3*valid - sum t.t) / 4, exactly, in int32.  One v_mfma_i32_32x32x32_i8 covers 32 sites
 // of one component for a 32 x 32 block of pairs; the order of the 32 bytes inside a K chunk is
 // irrelevant as long as both operands use the same one (byte i = site i of the word).
-// Workgroup tile: 128 queries x 128 reference slots, four wavefronts of 64 x 64 (2 x 2 MFMA tiles,
-// two int32 accumulator sets).  Queries arrive pre-expanded (4 bytes/site, k_expand_queries_i8);
+// Workgroup tile: 256 queries x 128 reference slots, eight wavefronts of 64 x 64 (2 x 2 MFMA tiles,
+// two int32 accumulator sets): every expanded reference byte feeds 256 queries.  Queries arrive pre-expanded (4 bytes/site, k_expand_queries_i8);
 // reference rows are expanded from their bit planes on the fly into LDS, behind the MFMAs.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
@@ -233,37 +233,55 @@ __global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_i8(const uint8_t 
 // products land on distinct bit positions)
 __device__ __forceinline__ uint32_t spread4(uint32_t x) { return __umul24(x & 0xfu, 0x00204081u) & 0x01010101u; }
 // bytes 0/1 -> bytes 0x00/0xFF
-__device__ __forceinline__ uint32_t ffmask(uint32_t x) { return (x << 8) - x; }
-
-// 32 bytes of one component for one word: v bytes = validity bits; signed component = v | 0xFF where negative
-__device__ __forceinline__ void expand_comp(uint32_t m, uint32_t neg, bool is_signed, uint4 *dst) {
-    uint32_t o[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        uint32_t x = spread4(m >> (4 * k));
-        if (is_signed) x |= ffmask(spread4(neg >> (4 * k)));
-        o[k] = x;
-    }
-    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+__device__ __forceinline__ uint32_t ffmask(uint32_t x) {
+    uint32_t y;
+    asm("v_lshlrev_b32 %0, 8, %1" : "=v"(y) : "v"(x));  // (x << 8) - x; written out so that it does not become a quarter-rate v_mul_lo_u32
+    return y - x;
 }
 
+// One thread expands 16 sites (half a word) of one reference row into the four component chunks:
+// v = validity bits as bytes; a signed component = v | 0xFF where its sign bit is set.
+__device__ __forceinline__ void expand_half(uint32_t m16, uint32_t c0_16, uint32_t c1_16, uint8_t *row, int half) {
+    uint32_t sm[4], t1[4], t2[4], t3[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sm[k] = spread4(m16 >> (4 * k));
+        t1[k] = sm[k] | ffmask(spread4(c1_16 >> (4 * k)));
+        t2[k] = sm[k] | ffmask(spread4(c0_16 >> (4 * k)));
+        t3[k] = sm[k] | ffmask(spread4((c0_16 ^ c1_16) >> (4 * k)));
+    }
+    uint4 *d = reinterpret_cast<uint4 *>(row + half * 16);  // chunk c of the row starts at c * 32
+    d[0] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+    d[2] = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+    d[4] = make_uint4(t3[0], t3[1], t3[2], t3[3]);
+    d[6] = make_uint4(sm[0], sm[1], sm[2], sm[3]);
+}
+
+__device__ __forceinline__ uint32_t comp4(const uint4 &v, int x) { return x == 0 ? v.x : (x == 1 ? v.y : (x == 2 ? v.z : v.w)); }
+
+#define MF_TPB 512
+#define MF_QT 256  // queries per workgroup tile
 template <int MODE>
-__global__ __launch_bounds__(APPLES_TPB) void k_jc69_mfma(const uint4 *__restrict__ refp, const uint8_t *__restrict__ qi8,
+__global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict__ refp, const uint8_t *__restrict__ qi8,
                                                           double *__restrict__ dist, uint32_t *__restrict__ counts,
                                                           int64_t n_slots, int64_t slots_pad, int G, int W, int64_t nq,
                                                           int L, double overlap, const double *__restrict__ lut,
                                                           double thr, int32_t *__restrict__ seg_slot,
                                                           int32_t *__restrict__ seg_cnt, const int32_t *__restrict__ mmax) {
-    __shared__ __attribute__((aligned(16))) uint8_t Aq[128 * MF_RS];  // queries of the tile, one word
-    __shared__ __attribute__((aligned(16))) uint8_t Br[128 * MF_RS];  // reference slots of the tile, one word
+    // two generations of the tile images: the next word is expanded while this one is multiplied
+    __shared__ __attribute__((aligned(16))) uint8_t Aq[2][MF_QT * MF_RS];  // queries of the tile, one word
+    __shared__ __attribute__((aligned(16))) uint8_t Br[2][128 * MF_RS];    // reference slots of the tile, one word
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = wv >> 1, wr = wv & 1;
-    const int64_t r0 = (int64_t)blockIdx.x * 128, q0 = (int64_t)blockIdx.y * 128;
-    // loader roles
-    const int lrow = tid & 127, lpart = tid >> 7;       // reference row of the tile; components {t1,t2} or {t3,v}
-    const int lq = tid >> 1, lhalf = tid & 1;           // query of the tile; first or second 64 bytes of its 128
+    const int64_t r0 = (int64_t)blockIdx.x * 128, q0 = (int64_t)blockIdx.y * MF_QT;
+    // loader roles.  Expansion (wavefronts 0-3, one per SIMD): lane -> reference row (lane & 31) of the
+    // wavefront's 32 rows, 16-site half lane >> 5 (eight neighbouring lanes store to eight rows: no bank
+    // conflicts at the 144-byte row stride).  Query copy (all threads): 64 of a query's 128 bytes.
+    const bool expander = wv < 4;
+    const int lrow = (wv & 3) * 32 + (lane & 31), lhalf_r = lane >> 5;
+    const int lq = tid >> 1, lhalf = tid & 1;
     const uint8_t *qsrc = qi8 + ((q0 + lq) * (int64_t)W) * 128 + lhalf * 64;
+    const uint4 *rsrc = refp + r0 + lrow;
     v16i_t s1[2][2], s2[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -271,36 +289,40 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69_mfma(const uint4 *__restric
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int x = 0; x < 16; ++x) { s1[i][j][x] = 0; s2[i][j][x] = 0; }
-    uint4 pm = make_uint4(0, 0, 0, 0), p0 = pm, p1 = pm;
-    for (int w = 0; w < W; ++w) {
-        if ((w & 3) == 0) {  // a new group of four words: this row's three planes
-            const int g = w >> 2;
-            const uint4 *rp = refp + ((int64_t)g * 3) * slots_pad + r0 + lrow;
+    uint4 pm = make_uint4(0, 0, 0, 0), p0 = pm, p1 = pm, qa, qb, qc, qd;
+    auto fetch = [&](int w) {  // raw data of word w into registers
+        if (expander && (w & 3) == 0) {
+            const uint4 *rp = rsrc + ((int64_t)(w >> 2) * 3) * slots_pad;
             pm = rp[0]; p0 = rp[slots_pad]; p1 = rp[2 * slots_pad];
         }
         const uint4 *qs = reinterpret_cast<const uint4 *>(qsrc + (int64_t)w * 128);
-        const uint4 qa = qs[0], qb = qs[1], qc = qs[2], qd = qs[3];
-        const int x = w & 3;
-        const uint32_t m = x == 0 ? pm.x : (x == 1 ? pm.y : (x == 2 ? pm.z : pm.w));
-        const uint32_t c0 = x == 0 ? p0.x : (x == 1 ? p0.y : (x == 2 ? p0.z : p0.w));
-        const uint32_t c1 = x == 0 ? p1.x : (x == 1 ? p1.y : (x == 2 ? p1.z : p1.w));
-        __syncthreads();  // the previous word's MFMAs have read the tiles
-        {
-            uint4 *bd = reinterpret_cast<uint4 *>(Br + lrow * MF_RS + lpart * 64);
-            if (lpart == 0) { expand_comp(m, c1, true, bd); expand_comp(m, c0, true, bd + 2); }
-            else { expand_comp(m, c0 ^ c1, true, bd); expand_comp(m, 0, false, bd + 2); }
-            uint4 *ad = reinterpret_cast<uint4 *>(Aq + lq * MF_RS + lhalf * 64);
-            ad[0] = qa; ad[1] = qb; ad[2] = qc; ad[3] = qd;
+        qa = qs[0]; qb = qs[1]; qc = qs[2]; qd = qs[3];
+    };
+    auto stage = [&](int w) {  // registers -> tile images of generation w & 1
+        if (expander) {
+            const int x = w & 3, sh = lhalf_r * 16;
+            expand_half((comp4(pm, x) >> sh) & 0xffffu, (comp4(p0, x) >> sh) & 0xffffu, (comp4(p1, x) >> sh) & 0xffffu,
+                        Br[w & 1] + lrow * MF_RS, lhalf_r);
         }
-        __syncthreads();
-        const int fr = lane & 31, fh = lane >> 5;
+        uint4 *ad = reinterpret_cast<uint4 *>(Aq[w & 1] + lq * MF_RS + lhalf * 64);
+        ad[0] = qa; ad[1] = qb; ad[2] = qc; ad[3] = qd;
+    };
+    fetch(0);
+    stage(0);
+    if (W > 1) fetch(1);
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int w = 0; w < W; ++w) {
+        __syncthreads();  // images of word w complete; word w-1's reads done
+        if (w + 1 < W) stage(w + 1);
+        if (w + 2 < W) fetch(w + 2);
+        const uint8_t *A = Aq[w & 1], *B = Br[w & 1];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             v4i_t a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const v4i_t *>(Aq + (wq * 64 + i * 32 + fr) * MF_RS + c * 32 + fh * 16);
-                b[i] = *reinterpret_cast<const v4i_t *>(Br + (wr * 64 + i * 32 + fr) * MF_RS + c * 32 + fh * 16);
+                a[i] = *reinterpret_cast<const v4i_t *>(A + (wq * 64 + i * 32 + fr) * MF_RS + c * 32 + fh * 16);
+                b[i] = *reinterpret_cast<const v4i_t *>(B + (wr * 64 + i * 32 + fr) * MF_RS + c * 32 + fh * 16);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -312,7 +334,6 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69_mfma(const uint4 *__restric
         }
     }
     // C layout of the 32x32 tiles: column (reference slot) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    const int fr = lane & 31, fh = lane >> 5;
     if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -332,48 +353,59 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69_mfma(const uint4 *__restric
                 }
         return;
     }
+#ifdef MF_SKIP_EPILOGUE
+    if (s1[0][0][0] == 0x7fffffff) dist[0] = 1.0;  // timing experiment: main loop only
+    return;
+#endif
     // MODE 1: threshold test + per-segment compaction, the format k_select_fast reads.  This wavefront's
-    // 64 reference slots are one segment: column tile j = its lower or upper half.
+    // 64 reference slots are one segment: column tile j = its lower or upper half.  The test is the
+    // integer one (mism <= mmax[valid]; rows and queries beyond the ends have valid = 0, which never
+    // passes), with the table in the now idle tile memory; survivors are stored as their two counts
+    // (valid << 32 | mism in the 8-byte slot) and k_select_fast looks the distance up: no scattered
+    // table reads and no branches here.
+    __syncthreads();
+    int32_t *mm_lds = reinterpret_cast<int32_t *>(&Aq[0][0]);
+    for (int i = tid; i <= L; i += MF_TPB) mm_lds[i] = mmax[i];
+    __syncthreads();
     const int64_t seg = (r0 + wr * 64) >> 6;
     const int64_t n_seg = slots_pad >> 6;
+    unsigned long long *cnt_out = reinterpret_cast<unsigned long long *>(dist);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        uint32_t keepbits = 0;
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int valid = s2[i][j][x];
+                const int mism = (3 * valid - s1[i][j][x]) >> 2;
+                keepbits |= (mism <= mm_lds[valid] ? 1u : 0u) << (x * 2 + j);
+            }
+        const int64_t qbase = q0 + wq * 64 + i * 32 + 4 * fh;  // this lane half's first query of the 32
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
-            const int64_t q = q0 + wq * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * fh;  // differs between the lane halves
-            bool keep[2];
-            double d[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int64_t slot = r0 + wr * 64 + j * 32 + fr;
-                const uint32_t valid = (uint32_t)s2[i][j][x];
-                const uint32_t mism = (uint32_t)((3 * s2[i][j][x] - s1[i][j][x]) >> 2);
-                keep[j] = false;
-                d[j] = -1.0;
-                if (q < nq && slot < n_slots) {
-                    if (mmax) {
-                        keep[j] = (int)mism <= mmax[valid];
-                        if (keep[j]) d[j] = lut[(int64_t)valid * (valid + 1) / 2 + mism];
-                    } else {
-                        d[j] = jc69_from_counts(mism, valid, L, overlap, lut);
-                        keep[j] = d[j] >= 0 && d[j] <= thr;
-                    }
-                }
-            }
-            const unsigned long long b0 = __ballot(keep[0]), b1 = __ballot(keep[1]);
+            const int64_t q = qbase + (x & 3) + 8 * (x >> 2);
+            // (rows past this launch's queries may be real queries of the next sub-batch: not ours to write)
+            const bool k0 = ((keepbits >> (x * 2)) & 1u) && q < nq, k1 = ((keepbits >> (x * 2 + 1)) & 1u) && q < nq;
+            const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
             // this lane half's query: slots 0..31 of the segment from tile 0, 32..63 from tile 1
             const unsigned long long segmask = ((b0 >> (32 * fh)) & 0xffffffffull) | (((b1 >> (32 * fh)) & 0xffffffffull) << 32);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (keep[j]) {
-                    const int pos = j * 32 + fr;
-                    const int64_t o = q * slots_pad + seg * 64 + __popcll(segmask & ((1ull << pos) - 1ull));
-                    seg_slot[o] = (int32_t)(r0 + wr * 64 + pos);
-                    dist[o] = d[j];
-                }
+            const int64_t o0 = q * slots_pad + seg * 64;
+            if (k0) {
+                const int64_t o = o0 + __popcll(segmask & ((1ull << fr) - 1ull));
+                seg_slot[o] = (int32_t)(r0 + wr * 64 + fr);
+                const unsigned long long valid = (unsigned)s2[i][0][x];
+                cnt_out[o] = (valid << 32) | (unsigned)((3 * s2[i][0][x] - s1[i][0][x]) >> 2);
+            }
+            if (k1) {
+                const int64_t o = o0 + __popcll(segmask & ((1ull << (32 + fr)) - 1ull));
+                seg_slot[o] = (int32_t)(r0 + wr * 64 + 32 + fr);
+                const unsigned long long valid = (unsigned)s2[i][1][x];
+                cnt_out[o] = (valid << 32) | (unsigned)((3 * s2[i][1][x] - s1[i][1][x]) >> 2);
             }
             if (fr == 0 && q < nq) seg_cnt[q * n_seg + seg] = __popcll(segmask);
         }
+    }
 }
 
 template <int P, int MODE>
@@ -404,6 +436,12 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
 #undef LAUNCH2
 }
 
+// the fused pass runs on the matrix cores and leaves (valid, mism) pairs instead of distances
+bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb) {
+    static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
+    return qb.qi8 && ctx->aln.planes == 2 && ctx->jc_lut && ctx->jc_mmax && !no_mmax;
+}
+
 bool dist_mfma_enabled() {
     static const bool on = getenv("APPLES_DIST_MFMA") != nullptr;
     return on;
@@ -423,8 +461,8 @@ static int launch_mfma(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
                        int32_t *seg_slot, int32_t *seg_cnt) {
     const DevAlign &a = ctx->aln;
     static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
-    dim3 grid((unsigned)(a.slots_pad / 128), (unsigned)((nq + 127) / 128));
-    hipLaunchKernelGGL((k_jc69_mfma<MODE>), grid, dim3(APPLES_TPB), 0, ctx->stream, a.packed,
+    dim3 grid((unsigned)(a.slots_pad / 128), (unsigned)((nq + MF_QT - 1) / MF_QT));
+    hipLaunchKernelGGL((k_jc69_mfma<MODE>), grid, dim3(MF_TPB), 0, ctx->stream, a.packed,
                        qb.qi8 + q0 * (int64_t)a.W * 128, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, a.W, nq, a.L,
                        ctx->params.overlap_frac, ctx->jc_lut, ctx->params.filt_threshold, seg_slot, seg_cnt,
                        no_mmax ? nullptr : ctx->jc_mmax);
@@ -446,7 +484,7 @@ int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq,
 int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
                         int32_t *seg_slot, int32_t *seg_cnt) {
     if (nq == 0) return 0;
-    if (qb.qi8 && ctx->aln.planes == 2) return launch_mfma<1>(ctx, qb, q0, nq, seg_d, nullptr, seg_slot, seg_cnt);
+    if (fused_counts_format(ctx, qb)) return launch_mfma<1>(ctx, qb, q0, nq, seg_d, nullptr, seg_slot, seg_cnt);
     if (ctx->aln.planes == 2) launch_jc69_tile<2, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
     else launch_jc69_tile<8, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
     HIP_TRY(ctx, hipGetLastError());

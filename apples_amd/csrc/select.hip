@@ -375,6 +375,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
                 const int64_t src = (s0 + lo) * 64 + (e - sh_pref[lo]);
                 const int slot = sslot[src];
                 d = sd[src];
+                if (a.seg_lut) {  // the matrix-core distance pass leaves the two counts; same table, same bits
+                    const unsigned long long pk = (unsigned long long)__double_as_longlong(d);
+                    const long long valid = (long long)(pk >> 32), mism = (long long)(pk & 0xffffffffull);
+                    d = a.seg_lut[valid * (valid + 1) / 2 + mism];
+                }
                 if (slot != self) {
                     ++n_total;
                     node = a.slot_node[slot];
