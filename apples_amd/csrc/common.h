@@ -203,7 +203,7 @@ struct SelectArgs {
     apples_placement *out;    // [nq]
     // fused fast path (k_jc69 MODE 1 -> k_select_fast)
     const int32_t *seg_slot, *seg_cnt;  // [nq][stride], [nq][stride/64]
-    const double *seg_lut;              // non-null: the segments hold (valid << 32 | mism), distances are seg_lut[...]
+    const double *seg_lut;              // non-null: seg_slot holds position << 26 | valid << 13 | mism, distances are seg_lut[...]
     const int32_t *node_level;          // tree level by node id
     int32_t *slow_list, *slow_count;    // queries that need the top-up rule
     int32_t *cls_list, *cls_count;      // size-class work lists for the small-team sweep

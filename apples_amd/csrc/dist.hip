@@ -360,26 +360,27 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
     // MODE 1: threshold test + per-segment compaction, the format k_select_fast reads.  This wavefront's
     // 64 reference slots are one segment: column tile j = its lower or upper half.  The test is the
     // integer one (mism <= mmax[valid]; rows and queries beyond the ends have valid = 0, which never
-    // passes), with the table in the now idle tile memory; survivors are stored as their two counts
-    // (valid << 32 | mism in the 8-byte slot) and k_select_fast looks the distance up: no scattered
-    // table reads and no branches here.
+    // passes), with the table in the now idle tile memory.  A survivor is one 32-bit word in seg_slot:
+    // position in the segment (6 bits) | valid (13) | mism (13); k_select_fast looks the distance up.
+    // No scattered table reads and one store per survivor here.
     __syncthreads();
     int32_t *mm_lds = reinterpret_cast<int32_t *>(&Aq[0][0]);
     for (int i = tid; i <= L; i += MF_TPB) mm_lds[i] = mmax[i];
     __syncthreads();
     const int64_t seg = (r0 + wr * 64) >> 6;
     const int64_t n_seg = slots_pad >> 6;
-    unsigned long long *cnt_out = reinterpret_cast<unsigned long long *>(dist);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        uint32_t pk[16][2];
         uint32_t keepbits = 0;
 #pragma unroll
         for (int x = 0; x < 16; ++x)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int valid = s2[i][j][x];
-                const int mism = (3 * valid - s1[i][j][x]) >> 2;
+                const int mism = ((valid << 1) + valid - s1[i][j][x]) >> 2;  // (3 valid - sum t.t) / 4
                 keepbits |= (mism <= mm_lds[valid] ? 1u : 0u) << (x * 2 + j);
+                pk[x][j] = ((uint32_t)(j * 32 + fr) << 26) | ((uint32_t)valid << 13) | (uint32_t)mism;
             }
         const int64_t qbase = q0 + wq * 64 + i * 32 + 4 * fh;  // this lane half's first query of the 32
 #pragma unroll
@@ -389,21 +390,12 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
             const bool k0 = ((keepbits >> (x * 2)) & 1u) && q < nq, k1 = ((keepbits >> (x * 2 + 1)) & 1u) && q < nq;
             const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
             // this lane half's query: slots 0..31 of the segment from tile 0, 32..63 from tile 1
-            const unsigned long long segmask = ((b0 >> (32 * fh)) & 0xffffffffull) | (((b1 >> (32 * fh)) & 0xffffffffull) << 32);
-            const int64_t o0 = q * slots_pad + seg * 64;
-            if (k0) {
-                const int64_t o = o0 + __popcll(segmask & ((1ull << fr) - 1ull));
-                seg_slot[o] = (int32_t)(r0 + wr * 64 + fr);
-                const unsigned long long valid = (unsigned)s2[i][0][x];
-                cnt_out[o] = (valid << 32) | (unsigned)((3 * s2[i][0][x] - s1[i][0][x]) >> 2);
-            }
-            if (k1) {
-                const int64_t o = o0 + __popcll(segmask & ((1ull << (32 + fr)) - 1ull));
-                seg_slot[o] = (int32_t)(r0 + wr * 64 + 32 + fr);
-                const unsigned long long valid = (unsigned)s2[i][1][x];
-                cnt_out[o] = (valid << 32) | (unsigned)((3 * s2[i][1][x] - s1[i][1][x]) >> 2);
-            }
-            if (fr == 0 && q < nq) seg_cnt[q * n_seg + seg] = __popcll(segmask);
+            const uint32_t lo = (uint32_t)(b0 >> (32 * fh)), hi = (uint32_t)(b1 >> (32 * fh));
+            int32_t *row = seg_slot + q * slots_pad + seg * 64;
+            const uint32_t below = (1u << fr) - 1u;
+            if (k0) row[__popc(lo & below)] = (int32_t)pk[x][0];
+            if (k1) row[__popc(lo) + __popc(hi & below)] = (int32_t)pk[x][1];
+            if (fr == 0 && q < nq) seg_cnt[q * n_seg + seg] = __popc(lo) + __popc(hi);
         }
     }
 }
@@ -436,10 +428,11 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
 #undef LAUNCH2
 }
 
-// the fused pass runs on the matrix cores and leaves (valid, mism) pairs instead of distances
+// the fused pass runs on the matrix cores and leaves packed (position, valid, mism) words instead of
+// slots and distances
 bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb) {
     static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
-    return qb.qi8 && ctx->aln.planes == 2 && ctx->jc_lut && ctx->jc_mmax && !no_mmax;
+    return qb.qi8 && ctx->aln.planes == 2 && ctx->jc_lut && ctx->jc_mmax && !no_mmax && ctx->aln.L < 8192;  // 13-bit counts
 }
 
 bool dist_mfma_enabled() {

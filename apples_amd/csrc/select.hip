@@ -373,12 +373,14 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
                     if (sh_pref[mid] <= e) lo = mid; else hi = mid;
                 }
                 const int64_t src = (s0 + lo) * 64 + (e - sh_pref[lo]);
-                const int slot = sslot[src];
-                d = sd[src];
-                if (a.seg_lut) {  // the matrix-core distance pass leaves the two counts; same table, same bits
-                    const unsigned long long pk = (unsigned long long)__double_as_longlong(d);
-                    const long long valid = (long long)(pk >> 32), mism = (long long)(pk & 0xffffffffull);
+                int slot = sslot[src];
+                if (a.seg_lut) {  // the matrix-core distance pass leaves position | valid | mism; same table, same bits
+                    const uint32_t pk = (uint32_t)slot;
+                    const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
+                    slot = (int)((s0 + lo) * 64 + (pk >> 26));
                     d = a.seg_lut[valid * (valid + 1) / 2 + mism];
+                } else {
+                    d = sd[src];
                 }
                 if (slot != self) {
                     ++n_total;
