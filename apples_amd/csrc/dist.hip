@@ -257,6 +257,23 @@ __device__ __forceinline__ void expand_half(uint32_t m16, uint32_t c0_16, uint32
     d[6] = make_uint4(sm[0], sm[1], sm[2], sm[3]);
 }
 
+// One thread expands 8 sites (a quarter of a word) of one reference row into the four component chunks.
+__device__ __forceinline__ void expand_quarter(uint32_t m8, uint32_t c0_8, uint32_t c1_8, uint8_t *row, int quarter) {
+    uint32_t sm[2], t1[2], t2[2], t3[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        sm[k] = spread4(m8 >> (4 * k));
+        t1[k] = sm[k] | ffmask(spread4(c1_8 >> (4 * k)));
+        t2[k] = sm[k] | ffmask(spread4(c0_8 >> (4 * k)));
+        t3[k] = sm[k] | ffmask(spread4((c0_8 ^ c1_8) >> (4 * k)));
+    }
+    uint2 *d = reinterpret_cast<uint2 *>(row + quarter * 8);  // chunk c of the row starts at c * 32
+    d[0] = make_uint2(t1[0], t1[1]);
+    d[4] = make_uint2(t2[0], t2[1]);
+    d[8] = make_uint2(t3[0], t3[1]);
+    d[12] = make_uint2(sm[0], sm[1]);
+}
+
 __device__ __forceinline__ uint32_t comp4(const uint4 &v, int x) { return x == 0 ? v.x : (x == 1 ? v.y : (x == 2 ? v.z : v.w)); }
 
 #define MF_TPB 512
@@ -274,11 +291,10 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = wv >> 1, wr = wv & 1;
     const int64_t r0 = (int64_t)blockIdx.x * 128, q0 = (int64_t)blockIdx.y * MF_QT;
-    // loader roles.  Expansion (wavefronts 0-3, one per SIMD): lane -> reference row (lane & 31) of the
-    // wavefront's 32 rows, 16-site half lane >> 5 (eight neighbouring lanes store to eight rows: no bank
-    // conflicts at the 144-byte row stride).  Query copy (all threads): 64 of a query's 128 bytes.
-    const bool expander = wv < 4;
-    const int lrow = (wv & 3) * 32 + (lane & 31), lhalf_r = lane >> 5;
+    // loader roles.  Expansion: every thread takes 8 sites of one reference row (16 rows per
+    // wavefront; sixteen neighbouring lanes = 8 rows x 2 quarters hit 32 distinct banks at the
+    // 144-byte row stride).  Query copy: 64 of a query's 128 bytes.
+    const int lrow = wv * 16 + (lane & 7) + 8 * ((lane >> 5) & 1), lquarter = ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1);
     const int lq = tid >> 1, lhalf = tid & 1;
     const uint8_t *qsrc = qi8 + ((q0 + lq) * (int64_t)W) * 128 + lhalf * 64;
     const uint4 *rsrc = refp + r0 + lrow;
@@ -290,47 +306,64 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
 #pragma unroll
             for (int x = 0; x < 16; ++x) { s1[i][j][x] = 0; s2[i][j][x] = 0; }
     uint4 pm = make_uint4(0, 0, 0, 0), p0 = pm, p1 = pm, qa, qb, qc, qd;
-    auto fetch = [&](int w) {  // raw data of word w into registers
-        if (expander && (w & 3) == 0) {
+    const int Wp = G * 4;  // words of the packed rows (padding words are all zero: they add nothing)
+    auto fetch = [&](int w, bool planes) {  // raw data of word w into registers; branch-free for the scheduler
+        if (planes) {
             const uint4 *rp = rsrc + ((int64_t)(w >> 2) * 3) * slots_pad;
             pm = rp[0]; p0 = rp[slots_pad]; p1 = rp[2 * slots_pad];
         }
-        const uint4 *qs = reinterpret_cast<const uint4 *>(qsrc + (int64_t)w * 128);
+        const int wq_ = w < W ? w : W - 1;  // the query image has W words
+        const uint4 *qs = reinterpret_cast<const uint4 *>(qsrc + (int64_t)wq_ * 128);
         qa = qs[0]; qb = qs[1]; qc = qs[2]; qd = qs[3];
     };
-    auto stage = [&](int w) {  // registers -> tile images of generation w & 1
-        if (expander) {
-            const int x = w & 3, sh = lhalf_r * 16;
-            expand_half((comp4(pm, x) >> sh) & 0xffffu, (comp4(p0, x) >> sh) & 0xffffu, (comp4(p1, x) >> sh) & 0xffffu,
-                        Br[w & 1] + lrow * MF_RS, lhalf_r);
-        }
+    auto stage = [&](int w, int x) {  // registers -> tile images of generation w & 1
+        const int sh = lquarter * 8;
+        expand_quarter((comp4(pm, x) >> sh) & 0xffu, (comp4(p0, x) >> sh) & 0xffu, (comp4(p1, x) >> sh) & 0xffu,
+                       Br[w & 1] + lrow * MF_RS, lquarter);
         uint4 *ad = reinterpret_cast<uint4 *>(Aq[w & 1] + lq * MF_RS + lhalf * 64);
         ad[0] = qa; ad[1] = qb; ad[2] = qc; ad[3] = qd;
     };
-    fetch(0);
-    stage(0);
-    if (W > 1) fetch(1);
+    fetch(0, true);
+    stage(0, 0);
+    fetch(1, false);
     const int fr = lane & 31, fh = lane >> 5;
-    for (int w = 0; w < W; ++w) {
-        __syncthreads();  // images of word w complete; word w-1's reads done
-        if (w + 1 < W) stage(w + 1);
-        if (w + 2 < W) fetch(w + 2);
-        const uint8_t *A = Aq[w & 1], *B = Br[w & 1];
+    for (int g = 0; g < G; ++g) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            v4i_t a[2], b[2];
+        for (int x = 0; x < 4; ++x) {
+            const int w = g * 4 + x;
+            __syncthreads();  // images of word w complete; word w-1's reads done
+            const uint8_t *A = Aq[w & 1], *B = Br[w & 1];
+            // all sixteen operand fragments of this word first, then the MFMAs with the next word's
+            // expansion and the loads of the one after in their shadows (the whole workgroup moves in
+            // lockstep through the barrier: without this the matrix pipe idles while everybody expands)
+            v4i_t a[4][2], b[4][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const v4i_t *>(A + (wq * 64 + i * 32 + fr) * MF_RS + c * 32 + fh * 16);
-                b[i] = *reinterpret_cast<const v4i_t *>(B + (wr * 64 + i * 32 + fr) * MF_RS + c * 32 + fh * 16);
-            }
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (c < 3) s1[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], s1[i][j], 0, 0, 0);
-                    else s2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], s2[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) {
+                    a[c][i] = *reinterpret_cast<const v4i_t *>(A + (wq * 64 + i * 32 + fr) * MF_RS + c * 32 + fh * 16);
+                    b[c][i] = *reinterpret_cast<const v4i_t *>(B + (wr * 64 + i * 32 + fr) * MF_RS + c * 32 + fh * 16);
                 }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (c < 3) s1[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[c][i], b[c][j], s1[i][j], 0, 0, 0);
+                        else s2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[c][i], b[c][j], s2[i][j], 0, 0, 0);
+                    }
+            // (after the last word these two touch an image nobody reads and re-read the last query word)
+            stage(w + 1, (x + 1) & 3);
+            const int w2 = w + 2 < Wp ? w + 2 : Wp - 1;
+            fetch(w2, x == 2);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {  // scheduling pattern: one MFMA, then up to five VALU, one LDS write, one load
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
         }
     }
     // C layout of the 32x32 tiles: column (reference slot) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
