@@ -357,9 +357,13 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
             stage(w + 1, (x + 1) & 3);
             const int w2 = w + 2 < Wp ? w + 2 : Wp - 1;
             fetch(w2, x == 2);
+            // scheduling pattern: the first component's four fragments, then per MFMA one fragment read
+            // for the next component, up to five VALU, one LDS write, one global load
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {  // scheduling pattern: one MFMA, then up to five VALU, one LDS write, one load
+            for (int k = 0; k < 16; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -469,8 +473,8 @@ bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb) {
 }
 
 bool dist_mfma_enabled() {
-    static const bool on = getenv("APPLES_DIST_MFMA") != nullptr;
-    return on;
+    static const bool off = getenv("APPLES_NO_DIST_MFMA") != nullptr;  // diagnostic knob: bit-plane VALU kernel everywhere
+    return !off;
 }
 
 int launch_expand_queries_i8(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad) {
@@ -499,7 +503,8 @@ static int launch_mfma(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
 int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
                   uint32_t *d_counts) {
     if (nq == 0) return 0;
-    if (qb.qi8 && ctx->aln.planes == 2) return launch_mfma<0>(ctx, qb, q0, nq, d_dist, d_counts, nullptr, nullptr);
+    // (small explicit tiles are the streaming roofline runs of the bit-plane kernel: leave them alone)
+    if (qb.qi8 && ctx->aln.planes == 2 && tile >= 16) return launch_mfma<0>(ctx, qb, q0, nq, d_dist, d_counts, nullptr, nullptr);
     if (ctx->aln.planes == 2) launch_jc69_tile<2, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     else launch_jc69_tile<8, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     HIP_TRY(ctx, hipGetLastError());

@@ -123,7 +123,8 @@ def test_fused_and_full_row_selection_paths_agree(c2):
     byte-identical, also when every query needs the top-up rule (tiny threshold) and when large
     queries are routed to workgroup-sized sweep teams.  The top-up rule itself has two forms
     (streaming the full row, or ranking per-segment minima, the default for long rows): forced
-    here with APPLES_TOPUP_MIN_ROWS=0."""
+    here with APPLES_TOPUP_MIN_ROWS=0.  And the pair counts come from the int8 matrix-core kernel
+    by default, from the bit-plane VALU kernel with APPLES_NO_DIST_MFMA=1."""
     import subprocess
     d, nodes = c2
     code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
@@ -138,12 +139,12 @@ def test_fused_and_full_row_selection_paths_agree(c2):
             "sys.stdout.buffer.write(b''.join(out))\n" % ROOT)
     outs = []
     for env in ({}, {'APPLES_NO_FUSE': '1'}, {'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_TEAM': '256'},
-                {'APPLES_TOPUP_MIN_ROWS': '0'}):
+                {'APPLES_TOPUP_MIN_ROWS': '0'}, {'APPLES_NO_DIST_MFMA': '1'}):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(r.stdout)
     assert len(outs[0]) == 4 * 512 * 40
-    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4]
+    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4] == outs[5]
 
 
 def test_device_resident_results_visible_to_torch_zero_copy():
