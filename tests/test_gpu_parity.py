@@ -399,3 +399,31 @@ def test_both_sweep_layouts_agree_on_polytomies(monkeypatch):
             eng.close()
         assert outs[0].tobytes() == outs[1].tobytes(), (m, c)
     monkeypatch.delenv('APPLES_NODE_MAP', raising=False)
+
+
+@pytest.mark.parametrize('L,n_ref,n_q', [(77, 130, 16), (1000, 300, 100), (1620, 257, 300), (33, 64, 517)])
+def test_matrix_core_pair_counts_equal_the_bytewise_definition(L, n_ref, n_q):
+    """The tiled distance pass counts (mismatches, shared valid sites) with int8 MFMAs from
+    tetrahedral codes; apples/distance.py:733-737 defines the same two integers on bytes.  Ragged
+    sizes (L not a multiple of 32, rows and queries not multiples of the 128 x 256 tile), heavy
+    gaps, all-gap rows and identical rows; every count must be identical, and so must the counts of
+    the bit-plane VALU kernel the library uses for small query tiles."""
+    rng = np.random.default_rng(L * 1000 + n_q)
+    alpha = np.frombuffer(b'ACGT-', dtype=np.uint8)
+    ref = alpha[rng.choice(5, size=(n_ref, L), p=[0.22, 0.22, 0.22, 0.22, 0.12])]
+    qry = alpha[rng.choice(5, size=(n_q, L), p=[0.2, 0.2, 0.2, 0.2, 0.2])]
+    ref[0] = ord('-')
+    qry[1] = ord('-')
+    qry[2] = ref[5]
+    tree = read_tree(os.path.join(DATA, 'small_backbone.nwk'))
+    e = Engine(tree, ref, np.full(n_ref, -1, np.int32), method='OLS')
+    assert e.describe()['code_planes'] == 2
+    counts, dist = e.distances(qry)  # >= 16 queries: matrix-core kernel
+    nd_r, nd_q = ref != ord('-'), qry != ord('-')
+    valid = (nd_q[:, None, :] & nd_r[None, :, :]).sum(-1)
+    mism = ((qry[:, None, :] != ref[None, :, :]) & nd_q[:, None, :] & nd_r[None, :, :]).sum(-1)
+    want = np.stack([mism, valid], axis=-1).astype(np.uint32)  # Engine.distances: [..., 0] mismatches, [..., 1] valid
+    assert np.array_equal(counts, want)
+    few, _ = e.distances(qry[:7])  # < 16 queries: bit-plane kernel
+    assert np.array_equal(few, want[:7])
+    e.close()
