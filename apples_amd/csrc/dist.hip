@@ -305,23 +305,23 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int x = 0; x < 16; ++x) { s1[i][j][x] = 0; s2[i][j][x] = 0; }
-    uint4 pm = make_uint4(0, 0, 0, 0), p0 = pm, p1 = pm, qa, qb, qc, qd;
-    const int Wp = G * 4;  // words of the packed rows (padding words are all zero: they add nothing)
-    auto fetch = [&](int w, bool planes) {  // raw data of word w into registers; branch-free for the scheduler
-        if (planes) {
-            const uint4 *rp = rsrc + ((int64_t)(w >> 2) * 3) * slots_pad;
-            pm = rp[0]; p0 = rp[slots_pad]; p1 = rp[2 * slots_pad];
-        }
-        const int wq_ = w < W ? w : W - 1;  // the query image has W words
-        const uint4 *qs = reinterpret_cast<const uint4 *>(qsrc + (int64_t)wq_ * 128);
+    uint4 pm, p0, p1, pmN, p0N, p1N, qa, qb, qc, qd;
+    auto fetch_planes = [&](int g, uint4 &m, uint4 &c0, uint4 &c1) {
+        const uint4 *rp = rsrc + ((int64_t)(g < G ? g : G - 1) * 3) * slots_pad;
+        m = rp[0]; c0 = rp[slots_pad]; c1 = rp[2 * slots_pad];
+    };
+    auto fetch_query = [&](int w) {  // the query image has W words; beyond them the reference planes are zero anyway
+        const uint4 *qs = reinterpret_cast<const uint4 *>(qsrc + (int64_t)(w < W ? w : W - 1) * 128);
         qa = qs[0]; qb = qs[1]; qc = qs[2]; qd = qs[3];
     };
-    auto stage = [&](int w, int x) {  // registers -> tile images of generation w & 1
+    auto stage_queries = [&](int w) {  // registers -> query image of generation w & 1
+        uint4 *ad = reinterpret_cast<uint4 *>(Aq[w & 1] + lq * MF_RS + lhalf * 64);
+        ad[0] = qa; ad[1] = qb; ad[2] = qc; ad[3] = qd;
+    };
+    auto stage_refs = [&](int w, int x) {  // planes -> reference image of generation w & 1 (x = w & 3)
         const int sh = lquarter * 8;
         expand_quarter((comp4(pm, x) >> sh) & 0xffu, (comp4(p0, x) >> sh) & 0xffu, (comp4(p1, x) >> sh) & 0xffu,
                        Br[w & 1] + lrow * MF_RS, lquarter);
-        uint4 *ad = reinterpret_cast<uint4 *>(Aq[w & 1] + lq * MF_RS + lhalf * 64);
-        ad[0] = qa; ad[1] = qb; ad[2] = qc; ad[3] = qd;
     };
     const int fr = lane & 31, fh = lane >> 5;
     // operand fragments: components {t1, t2} and {t3, v} live in two register sets that are refilled
@@ -337,17 +337,24 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
                 fb[c][i] = *reinterpret_cast<const v4i_t *>(B + (wr * 64 + i * 32 + fr) * MF_RS + (cbase + c) * 32 + fh * 16);
             }
     };
-    fetch(0, true);
-    stage(0, 0);
-    fetch(1, false);
+    // Schedule of word w (one barrier per word, in the middle of its MFMA stream):
+    //   first half : MFMAs t1, t2 of w | query image of w+1 (stores first) | fragments t3, v of w | loads of query word w+2
+    //   barrier    : image w+1 complete, image w read by everybody
+    //   second half: MFMAs t3, v of w  | fragments t1, t2 of w+1 (first) | reference image of w+2 (into w's buffer)
+    // LDS completes in order behind one counter: what the barrier needs (the stores of the first half)
+    // goes out first, what the next half-word needs (fragments) next, the expansion's stores last.
+    fetch_planes(0, pm, p0, p1);
+    fetch_query(0);
+    stage_queries(0);
+    stage_refs(0, 0);
+    stage_refs(1, 1);
+    fetch_query(1);
     __syncthreads();
     load_frags(0, 0, a01, b01);
     for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const int w = g * 4 + x;
-            // ---- first half: t1, t2 of word w; meanwhile the next word's images are built, the word after
-            //      that is loaded, and this word's {t3, v} fragments come in
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -355,23 +362,29 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         s1[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a01[c][i], b01[c][j], s1[i][j], 0, 0, 0);
+            stage_queries(w + 1);
             load_frags(w, 2, a23, b23);
-            // (after the last word these two touch an image nobody reads and re-read the last query word)
-            stage(w + 1, (x + 1) & 3);
-            const int w2 = w + 2 < Wp ? w + 2 : Wp - 1;
-            fetch(w2, x == 2);
+            fetch_query(w + 2);
+            if (x == 1) fetch_planes(g + 1, pmN, p0N, p1N);  // used from the second half of the next word on
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {  // one MFMA, one fragment read, up to nine VALU, one LDS write, one load
+            for (int k = 0; k < 2; ++k) {  // the four wide stores
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             }
-            // ---- one barrier per word, in the middle of the MFMA stream: image w+1 is complete, image w
-            //      has been read by everybody (its buffer is rewritten in the next first half)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // the eight fragment reads, the loads
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
             __syncthreads();
-            // ---- second half: t3 and v of word w; the next word's {t1, t2} fragments come in
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -381,10 +394,19 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
 #pragma unroll
                 for (int j = 0; j < 2; ++j) s2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a23[1][i], b23[1][j], s2[i][j], 0, 0, 0);
             load_frags(w + 1, 0, a01, b01);
+            if (x == 2) { pm = pmN; p0 = p0N; p1 = p1N; }  // words 0, 1 of the next group from here on
+            stage_refs(w + 2, (x + 2) & 3);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {  // the eight fragment reads first, expansion arithmetic beside them
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // then the rest of the expansion and its four stores
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
         }
     }
