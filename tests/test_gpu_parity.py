@@ -336,11 +336,15 @@ def _random_newick(rng, n_leaves, shape):
     return nodes[0].rsplit(':', 1)[0] + ';'
 
 
-def test_random_trees_per_edge_bit_parity_with_c_oracle():
+@pytest.mark.parametrize('layout', ['bits', 'map'])
+def test_random_trees_per_edge_bit_parity_with_c_oracle(layout, monkeypatch):
     """Many small random trees (binary, caterpillar, polytomous; zero and tiny branch lengths) and
     random observed sets of every size from 2 up: valid set, LCA, S, R and the 2x2 solutions must
-    equal the C oracle's bit for bit, placements edge for edge (ties resolved by residual)."""
+    equal the C oracle's bit for bit, placements edge for edge (ties resolved by residual).  Both
+    node-lookup layouts of the sweep (LDS bit space; tagged node map of big trees)."""
     from oracle_c import COracle
+    if layout == 'map':
+        monkeypatch.setenv('APPLES_NODE_MAP', '1')
     from apples_amd.tree import parse_newick
     rng = np.random.default_rng(2024)
     n_cases = 0
