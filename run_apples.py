@@ -37,6 +37,31 @@ def read_dismat(f):
     return names, cols, (np.vstack(rows) if rows else np.zeros((0, len(cols))))
 
 
+def read_dismat_binary(path):
+    """Binary form of the same table (a 200 k-column table is 20 GB of text): a numpy
+    ``.npz`` with ``queries`` and ``columns`` (string arrays) and ``D`` (float64 [queries, columns],
+    negative = missing).  Written by ``numpy.savez(path, queries=..., columns=..., D=...)``."""
+    z = np.load(path, allow_pickle=False)
+    names = [str(x) for x in z['queries']]
+    cols = [str(x) for x in z['columns']]
+    D = np.ascontiguousarray(z['D'], dtype=np.float64)
+    if D.shape != (len(names), len(cols)):
+        raise ValueError('distance table shape %s does not match %d queries x %d columns' % (D.shape, len(names), len(cols)))
+    if len(set(cols)) != len(cols):  # the text reader's dict semantics: first position, last value
+        keep, seen = [], {}
+        for i, c in enumerate(cols):
+            if c in seen:
+                D[:, seen[c]] = D[:, i]
+            else:
+                seen[c] = len(keep)
+                keep.append(i)
+                if len(keep) - 1 != i:
+                    D[:, len(keep) - 1] = D[:, i]
+        cols = [cols[i] for i in keep]
+        D = np.ascontiguousarray(D[:, :len(cols)])
+    return names, cols, D
+
+
 def main(argv=None):
     startb = time.time()
     options, _ = options_config(argv)
@@ -60,8 +85,13 @@ def main(argv=None):
     devices = list(range(ngpu))
 
     if options.dist_fp:
-        with open(options.dist_fp) as f:
-            names, cols, D = read_dismat(f)
+        with open(options.dist_fp, 'rb') as f:
+            magic = f.read(2)
+        if magic == b'PK':  # a numpy .npz archive
+            names, cols, D = read_dismat_binary(options.dist_fp)
+        else:
+            with open(options.dist_fp) as f:
+                names, cols, D = read_dismat(f)
         worker = QueryWorker(tree, options, None, devices)
         startq = time.time()
         out_names, rows = worker.run_distances(names, cols, D, rows=True)

@@ -265,3 +265,26 @@ def test_native_fasta_scan_matches_record_reader(case, tmp_path):
             if want is not None:
                 assert want.names == got.names
                 assert np.array_equal(want.seqs, got.seqs)
+
+
+def test_binary_distance_table_equals_text_reader(tmp_path):
+    """The .npz form of a -d table gives run_apples.py the same names, columns and values as the
+    text form (run_apples.py:43-54), repeated column names included."""
+    import run_apples
+    rng = np.random.default_rng(3)
+    cols = ['a', 'b', 'c', 'b', 'd']
+    names = ['q1', 'q2', 'q3']
+    D = np.round(rng.random((3, 5)), 6)
+    D[1, 2] = -1.0
+    text = tmp_path / 'd.mat'
+    with open(text, 'w') as f:
+        f.write('x ' + ' '.join(cols) + '\n')
+        for n, row in zip(names, D):
+            f.write(n + ' ' + ' '.join(repr(float(v)) for v in row) + '\n')
+    with open(text) as f:
+        wn, wc, wD = run_apples.read_dismat(f)
+    npz = tmp_path / 'd.npz'
+    np.savez(npz, queries=np.array(names), columns=np.array(cols), D=D)
+    gn, gc, gD = run_apples.read_dismat_binary(str(npz))
+    assert gn == wn and gc == wc
+    assert np.array_equal(gD, wD)
