@@ -258,14 +258,17 @@ __device__ __forceinline__ void expand_half(uint32_t m16, uint32_t c0_16, uint32
 }
 
 // One thread expands 8 sites (a quarter of a word) of one reference row into the four component chunks.
+// spread4 and ffmask are XOR-linear on these operands, so the third component's sign bytes (code bits
+// c0 ^ c1) are the XOR of the other two's: no third spread.
 __device__ __forceinline__ void expand_quarter(uint32_t m8, uint32_t c0_8, uint32_t c1_8, uint8_t *row, int quarter) {
     uint32_t sm[2], t1[2], t2[2], t3[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         sm[k] = spread4(m8 >> (4 * k));
-        t1[k] = sm[k] | ffmask(spread4(c1_8 >> (4 * k)));
-        t2[k] = sm[k] | ffmask(spread4(c0_8 >> (4 * k)));
-        t3[k] = sm[k] | ffmask(spread4((c0_8 ^ c1_8) >> (4 * k)));
+        const uint32_t f1 = ffmask(spread4(c1_8 >> (4 * k))), f0 = ffmask(spread4(c0_8 >> (4 * k)));
+        t1[k] = sm[k] | f1;
+        t2[k] = sm[k] | f0;
+        t3[k] = sm[k] | (f0 ^ f1);
     }
     uint2 *d = reinterpret_cast<uint2 *>(row + quarter * 8);  // chunk c of the row starts at c * 32
     d[0] = make_uint2(t1[0], t1[1]);
