@@ -15,15 +15,17 @@
 // 64-byte line: the sweep's level steps are chains of dependent loads, and a separate load of the
 // children's records would add a link to every step.
 struct __attribute__((aligned(64))) NodeRec {
-    int32_t parent;     // -1 for the root
-    int32_t c0, c1;     // first two children in file order (-1 if absent)
+    // 16-byte chunks grouped by reader, so that each pass of the sweep touches as few as possible:
+    // top-down reads chunks 0-1, bottom-up chunks 0, 2 and the first word of 3
+    double e0, e1;        // the first two children's edge lengths
+    double e;             // edge length
+    int32_t c0, c1;       // first two children in file order (-1 if absent)
     int32_t nchild;
-    int32_t lpos;       // position in the level-ordered bit space (sweep.hip NodeBits)
-    int32_t ppos;       // the parent's lpos (-1 for the root)
-    int32_t c0pos, c1pos; // the children's lpos
-    double e;           // edge length
-    double e0, e1;      // the children's edge lengths
-    uint32_t kleaf;     // bit 0: c0 is a leaf, bit 1: c1 is a leaf
+    uint32_t kleaf;       // bit 0: c0 is a leaf, bit 1: c1 is a leaf
+    int32_t c0pos, c1pos; // the children's positions in the level-ordered bit space (sweep.hip NodeBits)
+    int32_t ppos;         // the parent's position (-1 for the root)
+    int32_t parent;       // -1 for the root
+    int32_t lpos;         // own position
     int32_t pad;
 };
 
