@@ -648,6 +648,61 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
 // smallest minima: pick those, rank their <= 64 * b entries, write the survivors in slot order.
 // The row itself (n_members values) is never streamed.
 #define TOPUP_MAX_B 256
+#define TOPUP_KEYS 16  // keys a thread can hold in registers for the fast selection
+
+// wavefront-wide lexicographic arg-min over (d, i) with payload j; result in every lane (shuffles only)
+__device__ __forceinline__ void wave_argmin3(double &d, int &i, int &j) {
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+        const double d2 = shfl_down_f64(d, o);
+        const int i2 = __shfl_down(i, o, WAVE);
+        const int j2 = __shfl_down(j, o, WAVE);
+        if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; j = j2; }
+    }
+    d = __hiloint2double(__shfl(__double2hiint(d), 0, WAVE), __shfl(__double2loint(d), 0, WAVE));
+    i = __shfl(i, 0, WAVE);
+    j = __shfl(j, 0, WAVE);
+}
+
+// The B smallest (d, i) keys of a workgroup, each thread holding up to TOPUP_KEYS keys in registers
+// (i == INT_MAX marks an empty slot).  Every wavefront first extracts its own B smallest with
+// shuffle-only rounds (no workgroup barrier per round), then the at most 4 B candidates are ranked by
+// counting.  Results in key order: out_d/out_i/out_j[0..n), n returned.  All in LDS.
+__device__ int block_smallest(const double (&kd)[TOPUP_KEYS], const int (&ki)[TOPUP_KEYS], const int (&kj)[TOPUP_KEYS],
+                              int B, double *cand_d, int *cand_i, int *cand_j, int *cand_n, double *out_d, int *out_i,
+                              int *out_j) {
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    double last_d = -INF_D;
+    int last_i = -1, mine = 0;
+    for (int k = 0; k < B; ++k) {
+        double bd = INF_D;
+        int bi = 0x7fffffff, bj = 0;
+#pragma unroll
+        for (int t = 0; t < TOPUP_KEYS; ++t)
+            if (ki[t] != 0x7fffffff && key_lt(last_d, last_i, kd[t], ki[t]) && key_lt(kd[t], ki[t], bd, bi)) { bd = kd[t]; bi = ki[t]; bj = kj[t]; }
+        wave_argmin3(bd, bi, bj);
+        if (bi == 0x7fffffff) break;
+        if (lane == 0) { cand_d[wv * TOPUP_MAX_B + k] = bd; cand_i[wv * TOPUP_MAX_B + k] = bi; cand_j[wv * TOPUP_MAX_B + k] = bj; }
+        last_d = bd; last_i = bi;
+        ++mine;
+    }
+    if (lane == 0) cand_n[wv] = mine;
+    __syncthreads();
+    int total = 0, n[APPLES_TPB / WAVE];
+    for (int w = 0; w < APPLES_TPB / WAVE; ++w) { n[w] = cand_n[w]; total += n[w]; }
+    for (int c = threadIdx.x; c < total; c += APPLES_TPB) {  // candidate c = the k-th of wavefront w
+        int w = 0, k = c;
+        while (k >= n[w]) { k -= n[w]; ++w; }
+        const double d = cand_d[w * TOPUP_MAX_B + k];
+        const int i = cand_i[w * TOPUP_MAX_B + k];
+        int rank = 0;
+        for (int w2 = 0; w2 < APPLES_TPB / WAVE; ++w2)
+            for (int k2 = 0; k2 < n[w2]; ++k2) rank += key_lt(cand_d[w2 * TOPUP_MAX_B + k2], cand_i[w2 * TOPUP_MAX_B + k2], d, i);
+        if (rank < B) { out_d[rank] = d; out_i[rank] = i; out_j[rank] = cand_j[w * TOPUP_MAX_B + k]; }
+    }
+    __syncthreads();
+    return total < B ? total : B;
+}
+
 __global__ __launch_bounds__(APPLES_TPB) void k_select_topup(SelectArgs a) {
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
@@ -655,6 +710,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_topup(SelectArgs a) {
     __shared__ int sh_cand[TOPUP_MAX_B];
     __shared__ int sh_sorted[TOPUP_MAX_B];
     __shared__ int sh_znode;
+    __shared__ double cand_d[(APPLES_TPB / WAVE) * TOPUP_MAX_B], out_d[TOPUP_MAX_B];
+    __shared__ int cand_i[(APPLES_TPB / WAVE) * TOPUP_MAX_B], cand_j[(APPLES_TPB / WAVE) * TOPUP_MAX_B], cand_n[APPLES_TPB / WAVE];
+    __shared__ int out_i[TOPUP_MAX_B];
     const int64_t n_list = *a.qcount;
     const int tid = threadIdx.x;
     const int64_t nm = a.n_members;
@@ -670,42 +728,76 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_topup(SelectArgs a) {
         double *o_dist = a.obs_dist + q * a.obs_cap;
         int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
         // ---- the B segments with the smallest minima, in key order
-        double last_d = -INF_D;
-        int last_i = -1;
         int n_cand = 0;
-        for (int k = 0; k < B; ++k) {
-            double bd = INF_D;
-            int bi = 0x7fffffff, bs = 0;
-            for (int sgm = tid; sgm < n_seg; sgm += APPLES_TPB) {
-                const double d = smd[sgm];
-                const int i = smi[sgm];
-                if (i != 0x7fffffff && key_lt(last_d, last_i, d, i) && key_lt(d, i, bd, bi)) { bd = d; bi = i; bs = sgm; }
+        if (n_seg <= TOPUP_KEYS * APPLES_TPB) {  // keys fit in registers: wavefront-local rounds + one ranking
+            double kd[TOPUP_KEYS];
+            int ki[TOPUP_KEYS], kj[TOPUP_KEYS];
+#pragma unroll
+            for (int t = 0; t < TOPUP_KEYS; ++t) {
+                const int sgm = tid + t * APPLES_TPB;
+                const bool ok = sgm < n_seg;
+                kd[t] = ok ? smd[sgm] : INF_D;
+                ki[t] = ok ? smi[sgm] : 0x7fffffff;
+                kj[t] = sgm;
             }
-            block_argmin3(bd, bi, bs, sh_d, sh_i, sh_j);
-            if (bi == 0x7fffffff) break;
-            if (tid == 0) sh_cand[k] = bs;
-            last_d = bd; last_i = bi;
-            ++n_cand;
+            n_cand = block_smallest(kd, ki, kj, B, cand_d, cand_i, cand_j, cand_n, out_d, out_i, sh_cand);
+        } else {
+            double last_d = -INF_D;
+            int last_i = -1;
+            for (int k = 0; k < B; ++k) {
+                double bd = INF_D;
+                int bi = 0x7fffffff, bs = 0;
+                for (int sgm = tid; sgm < n_seg; sgm += APPLES_TPB) {
+                    const double d = smd[sgm];
+                    const int i = smi[sgm];
+                    if (i != 0x7fffffff && key_lt(last_d, last_i, d, i) && key_lt(d, i, bd, bi)) { bd = d; bi = i; bs = sgm; }
+                }
+                block_argmin3(bd, bi, bs, sh_d, sh_i, sh_j);
+                if (bi == 0x7fffffff) break;
+                if (tid == 0) sh_cand[k] = bs;
+                last_d = bd; last_i = bi;
+                ++n_cand;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // ---- the B smallest keys among the candidates' entries -> the cut (Reference.py:144-152)
         const int n_ent = n_cand * 64;
         double cut_d = -INF_D;
         int cut_i = -1;
-        for (int k = 0; k < B; ++k) {
-            double bd = INF_D;
-            int bi = 0x7fffffff, bj = 0;
-            for (int e = tid; e < n_ent; e += APPLES_TPB) {
-                const int64_t s = (int64_t)sh_cand[e >> 6] * 64 + (e & 63);
-                if (s >= nm) continue;
-                const double d = row[s];
-                if (!(d >= 0)) continue;
-                const int i = a.slot_rep[s];
-                if (key_lt(cut_d, cut_i, d, i) && key_lt(d, i, bd, bi)) { bd = d; bi = i; }
+        if (n_ent <= TOPUP_KEYS * APPLES_TPB) {
+            double kd[TOPUP_KEYS];
+            int ki[TOPUP_KEYS], kj[TOPUP_KEYS];
+#pragma unroll
+            for (int t = 0; t < TOPUP_KEYS; ++t) {
+                const int e = tid + t * APPLES_TPB;
+                kd[t] = INF_D; ki[t] = 0x7fffffff; kj[t] = 0;
+                if (e < n_ent) {
+                    const int64_t s = (int64_t)sh_cand[e >> 6] * 64 + (e & 63);
+                    if (s < nm) {
+                        const double d = row[s];
+                        if (d >= 0) { kd[t] = d; ki[t] = a.slot_rep[s]; }
+                    }
+                }
             }
-            block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
-            if (bi == 0x7fffffff) break;
-            cut_d = bd; cut_i = bi;
+            const int n_top = block_smallest(kd, ki, kj, B, cand_d, cand_i, cand_j, cand_n, out_d, out_i, sh_sorted);
+            if (n_top > 0) { cut_d = out_d[n_top - 1]; cut_i = out_i[n_top - 1]; }
+            __syncthreads();
+        } else {
+            for (int k = 0; k < B; ++k) {
+                double bd = INF_D;
+                int bi = 0x7fffffff, bj = 0;
+                for (int e = tid; e < n_ent; e += APPLES_TPB) {
+                    const int64_t s = (int64_t)sh_cand[e >> 6] * 64 + (e & 63);
+                    if (s >= nm) continue;
+                    const double d = row[s];
+                    if (!(d >= 0)) continue;
+                    const int i = a.slot_rep[s];
+                    if (key_lt(cut_d, cut_i, d, i) && key_lt(d, i, bd, bi)) { bd = d; bi = i; }
+                }
+                block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
+                if (bi == 0x7fffffff) break;
+                cut_d = bd; cut_i = bi;
+            }
         }
         // ---- candidates in slot order
         if (tid < n_cand) {
