@@ -499,7 +499,7 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
     if (use_asm) LAUNCH2(TQ, true); else LAUNCH2(TQ, false)
 #define LAUNCH2(TQ, A)                                                                                               \
     hipLaunchKernelGGL((k_jc69<P, TQ, MODE, A>), dim3((unsigned)(a.slots_pad / APPLES_TPB),                          \
-                       (unsigned)(MODE == 2 ? std::min<int64_t>((nq + TQ - 1) / TQ, 8) : (nq + TQ - 1) / TQ)),         \
+                       (unsigned)(MODE == 2 ? std::min<int64_t>((nq + TQ - 1) / TQ, 64) : (nq + TQ - 1) / TQ)),         \
                        block, 0, ctx->stream, a.packed, qp, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,   \
                        ctx->params.overlap_frac, lut, ctx->params.filt_threshold, seg_slot, seg_cnt, qlist, qcount, mmax,    \
                        a.slot_rep, segmin_d, segmin_i)
@@ -574,8 +574,8 @@ int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64
 int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
                          const int32_t *qcount, double *d_dist, double *segmin_d, int32_t *segmin_i) {
     if (nq_max == 0) return 0;
-    if (ctx->aln.planes == 2) launch_jc69_tile<2, 2>(ctx, qb, q0, nq_max, 32, d_dist, nullptr, nullptr, nullptr, qlist, qcount, segmin_d, segmin_i);
-    else launch_jc69_tile<8, 2>(ctx, qb, q0, nq_max, 32, d_dist, nullptr, nullptr, nullptr, qlist, qcount, segmin_d, segmin_i);
+    if (ctx->aln.planes == 2) launch_jc69_tile<2, 2>(ctx, qb, q0, nq_max, 8, d_dist, nullptr, nullptr, nullptr, qlist, qcount, segmin_d, segmin_i);
+    else launch_jc69_tile<8, 2>(ctx, qb, q0, nq_max, 8, d_dist, nullptr, nullptr, nullptr, qlist, qcount, segmin_d, segmin_i);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
