@@ -24,9 +24,14 @@ def _binarize(tree):
     """children lists of a binary-resolved copy; new nodes get ids >= n_nodes and edge length 0.
     Resolution order as treeswift's resolve_polytomies: repeatedly replace the last two children
     by a new zero-length parent of them."""
+    import numpy as np
     n = tree.n_nodes
-    children = [list(tree.children(v)) for v in range(n)]
-    elen = [float(tree.edge_len[v]) if tree.has_len[v] else 0.0 for v in range(n)]
+    off = tree.child_off.tolist()
+    idx = tree.child_idx.tolist()
+    children = [idx[off[v]:off[v + 1]] for v in range(n)]
+    elen = np.where(tree.has_len, tree.edge_len, 0.0).tolist()
+    if n == 0 or int(np.max(np.diff(tree.child_off))) <= 2:
+        return children, elen  # already binary
     q = deque([tree.root])
     while q:
         v = q.popleft()
@@ -42,7 +47,9 @@ def _binarize(tree):
     return children, elen
 
 
-def _postorder(children, root):
+def _postorder(children, root, n_original):
+    if len(children) == n_original:  # no node was added: ids are post-order numbers already (apples/util.py:65-69)
+        return range(n_original)
     order = []
     stack = [(root, 0)]
     while stack:
@@ -78,7 +85,7 @@ def max_clusters(tree, threshold):
             st.extend(reversed(children[u]))
         return out
 
-    for v in _postorder(children, tree.root):
+    for v in _postorder(children, tree.root, tree.n_nodes):
         if deleted[v]:
             continue
         ch = children[v]
