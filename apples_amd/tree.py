@@ -169,25 +169,24 @@ def _len_str(x):
 
 def extended_newick(tree):
     """Newick with ``{edge_index}`` after every non-root node (apples/jutil.py:22-96)."""
-    strs = [None] * tree.n_nodes
-    for v in range(tree.n_nodes):  # ascending id is a post-order
-        ch = tree.children(v)
-        if len(ch) == 0:
-            strs[v] = '' if tree.labels[v] is None else str(tree.labels[v])
+    n = tree.n_nodes
+    off = tree.child_off.tolist()
+    idx = tree.child_idx.tolist()
+    labels = tree.labels
+    # what follows a node's own text inside its parent's parentheses: ':length' (if any) and '{edge_index}'
+    suffix = [(':%s{%d}' % (_len_str(x), c)) if h else '{%d}' % c
+              for c, (x, h) in enumerate(zip(tree.edge_len.tolist(), tree.has_len.tolist()))]
+    strs = [None] * n
+    for v in range(n):  # ascending id is a post-order
+        lab = labels[v]
+        a, b = off[v], off[v + 1]
+        if a == b:
+            strs[v] = '' if lab is None else str(lab)
         else:
-            out = ['(']
-            for c in ch:
-                out.append(strs[c])
-                if tree.has_len[c]:
-                    out.append(':%s' % _len_str(tree.edge_len[c]))
-                out.append('{%d}' % c)
-                out.append(',')
+            inner = ','.join([strs[c] + suffix[c] for c in idx[a:b]])
+            for c in idx[a:b]:
                 strs[c] = None
-            out.pop()
-            out.append(')')
-            if tree.labels[v] is not None:
-                out.append(str(tree.labels[v]))
-            strs[v] = ''.join(out)
+            strs[v] = '(' + inner + ')' if lab is None else '(' + inner + ')' + str(lab)
     s = strs[tree.root]
     if tree.is_rooted:
         return '[&R] %s;' % s
