@@ -77,9 +77,11 @@ def options_config(argv=None):
         if options.ref_fp:
             raise ValueError('Input should be either an alignment or a distance matrix, but not both!')
     if options.database_fp:
-        raise ValueError('APPLES database files (-a) are Python pickles of the reference implementation and are not '
-                         'supported by this build; pass -t and -s instead.')
-    if not options.tree_fp:
+        # apples/OptionsRun.py: a database replaces the tree and the reference alignment
+        if options.tree_fp or options.ref_fp or options.dist_fp:
+            raise ValueError('An APPLES database (-a) already holds the tree and the reference alignment; '
+                             'do not pass -t, -s or -d with it.')
+    elif not options.tree_fp:
         raise ValueError('No input backbone tree provided by user.')
     if options.query_fp and options.extended_ref_fp:
         raise ValueError('Input should be either an extended alignment or a query alignment, but not both!')

@@ -69,9 +69,19 @@ def main(argv=None):
         logging.warning('Backbone branch lengths are used as given: FastTree re-estimation is not part of this '
                         'build (equivalent to -D).')
     start = time.time()
-    tree = read_tree(options.tree_fp)
-    newick = extended_newick(tree)
-    logging.info('[%s] Tree is parsed and preprocessed in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))
+    reference = None
+    if options.database_fp:  # run_apples.py:25-35,69-75: tree, extended Newick and reduced reference from the cache
+        from apples_amd import database
+        tree, newick, reference, db_protein, _ = database.load(options.database_fp)
+        if db_protein != bool(options.protein_seqs):
+            raise ValueError('the database was built %s -p, the run was started %s it'
+                             % (('with', 'without') if db_protein else ('without', 'with')))
+        logging.info('[%s] Tree and reduced reference are loaded from the APPLES database in %.3f seconds.'
+                     % (time.strftime('%H:%M:%S'), time.time() - start))
+    else:
+        tree = read_tree(options.tree_fp)
+        newick = extended_newick(tree)
+        logging.info('[%s] Tree is parsed and preprocessed in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))
 
     ngpu = options.num_gpus
     if ngpu <= 0:
@@ -97,8 +107,10 @@ def main(argv=None):
         out_names, rows = worker.run_distances(names, cols, D, rows=True)
     else:
         start = time.time()
-        ref = read_alignment(options.ref_fp, options.protein_seqs, False)  # reference rows are never masked
-        if options.clusters_fp:
+        ref = reference.aln if reference is not None else read_alignment(options.ref_fp, options.protein_seqs, False)  # reference rows are never masked
+        if reference is not None:
+            clusters = None
+        elif options.clusters_fp:
             clusters = read_treecluster(options.clusters_fp)
         elif options.no_clusters:
             clusters = None
@@ -109,7 +121,8 @@ def main(argv=None):
             missing = [n for _, g in clusters for n in g if n not in in_aln]
             if missing:
                 raise KeyError('backbone leaf %s has no sequence in the reference alignment' % missing[0])
-        reference = ReducedReference(ref, options.protein_seqs, clusters)
+        if reference is None:
+            reference = ReducedReference(ref, options.protein_seqs, clusters)
         logging.info('[%s] Reduced reference is prepared in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))
         if options.query_fp:
             q = read_alignment(options.query_fp, options.protein_seqs, options.mask_lowconfidence)

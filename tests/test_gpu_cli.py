@@ -60,3 +60,22 @@ def test_cli_stdout_and_extended_reference(tmp_path):
     assert [p['n'] for p in got['placements']] == [p['n'] for p in want['placements']]
     for g, w in zip(got['placements'], want['placements']):
         assert_prow(g['p'][0], w['p'][0])
+
+
+def test_cli_database_cache_matches_reference_jplace(tmp_path):
+    """build_applesdtb.py + run_apples.py -a (the reference's database route, build_applesdtb.py:23-28,
+    run_apples.py:25-35,69-75) against the reference's own jplace for the same inputs."""
+    db = tmp_path / 'ref.dtb'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'build_applesdtb.py'), '-s', os.path.join(DATA, 'ref.fa'), '-t',
+                        os.path.join(DATA, 'backbone.nwk'), '-o', str(db), '-D'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / 'out.jplace'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_apples.py'), '-a', str(db), '-q', os.path.join(DATA, 'query.fa'),
+                        '-m', 'OLS', '-o', str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = json.load(open(out))
+    want = json.load(open(os.path.join(GOLD, 'g7_cli_aln_OLS.jplace')))
+    assert got['tree'] == want['tree']
+    assert [p['n'] for p in got['placements']] == [p['n'] for p in want['placements']]
+    for g, w in zip(got['placements'], want['placements']):
+        assert_prow(g['p'][0], w['p'][0], ctx='database %s' % w['n'][0])

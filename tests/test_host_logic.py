@@ -288,3 +288,34 @@ def test_binary_distance_table_equals_text_reader(tmp_path):
     gn, gc, gD = run_apples.read_dismat_binary(str(npz))
     assert gn == wn and gc == wc
     assert np.array_equal(gD, wD)
+
+
+def test_database_cache_round_trip(tmp_path):
+    """The .npz database holds exactly what a run would have built from the tree and the alignment:
+    tree arrays, extended Newick, alignment rows, clusters and consensus rows."""
+    import build_applesdtb
+    from apples_amd import database, treecluster
+    from apples_amd.fasta import read_alignment
+    from apples_amd.reference import ReducedReference
+    from apples_amd.tree import extended_newick, read_tree
+    db = str(tmp_path / 'c1.dtb')
+    build_applesdtb.main(['-s', os.path.join(DATA, 'ref.fa'), '-t', os.path.join(DATA, 'backbone.nwk'), '-o', db, '-f', '0.2'])
+    tree, newick, ref, protein, thr = database.load(db)
+    t0 = read_tree(os.path.join(DATA, 'backbone.nwk'))
+    a0 = read_alignment(os.path.join(DATA, 'ref.fa'), False, False)
+    r0 = ReducedReference(a0, False, treecluster.grouped(t0, 0.2 * 1.2))
+    assert protein is False and thr == 0.2 and newick == extended_newick(t0)
+    for f in ('parent', 'edge_len', 'has_len', 'child_off', 'child_idx', 'level'):
+        assert np.array_equal(getattr(tree, f), getattr(t0, f)), f
+    assert tree.labels == t0.labels and tree.is_rooted == t0.is_rooted and tree.name_to_node == t0.name_to_node
+    assert ref.aln.names == a0.names and np.array_equal(ref.aln.seqs, a0.seqs)
+    for got, want in zip(ref.cluster_arrays(), r0.cluster_arrays()):
+        assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        database.load(_not_a_database(tmp_path))
+
+
+def _not_a_database(tmp_path):
+    p = str(tmp_path / 'other.npz')
+    np.savez(p, x=np.arange(3))
+    return p
