@@ -383,10 +383,9 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     // small teams: one wavefront per query, up to 8 workgroups (32 waves) per CU on 256 CUs;
     // map is n_nodes ints per team (<= ~8 GiB in total), order/S/R share ~16 GiB
     int64_t nn = t.n_nodes;
-    // (with the dynamic queue the rate is flat from 2 048 to 8 192 teams: the kernel is bound by HBM
-    // random-access traffic, not by latency; 4 096 keeps the scratch footprint moderate)
     // big trees keep a node map of n_nodes ints per team (<= ~8 GiB in total)
-    int64_t teams = sweep_bits_in_lds(t) ? 4096 : std::min<int64_t>(4096, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
+    // (2 048 teams are resident at two wavefronts per SIMD; 3 072 measured best at both 10 k and 200 k leaves)
+    int64_t teams = sweep_bits_in_lds(t) ? 3072 : std::min<int64_t>(3072, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
