@@ -250,6 +250,8 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
     for (auto &qb : ctx->blocks) {
         if (!qb.live || qb.planes == 8) continue;
         dev_free(qb.packed);
+        dev_free(qb.qi8);  // the int8 image only serves the ACGT- fast path
+        qb.qi8 = nullptr;
         int64_t w = qb.n_pad * a.G * 9;
         if (dev_alloc(ctx, &qb.packed, w)) return 1;
         HIP_TRY(ctx, hipMemsetAsync(qb.packed, 0, (size_t)w * sizeof(uint4), ctx->stream));
