@@ -608,6 +608,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
         if (fused) {
             HIP_TRY(ctx, hipMemsetAsync(w.slow_count, 0, sizeof(int32_t), front));
             HIP_TRY(ctx, hipEventRecord(e[0], front));
+            if (fused_counts_format(ctx, qb))  // the matrix-core kernel writes only the non-empty segments' counts
+                HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (w.stride / 64) * sizeof(int32_t), front));
             if (launch_counts_fused(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, w.seg_slot, w.seg_cnt)) return 1;
             HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;

@@ -473,6 +473,7 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
             // (rows past this launch's queries may be real queries of the next sub-batch: not ours to write)
             const bool k0 = ((keepbits >> (x * 2)) & 1u) && q < nq, k1 = ((keepbits >> (x * 2 + 1)) & 1u) && q < nq;
             const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
+            if ((b0 | b1) == 0) continue;  // nobody in either half's segment survives: the counts stay at their preset zero
             // this lane half's query: slots 0..31 of the segment from tile 0, 32..63 from tile 1
             const uint32_t lo = (uint32_t)(b0 >> (32 * fh)), hi = (uint32_t)(b1 >> (32 * fh));
             int32_t *row = seg_slot + q * slots_pad + seg * 64;
