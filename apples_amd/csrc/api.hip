@@ -569,9 +569,9 @@ int dist_tile_for(int64_t nq) {
 }
 
 // One pass of the hot path over a resident query block.  The block is cut into sub-batches that
-// flow through two streams: front = distance + selection, back = sweep; with two sets of batch
-// buffers the distance kernel of sub-batch i+1 (VALU-bound) overlaps the sweep of sub-batch i
-// (memory-latency-bound).
+// run distance -> selection -> sweep back to back on one stream (default).  With APPLES_PIPELINE > 1
+// they flow through two streams instead (front = distance + selection, back = sweep, two sets of
+// batch buffers); measured slower on MI355X, kept as an experiment knob.
 int run_block(apples_ctx *ctx, QueryBlock &qb) {
     const DevAlign &a = ctx->aln;
     bool hybrid = ctx->params.criterion == APPLES_HYBRID;
@@ -702,7 +702,7 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         return fail();
     }
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return fail(); }
-    // stream2 is spare (the routed big-team sweep now shares one launch with the small teams)
+    // stream2 is spare; stream3 is the back stream of the APPLES_PIPELINE experiment
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
         hipStreamCreate(&ctx->stream3) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_front[0], hipEventDisableTiming) != hipSuccess ||

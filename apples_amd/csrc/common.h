@@ -138,7 +138,7 @@ struct Workspace {
 struct apples_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // big-team sweep of the routed queries, concurrent with the small teams
+    hipStream_t stream2 = nullptr;   // spare
     hipEvent_t ev_sel = nullptr, ev_big = nullptr;
     hipStream_t stream3 = nullptr;   // back stream: sweeps of batch i while the front stream works on batch i+1
     hipEvent_t ev_front[2] = {}, ev_back[2] = {}, ev_bigfree = nullptr;
