@@ -1,6 +1,6 @@
 """Distance kernel at query tile T (roofline point T=1): packed reference streamed once per T queries."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from apples_amd import synth
 from apples_amd.engine import Engine
