@@ -551,8 +551,11 @@ static int launch_mfma(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
 int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
                   uint32_t *d_counts) {
     if (nq == 0) return 0;
-    // (small explicit tiles are the streaming roofline runs of the bit-plane kernel: leave them alone)
-    if (qb.qi8 && ctx->aln.planes == 2 && tile >= 16) return launch_mfma<0>(ctx, qb, q0, nq, d_dist, d_counts, nullptr, nullptr);
+    // Full rows stay with the bit-plane kernel: with 8 bytes out per pair and a table lookup per pair the
+    // matrix-core form is slower here (0.64 against 0.58 ms at C2 size).  APPLES_DIST_MFMA_ROWS=1 routes
+    // tiles of 16 and more queries to it anyway (tests compare its counts with the bytewise definition).
+    if (qb.qi8 && ctx->aln.planes == 2 && tile >= 16 && getenv("APPLES_DIST_MFMA_ROWS"))
+        return launch_mfma<0>(ctx, qb, q0, nq, d_dist, d_counts, nullptr, nullptr);
     if (ctx->aln.planes == 2) launch_jc69_tile<2, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     else launch_jc69_tile<8, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     HIP_TRY(ctx, hipGetLastError());

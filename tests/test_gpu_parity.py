@@ -406,7 +406,7 @@ def test_both_sweep_layouts_agree_on_polytomies(monkeypatch):
 
 
 @pytest.mark.parametrize('L,n_ref,n_q', [(77, 130, 16), (1000, 300, 100), (1620, 257, 300), (33, 64, 517)])
-def test_matrix_core_pair_counts_equal_the_bytewise_definition(L, n_ref, n_q):
+def test_matrix_core_pair_counts_equal_the_bytewise_definition(L, n_ref, n_q, monkeypatch):
     """The tiled distance pass counts (mismatches, shared valid sites) with int8 MFMAs from
     tetrahedral codes; apples/distance.py:733-737 defines the same two integers on bytes.  Ragged
     sizes (L not a multiple of 32, rows and queries not multiples of the 128 x 256 tile), heavy
@@ -420,6 +420,7 @@ def test_matrix_core_pair_counts_equal_the_bytewise_definition(L, n_ref, n_q):
     qry[1] = ord('-')
     qry[2] = ref[5]
     tree = read_tree(os.path.join(DATA, 'small_backbone.nwk'))
+    monkeypatch.setenv('APPLES_DIST_MFMA_ROWS', '1')  # full rows normally come from the bit-plane kernel
     e = Engine(tree, ref, np.full(n_ref, -1, np.int32), method='OLS')
     assert e.describe()['code_planes'] == 2
     counts, dist = e.distances(qry)  # >= 16 queries: matrix-core kernel
