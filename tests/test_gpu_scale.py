@@ -195,3 +195,24 @@ def test_resident_distance_table_matches_host_entry_point():
         assert b[6]['flags'] & F_INSUFFICIENT and b[7]['flags'] & F_EXACT
         eng.free_queries(h)
         eng.close()
+
+
+def test_big_backbone_sample_against_c_oracle():
+    """A 100 k-leaf backbone exercises what the 10 k-leaf tests cannot: the tagged node map of the
+    sweep (the bit space no longer fits LDS), the top-up selection by segment minima (rows of 40 k
+    and more), multi-megabyte observation lists.  Thousands of queries go through the device in one
+    pass; a sample of them, including the ones with the fewest and the most observed leaves, is
+    checked byte for byte against the C oracle."""
+    d = synth.make_dataset(100000, 500, 2048)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    info = eng.describe()
+    assert info['n_nodes'] == 199999
+    got = eng.place_sequences(d.query_seqs)
+    eng.close()
+    order = np.argsort(got['n_obs'], kind='stable')
+    sample = np.unique(np.concatenate([order[:6], order[-6:], np.arange(0, 2048, 171)]))
+    co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', lut=jc69_lut(500, 0.001), threads=len(os.sched_getaffinity(0)))
+    want = co.place_sequences(d.query_seqs[sample])
+    assert got[sample].tobytes() == want.tobytes()
+    assert (got['n_obs'] >= 25).all() or (got['flags'] & (F_EXACT | F_INSUFFICIENT)).any()
