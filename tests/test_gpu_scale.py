@@ -216,3 +216,23 @@ def test_big_backbone_sample_against_c_oracle():
     want = co.place_sequences(d.query_seqs[sample])
     assert got[sample].tobytes() == want.tobytes()
     assert (got['n_obs'] >= 25).all() or (got['flags'] & (F_EXACT | F_INSUFFICIENT)).any()
+
+
+def test_big_protein_backbone_sample_against_c_oracle():
+    """The same at the amino-acid benchmark shape (50 k leaves, scoredist + FM): edges and counts
+    identical, lengths within 1e-9 relative (the table sums are fp64 on both sides; only their order
+    of summation is not pinned by the reference)."""
+    d = synth.make_dataset(50000, 300, 1024, protein=True)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, protein=True, method='FM')
+    got = eng.place_sequences(d.query_seqs)
+    eng.close()
+    order = np.argsort(got['n_obs'], kind='stable')
+    sample = np.unique(np.concatenate([order[:4], order[-4:], np.arange(0, 1024, 128)]))
+    co = COracle(d.tree, d.ref_seqs, nodes, protein=True, method='FM', threads=len(os.sched_getaffinity(0)))
+    want = co.place_sequences(d.query_seqs[sample])
+    g = got[sample]
+    for f in ('edge', 'flags', 'n_obs', 'n_valid'):
+        assert np.array_equal(g[f], want[f]), f
+    for f in ('error', 'distal', 'pendant'):
+        np.testing.assert_allclose(g[f], want[f], rtol=1e-9, atol=1e-15, err_msg=f)
