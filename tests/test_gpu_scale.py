@@ -236,3 +236,23 @@ def test_big_protein_backbone_sample_against_c_oracle():
         assert np.array_equal(g[f], want[f]), f
     for f in ('error', 'distal', 'pendant'):
         np.testing.assert_allclose(g[f], want[f], rtol=1e-9, atol=1e-15, err_msg=f)
+
+
+def test_big_distance_table_against_c_oracle():
+    """-d input at benchmark shape: a 100 k-column table (noisy path distances), BME, every row
+    checked byte for byte against the C oracle; rows with missing values, one exact hit."""
+    d = synth.make_dataset(100000, 8, 96)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ix = synth.TreeIndex(d.tree)
+    D = synth.fast_distance_rows(d.tree, ix, d.query_leaf, d.query_pendant, list(range(96)))
+    D[5, ::3] = -1.0
+    D[7, 4711] = 0.0
+    eng = Engine(d.tree, None, method='BME')
+    h, n = eng.upload_table(D, nodes)
+    eng.place_resident(h)
+    got = eng.fetch(h, n)
+    eng.free_queries(h)
+    eng.close()
+    want = COracle(d.tree, method='BME', threads=len(os.sched_getaffinity(0))).place_distances(D, nodes)
+    assert got.tobytes() == want.tobytes()
+    assert got[7]['flags'] & F_EXACT
