@@ -256,3 +256,25 @@ def test_big_distance_table_against_c_oracle():
     want = COracle(d.tree, method='BME', threads=len(os.sched_getaffinity(0))).place_distances(D, nodes)
     assert got.tobytes() == want.tobytes()
     assert got[7]['flags'] & F_EXACT
+
+
+@pytest.mark.parametrize('method,criterion', [('OLS', 'MLSE'), ('FM', 'HYBRID')])
+def test_clustered_reference_at_c2_size_against_c_oracle(c2, method, criterion):
+    """The command line's default route: max-diameter clusters at 1.2 x -f, consensus representatives,
+    heap-ordered cluster expansion (apples/Reference.py:117-157) -- full distance rows and the general
+    selection kernel -- at the 10 k-leaf benchmark size, byte for byte against the C oracle."""
+    from apples_amd import treecluster
+    from apples_amd.fasta import Alignment
+    from apples_amd.reference import ReducedReference
+    d, nodes = c2
+    ref = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, 0.2 * 1.2))
+    ca = ref.cluster_arrays()
+    assert len(ca[0]) > 100  # multi-member clusters with consensus rows
+    nq = 512
+    co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method=method, criterion=criterion, lut=jc69_lut(1000, 0.001),
+                 threads=len(os.sched_getaffinity(0)))
+    want = co.place_sequences(d.query_seqs[:nq])
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method=method, criterion=criterion)
+    got = eng.place_sequences(d.query_seqs[:nq])
+    eng.close()
+    _compare(got, want, co, d, nodes, 'clustered %s/%s' % (method, criterion))
