@@ -588,11 +588,15 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
     const int64_t step = pipelined ? std::min<int64_t>(w.batch, want) : w.batch;
     const int64_t n_sub = (qb.n + step - 1) / step;
     hipStream_t front = ctx->stream, back = pipelined ? ctx->stream3 : ctx->stream;
-    std::vector<hipEvent_t> ev((size_t)n_sub * 6);
-    for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
-    hipEvent_t e_start, e_stop;
-    HIP_TRY(ctx, hipEventCreate(&e_start));
-    HIP_TRY(ctx, hipEventCreate(&e_stop));
+    // timing events come from a pool that lives with the context (creating and destroying a dozen
+    // events per call costs host time inside every pass)
+    while (ctx->ev_pool.size() < (size_t)n_sub * 6 + 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    hipEvent_t *ev = ctx->ev_pool.data() + 2;
+    hipEvent_t e_start = ctx->ev_pool[0], e_stop = ctx->ev_pool[1];
     HIP_TRY(ctx, hipEventRecord(e_start, front));
     if (pipelined) HIP_TRY(ctx, hipStreamWaitEvent(back, e_start, 0));
     int launches = 0;
@@ -670,9 +674,6 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
     }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e_start, e_stop);
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(e_start);
-    (void)hipEventDestroy(e_stop);
     ctx->t_ms[APPLES_T_TOTAL] = ms;
     ctx->t_ms[APPLES_T_DIST_LAUNCHES] = launches;
     HIP_TRY(ctx, hipGetLastError());
@@ -782,6 +783,8 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     dev_free(ctx->d_col_level);
     for (int i = 0; i < 8; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (auto &e : ctx->ev_pool) (void)hipEventDestroy(e);
+    ctx->ev_pool.clear();
     for (int i = 0; i < 2; ++i) {
         if (ctx->ev_front[i]) (void)hipEventDestroy(ctx->ev_front[i]);
         if (ctx->ev_back[i]) (void)hipEventDestroy(ctx->ev_back[i]);

@@ -163,6 +163,7 @@ struct apples_ctx {
     std::vector<int32_t> h_col_perm;
     // timing
     hipEvent_t ev[8] = {};
+    std::vector<hipEvent_t> ev_pool;  // timing events of run_block, created once and reused
     double t_ms[APPLES_T_COUNT] = {};
 };
 
