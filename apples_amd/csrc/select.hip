@@ -135,20 +135,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     // column position for the stable sort at PoolQueryWorker.py:51
 #define SLOT_KEYIDX(s) (a.slot_rep[(s)])  // table input: slot_rep holds the column of the slot
 
-    // ---- pass A: observations inside the threshold (cluster input only; for singleton clusters the
-    // compaction pass below counts them itself and is simply repeated if the top-up rule applies) ----
+    // The compaction pass below also counts the observations inside the threshold (obs_num of
+    // Reference.py:144-152: valid member distances of the clusters whose representative is within the
+    // threshold); if they fall short of `-b` the top-up rule fixes the cut and the pass is repeated.
     int obs = 0;
     bool have_obs = false, topped = false;
-    if (!single) {
-        int cnt = 0;
-        for (int64_t j = tid; j < a.n_reps; j += APPLES_TPB) {
-            double d = DIST(a.rep_slot[j]);
-            if (d >= 0 && d <= thr)
-                for (int m = a.rep_moff[j]; m < a.rep_moff[j + 1]; ++m) cnt += !(DIST(a.mem_slot[m]) < 0);
-        }
-        obs = block_sum(cnt, sh_i);
-        have_obs = true;
-    }
     double cut_d = -INF_D;
     int cut_i = -1;
     int base = 0, n_total = 0;
@@ -224,7 +215,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     n_total = 0;    // len(obs_dist) after the self entry is removed
     // first zero distance in dict order: min over (d_rep, rep index, member position)
     z_d = INF_D; z_i = 0x7fffffff; z_p = 0x7fffffff; z_node = -2;
-    int thr_cnt = 0;  // singleton input: entries with 0 <= d <= thr (the obs_num the top-up rule looks at)
+    int thr_cnt = 0;  // observations inside the threshold (the obs_num the top-up rule looks at)
     constexpr int E = 4;
     for (int64_t s0 = 0; s0 <= nm; s0 += (int64_t)APPLES_TPB * E) {
         const int64_t sb = s0 + (int64_t)tid * E;
@@ -249,7 +240,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
                 } else {
                     ri = a.slot_rep[s]; mp = a.slot_mpos[s];
                     drep = DIST(a.rep_slot[ri]);
-                    in_dict = (drep >= 0) && (drep <= thr || key_le(drep, ri, cut_d, cut_i)) && !(dm[e] < 0);
+                    const bool member_ok = !(dm[e] < 0);
+                    thr_cnt += (drep >= 0) && (drep <= thr) && member_ok;
+                    in_dict = (drep >= 0) && (drep <= thr || key_le(drep, ri, cut_d, cut_i)) && member_ok;
                 }
                 if (in_dict && (int)s != self) {
                     n_total++;
@@ -275,7 +268,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
         }
         base += tot;
     }
-    if (!have_obs) {  // singleton input, first round: was the threshold set large enough?
+    if (!have_obs) {  // first round: was the threshold set large enough?
         obs = block_sum(thr_cnt, sh_i);
         have_obs = true;
         if (obs < a.baseobs) continue;  // no: apply the top-up rule and compact again
