@@ -250,8 +250,8 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
     for (auto &qb : ctx->blocks) {
         if (!qb.live || qb.planes == 8) continue;
         dev_free(qb.packed);
-        dev_free(qb.qi8);  // the int8 image only serves the ACGT- fast path
-        qb.qi8 = nullptr;
+        dev_free(qb.qf4);  // the fp4 image only serves the ACGT- fast path
+        qb.qf4 = nullptr;
         int64_t w = qb.n_pad * a.G * 9;
         if (dev_alloc(ctx, &qb.packed, w)) return 1;
         HIP_TRY(ctx, hipMemsetAsync(qb.packed, 0, (size_t)w * sizeof(uint4), ctx->stream));
@@ -449,8 +449,8 @@ int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t
         dev_free(d_exotic);
         if (planes == 2 && dist_mfma_enabled()) {  // int8 operand image for the matrix-core distance kernel
             const int64_t n128 = round_up(qb->n_pad, 256) + 256;  // a sub-batch may start at any multiple of 32
-            if (dev_alloc(ctx, &qb->qi8, n128 * a.W * 128)) return 1;
-            if (launch_expand_queries_i8(ctx, qb->raw, n, qb->qi8, n128)) return 1;
+            if (dev_alloc(ctx, &qb->qf4, n128 * a.G * 256)) return 1;
+            if (launch_expand_queries_f4(ctx, qb->raw, n, qb->qf4, n128)) return 1;
         }
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -459,7 +459,7 @@ int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t
 }
 
 void free_block(QueryBlock *qb) {
-    dev_free(qb->table); dev_free(qb->raw); dev_free(qb->packed); dev_free(qb->qi8); dev_free(qb->aa_idx); dev_free(qb->aa_mask); dev_free(qb->self_slot); dev_free(qb->out);
+    dev_free(qb->table); dev_free(qb->raw); dev_free(qb->packed); dev_free(qb->qf4); dev_free(qb->aa_idx); dev_free(qb->aa_mask); dev_free(qb->self_slot); dev_free(qb->out);
     *qb = QueryBlock();
 }
 

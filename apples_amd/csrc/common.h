@@ -78,7 +78,7 @@ struct QueryBlock {
     int64_t n_cols = 0;
     uint8_t *raw = nullptr;       // [n*L]
     uint4 *packed = nullptr;      // [n_pad/16][G][16][planes+1] uint4
-    uint8_t *qi8 = nullptr;       // [n_pad128][W][4][32] int8 operand image for the matrix-core distance kernel
+    uint8_t *qf4 = nullptr;       // [n_pad128][2G][4][32 B] fp4 operand image for the matrix-core distance kernel
     uint8_t *aa_idx = nullptr;    // [n_pad][Lpad16] residue index (20 = gap)
     uint16_t *aa_mask = nullptr;  // [n_pad][Lpad16/16]
     int32_t *self_slot = nullptr; // [n]
@@ -224,7 +224,7 @@ int launch_select_topup(apples_ctx *ctx, const SelectArgs &a, int64_t nq);  // l
 int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const int32_t *perm, int64_t nq, int64_t n_cols);
 bool dist_mfma_enabled();
 bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb);
-int launch_expand_queries_i8(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad);
+int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad);
 int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
                         int32_t *seg_slot, int32_t *seg_cnt);
 int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,

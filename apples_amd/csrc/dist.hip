@@ -187,94 +187,78 @@ __global__ __launch_bounds__(APPLES_TPB) void k_jc69(const uint4 *__restrict__ r
 }
 
 // ---------------------------------------------------------------------------------------------
-// int8 matrix-core form of the same counts (ACGT fast path, tiled case).  The bit-plane kernel above
-// is bound by VALU issue: 6 lane-ops per 32 sites and pair.  Counting is a bilinear form: give every
+// Matrix-core form of the same counts (ACGT fast path, tiled case).  The bit-plane kernel above is
+// bound by VALU issue: 6 lane-ops per 32 sites and pair.  Counting is a bilinear form: give every
 // site a vector t in {(1,1,1),(1,-1,-1),(-1,1,-1),(-1,-1,1)} (the corners of a tetrahedron, one per
 // nucleotide; zero for a gap) and a validity flag v.  Then for a pair of rows
 //     sum t_r . t_q = 3*match - mism        sum v_r * v_q = valid = match + mism
-// so mism = (3*valid - sum t.t) / 4, exactly, in int32.  One v_mfma_i32_32x32x32_i8 covers 32 sites
-// of one component for a 32 x 32 block of pairs; the order of the 32 bytes inside a K chunk is
-// irrelevant as long as both operands use the same one (byte i = site i of the word).
+// so mism = (3*valid - sum t.t) / 4, exactly.  The values 0, +1, -1 are exact in fp4 (e2m1: 0x0, 0x2,
+// 0xA) and the sums (< 2^24) are exact in the f32 accumulators, so the densest matrix-core format
+// serves: one v_mfma_f32_32x32x64_f8f6f4 (fp4 operands, no scaling) covers 64 sites of one
+// component for a 32 x 32 block of pairs.  The order of the 64 nibbles inside a K chunk is
+// irrelevant as long as both operands use the same one; the one used here makes the expansion two
+// ALU operations per 8 sites: dword j of a 32-site word holds sites j, j+4, j+8, ... in nibbles 0..7.
 // Workgroup tile: 256 queries x 128 reference slots, eight wavefronts of 64 x 64 (2 x 2 MFMA tiles,
-// two int32 accumulator sets): every expanded reference byte feeds 256 queries.  Queries arrive pre-expanded (4 bytes/site, k_expand_queries_i8);
-// reference rows are expanded from their bit planes on the fly into LDS, behind the MFMAs.
+// two accumulator sets): every expanded reference nibble feeds 256 queries.  Queries arrive
+// pre-expanded (2 bytes/site, k_expand_queries_f4); reference rows are expanded from their bit
+// planes on the fly into LDS, behind the MFMAs.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
-typedef int v16i_t __attribute__((ext_vector_type(16)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
 
 #define MF_RS 144  // LDS row stride in bytes: 4 components x 32 bytes + 16 (conflict-free 16-byte reads)
 
-// query rows -> int8 operand image: out[(q * W + w) * 128 + comp * 32 + i], comp = t1, t2, t3, v
-__global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_i8(const uint8_t *__restrict__ raw, int64_t n, int L, int W,
-                                                                  uint8_t *__restrict__ out, int64_t n_pad) {
-    const int64_t idx = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;  // one thread per (query, word, site)
-    const int64_t total = n_pad * W * 32;
+// query rows -> fp4 operand image: a 64-site block of a query is 128 bytes, component c (t1, t2, t3,
+// v) at c * 32, its first word's four dwords then its second word's
+__global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_f4(const uint8_t *__restrict__ raw, int64_t n, int L, int NB,
+                                                                  uint32_t *__restrict__ out, int64_t n_pad) {
+    const int64_t idx = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;  // one thread per (query, block, word, dword)
+    const int64_t total = n_pad * NB * 8;
     if (idx >= total) return;
-    const int i = (int)(idx & 31);
-    const int64_t qw = idx >> 5;
-    const int w = (int)(qw % W);
-    const int64_t q = qw / W;
-    const int site = w * 32 + i;
-    int t1 = 0, t2 = 0, t3 = 0, v = 0;
-    if (q < n && site < L) {
-        const uint32_t b = raw[q * (int64_t)L + site];
-        if (b != (uint32_t)'-') {
-            const uint32_t code = (b >> 1) & 3u;  // as k_pack_rows<2>
-            v = 1;
-            t1 = (code & 2u) ? -1 : 1;
-            t2 = (code & 1u) ? -1 : 1;
-            t3 = (((code >> 1) ^ code) & 1u) ? -1 : 1;
+    const int j = (int)(idx & 3), x = (int)((idx >> 2) & 1);
+    const int64_t qb = idx >> 3;
+    const int b = (int)(qb % NB);
+    const int64_t q = qb / NB;
+    uint32_t t1 = 0, t2 = 0, t3 = 0, v = 0;
+    if (q < n) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int site = (b * 2 + x) * 32 + 4 * i + j;
+            if (site >= L) break;
+            const uint32_t c = raw[q * (int64_t)L + site];
+            if (c == (uint32_t)'-') continue;
+            const uint32_t code = (c >> 1) & 3u;  // as k_pack_rows<2>
+            v |= 0x2u << (4 * i);
+            t1 |= (0x2u | ((code & 2u) << 2)) << (4 * i);
+            t2 |= (0x2u | ((code & 1u) << 3)) << (4 * i);
+            t3 |= (0x2u | ((((code >> 1) ^ code) & 1u) << 3)) << (4 * i);
         }
     }
-    uint8_t *o = out + qw * 128 + i;
-    o[0] = (uint8_t)t1; o[32] = (uint8_t)t2; o[64] = (uint8_t)t3; o[96] = (uint8_t)v;
+    uint32_t *o = out + qb * 32 + x * 4 + j;
+    o[0] = t1; o[8] = t2; o[16] = t3; o[24] = v;
 }
 
-// bit i of x -> least significant bit of byte i, four bits at a time (no carries: the partial
-// products land on distinct bit positions)
-__device__ __forceinline__ uint32_t spread4(uint32_t x) { return __umul24(x & 0xfu, 0x00204081u) & 0x01010101u; }
-// bytes 0/1 -> bytes 0x00/0xFF
-__device__ __forceinline__ uint32_t ffmask(uint32_t x) {
-    uint32_t y;
-    asm("v_lshlrev_b32 %0, 8, %1" : "=v"(y) : "v"(x));  // (x << 8) - x; written out so that it does not become a quarter-rate v_mul_lo_u32
-    return y - x;
-}
-
-// One thread expands 16 sites (half a word) of one reference row into the four component chunks:
-// v = validity bits as bytes; a signed component = v | 0xFF where its sign bit is set.
-__device__ __forceinline__ void expand_half(uint32_t m16, uint32_t c0_16, uint32_t c1_16, uint8_t *row, int half) {
-    uint32_t sm[4], t1[4], t2[4], t3[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        sm[k] = spread4(m16 >> (4 * k));
-        t1[k] = sm[k] | ffmask(spread4(c1_16 >> (4 * k)));
-        t2[k] = sm[k] | ffmask(spread4(c0_16 >> (4 * k)));
-        t3[k] = sm[k] | ffmask(spread4((c0_16 ^ c1_16) >> (4 * k)));
-    }
-    uint4 *d = reinterpret_cast<uint4 *>(row + half * 16);  // chunk c of the row starts at c * 32
-    d[0] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
-    d[2] = make_uint4(t2[0], t2[1], t2[2], t2[3]);
-    d[4] = make_uint4(t3[0], t3[1], t3[2], t3[3]);
-    d[6] = make_uint4(sm[0], sm[1], sm[2], sm[3]);
-}
-
-// One thread expands 8 sites (a quarter of a word) of one reference row into the four component chunks.
-// spread4 and ffmask are XOR-linear on these operands, so the third component's sign bytes (code bits
-// c0 ^ c1) are the XOR of the other two's: no third spread.
-__device__ __forceinline__ void expand_quarter(uint32_t m8, uint32_t c0_8, uint32_t c1_8, uint8_t *row, int quarter) {
-    uint32_t sm[2], t1[2], t2[2], t3[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        sm[k] = spread4(m8 >> (4 * k));
-        const uint32_t f1 = ffmask(spread4(c1_8 >> (4 * k))), f0 = ffmask(spread4(c0_8 >> (4 * k)));
-        t1[k] = sm[k] | f1;
-        t2[k] = sm[k] | f0;
-        t3[k] = sm[k] | (f0 ^ f1);
-    }
+// One thread expands 16 sites of one reference row (dwords 2*(quarter&1), +1 of one 32-site word: the
+// word's bits j, j+4, ... become the nibbles of dword j) into the four component chunks.  A valid site
+// is the nibble 0x2 (+1.0); a set sign bit makes it 0xA (-1.0).  The sign planes are zero at gaps.
+// The third component's sign is the XOR of the other two's.
+__device__ __forceinline__ void expand_quarter(uint32_t m, uint32_t c0, uint32_t c1, uint8_t *row, int quarter) {
+    const int sh = (quarter & 1) * 2;
+    m >>= sh; c0 >>= sh; c1 >>= sh;
+    const uint32_t K2 = 0x22222222u, K8 = 0x88888888u;
+    const uint32_t v0 = (m << 1) & K2, v1 = m & K2;
+    const uint32_t c2 = c0 ^ c1;
     uint2 *d = reinterpret_cast<uint2 *>(row + quarter * 8);  // chunk c of the row starts at c * 32
-    d[0] = make_uint2(t1[0], t1[1]);
-    d[4] = make_uint2(t2[0], t2[1]);
-    d[8] = make_uint2(t3[0], t3[1]);
-    d[12] = make_uint2(sm[0], sm[1]);
+    d[0] = make_uint2(((c1 << 3) & K8) | v0, ((c1 << 2) & K8) | v1);
+    d[4] = make_uint2(((c0 << 3) & K8) | v0, ((c0 << 2) & K8) | v1);
+    d[8] = make_uint2(((c2 << 3) & K8) | v0, ((c2 << 2) & K8) | v1);
+    d[12] = make_uint2(v0, v1);
+}
+
+__device__ __forceinline__ v16f_t mfma_f4(const v4i_t &a, const v4i_t &b, const v16f_t &c) {
+    const v8i_t a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    // cbsz = blgp = 4: both operands fp4 (e2m1); scales 0 select the unscaled instruction
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0, 0, 0);
 }
 
 __device__ __forceinline__ uint32_t comp4(const uint4 &v, int x) { return x == 0 ? v.x : (x == 1 ? v.y : (x == 2 ? v.z : v.w)); }
@@ -282,56 +266,60 @@ __device__ __forceinline__ uint32_t comp4(const uint4 &v, int x) { return x == 0
 #define MF_TPB 512
 #define MF_QT 256  // queries per workgroup tile
 template <int MODE>
-__global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict__ refp, const uint8_t *__restrict__ qi8,
+__global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict__ refp, const uint8_t *__restrict__ qf4,
                                                           double *__restrict__ dist, uint32_t *__restrict__ counts,
-                                                          int64_t n_slots, int64_t slots_pad, int G, int W, int64_t nq,
+                                                          int64_t n_slots, int64_t slots_pad, int G, int64_t nq,
                                                           int L, double overlap, const double *__restrict__ lut,
                                                           double thr, int32_t *__restrict__ seg_slot,
                                                           int32_t *__restrict__ seg_cnt, const int32_t *__restrict__ mmax) {
-    // two generations of the tile images: the next word is expanded while this one is multiplied
-    __shared__ __attribute__((aligned(16))) uint8_t Aq[2][MF_QT * MF_RS];  // queries of the tile, one word
-    __shared__ __attribute__((aligned(16))) uint8_t Br[2][128 * MF_RS];    // reference slots of the tile, one word
+    // two generations of the tile images: the next 64-site block is expanded while this one is multiplied
+    __shared__ __attribute__((aligned(16))) uint8_t Aq[2][MF_QT * MF_RS];  // queries of the tile, one block
+    __shared__ __attribute__((aligned(16))) uint8_t Br[2][128 * MF_RS];    // reference slots of the tile, one block
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = wv >> 1, wr = wv & 1;
     const int64_t r0 = (int64_t)blockIdx.x * 128, q0 = (int64_t)blockIdx.y * MF_QT;
-    // loader roles.  Expansion: every thread takes 8 sites of one reference row (16 rows per
+    const int NB = 2 * G;  // 64-site blocks: two per group of four plane words
+    // loader roles.  Expansion: every thread takes 16 sites of one reference row (16 rows per
     // wavefront; sixteen neighbouring lanes = 8 rows x 2 quarters hit 32 distinct banks at the
-    // 144-byte row stride).  Query copy: 64 of a query's 128 bytes.
+    // 144-byte row stride).  Query copy: 64 of a query block's 128 bytes.
     const int lrow = wv * 16 + (lane & 7) + 8 * ((lane >> 5) & 1), lquarter = ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1);
     const int lq = tid >> 1, lhalf = tid & 1;
-    const uint8_t *qsrc = qi8 + ((q0 + lq) * (int64_t)W) * 128 + lhalf * 64;
+    const uint8_t *qsrc = qf4 + ((q0 + lq) * (int64_t)NB) * 128 + lhalf * 64;
     const uint4 *rsrc = refp + r0 + lrow;
-    v16i_t s1[2][2], s2[2][2];
+    v16f_t s1[2][2], s2[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int x = 0; x < 16; ++x) { s1[i][j][x] = 0; s2[i][j][x] = 0; }
+            for (int x = 0; x < 16; ++x) { s1[i][j][x] = 0.f; s2[i][j][x] = 0.f; }
+    // plane words of the group being expanded (pm, p0, p1) and of the one after it (pmN, ...)
     uint4 pm, p0, p1, pmN, p0N, p1N, qa, qb, qc, qd;
     auto fetch_planes = [&](int g, uint4 &m, uint4 &c0, uint4 &c1) {
         const uint4 *rp = rsrc + ((int64_t)(g < G ? g : G - 1) * 3) * slots_pad;
         m = rp[0]; c0 = rp[slots_pad]; c1 = rp[2 * slots_pad];
     };
-    auto fetch_query = [&](int w) {  // the query image has W words; beyond them the reference planes are zero anyway
-        const uint4 *qs = reinterpret_cast<const uint4 *>(qsrc + (int64_t)(w < W ? w : W - 1) * 128);
+    auto fetch_query = [&](int b) {  // the query image has NB blocks; what is staged beyond them is never multiplied
+        const uint4 *qs = reinterpret_cast<const uint4 *>(qsrc + (int64_t)(b < NB ? b : NB - 1) * 128);
         qa = qs[0]; qb = qs[1]; qc = qs[2]; qd = qs[3];
     };
-    auto stage_queries = [&](int w) {  // registers -> query image of generation w & 1
-        uint4 *ad = reinterpret_cast<uint4 *>(Aq[w & 1] + lq * MF_RS + lhalf * 64);
+    auto stage_queries = [&](int b) {  // registers -> query image of generation b & 1
+        uint4 *ad = reinterpret_cast<uint4 *>(Aq[b & 1] + lq * MF_RS + lhalf * 64);
         ad[0] = qa; ad[1] = qb; ad[2] = qc; ad[3] = qd;
     };
-    auto stage_refs = [&](int w, int x) {  // planes -> reference image of generation w & 1 (x = w & 3)
-        const int sh = lquarter * 8;
-        expand_quarter((comp4(pm, x) >> sh) & 0xffu, (comp4(p0, x) >> sh) & 0xffu, (comp4(p1, x) >> sh) & 0xffu,
-                       Br[w & 1] + lrow * MF_RS, lquarter);
+    auto stage_refs = [&](int b, int y) {  // planes -> reference image of generation b & 1 (y = b & 1: words 2y, 2y+1 of the group)
+        const bool second = lquarter >> 1;
+        const uint32_t m = second ? comp4(pm, 2 * y + 1) : comp4(pm, 2 * y);
+        const uint32_t c0 = second ? comp4(p0, 2 * y + 1) : comp4(p0, 2 * y);
+        const uint32_t c1 = second ? comp4(p1, 2 * y + 1) : comp4(p1, 2 * y);
+        expand_quarter(m, c0, c1, Br[b & 1] + lrow * MF_RS, lquarter);
     };
     const int fr = lane & 31, fh = lane >> 5;
     // operand fragments: components {t1, t2} and {t3, v} live in two register sets that are refilled
-    // half a word ahead of their use, so no MFMA ever waits for LDS after the barrier
+    // half a block ahead of their use, so no MFMA ever waits for LDS after the barrier
     v4i_t a01[2][2], b01[2][2], a23[2][2], b23[2][2];
-    auto load_frags = [&](int w, int cbase, v4i_t (&fa)[2][2], v4i_t (&fb)[2][2]) {
-        const uint8_t *A = Aq[w & 1], *B = Br[w & 1];
+    auto load_frags = [&](int b, int cbase, v4i_t (&fa)[2][2], v4i_t (&fb)[2][2]) {
+        const uint8_t *A = Aq[b & 1], *B = Br[b & 1];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -340,35 +328,36 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
                 fb[c][i] = *reinterpret_cast<const v4i_t *>(B + (wr * 64 + i * 32 + fr) * MF_RS + (cbase + c) * 32 + fh * 16);
             }
     };
-    // Schedule of word w (one barrier per word, in the middle of its MFMA stream):
-    //   first half : MFMAs t1, t2 of w | query image of w+1 (stores first) | fragments t3, v of w | loads of query word w+2
-    //   barrier    : image w+1 complete, image w read by everybody
-    //   second half: MFMAs t3, v of w  | fragments t1, t2 of w+1 (first) | reference image of w+2 (into w's buffer)
+    // Schedule of block b (one barrier per block, in the middle of its MFMA stream):
+    //   first half : MFMAs t1, t2 of b | query image of b+1 (stores first) | fragments t3, v of b | loads of query block b+2
+    //   barrier    : image b+1 complete, image b read by everybody
+    //   second half: MFMAs t3, v of b  | fragments t1, t2 of b+1 (first) | reference image of b+2 (into b's buffer)
     // LDS completes in order behind one counter: what the barrier needs (the stores of the first half)
-    // goes out first, what the next half-word needs (fragments) next, the expansion's stores last.
+    // goes out first, what the next half-block needs (fragments) next, the expansion's stores last.
+    // Block b+2 lies in the next group: its planes were fetched a whole group earlier.
     fetch_planes(0, pm, p0, p1);
     fetch_query(0);
     stage_queries(0);
     stage_refs(0, 0);
     stage_refs(1, 1);
+    fetch_planes(1, pm, p0, p1);
     fetch_query(1);
     __syncthreads();
     load_frags(0, 0, a01, b01);
     for (int g = 0; g < G; ++g) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int w = g * 4 + x;
+        for (int y = 0; y < 2; ++y) {
+            const int b = g * 2 + y;
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        s1[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a01[c][i], b01[c][j], s1[i][j], 0, 0, 0);
-            stage_queries(w + 1);
-            load_frags(w, 2, a23, b23);
-            fetch_query(w + 2);
-            if (x == 1) fetch_planes(g + 1, pmN, p0N, p1N);  // used from the second half of the next word on
+                    for (int j = 0; j < 2; ++j) s1[i][j] = mfma_f4(a01[c][i], b01[c][j], s1[i][j]);
+            stage_queries(b + 1);
+            load_frags(b, 2, a23, b23);
+            fetch_query(b + 2);
+            if (y == 0) fetch_planes(g + 2, pmN, p0N, p1N);  // expanded during the next group
 #pragma unroll
             for (int k = 0; k < 2; ++k) {  // the four wide stores
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -391,24 +380,24 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) s1[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a23[0][i], b23[0][j], s1[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) s1[i][j] = mfma_f4(a23[0][i], b23[0][j], s1[i][j]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) s2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a23[1][i], b23[1][j], s2[i][j], 0, 0, 0);
-            load_frags(w + 1, 0, a01, b01);
-            if (x == 2) { pm = pmN; p0 = p0N; p1 = p1N; }  // words 0, 1 of the next group from here on
-            stage_refs(w + 2, (x + 2) & 3);
+                for (int j = 0; j < 2; ++j) s2[i][j] = mfma_f4(a23[1][i], b23[1][j], s2[i][j]);
+            load_frags(b + 1, 0, a01, b01);
+            stage_refs(b + 2, y);
+            if (y == 1) { pm = pmN; p0 = p0N; p1 = p1N; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // the eight fragment reads first, expansion arithmetic beside them
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // then the rest of the expansion and its four stores
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
         }
@@ -424,8 +413,8 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
                     const int64_t q = q0 + wq * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * fh;
                     const int64_t slot = r0 + wr * 64 + j * 32 + fr;
                     if (q < nq && slot < n_slots) {
-                        const uint32_t valid = (uint32_t)s2[i][j][x];
-                        const uint32_t mism = (uint32_t)((3 * s2[i][j][x] - s1[i][j][x]) >> 2);
+                        const uint32_t valid = (uint32_t)(int)s2[i][j][x];
+                        const uint32_t mism = (uint32_t)((3 * (int)s2[i][j][x] - (int)s1[i][j][x]) >> 2);
                         const int64_t o = q * slots_pad + slot;
                         if (dist) dist[o] = jc69_from_counts(mism, valid, L, overlap, lut);
                         if (counts) counts[o] = (mism << 16) | valid;
@@ -436,7 +425,7 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
 #ifdef MF_SKIP_EPILOGUE
     {   // timing experiment: main loop only (every accumulator stays live)
         int acc = 0;
-        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int x = 0; x < 16; ++x) acc += s1[i][j][x] ^ s2[i][j][x];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int x = 0; x < 16; ++x) acc += (int)s1[i][j][x] ^ (int)s2[i][j][x];
         if (acc == 0x7fffffff) dist[0] = 1.0;
         return;
     }
@@ -461,8 +450,8 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
         for (int x = 0; x < 16; ++x)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int valid = s2[i][j][x];
-                const int mism = ((valid << 1) + valid - s1[i][j][x]) >> 2;  // (3 valid - sum t.t) / 4
+                const int valid = (int)s2[i][j][x];
+                const int mism = ((valid << 1) + valid - (int)s1[i][j][x]) >> 2;  // (3 valid - sum t.t) / 4
                 keepbits |= (mism <= mm_lds[valid] ? 1u : 0u) << (x * 2 + j);
                 pk[x][j] = ((uint32_t)(j * 32 + fr) << 26) | ((uint32_t)valid << 13) | (uint32_t)mism;
             }
@@ -517,7 +506,7 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
 // slots and distances
 bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb) {
     static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
-    return qb.qi8 && ctx->aln.planes == 2 && ctx->jc_lut && ctx->jc_mmax && !no_mmax && ctx->aln.L < 8192;  // 13-bit counts
+    return qb.qf4 && ctx->aln.planes == 2 && ctx->jc_lut && ctx->jc_mmax && !no_mmax && ctx->aln.L < 8192;  // 13-bit counts
 }
 
 bool dist_mfma_enabled() {
@@ -525,11 +514,11 @@ bool dist_mfma_enabled() {
     return !off;
 }
 
-int launch_expand_queries_i8(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad) {
+int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad) {
     const DevAlign &a = ctx->aln;
-    const int64_t total = n_pad * a.W * 32;
-    hipLaunchKernelGGL(k_expand_queries_i8, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0,
-                       ctx->stream, d_raw, n, a.L, a.W, d_out, n_pad);
+    const int64_t total = n_pad * a.G * 2 * 8;
+    hipLaunchKernelGGL(k_expand_queries_f4, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0,
+                       ctx->stream, d_raw, n, a.L, a.G * 2, reinterpret_cast<uint32_t *>(d_out), n_pad);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -541,7 +530,7 @@ static int launch_mfma(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
     static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
     dim3 grid((unsigned)(a.slots_pad / 128), (unsigned)((nq + MF_QT - 1) / MF_QT));
     hipLaunchKernelGGL((k_jc69_mfma<MODE>), grid, dim3(MF_TPB), 0, ctx->stream, a.packed,
-                       qb.qi8 + q0 * (int64_t)a.W * 128, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, a.W, nq, a.L,
+                       qb.qf4 + q0 * (int64_t)a.G * 256, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,
                        ctx->params.overlap_frac, ctx->jc_lut, ctx->params.filt_threshold, seg_slot, seg_cnt,
                        no_mmax ? nullptr : ctx->jc_mmax);
     HIP_TRY(ctx, hipGetLastError());
@@ -554,7 +543,7 @@ int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq,
     // Full rows stay with the bit-plane kernel: with 8 bytes out per pair and a table lookup per pair the
     // matrix-core form is slower here (0.64 against 0.58 ms at C2 size).  APPLES_DIST_MFMA_ROWS=1 routes
     // tiles of 16 and more queries to it anyway (tests compare its counts with the bytewise definition).
-    if (qb.qi8 && ctx->aln.planes == 2 && tile >= 16 && getenv("APPLES_DIST_MFMA_ROWS"))
+    if (qb.qf4 && ctx->aln.planes == 2 && tile >= 16 && getenv("APPLES_DIST_MFMA_ROWS"))
         return launch_mfma<0>(ctx, qb, q0, nq, d_dist, d_counts, nullptr, nullptr);
     if (ctx->aln.planes == 2) launch_jc69_tile<2, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     else launch_jc69_tile<8, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
