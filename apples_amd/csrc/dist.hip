@@ -344,6 +344,9 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
     fetch_query(1);
     __syncthreads();
     load_frags(0, 0, a01, b01);
+#ifdef MF_NO_FRAGS
+    load_frags(0, 2, a23, b23);
+#endif
     for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
@@ -354,9 +357,15 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) s1[i][j] = mfma_f4(a01[c][i], b01[c][j], s1[i][j]);
+#ifndef MF_NO_QSTAGE
             stage_queries(b + 1);
+#endif
+#ifndef MF_NO_FRAGS
             load_frags(b, 2, a23, b23);
+#endif
+#ifndef MF_NO_QFETCH
             fetch_query(b + 2);
+#endif
             if (y == 0) fetch_planes(g + 2, pmN, p0N, p1N);  // expanded during the next group
 #pragma unroll
             for (int k = 0; k < 2; ++k) {  // the four wide stores
@@ -385,8 +394,12 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) s2[i][j] = mfma_f4(a23[1][i], b23[1][j], s2[i][j]);
+#ifndef MF_NO_FRAGS
             load_frags(b + 1, 0, a01, b01);
+#endif
+#ifndef MF_NO_RSTAGE
             stage_refs(b + 2, y);
+#endif
             if (y == 1) { pm = pmN; p0 = p0N; p1 = p1N; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // the eight fragment reads first, expansion arithmetic beside them
@@ -432,44 +445,54 @@ __global__ __launch_bounds__(MF_TPB, 2) void k_jc69_mfma(const uint4 *__restrict
 #endif
     // MODE 1: threshold test + per-segment compaction, the format k_select_fast reads.  This wavefront's
     // 64 reference slots are one segment: column tile j = its lower or upper half.  The test is the
-    // integer one (mism <= mmax[valid]; rows and queries beyond the ends have valid = 0, which never
-    // passes), with the table in the now idle tile memory.  A survivor is one 32-bit word in seg_slot:
+    // integer one, mism <= mmax[valid], carried out on the accumulators as they are: 3 valid - sum t.t
+    // = 4 mism exactly, against 4 mmax[valid] as a float table in the now idle tile memory (-4 where
+    // no count passes: valid = 0, too little overlap).  A survivor is one 32-bit word in seg_slot:
     // position in the segment (6 bits) | valid (13) | mism (13); k_select_fast looks the distance up.
     // No scattered table reads and one store per survivor here.
     __syncthreads();
-    int32_t *mm_lds = reinterpret_cast<int32_t *>(&Aq[0][0]);
-    for (int i = tid; i <= L; i += MF_TPB) mm_lds[i] = mmax[i];
+    float *mm_lds = reinterpret_cast<float *>(&Aq[0][0]);
+    for (int i = tid; i <= L; i += MF_TPB) mm_lds[i] = (float)(4 * mmax[i]);
     __syncthreads();
     const int64_t seg = (r0 + wr * 64) >> 6;
     const int64_t n_seg = slots_pad >> 6;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        uint32_t pk[16][2];
         uint32_t keepbits = 0;
 #pragma unroll
         for (int x = 0; x < 16; ++x)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int valid = (int)s2[i][j][x];
-                const int mism = ((valid << 1) + valid - (int)s1[i][j][x]) >> 2;  // (3 valid - sum t.t) / 4
-                keepbits |= (mism <= mm_lds[valid] ? 1u : 0u) << (x * 2 + j);
-                pk[x][j] = ((uint32_t)(j * 32 + fr) << 26) | ((uint32_t)valid << 13) | (uint32_t)mism;
+                const float valid = s2[i][j][x];
+                const float mism4 = __builtin_fmaf(valid, 3.f, -s1[i][j][x]);
+                keepbits |= (mism4 <= mm_lds[(int)valid] ? 1u : 0u) << (x * 2 + j);
             }
+        if (__ballot(keepbits != 0) == 0ull) continue;  // no survivor among these 32 queries x 64 slots
         const int64_t qbase = q0 + wq * 64 + i * 32 + 4 * fh;  // this lane half's first query of the 32
+        // (rows past this launch's queries may be real queries of the next sub-batch: not ours to write)
+        const int rem = (int)(nq - qbase < 32 ? nq - qbase : 32);
+        int32_t *row0 = seg_slot + qbase * slots_pad + seg * 64;
+        int32_t *cnt0 = seg_cnt + qbase * n_seg + seg;
+        const uint32_t below = (1u << fr) - 1u;
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
-            const int64_t q = qbase + (x & 3) + 8 * (x >> 2);
-            // (rows past this launch's queries may be real queries of the next sub-batch: not ours to write)
-            const bool k0 = ((keepbits >> (x * 2)) & 1u) && q < nq, k1 = ((keepbits >> (x * 2 + 1)) & 1u) && q < nq;
+            const int cx = (x & 3) + 8 * (x >> 2);  // this register's query, relative to qbase
+            const bool in = cx < rem;
+            const bool k0 = ((keepbits >> (x * 2)) & 1u) && in, k1 = ((keepbits >> (x * 2 + 1)) & 1u) && in;
             const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
             if ((b0 | b1) == 0) continue;  // nobody in either half's segment survives: the counts stay at their preset zero
             // this lane half's query: slots 0..31 of the segment from tile 0, 32..63 from tile 1
             const uint32_t lo = (uint32_t)(b0 >> (32 * fh)), hi = (uint32_t)(b1 >> (32 * fh));
-            int32_t *row = seg_slot + q * slots_pad + seg * 64;
-            const uint32_t below = (1u << fr) - 1u;
-            if (k0) row[__popc(lo & below)] = (int32_t)pk[x][0];
-            if (k1) row[__popc(lo) + __popc(hi & below)] = (int32_t)pk[x][1];
-            if (fr == 0 && q < nq) seg_cnt[q * n_seg + seg] = __popc(lo) + __popc(hi);
+            int32_t *row = row0 + (int64_t)cx * slots_pad;
+            if (k0) {
+                const int valid = (int)s2[i][0][x], mism = (3 * valid - (int)s1[i][0][x]) >> 2;
+                row[__popc(lo & below)] = (int32_t)(((uint32_t)fr << 26) | ((uint32_t)valid << 13) | (uint32_t)mism);
+            }
+            if (k1) {
+                const int valid = (int)s2[i][1][x], mism = (3 * valid - (int)s1[i][1][x]) >> 2;
+                row[__popc(lo) + __popc(hi & below)] = (int32_t)(((uint32_t)(32 + fr) << 26) | ((uint32_t)valid << 13) | (uint32_t)mism);
+            }
+            if (fr == 0 && in) cnt0[(int64_t)cx * n_seg] = __popc(lo) + __popc(hi);
         }
     }
 }
