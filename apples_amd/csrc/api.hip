@@ -97,12 +97,18 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
         r.kleaf = 0;
         if (r.c0 >= 0 && t->child_off[r.c0 + 1] == t->child_off[r.c0]) r.kleaf |= 1u;
         if (r.c1 >= 0 && t->child_off[r.c1 + 1] == t->child_off[r.c1]) r.kleaf |= 2u;
-        r.pad = 0;
+        r.node = i;
     }
     std::vector<int32_t> npos((size_t)t->n_nodes * 2);
     for (int i = 0; i < t->n_nodes; ++i) { npos[2 * (size_t)i] = rec[i].lpos; npos[2 * (size_t)i + 1] = rec[i].ppos; }
     if (dev_upload(ctx, &d.npos, npos.data(), (int64_t)npos.size())) return 1;
     if (dev_upload(ctx, &d.rec, rec.data(), t->n_nodes)) return 1;
+    {
+        std::vector<NodeRec> rec_l((size_t)std::max(words, 1) * 64);
+        std::memset(rec_l.data(), 0xff, rec_l.size() * sizeof(NodeRec));
+        for (int i = 0; i < t->n_nodes; ++i) rec_l[lpos[i]] = rec[i];
+        if (dev_upload(ctx, &d.rec_l, rec_l.data(), (int64_t)rec_l.size())) return 1;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -775,7 +781,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     for (auto &qb : ctx->blocks) free_block(&qb);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
-    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.npos);
+    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos);
     DevAlign &a = ctx->aln;
     dev_free(a.raw); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);

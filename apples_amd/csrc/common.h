@@ -26,7 +26,7 @@ struct __attribute__((aligned(64))) NodeRec {
     int32_t ppos;         // the parent's position (-1 for the root)
     int32_t parent;       // -1 for the root
     int32_t lpos;         // own position
-    int32_t pad;
+    int32_t node;         // own id (what a reader of the position-ordered copy needs)
 };
 
 struct DevTree {
@@ -44,6 +44,7 @@ struct DevTree {
     int32_t bm_words = 0;        // 64-bit words of the whole space
     int32_t *lvlw = nullptr;     // [2*(height+1)+1] first word of level l's internal block at 2l, leaf block at 2l+1
     int32_t *lnode = nullptr;    // [bm_words*64] node at a bit position (-1 = padding)
+    NodeRec *rec_l = nullptr;    // [bm_words*64] the records in bit-position order: position -> record in one load
     int32_t *npos = nullptr;     // [n_nodes][2] lpos, ppos (what a leaf needs, without its 64-byte record)
 };
 

@@ -590,8 +590,9 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                 int parent = -1;
                 Rec r;
                 if (active) {
-                    r.node = umap ? order[base + k] : T.lnode[kth_in_block(nb, w0, w1, k)];
-                    const NodeRec nr = NR[r.node];
+                    // (bit space: the k-th set bit's position leads straight to the record)
+                    const NodeRec nr = umap ? NR[order[base + k]] : T.rec_l[kth_in_block(nb, w0, w1, k)];
+                    r.node = nr.node;
                     parent = nr.parent;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) r.T[c] = 0;
