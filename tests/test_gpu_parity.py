@@ -405,11 +405,12 @@ def test_both_sweep_layouts_agree_on_polytomies(monkeypatch):
     monkeypatch.delenv('APPLES_NODE_MAP', raising=False)
 
 
-@pytest.mark.parametrize('L,n_ref,n_q', [(77, 130, 16), (1000, 300, 100), (1620, 257, 300), (33, 64, 517)])
+@pytest.mark.parametrize('L,n_ref,n_q', [(77, 130, 16), (1000, 300, 100), (1620, 257, 300), (33, 64, 517), (64, 129, 17),
+                                          (4099, 70, 40)])
 def test_matrix_core_pair_counts_equal_the_bytewise_definition(L, n_ref, n_q, monkeypatch):
-    """The tiled distance pass counts (mismatches, shared valid sites) with int8 MFMAs from
+    """The tiled distance pass counts (mismatches, shared valid sites) with fp4 MFMAs from
     tetrahedral codes; apples/distance.py:733-737 defines the same two integers on bytes.  Ragged
-    sizes (L not a multiple of 32, rows and queries not multiples of the 128 x 256 tile), heavy
+    sizes (L not a multiple of 32 or of the 64-site MFMA block, rows and queries not multiples of the 128 x 256 tile), heavy
     gaps, all-gap rows and identical rows; every count must be identical, and so must the counts of
     the bit-plane VALU kernel the library uses for small query tiles."""
     rng = np.random.default_rng(L * 1000 + n_q)

@@ -123,7 +123,7 @@ def test_fused_and_full_row_selection_paths_agree(c2):
     byte-identical, also when every query needs the top-up rule (tiny threshold) and when large
     queries are routed to workgroup-sized sweep teams.  The top-up rule itself has two forms
     (streaming the full row, or ranking per-segment minima, the default for long rows): forced
-    here with APPLES_TOPUP_MIN_ROWS=0.  And the pair counts come from the int8 matrix-core kernel
+    here with APPLES_TOPUP_MIN_ROWS=0.  And the pair counts come from the fp4 matrix-core kernel
     by default, from the bit-plane VALU kernel with APPLES_NO_DIST_MFMA=1."""
     import subprocess
     d, nodes = c2
