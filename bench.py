@@ -101,8 +101,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus and world > 1:
         args.gpus = world
+    # APPLES_BENCH_FORCE_DIST=1 (tests): take the multi-rank code path -- process group, gather,
+    # max over ranks -- even with a single rank, so that one GPU is enough to exercise it
+    use_dist = world > 1 or bool(os.environ.get('APPLES_BENCH_FORCE_DIST'))
     dist = torch = None
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -130,7 +133,7 @@ def main():
                      baseobs=25, overlap=0.001, device=local_rank)
         handle, nq = eng.upload_queries(ds.query_seqs)
 
-    if world > 1:
+    if use_dist:
         class _DevArray:  # zero-copy view of the device-resident placement structs
             def __init__(self, ptr, nbytes):
                 self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
@@ -139,12 +142,12 @@ def main():
 
     def step():
         eng.place_resident(handle)  # returns after the stream has drained
-        if world > 1:
+        if use_dist:
             # the end-of-run gather over RCCL/xGMI (replaces starmap's pickle return)
             gather_bytes(res, rank, world, dist)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -162,12 +165,17 @@ def main():
         launches += t['dist_launches']
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     out = eng.fetch(handle, nq)
+    if use_dist:  # untimed: what the gather delivers for this rank is what the device holds
+        parts = gather_bytes(res, rank, world, dist)
+        torch.cuda.synchronize()
+        if rank == 0 and parts[0].cpu().numpy().tobytes() != out.tobytes():
+            raise SystemExit('bench: gathered placements differ from the device buffer')
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * nq / (dt / args.steps)
@@ -224,7 +232,7 @@ def main():
         print(json.dumps(line), flush=True)
     eng.free_queries(handle)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -79,3 +79,20 @@ def test_cli_database_cache_matches_reference_jplace(tmp_path):
     assert [p['n'] for p in got['placements']] == [p['n'] for p in want['placements']]
     for g, w in zip(got['placements'], want['placements']):
         assert_prow(g['p'][0], w['p'][0], ctx='database %s' % w['n'][0])
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py's multi-rank path (process group over RCCL, zero-copy view of the device-resident
+    placements, gather to rank 0, max over ranks), launched the way the driver launches it, with a
+    single rank so that one GPU is enough: the contract line must come out, and bench.py itself
+    checks that what the gather delivers is what the device buffer holds."""
+    env = dict(os.environ, APPLES_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+           '127.0.0.1', '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2',
+           '--warmup', '1', '--workload', 'small', '--no-cpu']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['steps'] == 2 and line['scaling'] == 'weak'
+    assert line['value'] > 0 and line['roofline']['frac'] > 0
+    assert line['config']['placed'] > 0
