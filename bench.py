@@ -73,6 +73,31 @@ def cpu_baseline_table(ds, D, method, threshold, target_cpu_seconds=20.0):
                       'counted; %.3f s for one query on one core)' % (n, cores, dt, startup, t1)}
 
 
+def distance_stream_point(eng, ds, L):
+    """BASELINE.json's second figure, measured live: the distance kernel at query tile T = 1 (SURVEY
+    8d's roofline point: the packed reference streamed once per query, full fp64 rows out), on up to
+    256 of the workload's queries, outside the timed region.  `delivered` counts the bytes the kernel
+    moves (packed reference + 8 B per pair); whether they come from HBM or from the caches depends
+    on the reference's size, which is reported beside it."""
+    n = min(256, len(ds.query_seqs))
+    h, n = eng.upload_queries(ds.query_seqs[:n])
+    for _ in range(3):
+        eng.distances_resident(h, 1)
+    ms = eng.timing()['dist_ms']
+    info = eng.describe()
+    eng.free_queries(h)
+    if ms <= 0:
+        return None
+    moved = n * (info['packed_bytes'] + info['n_rows'] * 8.0)
+    algo = n * (info['n_rows'] * (L + 8.0) + L)
+    gbs = moved / (ms * 1e-3) / 1e9
+    return {'query_tile': 1, 'queries': n, 'ms': ms, 'packed_reference_bytes': info['packed_bytes'],
+            'delivered_GBps': gbs, 'peak_GBps': HBM_PEAK_GBS, 'frac': gbs / HBM_PEAK_GBS,
+            'algorithmic_GBps': algo / (ms * 1e-3) / 1e9,
+            'served_from': 'L2 / Infinity Cache (reference smaller than the 256 MiB cache)'
+                           if info['packed_bytes'] < (256 << 20) else 'HBM'}
+
+
 def load_traffic(workload, kernel):
     """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
     (profiles/pmc_summary.json, written by scripts/pmc_to_traffic.py from separate --pmc runs of
@@ -208,6 +233,9 @@ def main():
             roofline.update({'bound': 'mfma', 'achieved': tops, 'peak': MFMA_F4_PEAK_TOPS, 'unit': 'TFLOP/s',
                              'frac': tops / MFMA_F4_PEAK_TOPS, 'algorithmic_ops_per_launch': ops / n_launch,
                              'hbm_algorithmic_GBps': achieved})
+        stream = None
+        if world == 1 and not table and not protein:
+            stream = distance_stream_point(eng, ds, L)
         cpu = None
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline_table(ds, D, method, thr) if table else cpu_baseline(ds, protein, method, thr)
@@ -225,6 +253,7 @@ def main():
                        'mean_observed': float(np.mean(out['n_obs'])), 'mean_swept_nodes': mean_v,
                        'placed': int(placed.sum()), 'parallelism': 'query-sharded x%d' % world},
             'roofline': roofline,
+            'distance_kernel_stream': stream,
             'cpu_baseline': cpu,
         }
         if cpu:
