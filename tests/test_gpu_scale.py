@@ -278,3 +278,28 @@ def test_clustered_reference_at_c2_size_against_c_oracle(c2, method, criterion):
     got = eng.place_sequences(d.query_seqs[:nq])
     eng.close()
     _compare(got, want, co, d, nodes, 'clustered %s/%s' % (method, criterion))
+
+
+@pytest.mark.parametrize('L', [4097, 8190])
+def test_long_alignments_through_the_fused_matrix_core_pass(L):
+    """The fused distance pass packs (valid, mism) into 13-bit fields and counts in f32
+    accumulators over 64-site fp4 blocks: alignments just past 4 096 sites (odd number of blocks,
+    ragged last word) and just below the 8 192 limit of the packed format, with heavy gaps so that
+    the overlap rule and short valid counts occur.  Placements identical to the C oracle's."""
+    d = synth.make_dataset(600, L, 300, seed_tree=11, seed_aln=12, seed_query=13)
+    rng = np.random.default_rng(L)
+    ref = d.ref_seqs.copy()
+    qry = d.query_seqs.copy()
+    ref[rng.random(ref.shape) < 0.3] = ord('-')           # a third of every row missing
+    qry[:, : L // 2][rng.random((len(qry), L // 2)) < 0.5] = ord('-')
+    qry[7] = ord('-')                                      # all-gap query
+    qry[8] = ref[3]                                        # exact copy of a reference row
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    co = COracle(d.tree, ref, nodes, method='OLS', criterion='MLSE', lut=jc69_lut(L, 0.001),
+                 threads=len(os.sched_getaffinity(0)))
+    want = co.place_sequences(qry)
+    eng = Engine(d.tree, ref, nodes, method='OLS', criterion='MLSE')
+    assert eng.describe()['code_planes'] == 2
+    got = eng.place_sequences(qry)
+    _compare(got, want, co, d, nodes, 'long alignment L=%d' % L)
+    eng.close()
