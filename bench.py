@@ -11,9 +11,11 @@ every rank places its own shard of the same size (weak scaling, no collective in
 and the placements are gathered to rank 0 with one RCCL gather inside the timed region.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, algorithmic bytes / HIP-event
-time) and `cpu_baseline` (the CPU restatement of the reference path -- per-query
-numpy/Python worker under a fork pool, as run_apples.py:101-102 -- timed on this host's cores on
-a bounded sample of the same workload).
+time), `distance_kernel_stream` (BASELINE.json's second figure: the distance kernel
+at one query per pass over the packed reference, bytes moved / HIP-event time against the 8 TB/s
+peak, measured after the timed region) and `cpu_baseline` (the CPU restatement of the reference
+path -- per-query numpy/Python worker under a fork pool, as run_apples.py:101-102 -- timed on this
+host's cores on a bounded sample of the same workload).
 """
 import argparse
 import json
