@@ -130,6 +130,10 @@ def _load_io():
             lib.apples_fasta_scan.restype = ctypes.c_int
             lib.apples_fasta_scan.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                               ctypes.c_int64] + [ctypes.c_void_p] * 6
+            if hasattr(lib, 'apples_newick_scan'):
+                lib.apples_newick_scan.restype = ctypes.c_int
+                lib.apples_newick_scan.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64] + \
+                    [ctypes.c_void_p] * 11
             _io_lib = lib
     return _io_lib or None
 

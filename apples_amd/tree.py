@@ -49,18 +49,12 @@ class Tree:
         return self.child_idx[self.child_off[v]:self.child_off[v + 1]]
 
 
-def parse_newick(text):
-    """Parse one Newick tree string into a :class:`Tree`."""
-    text = text.strip()
-    is_rooted = False
-    if text.startswith('[&R]'):
-        is_rooted = True
-        text = text[4:].lstrip()
-    elif text.startswith('[&U]'):
-        text = text[4:].lstrip()
-
+def _scan_py(text):
+    """Token loop of the reader.  Returns, per node in creation (= pre-) order: parent (creation
+    index), depth, subtree size, label (str or None), branch length (nan where absent) and whether
+    one was given."""
     # creation-order (= pre-order) temporary nodes; depth and subtree size come out of the token
-    # loop, so the post-order numbering below needs no traversal
+    # loop, so the post-order numbering needs no traversal
     t_parent = [-1]
     t_label = [None]
     t_len = [None]
@@ -118,24 +112,75 @@ def parse_newick(text):
         raise ValueError('malformed Newick: unexpected end of input')
     if cur != 0:
         raise ValueError('malformed Newick: unbalanced parentheses')
-
     n = len(t_parent)
-    # left-to-right post-order number (apples/util.py:65-69) of the node created k-th (pre-order):
-    # k - depth + size - 1  (the nodes before it in pre-order that are not its ancestors, plus its
-    # own descendants)
-    pre_parent = np.array(t_parent, dtype=np.int64)
-    pre_depth = np.array(t_depth, dtype=np.int64)
     size = np.ones(n, dtype=np.int64)
     if t_size:
         size[np.fromiter(t_size.keys(), dtype=np.int64, count=len(t_size))] = \
             np.fromiter(t_size.values(), dtype=np.int64, count=len(t_size))
+    lens = np.array([np.nan if x is None else x for x in t_len], dtype=np.float64)
+    given = np.array([x is not None for x in t_len], dtype=bool)
+    return np.array(t_parent, dtype=np.int64), np.array(t_depth, dtype=np.int64), size, t_label, lens, given
+
+
+def _scan_native(text):
+    """The same through libapples_io.so (include/apples_io.h: apples_newick_scan), or None when the
+    library is missing, the text is not plain ASCII, or the scanner met something it leaves to
+    :func:`_scan_py` (malformed input: that parser words the error)."""
+    from .fasta import _load_io
+    lib = _load_io()
+    if lib is None or not hasattr(lib, 'apples_newick_scan') or not text.isascii():
+        return None
+    import ctypes
+    raw = text.encode('ascii')
+    cap = 1 + raw.count(b'(') + raw.count(b',')
+    par = np.empty(cap, np.int32); dep = np.empty(cap, np.int32); siz = np.empty(cap, np.int32)
+    loff = np.empty(cap, np.int64); llen = np.empty(cap, np.int32); lq = np.empty(cap, np.uint8)
+    val = np.empty(cap, np.float64); st = np.empty(cap, np.uint8)
+    voff = np.empty(cap, np.int64); vlen = np.empty(cap, np.int32)
+    n = ctypes.c_int64(0)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.apples_newick_scan(raw, len(raw), cap, ptr(par), ptr(dep), ptr(siz), ptr(loff), ptr(llen), ptr(lq),
+                                ptr(val), ptr(st), ptr(voff), ptr(vlen), ctypes.byref(n))
+    if rc != 0:
+        return None
+    n = n.value
+    loff = loff[:n].tolist(); llen = llen[:n].tolist()
+    labels = [text[o:o + k] if k >= 0 else None for o, k in zip(loff, llen)]
+    for k in np.nonzero(lq[:n])[0].tolist():
+        labels[k] = labels[k].replace("''", "'")
+    st = st[:n]
+    lens = np.where(st == 1, val[:n], np.nan)
+    try:
+        for k in np.nonzero(st == 2)[0].tolist():  # spellings left to float(): nan, inf, 1_000, ...
+            lens[k] = float(text[voff[k]:voff[k] + vlen[k]])
+    except ValueError:
+        return None  # not a number: _scan_py reports the first one in file order
+    return par[:n].astype(np.int64), dep[:n].astype(np.int64), siz[:n].astype(np.int64), labels, lens, st != 0
+
+
+def parse_newick(text):
+    """Parse one Newick tree string into a :class:`Tree`."""
+    text = text.strip()
+    is_rooted = False
+    if text.startswith('[&R]'):
+        is_rooted = True
+        text = text[4:].lstrip()
+    elif text.startswith('[&U]'):
+        text = text[4:].lstrip()
+
+    scanned = _scan_native(text)
+    if scanned is None:
+        scanned = _scan_py(text)
+    pre_parent, pre_depth, size, t_label, lens, given = scanned
+    n = len(pre_parent)
+    # left-to-right post-order number (apples/util.py:65-69) of the node created k-th (pre-order):
+    # k - depth + size - 1  (the nodes before it in pre-order that are not its ancestors, plus its
+    # own descendants)
     post = np.arange(n, dtype=np.int64) - pre_depth + size - 1
 
     parent = np.full(n, -1, dtype=np.int32)
     nonroot = pre_parent >= 0
     parent[post[nonroot]] = post[pre_parent[nonroot]]
-    lens = np.array([np.nan if x is None else x for x in t_len], dtype=np.float64)
-    given = np.array([x is not None for x in t_len], dtype=bool)
     edge_len = np.zeros(n, dtype=np.float64)
     has_len = np.zeros(n, dtype=bool)
     edge_len[post[given]] = lens[given]

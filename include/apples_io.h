@@ -26,6 +26,24 @@ int apples_fasta_scan(const uint8_t *data, int64_t n_bytes, const uint8_t *trans
                       uint8_t *rows, int64_t n_rows, int64_t *n_records, int64_t *length,
                       int64_t *name_off, int32_t *name_len, int64_t *bad_record, int64_t *bad_length);
 
+/* apples_newick_scan replaces the token loop of the Newick reader (apples_amd/tree.py:parse_newick;
+ * reader contract: SURVEY.md Appendix B, for apples/prepareTree.py:24-36 and apples/util.py:57-88)
+ * for backbones of 10^5..10^6 leaves.  `text` is the tree string after the optional [&R]/[&U]
+ * prefix, ASCII only.  Tokens: ( ) , : ; | '...' with '' for a quote | [...] comment, dropped |
+ * any other run of characters, stripped of white space: a label, or after ':' a branch length.
+ * Output, per node in creation (= pre-) order, arrays of `cap` entries (cap >= 1 + number of '('
+ * and ',' in the text is always enough): parent (creation index, -1 for the root), depth, size
+ * (nodes in the subtree), the label's byte range in `text` (label_len = -1: none; label_quoted:
+ * the range is the inside of a quoted label, '' still doubled), the branch length
+ * (length_state 0: none, 1: parsed into `length` -- plain decimal spellings only, on which strtod
+ * and Python's float() agree, 2: the caller converts text[length_off : length_off + length_len]).
+ * Returns 0 and *n_nodes, 1 on anything malformed (the caller's own parser then decides and words
+ * the error), 2 if cap is too small. */
+int apples_newick_scan(const uint8_t *text, int64_t n_bytes, int64_t cap, int32_t *parent, int32_t *depth,
+                       int32_t *size, int64_t *label_off, int32_t *label_len, uint8_t *label_quoted,
+                       double *length, uint8_t *length_state, int64_t *length_off, int32_t *length_len,
+                       int64_t *n_nodes);
+
 #ifdef __cplusplus
 }
 #endif

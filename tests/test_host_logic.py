@@ -319,3 +319,93 @@ def _not_a_database(tmp_path):
     p = str(tmp_path / 'other.npz')
     np.savez(p, x=np.arange(3))
     return p
+
+
+def _parse_both(text, monkeypatch):
+    """parse_newick through the native scanner and through the Python token loop."""
+    from apples_amd import tree as T
+    out = []
+    for native in (True, False):
+        with monkeypatch.context() as m:
+            if not native:
+                m.setattr(T, '_scan_native', lambda t: None)
+            try:
+                out.append(('ok', T.parse_newick(text)))
+            except Exception as e:  # noqa: BLE001 -- the two paths must fail alike, whatever the failure
+                out.append(('err', type(e).__name__, str(e)))
+    return out
+
+
+def _same_tree(a, b):
+    if a[0] != b[0]:
+        return False
+    if a[0] == 'err':
+        return a[1:] == b[1:]
+    x, y = a[1], b[1]
+    return (np.array_equal(x.parent, y.parent) and np.array_equal(x.edge_len, y.edge_len, equal_nan=True)
+            and np.array_equal(x.has_len, y.has_len) and x.labels == y.labels
+            and np.array_equal(x.child_off, y.child_off) and np.array_equal(x.child_idx, y.child_idx)
+            and np.array_equal(x.level, y.level) and x.is_rooted == y.is_rooted)
+
+
+NEWICK_CASES = [
+    "(A:1,B:2);", "[&R] ((A:0.1,B:0.2)X:0.3,C:1e-3)root;", "(A,B,(C,D)E)F;", "('it''s':1,'b c':2)'r';",
+    "(A:1,B:2", "(A:1,,B:2);", "(A:,B:1);", "(A:1[c],B[comment]:2)[x];", "(A:1,B:2));", "A;", ";", "",
+    "(A:nan,B:inf);", "(A:1_0,B:0x10);", "(A:abc,B:def);", "( A : 1.5 , B :\t2 ) ;", "(A:1,B:2)C:3;D",
+    "('a:1,b:2);", "(a]b:1,c[d:2);", "(A:'1',B:2);", "(A:+.5,B:-1.E3,C:1.,D:.e1);", "('''':1,'''a':2);",
+    "(A:1,'b'c:2);", "(A B:1, C  D :2);", "(A:1\n,\nB:2\n)\n;\n", "((((A))));", "(,);", "(:1,:2):3;",
+    "(A:1e400,B:1e-400,C:00012.5000);", "(A:1,B:2);(C:1,D:2);", "[&U](A:1,B:2);", "(A:1:2,B:3);", "(A::1,B:3);",
+    "(a'b':1,c:2);", "(\x1fA\x1f:1,\x0bB:2);", "(A:1,B:2)é;", "(A:1e-:8,B:2);", "(A:1x:2,B:zz);", "(''':1,B:2);",
+]
+
+
+@pytest.mark.parametrize('text', NEWICK_CASES)
+def test_native_newick_scanner_equals_python_token_loop_on_odd_inputs(text, monkeypatch):
+    """include/apples_io.h:apples_newick_scan against the token loop of apples_amd/tree.py (SURVEY
+    Appendix B contract): quoted labels with doubled quotes, comments, stray brackets and quotes,
+    white space, missing / repeated / non-decimal branch lengths, polytomies, unbalanced input,
+    text after the semicolon, non-ASCII labels -- same arrays, or the same error with the same words."""
+    a, b = _parse_both(text, monkeypatch)
+    assert _same_tree(a, b), (text, a[:3], b[:3])
+
+
+def test_native_newick_scanner_equals_python_token_loop_on_random_trees(monkeypatch):
+    import random
+    rng = random.Random(5)
+
+    def label():
+        k = rng.random()
+        if k < 0.3:
+            return ''
+        if k < 0.5:
+            return "'q %d''x'" % rng.randrange(100)
+        if k < 0.6:
+            return ' t%d ' % rng.randrange(1000)
+        return 't%d' % rng.randrange(100000)
+
+    def length():
+        k = rng.random()
+        if k < 0.15:
+            return ''
+        if k < 0.25:
+            return ':%d' % rng.randrange(10)
+        if k < 0.3:
+            return ': %.3e ' % rng.random()
+        if k < 0.32:
+            return ':-0.5'
+        return ':' + repr(rng.random() * 10 ** rng.randrange(-8, 3))
+
+    def subtree(depth=0):
+        comment = '[c%d]' % rng.randrange(9) if rng.random() < 0.05 else ''
+        if depth > 12 or rng.random() < 0.35:
+            return label() + comment + length()
+        k = 2 if rng.random() < 0.8 else rng.randrange(1, 6)
+        return '(' + ','.join(subtree(depth + 1) for _ in range(k)) + ')' + label() + length()
+
+    for _ in range(800):
+        text = subtree() + ';'
+        if rng.random() < 0.15:  # one character replaced: mostly malformed, sometimes just different
+            j = rng.randrange(len(text))
+            text = text[:j] + rng.choice("(),:;'[]x ") + text[j + 1:]
+        a, b = _parse_both(text, monkeypatch)
+        assert _same_tree(a, b), (text[:300], a[:3], b[:3])
