@@ -971,6 +971,7 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.slot_node = ctx->d_col_node; s.slot_level = ctx->d_col_level; s.slot_rep = ctx->d_col_perm;
     s.node_level = ctx->tree.level;
     s.n_members = n_cols; s.n_reps = n_cols; s.all_singleton = 1; s.table_mode = 1; s.self_slot = d_self;
+    s.cols_all_in_tree = std::all_of(ctx->h_col_node.begin(), ctx->h_col_node.end(), [](int32_t v) { return v >= 0; });
     s.thr = ctx->params.filt_threshold; s.baseobs = ctx->params.base_observation; s.height = ctx->tree.height;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.out = d_out;

@@ -199,6 +199,7 @@ struct SelectArgs {
     int64_t n_members, n_reps;
     int all_singleton;
     int table_mode;           // 1: -d semantics (rows not in the tree are ignored entirely)
+    int cols_all_in_tree;     // table mode: every column is a tree leaf (no per-entry node test while streaming)
     const int32_t *self_slot; // [nq] or nullptr
     double thr;
     int baseobs;
