@@ -549,18 +549,32 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
                 auto refill = [&](double lo_d, int lo_i) {
                     filled = 0; head = 0;
                     int seen = 0;
-                    for (int64_t s = tid; s < nm; s += APPLES_TPB) {
-                        if (early_node && a.slot_node[s] < 0) continue;
-                        const double d = row[s];
-                        const int i = a.slot_rep[s];
-                        if (!(d >= 0 && d > thr) || !key_lt(lo_d, lo_i, d, i)) continue;
-                        ++seen;
-                        int pos = filled < KL ? filled : KL;
-                        while (pos > 0 && key_lt(d, i, cd[pos - 1], ci[pos - 1])) --pos;
-                        if (pos < KL) {
-                            for (int k = (filled < KL ? filled : KL - 1); k > pos; --k) { cd[k] = cd[k - 1]; ci[k] = ci[k - 1]; }
-                            cd[pos] = d; ci[pos] = i;
-                            if (filled < KL) ++filled;
+                    for (int64_t s0 = tid; s0 < nm; s0 += 4 * APPLES_TPB) {  // four independent loads in flight
+                        double dd[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int64_t s = s0 + u * APPLES_TPB;
+                            dd[u] = s < nm ? row[s] : -1.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int64_t s = s0 + u * APPLES_TPB;
+                            const double d = dd[u];
+                            if (!(d >= 0 && d > thr) || d < lo_d) continue;
+                            if (early_node && a.slot_node[s] < 0) continue;
+                            // the index decides ties only: beyond the cut and beyond the cache's last key it is not needed
+                            const bool fits = filled < KL || d <= cd[KL - 1];
+                            if (d > lo_d && !fits) { ++seen; continue; }
+                            const int i = a.slot_rep[s];
+                            if (!key_lt(lo_d, lo_i, d, i)) continue;
+                            ++seen;
+                            int pos = filled < KL ? filled : KL;
+                            while (pos > 0 && key_lt(d, i, cd[pos - 1], ci[pos - 1])) --pos;
+                            if (pos < KL) {
+                                for (int k = (filled < KL ? filled : KL - 1); k > pos; --k) { cd[k] = cd[k - 1]; ci[k] = ci[k - 1]; }
+                                cd[pos] = d; ci[pos] = i;
+                                if (filled < KL) ++filled;
+                            }
                         }
                     }
                     more = seen > filled;
