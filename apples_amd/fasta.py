@@ -134,6 +134,11 @@ def _load_io():
                 lib.apples_newick_scan.restype = ctypes.c_int
                 lib.apples_newick_scan.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64] + \
                     [ctypes.c_void_p] * 11
+            if hasattr(lib, 'apples_max_clusters'):
+                lib.apples_max_clusters.restype = ctypes.c_int
+                lib.apples_max_clusters.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_int32, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p]
             _io_lib = lib
     return _io_lib or None
 

@@ -12,6 +12,9 @@ method: the fewest clusters such that every pairwise leaf distance inside a clus
   off and its remaining leaves become a cluster;
 * what is left at the end is one more cluster; one-leaf clusters get the id ``-1``.
 
+The sweep also exists natively (include/apples_io.h: apples_max_clusters), statement for statement;
+:func:`max_clusters` uses it when libapples_io.so is there, and the two are compared in the tests.
+
 **Parity unpinned**: no TreeCluster run exists in this environment to compare against; the
 polytomy resolution order and cluster numbering follow the tool's documented behaviour as
 recalled, not a verified trace.  Cluster assignment is an *input* of the hot path (a
@@ -63,8 +66,40 @@ def _postorder(children, root, n_original):
     return order
 
 
+def _max_clusters_native(tree, threshold):
+    """The sweep through libapples_io.so (include/apples_io.h: apples_max_clusters); None without the library."""
+    import ctypes
+    import numpy as np
+    from .fasta import _load_io
+    lib = _load_io()
+    if lib is None or not hasattr(lib, 'apples_max_clusters') or tree.n_nodes == 0:
+        return None
+    off = np.ascontiguousarray(tree.child_off, np.int32)
+    idx = np.ascontiguousarray(tree.child_idx, np.int32)
+    elen = np.ascontiguousarray(np.where(tree.has_len, tree.edge_len, 0.0), np.float64)
+    n_leaves = int(np.count_nonzero(np.diff(off) == 0))
+    order = np.empty(max(n_leaves, 1), np.int32)
+    ends = np.empty(n_leaves + 2, np.int32)
+    n_cl = ctypes.c_int32(0)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    if lib.apples_max_clusters(tree.n_nodes, ptr(off), ptr(idx), ptr(elen), int(tree.root), float(threshold), ptr(order),
+                               ptr(ends), ctypes.byref(n_cl)) != 0:
+        return None
+    labels = tree.labels
+    names = [labels[u] for u in order[:int(ends[n_cl.value])].tolist()]
+    e = ends[:n_cl.value + 1].tolist()
+    return [names[a:b] for a, b in zip(e[:-1], e[1:])]
+
+
 def max_clusters(tree, threshold):
     """[[leaf label, ...], ...] in the order the sweep closes them (the remainder last)."""
+    native = _max_clusters_native(tree, threshold)
+    if native is not None:
+        return native
+    return _max_clusters_py(tree, threshold)
+
+
+def _max_clusters_py(tree, threshold):
     children, elen = _binarize(tree)
     total = len(children)
     deleted = [False] * total

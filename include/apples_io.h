@@ -44,6 +44,17 @@ int apples_newick_scan(const uint8_t *text, int64_t n_bytes, int64_t cap, int32_
                        double *length, uint8_t *length_state, int64_t *length_off, int32_t *length_len,
                        int64_t *n_nodes);
 
+/* apples_max_clusters is the clustering sweep of apples_amd/treecluster.py:max_clusters (the
+ * TreeCluster "max" method the reference runs as an external tool with -t 1.2*f,
+ * apples/Reference.py:87-88; restated from the published algorithm, parity unpinned -- see that
+ * module) on the tree's arrays: children in file order as CSR, edge lengths with 0 where the Newick
+ * had none.  Output: the leaves (node ids) cluster by cluster in the order the sweep closes the
+ * clusters, leaves of a cluster left to right (leaf_order[n_leaves]), and the clusters' end offsets
+ * into it (cluster_end[n_leaves + 1], cluster_end[0] = 0).  Returns 0. */
+int apples_max_clusters(int32_t n_nodes, const int32_t *child_off, const int32_t *child_idx,
+                        const double *edge_len, int32_t root, double threshold, int32_t *leaf_order,
+                        int32_t *cluster_end, int32_t *n_clusters);
+
 #ifdef __cplusplus
 }
 #endif

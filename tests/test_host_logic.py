@@ -409,3 +409,39 @@ def test_native_newick_scanner_equals_python_token_loop_on_random_trees(monkeypa
             text = text[:j] + rng.choice("(),:;'[]x ") + text[j + 1:]
         a, b = _parse_both(text, monkeypatch)
         assert _same_tree(a, b), (text[:300], a[:3], b[:3])
+
+
+def test_native_clustering_sweep_equals_the_python_sweep():
+    """include/apples_io.h:apples_max_clusters against apples_amd/treecluster.py:_max_clusters_py on random
+    trees with polytomies, unifurcations, zero and missing lengths, at thresholds from "every leaf alone"
+    to "one cluster": the same clusters, in the same order, leaves in the same order."""
+    import random
+    from apples_amd import treecluster as C
+    from apples_amd.tree import parse_newick
+    rng = random.Random(9)
+
+    def length():
+        k = rng.random()
+        if k < 0.1:
+            return ''
+        if k < 0.15:
+            return ':0'
+        return ':' + repr(rng.random() * rng.choice([0.001, 0.01, 0.1, 1.0]))
+
+    def subtree(depth=0):
+        if depth > 10 or rng.random() < 0.3:
+            return 't%d' % rng.randrange(10 ** 9) + length()
+        r = rng.random()
+        k = 2 if r < 0.7 else (1 if r < 0.75 else rng.randrange(3, 7))
+        return '(' + ','.join(subtree(depth + 1) for _ in range(k)) + ')' + length()
+
+    checked = 0
+    for _ in range(300):
+        tree = parse_newick(subtree() + ';')
+        for thr in (0.0, 0.05, 0.24, 1.0, 100.0):
+            native = C._max_clusters_native(tree, thr)
+            if native is None:
+                pytest.skip('libapples_io.so not built')
+            assert native == C._max_clusters_py(tree, thr)
+            checked += 1
+    assert checked == 1500
