@@ -340,13 +340,14 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     if (ctx->params.max_batch > 0) batch = std::min(batch, (int64_t)ctx->params.max_batch);
     int64_t per_q = stride * 8 + members * 12 + (int64_t)(t.height + 2) * 4 + (need_counts ? stride * 4 : 0) +
                     (need_fused ? stride * 12 + stride / 16 : 0);
-    // batch buffers: up to 160 GiB, at most 55 % of what is free on the card (288 GB HBM3E; the sweep
-    // scratch below takes up to 40 GiB more; bigger batches amortise the sweep's tail: at 200 k leaves
-    // 16 k-query batches are 13 % faster than 5 k, 25 k-query batches another 3 %)
-    int64_t budget_gib = 160;
+    // batch buffers: up to 96 GiB, at most 40 % of what is free on the card (288 GB HBM3E; bigger
+    // batches amortise the sweep's tail: at 200 k leaves 16 k-query batches are 13 % faster than 5 k).
+    // Allocating them is not free: with 160 GiB a resident C3 pass is another 4 % faster, but a one-shot
+    // command-line run of the same size pays 1.1 to 3.4 s more for the allocation.
+    int64_t budget_gib = 96;
     {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_gib = std::max<int64_t>(8, std::min<int64_t>(160, (int64_t)(fr >> 30) * 11 / 20));
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_gib = std::max<int64_t>(8, std::min<int64_t>(96, (int64_t)(fr >> 30) * 2 / 5));
     }
     if (const char *e = getenv("APPLES_BATCH_GIB")) budget_gib = std::max<int64_t>(1, atoll(e));  // tuning knob
     int64_t capq = std::max<int64_t>(32, ((need_alt ? budget_gib / 2 : budget_gib) << 30) / std::max<int64_t>(per_q, 1));
