@@ -560,7 +560,9 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     sm.cls_count = w.cls_count;
     sm.cursor = w.cls_count + 4;
     if (launch_sweep_mixed(ctx, sm, b, nq, w.small.wgs, w.big.wgs, st)) return 1;
-    // whatever did not fit a small team's scratch (usually nothing)
+    // whatever did not fit a small team's scratch (usually nothing; nothing at all when that scratch
+    // holds the whole tree: the overflow test in the kernel is `cap < n_nodes && ...`)
+    if (w.small.cap >= ctx->tree.n_nodes) return 0;
     b.work_list = w.overflow_list;
     b.work_count = w.overflow_count;
     b.cursor = w.cls_count + 6;
