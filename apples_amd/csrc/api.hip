@@ -298,13 +298,13 @@ void free_workspace(Workspace &w) {
         BatchBuf &a = w.alt;
         dev_free(a.dist); dev_free(a.counts); dev_free(a.obs_node); dev_free(a.obs_dist); dev_free(a.cnt_gt);
         dev_free(a.n_obs); dev_free(a.seg_slot); dev_free(a.seg_cnt); dev_free(a.dist_slow); dev_free(a.slow_list);
-        dev_free(a.slow_count); dev_free(a.route_list); dev_free(a.route_count); dev_free(a.overflow_list);
-        dev_free(a.overflow_count); dev_free(a.cls_list); dev_free(a.cls_count);
+        dev_free(a.route_list); dev_free(a.overflow_list);
+        dev_free(a.cls_list); dev_free(a.cls_count);  // (the other counters live inside cls_count's block)
     }
     dev_free(w.dist); dev_free(w.counts); dev_free(w.obs_node); dev_free(w.obs_dist); dev_free(w.cnt_gt);
-    dev_free(w.n_obs); dev_free(w.overflow_list); dev_free(w.overflow_count); dev_free(w.route_list); dev_free(w.route_count);
+    dev_free(w.n_obs); dev_free(w.overflow_list); dev_free(w.route_list);
     dev_free(w.cls_list); dev_free(w.cls_count); dev_free(w.seg_slot); dev_free(w.seg_cnt);
-    dev_free(w.dist_slow); dev_free(w.slow_list); dev_free(w.slow_count);
+    dev_free(w.dist_slow); dev_free(w.slow_list);
     free_sweep(w.small);
     free_sweep(w.big);
     w = Workspace();
@@ -379,14 +379,16 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
             if (dev_alloc(ctx, &w.seg_cnt, batch * std::max<int64_t>(stride / 64, 1))) return 1;
             if (dev_alloc(ctx, &w.dist_slow, batch * std::max<int64_t>(stride, 1))) return 1;
             if (dev_alloc(ctx, &w.slow_list, batch)) return 1;
-            if (dev_alloc(ctx, &w.slow_count, 1)) return 1;
         }
         if (dev_alloc(ctx, &w.route_list, batch)) return 1;
-        if (dev_alloc(ctx, &w.route_count, 1)) return 1;
         if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
-        if (dev_alloc(ctx, &w.overflow_count, 1)) return 1;
         if (dev_alloc(ctx, &w.cls_list, 4 * batch)) return 1;
-        if (dev_alloc(ctx, &w.cls_count, 8)) return 1;
+        // one block for every per-batch counter, cleared by one memset: [0..3] size-class counts,
+        // [4..6] the sweep launches' work cursors, [8] routed, [9] top-up list, [10] overflow
+        if (dev_alloc(ctx, &w.cls_count, 16)) return 1;
+        w.route_count = w.cls_count + 8;
+        w.slow_count = w.cls_count + 9;
+        w.overflow_count = w.cls_count + 10;
         if (alt && set == 0) swap_bufs(w);
     }
     w.has_alt = alt;
@@ -554,7 +556,8 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     // wavefront-sized teams for the size-class queues
     b.work_list = w.route_list;
     b.work_count = w.route_count;
-    HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), st));
+    const bool can_overflow = w.small.cap < ctx->tree.n_nodes;
+    if (can_overflow) HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), st));
     SweepArgs sm = sweep_args(ctx, w.small, out, false);
     sm.cls_list = w.cls_list;  // size-class queues written by the selection kernels, largest first
     sm.cls_count = w.cls_count;
@@ -562,7 +565,7 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     if (launch_sweep_mixed(ctx, sm, b, nq, w.small.wgs, w.big.wgs, st)) return 1;
     // whatever did not fit a small team's scratch (usually nothing; nothing at all when that scratch
     // holds the whole tree: the overflow test in the kernel is `cap < n_nodes && ...`)
-    if (w.small.cap >= ctx->tree.n_nodes) return 0;
+    if (!can_overflow) return 0;
     b.work_list = w.overflow_list;
     b.work_count = w.overflow_count;
     b.cursor = w.cls_count + 6;
@@ -617,10 +620,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
         if (pipelined && i > 0) swap_bufs(w);  // host view: w.* now names buffer set `set`
         if (pipelined && i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_back[set], 0));  // set free again
         hipEvent_t *e = &ev[(size_t)i * 6];
-        HIP_TRY(ctx, hipMemsetAsync(w.route_count, 0, sizeof(int32_t), front));
-        HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 8 * sizeof(int32_t), front));
+        HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 16 * sizeof(int32_t), front));  // every counter of the batch
         if (fused) {
-            HIP_TRY(ctx, hipMemsetAsync(w.slow_count, 0, sizeof(int32_t), front));
             HIP_TRY(ctx, hipEventRecord(e[0], front));
             if (fused_counts_format(ctx, qb))  // the matrix-core kernel writes only the non-empty segments' counts
                 HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (w.stride / 64) * sizeof(int32_t), front));
@@ -981,8 +982,7 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.out = d_out;
     s.big_threshold = big_threshold(); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
-    HIP_TRY(ctx, hipMemsetAsync(w.route_count, 0, sizeof(int32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 8 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 16 * sizeof(int32_t), ctx->stream));  // every counter of the batch
     pt.flush();
     pt.begin(APPLES_T_SELECT);
     if (launch_select(ctx, s, nq)) return 1;
