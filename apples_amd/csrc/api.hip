@@ -39,6 +39,44 @@ void dev_free(void *p) {
 
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Buffers of query blocks come from a small cache that lives with the context: a host-buffer call
+// (apples_place_from_sequences) would otherwise pay hipMalloc + hipFree of several hundred MB each time.
+template <typename T>
+int blk_alloc(apples_ctx *ctx, T **p, int64_t n) {
+    const size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T);
+    size_t best = ctx->blk_cache.size();
+    for (size_t i = 0; i < ctx->blk_cache.size(); ++i) {
+        const size_t have = ctx->blk_cache[i].first;
+        if (have >= bytes && have <= 2 * bytes + 4096 && (best == ctx->blk_cache.size() || have < ctx->blk_cache[best].first)) best = i;
+    }
+    if (best < ctx->blk_cache.size()) {
+        *p = (T *)ctx->blk_cache[best].second;
+        ctx->blk_size[*p] = ctx->blk_cache[best].first;
+        ctx->blk_cache.erase(ctx->blk_cache.begin() + best);
+        return 0;
+    }
+    if (dev_alloc(ctx, p, n)) {  // out of memory: drop the cache and try once more
+        for (auto &c : ctx->blk_cache) dev_free(c.second);
+        ctx->blk_cache.clear();
+        if (dev_alloc(ctx, p, n)) return 1;
+    }
+    ctx->blk_size[*p] = bytes;
+    return 0;
+}
+
+void blk_free(apples_ctx *ctx, void *p) {
+    if (!p) return;
+    auto it = ctx->blk_size.find(p);
+    if (it == ctx->blk_size.end()) { dev_free(p); return; }
+    const size_t bytes = it->second;
+    ctx->blk_size.erase(it);
+    if (ctx->blk_cache.size() >= 24) {  // keep the cache bounded: the oldest entry goes
+        dev_free(ctx->blk_cache.front().second);
+        ctx->blk_cache.erase(ctx->blk_cache.begin());
+    }
+    ctx->blk_cache.emplace_back(bytes, p);
+}
+
 // BLOSUM45-derived dissimilarities (FastTree2's table, the data apples/distance.py:12-415 reads);
 // supplied by the host in params? No: it is part of the algorithm, so it is compiled in via
 // blosum45_table.inc, generated from apples_amd/data/blosum45_dist.txt by the build script.
@@ -255,11 +293,11 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
     // existing query blocks were packed with 2 planes: repack them
     for (auto &qb : ctx->blocks) {
         if (!qb.live || qb.planes == 8) continue;
-        dev_free(qb.packed);
-        dev_free(qb.qf4);  // the fp4 image only serves the ACGT- fast path
+        blk_free(ctx, qb.packed);
+        blk_free(ctx, qb.qf4);  // the fp4 image only serves the ACGT- fast path
         qb.qf4 = nullptr;
         int64_t w = qb.n_pad * a.G * 9;
-        if (dev_alloc(ctx, &qb.packed, w)) return 1;
+        if (blk_alloc(ctx, &qb.packed, w)) return 1;
         HIP_TRY(ctx, hipMemsetAsync(qb.packed, 0, (size_t)w * sizeof(uint4), ctx->stream));
         int *d_ex2 = nullptr;
         if (dev_alloc(ctx, &d_ex2, 1)) return 1;
@@ -413,64 +451,96 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     return 0;
 }
 
-int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t *self_row, QueryBlock *qb) {
+void free_block(apples_ctx *ctx, QueryBlock *qb) {
+    blk_free(ctx, qb->table); blk_free(ctx, qb->raw); blk_free(ctx, qb->packed); blk_free(ctx, qb->qf4);
+    blk_free(ctx, qb->aa_idx); blk_free(ctx, qb->aa_mask); blk_free(ctx, qb->self_slot); blk_free(ctx, qb->out);
+    *qb = QueryBlock();
+}
+
+// Device buffers of a block of n queries (nothing uploaded yet); padding rows are preset on `st`.
+int alloc_block(apples_ctx *ctx, int64_t n, const int32_t *self_row, int planes, QueryBlock *qb, hipStream_t st) {
     DevAlign &a = ctx->aln;
     qb->n = n;
     qb->n_pad = round_up(std::max<int64_t>(n, 1), 32);
-    if (dev_upload(ctx, &qb->raw, queries, n * a.L)) return 1;
+    if (blk_alloc(ctx, &qb->raw, n * a.L)) return 1;
     std::vector<int32_t> self(std::max<int64_t>(n, 1), -1);
     if (self_row)
         for (int64_t i = 0; i < n; ++i) {
             if (self_row[i] >= a.n_refs) { ctx->err = "self_row out of range"; return 1; }
             self[i] = self_row[i] >= 0 ? a.row_slot[self_row[i]] : -1;
         }
-    if (dev_upload(ctx, &qb->self_slot, self.data(), (int64_t)self.size())) return 1;
-    if (dev_alloc(ctx, &qb->out, std::max<int64_t>(n, 1))) return 1;
+    if (blk_alloc(ctx, &qb->self_slot, (int64_t)self.size())) return 1;
+    HIP_TRY(ctx, hipMemcpyAsync(qb->self_slot, self.data(), self.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));  // `self` goes out of scope
+    if (blk_alloc(ctx, &qb->out, std::max<int64_t>(n, 1))) return 1;
     if (ctx->params.model == APPLES_SCOREDIST) {
         int Lpad = (a.L + 15) / 16 * 16;
-        if (dev_alloc(ctx, &qb->aa_idx, qb->n_pad * Lpad)) return 1;
-        HIP_TRY(ctx, hipMemsetAsync(qb->aa_idx, 20, (size_t)qb->n_pad * Lpad, ctx->stream));
-        if (dev_alloc(ctx, &qb->aa_mask, qb->n_pad * (Lpad / 16))) return 1;
-        HIP_TRY(ctx, hipMemsetAsync(qb->aa_mask, 0, (size_t)qb->n_pad * (Lpad / 16) * 2, ctx->stream));
-        if (launch_pack_aa(ctx, qb->raw, n, a.L, qb->aa_idx, qb->aa_mask, 0, true)) return 1;
+        if (blk_alloc(ctx, &qb->aa_idx, qb->n_pad * Lpad)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(qb->aa_idx, 20, (size_t)qb->n_pad * Lpad, st));
+        if (blk_alloc(ctx, &qb->aa_mask, qb->n_pad * (Lpad / 16))) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(qb->aa_mask, 0, (size_t)qb->n_pad * (Lpad / 16) * 2, st));
     } else {
-        int *d_exotic = nullptr;
-        if (dev_alloc(ctx, &d_exotic, 1)) return 1;
-        HIP_TRY(ctx, hipMemsetAsync(d_exotic, 0, sizeof(int), ctx->stream));
-        int planes = a.planes;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            int64_t w = qb->n_pad * a.G * (planes + 1);
-            if (dev_alloc(ctx, &qb->packed, w)) return 1;
-            HIP_TRY(ctx, hipMemsetAsync(qb->packed, 0, (size_t)w * sizeof(uint4), ctx->stream));
-            if (launch_pack_rows(ctx, qb->raw, n, a.L, planes, qb->packed, 0, true, d_exotic)) return 1;
-            int exotic = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(&exotic, d_exotic, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (planes == 2 && exotic) {
-                dev_free(qb->packed);
-                qb->packed = nullptr;
-                if (repack_to_bytes(ctx)) return 1;
-                planes = 8;
-                continue;
-            }
-            break;
-        }
         qb->planes = planes;
-        dev_free(d_exotic);
-        if (planes == 2 && dist_mfma_enabled()) {  // int8 operand image for the matrix-core distance kernel
+        int64_t w = qb->n_pad * a.G * (planes + 1);
+        if (blk_alloc(ctx, &qb->packed, w)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(qb->packed, 0, (size_t)w * sizeof(uint4), st));
+        if (planes == 2 && dist_mfma_enabled()) {  // fp4 operand image for the matrix-core distance kernel
             const int64_t n128 = round_up(qb->n_pad, 256) + 256;  // a sub-batch may start at any multiple of 32
-            if (dev_alloc(ctx, &qb->qf4, n128 * a.G * 256)) return 1;
-            if (launch_expand_queries_f4(ctx, qb->raw, n, qb->qf4, n128)) return 1;
+            if (blk_alloc(ctx, &qb->qf4, n128 * a.G * 256)) return 1;
         }
+    }
+    return 0;
+}
+
+// Upload queries [q0, q0 + nq) of the block from the caller's buffer and bring them into the device
+// layouts, all on `st`.  q0 is a multiple of 32.  Symbols beyond ACGT- raise the context's d_exotic flag
+// (2-plane packing only); the caller reads it.
+int fill_block(apples_ctx *ctx, QueryBlock *qb, const uint8_t *queries, int64_t q0, int64_t nq, hipStream_t st) {
+    DevAlign &a = ctx->aln;
+    if (nq <= 0) return 0;
+    HIP_TRY(ctx, hipMemcpyAsync(qb->raw + q0 * a.L, queries + q0 * a.L, (size_t)nq * a.L, hipMemcpyHostToDevice, st));
+    if (ctx->params.model == APPLES_SCOREDIST) {
+        int Lpad = (a.L + 15) / 16 * 16;
+        return launch_pack_aa(ctx, qb->raw + q0 * a.L, nq, a.L, qb->aa_idx + q0 * Lpad, qb->aa_mask + q0 * (Lpad / 16), 0, true, st);
+    }
+    if (launch_pack_rows(ctx, qb->raw + q0 * a.L, nq, a.L, qb->planes, qb->packed + q0 * a.G * (qb->planes + 1), 0, true,
+                         ctx->d_exotic, st)) return 1;
+    if (qb->qf4) {
+        const int64_t n128 = round_up(qb->n_pad, 256) + 256;
+        const bool last = q0 + nq >= qb->n;  // the last chunk also zeroes the image's padding rows
+        if (launch_expand_queries_f4(ctx, qb->raw + q0 * a.L, nq, qb->qf4 + q0 * (int64_t)a.G * 256, last ? n128 - q0 : nq, st)) return 1;
+    }
+    return 0;
+}
+
+// read and clear the exotic-symbol flag (after the packing on `st` has drained)
+int take_exotic(apples_ctx *ctx, hipStream_t st, int *exotic) {
+    *exotic = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(exotic, ctx->d_exotic, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (*exotic) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_exotic, 0, sizeof(int), st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+// whole block at once on the context's stream (apples_queries_upload)
+int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t *self_row, QueryBlock *qb) {
+    DevAlign &a = ctx->aln;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (alloc_block(ctx, n, self_row, a.planes, qb, ctx->stream)) return 1;
+        if (fill_block(ctx, qb, queries, 0, n, ctx->stream)) return 1;
+        if (ctx->params.model == APPLES_SCOREDIST) break;
+        int exotic = 0;
+        if (take_exotic(ctx, ctx->stream, &exotic)) return 1;
+        if (!(exotic && qb->planes == 2)) break;
+        free_block(ctx, qb);  // symbols beyond ACGT-: widen the reference, pack again with 8 planes
+        if (repack_to_bytes(ctx)) return 1;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     qb->live = true;
     return 0;
-}
-
-void free_block(QueryBlock *qb) {
-    dev_free(qb->table); dev_free(qb->raw); dev_free(qb->packed); dev_free(qb->qf4); dev_free(qb->aa_idx); dev_free(qb->aa_mask); dev_free(qb->self_slot); dev_free(qb->out);
-    *qb = QueryBlock();
 }
 
 struct PhaseTimer {
@@ -585,7 +655,14 @@ int dist_tile_for(int64_t nq) {
 // run distance -> selection -> sweep back to back on one stream (default).  With APPLES_PIPELINE > 1
 // they flow through two streams instead (front = distance + selection, back = sweep, two sets of
 // batch buffers); measured slower on MI355X, kept as an experiment knob.
-int run_block(apples_ctx *ctx, QueryBlock &qb) {
+// `feed` (optional): the block's queries are still in the caller's host buffer.  Chunk i = the queries of
+// sub-batch i is uploaded and packed on stream2 while the main stream works on sub-batch i - 1, so that
+// the copy hides behind the kernels (apples_place_from_sequences: host buffer in, host buffer out).
+struct Feeder {
+    const uint8_t *host;
+};
+
+int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     const DevAlign &a = ctx->aln;
     bool hybrid = ctx->params.criterion == APPLES_HYBRID;
     // fused path: threshold compaction in the distance kernel's epilogue; only queries that need
@@ -610,6 +687,15 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
     }
     hipEvent_t *ev = ctx->ev_pool.data() + 2;
     hipEvent_t e_start = ctx->ev_pool[0], e_stop = ctx->ev_pool[1];
+    if (feed) {
+        while (ctx->ev_feed.size() < (size_t)n_sub) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->ev_feed.push_back(e);
+        }
+        if (fill_block(ctx, &qb, feed->host, 0, std::min(step, qb.n), ctx->stream2)) return 1;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_feed[0], ctx->stream2));
+    }
     HIP_TRY(ctx, hipEventRecord(e_start, front));
     if (pipelined) HIP_TRY(ctx, hipStreamWaitEvent(back, e_start, 0));
     int launches = 0;
@@ -620,6 +706,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
         if (pipelined && i > 0) swap_bufs(w);  // host view: w.* now names buffer set `set`
         if (pipelined && i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_back[set], 0));  // set free again
         hipEvent_t *e = &ev[(size_t)i * 6];
+        if (feed) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[i], 0));  // chunk i is on the device
         HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 16 * sizeof(int32_t), front));  // every counter of the batch
         if (fused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
@@ -667,6 +754,11 @@ int run_block(apples_ctx *ctx, QueryBlock &qb) {
         if (run_sweep(ctx, qb.out + q0, nq, back)) return 1;
         HIP_TRY(ctx, hipEventRecord(e[4], back));
         if (pipelined) HIP_TRY(ctx, hipEventRecord(ctx->ev_back[set], back));
+        if (feed && i + 1 < n_sub) {  // the next chunk travels while this sub-batch's kernels run
+            const int64_t q1 = (i + 1) * step;
+            if (fill_block(ctx, &qb, feed->host, q1, std::min(step, qb.n - q1), ctx->stream2)) return 1;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_feed[i + 1], ctx->stream2));
+        }
     }
     if (pipelined) {
         HIP_TRY(ctx, hipEventRecord(e_stop, back));
@@ -727,6 +819,7 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
     for (int i = 0; i < 8; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return fail(); }
     if (tree->n_nodes < 2) { ctx->err = "tree needs at least two nodes"; return fail(); }
+    if (dev_alloc(ctx, &ctx->d_exotic, 1) || hipMemset(ctx->d_exotic, 0, sizeof(int)) != hipSuccess) return fail();
     if (upload_tree(ctx, tree)) return fail();
     if (aln) {
         if (setup_alignment(ctx, tree, aln)) return fail();
@@ -739,6 +832,7 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
 }
 
 int apples_set_params(apples_ctx *ctx, const apples_params *params) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // the caller's thread may have another device current
     int model = ctx->params.model;
     if (ctx->has_aln && params->model != model) { ctx->err = "the distance model is fixed at context creation"; return 1; }
     ctx->params = *params;
@@ -780,10 +874,15 @@ int apples_set_params(apples_ctx *ctx, const apples_params *params) {
 
 void apples_ctx_destroy(apples_ctx *ctx) {
     if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
-    for (auto &qb : ctx->blocks) free_block(&qb);
+    for (auto &qb : ctx->blocks) free_block(ctx, &qb);
+    for (auto &c : ctx->blk_cache) dev_free(c.second);
+    ctx->blk_cache.clear();
+    dev_free(ctx->d_exotic);
+    for (auto &e : ctx->ev_feed) (void)hipEventDestroy(e);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos);
@@ -809,16 +908,21 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     delete ctx;
 }
 
-int apples_queries_upload(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries, const int32_t *self_row,
-                          int64_t *handle) {
-    if (!ctx->has_aln) { ctx->err = "context has no alignment"; return 1; }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+static int new_block_slot(apples_ctx *ctx) {
     size_t slot = ctx->blocks.size();
     for (size_t i = 0; i < ctx->blocks.size(); ++i)
         if (!ctx->blocks[i].live) { slot = i; break; }
     if (slot == ctx->blocks.size()) ctx->blocks.emplace_back();
+    return (int)slot;
+}
+
+int apples_queries_upload(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries, const int32_t *self_row,
+                          int64_t *handle) {
+    if (!ctx->has_aln) { ctx->err = "context has no alignment"; return 1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     QueryBlock qb;
-    if (make_block(ctx, queries, n_queries, self_row, &qb)) { free_block(&qb); return 1; }
+    if (make_block(ctx, queries, n_queries, self_row, &qb)) { free_block(ctx, &qb); return 1; }
+    const int slot = new_block_slot(ctx);
     ctx->blocks[slot] = qb;
     *handle = (int64_t)slot;
     return 0;
@@ -826,7 +930,8 @@ int apples_queries_upload(apples_ctx *ctx, const uint8_t *queries, int64_t n_que
 
 int apples_queries_free(apples_ctx *ctx, int64_t handle) {
     if (handle < 0 || handle >= (int64_t)ctx->blocks.size() || !ctx->blocks[handle].live) { ctx->err = "bad handle"; return 1; }
-    free_block(&ctx->blocks[handle]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    free_block(ctx, &ctx->blocks[handle]);
     return 0;
 }
 
@@ -841,6 +946,7 @@ int apples_place_resident(apples_ctx *ctx, int64_t handle) {
 
 int apples_fetch_placements(apples_ctx *ctx, int64_t handle, apples_placement *out) {
     if (handle < 0 || handle >= (int64_t)ctx->blocks.size() || !ctx->blocks[handle].live) { ctx->err = "bad handle"; return 1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     QueryBlock &qb = ctx->blocks[handle];
     HIP_TRY(ctx, hipMemcpyAsync(out, qb.out, (size_t)qb.n * sizeof(apples_placement), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -853,14 +959,42 @@ int apples_placements_device_ptr(apples_ctx *ctx, int64_t handle, void **ptr) {
     return 0;
 }
 
+// Host buffer in, placements left on the device: the queries are uploaded and packed chunk by chunk on
+// a second stream while the kernels of the previous chunk run (Feeder above), so the copy of all but the
+// first chunk costs nothing.
+int apples_place_sequences_streamed(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries, const int32_t *self_row,
+                                    int64_t *handle) {
+    if (!ctx->has_aln) { ctx->err = "context has no alignment"; return 1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    QueryBlock qb;
+    const int planes = ctx->aln.planes;
+    if (alloc_block(ctx, n_queries, self_row, planes, &qb, ctx->stream2)) { free_block(ctx, &qb); return 1; }
+    qb.live = true;
+    Feeder feed{queries};
+    int rc = run_block(ctx, qb, &feed);
+    int exotic = 0;
+    if (!rc && ctx->params.model != APPLES_SCOREDIST) rc = take_exotic(ctx, ctx->stream2, &exotic);
+    if (!rc && exotic && planes == 2) {
+        // a query carried a symbol beyond ACGT-: the 2-plane images are not valid for it.  Rare: widen
+        // the reference to raw bytes and run the block again from a whole-block upload
+        free_block(ctx, &qb);
+        rc = make_block(ctx, queries, n_queries, self_row, &qb);
+        if (!rc) rc = run_block(ctx, qb);
+    }
+    if (rc) { (void)hipDeviceSynchronize(); free_block(ctx, &qb); return 1; }
+    const int slot = new_block_slot(ctx);
+    ctx->blocks[slot] = qb;
+    *handle = (int64_t)slot;
+    return 0;
+}
+
 int apples_place_from_sequences(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries, const int32_t *self_row,
                                 apples_placement *out) {
     if (n_queries == 0) return 0;
     int64_t h;
-    if (apples_queries_upload(ctx, queries, n_queries, self_row, &h)) return 1;
-    int rc = apples_place_resident(ctx, h);
-    if (!rc) rc = apples_fetch_placements(ctx, h, out);
-    free_block(&ctx->blocks[h]);
+    if (apples_place_sequences_streamed(ctx, queries, n_queries, self_row, &h)) return 1;
+    int rc = apples_fetch_placements(ctx, h, out);
+    free_block(ctx, &ctx->blocks[h]);
     return rc;
 }
 
@@ -933,7 +1067,7 @@ int apples_distances(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries,
                 }
             }
     }
-    free_block(&ctx->blocks[h]);
+    free_block(ctx, &ctx->blocks[h]);
     return rc;
 }
 
@@ -963,6 +1097,7 @@ static int setup_columns(apples_ctx *ctx, int64_t n_cols, const int32_t *col_nod
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->h_col_node.assign(col_node, col_node + n_cols);
     ctx->dcols = n_cols;
+    ++ctx->col_gen;  // resident tables permuted with the previous layout are stale from here on
     return 0;
 }
 
@@ -1048,25 +1183,23 @@ int apples_table_upload(apples_ctx *ctx, const double *dist, int64_t n_queries, 
     if (self_col)
         for (int64_t i = 0; i < n_queries; ++i)
             if (self_col[i] >= 0 && self_col[i] < n_cols) self[i] = col_slot[self_col[i]];
-    size_t slot = ctx->blocks.size();
-    for (size_t i = 0; i < ctx->blocks.size(); ++i)
-        if (!ctx->blocks[i].live) { slot = i; break; }
-    if (slot == ctx->blocks.size()) ctx->blocks.emplace_back();
     QueryBlock qb;
     qb.n = n_queries;
     qb.n_cols = n_cols;
+    qb.col_gen = ctx->col_gen;
     double *d_stage = nullptr;
     if (dev_upload(ctx, &d_stage, dist, n_queries * n_cols) || dev_alloc(ctx, &qb.table, n_queries * n_cols) ||
         dev_upload(ctx, &qb.self_slot, self.data(), (int64_t)self.size()) ||
         dev_alloc(ctx, &qb.out, std::max<int64_t>(n_queries, 1)) ||
         launch_permute_cols(ctx, d_stage, qb.table, ctx->d_col_perm, n_queries, n_cols)) {
         dev_free(d_stage);
-        free_block(&qb);
+        free_block(ctx, &qb);
         return 1;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     dev_free(d_stage);
     qb.live = true;
+    const int slot = new_block_slot(ctx);
     ctx->blocks[slot] = qb;
     *handle = (int64_t)slot;
     return 0;
@@ -1074,13 +1207,20 @@ int apples_table_upload(apples_ctx *ctx, const double *dist, int64_t n_queries, 
 
 static int run_table_block(apples_ctx *ctx, QueryBlock &qb) {
     bool hybrid = ctx->params.criterion == APPLES_HYBRID;
-    if (qb.n_cols != ctx->dcols) { ctx->err = "the column layout changed since this table was uploaded"; return 1; }
+    if (qb.n_cols != ctx->dcols || qb.col_gen != ctx->col_gen) {
+        ctx->err = "the column layout changed since this table was uploaded (another table with different columns was "
+                   "placed on this context): upload the table again";
+        return 1;
+    }
     if (ensure_workspace(ctx, qb.n_cols, qb.n_cols, qb.n, false, false, hybrid)) return 1;
     Workspace &w = ctx->ws;
     PhaseTimer pt{ctx};
-    hipEvent_t e_start, e_stop;
-    HIP_TRY(ctx, hipEventCreate(&e_start));
-    HIP_TRY(ctx, hipEventCreate(&e_stop));
+    while (ctx->ev_pool.size() < 2) {  // timing events live with the context
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    hipEvent_t e_start = ctx->ev_pool[0], e_stop = ctx->ev_pool[1];
     HIP_TRY(ctx, hipEventRecord(e_start, ctx->stream));
     for (int64_t q0 = 0; q0 < qb.n; q0 += w.batch) {
         int64_t nq = std::min(w.batch, qb.n - q0);
@@ -1091,8 +1231,6 @@ static int run_table_block(apples_ctx *ctx, QueryBlock &qb) {
     pt.flush();
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e_start, e_stop);
-    (void)hipEventDestroy(e_start);
-    (void)hipEventDestroy(e_stop);
     for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = pt.acc[i];
     ctx->t_ms[APPLES_T_TOTAL] = ms;
     return 0;

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/apples_hip.h"
@@ -85,6 +86,7 @@ struct QueryBlock {
     int32_t *self_slot = nullptr; // [n]
     apples_placement *out = nullptr;  // [n] device
     int planes = 0;
+    int64_t col_gen = 0;          // distance-table block: generation of the column layout it was permuted with
     bool live = false;
 };
 
@@ -155,7 +157,15 @@ struct apples_ctx {
     double *blosum = nullptr;  // 21x21 table (row/col 20 = gap -> 0)
     Workspace ws;
     std::vector<QueryBlock> blocks;
+    // buffers of freed query blocks, kept for the next block (a host-buffer call would otherwise pay
+    // hipMalloc + hipFree of a few hundred MB every time): size -> pointer, plus the size of every
+    // block buffer handed out
+    std::vector<std::pair<size_t, void *>> blk_cache;
+    std::unordered_map<void *, size_t> blk_size;
+    int *d_exotic = nullptr;         // device flag: a packed query block carried a symbol beyond ACGT-
+    std::vector<hipEvent_t> ev_feed; // "chunk i of a streamed block is uploaded and packed"
     // -d path: column layout cache
+    int64_t col_gen = 0;             // bumped whenever the column layout below is replaced
     int64_t dcols = 0;
     int32_t *d_col_perm = nullptr;   // [n_cols] slot -> column, level-sorted
     int32_t *d_col_node = nullptr;   // [n_cols] slot -> node
@@ -182,9 +192,9 @@ extern thread_local std::string g_create_error;
 // ---- kernels' host launchers (defined in the .hip files) -----------------------------------------
 // pack.hip
 int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, int planes, uint4 *d_out,
-                     int64_t slots_pad, bool query_layout, int *d_exotic);
+                     int64_t slots_pad, bool query_layout, int *d_exotic, hipStream_t st = nullptr);
 int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, uint16_t *d_mask,
-                   int64_t slots_pad, bool query_layout);
+                   int64_t slots_pad, bool query_layout, hipStream_t st = nullptr);
 // dist.hip
 int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
                   uint32_t *d_counts);
@@ -226,7 +236,8 @@ int launch_select_topup(apples_ctx *ctx, const SelectArgs &a, int64_t nq);  // l
 int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const int32_t *perm, int64_t nq, int64_t n_cols);
 bool dist_mfma_enabled();
 bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb);
-int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad);
+int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad,
+                             hipStream_t st = nullptr);
 int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
                         int32_t *seg_slot, int32_t *seg_cnt);
 int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,

@@ -537,11 +537,13 @@ bool dist_mfma_enabled() {
     return !off;
 }
 
-int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad) {
+int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad,
+                             hipStream_t st) {
     const DevAlign &a = ctx->aln;
+    if (!st) st = ctx->stream;
     const int64_t total = n_pad * a.G * 2 * 8;
     hipLaunchKernelGGL(k_expand_queries_f4, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0,
-                       ctx->stream, d_raw, n, a.L, a.G * 2, reinterpret_cast<uint32_t *>(d_out), n_pad);
+                       st, d_raw, n, a.L, a.G * 2, reinterpret_cast<uint32_t *>(d_out), n_pad);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -60,15 +60,16 @@ __global__ __launch_bounds__(APPLES_TPB) void k_pack_rows(const uint8_t *__restr
 }
 
 int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, int planes, uint4 *d_out,
-                     int64_t slots_pad, bool query_layout, int *d_exotic) {
+                     int64_t slots_pad, bool query_layout, int *d_exotic, hipStream_t st) {
     if (n_rows == 0) return 0;
+    if (!st) st = ctx->stream;
     int G = ctx->aln.G;
     dim3 grid((unsigned)((n_rows + APPLES_TPB - 1) / APPLES_TPB), (unsigned)G);
     if (planes == 2)
-        hipLaunchKernelGGL(k_pack_rows<2>, grid, dim3(APPLES_TPB), 0, ctx->stream, d_raw, n_rows, L, G, d_out, slots_pad,
+        hipLaunchKernelGGL(k_pack_rows<2>, grid, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, G, d_out, slots_pad,
                            query_layout ? 1 : 0, d_exotic);
     else
-        hipLaunchKernelGGL(k_pack_rows<8>, grid, dim3(APPLES_TPB), 0, ctx->stream, d_raw, n_rows, L, G, d_out, slots_pad,
+        hipLaunchKernelGGL(k_pack_rows<8>, grid, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, G, d_out, slots_pad,
                            query_layout ? 1 : 0, d_exotic);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -136,11 +137,12 @@ __global__ __launch_bounds__(APPLES_TPB) void k_pack_aa(const uint8_t *__restric
 }
 
 int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, uint16_t *d_mask,
-                   int64_t slots_pad, bool query_layout) {
+                   int64_t slots_pad, bool query_layout, hipStream_t st) {
     if (n_rows == 0) return 0;
+    if (!st) st = ctx->stream;
     int Lpad = (L + 15) / 16 * 16;
     dim3 grid((unsigned)((n_rows + APPLES_TPB - 1) / APPLES_TPB), (unsigned)(Lpad / 16));
-    hipLaunchKernelGGL(k_pack_aa, grid, dim3(APPLES_TPB), 0, ctx->stream, d_raw, n_rows, L, Lpad, d_out, d_mask,
+    hipLaunchKernelGGL(k_pack_aa, grid, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, Lpad, d_out, d_mask,
                        slots_pad, query_layout ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;

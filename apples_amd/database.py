@@ -27,6 +27,8 @@ def save(path, tree, newick, reference, filt_threshold):
         clustered=np.array(ca is not None))
     if ca is not None:
         arrays.update(cons=ca[0], rep_row=ca[1], member_off=ca[2], member_row=ca[3])
+    if reference.eng_rows is not None:  # -s held rows beyond the clustered ones (cluster arrays number the kept rows)
+        arrays.update(eng_rows=np.asarray(reference.eng_rows, np.int64))
     with open(path, 'wb') as f:  # (np.savez appends .npz to a path without it: keep the caller's name)
         np.savez(f, **arrays)
 
@@ -45,6 +47,8 @@ def load(path):
                 bool(z['is_rooted']))
     aln = Alignment([str(x) for x in z['names']], z['seqs'])
     ref = ReducedReference(aln, bool(z['protein']), None)
+    if 'eng_rows' in z.files:
+        ref._restrict(z['eng_rows'])
     if bool(z['clustered']):
         ref.cons = z['cons']
         ref.rep_row, ref.member_off, ref.member_row = z['rep_row'], z['member_off'], z['member_row']

@@ -22,7 +22,7 @@ PLACEMENT_DTYPE = np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'),
                             ('pendant', '<f8'), ('n_obs', '<i4'), ('n_valid', '<i4')], align=True)
 
 EXPORTS = ['apples_ctx_create', 'apples_ctx_destroy', 'apples_last_error', 'apples_set_params', 'apples_distances',
-           'apples_place_from_sequences', 'apples_place_from_distances', 'apples_sweep_edges',
+           'apples_place_from_sequences', 'apples_place_from_distances', 'apples_sweep_edges', 'apples_place_sequences_streamed',
            'apples_queries_upload', 'apples_table_upload', 'apples_queries_free', 'apples_place_resident', 'apples_fetch_placements',
            'apples_distances_resident', 'apples_placements_device_ptr', 'apples_last_timing', 'apples_describe']
 
@@ -70,6 +70,7 @@ def load_library():
                                                 C.c_void_p]
     lib.apples_sweep_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 7
     lib.apples_queries_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.apples_place_sequences_streamed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
     lib.apples_table_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_int64)]
     lib.apples_queries_free.argtypes = [C.c_void_p, C.c_int64]
@@ -215,10 +216,24 @@ class Engine:
         return {'pack_ms': ms[T_PACK], 'dist_ms': ms[T_DIST], 'select_ms': ms[T_SELECT], 'sweep_ms': ms[T_SWEEP],
                 'total_ms': ms[T_TOTAL], 'dist_launches': int(ms[T_DIST_LAUNCHES])}
 
+    def _queries(self, queries):
+        """uint8[Q, L] with L = the reference alignment's length.  The reference fails loudly on a query
+        of another length (numpy elementwise compare, apples/distance.py:733); so does this: bytes are
+        never re-chunked into a different number of queries."""
+        if self.length <= 0:
+            raise ValueError('this context has no reference alignment (distance-table context)')
+        q = np.asarray(queries)
+        if q.ndim == 1 and q.size == self.length:
+            q = q.reshape(1, -1)
+        if q.ndim != 2 or q.shape[1] != self.length:
+            raise ValueError('query alignment must be a [Q, %d] byte matrix (reference alignment length %d), got shape %s'
+                             % (self.length, self.length, q.shape))
+        return np.ascontiguousarray(q, np.uint8)
+
     # ------------------------------------------------------------------ seam B2
     def distances(self, queries, want_counts=True):
         """(counts uint32[Q, n_rows, 2] or None, dist float64[Q, n_rows]) in caller row order."""
-        q = np.ascontiguousarray(queries, np.uint8).reshape(-1, self.length)
+        q = self._queries(queries)
         dist = np.empty((len(q), self.n_rows), np.float64)
         counts = np.empty((len(q), self.n_rows, 2), np.uint32) if want_counts else None
         self._check(self.lib.apples_distances(self.ctx, _ptr(q), len(q), _ptr(counts), _ptr(dist)))
@@ -226,11 +241,29 @@ class Engine:
 
     # ------------------------------------------------------------------ seam B1
     def place_sequences(self, queries, self_rows=None):
-        q = np.ascontiguousarray(queries, np.uint8).reshape(-1, self.length)
+        q = self._queries(queries)
         out = np.zeros(len(q), PLACEMENT_DTYPE)
-        sr = np.ascontiguousarray(self_rows, np.int32) if self_rows is not None else None
+        sr = self._self_rows(self_rows, len(q))
         self._check(self.lib.apples_place_from_sequences(self.ctx, _ptr(q), len(q), _ptr(sr), _ptr(out)))
         return out
+
+    def place_sequences_streamed(self, queries, self_rows=None):
+        """Same work, placements left on the device: returns (handle, n) for fetch / placements_device_ptr
+        / free_queries."""
+        q = self._queries(queries)
+        sr = self._self_rows(self_rows, len(q))
+        h = C.c_int64()
+        self._check(self.lib.apples_place_sequences_streamed(self.ctx, _ptr(q), len(q), _ptr(sr), C.byref(h)))
+        return h.value, len(q)
+
+    @staticmethod
+    def _self_rows(self_rows, n):
+        if self_rows is None:
+            return None
+        sr = np.ascontiguousarray(self_rows, np.int32)
+        if sr.shape != (n,):
+            raise ValueError('self_rows must have one entry per query')
+        return sr
 
     def place_distances(self, dist, col_nodes, self_cols=None):
         d = np.ascontiguousarray(dist, np.float64)
@@ -259,8 +292,8 @@ class Engine:
 
     # ------------------------------------------------------------------ resident blocks (bench)
     def upload_queries(self, queries, self_rows=None):
-        q = np.ascontiguousarray(queries, np.uint8).reshape(-1, self.length)
-        sr = np.ascontiguousarray(self_rows, np.int32) if self_rows is not None else None
+        q = self._queries(queries)
+        sr = self._self_rows(self_rows, len(q))
         h = C.c_int64()
         self._check(self.lib.apples_queries_upload(self.ctx, _ptr(q), len(q), _ptr(sr), C.byref(h)))
         return h.value, len(q)

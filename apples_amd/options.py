@@ -61,7 +61,8 @@ def build_parser():
 
 
 def options_config(argv=None):
-    """Parse + validate exactly as apples/OptionsBasic.py:72-92 and apples/OptionsRun.py:86-110."""
+    """Parse + validate as apples/OptionsBasic.py:72-92 and apples/OptionsRun.py:86-110 (same errors, same
+    warnings, same precedence of -t over the database's tree and of -d over its sequences)."""
     parser = build_parser()
     options, args = parser.parse_args(argv)
     if options.print_version:
@@ -76,12 +77,17 @@ def options_config(argv=None):
         options.reestimate_backbone = False
         if options.ref_fp:
             raise ValueError('Input should be either an alignment or a distance matrix, but not both!')
-    if options.database_fp:
-        # apples/OptionsRun.py: a database replaces the tree and the reference alignment
-        if options.tree_fp or options.ref_fp or options.dist_fp:
-            raise ValueError('An APPLES database (-a) already holds the tree and the reference alignment; '
-                             'do not pass -t, -s or -d with it.')
-    elif not options.tree_fp:
+        if options.database_fp:  # apples/OptionsRun.py:92-97
+            logging.warning('Input contains both an APPLES database and a distance matrix. Database sequences '
+                            'will be ignored. Database phylogeny will be used if user did not provide a phylogeny '
+                            '(using -t option). ')
+    if options.database_fp:  # apples/OptionsRun.py:99-106
+        if options.ref_fp:
+            raise ValueError('Input should be either an alignment or a APPLES database file, but not both!')
+        if options.tree_fp:
+            logging.warning('Input contains both an APPLES database and a tree file. User provided tree has '
+                            'higher priority and therefore will be used.')
+    if not options.tree_fp and not options.database_fp:
         raise ValueError('No input backbone tree provided by user.')
     if options.query_fp and options.extended_ref_fp:
         raise ValueError('Input should be either an extended alignment or a query alignment, but not both!')

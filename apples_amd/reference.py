@@ -35,35 +35,54 @@ def read_treecluster(path):
 
 class ReducedReference:
     def __init__(self, alignment, protein, clusters=None):
-        """alignment: apples_amd.fasta.Alignment.  clusters: None or [(id, [names])]."""
+        """alignment: apples_amd.fasta.Alignment.  clusters: None or [(id, [names])].
+
+        The reference builds its representatives from TreeCluster's output alone (Reference.py:94-107),
+        which names backbone leaves: alignment rows that belong to no cluster are never compared with a
+        query, though their names still decide which rows of an extended alignment are queries
+        (run_apples.py:85-89).  So ``aln`` keeps every row, and ``eng_aln`` -- what the device holds --
+        only the clustered ones (the same object when every row is clustered)."""
         self.aln = alignment
+        self.eng_aln = alignment
+        self.eng_rows = None  # rows of ``aln`` in ``eng_aln`` (None = all of them, in order)
         self.protein = protein
         self.cons = np.zeros((0, alignment.length), np.uint8)
         self.rep_row = None
         self.member_off = None
         self.member_row = None
         if clusters is not None:
+            full_rows = [alignment.index[n] for _, group in clusters for n in group]  # KeyError as Reference.py:149
+            if len(set(full_rows)) != len(full_rows):
+                raise ValueError('a reference sequence is listed in more than one cluster')
+            if len(full_rows) != len(alignment):
+                self._restrict(np.array(sorted(full_rows), np.int64))
+            index = self.eng_aln.index
+            seqs = self.eng_aln.seqs
             cons, rep_row, moff, mrow = [], [], [0], []
             for key, group in clusters:
-                rows = [alignment.index[n] for n in group]
+                rows = [index[n] for n in group]
                 if key == '-1':  # singletons pass through (PoolRepresentativeWorker.py:99-101)
                     for r in rows:
                         rep_row.append(r)
                         mrow.append(r)
                         moff.append(len(mrow))
                 else:
-                    rep_row.append(len(alignment) + len(cons))
-                    cons.append(consensus(alignment.seqs[rows], protein))
+                    rep_row.append(len(self.eng_aln) + len(cons))
+                    cons.append(consensus(seqs[rows], protein))
                     mrow += rows
                     moff.append(len(mrow))
-            if len(mrow) != len(alignment) or len(set(mrow)) != len(mrow):
-                raise ValueError('clusters must cover every reference sequence exactly once')
             self.cons = np.array(cons, np.uint8).reshape(-1, alignment.length)
             self.rep_row = np.array(rep_row, np.int32)
             self.member_off = np.array(moff, np.int32)
             self.member_row = np.array(mrow, np.int32)
 
+    def _restrict(self, rows):
+        from .fasta import Alignment
+        self.eng_rows = rows
+        self.eng_aln = Alignment([self.aln.names[i] for i in rows], self.aln.seqs[rows])
+
     def cluster_arrays(self):
+        """(consensus rows, rep_row, member_off, member_row) in ``eng_aln`` row numbers, or None."""
         if self.rep_row is None:
             return None
         return self.cons, self.rep_row, self.member_off, self.member_row

@@ -26,19 +26,21 @@ class QueryWorker:
         self.devices = list(devices)
         self._engines = {}
 
-    def _engine(self, device):
-        if device not in self._engines:
+    def _engine(self, k):
+        """The context of shard k (one per entry of ``devices``; two entries may name the same device)."""
+        device = self.devices[k]
+        if k not in self._engines:
             o = self.options
             kw = dict(protein=o.protein_seqs, method=o.method_name, criterion=o.criterion_name,
                       negative=bool(o.negative_branch), threshold=o.filt_threshold,
                       baseobs=o.base_observation_threshold, overlap=o.minimum_alignment_overlap, device=device)
             if self.reference is not None:
-                aln = self.reference.aln
+                aln = self.reference.eng_aln  # the clustered rows (every row, unless -s holds more than the tree)
                 nodes = np.array([self.tree.name_to_node.get(n, -1) for n in aln.names], np.int32)
-                self._engines[device] = Engine(self.tree, aln.seqs, nodes, clusters=self.reference.cluster_arrays(), **kw)
+                self._engines[k] = Engine(self.tree, aln.seqs, nodes, clusters=self.reference.cluster_arrays(), **kw)
             else:
-                self._engines[device] = Engine(self.tree, None, **kw)
-        return self._engines[device]
+                self._engines[k] = Engine(self.tree, None, **kw)
+        return self._engines[k]
 
     def close(self):
         for e in self._engines.values():
@@ -54,7 +56,7 @@ class QueryWorker:
         def work(k):
             try:
                 lo, hi = parts[k]
-                outs[k] = fn(self._engine(self.devices[k]), lo, hi)
+                outs[k] = fn(self._engine(k), lo, hi)
             except Exception as e:  # an exception in any worker aborts the run, as starmap does
                 errs.append(e)
 
@@ -70,7 +72,7 @@ class QueryWorker:
 
     # ------------------------------------------------------------------ alignment input
     def run_sequences(self, names, seqs, rows=False):
-        aln = self.reference.aln
+        aln = self.reference.eng_aln
         # the entry runquery deletes: query name is a backbone leaf and names a reference row (:63-66)
         self_rows = np.array([aln.index.get(n, -1) if n in self.tree.name_to_node else -1 for n in names], np.int32)
         out = self._run_sharded(len(names), lambda eng, lo, hi: eng.place_sequences(seqs[lo:hi], self_rows[lo:hi]))

@@ -1,78 +1,121 @@
 #!/usr/bin/env python3
 """Benchmark of the APPLES per-query hot path on MI355X (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|small] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5|c3-clustered|small]
+                    [--scaling weak|strong] [--no-cpu] [--queries Q]
 
-A step = one pass of the hot path (distance vector -> observed-set selection -> least-squares
-sweep -> best edge) over one block of synthetic queries whose packed form, together with the
-packed reference alignment and the tree, is already resident in HBM.  value = query
-placements/s for the whole job.  For N > 1 (launched by torch.distributed.run, one rank per GPU)
-every rank places its own shard of the same size (weak scaling, no collective in the data path)
-and the placements are gathered to rank 0 with one RCCL gather inside the timed region.
+Default workload = BASELINE.json config 3, the one the targets are quoted on: synthetic 200 k-leaf
+backbone, L = 1000 nt, 100 k queries, OLS/JC69, -f 0.2 -b 25.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, algorithmic bytes / HIP-event
-time), `distance_kernel_stream` (BASELINE.json's second figure: the distance kernel
-at one query per pass over the packed reference, bytes moved / HIP-event time against the 8 TB/s
-peak, measured after the timed region) and `cpu_baseline` (the CPU restatement of the reference
-path -- per-query numpy/Python worker under a fork pool, as run_apples.py:101-102 -- timed on this
-host's cores on a bounded sample of the same workload).
+A step = one pass of the hot path over one block of synthetic queries, timed the way the reference
+times its own "Processed all queries" interval (run_apples.py:93-104): the queries start as byte
+arrays in host memory (the reference's S1 arrays) and the step ends when the placements are back in
+host memory -- upload, packing into the device layouts, distance vector, observed-set selection,
+least-squares sweep, best edge, copy back (apples_place_from_sequences).  The packed reference
+alignment and the tree are resident in HBM (the reference's workers likewise hold them before the
+timer starts).  value = query placements/s for the whole job.  `resident` in the JSON line is the
+same pass with the query block already uploaded and packed (device time only).
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank places its own shard with
+no collective in the data path and the 40-byte placement structs are gathered to rank 0 with one RCCL
+gather inside the timed region.  --scaling weak (default): every rank places a block of the workload's
+size; --scaling strong: the workload's queries are split over the ranks (BASELINE config 3's
+"100 k queries, 1 -> 8 GPUs").
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, algorithmic bytes or operations /
+HIP-event time), `distance_kernel_stream` (BASELINE.json's second figure: the distance
+kernel at one query per pass over the packed reference, measured after the timed region) and
+`cpu_baseline` (the CPU restatement of the reference path -- per-query numpy/Python worker under a
+fork pool, as run_apples.py:101-102 -- timed on this host's cores on a bounded sample of the same
+workload).
 """
-import argparse
-import json
 import os
-import sys
-import time
 
-import numpy as np
+# the CPU baseline's workers are single-threaded processes, as the reference's are
+os.environ.setdefault('OMP_NUM_THREADS', '1')
+os.environ.setdefault('OPENBLAS_NUM_THREADS', '1')
+os.environ.setdefault('MKL_NUM_THREADS', '1')
+
+import argparse  # noqa: E402
+import json  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (leaves, L, queries per GPU, protein, method, threshold)   -- BASELINE.json configs
+    # name: (leaves, L, queries, protein, method, threshold)   -- BASELINE.json configs
     'c2': (10000, 1000, 10000, False, 'OLS', 0.2),
     'c3': (200000, 1000, 100000, False, 'OLS', 0.2),
     'c4': (50000, 500, 50000, True, 'FM', 0.2),
     'small': (2000, 500, 2048, False, 'OLS', 0.2),
-    # C5: distance-table input (-d), least-squares-only path; L is irrelevant (no alignment)
-    'c5': (200000, 0, 100000, False, 'BME', 0.2),
+    # C5: distance-table input (-d), least-squares-only path; L is irrelevant (no alignment).  100 k rows of
+    # 200 k fp64 columns are 160 GB: the bench holds a block of 4 096 rows (6.5 GB) unless --queries says otherwise
+    'c5': (200000, 0, 4096, False, 'BME', 0.2),
+    # the command line's default route at C3 size: max-diameter clusters at 1.2 x -f with consensus
+    # representatives (apples/Reference.py:84-157) instead of all-singleton clusters
+    'c3-clustered': (200000, 1000, 100000, False, 'OLS', 0.2),
 }
 MFMA_F4_PEAK_TOPS = 10000.0  # dense fp4 peak at the nominal clock, /opt/skills/guides/MI355X_MICROARCH.md, matrix cores table
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+LDS_PEAK_GBS = 150000.0  # ds_read_b64/b128 with every CU streaming (MI355X_MICROARCH.md, LDS section)
 
 
-def cpu_baseline(ds, protein, method, threshold, target_cpu_seconds=20.0):
+def _cores():
+    """(logical CPUs this process may use, distinct physical cores among them)."""
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
+    phys = set()
+    for c in cpus:
+        try:
+            with open('/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % c) as f:
+                phys.add(f.read().strip())
+        except OSError:
+            phys.add(str(c))
+    return len(cpus), len(phys)
+
+
+def cpu_baseline(ds, protein, method, threshold, target_cpu_seconds=10.0):
     """Time the oracle's pool driver on a bounded, seeded sample of the same queries."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import apples_oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores, phys = _cores()
     kw = dict(protein=protein, method=method, criterion='MLSE', threshold=threshold, baseobs=25, overlap=0.001)
-    t0 = time.time()
-    orc.run_pool(ds.tree, ds.ref_names, ds.ref_seqs, ds.query_names[:1], ds.query_seqs[:1], threads=1, **kw)
-    t1 = max(time.time() - t0, 1e-3)
-    # every core gets 8 queries; the pool is started and warmed before the clock starts (start-up,
-    # which the reference's own "Processed all queries" timer would include, is reported apart)
-    n = int(min(len(ds.query_names), max(8 * cores, min(16 * cores, target_cpu_seconds / t1))))
+    # one core, two queries, inside a one-process pool (the first warms the worker)
+    dt1, _, _ = orc.time_pool(ds.tree, ds.ref_names, ds.ref_seqs, ds.query_names[:3], ds.query_seqs[:3], 1, **kw)
+    t1 = max(dt1 / 3.0, 1e-4)
+    # every core gets the same number of queries; about target_cpu_seconds of wall time if the pool scaled
+    # perfectly.  The pool is started and warmed before the clock starts (start-up, which the reference's
+    # own "Processed all queries" timer would include, is reported apart)
+    per_core = int(max(1, min(64, target_cpu_seconds / t1)))
+    n = int(min(len(ds.query_names), per_core * cores))
     dt, startup, _ = orc.time_pool(ds.tree, ds.ref_names, ds.ref_seqs, ds.query_names[:n], ds.query_seqs[:n], cores, **kw)
+    ideal = cores / t1
     return {'value': n / dt, 'unit': 'queries/s', 'cores': cores, 'kind': 'port',
-            'sample': 'first %d of the %d synthetic queries on a warmed %d-process fork pool: %.2f s steady state '
-                      '(pool start-up %.1f s not counted; %.3f s for one query on one core)'
-                      % (n, len(ds.query_names), cores, dt, startup, t1)}
+            'physical_cores': phys, 'single_core_queries_per_s': 1.0 / t1, 'single_core_x_cores': ideal,
+            'pool_efficiency': (n / dt) / ideal,
+            'sample': 'first %d of the %d synthetic queries on a warmed %d-process fork pool (%d physical cores, '
+                      'single-threaded numpy): %.2f s steady state (pool start-up %.1f s not counted); one core '
+                      'alone places %.3f queries/s, x %d = %.1f: the pool reaches %.0f %% of that (SMT siblings share a '
+                      'core; every worker streams the whole reference per query)'
+                      % (n, len(ds.query_names), cores, phys, dt, startup, 1.0 / t1, cores, ideal, 100.0 * (n / dt) / ideal)}
 
 
-def cpu_baseline_table(ds, D, method, threshold, target_cpu_seconds=20.0):
+def cpu_baseline_table(ds, D, method, threshold, target_cpu_seconds=10.0):
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import apples_oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores, phys = _cores()
     t0 = time.time()
     orc.time_pool_table(ds.tree, ds.ref_names, ds.query_names[:1], D[:1], 1, method=method, threshold=threshold)
     t1 = max(time.time() - t0, 1e-3)
-    n = int(min(len(D), max(2 * cores, min(8 * cores, target_cpu_seconds / t1))))
+    n = int(min(len(D), max(cores, min(8 * cores, cores * target_cpu_seconds / t1))))
     dt, startup, _ = orc.time_pool_table(ds.tree, ds.ref_names, ds.query_names[:n], D[:n], cores, method=method,
                                          threshold=threshold)
-    return {'value': n / dt, 'unit': 'queries/s', 'cores': cores, 'kind': 'port',
+    return {'value': n / dt, 'unit': 'queries/s', 'cores': cores, 'kind': 'port', 'physical_cores': phys,
             'sample': 'first %d table rows on a warmed %d-process fork pool: %.2f s steady state (start-up %.1f s not '
-                      'counted; %.3f s for one query on one core)' % (n, cores, dt, startup, t1)}
+                      'counted; %.3f s for one query on one core incl. pool start)' % (n, cores, dt, startup, t1)}
 
 
 def distance_stream_point(eng, ds, L):
@@ -80,7 +123,8 @@ def distance_stream_point(eng, ds, L):
     8d's roofline point: the packed reference streamed once per query, full fp64 rows out), on up to
     256 of the workload's queries, outside the timed region.  `delivered` counts the bytes the kernel
     moves (packed reference + 8 B per pair); whether they come from HBM or from the caches depends
-    on the reference's size, which is reported beside it."""
+    on the reference's size, which is reported beside it (profiles/ holds the HBM-only point on a
+    reference larger than every cache, with its FETCH_SIZE counter pass)."""
     n = min(256, len(ds.query_seqs))
     h, n = eng.upload_queries(ds.query_seqs[:n])
     for _ in range(3):
@@ -96,21 +140,33 @@ def distance_stream_point(eng, ds, L):
     return {'query_tile': 1, 'queries': n, 'ms': ms, 'packed_reference_bytes': info['packed_bytes'],
             'delivered_GBps': gbs, 'peak_GBps': HBM_PEAK_GBS, 'frac': gbs / HBM_PEAK_GBS,
             'algorithmic_GBps': algo / (ms * 1e-3) / 1e9,
-            'served_from': 'L2 / Infinity Cache (reference smaller than the 256 MiB cache)'
+            'served_from': 'L2 / Infinity Cache (reference smaller than the 256 MiB cache): not an HBM measurement'
                            if info['packed_bytes'] < (256 << 20) else 'HBM'}
 
 
 def load_traffic(workload, kernel):
     """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
     (profiles/pmc_summary.json, written by scripts/pmc_to_traffic.py from separate --pmc runs of
-    this same command; FETCH_SIZE/WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)."""
+    this same command; FETCH_SIZE/WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes), with the
+    commit the counters were collected at."""
     path = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
     try:
         with open(path) as f:
             d = json.load(f)
-        return d[workload][kernel]['hbm_bytes_per_launch']
+        e = d[workload][kernel]
+        return e['hbm_bytes_per_launch'], d[workload].get('measured_at_commit') or d.get('measured_at_commit')
     except Exception:
-        return None
+        return None, None
+
+
+def make_clusters(ds, threshold):
+    """Clusters + consensus rows of the command line's default route (run_apples.py: max-diameter
+    clusters at 1.2 x -f, apples/Reference.py:87)."""
+    from apples_amd import treecluster
+    from apples_amd.fasta import Alignment
+    from apples_amd.reference import ReducedReference
+    ref = ReducedReference(Alignment(ds.ref_names, ds.ref_seqs), False, treecluster.grouped(ds.tree, threshold * 1.2))
+    return ref.cluster_arrays()
 
 
 def main():
@@ -118,9 +174,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
-    ap.add_argument('--queries', type=int, default=0, help='override queries per GPU')
+    ap.add_argument('--queries', type=int, default=0, help='override the number of queries (per GPU when weak)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -139,39 +196,59 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from apples_amd import synth
-    from apples_amd.engine import Engine
+    from apples_amd.distributed import shard_bounds
+    from apples_amd.engine import Engine, PLACEMENT_DTYPE
 
     n_leaves, L, Q, protein, method, thr = WORKLOADS[args.workload]
     if args.queries:
         Q = args.queries
-    # every rank holds the same backbone + reference; queries are rank-specific shards
     table = args.workload == 'c5'
-    ds = synth.make_dataset(n_leaves, L if not table else 4, Q, protein=protein, seed_query=3 + rank)
+    clustered = args.workload == 'c3-clustered'
+    strong = args.scaling == 'strong'
+    # every rank holds the same backbone + reference.  weak: rank-specific blocks of Q queries (own seed);
+    # strong: one set of Q queries, rank r takes the contiguous block shard_bounds gives it
+    ds = synth.make_dataset(n_leaves, L if not table else 4, Q, protein=protein, seed_query=3 if strong else 3 + rank)
+    lo, hi = shard_bounds(Q, world)[rank] if strong else (0, Q)
+    queries = np.ascontiguousarray(ds.query_seqs[lo:hi])
+    sizes = [(b - a) for a, b in shard_bounds(Q, world)] if strong else [Q] * world
     nodes = np.array([ds.tree.name_to_node[n] for n in ds.ref_names], np.int32)
     D = None
     if table:
         # noisy true path distances, generated in binary (never as text)
         index = synth.TreeIndex(ds.tree)
-        D = synth.fast_distance_rows(ds.tree, index, ds.query_leaf, ds.query_pendant, list(range(Q)), seed_noise=7 + rank)
+        D = synth.fast_distance_rows(ds.tree, index, ds.query_leaf, ds.query_pendant, list(range(lo, hi)),
+                                     seed_noise=7 if strong else 7 + rank)
         eng = Engine(ds.tree, None, method=method, criterion='MLSE', threshold=thr, baseobs=25, device=local_rank)
-        handle, nq = eng.upload_table(D, nodes)
     else:
-        eng = Engine(ds.tree, ds.ref_seqs, nodes, protein=protein, method=method, criterion='MLSE', threshold=thr,
-                     baseobs=25, overlap=0.001, device=local_rank)
-        handle, nq = eng.upload_queries(ds.query_seqs)
+        eng = Engine(ds.tree, ds.ref_seqs, nodes, clusters=make_clusters(ds, thr) if clustered else None, protein=protein,
+                     method=method, criterion='MLSE', threshold=thr, baseobs=25, overlap=0.001, device=local_rank)
+    nq = hi - lo
+
+    class _DevArray:  # zero-copy view of the device-resident placement structs
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
 
     if use_dist:
-        class _DevArray:  # zero-copy view of the device-resident placement structs
-            def __init__(self, ptr, nbytes):
-                self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
-        res = torch.as_tensor(_DevArray(eng.placements_device_ptr(handle), nq * 40), device='cuda')
         from apples_amd.distributed import gather_bytes
 
     def step():
-        eng.place_resident(handle)  # returns after the stream has drained
-        if use_dist:
-            # the end-of-run gather over RCCL/xGMI (replaces starmap's pickle return)
-            gather_bytes(res, rank, world, dist)
+        """host buffer -> placements in host memory (on rank 0 for the whole job when N > 1)."""
+        if not use_dist:
+            return eng.place_distances(D, nodes) if table else eng.place_sequences(queries)
+        if table:
+            h, n = eng.upload_table(D, nodes)
+            eng.place_resident(h)
+        else:
+            h, n = eng.place_sequences_streamed(queries)
+        # the end-of-run gather over RCCL/xGMI (replaces starmap's pickle return), straight from the
+        # device-resident structs; rank 0 then brings the whole job's placements to the host
+        res = torch.as_tensor(_DevArray(eng.placements_device_ptr(h), n * 40), device='cuda')
+        parts = gather_bytes(res, rank, world, dist, [s * 40 for s in sizes])
+        out = None
+        if rank == 0:
+            out = np.frombuffer(torch.cat(parts).cpu().numpy().tobytes(), dtype=PLACEMENT_DTYPE)
+        eng.free_queries(h)
+        return out
 
     def sync():
         if use_dist:
@@ -184,8 +261,9 @@ def main():
     t0 = time.perf_counter()
     phases = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0}
     launches = 0
+    out = None
     for _ in range(args.steps):
-        step()
+        out = step()
         t = eng.timing()
         for k in phases:
             phases[k] += t[k]
@@ -197,37 +275,55 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    out = eng.fetch(handle, nq)
-    if use_dist:  # untimed: what the gather delivers for this rank is what the device holds
-        parts = gather_bytes(res, rank, world, dist)
-        torch.cuda.synchronize()
-        if rank == 0 and parts[0].cpu().numpy().tobytes() != out.tobytes():
-            raise SystemExit('bench: gathered placements differ from the device buffer')
+    # untimed: the resident form (query block / table already uploaded and packed; device time only)
+    if table:
+        handle, _ = eng.upload_table(D, nodes)
+    else:
+        handle, _ = eng.upload_queries(queries)
+    eng.place_resident(handle)
+    sync()
+    t1 = time.perf_counter()
+    res_phases = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0}
+    for _ in range(args.steps):
+        eng.place_resident(handle)
+        t = eng.timing()
+        for k in res_phases:
+            res_phases[k] += t[k]
+    dt_res = time.perf_counter() - t1
+    mine = eng.fetch(handle, nq)
+    eng.free_queries(handle)
     if rank == 0:
+        mine0 = out[:nq]
+        if mine0.tobytes() != mine.tobytes():
+            raise SystemExit('bench: the host-buffer pass and the resident pass disagree')
+        total_q = int(sum(sizes))
         ms_per_step = dt / args.steps * 1e3
-        value = world * nq / (dt / args.steps)
+        value = total_q / (dt / args.steps)
         rows = eng.n_rows if not table else n_leaves
-        placed = out['n_valid'] > 0
-        mean_v = float(np.mean(out['n_valid'][placed] + 1)) if placed.any() else 0.0
+        placed = mine['n_valid'] > 0
+        mean_v = float(np.mean(mine['n_valid'][placed] + 1)) if placed.any() else 0.0
         per_step = {k: v / args.steps for k, v in phases.items()}
         # algorithmic bytes per step: distance N_rows*(L+8)+L per query; sweep 332*V per query
         dist_bytes = nq * (rows * (L + 8) + L)
-        sweep_bytes = 332.0 * float(np.sum(out['n_valid'][placed] + 1))
+        sweep_bytes = 332.0 * float(np.sum(mine['n_valid'][placed] + 1))
         kernels = {'lsq_sweep': (sweep_bytes, per_step['sweep_ms'])}
         if table:  # the -d filter reads every table value once
             kernels['table_select'] = (nq * rows * 8.0, per_step['select_ms'])
         else:
             kernels['jc69_distance' if not protein else 'scoredist_distance'] = (dist_bytes, per_step['dist_ms'])
         dom = max(kernels, key=lambda k: kernels[k][1])
-        n_launch = max(launches / args.steps, 1) if dom != 'lsq_sweep' else max(launches / args.steps, 1)
+        n_launch = max(launches / args.steps, 1)
         achieved = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9 if kernels[dom][1] > 0 else 0.0
+        traffic, traffic_commit = load_traffic(args.workload, dom)
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(args.workload, dom),
+                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_measured_at_commit': traffic_commit,
                     'launches_per_step': n_launch, 'avg_launch_ms': kernels[dom][1] / n_launch,
                     'algorithmic_bytes_per_launch': kernels[dom][0] / n_launch,
                     'per_kernel_ms_per_step': per_step,
                     'all_kernels_GBps': {k: (v[0] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in kernels.items()}}
-        if dom == 'jc69_distance' and eng.describe().get('code_planes') == 2 and not os.environ.get('APPLES_NO_DIST_MFMA'):
+        info = eng.describe()
+        if dom == 'jc69_distance' and info.get('code_planes') == 2 and info.get('all_singleton') and \
+                not os.environ.get('APPLES_NO_DIST_MFMA') and not os.environ.get('APPLES_NO_FUSE'):
             # the tiled pair counts run on the matrix cores (fp4 operands, 4 MACs per site and pair:
             # DESIGN.md section 4): price them against the dense fp4 MFMA peak, 2 ops per MAC
             ops = 2.0 * 4.0 * nq * rows * 32.0 * ((L + 31) // 32)
@@ -235,33 +331,44 @@ def main():
             roofline.update({'bound': 'mfma', 'achieved': tops, 'peak': MFMA_F4_PEAK_TOPS, 'unit': 'TFLOP/s',
                              'frac': tops / MFMA_F4_PEAK_TOPS, 'algorithmic_ops_per_launch': ops / n_launch,
                              'hbm_algorithmic_GBps': achieved})
+        elif dom == 'scoredist_distance':
+            # one 8-byte table read from LDS per site and pair: the LDS read rate bounds it
+            lds = 8.0 * nq * rows * L / (kernels[dom][1] * 1e-3) / 1e9
+            roofline.update({'bound': 'lds', 'achieved': lds, 'peak': LDS_PEAK_GBS, 'frac': lds / LDS_PEAK_GBS,
+                             'hbm_algorithmic_GBps': achieved})
         stream = None
-        if world == 1 and not table and not protein:
+        if world == 1 and not table and not protein and not clustered:
             stream = distance_stream_point(eng, ds, L)
         cpu = None
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not clustered:
             cpu = cpu_baseline_table(ds, D, method, thr) if table else cpu_baseline(ds, protein, method, thr)
+        res_ms = dt_res / args.steps * 1e3
         line = {
             'metric': 'query placements/sec (whole node)', 'value': value, 'unit': 'queries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': ('%s: synthetic %d-leaf backbone, -d distance-table input (noisy path distances, binary), '
-                                    '%d queries per GPU, %s, -f %.1f -b 25' % (args.workload, n_leaves, nq, method, thr)) if table
-                       else '%s: synthetic %d-leaf backbone, L=%d %s, %d queries per GPU, %s/%s, -f %.1f -b 25, '
-                       'all-singleton clusters' % (args.workload, n_leaves, L, 'aa' if protein else 'nt', nq,
-                                                  method, 'scoredist' if protein else 'JC69', thr),
-                       'n_ref': n_leaves, 'L': L, 'queries_per_gpu': nq, 'method': method,
-                       'mean_observed': float(np.mean(out['n_obs'])), 'mean_swept_nodes': mean_v,
+                                    '%d queries%s, %s, -f %.1f -b 25' % (args.workload, n_leaves, Q, '' if strong else ' per GPU', method, thr)) if table
+                       else '%s: synthetic %d-leaf backbone, L=%d %s, %d queries%s, %s/%s, -f %.1f -b 25, %s'
+                       % (args.workload, n_leaves, L, 'aa' if protein else 'nt', Q, ' in all' if strong else ' per GPU',
+                          method, 'scoredist' if protein else 'JC69', thr,
+                          'max-diameter clusters at 1.2 x -f with consensus representatives (%d representatives)' % info['n_reps']
+                          if clustered else 'all-singleton clusters'),
+                       'timed': 'host byte arrays -> placements in host memory (upload, packing, kernels, copy back)',
+                       'n_ref': n_leaves, 'L': L, 'queries_this_rank': nq, 'queries_total': total_q, 'method': method,
+                       'mean_observed': float(np.mean(mine['n_obs'])), 'mean_swept_nodes': mean_v,
                        'placed': int(placed.sum()), 'parallelism': 'query-sharded x%d' % world},
             'roofline': roofline,
+            'resident': {'value': world * nq / (dt_res / args.steps), 'ms_per_step': res_ms, 'unit': 'queries/s',
+                         'per_kernel_ms_per_step': {k: v / args.steps for k, v in res_phases.items()},
+                         'note': 'same pass, query block already uploaded and packed (rank 0, device time only)'},
             'distance_kernel_stream': stream,
             'cpu_baseline': cpu,
         }
         if cpu:
             line['speedup_vs_cpu_baseline'] = value / cpu['value']
         print(json.dumps(line), flush=True)
-    eng.free_queries(handle)
     eng.close()
     if use_dist:
         dist.barrier()

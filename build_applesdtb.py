@@ -44,6 +44,8 @@ def main(argv=None):
         clusters = read_treecluster(options.clusters_fp)
     elif options.no_clusters:
         clusters = None
+        if any(n not in tree.name_to_node for n in ref.names):  # only backbone leaves are ever observed
+            clusters = [('-1', [n for n in ref.names if n in tree.name_to_node])]
     else:
         clusters = treecluster.grouped(tree, options.filt_threshold * 1.2)
     reference = ReducedReference(ref, options.protein_seqs, clusters)

@@ -143,6 +143,14 @@ int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *o
                        uint8_t *valid, double *S, double *R, double *x, double *err, int32_t *lca,
                        apples_placement *out);
 
+/* Seam B1 with the placements left on the device: same work as apples_place_from_sequences (the
+ * caller's host buffer is uploaded and packed chunk by chunk on a second stream while the previous
+ * chunk's kernels run), but the result stays in a block owned by the context; fetch it with
+ * apples_fetch_placements, hand it to a collective through apples_placements_device_ptr, release it
+ * with apples_queries_free.  apples_place_from_sequences = this + fetch + free. */
+int apples_place_sequences_streamed(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries,
+                                    const int32_t *self_row, int64_t *handle);
+
 /* ---- device-resident variants used by bench.py (inputs already in HBM when timing starts) ---- */
 /* Upload and pack a block of queries; returns a handle owned by the context. */
 int apples_queries_upload(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries,

@@ -442,28 +442,70 @@ def _noop(_):
     return 0
 
 
+class _RowReps:
+    """All-singleton representatives over one 2-D byte matrix: what ``get_obs_dist`` iterates and indexes
+    (``(sequence, [member keys])``), with the row number as the member key.  The timed pool uses it
+    instead of 200 k (array, [name]) tuples: forked workers would copy-on-write every page holding
+    those objects the first time they walk the list (reference counts are written on every access),
+    which at 200 k references costs each worker more than the queries themselves."""
+
+    def __init__(self, seqs):
+        self.seqs = seqs
+
+    def __len__(self):
+        return len(self.seqs)
+
+    def __getitem__(self, i):
+        return self.seqs[i], (i,)
+
+    def __iter__(self):
+        seqs = self.seqs
+        for i in range(len(seqs)):
+            yield seqs[i], (i,)
+
+
+class _RowWorker:
+    tree = None
+    seqs = None
+    names = None
+    dist_fn = None
+    params = None
+
+    @classmethod
+    def run(cls, name, seq):
+        p = cls.params
+        obs = get_obs_dist(seq, _RowReps(cls.seqs), cls.seqs, cls.dist_fn, p['threshold'], p['baseobs'], p['overlap'])
+        names = cls.names
+        obs = {names[i]: d for i, d in obs.items()}  # same insertion order as with name keys
+        return runquery(cls.tree, name, obs, p['method'], p['criterion'], p['negative'], p['exclude'])
+
+
 def time_pool(tree, ref_names, ref_seqs, query_names, query_seqs, threads, **kw):
     """Steady-state timing of the pool driver for bench.py's cpu_baseline: the fork pool is started
     and warmed first (its start-up, which the reference's own "Processed all queries" timer includes,
-    is returned separately), then the starmap over the sample is timed.
+    is returned separately), then the starmap over the sample is timed (run_apples.py:101-102; one task
+    per chunk so that no worker sits on a queue of slow queries).
     Returns (seconds_steady, seconds_startup, results)."""
     import multiprocessing as mp
     import time
-    rows = {n: ref_seqs[i] for i, n in enumerate(ref_names)}
-    _Worker.tree = tree
-    _Worker.reps = [(ref_seqs[i], [n]) for i, n in enumerate(ref_names)]
-    _Worker.rows = rows
-    _Worker.dist_fn = scoredist if kw.get('protein') else jc69
-    _Worker.params = dict(threshold=kw.get('threshold', 0.2), baseobs=kw.get('baseobs', 25),
-                          overlap=kw.get('overlap', 0.001), method=kw.get('method', 'FM'),
-                          criterion=kw.get('criterion', 'MLSE'), negative=False, exclude=False)
+    _RowWorker.tree = tree
+    _RowWorker.seqs = ref_seqs
+    _RowWorker.names = list(ref_names)
+    _RowWorker.dist_fn = scoredist if kw.get('protein') else jc69
+    _RowWorker.params = dict(threshold=kw.get('threshold', 0.2), baseobs=kw.get('baseobs', 25),
+                             overlap=kw.get('overlap', 0.001), method=kw.get('method', 'FM'),
+                             criterion=kw.get('criterion', 'MLSE'), negative=False, exclude=False)
     tasks = [(n, query_seqs[i]) for i, n in enumerate(query_names)]
+    if threads <= 1:
+        t1 = time.time()
+        res = [_RowWorker.run(*t) for t in tasks]
+        return time.time() - t1, 0.0, res
     ctx = mp.get_context('fork')
     t0 = time.time()
     with ctx.Pool(threads) as pool:
         pool.map(_noop, range(4 * threads))
         t1 = time.time()
-        res = pool.starmap(_Worker.run, tasks)
+        res = pool.starmap(_RowWorker.run, tasks, chunksize=1)
         t2 = time.time()
     return t2 - t1, t1 - t0, res
 
@@ -493,6 +535,6 @@ def time_pool_table(tree, col_names, query_names, D, threads, method='BME', crit
     with ctx.Pool(threads) as pool:
         pool.map(_noop, range(4 * threads))
         t1 = time.time()
-        res = pool.starmap(_TableWorker.run, tasks)
+        res = pool.starmap(_TableWorker.run, tasks, chunksize=1)
         t2 = time.time()
     return t2 - t1, t1 - t0, res

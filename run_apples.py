@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Drop-in for the reference's run_apples.py on its per-query hot path: same flags, same jplace,
-placements computed on MI355X.  Backbone branch re-estimation (FastTree) and
-APPLES database pickles are outside this build: the tree is taken as given (-D semantics)."""
+placements computed on MI355X.  -a reads this build's own database cache
+(build_applesdtb.py; the reference's pickles of third-party classes cannot be read)."""
 import logging
 import re
 import sys
@@ -72,13 +72,22 @@ def main(argv=None):
     reference = None
     if options.database_fp:  # run_apples.py:25-35,69-75: tree, extended Newick and reduced reference from the cache
         from apples_amd import database
-        tree, newick, reference, db_protein, _ = database.load(options.database_fp)
-        if db_protein != bool(options.protein_seqs):
-            raise ValueError('the database was built %s -p, the run was started %s it'
-                             % (('with', 'without') if db_protein else ('without', 'with')))
+        tree, newick, reference, db_protein, db_threshold = database.load(options.database_fp)
+        if options.dist_fp:
+            reference = None  # database sequences are ignored with -d (apples/OptionsRun.py:92-97)
+        else:
+            if db_protein != bool(options.protein_seqs):
+                raise ValueError('the database was built %s -p, the run was started %s it'
+                                 % (('with', 'without') if db_protein else ('without', 'with')))
+            if db_threshold != options.filt_threshold:
+                # the reference's reduced reference keeps the threshold it was built with and walks the
+                # representatives with it (apples/Reference.py:82,146); -f at run time does not reach it
+                logging.info('[%s] The database was built with -f %s: that threshold is used for the observed sets.'
+                             % (time.strftime('%H:%M:%S'), db_threshold))
+                options.filt_threshold = db_threshold
         logging.info('[%s] Tree and reduced reference are loaded from the APPLES database in %.3f seconds.'
                      % (time.strftime('%H:%M:%S'), time.time() - start))
-    else:
+    if options.tree_fp:  # the user's tree wins over the database's (run_apples.py:37-38)
         tree = read_tree(options.tree_fp)
         newick = extended_newick(tree)
         logging.info('[%s] Tree is parsed and preprocessed in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))
@@ -114,6 +123,9 @@ def main(argv=None):
             clusters = read_treecluster(options.clusters_fp)
         elif options.no_clusters:
             clusters = None
+            if any(n not in tree.name_to_node for n in ref.names):
+                # only backbone leaves are ever observed (the reference's clusters name tree leaves)
+                clusters = [('-1', [n for n in ref.names if n in tree.name_to_node])]
         else:  # as the reference: max-diameter clusters at 1.2 x the filter threshold (Reference.py:87)
             from apples_amd import treecluster
             clusters = treecluster.grouped(tree, options.filt_threshold * 1.2)
@@ -126,9 +138,13 @@ def main(argv=None):
         logging.info('[%s] Reduced reference is prepared in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))
         if options.query_fp:
             q = read_alignment(options.query_fp, options.protein_seqs, options.mask_lowconfidence)
+            if len(q) and q.length != ref.length:
+                raise ValueError('the query alignment has %d sites, the reference alignment %d' % (q.length, ref.length))
             qnames, qseqs = q.names, q.seqs
         else:
             ext = read_alignment(options.extended_ref_fp, options.protein_seqs, options.mask_lowconfidence)
+            if ext.length != ref.length:
+                raise ValueError('the extended alignment has %d sites, the reference alignment %d' % (ext.length, ref.length))
             keep = [i for i, n in enumerate(ext.names) if n not in ref.index]
             qnames, qseqs = [ext.names[i] for i in keep], ext.seqs[keep]
         worker = QueryWorker(tree, options, reference, devices)

@@ -448,7 +448,30 @@ def g6():
 
 
 # ============================================================================= G7 whole-CLI runs
-def g7():
+def superset_alignment(path):
+    """data/ref.fa plus the first three records of data/query.fa: a reference alignment that holds
+    rows beyond the backbone's leaves (written at generation time and again by the test)."""
+    with open(path, 'w') as f:
+        f.write(open(os.path.join(DATA, 'ref.fa')).read())
+        recs = open(os.path.join(DATA, 'query.fa')).read().split('>')[1:4]
+        f.write(''.join('>' + r for r in recs))
+    return path
+
+
+def g8():
+    """-s with rows that are not backbone leaves + -x: the reference ignores those rows as references
+    (TreeCluster's table names tree leaves only) but keeps them out of the query set."""
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    sup = superset_alignment(os.path.join(tmp, 'superset_ref.fa'))
+    ext = os.path.join(tmp, 'extended_ref.fa')  # = data/ref.fa + data/query.fa (SURVEY section 4)
+    with open(ext, 'w') as f:
+        f.write(open(os.path.join(DATA, 'ref.fa')).read() + open(os.path.join(DATA, 'query.fa')).read())
+    g7({'aln_superset': ['-s', sup, '-x', ext, '-t', os.path.join(DATA, 'backbone.nwk'), '-m', 'OLS', '-D', '-T', '2']},
+       rename={sup: 'superset_ref.fa', ext: 'extended_ref.fa'})
+
+
+def g7(runs=None, rename=None):
     """Run the reference's own run_apples.py end to end (treeswift stand-in registered above, and
     a stub TreeCluster.py on PATH that labels every leaf '-1' = all-singleton clusters)."""
     import runpy
@@ -472,7 +495,7 @@ def g7():
                 '    treecluster.write_table(t, float(a[a.index("-t") + 1]), out)\n' % (sys.executable, ROOT))
     os.chmod(stub, os.stat(stub).st_mode | stat.S_IEXEC)
     os.environ['PATH'] = tmp + os.pathsep + os.environ['PATH']
-    runs = {
+    runs = runs or {
         'aln_OLS': ['-s', os.path.join(DATA, 'ref.fa'), '-q', os.path.join(DATA, 'query.fa'), '-t',
                     os.path.join(DATA, 'backbone.nwk'), '-m', 'OLS', '-D', '-T', '2'],
         'aln_default': ['-s', os.path.join(DATA, 'ref.fa'), '-q', os.path.join(DATA, 'query.fa'), '-t',
@@ -509,13 +532,14 @@ def g7():
             sys.argv = old
         # keep the fixture location-independent
         j = json.load(open(outp))
-        j['metadata']['invocation'] = 'run_apples.py ' + ' '.join(a.replace(DATA + os.sep, 'data/') for a in args)
+        j['metadata']['invocation'] = 'run_apples.py ' + ' '.join(
+            (rename or {}).get(a, a).replace(DATA + os.sep, 'data/') for a in args)
         with open(outp, 'w') as f:
             f.write(json.dumps(j, sort_keys=True, indent=4) + '\n')
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
     for w in which:
         print('generating', w, flush=True)
         globals()[w]()

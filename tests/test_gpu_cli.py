@@ -81,18 +81,85 @@ def test_cli_database_cache_matches_reference_jplace(tmp_path):
         assert_prow(g['p'][0], w['p'][0], ctx='database %s' % w['n'][0])
 
 
-def test_bench_multi_rank_path_on_one_gpu():
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_bench_multi_rank_path_on_one_gpu(scaling):
     """bench.py's multi-rank path (process group over RCCL, zero-copy view of the device-resident
     placements, gather to rank 0, max over ranks), launched the way the driver launches it, with a
     single rank so that one GPU is enough: the contract line must come out, and bench.py itself
     checks that what the gather delivers is what the device buffer holds."""
     env = dict(os.environ, APPLES_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
-           '127.0.0.1', '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2',
-           '--warmup', '1', '--workload', 'small', '--no-cpu']
+           '127.0.0.1', '--master-port', '29533' if scaling == 'weak' else '29534', os.path.join(ROOT, 'bench.py'),
+           '--gpus', '1', '--steps', '2', '--warmup', '1', '--workload', 'small', '--no-cpu', '--scaling', scaling]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line['n_gpus'] == 1 and line['steps'] == 2 and line['scaling'] == 'weak'
-    assert line['value'] > 0 and line['roofline']['frac'] > 0
+    assert line['n_gpus'] == 1 and line['steps'] == 2 and line['scaling'] == scaling
+    assert line['value'] > 0 and line['roofline']['frac'] > 0 and line['resident']['value'] >= line['value'] * 0.5
+    assert line['config']['queries_total'] == 2048
     assert line['config']['placed'] > 0
+
+
+def test_cli_reference_alignment_with_rows_beyond_the_tree(tmp_path):
+    """-s holds three rows that are not backbone leaves, -x the extended alignment: the reference
+    (fixture g7_cli_aln_superset.jplace, written by its own run_apples.py) never compares those rows
+    with a query but keeps them out of the query set.  Default route (clusters built from the tree)."""
+    sup = tmp_path / 'superset_ref.fa'
+    with open(sup, 'w') as f:  # as tests/golden/make_goldens.py:superset_alignment
+        f.write(open(os.path.join(DATA, 'ref.fa')).read())
+        f.write(''.join('>' + r for r in open(os.path.join(DATA, 'query.fa')).read().split('>')[1:4]))
+    ext = tmp_path / 'extended_ref.fa'
+    with open(ext, 'w') as f:
+        f.write(open(os.path.join(DATA, 'ref.fa')).read() + open(os.path.join(DATA, 'query.fa')).read())
+    want = json.load(open(os.path.join(GOLD, 'g7_cli_aln_superset.jplace')))
+    for extra in ([], ['--no-clusters']):
+        out = tmp_path / ('out%d.jplace' % len(extra))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_apples.py'), '-s', str(sup), '-x', str(ext), '-t',
+                            os.path.join(DATA, 'backbone.nwk'), '-m', 'OLS', '-D', '-o', str(out)] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        got = json.load(open(out))
+        assert [p['n'] for p in got['placements']] == [p['n'] for p in want['placements']]
+        if not extra:  # the fixture's clusters are this build's default clusters
+            for g, w in zip(got['placements'], want['placements']):
+                assert_prow(g['p'][0], w['p'][0], ctx='superset %s' % w['n'][0])
+
+
+def test_cli_rejects_a_query_alignment_of_another_length(tmp_path):
+    q = tmp_path / 'short.fa'
+    with open(q, 'w') as f:
+        f.write('>q1\nACGTACGT\n>q2\nACGTACGA\n')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_apples.py'), '-s', os.path.join(DATA, 'ref.fa'), '-q', str(q),
+                        '-t', os.path.join(DATA, 'backbone.nwk'), '-D'], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and 'sites' in r.stderr
+
+
+def test_worker_with_two_device_entries_matches_one(tmp_path):
+    """worker._run_sharded: one host thread and one engine context per device entry, contiguous query
+    shards, host concatenation.  Two entries naming device 0 exercise the threaded path on a one-GPU
+    box (every C-ABI entry sets its context's device itself); set_options from the main thread
+    afterwards must land on the contexts' device."""
+    import numpy as np
+    from apples_amd import synth
+    from apples_amd.fasta import Alignment
+    from apples_amd.options import options_config
+    from apples_amd.reference import ReducedReference
+    from apples_amd.worker import QueryWorker
+    d = synth.make_dataset(1500, 300, 301)
+    opts, _ = options_config(['-t', 'x', '-s', 'r', '-q', 'q', '-m', 'OLS'])
+    ref = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, None)
+    one = QueryWorker(d.tree, opts, ref, devices=(0,))
+    n1, r1 = one.run_sequences(d.query_names, d.query_seqs, rows=True)
+    one.close()
+    two = QueryWorker(d.tree, opts, ref, devices=(0, 0, 0))
+    n2, r2 = two.run_sequences(d.query_names, d.query_seqs, rows=True)
+    assert n1 == n2 and r1 == r2 and len(two._engines) == 3
+    for e in two._engines.values():
+        e.set_options(method='FM')
+    opts.method_name = 'FM'
+    n3, r3 = two.run_sequences(d.query_names, d.query_seqs, rows=True)
+    two.close()
+    fm = QueryWorker(d.tree, opts, ref, devices=(0,))
+    n4, r4 = fm.run_sequences(d.query_names, d.query_seqs, rows=True)
+    fm.close()
+    assert r3 == r4 and r3 != r1

@@ -24,6 +24,14 @@ def c2():
     return d, nodes
 
 
+@pytest.fixture(scope='module')
+def c2_full():
+    """BASELINE config 2 in full: 10 000 leaves, L = 1000, 10 000 queries."""
+    d = synth.make_dataset(10000, 1000, 10000)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    return d, nodes
+
+
 def _compare(got, want, co, d, nodes, what):
     """Edges bit-exact, lengths within 1e-6 relative; a differing edge is accepted only if it is the
     documented tie class: the two candidate edges' residuals agree to 1e-12."""
@@ -90,13 +98,18 @@ def test_big_tree_node_map_and_tag_wrap_around(c2, monkeypatch):
     assert again.tobytes() == want.tobytes()
 
 
-def test_properties_at_full_c2_query_count(c2):
-    """Size-independent properties on the whole pass: determinism across runs and batch sizes,
-    permutation equivariance over queries, duplicates of reference rows place exactly."""
-    d, nodes = c2
+def test_properties_at_full_c2_query_count(c2_full):
+    """Size-independent properties on the whole C2 pass (all 10 000 queries): determinism across runs
+    and batch sizes, permutation equivariance over queries, duplicates of reference rows place exactly;
+    a strided sample of 80 queries byte for byte against the C oracle."""
+    d, nodes = c2_full
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
     q = d.query_seqs
+    assert len(q) == 10000
     a = eng.place_sequences(q)
+    sample = np.arange(0, 10000, 125)
+    co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', lut=jc69_lut(1000, 0.001), threads=len(os.sched_getaffinity(0)))
+    assert a[sample].tobytes() == co.place_sequences(q[sample]).tobytes()
     b = eng.place_sequences(q)
     assert a.tobytes() == b.tobytes()
     perm = np.random.default_rng(0).permutation(len(q))

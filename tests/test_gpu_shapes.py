@@ -1,0 +1,176 @@
+"""HIP path vs the C oracle at the FULL shapes of BASELINE.json's configs 3, 4 and 5 (reference size,
+alignment length, method), with enough queries for several device batches; a sample of at least 64
+queries per config -- the ones with the fewest and the most observed leaves plus a strided set -- is
+compared with the C oracle, and the whole pass must not depend on how the device cuts it into
+batches.  Needs an MI355X (and a few GB of host memory for the synthetic inputs)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+from oracle_c import COracle  # noqa: E402
+
+from apples_amd import synth  # noqa: E402
+from apples_amd.engine import Engine, jc69_lut, F_EXACT, F_INSUFFICIENT  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+NTHREADS = len(os.sched_getaffinity(0))
+
+
+def _sample(got, n, extremes=8, strided=56):
+    order = np.argsort(got['n_obs'], kind='stable')
+    return np.unique(np.concatenate([order[:extremes], order[-extremes:],
+                                     np.linspace(0, n - 1, strided).astype(np.int64)]))
+
+
+def test_c3_shape_200k_leaves_two_device_batches():
+    """Config 3: 200 000-leaf backbone, L = 1000 nt, OLS/JC69, -f 0.2 -b 25.  20 000 queries: at
+    this reference size a device batch holds about 14 000, so the tagged node map of the sweep is
+    reused across batches, the top-up selection by segment minima runs on 200 k-slot rows and the
+    host-buffer entry point streams its chunks.  Checked: >= 64 sampled queries byte for byte
+    against the C oracle; the resident and the streamed entry points agree; the result does not
+    depend on the batch size."""
+    nq = 20000
+    d = synth.make_dataset(200000, 1000, nq)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    info = eng.describe()
+    assert info['n_nodes'] == 399999 and info['n_refs'] == 200000 and info['length'] == 1000
+    got = eng.place_sequences(d.query_seqs)          # host buffer in, host buffer out (streamed chunks)
+    batch = eng.describe()['batch']
+    assert batch < nq, 'expected at least two device batches, got batch = %d' % batch
+    h, n = eng.upload_queries(d.query_seqs)          # resident block
+    eng.place_resident(h)
+    assert eng.fetch(h, n).tobytes() == got.tobytes()
+    eng.free_queries(h)
+    eng.close()
+    sample = _sample(got, nq)
+    assert len(sample) >= 64
+    co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', lut=jc69_lut(1000, 0.001), threads=NTHREADS)
+    want = co.place_sequences(d.query_seqs[sample])
+    assert np.array_equal(got[sample]['edge'], want['edge'])
+    assert got[sample].tobytes() == want.tobytes()
+    assert ((got['flags'] & (F_EXACT | F_INSUFFICIENT)) != 0).sum() < nq // 50
+    # another cut into device batches: same bytes
+    e2 = Engine(d.tree, d.ref_seqs, nodes, method='OLS', max_batch=4096)
+    again = e2.place_sequences(d.query_seqs[:9000])
+    assert e2.describe()['batch'] == 4096
+    e2.close()
+    assert again.tobytes() == got[:9000].tobytes()
+
+
+def test_c4_shape_50k_leaves_L500_protein_fm():
+    """Config 4: 50 000-leaf backbone, L = 500 aa, scoredist + FM.  8 192 queries through the device;
+    sampled queries against the C oracle: edges, flags and counts identical, lengths and residuals
+    within 1e-9 relative (both sides sum the table values in fp64 left to right; the reference's own
+    order is BLAS-internal, SURVEY row a3, which is why this row is tolerance-checked)."""
+    nq = 8192
+    d = synth.make_dataset(50000, 500, nq, protein=True)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, protein=True, method='FM')
+    assert eng.describe()['length'] == 500 and eng.describe()['n_refs'] == 50000
+    got = eng.place_sequences(d.query_seqs)
+    eng.close()
+    e2 = Engine(d.tree, d.ref_seqs, nodes, protein=True, method='FM', max_batch=1024)
+    again = e2.place_sequences(d.query_seqs[:3000])
+    e2.close()
+    assert again.tobytes() == got[:3000].tobytes()
+    sample = _sample(got, nq)
+    assert len(sample) >= 64
+    co = COracle(d.tree, d.ref_seqs, nodes, protein=True, method='FM', threads=NTHREADS)
+    want = co.place_sequences(d.query_seqs[sample])
+    g = got[sample]
+    for f in ('edge', 'flags', 'n_obs', 'n_valid'):
+        assert np.array_equal(g[f], want[f]), f
+    for f in ('error', 'distal', 'pendant'):
+        np.testing.assert_allclose(g[f], want[f], rtol=1e-9, atol=1e-15, err_msg=f)
+
+
+def test_c5_shape_200k_column_distance_table_bme():
+    """Config 5: -d input, 200 000 columns, BME.  256 table rows (410 MB), several device batches
+    (max_batch = 96), rows with missing values, an exact hit, a row with nothing observed; every row
+    byte for byte against the C oracle, resident and host-buffer entry points identical."""
+    nq = 256
+    d = synth.make_dataset(200000, 8, nq)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ix = synth.TreeIndex(d.tree)
+    D = synth.fast_distance_rows(d.tree, ix, d.query_leaf, d.query_pendant, list(range(nq)))
+    D[5, ::3] = -1.0
+    D[6, :] = -1.0
+    D[7, 123456] = 0.0
+    eng = Engine(d.tree, None, method='BME', max_batch=96)
+    h, n = eng.upload_table(D, nodes)
+    eng.place_resident(h)
+    got = eng.fetch(h, n)
+    eng.free_queries(h)
+    assert eng.describe()['batch'] == 96
+    assert eng.place_distances(D, nodes).tobytes() == got.tobytes()
+    eng.close()
+    e2 = Engine(d.tree, None, method='BME')
+    assert e2.place_distances(D[:100], nodes).tobytes() == got[:100].tobytes()
+    e2.close()
+    want = COracle(d.tree, method='BME', threads=NTHREADS).place_distances(D, nodes)
+    assert got.tobytes() == want.tobytes()
+    assert got[7]['flags'] & F_EXACT and got[6]['flags'] & F_INSUFFICIENT
+
+
+def test_resident_table_is_refused_after_the_column_layout_changed():
+    """A resident -d block was permuted with the column order of its upload; placing another table
+    with different columns of the same number replaces that order.  The old block must be refused,
+    not silently run against the wrong node map."""
+    d = synth.make_dataset(400, 8, 8)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ix = synth.TreeIndex(d.tree)
+    D = synth.fast_distance_rows(d.tree, ix, d.query_leaf, d.query_pendant, list(range(8)))
+    eng = Engine(d.tree, None, method='BME')
+    h, n = eng.upload_table(D, nodes)
+    eng.place_resident(h)
+    first = eng.fetch(h, n)
+    perm = np.random.default_rng(1).permutation(len(nodes))
+    other = eng.place_distances(D[:, perm], nodes[perm])      # same table, columns in another order
+    assert other.tobytes() == first.tobytes()
+    with pytest.raises(RuntimeError, match='column layout changed'):
+        eng.place_resident(h)
+    eng.free_queries(h)
+    h2, n = eng.upload_table(D, nodes)
+    eng.place_resident(h2)
+    assert eng.fetch(h2, n).tobytes() == first.tobytes()
+    eng.close()
+
+
+def test_query_matrix_of_another_length_is_refused():
+    """The reference fails loudly when query and reference lengths differ (numpy elementwise compare,
+    apples/distance.py:733); bytes must never be re-chunked into a different number of queries."""
+    d = synth.make_dataset(300, 64, 4)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    bad = np.full((4, 32), ord('A'), np.uint8)   # 4 x 32 bytes would re-chunk into 2 x 64
+    for call in (eng.place_sequences, eng.upload_queries, eng.distances, eng.place_sequences_streamed):
+        with pytest.raises(ValueError, match='reference alignment length'):
+            call(bad)
+    assert len(eng.place_sequences(d.query_seqs)) == 4
+    eng.close()
+
+
+def test_exotic_symbols_in_a_later_chunk_of_a_streamed_block():
+    """apples_place_from_sequences streams the caller's buffer chunk by chunk; a symbol beyond ACGT-
+    in a later chunk is only seen after earlier chunks ran on the 2-plane images.  The call must then
+    widen the reference to raw bytes and give the same answer as a context that saw such a symbol from
+    the start ("any other byte is an ordinary symbol", apples/distance.py:733)."""
+    d = synth.make_dataset(1500, 200, 400)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    q = d.query_seqs.copy()
+    q[333, 17] = ord('*')
+    q[334, :50] = ord('N')
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS', max_batch=64)
+    assert eng.describe()['code_planes'] == 2
+    got = eng.place_sequences(q)
+    assert eng.describe()['code_planes'] == 8
+    eng.close()
+    co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', lut=jc69_lut(200, 0.001), threads=NTHREADS)
+    want = co.place_sequences(q)
+    assert got.tobytes() == want.tobytes()

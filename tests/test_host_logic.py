@@ -445,3 +445,60 @@ def test_native_clustering_sweep_equals_the_python_sweep():
             assert native == C._max_clusters_py(tree, thr)
             checked += 1
     assert checked == 1500
+
+
+def test_database_flag_combinations_follow_the_reference(caplog):
+    """apples/OptionsRun.py:88-107: -a with -s is an error; -a with -t or -d is accepted with a warning
+    (the user's tree wins, database sequences are ignored); -a alone needs no -t."""
+    import logging
+    with pytest.raises(ValueError):
+        options_config(['-a', 'db', '-s', 'r.fa', '-q', 'q.fa'])
+    with caplog.at_level(logging.WARNING):
+        o, _ = options_config(['-a', 'db', '-t', 'x.nwk', '-q', 'q.fa'])
+        assert o.tree_fp == 'x.nwk' and o.database_fp == 'db'
+        assert 'User provided tree has higher priority' in caplog.text
+        caplog.clear()
+        o, _ = options_config(['-a', 'db', '-d', 'd.mat'])
+        assert o.reestimate_backbone is False
+        assert 'Database sequences will be ignored' in caplog.text
+    o, _ = options_config(['-a', 'db', '-q', 'q.fa'])
+    assert o.tree_fp is None
+    with pytest.raises(ValueError):
+        options_config(['-q', 'q.fa'])
+
+
+def test_reference_alignment_may_hold_rows_beyond_the_clusters(tmp_path):
+    """The reference builds representatives from TreeCluster's output (backbone leaves) alone
+    (apples/Reference.py:94-107): rows of -s that are not backbone leaves are never compared, but
+    their names still keep them out of the query set of an extended alignment (run_apples.py:85-89).
+    ReducedReference keeps the full alignment for names and a clustered subset for the device."""
+    from apples_amd import database, treecluster
+    from apples_amd.fasta import Alignment
+    from apples_amd.tree import extended_newick, read_tree
+    tree = read_tree(os.path.join(DATA, 'backbone.nwk'))
+    a0 = read_alignment(os.path.join(DATA, 'ref.fa'), False, False)
+    extra = np.full((2, a0.length), ord('A'), np.uint8)
+    # two extra rows, one in the middle, one at the end
+    names = a0.names[:100] + ['not_in_tree_1'] + a0.names[100:] + ['not_in_tree_2']
+    seqs = np.vstack([a0.seqs[:100], extra[:1], a0.seqs[100:], extra[1:]])
+    sup = Alignment(names, seqs)
+    clusters = treecluster.grouped(tree, 0.2 * 1.2)
+    r0 = ReducedReference(a0, False, clusters)
+    r1 = ReducedReference(sup, False, clusters)
+    assert r0.eng_rows is None and r0.eng_aln is r0.aln
+    assert len(r1.aln) == len(a0) + 2 and 'not_in_tree_1' in r1.aln.index
+    assert r1.eng_aln.names == a0.names and np.array_equal(r1.eng_aln.seqs, a0.seqs)
+    for got, want in zip(r1.cluster_arrays(), r0.cluster_arrays()):
+        assert np.array_equal(got, want)
+    # the database cache keeps both views
+    db = str(tmp_path / 'sup.dtb')
+    database.save(db, tree, extended_newick(tree), r1, 0.2)
+    _, _, r2, _, _ = database.load(db)
+    assert r2.aln.names == names and r2.eng_aln.names == a0.names
+    for got, want in zip(r2.cluster_arrays(), r0.cluster_arrays()):
+        assert np.array_equal(got, want)
+    # a sequence listed twice is still an error; a cluster member without a sequence is a KeyError
+    with pytest.raises(ValueError):
+        ReducedReference(a0, False, [('-1', [a0.names[0], a0.names[0]])])
+    with pytest.raises(KeyError):
+        ReducedReference(a0, False, [('-1', ['no_such_sequence'])])
