@@ -147,14 +147,109 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
         for (int i = 0; i < t->n_nodes; ++i) rec_l[lpos[i]] = rec[i];
         if (dev_upload(ctx, &d.rec_l, rec_l.data(), (int64_t)rec_l.size())) return 1;
     }
+    // Scan formulation of the sweep (sweep_scan.hip), an alternative kept behind APPLES_SWEEP_SCAN=1: same
+    // bytes out, no atomics and no node map, but slower than the level loop on MI355X as measured.
+    // Per leaf, by level, the ancestor's edge length and node id, and an Euler-tour range-minimum table for
+    // lowest common ancestors.  Needs post-order node ids (a subtree = a contiguous id range ending at its
+    // root), at most 254 levels and tables of a sensible size.
+    d.scan = false;
+    if (getenv("APPLES_SWEEP_SCAN") && h <= 254) {
+        const int n = t->n_nodes;
+        std::vector<int64_t> size(n, 1);
+        bool postorder = true;
+        for (int i = 0; i < n - 1 && postorder; ++i) {
+            const int p = t->parent[i];
+            if (p <= i || p >= n) postorder = false; else size[p] += size[i];
+        }
+        if (postorder && (t->parent[n - 1] != -1 || size[n - 1] != n)) postorder = false;
+        for (int i = 0; i < n && postorder; ++i) {  // children tile the parent's range from the left, in file order
+            int64_t at = i - size[i] + 1;
+            for (int c = t->child_off[i]; c < t->child_off[i + 1]; ++c) {
+                const int k = t->child_idx[c];
+                if (k - size[k] + 1 != at) { postorder = false; break; }
+                at = k + 1;
+            }
+            if (postorder && t->child_off[i + 1] > t->child_off[i] && at != i) postorder = false;
+        }
+        int64_t total = 0;
+        for (int i = 0; i < n; ++i)
+            if (t->child_off[i + 1] == t->child_off[i]) total += t->level[i] + 1;
+        static const int64_t max_entries = getenv("APPLES_SCAN_TABLE_MAX") ? atoll(getenv("APPLES_SCAN_TABLE_MAX")) : ((int64_t)200 << 20);
+        if (postorder && total <= max_entries) {
+            std::vector<int4> info(n);
+            std::vector<AncRec> anc((size_t)total);
+            int64_t at = 0;
+            for (int i = 0; i < n; ++i) {
+                info[i] = make_int4(-1, t->level[i], -1, 0);
+                if (t->child_off[i + 1] != t->child_off[i]) continue;
+                info[i].x = (int32_t)at;
+                int v = i;
+                for (int m = t->level[i]; m >= 0; --m) {
+                    if (v < 0 || t->level[v] != m) { postorder = false; break; }  // (level must be the depth)
+                    anc[(size_t)at + m].e = t->edge_len[v];
+                    anc[(size_t)at + m].node = v;
+                    anc[(size_t)at + m].pad = 0;
+                    v = t->parent[v];
+                }
+                at += t->level[i] + 1;
+            }
+            // Euler tour of levels (a node's level on entry and again after each child) and its sparse table
+            std::vector<uint8_t> euler;
+            euler.reserve((size_t)2 * n);
+            {
+                std::vector<std::pair<int, int>> stack;  // (node, next child)
+                stack.emplace_back(n - 1, 0);
+                while (!stack.empty() && postorder) {
+                    auto &top = stack.back();
+                    const int v = top.first;
+                    if (top.second == 0 && t->child_off[v + 1] == t->child_off[v]) info[v].z = (int32_t)euler.size();
+                    euler.push_back((uint8_t)t->level[v]);
+                    const int c = t->child_off[v] + top.second;
+                    if (c < t->child_off[v + 1]) { ++top.second; stack.emplace_back(t->child_idx[c], 0); }
+                    else {
+                        stack.pop_back();
+                        // (the parent's level is appended when control returns to it: its loop iteration pushes it)
+                    }
+                }
+            }
+            const int64_t elen = (int64_t)euler.size();
+            int K = 1;
+            while (((int64_t)1 << K) <= elen) ++K;
+            if (postorder && elen * K <= ((int64_t)1 << 31)) {
+                std::vector<uint8_t> rmq((size_t)elen * K);
+                std::copy(euler.begin(), euler.end(), rmq.begin());
+                for (int k = 1; k < K; ++k) {
+                    const uint8_t *prev = rmq.data() + (size_t)(k - 1) * elen;
+                    uint8_t *cur = rmq.data() + (size_t)k * elen;
+                    const int64_t half = (int64_t)1 << (k - 1);
+                    for (int64_t x = 0; x < elen; ++x) cur[x] = std::min(prev[x], prev[std::min(x + half, elen - 1)]);
+                }
+                if (dev_upload(ctx, &d.leaf_info, info.data(), n)) return 1;
+                if (dev_upload(ctx, &d.anc, anc.data(), total)) return 1;
+                if (dev_upload(ctx, &d.rmq, rmq.data(), (int64_t)rmq.size())) return 1;
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                d.euler_len = (int32_t)elen;
+                d.rmq_k = K;
+                d.scan = true;
+            }
+        }
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
 // sort keys so that deeper leaves come first; rows that are not tree leaves go last
-std::vector<int32_t> level_order(const int32_t *node, int64_t n, const std::vector<int32_t> &level) {
+// (scan formulation of the sweep: by node id alone -- the sweep wants its leaves in post-order)
+std::vector<int32_t> level_order(const int32_t *node, int64_t n, const std::vector<int32_t> &level, bool by_id = false) {
     std::vector<int32_t> idx(n);
     std::iota(idx.begin(), idx.end(), 0);
+    if (by_id) {
+        std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
+            const int64_t ka = node[a] >= 0 ? node[a] : ((int64_t)1 << 40), kb = node[b] >= 0 ? node[b] : ((int64_t)1 << 40);
+            return ka < kb;
+        });
+        return idx;
+    }
     std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
         int la = node[a] >= 0 ? level[node[a]] : -1;
         int lb = node[b] >= 0 ? level[node[b]] : -1;
@@ -179,7 +274,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
     std::vector<int32_t> level(t->level, t->level + t->n_nodes);
     for (int64_t r = 0; r < a.n_refs; ++r)
         if (al->row_node[r] >= t->n_nodes) { ctx->err = "row_node out of range"; return 1; }
-    std::vector<int32_t> ord = level_order(al->row_node, a.n_refs, level);
+    std::vector<int32_t> ord = level_order(al->row_node, a.n_refs, level, ctx->tree.scan);
     a.slot_row.assign(a.n_rows, 0);
     a.row_slot.assign(a.n_rows, 0);
     for (int64_t s = 0; s < a.n_refs; ++s) { a.slot_row[s] = ord[s]; a.row_slot[ord[s]] = (int32_t)s; }
@@ -310,13 +405,15 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
 }
 
 // observed-leaf count above which a query goes straight to a workgroup-sized sweep team
-int big_threshold() {
+int big_threshold(const apples_ctx *ctx) {
     static const int v = getenv("APPLES_BIG_THRESHOLD") ? atoi(getenv("APPLES_BIG_THRESHOLD")) : 4096;
-    return v;
+    // scan sweep: a wavefront-sized team keeps the per-leaf state of at most SCAN_LDS_LEAVES_SMALL leaves in LDS
+    return ctx->tree.scan ? std::min(v, SCAN_LDS_LEAVES_SMALL) : v;
 }
 
 void free_sweep(Workspace::Sweep &sw) {
     dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
+    dev_free(sw.ent_f); dev_free(sw.ent_i); dev_free(sw.leaf_g); dev_free(sw.meta);
     sw = Workspace::Sweep();
 }
 
@@ -354,6 +451,22 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
     sw.teams = (int64_t)wgs * teams_per_wg;
     sw.cap = cap;
     sw.leaf_cap = leaf_cap;
+    if (t.scan) {  // scan formulation: component arrays of `cap` entries per team (16-byte aligned pairs)
+        sw.cap = cap = round_up(cap, 64);
+        if (dev_alloc(ctx, &sw.ent_f, sw.teams * 13 * cap)) return 1;
+        if (dev_alloc(ctx, &sw.ent_i, sw.teams * 5 * cap)) return 1;
+        if (dev_alloc(ctx, &sw.meta, sw.teams * 4)) return 1;
+        const int lds_leaves = teams_per_wg == 1 ? SCAN_LDS_LEAVES_BIG : SCAN_LDS_LEAVES_SMALL;
+        if (leaf_cap > lds_leaves) {
+            sw.leaf_cap = leaf_cap = round_up(leaf_cap, 2);
+            if (dev_alloc(ctx, &sw.leaf_g, sw.teams * leaf_cap * 3)) return 1;  // 6 bytes per leaf
+        } else {
+            sw.leaf_cap = 0;
+        }
+        if (xe)
+            if (dev_alloc(ctx, &sw.xe, sw.teams * cap * 18)) return 1;
+        return 0;
+    }
     if (!sweep_bits_in_lds(t)) {
         if (dev_alloc(ctx, &sw.map, sw.teams * (int64_t)t.n_nodes)) return 1;
         HIP_TRY(ctx, hipMemsetAsync(sw.map, 0, (size_t)sw.teams * t.n_nodes * 4, ctx->stream));
@@ -435,13 +548,13 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     int64_t nn = t.n_nodes;
     // big trees keep a node map of n_nodes ints per team (<= ~8 GiB in total)
     // (2 048 teams are resident at two wavefronts per SIMD; 3 072 measured best at both 10 k and 200 k leaves)
-    int64_t teams = sweep_bits_in_lds(t) ? 3072 : std::min<int64_t>(3072, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
+    int64_t teams = (t.scan || sweep_bits_in_lds(t)) ? 3072 : std::min<int64_t>(3072, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
-    int64_t per_node = 68 + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
+    int64_t per_node = t.scan ? 120 + (xe ? 144 : 0) : 68 + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
-    if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold())), xe)) return 1;
+    if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, t.scan ? 0 : std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold(ctx))), xe)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
     int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 4;
     int64_t big_max = getenv("APPLES_SWEEP_BIG_WGS") ? atoi(getenv("APPLES_SWEEP_BIG_WGS")) : 512;
@@ -572,9 +685,10 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     s.n_members = a.n_refs; s.n_reps = a.n_reps; s.all_singleton = a.all_singleton ? 1 : 0; s.table_mode = 0;
     s.self_slot = qb.self_slot + q0;
     s.thr = ctx->params.filt_threshold; s.baseobs = ctx->params.base_observation; s.height = ctx->tree.height;
-    s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
+    s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.n_obs = w.n_obs;
+    s.cnt_gt = ctx->tree.scan ? nullptr : w.cnt_gt;  // (the scan sweep takes its leaves in node-id order and needs no per-level offsets)
     s.out = qb.out + q0;
-    s.big_threshold = big_threshold(); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+    s.big_threshold = big_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     s.seg_slot = w.seg_slot; s.seg_cnt = w.seg_cnt; s.node_level = ctx->tree.level;
     s.slow_list = w.slow_list; s.slow_count = w.slow_count; s.qlist = nullptr; s.qcount = nullptr;
@@ -598,11 +712,58 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
     static const int dbg = getenv("APPLES_SWEEP_DEBUG_PHASE") ? atoi(getenv("APPLES_SWEEP_DEBUG_PHASE")) : 0;
     s.debug_phase = dbg;
-    s.work_list = nullptr; s.work_count = nullptr; s.big_threshold = big_threshold();
+    s.work_list = nullptr; s.work_count = nullptr; s.big_threshold = big_threshold(ctx);
     s.cls_list = nullptr; s.cls_count = nullptr; s.cls_stride = w.batch; s.cursor = w.cls_count + 4;
     s.overflow_list = w.overflow_list; s.overflow_count = w.overflow_count;
     s.out = out;
     return s;
+}
+
+ScanArgs scan_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placement *out, bool keep_edges, bool big) {
+    Workspace &w = ctx->ws;
+    const DevTree &t = ctx->tree;
+    ScanArgs s{};
+    s.leaf_info = t.leaf_info; s.anc = t.anc; s.rmq = t.rmq; s.euler_len = t.euler_len; s.n_nodes = t.n_nodes; s.height = t.height;
+    s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.n_obs = w.n_obs;
+    s.ent_f = sw.ent_f; s.ent_i = sw.ent_i; s.xe = sw.xe; s.leaf_g = sw.leaf_g; s.meta = sw.meta;
+    s.cap = sw.cap; s.leaf_cap = sw.leaf_cap;
+    s.lds_leaves = big ? SCAN_LDS_LEAVES_BIG : SCAN_LDS_LEAVES_SMALL;
+    s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
+    s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
+    s.big_threshold = big_threshold(ctx);
+    s.work_list = nullptr; s.work_count = nullptr; s.cls_list = nullptr; s.cls_count = nullptr; s.cls_stride = w.batch;
+    s.cursor = w.cls_count + 4;
+    s.overflow_list = w.overflow_list; s.overflow_count = w.overflow_count;
+    s.out = out;
+    s.prof = ctx->scan_prof;
+    return s;
+}
+
+// the same launch structure as run_sweep below, for the scan formulation (sweep_scan.hip)
+int run_scan(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st) {
+    Workspace &w = ctx->ws;
+    static const int small_team = getenv("APPLES_SWEEP_TEAM") ? atoi(getenv("APPLES_SWEEP_TEAM")) : 64;  // tuning knob
+    ScanArgs b = scan_args(ctx, w.big, out, false, true);
+    b.overflow_list = nullptr;  // a big team's scratch holds the whole tree and any number of leaves
+    b.overflow_count = nullptr;
+    b.cursor = w.cls_count + 5;
+    if (small_team != 64) {  // diagnostic mode: workgroup-sized teams for everything
+        b.cursor = w.cls_count + 4;
+        return launch_scan(ctx, b, nq, w.big.wgs, 256, st);
+    }
+    b.work_list = w.route_list;
+    b.work_count = w.route_count;
+    HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), st));
+    ScanArgs sm = scan_args(ctx, w.small, out, false, false);
+    sm.cls_list = w.cls_list;
+    sm.cls_count = w.cls_count;
+    sm.cursor = w.cls_count + 4;
+    if (launch_scan_mixed(ctx, sm, b, nq, w.small.wgs, w.big.wgs, st)) return 1;
+    if (w.small.cap >= ctx->tree.n_nodes) return 0;  // a small team's arrays hold any subtree: nothing can overflow
+    b.work_list = w.overflow_list;
+    b.work_count = w.overflow_count;
+    b.cursor = w.cls_count + 6;
+    return launch_scan(ctx, b, nq, w.big.wgs, 256, st);
 }
 
 // The sweep for one device batch: wavefront-sized teams first, then workgroup-sized teams with
@@ -612,6 +773,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
 int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st = nullptr) {
     Workspace &w = ctx->ws;
     if (!st) st = ctx->stream;
+    if (ctx->tree.scan) return run_scan(ctx, out, nq, st);
     static const int small_team = getenv("APPLES_SWEEP_TEAM") ? atoi(getenv("APPLES_SWEEP_TEAM")) : 64;  // tuning knob
     SweepArgs b = sweep_args(ctx, w.big, out, false);
     b.overflow_list = nullptr;  // a big team's scratch holds the whole tree: it cannot overflow
@@ -820,6 +982,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return fail(); }
     if (tree->n_nodes < 2) { ctx->err = "tree needs at least two nodes"; return fail(); }
     if (dev_alloc(ctx, &ctx->d_exotic, 1) || hipMemset(ctx->d_exotic, 0, sizeof(int)) != hipSuccess) return fail();
+    if (getenv("APPLES_SCAN_PROFILE"))
+        if (dev_alloc(ctx, &ctx->scan_prof, 8) || hipMemset(ctx->scan_prof, 0, 64) != hipSuccess) return fail();
     if (upload_tree(ctx, tree)) return fail();
     if (aln) {
         if (setup_alignment(ctx, tree, aln)) return fail();
@@ -878,6 +1042,15 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+    if (ctx->scan_prof) {  // diagnostic: where the scan sweep's teams spent their cycles
+        unsigned long long h[8] = {};
+        (void)hipMemcpy(h, ctx->scan_prof, sizeof h, hipMemcpyDeviceToHost);
+        double tot = 0;
+        for (int i = 0; i < 6; ++i) tot += (double)h[i];
+        fprintf(stderr, "scan sweep phases (share of team cycles): queue %.3f  phase0 %.3f  phase1 %.3f  bottom-up %.3f  top-down %.3f  select %.3f  (queries %llu)\n",
+                h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6]);
+        dev_free(ctx->scan_prof);
+    }
     for (auto &qb : ctx->blocks) free_block(ctx, &qb);
     for (auto &c : ctx->blk_cache) dev_free(c.second);
     ctx->blk_cache.clear();
@@ -885,7 +1058,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     for (auto &e : ctx->ev_feed) (void)hipEventDestroy(e);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
-    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos);
+    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
     dev_free(a.raw); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
@@ -1083,7 +1256,7 @@ static int setup_columns(apples_ctx *ctx, int64_t n_cols, const int32_t *col_nod
     for (int64_t c = 0; c < n_cols; ++c)
         if (col_node[c] >= t.n_nodes) { ctx->err = "col_node out of range"; return 1; }
     std::vector<int32_t> &perm = ctx->h_col_perm;
-    perm = level_order(col_node, n_cols, level);
+    perm = level_order(col_node, n_cols, level, ctx->tree.scan);
     std::vector<int32_t> s_node(n_cols), s_level(n_cols);
     for (int64_t s = 0; s < n_cols; ++s) {
         int nd = col_node[perm[s]];
@@ -1113,9 +1286,10 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.n_members = n_cols; s.n_reps = n_cols; s.all_singleton = 1; s.table_mode = 1; s.self_slot = d_self;
     s.cols_all_in_tree = std::all_of(ctx->h_col_node.begin(), ctx->h_col_node.end(), [](int32_t v) { return v >= 0; });
     s.thr = ctx->params.filt_threshold; s.baseobs = ctx->params.base_observation; s.height = ctx->tree.height;
-    s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
+    s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.n_obs = w.n_obs;
+    s.cnt_gt = ctx->tree.scan ? nullptr : w.cnt_gt;
     s.out = d_out;
-    s.big_threshold = big_threshold(); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+    s.big_threshold = big_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 16 * sizeof(int32_t), ctx->stream));  // every counter of the batch
     pt.flush();
@@ -1236,11 +1410,62 @@ static int run_table_block(apples_ctx *ctx, QueryBlock &qb) {
     return 0;
 }
 
+static int sweep_edges_scan(apples_ctx *ctx, const int32_t *obs_node, const double *obs_dist, int32_t n_obs, uint8_t *valid,
+                            double *S, double *R, double *x, double *err, int32_t *lca, apples_placement *out) {
+    const DevTree &t = ctx->tree;
+    std::vector<int32_t> level;  // unused by the id ordering
+    std::vector<int32_t> ord = level_order(obs_node, n_obs, level, true);
+    std::vector<int32_t> s_node(n_obs);
+    std::vector<double> s_dist(n_obs);
+    for (int i = 0; i < n_obs; ++i) { s_node[i] = obs_node[ord[i]]; s_dist[i] = obs_dist[ord[i]]; }
+    for (int i = 1; i < n_obs; ++i)
+        if (s_node[i] == s_node[i - 1]) { ctx->err = "an observed leaf is listed twice"; return 1; }
+    if (ensure_workspace(ctx, std::max<int64_t>(n_obs, ctx->ws.obs_cap), std::max<int64_t>(n_obs, 1), 1, true, false, true)) return 1;
+    Workspace &w = ctx->ws;
+    apples_placement *d_out = nullptr;
+    if (dev_alloc(ctx, &d_out, 1)) return 1;
+    apples_placement init{};
+    init.n_obs = n_obs;
+    HIP_TRY(ctx, hipMemcpy(d_out, &init, sizeof(init), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(w.obs_node, s_node.data(), (size_t)n_obs * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(w.obs_dist, s_dist.data(), (size_t)n_obs * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(w.n_obs, &n_obs, 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 16 * sizeof(int32_t), ctx->stream));
+    ScanArgs sa = scan_args(ctx, w.big, d_out, true, true);
+    sa.overflow_list = nullptr; sa.overflow_count = nullptr;
+    if (launch_scan(ctx, sa, 1, 1, 256, ctx->stream)) { dev_free(d_out); return 1; }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    apples_placement res;
+    HIP_TRY(ctx, hipMemcpy(&res, d_out, sizeof(res), hipMemcpyDeviceToHost));
+    dev_free(d_out);
+    if (out) *out = res;
+    int32_t meta[4];
+    HIP_TRY(ctx, hipMemcpy(meta, w.big.meta, sizeof meta, hipMemcpyDeviceToHost));
+    const int V = meta[0];
+    if (lca) *lca = meta[1];
+    std::vector<double> xe((size_t)std::max(V, 1) * 18);
+    HIP_TRY(ctx, hipMemcpy(xe.data(), w.big.xe, (size_t)V * 144, hipMemcpyDeviceToHost));
+    if (valid) memset(valid, 0, t.n_nodes);
+    for (int i = 0; i < V; ++i) {
+        const double *xp = &xe[(size_t)i * 18];
+        const int v = (int)(xp[17] < 0 ? -xp[17] : xp[17]) - 1;  // the record's last slot carries the node id
+        if (valid) valid[v] = 1;
+        if (S) memcpy(S + (size_t)v * 6, xp + 11, 48);
+        if (R) memcpy(R + (size_t)v * 6, xp + 5, 48);
+        if (x) memcpy(x + (size_t)v * 4, xp, 32);
+        if (err) err[v] = xp[4];
+    }
+    return 0;
+}
+
 int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *obs_dist, int32_t n_obs, uint8_t *valid,
                        double *S, double *R, double *x, double *err, int32_t *lca, apples_placement *out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const DevTree &t = ctx->tree;
     if (n_obs < 2) { ctx->err = "need at least two observed leaves"; return 1; }
+    for (int i = 0; i < n_obs; ++i)
+        if (obs_node[i] < 0 || obs_node[i] >= t.n_nodes) { ctx->err = "obs_node out of range"; return 1; }
+    if (t.scan) return sweep_edges_scan(ctx, obs_node, obs_dist, n_obs, valid, S, R, x, err, lca, out);
     std::vector<int32_t> level(t.n_nodes);
     HIP_TRY(ctx, hipMemcpy(level.data(), t.level, (size_t)t.n_nodes * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < n_obs; ++i)
@@ -1335,11 +1560,11 @@ const char *apples_describe(apples_ctx *ctx) {
     snprintf(buf, sizeof buf,
              "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"n_rows\": %lld, "
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
-             "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d}",
+             "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\"}",
              name, cus, ctx->tree.n_nodes, ctx->tree.height, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
              (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
-             (long long)ctx->ws.small.cap, ctx->ws.big.wgs, ctx->jc_lut ? 1 : 0);
+             (long long)ctx->ws.small.cap, ctx->ws.big.wgs, ctx->jc_lut ? 1 : 0, ctx->tree.scan ? "scan" : "levels");
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

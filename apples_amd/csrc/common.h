@@ -30,6 +30,13 @@ struct __attribute__((aligned(64))) NodeRec {
     int32_t node;         // own id (what a reader of the position-ordered copy needs)
 };
 
+// one ancestor of a leaf (scan formulation of the sweep): edge length and node id
+struct __attribute__((aligned(16))) AncRec {
+    double e;
+    int32_t node;
+    int32_t pad;
+};
+
 struct DevTree {
     int32_t n_nodes = 0;
     int32_t height = 0;  // max level
@@ -47,7 +54,17 @@ struct DevTree {
     int32_t *lnode = nullptr;    // [bm_words*64] node at a bit position (-1 = padding)
     NodeRec *rec_l = nullptr;    // [bm_words*64] the records in bit-position order: position -> record in one load
     int32_t *npos = nullptr;     // [n_nodes][2] lpos, ppos (what a leaf needs, without its 64-byte record)
+    // scan formulation of the sweep (sweep_scan.hip): per leaf, by level m = 0..level(leaf), the ancestor at
+    // that level.  Built when the tree is shallow enough for the tables to fit (else the level-loop sweep runs).
+    bool scan = false;
+    int4 *leaf_info = nullptr;   // [n_nodes] {offset of the leaf's rows in `anc` (-1: not a leaf), level, Euler position, -}
+    AncRec *anc = nullptr;       // [sum(level+1)] the ancestor's edge length and node id
+    // level of the lowest common ancestor of two leaves = minimum of the Euler tour's levels between
+    // their positions: sparse table of range minima, rmq[k][t] = min level over tour steps [t, t + 2^k)
+    uint8_t *rmq = nullptr;      // [rmq_k][euler_len]
+    int32_t euler_len = 0, rmq_k = 0;
 };
+
 
 // Slot = physical position of an alignment row on the device.  Member slots [0, n_refs) are the
 // reference rows sorted by tree level, deepest first (rows that are not tree leaves last);
@@ -122,6 +139,11 @@ struct Workspace {
         void *A = nullptr;        // [teams][cap+1] Rec (64 B): S then R tuple, first two valid children, node
         void *B = nullptr;        // [teams][cap+1][6] R values in waiting; trees with polytomies only
         double *xe = nullptr;     // [teams][cap+leaf_cap][18] per-edge x, err, R, S (HYBRID / inspection)
+        // scan formulation: per team `cap` entries (one per subtree node) as component arrays
+        double *ent_f = nullptr;  // [teams][13][cap]: S[6], R[6] as pairs, edge length
+        int32_t *ent_i = nullptr; // [teams][5][cap]: ancestor-table row then node id, parent entry, first child entry, number of children, leaf index
+        uint16_t *leaf_g = nullptr; // [teams][leaf_cap] per-leaf (level, lca level) when a team's LDS cannot hold them
+        int32_t *meta = nullptr;  // [teams][4]: V, lca node, top level, -
     } small, big;
     int32_t *seg_slot = nullptr;       // [batch][stride] fused path: slots of the kept entries
     int32_t *seg_cnt = nullptr;        // [batch][stride/64]
@@ -164,6 +186,7 @@ struct apples_ctx {
     std::unordered_map<void *, size_t> blk_size;
     int *d_exotic = nullptr;         // device flag: a packed query block carried a symbol beyond ACGT-
     std::vector<hipEvent_t> ev_feed; // "chunk i of a streamed block is uploaded and packed"
+    unsigned long long *scan_prof = nullptr;  // APPLES_SCAN_PROFILE: per-phase cycle sums of the scan sweep
     // -d path: column layout cache
     int64_t col_gen = 0;             // bumped whenever the column layout below is replaced
     int64_t dcols = 0;
@@ -267,6 +290,29 @@ struct SweepArgs {
     int32_t *overflow_count;
     apples_placement *out;
 };
+// sweep_scan.hip
+struct ScanArgs {
+    const int4 *leaf_info; const AncRec *anc; const uint8_t *rmq;
+    int32_t euler_len;
+    int32_t n_nodes, height;
+    const int32_t *obs_node; const double *obs_dist; int64_t obs_cap; const int32_t *n_obs;
+    double *ent_f; int32_t *ent_i; double *xe; uint16_t *leaf_g; int32_t *meta;
+    int64_t cap;              // entries of scratch per team
+    int64_t leaf_cap;         // leaves a team's global leaf-state area holds (0: none)
+    int lds_leaves;           // leaves a team's LDS leaf-state area holds
+    int method, criterion, negative, keep_edges;
+    int big_threshold;
+    const int32_t *work_list; const int32_t *work_count;
+    const int32_t *cls_list; const int32_t *cls_count; int64_t cls_stride;
+    int32_t *cursor;
+    int32_t *overflow_list; int32_t *overflow_count;
+    apples_placement *out;
+    unsigned long long *prof;  // diagnostic (APPLES_SCAN_PROFILE): [8] cycles per phase summed over teams, or nullptr
+};
+int launch_scan_mixed(apples_ctx *ctx, const ScanArgs &small, const ScanArgs &big, int64_t nq, int wgs, int n_big, hipStream_t st);
+int launch_scan(apples_ctx *ctx, const ScanArgs &a, int64_t nq, int wgs, int team, hipStream_t st);
+#define SCAN_LDS_LEAVES_SMALL 2048   // per wavefront-sized team (4 per workgroup); 6 bytes of LDS per leaf
+#define SCAN_LDS_LEAVES_BIG 8192     // per workgroup-sized team
 bool sweep_bits_in_lds(const DevTree &t);  // the sweep's node bits fit in LDS (else: tagged node map in global scratch)
 int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team, hipStream_t stream = nullptr);
 int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,

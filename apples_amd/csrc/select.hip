@@ -147,7 +147,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     int z_i = 0x7fffffff, z_p = 0x7fffffff, z_node = -2;
     int32_t *o_node = a.obs_node + q * a.obs_cap;
     double *o_dist = a.obs_dist + q * a.obs_cap;
-    int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
+    int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
     for (int round = 0; round < 2; ++round) {
     // ---- top-up: smallest (d, i) beyond the threshold until baseobs observations -------------------
     // Each thread first caches the KL smallest candidates of its own strided slice (one pass over
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int64_t s = sb + e;
-            if (s <= nm) {  // level boundaries (virtual end slot nm has level -1)
+            if (cg && s <= nm) {  // level boundaries (virtual end slot nm has level -1)
                 int lv = (s < nm) ? a.slot_level[s] : -1;
                 int lprev = (s == 0) ? a.height + 1 : a.slot_level[s - 1];
                 for (int l = lv; l < lprev; ++l) cg[l + 1] = pos;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     }
     int32_t *o_node = a.obs_node + q * a.obs_cap;
     double *o_dist = a.obs_dist + q * a.obs_cap;
-    int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
+    int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
     int base = 0, n_total = 0;
     int z_i = 0x7fffffff, z_node = -2;
     for (int64_t s0 = 0; s0 < n_seg; s0 += APPLES_TPB) {
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     __syncthreads();
     const int n_emit = base;
     // per-level offsets into the level-sorted list (the sweep's cnt_gt)
-    for (int i = tid; i <= n_emit; i += APPLES_TPB) {
+    for (int i = tid; cg && i <= n_emit; i += APPLES_TPB) {
         const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
         const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
         for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
         const int self = a.self_slot ? a.self_slot[q] : -1;
         int32_t *o_node = a.obs_node + q * a.obs_cap;
         double *o_dist = a.obs_dist + q * a.obs_cap;
-        int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
+        int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
         double cut_d = -INF_D;
         int cut_i = -1;
         int n_total = 0, thr_cnt = 0, n_emit = 0;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
         if (z_i == zi && zi != 0x7fffffff) sh_znode = z_node;
         __syncthreads();
         // per-level offsets into the level-sorted list (the sweep's cnt_gt)
-        for (int i = tid; i <= n_emit; i += APPLES_TPB) {
+        for (int i = tid; cg && i <= n_emit; i += APPLES_TPB) {
             const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
             const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
             for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_topup(SelectArgs a) {
         const int self = a.self_slot ? a.self_slot[q] : -1;
         int32_t *o_node = a.obs_node + q * a.obs_cap;
         double *o_dist = a.obs_dist + q * a.obs_cap;
-        int32_t *cg = a.cnt_gt + q * (int64_t)(a.height + 2);
+        int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
         // ---- the B segments with the smallest minima, in key order
         int n_cand = 0;
         if (n_seg <= TOPUP_KEYS * APPLES_TPB) {  // keys fit in registers: wavefront-local rounds + one ranking
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_topup(SelectArgs a) {
         if (z_i == zi && zi != 0x7fffffff) sh_znode = z_node;
         __syncthreads();
         // per-level offsets into the level-sorted list (the sweep's cnt_gt)
-        for (int i = tid; i <= n_emit; i += APPLES_TPB) {
+        for (int i = tid; cg && i <= n_emit; i += APPLES_TPB) {
             const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
             const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
             for (int l = lv; l < lprev; ++l) cg[l + 1] = i;

@@ -393,16 +393,19 @@ def test_both_sweep_layouts_agree_on_polytomies(monkeypatch):
     cols = leaves.astype(np.int32)
     for m, c in (('OLS', 'MLSE'), ('BME', 'HYBRID'), ('FM', 'ME'), ('BE', 'HYBRID')):
         outs = []
-        for layout in ('bits', 'map'):
+        for layout in ('bits', 'map', 'scan'):
+            monkeypatch.delenv('APPLES_NODE_MAP', raising=False)
+            monkeypatch.delenv('APPLES_SWEEP_SCAN', raising=False)
+            if layout == 'scan':
+                monkeypatch.setenv('APPLES_SWEEP_SCAN', '1')
             if layout == 'map':
                 monkeypatch.setenv('APPLES_NODE_MAP', '1')
-            else:
-                monkeypatch.delenv('APPLES_NODE_MAP', raising=False)
             eng = Engine(tree, None, method=m, criterion=c, threshold=10.0, baseobs=5)
             outs.append(eng.place_distances(D, cols))
             eng.close()
-        assert outs[0].tobytes() == outs[1].tobytes(), (m, c)
+        assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes(), (m, c)
     monkeypatch.delenv('APPLES_NODE_MAP', raising=False)
+    monkeypatch.delenv('APPLES_SWEEP_SCAN', raising=False)
 
 
 @pytest.mark.parametrize('L,n_ref,n_q', [(77, 130, 16), (1000, 300, 100), (1620, 257, 300), (33, 64, 517), (64, 129, 17),

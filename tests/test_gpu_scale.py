@@ -59,12 +59,15 @@ def test_c2_reference_size_against_c_oracle(c2, method, criterion):
     eng.close()
 
 
-@pytest.mark.parametrize('layout', ['bits', 'map'])
+@pytest.mark.parametrize('layout', ['scan', 'bits', 'map'])
 def test_all_observed_stress_and_batching(c2, layout, monkeypatch):
     """-f huge: every leaf observed (worst case for both kernels, V = 2N-2; more than 4 096 observed
     leaves send every query to the workgroup-sized teams); also forces several device batches and
-    checks they agree with one big batch.  Both node-lookup layouts of the sweep."""
+    checks they agree with one big batch.  Both node-lookup layouts of the level-loop sweep and the scan
+    formulation (per-leaf state beyond a team's LDS share)."""
     d, nodes = c2
+    if layout == 'scan':
+        monkeypatch.setenv('APPLES_SWEEP_SCAN', '1')
     if layout == 'map':
         monkeypatch.setenv('APPLES_NODE_MAP', '1')
     nthreads = len(os.sched_getaffinity(0))
@@ -72,7 +75,7 @@ def test_all_observed_stress_and_batching(c2, layout, monkeypatch):
     want = co.place_sequences(d.query_seqs[:96])
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS', threshold=1e9, max_batch=32)
     got = eng.place_sequences(d.query_seqs[:96])
-    assert eng.describe()['batch'] == 32
+    assert eng.describe()['batch'] == 32 and eng.describe()['sweep'] == ('scan' if layout == 'scan' else 'levels')
     _compare(got, want, co, d, nodes, 'all observed')
     assert (got['n_valid'] >= 2 * 10000 - 3).all()
     eng.close()
@@ -152,12 +155,13 @@ def test_fused_and_full_row_selection_paths_agree(c2):
             "sys.stdout.buffer.write(b''.join(out))\n" % ROOT)
     outs = []
     for env in ({}, {'APPLES_NO_FUSE': '1'}, {'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_TEAM': '256'},
-                {'APPLES_TOPUP_MIN_ROWS': '0'}, {'APPLES_NO_DIST_MFMA': '1'}):
+                {'APPLES_TOPUP_MIN_ROWS': '0'}, {'APPLES_NO_DIST_MFMA': '1'}, {'APPLES_SWEEP_SCAN': '1'},
+                {'APPLES_SWEEP_SCAN': '1', 'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_SCAN': '1', 'APPLES_SWEEP_TEAM': '256'}):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(r.stdout)
     assert len(outs[0]) == 4 * 512 * 40
-    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4] == outs[5]
+    assert all(o == outs[0] for o in outs)
 
 
 def test_device_resident_results_visible_to_torch_zero_copy():

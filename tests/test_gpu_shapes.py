@@ -174,3 +174,48 @@ def test_exotic_symbols_in_a_later_chunk_of_a_streamed_block():
     co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', lut=jc69_lut(200, 0.001), threads=NTHREADS)
     want = co.place_sequences(q)
     assert got.tobytes() == want.tobytes()
+
+
+def test_scan_sweep_at_c3_shape_and_on_a_deep_tree(monkeypatch):
+    """The scan formulation of the sweep (APPLES_SWEEP_SCAN=1: id-sorted leaves, Euler-tour lowest common
+    ancestors, prefix counts instead of a node map) returns the level loop's bytes at the 200 000-leaf
+    shape; a tree deeper than its 254-level tables (a caterpillar) quietly keeps the level loop."""
+    from apples_amd.tree import parse_newick
+    d = synth.make_dataset(200000, 1000, 3000)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    assert eng.describe()['sweep'] == 'levels'
+    want = eng.place_sequences(d.query_seqs)
+    eng.close()
+    monkeypatch.setenv('APPLES_SWEEP_SCAN', '1')
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    assert eng.describe()['sweep'] == 'scan'
+    got = eng.place_sequences(d.query_seqs)
+    eng.close()
+    assert got.tobytes() == want.tobytes()
+    n = 400
+    rng = np.random.default_rng(9)
+    s = 't0:0.01'
+    for i in range(1, n):
+        s = '(%s,t%d:%.4f):%.4f' % (s, i, rng.uniform(0.005, 0.02), rng.uniform(0.001, 0.01))
+    tree = parse_newick(s[:s.rindex(':')] + ';')
+    assert int(np.max(tree.level)) > 254
+    base = rng.integers(0, 4, size=300)
+    alpha = np.frombuffer(b'ACGT', np.uint8)
+    names = ['t%d' % i for i in range(n)]
+    seqs = np.empty((n, 300), np.uint8)
+    for i in range(n):
+        row = base.copy()
+        hit = rng.random(300) < 0.06
+        row[hit] = rng.integers(0, 4, size=int(hit.sum()))
+        seqs[i] = alpha[row]
+    qry = seqs[rng.integers(0, n, size=40)].copy()
+    qry[rng.random(qry.shape) < 0.03] = ord('G')
+    nodes = np.array([tree.name_to_node[x] for x in names], np.int32)
+    eng = Engine(tree, seqs, nodes, method='FM', threshold=0.08, baseobs=10)
+    assert eng.describe()['sweep'] == 'levels'
+    got = eng.place_sequences(qry)
+    eng.close()
+    want = COracle(tree, seqs, nodes, method='FM', threshold=0.08, baseobs=10, lut=jc69_lut(300, 0.001),
+                   threads=NTHREADS).place_sequences(qry)
+    assert got.tobytes() == want.tobytes()
