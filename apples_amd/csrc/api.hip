@@ -326,12 +326,11 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
     if (dev_upload(ctx, &a.rep_moff, rep_moff.data(), a.n_reps + 1)) return 1;
     if (dev_upload(ctx, &a.mem_slot, mem_slot.data(), (int64_t)mem_slot.size())) return 1;
 
-    // rows in slot order -> device, then pack on the device
-    std::vector<uint8_t> stage((size_t)a.n_rows * a.L);
-    for (int64_t s = 0; s < a.n_rows; ++s)
-        memcpy(stage.data() + (size_t)s * a.L, al->rows + (size_t)a.slot_row[s] * a.L, a.L);
-    if (dev_upload(ctx, &a.raw, stage.data(), (int64_t)stage.size())) return 1;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // stage goes out of scope
+    // the rows go to the device as the caller holds them (one copy, no re-ordered staging buffer on the
+    // host); the packing kernels gather them into slot order through d_slot_row
+    if (dev_upload(ctx, &a.raw, al->rows, a.n_rows * (int64_t)a.L)) return 1;
+    if (dev_upload(ctx, &a.d_slot_row, a.slot_row.data(), a.n_rows)) return 1;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
     if (ctx->params.model == APPLES_SCOREDIST) {
         int Lpad = (a.L + 15) / 16 * 16;
@@ -339,7 +338,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         HIP_TRY(ctx, hipMemsetAsync(a.aa_idx, 160, (size_t)(Lpad / 16) * a.slots_pad * 16, ctx->stream));
         if (dev_alloc(ctx, &a.aa_mask, (int64_t)(Lpad / 16) * a.slots_pad)) return 1;
         HIP_TRY(ctx, hipMemsetAsync(a.aa_mask, 0, (size_t)(Lpad / 16) * a.slots_pad * 2, ctx->stream));
-        if (launch_pack_aa(ctx, a.raw, a.n_rows, a.L, a.aa_idx, a.aa_mask, a.slots_pad, false)) return 1;
+        if (launch_pack_aa(ctx, a.raw, a.n_rows, a.L, a.aa_idx, a.aa_mask, a.slots_pad, false, nullptr, a.d_slot_row)) return 1;
         a.planes = 0;
         double tab[21 * 21];
         for (int i = 0; i < 21; ++i)
@@ -354,7 +353,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         int64_t words = (int64_t)a.G * 3 * a.slots_pad;
         if (dev_alloc(ctx, &a.packed, words)) return 1;
         HIP_TRY(ctx, hipMemsetAsync(a.packed, 0, (size_t)words * sizeof(uint4), ctx->stream));
-        if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 2, a.packed, a.slots_pad, false, d_exotic)) return 1;
+        if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 2, a.packed, a.slots_pad, false, d_exotic, nullptr, a.d_slot_row)) return 1;
         int exotic = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&exotic, d_exotic, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -364,7 +363,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
             words = (int64_t)a.G * 9 * a.slots_pad;
             if (dev_alloc(ctx, &a.packed, words)) return 1;
             HIP_TRY(ctx, hipMemsetAsync(a.packed, 0, (size_t)words * sizeof(uint4), ctx->stream));
-            if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 8, a.packed, a.slots_pad, false, d_exotic)) return 1;
+            if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 8, a.packed, a.slots_pad, false, d_exotic, nullptr, a.d_slot_row)) return 1;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
         dev_free(d_exotic);
@@ -382,7 +381,7 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
     int64_t words = (int64_t)a.G * 9 * a.slots_pad;
     if (dev_alloc(ctx, &a.packed, words)) return 1;
     HIP_TRY(ctx, hipMemsetAsync(a.packed, 0, (size_t)words * sizeof(uint4), ctx->stream));
-    if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 8, a.packed, a.slots_pad, false, d_exotic)) return 1;
+    if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 8, a.packed, a.slots_pad, false, d_exotic, nullptr, a.d_slot_row)) return 1;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     dev_free(d_exotic);
     // existing query blocks were packed with 2 planes: repack them
@@ -1060,7 +1059,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

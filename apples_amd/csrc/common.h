@@ -76,7 +76,8 @@ struct DevAlign {
     int32_t L = 0, W = 0, G = 0;  // sites, 32-site words, groups of 4 words
     int32_t planes = 0;           // code planes in the packed layout: 2 (ACGT fast path) or 8 (raw byte)
     bool all_singleton = true;
-    uint8_t *raw = nullptr;       // [n_rows*L] bytes in slot order (kept for lazy repacking / scoredist)
+    uint8_t *raw = nullptr;       // [n_rows*L] bytes in the caller's row order (kept for lazy repacking)
+    int32_t *d_slot_row = nullptr;// [n_rows] slot -> caller's row (the packing kernels gather through it)
     uint4 *packed = nullptr;      // [G][planes+1][slots_pad] uint4 = 4 consecutive 32-site words
     uint8_t *aa_idx = nullptr;    // scoredist: [Lpad16/16][slots_pad][16] residue index * 8 (0..152, 160 = gap)
     uint16_t *aa_mask = nullptr;  // scoredist: [Lpad16/16][slots_pad] bit k = site 16*s16+k is not a gap
@@ -215,9 +216,10 @@ extern thread_local std::string g_create_error;
 // ---- kernels' host launchers (defined in the .hip files) -----------------------------------------
 // pack.hip
 int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, int planes, uint4 *d_out,
-                     int64_t slots_pad, bool query_layout, int *d_exotic, hipStream_t st = nullptr);
+                     int64_t slots_pad, bool query_layout, int *d_exotic, hipStream_t st = nullptr,
+                     const int32_t *d_src_row = nullptr);
 int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, uint16_t *d_mask,
-                   int64_t slots_pad, bool query_layout, hipStream_t st = nullptr);
+                   int64_t slots_pad, bool query_layout, hipStream_t st = nullptr, const int32_t *d_src_row = nullptr);
 // dist.hip
 int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
                   uint32_t *d_counts);

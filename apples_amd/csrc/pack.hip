@@ -13,11 +13,13 @@
 template <int P>
 __global__ __launch_bounds__(APPLES_TPB) void k_pack_rows(const uint8_t *__restrict__ raw, int64_t n_rows, int L, int G,
                                                           uint4 *__restrict__ out, int64_t slots_pad, int query_layout,
-                                                          int *__restrict__ exotic) {
+                                                          int *__restrict__ exotic, const int32_t *__restrict__ src_row) {
     int64_t row = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
     int g = blockIdx.y;
     if (row >= n_rows) return;
-    const uint8_t *src = raw + row * (int64_t)L;
+    // reference layout: slot `row` holds the caller's row src_row[row] (the alignment stays in the caller's
+    // order on the device; no re-ordered copy is made on the host)
+    const uint8_t *src = raw + (src_row ? (int64_t)src_row[row] : row) * (int64_t)L;
     uint32_t m[4] = {0, 0, 0, 0};
     uint32_t c[P][4];
 #pragma unroll
@@ -60,17 +62,17 @@ __global__ __launch_bounds__(APPLES_TPB) void k_pack_rows(const uint8_t *__restr
 }
 
 int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, int planes, uint4 *d_out,
-                     int64_t slots_pad, bool query_layout, int *d_exotic, hipStream_t st) {
+                     int64_t slots_pad, bool query_layout, int *d_exotic, hipStream_t st, const int32_t *d_src_row) {
     if (n_rows == 0) return 0;
     if (!st) st = ctx->stream;
     int G = ctx->aln.G;
     dim3 grid((unsigned)((n_rows + APPLES_TPB - 1) / APPLES_TPB), (unsigned)G);
     if (planes == 2)
         hipLaunchKernelGGL(k_pack_rows<2>, grid, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, G, d_out, slots_pad,
-                           query_layout ? 1 : 0, d_exotic);
+                           query_layout ? 1 : 0, d_exotic, d_src_row);
     else
         hipLaunchKernelGGL(k_pack_rows<8>, grid, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, G, d_out, slots_pad,
-                           query_layout ? 1 : 0, d_exotic);
+                           query_layout ? 1 : 0, d_exotic, d_src_row);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -111,11 +113,11 @@ __device__ __forceinline__ uint8_t aa_index(uint8_t b) {
 
 __global__ __launch_bounds__(APPLES_TPB) void k_pack_aa(const uint8_t *__restrict__ raw, int64_t n_rows, int L, int Lpad,
                                                         uint8_t *__restrict__ out, uint16_t *__restrict__ mask,
-                                                        int64_t slots_pad, int query_layout) {
+                                                        int64_t slots_pad, int query_layout, const int32_t *__restrict__ src_row) {
     int64_t row = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
     int s16 = blockIdx.y;
     if (row >= n_rows) return;
-    const uint8_t *src = raw + row * (int64_t)L;
+    const uint8_t *src = raw + (src_row ? (int64_t)src_row[row] : row) * (int64_t)L;
     uint32_t w[4] = {0, 0, 0, 0};
     uint32_t m = 0;
     const uint32_t scale = query_layout ? 1u : 8u;
@@ -137,13 +139,13 @@ __global__ __launch_bounds__(APPLES_TPB) void k_pack_aa(const uint8_t *__restric
 }
 
 int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, uint16_t *d_mask,
-                   int64_t slots_pad, bool query_layout, hipStream_t st) {
+                   int64_t slots_pad, bool query_layout, hipStream_t st, const int32_t *d_src_row) {
     if (n_rows == 0) return 0;
     if (!st) st = ctx->stream;
     int Lpad = (L + 15) / 16 * 16;
     dim3 grid((unsigned)((n_rows + APPLES_TPB - 1) / APPLES_TPB), (unsigned)(Lpad / 16));
     hipLaunchKernelGGL(k_pack_aa, grid, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, Lpad, d_out, d_mask,
-                       slots_pad, query_layout ? 1 : 0);
+                       slots_pad, query_layout ? 1 : 0, d_src_row);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

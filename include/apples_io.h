@@ -55,6 +55,20 @@ int apples_max_clusters(int32_t n_nodes, const int32_t *child_off, const int32_t
                         const double *edge_len, int32_t root, double threshold, int32_t *leaf_order,
                         int32_t *cluster_end, int32_t *n_clusters);
 
+/* apples_dismat_scan replaces the per-value Python of the reference's distance-table reader
+ * (run_apples.py:43-54 read_dismat) for tables of 10^8 and more values.  `data` is the file image.
+ * Reader semantics kept: universal newlines; the header line is right-stripped and split on white
+ * space and its first field dropped; every other line is stripped and split: first field the query
+ * name, then one value per tag, surplus values ignored, a tag without a value stays -1 (absent from
+ * the reference's dict, and negatives are dropped at apples/PoolQueryWorker.py:52 anyway).
+ * Pass 1 (out == NULL): counts tags and rows.  Pass 2: fills out[n_rows][n_tags] and the byte ranges
+ * of tags and names inside `data`.  Returns 0; 1 when some value is not a plain decimal spelling
+ * (on which strtod and Python's float() agree: the caller then uses its own reader); 2 when a
+ * capacity is too small.  Duplicate tag names are the caller's business (dict(zip(...)) semantics). */
+int apples_dismat_scan(const uint8_t *data, int64_t n_bytes, double *out, int64_t n_tags_cap, int64_t n_rows_cap,
+                       int64_t *n_tags, int64_t *n_rows, int64_t *tag_off, int32_t *tag_len, int64_t *name_off,
+                       int32_t *name_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,12 +3,12 @@
 placements computed on MI355X.  -a reads this build's own database cache
 (build_applesdtb.py; the reference's pickles of third-party classes cannot be read)."""
 import logging
-import re
 import sys
 import time
 
 import numpy as np
 
+from apples_amd.dismat import read_dismat as read_distance_table, read_dismat_binary, read_dismat_py  # noqa: F401
 from apples_amd.fasta import read_alignment
 from apples_amd.jplace import iter_text, keep_mask
 from apples_amd.options import options_config
@@ -18,48 +18,8 @@ from apples_amd.worker import QueryWorker
 
 
 def read_dismat(f):
-    """Header: whitespace-split names after the first field; rows: name then floats
-    (run_apples.py:43-54).  Returns (query names, column names, float64 matrix)."""
-    tags = re.split(r'\s+', f.readline().rstrip())[1:]
-    cols, seen = [], {}
-    for t in tags:  # dict(zip(tags, ...)): a repeated name keeps its first position, last value
-        if t not in seen:
-            seen[t] = len(cols)
-            cols.append(t)
-    names, rows = [], []
-    for line in f.readlines():
-        d = re.split(r'\s+', line.strip())
-        names.append(d[0])
-        row = np.full(len(cols), -1.0)
-        for t, v in zip(tags, d[1:]):
-            row[seen[t]] = float(v)
-        rows.append(row)
-    return names, cols, (np.vstack(rows) if rows else np.zeros((0, len(cols))))
-
-
-def read_dismat_binary(path):
-    """Binary form of the same table (a 200 k-column table is 20 GB of text): a numpy
-    ``.npz`` with ``queries`` and ``columns`` (string arrays) and ``D`` (float64 [queries, columns],
-    negative = missing).  Written by ``numpy.savez(path, queries=..., columns=..., D=...)``."""
-    z = np.load(path, allow_pickle=False)
-    names = [str(x) for x in z['queries']]
-    cols = [str(x) for x in z['columns']]
-    D = np.ascontiguousarray(z['D'], dtype=np.float64)
-    if D.shape != (len(names), len(cols)):
-        raise ValueError('distance table shape %s does not match %d queries x %d columns' % (D.shape, len(names), len(cols)))
-    if len(set(cols)) != len(cols):  # the text reader's dict semantics: first position, last value
-        keep, seen = [], {}
-        for i, c in enumerate(cols):
-            if c in seen:
-                D[:, seen[c]] = D[:, i]
-            else:
-                seen[c] = len(keep)
-                keep.append(i)
-                if len(keep) - 1 != i:
-                    D[:, len(keep) - 1] = D[:, i]
-        cols = [cols[i] for i in keep]
-        D = np.ascontiguousarray(D[:, :len(cols)])
-    return names, cols, D
+    """(kept under the reference's name) text table from an open file: apples_amd.dismat.read_dismat_py"""
+    return read_dismat_py(f)
 
 
 def main(argv=None):
@@ -104,13 +64,7 @@ def main(argv=None):
     devices = list(range(ngpu))
 
     if options.dist_fp:
-        with open(options.dist_fp, 'rb') as f:
-            magic = f.read(2)
-        if magic == b'PK':  # a numpy .npz archive
-            names, cols, D = read_dismat_binary(options.dist_fp)
-        else:
-            with open(options.dist_fp) as f:
-                names, cols, D = read_dismat(f)
+        names, cols, D = read_distance_table(options.dist_fp)  # text (native scanner) or .npz
         worker = QueryWorker(tree, options, None, devices)
         startq = time.time()
         out_names, rows = worker.run_distances(names, cols, D, rows=True)

@@ -502,3 +502,78 @@ def test_reference_alignment_may_hold_rows_beyond_the_clusters(tmp_path):
         ReducedReference(a0, False, [('-1', [a0.names[0], a0.names[0]])])
     with pytest.raises(KeyError):
         ReducedReference(a0, False, [('-1', ['no_such_sequence'])])
+
+
+@pytest.mark.parametrize('text', [
+    '\tA B C\nq1 0.1 0.2 0.3\nq2 1e-3 -1 2.5E+1\n',
+    'x A B A\r\nq 1 2 3\r\n  r\t4\t5\t6  \r\n',                 # first header field dropped, duplicate tag, CRLF, padding
+    ' A B C D\nq 1 2\n\nlast 7 8 9 10 11 12',                   # short row, empty line, surplus values, no final newline
+    '\tA B\nq nan 1\n',                                          # not a plain decimal: the Python reader decides
+    '\tA B\nq 1_0 2\n',
+    '\tA\n',
+    '',
+])
+def test_native_distance_table_scanner_equals_the_python_reader(text, tmp_path):
+    from apples_amd import dismat
+    p = tmp_path / 't.mat'
+    with open(p, 'w', newline='') as f:
+        f.write(text)
+    with open(p) as f:
+        try:
+            want = dismat.read_dismat_py(f)
+        except Exception as e:  # whatever the reference's reader raises, the front end raises too
+            with pytest.raises(type(e)):
+                dismat.read_dismat_text(str(p))
+            return
+    got = dismat.read_dismat_text(str(p))
+    assert got[0] == want[0] and got[1] == want[1]
+    assert got[2].shape == want[2].shape and np.array_equal(got[2], want[2], equal_nan=True)
+
+
+def test_native_distance_table_scanner_on_the_reference_tables_and_at_size(tmp_path):
+    from apples_amd import dismat
+    from apples_amd.fasta import _load_io
+    assert hasattr(_load_io(), 'apples_dismat_scan')
+    for name in ('dist.mat', 'small_dist.mat'):
+        with open(os.path.join(DATA, name)) as f:
+            want = dismat.read_dismat_py(f)
+        got = dismat.read_dismat(os.path.join(DATA, name))
+        assert got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2])
+    rng = np.random.default_rng(3)
+    D = np.round(rng.uniform(0, 2, size=(40, 3000)), 8)
+    D[3, ::7] = -1.0
+    p = tmp_path / 'big.mat'
+    with open(p, 'w') as f:
+        f.write('\t' + ' '.join('c%d' % i for i in range(3000)) + '\n')
+        for i in range(40):
+            f.write('q%d ' % i + ' '.join(repr(float(v)) for v in D[i]) + '\n')
+    names, cols, got = dismat.read_dismat(str(p))
+    assert names == ['q%d' % i for i in range(40)] and cols == ['c%d' % i for i in range(3000)]
+    assert np.array_equal(got, D)
+
+
+def test_native_distance_table_values_equal_python_float_on_random_spellings(tmp_path):
+    """The scanner's exact fast path (at most 15 significant digits, power of ten within 10^22) and its
+    strtod path against Python's float() on 30 000 random decimal spellings."""
+    import random
+    from apples_amd import dismat
+    random.seed(7)
+    vals = []
+    for _ in range(30000):
+        k = random.randint(1, 18)
+        digs = ''.join(random.choice('0123456789') for _ in range(k))
+        pos = random.randint(0, k)
+        s = digs[:pos] + '.' + digs[pos:] if random.random() < 0.8 else digs
+        if s == '.':
+            s = '0.'
+        if random.random() < 0.3:
+            s += 'e%+d' % random.randint(-30, 30)
+        if random.random() < 0.2:
+            s = '-' + s
+        vals.append(s)
+    p = tmp_path / 's.mat'
+    with open(p, 'w') as f:
+        f.write('\t' + ' '.join('c%d' % i for i in range(len(vals))) + '\n')
+        f.write('q ' + ' '.join(vals) + '\n')
+    _, _, G = dismat.read_dismat(str(p))
+    assert np.array_equal(G[0], np.array([float(v) for v in vals]))
