@@ -2,7 +2,7 @@
 """Builds the APPLES database cache that ``run_apples.py -a`` reads (the reference's
 build_applesdtb.py, flags of apples/OptionsBasic.py:15-70): backbone tree + reference alignment ->
 indexed tree, extended Newick, reduced reference (clusters at 1.2 x -f, consensus representatives).
-The tree is taken as given (no FastTree re-estimation in this build)."""
+Branch lengths are re-estimated first when a FastTree executable is available (apples_amd/reestimate.py)."""
 import logging
 import sys
 import time
@@ -26,7 +26,8 @@ def main(argv=None):
     p.add_option('-f', '--filter', dest='filt_threshold', type=float, default=0.2, metavar='NUMBER',
                  help='ignores distances higher than the given threshold (clusters are cut at 1.2 x this)')
     p.add_option('-D', '--disable-reestimation', dest='disable_reestimation', action='store_true', default=False,
-                 help='accepted for compatibility: the tree is always used as given')
+                 help='disables branch length reestimation of the backbone tree')
+    p.add_option('--fasttree', dest='fasttree_fp', metavar='FILE', help='FastTree executable for the reestimation')
     p.add_option('--clusters', dest='clusters_fp', metavar='FILE', help='TreeCluster output to use instead of the built-in clustering')
     p.add_option('--no-clusters', dest='no_clusters', action='store_true', default=False,
                  help='every reference sequence is its own cluster')
@@ -37,6 +38,9 @@ def main(argv=None):
         raise ValueError('No reference alignment provided by user.')
     if not options.output_fp:
         raise ValueError('No output path provided by user.')
+    if not options.disable_reestimation:  # build_applesdtb.py -> prepareTree (apples/prepareTree.py:20-21)
+        from apples_amd.reestimate import reestimate_backbone
+        reestimate_backbone(options)
     tree = read_tree(options.tree_fp)
     newick = extended_newick(tree)
     ref = read_alignment(options.ref_fp, options.protein_seqs, False)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Drop-in for the reference's run_apples.py on its per-query hot path: same flags, same jplace,
 placements computed on MI355X.  -a reads this build's own database cache
-(build_applesdtb.py; the reference's pickles of third-party classes cannot be read)."""
+(build_applesdtb.py; the reference's pickles of third-party classes cannot be read).  Backbone branch
+re-estimation runs an external FastTree when one is found (apples_amd/reestimate.py), else the tree is
+taken as given (-D)."""
 import logging
 import sys
 import time
@@ -25,9 +27,6 @@ def read_dismat(f):
 def main(argv=None):
     startb = time.time()
     options, _ = options_config(argv)
-    if options.reestimate_backbone and not options.dist_fp:
-        logging.warning('Backbone branch lengths are used as given: FastTree re-estimation is not part of this '
-                        'build (equivalent to -D).')
     start = time.time()
     reference = None
     if options.database_fp:  # run_apples.py:25-35,69-75: tree, extended Newick and reduced reference from the cache
@@ -48,6 +47,12 @@ def main(argv=None):
         logging.info('[%s] Tree and reduced reference are loaded from the APPLES database in %.3f seconds.'
                      % (time.strftime('%H:%M:%S'), time.time() - start))
     if options.tree_fp:  # the user's tree wins over the database's (run_apples.py:37-38)
+        if options.reestimate_backbone:  # apples/prepareTree.py:20-21 (off with -D and with -d)
+            if options.ref_fp:
+                from apples_amd.reestimate import reestimate_backbone
+                reestimate_backbone(options)  # rewrites options.tree_fp when a FastTree executable exists
+            else:
+                logging.warning('Backbone branch lengths are used as given: reestimation needs the reference alignment (-s).')
         tree = read_tree(options.tree_fp)
         newick = extended_newick(tree)
         logging.info('[%s] Tree is parsed and preprocessed in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))

@@ -163,3 +163,33 @@ def test_worker_with_two_device_entries_matches_one(tmp_path):
     n4, r4 = fm.run_sequences(d.query_names, d.query_seqs, rows=True)
     fm.close()
     assert r3 == r4 and r3 != r1
+
+
+def test_cli_reestimates_the_backbone_through_an_external_fasttree(tmp_path):
+    """Without -D the reference re-estimates the backbone's branch lengths with FastTree before placing
+    (apples/prepareTree.py:20-21).  Here: a stand-in executable that doubles every length; the placements
+    must be made on the tree it returns, and with no executable at all the run equals -D."""
+    import stat
+    stub = tmp_path / 'FastTree'
+    with open(stub, 'w') as f:
+        f.write('#!%s\nimport sys\nsys.path.insert(0, %r)\nfrom apples_amd import reestimate as R\n'
+                'a = sys.argv\nt = R.from_newick(open(a[a.index("-intree") + 1]).read())\nstack = [t]\n'
+                'while stack:\n    v = stack.pop(); stack.extend(v.children)\n    v.length = None if v.length is None else 2 * v.length\n'
+                'print(R.to_newick(t))\n' % (sys.executable, ROOT))
+    os.chmod(stub, os.stat(stub).st_mode | stat.S_IEXEC)
+    base = [sys.executable, os.path.join(ROOT, 'run_apples.py'), '-s', os.path.join(DATA, 'ref.fa'), '-q',
+            os.path.join(DATA, 'query.fa'), '-t', os.path.join(DATA, 'backbone.nwk'), '-m', 'OLS', '--no-clusters']
+    env = dict(os.environ, PATH=os.path.dirname(sys.executable) + ':/usr/bin:/bin')
+    env.pop('APPLES_FASTTREE', None)
+    outs = {}
+    for label, extra, e in (('D', ['-D'], env), ('none', [], env), ('stub', ['--fasttree', str(stub)], env)):
+        out = tmp_path / (label + '.jplace')
+        r = subprocess.run(base + extra + ['-o', str(out)], capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stderr
+        outs[label] = (json.load(open(out)), r.stderr)
+    assert outs['none'][0]['tree'] == outs['D'][0]['tree'] and 'no FastTree executable found' in outs['none'][1]
+    assert outs['none'][0]['placements'] == outs['D'][0]['placements']
+    assert outs['stub'][0]['tree'] != outs['D'][0]['tree'] and len(outs['stub'][0]['placements']) == 10
+    # every branch twice as long and the observed distances unchanged: other optima, same format
+    for p in outs['stub'][0]['placements']:
+        assert len(p['p'][0]) == 5 and p['p'][0][0] >= 0

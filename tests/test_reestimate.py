@@ -1,0 +1,175 @@
+"""Backbone branch re-estimation wrapper (apples_amd/reestimate.py; apples/reestimateBackbone.py:22-118):
+polytomy resolution, Newick round trip, re-rooting FastTree's unrooted answer on the input's root edge.
+FastTree itself is external: a stand-in script here, the reference's bundled binary when this container
+has it."""
+import os
+import stat
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from helpers import DATA, ROOT
+
+sys.path.insert(0, ROOT)
+from apples_amd import reestimate as R  # noqa: E402
+from apples_amd import synth  # noqa: E402
+from apples_amd.tree import parse_newick  # noqa: E402
+
+
+def _splits(root):
+    """{frozenset(leaf labels below an edge): edge length} for every non-root node."""
+    out = {}
+
+    def walk(v):
+        if not v.children:
+            s = frozenset([v.label])
+        else:
+            s = frozenset().union(*[walk(c) for c in v.children])
+        if v.parent is not None:
+            out[s] = v.length
+        return s
+    sys.setrecursionlimit(100000)
+    walk(root)
+    return out
+
+
+def test_resolve_polytomies_and_unifurcations():
+    t = R.from_newick('((A:1,B:2,C:3,D:4):1,((E:1):2):3,F:1,G:1,H:1);')
+    t = R.suppress_unifurcations(t)
+    assert 'E' in [c.label for c in t.children] and [c.length for c in t.children if c.label == 'E'] == [6.0]
+    assert len(t.children) == 5
+    R.resolve_polytomies(t)
+    stack = [t]
+    while stack:
+        v = stack.pop()
+        assert len(v.children) in (0, 2)
+        stack.extend(v.children)
+    assert sorted(x.label for x in t.leaves()) == list('ABCDEFGH')
+    # new internal nodes sit on zero-length edges; original edges keep their lengths
+    s = _splits(t)
+    assert s[frozenset('ABCD')] == 1.0 and s[frozenset('A')] == 1.0 and s[frozenset('D')] == 4.0
+    assert parse_newick(R.to_newick(t)).n_leaves == 8
+
+
+def _unroot(root):
+    """What FastTree prints for a rooted binary tree: the root's first internal child is merged into it."""
+    a, b = root.children
+    keep, merge = (a, b) if b.children else (b, a)
+    root.children = [keep] + merge.children
+    for c in merge.children:
+        c.parent = root
+    keep.length = keep.length + merge.length
+    return root
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3, 4])
+def test_rerooting_restores_the_input_root(seed):
+    nw = synth.random_tree_newick(40, seed=seed)
+    orig = R.from_newick(nw)
+    want = _splits(orig)
+    left, right = orig.children
+    if left.children:
+        two, one, l2, l1 = [c.first_leaf().label for c in left.children], right.first_leaf().label, left.length, right.length
+    else:
+        two, one, l2, l1 = [c.first_leaf().label for c in right.children], left.first_leaf().label, right.length, left.length
+    ft = _unroot(R.from_newick(nw))
+    assert len(ft.children) == 3
+    by = {x.label: x for x in ft.leaves()}
+    ft = R.reroot(ft, by[one], None)
+    m = R.mrca(ft, [by[x] for x in two])
+    ml = m.length
+    ft = R.reroot(ft, m, ml / 2)
+    for i in range(2):
+        if ft.children[i] is m:
+            ft.children[i].length = ml * l2 / (l2 + l1)
+            ft.children[1 - i].length = ml * l1 / (l2 + l1)
+    got = _splits(ft)
+    assert set(got) == set(want) and len(ft.children) == 2
+    for k in want:
+        assert got[k] == pytest.approx(want[k], rel=1e-12, abs=1e-15)
+
+
+def _options(tree_fp, ref_fp, exe=None, protein=False):
+    return types.SimpleNamespace(tree_fp=tree_fp, ref_fp=ref_fp, protein_seqs=protein, fasttree_fp=exe)
+
+
+def test_wrapper_with_a_stand_in_fasttree(tmp_path, monkeypatch):
+    stub = tmp_path / 'FastTree'
+    with open(stub, 'w') as f:
+        f.write('#!%s\nimport sys\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n'
+                'from apples_amd import reestimate as R\nfrom test_reestimate import _unroot\n'
+                'a = sys.argv\nassert "-nosupport" in a and "-nome" in a and "-noml" in a and "-nt" in a\n'
+                'assert sys.stdin.read(1) == ">"\n'
+                't = R.from_newick(open(a[a.index("-intree") + 1]).read())\n'
+                'stack = [t]\n'
+                'while stack:\n    v = stack.pop(); stack.extend(v.children)\n    v.length = None if v.length is None else 2 * v.length\n'
+                'print(R.to_newick(_unroot(t)))\n' % (sys.executable, ROOT, os.path.join(ROOT, 'tests')))
+    os.chmod(stub, os.stat(stub).st_mode | stat.S_IEXEC)
+    nw = synth.random_tree_newick(30, seed=7)
+    tree_fp = tmp_path / 'bb.nwk'
+    open(tree_fp, 'w').write(nw + '\n')
+    ref_fp = tmp_path / 'ref.fa'
+    open(ref_fp, 'w').write('>t0\nACGT\n')
+    # none found: tree as given
+    monkeypatch.setenv('PATH', str(tmp_path / 'nowhere'))
+    monkeypatch.delenv('APPLES_FASTTREE', raising=False)
+    o = _options(str(tree_fp), str(ref_fp))
+    assert R.reestimate_backbone(o) is False and o.tree_fp == str(tree_fp)
+    with pytest.raises(ValueError):
+        R.find_fasttree(str(tmp_path / 'missing'))
+    # found through the environment
+    monkeypatch.setenv('APPLES_FASTTREE', str(stub))
+    assert R.reestimate_backbone(o) is True and o.tree_fp != str(tree_fp)
+    want = _splits(R.from_newick(nw))
+    got_root = R.from_newick(open(o.tree_fp).read())
+    got = _splits(got_root)
+    assert set(got) == set(want) and len(got_root.children) == 2
+    for k in want:
+        assert got[k] == pytest.approx(2 * want[k], rel=1e-12)
+
+
+BUNDLED = '/root/reference/apples/tools/FastTree-linux'
+
+
+@pytest.mark.skipif(not os.path.exists(BUNDLED), reason='the reference tree (with its bundled FastTree) is only in the build container')
+def test_wrapper_with_the_bundled_fasttree_on_the_example_data():
+    """End to end on data/backbone.nwk + data/ref.fa with the FastTree the reference ships: same leaf set,
+    same splits (the topology is fixed by -intree), same root edge, finite lengths, and the result is a
+    tree this build's reader and the placement path accept."""
+    o = _options(os.path.join(DATA, 'backbone.nwk'), os.path.join(DATA, 'ref.fa'), BUNDLED)
+    assert R.reestimate_backbone(o) is True
+    before = R.from_newick(open(os.path.join(DATA, 'backbone.nwk')).read())
+    after = R.from_newick(open(o.tree_fp).read())
+    assert sorted(x.label for x in before.leaves()) == sorted(x.label for x in after.leaves())
+    sb, sa = _splits(before), _splits(after)
+    # data/backbone.nwk has a trifurcating root (unrooted): FastTree's answer is used as it comes
+    assert len(before.children) == 3
+    allb = frozenset(x.label for x in before.leaves())
+    canon = lambda s: min(s, allb - s, key=lambda x: (len(x), sorted(x)))  # noqa: E731  (a split, whichever side is below)
+    assert {canon(s) for s in sb} == {canon(s) for s in sa}
+    assert all(v is not None and np.isfinite(v) for v in sa.values())
+    t = parse_newick(open(o.tree_fp).read())
+    assert t.n_leaves == 490
+
+
+@pytest.mark.skipif(not os.path.exists(BUNDLED), reason='the reference tree (with its bundled FastTree) is only in the build container')
+def test_bundled_fasttree_on_a_rooted_tree_keeps_the_root_edge(tmp_path):
+    d = synth.make_dataset(60, 400, 1)
+    tree_fp, ref_fp = tmp_path / 'bb.nwk', tmp_path / 'ref.fa'
+    open(tree_fp, 'w').write(d.newick + '\n')
+    with open(ref_fp, 'w') as f:
+        for n, s in zip(d.ref_names, d.ref_seqs):
+            f.write('>%s\n%s\n' % (n, s.tobytes().decode()))
+    o = _options(str(tree_fp), str(ref_fp), BUNDLED)
+    assert R.reestimate_backbone(o) is True
+    before, after = R.from_newick(d.newick), R.from_newick(open(o.tree_fp).read())
+    assert len(after.children) == 2
+    assert set(_splits(before)) == set(_splits(after))  # rooted splits: the root edge is where it was
+    lb = [c.length for c in before.children]
+    la = {frozenset(x.label for x in c.leaves()): c.length for c in after.children}
+    kb = {frozenset(x.label for x in c.leaves()): c.length for c in before.children}
+    tot_a, tot_b = sum(la.values()), sum(lb)
+    for k in kb:  # the new root-edge length is split in the input's proportion (reestimateBackbone.py:103-110)
+        assert la[k] / tot_a == pytest.approx(kb[k] / tot_b, rel=1e-9)
