@@ -367,6 +367,10 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
         dev_free(d_exotic);
+        // clustered reference on the ACGT- fast path: panels for the fused selection by representatives
+        if (!a.all_singleton && a.planes == 2 && a.n_refs <= SELECT_CLUSTERS_MAX_SLOTS && a.G <= 64 &&
+            !getenv("APPLES_NO_CLUSTER_FUSE") && dist_mfma_enabled())
+            if (launch_build_cluster_panels(ctx)) return 1;
     }
     return 0;
 }
@@ -376,6 +380,8 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
     if (a.planes == 8) return 0;
     int *d_exotic = nullptr;
     if (dev_alloc(ctx, &d_exotic, 1)) return 1;
+    dev_free(a.rep_packed); dev_free(a.packed_rm);  // the clustered fast path is for ACGT- contexts only
+    a.rep_packed = a.packed_rm = nullptr;
     dev_free(a.packed);
     a.planes = 8;
     int64_t words = (int64_t)a.G * 9 * a.slots_pad;
@@ -830,7 +836,12 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     // the top-up rule get full distance rows
     static const bool no_fuse = getenv("APPLES_NO_FUSE") != nullptr;  // tuning/diagnostic knobs
     static const int n_pipe = getenv("APPLES_PIPELINE") ? atoi(getenv("APPLES_PIPELINE")) : 1;  // >1: measured slower (sweep and distance kernels contend), kept as a knob
-    const bool fused = !no_fuse && a.all_singleton && ctx->params.model == APPLES_JC69;
+    // clustered references: the matrix-core pass runs over the representatives only, k_select_clusters expands
+    // the accepted clusters (needs the panels of setup_alignment, the tabulated distances and their integer
+    // threshold form)
+    const bool cfused = !no_fuse && !a.all_singleton && ctx->params.model == APPLES_JC69 && a.rep_packed && a.packed_rm &&
+                        fused_counts_format(ctx, qb);
+    const bool fused = !no_fuse && (a.all_singleton || cfused) && ctx->params.model == APPLES_JC69;
     const bool pipelined = n_pipe > 1 && qb.n >= 1024;
     int64_t want = qb.n;
     if (pipelined) want = round_up((qb.n + n_pipe - 1) / n_pipe, 32);
@@ -869,7 +880,26 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         hipEvent_t *e = &ev[(size_t)i * 6];
         if (feed) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[i], 0));  // chunk i is on the device
         HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 16 * sizeof(int32_t), front));  // every counter of the batch
-        if (fused) {
+        if (cfused) {
+            HIP_TRY(ctx, hipEventRecord(e[0], front));
+            HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (a.reps_pad / 64) * sizeof(int32_t), front));
+            if (launch_counts_reps(ctx, qb, q0, nq, w.seg_slot, w.seg_cnt)) return 1;
+            HIP_TRY(ctx, hipEventRecord(e[1], front));
+            ++launches;
+            SelectArgs sa = select_args_alignment(ctx, qb, q0);
+            sa.seg_lut = ctx->jc_lut;
+            sa.packed_rm = a.packed_rm; sa.qpacked = qb.packed + q0 * a.G * 3; sa.G = a.G; sa.L = a.L;
+            sa.overlap = ctx->params.overlap_frac; sa.rep_stride = a.reps_pad; sa.tmp_d = w.dist;
+            if (launch_select_clusters(ctx, sa, nq)) return 1;
+            // queries whose accepted clusters hold fewer than -b valid distances: full rows + general selection
+            sa.seg_lut = nullptr;
+            if (launch_counts_listed(ctx, qb, q0, nq, w.slow_list, w.slow_count, w.dist_slow, nullptr, nullptr)) return 1;
+            sa.dist = w.dist_slow;
+            sa.qlist = w.slow_list;
+            sa.qcount = w.slow_count;
+            if (launch_select(ctx, sa, nq)) return 1;
+            HIP_TRY(ctx, hipEventRecord(e[2], front));
+        } else if (fused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
             if (fused_counts_format(ctx, qb))  // the matrix-core kernel writes only the non-empty segments' counts
                 HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (w.stride / 64) * sizeof(int32_t), front));
@@ -1059,7 +1089,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

@@ -79,6 +79,10 @@ struct DevAlign {
     uint8_t *raw = nullptr;       // [n_rows*L] bytes in the caller's row order (kept for lazy repacking)
     int32_t *d_slot_row = nullptr;// [n_rows] slot -> caller's row (the packing kernels gather through it)
     uint4 *packed = nullptr;      // [G][planes+1][slots_pad] uint4 = 4 consecutive 32-site words
+    // clustered references (fused selection by representatives, select.hip k_select_clusters):
+    uint4 *packed_rm = nullptr;   // [slots_pad][G*3] the same words row-major: one member row = 3*G contiguous uint4
+    uint4 *rep_packed = nullptr;  // [G][3][reps_pad] the representatives' rows, in representative order
+    int64_t reps_pad = 0;
     uint8_t *aa_idx = nullptr;    // scoredist: [Lpad16/16][slots_pad][16] residue index * 8 (0..152, 160 = gap)
     uint16_t *aa_mask = nullptr;  // scoredist: [Lpad16/16][slots_pad] bit k = site 16*s16+k is not a gap
     int32_t *slot_node = nullptr; // [n_refs] tree node or -1
@@ -254,10 +258,18 @@ struct SelectArgs {
     const int32_t *qlist, *qcount;
     // top-up by segment minima (k_jc69 MODE 2 -> k_select_topup): [listed row][stride]
     const double *segmin_d; const int32_t *segmin_i;
+    // clustered fast path (k_select_clusters): survivors among the representatives come in seg_slot/seg_cnt with
+    // row stride rep_stride; member rows are read row-major, the query's words from its packed tile
+    const uint4 *packed_rm; const uint4 *qpacked; int G; int L; double overlap; int64_t rep_stride;
+    double *tmp_d;            // [nq][stride] member distances before the ordered emission
 };
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
-int launch_select_topup(apples_ctx *ctx, const SelectArgs &a, int64_t nq);  // listed queries, needs segmin_d/segmin_i; baseobs <= 256
+int launch_select_topup(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
+int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq);  // needs n_members <= SELECT_CLUSTERS_MAX_SLOTS
+#define SELECT_CLUSTERS_MAX_SLOTS 229376
+int launch_counts_reps(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);
+int launch_build_cluster_panels(apples_ctx *ctx);  // listed queries, needs segmin_d/segmin_i; baseobs <= 256
 int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const int32_t *perm, int64_t nq, int64_t n_cols);
 bool dist_mfma_enabled();
 bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb);

@@ -562,6 +562,56 @@ static int launch_mfma(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
     return 0;
 }
 
+// ---- clustered references: panels for the fused selection by representatives (select.hip k_select_clusters)
+__global__ __launch_bounds__(APPLES_TPB) void k_gather_reps(const uint4 *__restrict__ packed, int64_t slots_pad,
+                                                            const int32_t *__restrict__ rep_slot, int64_t n_reps,
+                                                            int64_t reps_pad, uint4 *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    const int64_t gp = blockIdx.y;  // (word group, plane)
+    if (j < n_reps) out[gp * reps_pad + j] = packed[gp * slots_pad + rep_slot[j]];
+}
+
+__global__ __launch_bounds__(APPLES_TPB) void k_rows_major(const uint4 *__restrict__ packed, int64_t slots_pad, int64_t n_slots,
+                                                           int GP, uint4 *__restrict__ out) {
+    const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    const int gp = blockIdx.y;
+    if (slot < n_slots) out[slot * GP + gp] = packed[(int64_t)gp * slots_pad + slot];
+}
+
+// representative rows in representative order (the matrix-core pass runs on them alone) and every row
+// once more row-major (a member row = 3 G contiguous uint4); ACGT- contexts (2 code planes) only
+int launch_build_cluster_panels(apples_ctx *ctx) {
+    DevAlign &a = ctx->aln;
+    const int GP = a.G * 3;
+    a.reps_pad = (a.n_reps + 255) / 256 * 256;
+    if (a.rep_packed) (void)hipFree(a.rep_packed);
+    if (a.packed_rm) (void)hipFree(a.packed_rm);
+    a.rep_packed = a.packed_rm = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&a.rep_packed, (size_t)GP * a.reps_pad * sizeof(uint4)));
+    HIP_TRY(ctx, hipMemsetAsync(a.rep_packed, 0, (size_t)GP * a.reps_pad * sizeof(uint4), ctx->stream));
+    HIP_TRY(ctx, hipMalloc((void **)&a.packed_rm, (size_t)GP * a.slots_pad * sizeof(uint4)));
+    hipLaunchKernelGGL(k_gather_reps, dim3((unsigned)((a.n_reps + APPLES_TPB - 1) / APPLES_TPB), (unsigned)GP), dim3(APPLES_TPB), 0,
+                       ctx->stream, a.packed, a.slots_pad, a.rep_slot, a.n_reps, a.reps_pad, a.rep_packed);
+    hipLaunchKernelGGL(k_rows_major, dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)GP), dim3(APPLES_TPB), 0, ctx->stream,
+                       a.packed, a.slots_pad, a.slots_pad, GP, a.packed_rm);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// the fused matrix-core pass over the representatives alone: survivors (0 <= d <= threshold) per 64-representative
+// segment, in the packed (position, valid, mism) format, rows of reps_pad entries
+int launch_counts_reps(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt) {
+    if (nq == 0) return 0;
+    const DevAlign &a = ctx->aln;
+    dim3 grid((unsigned)(a.reps_pad / 128), (unsigned)((nq + MF_QT - 1) / MF_QT));
+    hipLaunchKernelGGL((k_jc69_mfma<1>), grid, dim3(MF_TPB), 0, ctx->stream, a.rep_packed,
+                       qb.qf4 + q0 * (int64_t)a.G * 256, (double *)nullptr, (uint32_t *)nullptr, a.n_reps, a.reps_pad, a.G, nq,
+                       a.L, ctx->params.overlap_frac, ctx->jc_lut, ctx->params.filt_threshold, seg_slot, seg_cnt, ctx->jc_mmax);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *d_dist,
                   uint32_t *d_counts) {
     if (nq == 0) return 0;

@@ -431,6 +431,212 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     }
 }
 
+// Fused selection for clustered references (the command line's default route, apples/Reference.py:117-157):
+// the matrix-core distance pass ran over the REPRESENTATIVES only and left, per query, the ones with
+// 0 <= d <= threshold (k_jc69_mfma<1> on the representative panel).  Those clusters are the accepted ones
+// unless they hold fewer than `baseobs` valid member distances -- then the reference keeps walking its
+// heap, and the query goes to the slow list (full rows + k_select), as in k_select_fast.  One workgroup
+// per query: the accepted clusters' members are expanded to a flat list, a thread computes one
+// (query, member) distance from the member's row-major packed row (the pair counts of k_jc69, same
+// table lookup), marks the member's slot in an LDS bitmap; ranks of the bitmap give the slot-ordered
+// (= level-ordered) observation list the sweep wants.
+#define ACC_CAP 512
+__global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
+    extern __shared__ unsigned long long dyn_bits[];  // [n_words] member bits in slot order, then uint32 [n_words] prefix
+    __shared__ int sh_i[8];
+    __shared__ int sh_j[8];
+    __shared__ double sh_d[8];
+    __shared__ uint4 sh_q[64 * 3];
+    __shared__ int sh_rep[ACC_CAP];
+    __shared__ double sh_drep[ACC_CAP];
+    __shared__ int sh_off[ACC_CAP + 1];
+    __shared__ int sh_znode, sh_nacc;
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int G = a.G;
+    const int64_t nm = a.n_members;
+    const int n_words = (int)((nm + 63) >> 6);
+    uint32_t *pre = reinterpret_cast<uint32_t *>(dyn_bits + n_words);
+    const int self = a.self_slot ? a.self_slot[q] : -1;
+    int32_t *o_node = a.obs_node + q * a.obs_cap;
+    double *o_dist = a.obs_dist + q * a.obs_cap;
+    double *tmp = a.tmp_d + q * a.stride;
+    auto to_slow = [&]() {
+        if (tid == 0) {
+            a.slow_list[atomicAdd(a.slow_count, 1)] = (int32_t)q;
+            a.n_obs[q] = 0;
+        }
+    };
+    // the query's packed words (tile layout of pack.hip: [(q/16)*G + g][q%16][plane])
+    for (int i = tid; i < G * 3; i += APPLES_TPB) {
+        const int g = i / 3, pl = i % 3;
+        sh_q[i] = a.qpacked[(((q >> 4) * G + g) * 16 + (q & 15)) * 3 + pl];
+    }
+    for (int i = tid; i < n_words; i += APPLES_TPB) dyn_bits[i] = 0;
+    // ---- accepted representatives: the survivors of the representative pass, in representative order
+    const int64_t n_seg = a.rep_stride >> 6;
+    const int32_t *cnt = a.seg_cnt + q * n_seg;
+    const int32_t *sslot = a.seg_slot + q * a.rep_stride;
+    int base = 0;
+    bool overflow = false;
+    for (int64_t s0 = 0; s0 < n_seg; s0 += APPLES_TPB) {
+        const int64_t s = s0 + tid;
+        const int my = s < n_seg ? cnt[s] : 0;
+        int chunk_total;
+        const int at = base + block_excl_scan_int(my, sh_i, &chunk_total);
+        if (at + my <= ACC_CAP) {
+            for (int k = 0; k < my; ++k) {
+                const uint32_t pk = (uint32_t)sslot[s * 64 + k];
+                const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
+                const int rep = (int)(s * 64 + (pk >> 26));
+                sh_rep[at + k] = rep;
+                sh_drep[at + k] = a.seg_lut[valid * (valid + 1) / 2 + mism];
+            }
+        } else if (my > 0) {
+            overflow = true;
+        }
+        base += chunk_total;
+    }
+    if (tid == 0) sh_nacc = base;
+    __syncthreads();
+    const int n_acc = sh_nacc;
+    if (n_acc > ACC_CAP || __syncthreads_or(overflow ? 1 : 0)) { to_slow(); return; }
+    // ---- members of the accepted clusters as one flat list: offsets by cluster
+    {
+        int carry = 0;
+        for (int k0 = 0; k0 < n_acc; k0 += APPLES_TPB) {
+            const int k = k0 + tid;
+            const int sz = k < n_acc ? a.rep_moff[sh_rep[k] + 1] - a.rep_moff[sh_rep[k]] : 0;
+            int tot;
+            const int off = carry + block_excl_scan_int(sz, sh_i, &tot);
+            if (k < n_acc) sh_off[k] = off;
+            carry += tot;
+        }
+        if (tid == 0) sh_off[n_acc] = carry;
+    }
+    __syncthreads();
+    const int M = sh_off[n_acc];
+    // ---- pass 1: one (query, member) distance per thread
+    int n_total = 0, obs_cnt = 0;
+    double z_d = INF_D;
+    int z_i = 0x7fffffff, z_p = 0x7fffffff, z_node = -2;
+    for (int m0 = 0; m0 < M; m0 += APPLES_TPB) {
+        const int m = m0 + tid;
+        if (m < M) {
+            int lo = 0, hi = n_acc;  // last cluster whose offset <= m
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (sh_off[mid] <= m) lo = mid; else hi = mid;
+            }
+            const int rep = sh_rep[lo], mp = m - sh_off[lo];
+            const int slot = a.mem_slot[a.rep_moff[rep] + mp];
+            const uint4 *row = a.packed_rm + (int64_t)slot * (G * 3);
+            uint32_t nv = 0, nmis = 0;
+            for (int g = 0; g < G; ++g) {
+                const uint4 rm = row[g * 3], r0 = row[g * 3 + 1], r1 = row[g * 3 + 2];
+                const uint4 qm = sh_q[g * 3], q0 = sh_q[g * 3 + 1], q1 = sh_q[g * 3 + 2];
+                const uint32_t m0_ = qm.x & rm.x, m1_ = qm.y & rm.y, m2_ = qm.z & rm.z, m3_ = qm.w & rm.w;
+                nv += __popc(m0_) + __popc(m1_) + __popc(m2_) + __popc(m3_);
+                nmis += __popc(((q0.x ^ r0.x) | (q1.x ^ r1.x)) & m0_) + __popc(((q0.y ^ r0.y) | (q1.y ^ r1.y)) & m1_) +
+                        __popc(((q0.z ^ r0.z) | (q1.z ^ r1.z)) & m2_) + __popc(((q0.w ^ r0.w) | (q1.w ^ r1.w)) & m3_);
+            }
+            const double d = a.seg_lut[(int64_t)nv * (nv + 1) / 2 + nmis];
+            double keep = -2.0;  // not emitted
+            if (!(d < 0)) {      // Reference.py:150: `if not dm < 0`
+                ++obs_cnt;
+                if (slot != self) {
+                    ++n_total;
+                    const int node = a.slot_node[slot];
+                    const double drep = sh_drep[lo];
+                    if (d == 0 && (drep < z_d || (drep == z_d && (rep < z_i || (rep == z_i && mp < z_p))))) {
+                        z_d = drep; z_i = rep; z_p = mp; z_node = node;
+                    }
+                    if (node >= 0) {
+                        keep = d;
+                        atomicOr(&dyn_bits[slot >> 6], 1ull << (slot & 63));
+                    }
+                }
+            }
+            tmp[m] = keep;
+        }
+    }
+    const int obs = block_sum(obs_cnt, sh_i);
+    if (obs < a.baseobs) { to_slow(); return; }  // the reference would pop further clusters (Reference.py:146)
+    // ---- ranks of the slot bitmap
+    int n_emit = 0;
+    for (int w0 = 0; w0 < n_words; w0 += APPLES_TPB) {
+        const int w = w0 + tid;
+        const int c = w < n_words ? __popcll(dyn_bits[w]) : 0;
+        int tot;
+        const int ex = n_emit + block_excl_scan_int(c, sh_i, &tot);
+        if (w < n_words) pre[w] = (uint32_t)ex;
+        n_emit += tot;
+    }
+    __syncthreads();
+    // ---- pass 2: emission in slot order
+    for (int m0 = 0; m0 < M; m0 += APPLES_TPB) {
+        const int m = m0 + tid;
+        if (m < M) {
+            const double d = tmp[m];
+            if (d >= 0) {
+                int lo = 0, hi = n_acc;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sh_off[mid] <= m) lo = mid; else hi = mid;
+                }
+                const int slot = a.mem_slot[a.rep_moff[sh_rep[lo]] + (m - sh_off[lo])];
+                const unsigned long long word = dyn_bits[slot >> 6];
+                const int pos = (int)pre[slot >> 6] + __popcll(word & ((1ull << (slot & 63)) - 1ull));
+                o_node[pos] = a.slot_node[slot];
+                o_dist[pos] = d;
+            }
+        }
+    }
+    n_total = block_sum(n_total, sh_i);  // (its barriers also publish the emission)
+    double zd = z_d; int zi = z_i, zp = z_p;
+    block_argmin3(zd, zi, zp, sh_d, sh_i, sh_j);
+    if (tid == 0) sh_znode = -2;
+    __syncthreads();
+    if (z_node != -2 && z_d == zd && z_i == zi && z_p == zp) sh_znode = z_node;
+    __syncthreads();
+    int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
+    for (int i = tid; cg && i <= n_emit; i += APPLES_TPB) {  // per-level offsets into the level-sorted list
+        const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
+        const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
+        for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
+    }
+    if (tid == 0) {
+        apples_placement p;
+        p.edge = 0; p.flags = 0; p.error = 0.0; p.distal = 0.0; p.pendant = 0.0; p.n_obs = n_total; p.n_valid = 0;
+        int ne = n_emit;
+        if (zi != 0x7fffffff) {
+            p.flags = APPLES_F_EXACT | APPLES_F_PENDANT_INT;
+            p.edge = sh_znode;
+            if (sh_znode < 0) { p.flags |= APPLES_F_ZERO_NOT_IN_TREE; p.edge = -1; }
+            ne = 0;
+        } else if (n_total <= 2) {
+            p.flags = APPLES_F_INSUFFICIENT | APPLES_F_PENDANT_INT;
+            p.edge = -1;
+            ne = 0;
+        } else if (ne < 2) {
+            p.flags = APPLES_F_DEGENERATE | APPLES_F_PENDANT_INT;
+            p.edge = -1;
+            ne = 0;
+        }
+        a.out[q] = p;
+        a.n_obs[q] = ne;
+        enlist(a, q, ne);
+    }
+}
+
+int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
+    if (nq == 0) return 0;
+    const size_t dyn = (size_t)((a.n_members + 63) >> 6) * 12;
+    hipLaunchKernelGGL(k_select_clusters, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 // Distance-table rows arrive in the caller's column order; the selection and the sweep want them
 // in slot order (columns sorted by tree level).  One gather pass per uploaded block, after which
 // every later pass over the rows is a coalesced stream.

@@ -219,3 +219,59 @@ def test_scan_sweep_at_c3_shape_and_on_a_deep_tree(monkeypatch):
     want = COracle(tree, seqs, nodes, method='FM', threshold=0.08, baseobs=10, lut=jc69_lut(300, 0.001),
                    threads=NTHREADS).place_sequences(qry)
     assert got.tobytes() == want.tobytes()
+
+
+def _clustered(d, thr):
+    from apples_amd import treecluster
+    from apples_amd.fasta import Alignment
+    from apples_amd.reference import ReducedReference
+    return ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, thr * 1.2)).cluster_arrays()
+
+
+@pytest.mark.parametrize('thr,b', [(0.2, 25), (0.02, 25), (0.05, 400)])
+def test_clustered_route_fused_by_representatives_against_c_oracle(thr, b, monkeypatch):
+    """The command line's default route (max-diameter clusters, consensus representatives, heap-ordered
+    cluster expansion, apples/Reference.py:117-157) on its fused path: matrix-core pass over the
+    representatives, members of the accepted clusters expanded per query, slow list for queries whose
+    accepted clusters hold fewer than -b valid distances (small thresholds send most queries there).
+    Byte for byte against the C oracle, and against the unfused path (full rows + general selection)."""
+    d = synth.make_dataset(6000, 700, 700)
+    q = d.query_seqs.copy()
+    q[5] = d.ref_seqs[77]            # exact hit through a cluster member
+    q[6] = ord('-')                  # nothing observed
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ca = _clustered(d, thr)
+    assert len(ca[0]) > 20
+    want = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', threshold=thr, baseobs=b, lut=jc69_lut(700, 0.001),
+                   threads=NTHREADS).place_sequences(q)
+    self_rows = np.full(len(q), -1, np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', threshold=thr, baseobs=b)
+    got = eng.place_sequences(q)
+    eng.close()
+    assert got.tobytes() == want.tobytes()
+    monkeypatch.setenv('APPLES_NO_CLUSTER_FUSE', '1')
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', threshold=thr, baseobs=b)
+    unfused = eng.place_sequences(q, self_rows)
+    eng.close()
+    assert unfused.tobytes() == want.tobytes()
+    assert got[5]['flags'] & F_EXACT and got[6]['flags'] & F_INSUFFICIENT
+
+
+def test_clustered_route_at_c3_shape(monkeypatch):
+    """The same at 200 000 leaves (about 5 000 clusters of 40): fused and unfused paths agree on 3 000
+    queries, a sample agrees with the C oracle."""
+    d = synth.make_dataset(200000, 1000, 3000)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ca = _clustered(d, 0.2)
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS')
+    got = eng.place_sequences(d.query_seqs)
+    eng.close()
+    monkeypatch.setenv('APPLES_NO_CLUSTER_FUSE', '1')
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS')
+    unfused = eng.place_sequences(d.query_seqs[:600])
+    eng.close()
+    assert unfused.tobytes() == got[:600].tobytes()
+    sample = _sample(got, 3000, extremes=4, strided=24)
+    want = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', lut=jc69_lut(1000, 0.001),
+                   threads=NTHREADS).place_sequences(d.query_seqs[sample])
+    assert got[sample].tobytes() == want.tobytes()
