@@ -488,14 +488,20 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
 }
 
 // workspaces for `members` rows/columns per query
+// `slim`: the fused matrix-core path writes no full distance rows for the batch -- only the queries on the top-up
+// list get them -- so dist and dist_slow hold a slice of the batch (an eighth) and the list is walked in slices:
+// a query then costs 4 + 2 bytes per reference slot instead of 20, and a C3 pass needs 4 device batches, not 7.
 int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t want_batch, bool need_dist,
-                     bool need_counts, bool need_xe, bool need_fused = false, bool need_alt = false) {
+                     bool need_counts, bool need_xe, bool need_fused = false, bool need_alt = false, bool slim = false) {
     Workspace &w = ctx->ws;
     const DevTree &t = ctx->tree;
     int64_t batch = want_batch;
     if (ctx->params.max_batch > 0) batch = std::min(batch, (int64_t)ctx->params.max_batch);
+    static const bool no_slim = getenv("APPLES_NO_SLIM_BATCH") != nullptr;  // diagnostic knob
+    slim = slim && need_fused && !need_counts && !need_alt && !no_slim;
     int64_t per_q = stride * 8 + members * 12 + (int64_t)(t.height + 2) * 4 + (need_counts ? stride * 4 : 0) +
                     (need_fused ? stride * 12 + stride / 16 : 0);
+    if (slim) per_q = stride * 4 + stride / 16 + stride * 2 + members * 12 + (int64_t)(t.height + 2) * 4;
     // batch buffers: up to 96 GiB, at most 40 % of what is free on the card (288 GB HBM3E; bigger
     // batches amortise the sweep's tail: at 200 k leaves 16 k-query batches are 13 % faster than 5 k).
     // Allocating them is not free: with 160 GiB a resident C3 pass is another 4 % faster, but a one-shot
@@ -510,9 +516,13 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     batch = std::min(batch, capq);
     batch = round_up(std::max<int64_t>(batch, 1), 32);
     bool regrow = batch > w.batch || members > w.obs_cap || stride > w.stride || (need_counts && !w.counts) ||
-                  (need_xe && !w.big.xe) || (need_dist && !w.dist) || (need_fused && !w.seg_slot) || (need_alt && !w.has_alt);
+                  (need_xe && !w.big.xe) || (need_dist && !w.dist) || (need_fused && !w.seg_slot) || (need_alt && !w.has_alt) ||
+                  (!slim && w.dist_rows < std::min(batch, w.batch));  // full rows wanted where only a slice exists
     if (!regrow) return 0;
-    batch = std::max(batch, w.batch);
+    if (slim == w.slim || !w.slim) batch = std::max(batch, w.batch);
+    if (!slim) batch = std::min(batch, std::max<int64_t>(capq, 32));  // (a slim workspace's batch would not fit with full rows)
+    batch = round_up(std::max<int64_t>(batch, 1), 32);
+    const int64_t drows = slim ? std::min(batch, std::max<int64_t>(2048, batch / 8)) : batch;
     int64_t obs_cap = std::max(members, w.obs_cap);
     stride = std::max(stride, w.stride);
     bool xe = need_xe || w.big.xe != nullptr, had_counts = w.counts != nullptr;
@@ -522,8 +532,10 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     w.batch = batch;
     w.obs_cap = obs_cap;
     w.stride = stride;
+    w.slim = slim;
+    w.dist_rows = drows;
     for (int set = 0; set < (alt ? 2 : 1); ++set) {
-        if (dev_alloc(ctx, &w.dist, batch * std::max<int64_t>(stride, 1))) return 1;
+        if (dev_alloc(ctx, &w.dist, drows * std::max<int64_t>(stride, 1))) return 1;
         if (need_counts || had_counts)
             if (dev_alloc(ctx, &w.counts, batch * std::max<int64_t>(stride, 1))) return 1;
         if (dev_alloc(ctx, &w.obs_node, batch * obs_cap)) return 1;
@@ -533,7 +545,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         if (fused) {
             if (dev_alloc(ctx, &w.seg_slot, batch * std::max<int64_t>(stride, 1))) return 1;
             if (dev_alloc(ctx, &w.seg_cnt, batch * std::max<int64_t>(stride / 64, 1))) return 1;
-            if (dev_alloc(ctx, &w.dist_slow, batch * std::max<int64_t>(stride, 1))) return 1;
+            if (dev_alloc(ctx, &w.dist_slow, drows * std::max<int64_t>(stride, 1))) return 1;
             if (dev_alloc(ctx, &w.slow_list, batch)) return 1;
         }
         if (dev_alloc(ctx, &w.route_list, batch)) return 1;
@@ -845,10 +857,12 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     const bool pipelined = n_pipe > 1 && qb.n >= 1024;
     int64_t want = qb.n;
     if (pipelined) want = round_up((qb.n + n_pipe - 1) / n_pipe, 32);
-    if (ensure_workspace(ctx, a.n_refs, a.slots_pad, want, true, false, hybrid, fused, pipelined)) return 1;
+    const bool slim = fused && a.all_singleton && fused_counts_format(ctx, qb) && !pipelined;
+    if (ensure_workspace(ctx, a.n_refs, a.slots_pad, want, true, false, hybrid, fused, pipelined, slim)) return 1;
     Workspace &w = ctx->ws;
-    const int64_t step = pipelined ? std::min<int64_t>(w.batch, want) : w.batch;
+    int64_t step = pipelined ? std::min<int64_t>(w.batch, want) : w.batch;
     const int64_t n_sub = (qb.n + step - 1) / step;
+    if (!pipelined && n_sub > 1) step = std::min(step, round_up((qb.n + n_sub - 1) / n_sub, 32));  // equal sub-batches
     hipStream_t front = ctx->stream, back = pipelined ? ctx->stream3 : ctx->stream;
     // timing events come from a pool that lives with the context (creating and destroying a dozen
     // events per call costs host time inside every pass)
@@ -916,14 +930,40 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             // (short rows are cheaper to stream twice than to rank: 2 x `-b` block arg-min rounds)
             static const int64_t topup_min = getenv("APPLES_TOPUP_MIN_ROWS") ? atoll(getenv("APPLES_TOPUP_MIN_ROWS")) : 40000;
             const bool topup = !no_topup && ctx->params.base_observation <= 256 && ctx->aln.n_refs >= topup_min;
-            if (launch_counts_listed(ctx, qb, q0, nq, w.slow_list, w.slow_count, w.dist_slow, topup ? w.dist : nullptr,
-                                     topup ? w.seg_slot : nullptr)) return 1;
             sa.dist = w.dist_slow;
-            sa.qlist = w.slow_list;
-            sa.qcount = w.slow_count;
             sa.segmin_d = w.dist;
             sa.segmin_i = w.seg_slot;
-            if (topup ? launch_select_topup(ctx, sa, nq) : launch_select(ctx, sa, nq)) return 1;
+            if (w.dist_rows < nq) {
+                // slim workspace: full rows exist for a slice of the batch only.  The list's length comes to the
+                // host (one short wait per batch) and the list is walked in slices of that many queries
+                int32_t hcnt = 0;
+                HIP_TRY(ctx, hipMemcpyAsync(&hcnt, w.slow_count, sizeof(int32_t), hipMemcpyDeviceToHost, front));
+                HIP_TRY(ctx, hipStreamSynchronize(front));
+                const int64_t R = w.dist_rows;
+                int32_t lens[64];
+                int n_sl = 0;
+                for (int64_t off = 0; off < hcnt && n_sl < 64; off += R) lens[n_sl++] = (int32_t)std::min<int64_t>(R, hcnt - off);
+                if (n_sl > 1) {
+                    if (!ctx->d_slice_cnt && dev_alloc(ctx, &ctx->d_slice_cnt, 64)) return 1;
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slice_cnt, lens, n_sl * sizeof(int32_t), hipMemcpyHostToDevice, front));
+                    HIP_TRY(ctx, hipStreamSynchronize(front));  // (lens is on the stack)
+                }
+                for (int k = 0; k < n_sl; ++k) {
+                    const int32_t *cntp = n_sl > 1 ? ctx->d_slice_cnt + k : w.slow_count;
+                    const int32_t *lst = w.slow_list + (int64_t)k * R;
+                    if (launch_counts_listed(ctx, qb, q0, lens[k], lst, cntp, w.dist_slow, topup ? w.dist : nullptr,
+                                             topup ? w.seg_slot : nullptr)) return 1;
+                    sa.qlist = lst;
+                    sa.qcount = cntp;
+                    if (topup ? launch_select_topup(ctx, sa, lens[k]) : launch_select(ctx, sa, lens[k])) return 1;
+                }
+            } else {
+                if (launch_counts_listed(ctx, qb, q0, nq, w.slow_list, w.slow_count, w.dist_slow, topup ? w.dist : nullptr,
+                                         topup ? w.seg_slot : nullptr)) return 1;
+                sa.qlist = w.slow_list;
+                sa.qcount = w.slow_count;
+                if (topup ? launch_select_topup(ctx, sa, nq) : launch_select(ctx, sa, nq)) return 1;
+            }
             HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
@@ -1084,6 +1124,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     for (auto &c : ctx->blk_cache) dev_free(c.second);
     ctx->blk_cache.clear();
     dev_free(ctx->d_exotic);
+    dev_free(ctx->d_slice_cnt);
     for (auto &e : ctx->ev_feed) (void)hipEventDestroy(e);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;

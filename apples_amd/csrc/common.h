@@ -124,6 +124,8 @@ struct BatchBuf {
 
 struct Workspace {
     int64_t batch = 0;            // queries per device batch
+    int64_t dist_rows = 0;        // rows of dist / dist_slow: `batch`, or a slice of it (slim: only listed queries use full rows)
+    bool slim = false;
     int64_t stride = 0;           // row stride of dist/counts
     double *dist = nullptr;       // [batch][slots_pad] fp64 distances in slot order
     uint32_t *counts = nullptr;   // [batch][slots_pad] (mism<<16|valid), only when requested
@@ -191,6 +193,7 @@ struct apples_ctx {
     std::unordered_map<void *, size_t> blk_size;
     int *d_exotic = nullptr;         // device flag: a packed query block carried a symbol beyond ACGT-
     std::vector<hipEvent_t> ev_feed; // "chunk i of a streamed block is uploaded and packed"
+    int32_t *d_slice_cnt = nullptr;  // [64] list lengths of the top-up slices (slim workspaces)
     unsigned long long *scan_prof = nullptr;  // APPLES_SCAN_PROFILE: per-phase cycle sums of the scan sweep
     // -d path: column layout cache
     int64_t col_gen = 0;             // bumped whenever the column layout below is replaced

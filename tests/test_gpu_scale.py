@@ -320,3 +320,31 @@ def test_long_alignments_through_the_fused_matrix_core_pass(L):
     got = eng.place_sequences(qry)
     _compare(got, want, co, d, nodes, 'long alignment L=%d' % L)
     eng.close()
+
+
+def test_top_up_list_walked_in_slices(c2_full):
+    """On the fused matrix-core path only the queries that need the top-up rule get full distance rows, and
+    the row buffers hold a slice of the batch (an eighth, at least 2 048 rows): with a tiny threshold every
+    one of 10 000 queries is on that list, which is then walked in five slices.  Same bytes as with
+    batch-sized row buffers (APPLES_NO_SLIM_BATCH=1) and as the C oracle."""
+    import subprocess
+    d, nodes = c2_full
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from apples_amd import synth\n"
+            "from apples_amd.engine import Engine\n"
+            "d = synth.make_dataset(10000, 1000, 10000)\n"
+            "nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)\n"
+            "e = Engine(d.tree, d.ref_seqs, nodes, method='OLS', threshold=0.01, baseobs=30)\n"
+            "sys.stdout.buffer.write(e.place_sequences(d.query_seqs).tobytes())\n" % ROOT)
+    outs = []
+    for env in ({}, {'APPLES_NO_SLIM_BATCH': '1'}):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(r.stdout)
+    assert len(outs[0]) == 10000 * 40 and outs[0] == outs[1]
+    got = np.frombuffer(outs[0], dtype=np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'), ('distal', '<f8'),
+                                                 ('pendant', '<f8'), ('n_obs', '<i4'), ('n_valid', '<i4')], align=True))
+    sample = np.arange(0, 10000, 200)
+    co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', threshold=0.01, baseobs=30, lut=jc69_lut(1000, 0.001),
+                 threads=len(os.sched_getaffinity(0)))
+    assert got[sample].tobytes() == co.place_sequences(d.query_seqs[sample]).tobytes()

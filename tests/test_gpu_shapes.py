@@ -28,13 +28,13 @@ def _sample(got, n, extremes=8, strided=56):
 
 
 def test_c3_shape_200k_leaves_two_device_batches():
-    """Config 3: 200 000-leaf backbone, L = 1000 nt, OLS/JC69, -f 0.2 -b 25.  20 000 queries: at
-    this reference size a device batch holds about 14 000, so the tagged node map of the sweep is
+    """Config 3: 200 000-leaf backbone, L = 1000 nt, OLS/JC69, -f 0.2 -b 25.  36 000 queries: at
+    this reference size a device batch holds about 28 000, so the tagged node map of the sweep is
     reused across batches, the top-up selection by segment minima runs on 200 k-slot rows and the
     host-buffer entry point streams its chunks.  Checked: >= 64 sampled queries byte for byte
     against the C oracle; the resident and the streamed entry points agree; the result does not
     depend on the batch size."""
-    nq = 20000
+    nq = 36000
     d = synth.make_dataset(200000, 1000, nq)
     nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
