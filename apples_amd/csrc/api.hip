@@ -853,7 +853,9 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     // threshold form)
     const bool cfused = !no_fuse && !a.all_singleton && ctx->params.model == APPLES_JC69 && a.rep_packed && a.packed_rm &&
                         fused_counts_format(ctx, qb);
-    const bool fused = !no_fuse && (a.all_singleton || cfused) && ctx->params.model == APPLES_JC69;
+    // scoredist with singleton clusters: threshold compaction in the distance kernel's epilogue as well
+    const bool sfused = !no_fuse && a.all_singleton && ctx->params.model == APPLES_SCOREDIST;
+    const bool fused = !no_fuse && (((a.all_singleton || cfused) && ctx->params.model == APPLES_JC69) || sfused);
     const bool pipelined = n_pipe > 1 && qb.n >= 1024;
     int64_t want = qb.n;
     if (pipelined) want = round_up((qb.n + n_pipe - 1) / n_pipe, 32);
@@ -911,6 +913,21 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             sa.dist = w.dist_slow;
             sa.qlist = w.slow_list;
             sa.qcount = w.slow_count;
+            if (launch_select(ctx, sa, nq)) return 1;
+            HIP_TRY(ctx, hipEventRecord(e[2], front));
+        } else if (sfused) {
+            HIP_TRY(ctx, hipEventRecord(e[0], front));
+            if (launch_scoredist_fused(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt, w.dist_slow)) return 1;
+            HIP_TRY(ctx, hipEventRecord(e[1], front));
+            ++launches;
+            SelectArgs sa = select_args_alignment(ctx, qb, q0);
+            sa.seg_lut = nullptr;
+            if (launch_select_fast(ctx, sa, nq)) return 1;
+            // the queries that need the top-up rule: streamed selection over their full rows (row = query)
+            sa.dist = w.dist_slow;
+            sa.qlist = w.slow_list;
+            sa.qcount = w.slow_count;
+            sa.rows_by_query = 1;
             if (launch_select(ctx, sa, nq)) return 1;
             HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else if (fused) {

@@ -232,6 +232,8 @@ int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq,
                   uint32_t *d_counts);
 int launch_scoredist(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *d_dist,
                      uint32_t *d_counts);
+int launch_scoredist_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, int32_t *seg_slot,
+                           int32_t *seg_cnt, double *full_rows);
 // select.hip
 struct SelectArgs {
     const double *dist;       // [nq][stride]
@@ -257,8 +259,9 @@ struct SelectArgs {
     int64_t cls_stride;
     int big_threshold;                  // n_obs above this -> straight to the big-team sweep list
     int32_t *overflow_list, *overflow_count;
-    // listed mode of k_select: block r handles query qlist[r] with distances in row r
+    // listed mode of k_select: block r handles query qlist[r] with distances in row r (rows_by_query: in row qlist[r])
     const int32_t *qlist, *qcount;
+    int rows_by_query;
     // top-up by segment minima (k_jc69 MODE 2 -> k_select_topup): [listed row][stride]
     const double *segmin_d; const int32_t *segmin_i;
     // clustered fast path (k_select_clusters): survivors among the representatives come in seg_slot/seg_cnt with

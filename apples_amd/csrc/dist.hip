@@ -654,23 +654,27 @@ int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int6
 // 21-entry row with their own residue, i.e. 21 consecutive 8-byte words: conflict-free ds_read_b64.
 // Sites are summed left to right in fp64 (the reference's order is whatever BLAS ddot does, so
 // this path is tolerance-checked, not bit-checked).
-template <int TQ>
+// MODE 0: full rows for queries q0.. ; MODE 1: fused threshold compaction per 64-slot segment (the format
+// k_select_fast reads, as k_jc69 MODE 1) with the full rows beside it
+template <int TQ, int MODE>
 __global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
                                                           const uint8_t *__restrict__ qa, const uint16_t *__restrict__ qm,
                                                           const double *__restrict__ table, double *__restrict__ dist,
                                                           uint32_t *__restrict__ counts, int64_t n_slots,
-                                                          int64_t slots_pad, int Lpad, int L, int64_t nq, double overlap) {
+                                                          int64_t slots_pad, int Lpad, int L, int64_t nq, double overlap,
+                                                          double thr, int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
+                                                          double *__restrict__ full) {
     __shared__ double T[21 * 21];
     for (int i = threadIdx.x; i < 21 * 21; i += APPLES_TPB) T[i] = table[i];
     __syncthreads();
     const char *Tb = reinterpret_cast<const char *>(T);
     const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    const int n16 = Lpad / 16;
     const int64_t q0 = (int64_t)blockIdx.y * TQ;
     double tot[TQ];
     uint32_t nv[TQ];
 #pragma unroll
     for (int t = 0; t < TQ; ++t) { tot[t] = 0.0; nv[t] = 0; }
-    const int n16 = Lpad / 16;
     for (int s16 = 0; s16 < n16; ++s16) {
         // this row's 16 residues as table column byte offsets (index * 8), unpacked once per block of
         // sites and reused for all TQ queries
@@ -702,12 +706,13 @@ __global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restr
             for (int t = 0; t < TQ; ++t) tot[t] += v[t];
         }
     }
-    if (slot >= n_slots) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t seg = slot >> 6, n_seg = slots_pad >> 6;
 #pragma unroll
     for (int t = 0; t < TQ; ++t) {
-        if (q0 + t < nq) {
-            int64_t o = (q0 + t) * slots_pad + slot;
-            uint32_t valid = nv[t];
+        if (q0 + t < nq) {  // wave-uniform
+            const int64_t o = (q0 + t) * slots_pad + slot;
+            const uint32_t valid = nv[t];
             double d;
             if (valid == 0 || (double)valid / (double)L < overlap) d = -1.0;
             else {
@@ -715,8 +720,23 @@ __global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restr
                 if (0 >= r1) d = -1.0;
                 else d = -log(r1) * 1.3;
             }
-            if (dist) dist[o] = d;
-            if (counts) counts[o] = valid;
+            if (MODE == 1) {
+                const bool keep = slot < n_slots && d >= 0 && d <= thr;
+                const unsigned long long m = __ballot(keep);
+                if (keep) {
+                    const int64_t oo = (q0 + t) * slots_pad + seg * 64 + __popcll(m & ((1ull << lane) - 1ull));
+                    seg_slot[oo] = (int32_t)slot;
+                    dist[oo] = d;
+                }
+                if (lane == 0) seg_cnt[(q0 + t) * n_seg + seg] = __popcll(m);
+                // the full row beside it: a table lookup per site makes these rows too dear to compute twice for
+                // the queries that turn out to need the top-up rule (with JC69 they are recomputed, which is cheaper
+                // than writing them for everybody)
+                if (full && slot < n_slots) full[o] = d;
+            } else if (slot < n_slots) {
+                if (dist) dist[o] = d;
+                if (counts) counts[o] = valid;
+            }
         }
     }
 }
@@ -727,10 +747,25 @@ int launch_scoredist(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t 
     const DevAlign &a = ctx->aln;
     int Lpad = (a.L + 15) / 16 * 16;
     constexpr int TQ = 8;
-    hipLaunchKernelGGL((k_scoredist<TQ>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)),
+    hipLaunchKernelGGL((k_scoredist<TQ, 0>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)),
                        dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask, qb.aa_idx + q0 * Lpad,
                        qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, d_dist, d_counts, a.n_rows, a.slots_pad, Lpad, a.L, nq,
-                       ctx->params.overlap_frac);
+                       ctx->params.overlap_frac, 0.0, (int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// fused threshold compaction (MODE 1: seg_d/seg_slot/seg_cnt as launch_counts_fused leaves them for k_select_fast)
+int launch_scoredist_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, int32_t *seg_slot,
+                           int32_t *seg_cnt, double *full_rows) {
+    if (nq == 0) return 0;
+    const DevAlign &a = ctx->aln;
+    int Lpad = (a.L + 15) / 16 * 16;
+    constexpr int TQ = 8;
+    hipLaunchKernelGGL((k_scoredist<TQ, 1>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)),
+                       dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask, qb.aa_idx + q0 * Lpad,
+                       qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, seg_d, (uint32_t *)nullptr, a.n_rows, a.slots_pad, Lpad, a.L, nq,
+                       ctx->params.overlap_frac, ctx->params.filt_threshold, seg_slot, seg_cnt, full_rows);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

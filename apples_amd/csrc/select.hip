@@ -123,7 +123,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     for (int64_t r = blockIdx.x; r < n_list; r += gridDim.x) {
     const int64_t q = a.qlist ? a.qlist[r] : r;
     const int tid = threadIdx.x;
-    const double *row = a.dist + r * a.stride;
+    const double *row = a.dist + (a.rows_by_query ? q : r) * a.stride;
     const int32_t *gather = a.gather;
     const int64_t nm = a.n_members;
     const int self = a.self_slot ? a.self_slot[q] : -1;
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
     const int64_t w_lo = std::min<int64_t>(nm, per * wv), w_hi = std::min<int64_t>(nm, per * (wv + 1));
     for (int64_t r = blockIdx.x; r < n_list; r += gridDim.x) {
         const int64_t q = a.qlist ? a.qlist[r] : r;
-        const double *row = a.dist + r * a.stride;
+        const double *row = a.dist + (a.rows_by_query ? q : r) * a.stride;
         const int self = a.self_slot ? a.self_slot[q] : -1;
         int32_t *o_node = a.obs_node + q * a.obs_cap;
         double *o_dist = a.obs_dist + q * a.obs_cap;

@@ -275,3 +275,36 @@ def test_clustered_route_at_c3_shape(monkeypatch):
     want = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', lut=jc69_lut(1000, 0.001),
                    threads=NTHREADS).place_sequences(d.query_seqs[sample])
     assert got[sample].tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize('thr,b', [(0.2, 25), (0.03, 60)])
+def test_scoredist_fused_threshold_compaction_equals_full_rows(thr, b):
+    """scoredist with singleton clusters keeps, like JC69, only the entries inside the threshold in the
+    distance kernel's epilogue; queries that need the top-up rule get full rows (listed mode).  Same bytes as
+    the unfused route (APPLES_NO_FUSE=1: full rows + general selection); edges and counts equal to the C
+    oracle's, lengths within 1e-9."""
+    import subprocess
+    d = synth.make_dataset(5000, 300, 900, protein=True)
+    q = d.query_seqs.copy()
+    q[3] = d.ref_seqs[11]
+    q[4] = ord('-')
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, protein=True, method='FM', threshold=thr, baseobs=b)
+    got = eng.place_sequences(q)
+    eng.close()
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from apples_amd import synth\nfrom apples_amd.engine import Engine\n"
+            "d = synth.make_dataset(5000, 300, 900, protein=True)\n"
+            "q = d.query_seqs.copy(); q[3] = d.ref_seqs[11]; q[4] = ord('-')\n"
+            "nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)\n"
+            "e = Engine(d.tree, d.ref_seqs, nodes, protein=True, method='FM', threshold=%r, baseobs=%d)\n"
+            "sys.stdout.buffer.write(e.place_sequences(q).tobytes())\n" % (ROOT, thr, b))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, APPLES_NO_FUSE='1'), timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout == got.tobytes()
+    want = COracle(d.tree, d.ref_seqs, nodes, protein=True, method='FM', threshold=thr, baseobs=b, threads=NTHREADS).place_sequences(q)
+    for f in ('edge', 'flags', 'n_obs', 'n_valid'):
+        assert np.array_equal(got[f], want[f]), f
+    for f in ('error', 'distal', 'pendant'):
+        np.testing.assert_allclose(got[f], want[f], rtol=1e-9, atol=1e-15, err_msg=f)
+    assert got[3]['flags'] & F_EXACT and got[4]['flags'] & F_INSUFFICIENT
