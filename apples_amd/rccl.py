@@ -1,0 +1,168 @@
+"""The end-of-run gather over RCCL/xGMI without PyTorch: ctypes on librccl.so and libamdhip64.so.
+
+Queries are sharded over the GPUs of one node, one process per GPU, with no collective in the data path; the
+40-byte placement structs are gathered to rank 0 once (``starmap``'s pickle return in the reference,
+run_apples.py:101-102).  Here that gather is one grouped ``ncclSend``/``ncclRecv`` straight from the
+device-resident structs (``apples_placements_device_ptr``).  The 128-byte communicator id travels from rank 0
+to the others over a plain TCP socket on ``MASTER_ADDR``; the same socket carries the host-side barrier and
+the max-over-ranks of the timing (a few bytes per rank: no reason to spend a collective on them).
+
+``apples_amd.distributed`` does the same through ``torch.distributed`` (what ``bench.py`` uses by default, and
+gloo in the CPU tests); this module is the torch-free form (``bench.py --gather rccl``).
+"""
+import ctypes as C
+import os
+import socket
+import struct
+import time
+
+NCCL_UINT8 = 1
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [('internal', C.c_char * 128)]
+
+
+def _lib(name, env):
+    for cand in (os.environ.get(env), name, os.path.join('/opt/rocm/lib', name)):
+        if not cand:
+            continue
+        try:
+            return C.CDLL(cand)
+        except OSError:
+            continue
+    raise RuntimeError('%s not found (set %s)' % (name, env))
+
+
+class Comm:
+    """One RCCL communicator over the ranks of one node + a TCP side channel through rank 0."""
+
+    def __init__(self, rank, world, device, addr=None, port=None, timeout=120.0):
+        self.rank, self.world = int(rank), int(world)
+        self.hip = _lib('libamdhip64.so', 'APPLES_HIP_LIB')
+        self.nccl = _lib('librccl.so', 'APPLES_RCCL_LIB')
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.nccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        self.nccl.ncclSend.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self.nccl.ncclRecv.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self.nccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        self._check_hip(self.hip.hipSetDevice(int(device)), 'hipSetDevice')
+        addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+        port = int(port or int(os.environ.get('MASTER_PORT', '29500')) + 1)
+        uid = _UniqueId()
+        self.peers = []   # rank 0: sockets of ranks 1..world-1, by rank
+        self.sock = None  # other ranks: socket to rank 0
+        if self.rank == 0:
+            self._check(self.nccl.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
+            if self.world > 1:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                srv.listen(self.world)
+                srv.settimeout(timeout)
+                got = {}
+                while len(got) < self.world - 1:
+                    conn, _ = srv.accept()
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    r = struct.unpack('<i', self._recv(conn, 4))[0]
+                    got[r] = conn
+                srv.close()
+                self.peers = [got[r] for r in range(1, self.world)]
+                for conn in self.peers:
+                    conn.sendall(bytes(uid.internal))
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    self.sock = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.1)
+            self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self.sock.settimeout(timeout)
+            self.sock.sendall(struct.pack('<i', self.rank))
+            C.memmove(C.byref(uid), self._recv(self.sock, 128), 128)
+        self.comm = C.c_void_p()
+        self._check(self.nccl.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        self._recv_buf = C.c_void_p()
+        self._recv_cap = 0
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _recv(conn, n):
+        buf = b''
+        while len(buf) < n:
+            part = conn.recv(n - len(buf))
+            if not part:
+                raise RuntimeError('rendezvous peer closed the connection')
+            buf += part
+        return buf
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError('%s failed with ncclResult %d' % (what, rc))
+
+    def _check_hip(self, rc, what):
+        if rc != 0:
+            raise RuntimeError('%s failed with hipError %d' % (what, rc))
+
+    # ------------------------------------------------------------------ host-side barrier / reduction through rank 0
+    def max_over_ranks(self, value):
+        """max of one float over the ranks (every rank gets it); doubles as a barrier."""
+        if self.world == 1:
+            return float(value)
+        if self.rank == 0:
+            vals = [float(value)] + [struct.unpack('<d', self._recv(c, 8))[0] for c in self.peers]
+            m = max(vals)
+            for c in self.peers:
+                c.sendall(struct.pack('<d', m))
+            return m
+        self.sock.sendall(struct.pack('<d', float(value)))
+        return struct.unpack('<d', self._recv(self.sock, 8))[0]
+
+    def barrier(self):
+        self.max_over_ranks(0.0)
+        self._check_hip(self.hip.hipDeviceSynchronize(), 'hipDeviceSynchronize')
+
+    # ------------------------------------------------------------------ the gather
+    def gather_to_host(self, dev_ptr, sizes):
+        """dev_ptr: this rank's device buffer of sizes[rank] bytes.  One grouped send/recv to rank 0, which
+        returns the concatenation (in rank order) as bytes; the other ranks return None."""
+        total = int(sum(sizes))
+        if self.rank == 0 and total > self._recv_cap:
+            if self._recv_buf:
+                self.hip.hipFree(self._recv_buf)
+            self._check_hip(self.hip.hipMalloc(C.byref(self._recv_buf), max(total, 1)), 'hipMalloc')
+            self._recv_cap = total
+        self._check(self.nccl.ncclGroupStart(), 'ncclGroupStart')
+        if sizes[self.rank]:
+            self._check(self.nccl.ncclSend(C.c_void_p(dev_ptr), sizes[self.rank], NCCL_UINT8, 0, self.comm, None), 'ncclSend')
+        if self.rank == 0:
+            off = 0
+            for r in range(self.world):
+                if sizes[r]:
+                    self._check(self.nccl.ncclRecv(C.c_void_p(self._recv_buf.value + off), sizes[r], NCCL_UINT8, r, self.comm, None), 'ncclRecv')
+                off += sizes[r]
+        self._check(self.nccl.ncclGroupEnd(), 'ncclGroupEnd')
+        self._check_hip(self.hip.hipDeviceSynchronize(), 'hipDeviceSynchronize')
+        if self.rank != 0:
+            return None
+        host = C.create_string_buffer(max(total, 1))
+        self._check_hip(self.hip.hipMemcpy(host, self._recv_buf, total, 2), 'hipMemcpy')  # 2 = device to host
+        return host.raw[:total]
+
+    def close(self):
+        if getattr(self, 'comm', None):
+            self.nccl.ncclCommDestroy(self.comm)
+            self.comm = None
+        if self._recv_buf:
+            self.hip.hipFree(self._recv_buf)
+            self._recv_buf = C.c_void_p()
+        for c in self.peers:
+            c.close()
+        if self.sock:
+            self.sock.close()

@@ -210,6 +210,9 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--queries', type=int, default=0, help='override the number of queries (per GPU when weak)')
+    ap.add_argument('--gather', default='torch', choices=['torch', 'rccl'],
+                    help='the end-of-run gather for N > 1: torch.distributed (backend nccl = RCCL) or ctypes on librccl.so '
+                         'without PyTorch (apples_amd/rccl.py)')
     ap.add_argument('--timed', default='', choices=['', 'host', 'resident'],
                     help='what a step covers: host = host buffers in, placements in host memory (default for alignment '
                          'workloads); resident = inputs already uploaded (default for c5: a 200 k-column table block is '
@@ -224,8 +227,11 @@ def main():
     # APPLES_BENCH_FORCE_DIST=1 (tests): take the multi-rank code path -- process group, gather,
     # max over ranks -- even with a single rank, so that one GPU is enough to exercise it
     use_dist = world > 1 or bool(os.environ.get('APPLES_BENCH_FORCE_DIST'))
-    dist = torch = None
-    if use_dist:
+    dist = torch = comm = None
+    if use_dist and args.gather == 'rccl':
+        from apples_amd.rccl import Comm
+        comm = Comm(rank, world, local_rank)
+    elif use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -268,7 +274,7 @@ def main():
         def __init__(self, ptr, nbytes):
             self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
 
-    if use_dist:
+    if use_dist and comm is None:
         from apples_amd.distributed import gather_bytes
 
     def step():
@@ -289,17 +295,24 @@ def main():
             h, n = eng.place_sequences_streamed(queries)
         # the end-of-run gather over RCCL/xGMI (replaces starmap's pickle return), straight from the
         # device-resident structs; rank 0 then brings the whole job's placements to the host
-        res = torch.as_tensor(_DevArray(eng.placements_device_ptr(h), n * 40), device='cuda')
-        parts = gather_bytes(res, rank, world, dist, [s * 40 for s in sizes])
         out = None
-        if rank == 0:
-            out = np.frombuffer(torch.cat(parts).cpu().numpy().tobytes(), dtype=PLACEMENT_DTYPE)
+        if comm is not None:
+            raw = comm.gather_to_host(eng.placements_device_ptr(h), [s * 40 for s in sizes])
+            if rank == 0:
+                out = np.frombuffer(raw, dtype=PLACEMENT_DTYPE)
+        else:
+            res = torch.as_tensor(_DevArray(eng.placements_device_ptr(h), n * 40), device='cuda')
+            parts = gather_bytes(res, rank, world, dist, [s * 40 for s in sizes])
+            if rank == 0:
+                out = np.frombuffer(torch.cat(parts).cpu().numpy().tobytes(), dtype=PLACEMENT_DTYPE)
         if res_handle is None:
             eng.free_queries(h)
         return out
 
     def sync():
-        if use_dist:
+        if comm is not None:
+            comm.barrier()
+        elif use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -318,7 +331,9 @@ def main():
         launches += t['dist_launches']
     sync()
     dt = time.perf_counter() - t0
-    if use_dist:
+    if comm is not None:
+        dt = comm.max_over_ranks(dt)
+    elif use_dist:
         tmax = torch.tensor([dt], device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -340,6 +355,7 @@ def main():
         for k in res_phases:
             res_phases[k] += t[k]
     dt_res = time.perf_counter() - t1
+    final_line = None
     mine = eng.fetch(handle, nq)
     eng.free_queries(handle)
     if rank == 0:
@@ -409,7 +425,8 @@ def main():
                        else 'inputs resident in HBM -> placements in host memory (kernels, copy back)',
                        'n_ref': n_leaves, 'L': L, 'queries_this_rank': nq, 'queries_total': total_q, 'method': method,
                        'mean_observed': float(np.mean(mine['n_obs'])), 'mean_swept_nodes': mean_v,
-                       'placed': int(placed.sum()), 'parallelism': 'query-sharded x%d' % world},
+                       'placed': int(placed.sum()), 'parallelism': 'query-sharded x%d' % world,
+                       'gather': ('librccl via ctypes (no PyTorch)' if comm is not None else 'torch.distributed nccl') if use_dist else None},
             'roofline': roofline,
             'resident': {'value': world * nq / (dt_res / args.steps), 'ms_per_step': res_ms, 'unit': 'queries/s',
                          'per_kernel_ms_per_step': {k: v / args.steps for k, v in res_phases.items()},
@@ -419,11 +436,23 @@ def main():
         }
         if cpu:
             line['speedup_vs_cpu_baseline'] = value / cpu['value']
-        print(json.dumps(line), flush=True)
+        final_line = json.dumps(line)
     eng.close()
-    if use_dist:
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+    elif use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line comes last: after the communicator is gone and whatever the collective library
+        # left in the C stdio buffer (its version banner) has been flushed
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(final_line, flush=True)
 
 
 if __name__ == '__main__':

@@ -81,6 +81,22 @@ def test_cli_database_cache_matches_reference_jplace(tmp_path):
         assert_prow(g['p'][0], w['p'][0], ctx='database %s' % w['n'][0])
 
 
+def test_bench_gather_through_librccl_without_torch():
+    """bench.py --gather rccl: the multi-rank code path with the end-of-run gather as one grouped
+    ncclSend/ncclRecv through ctypes (apples_amd/rccl.py), no PyTorch in the process; one rank, one GPU."""
+    env = dict(os.environ, APPLES_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', RANK='0', LOCAL_RANK='0',
+               WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--workload', 'small',"
+            " '--no-cpu', '--gather', 'rccl']\n"
+            "runpy.run_path(%r, run_name='__main__')\n"
+            "assert 'torch' not in sys.modules, 'PyTorch was imported'\n" % os.path.join(ROOT, 'bench.py'))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and 'librccl' in line['config']['gather']
+    assert r.stdout.strip().splitlines()[-1].startswith('{')  # the JSON line is the last thing on stdout
+
+
 @pytest.mark.parametrize('scaling', ['weak', 'strong'])
 def test_bench_multi_rank_path_on_one_gpu(scaling):
     """bench.py's multi-rank path (process group over RCCL, zero-copy view of the device-resident
