@@ -14,8 +14,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c
 cp $(ls $OUT/stats_c2/*/*kernel_stats.csv | head -1) $OUT/c2_kernel_stats.csv
 cd $R
 for W in c3 c2; do
-  Q=""; [ $W = c3 ] && Q="--queries 30000"
-  bash scripts/pmc_traffic_passes.sh $TAG/pmc_$W --workload $W $Q --steps 2 --warmup 1 > /dev/null 2>&1
+  # (the whole workload: the launch shape -- queries per device batch -- must be the bench's own)
+  bash scripts/pmc_traffic_passes.sh $TAG/pmc_$W --workload $W --steps 1 --warmup 1 > /dev/null 2>&1
   python scripts/pmc_to_traffic.py gpurun_out/$TAG/pmc_$W $W $OUT/pmc_traffic.json > /dev/null
 done
 python - <<PY
