@@ -268,6 +268,7 @@ struct SelectArgs {
     // row stride rep_stride; member rows are read row-major, the query's words from its packed tile
     const uint4 *packed_rm; const uint4 *qpacked; int G; int L; double overlap; int64_t rep_stride;
     double *tmp_d;            // [nq][stride] member distances before the ordered emission
+    int flat_pref;            // k_select_fast: the segment counts' prefix fits LDS (set by the launcher)
 };
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq);

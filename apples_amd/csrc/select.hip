@@ -331,9 +331,25 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     const int32_t *sslot = a.seg_slot + q * a.stride;
     const double *sd = a.dist + q * a.stride;
     const int self = a.self_slot ? a.self_slot[q] : -1;
-    int c = 0;
-    for (int64_t s = tid; s < n_seg; s += APPLES_TPB) c += cnt[s];
-    const int total = block_sum(c, sh_i);
+    // Rows of up to 16 384 segments (a million references): the exclusive prefix of the segment counts goes to
+    // LDS once, and the survivors are then walked as one flat list -- four rounds of loads for a thousand
+    // survivors instead of one per 256-segment chunk.  Longer rows take the chunked loop below.
+    extern __shared__ int dyn_pref[];
+    const bool flat = a.flat_pref != 0;
+    int total;
+    if (flat) {
+        const int K = (int)((n_seg + APPLES_TPB - 1) / APPLES_TPB);
+        const int64_t s_lo = (int64_t)tid * K, s_hi = s_lo + K < n_seg ? s_lo + K : n_seg;
+        int local = 0;
+        for (int64_t s = s_lo; s < s_hi; ++s) { const int v = cnt[s]; dyn_pref[s] = local; local += v; }
+        const int at = block_excl_scan_int(local, sh_i, &total);
+        for (int64_t s = s_lo; s < s_hi; ++s) dyn_pref[s] += at;
+        if (tid == 0) dyn_pref[n_seg] = total;
+    } else {
+        int c = 0;
+        for (int64_t s = tid; s < n_seg; s += APPLES_TPB) c += cnt[s];
+        total = block_sum(c, sh_i);
+    }
     if (total < a.baseobs) {
         if (tid == 0) {
             a.slow_list[atomicAdd(a.slow_count, 1)] = (int32_t)q;
@@ -346,6 +362,47 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
     int base = 0, n_total = 0;
     int z_i = 0x7fffffff, z_node = -2;
+    // one survivor: entry `off` of segment `seg` -> (slot, distance), own row dropped, first zero noted
+    auto take = [&](int64_t seg, int off, int &node, double &d) -> int {
+        const int64_t src = seg * 64 + off;
+        int slot = sslot[src];
+        if (a.seg_lut) {  // the matrix-core distance pass leaves position | valid | mism; same table, same bits
+            const uint32_t pk = (uint32_t)slot;
+            const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
+            slot = (int)(seg * 64 + (pk >> 26));
+            d = a.seg_lut[valid * (valid + 1) / 2 + mism];
+        } else {
+            d = sd[src];
+        }
+        if (slot == self) return 0;
+        ++n_total;
+        node = a.slot_node[slot];
+        if (d == 0) {
+            const int ri = a.slot_rep[slot];
+            if (ri < z_i) { z_i = ri; z_node = node; }
+        }
+        return node >= 0;
+    };
+    if (flat) {
+        __syncthreads();
+        for (int e0 = 0; e0 < total; e0 += APPLES_TPB) {
+            const int e = e0 + tid;
+            int emit = 0, node = -1;
+            double d = 0;
+            if (e < total) {
+                int64_t lo = 0, hi = n_seg + 1;  // last segment whose prefix <= e (empty segments share a prefix: the last one wins, and holds e)
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (dyn_pref[mid] <= e) lo = mid; else hi = mid;
+                }
+                emit = take(lo, e - dyn_pref[lo], node, d);
+            }
+            int tot;
+            const int pos = base + block_excl_scan(emit, sh_j, &tot);
+            if (emit) { o_node[pos] = node; o_dist[pos] = d; }
+            base += tot;
+        }
+    } else {
     for (int64_t s0 = 0; s0 < n_seg; s0 += APPLES_TPB) {
         const int64_t s = s0 + tid;
         const int my = s < n_seg ? cnt[s] : 0;
@@ -365,25 +422,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
                     int mid = (lo + hi) >> 1;
                     if (sh_pref[mid] <= e) lo = mid; else hi = mid;
                 }
-                const int64_t src = (s0 + lo) * 64 + (e - sh_pref[lo]);
-                int slot = sslot[src];
-                if (a.seg_lut) {  // the matrix-core distance pass leaves position | valid | mism; same table, same bits
-                    const uint32_t pk = (uint32_t)slot;
-                    const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
-                    slot = (int)((s0 + lo) * 64 + (pk >> 26));
-                    d = a.seg_lut[valid * (valid + 1) / 2 + mism];
-                } else {
-                    d = sd[src];
-                }
-                if (slot != self) {
-                    ++n_total;
-                    node = a.slot_node[slot];
-                    if (d == 0) {
-                        const int ri = a.slot_rep[slot];
-                        if (ri < z_i) { z_i = ri; z_node = node; }
-                    }
-                    emit = node >= 0;
-                }
+                emit = take(s0 + lo, e - sh_pref[lo], node, d);
             }
             int tot;
             const int pos = base + block_excl_scan(emit, sh_j, &tot);
@@ -391,6 +430,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
             base += tot;
         }
         __syncthreads();
+    }
     }
     n_total = block_sum(n_total, sh_i);
     double zd = 0; int zi = z_i, zp = 0;
@@ -657,7 +697,11 @@ int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const in
 
 int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
-    hipLaunchKernelGGL(k_select_fast, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
+    SelectArgs b = a;
+    const int64_t n_seg = a.stride >> 6;
+    b.flat_pref = n_seg <= 16384 ? 1 : 0;
+    hipLaunchKernelGGL(k_select_fast, dim3((unsigned)nq), dim3(APPLES_TPB), b.flat_pref ? (size_t)(n_seg + 1) * sizeof(int) : 0,
+                       ctx->stream, b);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
