@@ -875,6 +875,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     }
     hipEvent_t *ev = ctx->ev_pool.data() + 2;
     hipEvent_t e_start = ctx->ev_pool[0], e_stop = ctx->ev_pool[1];
+    if (n_sub == 0) feed = nullptr;  // an empty block: nothing to upload, nothing to place
     if (feed) {
         while (ctx->ev_feed.size() < (size_t)n_sub) {
             hipEvent_t e;

@@ -308,3 +308,16 @@ def test_scoredist_fused_threshold_compaction_equals_full_rows(thr, b):
     for f in ('error', 'distal', 'pendant'):
         np.testing.assert_allclose(got[f], want[f], rtol=1e-9, atol=1e-15, err_msg=f)
     assert got[3]['flags'] & F_EXACT and got[4]['flags'] & F_INSUFFICIENT
+
+
+def test_empty_query_block():
+    d = synth.make_dataset(300, 64, 4)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    none = np.zeros((0, 64), np.uint8)
+    assert len(eng.place_sequences(none)) == 0
+    h, n = eng.place_sequences_streamed(none)
+    assert n == 0 and len(eng.fetch(h, 0)) == 0
+    eng.free_queries(h)
+    assert len(eng.place_sequences(d.query_seqs)) == 4
+    eng.close()
