@@ -272,5 +272,14 @@ def reestimate_backbone(options):
     with open(out_fp, 'w') as f:
         f.write(text.strip() + '\n')
     options.tree_fp = out_fp
+    options.reestimate_tmp_dir = tmp  # the caller removes it once the tree is read (cleanup())
     logging.info('[%s] Reestimated branch lengths in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))
     return True
+
+
+def cleanup(options):
+    """Remove the temporary directory of :func:`reestimate_backbone` (tree files, FastTree log)."""
+    tmp = getattr(options, 'reestimate_tmp_dir', None)
+    if tmp and os.path.isdir(tmp):
+        shutil.rmtree(tmp, ignore_errors=True)
+        options.reestimate_tmp_dir = None

@@ -39,9 +39,11 @@ def main(argv=None):
     if not options.output_fp:
         raise ValueError('No output path provided by user.')
     if not options.disable_reestimation:  # build_applesdtb.py -> prepareTree (apples/prepareTree.py:20-21)
-        from apples_amd.reestimate import reestimate_backbone
+        from apples_amd.reestimate import cleanup, reestimate_backbone
         reestimate_backbone(options)
     tree = read_tree(options.tree_fp)
+    if not options.disable_reestimation:
+        cleanup(options)
     newick = extended_newick(tree)
     ref = read_alignment(options.ref_fp, options.protein_seqs, False)
     if options.clusters_fp:

@@ -49,11 +49,14 @@ def main(argv=None):
     if options.tree_fp:  # the user's tree wins over the database's (run_apples.py:37-38)
         if options.reestimate_backbone:  # apples/prepareTree.py:20-21 (off with -D and with -d)
             if options.ref_fp:
-                from apples_amd.reestimate import reestimate_backbone
+                from apples_amd.reestimate import cleanup, reestimate_backbone
                 reestimate_backbone(options)  # rewrites options.tree_fp when a FastTree executable exists
             else:
+                cleanup = None
                 logging.warning('Backbone branch lengths are used as given: reestimation needs the reference alignment (-s).')
         tree = read_tree(options.tree_fp)
+        if options.reestimate_backbone and options.ref_fp and not options.debug_mode:
+            cleanup(options)  # (--debug keeps the resolved tree, FastTree's log and its answer)
         newick = extended_newick(tree)
         logging.info('[%s] Tree is parsed and preprocessed in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - start))
 
