@@ -194,6 +194,19 @@ def mrca(root, leaves):
     return best
 
 
+def flatten(root):
+    """(nodes, parent, children): nodes in preorder, parent[v] (-1 at the root), children[v] lists in file order."""
+    nodes, index, st = [], {}, [root]
+    while st:
+        v = st.pop()
+        index[id(v)] = len(nodes)
+        nodes.append(v)
+        st.extend(reversed(v.children))
+    parent = [index[id(v.parent)] if v.parent is not None else -1 for v in nodes]
+    children = [[index[id(c)] for c in v.children] for v in nodes]
+    return nodes, parent, children
+
+
 def find_fasttree(explicit=None):
     for cand in (explicit, os.environ.get('APPLES_FASTTREE')):
         if cand:

@@ -1,0 +1,127 @@
+"""CPU restatement of FastTree's minimum-evolution branch lengths on a fixed topology.  TEST INFRASTRUCTURE ONLY.
+
+What the reference obtains from ``FastTree -nosupport -nome -noml -intree tree [-nt] < ref.fa``
+(apples/reestimateBackbone.py:82-84).  FastTree 2.1.11 is a third-party binary that the reference bundles
+(apples/tools/FastTree-linux) and whose source is not in the reference tree; this restates its published
+algorithm (Price, Dehal, Arkin: FastTree 2, PLoS ONE 2010, "profiles", "log-corrected distances",
+balanced minimum-evolution branch lengths):
+
+* a leaf's profile: per site a weight (1, or 0 for a gap / any symbol outside ACGT (U = T) / the 20 amino acids,
+  either case) and a frequency vector;
+* an internal node's profile: the mean of its two children's, site weights averaged, frequencies weighted by them;
+* the "up" profile of a node: everything not below it = mean of its sibling's profile and its parent's up profile
+  (children of a trifurcating root: the mean of the other two);
+* distance between two profiles: sum over sites of w1 w2 d / sum of w1 w2, with d the mismatch probability
+  (nucleotides) or the BLOSUM45-derived dissimilarity f1' D f2 (proteins; the table of apples/distance.py:12-415,
+  which is FastTree's), then log-corrected: -3/4 ln(1 - 4d/3) or -1.3 ln(1 - d);
+* branch of a leaf A with neighbours B, C: (d_AB + d_AC - d_BC) / 2; internal branch with children A1, A2 on one
+  side and B, C on the other: (d_A1B + d_A1C + d_A2B + d_A2C) / 4 - (d_A1A2 + d_BC) / 2.  Negative values stay.
+
+Pinned by ``tests/golden/g9_fasttree_*``: outputs of the bundled binary run in the build container
+(``tests/golden/make_goldens.py g9``); this restatement agrees with every printed length to the print's last
+digit (<= 5.1e-6).  FastTree collapses identical sequences and rearranges them; this does not (topology kept).
+"""
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BLOSUM45 = np.loadtxt(os.path.join(os.path.dirname(_HERE), 'apples_amd', 'data', 'blosum45_dist.txt')).reshape(20, 20)
+NT = b'ACGT'
+AA = b'ARNDCQEGHILKMFPSTWYV'
+
+
+def leaf_profile(seq, protein):
+    alpha = AA if protein else NT
+    code = np.full(256, -1)
+    for i, c in enumerate(alpha):
+        code[c] = i
+        code[ord(chr(c).lower())] = i
+    if not protein:
+        code[ord('U')] = code[ord('u')] = 3
+    c = code[np.asarray(seq, np.uint8)]
+    ok = c >= 0
+    f = np.zeros((len(c), len(alpha)))
+    f[np.nonzero(ok)[0], c[ok]] = 1.0
+    return ok.astype(np.float64), f
+
+
+def _avg(p1, p2):
+    w1, f1 = p1
+    w2, f2 = p2
+    w = 0.5 * w1 + 0.5 * w2
+    f = f1 * (0.5 * w1)[:, None] + f2 * (0.5 * w2)[:, None]
+    nz = w > 0
+    f[nz] /= w[nz, None]
+    return w, f
+
+
+def branch_lengths(n_nodes, parent, children, leaf_seq, protein):
+    """parent[v] (-1 root), children[v] (lists, file order), leaf_seq[v] (bytes-like for leaves, None otherwise).
+    Every internal node has two children, the root two or three.  Returns float64[n_nodes]: the branch above every
+    node (root: 0); for a two-child root both children carry the length of the ONE edge between them."""
+    D = BLOSUM45 if protein else None
+
+    def dist(p1, p2):
+        ww = p1[0] * p2[0]
+        den = ww.sum()
+        if den <= 0:
+            return 3.0
+        d = ((p1[1] @ D) * p2[1]).sum(1) if D is not None else 1.0 - (p1[1] * p2[1]).sum(1)
+        d = float((ww * d).sum() / den)
+        if protein:
+            return -1.3 * np.log(1 - min(d, 0.9))
+        return -0.75 * np.log(1 - 4 * min(d, 0.74) / 3)
+
+    root = [v for v in range(n_nodes) if parent[v] < 0][0]
+    order, st = [], [root]
+    while st:
+        v = st.pop()
+        order.append(v)
+        st.extend(children[v])
+    prof = {}
+    for v in reversed(order):
+        if not children[v]:
+            prof[v] = leaf_profile(leaf_seq[v], protein)
+        elif len(children[v]) == 2:
+            prof[v] = _avg(prof[children[v][0]], prof[children[v][1]])
+    binroot = len(children[root]) == 2
+    up = {}
+
+    def others(v):
+        p = parent[v]
+        sib = [c for c in children[p] if c != v]
+        if p == root:
+            if binroot:
+                s = sib[0]
+                return (prof[children[s][0]], prof[children[s][1]]) if children[s] else None
+            return prof[sib[0]], prof[sib[1]]
+        return prof[sib[0]], up_of(p)
+
+    def up_of(v):
+        if v not in up:
+            o = others(v)
+            up[v] = _avg(o[0], o[1]) if o is not None else prof[[c for c in children[parent[v]] if c != v][0]]
+        return up[v]
+
+    out = np.zeros(n_nodes)
+    for v in order:  # parents first: up profiles exist when needed
+        if v == root:
+            continue
+        o = others(v)
+        if o is None:
+            continue  # two-child root whose other child is a leaf: that leaf's own entry is the edge
+        B, C = o
+        if not children[v]:
+            A = prof[v]
+            out[v] = (dist(A, B) + dist(A, C) - dist(B, C)) / 2
+        else:
+            A1, A2 = prof[children[v][0]], prof[children[v][1]]
+            out[v] = (dist(A1, B) + dist(A1, C) + dist(A2, B) + dist(A2, C)) / 4 - (dist(A1, A2) + dist(B, C)) / 2
+    if binroot:
+        a, b = children[root]
+        if not children[a] and children[b]:
+            out[b] = out[a]
+        elif not children[b] and children[a]:
+            out[a] = out[b]
+    return out

@@ -471,6 +471,37 @@ def g8():
        rename={sup: 'superset_ref.fa', ext: 'extended_ref.fa'})
 
 
+def g9():
+    """Branch lengths of the FastTree binary the reference bundles (apples/tools/FastTree-linux, FastTree 2.1.11)
+    run as the reference runs it (apples/reestimateBackbone.py:82-84): pins oracle/fasttree_me.py and the HIP
+    estimator.  Fixtures: the binary's Newick output for data/backbone.nwk + data/ref.fa, for a rooted synthetic
+    nucleotide set with odd symbols and heavy gaps, and for a rooted synthetic protein set (inputs are
+    regenerated from seeds by the tests)."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    from fasttree_cases import fasttree_case, fasttree_cases
+    ft = os.path.join(REF, 'apples', 'tools', 'FastTree-linux')
+    tmp = tempfile.mkdtemp()
+
+    def run(tree_fp, fasta_fp, protein, out_name):
+        cmd = [ft, '-nosupport', '-nome', '-noml', '-intree', tree_fp] + ([] if protein else ['-nt'])
+        with open(fasta_fp) as f:
+            p = subprocess.run(cmd, stdin=f, capture_output=True, check=True)
+        with open(os.path.join(HERE, out_name), 'w') as o:
+            o.write(p.stdout.decode().strip() + '\n')
+
+    run(os.path.join(DATA, 'backbone.nwk'), os.path.join(DATA, 'ref.fa'), False, 'g9_fasttree_data.nwk')
+    for name, (n, L, protein, seed, odd) in fasttree_cases().items():
+        d, seqs = fasttree_case(n, L, protein, seed, odd)
+        tfp, ffp = os.path.join(tmp, name + '.nwk'), os.path.join(tmp, name + '.fa')
+        open(tfp, 'w').write(d.newick + '\n')
+        with open(ffp, 'w') as f:
+            for nm, sq in zip(d.ref_names, seqs):
+                f.write('>%s\n%s\n' % (nm, bytes(sq).decode()))
+        run(tfp, ffp, protein, 'g9_fasttree_%s.nwk' % name)
+
+
 def g7(runs=None, rename=None):
     """Run the reference's own run_apples.py end to end (treeswift stand-in registered above, and
     a stub TreeCluster.py on PATH that labels every leaf '-1' = all-singleton clusters)."""
@@ -539,7 +570,7 @@ def g7(runs=None, rename=None):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
     for w in which:
         print('generating', w, flush=True)
         globals()[w]()
