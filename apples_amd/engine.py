@@ -24,7 +24,8 @@ PLACEMENT_DTYPE = np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'),
 EXPORTS = ['apples_ctx_create', 'apples_ctx_destroy', 'apples_last_error', 'apples_set_params', 'apples_distances',
            'apples_place_from_sequences', 'apples_place_from_distances', 'apples_sweep_edges', 'apples_place_sequences_streamed',
            'apples_queries_upload', 'apples_table_upload', 'apples_queries_free', 'apples_place_resident', 'apples_fetch_placements',
-           'apples_distances_resident', 'apples_placements_device_ptr', 'apples_last_timing', 'apples_describe']
+           'apples_distances_resident', 'apples_placements_device_ptr', 'apples_last_timing', 'apples_describe',
+           'apples_backbone_lengths']
 
 
 class _Tree(C.Structure):
@@ -79,6 +80,8 @@ def load_library():
     lib.apples_distances_resident.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     lib.apples_placements_device_ptr.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     lib.apples_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.apples_backbone_lengths.argtypes = [C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_void_p]
     _lib = lib
     return lib
 
@@ -101,6 +104,28 @@ def jc69_lut(length, overlap_frac):
         pos = ok & ~zero & ~(0 >= loc)
         out[zero] = 0.0
         out[pos] = -0.75 * np.log(loc[pos])
+    return out
+
+
+def backbone_lengths(parent, children, leaf_row, rows, protein, device=0, site_chunk=0):
+    """Minimum-evolution branch lengths of a fixed topology on the GPU (apples_backbone_lengths; what the
+    reference gets from FastTree, apples/reestimateBackbone.py:82-84).  parent[v] (-1 root), children[v] lists,
+    leaf_row[v] row of `rows` (uint8 [n_rows, L], FASTA bytes) for leaves.  Returns float64[n_nodes]."""
+    lib = load_library()
+    n = len(parent)
+    par = np.ascontiguousarray(parent, dtype=np.int32)
+    off = np.zeros(n + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(c) for c in children])
+    idx = np.ascontiguousarray([c for cs in children for c in cs], dtype=np.int32)
+    lrow = np.ascontiguousarray(leaf_row, dtype=np.int32)
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    if rows.ndim != 2:
+        raise ValueError('rows must be a [n_rows, L] byte matrix')
+    out = np.zeros(n, dtype=np.float64)
+    rc = lib.apples_backbone_lengths(int(device), n, _ptr(par), _ptr(off), _ptr(idx), _ptr(lrow), _ptr(rows), rows.shape[0],
+                                     rows.shape[1], int(bool(protein)), int(site_chunk), _ptr(out))
+    if rc != 0:
+        raise RuntimeError(lib.apples_last_error(None).decode())
     return out
 
 

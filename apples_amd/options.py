@@ -23,8 +23,7 @@ def build_parser():
     p.add_option('-f', '--filter', dest='filt_threshold', type=float, default=0.2, metavar='NUMBER',
                  help='ignores distances higher than the given threshold')
     p.add_option('-D', '--disable-reestimation', dest='disable_reestimation', action='store_true', default=False,
-                 help='disables branch length reestimation of the backbone tree (without a FastTree executable -- '
-                      '--fasttree, $APPLES_FASTTREE or PATH -- the tree is taken as given anyway)')
+                 help='disables branch length reestimation of the backbone tree')
     p.add_option('--debug', dest='debug_mode', action='store_true', default=False, help='Enables debug mode.')
     p.add_option('-v', '--version', dest='print_version', action='store_true', default=False,
                  help='print version number')
@@ -57,7 +56,8 @@ def build_parser():
                  help='every reference sequence is its own cluster (no reduced reference)')
     p.add_option('--fasttree', dest='fasttree_fp', metavar='FILE',
                  help='FastTree executable for the backbone branch length reestimation (the reference bundles one; '
-                      'this build looks for $APPLES_FASTTREE, then FastTree on PATH)')
+                      'this build looks for $APPLES_FASTTREE, then FastTree on PATH, and without one -- or with '
+                      '"native" -- estimates the same minimum-evolution lengths on the GPU)')
     p.add_option('--gpus', dest='num_gpus', type=int, default=1, metavar='NUMBER',
                  help='number of MI355X devices to shard the queries over (0 = all visible)')
     return p

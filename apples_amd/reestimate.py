@@ -3,12 +3,16 @@
 The reference resolves polytomies, hands the topology to FastTree (``-nosupport -nome -noml -intree``,
 reestimateBackbone.py:82-84: branch lengths by FastTree's distance-based minimum-evolution estimates, JC69 or
 BLOSUM45 corrected), re-roots FastTree's unrooted answer where the input was rooted (:91-111) and places
-on that tree.  It ships FastTree as a prebuilt third-party binary; this build does not (and does not
-restate FastTree): the executable is looked up -- ``--fasttree``, ``$APPLES_FASTTREE``, then ``FastTree``,
-``FastTree-linux``, ``fasttree`` on PATH -- and when there is none the tree is used as given, which is the
-reference's ``-D``, with a message saying so.
+on that tree.  It ships FastTree as a prebuilt third-party binary; this build does not.  An executable is
+looked up -- ``--fasttree``, ``$APPLES_FASTTREE``, then ``FastTree``, ``FastTree-linux``, ``fasttree`` on PATH
+-- and used exactly as the reference uses it; when there is none (or with ``--fasttree native``) the lengths
+come from this build's own estimator on the GPU (``apples_backbone_lengths``, csrc/backbone_me.hip: FastTree's
+profile-based balanced minimum-evolution lengths, equal to the binary's output to its five printed decimals
+-- tests/golden/g9_*).  The native path keeps the input topology, child order and rooting as they are: the
+root edge gets the one estimated length split in the input's proportion (:103-110), and identical sequences
+are not collapsed (FastTree joins them under zero-length branches, rearranging the tree).
 
-Everything around the external call is this module's own: the mutable tree, ``suppress_unifurcations``,
+Everything around the estimator is this module's own: the mutable tree, ``suppress_unifurcations``,
 ``resolve_polytomies`` (treeswift's scheme as remembered: the last two children are joined under a new
 zero-length node until two remain -- parity unpinned, treeswift is absent here as it is in the survey),
 Newick out, re-rooting on the edge that separated the input root's two sides with the new length split in
@@ -208,6 +212,9 @@ def flatten(root):
 
 
 def find_fasttree(explicit=None):
+    """Path of the FastTree executable to run, or None for this build's own estimator."""
+    if explicit == 'native' or (not explicit and os.environ.get('APPLES_FASTTREE') == 'native'):
+        return None
     for cand in (explicit, os.environ.get('APPLES_FASTTREE')):
         if cand:
             if os.path.isfile(cand) and os.access(cand, os.X_OK):
@@ -220,15 +227,51 @@ def find_fasttree(explicit=None):
     return None
 
 
+def _read_rows(ref_fp, labels):
+    """Byte matrix [len(labels), L] of the FASTA's own characters for the given sequence names."""
+    import numpy as np
+    from .fasta import read_records
+    want = {x: i for i, x in enumerate(labels)}
+    rows, length = [None] * len(labels), None
+    with open(ref_fp) as f:
+        for name, seq in read_records(f):
+            i = want.get(name)
+            if i is None:
+                continue
+            if length is None:
+                length = len(seq)
+            elif len(seq) != length:
+                raise ValueError('Sequence %s has length %d, the alignment has %d columns' % (name, len(seq), length))
+            rows[i] = np.frombuffer(seq.encode('latin-1'), dtype=np.uint8)
+    missing = [x for x, r in zip(labels, rows) if r is None]
+    if missing:
+        raise ValueError('%d backbone leaves have no sequence in %s (first: %s)' % (len(missing), ref_fp, missing[0]))
+    return np.stack(rows)
+
+
+def native_lengths(root, ref_fp, protein, device=0):
+    """Sets every branch of `root` (binary below the root, two or three children at it) to this build's
+    minimum-evolution estimate, rounded to FastTree's five printed decimals.  A two-child root: the one estimate
+    goes on the first child, 0 on the second (the caller splits it)."""
+    from . import engine
+    nodes, parent, children = flatten(root)
+    leaves = [v for v in range(len(nodes)) if not children[v]]
+    rows = _read_rows(ref_fp, [nodes[v].label for v in leaves])
+    leaf_row = [-1] * len(nodes)
+    for i, v in enumerate(leaves):
+        leaf_row[v] = i
+    got = engine.backbone_lengths(parent, children, leaf_row, rows, protein, device)
+    for v, nd in enumerate(nodes):
+        nd.length = float('%.5f' % got[v]) if parent[v] >= 0 else None
+    if len(root.children) == 2:
+        root.children[1].length = 0.0
+
+
 def reestimate_backbone(options):
     """apples/reestimateBackbone.py:22-118.  Rewrites ``options.tree_fp`` to a temporary Newick file with
-    re-estimated branch lengths and returns True; returns False (tree used as given) without FastTree."""
+    re-estimated branch lengths and returns True."""
     assert options.ref_fp
     exe = find_fasttree(getattr(options, 'fasttree_fp', None))
-    if exe is None:
-        logging.warning('Backbone branch lengths are used as given: no FastTree executable found (--fasttree, '
-                        '$APPLES_FASTTREE or FastTree on PATH); this is what -D does.')
-        return False
     start = time.time()
     with open(options.tree_fp) as f:
         root = from_newick(f.read())
@@ -255,32 +298,44 @@ def reestimate_backbone(options):
         else:
             two, one, len_two, len_one = [c.first_leaf().label for c in right.children], left.first_leaf().label, right.length, left.length
     tmp = tempfile.mkdtemp(prefix='apples_bb_')
-    resolved_fp = os.path.join(tmp, 'resolved.nwk')
-    with open(resolved_fp, 'w') as f:
-        f.write(to_newick(root) + '\n')
-    log_fp = os.path.join(tmp, 'fasttree.log')
-    logging.info('FastTree log file is located here: %s' % log_fp)
-    cmd = [exe, '-nosupport', '-nome', '-noml', '-log', log_fp, '-intree', resolved_fp]
-    if not options.protein_seqs:
-        cmd.append('-nt')
-    with open(options.ref_fp) as rf:
-        p = subprocess.run(cmd, stdin=rf, stdout=subprocess.PIPE, stderr=sys.stderr)
-    if p.returncode != 0:
-        raise RuntimeError('FastTree failed with exit code %d (log: %s)' % (p.returncode, log_fp))
-    text = p.stdout.decode('utf-8').strip()
-    if restore:  # match the rooting of FastTree's output to the input tree (:91-111)
-        ft = from_newick(text)
-        by_label = {x.label: x for x in ft.leaves()}
-        ft = reroot(ft, by_label[one], None)
-        m = mrca(ft, [by_label[x] for x in two])
-        m_len = m.length
-        ft = reroot(ft, m, m_len / 2 if m_len is not None else None)
-        if m_len is not None and len_two + len_one > 0:
-            for i in range(2):
-                if ft.children[i] is m:
-                    ft.children[i].length = m_len * len_two / (len_two + len_one)
-                    ft.children[1 - i].length = m_len * len_one / (len_two + len_one)
-        text = to_newick(ft)
+    if exe is None:
+        if len(root.children) == 2:
+            in_len = [c.length for c in root.children]
+        native_lengths(root, options.ref_fp, options.protein_seqs, getattr(options, 'device', 0))
+        if len(root.children) == 2:  # one estimate for the root edge, split as the input had it (:103-110)
+            m_len = root.children[0].length
+            share = in_len[0] / (in_len[0] + in_len[1]) if restore and in_len[0] + in_len[1] > 0 else 0.5
+            root.children[0].length = m_len * share
+            root.children[1].length = m_len * (1 - share)
+        text = to_newick(root)
+        logging.info('Backbone branch lengths estimated on the GPU (no FastTree executable in use).')
+    else:
+        resolved_fp = os.path.join(tmp, 'resolved.nwk')
+        with open(resolved_fp, 'w') as f:
+            f.write(to_newick(root) + '\n')
+        log_fp = os.path.join(tmp, 'fasttree.log')
+        logging.info('FastTree log file is located here: %s' % log_fp)
+        cmd = [exe, '-nosupport', '-nome', '-noml', '-log', log_fp, '-intree', resolved_fp]
+        if not options.protein_seqs:
+            cmd.append('-nt')
+        with open(options.ref_fp) as rf:
+            p = subprocess.run(cmd, stdin=rf, stdout=subprocess.PIPE, stderr=sys.stderr)
+        if p.returncode != 0:
+            raise RuntimeError('FastTree failed with exit code %d (log: %s)' % (p.returncode, log_fp))
+        text = p.stdout.decode('utf-8').strip()
+        if restore:  # match the rooting of FastTree's output to the input tree (:91-111)
+            ft = from_newick(text)
+            by_label = {x.label: x for x in ft.leaves()}
+            ft = reroot(ft, by_label[one], None)
+            m = mrca(ft, [by_label[x] for x in two])
+            m_len = m.length
+            ft = reroot(ft, m, m_len / 2 if m_len is not None else None)
+            if m_len is not None and len_two + len_one > 0:
+                for i in range(2):
+                    if ft.children[i] is m:
+                        ft.children[i].length = m_len * len_two / (len_two + len_one)
+                        ft.children[1 - i].length = m_len * len_one / (len_two + len_one)
+            text = to_newick(ft)
     out_fp = os.path.join(tmp, 'backbone_reestimated.nwk')
     with open(out_fp, 'w') as f:
         f.write(text.strip() + '\n')

@@ -179,6 +179,20 @@ int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n);
 /* Introspection: device name, packed layout, workspace sizes (JSON text, owned by ctx). */
 const char *apples_describe(apples_ctx *ctx);
 
+/* Backbone branch lengths on a fixed topology, no context needed: replaces the external call
+ * `FastTree -nosupport -nome -noml -intree tree [-nt] < ref.fa` (apples/reestimateBackbone.py:82-84) --
+ * balanced minimum-evolution lengths from log-corrected profile distances (nucleotide: -3/4 ln(1 - 4d/3);
+ * protein: BLOSUM45 dissimilarity, -1.3 ln(1 - d)).  The tree as parent[] (-1 at the root) and a CSR of
+ * children; every internal node has two children, the root two or three (resolve_polytomies first, as
+ * reestimateBackbone.py:40-46 does).  leaf_row[v] = row of `rows` ([n_rows x length], the FASTA's own bytes:
+ * either case, U = T, anything outside the alphabet a gap) for leaves, ignored otherwise.  out_len[v] = the
+ * branch above v (0 at the root; a two-child root: both children carry the length of the one edge between
+ * them).  Negative estimates are kept, as FastTree prints them.  site_chunk = 0 sizes the site chunk from free
+ * memory (tests pass a multiple of 64).  Errors: apples_last_error(NULL). */
+int apples_backbone_lengths(int device, int32_t n_nodes, const int32_t *parent, const int32_t *child_off,
+                            const int32_t *child_idx, const int32_t *leaf_row, const uint8_t *rows,
+                            int64_t n_rows, int32_t length, int protein, int64_t site_chunk, double *out_len);
+
 #ifdef __cplusplus
 }
 #endif

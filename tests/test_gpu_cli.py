@@ -181,10 +181,11 @@ def test_worker_with_two_device_entries_matches_one(tmp_path):
     assert r3 == r4 and r3 != r1
 
 
-def test_cli_reestimates_the_backbone_through_an_external_fasttree(tmp_path):
+def test_cli_reestimates_the_backbone(tmp_path):
     """Without -D the reference re-estimates the backbone's branch lengths with FastTree before placing
-    (apples/prepareTree.py:20-21).  Here: a stand-in executable that doubles every length; the placements
-    must be made on the tree it returns, and with no executable at all the run equals -D."""
+    (apples/prepareTree.py:20-21).  Here: a stand-in executable that doubles every length -- the placements
+    must be made on the tree it returns; with no executable the lengths are estimated on the GPU and equal the
+    bundled FastTree's output on the same inputs (tests/golden/g9_fasttree_data.nwk) to its printed digits."""
     import stat
     stub = tmp_path / 'FastTree'
     with open(stub, 'w') as f:
@@ -203,8 +204,13 @@ def test_cli_reestimates_the_backbone_through_an_external_fasttree(tmp_path):
         r = subprocess.run(base + extra + ['-o', str(out)], capture_output=True, text=True, timeout=600, env=e)
         assert r.returncode == 0, r.stderr
         outs[label] = (json.load(open(out)), r.stderr)
-    assert outs['none'][0]['tree'] == outs['D'][0]['tree'] and 'no FastTree executable found' in outs['none'][1]
-    assert outs['none'][0]['placements'] == outs['D'][0]['placements']
+    import re
+    from apples_amd import reestimate as R
+    from test_fasttree_me import GOLD, splits
+    assert outs['none'][0]['tree'] != outs['D'][0]['tree'] and len(outs['none'][0]['placements']) == 10
+    have = splits(R.from_newick(re.sub(r'\{\d+\}', '', outs['none'][0]['tree'])))
+    want = splits(R.from_newick(open(os.path.join(GOLD, 'g9_fasttree_data.nwk')).read()))
+    assert set(have) == set(want) and max(abs(have[k] - want[k]) for k in want) <= 1.01e-5
     assert outs['stub'][0]['tree'] != outs['D'][0]['tree'] and len(outs['stub'][0]['placements']) == 10
     # every branch twice as long and the observed distances unchanged: other optima, same format
     for p in outs['stub'][0]['placements']:

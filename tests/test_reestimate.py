@@ -112,11 +112,10 @@ def test_wrapper_with_a_stand_in_fasttree(tmp_path, monkeypatch):
     open(tree_fp, 'w').write(nw + '\n')
     ref_fp = tmp_path / 'ref.fa'
     open(ref_fp, 'w').write('>t0\nACGT\n')
-    # none found: tree as given
     monkeypatch.setenv('PATH', str(tmp_path / 'nowhere'))
     monkeypatch.delenv('APPLES_FASTTREE', raising=False)
     o = _options(str(tree_fp), str(ref_fp))
-    assert R.reestimate_backbone(o) is False and o.tree_fp == str(tree_fp)
+    assert R.find_fasttree(None) is None and R.find_fasttree('native') is None  # this build's own estimator
     with pytest.raises(ValueError):
         R.find_fasttree(str(tmp_path / 'missing'))
     # found through the environment
@@ -173,3 +172,57 @@ def test_bundled_fasttree_on_a_rooted_tree_keeps_the_root_edge(tmp_path):
     tot_a, tot_b = sum(la.values()), sum(lb)
     for k in kb:  # the new root-edge length is split in the input's proportion (reestimateBackbone.py:103-110)
         assert la[k] / tot_a == pytest.approx(kb[k] / tot_b, rel=1e-9)
+
+
+def test_native_route_of_the_wrapper(tmp_path, monkeypatch):
+    """No FastTree executable: the lengths come from apples_backbone_lengths (here replaced by the oracle, the
+    GPU is not needed for the host logic): topology, child order and rooting stay, the root edge gets ONE
+    estimate split in the input's proportion, lengths carry five decimals, polytomies are resolved first."""
+    from apples_amd import engine
+    from oracle import fasttree_me
+
+    def on_cpu(parent, children, leaf_row, rows, protein, device=0, site_chunk=0):
+        seqs = [rows[r] if r >= 0 else None for r in leaf_row]
+        return fasttree_me.branch_lengths(len(parent), parent, children, seqs, protein)
+
+    monkeypatch.setattr(engine, 'backbone_lengths', on_cpu)
+    monkeypatch.setenv('PATH', str(tmp_path / 'nowhere'))
+    monkeypatch.delenv('APPLES_FASTTREE', raising=False)
+    d = synth.make_dataset(40, 300, 1)
+    nw = d.newick
+    tree_fp, ref_fp = tmp_path / 'bb.nwk', tmp_path / 'ref.fa'
+    open(tree_fp, 'w').write(nw + '\n')
+    with open(ref_fp, 'w') as f:
+        for n, s in zip(d.ref_names, d.ref_seqs):
+            f.write('>%s\n%s\n' % (n, s.tobytes().decode()))
+        f.write('>not_in_tree\n%s\n' % ('A' * 300))
+    o = _options(str(tree_fp), str(ref_fp))
+    assert R.reestimate_backbone(o) is True
+    before, after = R.from_newick(nw), R.from_newick(open(o.tree_fp).read())
+    assert [x.label for x in before.leaves()] == [x.label for x in after.leaves()]  # order kept
+    assert set(_splits(before)) == set(_splits(after)) and len(after.children) == 2
+    lb, la = [c.length for c in before.children], [c.length for c in after.children]
+    assert la[0] / sum(la) == pytest.approx(lb[0] / sum(lb), rel=1e-9)
+    assert round(sum(la), 5) == pytest.approx(sum(la), abs=1e-12)
+    stack = [c for r in after.children for c in r.children]
+    while stack:
+        v = stack.pop()
+        stack.extend(v.children)
+        assert float('%.5f' % v.length) == v.length
+    R.cleanup(o)
+    # a leaf without a sequence is an error, as it is for FastTree
+    open(tree_fp, 'w').write(nw.replace('t3:', 'nobody:') + '\n')
+    o = _options(str(tree_fp), str(ref_fp))
+    with pytest.raises(ValueError, match='no sequence'):
+        R.reestimate_backbone(o)
+    # polytomy: resolved into zero-length joins before the estimate (reestimateBackbone.py:40-46)
+    star = '((a:0.1,b:0.1,c:0.1,d:0.1):0.1,e:0.2,f:0.2);'
+    open(tree_fp, 'w').write(star + '\n')
+    with open(ref_fp, 'w') as f:
+        for n, s in zip('abcdef', ('ACGTACGTAC', 'ACGTACGTAA', 'ACGTACGAAA', 'ACGTAAGAAA', 'TCGTAAGAAT', 'TCTTAAGAAT')):
+            f.write('>%s\n%s\n' % (n, s))
+    o = _options(str(tree_fp), str(ref_fp))
+    assert R.reestimate_backbone(o) is True
+    after = R.from_newick(open(o.tree_fp).read())
+    assert len(after.children) == 3 and sorted(x.label for x in after.leaves()) == list('abcdef')
+    assert all(len(v.children) in (0, 2) for c in after.children for v in [c])
