@@ -2,7 +2,7 @@
 """Builds the APPLES database cache that ``run_apples.py -a`` reads (the reference's
 build_applesdtb.py, flags of apples/OptionsBasic.py:15-70): backbone tree + reference alignment ->
 indexed tree, extended Newick, reduced reference (clusters at 1.2 x -f, consensus representatives).
-Branch lengths are re-estimated first when a FastTree executable is available (apples_amd/reestimate.py)."""
+Branch lengths are re-estimated first unless -D (apples_amd/reestimate.py: FastTree if installed, else the GPU estimator)."""
 import logging
 import sys
 import time

@@ -2,8 +2,8 @@
 """Drop-in for the reference's run_apples.py on its per-query hot path: same flags, same jplace,
 placements computed on MI355X.  -a reads this build's own database cache
 (build_applesdtb.py; the reference's pickles of third-party classes cannot be read).  Backbone branch
-re-estimation runs an external FastTree when one is found (apples_amd/reestimate.py), else the tree is
-taken as given (-D)."""
+re-estimation (off with -D) runs an external FastTree when one is found, else this build's GPU estimator of
+the same minimum-evolution lengths (apples_amd/reestimate.py)."""
 import logging
 import sys
 import time
@@ -50,7 +50,7 @@ def main(argv=None):
         if options.reestimate_backbone:  # apples/prepareTree.py:20-21 (off with -D and with -d)
             if options.ref_fp:
                 from apples_amd.reestimate import cleanup, reestimate_backbone
-                reestimate_backbone(options)  # rewrites options.tree_fp when a FastTree executable exists
+                reestimate_backbone(options)  # rewrites options.tree_fp
             else:
                 cleanup = None
                 logging.warning('Backbone branch lengths are used as given: reestimation needs the reference alignment (-s).')
