@@ -299,7 +299,7 @@ def test_database_cache_round_trip(tmp_path):
     from apples_amd.reference import ReducedReference
     from apples_amd.tree import extended_newick, read_tree
     db = str(tmp_path / 'c1.dtb')
-    build_applesdtb.main(['-s', os.path.join(DATA, 'ref.fa'), '-t', os.path.join(DATA, 'backbone.nwk'), '-o', db, '-f', '0.2'])
+    build_applesdtb.main(['-s', os.path.join(DATA, 'ref.fa'), '-t', os.path.join(DATA, 'backbone.nwk'), '-o', db, '-f', '0.2', '-D'])
     tree, newick, ref, protein, thr = database.load(db)
     t0 = read_tree(os.path.join(DATA, 'backbone.nwk'))
     a0 = read_alignment(os.path.join(DATA, 'ref.fa'), False, False)
