@@ -367,6 +367,12 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
         dev_free(d_exotic);
+        // pre-expanded reference image for the GEMM form of the fused pass (dist_gemm.hip): 2 bytes per site
+        if (a.all_singleton && a.planes == 2 && a.L <= 2047 && dist_mfma_enabled() && !getenv("APPLES_NO_DIST_GEMM")) {
+            if (dev_alloc(ctx, &a.ref_f4, a.slots_pad * (int64_t)a.G * 256)) return 1;
+            if (launch_expand_queries_f4(ctx, a.raw, a.n_rows, a.ref_f4, a.slots_pad, ctx->stream, a.d_slot_row)) return 1;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
         // clustered reference on the ACGT- fast path: panels for the fused selection by representatives
         if (!a.all_singleton && a.planes == 2 && a.n_refs <= SELECT_CLUSTERS_MAX_SLOTS && a.G <= 64 &&
             !getenv("APPLES_NO_CLUSTER_FUSE") && dist_mfma_enabled())
@@ -380,8 +386,9 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
     if (a.planes == 8) return 0;
     int *d_exotic = nullptr;
     if (dev_alloc(ctx, &d_exotic, 1)) return 1;
-    dev_free(a.rep_packed); dev_free(a.packed_rm);  // the clustered fast path is for ACGT- contexts only
+    dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.ref_f4);  // the fast paths are for ACGT- contexts only
     a.rep_packed = a.packed_rm = nullptr;
+    a.ref_f4 = nullptr;
     dev_free(a.packed);
     a.planes = 8;
     int64_t words = (int64_t)a.G * 9 * a.slots_pad;
@@ -1148,7 +1155,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

@@ -79,6 +79,7 @@ struct DevAlign {
     uint8_t *raw = nullptr;       // [n_rows*L] bytes in the caller's row order (kept for lazy repacking)
     int32_t *d_slot_row = nullptr;// [n_rows] slot -> caller's row (the packing kernels gather through it)
     uint4 *packed = nullptr;      // [G][planes+1][slots_pad] uint4 = 4 consecutive 32-site words
+    uint8_t *ref_f4 = nullptr;    // [slots_pad][2G][4][32 B] fp4 operand image of the reference (dist_gemm.hip), ACGT- singleton contexts
     // clustered references (fused selection by representatives, select.hip k_select_clusters):
     uint4 *packed_rm = nullptr;   // [slots_pad][G*3] the same words row-major: one member row = 3*G contiguous uint4
     uint4 *rep_packed = nullptr;  // [G][3][reps_pad] the representatives' rows, in representative order
@@ -281,7 +282,10 @@ int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const in
 bool dist_mfma_enabled();
 bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb);
 int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad,
-                             hipStream_t st = nullptr);
+                             hipStream_t st, const int32_t *d_src_row = nullptr);
+// dist_gemm.hip
+bool dist_gemm_usable(const apples_ctx *ctx);
+int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);
 int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
                         int32_t *seg_slot, int32_t *seg_cnt);
 int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,

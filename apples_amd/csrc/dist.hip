@@ -210,8 +210,10 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 
 // query rows -> fp4 operand image: a 64-site block of a query is 128 bytes, component c (t1, t2, t3,
 // v) at c * 32, its first word's four dwords then its second word's
+// (src_row: row r of the image comes from raw row src_row[r] -- the reference image in slot order)
 __global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_f4(const uint8_t *__restrict__ raw, int64_t n, int L, int NB,
-                                                                  uint32_t *__restrict__ out, int64_t n_pad) {
+                                                                  uint32_t *__restrict__ out, int64_t n_pad,
+                                                                  const int32_t *__restrict__ src_row) {
     const int64_t idx = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;  // one thread per (query, block, word, dword)
     const int64_t total = n_pad * NB * 8;
     if (idx >= total) return;
@@ -221,11 +223,12 @@ __global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_f4(const uint8_t 
     const int64_t q = qb / NB;
     uint32_t t1 = 0, t2 = 0, t3 = 0, v = 0;
     if (q < n) {
+        const int64_t src = src_row ? src_row[q] : q;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int site = (b * 2 + x) * 32 + 4 * i + j;
             if (site >= L) break;
-            const uint32_t c = raw[q * (int64_t)L + site];
+            const uint32_t c = raw[src * (int64_t)L + site];
             if (c == (uint32_t)'-') continue;
             const uint32_t code = (c >> 1) & 3u;  // as k_pack_rows<2>
             v |= 0x2u << (4 * i);
@@ -538,12 +541,12 @@ bool dist_mfma_enabled() {
 }
 
 int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad,
-                             hipStream_t st) {
+                             hipStream_t st, const int32_t *d_src_row) {
     const DevAlign &a = ctx->aln;
     if (!st) st = ctx->stream;
     const int64_t total = n_pad * a.G * 2 * 8;
     hipLaunchKernelGGL(k_expand_queries_f4, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0,
-                       st, d_raw, n, a.L, a.G * 2, reinterpret_cast<uint32_t *>(d_out), n_pad);
+                       st, d_raw, n, a.L, a.G * 2, reinterpret_cast<uint32_t *>(d_out), n_pad, d_src_row);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -630,7 +633,9 @@ int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq,
 int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int tile, double *seg_d,
                         int32_t *seg_slot, int32_t *seg_cnt) {
     if (nq == 0) return 0;
-    if (fused_counts_format(ctx, qb)) return launch_mfma<1>(ctx, qb, q0, nq, seg_d, nullptr, seg_slot, seg_cnt);
+    if (fused_counts_format(ctx, qb))
+        return dist_gemm_usable(ctx) ? launch_counts_gemm(ctx, qb, q0, nq, seg_slot, seg_cnt)
+                                     : launch_mfma<1>(ctx, qb, q0, nq, seg_d, nullptr, seg_slot, seg_cnt);
     if (ctx->aln.planes == 2) launch_jc69_tile<2, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
     else launch_jc69_tile<8, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
     HIP_TRY(ctx, hipGetLastError());

@@ -1,0 +1,186 @@
+// The fused JC69 pass as a plain fp4 GEMM (default for ACGT- inputs, L <= 2047, singleton clusters).
+//
+// Same arithmetic as k_jc69_mfma (dist.hip): every site is a corner of a tetrahedron (components t1, t2, t3 =
+// +-1, 0 for a gap) plus a validity flag v; sum t.t = 3 match - mism and sum v.v = valid.  Differences:
+//   * BOTH operands are kept pre-expanded in HBM (2 bytes per site: the query image as before, the reference
+//     image built once per context, 410 MB at 200 k x 1000), so the kernel has no expansion arithmetic and no
+//     register -> LDS stores at all: the 256 x 128-byte tile images of a 64-site step arrive by LDS-DMA
+//     (global_load_lds_dwordx4), lane-linear in LDS with the 16-byte chunk permutation applied to the lanes'
+//     SOURCE addresses (chunk c of row r sits in slot c ^ ((r >> 1) & 7): conflict-free ds_read_b128);
+//   * ONE accumulator set: the v component is multiplied through the block-scaled MFMA with a scale of 2^13 on
+//     the query side, acc = sum t.t + 8192 valid.  With valid <= 2047 both integers decode exactly
+//     (-valid <= sum t.t <= 3 valid: the ranges of neighbouring `valid` do not overlap, and acc < 2^24);
+//   * which makes room for a 64 x 128 wavefront tile (2 x 4 MFMA tiles, 128 accumulator registers) and a
+//     256 x 256 workgroup tile: 24 fragment reads per 32 MFMAs instead of 16 per 16, half the staging bytes
+//     per MFMA;
+//   * workgroups walk the tile grid in strips of 4 reference tiles per XCD (a strip's 2 MB stay in that XCD's
+//     L2 while the query tiles stream past).
+// Epilogue and output format are those of k_jc69_mfma<1> (threshold on the integers, ballot compaction per
+// 64-slot segment, one packed word per survivor).
+#include "common.h"
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+#define GM_TPB 512
+#define GM_T 256      // tile edge: queries and reference slots per workgroup
+#define GM_STRIP 4    // reference tiles per strip
+#define GM_VSHIFT 13  // the validity sum rides at 2^13
+
+namespace {
+
+__device__ __forceinline__ v16f_t mfma_f4(const v4i_t &a, const v4i_t &b, const v16f_t &c) {
+    const v8i_t a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0, 0, 0);  // fp4 x fp4, unscaled
+}
+
+__device__ __forceinline__ v16f_t mfma_f4_v(const v4i_t &a, const v4i_t &b, const v16f_t &c) {
+    const v8i_t a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    // E8M0 scales: 127 + 13 on the first operand, 127 (= 1.0) on the second
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 127 + GM_VSHIFT, 0, 127);
+}
+
+__global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict__ rf4, const uint8_t *__restrict__ qf4,
+                                                      int64_t slots_pad, int NB, int64_t nq, int L, int TQ, int TR,
+                                                      int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
+                                                      const int32_t *__restrict__ mmax) {
+    __shared__ __attribute__((aligned(1024))) uint8_t Aq[2][GM_T * 128];  // query rows of the tile, one 64-site step
+    __shared__ __attribute__((aligned(1024))) uint8_t Br[2][GM_T * 128];  // reference slots of the tile
+    __shared__ float mm_lds[2048];
+    // tile of this workgroup: workgroup ids go round the XCDs; XCD x takes the strips x, x + 8, ...
+    const int xcd = blockIdx.x & 7;
+    const int64_t loc = blockIdx.x >> 3;
+    const int64_t per_strip = (int64_t)TQ * GM_STRIP;
+    const int64_t strip = (loc / per_strip) * 8 + xcd;
+    const int64_t within = loc % per_strip;
+    const int64_t rt = strip * GM_STRIP + within % GM_STRIP, qt = within / GM_STRIP;
+    if (rt >= TR) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wq = wv >> 1, wr = wv & 1;
+    const int64_t r0 = rt * GM_T, q0 = qt * GM_T;
+    for (int i = tid; i < 2048; i += GM_TPB) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
+    // DMA roles: piece k of this wavefront fills rows (wv * 4 + k) * 8 .. + 7 of an image; lane l lands in row
+    // l >> 3, slot l & 7 and fetches chunk (l & 7) ^ ((row >> 1) & 7) of that row
+    int doff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = (wv * 4 + k) * 8 + (lane >> 3);
+        doff[k] = row * NB * 128 + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    const uint8_t *qtile = qf4 + q0 * (int64_t)NB * 128, *rtile = rf4 + r0 * (int64_t)NB * 128;
+    auto dma = [&](int b) {  // step b -> generation b & 1
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qtile + doff[k] + b * 128),
+                                             (__attribute__((address_space(3))) void *)(Aq[b & 1] + (wv * 4 + k) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rtile + doff[k] + b * 128),
+                                             (__attribute__((address_space(3))) void *)(Br[b & 1] + (wv * 4 + k) * 1024), 16, 0, 0);
+        }
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    int coff[4];  // byte offset of component c's chunk for this lane's row parity and K half
+#pragma unroll
+    for (int c = 0; c < 4; ++c) coff[c] = ((c * 2 + fh) ^ ((fr >> 1) & 7)) * 16;
+    const int arow = (wq * 64 + fr) * 128, brow = (wr * 128 + fr) * 128;
+    v16f_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+    v4i_t fa[2][2], fb[2][4];
+    auto load_frags = [&](int b, int c, int set) {
+        const uint8_t *A = Aq[b & 1] + arow + coff[c], *B = Br[b & 1] + brow + coff[c];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const v4i_t *>(A + i * 32 * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const v4i_t *>(B + j * 32 * 128);
+    };
+    dma(0);
+    __syncthreads();  // (drains the DMA: vmcnt(0) before the barrier)
+    for (int b = 0; b < NB; ++b) {
+        load_frags(b, 0, 0);
+        if (b + 1 < NB) dma(b + 1);  // into the image every wavefront finished reading before the last barrier
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < 3) load_frags(b, c + 1, (c + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = c < 3 ? mfma_f4(fa[c & 1][i], fb[c & 1][j], acc[i][j]) : mfma_f4_v(fa[c & 1][i], fb[c & 1][j], acc[i][j]);
+        }
+        __syncthreads();  // step b + 1 has landed everywhere, step b's image is free
+    }
+    // C layout of the 32x32 tiles: column (reference slot) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    // acc = sum t.t + 8192 valid, so valid = floor((acc + 2047) / 8192) and 4 mism = 3 valid - sum t.t = 8195 valid - acc,
+    // every step exact in f32; the test is mism <= mmax[valid] as 4 mism <= 4 mmax[valid] (-4 where nothing passes).
+    const int64_t n_seg = slots_pad >> 6;
+    const uint32_t below = (1u << fr) - 1u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t qbase = q0 + wq * 64 + i * 32 + 4 * fh;  // this lane half's first query of the 32
+        // (rows past this launch's queries may be real queries of the next sub-batch: not ours to write)
+        const int rem = (int)(nq - qbase < 32 ? nq - qbase : 32);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t keepbits = 0;
+#pragma unroll
+            for (int x = 0; x < 16; ++x)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float S = acc[i][2 * s + j][x];
+                    const float valid = __builtin_floorf((S + 2047.f) * (1.f / 8192.f));
+                    const float mism4 = __builtin_fmaf(valid, 8195.f, -S);
+                    keepbits |= (mism4 <= mm_lds[(int)valid] ? 1u : 0u) << (x * 2 + j);
+                }
+            if (__ballot(keepbits != 0) == 0ull) continue;  // no survivor among these 32 queries x 64 slots
+            const int64_t seg = (r0 + wr * 128 + s * 64) >> 6;
+            int32_t *row0 = seg_slot + qbase * slots_pad + seg * 64;
+            int32_t *cnt0 = seg_cnt + qbase * n_seg + seg;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const int cx = (x & 3) + 8 * (x >> 2);  // this register's query, relative to qbase
+                const bool in = cx < rem;
+                const bool k0 = ((keepbits >> (x * 2)) & 1u) && in, k1 = ((keepbits >> (x * 2 + 1)) & 1u) && in;
+                const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
+                if ((b0 | b1) == 0) continue;  // the counts stay at their preset zero
+                const uint32_t lo = (uint32_t)(b0 >> (32 * fh)), hi = (uint32_t)(b1 >> (32 * fh));
+                int32_t *row = row0 + (int64_t)cx * slots_pad;
+                if (k0) {
+                    const float S = acc[i][2 * s][x];
+                    const int valid = (int)__builtin_floorf((S + 2047.f) * (1.f / 8192.f));
+                    const int mism = (8195 * valid - (int)S) >> 2;
+                    row[__popc(lo & below)] = (int32_t)(((uint32_t)fr << 26) | ((uint32_t)valid << 13) | (uint32_t)mism);
+                }
+                if (k1) {
+                    const float S = acc[i][2 * s + 1][x];
+                    const int valid = (int)__builtin_floorf((S + 2047.f) * (1.f / 8192.f));
+                    const int mism = (8195 * valid - (int)S) >> 2;
+                    row[__popc(lo) + __popc(hi & below)] = (int32_t)(((uint32_t)(32 + fr) << 26) | ((uint32_t)valid << 13) | (uint32_t)mism);
+                }
+                if (fr == 0 && in) cnt0[(int64_t)cx * n_seg] = __popc(lo) + __popc(hi);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool dist_gemm_usable(const apples_ctx *ctx) {
+    static const bool off = getenv("APPLES_NO_DIST_GEMM") != nullptr;  // diagnostic knob: the bit-plane-fed MFMA kernel instead
+    return !off && ctx->aln.ref_f4 && ctx->aln.L <= 2047;
+}
+
+int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt) {
+    const DevAlign &a = ctx->aln;
+    const int TQ = (int)((nq + GM_T - 1) / GM_T), TR = (int)(a.slots_pad / GM_T);
+    const int64_t strips = (TR + GM_STRIP - 1) / GM_STRIP;
+    const int64_t grid = 8 * ((strips + 7) / 8) * (int64_t)TQ * GM_STRIP;
+    hipLaunchKernelGGL(k_jc69_gemm, dim3((unsigned)grid), dim3(GM_TPB), 0, ctx->stream, a.ref_f4,
+                       qb.qf4 + q0 * (int64_t)a.G * 256, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt, ctx->jc_mmax);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
