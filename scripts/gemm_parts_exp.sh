@@ -1,0 +1,9 @@
+# What the GEMM-form distance kernel spends its time on: leave one part out at a time (results are garbage,
+# only the distance pass's time is meaningful).
+one() { timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu --workload c3 --timed resident 2>&1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['roofline']['per_kernel_ms_per_step']['dist_ms'])"; }
+for flags in "" "-DGM_SKIP_EPILOGUE" "-DGM_SKIP_EPILOGUE -DGM_NO_DMA" "-DGM_SKIP_EPILOGUE -DGM_NO_FRAGS" "-DGM_SKIP_EPILOGUE -DGM_NO_DMA -DGM_NO_FRAGS"; do
+  rm -f apples_amd/csrc/dist_gemm.o
+  APPLES_EXTRA_HIPCC_FLAGS="$flags" python -m apples_amd.build > /dev/null 2>&1 || { echo "build failed: $flags"; continue; }
+  echo "== [$flags] $(one)"
+done
+rm -f apples_amd/csrc/dist_gemm.o; python -m apples_amd.build > /dev/null 2>&1
