@@ -1,5 +1,6 @@
 // C ABI of libapples_hip.so: context, uploads, batch driver, timing.  See include/apples_hip.h.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -368,7 +369,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         }
         dev_free(d_exotic);
         // pre-expanded reference image for the GEMM form of the fused pass (dist_gemm.hip): 2 bytes per site
-        if (a.all_singleton && a.planes == 2 && a.L <= 2047 && dist_mfma_enabled() && !getenv("APPLES_NO_DIST_GEMM")) {
+        if (a.all_singleton && a.planes == 2 && a.L <= GEMM_MAX_L && dist_mfma_enabled() && !getenv("APPLES_NO_DIST_GEMM")) {
             if (dev_alloc(ctx, &a.ref_f4, a.slots_pad * (int64_t)a.G * 256)) return 1;
             if (launch_expand_queries_f4(ctx, a.raw, a.n_rows, a.ref_f4, a.slots_pad, ctx->stream, a.d_slot_row)) return 1;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1089,6 +1090,39 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
     return 0;
 }
 
+// mmax[valid] as a linear rule in float arithmetic for dist_gemm.hip's epilogue: from the first valid count that
+// admits anything, mmax[valid] = floor(p_f valid) with p_f = 3/4 (1 - exp(-4 f / 3)); the kernel evaluates
+// t = fmaf(8192 valid, slope, off) and keeps 4 mism <= t.  A candidate (slope, off) is accepted only if it
+// reproduces the table for EVERY valid count: 4 mmax <= t < 4 mmax + 4.
+static GemmThreshold gemm_threshold(const std::vector<int32_t> &mmax, double f) {
+    GemmThreshold g;
+    const int L = (int)mmax.size() - 1;
+    if (L > GEMM_MAX_L) return g;
+    int vmin = 0;
+    while (vmin <= L && mmax[vmin] < 0) ++vmin;
+    for (int v = vmin; v <= L; ++v)
+        if (mmax[v] < 0) return g;
+    const double pf = 0.75 * (1.0 - std::exp(-4.0 * f / 3.0));
+    const float s0 = (float)(4.0 * pf / 8192.0);
+    const float offs[] = {0.f, 0.0005f, -0.0005f, 0.001f, -0.001f, 0.002f, -0.002f, 0.004f, -0.004f};
+    for (int ds = 0; ds < 5; ++ds) {
+        float slope = s0;
+        for (int k = 0; k < (ds + 1) / 2; ++k) slope = std::nextafterf(slope, (ds & 1) ? 1.f : -1.f);
+        for (float off : offs) {
+            bool good = true;
+            for (int v = vmin; v <= L && good; ++v) {
+                const float t = std::fmaf(8192.f * (float)v, slope, off);
+                good = 4.f * (float)mmax[v] <= t && t < 4.f * (float)mmax[v] + 4.f;
+            }
+            if (good) {
+                g.slope = slope; g.off = off; g.vmin8 = 8192.f * (float)vmin; g.ok = true;
+                return g;
+            }
+        }
+    }
+    return g;
+}
+
 int apples_set_params(apples_ctx *ctx, const apples_params *params) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));  // the caller's thread may have another device current
     int model = ctx->params.model;
@@ -1105,6 +1139,7 @@ int apples_set_params(apples_ctx *ctx, const apples_params *params) {
         ctx->jc_lut_len = params->jc_lut_len;
         dev_free(ctx->jc_mmax);
         ctx->jc_mmax = nullptr;
+        ctx->gemm_thr = GemmThreshold();
         if (ctx->has_aln) {  // integer form of 0 <= d <= threshold, valid only if the table is monotone in mism
             std::vector<int32_t> mmax(L + 1, -1);
             bool monotone = true;
@@ -1118,6 +1153,7 @@ int apples_set_params(apples_ctx *ctx, const apples_params *params) {
                 mmax[v] = last;
             }
             if (monotone && dev_upload(ctx, &ctx->jc_mmax, mmax.data(), L + 1)) return 1;
+            ctx->gemm_thr = monotone ? gemm_threshold(mmax, params->filt_threshold) : GemmThreshold();
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     } else {
@@ -1126,6 +1162,7 @@ int apples_set_params(apples_ctx *ctx, const apples_params *params) {
         ctx->jc_lut_len = 0;
         dev_free(ctx->jc_mmax);
         ctx->jc_mmax = nullptr;
+        ctx->gemm_thr = GemmThreshold();
     }
     return 0;
 }

@@ -70,6 +70,14 @@ struct DevTree {
 // reference rows sorted by tree level, deepest first (rows that are not tree leaves last);
 // consensus slots follow.  Sorting by level lets the selection kernel's ordered compaction
 // hand the sweep kernel its leaves already grouped by level.
+// threshold of the GEMM-form distance pass as a linear function of the valid count (dist_gemm.hip): 4 mism <=
+// slope * (8192 valid) + off and 8192 valid >= vmin8 <=> mism <= mmax[valid], verified for every valid in [0, L]
+struct GemmThreshold {
+    float slope = 0.f, off = 0.f, vmin8 = 0.f;
+    bool ok = false;
+};
+#define GEMM_MAX_L 2046  // the merged accumulator decodes exactly while valid <= 2046
+
 struct DevAlign {
     int64_t n_rows = 0, n_refs = 0, n_reps = 0;
     int64_t slots_pad = 0;  // n_rows rounded up to a multiple of APPLES_TPB
@@ -183,6 +191,7 @@ struct apples_ctx {
     bool has_aln = false;
     double *jc_lut = nullptr;
     int64_t jc_lut_len = 0;
+    GemmThreshold gemm_thr;
     int32_t *jc_mmax = nullptr;  // [L+1] largest mismatch count with 0 <= lut <= threshold, per valid count
     double *blosum = nullptr;  // 21x21 table (row/col 20 = gap -> 0)
     Workspace ws;

@@ -22,6 +22,7 @@
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 
 #define GM_TPB 512
 #define GM_T 256      // tile edge: queries and reference slots per workgroup
@@ -41,10 +42,11 @@ __device__ __forceinline__ v16f_t mfma_f4_v(const v4i_t &a, const v4i_t &b, cons
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 127 + GM_VSHIFT, 0, 127);
 }
 
+template <bool LIN>
 __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict__ rf4, const uint8_t *__restrict__ qf4,
                                                       int64_t slots_pad, int NB, int64_t nq, int L, int TQ, int TR,
                                                       int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
-                                                      const int32_t *__restrict__ mmax) {
+                                                      const int32_t *__restrict__ mmax, GemmThreshold lin) {
     // ONE LDS object (the compiler's alias analysis then sees constant, disjoint ranges and does not drain the DMA
     // queue before unrelated reads): per generation g the 256 query rows of one 64-site step at g * 64 KB, the 256
     // reference slots 32 KB further; the threshold table behind both generations
@@ -63,7 +65,8 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = wv >> 1, wr = wv & 1;
     const int64_t r0 = rt * GM_T, q0 = qt * GM_T;
-    for (int i = tid; i < 2048; i += GM_TPB) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
+    if (!LIN)
+        for (int i = tid; i < 2048; i += GM_TPB) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
     // DMA roles: piece k of this wavefront fills rows (wv * 4 + k) * 8 .. + 7 of an image; lane l lands in row
     // l >> 3, slot l & 7 and fetches chunk (l & 7) ^ ((row >> 1) & 7) of that row
     int doff[4];
@@ -186,10 +189,62 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     }
 #endif
     // C layout of the 32x32 tiles: column (reference slot) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-    // acc = sum t.t + 8192 valid, so valid = floor((acc + 2047) / 8192) and 4 mism = 3 valid - sum t.t = 8195 valid - acc,
-    // every step exact in f32; the test is mism <= mmax[valid] as 4 mism <= 4 mmax[valid] (-4 where nothing passes).
+    // acc = sum t.t + 8192 valid.  Decoding, every step exact in f32: 8192 valid = ((acc - 2049) + 2^36) - 2^36 (the
+    // sum rounds to the nearest multiple of 8192; acc + 2047 is never a multiple of 8192 while valid <= 2046),
+    // 4 mism = 3 valid - sum t.t = 8195 valid - acc.  The test mism <= mmax[valid]: LIN -- mmax[valid] =
+    // floor(p_f valid) from valid = vmin on, evaluated as 4 mism <= slope * 8192 valid + off with constants the
+    // host verified against the table for every valid (api.hip gemm_threshold), two elements per packed
+    // instruction and the compare's lane mask used as it is; otherwise through the table in LDS (-4 where
+    // nothing passes).
     const int64_t n_seg = slots_pad >> 6;
     const uint32_t below = (1u << fr) - 1u;
+    if (LIN) {
+        const v2f_t kA = {-2049.f, -2049.f}, kC = {68719476736.f, 68719476736.f}, kM = {8195.f / 8192.f, 8195.f / 8192.f};
+        const v2f_t kS = {lin.slope, lin.slope}, kO = {lin.off, lin.off};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t qbase = q0 + wq * 64 + i * 32 + 4 * fh;  // this lane half's first query of the 32
+            // (rows past this launch's queries may be real queries of the next sub-batch: not ours to write)
+            const int rem = (int)(nq - qbase < 32 ? nq - qbase : 32);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int64_t seg = (r0 + wr * 128 + s * 64) >> 6;
+                int32_t *row0 = seg_slot + qbase * slots_pad + seg * 64;
+                int32_t *cnt0 = seg_cnt + qbase * n_seg + seg;
+#pragma unroll
+                for (int xp = 0; xp < 8; ++xp) {
+                    const v2f_t S0 = {acc[i][2 * s][2 * xp], acc[i][2 * s][2 * xp + 1]};
+                    const v2f_t S1 = {acc[i][2 * s + 1][2 * xp], acc[i][2 * s + 1][2 * xp + 1]};
+                    const v2f_t v0 = ((S0 + kA) + kC) - kC, v1 = ((S1 + kA) + kC) - kC;  // 8192 valid
+                    const v2f_t m0 = __builtin_elementwise_fma(v0, kM, -S0), m1 = __builtin_elementwise_fma(v1, kM, -S1);  // 4 mism
+                    const v2f_t t0 = __builtin_elementwise_fma(v0, kS, kO), t1 = __builtin_elementwise_fma(v1, kS, kO);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int x = 2 * xp + e, cx = (x & 3) + 8 * (x >> 2);  // this register's query, relative to qbase
+                        const bool in = cx < rem;
+                        const bool c0 = m0[e] <= t0[e] && in, c1 = m1[e] <= t1[e] && in;
+                        if (__ballot(c0 || c1) == 0ull) continue;
+                        const bool k0 = c0 && v0[e] >= lin.vmin8, k1 = c1 && v1[e] >= lin.vmin8;
+                        const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
+                        if ((b0 | b1) == 0) continue;  // the counts stay at their preset zero
+                        // this lane half's query: slots 0..31 of the segment from tile 0, 32..63 from tile 1
+                        const uint32_t lo = (uint32_t)(b0 >> (32 * fh)), hi = (uint32_t)(b1 >> (32 * fh));
+                        int32_t *row = row0 + (int64_t)cx * slots_pad;
+                        if (k0) {
+                            const int valid = (int)(v0[e] * (1.f / 8192.f)), mism = (int)m0[e] >> 2;
+                            row[__popc(lo & below)] = (int32_t)(((uint32_t)fr << 26) | ((uint32_t)valid << 13) | (uint32_t)mism);
+                        }
+                        if (k1) {
+                            const int valid = (int)(v1[e] * (1.f / 8192.f)), mism = (int)m1[e] >> 2;
+                            row[__popc(lo) + __popc(hi & below)] = (int32_t)(((uint32_t)(32 + fr) << 26) | ((uint32_t)valid << 13) | (uint32_t)mism);
+                        }
+                        if (fr == 0 && in) cnt0[(int64_t)cx * n_seg] = __popc(lo) + __popc(hi);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int64_t qbase = q0 + wq * 64 + i * 32 + 4 * fh;  // this lane half's first query of the 32
@@ -242,7 +297,7 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
 
 bool dist_gemm_usable(const apples_ctx *ctx) {
     static const bool off = getenv("APPLES_NO_DIST_GEMM") != nullptr;  // diagnostic knob: the bit-plane-fed MFMA kernel instead
-    return !off && ctx->aln.ref_f4 && ctx->aln.L <= 2047;
+    return !off && ctx->aln.ref_f4 && ctx->aln.L <= GEMM_MAX_L;
 }
 
 int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt) {
@@ -250,8 +305,15 @@ int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
     const int TQ = (int)((nq + GM_T - 1) / GM_T), TR = (int)(a.slots_pad / GM_T);
     const int64_t strips = (TR + GM_STRIP - 1) / GM_STRIP;
     const int64_t grid = 8 * ((strips + 7) / 8) * (int64_t)TQ * GM_STRIP;
-    hipLaunchKernelGGL(k_jc69_gemm, dim3((unsigned)grid), dim3(GM_TPB), 0, ctx->stream, a.ref_f4,
-                       qb.qf4 + q0 * (int64_t)a.G * 256, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt, ctx->jc_mmax);
+    static const bool table = getenv("APPLES_GEMM_TABLE") != nullptr;  // diagnostic knob: threshold through the LDS table
+    if (ctx->gemm_thr.ok && !table)
+        hipLaunchKernelGGL(k_jc69_gemm<true>, dim3((unsigned)grid), dim3(GM_TPB), 0, ctx->stream, a.ref_f4,
+                           qb.qf4 + q0 * (int64_t)a.G * 256, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt, ctx->jc_mmax,
+                           ctx->gemm_thr);
+    else
+        hipLaunchKernelGGL(k_jc69_gemm<false>, dim3((unsigned)grid), dim3(GM_TPB), 0, ctx->stream, a.ref_f4,
+                           qb.qf4 + q0 * (int64_t)a.G * 256, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt, ctx->jc_mmax,
+                           ctx->gemm_thr);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
