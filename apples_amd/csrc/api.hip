@@ -370,7 +370,8 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         dev_free(d_exotic);
         // pre-expanded reference image for the GEMM form of the fused pass (dist_gemm.hip): 2 bytes per site
         if (a.all_singleton && a.planes == 2 && a.L <= GEMM_MAX_L && dist_mfma_enabled() && !getenv("APPLES_NO_DIST_GEMM")) {
-            if (dev_alloc(ctx, &a.ref_f4, a.slots_pad * (int64_t)a.G * 256)) return 1;
+            // (the image's own allocation marks the context's fp4 images as compact: 96 bytes per 64-site block)
+            if (dev_alloc(ctx, &a.ref_f4, a.slots_pad * (int64_t)a.G * 192)) return 1;
             if (launch_expand_queries_f4(ctx, a.raw, a.n_rows, a.ref_f4, a.slots_pad, ctx->stream, a.d_slot_row)) return 1;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
@@ -646,7 +647,8 @@ int fill_block(apples_ctx *ctx, QueryBlock *qb, const uint8_t *queries, int64_t 
     if (qb->qf4) {
         const int64_t n128 = round_up(qb->n_pad, 256) + 256;
         const bool last = q0 + nq >= qb->n;  // the last chunk also zeroes the image's padding rows
-        if (launch_expand_queries_f4(ctx, qb->raw + q0 * a.L, nq, qb->qf4 + q0 * (int64_t)a.G * 256, last ? n128 - q0 : nq, st)) return 1;
+        const int64_t row_bytes = (int64_t)a.G * (a.ref_f4 ? 192 : 256);  // compact images beside a reference image
+        if (launch_expand_queries_f4(ctx, qb->raw + q0 * a.L, nq, qb->qf4 + q0 * row_bytes, last ? n128 - q0 : nq, st)) return 1;
     }
     return 0;
 }

@@ -213,7 +213,7 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 // (src_row: row r of the image comes from raw row src_row[r] -- the reference image in slot order)
 __global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_f4(const uint8_t *__restrict__ raw, int64_t n, int L, int NB,
                                                                   uint32_t *__restrict__ out, int64_t n_pad,
-                                                                  const int32_t *__restrict__ src_row) {
+                                                                  const int32_t *__restrict__ src_row, int compact) {
     const int64_t idx = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;  // one thread per (query, block, word, dword)
     const int64_t total = n_pad * NB * 8;
     if (idx >= total) return;
@@ -237,8 +237,10 @@ __global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_f4(const uint8_t 
             t3 |= (0x2u | ((((code >> 1) ^ code) & 1u) << 3)) << (4 * i);
         }
     }
-    uint32_t *o = out + qb * 32 + x * 4 + j;
-    o[0] = t1; o[8] = t2; o[16] = t3; o[24] = v;
+    // compact: 96 bytes per block, no validity component (dist_gemm.hip derives it from t1)
+    uint32_t *o = out + qb * (compact ? 24 : 32) + x * 4 + j;
+    o[0] = t1; o[8] = t2; o[16] = t3;
+    if (!compact) o[24] = v;
 }
 
 // One thread expands 16 sites of one reference row (dwords 2*(quarter&1), +1 of one 32-site word: the
@@ -546,7 +548,7 @@ int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, u
     if (!st) st = ctx->stream;
     const int64_t total = n_pad * a.G * 2 * 8;
     hipLaunchKernelGGL(k_expand_queries_f4, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0,
-                       st, d_raw, n, a.L, a.G * 2, reinterpret_cast<uint32_t *>(d_out), n_pad, d_src_row);
+                       st, d_raw, n, a.L, a.G * 2, reinterpret_cast<uint32_t *>(d_out), n_pad, d_src_row, a.ref_f4 != nullptr ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -621,7 +623,7 @@ int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq,
     // Full rows stay with the bit-plane kernel: with 8 bytes out per pair and a table lookup per pair the
     // matrix-core form is slower here (0.64 against 0.58 ms at C2 size).  APPLES_DIST_MFMA_ROWS=1 routes
     // tiles of 16 and more queries to it anyway (tests compare its counts with the bytewise definition).
-    if (qb.qf4 && ctx->aln.planes == 2 && tile >= 16 && getenv("APPLES_DIST_MFMA_ROWS"))
+    if (qb.qf4 && !ctx->aln.ref_f4 && ctx->aln.planes == 2 && tile >= 16 && getenv("APPLES_DIST_MFMA_ROWS"))
         return launch_mfma<0>(ctx, qb, q0, nq, d_dist, d_counts, nullptr, nullptr);
     if (ctx->aln.planes == 2) launch_jc69_tile<2, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     else launch_jc69_tile<8, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);

@@ -2,11 +2,12 @@
 //
 // Same arithmetic as k_jc69_mfma (dist.hip): every site is a corner of a tetrahedron (components t1, t2, t3 =
 // +-1, 0 for a gap) plus a validity flag v; sum t.t = 3 match - mism and sum v.v = valid.  Differences:
-//   * BOTH operands are kept pre-expanded in HBM (2 bytes per site: the query image as before, the reference
-//     image built once per context, 410 MB at 200 k x 1000), so the kernel has no expansion arithmetic and no
-//     register -> LDS stores at all: the 256 x 128-byte tile images of a 64-site step arrive by LDS-DMA
-//     (global_load_lds_dwordx4), lane-linear in LDS with the 16-byte chunk permutation applied to the lanes'
-//     SOURCE addresses (chunk c of row r sits in slot c ^ ((r >> 1) & 7): conflict-free ds_read_b128);
+//   * BOTH operands are kept pre-expanded in HBM (1.5 bytes per site: t1, t2, t3 only -- the validity operand is
+//     t1 with the sign bits cleared, one v_and per fragment register; the reference image is built once per
+//     context, 307 MB at 200 k x 1000), so the kernel has no expansion arithmetic and no register -> LDS stores at
+//     all: the 256 x 96-byte tile images of a 64-site step arrive by LDS-DMA (global_load_lds_dwordx4), lane-
+//     linear in LDS with a chunk permutation applied to the lanes' SOURCE addresses (conflict-free
+//     ds_read_b128), three generations deep: the DMA runs two steps ahead of the MFMAs;
 //   * ONE accumulator set: the v component is multiplied through the block-scaled MFMA with a scale of 2^13 on
 //     the query side, acc = sum t.t + 8192 valid.  With valid <= 2047 both integers decode exactly
 //     (-valid <= sum t.t <= 3 valid: the ranges of neighbouring `valid` do not overlap, and acc < 2^24);
@@ -28,6 +29,7 @@ typedef float v2f_t __attribute__((ext_vector_type(2)));
 #define GM_T 256      // tile edge: queries and reference slots per workgroup
 #define GM_STRIP 4    // reference tiles per strip
 #define GM_VSHIFT 13  // the validity sum rides at 2^13
+#define GM_GEN (2 * GM_T * 96)  // LDS bytes of one generation: query and reference image of one step
 
 namespace {
 
@@ -42,18 +44,20 @@ __device__ __forceinline__ v16f_t mfma_f4_v(const v4i_t &a, const v4i_t &b, cons
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 127 + GM_VSHIFT, 0, 127);
 }
 
-template <bool LIN>
+// R = (NB - 2) % 3: the shape of the main loop's tail, fixed per launch (a run-time choice between the three tails
+// merges 128 accumulator registers three ways and the kernel spills)
+template <bool LIN, int R>
 __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict__ rf4, const uint8_t *__restrict__ qf4,
                                                       int64_t slots_pad, int NB, int64_t nq, int L, int TQ, int TR,
                                                       int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
                                                       const int32_t *__restrict__ mmax, GemmThreshold lin) {
     // ONE LDS object (the compiler's alias analysis then sees constant, disjoint ranges and does not drain the DMA
-    // queue before unrelated reads): per generation g the 256 query rows of one 64-site step at g * 64 KB, the 256
-    // reference slots 32 KB further; the threshold table behind both generations
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 2 * GM_T * 128 + 2048 * 4];
-#define Aq(g) (lds + (g) * 65536)
-#define Br(g) (lds + (g) * 65536 + 32768)
-    float *mm_lds = reinterpret_cast<float *>(lds + 131072);
+    // queue before unrelated reads): three generations of 48 KB -- the 256 query rows of one 64-site step (96
+    // bytes each: t1, t2, t3), the 256 reference slots 24 KB further -- and the threshold table behind them
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[3 * GM_GEN + 2048 * 4];
+#define Aq(g) (lds + (g) * GM_GEN)
+#define Br(g) (lds + (g) * GM_GEN + GM_T * 96)
+    float *mm_lds = reinterpret_cast<float *>(lds + 3 * GM_GEN);
     // tile of this workgroup: workgroup ids go round the XCDs; XCD x takes the strips x, x + 8, ...
     const int xcd = blockIdx.x & 7;
     const int64_t loc = blockIdx.x >> 3;
@@ -67,20 +71,21 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     const int64_t r0 = rt * GM_T, q0 = qt * GM_T;
     if (!LIN)
         for (int i = tid; i < 2048; i += GM_TPB) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
-    // DMA roles: piece k of this wavefront fills rows (wv * 4 + k) * 8 .. + 7 of an image; lane l lands in row
-    // l >> 3, slot l & 7 and fetches chunk (l & 7) ^ ((row >> 1) & 7) of that row
-    int doff[4];
+    // DMA roles: an image is 1536 16-byte chunks = 24 pieces of 1 KB; this wavefront moves pieces wv * 3 + k.  Lane
+    // l of piece P lands in linear chunk p = 64 P + l = row p / 6, slot p % 6, and fetches chunk slot ^ ((row >> 4)
+    // & 1) of that row: with the 96-byte stride the 16 lanes of a ds_read_b128 group then cover all 16 bank quads.
+    uint32_t doff[3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int row = (wv * 4 + k) * 8 + (lane >> 3);
-        doff[k] = row * NB * 128 + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    for (int k = 0; k < 3; ++k) {
+        const int p = (wv * 3 + k) * 64 + lane, row = p / 6, slot = p - row * 6;
+        doff[k] = (uint32_t)(row * NB * 96 + ((slot ^ ((row >> 4) & 1)) * 16));
     }
-    const uint8_t *qtile = qf4 + q0 * (int64_t)NB * 128, *rtile = rf4 + r0 * (int64_t)NB * 128;
+    const uint8_t *qtile = qf4 + q0 * (int64_t)NB * 96, *rtile = rf4 + r0 * (int64_t)NB * 96;
     const int fr = lane & 31, fh = lane >> 5;
-    int coff[4];  // byte offset of component c's chunk for this lane's row parity and K half
+    int coff[3];  // byte offset of component c's chunk for this lane's row and K half
 #pragma unroll
-    for (int c = 0; c < 4; ++c) coff[c] = ((c * 2 + fh) ^ ((fr >> 1) & 7)) * 16;
-    const int arow = (wq * 64 + fr) * 128, brow = (wr * 128 + fr) * 128;
+    for (int c = 0; c < 3; ++c) coff[c] = ((c * 2 + fh) ^ ((fr >> 4) & 1)) * 16;
+    const int arow = (wq * 64 + fr) * 96, brow = (wr * 128 + fr) * 96;
     v16f_t acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -88,80 +93,98 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
-    // pieces k0 .. k0 + 3 of step b's images -> generation g (pieces 0-3: the query image, 4-7: the reference image)
-    auto dma = [&](int b, int g, int k0) {
+    // pieces k0, k0 + 1 of step b's images -> generation g (pieces 0-2: the query image, 3-5: the reference image)
+    auto dma = [&](int b, int g, int k0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = k0; k < k0 + 4; ++k) {
-            const uint8_t *src = (k < 4 ? qtile : rtile) + doff[k & 3] + b * 128;
-            uint8_t *dst = (k < 4 ? Aq(g) : Br(g)) + (wv * 4 + (k & 3)) * 1024;
+        for (int k = k0; k < k0 + 2; ++k) {
+            const uint8_t *src = ((k < 3 ? qtile : rtile) + b * 96) + doff[k % 3];  // uniform base + 32-bit lane offset
+            uint8_t *dst = (k < 3 ? Aq(g) : Br(g)) + (wv * 3 + k % 3) * 1024;
 #ifndef GM_NO_DMA
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
 #endif
         }
     };
-    v4i_t fa[2][2], fb[2][4];  // two fragment sets: component c uses set c & 1 while c + 1 is being read
-    auto load_frags = [&](int g, int c, int set) {
+    v4i_t fa[3][2], fb[3][4];  // one fragment set per component; set 0 is turned into the validity operand in place
+    auto load_frags = [&](int g, int c) __attribute__((always_inline)) {
 #ifndef GM_NO_FRAGS
         const uint8_t *A = Aq(g) + arow + coff[c], *B = Br(g) + brow + coff[c];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const v4i_t *>(A + i * 32 * 128);
+        for (int i = 0; i < 2; ++i) fa[c][i] = *reinterpret_cast<const v4i_t *>(A + i * 32 * 96);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const v4i_t *>(B + j * 32 * 128);
+        for (int j = 0; j < 4; ++j) fb[c][j] = *reinterpret_cast<const v4i_t *>(B + j * 32 * 96);
 #endif
     };
-    auto mfmas = [&](int c) {
+    auto mfmas = [&](int c, bool valid) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = c < 3 ? mfma_f4(fa[c & 1][i], fb[c & 1][j], acc[i][j]) : mfma_f4_v(fa[c & 1][i], fb[c & 1][j], acc[i][j]);
+                acc[i][j] = valid ? mfma_f4_v(fa[c][i], fb[c][j], acc[i][j]) : mfma_f4(fa[c][i], fb[c][j], acc[i][j]);
     };
-    // One step = 64 sites = 4 components x 8 MFMAs per wavefront, generation g = step & 1.  Entry: set 0 holds
-    // component 0 (read after the previous barrier).  The DMA of step + 1 goes out in the first two component
-    // sections, between the MFMAs; the barrier (with the DMA drained) sits before the last section, whose MFMAs
-    // cover the first fragment reads of the next step.
-    auto step = [&](int b, int g, bool more) {
-        load_frags(g, 1, 1);
-        if (more) dma(b + 1, g ^ 1, 0);
-        mfmas(0);
+    auto strip_signs = [&]() __attribute__((always_inline)) {  // t1 = +-1 or 0 -> v = |t1|: clear the sign bit of every fp4 nibble
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[0][i] &= 0x77777777;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[0][j] &= 0x77777777;
+    };
+    // One step = 64 sites = 4 sections of 8 MFMAs per wavefront (t1, validity, t2, t3), generation g = step % 3.
+    // Entry: set 0 holds t1 (read after the previous barrier).  The DMA of step + 2 goes out two pieces per section
+    // between the MFMAs of the first three sections, into the generation every wavefront left at the previous
+    // barrier; this step's barrier -- before the last section, whose MFMAs cover the first fragment reads of the
+    // next step -- needs step + 1 landed (issued a whole step ago) and lets those six pieces stay in flight.
+    auto step = [&](int b, int g, bool feed, bool more) __attribute__((always_inline)) {
+        const int gn = g == 2 ? 0 : g + 1, gf = g == 0 ? 2 : g - 1;  // next step's generation; the free one
+        load_frags(g, 1);
+        if (feed) dma(b + 2, gf, 0);
+        mfmas(0, false);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (k >= 1 && k < 5) {
+            if (k == 1 || k == 4) {
                 __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(g, 2, 0);
-        if (more) dma(b + 1, g ^ 1, 4);
-        mfmas(1);
+        strip_signs();
+        load_frags(g, 2);
+        if (feed) dma(b + 2, gf, 2);
+        mfmas(0, true);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (k >= 1 && k < 5) {
+            if (k == 2 || k == 5) {
                 __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(g, 3, 1);
-        mfmas(2);
+        if (feed) dma(b + 2, gf, 4);
+        mfmas(1, false);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (k == 1 || k == 4) {
+                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // step b + 1 has landed everywhere (own DMA drained, then the barrier), step b's images are free
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // step b + 1 has landed everywhere (own pieces first, then the barrier); step b's images are free
+#ifdef GM_NO_VMWAIT
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+        if (feed) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (more) load_frags(g ^ 1, 0, 0);
-        mfmas(3);
+        if (more) load_frags(gn, 0);
+        mfmas(2, false);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -169,17 +192,33 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    dma(0, 0, 0);
-    dma(0, 0, 4);
-    __syncthreads();
-    load_frags(0, 0, 0);
+    dma(0, 0, 0); dma(0, 0, 2); dma(0, 0, 4);
+    dma(1, 1, 0); dma(1, 1, 2); dma(1, 1, 4);
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");  // step 0 landed (and the table is written); step 1 stays in flight
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    for (int b = 0; b + 2 < NB; b += 2) {  // NB is even
-        step(b, 0, true);
-        step(b + 1, 1, true);
+    // NB (even, >= 2) steps: NB - 2 feeding ones, then one that only prefetches fragments, then the last
+    const int F = NB - 2;
+    int b = 0;
+    for (; b + 3 <= F; b += 3) {
+        step(b, 0, true, true);
+        step(b + 1, 1, true, true);
+        step(b + 2, 2, true, true);
     }
-    step(NB - 2, 0, true);
-    step(NB - 1, 1, false);
+    if (R == 0) {
+        step(b, 0, false, true);
+        step(b + 1, 1, false, false);
+    } else if (R == 1) {
+        step(b, 0, true, true);
+        step(b + 1, 1, false, true);
+        step(b + 2, 2, false, false);
+    } else {
+        step(b, 0, true, true);
+        step(b + 1, 1, true, true);
+        step(b + 2, 2, false, true);
+        step(b + 3, 0, false, false);
+    }
 #ifdef GM_SKIP_EPILOGUE
     {   // timing experiment: main loop only (every accumulator stays live)
         int a = 0;
@@ -306,14 +345,15 @@ int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
     const int64_t strips = (TR + GM_STRIP - 1) / GM_STRIP;
     const int64_t grid = 8 * ((strips + 7) / 8) * (int64_t)TQ * GM_STRIP;
     static const bool table = getenv("APPLES_GEMM_TABLE") != nullptr;  // diagnostic knob: threshold through the LDS table
-    if (ctx->gemm_thr.ok && !table)
-        hipLaunchKernelGGL(k_jc69_gemm<true>, dim3((unsigned)grid), dim3(GM_TPB), 0, ctx->stream, a.ref_f4,
-                           qb.qf4 + q0 * (int64_t)a.G * 256, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt, ctx->jc_mmax,
-                           ctx->gemm_thr);
-    else
-        hipLaunchKernelGGL(k_jc69_gemm<false>, dim3((unsigned)grid), dim3(GM_TPB), 0, ctx->stream, a.ref_f4,
-                           qb.qf4 + q0 * (int64_t)a.G * 256, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt, ctx->jc_mmax,
-                           ctx->gemm_thr);
+    const bool lin = ctx->gemm_thr.ok && !table;
+    const int R = (a.G * 2 - 2) % 3;
+#define GM_LAUNCH(LIN_, R_)                                                                                          \
+    hipLaunchKernelGGL((k_jc69_gemm<LIN_, R_>), dim3((unsigned)grid), dim3(GM_TPB), 0, ctx->stream, a.ref_f4,        \
+                       qb.qf4 + q0 * (int64_t)a.G * 192, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt,   \
+                       ctx->jc_mmax, ctx->gemm_thr)
+    if (lin) { if (R == 0) GM_LAUNCH(true, 0); else if (R == 1) GM_LAUNCH(true, 1); else GM_LAUNCH(true, 2); }
+    else { if (R == 0) GM_LAUNCH(false, 0); else if (R == 1) GM_LAUNCH(false, 1); else GM_LAUNCH(false, 2); }
+#undef GM_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
