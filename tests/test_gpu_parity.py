@@ -425,6 +425,7 @@ def test_matrix_core_pair_counts_equal_the_bytewise_definition(L, n_ref, n_q, mo
     qry[2] = ref[5]
     tree = read_tree(os.path.join(DATA, 'small_backbone.nwk'))
     monkeypatch.setenv('APPLES_DIST_MFMA_ROWS', '1')  # full rows normally come from the bit-plane kernel
+    monkeypatch.setenv('APPLES_NO_DIST_GEMM', '1')    # (the GEMM form keeps compact images that this kernel does not read)
     e = Engine(tree, ref, np.full(n_ref, -1, np.int32), method='OLS')
     assert e.describe()['code_planes'] == 2
     counts, dist = e.distances(qry)  # >= 16 queries: matrix-core kernel
@@ -436,3 +437,30 @@ def test_matrix_core_pair_counts_equal_the_bytewise_definition(L, n_ref, n_q, mo
     few, _ = e.distances(qry[:7])  # < 16 queries: bit-plane kernel
     assert np.array_equal(few, want[:7])
     e.close()
+
+
+def test_gemm_form_of_the_fused_pass_at_many_lengths():
+    """dist_gemm.hip: every tail shape of its three-generation main loop ((2G - 2) % 3 = 0, 1, 2), the shortest
+    alignment (two 64-site steps), the longest it takes (2046 sites; 2047 goes to the bit-plane-fed kernel), heavy
+    gaps (small valid counts: the overlap rule and the linear threshold's lower end).  Placements must be byte-
+    identical to the bit-plane-fed matrix-core kernel (APPLES_NO_DIST_GEMM), to the table form of the threshold
+    (APPLES_GEMM_TABLE) and to the full-row route (APPLES_NO_FUSE), which share no distance code with it."""
+    import subprocess
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from apples_amd import synth\n"
+            "from apples_amd.engine import Engine\n"
+            "out = []\n"
+            "for L, gap, thr in ((64, 0.05, 0.3), (100, 0.3, 0.2), (300, 0.05, 0.2), (450, 0.5, 0.25), (700, 0.1, 0.15), (900, 0.05, 0.2),\n"
+            "                    (1620, 0.2, 0.2), (2046, 0.05, 0.1), (2047, 0.05, 0.1)):\n"
+            "    d = synth.make_dataset(700, L, 300, gap_rate=gap, seed_tree=L)\n"
+            "    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)\n"
+            "    e = Engine(d.tree, d.ref_seqs, nodes, method='FM', threshold=thr, baseobs=10)\n"
+            "    out.append(e.place_sequences(d.query_seqs).tobytes()); e.close()\n"
+            "sys.stdout.buffer.write(b''.join(out))\n" % ROOT)
+    outs = []
+    for env in ({}, {'APPLES_NO_DIST_GEMM': '1'}, {'APPLES_GEMM_TABLE': '1'}, {'APPLES_NO_FUSE': '1'}):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(r.stdout)
+    assert len(outs[0]) == 9 * 300 * 40
+    assert all(o == outs[0] for o in outs)
