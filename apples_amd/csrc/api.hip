@@ -647,8 +647,9 @@ int fill_block(apples_ctx *ctx, QueryBlock *qb, const uint8_t *queries, int64_t 
     if (qb->qf4) {
         const int64_t n128 = round_up(qb->n_pad, 256) + 256;
         const bool last = q0 + nq >= qb->n;  // the last chunk also zeroes the image's padding rows
-        const int64_t row_bytes = (int64_t)a.G * (a.ref_f4 ? 192 : 256);  // compact images beside a reference image
-        if (launch_expand_queries_f4(ctx, qb->raw + q0 * a.L, nq, qb->qf4 + q0 * row_bytes, last ? n128 - q0 : nq, st)) return 1;
+        if (a.ref_f4) {  // compact, tiled images beside a reference image: addressed by image row
+            if (launch_expand_queries_f4(ctx, qb->raw + q0 * a.L, nq, qb->qf4, last ? n128 - q0 : nq, st, nullptr, q0)) return 1;
+        } else if (launch_expand_queries_f4(ctx, qb->raw + q0 * a.L, nq, qb->qf4 + q0 * (int64_t)a.G * 256, last ? n128 - q0 : nq, st)) return 1;
     }
     return 0;
 }
@@ -875,6 +876,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     int64_t step = pipelined ? std::min<int64_t>(w.batch, want) : w.batch;
     const int64_t n_sub = (qb.n + step - 1) / step;
     if (!pipelined && n_sub > 1) step = std::min(step, round_up((qb.n + n_sub - 1) / n_sub, 32));  // equal sub-batches
+    // (the GEMM-form distance pass reads whole contiguous kilobytes when a sub-batch starts on a 256-row image tile)
+    if (!pipelined && n_sub > 1 && step >= 2048 && dist_gemm_usable(ctx) && round_up(step, 256) <= w.batch) step = round_up(step, 256);
     hipStream_t front = ctx->stream, back = pipelined ? ctx->stream3 : ctx->stream;
     // timing events come from a pool that lives with the context (creating and destroying a dozen
     // events per call costs host time inside every pass)

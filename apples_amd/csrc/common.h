@@ -290,8 +290,10 @@ int launch_build_cluster_panels(apples_ctx *ctx);  // listed queries, needs segm
 int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const int32_t *perm, int64_t nq, int64_t n_cols);
 bool dist_mfma_enabled();
 bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb);
+// (contexts with a reference image keep compact, tiled images: d_out is then the image's base and row0 the image row
+// of d_raw's first row)
 int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad,
-                             hipStream_t st, const int32_t *d_src_row = nullptr);
+                             hipStream_t st, const int32_t *d_src_row = nullptr, int64_t row0 = 0);
 // dist_gemm.hip
 bool dist_gemm_usable(const apples_ctx *ctx);
 int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);

@@ -211,9 +211,14 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 // query rows -> fp4 operand image: a 64-site block of a query is 128 bytes, component c (t1, t2, t3,
 // v) at c * 32, its first word's four dwords then its second word's
 // (src_row: row r of the image comes from raw row src_row[r] -- the reference image in slot order)
+// compact (the images dist_gemm.hip reads): no validity component, and the bytes stored as that kernel's LDS image
+// of a 256-row tile and 64-site step -- image row row0 + q is row rr = (row0 + q) & 255 of tile (row0 + q) >> 8; a
+// tile-step is 1536 16-byte chunks, chunk c (component * 2 + word) of row rr at position 6 rr + (c ^ ((rr >> 4) & 1)):
+// the kernel's DMA pieces are then whole contiguous kilobytes
 __global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_f4(const uint8_t *__restrict__ raw, int64_t n, int L, int NB,
                                                                   uint32_t *__restrict__ out, int64_t n_pad,
-                                                                  const int32_t *__restrict__ src_row, int compact) {
+                                                                  const int32_t *__restrict__ src_row, int compact,
+                                                                  int64_t row0) {
     const int64_t idx = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;  // one thread per (query, block, word, dword)
     const int64_t total = n_pad * NB * 8;
     if (idx >= total) return;
@@ -237,10 +242,15 @@ __global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_f4(const uint8_t 
             t3 |= (0x2u | ((((code >> 1) ^ code) & 1u) << 3)) << (4 * i);
         }
     }
-    // compact: 96 bytes per block, no validity component (dist_gemm.hip derives it from t1)
-    uint32_t *o = out + qb * (compact ? 24 : 32) + x * 4 + j;
-    o[0] = t1; o[8] = t2; o[16] = t3;
-    if (!compact) o[24] = v;
+    if (compact) {
+        const int64_t ar = row0 + q, tile = ar >> 8;
+        const int rr = (int)(ar & 255), sw = (rr >> 4) & 1;
+        uint32_t *o = out + ((tile * NB + b) * 1536 + rr * 6) * 4 + j;
+        o[((0 + x) ^ sw) * 4] = t1; o[((2 + x) ^ sw) * 4] = t2; o[((4 + x) ^ sw) * 4] = t3;
+        return;
+    }
+    uint32_t *o = out + qb * 32 + x * 4 + j;
+    o[0] = t1; o[8] = t2; o[16] = t3; o[24] = v;
 }
 
 // One thread expands 16 sites of one reference row (dwords 2*(quarter&1), +1 of one 32-site word: the
@@ -543,12 +553,12 @@ bool dist_mfma_enabled() {
 }
 
 int launch_expand_queries_f4(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_pad,
-                             hipStream_t st, const int32_t *d_src_row) {
+                             hipStream_t st, const int32_t *d_src_row, int64_t row0) {
     const DevAlign &a = ctx->aln;
     if (!st) st = ctx->stream;
     const int64_t total = n_pad * a.G * 2 * 8;
     hipLaunchKernelGGL(k_expand_queries_f4, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0,
-                       st, d_raw, n, a.L, a.G * 2, reinterpret_cast<uint32_t *>(d_out), n_pad, d_src_row, a.ref_f4 != nullptr ? 1 : 0);
+                       st, d_raw, n, a.L, a.G * 2, reinterpret_cast<uint32_t *>(d_out), n_pad, d_src_row, a.ref_f4 != nullptr ? 1 : 0, row0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -48,7 +48,7 @@ __device__ __forceinline__ v16f_t mfma_f4_v(const v4i_t &a, const v4i_t &b, cons
 // merges 128 accumulator registers three ways and the kernel spills)
 template <bool LIN, int R>
 __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict__ rf4, const uint8_t *__restrict__ qf4,
-                                                      int64_t slots_pad, int NB, int64_t nq, int L, int TQ, int TR,
+                                                      int64_t qrow0, int64_t slots_pad, int NB, int64_t nq, int L, int TQ, int TR,
                                                       int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
                                                       const int32_t *__restrict__ mmax, GemmThreshold lin) {
     // ONE LDS object (the compiler's alias analysis then sees constant, disjoint ranges and does not drain the DMA
@@ -68,19 +68,25 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     if (rt >= TR) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = wv >> 1, wr = wv & 1;
-    const int64_t r0 = rt * GM_T, q0 = qt * GM_T;
+    const int64_t r0 = rt * GM_T, q0 = qt * GM_T;  // (q0: relative to this launch's first query)
     if (!LIN)
         for (int i = tid; i < 2048; i += GM_TPB) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
-    // DMA roles: an image is 1536 16-byte chunks = 24 pieces of 1 KB; this wavefront moves pieces wv * 3 + k.  Lane
-    // l of piece P lands in linear chunk p = 64 P + l = row p / 6, slot p % 6, and fetches chunk slot ^ ((row >> 4)
-    // & 1) of that row: with the 96-byte stride the 16 lanes of a ds_read_b128 group then cover all 16 bank quads.
+    // DMA roles: a tile-step image is 1536 16-byte chunks = 24 pieces of 1 KB, stored in HBM exactly as it lies in
+    // LDS (k_expand_queries_f4, compact form): chunk p = row p / 6, slot p % 6, the slot holding chunk slot ^ ((row
+    // >> 4) & 1) of the row, so that with the 96-byte stride the 16 lanes of a ds_read_b128 group cover all 16 bank
+    // quads.  This wavefront moves pieces wv * 3 + k; lane l of piece P fills chunk 64 P + l.  Reference tiles are
+    // image tiles: whole contiguous kilobytes.  The query tile starts at image row qrow0 + q0, a multiple of 32 (of
+    // 256 for the sub-batches the driver cuts): its rows may lie in two image tiles, same slots.
     uint32_t doff[3];
+    const int64_t qabs = qrow0 + qt * GM_T;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int p = (wv * 3 + k) * 64 + lane, row = p / 6, slot = p - row * 6;
-        doff[k] = (uint32_t)(row * NB * 96 + ((slot ^ ((row >> 4) & 1)) * 16));
+        const int64_t ar = qabs + row;
+        doff[k] = (uint32_t)((((ar >> 8) - (qabs >> 8)) * NB * 1536 + (ar & 255) * 6 + slot) * 16);
     }
-    const uint8_t *qtile = qf4 + q0 * (int64_t)NB * 96, *rtile = rf4 + r0 * (int64_t)NB * 96;
+    const uint32_t roff = (uint32_t)(wv * 3 * 1024 + lane * 16);
+    const uint8_t *qtile = qf4 + (qabs >> 8) * (int64_t)NB * 24576, *rtile = rf4 + rt * (int64_t)NB * 24576;
     const int fr = lane & 31, fh = lane >> 5;
     int coff[3];  // byte offset of component c's chunk for this lane's row and K half
 #pragma unroll
@@ -97,7 +103,8 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     auto dma = [&](int b, int g, int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = k0; k < k0 + 2; ++k) {
-            const uint8_t *src = ((k < 3 ? qtile : rtile) + b * 96) + doff[k % 3];  // uniform base + 32-bit lane offset
+            // uniform base + 32-bit lane offset
+            const uint8_t *src = k < 3 ? (qtile + b * 24576) + doff[k] : (rtile + b * 24576 + (k - 3) * 1024) + roff;
             uint8_t *dst = (k < 3 ? Aq(g) : Br(g)) + (wv * 3 + k % 3) * 1024;
 #ifndef GM_NO_DMA
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -349,7 +356,7 @@ int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
     const int R = (a.G * 2 - 2) % 3;
 #define GM_LAUNCH(LIN_, R_)                                                                                          \
     hipLaunchKernelGGL((k_jc69_gemm<LIN_, R_>), dim3((unsigned)grid), dim3(GM_TPB), 0, ctx->stream, a.ref_f4,        \
-                       qb.qf4 + q0 * (int64_t)a.G * 192, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt,   \
+                       qb.qf4, q0, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt,                         \
                        ctx->jc_mmax, ctx->gemm_thr)
     if (lin) { if (R == 0) GM_LAUNCH(true, 0); else if (R == 1) GM_LAUNCH(true, 1); else GM_LAUNCH(true, 2); }
     else { if (R == 0) GM_LAUNCH(false, 0); else if (R == 1) GM_LAUNCH(false, 1); else GM_LAUNCH(false, 2); }
