@@ -192,6 +192,7 @@ struct apples_ctx {
     double *jc_lut = nullptr;
     int64_t jc_lut_len = 0;
     GemmThreshold gemm_thr;
+    int n_cu = 0;  // compute units of the device (dist_gemm.hip's persistent grid)
     int32_t *jc_mmax = nullptr;  // [L+1] largest mismatch count with 0 <= lut <= threshold, per valid count
     double *blosum = nullptr;  // 21x21 table (row/col 20 = gap -> 0)
     Workspace ws;

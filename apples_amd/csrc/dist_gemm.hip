@@ -58,17 +58,26 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
 #define Aq(g) (lds + (g) * GM_GEN)
 #define Br(g) (lds + (g) * GM_GEN + GM_T * 96)
     float *mm_lds = reinterpret_cast<float *>(lds + 3 * GM_GEN);
-    // tile of this workgroup: workgroup ids go round the XCDs; XCD x takes the strips x, x + 8, ...
+    // Workgroups are persistent (one per CU) and walk the tile grid: workgroup ids go round the XCDs; XCD x takes the
+    // strips x, x + 8, ... of GM_STRIP reference tiles, and within the XCD the tiles (query tile major, the strip's
+    // reference tiles inside) are dealt round-robin to its workgroups, so that the 32 tiles in flight on an XCD are 8
+    // consecutive query tiles x one strip.
     const int xcd = blockIdx.x & 7;
-    const int64_t loc = blockIdx.x >> 3;
-    const int64_t per_strip = (int64_t)TQ * GM_STRIP;
-    const int64_t strip = (loc / per_strip) * 8 + xcd;
-    const int64_t within = loc % per_strip;
-    const int64_t rt = strip * GM_STRIP + within % GM_STRIP, qt = within / GM_STRIP;
-    if (rt >= TR) return;
+    const int64_t per_strip = (int64_t)TQ * GM_STRIP, stride = gridDim.x >> 3;
+    const int64_t l_end = (((TR + GM_STRIP - 1) / GM_STRIP + 7) / 8) * per_strip;
+    auto tile_at = [&](int64_t l, int64_t &qt_, int64_t &rt_) __attribute__((always_inline)) {
+        const int64_t strip = (l / per_strip) * 8 + xcd, within = l % per_strip;
+        rt_ = strip * GM_STRIP + within % GM_STRIP;
+        qt_ = within / GM_STRIP;
+    };
+    int64_t l = blockIdx.x >> 3, qt = 0, rt = 0;
+    for (;; l += stride) {  // first tile
+        if (l >= l_end) return;
+        tile_at(l, qt, rt);
+        if (rt < TR) break;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = wv >> 1, wr = wv & 1;
-    const int64_t r0 = rt * GM_T, q0 = qt * GM_T;  // (q0: relative to this launch's first query)
     if (!LIN)
         for (int i = tid; i < 2048; i += GM_TPB) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
     // DMA roles: a tile-step image is 1536 16-byte chunks = 24 pieces of 1 KB, stored in HBM exactly as it lies in
@@ -78,27 +87,20 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     // image tiles: whole contiguous kilobytes.  The query tile starts at image row qrow0 + q0, a multiple of 32 (of
     // 256 for the sub-batches the driver cuts): its rows may lie in two image tiles, same slots.
     uint32_t doff[3];
-    const int64_t qabs = qrow0 + qt * GM_T;
+    const int qin = (int)(qrow0 & 255);  // first row of every query tile inside its image tile
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int p = (wv * 3 + k) * 64 + lane, row = p / 6, slot = p - row * 6;
-        const int64_t ar = qabs + row;
-        doff[k] = (uint32_t)((((ar >> 8) - (qabs >> 8)) * NB * 1536 + (ar & 255) * 6 + slot) * 16);
+        const int p = (wv * 3 + k) * 64 + lane, row = p / 6, slot = p - row * 6, ar = qin + row;
+        doff[k] = (uint32_t)(((ar >> 8) * NB * 1536 + (ar & 255) * 6 + slot) * 16);
     }
     const uint32_t roff = (uint32_t)(wv * 3 * 1024 + lane * 16);
-    const uint8_t *qtile = qf4 + (qabs >> 8) * (int64_t)NB * 24576, *rtile = rf4 + rt * (int64_t)NB * 24576;
+    const uint8_t *qtile = qf4 + ((qrow0 >> 8) + qt) * (int64_t)NB * 24576, *rtile = rf4 + rt * (int64_t)NB * 24576;
     const int fr = lane & 31, fh = lane >> 5;
     int coff[3];  // byte offset of component c's chunk for this lane's row and K half
 #pragma unroll
     for (int c = 0; c < 3; ++c) coff[c] = ((c * 2 + fh) ^ ((fr >> 4) & 1)) * 16;
     const int arow = (wq * 64 + fr) * 96, brow = (wr * 128 + fr) * 96;
     v16f_t acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
     // pieces k0, k0 + 1 of step b's images -> generation g (pieces 0-2: the query image, 3-5: the reference image)
     auto dma = [&](int b, int g, int k0) __attribute__((always_inline)) {
 #pragma unroll
@@ -199,9 +201,21 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    const int64_t n_seg = slots_pad >> 6;
+    const uint32_t below = (1u << fr) - 1u;
     dma(0, 0, 0); dma(0, 0, 2); dma(0, 0, 4);
     dma(1, 1, 0); dma(1, 1, 2); dma(1, 1, 4);
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");  // step 0 landed (and the table is written); step 1 stays in flight
+    for (;;) {  // tiles of this workgroup; entry: the first two steps of the tile are on their way
+    const int64_t r0 = rt * GM_T, q0 = qt * GM_T;  // (q0: relative to this launch's first query)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+    // steps 0 and 1 landed (they had the previous tile's epilogue to do so; the epilogue's stores share the counter,
+    // hence no counted wait here), the table is written
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     load_frags(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -226,14 +240,26 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
         step(b + 2, 2, false, true);
         step(b + 3, 0, false, false);
     }
+    // the next tile's first two steps go out before the epilogue: after the last barrier nobody reads LDS any more
+    int64_t nl = l + stride, nqt = 0, nrt = 0;
+    bool have = false;
+    for (; nl < l_end; nl += stride) {
+        tile_at(nl, nqt, nrt);
+        if (nrt < TR) { have = true; break; }
+    }
+    if (have) {
+        qtile = qf4 + ((qrow0 >> 8) + nqt) * (int64_t)NB * 24576;
+        rtile = rf4 + nrt * (int64_t)NB * 24576;
+        dma(0, 0, 0); dma(0, 0, 2); dma(0, 0, 4);
+        dma(1, 1, 0); dma(1, 1, 2); dma(1, 1, 4);
+    }
 #ifdef GM_SKIP_EPILOGUE
     {   // timing experiment: main loop only (every accumulator stays live)
         int a = 0;
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int x = 0; x < 16; ++x) a += (int)acc[i][j][x];
         if (a == 0x7fffffff) seg_cnt[0] = 1;
-        return;
     }
-#endif
+#else
     // C layout of the 32x32 tiles: column (reference slot) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
     // acc = sum t.t + 8192 valid.  Decoding, every step exact in f32: 8192 valid = ((acc - 2049) + 2^36) - 2^36 (the
     // sum rounds to the nearest multiple of 8192; acc + 2047 is never a multiple of 8192 while valid <= 2046),
@@ -242,8 +268,6 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     // host verified against the table for every valid (api.hip gemm_threshold), two elements per packed
     // instruction and the compare's lane mask used as it is; otherwise through the table in LDS (-4 where
     // nothing passes).
-    const int64_t n_seg = slots_pad >> 6;
-    const uint32_t below = (1u << fr) - 1u;
     if (LIN) {
         const v2f_t kA = {-2049.f, -2049.f}, kC = {68719476736.f, 68719476736.f}, kM = {8195.f / 8192.f, 8195.f / 8192.f};
         const v2f_t kS = {lin.slope, lin.slope}, kO = {lin.off, lin.off};
@@ -289,8 +313,7 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
                 }
             }
         }
-        return;
-    }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int64_t qbase = q0 + wq * 64 + i * 32 + 4 * fh;  // this lane half's first query of the 32
@@ -337,6 +360,11 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
             }
         }
     }
+    }
+#endif
+    if (!have) break;
+    l = nl; qt = nqt; rt = nrt;
+    }
 }
 
 }  // namespace
@@ -349,8 +377,13 @@ bool dist_gemm_usable(const apples_ctx *ctx) {
 int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt) {
     const DevAlign &a = ctx->aln;
     const int TQ = (int)((nq + GM_T - 1) / GM_T), TR = (int)(a.slots_pad / GM_T);
-    const int64_t strips = (TR + GM_STRIP - 1) / GM_STRIP;
-    const int64_t grid = 8 * ((strips + 7) / 8) * (int64_t)TQ * GM_STRIP;
+    // persistent workgroups: one per CU (the kernel's LDS allows no second one), a multiple of the 8 XCDs
+    if (ctx->n_cu == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->n_cu = prop.multiProcessorCount;
+    }
+    const int64_t grid = std::max(8, ctx->n_cu / 8 * 8);
     static const bool table = getenv("APPLES_GEMM_TABLE") != nullptr;  // diagnostic knob: threshold through the LDS table
     const bool lin = ctx->gemm_thr.ok && !table;
     const int R = (a.G * 2 - 2) % 3;
