@@ -11,7 +11,7 @@ import json, os, subprocess, sys
 d, workload = sys.argv[1], sys.argv[2]
 out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_summary.json')
 summ = json.loads(subprocess.check_output([sys.executable, os.path.join(os.path.dirname(__file__), 'pmc_summary.py'), d]))
-names = {'k_jc69_mfma': 'jc69_distance', 'k_jc69': 'jc69_distance', 'k_scoredist': 'scoredist_distance', 'k_select_fast': 'select_fast', 'k_select': 'select',
+names = {'k_jc69_gemm': 'jc69_distance', 'k_jc69_mfma': 'jc69_distance', 'k_jc69': 'jc69_distance', 'k_scoredist': 'scoredist_distance', 'k_select_fast': 'select_fast', 'k_select': 'select',
          'k_sweep': 'lsq_sweep'}
 res = {}
 for k, v in summ.items():
