@@ -6,11 +6,11 @@ res = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(d, '*', '*', '*counter_collection.csv')) + glob.glob(os.path.join(d, '*', '*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0][:40]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:40]
         res[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for f in glob.glob(os.path.join(d, '*', '*', '*kernel_trace.csv')) + glob.glob(os.path.join(d, '*', '*kernel_trace.csv')):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0][:40]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:40]
         dur[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
 out = {}
 for k in res:

@@ -456,11 +456,15 @@ def test_gemm_form_of_the_fused_pass_at_many_lengths():
             "    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)\n"
             "    e = Engine(d.tree, d.ref_seqs, nodes, method='FM', threshold=thr, baseobs=10)\n"
             "    out.append(e.place_sequences(d.query_seqs).tobytes()); e.close()\n"
+            "    if L in (300, 900):  # device batches that start inside a 256-row image tile (rows 96, 192, 288)\n"
+            "        e = Engine(d.tree, d.ref_seqs, nodes, method='FM', threshold=thr, baseobs=10, max_batch=96)\n"
+            "        out.append(e.place_sequences(d.query_seqs).tobytes()); e.close()\n"
+            "        assert out[-1] == out[-2]\n"
             "sys.stdout.buffer.write(b''.join(out))\n" % ROOT)
     outs = []
     for env in ({}, {'APPLES_NO_DIST_GEMM': '1'}, {'APPLES_GEMM_TABLE': '1'}, {'APPLES_NO_FUSE': '1'}):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(r.stdout)
-    assert len(outs[0]) == 9 * 300 * 40
+    assert len(outs[0]) == 11 * 300 * 40
     assert all(o == outs[0] for o in outs)
