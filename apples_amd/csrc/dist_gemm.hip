@@ -383,7 +383,8 @@ int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
         ctx->n_cu = prop.multiProcessorCount;
     }
-    const int64_t grid = std::max(8, ctx->n_cu / 8 * 8);
+    static const int cus = getenv("APPLES_GEMM_CUS") ? atoi(getenv("APPLES_GEMM_CUS")) : 0;  // experiment: leave CUs to a concurrent sweep
+    const int64_t grid = std::max(8, (cus > 0 ? std::min(cus, ctx->n_cu) : ctx->n_cu) / 8 * 8);
     static const bool table = getenv("APPLES_GEMM_TABLE") != nullptr;  // diagnostic knob: threshold through the LDS table
     const bool lin = ctx->gemm_thr.ok && !table;
     const int R = (a.G * 2 - 2) % 3;
