@@ -27,7 +27,9 @@ typedef float v2f_t __attribute__((ext_vector_type(2)));
 
 #define GM_TPB 512
 #define GM_T 256      // tile edge: queries and reference slots per workgroup
+#ifndef GM_STRIP
 #define GM_STRIP 4    // reference tiles per strip
+#endif
 #define GM_VSHIFT 13  // the validity sum rides at 2^13
 #define GM_GEN (2 * GM_T * 96)  // LDS bytes of one generation: query and reference image of one step
 
