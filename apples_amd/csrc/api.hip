@@ -370,8 +370,8 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         dev_free(d_exotic);
         // pre-expanded reference image for the GEMM form of the fused pass (dist_gemm.hip): 2 bytes per site
         if (a.all_singleton && a.planes == 2 && a.L <= GEMM_MAX_L && dist_mfma_enabled() && !getenv("APPLES_NO_DIST_GEMM")) {
-            // (the image's own allocation marks the context's fp4 images as compact: 96 bytes per 64-site block)
-            if (dev_alloc(ctx, &a.ref_f4, a.slots_pad * (int64_t)a.G * 192)) return 1;
+            // (the image's own allocation marks the context's fp4 images as compact: 64 bytes per 64-site block)
+            if (dev_alloc(ctx, &a.ref_f4, a.slots_pad * (int64_t)a.G * 128)) return 1;
             if (launch_expand_queries_f4(ctx, a.raw, a.n_rows, a.ref_f4, a.slots_pad, ctx->stream, a.d_slot_row)) return 1;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }

@@ -211,10 +211,10 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 // query rows -> fp4 operand image: a 64-site block of a query is 128 bytes, component c (t1, t2, t3,
 // v) at c * 32, its first word's four dwords then its second word's
 // (src_row: row r of the image comes from raw row src_row[r] -- the reference image in slot order)
-// compact (the images dist_gemm.hip reads): no validity component, and the bytes stored as that kernel's LDS image
-// of a 256-row tile and 64-site step -- image row row0 + q is row rr = (row0 + q) & 255 of tile (row0 + q) >> 8; a
-// tile-step is 1536 16-byte chunks, chunk c (component * 2 + word) of row rr at position 6 rr + (c ^ ((rr >> 4) & 1)):
-// the kernel's DMA pieces are then whole contiguous kilobytes
+// compact (the images dist_gemm.hip reads): t1 and t2 only (that kernel derives t3 and the validity operand), and
+// the bytes stored as its LDS image of a 256-row tile and 64-site step -- image row row0 + q is row rr = (row0 + q)
+// & 255 of tile (row0 + q) >> 8; a tile-step is 1024 16-byte chunks, chunk c (component * 2 + word) of row rr at
+// position 4 rr + (c ^ ((rr >> 2) & 3)): the kernel's DMA pieces are then whole contiguous kilobytes
 __global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_f4(const uint8_t *__restrict__ raw, int64_t n, int L, int NB,
                                                                   uint32_t *__restrict__ out, int64_t n_pad,
                                                                   const int32_t *__restrict__ src_row, int compact,
@@ -244,9 +244,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_f4(const uint8_t 
     }
     if (compact) {
         const int64_t ar = row0 + q, tile = ar >> 8;
-        const int rr = (int)(ar & 255), sw = (rr >> 4) & 1;
-        uint32_t *o = out + ((tile * NB + b) * 1536 + rr * 6) * 4 + j;
-        o[((0 + x) ^ sw) * 4] = t1; o[((2 + x) ^ sw) * 4] = t2; o[((4 + x) ^ sw) * 4] = t3;
+        const int rr = (int)(ar & 255), sw = (rr >> 2) & 3;
+        uint32_t *o = out + ((tile * NB + b) * 1024 + rr * 4) * 4 + j;
+        o[((0 + x) ^ sw) * 4] = t1; o[((2 + x) ^ sw) * 4] = t2;
         return;
     }
     uint32_t *o = out + qb * 32 + x * 4 + j;

@@ -2,12 +2,13 @@
 //
 // Same arithmetic as k_jc69_mfma (dist.hip): every site is a corner of a tetrahedron (components t1, t2, t3 =
 // +-1, 0 for a gap) plus a validity flag v; sum t.t = 3 match - mism and sum v.v = valid.  Differences:
-//   * BOTH operands are kept pre-expanded in HBM (1.5 bytes per site: t1, t2, t3 only -- the validity operand is
-//     t1 with the sign bits cleared, one v_and per fragment register; the reference image is built once per
-//     context, 307 MB at 200 k x 1000), so the kernel has no expansion arithmetic and no register -> LDS stores at
-//     all: the 256 x 96-byte tile images of a 64-site step arrive by LDS-DMA (global_load_lds_dwordx4), lane-
-//     linear in LDS with a chunk permutation applied to the lanes' SOURCE addresses (conflict-free
-//     ds_read_b128), three generations deep: the DMA runs two steps ahead of the MFMAs;
+//   * BOTH operands are kept pre-expanded in HBM (1 byte per site: t1 and t2 only -- t3 is t1 with the sign flipped
+//     where t2 is negative and the validity operand is t1 with the sign bits cleared, one bit operation per
+//     fragment register each; the reference image is built once per context, 205 MB at 200 k x 1000), so the
+//     kernel has no expansion arithmetic and no register -> LDS stores at all: the 256 x 64-byte tile images of a
+//     64-site step arrive by LDS-DMA (global_load_lds_dwordx4) as contiguous kilobytes, stored in HBM as they lie
+//     in LDS (chunk permutation for conflict-free ds_read_b128), three generations deep: the DMA runs two steps
+//     ahead of the MFMAs;
 //   * ONE accumulator set: the v component is multiplied through the block-scaled MFMA with a scale of 2^13 on
 //     the query side, acc = sum t.t + 8192 valid.  With valid <= 2047 both integers decode exactly
 //     (-valid <= sum t.t <= 3 valid: the ranges of neighbouring `valid` do not overlap, and acc < 2^24);
@@ -31,7 +32,8 @@ typedef float v2f_t __attribute__((ext_vector_type(2)));
 #define GM_STRIP 4    // reference tiles per strip
 #endif
 #define GM_VSHIFT 13  // the validity sum rides at 2^13
-#define GM_GEN (2 * GM_T * 96)  // LDS bytes of one generation: query and reference image of one step
+#define GM_IMG (GM_T * 64)   // bytes of one tile-step image: 256 rows x (t1, t2) x 32 bytes
+#define GM_GEN (2 * GM_IMG)  // LDS bytes of one generation: query and reference image of one step
 
 namespace {
 
@@ -54,11 +56,11 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
                                                       int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
                                                       const int32_t *__restrict__ mmax, GemmThreshold lin) {
     // ONE LDS object (the compiler's alias analysis then sees constant, disjoint ranges and does not drain the DMA
-    // queue before unrelated reads): three generations of 48 KB -- the 256 query rows of one 64-site step (96
-    // bytes each: t1, t2, t3), the 256 reference slots 24 KB further -- and the threshold table behind them
+    // queue before unrelated reads): three generations of 32 KB -- the 256 query rows of one 64-site step (64
+    // bytes each: t1, t2), the 256 reference slots 16 KB further -- and the threshold table behind them
     __shared__ __attribute__((aligned(1024))) uint8_t lds[3 * GM_GEN + 2048 * 4];
 #define Aq(g) (lds + (g) * GM_GEN)
-#define Br(g) (lds + (g) * GM_GEN + GM_T * 96)
+#define Br(g) (lds + (g) * GM_GEN + GM_IMG)
     float *mm_lds = reinterpret_cast<float *>(lds + 3 * GM_GEN);
     // Workgroups are persistent (one per CU) and walk the tile grid: workgroup ids go round the XCDs; XCD x takes the
     // strips x, x + 8, ... of GM_STRIP reference tiles, and within the XCD the tiles (query tile major, the strip's
@@ -82,73 +84,83 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     const int wq = wv >> 1, wr = wv & 1;
     if (!LIN)
         for (int i = tid; i < 2048; i += GM_TPB) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
-    // DMA roles: a tile-step image is 1536 16-byte chunks = 24 pieces of 1 KB, stored in HBM exactly as it lies in
-    // LDS (k_expand_queries_f4, compact form): chunk p = row p / 6, slot p % 6, the slot holding chunk slot ^ ((row
-    // >> 4) & 1) of the row, so that with the 96-byte stride the 16 lanes of a ds_read_b128 group cover all 16 bank
-    // quads.  This wavefront moves pieces wv * 3 + k; lane l of piece P fills chunk 64 P + l.  Reference tiles are
-    // image tiles: whole contiguous kilobytes.  The query tile starts at image row qrow0 + q0, a multiple of 32 (of
-    // 256 for the sub-batches the driver cuts): its rows may lie in two image tiles, same slots.
-    uint32_t doff[3];
+    // DMA roles: a tile-step image is 1024 16-byte chunks = 16 pieces of 1 KB, stored in HBM exactly as it lies in
+    // LDS (k_expand_queries_f4, compact form): row r's four chunks (t1 and t2, two 32-site words each) at 4 r, chunk c
+    // in slot c ^ ((r >> 2) & 3), so that with the 64-byte stride the 16 lanes of a ds_read_b128 group cover all 16
+    // bank quads.  This wavefront moves pieces wv * 2 + k; lane l of piece P fills chunk 64 P + l.  Reference tiles
+    // are image tiles: whole contiguous kilobytes.  The query tile starts at image row qrow0 + q0, a multiple of 32
+    // (of 256 for the sub-batches the driver cuts): its rows may lie in two image tiles, same slots.
+    uint32_t doff[2];
     const int qin = (int)(qrow0 & 255);  // first row of every query tile inside its image tile
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int p = (wv * 3 + k) * 64 + lane, row = p / 6, slot = p - row * 6, ar = qin + row;
-        doff[k] = (uint32_t)(((ar >> 8) * NB * 1536 + (ar & 255) * 6 + slot) * 16);
+    for (int k = 0; k < 2; ++k) {
+        const int row = (wv * 2 + k) * 16 + (lane >> 2), slot = lane & 3, ar = qin + row;
+        doff[k] = (uint32_t)(((ar >> 8) * NB * 1024 + (ar & 255) * 4 + slot) * 16);
     }
-    const uint32_t roff = (uint32_t)(wv * 3 * 1024 + lane * 16);
-    const uint8_t *qtile = qf4 + ((qrow0 >> 8) + qt) * (int64_t)NB * 24576, *rtile = rf4 + rt * (int64_t)NB * 24576;
+    const uint32_t roff = (uint32_t)(wv * 2 * 1024 + lane * 16);
+    const uint8_t *qtile = qf4 + ((qrow0 >> 8) + qt) * (int64_t)NB * GM_IMG, *rtile = rf4 + rt * (int64_t)NB * GM_IMG;
     const int fr = lane & 31, fh = lane >> 5;
-    int coff[3];  // byte offset of component c's chunk for this lane's row and K half
+    int coff[2];  // byte offset of component c's chunk for this lane's row and K half
 #pragma unroll
-    for (int c = 0; c < 3; ++c) coff[c] = ((c * 2 + fh) ^ ((fr >> 4) & 1)) * 16;
-    const int arow = (wq * 64 + fr) * 96, brow = (wr * 128 + fr) * 96;
+    for (int c = 0; c < 2; ++c) coff[c] = ((c * 2 + fh) ^ ((fr >> 2) & 3)) * 16;
+    const int arow = (wq * 64 + fr) * 64, brow = (wr * 128 + fr) * 64;
     v16f_t acc[2][4];
-    // pieces k0, k0 + 1 of step b's images -> generation g (pieces 0-2: the query image, 3-5: the reference image)
+    // pieces k0, k0 + 1 of step b's images -> generation g (pieces 0, 1: the query image, 2, 3: the reference image)
     auto dma = [&](int b, int g, int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = k0; k < k0 + 2; ++k) {
             // uniform base + 32-bit lane offset
-            const uint8_t *src = k < 3 ? (qtile + b * 24576) + doff[k] : (rtile + b * 24576 + (k - 3) * 1024) + roff;
-            uint8_t *dst = (k < 3 ? Aq(g) : Br(g)) + (wv * 3 + k % 3) * 1024;
+            const uint8_t *src = k < 2 ? (qtile + b * GM_IMG) + doff[k] : (rtile + b * GM_IMG + (k - 2) * 1024) + roff;
+            uint8_t *dst = (k < 2 ? Aq(g) : Br(g)) + (wv * 2 + (k & 1)) * 1024;
 #ifndef GM_NO_DMA
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
 #endif
         }
     };
-    v4i_t fa[3][2], fb[3][4];  // one fragment set per component; set 0 is turned into the validity operand in place
-    auto load_frags = [&](int g, int c) __attribute__((always_inline)) {
+    // Three fragment sets that rotate with the generations: in a step of generation g, set g holds t1 (and becomes
+    // the validity operand in place: sign bits cleared), set g + 1 holds t2 and becomes t3 in place (t3 = t1 with
+    // the sign flipped where t2 is negative: one three-input bit operation per register) and then receives the next
+    // step's t1; set g + 2 is the next step's t2 set.  Only t1 and t2 are ever loaded.
+    v4i_t fa[3][2], fb[3][4];
+    auto load_frags = [&](int g, int c, int set) __attribute__((always_inline)) {
 #ifndef GM_NO_FRAGS
         const uint8_t *A = Aq(g) + arow + coff[c], *B = Br(g) + brow + coff[c];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[c][i] = *reinterpret_cast<const v4i_t *>(A + i * 32 * 96);
+        for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const v4i_t *>(A + i * 32 * 64);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[c][j] = *reinterpret_cast<const v4i_t *>(B + j * 32 * 96);
+        for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const v4i_t *>(B + j * 32 * 64);
 #endif
     };
-    auto mfmas = [&](int c, bool valid) __attribute__((always_inline)) {
+    auto mfmas = [&](int set, bool valid) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = valid ? mfma_f4_v(fa[c][i], fb[c][j], acc[i][j]) : mfma_f4(fa[c][i], fb[c][j], acc[i][j]);
+                acc[i][j] = valid ? mfma_f4_v(fa[set][i], fb[set][j], acc[i][j]) : mfma_f4(fa[set][i], fb[set][j], acc[i][j]);
     };
-    auto strip_signs = [&]() __attribute__((always_inline)) {  // t1 = +-1 or 0 -> v = |t1|: clear the sign bit of every fp4 nibble
+    auto make_t3 = [&](int s1, int s2) __attribute__((always_inline)) {  // set s2 (t2) -> t3 = t1 ^ sign(t2)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[0][i] &= 0x77777777;
+        for (int i = 0; i < 2; ++i) fa[s2][i] = fa[s1][i] ^ (fa[s2][i] & (int)0x88888888);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[0][j] &= 0x77777777;
+        for (int j = 0; j < 4; ++j) fb[s2][j] = fb[s1][j] ^ (fb[s2][j] & (int)0x88888888);
     };
-    // One step = 64 sites = 4 sections of 8 MFMAs per wavefront (t1, validity, t2, t3), generation g = step % 3.
-    // Entry: set 0 holds t1 (read after the previous barrier).  The DMA of step + 2 goes out two pieces per section
-    // between the MFMAs of the first three sections, into the generation every wavefront left at the previous
-    // barrier; this step's barrier -- before the last section, whose MFMAs cover the first fragment reads of the
-    // next step -- needs step + 1 landed (issued a whole step ago) and lets those six pieces stay in flight.
+    auto strip_signs = [&](int s1) __attribute__((always_inline)) {  // t1 = +-1 or 0 -> v = |t1|: clear the sign bit of every fp4 nibble
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[s1][i] &= 0x77777777;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[s1][j] &= 0x77777777;
+    };
+    // One step = 64 sites = 4 sections of 8 MFMAs per wavefront (t1, t2, t3, validity), generation g = step % 3.
+    // Entry: set g holds t1 (read after the previous barrier).  The DMA of step + 2 goes out two pieces per section
+    // between the MFMAs of the first two sections, into the generation every wavefront left at the previous barrier;
+    // this step's barrier -- before the last section, whose MFMAs cover the first fragment reads of the next step --
+    // needs step + 1 landed (issued a whole step ago) and lets those four pieces stay in flight.
     auto step = [&](int b, int g, bool feed, bool more) __attribute__((always_inline)) {
         const int gn = g == 2 ? 0 : g + 1, gf = g == 0 ? 2 : g - 1;  // next step's generation; the free one
-        load_frags(g, 1);
+        load_frags(g, 1, gn);
         if (feed) dma(b + 2, gf, 0);
-        mfmas(0, false);
+        mfmas(g, false);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -159,54 +171,49 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        strip_signs();
-        load_frags(g, 2);
         if (feed) dma(b + 2, gf, 2);
-        mfmas(0, true);
+        mfmas(gn, false);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (k == 1 || k == 4) {
+                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        make_t3(g, gn);
+        mfmas(gn, false);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (k == 2 || k == 5) {
-                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (feed) dma(b + 2, gf, 4);
-        mfmas(1, false);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (k == 1 || k == 4) {
-                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // step b + 1 has landed everywhere (own pieces first, then the barrier); step b's images are free
 #ifdef GM_NO_VMWAIT
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-        if (feed) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        if (feed) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (more) load_frags(gn, 0);
-        mfmas(2, false);
+        strip_signs(g);
+        if (more) load_frags(gn, 0, gn);
+        mfmas(g, true);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
     const int64_t n_seg = slots_pad >> 6;
     const uint32_t below = (1u << fr) - 1u;
-    dma(0, 0, 0); dma(0, 0, 2); dma(0, 0, 4);
-    dma(1, 1, 0); dma(1, 1, 2); dma(1, 1, 4);
+    dma(0, 0, 0); dma(0, 0, 2);
+    dma(1, 1, 0); dma(1, 1, 2);
     for (;;) {  // tiles of this workgroup; entry: the first two steps of the tile are on their way
     const int64_t r0 = rt * GM_T, q0 = qt * GM_T;  // (q0: relative to this launch's first query)
 #pragma unroll
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     // hence no counted wait here), the table is written
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    load_frags(0, 0);
+    load_frags(0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     // NB (even, >= 2) steps: NB - 2 feeding ones, then one that only prefetches fragments, then the last
     const int F = NB - 2;
@@ -250,10 +257,10 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
         if (nrt < TR) { have = true; break; }
     }
     if (have) {
-        qtile = qf4 + ((qrow0 >> 8) + nqt) * (int64_t)NB * 24576;
-        rtile = rf4 + nrt * (int64_t)NB * 24576;
-        dma(0, 0, 0); dma(0, 0, 2); dma(0, 0, 4);
-        dma(1, 1, 0); dma(1, 1, 2); dma(1, 1, 4);
+        qtile = qf4 + ((qrow0 >> 8) + nqt) * (int64_t)NB * GM_IMG;
+        rtile = rf4 + nrt * (int64_t)NB * GM_IMG;
+        dma(0, 0, 0); dma(0, 0, 2);
+        dma(1, 1, 0); dma(1, 1, 2);
     }
 #ifdef GM_SKIP_EPILOGUE
     {   // timing experiment: main loop only (every accumulator stays live)
