@@ -33,7 +33,6 @@ typedef float v2f_t __attribute__((ext_vector_type(2)));
 #endif
 #define GM_VSHIFT 13  // the validity sum rides at 2^13
 #define GM_IMG (GM_T * 64)   // bytes of one tile-step image: 256 rows x (t1, t2) x 32 bytes
-#define GM_GEN (2 * GM_IMG)  // LDS bytes of one generation: query and reference image of one step
 
 namespace {
 
@@ -50,18 +49,22 @@ __device__ __forceinline__ v16f_t mfma_f4_v(const v4i_t &a, const v4i_t &b, cons
 
 // R = (NB - 2) % 3: the shape of the main loop's tail, fixed per launch (a run-time choice between the three tails
 // merges 128 accumulator registers three ways and the kernel spills)
-template <bool LIN, int R>
-__global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict__ rf4, const uint8_t *__restrict__ qf4,
+// QT = query rows per workgroup tile: 256 (eight wavefronts, one workgroup per CU) or 128 (four wavefronts, two
+// workgroups per CU: one's epilogue and barrier stalls run beside the other's MFMAs, for half as much reuse of the
+// reference image per byte moved)
+template <bool LIN, int R, int QT>
+__global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *__restrict__ rf4, const uint8_t *__restrict__ qf4,
                                                       int64_t qrow0, int64_t slots_pad, int NB, int64_t nq, int L, int TQ, int TR,
                                                       int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
                                                       const int32_t *__restrict__ mmax, GemmThreshold lin) {
     // ONE LDS object (the compiler's alias analysis then sees constant, disjoint ranges and does not drain the DMA
-    // queue before unrelated reads): three generations of 32 KB -- the 256 query rows of one 64-site step (64
-    // bytes each: t1, t2), the 256 reference slots 16 KB further -- and the threshold table behind them
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[3 * GM_GEN + 2048 * 4];
-#define Aq(g) (lds + (g) * GM_GEN)
-#define Br(g) (lds + (g) * GM_GEN + GM_IMG)
-    float *mm_lds = reinterpret_cast<float *>(lds + 3 * GM_GEN);
+    // queue before unrelated reads): three generations -- the QT query rows of one 64-site step (64 bytes each:
+    // t1, t2), the 256 reference slots behind them -- and, for the table form of the threshold, the table
+    constexpr int AI = QT * 64, GEN = AI + GM_IMG, NW = QT / 32, PB = 16 / NW;  // A image, generation, wavefronts, B pieces per wavefront
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[3 * GEN + (LIN ? 0 : 2048 * 4)];
+#define Aq(g) (lds + (g) * GEN)
+#define Br(g) (lds + (g) * GEN + AI)
+    float *mm_lds = reinterpret_cast<float *>(lds + 3 * GEN);
     // Workgroups are persistent (one per CU) and walk the tile grid: workgroup ids go round the XCDs; XCD x takes the
     // strips x, x + 8, ... of GM_STRIP reference tiles, and within the XCD the tiles (query tile major, the strip's
     // reference tiles inside) are dealt round-robin to its workgroups, so that the 32 tiles in flight on an XCD are 8
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = wv >> 1, wr = wv & 1;
     if (!LIN)
-        for (int i = tid; i < 2048; i += GM_TPB) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
+        for (int i = tid; i < 2048; i += QT * 2) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
     // DMA roles: a tile-step image is 1024 16-byte chunks = 16 pieces of 1 KB, stored in HBM exactly as it lies in
     // LDS (k_expand_queries_f4, compact form): row r's four chunks (t1 and t2, two 32-site words each) at 4 r, chunk c
     // in slot c ^ ((r >> 2) & 3), so that with the 64-byte stride the 16 lanes of a ds_read_b128 group cover all 16
@@ -91,27 +94,36 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     // are image tiles: whole contiguous kilobytes.  The query tile starts at image row qrow0 + q0, a multiple of 32
     // (of 256 for the sub-batches the driver cuts): its rows may lie in two image tiles, same slots.
     uint32_t doff[2];
-    const int qin = (int)(qrow0 & 255);  // first row of every query tile inside its image tile
+    const uint8_t *qtile, *rtile;
+    auto set_tile = [&](int64_t qt_, int64_t rt_) __attribute__((always_inline)) {
+        const int64_t qabs = qrow0 + qt_ * QT;
+        const int qin = (int)(qabs & 255);  // first row of the query tile inside its image tile
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int row = (wv * 2 + k) * 16 + (lane >> 2), slot = lane & 3, ar = qin + row;
-        doff[k] = (uint32_t)(((ar >> 8) * NB * 1024 + (ar & 255) * 4 + slot) * 16);
-    }
-    const uint32_t roff = (uint32_t)(wv * 2 * 1024 + lane * 16);
-    const uint8_t *qtile = qf4 + ((qrow0 >> 8) + qt) * (int64_t)NB * GM_IMG, *rtile = rf4 + rt * (int64_t)NB * GM_IMG;
+        for (int k = 0; k < 2; ++k) {
+            const int row = (wv * 2 + k) * 16 + (lane >> 2), slot = lane & 3, ar = qin + row;
+            doff[k] = (uint32_t)(((ar >> 8) * NB * 1024 + (ar & 255) * 4 + slot) * 16);
+        }
+        qtile = qf4 + (qabs >> 8) * (int64_t)NB * GM_IMG;
+        rtile = rf4 + rt_ * (int64_t)NB * GM_IMG;
+    };
+    set_tile(qt, rt);
+    const uint32_t roff = (uint32_t)(wv * PB * 1024 + lane * 16);
     const int fr = lane & 31, fh = lane >> 5;
     int coff[2];  // byte offset of component c's chunk for this lane's row and K half
 #pragma unroll
     for (int c = 0; c < 2; ++c) coff[c] = ((c * 2 + fh) ^ ((fr >> 2) & 3)) * 16;
     const int arow = (wq * 64 + fr) * 64, brow = (wr * 128 + fr) * 64;
     v16f_t acc[2][4];
-    // pieces k0, k0 + 1 of step b's images -> generation g (pieces 0, 1: the query image, 2, 3: the reference image)
-    auto dma = [&](int b, int g, int k0) __attribute__((always_inline)) {
+    // this wavefront's pieces of step b's images -> generation g: its two of the query image (part 0), its PB of the
+    // reference image two at a time (parts 1, 2)
+    auto dma = [&](int b, int g, int part) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = k0; k < k0 + 2; ++k) {
+        for (int k = 0; k < 2; ++k) {
+            if (part > 0 && (part - 1) * 2 + k >= PB) continue;
+            const int kb = (part - 1) * 2 + k;
             // uniform base + 32-bit lane offset
-            const uint8_t *src = k < 2 ? (qtile + b * GM_IMG) + doff[k] : (rtile + b * GM_IMG + (k - 2) * 1024) + roff;
-            uint8_t *dst = (k < 2 ? Aq(g) : Br(g)) + (wv * 2 + (k & 1)) * 1024;
+            const uint8_t *src = part == 0 ? (qtile + b * GM_IMG) + doff[k] : (rtile + b * GM_IMG + kb * 1024) + roff;
+            uint8_t *dst = part == 0 ? Aq(g) + (wv * 2 + k) * 1024 : Br(g) + (wv * PB + kb) * 1024;
 #ifndef GM_NO_DMA
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (feed) dma(b + 2, gf, 2);
+        if (feed) dma(b + 2, gf, 1);
         mfmas(gn, false);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -183,18 +195,24 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
         }
         __builtin_amdgcn_sched_barrier(0);
         make_t3(g, gn);
+        if (feed && PB > 2) dma(b + 2, gf, 2);
         mfmas(gn, false);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (PB > 2 && (k == 2 || k == 5)) {
+                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // step b + 1 has landed everywhere (own pieces first, then the barrier); step b's images are free
 #ifdef GM_NO_VMWAIT
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-        if (feed) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        if (feed && PB == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (feed) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
         __builtin_amdgcn_s_barrier();
@@ -212,10 +230,10 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
     };
     const int64_t n_seg = slots_pad >> 6;
     const uint32_t below = (1u << fr) - 1u;
-    dma(0, 0, 0); dma(0, 0, 2);
-    dma(1, 1, 0); dma(1, 1, 2);
+    dma(0, 0, 0); dma(0, 0, 1); dma(0, 0, 2);
+    dma(1, 1, 0); dma(1, 1, 1); dma(1, 1, 2);
     for (;;) {  // tiles of this workgroup; entry: the first two steps of the tile are on their way
-    const int64_t r0 = rt * GM_T, q0 = qt * GM_T;  // (q0: relative to this launch's first query)
+    const int64_t r0 = rt * GM_T, q0 = qt * QT;  // (q0: relative to this launch's first query)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -257,10 +275,9 @@ __global__ __launch_bounds__(GM_TPB) void k_jc69_gemm(const uint8_t *__restrict_
         if (nrt < TR) { have = true; break; }
     }
     if (have) {
-        qtile = qf4 + ((qrow0 >> 8) + nqt) * (int64_t)NB * GM_IMG;
-        rtile = rf4 + nrt * (int64_t)NB * GM_IMG;
-        dma(0, 0, 0); dma(0, 0, 2);
-        dma(1, 1, 0); dma(1, 1, 2);
+        set_tile(nqt, nrt);
+        dma(0, 0, 0); dma(0, 0, 1); dma(0, 0, 2);
+        dma(1, 1, 0); dma(1, 1, 1); dma(1, 1, 2);
     }
 #ifdef GM_SKIP_EPILOGUE
     {   // timing experiment: main loop only (every accumulator stays live)
@@ -385,24 +402,32 @@ bool dist_gemm_usable(const apples_ctx *ctx) {
 
 int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt) {
     const DevAlign &a = ctx->aln;
-    const int TQ = (int)((nq + GM_T - 1) / GM_T), TR = (int)(a.slots_pad / GM_T);
-    // persistent workgroups: one per CU (the kernel's LDS allows no second one), a multiple of the 8 XCDs
+    // tuning knob: 128 = two four-wavefront workgroups per CU (measured at C3: 30.8 ms against 29.4 -- what the second
+    // workgroup hides of the first one's epilogue and barrier stalls costs more in DMA traffic)
+    static const int qt_env = getenv("APPLES_GEMM_QT") ? atoi(getenv("APPLES_GEMM_QT")) : 256;
+    const int QT = qt_env == 128 ? 128 : 256;
+    const int TQ = (int)((nq + QT - 1) / QT), TR = (int)(a.slots_pad / GM_T);
+    // persistent workgroups: as many as the CUs hold (the kernel's LDS and registers allow 256 / QT per CU), a
+    // multiple of the 8 XCDs
     if (ctx->n_cu == 0) {
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
         ctx->n_cu = prop.multiProcessorCount;
     }
     static const int cus = getenv("APPLES_GEMM_CUS") ? atoi(getenv("APPLES_GEMM_CUS")) : 0;  // experiment: leave CUs to a concurrent sweep
-    const int64_t grid = std::max(8, (cus > 0 ? std::min(cus, ctx->n_cu) : ctx->n_cu) / 8 * 8);
+    const int64_t grid = std::max(8, (cus > 0 ? std::min(cus, ctx->n_cu) : ctx->n_cu) / 8 * 8) * (256 / QT);
     static const bool table = getenv("APPLES_GEMM_TABLE") != nullptr;  // diagnostic knob: threshold through the LDS table
     const bool lin = ctx->gemm_thr.ok && !table;
     const int R = (a.G * 2 - 2) % 3;
-#define GM_LAUNCH(LIN_, R_)                                                                                          \
-    hipLaunchKernelGGL((k_jc69_gemm<LIN_, R_>), dim3((unsigned)grid), dim3(GM_TPB), 0, ctx->stream, a.ref_f4,        \
+#define GM_LAUNCH(LIN_, R_, QT_)                                                                                     \
+    hipLaunchKernelGGL((k_jc69_gemm<LIN_, R_, QT_>), dim3((unsigned)grid), dim3(QT_ * 2), 0, ctx->stream, a.ref_f4,  \
                        qb.qf4, q0, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt,                         \
                        ctx->jc_mmax, ctx->gemm_thr)
-    if (lin) { if (R == 0) GM_LAUNCH(true, 0); else if (R == 1) GM_LAUNCH(true, 1); else GM_LAUNCH(true, 2); }
-    else { if (R == 0) GM_LAUNCH(false, 0); else if (R == 1) GM_LAUNCH(false, 1); else GM_LAUNCH(false, 2); }
+#define GM_LAUNCH_R(LIN_, QT_)                                                                                       \
+    do { if (R == 0) GM_LAUNCH(LIN_, 0, QT_); else if (R == 1) GM_LAUNCH(LIN_, 1, QT_); else GM_LAUNCH(LIN_, 2, QT_); } while (0)
+    if (QT == 256) { if (lin) GM_LAUNCH_R(true, 256); else GM_LAUNCH_R(false, 256); }
+    else { if (lin) GM_LAUNCH_R(true, 128); else GM_LAUNCH_R(false, 128); }
+#undef GM_LAUNCH_R
 #undef GM_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     return 0;

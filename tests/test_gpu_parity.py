@@ -462,7 +462,7 @@ def test_gemm_form_of_the_fused_pass_at_many_lengths():
             "        assert out[-1] == out[-2]\n"
             "sys.stdout.buffer.write(b''.join(out))\n" % ROOT)
     outs = []
-    for env in ({}, {'APPLES_NO_DIST_GEMM': '1'}, {'APPLES_GEMM_TABLE': '1'}, {'APPLES_NO_FUSE': '1'}):
+    for env in ({}, {'APPLES_NO_DIST_GEMM': '1'}, {'APPLES_GEMM_TABLE': '1'}, {'APPLES_NO_FUSE': '1'}, {'APPLES_GEMM_QT': '128'}):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(r.stdout)

@@ -155,7 +155,7 @@ def test_fused_and_full_row_selection_paths_agree(c2):
             "sys.stdout.buffer.write(b''.join(out))\n" % ROOT)
     outs = []
     for env in ({}, {'APPLES_NO_FUSE': '1'}, {'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_TEAM': '256'},
-                {'APPLES_TOPUP_MIN_ROWS': '0'}, {'APPLES_NO_DIST_MFMA': '1'}, {'APPLES_NO_DIST_GEMM': '1'}, {'APPLES_GEMM_TABLE': '1'}, {'APPLES_SWEEP_SCAN': '1'},
+                {'APPLES_TOPUP_MIN_ROWS': '0'}, {'APPLES_NO_DIST_MFMA': '1'}, {'APPLES_NO_DIST_GEMM': '1'}, {'APPLES_GEMM_TABLE': '1'}, {'APPLES_GEMM_QT': '128'}, {'APPLES_GEMM_QT': '128', 'APPLES_GEMM_TABLE': '1'}, {'APPLES_SWEEP_SCAN': '1'},
                 {'APPLES_SWEEP_SCAN': '1', 'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_SCAN': '1', 'APPLES_SWEEP_TEAM': '256'}):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
