@@ -1697,11 +1697,16 @@ const char *apples_describe(apples_ctx *ctx) {
     snprintf(buf, sizeof buf,
              "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"n_rows\": %lld, "
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
-             "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\"}",
+             "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\", "
+             "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld}",
              name, cus, ctx->tree.n_nodes, ctx->tree.height, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
              (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
-             (long long)ctx->ws.small.cap, ctx->ws.big.wgs, ctx->jc_lut ? 1 : 0, ctx->tree.scan ? "scan" : "levels");
+             (long long)ctx->ws.small.cap, ctx->ws.big.wgs, ctx->jc_lut ? 1 : 0, ctx->tree.scan ? "scan" : "levels",
+             // which kernel the fused pass of ACGT- query blocks runs on (dist_gemm.hip / dist.hip k_jc69_mfma / k_jc69 or k_scoredist)
+             dist_gemm_usable(ctx) ? (ctx->gemm_thr.ok ? "fp4 gemm, linear threshold" : "fp4 gemm, threshold table")
+                                   : (a.planes == 2 && dist_mfma_enabled() ? "fp4 mfma, bit-plane fed" : "valu"),
+             (long long)(a.ref_f4 ? a.slots_pad * (int64_t)a.G * 128 : 0));
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

@@ -111,7 +111,8 @@ struct QueryBlock {
     int64_t n_cols = 0;
     uint8_t *raw = nullptr;       // [n*L]
     uint4 *packed = nullptr;      // [n_pad/16][G][16][planes+1] uint4
-    uint8_t *qf4 = nullptr;       // [n_pad128][2G][4][32 B] fp4 operand image for the matrix-core distance kernel
+    uint8_t *qf4 = nullptr;       // fp4 operand image for the matrix-core distance kernels: [n_pad128][2G][4][32 B] (t1, t2, t3, v) for
+                                  // k_jc69_mfma; beside a reference image (DevAlign::ref_f4) the compact tiled form of dist_gemm.hip
     uint8_t *aa_idx = nullptr;    // [n_pad][Lpad16] residue index (20 = gap)
     uint16_t *aa_mask = nullptr;  // [n_pad][Lpad16/16]
     int32_t *self_slot = nullptr; // [n]

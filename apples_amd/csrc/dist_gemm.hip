@@ -26,7 +26,6 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 
-#define GM_TPB 512
 #define GM_T 256      // tile edge: queries and reference slots per workgroup
 #ifndef GM_STRIP
 #define GM_STRIP 4    // reference tiles per strip

@@ -40,6 +40,9 @@ def test_c3_shape_200k_leaves_two_device_batches():
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
     info = eng.describe()
     assert info['n_nodes'] == 399999 and info['n_refs'] == 200000 and info['length'] == 1000
+    # the fused pass of this workload is the GEMM form on the pre-expanded reference image (1 byte per site and slot)
+    assert info['fused_distance_pass'] == 'fp4 gemm, linear threshold', info['fused_distance_pass']
+    assert info['fp4_reference_image_bytes'] == 200192 * 16 * 64
     got = eng.place_sequences(d.query_seqs)          # host buffer in, host buffer out (streamed chunks)
     batch = eng.describe()['batch']
     assert batch < nq, 'expected at least two device batches, got batch = %d' % batch
