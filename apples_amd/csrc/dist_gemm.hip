@@ -1,4 +1,4 @@
-// The fused JC69 pass as a plain fp4 GEMM (default for ACGT- inputs, L <= 2047, singleton clusters).
+// The fused JC69 pass as a plain fp4 GEMM (default for ACGT- inputs, L <= 2046, singleton clusters).
 //
 // Same arithmetic as k_jc69_mfma (dist.hip): every site is a corner of a tetrahedron (components t1, t2, t3 =
 // +-1, 0 for a gap) plus a validity flag v; sum t.t = 3 match - mism and sum v.v = valid.  Differences:
@@ -10,15 +10,14 @@
 //     in LDS (chunk permutation for conflict-free ds_read_b128), three generations deep: the DMA runs two steps
 //     ahead of the MFMAs;
 //   * ONE accumulator set: the v component is multiplied through the block-scaled MFMA with a scale of 2^13 on
-//     the query side, acc = sum t.t + 8192 valid.  With valid <= 2047 both integers decode exactly
+//     the query side, acc = sum t.t + 8192 valid.  With valid <= 2046 both integers decode exactly
 //     (-valid <= sum t.t <= 3 valid: the ranges of neighbouring `valid` do not overlap, and acc < 2^24);
 //   * which makes room for a 64 x 128 wavefront tile (2 x 4 MFMA tiles, 128 accumulator registers) and a
-//     256 x 256 workgroup tile: 24 fragment reads per 32 MFMAs instead of 16 per 16, half the staging bytes
-//     per MFMA;
-//   * workgroups walk the tile grid in strips of 4 reference tiles per XCD (a strip's 2 MB stay in that XCD's
-//     L2 while the query tiles stream past).
-// Epilogue and output format are those of k_jc69_mfma<1> (threshold on the integers, ballot compaction per
-// 64-slot segment, one packed word per survivor).
+//     256 x 256 workgroup tile: 12 fragment reads and 4 DMA pieces per 32 MFMAs and wavefront (k_jc69_mfma: 16
+//     reads, 4 wide stores and the expansion arithmetic per 16 MFMAs);
+//   * persistent workgroups walk the tile grid in strips of 4 reference tiles per XCD.
+// Output format is that of k_jc69_mfma<1> (threshold on the integers, ballot compaction per 64-slot segment, one
+// packed word per survivor); the epilogue decodes on packed fp32 pairs and tests a host-verified linear threshold.
 #include "common.h"
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
