@@ -30,6 +30,9 @@ typedef float v2f_t __attribute__((ext_vector_type(2)));
 #define GM_STRIP 4    // reference tiles per strip
 #endif
 #define GM_VSHIFT 13  // the validity sum rides at 2^13
+#ifndef GM_AUX
+#define GM_AUX 0       // cache policy bits of the DMA loads (experiments: 1 = sc0, 2 = nt)
+#endif
 #define GM_IMG (GM_T * 64)   // bytes of one tile-step image: 256 rows x (t1, t2) x 32 bytes
 
 namespace {
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
             uint8_t *dst = part == 0 ? Aq(g) + (wv * 2 + k) * 1024 : Br(g) + (wv * PB + kb) * 1024;
 #ifndef GM_NO_DMA
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, GM_AUX);
 #endif
         }
     };
