@@ -10,7 +10,7 @@ code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
         "from apples_amd.engine import Engine\n"
         "rng = np.random.default_rng(%d)\n"
         "for c in range(%d):\n"
-        "    n = int(rng.choice([40, 257, 600, 1500, 5000])); L = int(rng.integers(20, 2047)); nq = int(rng.integers(1, 700))\n"
+        "    n = int(rng.choice([40, 257, 600, 1500, 5000, 20000])); L = int(rng.integers(20, 2047)); nq = int(rng.integers(1, 700))\n"
         "    gap = float(rng.choice([0.0, 0.05, 0.3, 0.6])); thr = float(rng.choice([0.05, 0.2, 0.5, 1.2])); b = int(rng.choice([3, 25, 200]))\n"
         "    mb = int(rng.choice([0, 0, 32, 96, 160, 512])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))\n"
         "    d = synth.make_dataset(n, L, nq, gap_rate=gap, seed_tree=100 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])))\n"
