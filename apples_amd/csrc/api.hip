@@ -426,7 +426,7 @@ int big_threshold(const apples_ctx *ctx) {
 }
 
 void free_sweep(Workspace::Sweep &sw) {
-    dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
+    dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.ent); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
     dev_free(sw.ent_f); dev_free(sw.ent_i); dev_free(sw.leaf_g); dev_free(sw.meta);
     sw = Workspace::Sweep();
 }
@@ -481,7 +481,9 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
             if (dev_alloc(ctx, &sw.xe, sw.teams * cap * 18)) return 1;
         return 0;
     }
-    if (!sweep_bits_in_lds(t)) {
+    if (teams_per_wg == 4 && sweep_merge_lists(t)) {
+        if (dev_alloc(ctx, &sw.ent, sw.teams * (cap + 1))) return 1;
+    } else if (!sweep_bits_in_lds(t)) {
         if (dev_alloc(ctx, &sw.map, sw.teams * (int64_t)t.n_nodes)) return 1;
         HIP_TRY(ctx, hipMemsetAsync(sw.map, 0, (size_t)sw.teams * t.n_nodes * 4, ctx->stream));
         if (dev_alloc(ctx, &sw.ver, sw.teams)) return 1;
@@ -730,7 +732,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.tree = ctx->tree;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
-    s.map = sw.map; s.map_ver = sw.ver; s.order = sw.order;
+    s.map = sw.map; s.map_ver = sw.ver; s.order = sw.order; s.ent = sw.ent;
     s.map_bits = 1;
     while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
     if (const char *e = getenv("APPLES_MAP_BITS")) s.map_bits = std::min(30, std::max(s.map_bits, atoi(e)));  // test knob: few tags, early wrap

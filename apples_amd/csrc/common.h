@@ -152,6 +152,7 @@ struct Workspace {
         uint32_t *map = nullptr;  // [teams][n_nodes] big trees: node -> tagged descriptor (sweep.hip NodeMap)
         uint32_t *ver = nullptr;  // [teams] last tag used in the team's map
         int32_t *order = nullptr; // [teams][cap+1] big trees: node ids in compact order
+        int4 *ent = nullptr;      // [teams][cap+1] merge layout (sweep.hip): node, first two valid children, the first one's node id
         int32_t *grp_off = nullptr; // [teams][height+4] level groups in compact order, deepest first
         void *A = nullptr;        // [teams][cap+1] Rec (64 B): S then R tuple, first two valid children, node
         void *B = nullptr;        // [teams][cap+1][6] R values in waiting; trees with polytomies only
@@ -311,6 +312,7 @@ struct SweepArgs {
     uint32_t *map;            // big trees: [teams][n_nodes] tagged node map; nullptr = node bits in LDS
     uint32_t *map_ver;        // [teams] version tags of the maps
     int32_t *order;           // [teams][cap+1]
+    int4 *ent;                // [teams][cap+1] merge layout: nullptr = node map or node bits
     int map_bits;             // payload bits of a map entry; the tag sits above them
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
@@ -351,6 +353,7 @@ int launch_scan_mixed(apples_ctx *ctx, const ScanArgs &small, const ScanArgs &bi
 int launch_scan(apples_ctx *ctx, const ScanArgs &a, int64_t nq, int wgs, int team, hipStream_t st);
 #define SCAN_LDS_LEAVES_SMALL 2048   // per wavefront-sized team (4 per workgroup); 6 bytes of LDS per leaf
 #define SCAN_LDS_LEAVES_BIG 8192     // per workgroup-sized team
+bool sweep_merge_lists(const DevTree &t);  // big binary trees, wavefront-sized teams: level lists by merging, no node map
 bool sweep_bits_in_lds(const DevTree &t);  // the sweep's node bits fit in LDS (else: tagged node map in global scratch)
 int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team, hipStream_t stream = nullptr);
 int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,

@@ -213,12 +213,64 @@ struct SweepShared {
     int cnt[APPLES_TPB / WAVE][4];
     int i[4];
     int w[APPLES_TPB / WAVE];
+    int mk[APPLES_TPB / WAVE][2][WAVE];  // merge layout: the two 64-key windows of a wavefront's merge step
 };
 
 __device__ __forceinline__ void sweep_shared_init(SweepShared &sh) {
     for (int i = threadIdx.x; i < 384; i += APPLES_TPB) sh.pow[i] = (&kPowLogTab[0][0])[i];
     for (int i = threadIdx.x; i < 256; i += APPLES_TPB) sh.pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
     __syncthreads();
+}
+
+// Merge layout (big binary trees, wavefront-sized teams): the next level's list of internal nodes without a node
+// map.  The nodes of one level sorted by node id (= post-order) have their siblings next to each other and their
+// parents in sorted order, so the parents of this level's internal nodes (ent[base .. base + nA), sorted) and of
+// its observed leaves (o_node[lo .. lo + nB), sorted) merged by node id are the next list in sorted order, and a
+// parent's valid children are the run of (at most two) neighbours that name it.  One wavefront merges 64 keys
+// per step through two windows in LDS (merge path: lane p finds the p-th smallest by a binary search on the
+// diagonal); a run is never cut: a step whose last key opens a run leaves it to the next step.
+// Entry = {node, first valid child, second valid child or 0, node id of the first valid child}; child descriptors as
+// everywhere (> 0: compact index + 1 of an internal node, <= -2: -(j + 2) for observed leaf j).  Returns the number
+// of entries written at ent[next_base ...].
+__device__ __forceinline__ int merge_parents(int4 *__restrict__ ent, int base, int nA, const int32_t *__restrict__ o_node,
+                                             int lo, int nB, int next_base, const int32_t *__restrict__ parent_of,
+                                             int *mk_a, int *mk_b, int lane) {
+    int out = 0, ia = 0, ib = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    while (ia < nA || ib < nB) {
+        const int rem = (nA - ia) + (nB - ib);
+        const int wa = min(nA - ia, WAVE), wb = min(nB - ib, WAVE);
+        mk_a[lane] = lane < wa ? ent[base + ia + lane].x : 0x7fffffff;
+        mk_b[lane] = lane < wb ? o_node[lo + ib + lane] : 0x7fffffff;
+        __builtin_amdgcn_wave_barrier();
+        const int tot = min(wa + wb, WAVE);
+        const bool active = lane < tot;
+        int i_lo = max(0, lane - wb), i_hi = min(lane, wa);  // i = keys of the first window among the lane smallest
+        while (i_lo < i_hi) {
+            const int i = (i_lo + i_hi) >> 1;
+            if (mk_a[i] < mk_b[lane - 1 - i]) i_lo = i + 1; else i_hi = i;
+        }
+        const int i = i_lo, j = lane - i_lo;
+        const int ka = i < wa ? mk_a[i] : 0x7fffffff, kb = j < wb ? mk_b[j] : 0x7fffffff;
+        const bool from_a = ka < kb;
+        const int key = from_a ? ka : kb;
+        const int desc = from_a ? base + ia + i + 1 : -(lo + ib + j) - 2;
+        const int par = active ? parent_of[key] : -3;
+        const int prev = __shfl_up(par, 1, WAVE);
+        const bool first = active && (lane == 0 || par != prev);
+        const int last_first = __shfl(first ? 1 : 0, tot - 1, WAVE);
+        const int use = (rem > tot && last_first && tot > 1) ? tot - 1 : tot;
+        const int next_desc = __shfl_down(desc, 1, WAVE), next_first = __shfl_down(first ? 1 : 0, 1, WAVE);
+        const bool mine = first && lane < use;
+        const unsigned long long fm = __ballot(mine);
+        if (mine) ent[next_base + out + __popcll(fm & below)] = make_int4(par, desc, (lane + 1 < use && !next_first) ? next_desc : 0, key);
+        const int ca = __popcll(__ballot(lane < use && from_a));
+        ia += ca;
+        ib += use - ca;
+        out += __popcll(fm);
+        __builtin_amdgcn_wave_barrier();
+    }
+    return out;
 }
 
 template <int M, int TEAM>
@@ -242,6 +294,9 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
     // Two ways to know which nodes are in the subtree.  Small trees: the level-ordered bit space,
     // a few KB of LDS per team.  Big trees: the tagged node map in global scratch.
     const bool umap = a.map != nullptr;
+    const bool umerge = TEAM == WAVE && a.ent != nullptr;  // level lists by merging (merge_parents), no map, no bits
+    int4 *ent = umerge ? a.ent + team * (cap + 1) : nullptr;
+    int *mk_a = sh.mk[threadIdx.x / WAVE][0], *mk_b = sh.mk[threadIdx.x / WAVE][1];
     NodeBits nb;
     NodeMap map;
     const int bm_words = T.bm_words;
@@ -252,6 +307,9 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
         map.ver = a.map_ver[team];
         order = a.order + team * (cap + 1);
         nb.bm = nullptr; nb.pre = nullptr;
+    } else if (umerge) {
+        nb.bm = nullptr; nb.pre = nullptr;
+        map.m = nullptr; map.vb = 0; map.ver = 0;
     } else {  // dynamic LDS: [teams of this workgroup][bm_words] words, then the ranks
         extern __shared__ unsigned long long dyn_lds[];
         nb.bm = dyn_lds + (size_t)team_in_wg * bm_words;
@@ -322,6 +380,8 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
             ++map.ver;
             if (tid < 3) sh_cnt[tid] = 0;
             for (int j = tid; j < n; j += TEAM) map.set_leaf(o_node[j], j);
+        } else if (umerge) {
+            if (tid < 3) sh_cnt[tid] = 0;
         } else {
             for (int i = tid; i < bm_words; i += TEAM) nb.bm[i] = 0;  // unroll_changes of the previous query
             team_sync<TEAM>();
@@ -338,7 +398,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
             const int lo = cg[lvl + 1], hi = cg[lvl];  // observed leaves of this level: obs[lo, hi)
             const int n_leaf = hi - lo;
             int w0 = 0, w1 = 0;
-            if (!umap) {
+            if (!umap && !umerge) {
                 // all children of this level's nodes have reported: rank the level's two blocks
                 w0 = lvlw[2 * lvl]; w1 = lvlw[2 * lvl + 1];
                 const int wl1 = lvlw[2 * lvl + 2];
@@ -347,10 +407,10 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                 team_sync<TEAM>();
             }
             if (n_par + n_leaf == 1 && hi == n) {  // one node left in the frontier: the LCA (Subtree.py:36-43)
-                lca = (n_par == 1) ? (umap ? order[base] : T.lnode[kth_in_block(nb, w0, w1, 0)]) : o_node[lo];
+                lca = (n_par == 1) ? (umap ? order[base] : umerge ? ent[base].x : T.lnode[kth_in_block(nb, w0, w1, 0)]) : o_node[lo];
                 break;
             }
-            if (cap < nn && (int64_t)base + (umap ? 2 * (int64_t)n_par + n_leaf : (int64_t)n_par) > cap) { overflow = true; break; }
+            if (cap < nn && (int64_t)base + (umap || umerge ? 2 * (int64_t)n_par + n_leaf : (int64_t)n_par) > cap) { overflow = true; break; }
             if (tid == 0) { grp_off[G] = base; if (umap) sh_cnt[(G + 1) % 3] = 0; }
             int *next_cnt = &sh_cnt[G % 3];
             const int next_base = base + n_par;
@@ -380,14 +440,22 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                 Rec r;
                 if (active) {
                     // (bit space: the k-th set bit's position leads straight to the record)
-                    const NodeRec nr = umap ? NR[order[base + k]] : T.rec_l[kth_in_block(nb, w0, w1, k)];
+                    int4 e = make_int4(0, 0, 0, 0);
+                    if (umerge) e = ent[base + k];
+                    const NodeRec nr = umap ? NR[order[base + k]] : umerge ? NR[e.x] : T.rec_l[kth_in_block(nb, w0, w1, k)];
                     r.node = nr.node;
                     parent = nr.parent;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) r.T[c] = 0;
                     if (nr.nchild <= 2) {
-                        const int m0 = nr.nchild >= 1 ? desc_of(nr.c0, nr.c0pos, nr.kleaf & 1u, kid_base, lo_kids) : 0;
-                        const int m1 = nr.nchild >= 2 ? desc_of(nr.c1, nr.c1pos, nr.kleaf & 2u, kid_base, lo_kids) : 0;
+                        int m0, m1;
+                        if (umerge) {  // the entry names the valid children; a single one is the first or the second child
+                            m0 = (e.z != 0 || e.w == nr.c0) ? e.y : 0;
+                            m1 = e.z != 0 ? e.z : (e.w == nr.c0 ? 0 : e.y);
+                        } else {
+                            m0 = nr.nchild >= 1 ? desc_of(nr.c0, nr.c0pos, nr.kleaf & 1u, kid_base, lo_kids) : 0;
+                            m1 = nr.nchild >= 2 ? desc_of(nr.c1, nr.c1pos, nr.kleaf & 2u, kid_base, lo_kids) : 0;
+                        }
                         const int nk = (m0 != 0) + (m1 != 0);
                         const double coef = BME ? 1.0 / (double)nk : 1.0;  // apples/BME.py:20
                         r.k0 = m0 ? m0 : m1;
@@ -433,7 +501,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         }
                         r.meta = (uint32_t)nk | META_POLY;
                     }
-                    if (!umap && nr.ppos >= 0) nb.set(nr.ppos);  // tell the parent
+                    if (!umap && !umerge && nr.ppos >= 0) nb.set(nr.ppos);  // tell the parent
                 }
                 if (staged) team_sync<TEAM>();  // everybody has read the level below
                 __builtin_amdgcn_wave_barrier();
@@ -463,9 +531,12 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
             }
             team_sync<TEAM>();
             prev_staged = n_par > 0 && n_par <= TEAM;
+            int merged = 0;
+            if (umerge) merged = merge_parents(ent, base, n_par, o_node, lo, n_leaf, next_base, T.parent, mk_a, mk_b, lane);
             kid_base = base;
             base = next_base;
             if (umap) n_par = *next_cnt;
+            if (umerge) n_par = merged;
             ++G;
             --lvl;
         }
@@ -485,8 +556,15 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
             int nk = 0, k0 = 0, k1 = 0, first = -1;
             const int klo = lvl + 2 <= T.height + 1 ? cg[lvl + 2] : 0;
             if (nr.nchild <= 2) {
-                const int m0 = nr.nchild >= 1 ? desc_of(nr.c0, nr.c0pos, nr.kleaf & 1u, kid_base, klo) : 0;
-                const int m1 = nr.nchild >= 2 ? desc_of(nr.c1, nr.c1pos, nr.kleaf & 2u, kid_base, klo) : 0;
+                int m0, m1;
+                if (umerge) {
+                    const int4 e = nr.nchild > 0 ? ent[VI] : make_int4(0, 0, 0, 0);
+                    m0 = (e.z != 0 || e.w == nr.c0) ? e.y : 0;
+                    m1 = e.z != 0 ? e.z : (e.w == nr.c0 ? 0 : e.y);
+                } else {
+                    m0 = nr.nchild >= 1 ? desc_of(nr.c0, nr.c0pos, nr.kleaf & 1u, kid_base, klo) : 0;
+                    m1 = nr.nchild >= 2 ? desc_of(nr.c1, nr.c1pos, nr.kleaf & 2u, kid_base, klo) : 0;
+                }
                 nk = (m0 != 0) + (m1 != 0);
                 k0 = m0 ? m0 : m1;
                 k1 = (m0 && m1) ? m1 : 0;
@@ -711,6 +789,11 @@ __global__ __launch_bounds__(APPLES_TPB, APPLES_SWEEP_WAVES) void k_sweep_mixed(
         __syncthreads();
     }
     sweep_team<M, WAVE>(small, nq, sh);
+}
+
+bool sweep_merge_lists(const DevTree &t) {
+    static const bool on = getenv("APPLES_SWEEP_MERGE") != nullptr;  // experiment: level lists by merging instead of the node map
+    return on && !t.scan && t.max_children <= 2 && !sweep_bits_in_lds(t);
 }
 
 bool sweep_bits_in_lds(const DevTree &t) {
