@@ -481,7 +481,7 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
             if (dev_alloc(ctx, &sw.xe, sw.teams * cap * 18)) return 1;
         return 0;
     }
-    if (teams_per_wg == 4 && sweep_merge_lists(t)) {
+    if (sweep_merge_lists(t)) {
         if (dev_alloc(ctx, &sw.ent, sw.teams * (cap + 1))) return 1;
     } else if (!sweep_bits_in_lds(t)) {
         if (dev_alloc(ctx, &sw.map, sw.teams * (int64_t)t.n_nodes)) return 1;
@@ -576,11 +576,11 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     int64_t nn = t.n_nodes;
     // big trees keep a node map of n_nodes ints per team (<= ~8 GiB in total)
     // (2 048 teams are resident at two wavefronts per SIMD; 3 072 measured best at both 10 k and 200 k leaves)
-    int64_t teams = (t.scan || sweep_bits_in_lds(t)) ? 3072 : std::min<int64_t>(3072, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
+    int64_t teams = (t.scan || sweep_bits_in_lds(t) || sweep_merge_lists(t)) ? 3072 : std::min<int64_t>(3072, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
-    int64_t per_node = t.scan ? 120 + (xe ? 144 : 0) : 68 + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
+    int64_t per_node = t.scan ? 120 + (xe ? 144 : 0) : 68 + (sweep_merge_lists(t) ? 12 : 0) + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
     if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, t.scan ? 0 : std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold(ctx))), xe)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
@@ -1700,7 +1700,7 @@ const char *apples_describe(apples_ctx *ctx) {
              "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"n_rows\": %lld, "
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
              "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\", "
-             "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld}",
+             "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld, \"sweep_layout\": \"%s\"}",
              name, cus, ctx->tree.n_nodes, ctx->tree.height, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
              (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
@@ -1708,7 +1708,9 @@ const char *apples_describe(apples_ctx *ctx) {
              // which kernel the fused pass of ACGT- query blocks runs on (dist_gemm.hip / dist.hip k_jc69_mfma / k_jc69 or k_scoredist)
              dist_gemm_usable(ctx) ? (ctx->gemm_thr.ok ? "fp4 gemm, linear threshold" : "fp4 gemm, threshold table")
                                    : (a.planes == 2 && dist_mfma_enabled() ? "fp4 mfma, bit-plane fed" : "valu"),
-             (long long)(a.ref_f4 ? a.slots_pad * (int64_t)a.G * 128 : 0));
+             (long long)(a.ref_f4 ? a.slots_pad * (int64_t)a.G * 128 : 0),
+             // how the level-loop sweep knows a query's subtree: merged level lists / node bits in LDS / tagged node map
+             ctx->tree.scan ? "scan" : sweep_merge_lists(ctx->tree) ? "merge" : sweep_bits_in_lds(ctx->tree) ? "bits" : "map");
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

@@ -213,7 +213,9 @@ struct SweepShared {
     int cnt[APPLES_TPB / WAVE][4];
     int i[4];
     int w[APPLES_TPB / WAVE];
-    int mk[APPLES_TPB / WAVE][2][WAVE];  // merge layout: the two 64-key windows of a wavefront's merge step
+    int mk[APPLES_TPB / WAVE][2][WAVE];  // merge layout: the two 64-key windows of a wavefront's merge step (a workgroup-sized team: two 256-key windows)
+    int mx[2][APPLES_TPB];               // merge layout, workgroup-sized team: parents and descriptors of a step's keys
+    int mcnt[2][APPLES_TPB / WAVE];      // ... per-wavefront counts of a step
 };
 
 __device__ __forceinline__ void sweep_shared_init(SweepShared &sh) {
@@ -273,6 +275,62 @@ __device__ __forceinline__ int merge_parents(int4 *__restrict__ ent, int base, i
     return out;
 }
 
+// The same for a workgroup-sized team: 256 keys per step, neighbours and counts through LDS instead of shuffles.
+__device__ __forceinline__ int merge_parents_wg(int4 *__restrict__ ent, int base, int nA, const int32_t *__restrict__ o_node,
+                                                int lo, int nB, int next_base, const int32_t *__restrict__ parent_of,
+                                                SweepShared &sh) {
+    int *mk_a = &sh.mk[0][0][0], *mk_b = mk_a + APPLES_TPB;
+    int *m_par = sh.mx[0], *m_desc = sh.mx[1];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    int out = 0, ia = 0, ib = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    while (ia < nA || ib < nB) {
+        const int rem = (nA - ia) + (nB - ib);
+        const int wa = min(nA - ia, APPLES_TPB), wb = min(nB - ib, APPLES_TPB);
+        mk_a[tid] = tid < wa ? ent[base + ia + tid].x : 0x7fffffff;
+        mk_b[tid] = tid < wb ? o_node[lo + ib + tid] : 0x7fffffff;
+        __syncthreads();
+        const int tot = min(wa + wb, APPLES_TPB);
+        const bool active = tid < tot;
+        int i_lo = max(0, tid - wb), i_hi = min(tid, wa);
+        while (i_lo < i_hi) {
+            const int i = (i_lo + i_hi) >> 1;
+            if (mk_a[i] < mk_b[tid - 1 - i]) i_lo = i + 1; else i_hi = i;
+        }
+        const int i = i_lo, j = tid - i_lo;
+        const int ka = i < wa ? mk_a[i] : 0x7fffffff, kb = j < wb ? mk_b[j] : 0x7fffffff;
+        const bool from_a = ka < kb;
+        const int key = from_a ? ka : kb;
+        const int desc = from_a ? base + ia + i + 1 : -(lo + ib + j) - 2;
+        const int par = active ? parent_of[key] : -3;
+        m_par[tid] = par;
+        m_desc[tid] = desc;
+        __syncthreads();
+        const bool first = active && (tid == 0 || par != m_par[tid - 1]);
+        const bool last_first = tot == 1 || m_par[tot - 1] != m_par[tot - 2];
+        const int use = (rem > tot && last_first && tot > 1) ? tot - 1 : tot;
+        const bool next_first = tid + 1 >= tot || m_par[tid + 1] != par;
+        const int next_desc = tid + 1 < APPLES_TPB ? m_desc[tid + 1] : 0;
+        const bool mine = first && tid < use;
+        const unsigned long long fm = __ballot(mine), am = __ballot(tid < use && from_a);
+        if (lane == 0) { sh.mcnt[0][wave] = __popcll(fm); sh.mcnt[1][wave] = __popcll(am); }
+        __syncthreads();
+        int before = 0, total = 0, ca = 0;
+#pragma unroll
+        for (int w = 0; w < APPLES_TPB / WAVE; ++w) {
+            if (w < wave) before += sh.mcnt[0][w];
+            total += sh.mcnt[0][w];
+            ca += sh.mcnt[1][w];
+        }
+        if (mine) ent[next_base + out + before + __popcll(fm & below)] = make_int4(par, desc, (tid + 1 < use && !next_first) ? next_desc : 0, key);
+        ia += ca;
+        ib += use - ca;
+        out += total;
+        __syncthreads();
+    }
+    return out;
+}
+
 template <int M, int TEAM>
 __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
     constexpr int TEAMS_PER_WG = APPLES_TPB / TEAM;
@@ -294,7 +352,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
     // Two ways to know which nodes are in the subtree.  Small trees: the level-ordered bit space,
     // a few KB of LDS per team.  Big trees: the tagged node map in global scratch.
     const bool umap = a.map != nullptr;
-    const bool umerge = TEAM == WAVE && a.ent != nullptr;  // level lists by merging (merge_parents), no map, no bits
+    const bool umerge = a.ent != nullptr;  // level lists by merging (merge_parents), no map, no bits
     int4 *ent = umerge ? a.ent + team * (cap + 1) : nullptr;
     int *mk_a = sh.mk[threadIdx.x / WAVE][0], *mk_b = sh.mk[threadIdx.x / WAVE][1];
     NodeBits nb;
@@ -532,7 +590,8 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
             team_sync<TEAM>();
             prev_staged = n_par > 0 && n_par <= TEAM;
             int merged = 0;
-            if (umerge) merged = merge_parents(ent, base, n_par, o_node, lo, n_leaf, next_base, T.parent, mk_a, mk_b, lane);
+            if (umerge) merged = TEAM == WAVE ? merge_parents(ent, base, n_par, o_node, lo, n_leaf, next_base, T.parent, mk_a, mk_b, lane)
+                                              : merge_parents_wg(ent, base, n_par, o_node, lo, n_leaf, next_base, T.parent, sh);
             kid_base = base;
             base = next_base;
             if (umap) n_par = *next_cnt;
@@ -792,12 +851,16 @@ __global__ __launch_bounds__(APPLES_TPB, APPLES_SWEEP_WAVES) void k_sweep_mixed(
 }
 
 bool sweep_merge_lists(const DevTree &t) {
-    static const bool on = getenv("APPLES_SWEEP_MERGE") != nullptr;  // experiment: level lists by merging instead of the node map
-    return on && !t.scan && t.max_children <= 2 && !sweep_bits_in_lds(t);
+    // knobs: APPLES_NO_SWEEP_MERGE = the tagged node map for big trees as before; APPLES_SWEEP_MERGE = the merge layout
+    // also where the node bits would fit in LDS (tests run it on small trees)
+    const bool off = getenv("APPLES_NO_SWEEP_MERGE") != nullptr, force = getenv("APPLES_SWEEP_MERGE") != nullptr;
+    if (off || t.scan || t.max_children > 2 || getenv("APPLES_NODE_MAP")) return false;
+    return force || (size_t)4 * t.bm_words * 12 > 40 * 1024;
 }
 
 bool sweep_bits_in_lds(const DevTree &t) {
     if (getenv("APPLES_NODE_MAP")) return false;  // test knob: exercise the big-tree layout on a small tree
+    if (getenv("APPLES_SWEEP_MERGE") && t.max_children <= 2 && !t.scan && !getenv("APPLES_NO_SWEEP_MERGE")) return false;  // (forced merge layout)
     return (size_t)4 * t.bm_words * 12 <= 40 * 1024;
 }
 static size_t dyn_lds_bytes(const DevTree &t, int teams_per_wg) {

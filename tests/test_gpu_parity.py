@@ -336,15 +336,18 @@ def _random_newick(rng, n_leaves, shape):
     return nodes[0].rsplit(':', 1)[0] + ';'
 
 
-@pytest.mark.parametrize('layout', ['bits', 'map'])
+@pytest.mark.parametrize('layout', ['bits', 'map', 'merge'])
 def test_random_trees_per_edge_bit_parity_with_c_oracle(layout, monkeypatch):
     """Many small random trees (binary, caterpillar, polytomous; zero and tiny branch lengths) and
     random observed sets of every size from 2 up: valid set, LCA, S, R and the 2x2 solutions must
     equal the C oracle's bit for bit, placements edge for edge (ties resolved by residual).  Both
-    node-lookup layouts of the sweep (LDS bit space; tagged node map of big trees)."""
+    node-lookup layouts of the sweep (LDS bit space; tagged node map of big trees) and the merged level lists that
+    big binary trees get by default (forced here; the polytomous shapes fall back to the bit space)."""
     from oracle_c import COracle
     if layout == 'map':
         monkeypatch.setenv('APPLES_NODE_MAP', '1')
+    if layout == 'merge':
+        monkeypatch.setenv('APPLES_SWEEP_MERGE', '1')
     from apples_amd.tree import parse_newick
     rng = np.random.default_rng(2024)
     n_cases = 0
@@ -353,6 +356,8 @@ def test_random_trees_per_edge_bit_parity_with_c_oracle(layout, monkeypatch):
             tree = parse_newick(_random_newick(rng, n_leaves, shape))
             leaves = tree.leaves
             eng = Engine(tree, None, method='OLS')
+            if layout == 'merge' and shape != 'bushy':
+                assert eng.describe()['sweep_layout'] == 'merge'
             for m in METHODS:
                 eng.set_options(method=m, criterion='MLSE')
                 co = COracle(tree, method=m)

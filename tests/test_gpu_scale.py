@@ -59,7 +59,7 @@ def test_c2_reference_size_against_c_oracle(c2, method, criterion):
     eng.close()
 
 
-@pytest.mark.parametrize('layout', ['scan', 'bits', 'map'])
+@pytest.mark.parametrize('layout', ['scan', 'bits', 'map', 'merge'])
 def test_all_observed_stress_and_batching(c2, layout, monkeypatch):
     """-f huge: every leaf observed (worst case for both kernels, V = 2N-2; more than 4 096 observed
     leaves send every query to the workgroup-sized teams); also forces several device batches and
@@ -70,12 +70,15 @@ def test_all_observed_stress_and_batching(c2, layout, monkeypatch):
         monkeypatch.setenv('APPLES_SWEEP_SCAN', '1')
     if layout == 'map':
         monkeypatch.setenv('APPLES_NODE_MAP', '1')
+    if layout == 'merge':
+        monkeypatch.setenv('APPLES_SWEEP_MERGE', '1')
     nthreads = len(os.sched_getaffinity(0))
     co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', threshold=1e9, lut=jc69_lut(1000, 0.001), threads=nthreads)
     want = co.place_sequences(d.query_seqs[:96])
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS', threshold=1e9, max_batch=32)
     got = eng.place_sequences(d.query_seqs[:96])
     assert eng.describe()['batch'] == 32 and eng.describe()['sweep'] == ('scan' if layout == 'scan' else 'levels')
+    assert eng.describe()['sweep_layout'] == layout
     _compare(got, want, co, d, nodes, 'all observed')
     assert (got['n_valid'] >= 2 * 10000 - 3).all()
     eng.close()
@@ -156,6 +159,7 @@ def test_fused_and_full_row_selection_paths_agree(c2):
     outs = []
     for env in ({}, {'APPLES_NO_FUSE': '1'}, {'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_TEAM': '256'},
                 {'APPLES_TOPUP_MIN_ROWS': '0'}, {'APPLES_NO_DIST_MFMA': '1'}, {'APPLES_NO_DIST_GEMM': '1'}, {'APPLES_GEMM_TABLE': '1'}, {'APPLES_GEMM_QT': '128'}, {'APPLES_GEMM_QT': '128', 'APPLES_GEMM_TABLE': '1'}, {'APPLES_SWEEP_SCAN': '1'},
+                {'APPLES_SWEEP_MERGE': '1'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_SWEEP_TEAM': '256'},
                 {'APPLES_SWEEP_SCAN': '1', 'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_SCAN': '1', 'APPLES_SWEEP_TEAM': '256'}):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-2000:]

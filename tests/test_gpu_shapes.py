@@ -43,6 +43,7 @@ def test_c3_shape_200k_leaves_two_device_batches():
     # the fused pass of this workload is the GEMM form on the pre-expanded reference image (1 byte per site and slot)
     assert info['fused_distance_pass'] == 'fp4 gemm, linear threshold', info['fused_distance_pass']
     assert info['fp4_reference_image_bytes'] == 200192 * 16 * 64
+    assert info['sweep_layout'] == 'merge'  # level lists by merging: the default of big binary trees
     got = eng.place_sequences(d.query_seqs)          # host buffer in, host buffer out (streamed chunks)
     batch = eng.describe()['batch']
     assert batch < nq, 'expected at least two device batches, got batch = %d' % batch
