@@ -230,7 +230,9 @@ __device__ __forceinline__ void sweep_shared_init(SweepShared &sh) {
 // its observed leaves (o_node[lo .. lo + nB), sorted) merged by node id are the next list in sorted order, and a
 // parent's valid children are the run of (at most two) neighbours that name it.  One wavefront merges 64 keys
 // per step through two windows in LDS (merge path: lane p finds the p-th smallest by a binary search on the
-// diagonal); a run is never cut: a step whose last key opens a run leaves it to the next step.
+// diagonal); the first two keys of a run are never separated: a step whose last key opens a run leaves it to the
+// next step (longer runs -- polytomies -- may continue into the next step; their parents look their children up
+// by binary search in the sorted lists instead of reading them from the entry).
 // Entry = {node, first valid child, second valid child or 0, node id of the first valid child}; child descriptors as
 // everywhere (> 0: compact index + 1 of an internal node, <= -2: -(j + 2) for observed leaf j).  Returns the number
 // of entries written at ent[next_base ...].
@@ -238,6 +240,7 @@ __device__ __forceinline__ int merge_parents(int4 *__restrict__ ent, int base, i
                                              int lo, int nB, int next_base, const int32_t *__restrict__ parent_of,
                                              int *mk_a, int *mk_b, int lane) {
     int out = 0, ia = 0, ib = 0;
+    int carry = -2;  // parent of the last key of the previous step (a polytomy's run may continue across steps)
     const unsigned long long below = (1ull << lane) - 1ull;
     while (ia < nA || ib < nB) {
         const int rem = (nA - ia) + (nB - ib);
@@ -259,7 +262,7 @@ __device__ __forceinline__ int merge_parents(int4 *__restrict__ ent, int base, i
         const int desc = from_a ? base + ia + i + 1 : -(lo + ib + j) - 2;
         const int par = active ? parent_of[key] : -3;
         const int prev = __shfl_up(par, 1, WAVE);
-        const bool first = active && (lane == 0 || par != prev);
+        const bool first = active && par != (lane == 0 ? carry : prev);
         const int last_first = __shfl(first ? 1 : 0, tot - 1, WAVE);
         const int use = (rem > tot && last_first && tot > 1) ? tot - 1 : tot;
         const int next_desc = __shfl_down(desc, 1, WAVE), next_first = __shfl_down(first ? 1 : 0, 1, WAVE);
@@ -267,6 +270,7 @@ __device__ __forceinline__ int merge_parents(int4 *__restrict__ ent, int base, i
         const unsigned long long fm = __ballot(mine);
         if (mine) ent[next_base + out + __popcll(fm & below)] = make_int4(par, desc, (lane + 1 < use && !next_first) ? next_desc : 0, key);
         const int ca = __popcll(__ballot(lane < use && from_a));
+        carry = __shfl(par, use - 1, WAVE);
         ia += ca;
         ib += use - ca;
         out += __popcll(fm);
@@ -283,6 +287,7 @@ __device__ __forceinline__ int merge_parents_wg(int4 *__restrict__ ent, int base
     int *m_par = sh.mx[0], *m_desc = sh.mx[1];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     int out = 0, ia = 0, ib = 0;
+    int carry = -2;
     const unsigned long long below = (1ull << lane) - 1ull;
     while (ia < nA || ib < nB) {
         const int rem = (nA - ia) + (nB - ib);
@@ -306,8 +311,8 @@ __device__ __forceinline__ int merge_parents_wg(int4 *__restrict__ ent, int base
         m_par[tid] = par;
         m_desc[tid] = desc;
         __syncthreads();
-        const bool first = active && (tid == 0 || par != m_par[tid - 1]);
-        const bool last_first = tot == 1 || m_par[tot - 1] != m_par[tot - 2];
+        const bool first = active && par != (tid == 0 ? carry : m_par[tid - 1]);
+        const bool last_first = m_par[tot - 1] != (tot == 1 ? carry : m_par[tot - 2]);
         const int use = (rem > tot && last_first && tot > 1) ? tot - 1 : tot;
         const bool next_first = tid + 1 >= tot || m_par[tid + 1] != par;
         const int next_desc = tid + 1 < APPLES_TPB ? m_desc[tid + 1] : 0;
@@ -323,6 +328,7 @@ __device__ __forceinline__ int merge_parents_wg(int4 *__restrict__ ent, int base
             ca += sh.mcnt[1][w];
         }
         if (mine) ent[next_base + out + before + __popcll(fm & below)] = make_int4(par, desc, (tid + 1 < use && !next_first) ? next_desc : 0, key);
+        carry = m_par[use - 1];
         ia += ca;
         ib += use - ca;
         out += total;
@@ -378,7 +384,23 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
     const int32_t *__restrict__ lvlw = T.lvlw;
     const int2 *__restrict__ npos = reinterpret_cast<const int2 *>(T.npos);
     // descriptor of node v (tree record position lpos / leaf flag), whichever layout is in use
-    auto desc_of = [&](int v, int lpos, bool leaf, int base_int, int lo_leaf) -> int {
+    const int32_t *cur_obs = nullptr;  // the current query's observed leaves (set per query)
+    // (merge layout: polytomies and the HYBRID re-ranking -- by binary search in the node's level: its observed leaves
+    // o_node[lo_leaf, hi_leaf) and its entries ent[base_int, end_int), both sorted by node id)
+    auto desc_of = [&](int v, int lpos, bool leaf, int base_int, int lo_leaf, int end_int, int hi_leaf) -> int {
+        if (umerge) {
+            int l = leaf ? lo_leaf : base_int, h = leaf ? hi_leaf : end_int;
+            while (l < h) {
+                const int mid = (l + h) >> 1;
+                const int key = leaf ? cur_obs[mid] : ent[mid].x;
+                if (key < v) l = mid + 1; else h = mid;
+            }
+            const int end = leaf ? hi_leaf : end_int;
+            if (l >= end) return 0;
+            const int key = leaf ? cur_obs[l] : ent[l].x;
+            if (key != v) return 0;
+            return leaf ? -l - 2 : l + 1;
+        }
         return umap ? map.get(v) : nb.desc_at(lpos, leaf, base_int, lo_leaf);
     };
     Rec *rec = reinterpret_cast<Rec *>(a.A) + team * (cap + 1);
@@ -418,6 +440,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
         if (n == 0) continue;
         if (TEAM == WAVE && !a.work_list && !a.cls_list && n > a.big_threshold) continue;  // listed for a workgroup-sized team
         const int32_t *o_node = a.obs_node + q * a.obs_cap;
+        cur_obs = o_node;
         const double *o_dist = a.obs_dist + q * a.obs_cap;
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
 
@@ -511,8 +534,8 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                             m0 = (e.z != 0 || e.w == nr.c0) ? e.y : 0;
                             m1 = e.z != 0 ? e.z : (e.w == nr.c0 ? 0 : e.y);
                         } else {
-                            m0 = nr.nchild >= 1 ? desc_of(nr.c0, nr.c0pos, nr.kleaf & 1u, kid_base, lo_kids) : 0;
-                            m1 = nr.nchild >= 2 ? desc_of(nr.c1, nr.c1pos, nr.kleaf & 2u, kid_base, lo_kids) : 0;
+                            m0 = nr.nchild >= 1 ? desc_of(nr.c0, nr.c0pos, nr.kleaf & 1u, kid_base, lo_kids, base, lo) : 0;
+                            m1 = nr.nchild >= 2 ? desc_of(nr.c1, nr.c1pos, nr.kleaf & 2u, kid_base, lo_kids, base, lo) : 0;
                         }
                         const int nk = (m0 != 0) + (m1 != 0);
                         const double coef = BME ? 1.0 / (double)nk : 1.0;  // apples/BME.py:20
@@ -540,14 +563,14 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         r.k0 = r.k1 = 0;
                         const int cb = T.child_off[r.node], ce = cb + nr.nchild;
                         for (int ci = cb; ci < ce; ++ci) {
-                            const int mc = desc_of(T.child_idx[ci], npos[T.child_idx[ci]].x, NR[T.child_idx[ci]].nchild == 0, kid_base, lo_kids);
+                            const int mc = desc_of(T.child_idx[ci], npos[T.child_idx[ci]].x, NR[T.child_idx[ci]].nchild == 0, kid_base, lo_kids, base, lo);
                             if (mc != 0) { if (nk == 0) r.k0 = mc; else if (nk == 1) r.k1 = mc; ++nk; }
                         }
                         const double coef = BME ? 1.0 / (double)nk : 1.0;
                         for (int ci = cb; ci < ce; ++ci) {
                             const int cn = T.child_idx[ci];
                             const NodeRec cr = NR[cn];
-                            const int mc = desc_of(cn, cr.lpos, cr.nchild == 0, kid_base, lo_kids);
+                            const int mc = desc_of(cn, cr.lpos, cr.nchild == 0, kid_base, lo_kids, base, lo);
                             if (mc != 0) {
                                 Kid kd;
                                 load_kid<M>(mc, cn, cr.e, rec, o_dist, kd);
@@ -621,8 +644,8 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                     m0 = (e.z != 0 || e.w == nr.c0) ? e.y : 0;
                     m1 = e.z != 0 ? e.z : (e.w == nr.c0 ? 0 : e.y);
                 } else {
-                    m0 = nr.nchild >= 1 ? desc_of(nr.c0, nr.c0pos, nr.kleaf & 1u, kid_base, klo) : 0;
-                    m1 = nr.nchild >= 2 ? desc_of(nr.c1, nr.c1pos, nr.kleaf & 2u, kid_base, klo) : 0;
+                    m0 = nr.nchild >= 1 ? desc_of(nr.c0, nr.c0pos, nr.kleaf & 1u, kid_base, klo, VI, cg[lvl + 1]) : 0;
+                    m1 = nr.nchild >= 2 ? desc_of(nr.c1, nr.c1pos, nr.kleaf & 2u, kid_base, klo, VI, cg[lvl + 1]) : 0;
                 }
                 nk = (m0 != 0) + (m1 != 0);
                 k0 = m0 ? m0 : m1;
@@ -631,7 +654,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
             } else {
                 const int cb = T.child_off[lca];
                 for (int ci = cb; ci < cb + nr.nchild; ++ci) {
-                    const int mc = desc_of(T.child_idx[ci], npos[T.child_idx[ci]].x, NR[T.child_idx[ci]].nchild == 0, kid_base, klo);
+                    const int mc = desc_of(T.child_idx[ci], npos[T.child_idx[ci]].x, NR[T.child_idx[ci]].nchild == 0, kid_base, klo, VI, cg[lvl + 1]);
                     if (mc != 0) { if (nk == 0) k0 = mc; else if (nk == 1) k1 = mc; ++nk; }
                 }
             }
@@ -714,7 +737,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                     for (int ci = cb; ci < ce; ++ci) {
                         const int cn = T.child_idx[ci];
                         const NodeRec cr = NR[cn];
-                        const int mc = desc_of(cn, cr.lpos, cr.nchild == 0, kb, klo);
+                        const int mc = desc_of(cn, cr.lpos, cr.nchild == 0, kb, klo, g0, cg[lvl_first - g + 1]);
                         if (mc == 0) continue;
                         double acc[6];
 #pragma unroll
@@ -723,7 +746,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                             if (cj == ci) continue;
                             const int sn = T.child_idx[cj];
                             const NodeRec sr = NR[sn];
-                            const int ms = desc_of(sn, sr.lpos, sr.nchild == 0, kb, klo);
+                            const int ms = desc_of(sn, sr.lpos, sr.nchild == 0, kb, klo, g0, cg[lvl_first - g + 1]);
                             if (ms != 0) {
                                 Kid sk;
                                 load_kid<M>(ms, sn, sr.e, rec, o_dist, sk);
@@ -742,7 +765,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                         finish_kid(mc, kr, acc, true);
                     }
                     for (int ci = cb; ci < ce; ++ci) {  // all siblings done: S -> R in place
-                        const int mc = desc_of(T.child_idx[ci], npos[T.child_idx[ci]].x, NR[T.child_idx[ci]].nchild == 0, kb, klo);
+                        const int mc = desc_of(T.child_idx[ci], npos[T.child_idx[ci]].x, NR[T.child_idx[ci]].nchild == 0, kb, klo, g0, cg[lvl_first - g + 1]);
                         if (mc > 0) {
 #pragma unroll
                             for (int x = 0; x < 6; ++x) rec[mc - 1].T[x] = rtmp[(int64_t)(mc - 1) * 6 + x];
@@ -780,7 +803,7 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
                 if (kv == 0x7fffffff) break;
                 last_e = ke; last_v = kv;
                 const int kl = T.level[kv];
-                const int mk = desc_of(kv, npos[kv].x, NR[kv].nchild == 0, grp_off[lvl_first - kl], cg[kl + 1]);
+                const int mk = desc_of(kv, npos[kv].x, NR[kv].nchild == 0, grp_off[lvl_first - kl], cg[kl + 1], grp_off[lvl_first - kl + 1], cg[kl]);
                 const int64_t slot = mk > 0 ? mk - 1 : cap + (-mk - 2);
                 const double x1 = xe[slot * XE_STRIDE + 0];
                 if (win < 0 || x1 < bx) { bx = x1; win = kv; win_slot = (int)slot; }
@@ -854,13 +877,13 @@ bool sweep_merge_lists(const DevTree &t) {
     // knobs: APPLES_NO_SWEEP_MERGE = the tagged node map for big trees as before; APPLES_SWEEP_MERGE = the merge layout
     // also where the node bits would fit in LDS (tests run it on small trees)
     const bool off = getenv("APPLES_NO_SWEEP_MERGE") != nullptr, force = getenv("APPLES_SWEEP_MERGE") != nullptr;
-    if (off || t.scan || t.max_children > 2 || getenv("APPLES_NODE_MAP")) return false;
+    if (off || t.scan || getenv("APPLES_NODE_MAP")) return false;
     return force || (size_t)4 * t.bm_words * 12 > 40 * 1024;
 }
 
 bool sweep_bits_in_lds(const DevTree &t) {
     if (getenv("APPLES_NODE_MAP")) return false;  // test knob: exercise the big-tree layout on a small tree
-    if (getenv("APPLES_SWEEP_MERGE") && t.max_children <= 2 && !t.scan && !getenv("APPLES_NO_SWEEP_MERGE")) return false;  // (forced merge layout)
+    if (getenv("APPLES_SWEEP_MERGE") && !t.scan && !getenv("APPLES_NO_SWEEP_MERGE")) return false;  // (forced merge layout)
     return (size_t)4 * t.bm_words * 12 <= 40 * 1024;
 }
 static size_t dyn_lds_bytes(const DevTree &t, int teams_per_wg) {

@@ -342,7 +342,7 @@ def test_random_trees_per_edge_bit_parity_with_c_oracle(layout, monkeypatch):
     random observed sets of every size from 2 up: valid set, LCA, S, R and the 2x2 solutions must
     equal the C oracle's bit for bit, placements edge for edge (ties resolved by residual).  Both
     node-lookup layouts of the sweep (LDS bit space; tagged node map of big trees) and the merged level lists that
-    big binary trees get by default (forced here; the polytomous shapes fall back to the bit space)."""
+    big trees get by default (forced here)."""
     from oracle_c import COracle
     if layout == 'map':
         monkeypatch.setenv('APPLES_NODE_MAP', '1')
@@ -356,7 +356,7 @@ def test_random_trees_per_edge_bit_parity_with_c_oracle(layout, monkeypatch):
             tree = parse_newick(_random_newick(rng, n_leaves, shape))
             leaves = tree.leaves
             eng = Engine(tree, None, method='OLS')
-            if layout == 'merge' and shape != 'bushy':
+            if layout == 'merge':
                 assert eng.describe()['sweep_layout'] == 'merge'
             for m in METHODS:
                 eng.set_options(method=m, criterion='MLSE')
@@ -398,19 +398,24 @@ def test_both_sweep_layouts_agree_on_polytomies(monkeypatch):
     cols = leaves.astype(np.int32)
     for m, c in (('OLS', 'MLSE'), ('BME', 'HYBRID'), ('FM', 'ME'), ('BE', 'HYBRID')):
         outs = []
-        for layout in ('bits', 'map', 'scan'):
+        for layout in ('bits', 'map', 'scan', 'merge'):
             monkeypatch.delenv('APPLES_NODE_MAP', raising=False)
             monkeypatch.delenv('APPLES_SWEEP_SCAN', raising=False)
+            monkeypatch.delenv('APPLES_SWEEP_MERGE', raising=False)
             if layout == 'scan':
                 monkeypatch.setenv('APPLES_SWEEP_SCAN', '1')
             if layout == 'map':
                 monkeypatch.setenv('APPLES_NODE_MAP', '1')
+            if layout == 'merge':  # (big trees' default: level lists by merging; polytomies look their children up by search)
+                monkeypatch.setenv('APPLES_SWEEP_MERGE', '1')
             eng = Engine(tree, None, method=m, criterion=c, threshold=10.0, baseobs=5)
+            assert eng.describe()['sweep_layout'] == layout
             outs.append(eng.place_distances(D, cols))
             eng.close()
-        assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes(), (m, c)
+        assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes() == outs[3].tobytes(), (m, c)
     monkeypatch.delenv('APPLES_NODE_MAP', raising=False)
     monkeypatch.delenv('APPLES_SWEEP_SCAN', raising=False)
+    monkeypatch.delenv('APPLES_SWEEP_MERGE', raising=False)
 
 
 @pytest.mark.parametrize('L,n_ref,n_q', [(77, 130, 16), (1000, 300, 100), (1620, 257, 300), (33, 64, 517), (64, 129, 17),
