@@ -1,6 +1,7 @@
 """Differential fuzz of the GEMM-form fused distance pass: random reference sizes, alignment lengths, gap rates,
 thresholds, -b values, methods and device batch sizes; placements must be byte-identical with APPLES_NO_DIST_GEMM=1
-(bit-plane-fed matrix-core kernel) and APPLES_NO_FUSE=1 (full rows)."""
+(bit-plane-fed matrix-core kernel; with the sweep's merged level lists forced) and APPLES_NO_FUSE=1 (full rows; with the
+sweep's node map forced); the default run uses the node bits in LDS at these tree sizes."""
 import hashlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
@@ -20,7 +21,7 @@ code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
         "    print(c, n, L, nq, gap, thr, b, mb, m, info['fused_distance_pass'], int((out['edge'] >= 0).sum()), hashlib.sha1(out.tobytes()).hexdigest()[:16], flush=True)\n"
         % (ROOT, seed, ncfg))
 res = []
-for env in ({}, {'APPLES_NO_DIST_GEMM': '1'}, {'APPLES_NO_FUSE': '1'}):
+for env in ({}, {'APPLES_NO_DIST_GEMM': '1', 'APPLES_SWEEP_MERGE': '1'}, {'APPLES_NO_FUSE': '1', 'APPLES_NODE_MAP': '1'}):
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=3000)
     if r.returncode != 0:
         print(env, 'FAILED', r.stderr.decode()[-1500:])
