@@ -16,15 +16,22 @@ alignment and the tree are resident in HBM (the reference's workers likewise hol
 timer starts).  value = query placements/s for the whole job.  `resident` in the JSON line is the
 same pass with the query block already uploaded and packed (device time only).
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank places its own shard with
-no collective in the data path and the 40-byte placement structs are gathered to rank 0 with one RCCL
-gather inside the timed region.  --scaling weak (default): every rank places a block of the workload's
-size; --scaling strong: the workload's queries are split over the ranks (BASELINE config 3's
-"100 k queries, 1 -> 8 GPUs").
+For N > 1 there is one rank process per GPU: `python bench.py --gpus N` starts them itself (a parent that never
+touches a device spawns N fresh interpreters with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and relays rank
+0's line: apples_amd/launcher.py, in place of run_apples.py:93-102's fork pool), and under torch.distributed.run
+(RANK already in the environment) the process is a rank.  Every rank places its own shard with no collective in
+the data path and the 40-byte placement structs are gathered to rank 0 with one RCCL gather inside the timed
+region (--gather rccl, the default: ctypes on librccl.so, no PyTorch in the process; --gather torch:
+torch.distributed, backend nccl).  --scaling strong (default for c3, BASELINE config 3's "100 k queries, 1 -> 8
+GPUs"): the workload's queries are split over the ranks; --scaling weak (default elsewhere): every rank places a
+block of the workload's size.  Fewer visible devices than ranks is an error, not an oversubscription.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, algorithmic bytes or operations /
-HIP-event time), `distance_kernel_stream` (BASELINE.json's second figure: the distance
-kernel at one query per pass over the packed reference, measured after the timed region) and
+HIP-event time), `roofline_hbm_point` (BASELINE.json's second figure: the distance kernel at one
+query per pass over a packed reference larger than every cache, streamed from HBM for several seconds after the
+timed region), `distance_kernel_stream` (the same kernel on the workload's own reference, which the Infinity
+Cache holds: the cache figure), `strong_scaling_proxy` (the 8-GPU shards of the query set timed one by one on
+this GPU), `clustered` (the command line's default route on the same inputs) and
 `cpu_baseline` (the CPU restatement of the reference path -- per-query numpy/Python worker under a
 fork pool, as run_apples.py:101-102 -- timed on this host's cores on a bounded sample of the same
 workload).
@@ -176,6 +183,103 @@ def distance_stream_point(eng, ds, L):
                            if info['packed_bytes'] < (256 << 20) else 'HBM'}
 
 
+def hbm_point(ref_seqs, queries, device, seconds=5.0, min_packed_bytes=560 << 20):
+    """BASELINE.json's second figure where no cache can serve it: the distance kernel at query tile T = 1 (SURVEY
+    8d's roofline point: the packed reference streamed once per query, full fp64 rows out) over a reference made of
+    the workload's rows repeated until its packed form exceeds 512 MiB (the Infinity Cache holds 256 MiB), launched
+    back to back for `seconds` of continuous kernel time.  delivered = (packed reference + 8 B per pair) per query /
+    HIP-event time of the launch (median over the launches)."""
+    from apples_amd.engine import Engine
+    from apples_amd.tree import parse_newick
+    n0, L = ref_seqs.shape
+    bytes_per_row = 12 * ((L + 31) // 32)           # gap plane + two code planes per 32-site word (DESIGN.md section 3)
+    reps = max(1, -(-min_packed_bytes // (bytes_per_row * n0)))
+    ref = np.ascontiguousarray(np.tile(ref_seqs, (reps, 1)))
+    nq = min(256, len(queries))
+    tree = parse_newick('((A:0.1,B:0.2):0.25,(C:0.3,(D:0.2,E:0.2):0.2):0.25);')
+    eng = Engine(tree, ref, np.full(len(ref), -1, np.int32), method='OLS', max_batch=nq, device=device)
+    del ref
+    try:
+        h, n = eng.upload_queries(queries[:nq])
+        eng.distances_resident(h, 1)
+        ms = []
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            eng.distances_resident(h, 1)
+            ms.append(eng.timing()['dist_ms'])
+        wall = time.perf_counter() - t0
+        info = eng.describe()
+        eng.free_queries(h)
+    finally:
+        eng.close()
+    med = float(np.median(ms))
+    moved = n * (info['packed_bytes'] + info['n_rows'] * 8.0)
+    gbs = moved / (med * 1e-3) / 1e9
+    return {'kernel': 'k_jc69 (bit planes), query tile 1, full fp64 rows out', 'rows': int(info['n_rows']), 'L': int(L),
+            'queries_per_launch': int(n), 'launches': len(ms), 'continuous_kernel_seconds': float(sum(ms) * 1e-3),
+            'wall_seconds': wall, 'ms_per_launch_median': med, 'us_per_query': med * 1e3 / n,
+            'packed_reference_bytes': int(info['packed_bytes']), 'bytes_moved_per_launch': moved,
+            'delivered_GBps': gbs, 'peak_GBps': HBM_PEAK_GBS, 'frac_of_8000': gbs / HBM_PEAK_GBS,
+            'frac_of_6300_achievable': gbs / 6300.0,
+            'algorithmic_GBps': n * (info['n_rows'] * (L + 8.0) + L) / (med * 1e-3) / 1e9,
+            'served_from': 'HBM: the packed reference (%d MiB) is larger than the 256 MiB Infinity Cache and is streamed whole '
+                           'for every query' % (info['packed_bytes'] >> 20)}
+
+
+def strong_scaling_proxy(eng, queries, ms_full, parts=8, reps=3):
+    """What a single GPU can say about BASELINE config 3's 1 -> 8 GPU curve: the `parts` contiguous shards of the one
+    query set (apples_amd/distributed.py:shard_bounds, what rank r of an 8-GPU job places) timed one after the other,
+    host buffer -> placements in host memory like the step itself.  The 8-GPU step ends when its slowest rank does
+    (observed sets are heavy-tailed), so the prediction uses the slowest shard; the gather of
+    40 B per query over xGMI is not in it."""
+    from apples_amd.distributed import shard_bounds
+    ms = []
+    for lo, hi in shard_bounds(len(queries), parts):
+        block = np.ascontiguousarray(queries[lo:hi])
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            eng.place_sequences(block)
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+        ms.append(best)
+    return {'parts': parts, 'queries_per_shard': [b - a for a, b in shard_bounds(len(queries), parts)],
+            'ms_shard': ms, 'ms_shard_max': max(ms), 'ms_shard_mean': float(np.mean(ms)), 'ms_full_set': ms_full,
+            'predicted_speedup_at_%d' % parts: ms_full / max(ms),
+            'note': 'shards of the one query set timed one by one on this GPU (best of %d, host buffer -> host); prediction = '
+                    'full-set step / slowest shard; the end-of-run gather (40 B per query) is not included' % reps}
+
+
+def clustered_leg(ds, nodes, queries, thr, method, device, steps=3):
+    """The command line's default route on the same inputs (run_apples.py without --no-clusters, as the reference's
+    default, apples/Reference.py:84-157): max-diameter clusters at 1.2 x -f with consensus representatives."""
+    from apples_amd.engine import Engine
+    t0 = time.perf_counter()
+    clusters = make_clusters(ds, thr)
+    t_clusters = time.perf_counter() - t0
+    eng = Engine(ds.tree, ds.ref_seqs, nodes, clusters=clusters, protein=False, method=method, criterion='MLSE',
+                 threshold=thr, baseobs=25, overlap=0.001, device=device)
+    try:
+        out = eng.place_sequences(queries)
+        ph = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = eng.place_sequences(queries)
+            t = eng.timing()
+            for k in ph:
+                ph[k] += t[k]
+        dt = (time.perf_counter() - t0) / steps
+        info = eng.describe()
+    finally:
+        eng.close()
+    return {'value': len(queries) / dt, 'unit': 'queries/s', 'ms_per_step': dt * 1e3, 'steps': steps,
+            'per_kernel_ms_per_step': {k: v / steps for k, v in ph.items()}, 'n_reps': int(info['n_reps']),
+            'mean_observed': float(np.mean(out['n_obs'])), 'placed': int((out['n_valid'] > 0).sum()),
+            'clustering_and_consensus_s': t_clusters,
+            'note': 'same tree, reference and queries through max-diameter clusters at 1.2 x -f with consensus representatives '
+                    '(the route run_apples.py takes by default); host buffer -> placements in host memory'}
+
+
 def load_traffic(workload, kernel):
     """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
     (profiles/pmc_summary.json, written by scripts/pmc_to_traffic.py from separate --pmc runs of
@@ -207,17 +311,28 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--scaling', default='', choices=['', 'weak', 'strong'],
+                    help="strong: the workload's queries are split over the ranks (default for c3 = BASELINE config 3); "
+                         'weak: every rank places a block of the workload\'s size (default for the other workloads)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--queries', type=int, default=0, help='override the number of queries (per GPU when weak)')
-    ap.add_argument('--gather', default='torch', choices=['torch', 'rccl'],
-                    help='the end-of-run gather for N > 1: torch.distributed (backend nccl = RCCL) or ctypes on librccl.so '
-                         'without PyTorch (apples_amd/rccl.py)')
+    ap.add_argument('--gather', default='rccl', choices=['torch', 'rccl'],
+                    help='the end-of-run gather for N > 1: ctypes on librccl.so without PyTorch (apples_amd/rccl.py, default) '
+                         'or torch.distributed (backend nccl = RCCL)')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the untimed extras of the N = 1 line (HBM point, strong-scaling proxy, clustered route)')
     ap.add_argument('--timed', default='', choices=['', 'host', 'resident'],
                     help='what a step covers: host = host buffers in, placements in host memory (default for alignment '
                          'workloads); resident = inputs already uploaded (default for c5: a 200 k-column table block is '
                          'gigabytes over PCIe, which is the copy and not the path)')
     args = ap.parse_args()
+    if not args.scaling:
+        args.scaling = 'strong' if args.workload == 'c3' else 'weak'
+
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # the parent of the rank processes: starts them before anything here touches a device and never does itself
+        from apples_amd.launcher import launch
+        sys.exit(launch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -402,9 +517,12 @@ def main():
             lds = 8.0 * nq * rows * L / (kernels[dom][1] * 1e-3) / 1e9
             roofline.update({'bound': 'lds', 'achieved': lds, 'peak': LDS_PEAK_GBS, 'frac': lds / LDS_PEAK_GBS,
                              'hbm_algorithmic_GBps': achieved})
-        stream = None
+        stream = proxy = None
         if world == 1 and not table and not protein and not clustered:
             stream = distance_stream_point(eng, ds, L)
+        extras = world == 1 and not args.no_extras and not use_dist
+        if extras and args.workload == 'c3':
+            proxy = strong_scaling_proxy(eng, queries, ms_per_step)
         cpu = None
         if world == 1 and not args.no_cpu and not clustered:
             cpu = cpu_baseline_table(ds, D, method, thr) if table else cpu_baseline(ds, protein, method, thr)
@@ -436,8 +554,15 @@ def main():
         }
         if cpu:
             line['speedup_vs_cpu_baseline'] = value / cpu['value']
-        final_line = json.dumps(line)
+        if proxy:
+            line['strong_scaling_proxy'] = proxy
     eng.close()
+    if rank == 0:
+        if extras and args.workload == 'c3':
+            line['clustered'] = clustered_leg(ds, nodes, queries, thr, method, local_rank)
+        if extras and not table and not protein:
+            line['roofline_hbm_point'] = hbm_point(ds.ref_seqs, queries, local_rank)
+        final_line = json.dumps(line)
     if comm is not None:
         comm.barrier()
         comm.close()

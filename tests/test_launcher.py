@@ -1,0 +1,91 @@
+"""bench.py --gpus N starts its own ranks (apples_amd/launcher.py; in place of the reference's fork pool,
+run_apples.py:93-102).  Driven here on the CPU with a stub rank: the parent must never need a device."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+STUB = r'''
+import json, os, sys, time
+rank = int(os.environ['RANK'])
+mode = os.environ.get('STUB_MODE', 'ok')
+if mode == 'fail' and rank == 1:
+    sys.exit(7)
+if mode == 'fail' and rank != 1:
+    time.sleep(60)       # must be stopped by the launcher, not run to its end
+print(json.dumps({'rank': rank, 'local_rank': int(os.environ['LOCAL_RANK']), 'world': int(os.environ['WORLD_SIZE']),
+                  'addr': os.environ['MASTER_ADDR'], 'port': int(os.environ['MASTER_PORT']), 'argv': sys.argv[1:],
+                  'ipc': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}), flush=True)
+'''
+
+
+def _run(tmp_path, gpus, devices, mode='ok', extra=()):
+    stub = tmp_path / 'stub_rank.py'
+    stub.write_text(STUB)
+    env = dict(os.environ)
+    env.pop('RANK', None)
+    env.pop('WORLD_SIZE', None)
+    env.update({'APPLES_LAUNCH_DEVICE_COUNT': str(devices), 'APPLES_LAUNCH_RANK_CMD': json.dumps([sys.executable, str(stub)]),
+                'STUB_MODE': mode})
+    return subprocess.run([sys.executable, BENCH, '--gpus', str(gpus), '--steps', '2', '--warmup', '1'] + list(extra),
+                          env=env, capture_output=True, text=True, timeout=120)
+
+
+def test_launcher_starts_one_rank_per_gpu_and_relays_rank0(tmp_path):
+    r = _run(tmp_path, 4, 8)
+    assert r.returncode == 0, r.stderr
+    out = [json.loads(x) for x in r.stdout.splitlines() if x.strip()]
+    assert len(out) == 1 and out[0]['rank'] == 0            # ONE line on stdout: rank 0's
+    others = [json.loads(x) for x in r.stderr.splitlines() if x.startswith('{')]
+    assert sorted(o['rank'] for o in others) == [1, 2, 3]
+    for o in out + others:
+        assert o['world'] == 4 and o['local_rank'] == o['rank'] and o['addr'] == '127.0.0.1' and o['ipc'] == '0'
+        assert o['port'] == out[0]['port']
+        assert o['argv'] == ['--gpus', '4', '--steps', '2', '--warmup', '1']
+
+
+def test_launcher_refuses_more_ranks_than_devices(tmp_path):
+    r = _run(tmp_path, 2, 1)
+    assert r.returncode != 0
+    assert '2 ranks requested, 1 device visible' in r.stderr
+    assert r.stdout.strip() == ''
+
+
+def test_launcher_failed_rank_stops_the_others(tmp_path):
+    import time
+    t0 = time.time()
+    r = _run(tmp_path, 3, 3, mode='fail')
+    assert r.returncode == 7
+    assert 'rank 1 ended with status 7' in r.stderr
+    assert time.time() - t0 < 30
+
+
+def test_defaults_strong_for_c3_and_torch_free_gather():
+    src = open(BENCH).read()
+    assert "default='rccl'" in src and "'strong' if args.workload == 'c3'" in src
+
+
+def test_parent_does_not_import_the_engine_or_torch(tmp_path):
+    """The launching parent must stay free of GPU state: with the rank command stubbed, a bench.py whose engine
+    import would fail (no library path) still launches."""
+    stub = tmp_path / 'stub_rank.py'
+    stub.write_text(STUB)
+    env = dict(os.environ)
+    env.pop('RANK', None)
+    env.update({'APPLES_LAUNCH_DEVICE_COUNT': '2', 'APPLES_LAUNCH_RANK_CMD': json.dumps([sys.executable, str(stub)])})
+    code = ('import sys, runpy\n'
+            'sys.argv = [%r, "--gpus", "2"]\n'
+            'import builtins\n'
+            'real = builtins.__import__\n'
+            'def guard(name, *a, **k):\n'
+            '    if name.split(".")[0] == "torch" or name in ("apples_amd.engine", "apples_amd.rccl"):\n'
+            '        raise AssertionError("parent imported " + name)\n'
+            '    return real(name, *a, **k)\n'
+            'builtins.__import__ = guard\n'
+            'runpy.run_path(%r, run_name="__main__")\n' % (BENCH, BENCH))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert 'parent imported' not in r.stderr
