@@ -145,8 +145,9 @@ __global__ __launch_bounds__(256) void k_edge(const int4 *__restrict__ quartets,
 __device__ inline double corrected(double num, double den, int protein) {
     if (!(den > 0)) return 3.0;  // no site in common
     double d = num / den;
-    if (protein) return -1.3 * log(1.0 - fmin(d, 0.9));
-    return -0.75 * log(1.0 - 4.0 * fmin(d, 0.74) / 3.0);
+    // FastTree's LogCorrect: 3.0 once the raw distance reaches 0.74 (nt) / 0.99 (aa), never more than 3.0
+    double c = protein ? (d < 0.99 ? -1.3 * log(1.0 - d) : 3.0) : (d < 0.74 ? -0.75 * log(1.0 - 4.0 * d / 3.0) : 3.0);
+    return fmin(c, 3.0);
 }
 
 __global__ void k_finish(const int4 *__restrict__ quartets, const double *__restrict__ acc, int n, int protein,

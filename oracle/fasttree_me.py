@@ -13,7 +13,8 @@ balanced minimum-evolution branch lengths):
   (children of a trifurcating root: the mean of the other two);
 * distance between two profiles: sum over sites of w1 w2 d / sum of w1 w2, with d the mismatch probability
   (nucleotides) or the BLOSUM45-derived dissimilarity f1' D f2 (proteins; the table of apples/distance.py:12-415,
-  which is FastTree's), then log-corrected: -3/4 ln(1 - 4d/3) or -1.3 ln(1 - d);
+  which is FastTree's), then log-corrected: -3/4 ln(1 - 4d/3) for d < 0.74 or -1.3 ln(1 - d) for d < 0.99, 3.0 beyond
+  and 3.0 at most (pinned by the *_saturated fixtures);
 * branch of a leaf A with neighbours B, C: (d_AB + d_AC - d_BC) / 2; internal branch with children A1, A2 on one
   side and B, C on the other: (d_A1B + d_A1C + d_A2B + d_A2C) / 4 - (d_A1A2 + d_BC) / 2.  Negative values stay.
 
@@ -69,9 +70,12 @@ def branch_lengths(n_nodes, parent, children, leaf_seq, protein):
             return 3.0
         d = ((p1[1] @ D) * p2[1]).sum(1) if D is not None else 1.0 - (p1[1] * p2[1]).sum(1)
         d = float((ww * d).sum() / den)
+        # FastTree's LogCorrect: 3.0 once the raw distance reaches 0.74 (nt) / 0.99 (aa), and never more than 3.0
         if protein:
-            return -1.3 * np.log(1 - min(d, 0.9))
-        return -0.75 * np.log(1 - 4 * min(d, 0.74) / 3)
+            c = -1.3 * np.log(1 - d) if d < 0.99 else 3.0
+        else:
+            c = -0.75 * np.log(1 - 4 * d / 3) if d < 0.74 else 3.0
+        return min(float(c), 3.0)
 
     root = [v for v in range(n_nodes) if parent[v] < 0][0]
     order, st = [], [root]

@@ -492,8 +492,8 @@ def g9():
             o.write(p.stdout.decode().strip() + '\n')
 
     run(os.path.join(DATA, 'backbone.nwk'), os.path.join(DATA, 'ref.fa'), False, 'g9_fasttree_data.nwk')
-    for name, (n, L, protein, seed, odd) in fasttree_cases().items():
-        d, seqs = fasttree_case(n, L, protein, seed, odd)
+    for name, (n, L, protein, seed, odd, mean_len) in fasttree_cases().items():
+        d, seqs = fasttree_case(n, L, protein, seed, odd, mean_len)
         tfp, ffp = os.path.join(tmp, name + '.nwk'), os.path.join(tmp, name + '.fa')
         open(tfp, 'w').write(d.newick + '\n')
         with open(ffp, 'w') as f:

@@ -55,8 +55,8 @@ def test_reference_test_data_unrooted():
 
 @pytest.mark.parametrize('name', sorted(fasttree_cases()))
 def test_rooted_inputs_nucleotide_with_odd_symbols_and_protein(name):
-    n, L, protein, seed, odd = fasttree_cases()[name]
-    d, seqs = fasttree_case(n, L, protein, seed, odd)
+    n, L, protein, seed, odd, mean_len = fasttree_cases()[name]
+    d, seqs = fasttree_case(n, L, protein, seed, odd, mean_len)
     seq_of = dict(zip(d.ref_names, seqs))
     root, nodes, parent, got, want = both(d.newick, seq_of, protein)
     assert np.abs(got - want).max() <= TOL
