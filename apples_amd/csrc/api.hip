@@ -138,6 +138,16 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
         if (r.c1 >= 0 && t->child_off[r.c1 + 1] == t->child_off[r.c1]) r.kleaf |= 2u;
         r.node = i;
     }
+    {
+        struct PE { int32_t parent, pad; double e; };
+        static_assert(sizeof(PE) == 16, "pe record");
+        std::vector<PE> pe(t->n_nodes);
+        for (int i = 0; i < t->n_nodes; ++i) pe[i] = PE{t->parent[i], 0, t->edge_len[i]};
+        PE *dpe = nullptr;
+        if (dev_upload(ctx, &dpe, pe.data(), t->n_nodes)) return 1;
+        d.pe = dpe;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (pe goes out of scope)
+    }
     std::vector<int32_t> npos((size_t)t->n_nodes * 2);
     for (int i = 0; i < t->n_nodes; ++i) { npos[2 * (size_t)i] = rec[i].lpos; npos[2 * (size_t)i + 1] = rec[i].ppos; }
     if (dev_upload(ctx, &d.npos, npos.data(), (int64_t)npos.size())) return 1;
@@ -427,7 +437,7 @@ int big_threshold(const apples_ctx *ctx) {
 
 void free_sweep(Workspace::Sweep &sw) {
     dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.ent); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
-    dev_free(sw.ent_f); dev_free(sw.ent_i); dev_free(sw.leaf_g); dev_free(sw.meta);
+    dev_free(sw.ent_f); dev_free(sw.ent_i); dev_free(sw.leaf_g); dev_free(sw.meta); dev_free(sw.lean);
     sw = Workspace::Sweep();
 }
 
@@ -479,6 +489,14 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
         }
         if (xe)
             if (dev_alloc(ctx, &sw.xe, sw.teams * cap * 18)) return 1;
+        return 0;
+    }
+    if (teams_per_wg == 4 && sweep_lean_layout(t, xe)) {  // sweep_lean.hip: field arrays in place of ent and A
+        sw.lean_cap1 = round_up(cap + 1, 4);
+        char *p = nullptr;
+        if (dev_alloc(ctx, &p, sw.teams * sw.lean_cap1 * LEAN_BYTES_PER_NODE)) return 1;
+        sw.lean = p;
+        if (dev_alloc(ctx, &sw.grp_off, sw.teams * (int64_t)(t.height + 4))) return 1;
         return 0;
     }
     if (sweep_merge_lists(t)) {
@@ -577,11 +595,14 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     // big trees keep a node map of n_nodes ints per team (<= ~8 GiB in total)
     // (2 048 teams are resident at two wavefronts per SIMD; 3 072 measured best at both 10 k and 200 k leaves)
     int64_t teams = (t.scan || sweep_bits_in_lds(t) || sweep_merge_lists(t)) ? 3072 : std::min<int64_t>(3072, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
+    if (sweep_lean_layout(t, xe)) teams = (int64_t)1536 * sweep_lean_waves();  // (1.5 x the resident teams, as above)
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
     int64_t per_node = t.scan ? 120 + (xe ? 144 : 0) : 68 + (sweep_merge_lists(t) ? 12 : 0) + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
+    if (sweep_lean_layout(t, xe)) per_node = LEAN_BYTES_PER_NODE + 4;
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
+    if (const char *e = getenv("APPLES_SWEEP_CAP")) cap = std::min<int64_t>(cap, std::max<int64_t>(64, atoll(e)));  // test knob: small teams overflow early
     if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, t.scan ? 0 : std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold(ctx))), xe)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
     int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 4;
@@ -733,6 +754,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
     s.map = sw.map; s.map_ver = sw.ver; s.order = sw.order; s.ent = sw.ent;
+    s.lean = sw.lean; s.lean_cap1 = sw.lean_cap1;
     s.map_bits = 1;
     while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
     if (const char *e = getenv("APPLES_MAP_BITS")) s.map_bits = std::min(30, std::max(s.map_bits, atoi(e)));  // test knob: few tags, early wrap
@@ -824,7 +846,16 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     sm.cls_list = w.cls_list;  // size-class queues written by the selection kernels, largest first
     sm.cls_count = w.cls_count;
     sm.cursor = w.cls_count + 4;
-    if (launch_sweep_mixed(ctx, sm, b, nq, w.small.wgs, w.big.wgs, st)) return 1;
+    if (w.small.lean && !sm.keep_edges) {
+        // big binary trees: the wavefront-sized teams run sweep_lean.hip; the queries routed to workgroup-sized teams
+        // (many observed leaves: the longest jobs) run beside them on a stream of their own
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_sel, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_big, ctx->ev_sel, 0));
+        if (launch_sweep(ctx, b, nq, w.big.wgs, 256, ctx->stream_big)) return 1;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_big, ctx->stream_big));
+        if (launch_sweep_lean(ctx, sm, nq, w.small.wgs, st)) return 1;
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_big, 0));
+    } else if (launch_sweep_mixed(ctx, sm, b, nq, w.small.wgs, w.big.wgs, st)) return 1;
     // whatever did not fit a small team's scratch (usually nothing; nothing at all when that scratch
     // holds the whole tree: the overflow test in the kernel is `cap < n_nodes && ...`)
     if (!can_overflow) return 0;
@@ -1072,7 +1103,7 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return fail(); }
     // stream2 is spare; stream3 is the back stream of the APPLES_PIPELINE experiment
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
-        hipStreamCreate(&ctx->stream3) != hipSuccess ||
+        hipStreamCreate(&ctx->stream3) != hipSuccess || hipStreamCreate(&ctx->stream_big) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_front[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_front[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_back[0], hipEventDisableTiming) != hipSuccess ||
@@ -1180,6 +1211,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+    if (ctx->stream_big) (void)hipStreamSynchronize(ctx->stream_big);
     if (ctx->scan_prof) {  // diagnostic: where the scan sweep's teams spent their cycles
         unsigned long long h[8] = {};
         (void)hipMemcpy(h, ctx->scan_prof, sizeof h, hipMemcpyDeviceToHost);
@@ -1197,7 +1229,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     for (auto &e : ctx->ev_feed) (void)hipEventDestroy(e);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
-    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
+    dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
     dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
@@ -1213,6 +1245,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     }
     if (ctx->ev_bigfree) (void)hipEventDestroy(ctx->ev_bigfree);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    if (ctx->stream_big) (void)hipStreamDestroy(ctx->stream_big);
     if (ctx->ev_sel) (void)hipEventDestroy(ctx->ev_sel);
     if (ctx->ev_big) (void)hipEventDestroy(ctx->ev_big);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -1710,7 +1743,7 @@ const char *apples_describe(apples_ctx *ctx) {
                                    : (a.planes == 2 && dist_mfma_enabled() ? "fp4 mfma, bit-plane fed" : "valu"),
              (long long)(a.ref_f4 ? a.slots_pad * (int64_t)a.G * 128 : 0),
              // how the level-loop sweep knows a query's subtree: merged level lists / node bits in LDS / tagged node map
-             ctx->tree.scan ? "scan" : sweep_merge_lists(ctx->tree) ? "merge" : sweep_bits_in_lds(ctx->tree) ? "bits" : "map");
+             ctx->tree.scan ? "scan" : ctx->ws.small.lean ? "lean" : sweep_merge_lists(ctx->tree) ? "merge" : sweep_bits_in_lds(ctx->tree) ? "bits" : "map");
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

@@ -54,6 +54,7 @@ struct DevTree {
     int32_t *lnode = nullptr;    // [bm_words*64] node at a bit position (-1 = padding)
     NodeRec *rec_l = nullptr;    // [bm_words*64] the records in bit-position order: position -> record in one load
     int32_t *npos = nullptr;     // [n_nodes][2] lpos, ppos (what a leaf needs, without its 64-byte record)
+    void *pe = nullptr;          // [n_nodes] {int32 parent, int32 -, double edge length}: the one tree gather of sweep_lean.hip
     // scan formulation of the sweep (sweep_scan.hip): per leaf, by level m = 0..level(leaf), the ancestor at
     // that level.  Built when the tree is shallow enough for the tables to fit (else the level-loop sweep runs).
     bool scan = false;
@@ -156,6 +157,8 @@ struct Workspace {
         int32_t *grp_off = nullptr; // [teams][height+4] level groups in compact order, deepest first
         void *A = nullptr;        // [teams][cap+1] Rec (64 B): S then R tuple, first two valid children, node
         void *B = nullptr;        // [teams][cap+1][6] R values in waiting; trees with polytomies only
+        void *lean = nullptr;     // sweep_lean.hip: [teams][LEAN_BYTES_PER_NODE * lean_cap1] field arrays (in place of ent and A)
+        int64_t lean_cap1 = 0;    // entries per field array: cap + 1 rounded up to a multiple of 4
         double *xe = nullptr;     // [teams][cap+leaf_cap][18] per-edge x, err, R, S (HYBRID / inspection)
         // scan formulation: per team `cap` entries (one per subtree node) as component arrays
         double *ent_f = nullptr;  // [teams][13][cap]: S[6], R[6] as pairs, edge length
@@ -184,6 +187,7 @@ struct apples_ctx {
     hipStream_t stream2 = nullptr;   // spare
     hipEvent_t ev_sel = nullptr, ev_big = nullptr;
     hipStream_t stream3 = nullptr;   // back stream: sweeps of batch i while the front stream works on batch i+1
+    hipStream_t stream_big = nullptr; // the workgroup-sized sweep teams of a batch, beside sweep_lean.hip's wavefront-sized ones
     hipEvent_t ev_front[2] = {}, ev_back[2] = {}, ev_bigfree = nullptr;
     std::string err;
     std::string desc;
@@ -313,6 +317,8 @@ struct SweepArgs {
     uint32_t *map_ver;        // [teams] version tags of the maps
     int32_t *order;           // [teams][cap+1]
     int4 *ent;                // [teams][cap+1] merge layout: nullptr = node map or node bits
+    void *lean;               // sweep_lean.hip: the teams' field arrays
+    int64_t lean_cap1;
     int map_bits;             // payload bits of a map entry; the tag sits above them
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
@@ -356,5 +362,10 @@ int launch_scan(apples_ctx *ctx, const ScanArgs &a, int64_t nq, int wgs, int tea
 bool sweep_merge_lists(const DevTree &t);  // big binary trees, wavefront-sized teams: level lists by merging, no node map
 bool sweep_bits_in_lds(const DevTree &t);  // the sweep's node bits fit in LDS (else: tagged node map in global scratch)
 int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team, hipStream_t stream = nullptr);
+// sweep_lean.hip: the three-pass form for big binary trees (wavefront-sized teams over the size-class queues)
+#define LEAN_BYTES_PER_NODE 84  // T0 T1 T2 E (16 B each), D N (8 B each), K (4 B)
+bool sweep_lean_layout(const DevTree &t, bool per_edge_records);
+int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st);
+int sweep_lean_waves();  // wavefronts per SIMD the lean kernel is built for (1 536 teams each)
 int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,
                        hipStream_t st);

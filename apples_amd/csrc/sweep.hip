@@ -881,6 +881,12 @@ bool sweep_merge_lists(const DevTree &t) {
     return force || (size_t)4 * t.bm_words * 12 > 40 * 1024;
 }
 
+// sweep_lean.hip serves the wavefront-sized teams of a big binary tree (merge layout, no polytomies, no per-edge
+// records -- HYBRID and inspection keep the level loop above).  APPLES_NO_SWEEP_LEAN: the level loop everywhere.
+bool sweep_lean_layout(const DevTree &t, bool per_edge_records) {
+    return sweep_merge_lists(t) && t.max_children <= 2 && !per_edge_records && t.pe != nullptr && !getenv("APPLES_NO_SWEEP_LEAN");
+}
+
 bool sweep_bits_in_lds(const DevTree &t) {
     if (getenv("APPLES_NODE_MAP")) return false;  // test knob: exercise the big-tree layout on a small tree
     if (getenv("APPLES_SWEEP_MERGE") && !t.scan && !getenv("APPLES_NO_SWEEP_MERGE")) return false;  // (forced merge layout)

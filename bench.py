@@ -183,10 +183,10 @@ def distance_stream_point(eng, ds, L):
                            if info['packed_bytes'] < (256 << 20) else 'HBM'}
 
 
-def hbm_point(ref_seqs, queries, device, seconds=5.0, min_packed_bytes=560 << 20):
+def hbm_point(ref_seqs, queries, device, seconds=5.0, min_packed_bytes=1100 << 20):
     """BASELINE.json's second figure where no cache can serve it: the distance kernel at query tile T = 1 (SURVEY
     8d's roofline point: the packed reference streamed once per query, full fp64 rows out) over a reference made of
-    the workload's rows repeated until its packed form exceeds 512 MiB (the Infinity Cache holds 256 MiB), launched
+    the workload's rows repeated until its packed form exceeds 1 GiB (four times the 256 MiB Infinity Cache), launched
     back to back for `seconds` of continuous kernel time.  delivered = (packed reference + 8 B per pair) per query /
     HIP-event time of the launch (median over the launches)."""
     from apples_amd.engine import Engine

@@ -59,7 +59,7 @@ def test_c2_reference_size_against_c_oracle(c2, method, criterion):
     eng.close()
 
 
-@pytest.mark.parametrize('layout', ['scan', 'bits', 'map', 'merge'])
+@pytest.mark.parametrize('layout', ['scan', 'bits', 'map', 'merge', 'lean'])
 def test_all_observed_stress_and_batching(c2, layout, monkeypatch):
     """-f huge: every leaf observed (worst case for both kernels, V = 2N-2; more than 4 096 observed
     leaves send every query to the workgroup-sized teams); also forces several device batches and
@@ -70,8 +70,10 @@ def test_all_observed_stress_and_batching(c2, layout, monkeypatch):
         monkeypatch.setenv('APPLES_SWEEP_SCAN', '1')
     if layout == 'map':
         monkeypatch.setenv('APPLES_NODE_MAP', '1')
+    if layout in ('merge', 'lean'):  # big trees' layouts, forced on a small one: merged level lists inside the level
+        monkeypatch.setenv('APPLES_SWEEP_MERGE', '1')  # loop, or (binary trees, the default there) the three-pass lean form
     if layout == 'merge':
-        monkeypatch.setenv('APPLES_SWEEP_MERGE', '1')
+        monkeypatch.setenv('APPLES_NO_SWEEP_LEAN', '1')
     nthreads = len(os.sched_getaffinity(0))
     co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', threshold=1e9, lut=jc69_lut(1000, 0.001), threads=nthreads)
     want = co.place_sequences(d.query_seqs[:96])
@@ -160,6 +162,9 @@ def test_fused_and_full_row_selection_paths_agree(c2):
     for env in ({}, {'APPLES_NO_FUSE': '1'}, {'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_TEAM': '256'},
                 {'APPLES_TOPUP_MIN_ROWS': '0'}, {'APPLES_NO_DIST_MFMA': '1'}, {'APPLES_NO_DIST_GEMM': '1'}, {'APPLES_GEMM_TABLE': '1'}, {'APPLES_GEMM_QT': '128'}, {'APPLES_GEMM_QT': '128', 'APPLES_GEMM_TABLE': '1'}, {'APPLES_SWEEP_SCAN': '1'},
                 {'APPLES_SWEEP_MERGE': '1'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_SWEEP_TEAM': '256'},
+                {'APPLES_SWEEP_MERGE': '1', 'APPLES_NO_SWEEP_LEAN': '1'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_NO_SWEEP_LEAN': '1', 'APPLES_BIG_THRESHOLD': '300'},
+                {'APPLES_SWEEP_MERGE': '1', 'APPLES_SWEEP_TEAMS': '8'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_SWEEP_CAP': '600'},
+                {'APPLES_SWEEP_MERGE': '1', 'APPLES_NO_SWEEP_LEAN': '1', 'APPLES_SWEEP_CAP': '600'},
                 {'APPLES_SWEEP_SCAN': '1', 'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_SCAN': '1', 'APPLES_SWEEP_TEAM': '256'}):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
