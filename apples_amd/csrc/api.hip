@@ -493,8 +493,10 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
     }
     if (teams_per_wg == 4 && sweep_lean_layout(t, xe)) {  // sweep_lean.hip: field arrays in place of ent and A
         sw.lean_cap1 = round_up(cap + 1, 4);
+        // (the selection kernel routes queries with more than big_threshold observed leaves to the workgroup-sized teams)
+        sw.lean_leaf1 = round_up(std::max<int64_t>(std::min<int64_t>(leaf_cap, big_threshold(ctx)), 4), 4);
         char *p = nullptr;
-        if (dev_alloc(ctx, &p, sw.teams * sw.lean_cap1 * LEAN_BYTES_PER_NODE)) return 1;
+        if (dev_alloc(ctx, &p, sw.teams * (sw.lean_cap1 * LEAN_BYTES_PER_NODE + sw.lean_leaf1 * LEAN_BYTES_PER_LEAF))) return 1;
         sw.lean = p;
         if (dev_alloc(ctx, &sw.grp_off, sw.teams * (int64_t)(t.height + 4))) return 1;
         return 0;
@@ -754,7 +756,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
     s.map = sw.map; s.map_ver = sw.ver; s.order = sw.order; s.ent = sw.ent;
-    s.lean = sw.lean; s.lean_cap1 = sw.lean_cap1;
+    s.lean = sw.lean; s.lean_cap1 = sw.lean_cap1; s.lean_leaf1 = sw.lean_leaf1;
     s.map_bits = 1;
     while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
     if (const char *e = getenv("APPLES_MAP_BITS")) s.map_bits = std::min(30, std::max(s.map_bits, atoi(e)));  // test knob: few tags, early wrap
@@ -848,12 +850,15 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     sm.cursor = w.cls_count + 4;
     if (w.small.lean && !sm.keep_edges) {
         // big binary trees: the wavefront-sized teams run sweep_lean.hip; the queries routed to workgroup-sized teams
-        // (many observed leaves: the longest jobs) run beside them on a stream of their own
+        // (many observed leaves: the longest jobs) run beside them.  Their launch goes first and on this stream, the lean
+        // kernel on a second stream behind an event: its persistent workgroups would otherwise take every slot of the
+        // chip and the long jobs would start when the short ones are done (measured: 3.3 + 3.1 ms per launch instead
+        // of the two side by side)
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sel, st));
+        if (launch_sweep(ctx, b, nq, w.big.wgs, 256, st)) return 1;
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_big, ctx->ev_sel, 0));
-        if (launch_sweep(ctx, b, nq, w.big.wgs, 256, ctx->stream_big)) return 1;
+        if (launch_sweep_lean(ctx, sm, nq, w.small.wgs, ctx->stream_big)) return 1;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_big, ctx->stream_big));
-        if (launch_sweep_lean(ctx, sm, nq, w.small.wgs, st)) return 1;
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_big, 0));
     } else if (launch_sweep_mixed(ctx, sm, b, nq, w.small.wgs, w.big.wgs, st)) return 1;
     // whatever did not fit a small team's scratch (usually nothing; nothing at all when that scratch

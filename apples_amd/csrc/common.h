@@ -159,6 +159,7 @@ struct Workspace {
         void *B = nullptr;        // [teams][cap+1][6] R values in waiting; trees with polytomies only
         void *lean = nullptr;     // sweep_lean.hip: [teams][LEAN_BYTES_PER_NODE * lean_cap1] field arrays (in place of ent and A)
         int64_t lean_cap1 = 0;    // entries per field array: cap + 1 rounded up to a multiple of 4
+        int64_t lean_leaf1 = 0;   // observed leaves a team's per-leaf arrays hold (a multiple of 4)
         double *xe = nullptr;     // [teams][cap+leaf_cap][18] per-edge x, err, R, S (HYBRID / inspection)
         // scan formulation: per team `cap` entries (one per subtree node) as component arrays
         double *ent_f = nullptr;  // [teams][13][cap]: S[6], R[6] as pairs, edge length
@@ -318,7 +319,7 @@ struct SweepArgs {
     int32_t *order;           // [teams][cap+1]
     int4 *ent;                // [teams][cap+1] merge layout: nullptr = node map or node bits
     void *lean;               // sweep_lean.hip: the teams' field arrays
-    int64_t lean_cap1;
+    int64_t lean_cap1, lean_leaf1;
     int map_bits;             // payload bits of a map entry; the tag sits above them
     int method, criterion, negative;
     int keep_edges;           // store per-edge x/err (inspection or HYBRID)
@@ -363,7 +364,9 @@ bool sweep_merge_lists(const DevTree &t);  // big binary trees, wavefront-sized 
 bool sweep_bits_in_lds(const DevTree &t);  // the sweep's node bits fit in LDS (else: tagged node map in global scratch)
 int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team, hipStream_t stream = nullptr);
 // sweep_lean.hip: the three-pass form for big binary trees (wavefront-sized teams over the size-class queues)
-#define LEAN_BYTES_PER_NODE 84  // T0 T1 T2 E (16 B each), D N (8 B each), K (4 B)
+#define LEAN_BYTES_PER_NODE 100  // T0 T1 T2 E DD (16 B each), D N (8 B each), K (4 B)
+#define LEAN_BYTES_PER_LEAF 12   // per observed leaf: edge length, parent
+#define LEAN_MAX_LEVELS 256      // per-level offsets of a query in LDS: trees up to 254 levels
 bool sweep_lean_layout(const DevTree &t, bool per_edge_records);
 int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st);
 int sweep_lean_waves();  // wavefronts per SIMD the lean kernel is built for (1 536 teams each)

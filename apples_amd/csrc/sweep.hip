@@ -884,7 +884,8 @@ bool sweep_merge_lists(const DevTree &t) {
 // sweep_lean.hip serves the wavefront-sized teams of a big binary tree (merge layout, no polytomies, no per-edge
 // records -- HYBRID and inspection keep the level loop above).  APPLES_NO_SWEEP_LEAN: the level loop everywhere.
 bool sweep_lean_layout(const DevTree &t, bool per_edge_records) {
-    return sweep_merge_lists(t) && t.max_children <= 2 && !per_edge_records && t.pe != nullptr && !getenv("APPLES_NO_SWEEP_LEAN");
+    return sweep_merge_lists(t) && t.max_children <= 2 && t.height + 2 <= LEAN_MAX_LEVELS && !per_edge_records && t.pe != nullptr &&
+           !getenv("APPLES_NO_SWEEP_LEAN");
 }
 
 bool sweep_bits_in_lds(const DevTree &t) {

@@ -1,24 +1,32 @@
 // Least-squares placement sweep, lean form for big binary trees (the C3 route): the level loop of sweep.hip with
-// the merged level lists, cut into three passes per query and with no tree records in it.
+// the merged level lists, without tree records and with the small levels kept on chip.
 //
-//   apples/Subtree.py:23-43 (validate_edges)        -> pass A: the level lists, by merging (structure only, integers)
-//   apples/OLS.py:12-44 ... (all_S_values)          -> pass B: S tuples, deepest level first
-//   apples/OLS.py:46-128 ..., util.py:6-54          -> pass C: R tuples, 2x2 solve, residual, running arg-min, top down
-//   apples/Algorithm.py:62-101 (placement)          -> wavefront arg-min, the placement struct
+//   apples/Subtree.py:23-43 (validate_edges), OLS.py:12-44 ... (all_S_values) -> bottom-up pass: level lists by merging,
+//                                                                                S tuples as the lists form
+//   apples/OLS.py:46-128 ..., util.py:6-54                                    -> top-down pass: R tuples, 2x2 solve,
+//                                                                                residual, running arg-min
+//   apples/Algorithm.py:62-101 (placement)                                    -> wavefront arg-min, the placement struct
 //
-// What sweep.hip's level step gathers per internal node and pass -- a 64-byte tree record, 25.6 MB of them at 200 k
-// leaves, out of the Infinity Cache at best -- is replaced by one 16-byte gather per swept node in pass A: {parent,
-// edge length} of every list key (`pe`, 6.4 MB).  A list entry then carries everything the later passes need of
-// its (at most two) valid children: descriptors, node ids and edge lengths.  Passes B and C read their levels
-// front to back out of arrays (one array per field: every load of a level is a contiguous run per wavefront), and a
-// child's tuple from the level below, whose entries are in the same order as their parents: near-sequential too.
-// A node's R tuple is stored already lifted over its own edge (the parent knows that length), so a node never needs
-// its own tree constants.  Levels of at most 64 nodes hand their tuples to the next level through LDS.
+// A query's sweep is a chain of level steps (some 45 at 200 k leaves) and a level step is a chain of dependent memory
+// round trips; what the kernel takes per launch is (queries / teams in flight) x (steps x trips x latency), far from
+// any bandwidth.  So this form removes trips:
+//   * no tree records.  What sweep.hip gathers per internal node and pass -- a 64-byte tree record, 25.6 MB of them at
+//     200 k leaves -- is one 16-byte gather per list key, {parent, edge length} (`pe`, 6.4 MB).  A list entry carries
+//     everything later steps need of its (at most two) valid children: descriptors, node ids, edge lengths and, for
+//     observed leaves, distances; a node's R tuple is stored already lifted over its own edge.  Entries are field
+//     arrays (every load of a level is a contiguous run per wavefront) and a child's tuple sits in the level below in
+//     its parent's order: near-sequential too;
+//   * a list of at most 64 entries stays in the lanes' registers, the gather for its keys is issued as soon as they
+//     exist and lands while the S tuples of the step are computed; the observed leaves of the next level (node,
+//     parent, edge length, distance: sequential arrays, the first two filled up front by independent gathers) are
+//     requested one step ahead; the per-level offsets sit in LDS.  A level that fits one merge step is then merged
+//     entirely out of LDS windows and hands its entries and S tuples to the next level through LDS: no dependent
+//     memory round trip in the step.
 //
 // Team = one wavefront per query (four per workgroup, no s_barrier).  Queries with many observed leaves are routed to
-// sweep.hip's workgroup-sized teams as before; so are trees with polytomies, the HYBRID criterion and per-edge
-// inspection (the launcher decides).  Arithmetic: sweep_math.h, shared with sweep.hip -- same expressions in the same
-// order, so placements are bit-identical to the level loop's.
+// sweep.hip's workgroup-sized teams as before; so are trees with polytomies or more than LEAN_MAX_LEVELS - 2 levels, the
+// HYBRID criterion and per-edge inspection (the launcher decides).  Arithmetic: sweep_math.h, shared with sweep.hip --
+// same expressions in the same order, so placements are bit-identical to the level loop's.
 #include <algorithm>
 #include <cstdlib>
 
@@ -28,32 +36,50 @@
 
 namespace {
 
+// LDS of one wavefront-sized team
+struct LeanWave {
+    int cg[LEAN_MAX_LEVELS];   // the query's per-level offsets into its level-sorted observation list (cnt_gt)
+    double2 stage[3][WAVE];    // S tuples of a level of at most 64 nodes, for the level above
+    // the two windows of a merge step: keys, and for a level that fits one step also parent, edge length (and, for an
+    // observed leaf, its distance) of every key
+    int ka[WAVE], kb[WAVE], pa[WAVE], pb[WAVE];
+    double ea[WAVE], eb[WAVE], db[WAVE];
+    // the entries a one-step merge produced, in list order: the next level takes them from here
+    int oK[WAVE];
+    int2 oD[WAVE], oN[WAVE];
+    double2 oE[WAVE], oDD[WAVE];
+};
+
 struct LeanShared {
-    double pow[384 + 256];                    // libm pow tables (sweep_math.h)
-    double2 stage[APPLES_TPB / WAVE][3][WAVE];  // per wavefront: the tuples of a level of at most 64 nodes
-    int mk[APPLES_TPB / WAVE][2][WAVE];       // the two key windows of a merge step
-    int w[APPLES_TPB / WAVE];
+    double pow[384 + 256];  // libm pow tables (sweep_math.h)
+    LeanWave w[APPLES_TPB / WAVE];
 };
 
-// per-team scratch: one array per field, `cap1` entries each (cap1 a multiple of 4)
+// per-team scratch: one array per field, `cap1` entries each (cap1 a multiple of 4), then two per observed leaf
 struct LeanTeam {
-    int32_t *K;     // node id
-    int2 *D;        // descriptors of the first and second valid child (> 0: entry index + 1, <= -2: observed leaf -(j+2), 0: none)
-    int2 *N;        // their node ids
-    double2 *E;     // their edge lengths
-    double2 *T0, *T1, *T2;  // the node's tuple: S after pass B, lift(R) after pass C reached its parent
+    double2 *T0, *T1, *T2;  // the node's tuple: S after the bottom-up pass, lift(R) once the top-down pass reached its parent
+    double2 *E;             // edge lengths of the first and second valid child
+    double2 *DD;            // their distances where they are observed leaves
+    int2 *D;                // their descriptors (> 0: entry index + 1, <= -2: observed leaf -(j+2), 0: none)
+    int2 *N;                // their node ids
+    int32_t *K;             // node id
+    double *LE;             // per observed leaf: edge length ...
+    int32_t *LP;            // ... and parent (pe gathered once, up front)
 };
 
-__device__ __forceinline__ LeanTeam lean_team(void *base, int64_t team, int64_t cap1) {
-    char *p = reinterpret_cast<char *>(base) + team * cap1 * LEAN_BYTES_PER_NODE;
+__device__ __forceinline__ LeanTeam lean_team(void *base, int64_t team, int64_t cap1, int64_t leaf1) {
+    char *p = reinterpret_cast<char *>(base) + team * (cap1 * LEAN_BYTES_PER_NODE + leaf1 * LEAN_BYTES_PER_LEAF);
     LeanTeam t;
     t.T0 = reinterpret_cast<double2 *>(p); p += cap1 * 16;
     t.T1 = reinterpret_cast<double2 *>(p); p += cap1 * 16;
     t.T2 = reinterpret_cast<double2 *>(p); p += cap1 * 16;
     t.E = reinterpret_cast<double2 *>(p); p += cap1 * 16;
+    t.DD = reinterpret_cast<double2 *>(p); p += cap1 * 16;
     t.D = reinterpret_cast<int2 *>(p); p += cap1 * 8;
     t.N = reinterpret_cast<int2 *>(p); p += cap1 * 8;
-    t.K = reinterpret_cast<int32_t *>(p);
+    t.K = reinterpret_cast<int32_t *>(p); p += cap1 * 4;
+    t.LE = reinterpret_cast<double *>(p); p += leaf1 * 8;
+    t.LP = reinterpret_cast<int32_t *>(p);
     return t;
 }
 
@@ -61,13 +87,17 @@ __device__ __forceinline__ double shfl_down_f64(double v, int delta) {
     return __hiloint2double(__shfl_down(__double2hiint(v), delta, WAVE), __shfl_down(__double2loint(v), delta, WAVE));
 }
 
-// Pass A, one level: merge by node id the parents of this level's internal nodes (K[base .. base + nA), sorted) and of
-// its observed leaves (o_node[lo .. lo + nB), sorted): the next level's list, sorted (sweep.hip:merge_parents -- the
-// same merge-path step of 64 keys through two LDS windows; a binary tree's runs have at most two keys and a step
-// whose last key opens a run leaves it to the next step).  The entry of a parent names its valid children and carries
-// their node ids and edge lengths.  Returns the number of entries written from next_base on.
-__device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, const int32_t *__restrict__ o_node, int lo, int nB,
-                                          int next_base, const int4 *__restrict__ pe, int *mk_a, int *mk_b, int lane) {
+__device__ __forceinline__ double pe_len(const int4 &r) { return __hiloint2double(r.w, r.z); }
+
+// One level of the lists, general form (any sizes): merge by node id the parents of this level's internal nodes
+// (K[base .. base + nA), sorted) and of its observed leaves (o_node[lo .. lo + nB), sorted): the next level's list, sorted
+// (sweep.hip:merge_parents -- the same merge-path step of 64 keys through two LDS windows; a binary tree's runs have at
+// most two keys and a step whose last key opens a run leaves it to the next step).  The entry of a parent names its
+// valid children and carries their node ids, edge lengths and (observed leaves) distances.  Returns the number of
+// entries written from next_base on.
+__device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, const int32_t *__restrict__ o_node,
+                                          const double *__restrict__ o_dist, int lo, int nB, int next_base,
+                                          const int4 *__restrict__ pe, int *mk_a, int *mk_b, int lane) {
     int out = 0, ia = 0, ib = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
     while (ia < nA || ib < nB) {
@@ -89,11 +119,17 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
         const int key = from_a ? ka : kb;
         const int desc = from_a ? base + ia + i + 1 : -(lo + ib + j) - 2;
         int par = -3;
-        double e = 0;
+        double e = 0, dist = 0;
         if (active) {
-            const int4 r = pe[key];
-            par = r.x;
-            e = __hiloint2double(r.w, r.z);
+            if (from_a) {
+                const int4 r = pe[key];
+                par = r.x;
+                e = pe_len(r);
+            } else {
+                par = t.LP[lo + ib + j];
+                e = t.LE[lo + ib + j];
+                dist = o_dist[lo + ib + j];
+            }
         }
         const int prev = __shfl_up(par, 1, WAVE);
         const bool first = active && (lane == 0 || par != prev);
@@ -101,7 +137,7 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
         const int use = (rem > tot && last_first && tot > 1) ? tot - 1 : tot;
         const int next_desc = __shfl_down(desc, 1, WAVE), next_key = __shfl_down(key, 1, WAVE);
         const int next_first = __shfl_down(first ? 1 : 0, 1, WAVE);
-        const double next_e = shfl_down_f64(e, 1);
+        const double next_e = shfl_down_f64(e, 1), next_dist = shfl_down_f64(dist, 1);
         const bool mine = first && lane < use;
         const bool two = lane + 1 < use && !next_first;
         const unsigned long long fm = __ballot(mine);
@@ -111,6 +147,7 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
             t.D[at] = make_int2(desc, two ? next_desc : 0);
             t.N[at] = make_int2(key, two ? next_key : -1);
             t.E[at] = make_double2(e, two ? next_e : 0.0);
+            t.DD[at] = make_double2(dist, two ? next_dist : 0.0);
         }
         const int ca = __popcll(__ballot(lane < use && from_a));
         ia += ca;
@@ -124,8 +161,8 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
 // a child's S tuple: an internal child's from the arrays (or from the LDS stage when its level is there), a leaf's
 // rebuilt from its distance
 template <int M>
-__device__ __forceinline__ void kid_tuple(int kd, const LeanTeam &t, const double2 (*stage)[WAVE], bool staged, int stage_base,
-                                          const double *__restrict__ o_dist, double *S) {
+__device__ __forceinline__ void kid_tuple(int kd, double dist, const LeanTeam &t, const double2 (*stage)[WAVE], bool staged,
+                                          int stage_base, double *S) {
     if (kd > 0) {
         double2 a, b, c;
         if (staged) {
@@ -136,7 +173,28 @@ __device__ __forceinline__ void kid_tuple(int kd, const LeanTeam &t, const doubl
         }
         S[0] = a.x; S[1] = a.y; S[2] = b.x; S[3] = b.y; S[4] = c.x; S[5] = c.y;
     } else {
-        leaf_tuple<M>(o_dist[-kd - 2], S);
+        leaf_tuple<M>(dist, S);
+    }
+}
+
+// S tuple of a node from its entry (apples/OLS.py:25-44: children in file order)
+template <int M>
+__device__ __forceinline__ void node_S(const int2 d, const double2 e, const double2 dd, const LeanTeam &t,
+                                       const double2 (*stage)[WAVE], bool staged, int kid_base, double *r) {
+    constexpr bool BME = (M == APPLES_BME);
+    const double coef = BME ? 1.0 / (double)(d.y != 0 ? 2 : 1) : 1.0;  // apples/BME.py:20
+    double S[6], u[6];
+    kid_tuple<M>(d.x, dd.x, t, stage, staged, kid_base, S);
+    lift<M>(S, e.x, u);
+#pragma unroll
+    for (int x = 0; x < 6; ++x) r[x] = 0;
+#pragma unroll
+    for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
+    if (d.y != 0) {
+        kid_tuple<M>(d.y, dd.y, t, stage, staged, kid_base, S);
+        lift<M>(S, e.y, u);
+#pragma unroll
+        for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
     }
 }
 
@@ -146,16 +204,17 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
     const double *lds_pow = sh.pow;
-    double2 (*stage)[WAVE] = sh.stage[wave];
-    int *mk_a = sh.mk[wave][0], *mk_b = sh.mk[wave][1];
+    LeanWave &L = sh.w[wave];
+    double2 (*stage)[WAVE] = L.stage;
     const DevTree &T = a.tree;
     const int4 *__restrict__ pe = reinterpret_cast<const int4 *>(T.pe);
     const int64_t cap = a.cap;
     const int64_t team = (int64_t)blockIdx.x * (APPLES_TPB / WAVE) + wave;
-    const LeanTeam t = lean_team(a.lean, team, a.lean_cap1);
+    const LeanTeam t = lean_team(a.lean, team, a.lean_cap1, a.lean_leaf1);
     int32_t *grp_off = a.grp_off + team * (T.height + 4);
     const int c0 = a.cls_count[0], c1 = a.cls_count[1], c2 = a.cls_count[2], c3 = a.cls_count[3];
     const int64_t n_work = (int64_t)c0 + c1 + c2 + c3;
+    const unsigned long long below = (1ull << lane) - 1ull;
     while (true) {
         // dynamic scheduling: one atomic add per query, broadcast to the wavefront
         int wq = 0;
@@ -173,26 +232,134 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
         const double *o_dist = a.obs_dist + q * a.obs_cap;
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
 
-        // ------------------------------------------------------------ pass A: the level lists (Subtree.py:23-43)
-        const int lvl_first = T.level[o_node[0]];
-        int lvl = lvl_first, base = 0, n_par = 0, G = 0, lca = -1;
-        bool overflow = false;
-        while (true) {
-            const int lo = cg[lvl + 1], hi = cg[lvl];  // observed leaves of this level: obs[lo, hi)
-            const int n_leaf = hi - lo;
-            if (n_par + n_leaf == 1 && hi == n) {  // one node left in the frontier: the LCA (Subtree.py:36-43)
-                lca = n_par == 1 ? t.K[base] : o_node[lo];
-                break;
+        // ------------------------------------------------------------ up front: the per-level offsets into LDS; parent and
+        // edge length of every observed leaf (independent gathers, all in flight together) into the team's arrays
+        for (int i = lane; i < T.height + 2; i += WAVE) L.cg[i] = cg[i];
+        for (int j0 = 0; j0 < n; j0 += 4 * WAVE) {
+            int4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * WAVE + lane;
+                r[u] = pe[o_node[j < n ? j : n - 1]];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * WAVE + lane;
+                if (j < n) { t.LP[j] = r[u].x; t.LE[j] = pe_len(r[u]); }
+            }
+        }
+        const int lvl_first = T.level[o_node[0]];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+        // ------------------------------------------------------------ bottom-up: the level lists (Subtree.py:23-43) and the S
+        // tuples (OLS.py:25-44) level by level.  The list of a level = the parents of the level below's internal nodes and
+        // observed leaves, merged by node id.  A list of at most 64 entries lives in the lanes' registers (entry k in
+        // lane k) with {parent, edge length} of its keys already on the way; a level that fits one merge step (list +
+        // observed leaves <= 64 keys) is merged out of LDS windows filled from registers -- no dependent memory round trip.
+        int lvl = lvl_first, base = 0, n_par = 0, G = 0, kid_base = 0;
+        bool overflow = false, prev_staged = false;
+        int cK = 0, pf_par = 0;
+        int2 cD = make_int2(0, 0), cN = make_int2(0, 0);
+        double2 cE = make_double2(0, 0), cDD = make_double2(0, 0);
+        double pf_e = 0;
+        int lo = L.cg[lvl + 1], hi = L.cg[lvl];  // observed leaves of this level: obs[lo, hi)
+        int n_leaf = hi - lo;
+        int lw_node = 0, lw_par = 0;
+        double lw_e = 0, lw_dist = 0;
+        if (n_leaf <= WAVE && lane < n_leaf) { lw_node = o_node[lo + lane]; lw_par = t.LP[lo + lane]; lw_e = t.LE[lo + lane]; lw_dist = o_dist[lo + lane]; }
+        while (true) {
+            if (n_par + n_leaf == 1 && hi == n) break;  // one node left in the frontier: the LCA (Subtree.py:36-43), entry `base`
             if ((int64_t)base + 2 * (int64_t)n_par + n_leaf > cap) { overflow = true; break; }
             if (lane == 0) grp_off[G] = base;
             const int next_base = base + n_par;
-            const int merged = lean_merge(t, base, n_par, o_node, lo, n_leaf, next_base, pe, mk_a, mk_b, lane);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            // ---- S tuples of this level's internal nodes
+            if (n_par > 0 && n_par <= WAVE) {
+                double r[6];
+                if (lane < n_par) {
+                    node_S<M>(cD, cE, cDD, t, stage, prev_staged, kid_base, r);
+                    t.T0[base + lane] = make_double2(r[0], r[1]);
+                    t.T1[base + lane] = make_double2(r[2], r[3]);
+                    t.T2[base + lane] = make_double2(r[4], r[5]);
+                }
+                __builtin_amdgcn_wave_barrier();  // (every lane's reads of the stage precede these stores)
+                if (lane < n_par) {
+                    stage[0][lane] = make_double2(r[0], r[1]);
+                    stage[1][lane] = make_double2(r[2], r[3]);
+                    stage[2][lane] = make_double2(r[4], r[5]);
+                }
+            } else if (n_par > WAVE) {
+                for (int idx = base + lane; idx < next_base; idx += WAVE) {
+                    double r[6];
+                    node_S<M>(t.D[idx], t.E[idx], t.DD[idx], t, stage, prev_staged, kid_base, r);
+                    t.T0[idx] = make_double2(r[0], r[1]);
+                    t.T1[idx] = make_double2(r[2], r[3]);
+                    t.T2[idx] = make_double2(r[4], r[5]);
+                }
+            }
+            // ---- the next level's list
+            int merged;
+            if (n_par <= WAVE && n_par + n_leaf <= WAVE) {
+                if (lane < n_par) { L.ka[lane] = cK; L.pa[lane] = pf_par; L.ea[lane] = pf_e; }
+                if (lane < n_leaf) { L.kb[lane] = lw_node; L.pb[lane] = lw_par; L.eb[lane] = lw_e; L.db[lane] = lw_dist; }
+                __builtin_amdgcn_wave_barrier();
+                const int tot = n_par + n_leaf;
+                const bool active = lane < tot;
+                int i_lo = max(0, lane - n_leaf), i_hi = min(lane, n_par);  // i = keys of the list among the lane smallest
+                while (i_lo < i_hi) {
+                    const int i = (i_lo + i_hi) >> 1;
+                    if (L.ka[i] < L.kb[lane - 1 - i]) i_lo = i + 1; else i_hi = i;
+                }
+                const int i = i_lo, j = lane - i_lo;
+                const int ka = i < n_par ? L.ka[i] : 0x7fffffff, kb = j < n_leaf ? L.kb[j] : 0x7fffffff;
+                const bool from_a = ka < kb;
+                const int key = from_a ? ka : kb;
+                const int desc = from_a ? base + i + 1 : -(lo + j) - 2;
+                int par = -3;
+                double e = 0, dist = 0;
+                if (active) {
+                    if (from_a) { par = L.pa[i]; e = L.ea[i]; }
+                    else { par = L.pb[j]; e = L.eb[j]; dist = L.db[j]; }
+                }
+                const int prev = __shfl_up(par, 1, WAVE);
+                const bool first = active && (lane == 0 || par != prev);
+                const int next_desc = __shfl_down(desc, 1, WAVE), next_key = __shfl_down(key, 1, WAVE);
+                const int next_first = __shfl_down(first ? 1 : 0, 1, WAVE);
+                const double next_e = shfl_down_f64(e, 1), next_dist = shfl_down_f64(dist, 1);
+                const bool two = lane + 1 < tot && !next_first;
+                const unsigned long long fm = __ballot(first);
+                merged = __popcll(fm);
+                if (first) {
+                    const int c = __popcll(fm & below);
+                    const int2 eD = make_int2(desc, two ? next_desc : 0), eN = make_int2(key, two ? next_key : -1);
+                    const double2 eE = make_double2(e, two ? next_e : 0.0), eDD = make_double2(dist, two ? next_dist : 0.0);
+                    L.oK[c] = par; L.oD[c] = eD; L.oN[c] = eN; L.oE[c] = eE; L.oDD[c] = eDD;
+                    t.K[next_base + c] = par; t.D[next_base + c] = eD; t.N[next_base + c] = eN; t.E[next_base + c] = eE; t.DD[next_base + c] = eDD;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < merged) { cK = L.oK[lane]; cD = L.oD[lane]; cN = L.oN[lane]; cE = L.oE[lane]; cDD = L.oDD[lane]; }
+            } else {
+                merged = lean_merge(t, base, n_par, o_node, o_dist, lo, n_leaf, next_base, pe, L.ka, L.kb, lane);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (merged <= WAVE && lane < merged) {
+                    cK = t.K[next_base + lane]; cD = t.D[next_base + lane]; cN = t.N[next_base + lane];
+                    cE = t.E[next_base + lane]; cDD = t.DD[next_base + lane];
+                }
+            }
+            // {parent, edge length} of the new list's keys: on the way while the next step computes its S tuples
+            if (merged <= WAVE && lane < merged) {
+                const int4 r = pe[cK];
+                pf_par = r.x;
+                pf_e = pe_len(r);
+            }
+            prev_staged = n_par > 0 && n_par <= WAVE;
+            kid_base = base;
             base = next_base;
             n_par = merged;
             ++G;
             --lvl;
+            lo = L.cg[lvl + 1]; hi = L.cg[lvl];
+            n_leaf = hi - lo;
+            if (n_leaf <= WAVE && lane < n_leaf) { lw_node = o_node[lo + lane]; lw_par = t.LP[lo + lane]; lw_e = t.LE[lo + lane]; lw_dist = o_dist[lo + lane]; }
         }
         if (overflow) {  // hand the query to the workgroup-sized teams with full-size scratch
             if (lane == 0) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
@@ -204,52 +371,9 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (a.debug_phase == 1) continue;
 
-        // ------------------------------------------------------------ pass B: S tuples, deepest level first (OLS.py:25-44)
-        // (group g = the internal nodes g levels above the deepest observed leaf; group 0 is empty, group G the LCA,
-        // whose own S nobody needs)
-        bool prev_staged = false;
-        int g_lo = grp_off[1];
-        for (int g = 1; g < G; ++g) {
-            const int g_hi = grp_off[g + 1];
-            const int kid_base = grp_off[g - 1];
-            const bool one_pass = g_hi - g_lo <= WAVE;
-            const bool staged = prev_staged && one_pass;
-            for (int idx = g_lo + lane; idx < g_hi; idx += WAVE) {
-                const int2 d = t.D[idx];
-                const double2 e = t.E[idx];
-                const double coef = BME ? 1.0 / (double)(d.y != 0 ? 2 : 1) : 1.0;  // apples/BME.py:20
-                double S[6], r[6], u[6];
-                kid_tuple<M>(d.x, t, stage, staged, kid_base, o_dist, S);
-                lift<M>(S, e.x, u);
-#pragma unroll
-                for (int x = 0; x < 6; ++x) r[x] = 0;
-#pragma unroll
-                for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
-                if (d.y != 0) {
-                    kid_tuple<M>(d.y, t, stage, staged, kid_base, o_dist, S);
-                    lift<M>(S, e.y, u);
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
-                }
-                t.T0[idx] = make_double2(r[0], r[1]);
-                t.T1[idx] = make_double2(r[2], r[3]);
-                t.T2[idx] = make_double2(r[4], r[5]);
-                if (one_pass) {  // (every lane's reads of the stage precede this store in the instruction stream)
-                    __builtin_amdgcn_wave_barrier();
-                    stage[0][idx - g_lo] = make_double2(r[0], r[1]);
-                    stage[1][idx - g_lo] = make_double2(r[2], r[3]);
-                    stage[2][idx - g_lo] = make_double2(r[4], r[5]);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            prev_staged = one_pass && g_hi > g_lo;
-            g_lo = g_hi;
-        }
-        if (a.debug_phase == 2) continue;
-
-        // ------------------------------------------------------------ pass C, top down and parent-centric: a node forms
-        // R for each valid child (all_R_values), solves it (placement_per_edge) and evaluates its residual
-        // (error_per_edge); an internal child's tuple becomes lift(R) over its own edge
+        // ------------------------------------------------------------ top down and parent-centric: a node forms R for each
+        // valid child (all_R_values), solves it (placement_per_edge) and evaluates its residual (error_per_edge); an
+        // internal child's tuple becomes lift(R) over its own edge
         double best_key = INF_D;
         int best_v = 0x7fffffff;
         double best_x1 = 0, best_x2 = 0, best_err = 0, best_e = 0;
@@ -259,7 +383,7 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
             for (int idx = g0 + lane; idx < g1; idx += WAVE) {
                 const bool is_lca = idx == VI;
                 const int2 d = t.D[idx], nd = t.N[idx];
-                const double2 e = t.E[idx];
+                const double2 e = t.E[idx], dd = t.DD[idx];
                 const int nk = d.y != 0 ? 2 : 1;
                 // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
                 const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
@@ -269,8 +393,8 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
                     plift[0] = p0.x; plift[1] = p0.y; plift[2] = p1.x; plift[3] = p1.y; plift[4] = p2.x; plift[5] = p2.y;
                 }
                 double Sk[6], Ss[6];  // the child in hand and its sibling
-                kid_tuple<M>(d.x, t, stage, false, 0, o_dist, Sk);
-                if (nk > 1) kid_tuple<M>(d.y, t, stage, false, 0, o_dist, Ss);
+                kid_tuple<M>(d.x, dd.x, t, stage, false, 0, Sk);
+                if (nk > 1) kid_tuple<M>(d.y, dd.y, t, stage, false, 0, Ss);
                 double ek = e.x, es = e.y;
                 int kd = d.x, ks = d.y, kn = nd.x, ksn = nd.y;
                 // one child at a time (the two swap roles in between): a rolled loop keeps one 2x2 solve's worth of
@@ -336,7 +460,6 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
             if (best_x1 == 0 && best_err > 0 && (best_x2 == 0 || best_x2 == best_e)) pl.flags |= APPLES_F_MISPLACED;
             a.out[q] = pl;
         }
-        (void)lca;
     }
 }
 
