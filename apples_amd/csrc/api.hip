@@ -491,10 +491,10 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
             if (dev_alloc(ctx, &sw.xe, sw.teams * cap * 18)) return 1;
         return 0;
     }
-    if (teams_per_wg == 4 && sweep_lean_layout(t, xe)) {  // sweep_lean.hip: field arrays in place of ent and A
+    if (sweep_lean_layout(t, xe)) {  // sweep_lean.hip: field arrays in place of ent and A
         sw.lean_cap1 = round_up(cap + 1, 4);
         // (the selection kernel routes queries with more than big_threshold observed leaves to the workgroup-sized teams)
-        sw.lean_leaf1 = round_up(std::max<int64_t>(std::min<int64_t>(leaf_cap, big_threshold(ctx)), 4), 4);
+        sw.lean_leaf1 = round_up(std::max<int64_t>(teams_per_wg == 4 ? std::min<int64_t>(leaf_cap, big_threshold(ctx)) : leaf_cap, 4), 4);
         char *p = nullptr;
         if (dev_alloc(ctx, &p, sw.teams * (sw.lean_cap1 * LEAN_BYTES_PER_NODE + sw.lean_leaf1 * LEAN_BYTES_PER_LEAF))) return 1;
         sw.lean = p;
@@ -607,7 +607,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     if (const char *e = getenv("APPLES_SWEEP_CAP")) cap = std::min<int64_t>(cap, std::max<int64_t>(64, atoll(e)));  // test knob: small teams overflow early
     if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, t.scan ? 0 : std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold(ctx))), xe)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
-    int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 4;
+    int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 4 + (sweep_lean_layout(t, xe) ? members * LEAN_BYTES_PER_LEAF : 0);
     int64_t big_max = getenv("APPLES_SWEEP_BIG_WGS") ? atoi(getenv("APPLES_SWEEP_BIG_WGS")) : 512;
     int wgs_big = (int)std::min<int64_t>(big_max, std::max<int64_t>(4, ((int64_t)24 << 30) / std::max<int64_t>(per_wg, 1)));
     wgs_big = (int)std::min<int64_t>(wgs_big, batch);
@@ -833,9 +833,13 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     b.overflow_list = nullptr;  // a big team's scratch holds the whole tree: it cannot overflow
     b.overflow_count = nullptr;
     b.cursor = w.cls_count + 5;
+    // workgroup-sized teams: sweep_lean.hip's where the workspace has its field arrays (big binary trees), else the level loop
+    auto launch_big = [&](const SweepArgs &x, hipStream_t s) {
+        return (w.big.lean && !x.keep_edges) ? launch_sweep_lean_big(ctx, x, nq, w.big.wgs, s) : launch_sweep(ctx, x, nq, w.big.wgs, 256, s);
+    };
     if (small_team != 64) {  // diagnostic mode: workgroup-sized teams for everything
         b.cursor = w.cls_count + 4;
-        return launch_sweep(ctx, b, nq, w.big.wgs, 256, st);
+        return launch_big(b, st);
     }
     // one launch: the first w.big.wgs workgroups first serve the queries the selection kernel
     // routed to workgroup-sized teams (many observed leaves), then all workgroups split into
@@ -855,7 +859,7 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
         // chip and the long jobs would start when the short ones are done (measured: 3.3 + 3.1 ms per launch instead
         // of the two side by side)
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sel, st));
-        if (launch_sweep(ctx, b, nq, w.big.wgs, 256, st)) return 1;
+        if (launch_big(b, st)) return 1;
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_big, ctx->ev_sel, 0));
         if (launch_sweep_lean(ctx, sm, nq, w.small.wgs, ctx->stream_big)) return 1;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_big, ctx->stream_big));
@@ -867,8 +871,7 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     b.work_list = w.overflow_list;
     b.work_count = w.overflow_count;
     b.cursor = w.cls_count + 6;
-    if (launch_sweep(ctx, b, nq, w.big.wgs, 256, st)) return 1;
-    return 0;
+    return launch_big(b, st);
 }
 
 int dist_tile_for(int64_t nq) {

@@ -369,6 +369,7 @@ int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int t
 #define LEAN_MAX_LEVELS 256      // per-level offsets of a query in LDS: trees up to 254 levels
 bool sweep_lean_layout(const DevTree &t, bool per_edge_records);
 int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st);
+int launch_sweep_lean_big(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st);
 int sweep_lean_waves();  // wavefronts per SIMD the lean kernel is built for (1 536 teams each)
 int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,
                        hipStream_t st);

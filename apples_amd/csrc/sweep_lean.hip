@@ -198,9 +198,103 @@ __device__ __forceinline__ void node_S(const int2 d, const double2 e, const doub
     }
 }
 
+// running arg-min of a lane over the edges it solved (apples/Algorithm.py:74-91: smallest key, ties to the smaller edge_index)
+struct LeanBest {
+    double key, x1, x2, err, e;
+    int v, x1_int;
+};
+
+__device__ __forceinline__ void lean_best_init(LeanBest &b) {
+    b.key = INF_D; b.v = 0x7fffffff; b.x1 = b.x2 = b.err = b.e = 0; b.x1_int = 0;
+}
+
+// Top-down step of one internal node (parent-centric): it forms R for each valid child (all_R_values, OLS.py:57-80),
+// solves it (placement_per_edge, util.py:6-54) and evaluates its residual (error_per_edge); an internal child's tuple
+// becomes lift(R) over its own edge, which is what that child will add for each of its own children.
+template <int M>
+__device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, bool is_lca, int negative, int criterion,
+                                             const double *lds_pow, LeanBest &best) {
+    constexpr bool BME = (M == APPLES_BME);
+    const int2 d = t.D[idx], nd = t.N[idx];
+    const double2 e = t.E[idx], dd = t.DD[idx];
+    const int nk = d.y != 0 ? 2 : 1;
+    // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
+    const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
+    double plift[6];
+    if (!is_lca) {  // this node's R, already lifted over its own edge by its parent
+        const double2 p0 = t.T0[idx], p1 = t.T1[idx], p2 = t.T2[idx];
+        plift[0] = p0.x; plift[1] = p0.y; plift[2] = p1.x; plift[3] = p1.y; plift[4] = p2.x; plift[5] = p2.y;
+    }
+    double Sk[6], Ss[6];  // the child in hand and its sibling
+    kid_tuple<M>(d.x, dd.x, t, nullptr, false, 0, Sk);
+    if (nk > 1) kid_tuple<M>(d.y, dd.y, t, nullptr, false, 0, Ss);
+    double ek = e.x, es = e.y;
+    int kd = d.x, ks = d.y, kn = nd.x, ksn = nd.y;
+    // one child at a time (the two swap roles in between): a rolled loop keeps one 2x2 solve's worth of
+    // temporaries live, which is what decides how many wavefronts a SIMD holds
+#pragma unroll 1
+    for (int z = 0; z < nk; ++z) {
+        double acc[6];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) acc[x] = 0;
+        if (nk > 1) {  // the one valid sibling (apples/OLS.py:59-69)
+            double u[6];
+            lift<M>(Ss, es, u);
+#pragma unroll
+            for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * u[x] : u[x];
+        }
+        if (!is_lca) {  // parent term last (apples/OLS.py:70-80)
+#pragma unroll
+            for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
+        }
+        const Sol r = solve_edge<M>(Sk, acc, ek, negative, lds_pow);
+        if (kd > 0) {
+            double u[6];
+            lift<M>(acc, ek, u);
+            t.T0[kd - 1] = make_double2(u[0], u[1]);
+            t.T1[kd - 1] = make_double2(u[2], u[3]);
+            t.T2[kd - 1] = make_double2(u[4], u[5]);
+        }
+        const double key = (criterion == APPLES_ME) ? r.x1 : r.err;
+        if (key < best.key || (key == best.key && kn < best.v)) {
+            best.key = key; best.v = kn; best.x1 = r.x1; best.x2 = r.x2; best.err = r.err; best.x1_int = r.x1_int; best.e = ek;
+        }
+#pragma unroll
+        for (int x = 0; x < 6; ++x) { const double w = Sk[x]; Sk[x] = Ss[x]; Ss[x] = w; }
+        { const double w = ek; ek = es; es = w; }
+        { const int w = kd; kd = ks; ks = w; }
+        { const int w = kn; kn = ksn; ksn = w; }
+    }
+}
+
+// the query's placement from the team's winner (apples/Algorithm.py:92-101); `mine` = this lane holds the winning edge
+__device__ __forceinline__ void lean_write_placement(apples_placement *out, int64_t q, int V, int win, bool mine, bool lane0,
+                                                     const LeanBest &best) {
+    if (win == 0x7fffffff) {
+        if (lane0) {
+            apples_placement pl = out[q];
+            pl.n_valid = V;
+            pl.edge = -1;
+            pl.flags |= APPLES_F_DEGENERATE | APPLES_F_PENDANT_INT;
+            out[q] = pl;
+        }
+    } else if (mine) {
+        apples_placement pl = out[q];
+        pl.n_valid = V;
+        pl.edge = win;
+        pl.error = best.err;
+        pl.distal = best.e - best.x2;
+        pl.pendant = best.x1;
+        pl.flags = 0;
+        if (best.x1_int) pl.flags |= APPLES_F_PENDANT_INT;
+        if (best.x1 == 0 && best.err > 0 && (best.x2 == 0 || best.x2 == best.e)) pl.flags |= APPLES_F_MISPLACED;
+        out[q] = pl;
+    }
+}
+
+
 template <int M>
 __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
-    constexpr bool BME = (M == APPLES_BME);
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
     const double *lds_pow = sh.pow;
@@ -374,92 +468,218 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
         // ------------------------------------------------------------ top down and parent-centric: a node forms R for each
         // valid child (all_R_values), solves it (placement_per_edge) and evaluates its residual (error_per_edge); an
         // internal child's tuple becomes lift(R) over its own edge
-        double best_key = INF_D;
-        int best_v = 0x7fffffff;
-        double best_x1 = 0, best_x2 = 0, best_err = 0, best_e = 0;
-        int best_int = 0;
+        LeanBest best;
+        lean_best_init(best);
         for (int g = G; g >= 1; --g) {
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
-            for (int idx = g0 + lane; idx < g1; idx += WAVE) {
-                const bool is_lca = idx == VI;
-                const int2 d = t.D[idx], nd = t.N[idx];
-                const double2 e = t.E[idx], dd = t.DD[idx];
-                const int nk = d.y != 0 ? 2 : 1;
-                // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
-                const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
-                double plift[6];
-                if (!is_lca) {  // this node's R, already lifted over its own edge by its parent
-                    const double2 p0 = t.T0[idx], p1 = t.T1[idx], p2 = t.T2[idx];
-                    plift[0] = p0.x; plift[1] = p0.y; plift[2] = p1.x; plift[3] = p1.y; plift[4] = p2.x; plift[5] = p2.y;
-                }
-                double Sk[6], Ss[6];  // the child in hand and its sibling
-                kid_tuple<M>(d.x, dd.x, t, stage, false, 0, Sk);
-                if (nk > 1) kid_tuple<M>(d.y, dd.y, t, stage, false, 0, Ss);
-                double ek = e.x, es = e.y;
-                int kd = d.x, ks = d.y, kn = nd.x, ksn = nd.y;
-                // one child at a time (the two swap roles in between): a rolled loop keeps one 2x2 solve's worth of
-                // temporaries live, which is what decides how many wavefronts a SIMD holds
-#pragma unroll 1
-                for (int z = 0; z < nk; ++z) {
-                    double acc[6];
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) acc[x] = 0;
-                    if (nk > 1) {  // the one valid sibling (apples/OLS.py:59-69)
-                        double u[6];
-                        lift<M>(Ss, es, u);
-#pragma unroll
-                        for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * u[x] : u[x];
-                    }
-                    if (!is_lca) {  // parent term last (apples/OLS.py:70-80)
-#pragma unroll
-                        for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
-                    }
-                    const Sol r = solve_edge<M>(Sk, acc, ek, a.negative, lds_pow);
-                    if (kd > 0) {  // what the child will add for each of its own children: lift(R) over its edge
-                        double u[6];
-                        lift<M>(acc, ek, u);
-                        t.T0[kd - 1] = make_double2(u[0], u[1]);
-                        t.T1[kd - 1] = make_double2(u[2], u[3]);
-                        t.T2[kd - 1] = make_double2(u[4], u[5]);
-                    }
-                    const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
-                    if (key < best_key || (key == best_key && kn < best_v)) {
-                        best_key = key; best_v = kn; best_x1 = r.x1; best_x2 = r.x2; best_err = r.err; best_int = r.x1_int; best_e = ek;
-                    }
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) { const double w = Sk[x]; Sk[x] = Ss[x]; Ss[x] = w; }
-                    { const double w = ek; ek = es; es = w; }
-                    { const int w = kd; kd = ks; ks = w; }
-                    { const int w = kn; kn = ksn; ksn = w; }
-                }
-            }
+            for (int idx = g0 + lane; idx < g1; idx += WAVE) lean_td_node<M>(t, idx, idx == VI, a.negative, a.criterion, lds_pow, best);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
 
         // ------------------------------------------------------------ selection (apples/Algorithm.py:74-91)
-        const int my_best = best_v;
-        team_argmin<WAVE>(best_key, best_v, nullptr, nullptr);
-        const int win = best_v;
-        if (win == 0x7fffffff) {
-            if (lane == 0) {
-                apples_placement pl = a.out[q];
-                pl.n_valid = V;
-                pl.edge = -1;
-                pl.flags |= APPLES_F_DEGENERATE | APPLES_F_PENDANT_INT;
-                a.out[q] = pl;
-            }
-        } else if (my_best == win) {
-            apples_placement pl = a.out[q];
-            pl.n_valid = V;
-            pl.edge = win;
-            pl.error = best_err;
-            pl.distal = best_e - best_x2;
-            pl.pendant = best_x1;
-            pl.flags = 0;
-            if (best_int) pl.flags |= APPLES_F_PENDANT_INT;
-            if (best_x1 == 0 && best_err > 0 && (best_x2 == 0 || best_x2 == best_e)) pl.flags |= APPLES_F_MISPLACED;
-            a.out[q] = pl;
+        const int my_best = best.v;
+        double wkey = best.key;
+        int win = best.v;
+        team_argmin<WAVE>(wkey, win, nullptr, nullptr);
+        lean_write_placement(a.out, q, V, win, my_best == win, lane == 0, best);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Workgroup-sized team (TEAM threads on one query): the queries with many observed leaves, whose levels hold thousands of
+// nodes.  The same passes in their general form: S tuples and top-down steps strided over the team, TEAM keys per merge
+// step (neighbours and counts through LDS instead of shuffles), a barrier where the wavefront-sized team has a fence.
+template <int TEAM>
+struct LeanBigShared {
+    double pow[384 + 256];
+    int cg[LEAN_MAX_LEVELS];
+    int ka[TEAM], kb[TEAM];                        // the two key windows of a merge step
+    int m_par[TEAM], m_desc[TEAM], m_key[TEAM];    // what a step's lanes tell their neighbours
+    double m_e[TEAM], m_dist[TEAM];
+    int mcnt[2][TEAM / WAVE];
+    double d[TEAM / WAVE];
+    int i[TEAM / WAVE];
+    int w;
+};
+
+template <int TEAM>
+__device__ __forceinline__ int lean_merge_wg(const LeanTeam &t, int base, int nA, const int32_t *__restrict__ o_node,
+                                             const double *__restrict__ o_dist, int lo, int nB, int next_base,
+                                             const int4 *__restrict__ pe, LeanBigShared<TEAM> &sh) {
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    int out = 0, ia = 0, ib = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    while (ia < nA || ib < nB) {
+        const int rem = (nA - ia) + (nB - ib);
+        const int wa = min(nA - ia, TEAM), wb = min(nB - ib, TEAM);
+        sh.ka[tid] = tid < wa ? t.K[base + ia + tid] : 0x7fffffff;
+        sh.kb[tid] = tid < wb ? o_node[lo + ib + tid] : 0x7fffffff;
+        __syncthreads();
+        const int tot = min(wa + wb, TEAM);
+        const bool active = tid < tot;
+        int i_lo = max(0, tid - wb), i_hi = min(tid, wa);
+        while (i_lo < i_hi) {
+            const int i = (i_lo + i_hi) >> 1;
+            if (sh.ka[i] < sh.kb[tid - 1 - i]) i_lo = i + 1; else i_hi = i;
         }
+        const int i = i_lo, j = tid - i_lo;
+        const int ka = i < wa ? sh.ka[i] : 0x7fffffff, kb = j < wb ? sh.kb[j] : 0x7fffffff;
+        const bool from_a = ka < kb;
+        const int key = from_a ? ka : kb;
+        const int desc = from_a ? base + ia + i + 1 : -(lo + ib + j) - 2;
+        int par = -3;
+        double e = 0, dist = 0;
+        if (active) {
+            if (from_a) {
+                const int4 r = pe[key];
+                par = r.x;
+                e = pe_len(r);
+            } else {
+                par = t.LP[lo + ib + j];
+                e = t.LE[lo + ib + j];
+                dist = o_dist[lo + ib + j];
+            }
+        }
+        sh.m_par[tid] = par; sh.m_desc[tid] = desc; sh.m_key[tid] = key; sh.m_e[tid] = e; sh.m_dist[tid] = dist;
+        __syncthreads();
+        const bool first = active && (tid == 0 || par != sh.m_par[tid - 1]);
+        const bool last_first = tot > 1 && sh.m_par[tot - 1] != sh.m_par[tot - 2];
+        const int use = (rem > tot && last_first) ? tot - 1 : tot;
+        const bool two = tid + 1 < use && sh.m_par[tid + 1] == par;
+        const bool mine = first && tid < use;
+        const unsigned long long fm = __ballot(mine), am = __ballot(tid < use && from_a);
+        if (lane == 0) { sh.mcnt[0][wave] = __popcll(fm); sh.mcnt[1][wave] = __popcll(am); }
+        __syncthreads();
+        int before = 0, total = 0, ca = 0;
+#pragma unroll
+        for (int w = 0; w < TEAM / WAVE; ++w) {
+            if (w < wave) before += sh.mcnt[0][w];
+            total += sh.mcnt[0][w];
+            ca += sh.mcnt[1][w];
+        }
+        if (mine) {
+            const int at = next_base + out + before + __popcll(fm & below);
+            t.K[at] = par;
+            t.D[at] = make_int2(desc, two ? sh.m_desc[tid + 1] : 0);
+            t.N[at] = make_int2(key, two ? sh.m_key[tid + 1] : -1);
+            t.E[at] = make_double2(e, two ? sh.m_e[tid + 1] : 0.0);
+            t.DD[at] = make_double2(dist, two ? sh.m_dist[tid + 1] : 0.0);
+        }
+        ia += ca;
+        ib += use - ca;
+        out += total;
+        __syncthreads();
+    }
+    return out;
+}
+
+// team-wide arg-min over (key, id) for a team of TEAM threads (sweep_math.h:team_argmin is tied to 256)
+template <int TEAM>
+__device__ __forceinline__ void lean_argmin_wg(double &d, int &i, LeanBigShared<TEAM> &sh) {
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+        const double d2 = shfl_down_f64s(d, o);
+        const int i2 = __shfl_down(i, o, WAVE);
+        if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; }
+    }
+    const int w = threadIdx.x / WAVE;
+    __syncthreads();
+    if ((threadIdx.x & (WAVE - 1)) == 0) { sh.d[w] = d; sh.i[w] = i; }
+    __syncthreads();
+    d = sh.d[0]; i = sh.i[0];
+    for (int k = 1; k < TEAM / WAVE; ++k) {
+        const double d2 = sh.d[k];
+        const int i2 = sh.i[k];
+        if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; }
+    }
+}
+
+template <int M, int TEAM>
+__device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM> &sh) {
+    const int tid = threadIdx.x;
+    const double *lds_pow = sh.pow;
+    const DevTree &T = a.tree;
+    const int4 *__restrict__ pe = reinterpret_cast<const int4 *>(T.pe);
+    const LeanTeam t = lean_team(a.lean, blockIdx.x, a.lean_cap1, a.lean_leaf1);
+    int32_t *grp_off = a.grp_off + (int64_t)blockIdx.x * (T.height + 4);
+    const int64_t n_work = a.work_count ? *a.work_count : nq;
+    while (true) {
+        if (tid == 0) sh.w = atomicAdd(a.cursor, 1);
+        __syncthreads();
+        const int64_t w = sh.w;
+        __syncthreads();
+        if (w >= n_work) break;
+        const int64_t q = a.work_list ? a.work_list[w] : w;
+        const int n = a.n_obs[q];
+        if (n == 0) continue;
+        const int32_t *o_node = a.obs_node + q * a.obs_cap;
+        const double *o_dist = a.obs_dist + q * a.obs_cap;
+        const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
+        for (int i = tid; i < T.height + 2; i += TEAM) sh.cg[i] = cg[i];
+        for (int j = tid; j < n; j += TEAM) {
+            const int4 r = pe[o_node[j]];
+            t.LP[j] = r.x;
+            t.LE[j] = pe_len(r);
+        }
+        const int lvl_first = T.level[o_node[0]];
+        __syncthreads();
+        int lvl = lvl_first, base = 0, n_par = 0, G = 0;
+        while (true) {
+            const int lo = sh.cg[lvl + 1], hi = sh.cg[lvl];
+            const int n_leaf = hi - lo;
+            if (n_par + n_leaf == 1 && hi == n) break;  // the LCA (Subtree.py:36-43), entry `base`
+            if (tid == 0) grp_off[G] = base;
+            const int next_base = base + n_par;
+            for (int idx = base + tid; idx < next_base; idx += TEAM) {  // S tuples of this level (the level below's are complete)
+                double r[6];
+                node_S<M>(t.D[idx], t.E[idx], t.DD[idx], t, nullptr, false, 0, r);
+                t.T0[idx] = make_double2(r[0], r[1]);
+                t.T1[idx] = make_double2(r[2], r[3]);
+                t.T2[idx] = make_double2(r[4], r[5]);
+            }
+            const int merged = lean_merge_wg<TEAM>(t, base, n_par, o_node, o_dist, lo, n_leaf, next_base, pe, sh);
+            __syncthreads();
+            base = next_base;
+            n_par = merged;
+            ++G;
+            --lvl;
+        }
+        const int VI = base, V = base + n;
+        if (tid == 0) { grp_off[G] = VI; grp_off[G + 1] = VI + 1; }
+        __syncthreads();
+        if (a.debug_phase == 1) continue;
+        LeanBest best;
+        lean_best_init(best);
+        for (int g = G; g >= 1; --g) {
+            const int g0 = grp_off[g], g1 = grp_off[g + 1];
+            for (int idx = g0 + tid; idx < g1; idx += TEAM) lean_td_node<M>(t, idx, idx == VI, a.negative, a.criterion, lds_pow, best);
+            __syncthreads();
+        }
+        const int my_best = best.v;
+        double wkey = best.key;
+        int win = best.v;
+        lean_argmin_wg<TEAM>(wkey, win, sh);
+        lean_write_placement(a.out, q, V, win, my_best == win, tid == 0, best);
+        __syncthreads();
+    }
+}
+
+template <int M, int TEAM>
+__global__ __launch_bounds__(TEAM, TEAM / 256 * 2 > 2 ? 2 : TEAM / 256 * 2) void k_sweep_lean_big(SweepArgs a, int64_t nq) {
+    __shared__ LeanBigShared<TEAM> sh;
+    for (int i = threadIdx.x; i < 384; i += TEAM) sh.pow[i] = (&kPowLogTab[0][0])[i];
+    for (int i = threadIdx.x; i < 256; i += TEAM) sh.pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
+    __syncthreads();
+    lean_big_loop<M, TEAM>(a, nq, sh);
+}
+
+template <int TEAM>
+void launch_lean_big_t(const SweepArgs &a, int64_t nq, dim3 grid, hipStream_t st) {
+    const dim3 block(TEAM);
+    switch (a.method) {
+        case APPLES_FM: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_FM, TEAM>), grid, block, 0, st, a, nq); break;
+        case APPLES_BME: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BME, TEAM>), grid, block, 0, st, a, nq); break;
+        case APPLES_BE: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BE, TEAM>), grid, block, 0, st, a, nq); break;
+        default: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_OLS, TEAM>), grid, block, 0, st, a, nq); break;
     }
 }
 
@@ -485,11 +705,22 @@ void launch_lean_w(const SweepArgs &a, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
-// wavefronts per SIMD the lean sweep is compiled for (registers: 2 -> 175 without spills, 3 -> 168 with a few spilled,
-// 4 -> 128); the workspace sizes its team count from it.  APPLES_LEAN_WAVES: tuning knob.
+// wavefronts per SIMD the lean sweep is compiled for (2: no spills; 3: 168 registers with some spilled; LDS allows no
+// more); the workspace sizes its team count from it.  APPLES_LEAN_WAVES: tuning knob.
 int sweep_lean_waves() {
-    static const int w = getenv("APPLES_LEAN_WAVES") ? std::min(4, std::max(2, atoi(getenv("APPLES_LEAN_WAVES")))) : 2;
+    static const int w = getenv("APPLES_LEAN_WAVES") ? std::min(3, std::max(2, atoi(getenv("APPLES_LEAN_WAVES")))) : 2;
     return w;
+}
+
+// workgroup-sized teams over a device-side list (routed or overflow queries); a.lean = the big teams' field arrays
+int launch_sweep_lean_big(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st) {
+    if (nq == 0) return 0;
+    static const int team = getenv("APPLES_LEAN_BIG_TEAM") ? atoi(getenv("APPLES_LEAN_BIG_TEAM")) : 256;  // tuning knob
+    const dim3 grid((unsigned)std::min<int64_t>(nq, wgs));
+    if (team == 512) launch_lean_big_t<512>(a, nq, grid, st);
+    else launch_lean_big_t<256>(a, nq, grid, st);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
 }
 
 // wavefront-sized teams over the size-class queues of one device batch; `a.lean` etc. set by the caller
@@ -498,7 +729,6 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, 
     const int64_t need = (nq + 3) / 4;
     const dim3 grid((unsigned)std::min<int64_t>(need, wgs));
     switch (sweep_lean_waves()) {
-        case 4: launch_lean_w<4>(a, grid, st); break;
         case 3: launch_lean_w<3>(a, grid, st); break;
         default: launch_lean_w<2>(a, grid, st); break;
     }
