@@ -757,6 +757,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
     s.map = sw.map; s.map_ver = sw.ver; s.order = sw.order; s.ent = sw.ent;
     s.lean = sw.lean; s.lean_cap1 = sw.lean_cap1; s.lean_leaf1 = sw.lean_leaf1;
+    s.prof = ctx->lean_prof;
     s.map_bits = 1;
     while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
     if (const char *e = getenv("APPLES_MAP_BITS")) s.map_bits = std::min(30, std::max(s.map_bits, atoi(e)));  // test knob: few tags, early wrap
@@ -1125,6 +1126,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
     if (dev_alloc(ctx, &ctx->d_exotic, 1) || hipMemset(ctx->d_exotic, 0, sizeof(int)) != hipSuccess) return fail();
     if (getenv("APPLES_SCAN_PROFILE"))
         if (dev_alloc(ctx, &ctx->scan_prof, 8) || hipMemset(ctx->scan_prof, 0, 64) != hipSuccess) return fail();
+    if (getenv("APPLES_LEAN_PROFILE"))
+        if (dev_alloc(ctx, &ctx->lean_prof, 16) || hipMemset(ctx->lean_prof, 0, 128) != hipSuccess) return fail();
     if (upload_tree(ctx, tree)) return fail();
     if (aln) {
         if (setup_alignment(ctx, tree, aln)) return fail();
@@ -1228,6 +1231,20 @@ void apples_ctx_destroy(apples_ctx *ctx) {
         fprintf(stderr, "scan sweep phases (share of team cycles): queue %.3f  phase0 %.3f  phase1 %.3f  bottom-up %.3f  top-down %.3f  select %.3f  (queries %llu)\n",
                 h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6]);
         dev_free(ctx->scan_prof);
+    }
+    if (ctx->lean_prof) {  // diagnostic: where the lean sweep's wavefront-sized teams spent their cycles
+        unsigned long long h[16] = {};
+        (void)hipMemcpy(h, ctx->lean_prof, sizeof h, hipMemcpyDeviceToHost);
+        double tot = 0;
+        for (int i = 0; i < 7; ++i) tot += (double)h[i];
+        if (tot > 0)
+            fprintf(stderr, "lean sweep phases (share of team cycles): queue %.3f  up-front %.3f  bottom-up on chip %.3f (%llu steps, %.0f cycles each)  "
+                            "bottom-up general %.3f (%llu steps, %.0f)  top-down pairs %.3f (%llu steps, %.0f)  top-down general %.3f (%llu steps, %.0f)  "
+                            "select %.3f  (queries %llu, %.0f cycles each)\n",
+                    h[0] / tot, h[1] / tot, h[2] / tot, h[8], h[8] ? (double)h[2] / h[8] : 0.0, h[3] / tot, h[9], h[9] ? (double)h[3] / h[9] : 0.0,
+                    h[4] / tot, h[10], h[10] ? (double)h[4] / h[10] : 0.0, h[5] / tot, h[11], h[11] ? (double)h[5] / h[11] : 0.0, h[6] / tot,
+                    h[12], h[12] ? tot / h[12] : 0.0);
+        dev_free(ctx->lean_prof);
     }
     for (auto &qb : ctx->blocks) free_block(ctx, &qb);
     for (auto &c : ctx->blk_cache) dev_free(c.second);

@@ -213,6 +213,7 @@ struct apples_ctx {
     std::vector<hipEvent_t> ev_feed; // "chunk i of a streamed block is uploaded and packed"
     int32_t *d_slice_cnt = nullptr;  // [64] list lengths of the top-up slices (slim workspaces)
     unsigned long long *scan_prof = nullptr;  // APPLES_SCAN_PROFILE: per-phase cycle sums of the scan sweep
+    unsigned long long *lean_prof = nullptr;  // APPLES_LEAN_PROFILE: the same for sweep_lean.hip's wavefront-sized teams
     // -d path: column layout cache
     int64_t col_gen = 0;             // bumped whenever the column layout below is replaced
     int64_t dcols = 0;
@@ -319,6 +320,7 @@ struct SweepArgs {
     int32_t *order;           // [teams][cap+1]
     int4 *ent;                // [teams][cap+1] merge layout: nullptr = node map or node bits
     void *lean;               // sweep_lean.hip: the teams' field arrays
+    unsigned long long *prof; // diagnostic (APPLES_LEAN_PROFILE): [16] cycles and step counts per phase summed over teams, or nullptr
     int64_t lean_cap1, lean_leaf1;
     int map_bits;             // payload bits of a map entry; the tag sits above them
     int method, criterion, negative;

@@ -208,12 +208,65 @@ __device__ __forceinline__ void lean_best_init(LeanBest &b) {
     b.key = INF_D; b.v = 0x7fffffff; b.x1 = b.x2 = b.err = b.e = 0; b.x1_int = 0;
 }
 
-// Top-down step of one internal node (parent-centric): it forms R for each valid child (all_R_values, OLS.py:57-80),
-// solves it (placement_per_edge, util.py:6-54) and evaluates its residual (error_per_edge); an internal child's tuple
-// becomes lift(R) over its own edge, which is what that child will add for each of its own children.
+// Top-down step for ONE valid child of an internal node (parent-centric): the node forms the child's R (all_R_values,
+// OLS.py:57-80: the valid sibling, then the node's own lifted R), solves it (placement_per_edge, util.py:6-54) and
+// evaluates its residual (error_per_edge); an internal child receives lift(R) over its own edge -- what it will add for
+// each of its own children -- in its tuple slot, or through LDS (`hand`) when its level has at most 64 nodes.
+// Sk / ek / kd / kn: the child's S tuple, edge length, descriptor, node id; Ss / es: the sibling's (nk > 1 only).
+template <int M>
+__device__ __forceinline__ void lean_td_kid(const LeanTeam &t, const double *Sk, const double *Ss, const double *plift, double ek,
+                                            double es, int kd, int kn, int nk, bool is_lca, double coef, int negative,
+                                            int criterion, const double *lds_pow, double2 (*hand)[WAVE], int hand_base,
+                                            LeanBest &best) {
+    constexpr bool BME = (M == APPLES_BME);
+    double acc[6];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) acc[x] = 0;
+    if (nk > 1) {  // the one valid sibling (apples/OLS.py:59-69)
+        double u[6];
+        lift<M>(Ss, es, u);
+#pragma unroll
+        for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * u[x] : u[x];
+    }
+    if (!is_lca) {  // parent term last (apples/OLS.py:70-80)
+#pragma unroll
+        for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
+    }
+    const Sol r = solve_edge<M>(Sk, acc, ek, negative, lds_pow);
+    if (kd > 0) {
+        double u[6];
+        lift<M>(acc, ek, u);
+        if (hand) {
+            const int p = kd - 1 - hand_base;
+            hand[0][p] = make_double2(u[0], u[1]);
+            hand[1][p] = make_double2(u[2], u[3]);
+            hand[2][p] = make_double2(u[4], u[5]);
+        } else {
+            t.T0[kd - 1] = make_double2(u[0], u[1]);
+            t.T1[kd - 1] = make_double2(u[2], u[3]);
+            t.T2[kd - 1] = make_double2(u[4], u[5]);
+        }
+    }
+    const double key = (criterion == APPLES_ME) ? r.x1 : r.err;
+    if (key < best.key || (key == best.key && kn < best.v)) {
+        best.key = key; best.v = kn; best.x1 = r.x1; best.x2 = r.x2; best.err = r.err; best.x1_int = r.x1_int; best.e = ek;
+    }
+}
+
+// the node's own lifted R: from the LDS hand-over of its parent's step (position p) or from its tuple slot
+__device__ __forceinline__ void lean_own_plift(const LeanTeam &t, int idx, const double2 (*hand)[WAVE], int p, double *plift) {
+    double2 p0, p1, p2;
+    if (hand) { p0 = hand[0][p]; p1 = hand[1][p]; p2 = hand[2][p]; }
+    else { p0 = t.T0[idx]; p1 = t.T1[idx]; p2 = t.T2[idx]; }
+    plift[0] = p0.x; plift[1] = p0.y; plift[2] = p1.x; plift[3] = p1.y; plift[4] = p2.x; plift[5] = p2.y;
+}
+
+// Top-down step of one internal node, both children in turn (the two swap roles in between): a rolled loop keeps one
+// 2x2 solve's worth of temporaries live, which is what decides how many wavefronts a SIMD holds.
 template <int M>
 __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, bool is_lca, int negative, int criterion,
-                                             const double *lds_pow, LeanBest &best) {
+                                             const double *lds_pow, const double2 (*hand_in)[WAVE], int in_pos,
+                                             double2 (*hand_out)[WAVE], int out_base, LeanBest &best) {
     constexpr bool BME = (M == APPLES_BME);
     const int2 d = t.D[idx], nd = t.N[idx];
     const double2 e = t.E[idx], dd = t.DD[idx];
@@ -221,50 +274,50 @@ __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, bool is
     // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
     const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
     double plift[6];
-    if (!is_lca) {  // this node's R, already lifted over its own edge by its parent
-        const double2 p0 = t.T0[idx], p1 = t.T1[idx], p2 = t.T2[idx];
-        plift[0] = p0.x; plift[1] = p0.y; plift[2] = p1.x; plift[3] = p1.y; plift[4] = p2.x; plift[5] = p2.y;
-    }
+    if (!is_lca) lean_own_plift(t, idx, hand_in, in_pos, plift);
     double Sk[6], Ss[6];  // the child in hand and its sibling
     kid_tuple<M>(d.x, dd.x, t, nullptr, false, 0, Sk);
     if (nk > 1) kid_tuple<M>(d.y, dd.y, t, nullptr, false, 0, Ss);
     double ek = e.x, es = e.y;
     int kd = d.x, ks = d.y, kn = nd.x, ksn = nd.y;
-    // one child at a time (the two swap roles in between): a rolled loop keeps one 2x2 solve's worth of
-    // temporaries live, which is what decides how many wavefronts a SIMD holds
 #pragma unroll 1
     for (int z = 0; z < nk; ++z) {
-        double acc[6];
-#pragma unroll
-        for (int x = 0; x < 6; ++x) acc[x] = 0;
-        if (nk > 1) {  // the one valid sibling (apples/OLS.py:59-69)
-            double u[6];
-            lift<M>(Ss, es, u);
-#pragma unroll
-            for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * u[x] : u[x];
-        }
-        if (!is_lca) {  // parent term last (apples/OLS.py:70-80)
-#pragma unroll
-            for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];
-        }
-        const Sol r = solve_edge<M>(Sk, acc, ek, negative, lds_pow);
-        if (kd > 0) {
-            double u[6];
-            lift<M>(acc, ek, u);
-            t.T0[kd - 1] = make_double2(u[0], u[1]);
-            t.T1[kd - 1] = make_double2(u[2], u[3]);
-            t.T2[kd - 1] = make_double2(u[4], u[5]);
-        }
-        const double key = (criterion == APPLES_ME) ? r.x1 : r.err;
-        if (key < best.key || (key == best.key && kn < best.v)) {
-            best.key = key; best.v = kn; best.x1 = r.x1; best.x2 = r.x2; best.err = r.err; best.x1_int = r.x1_int; best.e = ek;
-        }
+        lean_td_kid<M>(t, Sk, Ss, plift, ek, es, kd, kn, nk, is_lca, coef, negative, criterion, lds_pow, hand_out, out_base, best);
 #pragma unroll
         for (int x = 0; x < 6; ++x) { const double w = Sk[x]; Sk[x] = Ss[x]; Ss[x] = w; }
         { const double w = ek; ek = es; es = w; }
         { const int w = kd; kd = ks; ks = w; }
         { const int w = kn; kn = ksn; ksn = w; }
     }
+}
+
+// The same for a level of at most 32 nodes, one lane per (node, child): lanes 0-31 take the first valid children of
+// nodes g0 .. g0 + 31, lanes 32-63 the second: the 2x2 solve and the residual run once per level step, not twice.
+template <int M>
+__device__ __forceinline__ void lean_td_pairs(const LeanTeam &t, int g0, int ng, int VI, int lane, int negative, int criterion,
+                                              const double *lds_pow, const double2 (*hand_in)[WAVE], double2 (*hand_out)[WAVE],
+                                              int out_base, LeanBest &best) {
+    constexpr bool BME = (M == APPLES_BME);
+    const int i = lane & 31, z = lane >> 5;
+    const int idx = g0 + i;
+    const bool act = i < ng;
+    const bool is_lca = idx == VI;
+    int2 d = make_int2(0, 0), nd = make_int2(0, 0);
+    double2 e = make_double2(0, 0), dd = make_double2(0, 0);
+    if (act) { d = t.D[idx]; nd = t.N[idx]; e = t.E[idx]; dd = t.DD[idx]; }
+    const int nk = d.y != 0 ? 2 : 1;
+    const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
+    double plift[6], Sk[6], Ss[6];
+    const bool mine = act && z < nk;
+    if (mine) {
+        if (!is_lca) lean_own_plift(t, idx, hand_in, i, plift);
+        kid_tuple<M>(z ? d.y : d.x, z ? dd.y : dd.x, t, nullptr, false, 0, Sk);
+        if (nk > 1) kid_tuple<M>(z ? d.x : d.y, z ? dd.x : dd.y, t, nullptr, false, 0, Ss);
+    }
+    __builtin_amdgcn_wave_barrier();  // (every lane's reads of the hand-over precede the stores of this step)
+    if (mine)
+        lean_td_kid<M>(t, Sk, Ss, plift, z ? e.y : e.x, z ? e.x : e.y, z ? d.y : d.x, z ? nd.y : nd.x, nk, is_lca, coef, negative,
+                       criterion, lds_pow, hand_out, out_base, best);
 }
 
 // the query's placement from the team's winner (apples/Algorithm.py:92-101); `mine` = this lane holds the winning edge
@@ -309,6 +362,11 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
     const int c0 = a.cls_count[0], c1 = a.cls_count[1], c2 = a.cls_count[2], c3 = a.cls_count[3];
     const int64_t n_work = (int64_t)c0 + c1 + c2 + c3;
     const unsigned long long below = (1ull << lane) - 1ull;
+    // diagnostic (APPLES_LEAN_PROFILE): cycles per phase of this team, added to a.prof[phase] once per query by lane 0
+    unsigned long long pc[7] = {0, 0, 0, 0, 0, 0, 0}, pn[4] = {0, 0, 0, 0}, tk = 0;
+    const bool prof = a.prof != nullptr;
+#define LEAN_TICK(slot) do { if (prof) { const unsigned long long now_ = __builtin_readcyclecounter(); pc[slot] += now_ - tk; tk = now_; } } while (0)
+    if (prof) tk = __builtin_readcyclecounter();
     while (true) {
         // dynamic scheduling: one atomic add per query, broadcast to the wavefront
         int wq = 0;
@@ -325,6 +383,7 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
         const int32_t *o_node = a.obs_node + q * a.obs_cap;
         const double *o_dist = a.obs_dist + q * a.obs_cap;
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
+        LEAN_TICK(0);
 
         // ------------------------------------------------------------ up front: the per-level offsets into LDS; parent and
         // edge length of every observed leaf (independent gathers, all in flight together) into the team's arrays
@@ -361,6 +420,7 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
         int lw_node = 0, lw_par = 0;
         double lw_e = 0, lw_dist = 0;
         if (n_leaf <= WAVE && lane < n_leaf) { lw_node = o_node[lo + lane]; lw_par = t.LP[lo + lane]; lw_e = t.LE[lo + lane]; lw_dist = o_dist[lo + lane]; }
+        LEAN_TICK(1);
         while (true) {
             if (n_par + n_leaf == 1 && hi == n) break;  // one node left in the frontier: the LCA (Subtree.py:36-43), entry `base`
             if ((int64_t)base + 2 * (int64_t)n_par + n_leaf > cap) { overflow = true; break; }
@@ -445,6 +505,7 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
                 pf_par = r.x;
                 pf_e = pe_len(r);
             }
+            if (prof) { if (n_par <= WAVE && n_par + n_leaf <= WAVE) { LEAN_TICK(2); ++pn[0]; } else { LEAN_TICK(3); ++pn[1]; } }
             prev_staged = n_par > 0 && n_par <= WAVE;
             kid_base = base;
             base = next_base;
@@ -470,10 +531,24 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
         // internal child's tuple becomes lift(R) over its own edge
         LeanBest best;
         lean_best_init(best);
+        bool hand_in = false;  // this level's lifted R tuples wait in LDS (handed over by the level above)
         for (int g = G; g >= 1; --g) {
-            const int g0 = grp_off[g], g1 = grp_off[g + 1];
-            for (int idx = g0 + lane; idx < g1; idx += WAVE) lean_td_node<M>(t, idx, idx == VI, a.negative, a.criterion, lds_pow, best);
+            const int g0 = grp_off[g], g1 = grp_off[g + 1], k0 = grp_off[g - 1];
+            const int ng = g1 - g0;
+            const bool hand_out = g0 - k0 <= WAVE;  // the children's level has at most 64 nodes: their tuples go through LDS
+            if (ng <= 32) {
+                lean_td_pairs<M>(t, g0, ng, VI, lane, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
+                                 hand_out ? stage : nullptr, k0, best);
+            } else {
+                for (int idx = g0 + lane; idx < g1; idx += WAVE) {
+                    lean_td_node<M>(t, idx, idx == VI, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr, idx - g0,
+                                    hand_out ? stage : nullptr, k0, best);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            hand_in = hand_out;
+            if (prof) { if (ng <= 32) { LEAN_TICK(4); ++pn[2]; } else { LEAN_TICK(5); ++pn[3]; } }
         }
 
         // ------------------------------------------------------------ selection (apples/Algorithm.py:74-91)
@@ -482,7 +557,17 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
         int win = best.v;
         team_argmin<WAVE>(wkey, win, nullptr, nullptr);
         lean_write_placement(a.out, q, V, win, my_best == win, lane == 0, best);
+        if (prof) {
+            LEAN_TICK(6);
+            if (lane == 0) {
+                for (int k = 0; k < 7; ++k) { atomicAdd(a.prof + k, pc[k]); pc[k] = 0; }
+                for (int k = 0; k < 4; ++k) { atomicAdd(a.prof + 8 + k, pn[k]); pn[k] = 0; }
+                atomicAdd(a.prof + 12, 1ull);
+            }
+            tk = __builtin_readcyclecounter();
+        }
     }
+#undef LEAN_TICK
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -651,7 +736,7 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
         lean_best_init(best);
         for (int g = G; g >= 1; --g) {
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
-            for (int idx = g0 + tid; idx < g1; idx += TEAM) lean_td_node<M>(t, idx, idx == VI, a.negative, a.criterion, lds_pow, best);
+            for (int idx = g0 + tid; idx < g1; idx += TEAM) lean_td_node<M>(t, idx, idx == VI, a.negative, a.criterion, lds_pow, nullptr, 0, nullptr, 0, best);
             __syncthreads();
         }
         const int my_best = best.v;

@@ -135,25 +135,30 @@ __device__ __forceinline__ Sol solve_edge(const double *S, const double *R, doub
     r.x2 = r.x2n;
     r.x1_int = 0;
     if (!negative) {
-        double x1n = r.x1n, x2n = r.x2n;
-        if (x1n < 0 && x2n < 0) {
+        // the branch table of apples/util.py:32-50, evaluated in its order with strict comparisons; the three branches that
+        // divide all divide by a_11 (a_22 is the same number), so the quotient is formed once for whichever numerator the
+        // lane's branch names -- the same IEEE division as in the branch, but one instruction sequence instead of three
+        // when the lanes of a wavefront take different branches
+        const double x1n = r.x1n, x2n = r.x2n;
+        const bool n1 = x1n < 0, p1 = x1n > 0, n2 = x2n < 0, g2 = x2n > e, in2 = 0 <= x2n && x2n <= e;
+        const int br = (n1 && n2) ? 1 : (p1 && n2) ? 2 : (n1 && in2) ? 3 : (n1 && g2) ? 4 : (p1 && g2) ? 5 : 0;
+        if (br == 2 || br == 3 || br == 5) {
+            const double num = br == 3 ? c2 * 1.0 : (br == 5 ? c1 * 1.0 - a12 * e : c1 * 1.0);
+            const double qv = num / a11;
+            if (br == 3) {
+                r.x1 = 0; r.x1_int = 1;
+                double u = qv;
+                if (0 > u) u = 0;        // max(u, 0)
+                r.x2 = (e < u) ? e : u;  // min(., e)
+            } else {
+                if (0 > qv) { r.x1 = 0; r.x1_int = 1; } else r.x1 = qv;  // max(t, 0)
+                r.x2 = br == 2 ? 0 : e;
+            }
+        } else if (br == 1) {
             r.x1 = 0; r.x1_int = 1;
             r.x2 = 0;
-        } else if (x1n > 0 && x2n < 0) {
-            double t = c1 * 1.0 / a11;
-            if (0 > t) { r.x1 = 0; r.x1_int = 1; } else r.x1 = t;  // max(t, 0)
-            r.x2 = 0;
-        } else if (x1n < 0 && 0 <= x2n && x2n <= e) {
+        } else if (br == 4) {
             r.x1 = 0; r.x1_int = 1;
-            double u = c2 * 1.0 / a22;
-            if (0 > u) u = 0;      // max(u, 0)
-            r.x2 = (e < u) ? e : u;  // min(., e)
-        } else if (x1n < 0 && x2n > e) {
-            r.x1 = 0; r.x1_int = 1;
-            r.x2 = e;
-        } else if (x1n > 0 && x2n > e) {
-            double t = (c1 * 1.0 - a12 * e) / a11;
-            if (0 > t) { r.x1 = 0; r.x1_int = 1; } else r.x1 = t;
             r.x2 = e;
         }
     }

@@ -5,4 +5,5 @@ for w in 2 3; do
   echo "== lean, $w waves/SIMD: $(APPLES_LEAN_WAVES=$w one)"
   echo "== lean, $w waves/SIMD, bottom-up only: $(APPLES_LEAN_WAVES=$w APPLES_SWEEP_DEBUG_PHASE=1 one)"
 done
-echo "== level loop, bottom-up only: $(APPLES_NO_SWEEP_LEAN=1 APPLES_SWEEP_DEBUG_PHASE=1 one)"
+echo "== lean, big threshold 3072: $(APPLES_BIG_THRESHOLD=3072 one)"
+echo "== lean, big threshold 6144: $(APPLES_BIG_THRESHOLD=6144 one)"
