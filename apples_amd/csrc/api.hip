@@ -437,7 +437,7 @@ int big_threshold(const apples_ctx *ctx) {
 
 void free_sweep(Workspace::Sweep &sw) {
     dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.ent); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
-    dev_free(sw.ent_f); dev_free(sw.ent_i); dev_free(sw.leaf_g); dev_free(sw.meta); dev_free(sw.lean);
+    dev_free(sw.ent_f); dev_free(sw.ent_i); dev_free(sw.leaf_g); dev_free(sw.meta); dev_free(sw.lean); dev_free(sw.lean_leaf); dev_free(sw.lean_meta);
     sw = Workspace::Sweep();
 }
 
@@ -469,7 +469,7 @@ void free_workspace(Workspace &w) {
     w = Workspace();
 }
 
-int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg, int64_t cap, int64_t leaf_cap, bool xe) {
+int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg, int64_t cap, int64_t leaf_cap, bool xe, int64_t batch) {
     const DevTree &t = ctx->tree;
     sw.wgs = wgs;
     sw.teams = (int64_t)wgs * teams_per_wg;
@@ -491,10 +491,25 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
             if (dev_alloc(ctx, &sw.xe, sw.teams * cap * 18)) return 1;
         return 0;
     }
-    if (sweep_lean_layout(t, xe)) {  // sweep_lean.hip: field arrays in place of ent and A
+    if (sweep_lean_layout(t, xe) && teams_per_wg == 4) {
+        // sweep_lean.hip, wavefront-sized teams: a pool of entries for the whole batch (bottom-up and top-down are two
+        // kernels; a query's entries live from one to the other), per-query level offsets and hand-over records, and
+        // per-leaf scratch for the bottom-up teams.  `cap` = pool entries here.
+        sw.lean_cap1 = cap / 4 * 4;
+        sw.lean_leaf1 = round_up(std::max<int64_t>(std::min<int64_t>(leaf_cap, big_threshold(ctx)), 4), 4);
+        sw.teams = sweep_lean_up_teams(ctx);
+        char *p = nullptr;
+        if (dev_alloc(ctx, &p, sw.lean_cap1 * LEAN_BYTES_PER_NODE)) return 1;
+        sw.lean = p;
+        if (dev_alloc(ctx, &p, sw.teams * sw.lean_leaf1 * LEAN_BYTES_PER_LEAF)) return 1;
+        sw.lean_leaf = p;
+        if (dev_alloc(ctx, &sw.grp_off, batch * (int64_t)(t.height + 4))) return 1;
+        if (dev_alloc(ctx, &sw.lean_meta, batch)) return 1;
+        return 0;
+    }
+    if (sweep_lean_layout(t, xe)) {  // sweep_lean.hip, workgroup-sized teams: field arrays in place of ent and A
         sw.lean_cap1 = round_up(cap + 1, 4);
-        // (the selection kernel routes queries with more than big_threshold observed leaves to the workgroup-sized teams)
-        sw.lean_leaf1 = round_up(std::max<int64_t>(teams_per_wg == 4 ? std::min<int64_t>(leaf_cap, big_threshold(ctx)) : leaf_cap, 4), 4);
+        sw.lean_leaf1 = round_up(std::max<int64_t>(leaf_cap, 4), 4);
         char *p = nullptr;
         if (dev_alloc(ctx, &p, sw.teams * (sw.lean_cap1 * LEAN_BYTES_PER_NODE + sw.lean_leaf1 * LEAN_BYTES_PER_LEAF))) return 1;
         sw.lean = p;
@@ -597,21 +612,29 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     // big trees keep a node map of n_nodes ints per team (<= ~8 GiB in total)
     // (2 048 teams are resident at two wavefronts per SIMD; 3 072 measured best at both 10 k and 200 k leaves)
     int64_t teams = (t.scan || sweep_bits_in_lds(t) || sweep_merge_lists(t)) ? 3072 : std::min<int64_t>(3072, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
-    if (sweep_lean_layout(t, xe)) teams = (int64_t)1536 * sweep_lean_waves();  // (1.5 x the resident teams, as above)
     teams = std::min<int64_t>(teams, round_up(batch, 4));
     if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
     int64_t per_node = t.scan ? 120 + (xe ? 144 : 0) : 68 + (sweep_merge_lists(t) ? 12 : 0) + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
     if (sweep_lean_layout(t, xe)) per_node = LEAN_BYTES_PER_NODE + 4;
+    const bool lean_pool = sweep_lean_layout(t, xe);
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
     if (const char *e = getenv("APPLES_SWEEP_CAP")) cap = std::min<int64_t>(cap, std::max<int64_t>(64, atoll(e)));  // test knob: small teams overflow early
-    if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, t.scan ? 0 : std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold(ctx))), xe)) return 1;
+    if (lean_pool) {
+        // the batch's pool: what its queries ask for at 3 entries per observed leaf, within 12 GiB (queries beyond the
+        // pool go to the workgroup-sized teams); APPLES_LEAN_POOL_MB: test knob
+        int64_t want = batch * (3 * std::min<int64_t>(members, big_threshold(ctx)) + 1028);  // (sweep_lean.hip:lean_query_cap)
+        int64_t pool = std::min<int64_t>(want, ((int64_t)12 << 30) / LEAN_BYTES_PER_NODE);
+        if (const char *e = getenv("APPLES_LEAN_POOL_MB")) pool = std::max<int64_t>(1024, (atoll(e) << 20) / LEAN_BYTES_PER_NODE);
+        cap = std::min<int64_t>(pool, 0x7ffffff0ll);
+    }
+    if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, t.scan ? 0 : std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold(ctx))), xe, batch)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
     int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 4 + (sweep_lean_layout(t, xe) ? members * LEAN_BYTES_PER_LEAF : 0);
     int64_t big_max = getenv("APPLES_SWEEP_BIG_WGS") ? atoi(getenv("APPLES_SWEEP_BIG_WGS")) : 512;
     int wgs_big = (int)std::min<int64_t>(big_max, std::max<int64_t>(4, ((int64_t)24 << 30) / std::max<int64_t>(per_wg, 1)));
     wgs_big = (int)std::min<int64_t>(wgs_big, batch);
-    if (alloc_sweep(ctx, w.big, wgs_big, 1, nn, members, xe)) return 1;
+    if (alloc_sweep(ctx, w.big, wgs_big, 1, nn, members, xe, batch)) return 1;
     return 0;
 }
 
@@ -757,6 +780,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
     s.map = sw.map; s.map_ver = sw.ver; s.order = sw.order; s.ent = sw.ent;
     s.lean = sw.lean; s.lean_cap1 = sw.lean_cap1; s.lean_leaf1 = sw.lean_leaf1;
+    s.lean_leaf = sw.lean_leaf; s.lean_teams = sw.teams; s.lean_meta = sw.lean_meta; s.pool_cursor = (unsigned int *)(w.cls_count + 7);
     s.prof = ctx->lean_prof;
     s.map_bits = 1;
     while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
@@ -847,7 +871,7 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     // wavefront-sized teams for the size-class queues
     b.work_list = w.route_list;
     b.work_count = w.route_count;
-    const bool can_overflow = w.small.cap < ctx->tree.n_nodes;
+    const bool can_overflow = w.small.cap < ctx->tree.n_nodes || w.small.lean_leaf != nullptr;  // (pool: a query may ask for more than its share)
     if (can_overflow) HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), st));
     SweepArgs sm = sweep_args(ctx, w.small, out, false);
     sm.cls_list = w.cls_list;  // size-class queues written by the selection kernels, largest first
@@ -862,7 +886,9 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
         HIP_TRY(ctx, hipEventRecord(ctx->ev_sel, st));
         if (launch_big(b, st)) return 1;
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_big, ctx->ev_sel, 0));
-        if (launch_sweep_lean(ctx, sm, nq, w.small.wgs, ctx->stream_big)) return 1;
+        SweepArgs down = sm;
+        down.cursor = w.cls_count + 11;
+        if (launch_sweep_lean(ctx, sm, down, nq, ctx->stream_big)) return 1;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_big, ctx->stream_big));
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_big, 0));
     } else if (launch_sweep_mixed(ctx, sm, b, nq, w.small.wgs, w.big.wgs, st)) return 1;
@@ -1240,10 +1266,10 @@ void apples_ctx_destroy(apples_ctx *ctx) {
         if (tot > 0)
             fprintf(stderr, "lean sweep phases (share of team cycles): queue %.3f  up-front %.3f  bottom-up on chip %.3f (%llu steps, %.0f cycles each)  "
                             "bottom-up general %.3f (%llu steps, %.0f)  top-down pairs %.3f (%llu steps, %.0f)  top-down general %.3f (%llu steps, %.0f)  "
-                            "select %.3f  (queries %llu, %.0f cycles each)\n",
+                            "select %.3f  (queries %llu, %.0f cycles each; %llu handed to the workgroup-sized teams for want of room)\n",
                     h[0] / tot, h[1] / tot, h[2] / tot, h[8], h[8] ? (double)h[2] / h[8] : 0.0, h[3] / tot, h[9], h[9] ? (double)h[3] / h[9] : 0.0,
                     h[4] / tot, h[10], h[10] ? (double)h[4] / h[10] : 0.0, h[5] / tot, h[11], h[11] ? (double)h[5] / h[11] : 0.0, h[6] / tot,
-                    h[12], h[12] ? tot / h[12] : 0.0);
+                    h[12], h[12] ? tot / h[12] : 0.0, h[13]);
         dev_free(ctx->lean_prof);
     }
     for (auto &qb : ctx->blocks) free_block(ctx, &qb);

@@ -160,6 +160,9 @@ struct Workspace {
         void *lean = nullptr;     // sweep_lean.hip: [teams][LEAN_BYTES_PER_NODE * lean_cap1] field arrays (in place of ent and A)
         int64_t lean_cap1 = 0;    // entries per field array: cap + 1 rounded up to a multiple of 4
         int64_t lean_leaf1 = 0;   // observed leaves a team's per-leaf arrays hold (a multiple of 4)
+        void *lean_leaf = nullptr; // wavefront-sized teams: [teams][lean_leaf1] per-leaf scratch of the bottom-up kernel (then `lean` is the
+                                  // batch's pool of lean_cap1 entries, grp_off is per query and lean_meta holds what the top-down kernel needs)
+        int4 *lean_meta = nullptr;
         double *xe = nullptr;     // [teams][cap+leaf_cap][18] per-edge x, err, R, S (HYBRID / inspection)
         // scan formulation: per team `cap` entries (one per subtree node) as component arrays
         double *ent_f = nullptr;  // [teams][13][cap]: S[6], R[6] as pairs, edge length
@@ -319,7 +322,11 @@ struct SweepArgs {
     uint32_t *map_ver;        // [teams] version tags of the maps
     int32_t *order;           // [teams][cap+1]
     int4 *ent;                // [teams][cap+1] merge layout: nullptr = node map or node bits
-    void *lean;               // sweep_lean.hip: the teams' field arrays
+    void *lean;               // sweep_lean.hip: the teams' field arrays (workgroup-sized teams) or the batch's pool (wavefront-sized)
+    void *lean_leaf;          // wavefront-sized bottom-up teams: per-leaf scratch, lean_leaf1 entries per team
+    int64_t lean_teams;       // ... for this many teams
+    int4 *lean_meta;          // [batch] per query: {offset in the pool, number of level groups G (-1: not swept here), internal nodes, -}
+    unsigned int *pool_cursor; // next free pool entry (cleared per batch)
     unsigned long long *prof; // diagnostic (APPLES_LEAN_PROFILE): [16] cycles and step counts per phase summed over teams, or nullptr
     int64_t lean_cap1, lean_leaf1;
     int map_bits;             // payload bits of a map entry; the tag sits above them
@@ -370,8 +377,8 @@ int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int t
 #define LEAN_BYTES_PER_LEAF 12   // per observed leaf: edge length, parent
 #define LEAN_MAX_LEVELS 256      // per-level offsets of a query in LDS: trees up to 254 levels
 bool sweep_lean_layout(const DevTree &t, bool per_edge_records);
-int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st);
+int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &down, int64_t nq, hipStream_t st);
+int sweep_lean_up_teams(const apples_ctx *ctx);
 int launch_sweep_lean_big(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st);
-int sweep_lean_waves();  // wavefronts per SIMD the lean kernel is built for (1 536 teams each)
 int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,
                        hipStream_t st);

@@ -34,6 +34,15 @@
 
 #include "sweep_math.h"
 
+// wavefronts per SIMD the two kernels of the wavefront-sized teams are built for (registers: 171 and 157 unconstrained;
+// the bottom-up kernel's LDS, 40 KB per workgroup, would allow four workgroups per CU, its registers do not: 45 spilled)
+#ifndef LEAN_UP_WAVES
+#define LEAN_UP_WAVES 3
+#endif
+#ifndef LEAN_DOWN_WAVES
+#define LEAN_DOWN_WAVES 3
+#endif
+
 namespace {
 
 // LDS of one wavefront-sized team
@@ -50,9 +59,13 @@ struct LeanWave {
     double2 oE[WAVE], oDD[WAVE];
 };
 
-struct LeanShared {
-    double pow[384 + 256];  // libm pow tables (sweep_math.h)
+struct LeanUpShared {
     LeanWave w[APPLES_TPB / WAVE];
+};
+
+struct LeanDownShared {
+    double pow[384 + 256];  // libm pow tables (sweep_math.h)
+    double2 stage[APPLES_TPB / WAVE][3][WAVE];  // per wavefront: lifted R tuples on their way to a level of at most 64 nodes
 };
 
 // per-team scratch: one array per field, `cap1` entries each (cap1 a multiple of 4), then two per observed leaf
@@ -80,6 +93,26 @@ __device__ __forceinline__ LeanTeam lean_team(void *base, int64_t team, int64_t 
     t.K = reinterpret_cast<int32_t *>(p); p += cap1 * 4;
     t.LE = reinterpret_cast<double *>(p); p += leaf1 * 8;
     t.LP = reinterpret_cast<int32_t *>(p);
+    return t;
+}
+
+// A query's entries inside the batch's pool (wavefront-sized teams: the bottom-up and the top-down pass are two kernels,
+// so a query's arrays outlive the team that built them): `n` entries per field array, the query's at [off, off + its cap);
+// the two per-leaf arrays are scratch of the bottom-up team
+__device__ __forceinline__ LeanTeam lean_pool_view(void *pool, int64_t n, int64_t off, void *leaf, int64_t team, int64_t leaf1) {
+    char *p = reinterpret_cast<char *>(pool);
+    LeanTeam t;
+    t.T0 = reinterpret_cast<double2 *>(p) + off; p += n * 16;
+    t.T1 = reinterpret_cast<double2 *>(p) + off; p += n * 16;
+    t.T2 = reinterpret_cast<double2 *>(p) + off; p += n * 16;
+    t.E = reinterpret_cast<double2 *>(p) + off; p += n * 16;
+    t.DD = reinterpret_cast<double2 *>(p) + off; p += n * 16;
+    t.D = reinterpret_cast<int2 *>(p) + off; p += n * 8;
+    t.N = reinterpret_cast<int2 *>(p) + off; p += n * 8;
+    t.K = reinterpret_cast<int32_t *>(p) + off;
+    char *l = reinterpret_cast<char *>(leaf) + team * leaf1 * LEAN_BYTES_PER_LEAF;
+    t.LE = reinterpret_cast<double *>(l);
+    t.LP = reinterpret_cast<int32_t *>(l + leaf1 * 8);
     return t;
 }
 
@@ -346,21 +379,42 @@ __device__ __forceinline__ void lean_write_placement(apples_placement *out, int6
 }
 
 
+// The size-class queues of a batch (written by the selection kernels, largest class first): entry w -> query
+struct LeanQueue {
+    int c0, c1, c2, c3;
+    int64_t n_work;
+};
+__device__ __forceinline__ LeanQueue lean_queue(const SweepArgs &a) {
+    LeanQueue qu;
+    qu.c0 = a.cls_count[0]; qu.c1 = a.cls_count[1]; qu.c2 = a.cls_count[2]; qu.c3 = a.cls_count[3];
+    qu.n_work = (int64_t)qu.c0 + qu.c1 + qu.c2 + qu.c3;
+    return qu;
+}
+__device__ __forceinline__ int64_t lean_queue_at(const SweepArgs &a, const LeanQueue &qu, int64_t w) {
+    if (w < qu.c0) return a.cls_list[w];
+    if (w < qu.c0 + qu.c1) return a.cls_list[a.cls_stride + (w - qu.c0)];
+    if (w < (int64_t)qu.c0 + qu.c1 + qu.c2) return a.cls_list[2 * a.cls_stride + (w - qu.c0 - qu.c1)];
+    return a.cls_list[3 * a.cls_stride + (w - qu.c0 - qu.c1 - qu.c2)];
+}
+
+// entries a query may use in the pool: the internal nodes of its subtree plus the LCA.  Observed sets average 1.44
+// internal nodes per observed leaf at C3, but a handful of leaves far apart in the tree have a path of internal nodes
+// each (the -b nearest of a query with nothing inside the threshold): room for some 25 levels of those.  A query that
+// needs more than this goes to the workgroup-sized teams.
+__device__ __forceinline__ int lean_query_cap(int n) { return (3 * n + 128 + min(22 * n, 896) + 3) & ~3; }
+
+// Bottom-up kernel of the wavefront-sized teams: level lists and S tuples of one query after the other, into the pool
 template <int M>
-__device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
+__device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
-    const double *lds_pow = sh.pow;
     LeanWave &L = sh.w[wave];
     double2 (*stage)[WAVE] = L.stage;
     const DevTree &T = a.tree;
     const int4 *__restrict__ pe = reinterpret_cast<const int4 *>(T.pe);
-    const int64_t cap = a.cap;
     const int64_t team = (int64_t)blockIdx.x * (APPLES_TPB / WAVE) + wave;
-    const LeanTeam t = lean_team(a.lean, team, a.lean_cap1, a.lean_leaf1);
-    int32_t *grp_off = a.grp_off + team * (T.height + 4);
-    const int c0 = a.cls_count[0], c1 = a.cls_count[1], c2 = a.cls_count[2], c3 = a.cls_count[3];
-    const int64_t n_work = (int64_t)c0 + c1 + c2 + c3;
+    const LeanQueue qu = lean_queue(a);
+    const int64_t n_work = qu.n_work;
     const unsigned long long below = (1ull << lane) - 1ull;
     // diagnostic (APPLES_LEAN_PROFILE): cycles per phase of this team, added to a.prof[phase] once per query by lane 0
     unsigned long long pc[7] = {0, 0, 0, 0, 0, 0, 0}, pn[4] = {0, 0, 0, 0}, tk = 0;
@@ -371,18 +425,26 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
         // dynamic scheduling: one atomic add per query, broadcast to the wavefront
         int wq = 0;
         if (lane == 0) wq = atomicAdd(a.cursor, 1);
-        const int64_t w = __shfl(wq, 0, WAVE);
+        const int64_t w = __builtin_amdgcn_readfirstlane(wq);  // (scalar: the query's pointers and counts then live in SGPRs)
         if (w >= n_work) break;
-        int64_t q;
-        if (w < c0) q = a.cls_list[w];
-        else if (w < c0 + c1) q = a.cls_list[a.cls_stride + (w - c0)];
-        else if (w < (int64_t)c0 + c1 + c2) q = a.cls_list[2 * a.cls_stride + (w - c0 - c1)];
-        else q = a.cls_list[3 * a.cls_stride + (w - c0 - c1 - c2)];
+        const int64_t q = lean_queue_at(a, qu, w);
         const int n = a.n_obs[q];
         if (n == 0) continue;
         const int32_t *o_node = a.obs_node + q * a.obs_cap;
         const double *o_dist = a.obs_dist + q * a.obs_cap;
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
+        // the query's share of the pool (one atomic add per query); out of pool = the workgroup-sized teams take it
+        const int qcap = lean_query_cap(n);
+        unsigned int off0 = 0;
+        if (lane == 0) off0 = atomicAdd(a.pool_cursor, (unsigned int)qcap);
+        const int64_t off = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)off0);
+        int32_t *grp_off = a.grp_off + q * (int64_t)(T.height + 4);
+        if (off + qcap > a.lean_cap1) {
+            if (lane == 0) { a.lean_meta[q] = make_int4(0, -1, 0, 0); a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q; }
+            continue;
+        }
+        const int64_t cap = qcap - 1;
+        const LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, off, a.lean_leaf, team, a.lean_leaf1);
         LEAN_TICK(0);
 
         // ------------------------------------------------------------ up front: the per-level offsets into LDS; parent and
@@ -517,18 +579,54 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
             if (n_leaf <= WAVE && lane < n_leaf) { lw_node = o_node[lo + lane]; lw_par = t.LP[lo + lane]; lw_e = t.LE[lo + lane]; lw_dist = o_dist[lo + lane]; }
         }
         if (overflow) {  // hand the query to the workgroup-sized teams with full-size scratch
-            if (lane == 0) a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
+            if (lane == 0) { a.lean_meta[q] = make_int4(0, -1, 0, 0); a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q; }
+            if (prof && lane == 0) atomicAdd(a.prof + 13, 1ull);
             continue;
         }
-        const int VI = base;     // internal valid nodes; the LCA's entry sits at index VI
-        const int V = base + n;  // Subtree.num_nodes
-        if (lane == 0) { grp_off[G] = VI; grp_off[G + 1] = VI + 1; }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (a.debug_phase == 1) continue;
+        // internal valid nodes: base; the LCA's entry sits at that index.  What the top-down kernel needs of this query:
+        if (lane == 0) { grp_off[G] = base; grp_off[G + 1] = base + 1; a.lean_meta[q] = make_int4((int)off, G, base, 0); }
+        if (prof) {
+            if (lane == 0) {
+                for (int k = 0; k < 4; ++k) { atomicAdd(a.prof + k, pc[k]); pc[k] = 0; }
+                for (int k = 0; k < 2; ++k) { atomicAdd(a.prof + 8 + k, pn[k]); pn[k] = 0; }
+                atomicAdd(a.prof + 12, 1ull);
+            }
+            tk = __builtin_readcyclecounter();
+        }
+    }
+#undef LEAN_TICK
+}
 
-        // ------------------------------------------------------------ top down and parent-centric: a node forms R for each
-        // valid child (all_R_values), solves it (placement_per_edge) and evaluates its residual (error_per_edge); an
-        // internal child's tuple becomes lift(R) over its own edge
+// Top-down kernel of the wavefront-sized teams: a node forms R for each valid child (all_R_values), solves it
+// (placement_per_edge) and evaluates its residual (error_per_edge); an internal child's tuple becomes lift(R) over its own
+// edge; then the query's arg-min (apples/Algorithm.py:74-91)
+template <int M>
+__device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x / WAVE;
+    const double *lds_pow = sh.pow;
+    double2 (*stage)[WAVE] = sh.stage[wave];
+    const DevTree &T = a.tree;
+    const LeanQueue qu = lean_queue(a);
+    unsigned long long pc[7] = {0, 0, 0, 0, 0, 0, 0}, pn[4] = {0, 0, 0, 0}, tk = 0;
+    const bool prof = a.prof != nullptr;
+#define LEAN_TICK(slot) do { if (prof) { const unsigned long long now_ = __builtin_readcyclecounter(); pc[slot] += now_ - tk; tk = now_; } } while (0)
+    if (prof) tk = __builtin_readcyclecounter();
+    while (true) {
+        int wq = 0;
+        if (lane == 0) wq = atomicAdd(a.cursor, 1);
+        const int64_t w = __builtin_amdgcn_readfirstlane(wq);  // (scalar: the query's pointers and counts then live in SGPRs)
+        if (w >= qu.n_work) break;
+        const int64_t q = lean_queue_at(a, qu, w);
+        const int n = a.n_obs[q];
+        if (n == 0) continue;
+        const int4 meta = a.lean_meta[q];
+        const int G = meta.y, VI = meta.z;
+        if (G < 0) continue;  // handed to the workgroup-sized teams by the bottom-up kernel
+        const int V = VI + n;  // Subtree.num_nodes
+        const LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, meta.x & 0xffffffffll, nullptr, 0, 0);
+        const int32_t *grp_off = a.grp_off + q * (int64_t)(T.height + 4);
+        LEAN_TICK(0);
         LeanBest best;
         lean_best_init(best);
         bool hand_in = false;  // this level's lifted R tuples wait in LDS (handed over by the level above)
@@ -560,9 +658,9 @@ __device__ void lean_team_loop(const SweepArgs &a, LeanShared &sh) {
         if (prof) {
             LEAN_TICK(6);
             if (lane == 0) {
-                for (int k = 0; k < 7; ++k) { atomicAdd(a.prof + k, pc[k]); pc[k] = 0; }
-                for (int k = 0; k < 4; ++k) { atomicAdd(a.prof + 8 + k, pn[k]); pn[k] = 0; }
-                atomicAdd(a.prof + 12, 1ull);
+                atomicAdd(a.prof + 0, pc[0]); pc[0] = 0;
+                for (int k = 4; k < 7; ++k) { atomicAdd(a.prof + k, pc[k]); pc[k] = 0; }
+                for (int k = 2; k < 4; ++k) { atomicAdd(a.prof + 8 + k, pn[k]); pn[k] = 0; }
             }
             tk = __builtin_readcyclecounter();
         }
@@ -768,34 +866,22 @@ void launch_lean_big_t(const SweepArgs &a, int64_t nq, dim3 grid, hipStream_t st
     }
 }
 
-template <int M, int W>
-__global__ __launch_bounds__(APPLES_TPB, W) void k_sweep_lean(SweepArgs a) {
-    __shared__ LeanShared sh;
+template <int M>
+__global__ __launch_bounds__(APPLES_TPB, LEAN_UP_WAVES) void k_lean_up(SweepArgs a) {
+    __shared__ LeanUpShared sh;
+    lean_up_loop<M>(a, sh);
+}
+
+template <int M>
+__global__ __launch_bounds__(APPLES_TPB, LEAN_DOWN_WAVES) void k_lean_down(SweepArgs a) {
+    __shared__ LeanDownShared sh;
     for (int i = threadIdx.x; i < 384; i += APPLES_TPB) sh.pow[i] = (&kPowLogTab[0][0])[i];
     for (int i = threadIdx.x; i < 256; i += APPLES_TPB) sh.pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
     __syncthreads();
-    lean_team_loop<M>(a, sh);
-}
-
-template <int W>
-void launch_lean_w(const SweepArgs &a, dim3 grid, hipStream_t st) {
-    const dim3 block(APPLES_TPB);
-    switch (a.method) {
-        case APPLES_FM: hipLaunchKernelGGL((k_sweep_lean<APPLES_FM, W>), grid, block, 0, st, a); break;
-        case APPLES_BME: hipLaunchKernelGGL((k_sweep_lean<APPLES_BME, W>), grid, block, 0, st, a); break;
-        case APPLES_BE: hipLaunchKernelGGL((k_sweep_lean<APPLES_BE, W>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((k_sweep_lean<APPLES_OLS, W>), grid, block, 0, st, a); break;
-    }
+    lean_down_loop<M>(a, sh);
 }
 
 }  // namespace
-
-// wavefronts per SIMD the lean sweep is compiled for (2: no spills; 3: 168 registers with some spilled; LDS allows no
-// more); the workspace sizes its team count from it.  APPLES_LEAN_WAVES: tuning knob.
-int sweep_lean_waves() {
-    static const int w = getenv("APPLES_LEAN_WAVES") ? std::min(3, std::max(2, atoi(getenv("APPLES_LEAN_WAVES")))) : 2;
-    return w;
-}
 
 // workgroup-sized teams over a device-side list (routed or overflow queries); a.lean = the big teams' field arrays
 int launch_sweep_lean_big(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st) {
@@ -808,15 +894,40 @@ int launch_sweep_lean_big(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int w
     return 0;
 }
 
-// wavefront-sized teams over the size-class queues of one device batch; `a.lean` etc. set by the caller
-int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st) {
+// wavefront-sized teams over the size-class queues of one device batch: the bottom-up kernel, then (unless the timing
+// knob says bottom-up only) the top-down kernel, each a persistent grid of the workgroups its registers let a CU hold
+// (x 1.5: a second round shortens the tail).  `up` / `down` differ in their work cursor only.
+int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &down, int64_t nq, hipStream_t st) {
     if (nq == 0) return 0;
+    const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    static const int wg_up = getenv("APPLES_LEAN_UP_WGS") ? atoi(getenv("APPLES_LEAN_UP_WGS")) : 0;      // tuning knobs
+    static const int wg_down = getenv("APPLES_LEAN_DOWN_WGS") ? atoi(getenv("APPLES_LEAN_DOWN_WGS")) : 0;
     const int64_t need = (nq + 3) / 4;
-    const dim3 grid((unsigned)std::min<int64_t>(need, wgs));
-    switch (sweep_lean_waves()) {
-        case 3: launch_lean_w<3>(a, grid, st); break;
-        default: launch_lean_w<2>(a, grid, st); break;
+    const dim3 block(APPLES_TPB);
+    const dim3 gu((unsigned)std::min<int64_t>(need, wg_up > 0 ? wg_up : cus * LEAN_UP_WAVES * 3 / 2));
+    const dim3 gd((unsigned)std::min<int64_t>(need, wg_down > 0 ? wg_down : cus * LEAN_DOWN_WAVES * 3 / 2));
+    if ((int64_t)gu.x * 4 > up.lean_teams) { ctx->err = "lean sweep: more bottom-up teams than per-leaf scratch"; return 1; }
+    switch (up.method) {
+        case APPLES_FM: hipLaunchKernelGGL((k_lean_up<APPLES_FM>), gu, block, 0, st, up); break;
+        case APPLES_BME: hipLaunchKernelGGL((k_lean_up<APPLES_BME>), gu, block, 0, st, up); break;
+        case APPLES_BE: hipLaunchKernelGGL((k_lean_up<APPLES_BE>), gu, block, 0, st, up); break;
+        default: hipLaunchKernelGGL((k_lean_up<APPLES_OLS>), gu, block, 0, st, up); break;
+    }
+    if (up.debug_phase != 1) {
+        switch (down.method) {
+            case APPLES_FM: hipLaunchKernelGGL((k_lean_down<APPLES_FM>), gd, block, 0, st, down); break;
+            case APPLES_BME: hipLaunchKernelGGL((k_lean_down<APPLES_BME>), gd, block, 0, st, down); break;
+            case APPLES_BE: hipLaunchKernelGGL((k_lean_down<APPLES_BE>), gd, block, 0, st, down); break;
+            default: hipLaunchKernelGGL((k_lean_down<APPLES_OLS>), gd, block, 0, st, down); break;
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
+}
+
+// bottom-up teams the workspace must hold per-leaf scratch for
+int sweep_lean_up_teams(const apples_ctx *ctx) {
+    const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    const int wg_up = getenv("APPLES_LEAN_UP_WGS") ? atoi(getenv("APPLES_LEAN_UP_WGS")) : 0;
+    return 4 * (wg_up > 0 ? wg_up : cus * LEAN_UP_WAVES * 3 / 2);
 }

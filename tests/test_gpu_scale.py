@@ -163,7 +163,8 @@ def test_fused_and_full_row_selection_paths_agree(c2):
                 {'APPLES_TOPUP_MIN_ROWS': '0'}, {'APPLES_NO_DIST_MFMA': '1'}, {'APPLES_NO_DIST_GEMM': '1'}, {'APPLES_GEMM_TABLE': '1'}, {'APPLES_GEMM_QT': '128'}, {'APPLES_GEMM_QT': '128', 'APPLES_GEMM_TABLE': '1'}, {'APPLES_SWEEP_SCAN': '1'},
                 {'APPLES_SWEEP_MERGE': '1'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_SWEEP_TEAM': '256'},
                 {'APPLES_SWEEP_MERGE': '1', 'APPLES_NO_SWEEP_LEAN': '1'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_NO_SWEEP_LEAN': '1', 'APPLES_BIG_THRESHOLD': '300'},
-                {'APPLES_SWEEP_MERGE': '1', 'APPLES_SWEEP_TEAMS': '8'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_SWEEP_CAP': '600'},
+                {'APPLES_SWEEP_MERGE': '1', 'APPLES_LEAN_UP_WGS': '2', 'APPLES_LEAN_DOWN_WGS': '3'}, {'APPLES_SWEEP_MERGE': '1', 'APPLES_LEAN_POOL_MB': '1'},
+                {'APPLES_SWEEP_MERGE': '1', 'APPLES_LEAN_BIG_TEAM': '512', 'APPLES_BIG_THRESHOLD': '300'},
                 {'APPLES_SWEEP_MERGE': '1', 'APPLES_NO_SWEEP_LEAN': '1', 'APPLES_SWEEP_CAP': '600'},
                 {'APPLES_SWEEP_SCAN': '1', 'APPLES_BIG_THRESHOLD': '300'}, {'APPLES_SWEEP_SCAN': '1', 'APPLES_SWEEP_TEAM': '256'}):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, **env), timeout=900)
