@@ -291,6 +291,7 @@ struct SelectArgs {
     const uint4 *packed_rm; const uint4 *qpacked; int G; int L; double overlap; int64_t rep_stride;
     double *tmp_d;            // [nq][stride] member distances before the ordered emission
     int flat_pref;            // k_select_fast: the segment counts' prefix fits LDS (set by the launcher)
+    int64_t n_rows_plain;     // k_select / k_select_stream without a list: rows to select (set by the launcher; the grid may be smaller)
 };
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq);

@@ -17,6 +17,7 @@
 // kernel receives its leaves grouped by level together with the per-level offsets cnt_gt.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     __shared__ double sh_d[8];
     // listed mode (top-up path): a fixed grid walks the device-side list; entry r names query
     // qlist[r], whose distances are row r
-    const int64_t n_list = a.qcount ? (int64_t)*a.qcount : (int64_t)gridDim.x;
+    const int64_t n_list = a.qcount ? (int64_t)*a.qcount : a.n_rows_plain;
     for (int64_t r = blockIdx.x; r < n_list; r += gridDim.x) {
     const int64_t q = a.qlist ? a.qlist[r] : r;
     const int tid = threadIdx.x;
@@ -712,13 +713,24 @@ int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
 // a contiguous quarter of the slots, compacts its keepers with ballots into the start of its own
 // quarter of the output, and the four sparse pieces are then closed up.  If fewer than `baseobs`
 // entries pass the threshold the top-up rule computes a (d, i) cut and the row is streamed again.
-__global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
+#ifndef SU2_LOADS
+#define SU2_LOADS 4
+#endif
+#ifndef STREAM_WAVES
+#define STREAM_WAVES 4
+#endif
+#define STREAM_QUEUE ((SU2_LOADS > 4 ? SU2_LOADS : 4) * 128 + 128)  // candidates a wavefront queues before it looks at them (one
+                                                                     // round of loads adds at most SU x 128, or 8 x 64 with 8-byte loads)
+// (4 wavefronts per SIMD: the streaming pass wants its loads in flight, not registers)
+__global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(SelectArgs a) {
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
     __shared__ double sh_d[8];
     __shared__ int sh_wcnt[4];
     __shared__ int sh_znode;
-    const int64_t n_list = a.qcount ? (int64_t)*a.qcount : (int64_t)gridDim.x;
+    __shared__ int sh_qs[APPLES_TPB / WAVE][STREAM_QUEUE];     // per-wavefront queue of candidates: slot (relative to the quarter) ...
+    __shared__ double sh_qd[APPLES_TPB / WAVE][STREAM_QUEUE];  // ... and distance
+    const int64_t n_list = a.qcount ? (int64_t)*a.qcount : a.n_rows_plain;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
     const int64_t nm = a.n_members;
     const double thr = a.thr;
@@ -726,7 +738,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
     // A row's node is needed while streaming only to skip table columns that are not tree leaves; if
     // there are none (or this is not a table) it is looked up for the entries that are kept
     const bool early_node = table && !a.cols_all_in_tree;
-    constexpr int SU = 8;  // independent loads per lane in flight (4: 6 % slower on 200 k-column rows, 16: 9 % slower)
+    constexpr int SU1 = 8, SU2 = SU2_LOADS;  // independent load instructions per lane in flight (8-byte / 16-byte loads)
     // quarters aligned to 64 slots
     const int64_t per = ((nm + 4 * WAVE - 1) / (4 * WAVE)) * WAVE;
     const int64_t w_lo = std::min<int64_t>(nm, per * wv), w_hi = std::min<int64_t>(nm, per * (wv + 1));
@@ -745,36 +757,39 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
         for (int round = 0; round < 2; ++round) {
             n_total = 0; thr_cnt = 0; z_i = 0x7fffffff; z_node = -2; z_d = INF_D;
             int wbase = 0;  // keepers this wavefront has written (wave-uniform)
-            for (int64_t sb = w_lo; sb < w_hi; sb += SU * WAVE) {  // wave-uniform trip count
-                // SU independent loads per lane in flight before any of them is consumed
-                double dv[SU];
-                int nv_[SU];
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int64_t s = sb + u * WAVE + lane;
-                    dv[u] = s < w_hi ? row[s] : -1.0;
-                    nv_[u] = (early_node && s < w_hi) ? a.slot_node[s] : 0;
-                }
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int64_t s = sb + u * WAVE + lane;
+            // One pass over this wavefront's quarter of the row, V values per lane and load (V = 2: 16-byte loads, lane l of a
+            // load instruction holds slots 2l and 2l + 1 of its 128; rows whose quarter starts on an odd slot or at an
+            // unaligned address take V = 1).  SU load instructions are in flight before the first is consumed; survivors
+            // leave in slot order (lane-major, then the lane's own two).
+            // Candidates (0 <= d <= bound) go through a small per-wavefront queue in LDS, in slot order, and are looked at
+            // 64 at a time (node lookup, cut test, own entry, zero, ordered emission): the streaming loop itself then holds
+            // nothing but loads, two comparisons per value and a ballot, and its loads are waited for one by one.
+            int q_n = 0;  // queued candidates (wave-uniform)
+            auto drain = [&]() {
+                for (int i0 = 0; i0 < q_n; i0 += WAVE) {
+                    const int i = i0 + lane;
                     bool emit = false;
-                    const double d = dv[u];
-                    int node = nv_[u];
-                    const bool ok = (s < w_hi) && (d >= 0) && !(early_node && node < 0);
-                    if (ok) {
-                        const bool in_thr = d <= thr;
-                        thr_cnt += in_thr;
-                        bool in_dict = in_thr;
-                        if (!in_thr && cut_i >= 0) in_dict = key_le(d, a.slot_rep[s], cut_d, cut_i);
-                        if (in_dict && (int)s != self) {
-                            if (!early_node) node = a.slot_node[s];
-                            ++n_total;
-                            if (d == 0) {
-                                const int ri = a.slot_rep[s];
-                                if (ri < z_i) { z_i = ri; z_node = node; z_d = 0; }
+                    int node = 0;
+                    double d = 0;
+                    if (i < q_n) {
+                        const int64_t s = w_lo + sh_qs[wv][i];
+                        d = sh_qd[wv][i];
+                        bool ok = true;
+                        if (early_node) { node = a.slot_node[s]; ok = node >= 0; }
+                        if (ok) {
+                            const bool in_thr = d <= thr;
+                            thr_cnt += in_thr;
+                            bool in_dict = in_thr;
+                            if (!in_thr) in_dict = key_le(d, a.slot_rep[s], cut_d, cut_i);  // (bound > thr only with a cut)
+                            if (in_dict && (int)s != self) {
+                                if (!early_node) node = a.slot_node[s];
+                                ++n_total;
+                                if (d == 0) {
+                                    const int ri = a.slot_rep[s];
+                                    if (ri < z_i) { z_i = ri; z_node = node; z_d = 0; }
+                                }
+                                emit = node >= 0;
                             }
-                            emit = node >= 0;
                         }
                     }
                     const unsigned long long m = __ballot(emit);
@@ -785,7 +800,77 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_stream(SelectArgs a) {
                     }
                     wbase += __popcll(m);
                 }
-            }
+                q_n = 0;
+                __builtin_amdgcn_wave_barrier();
+            };
+            auto pass = [&](auto vc) {
+                constexpr int V = decltype(vc)::value;
+                constexpr int SU = V == 2 ? SU2 : SU1;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const double *wrow = row + w_lo;           // this wavefront's quarter: slots [0, wn) of it
+                const int wn_all = (int)(w_hi - w_lo);
+                const int wn = V == 2 ? (wn_all & ~1) : wn_all;  // 16-byte loads: whole pairs; an odd last slot follows below
+                if (wn < V) return;                        // (V == 2 is only chosen for quarters of at least two slots)
+                const int step = SU * WAVE * V;
+                // nothing above this bound can be kept: the threshold, or (second pass) the larger of it and the cut
+                const double bound = (cut_i >= 0 && cut_d > thr) ? cut_d : thr;
+                // loads are unconditional (the address is clamped into the quarter, the value masked by its slot
+                // afterwards): the round below is straight-line code, so every load is waited for by count, not all at once
+                const int last = wn - V;
+                auto fetch = [&](int s0, double *v) {
+                    const int c = s0 < last ? s0 : last;
+                    if (V == 2) {
+                        const double2 t2 = *reinterpret_cast<const double2 *>(wrow + c);
+                        v[0] = t2.x; v[V - 1] = t2.y;
+                    } else {
+                        v[0] = wrow[c];
+                    }
+                };
+                // a ring of SU loads per lane: slot u of the next round is requested before slot u of this round is looked
+                // at, so SU load instructions per lane stay in flight for the whole pass
+                double ring[SU][V];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) fetch((u * WAVE + lane) * V, ring[u]);
+                int sb = 0;
+                while (sb < wn) {
+                    do {  // rounds, until the queue might not hold another one's candidates
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) {
+                            const int s0 = sb + (u * WAVE + lane) * V;
+                            double cur[V];
+#pragma unroll
+                            for (int e = 0; e < V; ++e) cur[e] = ring[u][e];
+                            fetch(s0 + step, ring[u]);
+                            bool cand[V];
+#pragma unroll
+                            for (int e = 0; e < V; ++e) cand[e] = s0 + e < wn && cur[e] >= 0 && cur[e] <= bound;
+                            const unsigned long long m0 = __ballot(cand[0]);
+                            const unsigned long long m1 = V == 2 ? __ballot(cand[V - 1]) : 0ull;
+                            if (m0 | m1) {
+                                int at = q_n + __popcll(m0 & below) + __popcll(m1 & below);
+                                if (cand[0]) { sh_qs[wv][at] = s0; sh_qd[wv][at] = cur[0]; ++at; }
+                                if (V == 2 && cand[V - 1]) { sh_qs[wv][at] = s0 + 1; sh_qd[wv][at] = cur[V - 1]; }
+                                q_n += __popcll(m0) + __popcll(m1);
+                            }
+                        }
+                        sb += step;
+                    } while (sb < wn && q_n <= STREAM_QUEUE - SU * V * WAVE);
+                    __builtin_amdgcn_wave_barrier();
+                    drain();
+                }
+                if (V == 2 && (wn_all & 1)) {  // the quarter's odd last slot
+                    const double d = wrow[wn_all - 1];
+                    if (d >= 0 && d <= bound) {
+                        if (lane == 0) { sh_qs[wv][0] = wn_all - 1; sh_qd[wv][0] = d; }
+                        q_n = 1;
+                        __builtin_amdgcn_wave_barrier();
+                        drain();
+                    }
+                }
+            };
+            const bool vec2 = (((size_t)(row + w_lo)) & 15u) == 0 && w_hi - w_lo >= 2;
+            if (vec2) pass(std::integral_constant<int, 2>());
+            else pass(std::integral_constant<int, 1>());
             if (lane == 0) sh_wcnt[wv] = wbase;
             const int obs = block_sum(thr_cnt, sh_i);  // (barriers inside also publish sh_wcnt)
             if (round == 0 && obs < a.baseobs) {
@@ -1145,11 +1230,16 @@ int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
     // listed mode: the list length lives on the device, so a bounded grid loops over it
     unsigned grid = a.qcount ? (unsigned)std::min<int64_t>(nq, 512) : (unsigned)nq;
+    SelectArgs b = a;
+    b.n_rows_plain = nq;
     static const bool no_stream = getenv("APPLES_NO_STREAM_SELECT") != nullptr;  // diagnostic knob
-    if (a.all_singleton && !a.gather && !no_stream)  // singleton clusters, rows in slot order: barrier-free streaming form
-        hipLaunchKernelGGL(k_select_stream, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, a);
+    if (a.all_singleton && !a.gather && !no_stream) {  // singleton clusters, rows in slot order: barrier-free streaming form
+        static const int cap = getenv("APPLES_STREAM_GRID") ? atoi(getenv("APPLES_STREAM_GRID")) : 0;  // tuning knob
+        if (cap > 0) grid = std::min<unsigned>(grid, (unsigned)cap);
+        hipLaunchKernelGGL(k_select_stream, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);
+    }
     else
-        hipLaunchKernelGGL(k_select, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_select, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
