@@ -1794,7 +1794,9 @@ const char *apples_describe(apples_ctx *ctx) {
                                    : (a.planes == 2 && dist_mfma_enabled() ? "fp4 mfma, bit-plane fed" : "valu"),
              (long long)(a.ref_f4 ? a.slots_pad * (int64_t)a.G * 128 : 0),
              // how the level-loop sweep knows a query's subtree: merged level lists / node bits in LDS / tagged node map
-             ctx->tree.scan ? "scan" : ctx->ws.small.lean ? "lean" : sweep_merge_lists(ctx->tree) ? "merge" : sweep_bits_in_lds(ctx->tree) ? "bits" : "map");
+             // (lean: sweep_lean.hip on big binary trees -- the workspace decides; before there is one, what a plain MLSE / ME pass will get)
+             ctx->tree.scan ? "scan" : (ctx->ws.small.lean || (ctx->ws.batch == 0 && sweep_lean_layout(ctx->tree, false))) ? "lean"
+             : sweep_merge_lists(ctx->tree) ? "merge" : sweep_bits_in_lds(ctx->tree) ? "bits" : "map");
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

@@ -1234,7 +1234,9 @@ int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     b.n_rows_plain = nq;
     static const bool no_stream = getenv("APPLES_NO_STREAM_SELECT") != nullptr;  // diagnostic knob
     if (a.all_singleton && !a.gather && !no_stream) {  // singleton clusters, rows in slot order: barrier-free streaming form
-        static const int cap = getenv("APPLES_STREAM_GRID") ? atoi(getenv("APPLES_STREAM_GRID")) : 0;  // tuning knob
+        // one workgroup per row up to 4 per CU, then rows in turn (C5: 1.70 ms per 4 096 rows against 1.85-1.9 with one
+        // workgroup per row); APPLES_STREAM_GRID: tuning knob
+        static const int cap = getenv("APPLES_STREAM_GRID") ? atoi(getenv("APPLES_STREAM_GRID")) : 1024;
         if (cap > 0) grid = std::min<unsigned>(grid, (unsigned)cap);
         hipLaunchKernelGGL(k_select_stream, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);
     }

@@ -357,7 +357,9 @@ def test_random_trees_per_edge_bit_parity_with_c_oracle(layout, monkeypatch):
             leaves = tree.leaves
             eng = Engine(tree, None, method='OLS')
             if layout == 'merge':
-                assert eng.describe()['sweep_layout'] == 'merge'
+                # (before a workspace exists a binary tree reports the lean form its plain passes would get; per-edge
+                # inspection, used below, runs the level loop with merged lists)
+                assert eng.describe()['sweep_layout'] in ('merge', 'lean')
             for m in METHODS:
                 eng.set_options(method=m, criterion='MLSE')
                 co = COracle(tree, method=m)

@@ -1,8 +1,9 @@
-"""HIP path vs the C oracle at the FULL shapes of BASELINE.json's configs 3, 4 and 5 (reference size,
-alignment length, method), with enough queries for several device batches; a sample of at least 64
-queries per config -- the ones with the fewest and the most observed leaves plus a strided set -- is
-compared with the C oracle, and the whole pass must not depend on how the device cuts it into
-batches.  Needs an MI355X (and a few GB of host memory for the synthetic inputs)."""
+"""HIP path vs the C oracle at the FULL shapes AND query counts of BASELINE.json's configs 3, 4 and 5 (reference
+size, alignment length, method; 100 000 / 50 000 queries, and for the -d config the 4 096-row block the bench holds
+resident: 100 000 rows of 200 000 fp64 columns are 160 GB); a sample of at least 64 queries per config -- the ones
+with the fewest and the most observed leaves plus a strided set -- is compared with the C oracle, and the whole pass
+must not depend on how the device cuts it into batches.  Needs an MI355X (and some 10 GB of host memory for the
+synthetic inputs)."""
 import os
 import sys
 
@@ -27,14 +28,13 @@ def _sample(got, n, extremes=8, strided=56):
                                      np.linspace(0, n - 1, strided).astype(np.int64)]))
 
 
-def test_c3_shape_200k_leaves_two_device_batches():
-    """Config 3: 200 000-leaf backbone, L = 1000 nt, OLS/JC69, -f 0.2 -b 25.  36 000 queries: at
-    this reference size a device batch holds about 28 000, so the tagged node map of the sweep is
-    reused across batches, the top-up selection by segment minima runs on 200 k-slot rows and the
-    host-buffer entry point streams its chunks.  Checked: >= 64 sampled queries byte for byte
-    against the C oracle; the resident and the streamed entry points agree; the result does not
-    depend on the batch size."""
-    nq = 36000
+def test_c3_shape_200k_leaves_100k_queries():
+    """Config 3: 200 000-leaf backbone, L = 1000 nt, 100 000 queries, OLS/JC69, -f 0.2 -b 25: four device
+    batches of 25 000 (what the bench times), so the sweep's pool and work lists are reused across batches, the
+    top-up selection by segment minima runs on 200 k-slot rows and the host-buffer entry point streams its chunks.
+    Checked: >= 64 sampled queries byte for byte against the C oracle; the resident and the streamed entry points
+    agree; the result does not depend on the batch size."""
+    nq = 100000
     d = synth.make_dataset(200000, 1000, nq)
     nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
@@ -43,7 +43,7 @@ def test_c3_shape_200k_leaves_two_device_batches():
     # the fused pass of this workload is the GEMM form on the pre-expanded reference image (1 byte per site and slot)
     assert info['fused_distance_pass'] == 'fp4 gemm, linear threshold', info['fused_distance_pass']
     assert info['fp4_reference_image_bytes'] == 200192 * 16 * 64
-    assert info['sweep_layout'] == 'merge'  # level lists by merging: the default of big binary trees
+    assert info['sweep_layout'] == 'lean'  # sweep_lean.hip: the default of big binary trees
     got = eng.place_sequences(d.query_seqs)          # host buffer in, host buffer out (streamed chunks)
     batch = eng.describe()['batch']
     assert batch < nq, 'expected at least two device batches, got batch = %d' % batch
@@ -68,11 +68,11 @@ def test_c3_shape_200k_leaves_two_device_batches():
 
 
 def test_c4_shape_50k_leaves_L500_protein_fm():
-    """Config 4: 50 000-leaf backbone, L = 500 aa, scoredist + FM.  8 192 queries through the device;
+    """Config 4: 50 000-leaf backbone, L = 500 aa, 50 000 queries, scoredist + FM;
     sampled queries against the C oracle: edges, flags and counts identical, lengths and residuals
     within 1e-9 relative (both sides sum the table values in fp64 left to right; the reference's own
     order is BLAS-internal, SURVEY row a3, which is why this row is tolerance-checked)."""
-    nq = 8192
+    nq = 50000
     d = synth.make_dataset(50000, 500, nq, protein=True)
     nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
     eng = Engine(d.tree, d.ref_seqs, nodes, protein=True, method='FM')
@@ -95,10 +95,11 @@ def test_c4_shape_50k_leaves_L500_protein_fm():
 
 
 def test_c5_shape_200k_column_distance_table_bme():
-    """Config 5: -d input, 200 000 columns, BME.  256 table rows (410 MB), several device batches
-    (max_batch = 96), rows with missing values, an exact hit, a row with nothing observed; every row
-    byte for byte against the C oracle, resident and host-buffer entry points identical."""
-    nq = 256
+    """Config 5: -d input, 200 000 columns, BME.  The bench's block: 4 096 table rows (6.5 GB) resident, rows with
+    missing values, an exact hit, a row with nothing observed; 256 rows (the special ones, the extremes and a strided
+    set) byte for byte against the C oracle; the host-buffer entry point in several device batches (max_batch = 96)
+    on the first 300 rows and with the default batch on the first 100: identical bytes."""
+    nq = 4096
     d = synth.make_dataset(200000, 8, nq)
     nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
     ix = synth.TreeIndex(d.tree)
@@ -106,19 +107,23 @@ def test_c5_shape_200k_column_distance_table_bme():
     D[5, ::3] = -1.0
     D[6, :] = -1.0
     D[7, 123456] = 0.0
-    eng = Engine(d.tree, None, method='BME', max_batch=96)
+    eng = Engine(d.tree, None, method='BME')
     h, n = eng.upload_table(D, nodes)
     eng.place_resident(h)
     got = eng.fetch(h, n)
     eng.free_queries(h)
-    assert eng.describe()['batch'] == 96
-    assert eng.place_distances(D, nodes).tobytes() == got.tobytes()
     eng.close()
+    e1 = Engine(d.tree, None, method='BME', max_batch=96)
+    assert e1.place_distances(D[:300], nodes).tobytes() == got[:300].tobytes()
+    assert e1.describe()['batch'] == 96
+    e1.close()
     e2 = Engine(d.tree, None, method='BME')
     assert e2.place_distances(D[:100], nodes).tobytes() == got[:100].tobytes()
     e2.close()
-    want = COracle(d.tree, method='BME', threads=NTHREADS).place_distances(D, nodes)
-    assert got.tobytes() == want.tobytes()
+    sample = np.unique(np.concatenate([np.arange(16), _sample(got, nq, extremes=16, strided=208)]))
+    assert len(sample) >= 200
+    want = COracle(d.tree, method='BME', threads=NTHREADS).place_distances(np.ascontiguousarray(D[sample]), nodes)
+    assert got[sample].tobytes() == want.tobytes()
     assert got[7]['flags'] & F_EXACT and got[6]['flags'] & F_INSUFFICIENT
 
 
