@@ -594,7 +594,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
             if (dev_alloc(ctx, &w.dist_slow, drows * std::max<int64_t>(stride, 1))) return 1;
             if (dev_alloc(ctx, &w.slow_list, batch)) return 1;
         }
-        if (dev_alloc(ctx, &w.route_list, batch)) return 1;
+        if (dev_alloc(ctx, &w.route_list, 3 * batch)) return 1;
         if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
         if (dev_alloc(ctx, &w.cls_list, 4 * batch)) return 1;
         // one block for every per-batch counter, cleared by one memset: [0..3] size-class counts,
@@ -765,6 +765,7 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     s.cnt_gt = ctx->tree.scan ? nullptr : w.cnt_gt;  // (the scan sweep takes its leaves in node-id order and needs no per-level offsets)
     s.out = qb.out + q0;
     s.big_threshold = big_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+    s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;  // (what run_sweep's launch_big will run)
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     s.seg_slot = w.seg_slot; s.seg_cnt = w.seg_cnt; s.node_level = ctx->tree.level;
     s.slow_list = w.slow_list; s.slow_count = w.slow_count; s.qlist = nullptr; s.qcount = nullptr;
@@ -871,6 +872,7 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     // wavefront-sized teams for the size-class queues
     b.work_list = w.route_list;
     b.work_count = w.route_count;
+    b.route_classes = (w.big.lean && !b.keep_edges) ? 1 : 0;  // (as the selection kernels filed them: select_args_alignment)
     const bool can_overflow = w.small.cap < ctx->tree.n_nodes || w.small.lean_leaf != nullptr;  // (pool: a query may ask for more than its share)
     if (can_overflow) HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), st));
     SweepArgs sm = sweep_args(ctx, w.small, out, false);
@@ -897,6 +899,7 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     if (!can_overflow) return 0;
     b.work_list = w.overflow_list;
     b.work_count = w.overflow_count;
+    b.route_classes = 0;
     b.cursor = w.cls_count + 6;
     return launch_big(b, st);
 }
@@ -1513,6 +1516,7 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.cnt_gt = ctx->tree.scan ? nullptr : w.cnt_gt;
     s.out = d_out;
     s.big_threshold = big_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+    s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 16 * sizeof(int32_t), ctx->stream));  // every counter of the batch
     pt.flush();

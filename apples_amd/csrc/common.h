@@ -90,7 +90,7 @@ struct DevAlign {
     uint4 *packed = nullptr;      // [G][planes+1][slots_pad] uint4 = 4 consecutive 32-site words
     uint8_t *ref_f4 = nullptr;    // [slots_pad][2G][4][32 B] fp4 operand image of the reference (dist_gemm.hip), ACGT- singleton contexts
     // clustered references (fused selection by representatives, select.hip k_select_clusters):
-    uint4 *packed_rm = nullptr;   // [slots_pad][G*3] the same words row-major: one member row = 3*G contiguous uint4
+    uint4 *packed_rm = nullptr;   // the member rows cluster by cluster, interleaved per plane word (dist.hip:k_cluster_major): [n_refs * G*3]
     uint4 *rep_packed = nullptr;  // [G][3][reps_pad] the representatives' rows, in representative order
     int64_t reps_pad = 0;
     uint8_t *aa_idx = nullptr;    // scoredist: [Lpad16/16][slots_pad][16] residue index * 8 (0..152, 160 = gap)
@@ -175,7 +175,7 @@ struct Workspace {
     double *dist_slow = nullptr;       // [batch][stride] full rows for the top-up path
     int32_t *slow_list = nullptr;      // [batch]
     int32_t *slow_count = nullptr;     // [1]
-    int32_t *route_list = nullptr;     // [batch] queries routed to big teams by the selection kernel
+    int32_t *route_list = nullptr;     // [3][batch] queries routed to big teams by the selection kernel (one list, or three by size)
     int32_t *route_count = nullptr;    // [1]
     int32_t *overflow_list = nullptr;  // [batch]
     int32_t *overflow_count = nullptr; // [1]
@@ -281,6 +281,8 @@ struct SelectArgs {
     int64_t cls_stride;
     int big_threshold;                  // n_obs above this -> straight to the big-team sweep list
     int32_t *overflow_list, *overflow_count;
+    int route_classes;                  // the routed queries go to three lists by size (each cls_stride long, counts at overflow_count[4..6]):
+                                        // sweep_lean.hip's workgroup-sized teams take the largest first
     // listed mode of k_select: block r handles query qlist[r] with distances in row r (rows_by_query: in row qlist[r])
     const int32_t *qlist, *qcount;
     int rows_by_query;
@@ -339,6 +341,7 @@ struct SweepArgs {
     int big_threshold;        // small teams skip queries with more observed leaves (already listed for big teams)
     const int32_t *work_list; // queries to process (nullptr = 0..nq-1)
     const int32_t *work_count;// device count of work_list entries (nullptr = nq)
+    int route_classes;        // work_list = three lists of cls_stride entries by size class, counts at work_count[4..6] (largest first)
     const int32_t *cls_list;  // size-class lists (small teams): queue index -> query, largest class first
     const int32_t *cls_count; // [4] class counts
     int64_t cls_stride;

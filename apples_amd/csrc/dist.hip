@@ -586,15 +586,23 @@ __global__ __launch_bounds__(APPLES_TPB) void k_gather_reps(const uint4 *__restr
     if (j < n_reps) out[gp * reps_pad + j] = packed[gp * slots_pad + rep_slot[j]];
 }
 
-__global__ __launch_bounds__(APPLES_TPB) void k_rows_major(const uint4 *__restrict__ packed, int64_t slots_pad, int64_t n_slots,
-                                                           int GP, uint4 *__restrict__ out) {
-    const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+// member rows cluster by cluster, a cluster's members interleaved per plane word: element (gp, position in the cluster) of
+// cluster c at (rep_moff[c] * GP + gp * size(c) + position): the lanes of a wavefront that hold consecutive members of one
+// cluster read consecutive 16-byte words (k_select_clusters)
+__global__ __launch_bounds__(APPLES_TPB) void k_cluster_major(const uint4 *__restrict__ packed, int64_t slots_pad, int64_t n_mem,
+                                                              const int32_t *__restrict__ mem_slot, const int32_t *__restrict__ slot_rep,
+                                                              const int32_t *__restrict__ rep_moff, int GP, uint4 *__restrict__ out) {
+    const int64_t m = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
     const int gp = blockIdx.y;
-    if (slot < n_slots) out[slot * GP + gp] = packed[(int64_t)gp * slots_pad + slot];
+    if (m >= n_mem) return;
+    const int slot = mem_slot[m];
+    const int c = slot_rep[slot];
+    const int64_t b = rep_moff[c], sz = rep_moff[c + 1] - b;
+    out[b * GP + (int64_t)gp * sz + (m - b)] = packed[(int64_t)gp * slots_pad + slot];
 }
 
-// representative rows in representative order (the matrix-core pass runs on them alone) and every row
-// once more row-major (a member row = 3 G contiguous uint4); ACGT- contexts (2 code planes) only
+// representative rows in representative order (the matrix-core pass runs on them alone) and every member row
+// once more cluster by cluster (k_cluster_major); ACGT- contexts (2 code planes) only
 int launch_build_cluster_panels(apples_ctx *ctx) {
     DevAlign &a = ctx->aln;
     const int GP = a.G * 3;
@@ -607,8 +615,8 @@ int launch_build_cluster_panels(apples_ctx *ctx) {
     HIP_TRY(ctx, hipMalloc((void **)&a.packed_rm, (size_t)GP * a.slots_pad * sizeof(uint4)));
     hipLaunchKernelGGL(k_gather_reps, dim3((unsigned)((a.n_reps + APPLES_TPB - 1) / APPLES_TPB), (unsigned)GP), dim3(APPLES_TPB), 0,
                        ctx->stream, a.packed, a.slots_pad, a.rep_slot, a.n_reps, a.reps_pad, a.rep_packed);
-    hipLaunchKernelGGL(k_rows_major, dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)GP), dim3(APPLES_TPB), 0, ctx->stream,
-                       a.packed, a.slots_pad, a.slots_pad, GP, a.packed_rm);
+    hipLaunchKernelGGL(k_cluster_major, dim3((unsigned)((a.n_refs + APPLES_TPB - 1) / APPLES_TPB), (unsigned)GP), dim3(APPLES_TPB), 0,
+                       ctx->stream, a.packed, a.slots_pad, a.n_refs, a.mem_slot, a.slot_rep, a.rep_moff, GP, a.packed_rm);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;

@@ -106,7 +106,15 @@ __device__ int block_excl_scan_int(int v, int *sh /*[4+]*/, int *tot) {
 // largest class first (longest-processing-time order keeps the tail of the launch short)
 __device__ __forceinline__ void enlist(const SelectArgs &a, int64_t q, int ne) {
     if (ne <= 0) return;
-    if (ne > a.big_threshold && a.overflow_list) { a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q; return; }
+    if (ne > a.big_threshold && a.overflow_list) {
+        if (a.route_classes) {  // by size, so that the longest jobs start first (counts at overflow_count[4..6])
+            const int k = ne > 4 * a.big_threshold ? 0 : (ne > 2 * a.big_threshold ? 1 : 2);
+            a.overflow_list[k * a.cls_stride + atomicAdd(&a.overflow_count[4 + k], 1)] = (int32_t)q;
+        } else {
+            a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q;
+        }
+        return;
+    }
     if (!a.cls_list) return;
     const int k = ne > 1024 ? 0 : (ne > 512 ? 1 : (ne > 256 ? 2 : 3));
     a.cls_list[k * a.cls_stride + atomicAdd(&a.cls_count[k], 1)] = (int32_t)q;
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
 // unless they hold fewer than `baseobs` valid member distances -- then the reference keeps walking its
 // heap, and the query goes to the slow list (full rows + k_select), as in k_select_fast.  One workgroup
 // per query: the accepted clusters' members are expanded to a flat list, a thread computes one
-// (query, member) distance from the member's row-major packed row (the pair counts of k_jc69, same
+// (query, member) distance from the member's words in the cluster-major panel (the pair counts of k_jc69, same
 // table lookup), marks the member's slot in an LDS bitmap; ranks of the bitmap give the slot-ordered
 // (= level-ordered) observation list the sweep wants.
 #define ACC_CAP 512
@@ -570,17 +578,28 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
                 if (sh_off[mid] <= m) lo = mid; else hi = mid;
             }
             const int rep = sh_rep[lo], mp = m - sh_off[lo];
-            const int slot = a.mem_slot[a.rep_moff[rep] + mp];
-            const uint4 *row = a.packed_rm + (int64_t)slot * (G * 3);
+            const int mb = a.rep_moff[rep], sz = a.rep_moff[rep + 1] - mb;
+            const int slot = a.mem_slot[mb + mp];
+            // the member's words in the cluster-major panel: word (g, plane) of member mp at (g * 3 + plane) * sz + mp, so
+            // the lanes holding consecutive members of this cluster read consecutive 16 bytes
+            const uint4 *row = a.packed_rm + (int64_t)mb * (G * 3) + mp;
             uint32_t nv = 0, nmis = 0;
-            for (int g = 0; g < G; ++g) {
-                const uint4 rm = row[g * 3], r0 = row[g * 3 + 1], r1 = row[g * 3 + 2];
+            auto count = [&](const uint4 &rm, const uint4 &r0, const uint4 &r1, int g) {
                 const uint4 qm = sh_q[g * 3], q0 = sh_q[g * 3 + 1], q1 = sh_q[g * 3 + 2];
                 const uint32_t m0_ = qm.x & rm.x, m1_ = qm.y & rm.y, m2_ = qm.z & rm.z, m3_ = qm.w & rm.w;
                 nv += __popc(m0_) + __popc(m1_) + __popc(m2_) + __popc(m3_);
                 nmis += __popc(((q0.x ^ r0.x) | (q1.x ^ r1.x)) & m0_) + __popc(((q0.y ^ r0.y) | (q1.y ^ r1.y)) & m1_) +
                         __popc(((q0.z ^ r0.z) | (q1.z ^ r1.z)) & m2_) + __popc(((q0.w ^ r0.w) | (q1.w ^ r1.w)) & m3_);
+            };
+            int g = 0;
+            for (; g + 4 <= G; g += 4) {  // twelve loads in flight before the first is used (one round trip, not four)
+                uint4 w[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) w[k] = row[(int64_t)(g * 3 + k) * sz];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) count(w[3 * k], w[3 * k + 1], w[3 * k + 2], g + k);
             }
+            for (; g < G; ++g) count(row[(int64_t)(g * 3) * sz], row[(int64_t)(g * 3 + 1) * sz], row[(int64_t)(g * 3 + 2) * sz], g);
             const double d = a.seg_lut[(int64_t)nv * (nv + 1) / 2 + nmis];
             double keep = -2.0;  // not emitted
             if (!(d < 0)) {      // Reference.py:150: `if not dm < 0`

@@ -192,22 +192,22 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
 }
 
 // a child's S tuple: an internal child's from the arrays (or from the LDS stage when its level is there), a leaf's
-// rebuilt from its distance
+// rebuilt from its distance.  The loads from the arrays are unconditional (a leaf child or no child reads entry 0 and
+// drops it): no branch stands between the loads of a node's two children and of its own tuple, so they all leave together
+// and a step waits for one round trip, not for one per child.
 template <int M>
 __device__ __forceinline__ void kid_tuple(int kd, double dist, const LeanTeam &t, const double2 (*stage)[WAVE], bool staged,
                                           int stage_base, double *S) {
-    if (kd > 0) {
-        double2 a, b, c;
-        if (staged) {
-            const int p = kd - 1 - stage_base;
-            a = stage[0][p]; b = stage[1][p]; c = stage[2][p];
-        } else {
-            a = t.T0[kd - 1]; b = t.T1[kd - 1]; c = t.T2[kd - 1];
-        }
-        S[0] = a.x; S[1] = a.y; S[2] = b.x; S[3] = b.y; S[4] = c.x; S[5] = c.y;
+    double2 a, b, c;
+    if (staged) {  // (wave-uniform)
+        const int p = kd > 0 ? kd - 1 - stage_base : 0;
+        a = stage[0][p]; b = stage[1][p]; c = stage[2][p];
     } else {
-        leaf_tuple<M>(dist, S);
+        const int ki = kd > 0 ? kd - 1 : 0;
+        a = t.T0[ki]; b = t.T1[ki]; c = t.T2[ki];
     }
+    S[0] = a.x; S[1] = a.y; S[2] = b.x; S[3] = b.y; S[4] = c.x; S[5] = c.y;
+    if (kd <= 0) leaf_tuple<M>(dist, S);
 }
 
 // S tuple of a node from its entry (apples/OLS.py:25-44: children in file order)
@@ -216,16 +216,16 @@ __device__ __forceinline__ void node_S(const int2 d, const double2 e, const doub
                                        const double2 (*stage)[WAVE], bool staged, int kid_base, double *r) {
     constexpr bool BME = (M == APPLES_BME);
     const double coef = BME ? 1.0 / (double)(d.y != 0 ? 2 : 1) : 1.0;  // apples/BME.py:20
-    double S[6], u[6];
-    kid_tuple<M>(d.x, dd.x, t, stage, staged, kid_base, S);
-    lift<M>(S, e.x, u);
+    double S0[6], S1[6], u[6];
+    kid_tuple<M>(d.x, dd.x, t, stage, staged, kid_base, S0);
+    kid_tuple<M>(d.y, dd.y, t, stage, staged, kid_base, S1);  // (no second child: a dummy that is not used)
+    lift<M>(S0, e.x, u);
 #pragma unroll
     for (int x = 0; x < 6; ++x) r[x] = 0;
 #pragma unroll
     for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
     if (d.y != 0) {
-        kid_tuple<M>(d.y, dd.y, t, stage, staged, kid_base, S);
-        lift<M>(S, e.y, u);
+        lift<M>(S1, e.y, u);
 #pragma unroll
         for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
     }
@@ -307,10 +307,10 @@ __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, bool is
     // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
     const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
     double plift[6];
-    if (!is_lca) lean_own_plift(t, idx, hand_in, in_pos, plift);
+    lean_own_plift(t, idx, hand_in, in_pos, plift);  // (the LCA has none: what it reads there is not used)
     double Sk[6], Ss[6];  // the child in hand and its sibling
     kid_tuple<M>(d.x, dd.x, t, nullptr, false, 0, Sk);
-    if (nk > 1) kid_tuple<M>(d.y, dd.y, t, nullptr, false, 0, Ss);
+    kid_tuple<M>(d.y, dd.y, t, nullptr, false, 0, Ss);
     double ek = e.x, es = e.y;
     int kd = d.x, ks = d.y, kn = nd.x, ksn = nd.y;
 #pragma unroll 1
@@ -343,9 +343,9 @@ __device__ __forceinline__ void lean_td_pairs(const LeanTeam &t, int g0, int ng,
     double plift[6], Sk[6], Ss[6];
     const bool mine = act && z < nk;
     if (mine) {
-        if (!is_lca) lean_own_plift(t, idx, hand_in, i, plift);
+        lean_own_plift(t, idx, hand_in, i, plift);
         kid_tuple<M>(z ? d.y : d.x, z ? dd.y : dd.x, t, nullptr, false, 0, Sk);
-        if (nk > 1) kid_tuple<M>(z ? d.x : d.y, z ? dd.x : dd.y, t, nullptr, false, 0, Ss);
+        kid_tuple<M>(z ? d.x : d.y, z ? dd.x : dd.y, t, nullptr, false, 0, Ss);
     }
     __builtin_amdgcn_wave_barrier();  // (every lane's reads of the hand-over precede the stores of this step)
     if (mine)
@@ -784,14 +784,18 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
     const int4 *__restrict__ pe = reinterpret_cast<const int4 *>(T.pe);
     const LeanTeam t = lean_team(a.lean, blockIdx.x, a.lean_cap1, a.lean_leaf1);
     int32_t *grp_off = a.grp_off + (int64_t)blockIdx.x * (T.height + 4);
-    const int64_t n_work = a.work_count ? *a.work_count : nq;
+    // work: a device-side list, or (routed queries) three lists by size class, largest first
+    const int r0 = a.route_classes ? a.work_count[4] : 0, r1 = a.route_classes ? a.work_count[5] : 0;
+    const int64_t n_work = a.route_classes ? (int64_t)r0 + r1 + a.work_count[6] : (a.work_count ? *a.work_count : nq);
     while (true) {
         if (tid == 0) sh.w = atomicAdd(a.cursor, 1);
         __syncthreads();
         const int64_t w = sh.w;
         __syncthreads();
         if (w >= n_work) break;
-        const int64_t q = a.work_list ? a.work_list[w] : w;
+        int64_t q;
+        if (a.route_classes) q = w < r0 ? a.work_list[w] : (w < r0 + r1 ? a.work_list[a.cls_stride + (w - r0)] : a.work_list[2 * a.cls_stride + (w - r0 - r1)]);
+        else q = a.work_list ? a.work_list[w] : w;
         const int n = a.n_obs[q];
         if (n == 0) continue;
         const int32_t *o_node = a.obs_node + q * a.obs_cap;
