@@ -17,6 +17,12 @@ int dev_alloc(apples_ctx *ctx, T **p, int64_t n) {
     *p = nullptr;
     if (n <= 0) n = 1;
     hipError_t e = hipMalloc((void **)p, (size_t)n * sizeof(T));
+    if (e != hipSuccess && !ctx->blk_cache.empty()) {  // out of memory: give back the cached block buffers and try once more
+        (void)hipGetLastError();
+        for (auto &c : ctx->blk_cache) (void)hipFree(c.second);
+        ctx->blk_cache.clear();
+        e = hipMalloc((void **)p, (size_t)n * sizeof(T));
+    }
     if (e != hipSuccess) {
         size_t fr = 0, tot = 0;
         (void)hipMemGetInfo(&fr, &tot);
@@ -71,11 +77,15 @@ void blk_free(apples_ctx *ctx, void *p) {
     if (it == ctx->blk_size.end()) { dev_free(p); return; }
     const size_t bytes = it->second;
     ctx->blk_size.erase(it);
-    if (ctx->blk_cache.size() >= 24) {  // keep the cache bounded: the oldest entry goes
+    // (the caller has drained every stream that used the buffer: the entry points synchronise before they free a block)
+    ctx->blk_cache.emplace_back(bytes, p);
+    size_t held = 0;
+    for (auto &c : ctx->blk_cache) held += c.first;
+    while (!ctx->blk_cache.empty() && (ctx->blk_cache.size() > 24 || held > ((size_t)6 << 30))) {  // bounded by bytes: the oldest go
+        held -= ctx->blk_cache.front().first;
         dev_free(ctx->blk_cache.front().second);
         ctx->blk_cache.erase(ctx->blk_cache.begin());
     }
-    ctx->blk_cache.emplace_back(bytes, p);
 }
 
 // BLOSUM45-derived dissimilarities (FastTree2's table, the data apples/distance.py:12-415 reads);
@@ -164,6 +174,29 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
     // lowest common ancestors.  Needs post-order node ids (a subtree = a contiguous id range ending at its
     // root), at most 254 levels and tables of a sensible size.
     d.scan = false;
+    {
+        // left-to-right post-order ids (a subtree = a contiguous id range ending at its root, children tiling it from the
+        // left in file order): what the merged level lists of the sweep rely on.  apples_amd/tree.py numbers that way
+        // (apples/util.py:57-69); a C-ABI caller with another numbering gets the node map / node bits instead.
+        const int n = t->n_nodes;
+        std::vector<int64_t> size(n, 1);
+        bool postorder = true;
+        for (int i = 0; i < n - 1 && postorder; ++i) {
+            const int p = t->parent[i];
+            if (p <= i || p >= n) postorder = false; else size[p] += size[i];
+        }
+        if (postorder && (t->parent[n - 1] != -1 || size[n - 1] != n)) postorder = false;
+        for (int i = 0; i < n && postorder; ++i) {
+            int64_t at = i - size[i] + 1;
+            for (int c = t->child_off[i]; c < t->child_off[i + 1]; ++c) {
+                const int k = t->child_idx[c];
+                if (k < 0 || k >= n || k - size[k] + 1 != at) { postorder = false; break; }
+                at = k + 1;
+            }
+            if (postorder && t->child_off[i + 1] > t->child_off[i] && at != i) postorder = false;
+        }
+        d.merge_ok = postorder;
+    }
     if (getenv("APPLES_SWEEP_SCAN") && h <= 254) {
         const int n = t->n_nodes;
         std::vector<int64_t> size(n, 1);
@@ -285,6 +318,15 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
     std::vector<int32_t> level(t->level, t->level + t->n_nodes);
     for (int64_t r = 0; r < a.n_refs; ++r)
         if (al->row_node[r] >= t->n_nodes) { ctx->err = "row_node out of range"; return 1; }
+    {  // two reference rows on one tree leaf: the observed leaves of a query would not be distinct nodes
+        std::vector<uint8_t> seen(t->n_nodes, 0);
+        for (int64_t r = 0; r < a.n_refs; ++r) {
+            const int nd = al->row_node[r];
+            if (nd < 0) continue;
+            if (seen[nd]) { ctx->tree.merge_ok = false; break; }
+            seen[nd] = 1;
+        }
+    }
     std::vector<int32_t> ord = level_order(al->row_node, a.n_refs, level, ctx->tree.scan);
     a.slot_row.assign(a.n_rows, 0);
     a.row_slot.assign(a.n_rows, 0);
@@ -552,19 +594,28 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     // batches amortise the sweep's tail: at 200 k leaves 16 k-query batches are 13 % faster than 5 k).
     // Allocating them is not free: with 160 GiB a resident C3 pass is another 4 % faster, but a one-shot
     // command-line run of the same size pays 1.1 to 3.4 s more for the allocation.
-    int64_t budget_gib = 96;
-    {
+    int64_t capq = 0;
+    auto size_batch = [&]() {
+        int64_t budget_gib = 96;
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_gib = std::max<int64_t>(8, std::min<int64_t>(96, (int64_t)(fr >> 30) * 2 / 5));
-    }
-    if (const char *e = getenv("APPLES_BATCH_GIB")) budget_gib = std::max<int64_t>(1, atoll(e));  // tuning knob
-    int64_t capq = std::max<int64_t>(32, ((need_alt ? budget_gib / 2 : budget_gib) << 30) / std::max<int64_t>(per_q, 1));
-    batch = std::min(batch, capq);
-    batch = round_up(std::max<int64_t>(batch, 1), 32);
+        if (const char *e = getenv("APPLES_BATCH_GIB")) budget_gib = std::max<int64_t>(1, atoll(e));  // tuning knob
+        capq = std::max<int64_t>(32, ((need_alt ? budget_gib / 2 : budget_gib) << 30) / std::max<int64_t>(per_q, 1));
+        int64_t b = want_batch;
+        if (ctx->params.max_batch > 0) b = std::min(b, (int64_t)ctx->params.max_batch);
+        b = std::min(b, capq);
+        return round_up(std::max<int64_t>(b, 1), 32);
+    };
+    batch = size_batch();
     bool regrow = batch > w.batch || members > w.obs_cap || stride > w.stride || (need_counts && !w.counts) ||
                   (need_xe && !w.big.xe) || (need_dist && !w.dist) || (need_fused && !w.seg_slot) || (need_alt && !w.has_alt) ||
-                  (!slim && w.dist_rows < std::min(batch, w.batch));  // full rows wanted where only a slice exists
+                  (!slim && w.dist_rows < w.batch);  // full rows wanted where only a slice exists (run_block steps by w.batch)
     if (!regrow) return 0;
+    if (!ctx->blk_cache.empty()) {  // cached block buffers count as used in hipMemGetInfo: give them back, then size the batch
+        for (auto &c : ctx->blk_cache) dev_free(c.second);
+        ctx->blk_cache.clear();
+        batch = size_batch();
+    }
     if (slim == w.slim || !w.slim) batch = std::max(batch, w.batch);
     if (!slim) batch = std::min(batch, std::max<int64_t>(capq, 32));  // (a slim workspace's batch would not fit with full rows)
     batch = round_up(std::max<int64_t>(batch, 1), 32);
@@ -1045,6 +1096,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 int32_t lens[64];
                 int n_sl = 0;
                 for (int64_t off = 0; off < hcnt && n_sl < 64; off += R) lens[n_sl++] = (int32_t)std::min<int64_t>(R, hcnt - off);
+                if ((int64_t)n_sl * R < hcnt) { ctx->err = "top-up list longer than 64 slices of the batch's full rows"; return 1; }
                 if (n_sl > 1) {
                     if (!ctx->d_slice_cnt && dev_alloc(ctx, &ctx->d_slice_cnt, 64)) return 1;
                     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slice_cnt, lens, n_sl * sizeof(int32_t), hipMemcpyHostToDevice, front));
@@ -1481,6 +1533,20 @@ static int setup_columns(apples_ctx *ctx, int64_t n_cols, const int32_t *col_nod
     HIP_TRY(ctx, hipMemcpy(level.data(), t.level, (size_t)t.n_nodes * 4, hipMemcpyDeviceToHost));
     for (int64_t c = 0; c < n_cols; ++c)
         if (col_node[c] >= t.n_nodes) { ctx->err = "col_node out of range"; return 1; }
+    if (ctx->tree.merge_ok) {  // two columns on one tree leaf: no merged level lists (the workspace is laid out again)
+        std::vector<uint8_t> seen(t.n_nodes, 0);
+        for (int64_t c = 0; c < n_cols; ++c) {
+            const int nd = col_node[c];
+            if (nd < 0) continue;
+            if (seen[nd]) {
+                ctx->tree.merge_ok = false;
+                HIP_TRY(ctx, hipDeviceSynchronize());
+                free_workspace(ctx->ws);
+                break;
+            }
+            seen[nd] = 1;
+        }
+    }
     std::vector<int32_t> &perm = ctx->h_col_perm;
     perm = level_order(col_node, n_cols, level, ctx->tree.scan);
     std::vector<int32_t> s_node(n_cols), s_level(n_cols);

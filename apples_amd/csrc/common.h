@@ -41,6 +41,9 @@ struct DevTree {
     int32_t n_nodes = 0;
     int32_t height = 0;  // max level
     int32_t max_children = 0;
+    // the merged level lists (sweep.hip:merge_parents, sweep_lean.hip) need node ids in left-to-right post-order and observed
+    // leaves that are distinct nodes; a tree or an alignment / table that does not comply gets the node map or the node bits
+    bool merge_ok = false;
     int32_t *parent = nullptr;
     double *edge_len = nullptr;
     int32_t *child_off = nullptr;

@@ -490,6 +490,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
 // table lookup), marks the member's slot in an LDS bitmap; ranks of the bitmap give the slot-ordered
 // (= level-ordered) observation list the sweep wants.
 #define ACC_CAP 512
+#ifndef CLUSTER_UNROLL
+#define CLUSTER_UNROLL 1  // member word groups in flight per lane (3 16-byte loads each).  More is slower: the kernel is bound by
+                          // the rate the member panel (77 MB at 200 k leaves: Infinity Cache) delivers 120 GB per 100 k queries,
+                          // 38 / 42 / 48 / 43 ms per C3 pass with 1 / 2 / 4 / 8
+#endif
 __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     extern __shared__ unsigned long long dyn_bits[];  // [n_words] member bits in slot order, then uint32 [n_words] prefix
     __shared__ int sh_i[8];
@@ -499,6 +504,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     __shared__ int sh_rep[ACC_CAP];
     __shared__ double sh_drep[ACC_CAP];
     __shared__ int sh_off[ACC_CAP + 1];
+    __shared__ int sh_mb[ACC_CAP];  // first member (index into mem_slot / the cluster-major panel) of every accepted cluster
     __shared__ int sh_znode, sh_nacc;
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x;
@@ -555,10 +561,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
         int carry = 0;
         for (int k0 = 0; k0 < n_acc; k0 += APPLES_TPB) {
             const int k = k0 + tid;
-            const int sz = k < n_acc ? a.rep_moff[sh_rep[k] + 1] - a.rep_moff[sh_rep[k]] : 0;
+            const int mb0 = k < n_acc ? a.rep_moff[sh_rep[k]] : 0;
+            const int sz = k < n_acc ? a.rep_moff[sh_rep[k] + 1] - mb0 : 0;
             int tot;
             const int off = carry + block_excl_scan_int(sz, sh_i, &tot);
-            if (k < n_acc) sh_off[k] = off;
+            if (k < n_acc) { sh_off[k] = off; sh_mb[k] = mb0; }
             carry += tot;
         }
         if (tid == 0) sh_off[n_acc] = carry;
@@ -578,8 +585,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
                 if (sh_off[mid] <= m) lo = mid; else hi = mid;
             }
             const int rep = sh_rep[lo], mp = m - sh_off[lo];
-            const int mb = a.rep_moff[rep], sz = a.rep_moff[rep + 1] - mb;
-            const int slot = a.mem_slot[mb + mp];
+            const int mb = sh_mb[lo], sz = sh_off[lo + 1] - sh_off[lo];
+            const int slot = a.mem_slot[mb + mp];  // (on its way with the member's words below: neither waits for the other)
             // the member's words in the cluster-major panel: word (g, plane) of member mp at (g * 3 + plane) * sz + mp, so
             // the lanes holding consecutive members of this cluster read consecutive 16 bytes
             const uint4 *row = a.packed_rm + (int64_t)mb * (G * 3) + mp;
@@ -592,12 +599,12 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
                         __popc(((q0.z ^ r0.z) | (q1.z ^ r1.z)) & m2_) + __popc(((q0.w ^ r0.w) | (q1.w ^ r1.w)) & m3_);
             };
             int g = 0;
-            for (; g + 4 <= G; g += 4) {  // twelve loads in flight before the first is used (one round trip, not four)
-                uint4 w[12];
+            for (; g + CLUSTER_UNROLL <= G; g += CLUSTER_UNROLL) {  // 3 x CLUSTER_UNROLL loads in flight before the first is used
+                uint4 w[3 * CLUSTER_UNROLL];
 #pragma unroll
-                for (int k = 0; k < 12; ++k) w[k] = row[(int64_t)(g * 3 + k) * sz];
+                for (int k = 0; k < 3 * CLUSTER_UNROLL; ++k) w[k] = row[(int64_t)(g * 3 + k) * sz];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) count(w[3 * k], w[3 * k + 1], w[3 * k + 2], g + k);
+                for (int k = 0; k < CLUSTER_UNROLL; ++k) count(w[3 * k], w[3 * k + 1], w[3 * k + 2], g + k);
             }
             for (; g < G; ++g) count(row[(int64_t)(g * 3) * sz], row[(int64_t)(g * 3 + 1) * sz], row[(int64_t)(g * 3 + 2) * sz], g);
             const double d = a.seg_lut[(int64_t)nv * (nv + 1) / 2 + nmis];
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
                     const int mid = (lo + hi) >> 1;
                     if (sh_off[mid] <= m) lo = mid; else hi = mid;
                 }
-                const int slot = a.mem_slot[a.rep_moff[sh_rep[lo]] + (m - sh_off[lo])];
+                const int slot = a.mem_slot[sh_mb[lo] + (m - sh_off[lo])];
                 const unsigned long long word = dyn_bits[slot >> 6];
                 const int pos = (int)pre[slot >> 6] + __popcll(word & ((1ull << (slot & 63)) - 1ull));
                 o_node[pos] = a.slot_node[slot];

@@ -877,7 +877,7 @@ bool sweep_merge_lists(const DevTree &t) {
     // knobs: APPLES_NO_SWEEP_MERGE = the tagged node map for big trees as before; APPLES_SWEEP_MERGE = the merge layout
     // also where the node bits would fit in LDS (tests run it on small trees)
     const bool off = getenv("APPLES_NO_SWEEP_MERGE") != nullptr, force = getenv("APPLES_SWEEP_MERGE") != nullptr;
-    if (off || t.scan || getenv("APPLES_NODE_MAP")) return false;
+    if (off || t.scan || !t.merge_ok || getenv("APPLES_NODE_MAP")) return false;
     return force || (size_t)4 * t.bm_words * 12 > 40 * 1024;
 }
 
@@ -890,7 +890,8 @@ bool sweep_lean_layout(const DevTree &t, bool per_edge_records) {
 
 bool sweep_bits_in_lds(const DevTree &t) {
     if (getenv("APPLES_NODE_MAP")) return false;  // test knob: exercise the big-tree layout on a small tree
-    if (getenv("APPLES_SWEEP_MERGE") && !t.scan && !getenv("APPLES_NO_SWEEP_MERGE")) return false;  // (forced merge layout)
+    if (getenv("APPLES_SWEEP_MERGE") && !t.scan && t.merge_ok && !getenv("APPLES_NO_SWEEP_MERGE")) return false;  // (forced merge layout)
+    // (a big tree whose numbering the merged lists cannot take keeps the tagged node map)
     return (size_t)4 * t.bm_words * 12 <= 40 * 1024;
 }
 static size_t dyn_lds_bytes(const DevTree &t, int teams_per_wg) {

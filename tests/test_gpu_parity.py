@@ -480,3 +480,48 @@ def test_gemm_form_of_the_fused_pass_at_many_lengths():
         outs.append(r.stdout)
     assert len(outs[0]) == 11 * 300 * 40
     assert all(o == outs[0] for o in outs)
+
+
+def test_node_numbering_other_than_post_order_is_served_without_merged_lists(monkeypatch):
+    """The merged level lists of the sweep (the default of big trees, forced here) rely on left-to-right post-order
+    node ids, which apples_amd/tree.py produces as the reference does (apples/util.py:57-69).  A C-ABI caller with
+    another numbering must not get silently wrong placements: the context falls back to the node bits / node map, and
+    the placements are the same edges under the relabelling."""
+    import types
+    monkeypatch.setenv('APPLES_SWEEP_MERGE', '1')
+    d = synth.make_dataset(700, 200, 48)
+    t = d.tree
+    n = t.n_nodes
+    rng = np.random.default_rng(5)
+    pi = np.concatenate([rng.permutation(n - 1), [n - 1]]).astype(np.int32)   # new id of every node; the root stays last
+    inv = np.empty(n, np.int32)
+    inv[pi] = np.arange(n, dtype=np.int32)
+    parent = np.full(n, -1, np.int32)
+    parent[pi[:n - 1]] = pi[np.asarray(t.parent)[:n - 1]]
+    edge_len = np.zeros(n)
+    edge_len[pi] = np.asarray(t.edge_len)
+    level = np.zeros(n, np.int32)
+    level[pi] = np.asarray(t.level)
+    counts = np.zeros(n, np.int64)
+    counts[pi] = np.diff(np.asarray(t.child_off))
+    child_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    child_idx = np.empty(n - 1, np.int32)
+    for v in range(n):  # children keep their file order
+        kids = np.asarray(t.child_idx)[t.child_off[v]:t.child_off[v + 1]]
+        child_idx[child_off[pi[v]]:child_off[pi[v]] + len(kids)] = pi[kids]
+    relabelled = types.SimpleNamespace(n_nodes=n, parent=parent, edge_len=edge_len, child_off=child_off, child_idx=child_idx,
+                                       level=level)
+    nodes = np.array([t.name_to_node[x] for x in d.ref_names], np.int32)
+    e0 = Engine(t, d.ref_seqs, nodes, method='OLS')
+    want = e0.place_sequences(d.query_seqs)
+    assert e0.describe()['sweep_layout'] in ('merge', 'lean')
+    e0.close()
+    e1 = Engine(relabelled, d.ref_seqs, pi[nodes], method='OLS')
+    got = e1.place_sequences(d.query_seqs)
+    assert e1.describe()['sweep_layout'] == 'bits'
+    e1.close()
+    placed = want['edge'] >= 0
+    assert np.array_equal(got['edge'][placed], pi[want['edge'][placed]])
+    assert np.array_equal(got['edge'][~placed], want['edge'][~placed])
+    for f in ('error', 'distal', 'pendant', 'n_obs', 'n_valid', 'flags'):
+        assert np.array_equal(got[f], want[f]), f
