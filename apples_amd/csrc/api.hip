@@ -97,6 +97,7 @@ const double kBlosum45[400] = {
 
 int upload_tree(apples_ctx *ctx, const apples_tree *t) {
     DevTree &d = ctx->tree;
+    d.dbg = ctx->dbg;
     d.n_nodes = t->n_nodes;
     int h = 0;
     for (int i = 0; i < t->n_nodes; ++i) h = std::max(h, t->level[i]);
@@ -197,7 +198,7 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
         }
         d.merge_ok = postorder;
     }
-    if (getenv("APPLES_SWEEP_SCAN") && h <= 254) {
+    if ((ctx->dbg & APPLES_DBG_SWEEP_SCAN) && h <= 254) {
         const int n = t->n_nodes;
         std::vector<int64_t> size(n, 1);
         bool postorder = true;
@@ -421,7 +422,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         }
         dev_free(d_exotic);
         // pre-expanded reference image for the GEMM form of the fused pass (dist_gemm.hip): 2 bytes per site
-        if (a.all_singleton && a.planes == 2 && a.L <= GEMM_MAX_L && dist_mfma_enabled() && !getenv("APPLES_NO_DIST_GEMM")) {
+        if (a.all_singleton && a.planes == 2 && a.L <= GEMM_MAX_L && dist_mfma_enabled() && !(ctx->dbg & APPLES_DBG_NO_DIST_GEMM)) {
             // (the image's own allocation marks the context's fp4 images as compact: 64 bytes per 64-site block)
             if (dev_alloc(ctx, &a.ref_f4, a.slots_pad * (int64_t)a.G * 128)) return 1;
             if (launch_expand_queries_f4(ctx, a.raw, a.n_rows, a.ref_f4, a.slots_pad, ctx->stream, a.d_slot_row)) return 1;
@@ -979,7 +980,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     bool hybrid = ctx->params.criterion == APPLES_HYBRID;
     // fused path: threshold compaction in the distance kernel's epilogue; only queries that need
     // the top-up rule get full distance rows
-    static const bool no_fuse = getenv("APPLES_NO_FUSE") != nullptr;  // tuning/diagnostic knobs
+    const bool no_fuse = (ctx->dbg & APPLES_DBG_NO_FUSE) != 0;  // diagnostic switch
     static const int n_pipe = getenv("APPLES_PIPELINE") ? atoi(getenv("APPLES_PIPELINE")) : 1;  // >1: measured slower (sweep and distance kernels contend), kept as a knob
     // clustered references: the matrix-core pass runs over the representatives only, k_select_clusters expands
     // the accepted clusters (needs the panels of setup_alignment, the tabulated distances and their integer
@@ -1185,6 +1186,15 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
     };
     ctx->device = device;
     ctx->params = *params;
+    ctx->dbg = params->debug;
+    {
+        static const struct { const char *env; uint32_t bit; } knobs[] = {
+            {"APPLES_NO_FUSE", APPLES_DBG_NO_FUSE}, {"APPLES_SWEEP_SCAN", APPLES_DBG_SWEEP_SCAN}, {"APPLES_NODE_MAP", APPLES_DBG_NODE_MAP},
+            {"APPLES_SWEEP_MERGE", APPLES_DBG_SWEEP_MERGE}, {"APPLES_NO_SWEEP_MERGE", APPLES_DBG_NO_SWEEP_MERGE},
+            {"APPLES_NO_DIST_GEMM", APPLES_DBG_NO_DIST_GEMM}, {"APPLES_NO_SWEEP_LEAN", APPLES_DBG_NO_SWEEP_LEAN}};
+        for (const auto &k : knobs)
+            if (getenv(k.env)) ctx->dbg |= k.bit;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         ctx->err = "no HIP device available: the APPLES hot path needs an MI355X (there is no CPU fallback)";
@@ -1258,6 +1268,7 @@ int apples_set_params(apples_ctx *ctx, const apples_params *params) {
     int model = ctx->params.model;
     if (ctx->has_aln && params->model != model) { ctx->err = "the distance model is fixed at context creation"; return 1; }
     ctx->params = *params;
+    ctx->params.debug = ctx->dbg;  // (the switches are fixed at creation)
     ctx->params.jc_lut = nullptr;
     if (params->jc_lut && params->jc_lut_len > 0) {
         int64_t L = ctx->has_aln ? ctx->aln.L : 0;

@@ -44,6 +44,7 @@ struct DevTree {
     // the merged level lists (sweep.hip:merge_parents, sweep_lean.hip) need node ids in left-to-right post-order and observed
     // leaves that are distinct nodes; a tree or an alignment / table that does not comply gets the node map or the node bits
     bool merge_ok = false;
+    uint32_t dbg = 0;  // APPLES_DBG_* switches of the context (apples_params.debug | environment), fixed at creation
     int32_t *parent = nullptr;
     double *edge_len = nullptr;
     int32_t *child_off = nullptr;
@@ -199,6 +200,7 @@ struct apples_ctx {
     std::string err;
     std::string desc;
     apples_params params{};
+    uint32_t dbg = 0;  // APPLES_DBG_* (apples_params.debug at creation | the environment variables of the same names)
     DevTree tree;
     DevAlign aln;
     bool has_aln = false;

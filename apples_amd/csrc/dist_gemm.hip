@@ -397,8 +397,8 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
 }  // namespace
 
 bool dist_gemm_usable(const apples_ctx *ctx) {
-    static const bool off = getenv("APPLES_NO_DIST_GEMM") != nullptr;  // diagnostic knob: the bit-plane-fed MFMA kernel instead
-    return !off && ctx->aln.ref_f4 && ctx->aln.L <= GEMM_MAX_L;
+    // (APPLES_DBG_NO_DIST_GEMM: no reference image is built, the bit-plane-fed MFMA kernel runs instead)
+    return !(ctx->dbg & APPLES_DBG_NO_DIST_GEMM) && ctx->aln.ref_f4 && ctx->aln.L <= GEMM_MAX_L;
 }
 
 int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt) {

@@ -874,10 +874,10 @@ __global__ __launch_bounds__(APPLES_TPB, APPLES_SWEEP_WAVES) void k_sweep_mixed(
 }
 
 bool sweep_merge_lists(const DevTree &t) {
-    // knobs: APPLES_NO_SWEEP_MERGE = the tagged node map for big trees as before; APPLES_SWEEP_MERGE = the merge layout
-    // also where the node bits would fit in LDS (tests run it on small trees)
-    const bool off = getenv("APPLES_NO_SWEEP_MERGE") != nullptr, force = getenv("APPLES_SWEEP_MERGE") != nullptr;
-    if (off || t.scan || !t.merge_ok || getenv("APPLES_NODE_MAP")) return false;
+    // switches (apples_params.debug / environment): NO_SWEEP_MERGE = the tagged node map for big trees as before;
+    // SWEEP_MERGE = the merge layout also where the node bits would fit in LDS (tests run it on small trees)
+    const bool off = (t.dbg & APPLES_DBG_NO_SWEEP_MERGE) != 0, force = (t.dbg & APPLES_DBG_SWEEP_MERGE) != 0;
+    if (off || t.scan || !t.merge_ok || (t.dbg & APPLES_DBG_NODE_MAP)) return false;
     return force || (size_t)4 * t.bm_words * 12 > 40 * 1024;
 }
 
@@ -885,12 +885,12 @@ bool sweep_merge_lists(const DevTree &t) {
 // records -- HYBRID and inspection keep the level loop above).  APPLES_NO_SWEEP_LEAN: the level loop everywhere.
 bool sweep_lean_layout(const DevTree &t, bool per_edge_records) {
     return sweep_merge_lists(t) && t.max_children <= 2 && t.height + 2 <= LEAN_MAX_LEVELS && !per_edge_records && t.pe != nullptr &&
-           !getenv("APPLES_NO_SWEEP_LEAN");
+           !(t.dbg & APPLES_DBG_NO_SWEEP_LEAN);
 }
 
 bool sweep_bits_in_lds(const DevTree &t) {
-    if (getenv("APPLES_NODE_MAP")) return false;  // test knob: exercise the big-tree layout on a small tree
-    if (getenv("APPLES_SWEEP_MERGE") && !t.scan && t.merge_ok && !getenv("APPLES_NO_SWEEP_MERGE")) return false;  // (forced merge layout)
+    if (t.dbg & APPLES_DBG_NODE_MAP) return false;  // test knob: exercise the big-tree layout on a small tree
+    if ((t.dbg & APPLES_DBG_SWEEP_MERGE) && !t.scan && t.merge_ok && !(t.dbg & APPLES_DBG_NO_SWEEP_MERGE)) return false;  // (forced merge layout)
     // (a big tree whose numbering the merged lists cannot take keeps the tagged node map)
     return (size_t)4 * t.bm_words * 12 <= 40 * 1024;
 }

@@ -16,6 +16,8 @@ METHODS = {'OLS': 0, 'FM': 1, 'BME': 2, 'BE': 3}
 CRITERIA = {'MLSE': 0, 'ME': 1, 'HYBRID': 2}
 
 F_EXACT, F_INSUFFICIENT, F_MISPLACED, F_PENDANT_INT, F_ZERO_NOT_IN_TREE, F_DEGENERATE = 1, 2, 4, 8, 16, 32
+# apples_params.debug (include/apples_hip.h APPLES_DBG_*): alternative routes to the same placements, fixed at context creation
+DBG = {'no_fuse': 1, 'sweep_scan': 2, 'node_map': 4, 'sweep_merge': 8, 'no_sweep_merge': 16, 'no_dist_gemm': 32, 'no_sweep_lean': 64}
 T_PACK, T_DIST, T_SELECT, T_SWEEP, T_TOTAL, T_DIST_LAUNCHES, T_COUNT = range(7)
 
 PLACEMENT_DTYPE = np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'), ('distal', '<f8'),
@@ -42,7 +44,7 @@ class _Alignment(C.Structure):
 class _Params(C.Structure):
     _fields_ = [('model', C.c_int32), ('method', C.c_int32), ('criterion', C.c_int32), ('negative_branch', C.c_int32),
                 ('filt_threshold', C.c_double), ('base_observation', C.c_int32), ('overlap_frac', C.c_double),
-                ('jc_lut', C.c_void_p), ('jc_lut_len', C.c_int64), ('max_batch', C.c_int64)]
+                ('jc_lut', C.c_void_p), ('jc_lut_len', C.c_int64), ('max_batch', C.c_int64), ('debug', C.c_uint32)]
 
 
 _lib = None
@@ -140,7 +142,7 @@ class Engine:
 
     def __init__(self, tree, ref_seqs=None, ref_nodes=None, clusters=None, protein=False, method='FM',
                  criterion='MLSE', negative=False, threshold=0.2, baseobs=25, overlap=0.001, device=0,
-                 use_lut=True, max_batch=0):
+                 use_lut=True, max_batch=0, debug=()):
         """tree: apples_amd.tree.Tree.  ref_seqs: uint8[N, L] (None for a distance-table context).
         ref_nodes: int32[N] tree leaf of each row (-1 = not in tree).  clusters: None (all
         singletons) or (cons_rows uint8[C, L], rep_row int32[R], member_off int32[R+1], member_row)."""
@@ -183,6 +185,7 @@ class Engine:
             self._keep.append(a)
         self.use_lut = bool(use_lut)
         self.max_batch = int(max_batch)
+        self.debug = sum(DBG[k] for k in debug) if not isinstance(debug, int) else int(debug)
         self._opts = dict(method=method, criterion=criterion, negative=negative, threshold=threshold, baseobs=baseobs,
                           overlap=overlap)
         p = self._params()
@@ -204,6 +207,7 @@ class Engine:
         p.base_observation = int(o['baseobs'])
         p.overlap_frac = float(o['overlap'])
         p.max_batch = self.max_batch
+        p.debug = self.debug
         self._lut = None
         if not self.protein and self.use_lut and 0 < self.length <= self.LUT_MAX_LEN:
             self._lut = jc69_lut(self.length, float(o['overlap']))

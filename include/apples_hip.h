@@ -77,7 +77,20 @@ typedef struct {
     const double *jc_lut;
     int64_t jc_lut_len;
     int64_t max_batch;        /* queries per device batch; 0 = choose from free memory */
+    /* Diagnostic switches (APPLES_DBG_*), read when the context is created (the device layouts depend on them) and
+     * ignored by apples_set_params: alternative routes to the same placements, for tests that cross them inside one
+     * process.  0 = the measured-best defaults.  The environment variables of the same names (APPLES_NO_FUSE ...) set
+     * the same bits for a whole process. */
+    uint32_t debug;
 } apples_params;
+
+#define APPLES_DBG_NO_FUSE       1u   /* full distance rows + general selection instead of the fused epilogue */
+#define APPLES_DBG_SWEEP_SCAN    2u   /* scan formulation of the sweep (sweep_scan.hip) */
+#define APPLES_DBG_NODE_MAP      4u   /* tagged node map of the level loop also for small trees */
+#define APPLES_DBG_SWEEP_MERGE   8u   /* merged level lists also for small trees */
+#define APPLES_DBG_NO_SWEEP_MERGE 16u /* tagged node map instead of merged level lists on big trees */
+#define APPLES_DBG_NO_DIST_GEMM  32u  /* fused distance pass through the bit-plane-fed MFMA kernel, no reference image */
+#define APPLES_DBG_NO_SWEEP_LEAN 64u  /* level loop of sweep.hip where sweep_lean.hip would run */
 
 /* One placement = the p row runquery returns, [edge_num, likelihood(error), 1, distal, pendant]
  * (apples/Algorithm.py:98-101, apples/PoolQueryWorker.py:36-37,74,88,119-125). */

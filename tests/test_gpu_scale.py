@@ -174,6 +174,30 @@ def test_fused_and_full_row_selection_paths_agree(c2):
     assert all(o == outs[0] for o in outs)
 
 
+def test_debug_switches_cross_the_routes_inside_one_process(c2):
+    """apples_params.debug (include/apples_hip.h APPLES_DBG_*) selects, per context, the alternative routes that the
+    environment knobs select per process: full-row selection, the layouts of the level-loop sweep, the lean and the scan
+    sweep, the bit-plane-fed distance pass.  One process, one engine per combination, identical bytes."""
+    d, nodes = c2
+    outs = {}
+    for dbg in ((), ('no_fuse',), ('node_map',), ('sweep_merge',), ('sweep_merge', 'no_sweep_lean'), ('no_dist_gemm',), ('sweep_scan',),
+                ('no_fuse', 'sweep_merge'), ('no_dist_gemm', 'node_map')):
+        eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS', debug=dbg)
+        info = eng.describe()
+        if 'sweep_scan' in dbg:
+            assert info['sweep'] == 'scan'
+        elif 'sweep_merge' in dbg:
+            assert info['sweep_layout'] == ('merge' if 'no_sweep_lean' in dbg else 'lean')
+        elif 'node_map' in dbg:
+            assert info['sweep_layout'] == 'map'
+        else:
+            assert info['sweep_layout'] == 'bits'
+        assert ('gemm' in info['fused_distance_pass']) == ('no_dist_gemm' not in dbg)
+        outs[dbg] = eng.place_sequences(d.query_seqs[:768]).tobytes()
+        eng.close()
+    assert len(set(outs.values())) == 1, [k for k, v in outs.items() if v != outs[()]]
+
+
 def test_device_resident_results_visible_to_torch_zero_copy():
     """bench.py hands the device-resident placement structs to torch.distributed (RCCL gather)
     through __cuda_array_interface__ without a host round trip: the view must alias the bytes that

@@ -84,3 +84,26 @@ def test_jc69_table_matches_reference_expression():
                 want = orc.jc69_from_counts(mism, valid, L, V)
                 got = lut[valid * (valid + 1) // 2 + mism]
                 assert got == want and np.signbit(got) == np.signbit(want), (mism, valid)
+
+
+def test_params_struct_layout_matches_header(tmp_path):
+    """apples_params as the C compiler lays it out (gcc on include/apples_hip.h) against the ctypes mirror,
+    the debug switches included."""
+    import subprocess
+    from apples_amd import engine
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "apples_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(apples_params), offsetof(apples_params, filt_threshold), '
+                   'offsetof(apples_params, jc_lut), offsetof(apples_params, max_batch), offsetof(apples_params, debug)); '
+                   'printf("%u %u %u %u %u %u %u\\n", APPLES_DBG_NO_FUSE, APPLES_DBG_SWEEP_SCAN, APPLES_DBG_NODE_MAP, APPLES_DBG_SWEEP_MERGE, '
+                   'APPLES_DBG_NO_SWEEP_MERGE, APPLES_DBG_NO_DIST_GEMM, APPLES_DBG_NO_SWEEP_LEAN); return 0; }\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split('\n')
+    size, o_thr, o_lut, o_mb, o_dbg = map(int, out[0].split())
+    P = engine._Params
+    assert ctypes.sizeof(P) == size
+    assert (P.filt_threshold.offset, P.jc_lut.offset, P.max_batch.offset, P.debug.offset) == (o_thr, o_lut, o_mb, o_dbg)
+    bits = list(map(int, out[1].split()))
+    assert bits == [engine.DBG[k] for k in ('no_fuse', 'sweep_scan', 'node_map', 'sweep_merge', 'no_sweep_merge', 'no_dist_gemm',
+                                            'no_sweep_lean')]
