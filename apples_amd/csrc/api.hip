@@ -473,7 +473,11 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
 
 // observed-leaf count above which a query goes straight to a workgroup-sized sweep team
 int big_threshold(const apples_ctx *ctx) {
-    static const int v = getenv("APPLES_BIG_THRESHOLD") ? atoi(getenv("APPLES_BIG_THRESHOLD")) : 4096;
+    static const int env = getenv("APPLES_BIG_THRESHOLD") ? atoi(getenv("APPLES_BIG_THRESHOLD")) : 0;
+    // the lean sweep's wavefront-sized teams are the efficient ones and take their queue largest first, finely graded
+    // (C3 sweep 15.8 / 15.8 / 16.7 / 18.7 ms at 4 096 / 8 192 / 12 288 / 16 384, the clustered route's 38.4 / 35.5 / 35.1 / 36.0);
+    // the level loop's cut was measured at 4 096
+    const int v = env > 0 ? env : (sweep_lean_layout(ctx->tree, ctx->params.criterion == APPLES_HYBRID) ? LEAN_BIG_THRESHOLD : 4096);
     // scan sweep: a wavefront-sized team keeps the per-leaf state of at most SCAN_LDS_LEAVES_SMALL leaves in LDS
     return ctx->tree.scan ? std::min(v, SCAN_LDS_LEAVES_SMALL) : v;
 }
@@ -648,10 +652,12 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         }
         if (dev_alloc(ctx, &w.route_list, 3 * batch)) return 1;
         if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
-        if (dev_alloc(ctx, &w.cls_list, 4 * batch)) return 1;
+        if (dev_alloc(ctx, &w.cls_list, 8 * batch)) return 1;  // four size classes, then the largest class once more in four
         // one block for every per-batch counter, cleared by one memset: [0..3] size-class counts,
-        // [4..6] the sweep launches' work cursors, [8] routed, [9] top-up list, [10] overflow
-        if (dev_alloc(ctx, &w.cls_count, 16)) return 1;
+        // [4..6] the sweep launches' work cursors, [7] the lean sweep's pool cursor, [8] routed, [9] top-up list, [10] overflow,
+        // [11] the lean top-down kernel's cursor, [12..14] routed queries by size class, [16..19] the largest size class of the
+        // small teams split four ways (sweep_lean.hip takes the longest jobs first)
+        if (dev_alloc(ctx, &w.cls_count, 32)) return 1;
         w.route_count = w.cls_count + 8;
         w.slow_count = w.cls_count + 9;
         w.overflow_count = w.cls_count + 10;
@@ -1032,7 +1038,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         if (pipelined && i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_back[set], 0));  // set free again
         hipEvent_t *e = &ev[(size_t)i * 6];
         if (feed) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[i], 0));  // chunk i is on the device
-        HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 16 * sizeof(int32_t), front));  // every counter of the batch
+        HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), front));  // every counter of the batch
         if (cfused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
             HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (a.reps_pad / 64) * sizeof(int32_t), front));
@@ -1595,7 +1601,7 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.big_threshold = big_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
     s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
-    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 16 * sizeof(int32_t), ctx->stream));  // every counter of the batch
+    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), ctx->stream));  // every counter of the batch
     pt.flush();
     pt.begin(APPLES_T_SELECT);
     if (launch_select(ctx, s, nq)) return 1;
@@ -1734,7 +1740,7 @@ static int sweep_edges_scan(apples_ctx *ctx, const int32_t *obs_node, const doub
     HIP_TRY(ctx, hipMemcpy(w.obs_node, s_node.data(), (size_t)n_obs * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.obs_dist, s_dist.data(), (size_t)n_obs * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.n_obs, &n_obs, 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 16 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), ctx->stream));
     ScanArgs sa = scan_args(ctx, w.big, d_out, true, true);
     sa.overflow_list = nullptr; sa.overflow_count = nullptr;
     if (launch_scan(ctx, sa, 1, 1, 256, ctx->stream)) { dev_free(d_out); return 1; }
@@ -1795,7 +1801,7 @@ int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *o
     HIP_TRY(ctx, hipMemcpy(w.obs_dist, s_dist.data(), (size_t)n_obs * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.cnt_gt, cg.data(), cg.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.n_obs, &n_obs, 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 8 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), ctx->stream));
     if (launch_sweep(ctx, sweep_args(ctx, w.big, d_out, true), 1, 1, 256)) { dev_free(d_out); return 1; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     apples_placement res;

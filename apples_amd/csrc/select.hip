@@ -118,6 +118,10 @@ __device__ __forceinline__ void enlist(const SelectArgs &a, int64_t q, int ne) {
     if (!a.cls_list) return;
     const int k = ne > 1024 ? 0 : (ne > 512 ? 1 : (ne > 256 ? 2 : 3));
     a.cls_list[k * a.cls_stride + atomicAdd(&a.cls_count[k], 1)] = (int32_t)q;
+    if (k == 0) {  // the largest class once more, four ways (lists 4..7, counts at [16..19]): sweep_lean.hip starts the longest jobs first
+        const int u = ne > 8192 ? 0 : (ne > 4096 ? 1 : (ne > 2048 ? 2 : 3));
+        a.cls_list[(4 + u) * a.cls_stride + atomicAdd(&a.cls_count[16 + u], 1)] = (int32_t)q;
+    }
 }
 
 #define INF_D __longlong_as_double(0x7ff0000000000000LL)

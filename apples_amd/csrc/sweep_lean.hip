@@ -124,20 +124,22 @@ __device__ __forceinline__ double pe_len(const int4 &r) { return __hiloint2doubl
 
 // One level of the lists, general form (any sizes): merge by node id the parents of this level's internal nodes
 // (K[base .. base + nA), sorted) and of its observed leaves (o_node[lo .. lo + nB), sorted): the next level's list, sorted
-// (sweep.hip:merge_parents -- the same merge-path step of 64 keys through two LDS windows; a binary tree's runs have at
-// most two keys and a step whose last key opens a run leaves it to the next step).  The entry of a parent names its
-// valid children and carries their node ids, edge lengths and (observed leaves) distances.  Returns the number of
-// entries written from next_base on.
+// (sweep.hip:merge_parents -- the same merge-path step of 64 keys through two LDS windows).  The entry of a parent names
+// its valid children and carries their node ids, edge lengths and (observed leaves) distances.  A binary tree's runs
+// have at most two keys; a run cut by the end of a step is completed by the next step's first key, which patches the
+// entry -- so how far a step advances in the two lists is known right after its search, and the next step's windows are
+// requested before this step's gather is waited for: one memory round trip per 64 keys, not two.
+// Returns the number of entries written from next_base on.
 __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, const int32_t *__restrict__ o_node,
                                           const double *__restrict__ o_dist, int lo, int nB, int next_base,
                                           const int4 *__restrict__ pe, int *mk_a, int *mk_b, int lane) {
-    int out = 0, ia = 0, ib = 0;
+    int out = 0, ia = 0, ib = 0, carry = -2;
     const unsigned long long below = (1ull << lane) - 1ull;
+    int wk_a = lane < nA ? t.K[base + lane] : 0x7fffffff, wk_b = lane < nB ? o_node[lo + lane] : 0x7fffffff;
     while (ia < nA || ib < nB) {
-        const int rem = (nA - ia) + (nB - ib);
         const int wa = min(nA - ia, WAVE), wb = min(nB - ib, WAVE);
-        mk_a[lane] = lane < wa ? t.K[base + ia + lane] : 0x7fffffff;
-        mk_b[lane] = lane < wb ? o_node[lo + ib + lane] : 0x7fffffff;
+        mk_a[lane] = wk_a;
+        mk_b[lane] = wk_b;
         __builtin_amdgcn_wave_barrier();
         const int tot = min(wa + wb, WAVE);
         const bool active = lane < tot;
@@ -151,6 +153,10 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
         const bool from_a = ka < kb;
         const int key = from_a ? ka : kb;
         const int desc = from_a ? base + ia + i + 1 : -(lo + ib + j) - 2;
+        const int ca = __popcll(__ballot(active && from_a));
+        const int nia = ia + ca, nib = ib + tot - ca;
+        wk_a = nia + lane < nA ? t.K[base + nia + lane] : 0x7fffffff;  // the next step's windows
+        wk_b = nib + lane < nB ? o_node[lo + nib + lane] : 0x7fffffff;
         int par = -3;
         double e = 0, dist = 0;
         if (active) {
@@ -165,26 +171,29 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
             }
         }
         const int prev = __shfl_up(par, 1, WAVE);
-        const bool first = active && (lane == 0 || par != prev);
-        const int last_first = __shfl(first ? 1 : 0, tot - 1, WAVE);
-        const int use = (rem > tot && last_first && tot > 1) ? tot - 1 : tot;
+        const bool first = active && par != (lane == 0 ? carry : prev);
         const int next_desc = __shfl_down(desc, 1, WAVE), next_key = __shfl_down(key, 1, WAVE);
         const int next_first = __shfl_down(first ? 1 : 0, 1, WAVE);
         const double next_e = shfl_down_f64(e, 1), next_dist = shfl_down_f64(dist, 1);
-        const bool mine = first && lane < use;
-        const bool two = lane + 1 < use && !next_first;
-        const unsigned long long fm = __ballot(mine);
-        if (mine) {
+        const bool two = lane + 1 < tot && !next_first;
+        const unsigned long long fm = __ballot(first);
+        if (first) {
             const int at = next_base + out + __popcll(fm & below);
             t.K[at] = par;
             t.D[at] = make_int2(desc, two ? next_desc : 0);
             t.N[at] = make_int2(key, two ? next_key : -1);
             t.E[at] = make_double2(e, two ? next_e : 0.0);
             t.DD[at] = make_double2(dist, two ? next_dist : 0.0);
+        } else if (lane == 0 && active) {  // the second child of the previous step's last entry
+            const int at = next_base + out - 1;
+            reinterpret_cast<int *>(t.D + at)[1] = desc;
+            reinterpret_cast<int *>(t.N + at)[1] = key;
+            reinterpret_cast<double *>(t.E + at)[1] = e;
+            reinterpret_cast<double *>(t.DD + at)[1] = dist;
         }
-        const int ca = __popcll(__ballot(lane < use && from_a));
-        ia += ca;
-        ib += use - ca;
+        carry = __shfl(par, tot - 1, WAVE);
+        ia = nia;
+        ib = nib;
         out += __popcll(fm);
         __builtin_amdgcn_wave_barrier();
     }
@@ -228,6 +237,29 @@ __device__ __forceinline__ void node_S(const int2 d, const double2 e, const doub
         lift<M>(S1, e.y, u);
 #pragma unroll
         for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
+    }
+}
+
+// S tuples of the entries [lo, hi), `stride` lanes apart (a level of more than one chunk): the entries of the next chunk
+// are requested before this chunk's children are waited for, so a chunk costs one memory round trip, not two
+template <int M>
+__device__ __forceinline__ void lean_S_chunks(const LeanTeam &t, int lo, int hi, int first, int stride,
+                                              const double2 (*stage)[WAVE], bool staged, int kid_base) {
+    int idx = lo + first;
+    int2 d = make_int2(0, 0);
+    double2 e = make_double2(0, 0), dd = make_double2(0, 0);
+    if (idx < hi) { d = t.D[idx]; e = t.E[idx]; dd = t.DD[idx]; }
+    while (idx < hi) {
+        const int nidx = idx + stride;
+        int2 d2 = make_int2(0, 0);
+        double2 e2 = make_double2(0, 0), dd2 = make_double2(0, 0);
+        if (nidx < hi) { d2 = t.D[nidx]; e2 = t.E[nidx]; dd2 = t.DD[nidx]; }
+        double r[6];
+        node_S<M>(d, e, dd, t, stage, staged, kid_base, r);
+        t.T0[idx] = make_double2(r[0], r[1]);
+        t.T1[idx] = make_double2(r[2], r[3]);
+        t.T2[idx] = make_double2(r[4], r[5]);
+        idx = nidx; d = d2; e = e2; dd = dd2;
     }
 }
 
@@ -297,12 +329,11 @@ __device__ __forceinline__ void lean_own_plift(const LeanTeam &t, int idx, const
 // Top-down step of one internal node, both children in turn (the two swap roles in between): a rolled loop keeps one
 // 2x2 solve's worth of temporaries live, which is what decides how many wavefronts a SIMD holds.
 template <int M>
-__device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, bool is_lca, int negative, int criterion,
+__device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, const int2 d, const int2 nd, const double2 e, const double2 dd,
+                                             bool is_lca, int negative, int criterion,
                                              const double *lds_pow, const double2 (*hand_in)[WAVE], int in_pos,
                                              double2 (*hand_out)[WAVE], int out_base, LeanBest &best) {
     constexpr bool BME = (M == APPLES_BME);
-    const int2 d = t.D[idx], nd = t.N[idx];
-    const double2 e = t.E[idx], dd = t.DD[idx];
     const int nk = d.y != 0 ? 2 : 1;
     // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
     const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
@@ -321,6 +352,37 @@ __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, bool is
         { const double w = ek; ek = es; es = w; }
         { const int w = kd; kd = ks; ks = w; }
         { const int w = kn; kn = ksn; ksn = w; }
+    }
+}
+
+// Top-down steps of the entries [lo, hi), `stride` lanes apart.  AHEAD: the next chunk's entries requested ahead (as
+// lean_S_chunks) -- for the workgroup-sized teams, which wait on memory; the wavefront-sized teams' top-down kernel is
+// bound by instruction issue at three wavefronts per SIMD, and the registers of the look-ahead (spilled there) cost it
+// more than the round trip (measured: 6.9 against 5.0 ms per C3 pass)
+template <int M, bool AHEAD>
+__device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi, int first, int stride, int VI, int negative,
+                                               int criterion, const double *lds_pow, const double2 (*hand_in)[WAVE],
+                                               double2 (*hand_out)[WAVE], int out_base, LeanBest &best) {
+    int idx = lo + first;
+    int2 d = make_int2(0, 0), nd = make_int2(0, 0);
+    double2 e = make_double2(0, 0), dd = make_double2(0, 0);
+    if (!AHEAD) {
+        for (; idx < hi; idx += stride) {
+            lean_td_node<M>(t, idx, t.D[idx], t.N[idx], t.E[idx], t.DD[idx], idx == VI, negative, criterion, lds_pow, hand_in, idx - lo,
+                            hand_out, out_base, best);
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    if (idx < hi) { d = t.D[idx]; nd = t.N[idx]; e = t.E[idx]; dd = t.DD[idx]; }
+    while (idx < hi) {
+        const int nidx = idx + stride;
+        int2 d2 = make_int2(0, 0), nd2 = make_int2(0, 0);
+        double2 e2 = make_double2(0, 0), dd2 = make_double2(0, 0);
+        if (nidx < hi) { d2 = t.D[nidx]; nd2 = t.N[nidx]; e2 = t.E[nidx]; dd2 = t.DD[nidx]; }
+        lean_td_node<M>(t, idx, d, nd, e, dd, idx == VI, negative, criterion, lds_pow, hand_in, idx - lo, hand_out, out_base, best);
+        __builtin_amdgcn_wave_barrier();
+        idx = nidx; d = d2; nd = nd2; e = e2; dd = dd2;
     }
 }
 
@@ -379,22 +441,28 @@ __device__ __forceinline__ void lean_write_placement(apples_placement *out, int6
 }
 
 
-// The size-class queues of a batch (written by the selection kernels, largest class first): entry w -> query
+// The size-class queues of a batch (written by the selection kernels): entry w -> query, largest first: the four parts
+// of the largest class (lists 4..7, counts at cls_count[16..19]), then classes 1..3
 struct LeanQueue {
-    int c0, c1, c2, c3;
+    int c[7];
     int64_t n_work;
 };
 __device__ __forceinline__ LeanQueue lean_queue(const SweepArgs &a) {
     LeanQueue qu;
-    qu.c0 = a.cls_count[0]; qu.c1 = a.cls_count[1]; qu.c2 = a.cls_count[2]; qu.c3 = a.cls_count[3];
-    qu.n_work = (int64_t)qu.c0 + qu.c1 + qu.c2 + qu.c3;
+    qu.c[0] = a.cls_count[16]; qu.c[1] = a.cls_count[17]; qu.c[2] = a.cls_count[18]; qu.c[3] = a.cls_count[19];
+    qu.c[4] = a.cls_count[1]; qu.c[5] = a.cls_count[2]; qu.c[6] = a.cls_count[3];
+    qu.n_work = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) qu.n_work += qu.c[k];
     return qu;
 }
 __device__ __forceinline__ int64_t lean_queue_at(const SweepArgs &a, const LeanQueue &qu, int64_t w) {
-    if (w < qu.c0) return a.cls_list[w];
-    if (w < qu.c0 + qu.c1) return a.cls_list[a.cls_stride + (w - qu.c0)];
-    if (w < (int64_t)qu.c0 + qu.c1 + qu.c2) return a.cls_list[2 * a.cls_stride + (w - qu.c0 - qu.c1)];
-    return a.cls_list[3 * a.cls_stride + (w - qu.c0 - qu.c1 - qu.c2)];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        if (w < qu.c[k]) return a.cls_list[(k < 4 ? 4 + k : k - 3) * a.cls_stride + w];
+        w -= qu.c[k];
+    }
+    return 0;
 }
 
 // entries a query may use in the pool: the internal nodes of its subtree plus the LCA.  Observed sets average 1.44
@@ -504,13 +572,7 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh) {
                     stage[2][lane] = make_double2(r[4], r[5]);
                 }
             } else if (n_par > WAVE) {
-                for (int idx = base + lane; idx < next_base; idx += WAVE) {
-                    double r[6];
-                    node_S<M>(t.D[idx], t.E[idx], t.DD[idx], t, stage, prev_staged, kid_base, r);
-                    t.T0[idx] = make_double2(r[0], r[1]);
-                    t.T1[idx] = make_double2(r[2], r[3]);
-                    t.T2[idx] = make_double2(r[4], r[5]);
-                }
+                lean_S_chunks<M>(t, base, next_base, lane, WAVE, stage, prev_staged, kid_base);
             }
             // ---- the next level's list
             int merged;
@@ -638,11 +700,8 @@ __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
                 lean_td_pairs<M>(t, g0, ng, VI, lane, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
                                  hand_out ? stage : nullptr, k0, best);
             } else {
-                for (int idx = g0 + lane; idx < g1; idx += WAVE) {
-                    lean_td_node<M>(t, idx, idx == VI, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr, idx - g0,
-                                    hand_out ? stage : nullptr, k0, best);
-                    __builtin_amdgcn_wave_barrier();
-                }
+                lean_td_chunks<M, false>(t, g0, g1, lane, WAVE, VI, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
+                                  hand_out ? stage : nullptr, k0, best);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             hand_in = hand_out;
@@ -690,13 +749,13 @@ __device__ __forceinline__ int lean_merge_wg(const LeanTeam &t, int base, int nA
                                              const double *__restrict__ o_dist, int lo, int nB, int next_base,
                                              const int4 *__restrict__ pe, LeanBigShared<TEAM> &sh) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    int out = 0, ia = 0, ib = 0;
+    int out = 0, ia = 0, ib = 0, carry = -2;
     const unsigned long long below = (1ull << lane) - 1ull;
+    int wk_a = tid < nA ? t.K[base + tid] : 0x7fffffff, wk_b = tid < nB ? o_node[lo + tid] : 0x7fffffff;
     while (ia < nA || ib < nB) {
-        const int rem = (nA - ia) + (nB - ib);
         const int wa = min(nA - ia, TEAM), wb = min(nB - ib, TEAM);
-        sh.ka[tid] = tid < wa ? t.K[base + ia + tid] : 0x7fffffff;
-        sh.kb[tid] = tid < wb ? o_node[lo + ib + tid] : 0x7fffffff;
+        sh.ka[tid] = wk_a;
+        sh.kb[tid] = wk_b;
         __syncthreads();
         const int tot = min(wa + wb, TEAM);
         const bool active = tid < tot;
@@ -710,6 +769,15 @@ __device__ __forceinline__ int lean_merge_wg(const LeanTeam &t, int base, int nA
         const bool from_a = ka < kb;
         const int key = from_a ? ka : kb;
         const int desc = from_a ? base + ia + i + 1 : -(lo + ib + j) - 2;
+        const unsigned long long am = __ballot(active && from_a);
+        if (lane == 0) sh.mcnt[1][wave] = __popcll(am);
+        __syncthreads();  // (the windows are read: the next step may overwrite them after its own first barrier)
+        int ca = 0;
+#pragma unroll
+        for (int w = 0; w < TEAM / WAVE; ++w) ca += sh.mcnt[1][w];
+        const int nia = ia + ca, nib = ib + tot - ca;
+        wk_a = nia + tid < nA ? t.K[base + nia + tid] : 0x7fffffff;  // the next step's windows, before this step's gather is waited for
+        wk_b = nib + tid < nB ? o_node[lo + nib + tid] : 0x7fffffff;
         int par = -3;
         double e = 0, dist = 0;
         if (active) {
@@ -725,33 +793,38 @@ __device__ __forceinline__ int lean_merge_wg(const LeanTeam &t, int base, int nA
         }
         sh.m_par[tid] = par; sh.m_desc[tid] = desc; sh.m_key[tid] = key; sh.m_e[tid] = e; sh.m_dist[tid] = dist;
         __syncthreads();
-        const bool first = active && (tid == 0 || par != sh.m_par[tid - 1]);
-        const bool last_first = tot > 1 && sh.m_par[tot - 1] != sh.m_par[tot - 2];
-        const int use = (rem > tot && last_first) ? tot - 1 : tot;
-        const bool two = tid + 1 < use && sh.m_par[tid + 1] == par;
-        const bool mine = first && tid < use;
-        const unsigned long long fm = __ballot(mine), am = __ballot(tid < use && from_a);
-        if (lane == 0) { sh.mcnt[0][wave] = __popcll(fm); sh.mcnt[1][wave] = __popcll(am); }
+        const bool first = active && par != (tid == 0 ? carry : sh.m_par[tid - 1]);
+        const bool two = tid + 1 < tot && sh.m_par[tid + 1] == par;
+        const unsigned long long fm = __ballot(first);
+        if (lane == 0) sh.mcnt[0][wave] = __popcll(fm);
+        const int last_par = sh.m_par[tot - 1];
         __syncthreads();
-        int before = 0, total = 0, ca = 0;
+        int before = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < TEAM / WAVE; ++w) {
             if (w < wave) before += sh.mcnt[0][w];
             total += sh.mcnt[0][w];
-            ca += sh.mcnt[1][w];
         }
-        if (mine) {
+        if (first) {
             const int at = next_base + out + before + __popcll(fm & below);
             t.K[at] = par;
             t.D[at] = make_int2(desc, two ? sh.m_desc[tid + 1] : 0);
             t.N[at] = make_int2(key, two ? sh.m_key[tid + 1] : -1);
             t.E[at] = make_double2(e, two ? sh.m_e[tid + 1] : 0.0);
             t.DD[at] = make_double2(dist, two ? sh.m_dist[tid + 1] : 0.0);
+        } else if (tid == 0 && active) {  // the second child of the previous step's last entry
+            const int at = next_base + out - 1;
+            reinterpret_cast<int *>(t.D + at)[1] = desc;
+            reinterpret_cast<int *>(t.N + at)[1] = key;
+            reinterpret_cast<double *>(t.E + at)[1] = e;
+            reinterpret_cast<double *>(t.DD + at)[1] = dist;
         }
-        ia += ca;
-        ib += use - ca;
+        carry = last_par;
+        ia = nia;
+        ib = nib;
         out += total;
-        __syncthreads();
+        // (no barrier here: the next step writes the windows, which everybody has finished reading two barriers ago, and
+        // reaches m_par / mcnt[0] only after its own barriers)
     }
     return out;
 }
@@ -816,13 +889,7 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
             if (n_par + n_leaf == 1 && hi == n) break;  // the LCA (Subtree.py:36-43), entry `base`
             if (tid == 0) grp_off[G] = base;
             const int next_base = base + n_par;
-            for (int idx = base + tid; idx < next_base; idx += TEAM) {  // S tuples of this level (the level below's are complete)
-                double r[6];
-                node_S<M>(t.D[idx], t.E[idx], t.DD[idx], t, nullptr, false, 0, r);
-                t.T0[idx] = make_double2(r[0], r[1]);
-                t.T1[idx] = make_double2(r[2], r[3]);
-                t.T2[idx] = make_double2(r[4], r[5]);
-            }
+            lean_S_chunks<M>(t, base, next_base, tid, TEAM, nullptr, false, 0);  // S tuples of this level (the level below's are complete)
             const int merged = lean_merge_wg<TEAM>(t, base, n_par, o_node, o_dist, lo, n_leaf, next_base, pe, sh);
             __syncthreads();
             base = next_base;
@@ -838,7 +905,7 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
         lean_best_init(best);
         for (int g = G; g >= 1; --g) {
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
-            for (int idx = g0 + tid; idx < g1; idx += TEAM) lean_td_node<M>(t, idx, idx == VI, a.negative, a.criterion, lds_pow, nullptr, 0, nullptr, 0, best);
+            lean_td_chunks<M, true>(t, g0, g1, tid, TEAM, VI, a.negative, a.criterion, lds_pow, nullptr, nullptr, 0, best);
             __syncthreads();
         }
         const int my_best = best.v;
