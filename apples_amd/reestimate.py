@@ -249,6 +249,27 @@ def _read_rows(ref_fp, labels):
     return np.stack(rows)
 
 
+def unroot_like_fasttree(root):
+    """A two-child root as FastTree 2.1.11 prints it after ``-intree``: unrooted at a trifurcation.  The root's first child
+    is dissolved (its children become the root's, after the second child, which keeps the one length of the root
+    edge); where the first child is a leaf, the second is dissolved instead.  Convention read off the binary the
+    reference bundles (apples/tools/FastTree-linux) on seven small trees: tests/test_reestimate.py holds them.
+    `root.children[0].length` carries the root edge's one estimate on entry (native_lengths)."""
+    x, y = root.children
+    m_len = x.length
+    if x.children:
+        keep, gone = y, x
+        root.children = [y] + list(x.children)
+    else:
+        keep, gone = x, y
+        root.children = [x] + list(y.children)
+    for c in gone.children:
+        c.parent = root
+    keep.length = m_len
+    gone.children = []
+    gone.parent = None
+
+
 def native_lengths(root, ref_fp, protein, device=0):
     """Sets every branch of `root` (binary below the root, two or three children at it) to this build's
     minimum-evolution estimate, rounded to FastTree's five printed decimals.  A two-child root: the one estimate
@@ -302,11 +323,15 @@ def reestimate_backbone(options):
         if len(root.children) == 2:
             in_len = [c.length for c in root.children]
         native_lengths(root, options.ref_fp, options.protein_seqs, getattr(options, 'device', 0))
-        if len(root.children) == 2:  # one estimate for the root edge, split as the input had it (:103-110)
+        if len(root.children) == 2 and restore:  # one estimate for the root edge, split as the input had it (:103-110)
             m_len = root.children[0].length
-            share = in_len[0] / (in_len[0] + in_len[1]) if restore and in_len[0] + in_len[1] > 0 else 0.5
+            share = in_len[0] / (in_len[0] + in_len[1]) if in_len[0] + in_len[1] > 0 else 0.5
             root.children[0].length = m_len * share
             root.children[1].length = m_len * (1 - share)
+        elif len(root.children) == 2:
+            # nothing to restore (a rooted input without all its lengths, or a root polytomy resolved to two children):
+            # the reference places on FastTree's own answer, which is unrooted (:91 is skipped)
+            unroot_like_fasttree(root)
         text = to_newick(root)
         logging.info('Backbone branch lengths estimated on the GPU (no FastTree executable in use).')
     else:

@@ -226,3 +226,58 @@ def test_native_route_of_the_wrapper(tmp_path, monkeypatch):
     after = R.from_newick(open(o.tree_fp).read())
     assert len(after.children) == 3 and sorted(x.label for x in after.leaves()) == list('abcdef')
     assert all(len(v.children) in (0, 2) for c in after.children for v in [c])
+
+
+# what the bundled binary (apples/tools/FastTree-linux -nosupport -nome -noml -intree ... -nt) printed for two-child roots
+# (topology and child order only; recorded in the build container)
+FASTTREE_UNROOTING = [
+    ('((A,B),(C,(D,E)));', '((C,(D,E)),A,B);'),
+    ('((C,(D,E)),(A,B));', '((A,B),C,(D,E));'),
+    ('(A,(B,(C,(D,E))));', '(A,B,(C,(D,E)));'),
+    ('((B,(C,(D,E))),A);', '(A,B,(C,(D,E)));'),
+    ('(((A,B),F),(C,(D,E)));', '((C,(D,E)),(A,B),F);'),
+    ('((C,(D,E)),((A,B),F));', '(((A,B),F),C,(D,E));'),
+]
+
+
+@pytest.mark.parametrize('rooted,unrooted', FASTTREE_UNROOTING)
+def test_unrooting_follows_the_bundled_fasttree(rooted, unrooted):
+    root = R.from_newick(rooted)
+    root.children[0].length = 0.25  # the one estimate of the root edge (native_lengths puts it on the first child)
+    root.children[1].length = 0.0
+    R.unroot_like_fasttree(root)
+    import re
+    assert re.sub(r':[0-9.e-]+', '', R.to_newick(root)) == unrooted
+    kept = [c for c in root.children if c.length == 0.25]
+    assert len(root.children) == 3 and len(kept) == 1  # the surviving side carries the root edge's length
+
+
+def test_native_route_without_all_lengths_prints_fasttrees_unrooted_answer(tmp_path, monkeypatch):
+    """A rooted input that lacks a branch length: the reference does not re-root (reestimateBackbone.py:49,91) and
+    places on FastTree's unrooted answer; so does the native route (node count and edge numbering follow)."""
+    from apples_amd import engine
+    from oracle import fasttree_me
+
+    def on_cpu(parent, children, leaf_row, rows, protein, device=0, site_chunk=0):
+        return fasttree_me.branch_lengths(len(parent), parent, children, [rows[r] if r >= 0 else None for r in leaf_row], protein)
+
+    monkeypatch.setattr(engine, 'backbone_lengths', on_cpu)
+    monkeypatch.setenv('PATH', str(tmp_path / 'nowhere'))
+    monkeypatch.delenv('APPLES_FASTTREE', raising=False)
+    tree_fp, ref_fp = tmp_path / 'bb.nwk', tmp_path / 'ref.fa'
+    open(tree_fp, 'w').write('((A:0.1,B:0.1):0.1,(C:0.1,(D,E:0.1):0.1):0.1);\n')  # D has no length
+    with open(ref_fp, 'w') as f:
+        for n, s in zip('ABCDE', ('ACGTACGTACGTACGTAAAA', 'ACGTACGTACGAACGTAAAT', 'ACGTTCGTACGAACGTATAT', 'ACGATCGTACGAACCTATAT',
+                                  'ACGATCGAACGAACCTATTT')):
+            f.write('>%s\n%s\n' % (n, s))
+    o = _options(str(tree_fp), str(ref_fp))
+    assert R.reestimate_backbone(o) is True
+    after = R.from_newick(open(o.tree_fp).read())
+    import re
+    assert re.sub(r':-?[0-9.e-]+', '', R.to_newick(after)) == '((C,(D,E)),A,B);'
+    # lengths: the bundled binary printed ((C:-0.02420,(D:-0.01798,E:0.12531):0.14153):0.14153,A:0.12531,B:-0.01798);
+    want = {'A': 0.12531, 'B': -0.01798, 'C': -0.02420, 'D': -0.01798, 'E': 0.12531}
+    for leaf in after.leaves():
+        assert leaf.length == pytest.approx(want[leaf.label], abs=6e-6)
+    assert after.children[0].length == pytest.approx(0.14153, abs=6e-6)
+    R.cleanup(o)
