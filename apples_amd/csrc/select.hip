@@ -376,7 +376,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     int base = 0, n_total = 0;
     int z_i = 0x7fffffff, z_node = -2;
     // one survivor: entry `off` of segment `seg` -> (slot, distance), own row dropped, first zero noted
-    auto take = [&](int64_t seg, int off, int &node, double &d) -> int {
+    auto take = [&](int64_t seg, int off, int &node, double &d, int &lv) -> int {
         const int64_t src = seg * 64 + off;
         int slot = sslot[src];
         if (a.seg_lut) {  // the matrix-core distance pass leaves position | valid | mism; same table, same bits
@@ -390,17 +390,35 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
         if (slot == self) return 0;
         ++n_total;
         node = a.slot_node[slot];
+        lv = a.slot_level[slot];  // (beside the node: the per-level offsets below need no second pass over the list)
         if (d == 0) {
             const int ri = a.slot_rep[slot];
             if (ri < z_i) { z_i = ri; z_node = node; }
         }
         return node >= 0;
     };
+    // ordered emission of up to 256 entries (one per thread) + the per-level offsets they imply (the sweep's cnt_gt:
+    // cg[l + 1] = entries with a level above l = position of the first entry at level l or below; entries come in
+    // level order, so an entry whose predecessor sits at a higher level writes the offsets in between)
+    __shared__ int sh_lv[APPLES_TPB + 1];
+    int last_lv = a.height + 1;  // level of the entry before this round's first (block-uniform)
+    auto put = [&](int emit, int node, double d, int lv) {
+        int tot;
+        const int r = block_excl_scan(emit, sh_j, &tot);
+        if (emit) { o_node[base + r] = node; o_dist[base + r] = d; sh_lv[r + 1] = lv; }
+        if (tid == 0) sh_lv[0] = last_lv;
+        __syncthreads();
+        if (emit && cg)
+            for (int l = lv; l < sh_lv[r]; ++l) cg[l + 1] = base + r;
+        if (tot > 0) last_lv = sh_lv[tot];
+        base += tot;
+        __syncthreads();
+    };
     if (flat) {
         __syncthreads();
         for (int e0 = 0; e0 < total; e0 += APPLES_TPB) {
             const int e = e0 + tid;
-            int emit = 0, node = -1;
+            int emit = 0, node = -1, lv = 0;
             double d = 0;
             if (e < total) {
                 int64_t lo = 0, hi = n_seg + 1;  // last segment whose prefix <= e (empty segments share a prefix: the last one wins, and holds e)
@@ -408,12 +426,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
                     const int64_t mid = (lo + hi) >> 1;
                     if (dyn_pref[mid] <= e) lo = mid; else hi = mid;
                 }
-                emit = take(lo, e - dyn_pref[lo], node, d);
+                emit = take(lo, e - dyn_pref[lo], node, d, lv);
             }
-            int tot;
-            const int pos = base + block_excl_scan(emit, sh_j, &tot);
-            if (emit) { o_node[pos] = node; o_dist[pos] = d; }
-            base += tot;
+            put(emit, node, d, lv);
         }
     } else {
     for (int64_t s0 = 0; s0 < n_seg; s0 += APPLES_TPB) {
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
         // flat loop over this chunk's entries, in order
         for (int e0 = 0; e0 < chunk_total; e0 += APPLES_TPB) {
             const int e = e0 + tid;
-            int emit = 0, node = -1;
+            int emit = 0, node = -1, lv = 0;
             double d = 0;
             if (e < chunk_total) {
                 int lo = 0, hi = APPLES_TPB;  // last segment whose prefix <= e
@@ -435,12 +450,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
                     int mid = (lo + hi) >> 1;
                     if (sh_pref[mid] <= e) lo = mid; else hi = mid;
                 }
-                emit = take(s0 + lo, e - sh_pref[lo], node, d);
+                emit = take(s0 + lo, e - sh_pref[lo], node, d, lv);
             }
-            int tot;
-            const int pos = base + block_excl_scan(emit, sh_j, &tot);
-            if (emit) { o_node[pos] = node; o_dist[pos] = d; }
-            base += tot;
+            put(emit, node, d, lv);
         }
         __syncthreads();
     }
@@ -454,12 +466,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     if (z_i == zi && zi != 0x7fffffff) sh_znode = z_node;
     __syncthreads();
     const int n_emit = base;
-    // per-level offsets into the level-sorted list (the sweep's cnt_gt)
-    for (int i = tid; cg && i <= n_emit; i += APPLES_TPB) {
-        const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
-        const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
-        for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
-    }
+    // the offsets below the last entry's level (everything sits above those levels)
+    for (int l = -1 + tid; cg && l < last_lv; l += APPLES_TPB) cg[l + 1] = n_emit;
     if (tid == 0) {
         apples_placement p;
         p.edge = 0; p.flags = 0; p.error = 0.0; p.distal = 0.0; p.pendant = 0.0; p.n_obs = n_total; p.n_valid = 0;
@@ -768,6 +776,7 @@ __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(Sele
     // A row's node is needed while streaming only to skip table columns that are not tree leaves; if
     // there are none (or this is not a table) it is looked up for the entries that are kept
     const bool early_node = table && !a.cols_all_in_tree;
+    const bool late_node = a.cols_all_in_tree != 0;  // (table or alignment: no slot without a tree leaf)
     constexpr int SU1 = 8, SU2 = SU2_LOADS;  // independent load instructions per lane in flight (8-byte / 16-byte loads)
     // quarters aligned to 64 slots
     const int64_t per = ((nm + 4 * WAVE - 1) / (4 * WAVE)) * WAVE;
@@ -812,11 +821,14 @@ __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(Sele
                             bool in_dict = in_thr;
                             if (!in_thr) in_dict = key_le(d, a.slot_rep[s], cut_d, cut_i);  // (bound > thr only with a cut)
                             if (in_dict && (int)s != self) {
-                                if (!early_node) node = a.slot_node[s];
+                                // (every slot a tree leaf: the slot itself is written and turned into its node in the row's
+                                // tail, so this loop waits for no load)
+                                if (late_node) node = (int)s;
+                                else if (!early_node) node = a.slot_node[s];
                                 ++n_total;
                                 if (d == 0) {
                                     const int ri = a.slot_rep[s];
-                                    if (ri < z_i) { z_i = ri; z_node = node; z_d = 0; }
+                                    if (ri < z_i) { z_i = ri; z_node = late_node ? a.slot_node[s] : node; z_d = 0; }
                                 }
                                 emit = node >= 0;
                             }
@@ -986,11 +998,22 @@ __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(Sele
         __syncthreads();
         if (z_i == zi && zi != 0x7fffffff) sh_znode = z_node;
         __syncthreads();
-        // per-level offsets into the level-sorted list (the sweep's cnt_gt)
+        // per-level offsets into the level-sorted list (the sweep's cnt_gt); with the slots written in place of the nodes,
+        // level and node of an entry are two independent lookups by slot (one round trip per 256 entries, not two)
+        if (late_node) {
+            for (int i = tid; cg && i <= n_emit; i += APPLES_TPB) {
+                const int lv = (i < n_emit) ? a.slot_level[o_node[i]] : -1;
+                const int lprev = (i == 0) ? a.height + 1 : a.slot_level[o_node[i - 1]];
+                for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
+            }
+            __syncthreads();  // (every neighbour's slot has been read before it becomes a node)
+            for (int i = tid; i < n_emit; i += APPLES_TPB) o_node[i] = a.slot_node[o_node[i]];
+        } else {
         for (int i = tid; cg && i <= n_emit; i += APPLES_TPB) {
             const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
             const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
             for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
+        }
         }
         if (tid == 0) {
             apples_placement p;
