@@ -999,6 +999,10 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     const bool pipelined = n_pipe > 1 && qb.n >= 1024;
     int64_t want = qb.n;
     if (pipelined) want = round_up((qb.n + n_pipe - 1) / n_pipe, 32);
+    // (clustered references on the fused route keep full rows per query: with their member distances parked in the tail of
+    // the query's own observation row and 4 device batches of 25 000 in place of 7 of 14 300 the pass measured 80.5 ms
+    // against 69.2 -- lists of 3 126 observed leaves per query outgrow the Infinity Cache in the bigger batches -- and the
+    // selection kernel's load schedule suffered from the second home of the distances: 4.0 against 2.6 ms per batch)
     const bool slim = fused && a.all_singleton && fused_counts_format(ctx, qb) && !pipelined;
     if (ensure_workspace(ctx, a.n_refs, a.slots_pad, want, true, false, hybrid, fused, pipelined, slim)) return 1;
     Workspace &w = ctx->ws;
@@ -1030,6 +1034,30 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     HIP_TRY(ctx, hipEventRecord(e_start, front));
     if (pipelined) HIP_TRY(ctx, hipStreamWaitEvent(back, e_start, 0));
     int launches = 0;
+    // The queries on the top-up / slow list get full distance rows; a slim workspace holds rows for a slice of the batch
+    // only: the list's length comes to the host (one short wait per batch) and the list is walked in slices of that many
+    // queries.  fn(list, count pointer, entries at most) runs the listed distance pass + selection for one slice.
+    auto for_slow_slices = [&](int64_t nq, auto fn) -> int {
+        Workspace &w = ctx->ws;
+        hipStream_t front = ctx->stream;
+        if (w.dist_rows >= nq) return fn(w.slow_list, w.slow_count, nq);
+        int32_t hcnt = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&hcnt, w.slow_count, sizeof(int32_t), hipMemcpyDeviceToHost, front));
+        HIP_TRY(ctx, hipStreamSynchronize(front));
+        const int64_t R = w.dist_rows;
+        int32_t lens[64];
+        int n_sl = 0;
+        for (int64_t off = 0; off < hcnt && n_sl < 64; off += R) lens[n_sl++] = (int32_t)std::min<int64_t>(R, hcnt - off);
+        if ((int64_t)n_sl * R < hcnt) { ctx->err = "top-up list longer than 64 slices of the batch's full rows"; return 1; }
+        if (n_sl > 1) {
+            if (!ctx->d_slice_cnt && dev_alloc(ctx, &ctx->d_slice_cnt, 64)) return 1;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slice_cnt, lens, n_sl * sizeof(int32_t), hipMemcpyHostToDevice, front));
+            HIP_TRY(ctx, hipStreamSynchronize(front));  // (lens is on the stack)
+        }
+        for (int k = 0; k < n_sl; ++k)
+            if (fn(w.slow_list + (int64_t)k * R, n_sl > 1 ? ctx->d_slice_cnt + k : w.slow_count, lens[k])) return 1;
+        return 0;
+    };
     for (int64_t i = 0; i < n_sub; ++i) {
         const int64_t q0 = i * step;
         const int64_t nq = std::min(step, qb.n - q0);
@@ -1052,11 +1080,13 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             if (launch_select_clusters(ctx, sa, nq)) return 1;
             // queries whose accepted clusters hold fewer than -b valid distances: full rows + general selection
             sa.seg_lut = nullptr;
-            if (launch_counts_listed(ctx, qb, q0, nq, w.slow_list, w.slow_count, w.dist_slow, nullptr, nullptr)) return 1;
             sa.dist = w.dist_slow;
-            sa.qlist = w.slow_list;
-            sa.qcount = w.slow_count;
-            if (launch_select(ctx, sa, nq)) return 1;
+            if (for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
+                    if (launch_counts_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow, nullptr, nullptr)) return 1;
+                    sa.qlist = lst;
+                    sa.qcount = cntp;
+                    return launch_select(ctx, sa, n_max);
+                })) return 1;
             HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else if (sfused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
@@ -1093,38 +1123,13 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             sa.dist = w.dist_slow;
             sa.segmin_d = w.dist;
             sa.segmin_i = w.seg_slot;
-            if (w.dist_rows < nq) {
-                // slim workspace: full rows exist for a slice of the batch only.  The list's length comes to the
-                // host (one short wait per batch) and the list is walked in slices of that many queries
-                int32_t hcnt = 0;
-                HIP_TRY(ctx, hipMemcpyAsync(&hcnt, w.slow_count, sizeof(int32_t), hipMemcpyDeviceToHost, front));
-                HIP_TRY(ctx, hipStreamSynchronize(front));
-                const int64_t R = w.dist_rows;
-                int32_t lens[64];
-                int n_sl = 0;
-                for (int64_t off = 0; off < hcnt && n_sl < 64; off += R) lens[n_sl++] = (int32_t)std::min<int64_t>(R, hcnt - off);
-                if ((int64_t)n_sl * R < hcnt) { ctx->err = "top-up list longer than 64 slices of the batch's full rows"; return 1; }
-                if (n_sl > 1) {
-                    if (!ctx->d_slice_cnt && dev_alloc(ctx, &ctx->d_slice_cnt, 64)) return 1;
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slice_cnt, lens, n_sl * sizeof(int32_t), hipMemcpyHostToDevice, front));
-                    HIP_TRY(ctx, hipStreamSynchronize(front));  // (lens is on the stack)
-                }
-                for (int k = 0; k < n_sl; ++k) {
-                    const int32_t *cntp = n_sl > 1 ? ctx->d_slice_cnt + k : w.slow_count;
-                    const int32_t *lst = w.slow_list + (int64_t)k * R;
-                    if (launch_counts_listed(ctx, qb, q0, lens[k], lst, cntp, w.dist_slow, topup ? w.dist : nullptr,
+            if (for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
+                    if (launch_counts_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow, topup ? w.dist : nullptr,
                                              topup ? w.seg_slot : nullptr)) return 1;
                     sa.qlist = lst;
                     sa.qcount = cntp;
-                    if (topup ? launch_select_topup(ctx, sa, lens[k]) : launch_select(ctx, sa, lens[k])) return 1;
-                }
-            } else {
-                if (launch_counts_listed(ctx, qb, q0, nq, w.slow_list, w.slow_count, w.dist_slow, topup ? w.dist : nullptr,
-                                         topup ? w.seg_slot : nullptr)) return 1;
-                sa.qlist = w.slow_list;
-                sa.qcount = w.slow_count;
-                if (topup ? launch_select_topup(ctx, sa, nq) : launch_select(ctx, sa, nq)) return 1;
-            }
+                    return topup ? launch_select_topup(ctx, sa, n_max) : launch_select(ctx, sa, n_max);
+                })) return 1;
             HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
