@@ -374,6 +374,23 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
     }
     if (dev_upload(ctx, &a.slot_node, slot_node.data(), a.n_refs)) return 1;
     if (dev_upload(ctx, &a.slot_level, slot_level.data(), a.n_refs)) return 1;
+    dev_free(a.lvl_slots); a.lvl_slots = nullptr;
+    if (!ctx->tree.scan) {  // slots with a level above l, for l = -1 .. height (k_select_clusters ranks these in its bitmap)
+        const int H = ctx->tree.height;
+        std::vector<int32_t> lvl_slots(H + 2, 0);
+        bool sorted = true;
+        for (int64_t s = 0; s < a.n_refs; ++s) {
+            if (s > 0 && slot_level[s] > slot_level[s - 1]) sorted = false;
+            if (slot_level[s] > H) sorted = false;
+            else if (slot_level[s] >= 0) ++lvl_slots[slot_level[s]];  // for now: slots AT level l in entry l
+        }
+        for (int l = H, above = 0; l >= -1; --l) {  // entry l + 1 = slots above level l
+            const int at = l >= 0 ? lvl_slots[l] : 0;
+            lvl_slots[l + 1] = above;
+            above += at;
+        }
+        if (sorted && dev_upload(ctx, &a.lvl_slots, lvl_slots.data(), (int64_t)lvl_slots.size())) return 1;
+    }
     if (dev_upload(ctx, &a.slot_rep, slot_rep.data(), a.n_refs)) return 1;
     if (dev_upload(ctx, &a.slot_mpos, slot_mpos.data(), a.n_refs)) return 1;
     if (dev_upload(ctx, &a.rep_slot, rep_slot.data(), a.n_reps)) return 1;
@@ -648,7 +665,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
             if (dev_alloc(ctx, &w.seg_slot, batch * std::max<int64_t>(stride, 1))) return 1;
             if (dev_alloc(ctx, &w.seg_cnt, batch * std::max<int64_t>(stride / 64, 1))) return 1;
             if (dev_alloc(ctx, &w.dist_slow, drows * std::max<int64_t>(stride, 1))) return 1;
-            if (dev_alloc(ctx, &w.slow_list, batch)) return 1;
+            if (dev_alloc(ctx, &w.slow_list, 2 * batch)) return 1;  // the list, then what is known about its entries (SelectArgs.slow_hint)
         }
         if (dev_alloc(ctx, &w.route_list, 3 * batch)) return 1;
         if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
@@ -827,6 +844,7 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     s.seg_slot = w.seg_slot; s.seg_cnt = w.seg_cnt; s.node_level = ctx->tree.level;
     s.slow_list = w.slow_list; s.slow_count = w.slow_count; s.qlist = nullptr; s.qcount = nullptr;
+    s.slow_hint = nullptr; s.qhint = nullptr;
     s.seg_lut = nullptr;
     return s;
 }
@@ -1077,6 +1095,30 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             sa.seg_lut = ctx->jc_lut;
             sa.packed_rm = a.packed_rm; sa.qpacked = qb.packed + q0 * a.G * 3; sa.G = a.G; sa.L = a.L;
             sa.overlap = ctx->params.overlap_frac; sa.rep_stride = a.reps_pad; sa.tmp_d = w.dist;
+            sa.slow_hint = w.slow_list + w.batch;
+            sa.lvl_slots = a.lvl_slots;
+            {   // scratch of the cluster-major distance pass: per-cluster counters, the (query, offset) lists, the tile table
+                const int64_t n_ints = 3 * (int64_t)a.n_reps + 8, n_items = nq * SELECT_CLUSTERS_ACC_CAP,
+                              n_tiles = n_items / SELECT_CLUSTERS_MIN_TILE + a.n_reps + 1;
+                if (n_ints > ctx->cl_ints_cap) {
+                    dev_free(ctx->cl_ints); ctx->cl_ints = nullptr; ctx->cl_ints_cap = 0;
+                    if (dev_alloc(ctx, &ctx->cl_ints, n_ints)) return 1;
+                    ctx->cl_ints_cap = n_ints;
+                }
+                if (n_items > ctx->cl_items_cap) {
+                    dev_free(ctx->cl_items); ctx->cl_items = nullptr; ctx->cl_items_cap = 0;
+                    if (dev_alloc(ctx, &ctx->cl_items, n_items)) return 1;
+                    ctx->cl_items_cap = n_items;
+                }
+                if (n_tiles > ctx->cl_tiles_cap) {
+                    dev_free(ctx->cl_tiles); ctx->cl_tiles = nullptr; ctx->cl_tiles_cap = 0;
+                    if (dev_alloc(ctx, &ctx->cl_tiles, n_tiles)) return 1;
+                    ctx->cl_tiles_cap = n_tiles;
+                }
+                sa.cl_count = ctx->cl_ints; sa.cl_start = ctx->cl_ints + a.n_reps; sa.cl_fill = sa.cl_start + a.n_reps + 1;
+                sa.cl_ntiles = sa.cl_fill + a.n_reps;
+                sa.cl_items = ctx->cl_items; sa.cl_tiles = ctx->cl_tiles; sa.cl_tiles_cap = ctx->cl_tiles_cap;
+            }
             if (launch_select_clusters(ctx, sa, nq)) return 1;
             // queries whose accepted clusters hold fewer than -b valid distances: full rows + general selection
             sa.seg_lut = nullptr;
@@ -1085,6 +1127,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                     if (launch_counts_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow, nullptr, nullptr)) return 1;
                     sa.qlist = lst;
                     sa.qcount = cntp;
+                    sa.qhint = lst + w.batch;
                     return launch_select(ctx, sa, n_max);
                 })) return 1;
             HIP_TRY(ctx, hipEventRecord(e[2], front));
@@ -1354,12 +1397,13 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     ctx->blk_cache.clear();
     dev_free(ctx->d_exotic);
     dev_free(ctx->d_slice_cnt);
+    dev_free(ctx->cl_ints); dev_free(ctx->cl_items); dev_free(ctx->cl_tiles);
     for (auto &e : ctx->ev_feed) (void)hipEventDestroy(e);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

@@ -101,6 +101,8 @@ struct DevAlign {
     uint16_t *aa_mask = nullptr;  // scoredist: [Lpad16/16][slots_pad] bit k = site 16*s16+k is not a gap
     int32_t *slot_node = nullptr; // [n_refs] tree node or -1
     int32_t *slot_level = nullptr;// [n_refs] level or -1
+    int32_t *lvl_slots = nullptr; // [height + 2] entry l + 1: slots with a level above l (slots are sorted by level, deepest first); null
+                                  // where they are not (scan layout)
     int32_t *slot_rep = nullptr;  // [n_refs] representative index of the member's cluster
     int32_t *slot_mpos = nullptr; // [n_refs] position inside its cluster
     int32_t *rep_slot = nullptr;  // [n_reps] slot holding the representative's sequence
@@ -220,6 +222,10 @@ struct apples_ctx {
     int *d_exotic = nullptr;         // device flag: a packed query block carried a symbol beyond ACGT-
     std::vector<hipEvent_t> ev_feed; // "chunk i of a streamed block is uploaded and packed"
     int32_t *d_slice_cnt = nullptr;  // [64] list lengths of the top-up slices (slim workspaces)
+    // scratch of the clustered fast path's cluster-major distance pass (select.hip), grown on demand
+    int32_t *cl_ints = nullptr; int64_t cl_ints_cap = 0;
+    int2 *cl_items = nullptr; int64_t cl_items_cap = 0;
+    int4 *cl_tiles = nullptr; int64_t cl_tiles_cap = 0;
     unsigned long long *scan_prof = nullptr;  // APPLES_SCAN_PROFILE: per-phase cycle sums of the scan sweep
     unsigned long long *lean_prof = nullptr;  // APPLES_LEAN_PROFILE: the same for sweep_lean.hip's wavefront-sized teams
     // -d path: column layout cache
@@ -282,6 +288,9 @@ struct SelectArgs {
     const double *seg_lut;              // non-null: seg_slot holds position << 26 | valid << 13 | mism, distances are seg_lut[...]
     const int32_t *node_level;          // tree level by node id
     int32_t *slow_list, *slow_count;    // queries that need the top-up rule
+    int32_t *slow_hint;                 // [list position] or nullptr: what the listing kernel already knows about the query -- its
+                                        // count of observations inside the threshold (k_select then skips the pass that
+                                        // would only count them again), -1 = not known
     int32_t *cls_list, *cls_count;      // size-class work lists for the small-team sweep
     int64_t cls_stride;
     int big_threshold;                  // n_obs above this -> straight to the big-team sweep list
@@ -290,6 +299,7 @@ struct SelectArgs {
                                         // sweep_lean.hip's workgroup-sized teams take the largest first
     // listed mode of k_select: block r handles query qlist[r] with distances in row r (rows_by_query: in row qlist[r])
     const int32_t *qlist, *qcount;
+    const int32_t *qhint;     // [list position] or nullptr: see slow_hint
     int rows_by_query;
     // top-up by segment minima (k_jc69 MODE 2 -> k_select_topup): [listed row][stride]
     const double *segmin_d; const int32_t *segmin_i;
@@ -298,12 +308,22 @@ struct SelectArgs {
     const uint4 *packed_rm; const uint4 *qpacked; int G; int L; double overlap; int64_t rep_stride;
     double *tmp_d;            // [nq][stride] member distances before the ordered emission
     int flat_pref;            // k_select_fast: the segment counts' prefix fits LDS (set by the launcher)
+    // cluster-major member distances (k_select_clusters phases 1-3 around k_cluster_tiles / k_cluster_dist): per cluster the
+    // queries that accepted it, cut into tiles
+    int32_t *cl_count, *cl_start, *cl_fill, *cl_ntiles;  // [n_reps], [n_reps + 1], [n_reps], [1]
+    int2 *cl_items;           // [sum of the counts] (query, offset of the cluster's members in the query's flat member list)
+    int4 *cl_tiles;           // (cluster, first item, items, -)
+    int64_t cl_tiles_cap;
+    const int32_t *lvl_slots; // see DevAlign
+    int rep_cache;            // k_select, clustered rows: representatives whose distances are staged in LDS (set by the launcher; 0 = none)
     int64_t n_rows_plain;     // k_select / k_select_stream without a list: rows to select (set by the launcher; the grid may be smaller)
 };
 int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_topup(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq);  // needs n_members <= SELECT_CLUSTERS_MAX_SLOTS
+#define SELECT_CLUSTERS_ACC_CAP 512   // accepted clusters per query on the fast path (more: the query takes the general route)
+#define SELECT_CLUSTERS_MIN_TILE 16   // fewest queries a full tile of k_cluster_dist holds
 #define SELECT_CLUSTERS_MAX_SLOTS 229376
 int launch_counts_reps(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);
 int launch_build_cluster_panels(apples_ctx *ctx);  // listed queries, needs segmin_d/segmin_i; baseobs <= 256

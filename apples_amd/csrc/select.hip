@@ -126,7 +126,11 @@ __device__ __forceinline__ void enlist(const SelectArgs &a, int64_t q, int ne) {
 
 #define INF_D __longlong_as_double(0x7ff0000000000000LL)
 
+#ifndef SELECT_E
+#define SELECT_E 8  // slots per thread and round of the compaction pass (their loads are in flight together)
+#endif
 __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
+    extern __shared__ double dyn_drep[];  // clustered rows: the row's distances to the representatives (a.rep_cache of them)
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
     __shared__ double sh_d[8];
@@ -147,12 +151,23 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     // representative index used to break distance ties: heap of (d, i) at Reference.py:143, or the
     // column position for the stable sort at PoolQueryWorker.py:51
 #define SLOT_KEYIDX(s) (a.slot_rep[(s)])  // table input: slot_rep holds the column of the slot
+    // a member's key is its representative's distance: staged once per row (LDS) where the representatives fit, so that the
+    // compaction pass below waits for one level of loads per slot and not for slot -> representative -> slot -> distance
+#define DREP(ri) (a.rep_cache ? dyn_drep[(ri)] : DIST(a.rep_slot[(ri)]))
+    if (a.rep_cache && !single) {
+        for (int64_t ri = tid; ri < a.n_reps; ri += APPLES_TPB) dyn_drep[ri] = DIST(a.rep_slot[ri]);
+        __syncthreads();
+    }
 
     // The compaction pass below also counts the observations inside the threshold (obs_num of
     // Reference.py:144-152: valid member distances of the clusters whose representative is within the
     // threshold); if they fall short of `-b` the top-up rule fixes the cut and the pass is repeated.
     int obs = 0;
     bool have_obs = false, topped = false;
+    if (a.qhint && a.qhint[r] >= 0) {  // the listing kernel counted them already (k_select_clusters): straight to the top-up rule
+        obs = a.qhint[r];
+        have_obs = true;
+    }
     double cut_d = -INF_D;
     int cut_i = -1;
     int base = 0, n_total = 0;
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
                     d = DIST(s);
                     i = SLOT_KEYIDX(s);
                 } else {
-                    d = DIST(a.rep_slot[s]);
+                    d = DREP(s);
                     i = (int)s;
                 }
                 if (!(d >= 0 && d > thr) || !key_lt(lo_d, lo_i, d, i)) continue;
@@ -223,13 +238,13 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
         }
     }
 
-    // ---- pass B: ordered compaction of the observed leaves, 4 consecutive slots per thread ----------
+    // ---- pass B: ordered compaction of the observed leaves, SELECT_E consecutive slots per thread ----------
     base = 0;       // emitted so far
     n_total = 0;    // len(obs_dist) after the self entry is removed
     // first zero distance in dict order: min over (d_rep, rep index, member position)
     z_d = INF_D; z_i = 0x7fffffff; z_p = 0x7fffffff; z_node = -2;
     int thr_cnt = 0;  // observations inside the threshold (the obs_num the top-up rule looks at)
-    constexpr int E = 4;
+    constexpr int E = SELECT_E;
     for (int64_t s0 = 0; s0 <= nm; s0 += (int64_t)APPLES_TPB * E) {
         const int64_t sb = s0 + (int64_t)tid * E;
         int emit[E], node[E];
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
                     in_dict = ok && (dm[e] <= thr || key_le(dm[e], ri, cut_d, cut_i));
                 } else {
                     ri = a.slot_rep[s]; mp = a.slot_mpos[s];
-                    drep = DIST(a.rep_slot[ri]);
+                    drep = DREP(ri);
                     const bool member_ok = !(dm[e] < 0);
                     thr_cnt += (drep >= 0) && (drep <= thr) && member_ok;
                     in_dict = (drep >= 0) && (drep <= thr || key_le(drep, ri, cut_d, cut_i)) && member_ok;
@@ -323,6 +338,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     __syncthreads();  // shared scratch is reused by the next list entry
     }
 #undef DIST
+#undef DREP
 #undef SLOT_KEYIDX
 }
 
@@ -497,22 +513,42 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
 // 0 <= d <= threshold (k_jc69_mfma<1> on the representative panel).  Those clusters are the accepted ones
 // unless they hold fewer than `baseobs` valid member distances -- then the reference keeps walking its
 // heap, and the query goes to the slow list (full rows + k_select), as in k_select_fast.  One workgroup
-// per query: the accepted clusters' members are expanded to a flat list, a thread computes one
-// (query, member) distance from the member's words in the cluster-major panel (the pair counts of k_jc69, same
-// table lookup), marks the member's slot in an LDS bitmap; ranks of the bitmap give the slot-ordered
-// (= level-ordered) observation list the sweep wants.
-#define ACC_CAP 512
+// per query: the accepted clusters' members are expanded to a flat list, every (query, member) distance comes
+// from the member's words in the cluster-major panel (the pair counts of k_jc69, same table lookup), the member's
+// slot is marked in an LDS bitmap; ranks of the bitmap give the slot-ordered (= level-ordered) observation list
+// the sweep wants.
+//
+// Who computes the member distances (PHASE):
+//   0  this kernel, a thread per (query, member): every query reads the words of all its members, 384 B each at L = 1000
+//      -- 120 GB per 100 k queries against a 77 MB panel, bound by what the Infinity Cache delivers (2.6 ms per 14 300
+//      queries); kept for APPLES_CLUSTER_BY_QUERY and as the reference form of the phases below;
+//   1 -> k_cluster_tiles -> 2 -> k_cluster_dist -> 3  (default): cluster-major.  Phase 1 counts, per cluster, the queries that
+//      accepted it; k_cluster_tiles turns the counts into list offsets and tiles of up to 64 queries; phase 2 writes the
+//      lists (query, where the cluster's members start in the query's flat member list); k_cluster_dist takes a tile, keeps
+//      a member's words in registers and the tile's query words in LDS, and writes the distances into the queries' rows;
+//      phase 3 is phase 0 with the distance read from the row.  The panel is then read once per tile, not once per query.
+#define ACC_CAP SELECT_CLUSTERS_ACC_CAP
 #ifndef CLUSTER_UNROLL
-#define CLUSTER_UNROLL 1  // member word groups in flight per lane (3 16-byte loads each).  More is slower: the kernel is bound by
-                          // the rate the member panel (77 MB at 200 k leaves: Infinity Cache) delivers 120 GB per 100 k queries,
-                          // 38 / 42 / 48 / 43 ms per C3 pass with 1 / 2 / 4 / 8
+#define CLUSTER_UNROLL 1  // phase 0: member word groups in flight per lane (3 16-byte loads each); 38 / 42 / 48 / 43 ms per C3 pass
+                          // with 1 / 2 / 4 / 8 (the loop's load schedule is fragile: the same source measured 41 ms per pass
+                          // where an unrelated change had the compiler interleave the six loads with their uses)
 #endif
+// pair counts of one 128-site word group: rm / r0 / r1 = the member's mask and two code planes, qm / q0 / q1 the query's
+__device__ __forceinline__ void cluster_count(const uint4 &rm, const uint4 &r0, const uint4 &r1, const uint4 &qm, const uint4 &q0,
+                                              const uint4 &q1, uint32_t &nv, uint32_t &nmis) {
+    const uint32_t m0_ = qm.x & rm.x, m1_ = qm.y & rm.y, m2_ = qm.z & rm.z, m3_ = qm.w & rm.w;
+    nv += __popc(m0_) + __popc(m1_) + __popc(m2_) + __popc(m3_);
+    nmis += __popc(((q0.x ^ r0.x) | (q1.x ^ r1.x)) & m0_) + __popc(((q0.y ^ r0.y) | (q1.y ^ r1.y)) & m1_) +
+            __popc(((q0.z ^ r0.z) | (q1.z ^ r1.z)) & m2_) + __popc(((q0.w ^ r0.w) | (q1.w ^ r1.w)) & m3_);
+}
+
+template <int PHASE>
 __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     extern __shared__ unsigned long long dyn_bits[];  // [n_words] member bits in slot order, then uint32 [n_words] prefix
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
     __shared__ double sh_d[8];
-    __shared__ uint4 sh_q[64 * 3];
+    __shared__ uint4 sh_q[PHASE == 0 ? 64 * 3 : 1];
     __shared__ int sh_rep[ACC_CAP];
     __shared__ double sh_drep[ACC_CAP];
     __shared__ int sh_off[ACC_CAP + 1];
@@ -528,18 +564,23 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     int32_t *o_node = a.obs_node + q * a.obs_cap;
     double *o_dist = a.obs_dist + q * a.obs_cap;
     double *tmp = a.tmp_d + q * a.stride;
-    auto to_slow = [&]() {
+    auto to_slow = [&](int known_obs) {  // known_obs: the observations inside the threshold if they were counted, else -1
         if (tid == 0) {
-            a.slow_list[atomicAdd(a.slow_count, 1)] = (int32_t)q;
+            const int at = atomicAdd(a.slow_count, 1);
+            a.slow_list[at] = (int32_t)q;
+            if (a.slow_hint) a.slow_hint[at] = known_obs;
             a.n_obs[q] = 0;
         }
     };
-    // the query's packed words (tile layout of pack.hip: [(q/16)*G + g][q%16][plane])
-    for (int i = tid; i < G * 3; i += APPLES_TPB) {
-        const int g = i / 3, pl = i % 3;
-        sh_q[i] = a.qpacked[(((q >> 4) * G + g) * 16 + (q & 15)) * 3 + pl];
+    if (PHASE == 0) {
+        // the query's packed words (tile layout of pack.hip: [(q/16)*G + g][q%16][plane])
+        for (int i = tid; i < G * 3; i += APPLES_TPB) {
+            const int g = i / 3, pl = i % 3;
+            sh_q[i] = a.qpacked[(((q >> 4) * G + g) * 16 + (q & 15)) * 3 + pl];
+        }
     }
-    for (int i = tid; i < n_words; i += APPLES_TPB) dyn_bits[i] = 0;
+    if (PHASE == 0 || PHASE == 3)
+        for (int i = tid; i < n_words; i += APPLES_TPB) dyn_bits[i] = 0;
     // ---- accepted representatives: the survivors of the representative pass, in representative order
     const int64_t n_seg = a.rep_stride >> 6;
     const int32_t *cnt = a.seg_cnt + q * n_seg;
@@ -557,7 +598,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
                 const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
                 const int rep = (int)(s * 64 + (pk >> 26));
                 sh_rep[at + k] = rep;
-                sh_drep[at + k] = a.seg_lut[valid * (valid + 1) / 2 + mism];
+                if (PHASE == 0 || PHASE == 3) sh_drep[at + k] = a.seg_lut[valid * (valid + 1) / 2 + mism];
             }
         } else if (my > 0) {
             overflow = true;
@@ -567,7 +608,14 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     if (tid == 0) sh_nacc = base;
     __syncthreads();
     const int n_acc = sh_nacc;
-    if (n_acc > ACC_CAP || __syncthreads_or(overflow ? 1 : 0)) { to_slow(); return; }
+    if (n_acc > ACC_CAP || __syncthreads_or(overflow ? 1 : 0)) {
+        if (PHASE <= 1) to_slow(-1);  // (once: the later phases just leave the query alone)
+        return;
+    }
+    if (PHASE == 1) {  // one more query for every accepted cluster
+        for (int k = tid; k < n_acc; k += APPLES_TPB) atomicAdd(&a.cl_count[sh_rep[k]], 1);
+        return;
+    }
     // ---- members of the accepted clusters as one flat list: offsets by cluster
     {
         int carry = 0;
@@ -583,52 +631,84 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
         if (tid == 0) sh_off[n_acc] = carry;
     }
     __syncthreads();
+    if (PHASE == 2) {  // the query joins the lists of its clusters (in whatever order the additions land: every pair is on its own)
+        for (int k = tid; k < n_acc; k += APPLES_TPB) {
+            const int c = sh_rep[k];
+            a.cl_items[a.cl_start[c] + atomicAdd(&a.cl_fill[c], 1)] = make_int2((int)q, sh_off[k]);
+        }
+        return;
+    }
     const int M = sh_off[n_acc];
-    // ---- pass 1: one (query, member) distance per thread
+    // ---- pass 1: one (query, member) distance per thread; E members per thread and round, so that the lookups of a round
+    // (member -> slot -> node) are E in flight and not one after the other: the workgroup's time is their latency
+    constexpr int E = PHASE == 0 ? 1 : 4;
+    auto cluster_of = [&](int m) -> int {  // last accepted cluster whose offset <= m
+        int lo = 0, hi = n_acc;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sh_off[mid] <= m) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
     int n_total = 0, obs_cnt = 0;
     double z_d = INF_D;
     int z_i = 0x7fffffff, z_p = 0x7fffffff, z_node = -2;
-    for (int m0 = 0; m0 < M; m0 += APPLES_TPB) {
-        const int m = m0 + tid;
-        if (m < M) {
-            int lo = 0, hi = n_acc;  // last cluster whose offset <= m
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (sh_off[mid] <= m) lo = mid; else hi = mid;
-            }
-            const int rep = sh_rep[lo], mp = m - sh_off[lo];
-            const int mb = sh_mb[lo], sz = sh_off[lo + 1] - sh_off[lo];
-            const int slot = a.mem_slot[mb + mp];  // (on its way with the member's words below: neither waits for the other)
-            // the member's words in the cluster-major panel: word (g, plane) of member mp at (g * 3 + plane) * sz + mp, so
-            // the lanes holding consecutive members of this cluster read consecutive 16 bytes
-            const uint4 *row = a.packed_rm + (int64_t)mb * (G * 3) + mp;
-            uint32_t nv = 0, nmis = 0;
-            auto count = [&](const uint4 &rm, const uint4 &r0, const uint4 &r1, int g) {
-                const uint4 qm = sh_q[g * 3], q0 = sh_q[g * 3 + 1], q1 = sh_q[g * 3 + 2];
-                const uint32_t m0_ = qm.x & rm.x, m1_ = qm.y & rm.y, m2_ = qm.z & rm.z, m3_ = qm.w & rm.w;
-                nv += __popc(m0_) + __popc(m1_) + __popc(m2_) + __popc(m3_);
-                nmis += __popc(((q0.x ^ r0.x) | (q1.x ^ r1.x)) & m0_) + __popc(((q0.y ^ r0.y) | (q1.y ^ r1.y)) & m1_) +
-                        __popc(((q0.z ^ r0.z) | (q1.z ^ r1.z)) & m2_) + __popc(((q0.w ^ r0.w) | (q1.w ^ r1.w)) & m3_);
-            };
-            int g = 0;
-            for (; g + CLUSTER_UNROLL <= G; g += CLUSTER_UNROLL) {  // 3 x CLUSTER_UNROLL loads in flight before the first is used
-                uint4 w[3 * CLUSTER_UNROLL];
+    for (int m0 = 0; m0 < M; m0 += APPLES_TPB * E) {
+        int lo_[E], slot_[E], node_[E];
+        double d_[E];
 #pragma unroll
-                for (int k = 0; k < 3 * CLUSTER_UNROLL; ++k) w[k] = row[(int64_t)(g * 3 + k) * sz];
+        for (int e = 0; e < E; ++e) {
+            const int m = m0 + e * APPLES_TPB + tid;
+            lo_[e] = -1; slot_[e] = 0; d_[e] = -1.0;
+            if (m < M) {
+                const int lo = cluster_of(m), mp = m - sh_off[lo], mb = sh_mb[lo];
+                lo_[e] = lo;
+                slot_[e] = a.mem_slot[mb + mp];  // (on its way with the member's distance / words below: neither waits for the other)
+                if (PHASE == 3) {
+                    d_[e] = tmp[m];  // k_cluster_dist left it there
+                } else {
+                    // the member's words in the cluster-major panel: word (g, plane) of member mp at (g * 3 + plane) * sz + mp, so
+                    // the lanes holding consecutive members of this cluster read consecutive 16 bytes
+                    const int sz = sh_off[lo + 1] - sh_off[lo];
+                    const uint4 *row = a.packed_rm + (int64_t)mb * (G * 3) + mp;
+                    uint32_t nv = 0, nmis = 0;
+                    int g = 0;
+                    for (; g + CLUSTER_UNROLL <= G; g += CLUSTER_UNROLL) {  // 3 x CLUSTER_UNROLL loads in flight before the first is used
+                        uint4 w[3 * CLUSTER_UNROLL];
 #pragma unroll
-                for (int k = 0; k < CLUSTER_UNROLL; ++k) count(w[3 * k], w[3 * k + 1], w[3 * k + 2], g + k);
+                        for (int k = 0; k < 3 * CLUSTER_UNROLL; ++k) w[k] = row[(int64_t)(g * 3 + k) * sz];
+#pragma unroll
+                        for (int k = 0; k < CLUSTER_UNROLL; ++k)
+                            cluster_count(w[3 * k], w[3 * k + 1], w[3 * k + 2], sh_q[(g + k) * 3], sh_q[(g + k) * 3 + 1], sh_q[(g + k) * 3 + 2], nv, nmis);
+                    }
+                    for (; g < G; ++g)
+                        cluster_count(row[(int64_t)(g * 3) * sz], row[(int64_t)(g * 3 + 1) * sz], row[(int64_t)(g * 3 + 2) * sz], sh_q[g * 3],
+                                      sh_q[g * 3 + 1], sh_q[g * 3 + 2], nv, nmis);
+                    d_[e] = a.seg_lut[(int64_t)nv * (nv + 1) / 2 + nmis];
+                }
             }
-            for (; g < G; ++g) count(row[(int64_t)(g * 3) * sz], row[(int64_t)(g * 3 + 1) * sz], row[(int64_t)(g * 3 + 2) * sz], g);
-            const double d = a.seg_lut[(int64_t)nv * (nv + 1) / 2 + nmis];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e)  // (the node of every listed member: cheaper asked for than waited for)
+            node_[e] = lo_[e] >= 0 ? a.slot_node[slot_[e]] : -1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int m = m0 + e * APPLES_TPB + tid;
+            if (lo_[e] < 0) continue;
+            const int lo = lo_[e], slot = slot_[e];
+            const double d = d_[e];
             double keep = -2.0;  // not emitted
             if (!(d < 0)) {      // Reference.py:150: `if not dm < 0`
                 ++obs_cnt;
                 if (slot != self) {
                     ++n_total;
-                    const int node = a.slot_node[slot];
-                    const double drep = sh_drep[lo];
-                    if (d == 0 && (drep < z_d || (drep == z_d && (rep < z_i || (rep == z_i && mp < z_p))))) {
-                        z_d = drep; z_i = rep; z_p = mp; z_node = node;
+                    const int node = node_[e];
+                    if (d == 0) {
+                        const double drep = sh_drep[lo];
+                        const int rep = sh_rep[lo], mp = m - sh_off[lo];
+                        if (drep < z_d || (drep == z_d && (rep < z_i || (rep == z_i && mp < z_p)))) {
+                            z_d = drep; z_i = rep; z_p = mp; z_node = node;
+                        }
                     }
                     if (node >= 0) {
                         keep = d;
@@ -640,7 +720,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
         }
     }
     const int obs = block_sum(obs_cnt, sh_i);
-    if (obs < a.baseobs) { to_slow(); return; }  // the reference would pop further clusters (Reference.py:146)
+    if (obs < a.baseobs) { to_slow(obs); return; }  // the reference would pop further clusters (Reference.py:146)
     // ---- ranks of the slot bitmap
     int n_emit = 0;
     for (int w0 = 0; w0 < n_words; w0 += APPLES_TPB) {
@@ -652,24 +732,34 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
         n_emit += tot;
     }
     __syncthreads();
+    auto rank_of = [&](int slot) -> int {  // emitted members in the slots below `slot`
+        if ((slot >> 6) >= n_words) return n_emit;
+        return (int)pre[slot >> 6] + __popcll(dyn_bits[slot >> 6] & ((1ull << (slot & 63)) - 1ull));
+    };
     // ---- pass 2: emission in slot order
-    for (int m0 = 0; m0 < M; m0 += APPLES_TPB) {
-        const int m = m0 + tid;
-        if (m < M) {
-            const double d = tmp[m];
-            if (d >= 0) {
-                int lo = 0, hi = n_acc;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sh_off[mid] <= m) lo = mid; else hi = mid;
-                }
-                const int slot = a.mem_slot[sh_mb[lo] + (m - sh_off[lo])];
-                const unsigned long long word = dyn_bits[slot >> 6];
-                const int pos = (int)pre[slot >> 6] + __popcll(word & ((1ull << (slot & 63)) - 1ull));
-                o_node[pos] = a.slot_node[slot];
-                o_dist[pos] = d;
+    for (int m0 = 0; m0 < M; m0 += APPLES_TPB * E) {
+        int slot_[E];
+        double d_[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int m = m0 + e * APPLES_TPB + tid;
+            slot_[e] = -1; d_[e] = -2.0;
+            if (m < M) {
+                const int lo = cluster_of(m);
+                d_[e] = tmp[m];
+                slot_[e] = a.mem_slot[sh_mb[lo] + (m - sh_off[lo])];
             }
         }
+        int node_[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) node_[e] = slot_[e] >= 0 ? a.slot_node[slot_[e]] : -1;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (d_[e] >= 0) {
+                const int pos = rank_of(slot_[e]);
+                o_node[pos] = node_[e];
+                o_dist[pos] = d_[e];
+            }
     }
     n_total = block_sum(n_total, sh_i);  // (its barriers also publish the emission)
     double zd = z_d; int zi = z_i, zp = z_p;
@@ -678,11 +768,17 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     __syncthreads();
     if (z_node != -2 && z_d == zd && z_i == zi && z_p == zp) sh_znode = z_node;
     __syncthreads();
+    // per-level offsets into the level-sorted list (the sweep's cnt_gt): cg[l + 1] = entries above level l = the emitted members
+    // in the slots above level l (slots are sorted by level, deepest first; lvl_slots[l + 1] = how many slots those are)
     int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
-    for (int i = tid; cg && i <= n_emit; i += APPLES_TPB) {  // per-level offsets into the level-sorted list
-        const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
-        const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
-        for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
+    if (cg && a.lvl_slots) {
+        for (int i = tid; i < a.height + 2; i += APPLES_TPB) cg[i] = rank_of(a.lvl_slots[i]);
+    } else {
+        for (int i = tid; cg && i <= n_emit; i += APPLES_TPB) {
+            const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
+            const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
+            for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
+        }
     }
     if (tid == 0) {
         apples_placement p;
@@ -708,10 +804,130 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     }
 }
 
+// Queries per tile of a cluster with `sz` members (k_cluster_dist): a workgroup's 256 threads are P = min(sz, 256) member
+// lanes x QL = 256 / P query lanes, and a thread keeps up to 16 queries' counts in registers.
+__device__ __forceinline__ int cluster_tile_queries(int sz) {
+    const int P = sz < APPLES_TPB ? (sz > 0 ? sz : 1) : APPLES_TPB, QL = APPLES_TPB / P;
+    return QL * 16 < 64 ? QL * 16 : 64;
+}
+
+// One workgroup: the clusters' query counts -> list offsets (cl_start), cleared fill cursors, and the tile table.
+__global__ __launch_bounds__(APPLES_TPB) void k_cluster_tiles(SelectArgs a) {
+    __shared__ int sh_i[8];
+    const int tid = threadIdx.x;
+    int item_base = 0, tile_base = 0;
+    for (int64_t c0 = 0; c0 < a.n_reps; c0 += APPLES_TPB) {
+        const int64_t c = c0 + tid;
+        const int cnt = c < a.n_reps ? a.cl_count[c] : 0;
+        const int T = c < a.n_reps ? cluster_tile_queries(a.rep_moff[c + 1] - a.rep_moff[c]) : 1;
+        const int nt = (cnt + T - 1) / T;
+        int tot_i, tot_t;
+        const int at_i = item_base + block_excl_scan_int(cnt, sh_i, &tot_i);
+        const int at_t = tile_base + block_excl_scan_int(nt, sh_i, &tot_t);
+        if (c < a.n_reps) {
+            a.cl_start[c] = at_i;
+            a.cl_fill[c] = 0;
+            for (int k = 0; k < nt; ++k)
+                if (at_t + k < a.cl_tiles_cap) a.cl_tiles[at_t + k] = make_int4((int)c, at_i + k * T, cnt - k * T < T ? cnt - k * T : T, 0);
+        }
+        item_base += tot_i;
+        tile_base += tot_t;
+    }
+    if (tid == 0) {
+        a.cl_start[a.n_reps] = item_base;
+        *a.cl_ntiles = tile_base < a.cl_tiles_cap ? tile_base : (int)a.cl_tiles_cap;  // (the cap is the proven upper bound: never hit)
+    }
+}
+
+// The member distances of one tile = one cluster x up to 64 of the queries that accepted it.  Thread = (member lane,
+// query lane); per chunk of CL_GC word groups the member's words are loaded once into registers (lanes along the members:
+// consecutive 16 bytes of the cluster-major panel), the tile's query words are staged in LDS (a wavefront reads one or a few
+// addresses: broadcasts), and the thread adds the pair counts of its up to 16 queries.  Same counts and same table lookup as
+// phase 0 of k_select_clusters, so the same bits.  Persistent workgroups walk the tile table.
+#define CL_GC 4
+__global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist(SelectArgs a) {
+    __shared__ uint4 sh_qw[64][CL_GC * 3];
+    __shared__ int sh_q[64], sh_o[64];
+    const int tid = threadIdx.x;
+    const int G = a.G;
+    const int n_tiles = *a.cl_ntiles;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int4 tile = a.cl_tiles[t];
+        const int c = tile.x, nqt = tile.z;
+        const int mb = a.rep_moff[c], sz = a.rep_moff[c + 1] - mb;
+        __syncthreads();  // the previous tile's last readers of sh_q / sh_o / sh_qw
+        if (tid < nqt) {
+            const int2 it = a.cl_items[tile.y + tid];
+            sh_q[tid] = it.x; sh_o[tid] = it.y;
+        }
+        for (int mc0 = 0; mc0 < sz; mc0 += APPLES_TPB) {  // (clusters beyond 256 members: in chunks)
+            const int P = sz - mc0 < APPLES_TPB ? sz - mc0 : APPLES_TPB, QL = APPLES_TPB / P;
+            const int ml = tid % P, jl = tid / P;
+            const bool active = jl < QL;
+            uint32_t nv[16], nmis[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { nv[k] = 0; nmis[k] = 0; }
+            const uint4 *row = a.packed_rm + (int64_t)mb * (G * 3) + mc0 + ml;
+            for (int g0 = 0; g0 < G; g0 += CL_GC) {
+                __syncthreads();  // the list above is written / the previous chunk's words are read
+                for (int i = tid; i < nqt * (CL_GC * 3); i += APPLES_TPB) {
+                    const int j = i / (CL_GC * 3), w = i % (CL_GC * 3), g = g0 + w / 3, pl = w % 3;
+                    const int64_t q = sh_q[j];
+                    sh_qw[j][w] = g < G ? a.qpacked[(((q >> 4) * G + g) * 16 + (q & 15)) * 3 + pl] : make_uint4(0, 0, 0, 0);
+                }
+                uint4 mw[CL_GC * 3];
+                if (active) {
+#pragma unroll
+                    for (int w = 0; w < CL_GC * 3; ++w)
+                        mw[w] = g0 + w / 3 < G ? row[(int64_t)((g0 + w / 3) * 3 + w % 3) * sz] : make_uint4(0, 0, 0, 0);
+                }
+                __syncthreads();
+                if (active) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int j = jl + k * QL;
+                        if (j < nqt) {
+#pragma unroll
+                            for (int gg = 0; gg < CL_GC; ++gg)
+                                cluster_count(mw[gg * 3], mw[gg * 3 + 1], mw[gg * 3 + 2], sh_qw[j][gg * 3], sh_qw[j][gg * 3 + 1],
+                                              sh_qw[j][gg * 3 + 2], nv[k], nmis[k]);
+                        }
+                    }
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int j = jl + k * QL;
+                    if (j < nqt)
+                        a.tmp_d[(int64_t)sh_q[j] * a.stride + sh_o[j] + mc0 + ml] = a.seg_lut[(int64_t)nv[k] * (nv[k] + 1) / 2 + nmis[k]];
+                }
+            }
+        }
+    }
+}
+
 int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
     const size_t dyn = (size_t)((a.n_members + 63) >> 6) * 12;
-    hipLaunchKernelGGL(k_select_clusters, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
+    static const bool by_query = getenv("APPLES_CLUSTER_BY_QUERY") != nullptr;  // diagnostic knob: phase 0 alone
+    if (by_query || !a.cl_count) {
+        hipLaunchKernelGGL(k_select_clusters<0>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(a.cl_count, 0, (size_t)a.n_reps * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(k_select_clusters<1>, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_cluster_tiles, dim3(1), dim3(APPLES_TPB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_select_clusters<2>, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
+    if (ctx->n_cu == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->n_cu = prop.multiProcessorCount;
+    }
+    static const int per_cu = getenv("APPLES_CLUSTER_WGS") ? atoi(getenv("APPLES_CLUSTER_WGS")) : 8;  // tuning knob
+    hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_select_clusters<3>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -1293,8 +1509,11 @@ int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         if (cap > 0) grid = std::min<unsigned>(grid, (unsigned)cap);
         hipLaunchKernelGGL(k_select_stream, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);
     }
-    else
-        hipLaunchKernelGGL(k_select, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);
+    else {
+        // clustered rows: the representatives' distances in LDS where they fit (48 KB: 6 144 of them)
+        b.rep_cache = (!a.all_singleton && a.n_reps > 0 && a.n_reps <= 6144) ? 1 : 0;
+        hipLaunchKernelGGL(k_select, dim3(grid), dim3(APPLES_TPB), b.rep_cache ? (size_t)a.n_reps * sizeof(double) : 0, ctx->stream, b);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

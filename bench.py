@@ -367,6 +367,10 @@ def main():
     ds = synth.make_dataset(n_leaves, L if not table else 4, Q, protein=protein, seed_query=3 if strong else 3 + rank)
     lo, hi = shard_bounds(Q, world)[rank] if strong else (0, Q)
     queries = np.ascontiguousarray(ds.query_seqs[lo:hi])
+    if os.environ.get('APPLES_BENCH_TREE_ORDER'):
+        # experiment only (never the reported line): the block's queries in the tree order of their true sister leaves,
+        # to measure what locality between neighbouring queries is worth to the selection and the sweep
+        queries = np.ascontiguousarray(queries[np.argsort(ds.query_leaf[lo:hi], kind='stable')])
     sizes = [(b - a) for a, b in shard_bounds(Q, world)] if strong else [Q] * world
     nodes = np.array([ds.tree.name_to_node[n] for n in ds.ref_names], np.int32)
     D = None
