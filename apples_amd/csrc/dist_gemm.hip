@@ -416,7 +416,8 @@ int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
         ctx->n_cu = prop.multiProcessorCount;
     }
     static const int cus = getenv("APPLES_GEMM_CUS") ? atoi(getenv("APPLES_GEMM_CUS")) : 0;  // experiment: leave CUs to a concurrent sweep
-    const int64_t grid = std::max(8, (cus > 0 ? std::min(cus, ctx->n_cu) : ctx->n_cu) / 8 * 8) * (256 / QT);
+    static const int per_cu = getenv("APPLES_GEMM_WGS_PER_CU") ? atoi(getenv("APPLES_GEMM_WGS_PER_CU")) : 0;  // experiment: one four-wavefront workgroup per CU (QT = 128)
+    const int64_t grid = std::max(8, (cus > 0 ? std::min(cus, ctx->n_cu) : ctx->n_cu) / 8 * 8) * (per_cu > 0 ? std::min(per_cu, 256 / QT) : 256 / QT);
     static const bool table = getenv("APPLES_GEMM_TABLE") != nullptr;  // diagnostic knob: threshold through the LDS table
     const bool lin = ctx->gemm_thr.ok && !table;
     const int R = (a.G * 2 - 2) % 3;

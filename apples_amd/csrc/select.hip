@@ -127,7 +127,7 @@ __device__ __forceinline__ void enlist(const SelectArgs &a, int64_t q, int ne) {
 #define INF_D __longlong_as_double(0x7ff0000000000000LL)
 
 #ifndef SELECT_E
-#define SELECT_E 8  // slots per thread and round of the compaction pass (their loads are in flight together)
+#define SELECT_E 8  // slots per thread and round of the compaction pass (their loads are in flight together; 16: no faster)
 #endif
 __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     extern __shared__ double dyn_drep[];  // clustered rows: the row's distances to the representatives (a.rep_cache of them)
@@ -544,13 +544,14 @@ __device__ __forceinline__ void cluster_count(const uint4 &rm, const uint4 &r0, 
 
 template <int PHASE>
 __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
-    extern __shared__ unsigned long long dyn_bits[];  // [n_words] member bits in slot order, then uint32 [n_words] prefix
+    extern __shared__ unsigned long long dyn_bits[];  // [n_words] member bits in slot order, then uint16 [n_words]: the set bits before the
+                                                      // word inside its thread's run of 16 words (sh_base: before the run)
+    __shared__ int sh_base[APPLES_TPB];
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
     __shared__ double sh_d[8];
     __shared__ uint4 sh_q[PHASE == 0 ? 64 * 3 : 1];
     __shared__ int sh_rep[ACC_CAP];
-    __shared__ double sh_drep[ACC_CAP];
     __shared__ int sh_off[ACC_CAP + 1];
     __shared__ int sh_mb[ACC_CAP];  // first member (index into mem_slot / the cluster-major panel) of every accepted cluster
     __shared__ int sh_znode, sh_nacc;
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     const int G = a.G;
     const int64_t nm = a.n_members;
     const int n_words = (int)((nm + 63) >> 6);
-    uint32_t *pre = reinterpret_cast<uint32_t *>(dyn_bits + n_words);
+    uint16_t *pre = reinterpret_cast<uint16_t *>(dyn_bits + n_words);
     const int self = a.self_slot ? a.self_slot[q] : -1;
     int32_t *o_node = a.obs_node + q * a.obs_cap;
     double *o_dist = a.obs_dist + q * a.obs_cap;
@@ -595,10 +596,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
         if (at + my <= ACC_CAP) {
             for (int k = 0; k < my; ++k) {
                 const uint32_t pk = (uint32_t)sslot[s * 64 + k];
-                const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
-                const int rep = (int)(s * 64 + (pk >> 26));
-                sh_rep[at + k] = rep;
-                if (PHASE == 0 || PHASE == 3) sh_drep[at + k] = a.seg_lut[valid * (valid + 1) / 2 + mism];
+                sh_rep[at + k] = (int)(s * 64 + (pk >> 26));
             }
         } else if (my > 0) {
             overflow = true;
@@ -704,8 +702,16 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
                     ++n_total;
                     const int node = node_[e];
                     if (d == 0) {
-                        const double drep = sh_drep[lo];
+                        // (rare: the representative's own distance is looked up again among the survivors of its segment)
                         const int rep = sh_rep[lo], mp = m - sh_off[lo];
+                        double drep = 0.0;
+                        for (int k = 0; k < cnt[rep >> 6]; ++k) {
+                            const uint32_t pk = (uint32_t)sslot[(int64_t)(rep >> 6) * 64 + k];
+                            if ((int)(pk >> 26) == (rep & 63)) {
+                                const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
+                                drep = a.seg_lut[valid * (valid + 1) / 2 + mism];
+                            }
+                        }
                         if (drep < z_d || (drep == z_d && (rep < z_i || (rep == z_i && mp < z_p)))) {
                             z_d = drep; z_i = rep; z_p = mp; z_node = node;
                         }
@@ -721,20 +727,21 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     }
     const int obs = block_sum(obs_cnt, sh_i);
     if (obs < a.baseobs) { to_slow(obs); return; }  // the reference would pop further clusters (Reference.py:146)
-    // ---- ranks of the slot bitmap
-    int n_emit = 0;
-    for (int w0 = 0; w0 < n_words; w0 += APPLES_TPB) {
-        const int w = w0 + tid;
-        const int c = w < n_words ? __popcll(dyn_bits[w]) : 0;
-        int tot;
-        const int ex = n_emit + block_excl_scan_int(c, sh_i, &tot);
-        if (w < n_words) pre[w] = (uint32_t)ex;
-        n_emit += tot;
+    // ---- ranks of the slot bitmap: a thread counts its run of 16 words, one scan over the threads
+    int n_emit;
+    {
+        int c = 0;
+        for (int k = 0; k < 16; ++k) {
+            const int w = tid * 16 + k;
+            if (w < n_words) { pre[w] = (uint16_t)c; c += __popcll(dyn_bits[w]); }
+        }
+        sh_base[tid] = block_excl_scan_int(c, sh_i, &n_emit);
     }
     __syncthreads();
     auto rank_of = [&](int slot) -> int {  // emitted members in the slots below `slot`
-        if ((slot >> 6) >= n_words) return n_emit;
-        return (int)pre[slot >> 6] + __popcll(dyn_bits[slot >> 6] & ((1ull << (slot & 63)) - 1ull));
+        const int w = slot >> 6;
+        if (w >= n_words) return n_emit;
+        return sh_base[w >> 4] + (int)pre[w] + __popcll(dyn_bits[w] & ((1ull << (slot & 63)) - 1ull));
     };
     // ---- pass 2: emission in slot order
     for (int m0 = 0; m0 < M; m0 += APPLES_TPB * E) {
@@ -909,7 +916,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist(SelectArgs a) {
 
 int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
-    const size_t dyn = (size_t)((a.n_members + 63) >> 6) * 12;
+    const size_t dyn = (size_t)((a.n_members + 63) >> 6) * 10;  // the slot bitmap and its 16-bit in-run prefixes (runs of 16 words: 262 144 slots)
     static const bool by_query = getenv("APPLES_CLUSTER_BY_QUERY") != nullptr;  // diagnostic knob: phase 0 alone
     if (by_query || !a.cl_count) {
         hipLaunchKernelGGL(k_select_clusters<0>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
