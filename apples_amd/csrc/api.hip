@@ -1920,7 +1920,7 @@ const char *apples_describe(apples_ctx *ctx) {
              "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"n_rows\": %lld, "
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
              "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\", "
-             "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld, \"sweep_layout\": \"%s\"}",
+             "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld, \"sweep_layout\": \"%s\", \"cluster_fused\": %d}",
              name, cus, ctx->tree.n_nodes, ctx->tree.height, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
              (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
@@ -1932,7 +1932,9 @@ const char *apples_describe(apples_ctx *ctx) {
              // how the level-loop sweep knows a query's subtree: merged level lists / node bits in LDS / tagged node map
              // (lean: sweep_lean.hip on big binary trees -- the workspace decides; before there is one, what a plain MLSE / ME pass will get)
              ctx->tree.scan ? "scan" : (ctx->ws.small.lean || (ctx->ws.batch == 0 && sweep_lean_layout(ctx->tree, false))) ? "lean"
-             : sweep_merge_lists(ctx->tree) ? "merge" : sweep_bits_in_lds(ctx->tree) ? "bits" : "map");
+             : sweep_merge_lists(ctx->tree) ? "merge" : sweep_bits_in_lds(ctx->tree) ? "bits" : "map",
+             // clustered references with the panels of the fast path (representatives for the matrix-core pass, members cluster-major)
+             (!a.all_singleton && a.rep_packed && a.packed_rm && ctx->params.model == APPLES_JC69 && !(ctx->dbg & APPLES_DBG_NO_FUSE)) ? 1 : 0);
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

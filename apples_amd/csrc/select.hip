@@ -917,7 +917,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist(SelectArgs a) {
 int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
     const size_t dyn = (size_t)((a.n_members + 63) >> 6) * 10;  // the slot bitmap and its 16-bit in-run prefixes (runs of 16 words: 262 144 slots)
-    static const bool by_query = getenv("APPLES_CLUSTER_BY_QUERY") != nullptr;  // diagnostic knob: phase 0 alone
+    const bool by_query = getenv("APPLES_CLUSTER_BY_QUERY") != nullptr;  // diagnostic knob: phase 0 alone (read per launch: tests cross the two forms in one process)
     if (by_query || !a.cl_count) {
         hipLaunchKernelGGL(k_select_clusters<0>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());

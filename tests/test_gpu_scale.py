@@ -331,6 +331,45 @@ def test_clustered_reference_at_c2_size_against_c_oracle(c2, method, criterion):
     _compare(got, want, co, d, nodes, 'clustered %s/%s' % (method, criterion))
 
 
+def test_cluster_major_member_distances_on_awkward_cluster_sizes(c2, monkeypatch):
+    """The clustered fast path computes member distances cluster by cluster, a tile of the accepting queries at a time
+    (select.hip:k_cluster_dist).  Cluster sizes that exercise its shapes: more than 256 members (member chunks), 65-85
+    (three query lanes), singletons, pairs and triples (256, 128 and 85 query lanes), lists that end in partial tiles.
+    Against the C oracle byte for byte, and the by-query form of the same kernel (APPLES_CLUSTER_BY_QUERY) likewise."""
+    from apples_amd import treecluster
+    from apples_amd.fasta import Alignment
+    from apples_amd.reference import ReducedReference
+    d, nodes = c2
+    groups = treecluster.grouped(d.tree, 0.4)
+    sizes = sorted(len(g[1]) for g in groups)
+    assert sizes[-1] > 512 and sum(1 for s in sizes if s > 256) >= 8
+    # the smallest cluster is cut into singletons, pairs and triples
+    groups.sort(key=lambda g: len(g[1]))
+    small = groups.pop(0)[1]
+    i, k = 0, 0
+    while i < len(small):
+        n = 1 + k % 3
+        groups.append(('cut%d' % k, small[i:i + n]))
+        i += n
+        k += 1
+    ref = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, groups)
+    ca = ref.cluster_arrays()
+    nq = 700  # (not a multiple of the tile sizes)
+    thr = 0.45
+    co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', criterion='MLSE', threshold=thr,
+                 lut=jc69_lut(1000, 0.001), threads=len(os.sched_getaffinity(0)))
+    want = co.place_sequences(d.query_seqs[:nq])
+    for by_query in (False, True):
+        if by_query:
+            monkeypatch.setenv('APPLES_CLUSTER_BY_QUERY', '1')
+        eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', criterion='MLSE', threshold=thr)
+        assert eng.describe()['cluster_fused'], 'the clustered fast path is not the one under test'
+        got = eng.place_sequences(d.query_seqs[:nq])
+        eng.close()
+        _compare(got, want, co, d, nodes, 'awkward clusters, by query %s' % by_query)
+    assert (want['n_obs'] > 300).sum() > nq // 2  # whole big clusters were accepted
+
+
 @pytest.mark.parametrize('L', [4097, 8190])
 def test_long_alignments_through_the_fused_matrix_core_pass(L):
     """The fused distance pass packs (valid, mism) into 13-bit fields and counts in f32
