@@ -665,7 +665,8 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
             if (dev_alloc(ctx, &w.seg_slot, batch * std::max<int64_t>(stride, 1))) return 1;
             if (dev_alloc(ctx, &w.seg_cnt, batch * std::max<int64_t>(stride / 64, 1))) return 1;
             if (dev_alloc(ctx, &w.dist_slow, drows * std::max<int64_t>(stride, 1))) return 1;
-            if (dev_alloc(ctx, &w.slow_list, 2 * batch)) return 1;  // the list, then what is known about its entries (SelectArgs.slow_hint)
+            if (dev_alloc(ctx, &w.slow_list, 3 * batch)) return 1;  // the list, what is known about its entries (SelectArgs.slow_hint), and the
+                                                                    // list of what the clustered route's phase 4 forwards to the general selection
         }
         if (dev_alloc(ctx, &w.route_list, 3 * batch)) return 1;
         if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
@@ -673,7 +674,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         // one block for every per-batch counter, cleared by one memset: [0..3] size-class counts,
         // [4..6] the sweep launches' work cursors, [7] the lean sweep's pool cursor, [8] routed, [9] top-up list, [10] overflow,
         // [11] the lean top-down kernel's cursor, [12..14] routed queries by size class, [16..19] the largest size class of the
-        // small teams split four ways (sweep_lean.hip takes the longest jobs first)
+        // small teams split four ways (sweep_lean.hip takes the longest jobs first), [20] what the clustered route's top-up phase forwards
         if (dev_alloc(ctx, &w.cls_count, 32)) return 1;
         w.route_count = w.cls_count + 8;
         w.slow_count = w.cls_count + 9;
@@ -1055,12 +1056,13 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     // The queries on the top-up / slow list get full distance rows; a slim workspace holds rows for a slice of the batch
     // only: the list's length comes to the host (one short wait per batch) and the list is walked in slices of that many
     // queries.  fn(list, count pointer, entries at most) runs the listed distance pass + selection for one slice.
-    auto for_slow_slices = [&](int64_t nq, auto fn) -> int {
+    auto for_slow_slices = [&](int64_t nq, auto fn, const int32_t *list = nullptr, const int32_t *count = nullptr) -> int {
         Workspace &w = ctx->ws;
         hipStream_t front = ctx->stream;
-        if (w.dist_rows >= nq) return fn(w.slow_list, w.slow_count, nq);
+        if (!list) { list = w.slow_list; count = w.slow_count; }
+        if (w.dist_rows >= nq) return fn(list, count, nq);
         int32_t hcnt = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&hcnt, w.slow_count, sizeof(int32_t), hipMemcpyDeviceToHost, front));
+        HIP_TRY(ctx, hipMemcpyAsync(&hcnt, count, sizeof(int32_t), hipMemcpyDeviceToHost, front));
         HIP_TRY(ctx, hipStreamSynchronize(front));
         const int64_t R = w.dist_rows;
         int32_t lens[64];
@@ -1073,7 +1075,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             HIP_TRY(ctx, hipStreamSynchronize(front));  // (lens is on the stack)
         }
         for (int k = 0; k < n_sl; ++k)
-            if (fn(w.slow_list + (int64_t)k * R, n_sl > 1 ? ctx->d_slice_cnt + k : w.slow_count, lens[k])) return 1;
+            if (fn(list + (int64_t)k * R, n_sl > 1 ? ctx->d_slice_cnt + k : count, lens[k])) return 1;
         return 0;
     };
     for (int64_t i = 0; i < n_sub; ++i) {
@@ -1120,16 +1122,24 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 sa.cl_items = ctx->cl_items; sa.cl_tiles = ctx->cl_tiles; sa.cl_tiles_cap = ctx->cl_tiles_cap;
             }
             if (launch_select_clusters(ctx, sa, nq)) return 1;
-            // queries whose accepted clusters hold fewer than -b valid distances: full rows + general selection
+            // queries whose accepted clusters hold fewer than -b valid distances: the top-up rule over the representatives
+            // (phase 4 of k_select_clusters); what that cannot hold: full rows + general selection
+            static const bool no_listed = getenv("APPLES_NO_CLUSTER_TOPUP") != nullptr;  // diagnostic knob: everything through the general route
+            int32_t *fwd_list = w.slow_list + 2 * w.batch, *fwd_count = w.cls_count + 20;
+            if (!no_listed) {
+                sa.rep_panel = a.rep_packed; sa.slow2_list = fwd_list; sa.slow2_count = fwd_count;
+                sa.qlist = w.slow_list; sa.qcount = w.slow_count; sa.qhint = w.slow_list + w.batch;
+                if (launch_select_clusters_listed(ctx, sa, nq)) return 1;
+            }
             sa.seg_lut = nullptr;
             sa.dist = w.dist_slow;
             if (for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
                     if (launch_counts_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow, nullptr, nullptr)) return 1;
                     sa.qlist = lst;
                     sa.qcount = cntp;
-                    sa.qhint = lst + w.batch;
+                    sa.qhint = no_listed ? lst + w.batch : nullptr;
                     return launch_select(ctx, sa, n_max);
-                })) return 1;
+                }, no_listed ? nullptr : fwd_list, no_listed ? nullptr : fwd_count)) return 1;
             HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else if (sfused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));

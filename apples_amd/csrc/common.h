@@ -315,6 +315,9 @@ struct SelectArgs {
     int4 *cl_tiles;           // (cluster, first item, items, -)
     int64_t cl_tiles_cap;
     const int32_t *lvl_slots; // see DevAlign
+    // phase 4 of k_select_clusters (the slow list of the clustered fast path): the representative panel ([(g, plane)][rep_stride]),
+    // and where it forwards what it cannot serve (then full rows + k_select)
+    const uint4 *rep_panel; int32_t *slow2_list, *slow2_count;
     int rep_cache;            // k_select, clustered rows: representatives whose distances are staged in LDS (set by the launcher; 0 = none)
     int64_t n_rows_plain;     // k_select / k_select_stream without a list: rows to select (set by the launcher; the grid may be smaller)
 };
@@ -322,6 +325,7 @@ int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_topup(apples_ctx *ctx, const SelectArgs &a, int64_t nq);
 int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq);  // needs n_members <= SELECT_CLUSTERS_MAX_SLOTS
+int launch_select_clusters_listed(apples_ctx *ctx, const SelectArgs &a, int64_t nq_max);  // its slow list (qlist / qcount / qhint), top-up rule included
 #define SELECT_CLUSTERS_ACC_CAP 512   // accepted clusters per query on the fast path (more: the query takes the general route)
 #define SELECT_CLUSTERS_MIN_TILE 16   // fewest queries a full tile of k_cluster_dist holds
 #define SELECT_CLUSTERS_MAX_SLOTS 229376

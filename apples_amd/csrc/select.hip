@@ -550,17 +550,19 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
     __shared__ double sh_d[8];
-    __shared__ uint4 sh_q[PHASE == 0 ? 64 * 3 : 1];
+    __shared__ uint4 sh_q[(PHASE == 0 || PHASE == 4) ? 64 * 3 : 1];
     __shared__ int sh_rep[ACC_CAP];
     __shared__ int sh_off[ACC_CAP + 1];
     __shared__ int sh_mb[ACC_CAP];  // first member (index into mem_slot / the cluster-major panel) of every accepted cluster
     __shared__ int sh_znode, sh_nacc;
-    const int64_t q = blockIdx.x;
+    if (PHASE == 4 && (int)blockIdx.x >= *a.qcount) return;  // (phase 4: a workgroup per entry of the slow list)
+    const int64_t q = PHASE == 4 ? a.qlist[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
     const int G = a.G;
     const int64_t nm = a.n_members;
     const int n_words = (int)((nm + 63) >> 6);
     uint16_t *pre = reinterpret_cast<uint16_t *>(dyn_bits + n_words);
+    double *reprow = reinterpret_cast<double *>(dyn_bits + n_words + (n_words + 3) / 4);  // phase 4: the query's distance to every representative
     const int self = a.self_slot ? a.self_slot[q] : -1;
     int32_t *o_node = a.obs_node + q * a.obs_cap;
     double *o_dist = a.obs_dist + q * a.obs_cap;
@@ -573,21 +575,59 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
             a.n_obs[q] = 0;
         }
     };
-    if (PHASE == 0) {
+    auto forward = [&]() {  // phase 4 cannot serve the query: the general route (full rows + k_select) takes it
+        if (tid == 0) a.slow2_list[atomicAdd(a.slow2_count, 1)] = (int32_t)q;
+    };
+    if (PHASE == 4 && (a.qhint[blockIdx.x] < 0 || !a.rep_cache)) { forward(); return; }
+    if (PHASE == 0 || PHASE == 4) {
         // the query's packed words (tile layout of pack.hip: [(q/16)*G + g][q%16][plane])
         for (int i = tid; i < G * 3; i += APPLES_TPB) {
             const int g = i / 3, pl = i % 3;
             sh_q[i] = a.qpacked[(((q >> 4) * G + g) * 16 + (q & 15)) * 3 + pl];
         }
     }
-    if (PHASE == 0 || PHASE == 3)
+    if (PHASE == 0 || PHASE >= 3)
         for (int i = tid; i < n_words; i += APPLES_TPB) dyn_bits[i] = 0;
+    // a member's (or representative's) distance from its words: word (g, plane) at base[(g * 3 + plane) * stride] -- the
+    // cluster-major panel with the cluster's size as stride (the lanes holding consecutive members read consecutive 16
+    // bytes), or the representative panel with its padded length
+    auto by_query = [&](const uint4 *row, int64_t sz) -> double {
+        uint32_t nv = 0, nmis = 0;
+        int g = 0;
+        for (; g + CLUSTER_UNROLL <= G; g += CLUSTER_UNROLL) {  // 3 x CLUSTER_UNROLL loads in flight before the first is used
+            uint4 w[3 * CLUSTER_UNROLL];
+#pragma unroll
+            for (int k = 0; k < 3 * CLUSTER_UNROLL; ++k) w[k] = row[(int64_t)(g * 3 + k) * sz];
+#pragma unroll
+            for (int k = 0; k < CLUSTER_UNROLL; ++k)
+                cluster_count(w[3 * k], w[3 * k + 1], w[3 * k + 2], sh_q[(g + k) * 3], sh_q[(g + k) * 3 + 1], sh_q[(g + k) * 3 + 2], nv, nmis);
+        }
+        for (; g < G; ++g)
+            cluster_count(row[(int64_t)(g * 3) * sz], row[(int64_t)(g * 3 + 1) * sz], row[(int64_t)(g * 3 + 2) * sz], sh_q[g * 3],
+                          sh_q[g * 3 + 1], sh_q[g * 3 + 2], nv, nmis);
+        return a.seg_lut[(int64_t)nv * (nv + 1) / 2 + nmis];
+    };
     // ---- accepted representatives: the survivors of the representative pass, in representative order
     const int64_t n_seg = a.rep_stride >> 6;
     const int32_t *cnt = a.seg_cnt + q * n_seg;
     const int32_t *sslot = a.seg_slot + q * a.rep_stride;
     int base = 0;
     bool overflow = false;
+    if (PHASE == 4) {
+        // (phase 4 wants the distance to EVERY representative -- the top-up rule walks on beyond the threshold -- and computes
+        // them itself: same pair counts, same table, so the ones inside the threshold are the survivors the other phases read)
+        __syncthreads();  // sh_q
+        for (int64_t j0 = 0; j0 < a.n_reps; j0 += APPLES_TPB) {
+            const int64_t j = j0 + tid;
+            const double d = j < a.n_reps ? by_query(a.rep_panel + j, a.rep_stride) : -1.0;
+            if (j < a.n_reps) reprow[j] = d;
+            const int in = j < a.n_reps && d >= 0 && d <= a.thr;
+            int tot;
+            const int at = base + block_excl_scan(in, sh_i, &tot);
+            if (in && at < ACC_CAP) sh_rep[at] = (int)j;
+            base += tot;
+        }
+    } else
     for (int64_t s0 = 0; s0 < n_seg; s0 += APPLES_TPB) {
         const int64_t s = s0 + tid;
         const int my = s < n_seg ? cnt[s] : 0;
@@ -608,6 +648,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     const int n_acc = sh_nacc;
     if (n_acc > ACC_CAP || __syncthreads_or(overflow ? 1 : 0)) {
         if (PHASE <= 1) to_slow(-1);  // (once: the later phases just leave the query alone)
+        if (PHASE == 4) forward();
         return;
     }
     if (PHASE == 1) {  // one more query for every accepted cluster
@@ -636,12 +677,57 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
         }
         return;
     }
-    const int M = sh_off[n_acc];
+    int M = sh_off[n_acc];
+    int n_acc_all = n_acc;  // (phase 4: grows with the clusters the top-up rule accepts)
+    if (PHASE == 4) {
+        // ---- the members' distances (a thread per member), then Reference.py:144-152: while fewer than `-b` valid member
+        // distances are in, the representative with the next smallest (distance, index) beyond the threshold brings its cluster
+        int c = 0;
+        for (int m = tid; m < M; m += APPLES_TPB) {
+            int lo = 0, hi = n_acc;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (sh_off[mid] <= m) lo = mid; else hi = mid;
+            }
+            const double d = by_query(a.packed_rm + (int64_t)sh_mb[lo] * (G * 3) + (m - sh_off[lo]), sh_off[lo + 1] - sh_off[lo]);
+            tmp[m] = d;
+            c += !(d < 0);
+        }
+        int obs = block_sum(c, sh_i);
+        double cut_d = -INF_D;
+        int cut_i = -1;
+        while (obs < a.baseobs) {
+            double bd = INF_D;
+            int bi = 0x7fffffff, bj = 0;
+            for (int64_t j = tid; j < a.n_reps; j += APPLES_TPB) {
+                const double d = reprow[j];
+                if (d > a.thr && key_lt(cut_d, cut_i, d, (int)j) && key_lt(d, (int)j, bd, bi)) { bd = d; bi = (int)j; }
+            }
+            block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
+            if (bi == 0x7fffffff) break;  // nothing left
+            cut_d = bd;
+            cut_i = bi;
+            if (n_acc_all == ACC_CAP) { forward(); return; }
+            const int mb0 = a.rep_moff[bi], sz = a.rep_moff[bi + 1] - mb0;
+            __syncthreads();  // (the searches above are done with sh_off)
+            if (tid == 0) { sh_rep[n_acc_all] = bi; sh_mb[n_acc_all] = mb0; sh_off[n_acc_all + 1] = M + sz; }
+            c = 0;
+            for (int mp = tid; mp < sz; mp += APPLES_TPB) {
+                const double d = by_query(a.packed_rm + (int64_t)mb0 * (G * 3) + mp, sz);
+                tmp[M + mp] = d;
+                c += !(d < 0);
+            }
+            obs += block_sum(c, sh_i);
+            M += sz;
+            ++n_acc_all;
+        }
+        __syncthreads();  // tmp and the list are complete
+    }
     // ---- pass 1: one (query, member) distance per thread; E members per thread and round, so that the lookups of a round
     // (member -> slot -> node) are E in flight and not one after the other: the workgroup's time is their latency
     constexpr int E = PHASE == 0 ? 1 : 4;
     auto cluster_of = [&](int m) -> int {  // last accepted cluster whose offset <= m
-        int lo = 0, hi = n_acc;
+        int lo = 0, hi = n_acc_all;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (sh_off[mid] <= m) lo = mid; else hi = mid;
@@ -662,28 +748,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
                 const int lo = cluster_of(m), mp = m - sh_off[lo], mb = sh_mb[lo];
                 lo_[e] = lo;
                 slot_[e] = a.mem_slot[mb + mp];  // (on its way with the member's distance / words below: neither waits for the other)
-                if (PHASE == 3) {
-                    d_[e] = tmp[m];  // k_cluster_dist left it there
-                } else {
-                    // the member's words in the cluster-major panel: word (g, plane) of member mp at (g * 3 + plane) * sz + mp, so
-                    // the lanes holding consecutive members of this cluster read consecutive 16 bytes
-                    const int sz = sh_off[lo + 1] - sh_off[lo];
-                    const uint4 *row = a.packed_rm + (int64_t)mb * (G * 3) + mp;
-                    uint32_t nv = 0, nmis = 0;
-                    int g = 0;
-                    for (; g + CLUSTER_UNROLL <= G; g += CLUSTER_UNROLL) {  // 3 x CLUSTER_UNROLL loads in flight before the first is used
-                        uint4 w[3 * CLUSTER_UNROLL];
-#pragma unroll
-                        for (int k = 0; k < 3 * CLUSTER_UNROLL; ++k) w[k] = row[(int64_t)(g * 3 + k) * sz];
-#pragma unroll
-                        for (int k = 0; k < CLUSTER_UNROLL; ++k)
-                            cluster_count(w[3 * k], w[3 * k + 1], w[3 * k + 2], sh_q[(g + k) * 3], sh_q[(g + k) * 3 + 1], sh_q[(g + k) * 3 + 2], nv, nmis);
-                    }
-                    for (; g < G; ++g)
-                        cluster_count(row[(int64_t)(g * 3) * sz], row[(int64_t)(g * 3 + 1) * sz], row[(int64_t)(g * 3 + 2) * sz], sh_q[g * 3],
-                                      sh_q[g * 3 + 1], sh_q[g * 3 + 2], nv, nmis);
-                    d_[e] = a.seg_lut[(int64_t)nv * (nv + 1) / 2 + nmis];
-                }
+                if (PHASE >= 3) d_[e] = tmp[m];  // k_cluster_dist (phase 4: the block above) left it there
+                else d_[e] = by_query(a.packed_rm + (int64_t)mb * (G * 3) + mp, sh_off[lo + 1] - sh_off[lo]);
             }
         }
 #pragma unroll
@@ -704,8 +770,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
                     if (d == 0) {
                         // (rare: the representative's own distance is looked up again among the survivors of its segment)
                         const int rep = sh_rep[lo], mp = m - sh_off[lo];
-                        double drep = 0.0;
-                        for (int k = 0; k < cnt[rep >> 6]; ++k) {
+                        double drep = PHASE == 4 ? reprow[rep] : 0.0;
+                        for (int k = 0; PHASE != 4 && k < cnt[rep >> 6]; ++k) {
                             const uint32_t pk = (uint32_t)sslot[(int64_t)(rep >> 6) * 64 + k];
                             if ((int)(pk >> 26) == (rep & 63)) {
                                 const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
@@ -726,7 +792,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
         }
     }
     const int obs = block_sum(obs_cnt, sh_i);
-    if (obs < a.baseobs) { to_slow(obs); return; }  // the reference would pop further clusters (Reference.py:146)
+    if (PHASE != 4 && obs < a.baseobs) { to_slow(obs); return; }  // the reference would pop further clusters (Reference.py:146): phase 4 did
     // ---- ranks of the slot bitmap: a thread counts its run of 16 words, one scan over the threads
     int n_emit;
     {
@@ -935,6 +1001,23 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     static const int per_cu = getenv("APPLES_CLUSTER_WGS") ? atoi(getenv("APPLES_CLUSTER_WGS")) : 8;  // tuning knob
     hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_select_clusters<3>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// The slow list of the clustered fast path (fewer than `-b` valid member distances inside the threshold): phase 4 computes the
+// query's distance to every representative, walks the top-up rule over them and expands the clusters it accepts -- a few
+// thousand pair counts per query where the general route computes a full row of the reference first.  What it cannot
+// hold (more than ACC_CAP clusters, representatives beyond its LDS row) it forwards to that route.
+int launch_select_clusters_listed(apples_ctx *ctx, const SelectArgs &a, int64_t nq_max) {
+    if (nq_max == 0) return 0;
+    SelectArgs b = a;
+    const size_t n_words = (size_t)((a.n_members + 63) >> 6);
+    b.rep_cache = a.n_reps <= 8192 ? 1 : 0;
+    const size_t dyn = (n_words + (n_words + 3) / 4 + (b.rep_cache ? (size_t)a.n_reps : 0)) * 8;
+    if (dyn > 48 * 1024)  // (beyond the default allowance of dynamic LDS; per device, so asked for at every launch)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL(k_select_clusters<4>, dim3((unsigned)nq_max), dim3(APPLES_TPB), dyn, ctx->stream, b);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -370,6 +370,34 @@ def test_cluster_major_member_distances_on_awkward_cluster_sizes(c2, monkeypatch
     assert (want['n_obs'] > 300).sum() > nq // 2  # whole big clusters were accepted
 
 
+@pytest.mark.parametrize('thr,baseobs', [(0.02, 25), (0.05, 200), (0.0, 5)])
+def test_clustered_top_up_rule_over_the_representatives(c2, thr, baseobs, monkeypatch):
+    """Queries with fewer than `-b` valid member distances inside the threshold (apples/Reference.py:144-152: the heap walk goes
+    on beyond the threshold) are served by phase 4 of k_select_clusters: distances to every representative, the next
+    smallest (distance, index) until `-b` is reached, the clusters those accept.  A tight threshold sends most queries there.
+    Against the C oracle byte for byte, and against the general route (full rows + k_select, APPLES_NO_FUSE)."""
+    from apples_amd import treecluster
+    from apples_amd.fasta import Alignment
+    from apples_amd.reference import ReducedReference
+    d, nodes = c2
+    ref = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, 0.2 * 1.2))
+    ca = ref.cluster_arrays()
+    nq = 600
+    co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', criterion='MLSE', threshold=thr, baseobs=baseobs,
+                 lut=jc69_lut(1000, 0.001), threads=len(os.sched_getaffinity(0)))
+    want = co.place_sequences(d.query_seqs[:nq])
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', criterion='MLSE', threshold=thr, baseobs=baseobs)
+    assert eng.describe()['cluster_fused']
+    got = eng.place_sequences(d.query_seqs[:nq])
+    eng.close()
+    _compare(got, want, co, d, nodes, 'clustered top-up thr %g b %d' % (thr, baseobs))
+    monkeypatch.setenv('APPLES_NO_FUSE', '1')
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', criterion='MLSE', threshold=thr, baseobs=baseobs)
+    gen = eng.place_sequences(d.query_seqs[:nq])
+    eng.close()
+    assert gen.tobytes() == got.tobytes()
+
+
 @pytest.mark.parametrize('L', [4097, 8190])
 def test_long_alignments_through_the_fused_matrix_core_pass(L):
     """The fused distance pass packs (valid, mism) into 13-bit fields and counts in f32
