@@ -33,19 +33,21 @@ __device__ __forceinline__ double shfl_down_f64(double v, int delta) {
     return __hiloint2double(hi, lo);
 }
 
-// block-wide sum of an int; result valid in every thread
-__device__ int block_sum(int v, int *sh /*[4+]*/) {
+// block-wide sum of an int; result valid in every thread (NW = the workgroup's wavefronts; sh holds NW entries)
+template <int NW = APPLES_TPB / WAVE>
+__device__ int block_sum(int v, int *sh) {
     for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
     int w = threadIdx.x / WAVE;
     __syncthreads();
     if ((threadIdx.x & (WAVE - 1)) == 0) sh[w] = v;
     __syncthreads();
     int s = 0;
-    for (int k = 0; k < APPLES_TPB / WAVE; ++k) s += sh[k];
+    for (int k = 0; k < NW; ++k) s += sh[k];
     return s;
 }
 
 // block-wide lexicographic arg-min over (d, i, j); result valid in every thread
+template <int NW = APPLES_TPB / WAVE>
 __device__ void block_argmin3(double &d, int &i, int &j, double *shd, int *shi, int *shj) {
     for (int o = WAVE / 2; o > 0; o >>= 1) {
         double d2 = shfl_down_f64(d, o);
@@ -58,7 +60,7 @@ __device__ void block_argmin3(double &d, int &i, int &j, double *shd, int *shi, 
     if ((threadIdx.x & (WAVE - 1)) == 0) { shd[w] = d; shi[w] = i; shj[w] = j; }
     __syncthreads();
     d = shd[0]; i = shi[0]; j = shj[0];
-    for (int k = 1; k < APPLES_TPB / WAVE; ++k) {
+    for (int k = 1; k < NW; ++k) {
         double d2 = shd[k]; int i2 = shi[k], j2 = shj[k];
         if (d2 < d || (d2 == d && (i2 < i || (i2 == i && j2 < j)))) { d = d2; i = i2; j = j2; }
     }
@@ -82,7 +84,8 @@ __device__ int block_excl_scan(int flag, int *sh /*[4+]*/, int *tot) {
 }
 
 // exclusive prefix sum of an int across the block; returns this thread's offset, total in *tot
-__device__ int block_excl_scan_int(int v, int *sh /*[4+]*/, int *tot) {
+template <int NW = APPLES_TPB / WAVE>
+__device__ int block_excl_scan_int(int v, int *sh, int *tot) {
     int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     int incl = v;
     for (int o = 1; o < WAVE; o <<= 1) {
@@ -93,7 +96,7 @@ __device__ int block_excl_scan_int(int v, int *sh /*[4+]*/, int *tot) {
     if (lane == WAVE - 1) sh[w] = incl;
     __syncthreads();
     int base = 0, t = 0;
-    for (int k = 0; k < APPLES_TPB / WAVE; ++k) {
+    for (int k = 0; k < NW; ++k) {
         if (k < w) base += sh[k];
         t += sh[k];
     }
@@ -129,11 +132,13 @@ __device__ __forceinline__ void enlist(const SelectArgs &a, int64_t q, int ne) {
 #ifndef SELECT_E
 #define SELECT_E 8  // slots per thread and round of the compaction pass (their loads are in flight together; 16: no faster)
 #endif
-__global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
+    constexpr int NW = TPB / WAVE;
     extern __shared__ double dyn_drep[];  // clustered rows: the row's distances to the representatives (a.rep_cache of them)
-    __shared__ int sh_i[8];
-    __shared__ int sh_j[8];
-    __shared__ double sh_d[8];
+    __shared__ int sh_i[NW];
+    __shared__ int sh_j[NW];
+    __shared__ double sh_d[NW];
     // listed mode (top-up path): a fixed grid walks the device-side list; entry r names query
     // qlist[r], whose distances are row r
     const int64_t n_list = a.qcount ? (int64_t)*a.qcount : a.n_rows_plain;
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     // compaction pass below waits for one level of loads per slot and not for slot -> representative -> slot -> distance
 #define DREP(ri) (a.rep_cache ? dyn_drep[(ri)] : DIST(a.rep_slot[(ri)]))
     if (a.rep_cache && !single) {
-        for (int64_t ri = tid; ri < a.n_reps; ri += APPLES_TPB) dyn_drep[ri] = DIST(a.rep_slot[ri]);
+        for (int64_t ri = tid; ri < a.n_reps; ri += TPB) dyn_drep[ri] = DIST(a.rep_slot[ri]);
         __syncthreads();
     }
 
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
             filled = 0;
             head = 0;
             int seen = 0;
-            for (int64_t s = tid; s < n_items; s += APPLES_TPB) {
+            for (int64_t s = tid; s < n_items; s += TPB) {
                 double d;
                 int i;
                 if (single) {
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
             double bd = head < filled ? cd[head] : INF_D;
             int bi = head < filled ? ci[head] : 0x7fffffff, bj = 0;
             const int mine = bi;
-            block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
+            block_argmin3<NW>(bd, bi, bj, sh_d, sh_i, sh_j);
             if (bi == 0x7fffffff) break;  // nothing left
             if (mine == bi && head < filled) ++head;
             cut_d = bd;
@@ -232,8 +237,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
             if (single) obs += 1;
             else {
                 int c = 0;
-                for (int m = a.rep_moff[bi] + tid; m < a.rep_moff[bi + 1]; m += APPLES_TPB) c += !(DIST(a.mem_slot[m]) < 0);
-                obs += block_sum(c, sh_i);
+                for (int m = a.rep_moff[bi] + tid; m < a.rep_moff[bi + 1]; m += TPB) c += !(DIST(a.mem_slot[m]) < 0);
+                obs += block_sum<NW>(c, sh_i);
             }
         }
     }
@@ -245,28 +250,64 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
     z_d = INF_D; z_i = 0x7fffffff; z_p = 0x7fffffff; z_node = -2;
     int thr_cnt = 0;  // observations inside the threshold (the obs_num the top-up rule looks at)
     constexpr int E = SELECT_E;
-    for (int64_t s0 = 0; s0 <= nm; s0 += (int64_t)APPLES_TPB * E) {
+    static_assert(E % 4 == 0, "the compaction pass loads its slots four at a time");
+    // a thread's E consecutive slots come in 16-byte pieces (a wavefront's load instruction then covers whole cache lines:
+    // with one 4- or 8-byte element per lane at a stride of E elements the pass is bound by the rate of line requests, not by
+    // latency -- 24 us per 8 192 slots); rows whose start is not 16-byte aligned and gathered rows take the plain loads
+    const bool vec_ok = !gather && (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+    for (int64_t s0 = 0; s0 <= nm; s0 += (int64_t)TPB * E) {
         const int64_t sb = s0 + (int64_t)tid * E;
-        int emit[E], node[E];
+        int emit[E], node[E], v_rep[E], v_mp[E], v_lv[E];
         double dm[E];
+        if (vec_ok && sb + E <= nm) {
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                const int4 t = *reinterpret_cast<const int4 *>(a.slot_node + sb + 4 * k);
+                node[4 * k] = t.x; node[4 * k + 1] = t.y; node[4 * k + 2] = t.z; node[4 * k + 3] = t.w;
+                const int4 r = *reinterpret_cast<const int4 *>(a.slot_rep + sb + 4 * k);
+                v_rep[4 * k] = r.x; v_rep[4 * k + 1] = r.y; v_rep[4 * k + 2] = r.z; v_rep[4 * k + 3] = r.w;
+                int4 m = make_int4(0, 0, 0, 0), l = make_int4(0, 0, 0, 0);
+                if (!single) m = *reinterpret_cast<const int4 *>(a.slot_mpos + sb + 4 * k);
+                if (cg) l = *reinterpret_cast<const int4 *>(a.slot_level + sb + 4 * k);
+                v_mp[4 * k] = m.x; v_mp[4 * k + 1] = m.y; v_mp[4 * k + 2] = m.z; v_mp[4 * k + 3] = m.w;
+                v_lv[4 * k] = l.x; v_lv[4 * k + 1] = l.y; v_lv[4 * k + 2] = l.z; v_lv[4 * k + 3] = l.w;
+            }
+#pragma unroll
+            for (int k = 0; k < E / 2; ++k) {
+                const double2 t = *reinterpret_cast<const double2 *>(row + sb + 2 * k);
+                dm[2 * k] = t.x; dm[2 * k + 1] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int64_t s = sb + e;
+                node[e] = -1; dm[e] = -1.0; v_rep[e] = 0; v_mp[e] = 0; v_lv[e] = -1;
+                if (s < nm) {
+                    node[e] = a.slot_node[s];
+                    dm[e] = DIST(s);
+                    v_rep[e] = a.slot_rep[s];
+                    if (!single) v_mp[e] = a.slot_mpos[s];
+                    if (cg) v_lv[e] = a.slot_level[s];
+                }
+            }
+        }
+        const int lv_before = (cg && sb > 0 && sb <= nm) ? a.slot_level[sb - 1] : a.height + 1;  // level of the slot before this thread's first
         int n_emit_l = 0;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int64_t s = sb + e;
-            emit[e] = 0; node[e] = -1; dm[e] = -1.0;
+            emit[e] = 0;
             if (s < nm) {
-                node[e] = a.slot_node[s];
-                dm[e] = DIST(s);
                 bool in_dict;
                 double drep;
-                int ri, mp;
+                int ri = v_rep[e], mp;  // (table input: slot_rep holds the column of the slot)
                 if (single) {
-                    drep = dm[e]; ri = SLOT_KEYIDX(s); mp = 0;
+                    drep = dm[e]; mp = 0;
                     const bool ok = (dm[e] >= 0) && !(table && node[e] < 0);
                     thr_cnt += ok && dm[e] <= thr;
                     in_dict = ok && (dm[e] <= thr || key_le(dm[e], ri, cut_d, cut_i));
                 } else {
-                    ri = a.slot_rep[s]; mp = a.slot_mpos[s];
+                    mp = v_mp[e];
                     drep = DREP(ri);
                     const bool member_ok = !(dm[e] < 0);
                     thr_cnt += (drep >= 0) && (drep <= thr) && member_ok;
@@ -283,13 +324,13 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
             n_emit_l += emit[e];
         }
         int tot;
-        int pos = base + block_excl_scan_int(n_emit_l, sh_i, &tot);
+        int pos = base + block_excl_scan_int<NW>(n_emit_l, sh_i, &tot);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int64_t s = sb + e;
             if (cg && s <= nm) {  // level boundaries (virtual end slot nm has level -1)
-                int lv = (s < nm) ? a.slot_level[s] : -1;
-                int lprev = (s == 0) ? a.height + 1 : a.slot_level[s - 1];
+                const int lv = (s < nm) ? v_lv[e] : -1;
+                const int lprev = e == 0 ? lv_before : v_lv[e - 1];
                 for (int l = lv; l < lprev; ++l) cg[l + 1] = pos;
             }
             if (emit[e]) { o_node[pos] = node[e]; o_dist[pos] = dm[e]; ++pos; }
@@ -297,16 +338,16 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select(SelectArgs a) {
         base += tot;
     }
     if (!have_obs) {  // first round: was the threshold set large enough?
-        obs = block_sum(thr_cnt, sh_i);
+        obs = block_sum<NW>(thr_cnt, sh_i);
         have_obs = true;
         if (obs < a.baseobs) continue;  // no: apply the top-up rule and compact again
     }
     break;
     }  // round
-    n_total = block_sum(n_total, sh_i);
+    n_total = block_sum<NW>(n_total, sh_i);
     // pack (z_i, z_p) is not needed beyond ordering; carry the node through a second reduction
     double zd = z_d; int zi = z_i, zp = z_p;
-    block_argmin3(zd, zi, zp, sh_d, sh_i, sh_j);
+    block_argmin3<NW>(zd, zi, zp, sh_d, sh_i, sh_j);
     __shared__ int sh_znode;
     if (tid == 0) sh_znode = -2;
     __syncthreads();
@@ -369,8 +410,12 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     if (flat) {
         const int K = (int)((n_seg + APPLES_TPB - 1) / APPLES_TPB);
         const int64_t s_lo = (int64_t)tid * K, s_hi = s_lo + K < n_seg ? s_lo + K : n_seg;
+        // (the counts come in coalesced and are summed out of LDS: a thread reading its K consecutive counts from memory is K
+        // load instructions of 64 cache lines each)
+        for (int64_t s = tid; s < n_seg; s += APPLES_TPB) dyn_pref[s] = cnt[s];
+        __syncthreads();
         int local = 0;
-        for (int64_t s = s_lo; s < s_hi; ++s) { const int v = cnt[s]; dyn_pref[s] = local; local += v; }
+        for (int64_t s = s_lo; s < s_hi; ++s) { const int v = dyn_pref[s]; dyn_pref[s] = local; local += v; }
         const int at = block_excl_scan_int(local, sh_i, &total);
         for (int64_t s = s_lo; s < s_hi; ++s) dyn_pref[s] += at;
         if (tid == 0) dyn_pref[n_seg] = total;
@@ -555,7 +600,14 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     __shared__ int sh_off[ACC_CAP + 1];
     __shared__ int sh_mb[ACC_CAP];  // first member (index into mem_slot / the cluster-major panel) of every accepted cluster
     __shared__ int sh_znode, sh_nacc;
-    if (PHASE == 4 && (int)blockIdx.x >= *a.qcount) return;  // (phase 4: a workgroup per entry of the slow list)
+    if (PHASE == 4) {
+        // phase 4: a workgroup per entry of the slow list, up to the grid (the launcher does not know the list's length and a
+        // workgroup holds 80 KB of LDS: one grid's worth is served here, entries beyond it go on to the general route)
+        const int n_list = *a.qcount;
+        if (threadIdx.x == 0)
+            for (int r2 = blockIdx.x + gridDim.x; r2 < n_list; r2 += gridDim.x) a.slow2_list[atomicAdd(a.slow2_count, 1)] = a.qlist[r2];
+        if ((int)blockIdx.x >= n_list) return;
+    }
     const int64_t q = PHASE == 4 ? a.qlist[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
     const int G = a.G;
@@ -1017,7 +1069,7 @@ int launch_select_clusters_listed(apples_ctx *ctx, const SelectArgs &a, int64_t 
     const size_t dyn = (n_words + (n_words + 3) / 4 + (b.rep_cache ? (size_t)a.n_reps : 0)) * 8;
     if (dyn > 48 * 1024)  // (beyond the default allowance of dynamic LDS; per device, so asked for at every launch)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    hipLaunchKernelGGL(k_select_clusters<4>, dim3((unsigned)nq_max), dim3(APPLES_TPB), dyn, ctx->stream, b);
+    hipLaunchKernelGGL(k_select_clusters<4>, dim3((unsigned)std::min<int64_t>(nq_max, 1024)), dim3(APPLES_TPB), dyn, ctx->stream, b);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -1602,7 +1654,11 @@ int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     else {
         // clustered rows: the representatives' distances in LDS where they fit (48 KB: 6 144 of them)
         b.rep_cache = (!a.all_singleton && a.n_reps > 0 && a.n_reps <= 6144) ? 1 : 0;
-        hipLaunchKernelGGL(k_select, dim3(grid), dim3(APPLES_TPB), b.rep_cache ? (size_t)a.n_reps * sizeof(double) : 0, ctx->stream, b);
+        // a listed row is one workgroup's job and its time is that workgroup's latency (a few hundred rows per batch at most, far
+        // fewer than the chip holds): 1 024 threads per row there, a quarter of the rounds
+        const size_t dyn = b.rep_cache ? (size_t)a.n_reps * sizeof(double) : 0;
+        if (a.qcount) hipLaunchKernelGGL(k_select<1024>, dim3(grid), dim3(1024), dyn, ctx->stream, b);
+        else hipLaunchKernelGGL(k_select<APPLES_TPB>, dim3(grid), dim3(APPLES_TPB), dyn, ctx->stream, b);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
