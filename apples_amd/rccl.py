@@ -17,6 +17,7 @@ import struct
 import time
 
 NCCL_UINT8 = 1
+_PORT_SPAN = 16  # ports tried for the side channel, from MASTER_PORT + 1
 
 
 class _UniqueId(C.Structure):
@@ -34,8 +35,119 @@ def _lib(name, env):
     raise RuntimeError('%s not found (set %s)' % (name, env))
 
 
+class SideChannel:
+    """The TCP side channel through rank 0: carries one blob from rank 0 to every rank at start-up (the communicator id), then
+    the host-side barrier and the max-over-ranks of the timing.  Plain sockets, no GPU: tests/test_launcher.py runs it with
+    three processes on the CPU.
+
+    It listens on the first free port of MASTER_PORT + 1 .. + 16 (MASTER_PORT itself belongs to whoever launched the ranks);
+    a connection is one of ours only if it opens with this job's greeting, so a rank that reaches somebody else's listener
+    on one of those ports moves on to the next."""
+
+    def __init__(self, rank, world, blob=None, addr=None, port=None, timeout=120.0):
+        self.rank, self.world = int(rank), int(world)
+        addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+        base = int(port or int(os.environ.get('MASTER_PORT', '29500')) + 1)
+        self.peers = []   # rank 0: sockets of ranks 1..world-1, by rank
+        self.sock = None  # other ranks: socket to rank 0
+        self.blob = blob
+        hello = struct.pack('<8sii', b'APPLESRV', self.world, base)
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = None
+            for p in range(base, base + _PORT_SPAN):
+                cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                cand.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    cand.bind((addr, p))
+                    srv = cand
+                    break
+                except OSError:
+                    cand.close()
+            if srv is None:
+                raise RuntimeError('no free port for the rendezvous in %d..%d on %s' % (base, base + _PORT_SPAN - 1, addr))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            got = {}
+            while len(got) < self.world - 1:
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(10.0)
+                try:
+                    if self._recv(conn, len(hello)) != hello:
+                        raise RuntimeError('not a rank of this job')
+                    r = struct.unpack('<i', self._recv(conn, 4))[0]
+                    if not 0 < r < self.world or r in got:
+                        raise RuntimeError('unexpected rank %d' % r)
+                except (RuntimeError, OSError):
+                    conn.close()
+                    continue
+                conn.settimeout(timeout)
+                got[r] = conn
+            srv.close()
+            self.peers = [got[r] for r in range(1, self.world)]
+            for conn in self.peers:
+                conn.sendall(hello + struct.pack('<i', len(blob or b'')) + bytes(blob or b''))
+        else:
+            deadline = time.time() + timeout
+            while self.sock is None:
+                for p in range(base, base + _PORT_SPAN):
+                    try:
+                        s = socket.create_connection((addr, p), timeout=2.0)
+                    except OSError:
+                        continue
+                    try:
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        s.settimeout(timeout)
+                        s.sendall(hello + struct.pack('<i', self.rank))
+                        if self._recv(s, len(hello)) != hello:
+                            raise RuntimeError('not rank 0 of this job')
+                        n = struct.unpack('<i', self._recv(s, 4))[0]
+                        self.blob = self._recv(s, n) if n else b''
+                        self.sock = s
+                        break
+                    except (RuntimeError, OSError):
+                        s.close()
+                if self.sock is None:
+                    if time.time() > deadline:
+                        raise RuntimeError('rank %d found no rank 0 on %s:%d..%d' % (self.rank, addr, base, base + _PORT_SPAN - 1))
+                    time.sleep(0.1)
+
+    @staticmethod
+    def _recv(conn, n):
+        buf = b''
+        while len(buf) < n:
+            part = conn.recv(n - len(buf))
+            if not part:
+                raise RuntimeError('rendezvous peer closed the connection')
+            buf += part
+        return buf
+
+    def max_over_ranks(self, value):
+        """max of one float over the ranks (every rank gets it); doubles as a barrier."""
+        if self.world == 1:
+            return float(value)
+        if self.rank == 0:
+            vals = [float(value)] + [struct.unpack('<d', self._recv(c, 8))[0] for c in self.peers]
+            m = max(vals)
+            for c in self.peers:
+                c.sendall(struct.pack('<d', m))
+            return m
+        self.sock.sendall(struct.pack('<d', float(value)))
+        return struct.unpack('<d', self._recv(self.sock, 8))[0]
+
+    def close(self):
+        for c in self.peers:
+            c.close()
+        self.peers = []
+        if self.sock:
+            self.sock.close()
+            self.sock = None
+
+
 class Comm:
-    """One RCCL communicator over the ranks of one node + a TCP side channel through rank 0."""
+    """One RCCL communicator over the ranks of one node + the TCP side channel through rank 0."""
 
     def __init__(self, rank, world, device, addr=None, port=None, timeout=120.0):
         self.rank, self.world = int(rank), int(world)
@@ -49,59 +161,20 @@ class Comm:
         self.nccl.ncclRecv.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         self.nccl.ncclCommDestroy.argtypes = [C.c_void_p]
         self._check_hip(self.hip.hipSetDevice(int(device)), 'hipSetDevice')
-        addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
-        port = int(port or int(os.environ.get('MASTER_PORT', '29500')) + 1)
         uid = _UniqueId()
-        self.peers = []   # rank 0: sockets of ranks 1..world-1, by rank
-        self.sock = None  # other ranks: socket to rank 0
         if self.rank == 0:
             self._check(self.nccl.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
-            if self.world > 1:
-                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                srv.bind((addr, port))
-                srv.listen(self.world)
-                srv.settimeout(timeout)
-                got = {}
-                while len(got) < self.world - 1:
-                    conn, _ = srv.accept()
-                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    r = struct.unpack('<i', self._recv(conn, 4))[0]
-                    got[r] = conn
-                srv.close()
-                self.peers = [got[r] for r in range(1, self.world)]
-                for conn in self.peers:
-                    conn.sendall(bytes(uid.internal))
-        else:
-            deadline = time.time() + timeout
-            while True:
-                try:
-                    self.sock = socket.create_connection((addr, port), timeout=5.0)
-                    break
-                except OSError:
-                    if time.time() > deadline:
-                        raise
-                    time.sleep(0.1)
-            self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            self.sock.settimeout(timeout)
-            self.sock.sendall(struct.pack('<i', self.rank))
-            C.memmove(C.byref(uid), self._recv(self.sock, 128), 128)
+        self.side = SideChannel(rank, world, bytes(uid.internal) if self.rank == 0 else None, addr, port, timeout)
+        if self.rank != 0:
+            if len(self.side.blob) != 128:
+                raise RuntimeError('rendezvous delivered %d bytes in place of the 128-byte communicator id' % len(self.side.blob))
+            C.memmove(C.byref(uid), self.side.blob, 128)
         self.comm = C.c_void_p()
         self._check(self.nccl.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
         self._recv_buf = C.c_void_p()
         self._recv_cap = 0
 
     # ------------------------------------------------------------------ helpers
-    @staticmethod
-    def _recv(conn, n):
-        buf = b''
-        while len(buf) < n:
-            part = conn.recv(n - len(buf))
-            if not part:
-                raise RuntimeError('rendezvous peer closed the connection')
-            buf += part
-        return buf
-
     def _check(self, rc, what):
         if rc != 0:
             raise RuntimeError('%s failed with ncclResult %d' % (what, rc))
@@ -113,16 +186,7 @@ class Comm:
     # ------------------------------------------------------------------ host-side barrier / reduction through rank 0
     def max_over_ranks(self, value):
         """max of one float over the ranks (every rank gets it); doubles as a barrier."""
-        if self.world == 1:
-            return float(value)
-        if self.rank == 0:
-            vals = [float(value)] + [struct.unpack('<d', self._recv(c, 8))[0] for c in self.peers]
-            m = max(vals)
-            for c in self.peers:
-                c.sendall(struct.pack('<d', m))
-            return m
-        self.sock.sendall(struct.pack('<d', float(value)))
-        return struct.unpack('<d', self._recv(self.sock, 8))[0]
+        return self.side.max_over_ranks(value)
 
     def barrier(self):
         self.max_over_ranks(0.0)
@@ -162,7 +226,4 @@ class Comm:
         if self._recv_buf:
             self.hip.hipFree(self._recv_buf)
             self._recv_buf = C.c_void_p()
-        for c in self.peers:
-            c.close()
-        if self.sock:
-            self.sock.close()
+        self.side.close()

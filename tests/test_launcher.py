@@ -89,3 +89,65 @@ def test_parent_does_not_import_the_engine_or_torch(tmp_path):
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert 'parent imported' not in r.stderr
+
+
+def _side_rank(rank, world, port, q):
+    from apples_amd.rccl import SideChannel
+    try:
+        ch = SideChannel(rank, world, blob=(b'id' * 64 if rank == 0 else None), addr='127.0.0.1', port=port, timeout=30.0)
+        m = ch.max_over_ranks(10.0 + rank)
+        m2 = ch.max_over_ranks(-float(rank))
+        q.put((rank, bytes(ch.blob), m, m2))
+        ch.close()
+    except Exception as e:  # noqa: BLE001 (reported to the parent)
+        q.put((rank, repr(e), None, None))
+
+
+def test_side_channel_rendezvous_skips_a_foreign_listener():
+    """apples_amd/rccl.py's TCP side channel (the communicator id, the barrier and the max-over-ranks travel over it) with
+    three processes on the CPU; the first port of its range is held by somebody else's listener, which answers with
+    something that is not this job's greeting: every rank moves on to the next port."""
+    import multiprocessing as mp
+    import socket
+    import threading
+    from apples_amd.launcher import free_port
+    port = free_port()
+    foreign = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    foreign.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    foreign.bind(('127.0.0.1', port))
+    foreign.listen(8)
+    stop = threading.Event()
+
+    def serve():
+        foreign.settimeout(0.2)
+        while not stop.is_set():
+            try:
+                c, _ = foreign.accept()
+            except OSError:
+                continue
+            try:
+                c.sendall(b'HTTP/1.1 400 Bad Request\r\n\r\n' + b'x' * 64)
+            finally:
+                c.close()
+    th = threading.Thread(target=serve, daemon=True)
+    th.start()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_side_rank, args=(r, world, port, q)) for r in (2, 1, 0)]  # (rank 0 last: the others wait for it)
+    try:
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=60) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.terminate()
+        stop.set()
+        th.join(timeout=2)
+        foreign.close()
+    assert [g[0] for g in got] == [0, 1, 2]
+    for r, blob, m, m2 in got:
+        assert blob == b'id' * 64, (r, blob)
+        assert m == 12.0 and m2 == 0.0
