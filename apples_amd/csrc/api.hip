@@ -1296,8 +1296,9 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
 
 // mmax[valid] as a linear rule in float arithmetic for dist_gemm.hip's epilogue: from the first valid count that
 // admits anything, mmax[valid] = floor(p_f valid) with p_f = 3/4 (1 - exp(-4 f / 3)); the kernel evaluates
-// t = fmaf(8192 valid, slope, off) and keeps 4 mism <= t.  A candidate (slope, off) is accepted only if it
-// reproduces the table for EVERY valid count: 4 mmax <= t < 4 mmax + 4.
+// t = fmaf(8192 valid, slope, off) and keeps 4 mism + 2049 <= t (its accumulators start at -2049, the first addend of
+// the decode, so everything it compares carries that shift and `off` includes it).  A candidate (slope, off) is
+// accepted only if it reproduces the table for EVERY valid count: 4 mmax + 2049 <= t < 4 mmax + 2049 + 4.
 static GemmThreshold gemm_threshold(const std::vector<int32_t> &mmax, double f) {
     GemmThreshold g;
     const int L = (int)mmax.size() - 1;
@@ -1315,11 +1316,11 @@ static GemmThreshold gemm_threshold(const std::vector<int32_t> &mmax, double f) 
         for (float off : offs) {
             bool good = true;
             for (int v = vmin; v <= L && good; ++v) {
-                const float t = std::fmaf(8192.f * (float)v, slope, off);
-                good = 4.f * (float)mmax[v] <= t && t < 4.f * (float)mmax[v] + 4.f;
+                const float t = std::fmaf(8192.f * (float)v, slope, off + 2049.f);
+                good = 4.f * (float)mmax[v] + 2049.f <= t && t < 4.f * (float)mmax[v] + 2049.f + 4.f;
             }
             if (good) {
-                g.slope = slope; g.off = off; g.vmin8 = 8192.f * (float)vmin; g.ok = true;
+                g.slope = slope; g.off = off + 2049.f; g.vmin8 = 8192.f * (float)vmin; g.ok = true;
                 return g;
             }
         }

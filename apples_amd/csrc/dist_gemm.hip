@@ -240,7 +240,7 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+            for (int x = 0; x < 16; ++x) acc[i][j][x] = LIN ? -2049.f : 0.f;  // (LIN: the decode's first addend rides along, see the epilogue)
     // steps 0 and 1 landed (they had the previous tile's epilogue to do so; the epilogue's stores share the counter,
     // hence no counted wait here), the table is written
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -296,7 +296,9 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
     // instruction and the compare's lane mask used as it is; otherwise through the table in LDS (-4 where
     // nothing passes).
     if (LIN) {
-        const v2f_t kA = {-2049.f, -2049.f}, kC = {68719476736.f, 68719476736.f}, kM = {8195.f / 8192.f, 8195.f / 8192.f};
+        // (the accumulators start at -2049, so S below is acc - 2049 already: 8192 valid = (S + 2^36) - 2^36, and
+        // m = 8195 valid - S = 4 mism + 2049 is compared with t = slope * 8192 valid + (off + 2049), the form the host verified)
+        const v2f_t kC = {68719476736.f, 68719476736.f}, kM = {8195.f / 8192.f, 8195.f / 8192.f};
         const v2f_t kS = {lin.slope, lin.slope}, kO = {lin.off, lin.off};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -312,27 +314,28 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
                 for (int xp = 0; xp < 8; ++xp) {
                     const v2f_t S0 = {acc[i][2 * s][2 * xp], acc[i][2 * s][2 * xp + 1]};
                     const v2f_t S1 = {acc[i][2 * s + 1][2 * xp], acc[i][2 * s + 1][2 * xp + 1]};
-                    const v2f_t v0 = ((S0 + kA) + kC) - kC, v1 = ((S1 + kA) + kC) - kC;  // 8192 valid
+                    const v2f_t v0 = (S0 + kC) - kC, v1 = (S1 + kC) - kC;  // 8192 valid
                     const v2f_t m0 = __builtin_elementwise_fma(v0, kM, -S0), m1 = __builtin_elementwise_fma(v1, kM, -S1);  // 4 mism
                     const v2f_t t0 = __builtin_elementwise_fma(v0, kS, kO), t1 = __builtin_elementwise_fma(v1, kS, kO);
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int x = 2 * xp + e, cx = (x & 3) + 8 * (x >> 2);  // this register's query, relative to qbase
-                        const bool in = cx < rem;
-                        const bool c0 = m0[e] <= t0[e] && in, c1 = m1[e] <= t1[e] && in;
+                        // (rows past this launch's queries are looked at only where something passes)
+                        const bool c0 = m0[e] <= t0[e], c1 = m1[e] <= t1[e];
                         if (__ballot(c0 || c1) == 0ull) continue;
-                        const bool k0 = c0 && v0[e] >= lin.vmin8, k1 = c1 && v1[e] >= lin.vmin8;
+                        const bool in = cx < rem;
+                        const bool k0 = c0 && in && v0[e] >= lin.vmin8, k1 = c1 && in && v1[e] >= lin.vmin8;
                         const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
                         if ((b0 | b1) == 0) continue;  // the counts stay at their preset zero
                         // this lane half's query: slots 0..31 of the segment from tile 0, 32..63 from tile 1
                         const uint32_t lo = (uint32_t)(b0 >> (32 * fh)), hi = (uint32_t)(b1 >> (32 * fh));
                         int32_t *row = row0 + (int64_t)cx * slots_pad;
                         if (k0) {
-                            const int valid = (int)(v0[e] * (1.f / 8192.f)), mism = (int)m0[e] >> 2;
+                            const int valid = (int)(v0[e] * (1.f / 8192.f)), mism = ((int)m0[e] - 2049) >> 2;
                             row[__popc(lo & below)] = (int32_t)(((uint32_t)fr << 26) | ((uint32_t)valid << 13) | (uint32_t)mism);
                         }
                         if (k1) {
-                            const int valid = (int)(v1[e] * (1.f / 8192.f)), mism = (int)m1[e] >> 2;
+                            const int valid = (int)(v1[e] * (1.f / 8192.f)), mism = ((int)m1[e] - 2049) >> 2;
                             row[__popc(lo) + __popc(hi & below)] = (int32_t)(((uint32_t)(32 + fr) << 26) | ((uint32_t)valid << 13) | (uint32_t)mism);
                         }
                         if (fr == 0 && in) cnt0[(int64_t)cx * n_seg] = __popc(lo) + __popc(hi);

@@ -136,9 +136,9 @@ template <int TPB>
 __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
     constexpr int NW = TPB / WAVE;
     extern __shared__ double dyn_drep[];  // clustered rows: the row's distances to the representatives (a.rep_cache of them)
-    __shared__ int sh_i[NW];
-    __shared__ int sh_j[NW];
-    __shared__ double sh_d[NW];
+    __shared__ int sh_i[16];
+    __shared__ int sh_j[16];
+    __shared__ double sh_d[16];
     // listed mode (top-up path): a fixed grid walks the device-side list; entry r names query
     // qlist[r], whose distances are row r
     const int64_t n_list = a.qcount ? (int64_t)*a.qcount : a.n_rows_plain;
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
     int cut_i = -1;
     int base = 0, n_total = 0;
     double z_d = INF_D;
-    int z_i = 0x7fffffff, z_p = 0x7fffffff, z_node = -2;
+    int z_i = 0x7fffffff, z_p = 0x7fffffff;
+    int64_t z_s = -1;  // the slot of that first zero (its node is looked up once, at the end)
     int32_t *o_node = a.obs_node + q * a.obs_cap;
     double *o_dist = a.obs_dist + q * a.obs_cap;
     int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
@@ -247,14 +248,18 @@ __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
     base = 0;       // emitted so far
     n_total = 0;    // len(obs_dist) after the self entry is removed
     // first zero distance in dict order: min over (d_rep, rep index, member position)
-    z_d = INF_D; z_i = 0x7fffffff; z_p = 0x7fffffff; z_node = -2;
+    z_d = INF_D; z_i = 0x7fffffff; z_p = 0x7fffffff; z_s = -1;
     int thr_cnt = 0;  // observations inside the threshold (the obs_num the top-up rule looks at)
     constexpr int E = SELECT_E;
     static_assert(E % 4 == 0, "the compaction pass loads its slots four at a time");
     // a thread's E consecutive slots come in 16-byte pieces (a wavefront's load instruction then covers whole cache lines:
     // with one 4- or 8-byte element per lane at a stride of E elements the pass is bound by the rate of line requests, not by
     // latency -- 24 us per 8 192 slots); rows whose start is not 16-byte aligned and gathered rows take the plain loads
+#ifdef SELECT_NO_VEC
+    const bool vec_ok = false;
+#else
     const bool vec_ok = !gather && (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+#endif
     for (int64_t s0 = 0; s0 <= nm; s0 += (int64_t)TPB * E) {
         const int64_t sb = s0 + (int64_t)tid * E;
         int emit[E], node[E], v_rep[E], v_mp[E], v_lv[E];
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
                 if (in_dict && (int)s != self) {
                     n_total++;
                     if (dm[e] == 0 && (drep < z_d || (drep == z_d && (ri < z_i || (ri == z_i && mp < z_p))))) {
-                        z_d = drep; z_i = ri; z_p = mp; z_node = node[e];
+                        z_d = drep; z_i = ri; z_p = mp; z_s = s;
                     }
                     emit[e] = node[e] >= 0;
                 }
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
     __shared__ int sh_znode;
     if (tid == 0) sh_znode = -2;
     __syncthreads();
-    if (z_node != -2 && z_d == zd && z_i == zi && z_p == zp) sh_znode = z_node;
+    if (z_s >= 0 && z_d == zd && z_i == zi && z_p == zp) sh_znode = a.slot_node[z_s];
     __syncthreads();
 
     if (tid == 0) {

@@ -398,6 +398,31 @@ def test_clustered_top_up_rule_over_the_representatives(c2, thr, baseobs, monkey
     assert gen.tobytes() == got.tobytes()
 
 
+@pytest.mark.parametrize('no_fuse', [False, True])
+def test_exact_matches_among_the_members_of_one_cluster(no_fuse, monkeypatch):
+    """Short branches: many queries are identical to a reference, and some to TWO references of the same cluster -- the
+    reference reports the first zero in dict order (PoolQueryWorker.py:73-79: cluster by (d_rep, index), then member
+    position).  A differential fuzz (scripts/cluster_fuzz.py) once found the general selection pairing the right member
+    position with its neighbour's node; this is that configuration, against the C oracle on both routes."""
+    from apples_amd import treecluster
+    from apples_amd.fasta import Alignment
+    from apples_amd.reference import ReducedReference
+    d = synth.make_dataset(60, 950, 879, gap_rate=0.0, seed_tree=203, mean_len=0.003)
+    nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
+    ref = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, 0.24))
+    ca = ref.cluster_arrays()
+    co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', criterion='MLSE', threshold=0.02, baseobs=25,
+                 lut=jc69_lut(950, 0.001), threads=len(os.sched_getaffinity(0)))
+    want = co.place_sequences(d.query_seqs)
+    assert ((want['flags'] & F_EXACT) != 0).sum() > 50
+    if no_fuse:
+        monkeypatch.setenv('APPLES_NO_FUSE', '1')
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', criterion='MLSE', threshold=0.02, baseobs=25, max_batch=512)
+    got = eng.place_sequences(d.query_seqs)
+    eng.close()
+    assert got.tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize('L', [4097, 8190])
 def test_long_alignments_through_the_fused_matrix_core_pass(L):
     """The fused distance pass packs (valid, mism) into 13-bit fields and counts in f32
