@@ -1100,7 +1100,10 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             sa.slow_hint = w.slow_list + w.batch;
             sa.lvl_slots = a.lvl_slots;
             {   // scratch of the cluster-major distance pass: per-cluster counters, the (query, offset) lists, the tile table
-                const int64_t n_ints = 3 * (int64_t)a.n_reps + 8, n_items = nq * SELECT_CLUSTERS_ACC_CAP,
+                const bool big_form = a.n_reps > SELECT_CLUSTERS_ACC_CAP && a.n_reps <= SELECT_CLUSTERS_BIG_CAP &&
+                                      !getenv("APPLES_NO_CLUSTER_BIG");  // (diagnostic knob: queries beyond ACC_CAP clusters to the general route)
+                const int64_t n_ints = 3 * (int64_t)a.n_reps + 8 + SELECT_CLUSTERS_BIG_LIST + 8,
+                              n_items = nq * SELECT_CLUSTERS_ACC_CAP + (big_form ? std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps : 0),
                               n_tiles = n_items / SELECT_CLUSTERS_MIN_TILE + a.n_reps + 1;
                 if (n_ints > ctx->cl_ints_cap) {
                     dev_free(ctx->cl_ints); ctx->cl_ints = nullptr; ctx->cl_ints_cap = 0;
@@ -1119,6 +1122,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 }
                 sa.cl_count = ctx->cl_ints; sa.cl_start = ctx->cl_ints + a.n_reps; sa.cl_fill = sa.cl_start + a.n_reps + 1;
                 sa.cl_ntiles = sa.cl_fill + a.n_reps;
+                sa.big_count = big_form ? sa.cl_ntiles + 4 : nullptr;
+                sa.big_list = big_form ? sa.cl_ntiles + 8 : nullptr;
                 sa.cl_items = ctx->cl_items; sa.cl_tiles = ctx->cl_tiles; sa.cl_tiles_cap = ctx->cl_tiles_cap;
             }
             if (launch_select_clusters(ctx, sa, nq)) return 1;
@@ -1273,6 +1278,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         hipEventCreateWithFlags(&ctx->ev_back[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_back[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_bigfree, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_cl[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_cl[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_sel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return fail(); }
     for (int i = 0; i < 8; ++i)
@@ -1427,6 +1434,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
         if (ctx->ev_back[i]) (void)hipEventDestroy(ctx->ev_back[i]);
     }
     if (ctx->ev_bigfree) (void)hipEventDestroy(ctx->ev_bigfree);
+    for (auto &e : ctx->ev_cl) if (e) (void)hipEventDestroy(e);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream_big) (void)hipStreamDestroy(ctx->stream_big);
     if (ctx->ev_sel) (void)hipEventDestroy(ctx->ev_sel);

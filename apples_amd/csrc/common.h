@@ -199,6 +199,7 @@ struct apples_ctx {
     hipStream_t stream3 = nullptr;   // back stream: sweeps of batch i while the front stream works on batch i+1
     hipStream_t stream_big = nullptr; // the workgroup-sized sweep teams of a batch, beside sweep_lean.hip's wavefront-sized ones
     hipEvent_t ev_front[2] = {}, ev_back[2] = {}, ev_bigfree = nullptr;
+    hipEvent_t ev_cl[2] = {};        // clustered fast path: the few-query second form of its last phase runs beside the first on stream2
     std::string err;
     std::string desc;
     apples_params params{};
@@ -318,6 +319,7 @@ struct SelectArgs {
     // phase 4 of k_select_clusters (the slow list of the clustered fast path): the representative panel ([(g, plane)][rep_stride]),
     // and where it forwards what it cannot serve (then full rows + k_select)
     const uint4 *rep_panel; int32_t *slow2_list, *slow2_count;
+    int32_t *big_list, *big_count;  // queries with more than ACC_CAP accepted clusters: served by the phases' second form (CAP = BIG_CAP)
     int rep_cache;            // k_select, clustered rows: representatives whose distances are staged in LDS (set by the launcher; 0 = none)
     int64_t n_rows_plain;     // k_select / k_select_stream without a list: rows to select (set by the launcher; the grid may be smaller)
 };
@@ -328,6 +330,8 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq);  /
 int launch_select_clusters_listed(apples_ctx *ctx, const SelectArgs &a, int64_t nq_max);  // its slow list (qlist / qcount / qhint), top-up rule included
 #define SELECT_CLUSTERS_ACC_CAP 512   // accepted clusters per query on the fast path (more: the query takes the general route)
 #define SELECT_CLUSTERS_MIN_TILE 16   // fewest queries a full tile of k_cluster_dist holds
+#define SELECT_CLUSTERS_BIG_CAP 5120  // ... and on its second form, for the few queries beyond ACC_CAP (one workgroup per CU: 60 KB of lists)
+#define SELECT_CLUSTERS_BIG_LIST 1024 // queries a batch may send to that form (more: the general route)
 #define SELECT_CLUSTERS_MAX_SLOTS 229376
 int launch_counts_reps(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);
 int launch_build_cluster_panels(apples_ctx *ctx);  // listed queries, needs segmin_d/segmin_i; baseobs <= 256

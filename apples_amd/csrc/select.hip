@@ -577,7 +577,6 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
 //      lists (query, where the cluster's members start in the query's flat member list); k_cluster_dist takes a tile, keeps
 //      a member's words in registers and the tile's query words in LDS, and writes the distances into the queries' rows;
 //      phase 3 is phase 0 with the distance read from the row.  The panel is then read once per tile, not once per query.
-#define ACC_CAP SELECT_CLUSTERS_ACC_CAP
 #ifndef CLUSTER_UNROLL
 #define CLUSTER_UNROLL 1  // phase 0: member word groups in flight per lane (3 16-byte loads each); 38 / 42 / 48 / 43 ms per C3 pass
                           // with 1 / 2 / 4 / 8 (the loop's load schedule is fragile: the same source measured 41 ms per pass
@@ -592,14 +591,19 @@ __device__ __forceinline__ void cluster_count(const uint4 &rm, const uint4 &r0, 
             __popc(((q0.z ^ r0.z) | (q1.z ^ r1.z)) & m2_) + __popc(((q0.w ^ r0.w) | (q1.w ^ r1.w)) & m3_);
 }
 
-template <int PHASE>
-__global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
+//   CAP = accepted clusters a workgroup's lists hold: ACC_CAP for the launch over all queries; the queries beyond it (1 % at C3
+//   size: observed sets of tens of thousands) are listed by phase 1 and go through the same phases once more with CAP = BIG_CAP,
+//   a workgroup per list entry (LISTED; 60 KB of lists, so one workgroup per CU: a launch of their own keeps that occupancy
+//   and their long rounds away from the other 99 %).
+template <int PHASE, int CAP = SELECT_CLUSTERS_ACC_CAP, bool LISTED = (PHASE == 4), int TPB = APPLES_TPB>
+__global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
+    constexpr int ACC_CAP = CAP, NW = TPB / WAVE;
     extern __shared__ unsigned long long dyn_bits[];  // [n_words] member bits in slot order, then uint16 [n_words]: the set bits before the
                                                       // word inside its thread's run of 16 words (sh_base: before the run)
-    __shared__ int sh_base[APPLES_TPB];
-    __shared__ int sh_i[8];
-    __shared__ int sh_j[8];
-    __shared__ double sh_d[8];
+    __shared__ int sh_base[TPB];
+    __shared__ int sh_i[NW < 8 ? 8 : NW];
+    __shared__ int sh_j[NW < 8 ? 8 : NW];
+    __shared__ double sh_d[NW < 8 ? 8 : NW];
     __shared__ uint4 sh_q[(PHASE == 0 || PHASE == 4) ? 64 * 3 : 1];
     __shared__ int sh_rep[ACC_CAP];
     __shared__ int sh_off[ACC_CAP + 1];
@@ -613,7 +617,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
             for (int r2 = blockIdx.x + gridDim.x; r2 < n_list; r2 += gridDim.x) a.slow2_list[atomicAdd(a.slow2_count, 1)] = a.qlist[r2];
         if ((int)blockIdx.x >= n_list) return;
     }
-    const int64_t q = PHASE == 4 ? a.qlist[blockIdx.x] : blockIdx.x;
+    if (PHASE != 4 && LISTED) {
+        const int n_list = *a.qcount < (int)gridDim.x ? *a.qcount : (int)gridDim.x;  // (the list is capped at the grid where it is written)
+        if ((int)blockIdx.x >= n_list) return;
+    }
+    const int64_t q = LISTED ? a.qlist[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
     const int G = a.G;
     const int64_t nm = a.n_members;
@@ -638,13 +646,13 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     if (PHASE == 4 && (a.qhint[blockIdx.x] < 0 || !a.rep_cache)) { forward(); return; }
     if (PHASE == 0 || PHASE == 4) {
         // the query's packed words (tile layout of pack.hip: [(q/16)*G + g][q%16][plane])
-        for (int i = tid; i < G * 3; i += APPLES_TPB) {
+        for (int i = tid; i < G * 3; i += TPB) {
             const int g = i / 3, pl = i % 3;
             sh_q[i] = a.qpacked[(((q >> 4) * G + g) * 16 + (q & 15)) * 3 + pl];
         }
     }
     if (PHASE == 0 || PHASE >= 3)
-        for (int i = tid; i < n_words; i += APPLES_TPB) dyn_bits[i] = 0;
+        for (int i = tid; i < n_words; i += TPB) dyn_bits[i] = 0;
     // a member's (or representative's) distance from its words: word (g, plane) at base[(g * 3 + plane) * stride] -- the
     // cluster-major panel with the cluster's size as stride (the lanes holding consecutive members read consecutive 16
     // bytes), or the representative panel with its padded length
@@ -674,7 +682,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
         // (phase 4 wants the distance to EVERY representative -- the top-up rule walks on beyond the threshold -- and computes
         // them itself: same pair counts, same table, so the ones inside the threshold are the survivors the other phases read)
         __syncthreads();  // sh_q
-        for (int64_t j0 = 0; j0 < a.n_reps; j0 += APPLES_TPB) {
+        for (int64_t j0 = 0; j0 < a.n_reps; j0 += TPB) {
             const int64_t j = j0 + tid;
             const double d = j < a.n_reps ? by_query(a.rep_panel + j, a.rep_stride) : -1.0;
             if (j < a.n_reps) reprow[j] = d;
@@ -685,11 +693,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
             base += tot;
         }
     } else
-    for (int64_t s0 = 0; s0 < n_seg; s0 += APPLES_TPB) {
+    for (int64_t s0 = 0; s0 < n_seg; s0 += TPB) {
         const int64_t s = s0 + tid;
         const int my = s < n_seg ? cnt[s] : 0;
         int chunk_total;
-        const int at = base + block_excl_scan_int(my, sh_i, &chunk_total);
+        const int at = base + block_excl_scan_int<NW>(my, sh_i, &chunk_total);
         if (at + my <= ACC_CAP) {
             for (int k = 0; k < my; ++k) {
                 const uint32_t pk = (uint32_t)sslot[s * 64 + k];
@@ -704,23 +712,33 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     __syncthreads();
     const int n_acc = sh_nacc;
     if (n_acc > ACC_CAP || __syncthreads_or(overflow ? 1 : 0)) {
-        if (PHASE <= 1) to_slow(-1);  // (once: the later phases just leave the query alone)
+        // (once, in the first phase: the later ones just leave the query alone)
+        if (PHASE == 1 && !LISTED && a.big_list && a.n_reps <= SELECT_CLUSTERS_BIG_CAP) {  // the second form of the phases takes it
+            int at = SELECT_CLUSTERS_BIG_LIST;
+            if (tid == 0) {
+                at = atomicAdd(a.big_count, 1);
+                if (at < SELECT_CLUSTERS_BIG_LIST) a.big_list[at] = (int32_t)q;
+            }
+            if (tid == 0 && at >= SELECT_CLUSTERS_BIG_LIST) to_slow(-1);
+        } else if (PHASE <= 1) {
+            to_slow(-1);
+        }
         if (PHASE == 4) forward();
         return;
     }
     if (PHASE == 1) {  // one more query for every accepted cluster
-        for (int k = tid; k < n_acc; k += APPLES_TPB) atomicAdd(&a.cl_count[sh_rep[k]], 1);
+        for (int k = tid; k < n_acc; k += TPB) atomicAdd(&a.cl_count[sh_rep[k]], 1);
         return;
     }
     // ---- members of the accepted clusters as one flat list: offsets by cluster
     {
         int carry = 0;
-        for (int k0 = 0; k0 < n_acc; k0 += APPLES_TPB) {
+        for (int k0 = 0; k0 < n_acc; k0 += TPB) {
             const int k = k0 + tid;
             const int mb0 = k < n_acc ? a.rep_moff[sh_rep[k]] : 0;
             const int sz = k < n_acc ? a.rep_moff[sh_rep[k] + 1] - mb0 : 0;
             int tot;
-            const int off = carry + block_excl_scan_int(sz, sh_i, &tot);
+            const int off = carry + block_excl_scan_int<NW>(sz, sh_i, &tot);
             if (k < n_acc) { sh_off[k] = off; sh_mb[k] = mb0; }
             carry += tot;
         }
@@ -728,7 +746,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     }
     __syncthreads();
     if (PHASE == 2) {  // the query joins the lists of its clusters (in whatever order the additions land: every pair is on its own)
-        for (int k = tid; k < n_acc; k += APPLES_TPB) {
+        for (int k = tid; k < n_acc; k += TPB) {
             const int c = sh_rep[k];
             a.cl_items[a.cl_start[c] + atomicAdd(&a.cl_fill[c], 1)] = make_int2((int)q, sh_off[k]);
         }
@@ -740,7 +758,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
         // ---- the members' distances (a thread per member), then Reference.py:144-152: while fewer than `-b` valid member
         // distances are in, the representative with the next smallest (distance, index) beyond the threshold brings its cluster
         int c = 0;
-        for (int m = tid; m < M; m += APPLES_TPB) {
+        for (int m = tid; m < M; m += TPB) {
             int lo = 0, hi = n_acc;
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
@@ -750,17 +768,17 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
             tmp[m] = d;
             c += !(d < 0);
         }
-        int obs = block_sum(c, sh_i);
+        int obs = block_sum<NW>(c, sh_i);
         double cut_d = -INF_D;
         int cut_i = -1;
         while (obs < a.baseobs) {
             double bd = INF_D;
             int bi = 0x7fffffff, bj = 0;
-            for (int64_t j = tid; j < a.n_reps; j += APPLES_TPB) {
+            for (int64_t j = tid; j < a.n_reps; j += TPB) {
                 const double d = reprow[j];
                 if (d > a.thr && key_lt(cut_d, cut_i, d, (int)j) && key_lt(d, (int)j, bd, bi)) { bd = d; bi = (int)j; }
             }
-            block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
+            block_argmin3<NW>(bd, bi, bj, sh_d, sh_i, sh_j);
             if (bi == 0x7fffffff) break;  // nothing left
             cut_d = bd;
             cut_i = bi;
@@ -769,12 +787,12 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
             __syncthreads();  // (the searches above are done with sh_off)
             if (tid == 0) { sh_rep[n_acc_all] = bi; sh_mb[n_acc_all] = mb0; sh_off[n_acc_all + 1] = M + sz; }
             c = 0;
-            for (int mp = tid; mp < sz; mp += APPLES_TPB) {
+            for (int mp = tid; mp < sz; mp += TPB) {
                 const double d = by_query(a.packed_rm + (int64_t)mb0 * (G * 3) + mp, sz);
                 tmp[M + mp] = d;
                 c += !(d < 0);
             }
-            obs += block_sum(c, sh_i);
+            obs += block_sum<NW>(c, sh_i);
             M += sz;
             ++n_acc_all;
         }
@@ -794,12 +812,12 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     int n_total = 0, obs_cnt = 0;
     double z_d = INF_D;
     int z_i = 0x7fffffff, z_p = 0x7fffffff, z_node = -2;
-    for (int m0 = 0; m0 < M; m0 += APPLES_TPB * E) {
+    for (int m0 = 0; m0 < M; m0 += TPB * E) {
         int lo_[E], slot_[E], node_[E];
         double d_[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int m = m0 + e * APPLES_TPB + tid;
+            const int m = m0 + e * TPB + tid;
             lo_[e] = -1; slot_[e] = 0; d_[e] = -1.0;
             if (m < M) {
                 const int lo = cluster_of(m), mp = m - sh_off[lo], mb = sh_mb[lo];
@@ -814,7 +832,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
             node_[e] = lo_[e] >= 0 ? a.slot_node[slot_[e]] : -1;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int m = m0 + e * APPLES_TPB + tid;
+            const int m = m0 + e * TPB + tid;
             if (lo_[e] < 0) continue;
             const int lo = lo_[e], slot = slot_[e];
             const double d = d_[e];
@@ -848,7 +866,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
             tmp[m] = keep;
         }
     }
-    const int obs = block_sum(obs_cnt, sh_i);
+    const int obs = block_sum<NW>(obs_cnt, sh_i);
     if (PHASE != 4 && obs < a.baseobs) { to_slow(obs); return; }  // the reference would pop further clusters (Reference.py:146): phase 4 did
     // ---- ranks of the slot bitmap: a thread counts its run of 16 words, one scan over the threads
     int n_emit;
@@ -858,7 +876,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
             const int w = tid * 16 + k;
             if (w < n_words) { pre[w] = (uint16_t)c; c += __popcll(dyn_bits[w]); }
         }
-        sh_base[tid] = block_excl_scan_int(c, sh_i, &n_emit);
+        sh_base[tid] = block_excl_scan_int<NW>(c, sh_i, &n_emit);
     }
     __syncthreads();
     auto rank_of = [&](int slot) -> int {  // emitted members in the slots below `slot`
@@ -867,12 +885,12 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
         return sh_base[w >> 4] + (int)pre[w] + __popcll(dyn_bits[w] & ((1ull << (slot & 63)) - 1ull));
     };
     // ---- pass 2: emission in slot order
-    for (int m0 = 0; m0 < M; m0 += APPLES_TPB * E) {
+    for (int m0 = 0; m0 < M; m0 += TPB * E) {
         int slot_[E];
         double d_[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int m = m0 + e * APPLES_TPB + tid;
+            const int m = m0 + e * TPB + tid;
             slot_[e] = -1; d_[e] = -2.0;
             if (m < M) {
                 const int lo = cluster_of(m);
@@ -891,9 +909,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
                 o_dist[pos] = d_[e];
             }
     }
-    n_total = block_sum(n_total, sh_i);  // (its barriers also publish the emission)
+    n_total = block_sum<NW>(n_total, sh_i);  // (its barriers also publish the emission)
     double zd = z_d; int zi = z_i, zp = z_p;
-    block_argmin3(zd, zi, zp, sh_d, sh_i, sh_j);
+    block_argmin3<NW>(zd, zi, zp, sh_d, sh_i, sh_j);
     if (tid == 0) sh_znode = -2;
     __syncthreads();
     if (z_node != -2 && z_d == zd && z_i == zi && z_p == zp) sh_znode = z_node;
@@ -902,9 +920,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_clusters(SelectArgs a) {
     // in the slots above level l (slots are sorted by level, deepest first; lvl_slots[l + 1] = how many slots those are)
     int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
     if (cg && a.lvl_slots) {
-        for (int i = tid; i < a.height + 2; i += APPLES_TPB) cg[i] = rank_of(a.lvl_slots[i]);
+        for (int i = tid; i < a.height + 2; i += TPB) cg[i] = rank_of(a.lvl_slots[i]);
     } else {
-        for (int i = tid; cg && i <= n_emit; i += APPLES_TPB) {
+        for (int i = tid; cg && i <= n_emit; i += TPB) {
             const int lv = (i < n_emit) ? a.node_level[o_node[i]] : -1;
             const int lprev = (i == 0) ? a.height + 1 : a.node_level[o_node[i - 1]];
             for (int l = lv; l < lprev; ++l) cg[l + 1] = i;
@@ -1047,9 +1065,17 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         return 0;
     }
     HIP_TRY(ctx, hipMemsetAsync(a.cl_count, 0, (size_t)a.n_reps * sizeof(int32_t), ctx->stream));
+    constexpr int BIG = SELECT_CLUSTERS_BIG_CAP;
+    const bool big = a.big_list != nullptr;
+    SelectArgs b = a;  // the second form: a workgroup per entry of the list phase 1 writes
+    b.qlist = a.big_list; b.qcount = a.big_count;
+    const dim3 gbig((unsigned)std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST));
+    if (big) HIP_TRY(ctx, hipMemsetAsync(a.big_count, 0, sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(k_select_clusters<1>, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
+    if (big) hipLaunchKernelGGL((k_select_clusters<1, BIG, true>), gbig, dim3(APPLES_TPB), 0, ctx->stream, b);
     hipLaunchKernelGGL(k_cluster_tiles, dim3(1), dim3(APPLES_TPB), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_select_clusters<2>, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
+    if (big) hipLaunchKernelGGL((k_select_clusters<2, BIG, true>), gbig, dim3(APPLES_TPB), 0, ctx->stream, b);
     if (ctx->n_cu == 0) {
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
@@ -1057,7 +1083,16 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     }
     static const int per_cu = getenv("APPLES_CLUSTER_WGS") ? atoi(getenv("APPLES_CLUSTER_WGS")) : 8;  // tuning knob
     hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
+    // the second form's last phase beside the first's, on the spare stream: a hundred-odd workgroups of 1 024 threads (their
+    // rounds of member lookups are what such a workgroup takes: a quarter of the rounds of 256 threads) leave the chip idle
+    if (big) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_cl[0], ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_cl[0], 0));
+        hipLaunchKernelGGL((k_select_clusters<3, BIG, true, 1024>), gbig, dim3(1024), dyn, ctx->stream2, b);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_cl[1], ctx->stream2));
+    }
     hipLaunchKernelGGL(k_select_clusters<3>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
+    if (big) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cl[1], 0));
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
