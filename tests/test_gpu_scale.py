@@ -398,19 +398,22 @@ def test_clustered_top_up_rule_over_the_representatives(c2, thr, baseobs, monkey
     assert gen.tobytes() == got.tobytes()
 
 
-def test_queries_that_accept_more_clusters_than_a_workgroups_lists_hold(c2, monkeypatch):
+@pytest.mark.parametrize('diam', [0.08, 0.005])
+def test_queries_that_accept_more_clusters_than_a_workgroups_lists_hold(c2, diam, monkeypatch):
     """1 923 small clusters and a threshold that accepts nearly all of them for every query: more than the 512 the fast
     path's workgroups keep in LDS, so phase 1 lists the queries and the phases' second form (5 120 clusters per workgroup,
     a launch of its own) serves them -- up to 1 024 per device batch; with 1 536 queries in one batch the rest goes to the
-    general route.  Against the C oracle byte for byte, and with that second form switched off (APPLES_NO_CLUSTER_BIG)."""
+    general route.  Against the C oracle byte for byte, and with that second form switched off (APPLES_NO_CLUSTER_BIG); once more
+    with more clusters than the second form holds."""
     from apples_amd import treecluster
     from apples_amd.fasta import Alignment
     from apples_amd.reference import ReducedReference
     d, nodes = c2
-    ref = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, 0.08))
+    ref = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, diam))
     ca = ref.cluster_arrays()
-    assert 512 < len(ca[1]) <= 5120
-    nq = 1536
+    # (diameter 0.005: nearly every leaf its own cluster, more clusters than the second form holds either -- the general route)
+    assert 512 < len(ca[1]) <= 5120 if diam > 0.01 else len(ca[1]) > 5120
+    nq = 1536 if diam > 0.01 else 300
     co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', criterion='MLSE', threshold=1.0,
                  lut=jc69_lut(1000, 0.001), threads=len(os.sched_getaffinity(0)))
     want = co.place_sequences(d.query_seqs[:nq])
