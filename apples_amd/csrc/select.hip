@@ -960,18 +960,19 @@ __device__ __forceinline__ int cluster_tile_queries(int sz) {
 }
 
 // One workgroup: the clusters' query counts -> list offsets (cl_start), cleared fill cursors, and the tile table.
-__global__ __launch_bounds__(APPLES_TPB) void k_cluster_tiles(SelectArgs a) {
-    __shared__ int sh_i[8];
+#define CL_TILES_TPB 1024  // (one workgroup walks all clusters: its time is rounds of two scans, so make the rounds few)
+__global__ __launch_bounds__(CL_TILES_TPB) void k_cluster_tiles(SelectArgs a) {
+    __shared__ int sh_i[CL_TILES_TPB / WAVE];
     const int tid = threadIdx.x;
     int item_base = 0, tile_base = 0;
-    for (int64_t c0 = 0; c0 < a.n_reps; c0 += APPLES_TPB) {
+    for (int64_t c0 = 0; c0 < a.n_reps; c0 += CL_TILES_TPB) {
         const int64_t c = c0 + tid;
         const int cnt = c < a.n_reps ? a.cl_count[c] : 0;
         const int T = c < a.n_reps ? cluster_tile_queries(a.rep_moff[c + 1] - a.rep_moff[c]) : 1;
         const int nt = (cnt + T - 1) / T;
         int tot_i, tot_t;
-        const int at_i = item_base + block_excl_scan_int(cnt, sh_i, &tot_i);
-        const int at_t = tile_base + block_excl_scan_int(nt, sh_i, &tot_t);
+        const int at_i = item_base + block_excl_scan_int<CL_TILES_TPB / WAVE>(cnt, sh_i, &tot_i);
+        const int at_t = tile_base + block_excl_scan_int<CL_TILES_TPB / WAVE>(nt, sh_i, &tot_t);
         if (c < a.n_reps) {
             a.cl_start[c] = at_i;
             a.cl_fill[c] = 0;
@@ -1073,7 +1074,7 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (big) HIP_TRY(ctx, hipMemsetAsync(a.big_count, 0, sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(k_select_clusters<1>, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
     if (big) hipLaunchKernelGGL((k_select_clusters<1, BIG, true>), gbig, dim3(APPLES_TPB), 0, ctx->stream, b);
-    hipLaunchKernelGGL(k_cluster_tiles, dim3(1), dim3(APPLES_TPB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_cluster_tiles, dim3(1), dim3(CL_TILES_TPB), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_select_clusters<2>, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
     if (big) hipLaunchKernelGGL((k_select_clusters<2, BIG, true>), gbig, dim3(APPLES_TPB), 0, ctx->stream, b);
     if (ctx->n_cu == 0) {
