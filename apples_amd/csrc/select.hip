@@ -136,9 +136,9 @@ template <int TPB>
 __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
     constexpr int NW = TPB / WAVE;
     extern __shared__ double dyn_drep[];  // clustered rows: the row's distances to the representatives (a.rep_cache of them)
-    __shared__ int sh_i[16];
-    __shared__ int sh_j[16];
-    __shared__ double sh_d[16];
+    __shared__ int sh_i[NW];
+    __shared__ int sh_j[NW];
+    __shared__ double sh_d[NW];
     // listed mode (top-up path): a fixed grid walks the device-side list; entry r names query
     // qlist[r], whose distances are row r
     const int64_t n_list = a.qcount ? (int64_t)*a.qcount : a.n_rows_plain;
@@ -255,11 +255,7 @@ __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
     // a thread's E consecutive slots come in 16-byte pieces (a wavefront's load instruction then covers whole cache lines:
     // with one 4- or 8-byte element per lane at a stride of E elements the pass is bound by the rate of line requests, not by
     // latency -- 24 us per 8 192 slots); rows whose start is not 16-byte aligned and gathered rows take the plain loads
-#ifdef SELECT_NO_VEC
-    const bool vec_ok = false;
-#else
     const bool vec_ok = !gather && (reinterpret_cast<uintptr_t>(row) & 15) == 0;
-#endif
     for (int64_t s0 = 0; s0 <= nm; s0 += (int64_t)TPB * E) {
         const int64_t sb = s0 + (int64_t)tid * E;
         int emit[E], node[E], v_rep[E], v_mp[E], v_lv[E];
