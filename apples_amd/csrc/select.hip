@@ -326,14 +326,15 @@ __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
         }
         int tot;
         int pos = base + block_excl_scan_int<NW>(n_emit_l, sh_i, &tot);
+        int lprev = lv_before;  // (carried along: no v_lv[e - 1], which at e = 0 would name an element before the array)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int64_t s = sb + e;
             if (cg && s <= nm) {  // level boundaries (virtual end slot nm has level -1)
                 const int lv = (s < nm) ? v_lv[e] : -1;
-                const int lprev = e == 0 ? lv_before : v_lv[e - 1];
                 for (int l = lv; l < lprev; ++l) cg[l + 1] = pos;
             }
+            lprev = v_lv[e];
             if (emit[e]) { o_node[pos] = node[e]; o_dist[pos] = dm[e]; ++pos; }
         }
         base += tot;

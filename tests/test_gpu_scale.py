@@ -433,7 +433,9 @@ def test_exact_matches_among_the_members_of_one_cluster(no_fuse, monkeypatch):
     """Short branches: many queries are identical to a reference, and some to TWO references of the same cluster -- the
     reference reports the first zero in dict order (PoolQueryWorker.py:73-79: cluster by (d_rep, index), then member
     position).  A differential fuzz (scripts/cluster_fuzz.py) once found the general selection pairing the right member
-    position with its neighbour's node; this is that configuration, against the C oracle on both routes."""
+    position with its neighbour's node (an unrolled loop named element -1 of a register array in an arm that is never
+    taken at that iteration, and the optimiser made the rest of the loop pay for it); this is that configuration, against
+    the C oracle on both routes."""
     from apples_amd import treecluster
     from apples_amd.fasta import Alignment
     from apples_amd.reference import ReducedReference
