@@ -479,19 +479,56 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     };
     if (flat) {
         __syncthreads();
-        for (int e0 = 0; e0 < total; e0 += APPLES_TPB) {
-            const int e = e0 + tid;
-            int emit = 0, node = -1, lv = 0;
-            double d = 0;
-            if (e < total) {
+        // EF rounds of 256 survivors at a time: entry -> (slot, counts) -> (distance, node, level) are three dependent lookups, and
+        // a workgroup's time is their latency; with the rounds' lookups in flight together a typical query (1 000 survivors) pays
+        // for them once.  Addresses of lanes beyond the list are clamped to entry 0 so that every load is unconditional.
+        constexpr int EF = 4;
+        for (int e0 = 0; e0 < total; e0 += APPLES_TPB * EF) {
+            int64_t seg_[EF];
+            int raw_[EF], slot_[EF], node_[EF], lv_[EF];
+            double d_[EF];
+            bool in_[EF];
+#pragma unroll
+            for (int u = 0; u < EF; ++u) {
+                const int e = e0 + u * APPLES_TPB + tid;
+                in_[u] = e < total;
                 int64_t lo = 0, hi = n_seg + 1;  // last segment whose prefix <= e (empty segments share a prefix: the last one wins, and holds e)
                 while (hi - lo > 1) {
                     const int64_t mid = (lo + hi) >> 1;
-                    if (dyn_pref[mid] <= e) lo = mid; else hi = mid;
+                    if (dyn_pref[mid] <= (in_[u] ? e : 0)) lo = mid; else hi = mid;
                 }
-                emit = take(lo, e - dyn_pref[lo], node, d, lv);
+                seg_[u] = lo;
+                const int64_t src = in_[u] ? lo * 64 + (e - dyn_pref[lo]) : 0;
+                raw_[u] = sslot[src];
+                d_[u] = a.seg_lut ? 0.0 : sd[src];
             }
-            put(emit, node, d, lv);
+#pragma unroll
+            for (int u = 0; u < EF; ++u) {
+                slot_[u] = raw_[u];
+                if (a.seg_lut) {  // the matrix-core distance pass leaves position | valid | mism; same table, same bits
+                    const uint32_t pk = (uint32_t)raw_[u];
+                    const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
+                    slot_[u] = (int)(seg_[u] * 64 + (pk >> 26));
+                    d_[u] = a.seg_lut[in_[u] ? valid * (valid + 1) / 2 + mism : 0];
+                }
+                const int sl = in_[u] ? slot_[u] : 0;
+                node_[u] = a.slot_node[sl];
+                lv_[u] = a.slot_level[sl];  // (beside the node: the per-level offsets below need no second pass over the list)
+            }
+#pragma unroll
+            for (int u = 0; u < EF; ++u) {
+                if (e0 + u * APPLES_TPB >= total) break;  // (block-uniform)
+                int emit = 0;
+                if (in_[u] && slot_[u] != self) {  // own row dropped, first zero noted
+                    ++n_total;
+                    if (d_[u] == 0) {
+                        const int ri = a.slot_rep[slot_[u]];
+                        if (ri < z_i) { z_i = ri; z_node = node_[u]; }
+                    }
+                    emit = node_[u] >= 0;
+                }
+                put(emit, node_[u], d_[u], lv_[u]);
+            }
         }
     } else {
     for (int64_t s0 = 0; s0 < n_seg; s0 += APPLES_TPB) {
