@@ -67,7 +67,8 @@ __device__ void block_argmin3(double &d, int &i, int &j, double *shd, int *shi, 
 }
 
 // exclusive prefix sum of a 0/1 flag across the block; returns this thread's offset, total in *tot
-__device__ int block_excl_scan(int flag, int *sh /*[4+]*/, int *tot) {
+template <int NW = APPLES_TPB / WAVE>
+__device__ int block_excl_scan(int flag, int *sh, int *tot) {
     unsigned long long mask = __ballot(flag);
     int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     int pre = __popcll(mask & ((1ull << lane) - 1ull));
@@ -75,7 +76,7 @@ __device__ int block_excl_scan(int flag, int *sh /*[4+]*/, int *tot) {
     if (lane == 0) sh[w] = __popcll(mask);
     __syncthreads();
     int base = 0, t = 0;
-    for (int k = 0; k < APPLES_TPB / WAVE; ++k) {
+    for (int k = 0; k < NW; ++k) {
         if (k < w) base += sh[k];
         t += sh[k];
     }
@@ -391,11 +392,13 @@ __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
 // pushed to the slow list (full rows + k_select).  Otherwise the observed dict is exactly those
 // entries: drop the query's own row, find the first zero (smallest representative index, since all
 // zero keys tie on d = 0), count, and compact the tree leaves in slot order (= level order).
-__global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_select_fast(SelectArgs a) {
+    constexpr int NW = TPB / WAVE;
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
     __shared__ double sh_d[8];
-    __shared__ int sh_pref[APPLES_TPB + 1];
+    __shared__ int sh_pref[TPB + 1];
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x;
     const int64_t n_seg = a.stride >> 6;
@@ -410,21 +413,21 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     const bool flat = a.flat_pref != 0;
     int total;
     if (flat) {
-        const int K = (int)((n_seg + APPLES_TPB - 1) / APPLES_TPB);
+        const int K = (int)((n_seg + TPB - 1) / TPB);
         const int64_t s_lo = (int64_t)tid * K, s_hi = s_lo + K < n_seg ? s_lo + K : n_seg;
         // (the counts come in coalesced and are summed out of LDS: a thread reading its K consecutive counts from memory is K
         // load instructions of 64 cache lines each)
-        for (int64_t s = tid; s < n_seg; s += APPLES_TPB) dyn_pref[s] = cnt[s];
+        for (int64_t s = tid; s < n_seg; s += TPB) dyn_pref[s] = cnt[s];
         __syncthreads();
         int local = 0;
         for (int64_t s = s_lo; s < s_hi; ++s) { const int v = dyn_pref[s]; dyn_pref[s] = local; local += v; }
-        const int at = block_excl_scan_int(local, sh_i, &total);
+        const int at = block_excl_scan_int<NW>(local, sh_i, &total);
         for (int64_t s = s_lo; s < s_hi; ++s) dyn_pref[s] += at;
         if (tid == 0) dyn_pref[n_seg] = total;
     } else {
         int c = 0;
-        for (int64_t s = tid; s < n_seg; s += APPLES_TPB) c += cnt[s];
-        total = block_sum(c, sh_i);
+        for (int64_t s = tid; s < n_seg; s += TPB) c += cnt[s];
+        total = block_sum<NW>(c, sh_i);
     }
     if (total < a.baseobs) {
         if (tid == 0) {
@@ -463,11 +466,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     // ordered emission of up to 256 entries (one per thread) + the per-level offsets they imply (the sweep's cnt_gt:
     // cg[l + 1] = entries with a level above l = position of the first entry at level l or below; entries come in
     // level order, so an entry whose predecessor sits at a higher level writes the offsets in between)
-    __shared__ int sh_lv[APPLES_TPB + 1];
+    __shared__ int sh_lv[TPB + 1];
     int last_lv = a.height + 1;  // level of the entry before this round's first (block-uniform)
     auto put = [&](int emit, int node, double d, int lv) {
         int tot;
-        const int r = block_excl_scan(emit, sh_j, &tot);
+        const int r = block_excl_scan<NW>(emit, sh_j, &tot);
         if (emit) { o_node[base + r] = node; o_dist[base + r] = d; sh_lv[r + 1] = lv; }
         if (tid == 0) sh_lv[0] = last_lv;
         __syncthreads();
@@ -482,15 +485,15 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
         // EF rounds of 256 survivors at a time: entry -> (slot, counts) -> (distance, node, level) are three dependent lookups, and
         // a workgroup's time is their latency; with the rounds' lookups in flight together a typical query (1 000 survivors) pays
         // for them once.  Addresses of lanes beyond the list are clamped to entry 0 so that every load is unconditional.
-        constexpr int EF = 4;
-        for (int e0 = 0; e0 < total; e0 += APPLES_TPB * EF) {
+        constexpr int EF = 1024 / TPB;  // (a thousand survivors per outer round)
+        for (int e0 = 0; e0 < total; e0 += TPB * EF) {
             int64_t seg_[EF];
             int raw_[EF], slot_[EF], node_[EF], lv_[EF];
             double d_[EF];
             bool in_[EF];
 #pragma unroll
             for (int u = 0; u < EF; ++u) {
-                const int e = e0 + u * APPLES_TPB + tid;
+                const int e = e0 + u * TPB + tid;
                 in_[u] = e < total;
                 int64_t lo = 0, hi = n_seg + 1;  // last segment whose prefix <= e (empty segments share a prefix: the last one wins, and holds e)
                 while (hi - lo > 1) {
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < EF; ++u) {
-                if (e0 + u * APPLES_TPB >= total) break;  // (block-uniform)
+                if (e0 + u * TPB >= total) break;  // (block-uniform)
                 int emit = 0;
                 if (in_[u] && slot_[u] != self) {  // own row dropped, first zero noted
                     ++n_total;
@@ -531,21 +534,21 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
             }
         }
     } else {
-    for (int64_t s0 = 0; s0 < n_seg; s0 += APPLES_TPB) {
+    for (int64_t s0 = 0; s0 < n_seg; s0 += TPB) {
         const int64_t s = s0 + tid;
         const int my = s < n_seg ? cnt[s] : 0;
         int chunk_total;
-        const int pre = block_excl_scan_int(my, sh_i, &chunk_total);
+        const int pre = block_excl_scan_int<NW>(my, sh_i, &chunk_total);
         sh_pref[tid] = pre;
-        if (tid == 0) sh_pref[APPLES_TPB] = chunk_total;
+        if (tid == 0) sh_pref[TPB] = chunk_total;
         __syncthreads();
         // flat loop over this chunk's entries, in order
-        for (int e0 = 0; e0 < chunk_total; e0 += APPLES_TPB) {
+        for (int e0 = 0; e0 < chunk_total; e0 += TPB) {
             const int e = e0 + tid;
             int emit = 0, node = -1, lv = 0;
             double d = 0;
             if (e < chunk_total) {
-                int lo = 0, hi = APPLES_TPB;  // last segment whose prefix <= e
+                int lo = 0, hi = TPB;  // last segment whose prefix <= e
                 while (hi - lo > 1) {
                     int mid = (lo + hi) >> 1;
                     if (sh_pref[mid] <= e) lo = mid; else hi = mid;
@@ -557,9 +560,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
         __syncthreads();
     }
     }
-    n_total = block_sum(n_total, sh_i);
+    n_total = block_sum<NW>(n_total, sh_i);
     double zd = 0; int zi = z_i, zp = 0;
-    block_argmin3(zd, zi, zp, sh_d, sh_i, sh_j);
+    block_argmin3<NW>(zd, zi, zp, sh_d, sh_i, sh_j);
     __shared__ int sh_znode;
     if (tid == 0) sh_znode = -2;
     __syncthreads();
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_select_fast(SelectArgs a) {
     __syncthreads();
     const int n_emit = base;
     // the offsets below the last entry's level (everything sits above those levels)
-    for (int l = -1 + tid; cg && l < last_lv; l += APPLES_TPB) cg[l + 1] = n_emit;
+    for (int l = -1 + tid; cg && l < last_lv; l += TPB) cg[l + 1] = n_emit;
     if (tid == 0) {
         apples_placement p;
         p.edge = 0; p.flags = 0; p.error = 0.0; p.distal = 0.0; p.pendant = 0.0; p.n_obs = n_total; p.n_valid = 0;
@@ -1172,8 +1175,12 @@ int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     SelectArgs b = a;
     const int64_t n_seg = a.stride >> 6;
     b.flat_pref = n_seg <= 16384 ? 1 : 0;
-    hipLaunchKernelGGL(k_select_fast, dim3((unsigned)nq), dim3(APPLES_TPB), b.flat_pref ? (size_t)(n_seg + 1) * sizeof(int) : 0,
-                       ctx->stream, b);
+    // (APPLES_SELECT_FAST_TPB=128: two wavefronts per query and 16 workgroups per CU -- measured slower, 4.7 against 4.1 ms per C3
+    // pass: the rounds' barriers and scans cost more than the extra workgroups in flight bring)
+    static const int tpb = getenv("APPLES_SELECT_FAST_TPB") ? atoi(getenv("APPLES_SELECT_FAST_TPB")) : 256;
+    const size_t dyn = b.flat_pref ? (size_t)(n_seg + 1) * sizeof(int) : 0;
+    if (tpb == 128) hipLaunchKernelGGL(k_select_fast<128>, dim3((unsigned)nq), dim3(128), dyn, ctx->stream, b);
+    else hipLaunchKernelGGL(k_select_fast<256>, dim3((unsigned)nq), dim3(256), dyn, ctx->stream, b);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
