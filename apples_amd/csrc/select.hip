@@ -614,6 +614,9 @@ __global__ __launch_bounds__(TPB) void k_select_fast(SelectArgs a) {
 //      lists (query, where the cluster's members start in the query's flat member list); k_cluster_dist takes a tile, keeps
 //      a member's words in registers and the tile's query words in LDS, and writes the distances into the queries' rows;
 //      phase 3 is phase 0 with the distance read from the row.  The panel is then read once per tile, not once per query.
+//   4  the slow list (fewer than `baseobs` valid member distances inside the threshold): the query's distance to EVERY
+//      representative, the top-up rule over them, the members of the clusters it accepts (by-query arithmetic), then as phase 3;
+//      what it cannot hold goes on to full rows + k_select (launch_select_clusters_listed).
 #ifndef CLUSTER_UNROLL
 #define CLUSTER_UNROLL 1  // phase 0: member word groups in flight per lane (3 16-byte loads each); 38 / 42 / 48 / 43 ms per C3 pass
                           // with 1 / 2 / 4 / 8 (the loop's load schedule is fragile: the same source measured 41 ms per pass
