@@ -416,6 +416,17 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
             for (int j = 0; j < 21; ++j) tab[i * 21 + j] = (i < 20 && j < 20) ? kBlosum45[i * 20 + j] : 0.0;
         if (dev_upload(ctx, &ctx->blosum, tab, 21 * 21)) return 1;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // one-hot operand image of the reference rows for the matrix-core filter of the fused pass (dist_sd.hip): 10 bytes per
+        // site and slot (253 MB at 50 000 x 500)
+        if (a.all_singleton && !(ctx->dbg & APPLES_DBG_NO_SD_GEMM) && sd_steps(a.L) >= 2) {
+            uint8_t codes[400];
+            sd_table_codes(kBlosum45, codes);
+            if (dev_upload(ctx, &ctx->sd_tq4, codes, 400)) return 1;
+            if (dev_alloc(ctx, &a.sd_ref4, a.slots_pad * (int64_t)sd_steps(a.L) * 64)) return 1;
+            if (dev_alloc(ctx, &a.sd_nvr, a.slots_pad)) return 1;
+            if (launch_sd_expand(ctx, a.raw, a.n_rows, a.sd_ref4, a.slots_pad, ctx->stream, a.d_slot_row, 0, false, a.sd_nvr)) return 1;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (codes is on the stack)
+        }
     } else {
         int *d_exotic = nullptr;
         if (dev_alloc(ctx, &d_exotic, 1)) return 1;
@@ -717,6 +728,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
 void free_block(apples_ctx *ctx, QueryBlock *qb) {
     blk_free(ctx, qb->table); blk_free(ctx, qb->raw); blk_free(ctx, qb->packed); blk_free(ctx, qb->qf4);
     blk_free(ctx, qb->aa_idx); blk_free(ctx, qb->aa_mask); blk_free(ctx, qb->self_slot); blk_free(ctx, qb->out);
+    blk_free(ctx, qb->sd_q4); blk_free(ctx, qb->sd_nvq);
     *qb = QueryBlock();
 }
 
@@ -742,6 +754,11 @@ int alloc_block(apples_ctx *ctx, int64_t n, const int32_t *self_row, int planes,
         HIP_TRY(ctx, hipMemsetAsync(qb->aa_idx, 20, (size_t)qb->n_pad * Lpad, st));
         if (blk_alloc(ctx, &qb->aa_mask, qb->n_pad * (Lpad / 16))) return 1;
         HIP_TRY(ctx, hipMemsetAsync(qb->aa_mask, 0, (size_t)qb->n_pad * (Lpad / 16) * 2, st));
+        if (a.sd_ref4) {  // operand image for the matrix-core filter (dist_sd.hip), tiled like the reference's
+            const int64_t n_img = round_up(qb->n_pad, 256) + 256;  // a sub-batch may start at any multiple of 32
+            if (blk_alloc(ctx, &qb->sd_q4, n_img * sd_steps(a.L) * 64)) return 1;
+            if (blk_alloc(ctx, &qb->sd_nvq, n_img)) return 1;
+        }
     } else {
         qb->planes = planes;
         int64_t w = qb->n_pad * a.G * (planes + 1);
@@ -764,7 +781,13 @@ int fill_block(apples_ctx *ctx, QueryBlock *qb, const uint8_t *queries, int64_t 
     HIP_TRY(ctx, hipMemcpyAsync(qb->raw + q0 * a.L, queries + q0 * a.L, (size_t)nq * a.L, hipMemcpyHostToDevice, st));
     if (ctx->params.model == APPLES_SCOREDIST) {
         int Lpad = (a.L + 15) / 16 * 16;
-        return launch_pack_aa(ctx, qb->raw + q0 * a.L, nq, a.L, qb->aa_idx + q0 * Lpad, qb->aa_mask + q0 * (Lpad / 16), 0, true, st);
+        if (launch_pack_aa(ctx, qb->raw + q0 * a.L, nq, a.L, qb->aa_idx + q0 * Lpad, qb->aa_mask + q0 * (Lpad / 16), 0, true, st)) return 1;
+        if (qb->sd_q4) {
+            const int64_t n_img = round_up(qb->n_pad, 256) + 256;
+            const bool last = q0 + nq >= qb->n;  // the last chunk also zeroes the image's padding rows
+            if (launch_sd_expand(ctx, qb->raw + q0 * a.L, nq, qb->sd_q4, last ? n_img - q0 : nq, st, nullptr, q0, true, qb->sd_nvq)) return 1;
+        }
+        return 0;
     }
     if (launch_pack_rows(ctx, qb->raw + q0 * a.L, nq, a.L, qb->planes, qb->packed + q0 * a.G * (qb->planes + 1), 0, true,
                          ctx->d_exotic, st)) return 1;
@@ -1148,18 +1171,27 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else if (sfused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
-            if (launch_scoredist_fused(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt, w.dist_slow)) return 1;
+            if (qb.sd_q4 && sd_gemm_usable(ctx)) {
+                // lower bounds on the matrix cores -> candidates per segment -> exact distances of the candidates, the
+                // segments closed up in place (dist_sd.hip)
+                HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (w.stride / 64) * sizeof(int32_t), front));
+                if (launch_sd_filter(ctx, qb, q0, nq, w.seg_slot, w.seg_cnt)) return 1;
+                if (launch_sd_exact(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt)) return 1;
+            } else if (launch_scoredist_fused(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt, nullptr)) return 1;
             HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;
             SelectArgs sa = select_args_alignment(ctx, qb, q0);
             sa.seg_lut = nullptr;
             if (launch_select_fast(ctx, sa, nq)) return 1;
-            // the queries that need the top-up rule: streamed selection over their full rows (row = query)
+            // the queries that need the top-up rule: full rows for the listed queries only (row r of dist_slow = list
+            // entry r), a slice of the list at a time, then the general selection over those rows
             sa.dist = w.dist_slow;
-            sa.qlist = w.slow_list;
-            sa.qcount = w.slow_count;
-            sa.rows_by_query = 1;
-            if (launch_select(ctx, sa, nq)) return 1;
+            if (for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
+                    if (launch_scoredist_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow)) return 1;
+                    sa.qlist = lst;
+                    sa.qcount = cntp;
+                    return launch_select(ctx, sa, n_max);
+                })) return 1;
             HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else if (fused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
@@ -1260,7 +1292,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         static const struct { const char *env; uint32_t bit; } knobs[] = {
             {"APPLES_NO_FUSE", APPLES_DBG_NO_FUSE}, {"APPLES_SWEEP_SCAN", APPLES_DBG_SWEEP_SCAN}, {"APPLES_NODE_MAP", APPLES_DBG_NODE_MAP},
             {"APPLES_SWEEP_MERGE", APPLES_DBG_SWEEP_MERGE}, {"APPLES_NO_SWEEP_MERGE", APPLES_DBG_NO_SWEEP_MERGE},
-            {"APPLES_NO_DIST_GEMM", APPLES_DBG_NO_DIST_GEMM}, {"APPLES_NO_SWEEP_LEAN", APPLES_DBG_NO_SWEEP_LEAN}};
+            {"APPLES_NO_DIST_GEMM", APPLES_DBG_NO_DIST_GEMM}, {"APPLES_NO_SWEEP_LEAN", APPLES_DBG_NO_SWEEP_LEAN},
+            {"APPLES_NO_SD_GEMM", APPLES_DBG_NO_SD_GEMM}};
         for (const auto &k : knobs)
             if (getenv(k.env)) ctx->dbg |= k.bit;
     }
@@ -1421,7 +1454,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(ctx->sd_tq4); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

@@ -37,6 +37,34 @@ struct __attribute__((aligned(16))) AncRec {
     int32_t pad;
 };
 
+// residue -> BLOSUM45 row/column (apples/distance.py:418-678: a2i, both cases; anything else counts as 'A'), 20 = gap
+__device__ __forceinline__ uint8_t aa_index(uint8_t b) {
+    switch (b) {
+        case 'A': case 'a': return 0;
+        case 'R': case 'r': return 1;
+        case 'N': case 'n': return 2;
+        case 'D': case 'd': return 3;
+        case 'C': case 'c': return 4;
+        case 'Q': case 'q': return 5;
+        case 'E': case 'e': return 6;
+        case 'G': case 'g': return 7;
+        case 'H': case 'h': return 8;
+        case 'I': case 'i': return 9;
+        case 'L': case 'l': return 10;
+        case 'K': case 'k': return 11;
+        case 'M': case 'm': return 12;
+        case 'F': case 'f': return 13;
+        case 'P': case 'p': return 14;
+        case 'S': case 's': return 15;
+        case 'T': case 't': return 16;
+        case 'W': case 'w': return 17;
+        case 'Y': case 'y': return 18;
+        case 'V': case 'v': return 19;
+        case '-': return 20;
+        default: return 0;
+    }
+}
+
 struct DevTree {
     int32_t n_nodes = 0;
     int32_t height = 0;  // max level
@@ -99,6 +127,9 @@ struct DevAlign {
     int64_t reps_pad = 0;
     uint8_t *aa_idx = nullptr;    // scoredist: [Lpad16/16][slots_pad][16] residue index * 8 (0..152, 160 = gap)
     uint16_t *aa_mask = nullptr;  // scoredist: [Lpad16/16][slots_pad] bit k = site 16*s16+k is not a gap
+    uint8_t *sd_ref4 = nullptr;   // scoredist, singleton clusters: one-hot fp4 operand image of the reference rows (dist_sd.hip),
+                                  // [slots_pad / 256][steps][1024 chunks of 16 B], 20 values per site
+    float *sd_nvr = nullptr;      // [slots_pad] sites of the row that are not gaps (-1: no row in the slot)
     int32_t *slot_node = nullptr; // [n_refs] tree node or -1
     int32_t *slot_level = nullptr;// [n_refs] level or -1
     int32_t *lvl_slots = nullptr; // [height + 2] entry l + 1: slots with a level above l (slots are sorted by level, deepest first); null
@@ -122,6 +153,9 @@ struct QueryBlock {
                                   // k_jc69_mfma; beside a reference image (DevAlign::ref_f4) the compact tiled form of dist_gemm.hip
     uint8_t *aa_idx = nullptr;    // [n_pad][Lpad16] residue index (20 = gap)
     uint16_t *aa_mask = nullptr;  // [n_pad][Lpad16/16]
+    uint8_t *sd_q4 = nullptr;     // scoredist beside a reference image (DevAlign::sd_ref4): the rounded-down table rows of the query's
+                                  // residues as an fp4 operand image, same tiled form
+    float *sd_nvq = nullptr;      // [image rows] the query's sites that are not gaps (-1: padding row)
     int32_t *self_slot = nullptr; // [n]
     apples_placement *out = nullptr;  // [n] device
     int planes = 0;
@@ -213,6 +247,7 @@ struct apples_ctx {
     int n_cu = 0;  // compute units of the device (dist_gemm.hip's persistent grid)
     int32_t *jc_mmax = nullptr;  // [L+1] largest mismatch count with 0 <= lut <= threshold, per valid count
     double *blosum = nullptr;  // 21x21 table (row/col 20 = gap -> 0)
+    uint8_t *sd_tq4 = nullptr; // [20][20] fp4 codes of the table rounded down to the grid {0, .5, 1, 1.5, 2, 3, 4, 6} / 4 (dist_sd.hip)
     Workspace ws;
     std::vector<QueryBlock> blocks;
     // buffers of freed query blocks, kept for the next block (a host-buffer call would otherwise pay
@@ -268,6 +303,18 @@ int launch_scoredist(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t 
                      uint32_t *d_counts);
 int launch_scoredist_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, int32_t *seg_slot,
                            int32_t *seg_cnt, double *full_rows);
+int launch_scoredist_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
+                            const int32_t *qcount, double *d_dist);
+// dist_sd.hip: the fused scoredist pass as a lower bound on the matrix cores + exact evaluation of the candidates
+#define SD_GEMM_MAX_THRESHOLD 0.25  // -f beyond this: too many pairs pass for a filter to pay (full rows instead)
+void sd_table_codes(const double *blosum20x20, uint8_t *codes);
+int sd_steps(int L);                // 128-value K steps of the operand images
+bool sd_gemm_usable(const apples_ctx *ctx);
+int launch_sd_expand(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_img, hipStream_t st,
+                     const int32_t *d_src_row, int64_t row0, bool query, float *d_nv);
+int launch_sd_filter(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);
+int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, int32_t *seg_slot,
+                    int32_t *seg_cnt);
 // select.hip
 struct SelectArgs {
     const double *dist;       // [nq][stride]

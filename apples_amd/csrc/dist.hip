@@ -8,6 +8,7 @@
 // the scalar cache and occupy SGPRs, not LDS.  HBM traffic per launch is the packed reference
 // once per query tile plus 8 B per pair of output.  No MFMA: this is popcount, not a contraction.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -679,56 +680,103 @@ int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int6
 // 21-entry row with their own residue, i.e. 21 consecutive 8-byte words: conflict-free ds_read_b64.
 // Sites are summed left to right in fp64 (the reference's order is whatever BLAS ddot does, so
 // this path is tolerance-checked, not bit-checked).
-// MODE 0: full rows for queries q0.. ; MODE 1: fused threshold compaction per 64-slot segment (the format
-// k_select_fast reads, as k_jc69 MODE 1) with the full rows beside it
+// Workgroup = 256 reference slots x TQ queries; blockIdx.x walks the query tiles, blockIdx.y the slot blocks, so that the
+// workgroups in flight together share one 140 KB slice of the reference (L2) and stream the queries.
+// MODE 0: full rows for queries q0.. ; MODE 2: full rows for the queries named by qlist[0..*qcount) (top-up path), row r
+// of dist belongs to qlist[r]; MODE 1: fused threshold compaction per 64-slot segment (the format k_select_fast reads, as
+// k_jc69 MODE 1), with an exact early exit: the table is >= 0, so the partial sums only grow, and d <= thr <=> tot <=
+// c valid with c = 1 - exp(-thr / 1.3).  valid comes first (gap masks only); a query of the tile whose 64 partial sums
+// all exceed c valid (1 + 1e-9) is dropped from the wavefront's site loop (a wave-uniform mask), which ends when none is
+// left.  (The default fused route is dist_sd.hip's: this one serves wide thresholds, clustered references' representatives
+// excepted, and APPLES_NO_SD_GEMM.)
 template <int TQ, int MODE>
 __global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
                                                           const uint8_t *__restrict__ qa, const uint16_t *__restrict__ qm,
                                                           const double *__restrict__ table, double *__restrict__ dist,
                                                           uint32_t *__restrict__ counts, int64_t n_slots,
                                                           int64_t slots_pad, int Lpad, int L, int64_t nq, double overlap,
-                                                          double thr, int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
-                                                          double *__restrict__ full) {
+                                                          double thr, double cfrac, int32_t *__restrict__ seg_slot,
+                                                          int32_t *__restrict__ seg_cnt, const int32_t *__restrict__ qlist,
+                                                          const int32_t *__restrict__ qcount) {
     __shared__ double T[21 * 21];
     for (int i = threadIdx.x; i < 21 * 21; i += APPLES_TPB) T[i] = table[i];
     __syncthreads();
     const char *Tb = reinterpret_cast<const char *>(T);
-    const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    const int64_t slot = (int64_t)blockIdx.y * APPLES_TPB + threadIdx.x;
     const int n16 = Lpad / 16;
-    const int64_t q0 = (int64_t)blockIdx.y * TQ;
+    if (MODE == 2) nq = *qcount;
+    // listed mode: the list length lives on the device, so a bounded grid.x loops over the tiles
+    for (int64_t q0 = (int64_t)blockIdx.x * TQ; q0 < nq; q0 += (MODE == 2 ? (int64_t)gridDim.x * TQ : nq)) {
+    int64_t qi[TQ];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) qi[t] = (MODE == 2) ? (int64_t)qlist[(q0 + t < nq) ? q0 + t : q0] : q0 + t;
     double tot[TQ];
     uint32_t nv[TQ];
 #pragma unroll
     for (int t = 0; t < TQ; ++t) { tot[t] = 0.0; nv[t] = 0; }
-    for (int s16 = 0; s16 < n16; ++s16) {
+    uint32_t alive = (1u << TQ) - 1u;  // wave-uniform
+    double cut[TQ];
+    if (MODE == 1) {
+        for (int s16 = 0; s16 < n16; ++s16) {
+            const uint32_t rmask = refm[(int64_t)s16 * slots_pad + slot];
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) nv[t] += __popc(rmask & (uint32_t)qm[qi[t] * (int64_t)n16 + s16]);
+        }
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            const bool ok = slot < n_slots && nv[t] != 0 && !((double)nv[t] / (double)L < overlap);
+            cut[t] = ok ? (double)nv[t] * cfrac : -1.0;
+            if (q0 + t >= nq || __ballot(ok) == 0ull) alive &= ~(1u << t);
+        }
+    }
+    for (int s16 = 0; s16 < n16 && alive; ++s16) {
         // this row's 16 residues as table column byte offsets (index * 8), unpacked once per block of
         // sites and reused for all TQ queries
         const uint4 rw = *reinterpret_cast<const uint4 *>(refa + ((int64_t)s16 * slots_pad + slot) * 16);
-        const uint32_t rmask = refm[(int64_t)s16 * slots_pad + slot];
         uint32_t r8[16];
         const uint32_t rr[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
         for (int k = 0; k < 16; ++k) r8[k] = (rr[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        // wave-uniform: the queries' residues select table rows (scalar arithmetic)
-        uint32_t qv[TQ][4];
-#pragma unroll
-        for (int t = 0; t < TQ; ++t) {
-            const uint4 qw = *reinterpret_cast<const uint4 *>(qa + (q0 + t) * (int64_t)Lpad + s16 * 16);
-            qv[t][0] = qw.x; qv[t][1] = qw.y; qv[t][2] = qw.z; qv[t][3] = qw.w;
-            nv[t] += __popc(rmask & (uint32_t)qm[(q0 + t) * (int64_t)n16 + s16]);
-        }
-        // site-major: the TQ table reads of one site are independent, so they are in flight together;
-        // each query still sums its sites left to right
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            double v[TQ];
+        if (MODE != 1) {
+            const uint32_t rmask = refm[(int64_t)s16 * slots_pad + slot];
+            // wave-uniform: the queries' residues select table rows (scalar arithmetic)
+            uint32_t qv[TQ][4];
 #pragma unroll
             for (int t = 0; t < TQ; ++t) {
-                const uint32_t qrow = ((qv[t][k >> 2] >> (8 * (k & 3))) & 0xffu) * 168u;  // 21 columns * 8 bytes
-                v[t] = *reinterpret_cast<const double *>(Tb + qrow + r8[k]);               // gap row/column = +0.0
+                const uint4 qw = *reinterpret_cast<const uint4 *>(qa + qi[t] * (int64_t)Lpad + s16 * 16);
+                qv[t][0] = qw.x; qv[t][1] = qw.y; qv[t][2] = qw.z; qv[t][3] = qw.w;
+                nv[t] += __popc(rmask & (uint32_t)qm[qi[t] * (int64_t)n16 + s16]);
             }
+            // site-major: the TQ table reads of one site are independent, so they are in flight together;
+            // each query still sums its sites left to right
 #pragma unroll
-            for (int t = 0; t < TQ; ++t) tot[t] += v[t];
+            for (int k = 0; k < 16; ++k) {
+                double v[TQ];
+#pragma unroll
+                for (int t = 0; t < TQ; ++t) {
+                    const uint32_t qrow = ((qv[t][k >> 2] >> (8 * (k & 3))) & 0xffu) * 168u;  // 21 columns * 8 bytes
+                    v[t] = *reinterpret_cast<const double *>(Tb + qrow + r8[k]);               // gap row/column = +0.0
+                }
+#pragma unroll
+                for (int t = 0; t < TQ; ++t) tot[t] += v[t];
+            }
+        } else {
+            // query-major over the queries still alive: a query's 16 lookups are independent of one another
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) {
+                if (!((alive >> t) & 1u)) continue;  // (wave-uniform)
+                const uint4 qw = *reinterpret_cast<const uint4 *>(qa + qi[t] * (int64_t)Lpad + s16 * 16);
+                const uint32_t qq[4] = {qw.x, qw.y, qw.z, qw.w};
+                double v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t qrow = ((qq[k >> 2] >> (8 * (k & 3))) & 0xffu) * 168u;
+                    v[k] = *reinterpret_cast<const double *>(Tb + qrow + r8[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) tot[t] += v[k];
+                if (__ballot(tot[t] <= cut[t]) == 0ull) alive &= ~(1u << t);
+            }
         }
     }
     const int lane = threadIdx.x & 63;
@@ -746,7 +794,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restr
                 else d = -log(r1) * 1.3;
             }
             if (MODE == 1) {
-                const bool keep = slot < n_slots && d >= 0 && d <= thr;
+                // (a query dropped from the site loop has no pair left that can pass; the pairs of the others whose sums
+                // stopped growing when they exceeded their cut fail the test below on the partial sum already)
+                const bool keep = ((alive >> t) & 1u) && slot < n_slots && tot[t] <= cut[t] && d >= 0 && d <= thr;
                 const unsigned long long m = __ballot(keep);
                 if (keep) {
                     const int64_t oo = (q0 + t) * slots_pad + seg * 64 + __popcll(m & ((1ull << lane) - 1ull));
@@ -754,17 +804,16 @@ __global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restr
                     dist[oo] = d;
                 }
                 if (lane == 0) seg_cnt[(q0 + t) * n_seg + seg] = __popcll(m);
-                // the full row beside it: a table lookup per site makes these rows too dear to compute twice for
-                // the queries that turn out to need the top-up rule (with JC69 they are recomputed, which is cheaper
-                // than writing them for everybody)
-                if (full && slot < n_slots) full[o] = d;
             } else if (slot < n_slots) {
                 if (dist) dist[o] = d;
                 if (counts) counts[o] = valid;
             }
         }
     }
+    }
 }
+
+static double sd_cut_fraction(double thr) { return (1.0 - std::exp(-thr / 1.3)) * (1.0 + 1e-9); }
 
 int launch_scoredist(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *d_dist,
                      uint32_t *d_counts) {
@@ -772,25 +821,44 @@ int launch_scoredist(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t 
     const DevAlign &a = ctx->aln;
     int Lpad = (a.L + 15) / 16 * 16;
     constexpr int TQ = 8;
-    hipLaunchKernelGGL((k_scoredist<TQ, 0>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)),
+    hipLaunchKernelGGL((k_scoredist<TQ, 0>), dim3((unsigned)((nq + TQ - 1) / TQ), (unsigned)(a.slots_pad / APPLES_TPB)),
                        dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask, qb.aa_idx + q0 * Lpad,
                        qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, d_dist, d_counts, a.n_rows, a.slots_pad, Lpad, a.L, nq,
-                       ctx->params.overlap_frac, 0.0, (int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr);
+                       ctx->params.overlap_frac, 0.0, 0.0, (int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
 // fused threshold compaction (MODE 1: seg_d/seg_slot/seg_cnt as launch_counts_fused leaves them for k_select_fast)
 int launch_scoredist_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, int32_t *seg_slot,
-                           int32_t *seg_cnt, double *full_rows) {
+                           int32_t *seg_cnt, double *) {
     if (nq == 0) return 0;
     const DevAlign &a = ctx->aln;
     int Lpad = (a.L + 15) / 16 * 16;
     constexpr int TQ = 8;
-    hipLaunchKernelGGL((k_scoredist<TQ, 1>), dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)((nq + TQ - 1) / TQ)),
+    hipLaunchKernelGGL((k_scoredist<TQ, 1>), dim3((unsigned)((nq + TQ - 1) / TQ), (unsigned)(a.slots_pad / APPLES_TPB)),
                        dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask, qb.aa_idx + q0 * Lpad,
                        qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, seg_d, (uint32_t *)nullptr, a.n_rows, a.slots_pad, Lpad, a.L, nq,
-                       ctx->params.overlap_frac, ctx->params.filt_threshold, seg_slot, seg_cnt, full_rows);
+                       ctx->params.overlap_frac, ctx->params.filt_threshold, sd_cut_fraction(ctx->params.filt_threshold), seg_slot,
+                       seg_cnt, (const int32_t *)nullptr, (const int32_t *)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// full rows for a device-side list of queries of the block starting at q0 (MODE 2): row r of d_dist = query qlist[r]; the grid
+// covers at most nq_max list entries and tiles beyond *qcount exit at once
+int launch_scoredist_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
+                            const int32_t *qcount, double *d_dist) {
+    if (nq_max == 0) return 0;
+    const DevAlign &a = ctx->aln;
+    int Lpad = (a.L + 15) / 16 * 16;
+    constexpr int TQ = 8;
+    const int64_t tiles = std::min<int64_t>((nq_max + TQ - 1) / TQ, 4096);
+    hipLaunchKernelGGL((k_scoredist<TQ, 2>), dim3((unsigned)tiles, (unsigned)(a.slots_pad / APPLES_TPB)),
+                       dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask, qb.aa_idx + q0 * Lpad,
+                       qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, d_dist, (uint32_t *)nullptr, a.n_rows, a.slots_pad, Lpad, a.L,
+                       nq_max, ctx->params.overlap_frac, 0.0, 0.0, (int32_t *)nullptr, (int32_t *)nullptr, qlist, qcount);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

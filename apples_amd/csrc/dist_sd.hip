@@ -1,0 +1,490 @@
+// scoredist (apples/distance.py:681-715) with singleton clusters, fused route: "most pairs fail the threshold".
+//
+// d <= f  <=>  tot / valid <= c = 1 - exp(-f / 1.3), tot = sum over sites of T[q_s][r_s] (the BLOSUM45 dissimilarities,
+// all >= 0, zero against a gap), and only 0.3 % of the pairs of the benchmark shape pass.  Two kernels:
+//
+//  1. k_sd_gemm: an exact LOWER BOUND of tot for every pair on the matrix cores.  tot is the bilinear form
+//     sum_s sum_a Tq[q_s][a] * [r_s == a] over the 20 residues: the reference row as a one-hot image (20 fp4 values per
+//     site: 1.0 at its residue, all zero at a gap), the query row as 20 table values per site, each ROUNDED DOWN to the
+//     fp4 grid v / 4 with v in {0, .5, 1, 1.5, 2, 3, 4, 6} (e2m1).  Products and sums of these are exact in the f32
+//     accumulators (multiples of 0.5 below 2^24), so acc / 4 <= tot holds as a statement about real numbers, and a
+//     pair whose bound exceeds c * min(valid sites of the query, of the reference) >= c * valid cannot pass.  What is
+//     left (0.8 - 1.1 % of the pairs at the benchmark shape: the quantised table gives 0.83 of tot on average) is
+//     written per 64-slot segment in slot order -- the format k_select_fast reads -- as CANDIDATES.
+//     The kernel is dist_gemm.hip's pipeline (pre-expanded operand images in HBM stored as the kernel's LDS tile
+//     images, LDS-DMA two steps ahead, three generations, 256 x 256 workgroup tiles, persistent workgroups walking
+//     strips per XCD) with a plain K loop: a step is 128 K values = 64 bytes per row = two MFMAs per tile pair.
+//  2. k_sd_exact: a workgroup per query walks its candidates, evaluates each pair exactly as k_scoredist does (fp64,
+//     sites left to right, the same table in LDS: the same bits), applies the real test 0 <= d <= f and closes the
+//     segments up in place.  k_select_fast then sees what k_scoredist<MODE 1> would have written.
+//
+// Queries left with fewer than `-b` survivors take the top-up rule on full rows (k_scoredist listed mode), as before.
+#include <cmath>
+
+#include "common.h"
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+#define SD_T 256             // tile edge: queries and reference slots per workgroup
+#ifndef SD_STRIP
+#define SD_STRIP 4           // reference tiles per strip
+#endif
+#define SD_IMG (SD_T * 64)   // bytes of one tile-step image: 256 rows x 128 fp4 values
+
+namespace {
+
+__device__ __forceinline__ v16f_t sd_mfma(const v4i_t &a, const v4i_t &b, const v16f_t &c) {
+    const v8i_t a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0, 0, 0);  // fp4 x fp4, unscaled
+}
+
+// rows -> operand image.  K index of (site s, residue a) = 20 s + a; a step is 128 K values, chunk c of a row its
+// values 32 c .. 32 c + 31 (16 bytes: value e in nibble e & 7 of dword e >> 3 -- any order serves as long as both
+// operands share it).  The image is stored as the kernel's LDS image of a 256-row tile and one step: row rr's chunk c
+// at position 4 rr + (c ^ ((rr >> 2) & 3)) of the tile-step's 1024 chunks (dist_gemm.hip).  tq4 == nullptr: one-hot
+// (reference side); else the fp4 codes of the rounded-down table row of the query's residue.  nv[image row] = the
+// row's sites that are not gaps, -1 for padding rows (no pair with them may pass).
+__global__ __launch_bounds__(APPLES_TPB) void k_sd_expand(const uint8_t *__restrict__ raw, int64_t n, int L, int NB,
+                                                          uint4 *__restrict__ out, int64_t n_img,
+                                                          const int32_t *__restrict__ src_row, int64_t row0,
+                                                          const uint8_t *__restrict__ tq4, float *__restrict__ nv) {
+    const int64_t idx = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;  // one thread per (row, step, chunk)
+    if (idx >= n_img * NB * 4) return;
+    const int c = (int)(idx & 3);
+    const int64_t rb = idx >> 2;
+    const int b = (int)(rb % NB);
+    const int64_t q = rb / NB;
+    uint32_t w[4] = {0, 0, 0, 0};
+    const uint8_t *row = nullptr;
+    if (q < n) {
+        row = raw + (src_row ? (int64_t)src_row[q] : q) * (int64_t)L;
+        const int k0 = b * 128 + c * 32;
+        int s = k0 / 20, a = k0 - s * 20;
+        uint32_t v = s < L ? aa_index(row[s]) : 20u;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            uint32_t nib = 0;
+            if (v < 20u) nib = tq4 ? tq4[v * 20u + a] : (v == (uint32_t)a ? 2u : 0u);
+            w[e >> 3] |= nib << (4 * (e & 7));
+            if (++a == 20) {
+                a = 0;
+                ++s;
+                v = s < L ? aa_index(row[s]) : 20u;
+            }
+        }
+    }
+    const int64_t ar = row0 + q, tile = ar >> 8;
+    const int rr = (int)(ar & 255), sw = (rr >> 2) & 3;
+    out[(tile * NB + b) * 1024 + rr * 4 + (c ^ sw)] = make_uint4(w[0], w[1], w[2], w[3]);
+    if (b == 0 && c == 0) {
+        int cnt = -1;
+        if (q < n) {
+            cnt = 0;
+            for (int s = 0; s < L; ++s) cnt += row[s] != (uint8_t)'-';
+        }
+        nv[ar] = (float)cnt;
+    }
+}
+
+// R = (NB - 2) % 3: the shape of the main loop's tail, fixed per launch (as k_jc69_gemm)
+template <int R>
+__global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ rf4, const uint8_t *__restrict__ qf4,
+                                                    int64_t qrow0, int64_t slots_pad, int NB, int64_t nq, int TQ, int TR,
+                                                    const float *__restrict__ nvr, const float *__restrict__ nvq, float k4c,
+                                                    int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt) {
+    constexpr int QT = SD_T, AI = QT * 64, GEN = AI + SD_IMG;
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[3 * GEN];
+#define Aq(g) (lds + (g) * GEN)
+#define Br(g) (lds + (g) * GEN + AI)
+    // persistent workgroups, one per CU: XCD x takes the strips x, x + 8, ... of SD_STRIP reference tiles; within the XCD the
+    // tiles (query tile major, the strip's reference tiles inside) are dealt round-robin to its workgroups
+    const int xcd = blockIdx.x & 7;
+    const int64_t per_strip = (int64_t)TQ * SD_STRIP, stride = gridDim.x >> 3;
+    const int64_t l_end = (((TR + SD_STRIP - 1) / SD_STRIP + 7) / 8) * per_strip;
+    auto tile_at = [&](int64_t l, int64_t &qt_, int64_t &rt_) __attribute__((always_inline)) {
+        const int64_t strip = (l / per_strip) * 8 + xcd, within = l % per_strip;
+        rt_ = strip * SD_STRIP + within % SD_STRIP;
+        qt_ = within / SD_STRIP;
+    };
+    int64_t l = blockIdx.x >> 3, qt = 0, rt = 0;
+    for (;; l += stride) {  // first tile
+        if (l >= l_end) return;
+        tile_at(l, qt, rt);
+        if (rt < TR) break;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wq = wv >> 1, wr = wv & 1;
+    // DMA roles (dist_gemm.hip): a tile-step image is 16 pieces of 1 KB; this wavefront moves pieces 2 wv, 2 wv + 1 of the
+    // query image and of the reference image.  The query tile starts at image row qrow0 + q0, a multiple of 32: its rows
+    // may lie in two image tiles.
+    uint32_t doff[2];
+    const uint8_t *qtile, *rtile;
+    auto set_tile = [&](int64_t qt_, int64_t rt_) __attribute__((always_inline)) {
+        const int64_t qabs = qrow0 + qt_ * QT;
+        const int qin = (int)(qabs & 255);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = (wv * 2 + k) * 16 + (lane >> 2), slot = lane & 3, ar = qin + row;
+            doff[k] = (uint32_t)(((ar >> 8) * NB * 1024 + (ar & 255) * 4 + slot) * 16);
+        }
+        qtile = qf4 + (qabs >> 8) * (int64_t)NB * SD_IMG;
+        rtile = rf4 + rt_ * (int64_t)NB * SD_IMG;
+    };
+    set_tile(qt, rt);
+    const uint32_t roff = (uint32_t)(wv * 2 * 1024 + lane * 16);
+    const int fr = lane & 31, fh = lane >> 5;
+    int coff[2];  // byte offset of this lane's chunk of K half h of the step (its row, its 32 of the MFMA's 64 values)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) coff[h] = ((h * 2 + fh) ^ ((fr >> 2) & 3)) * 16;
+    const int arow = (wq * 64 + fr) * 64, brow = (wr * 128 + fr) * 64;
+    v16f_t acc[2][4];
+    auto dma = [&](int b, int g, int part) __attribute__((always_inline)) {  // part 0: query pieces, 1: reference pieces
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint8_t *src = part == 0 ? (qtile + b * SD_IMG) + doff[k] : (rtile + b * SD_IMG + k * 1024) + roff;
+            uint8_t *dst = part == 0 ? Aq(g) + (wv * 2 + k) * 1024 : Br(g) + (wv * 2 + k) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+    v4i_t fa[2][2], fb[2][4];  // fragment sets: [0] the step's first K half, [1] its second
+    auto load_frags = [&](int g, int h) __attribute__((always_inline)) {
+        const uint8_t *A = Aq(g) + arow + coff[h], *B = Br(g) + brow + coff[h];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[h][i] = *reinterpret_cast<const v4i_t *>(A + i * 32 * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[h][j] = *reinterpret_cast<const v4i_t *>(B + j * 32 * 64);
+    };
+    auto mfmas = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = sd_mfma(fa[h][i], fb[h][j], acc[i][j]);
+    };
+    // One step = 128 K values = 2 sections of 8 MFMAs per wavefront, generation g = step % 3.  Entry: set 0 holds the
+    // first half's fragments (read after the previous barrier).  Section 0: the second half's fragments are requested, the
+    // query pieces of step + 2 go out into the generation every wavefront left at the previous barrier.  Then the
+    // barrier: own reads of generation g done, step + 1 landed (everything but the two pieces just issued).  Section 1:
+    // the reference pieces of step + 2, the first fragments of step + 1.
+    auto step = [&](int b, int g, bool feed, bool more) __attribute__((always_inline)) {
+        const int gn = g == 2 ? 0 : g + 1, gf = g == 0 ? 2 : g - 1;
+        load_frags(g, 1);
+        if (feed) dma(b + 2, gf, 0);
+        mfmas(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (k == 1 || k == 4) {
+                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (feed) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_frags(gn, 0);
+        if (feed) dma(b + 2, gf, 1);
+        mfmas(1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (k == 1 || k == 4) {
+                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int64_t n_seg = slots_pad >> 6;
+    const uint32_t below = (1u << fr) - 1u;
+    dma(0, 0, 0); dma(0, 0, 1);
+    dma(1, 1, 0); dma(1, 1, 1);
+    for (;;) {  // tiles of this workgroup; entry: the first two steps of the tile are on their way
+        const int64_t r0 = rt * SD_T, q0 = qt * QT;  // (q0: relative to this launch's first query)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // NB (>= 2) steps: NB - 2 feeding ones, then one that only prefetches fragments, then the last
+        const int F = NB - 2;
+        int b = 0;
+        for (; b + 3 <= F; b += 3) {
+            step(b, 0, true, true);
+            step(b + 1, 1, true, true);
+            step(b + 2, 2, true, true);
+        }
+        if (R == 0) {
+            step(b, 0, false, true);
+            step(b + 1, 1, false, false);
+        } else if (R == 1) {
+            step(b, 0, true, true);
+            step(b + 1, 1, false, true);
+            step(b + 2, 2, false, false);
+        } else {
+            step(b, 0, true, true);
+            step(b + 1, 1, true, true);
+            step(b + 2, 2, false, true);
+            step(b + 3, 0, false, false);
+        }
+        // the thresholds of this tile's rows and columns, then the next tile's first two steps: after the last barrier
+        // nobody reads LDS any more.  Loads complete in order, so the counted wait below leaves the 8 pieces in flight.
+        float cq[2][16], cr[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float *p = nvq + qrow0 + q0 + wq * 64 + i * 32 + 4 * fh;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 v = *reinterpret_cast<const float4 *>(p + 8 * g4);
+                cq[i][4 * g4] = v.x * k4c; cq[i][4 * g4 + 1] = v.y * k4c; cq[i][4 * g4 + 2] = v.z * k4c; cq[i][4 * g4 + 3] = v.w * k4c;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cr[j] = nvr[r0 + wr * 128 + j * 32 + fr] * k4c;
+        int64_t nl = l + stride, nqt = 0, nrt = 0;
+        bool have = false;
+        for (; nl < l_end; nl += stride) {
+            tile_at(nl, nqt, nrt);
+            if (nrt < TR) { have = true; break; }
+        }
+        if (have) {
+            __builtin_amdgcn_sched_barrier(0);
+            set_tile(nqt, nrt);
+            dma(0, 0, 0); dma(0, 0, 1);
+            dma(1, 1, 0); dma(1, 1, 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // C layout of the 32x32 tiles: column (reference slot) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+        // A pair is a candidate when acc <= 4 c (1 + 1e-6) min(nv of its query, nv of its reference row)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t qbase = q0 + wq * 64 + i * 32 + 4 * fh;  // this lane half's first query of the 32
+            // (rows past this launch's queries may be real queries of the next sub-batch: not ours to write)
+            const int rem = (int)(nq - qbase < 32 ? nq - qbase : 32);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int64_t seg = (r0 + wr * 128 + s * 64) >> 6;
+                int32_t *row0 = seg_slot + qbase * slots_pad + seg * 64;
+                int32_t *cnt0 = seg_cnt + qbase * n_seg + seg;
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const int cx = (x & 3) + 8 * (x >> 2);  // this register's query, relative to qbase
+                    const bool c0 = acc[i][2 * s][x] <= fminf(cq[i][x], cr[2 * s]);
+                    const bool c1 = acc[i][2 * s + 1][x] <= fminf(cq[i][x], cr[2 * s + 1]);
+                    if (__ballot(c0 || c1) == 0ull) continue;
+                    const bool in = cx < rem;
+                    const bool k0 = c0 && in, k1 = c1 && in;
+                    const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
+                    if ((b0 | b1) == 0) continue;  // the counts stay at their preset zero
+                    // this lane half's query: slots 0..31 of the segment from tile 2 s, 32..63 from tile 2 s + 1
+                    const uint32_t lo = (uint32_t)(b0 >> (32 * fh)), hi = (uint32_t)(b1 >> (32 * fh));
+                    int32_t *row = row0 + (int64_t)cx * slots_pad;
+                    if (k0) row[__popc(lo & below)] = (int32_t)(seg * 64 + fr);
+                    if (k1) row[__popc(lo) + __popc(hi & below)] = (int32_t)(seg * 64 + 32 + fr);
+                    if (fr == 0 && in) cnt0[(int64_t)cx * n_seg] = __popc(lo) + __popc(hi);
+                }
+            }
+        }
+        if (!have) break;
+        l = nl; qt = nqt; rt = nrt;
+    }
+#undef Aq
+#undef Br
+}
+
+// exact scoredist of (the block's query, reference slot), the arithmetic of k_scoredist (dist.hip): sites left to right in
+// fp64, the 21 x 21 table (zero gap row / column) in LDS at Tb; the query's residues are workgroup-uniform
+__device__ __forceinline__ double sd_pair_exact(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
+                                                int64_t slots_pad, int64_t slot, const uint8_t *__restrict__ qrow,
+                                                const uint16_t *__restrict__ qmask, int n16, const char *Tb, int L,
+                                                double overlap) {
+    double tot = 0.0;
+    uint32_t valid = 0;
+    uint4 rw = *reinterpret_cast<const uint4 *>(refa + slot * 16);
+    uint32_t rmask = refm[slot];
+    for (int s16 = 0; s16 < n16; ++s16) {
+        const uint4 cw = rw;
+        const uint32_t cm = rmask;
+        if (s16 + 1 < n16) {  // the next block's gather leaves before this block's sixteen lookups
+            rw = *reinterpret_cast<const uint4 *>(refa + ((int64_t)(s16 + 1) * slots_pad + slot) * 16);
+            rmask = refm[(int64_t)(s16 + 1) * slots_pad + slot];
+        }
+        const uint4 qw = *reinterpret_cast<const uint4 *>(qrow + s16 * 16);
+        valid += __popc(cm & (uint32_t)qmask[s16]);
+        const uint32_t rr[4] = {cw.x, cw.y, cw.z, cw.w}, qq[4] = {qw.x, qw.y, qw.z, qw.w};
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t r8 = (rr[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            const uint32_t qr = ((qq[k >> 2] >> (8 * (k & 3))) & 0xffu) * 168u;  // 21 columns * 8 bytes
+            v[k] = *reinterpret_cast<const double *>(Tb + qr + r8);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += v[k];
+    }
+    if (valid == 0 || (double)valid / (double)L < overlap) return -1.0;
+    const double r1 = 1 - tot / (double)valid;
+    if (0 >= r1) return -1.0;
+    return -log(r1) * 1.3;
+}
+
+// candidates -> survivors, in place (see the head of the file).  One workgroup per query; the segments are walked in
+// chunks of 256, a chunk's candidates as one flat list, 256 at a time.
+__global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
+                                                         const uint8_t *__restrict__ qa, const uint16_t *__restrict__ qm,
+                                                         const double *__restrict__ table, int64_t n_slots, int64_t slots_pad,
+                                                         int Lpad, int L, double overlap, double thr,
+                                                         double *__restrict__ seg_d, int32_t *__restrict__ seg_slot,
+                                                         int32_t *__restrict__ seg_cnt) {
+    constexpr int TPB = APPLES_TPB, NW = TPB / 64;
+    __shared__ double T[21 * 21];
+    __shared__ int sh_pref[TPB + 1];
+    __shared__ int sh_w[NW];
+    __shared__ uint8_t sh_keep[TPB * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 21 * 21; i += TPB) T[i] = table[i];
+    const char *Tb = reinterpret_cast<const char *>(T);
+    const int64_t q = blockIdx.x;
+    const int n16 = Lpad / 16;
+    const int64_t n_seg = slots_pad >> 6;
+    int32_t *cnt = seg_cnt + q * n_seg;
+    int32_t *sslot = seg_slot + q * slots_pad;
+    double *sd = seg_d + q * slots_pad;
+    const uint8_t *qrow = qa + q * (int64_t)Lpad;
+    const uint16_t *qmask = qm + q * (int64_t)n16;
+    for (int64_t s0 = 0; s0 < n_seg; s0 += TPB) {
+        const int64_t sg = s0 + tid;
+        const int my = sg < n_seg ? cnt[sg] : 0;
+        // exclusive prefix of the chunk's counts
+        int incl = my;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        __syncthreads();  // (the previous chunk is done with sh_pref / sh_keep; first chunk: the table is written)
+        if (lane == 63) sh_w[w] = incl;
+        __syncthreads();
+        int base = 0, chunk_total = 0;
+        for (int k = 0; k < NW; ++k) {
+            if (k < w) base += sh_w[k];
+            chunk_total += sh_w[k];
+        }
+        sh_pref[tid] = base + incl - my;
+        if (tid == 0) sh_pref[TPB] = chunk_total;
+        __syncthreads();
+        for (int e0 = 0; e0 < chunk_total; e0 += TPB) {  // (block-uniform)
+            const int e = e0 + tid;
+            const bool in = e < chunk_total;
+            int lo = 0, slot = 0, first = 0;
+            bool keep = false, last = false;
+            double d = -1.0;
+            if (in) {
+                int hi = TPB;  // last segment whose prefix <= e (empty segments share a prefix: the last one wins, and holds e)
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sh_pref[mid] <= e) lo = mid; else hi = mid;
+                }
+                first = sh_pref[lo];
+                last = e + 1 == sh_pref[lo + 1];
+                slot = sslot[(s0 + lo) * 64 + (e - first)];
+                if (slot < n_slots) d = sd_pair_exact(refa, refm, slots_pad, slot, qrow, qmask, n16, Tb, L, overlap);
+                keep = d >= 0 && d <= thr;
+                sh_keep[e] = keep ? 1 : 0;
+            }
+            __syncthreads();  // this round's candidates are read and judged: survivors may now move left
+            if (in && (keep || last)) {
+                int pos = 0;
+                for (int k = first; k < e; ++k) pos += sh_keep[k];
+                if (keep) {
+                    sslot[(s0 + lo) * 64 + pos] = slot;
+                    sd[(s0 + lo) * 64 + pos] = d;
+                }
+                if (last) cnt[s0 + lo] = pos + (keep ? 1 : 0);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// fp4 codes of the rounded-down table: code of the largest v in {0, .5, 1, 1.5, 2, 3, 4, 6} with v / 4 <= T[a][b]
+void sd_table_codes(const double *blosum20x20, uint8_t *codes /* [20][20] */) {
+    static const double grid[8] = {0, 0.5, 1, 1.5, 2, 3, 4, 6};
+    for (int i = 0; i < 400; ++i) {
+        int c = 0;
+        for (int k = 0; k < 8; ++k)
+            if (grid[k] / 4.0 <= blosum20x20[i]) c = k;
+        codes[i] = (uint8_t)c;
+    }
+}
+
+int sd_steps(int L) { return (20 * L + 127) / 128; }
+
+bool sd_gemm_usable(const apples_ctx *ctx) {
+    // (a wide threshold keeps most pairs: nothing to filter; the full rows of k_scoredist are then the cheaper form)
+    return ctx->aln.sd_ref4 != nullptr && ctx->params.filt_threshold <= SD_GEMM_MAX_THRESHOLD;
+}
+
+int launch_sd_expand(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_img, hipStream_t st,
+                     const int32_t *d_src_row, int64_t row0, bool query, float *d_nv) {
+    if (n_img <= 0) return 0;
+    const int NB = sd_steps(ctx->aln.L);
+    const int64_t total = n_img * NB * 4;
+    hipLaunchKernelGGL(k_sd_expand, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0, st ? st : ctx->stream,
+                       d_raw, n, ctx->aln.L, NB, reinterpret_cast<uint4 *>(d_out), n_img, d_src_row, row0,
+                       query ? ctx->sd_tq4 : (const uint8_t *)nullptr, d_nv);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// candidates of queries [q0, q0 + nq) of the block: seg_slot / seg_cnt rows relative to q0 (seg_cnt preset to zero)
+int launch_sd_filter(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt) {
+    if (nq == 0) return 0;
+    const DevAlign &a = ctx->aln;
+    const int NB = sd_steps(a.L);
+    const int TQ = (int)((nq + SD_T - 1) / SD_T), TR = (int)(a.slots_pad / SD_T);
+    if (ctx->n_cu == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->n_cu = prop.multiProcessorCount;
+    }
+    const int64_t grid = std::max(8, ctx->n_cu / 8 * 8);
+    // d <= f <=> tot <= c valid with c = 1 - exp(-f / 1.3); the bound is 4 sum of the rounded-down values: margin 1e-6
+    const double c = 1.0 - std::exp(-ctx->params.filt_threshold / 1.3);
+    float k4c = (float)(4.0 * c * (1.0 + 1e-6));
+    k4c = std::nextafterf(k4c, INFINITY);
+    const int R = (NB - 2) % 3;
+#define SD_LAUNCH(R_)                                                                                              \
+    hipLaunchKernelGGL((k_sd_gemm<R_>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, a.sd_ref4, qb.sd_q4, q0,  \
+                       a.slots_pad, NB, nq, TQ, TR, a.sd_nvr, qb.sd_nvq, k4c, seg_slot, seg_cnt)
+    if (R == 0) SD_LAUNCH(0); else if (R == 1) SD_LAUNCH(1); else SD_LAUNCH(2);
+#undef SD_LAUNCH
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, int32_t *seg_slot,
+                    int32_t *seg_cnt) {
+    if (nq == 0) return 0;
+    const DevAlign &a = ctx->aln;
+    const int Lpad = (a.L + 15) / 16 * 16;
+    hipLaunchKernelGGL(k_sd_exact, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask,
+                       qb.aa_idx + q0 * Lpad, qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L,
+                       ctx->params.overlap_frac, ctx->params.filt_threshold, seg_d, seg_slot, seg_cnt);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

@@ -84,32 +84,7 @@ int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int 
 //                    table column, so the kernel adds it to a row base without scaling)
 //   query rows     : aa[q * Lpad + site] = index
 //   gap masks      : mask[s16 * slots_pad + slot] / mask[q * (Lpad/16) + s16]: bit k = site is not '-'
-__device__ __forceinline__ uint8_t aa_index(uint8_t b) {
-    switch (b) {
-        case 'A': case 'a': return 0;
-        case 'R': case 'r': return 1;
-        case 'N': case 'n': return 2;
-        case 'D': case 'd': return 3;
-        case 'C': case 'c': return 4;
-        case 'Q': case 'q': return 5;
-        case 'E': case 'e': return 6;
-        case 'G': case 'g': return 7;
-        case 'H': case 'h': return 8;
-        case 'I': case 'i': return 9;
-        case 'L': case 'l': return 10;
-        case 'K': case 'k': return 11;
-        case 'M': case 'm': return 12;
-        case 'F': case 'f': return 13;
-        case 'P': case 'p': return 14;
-        case 'S': case 's': return 15;
-        case 'T': case 't': return 16;
-        case 'W': case 'w': return 17;
-        case 'Y': case 'y': return 18;
-        case 'V': case 'v': return 19;
-        case '-': return 20;
-        default: return 0;
-    }
-}
+// (aa_index: common.h)
 
 __global__ __launch_bounds__(APPLES_TPB) void k_pack_aa(const uint8_t *__restrict__ raw, int64_t n_rows, int L, int Lpad,
                                                         uint8_t *__restrict__ out, uint16_t *__restrict__ mask,

@@ -91,6 +91,7 @@ typedef struct {
 #define APPLES_DBG_NO_SWEEP_MERGE 16u /* tagged node map instead of merged level lists on big trees */
 #define APPLES_DBG_NO_DIST_GEMM  32u  /* fused distance pass through the bit-plane-fed MFMA kernel, no reference image */
 #define APPLES_DBG_NO_SWEEP_LEAN 64u  /* level loop of sweep.hip where sweep_lean.hip would run */
+#define APPLES_DBG_NO_SD_GEMM    128u /* scoredist: the fused pass evaluates every pair (k_scoredist), no matrix-core filter */
 
 /* One placement = the p row runquery returns, [edge_num, likelihood(error), 1, distal, pendant]
  * (apples/Algorithm.py:98-101, apples/PoolQueryWorker.py:36-37,74,88,119-125). */

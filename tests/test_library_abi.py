@@ -95,8 +95,8 @@ def test_params_struct_layout_matches_header(tmp_path):
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "apples_hip.h"\n'
                    'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(apples_params), offsetof(apples_params, filt_threshold), '
                    'offsetof(apples_params, jc_lut), offsetof(apples_params, max_batch), offsetof(apples_params, debug)); '
-                   'printf("%u %u %u %u %u %u %u\\n", APPLES_DBG_NO_FUSE, APPLES_DBG_SWEEP_SCAN, APPLES_DBG_NODE_MAP, APPLES_DBG_SWEEP_MERGE, '
-                   'APPLES_DBG_NO_SWEEP_MERGE, APPLES_DBG_NO_DIST_GEMM, APPLES_DBG_NO_SWEEP_LEAN); return 0; }\n')
+                   'printf("%u %u %u %u %u %u %u %u\\n", APPLES_DBG_NO_FUSE, APPLES_DBG_SWEEP_SCAN, APPLES_DBG_NODE_MAP, APPLES_DBG_SWEEP_MERGE, '
+                   'APPLES_DBG_NO_SWEEP_MERGE, APPLES_DBG_NO_DIST_GEMM, APPLES_DBG_NO_SWEEP_LEAN, APPLES_DBG_NO_SD_GEMM); return 0; }\n')
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     out = subprocess.check_output([str(exe)], text=True).split('\n')
@@ -106,4 +106,4 @@ def test_params_struct_layout_matches_header(tmp_path):
     assert (P.filt_threshold.offset, P.jc_lut.offset, P.max_batch.offset, P.debug.offset) == (o_thr, o_lut, o_mb, o_dbg)
     bits = list(map(int, out[1].split()))
     assert bits == [engine.DBG[k] for k in ('no_fuse', 'sweep_scan', 'node_map', 'sweep_merge', 'no_sweep_merge', 'no_dist_gemm',
-                                            'no_sweep_lean')]
+                                            'no_sweep_lean', 'no_sd_gemm')]
