@@ -1186,8 +1186,18 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             // the queries that need the top-up rule: full rows for the listed queries only (row r of dist_slow = list
             // entry r), a slice of the list at a time, then the general selection over those rows
             sa.dist = w.dist_slow;
+            static const bool no_sd_topup = getenv("APPLES_NO_SD_TOPUP") != nullptr;  // diagnostic knob: full rows for the listed queries
+            const bool lb_topup = qb.sd_q4 && sd_gemm_usable(ctx) && !no_sd_topup && w.dist_rows >= nq;
+            if (lb_topup && ctx->sd_list_rows < w.batch) {
+                dev_free(ctx->sd_list_img); ctx->sd_list_img = nullptr; ctx->sd_list_rows = 0;
+                if (dev_alloc(ctx, &ctx->sd_list_img, round_up(w.batch, 256) * sd_steps(a.L) * 64)) return 1;
+                ctx->sd_list_rows = w.batch;
+            }
             if (for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
-                    if (launch_scoredist_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow)) return 1;
+                    // rows of lower bounds on the matrix cores (into the listed queries' rows of w.dist: k_select_fast is done
+                    // with them), exact distances only where the `-b` nearest can be (dist_sd.hip:k_sd_topup); else full rows
+                    if (lb_topup ? launch_sd_topup(ctx, qb, q0, n_max, lst, cntp, ctx->sd_list_img, w.dist, w.dist_slow)
+                                 : launch_scoredist_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow)) return 1;
                     sa.qlist = lst;
                     sa.qcount = cntp;
                     return launch_select(ctx, sa, n_max);
@@ -1454,7 +1464,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(ctx->sd_tq4); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

@@ -258,6 +258,7 @@ struct apples_ctx {
     int *d_exotic = nullptr;         // device flag: a packed query block carried a symbol beyond ACGT-
     std::vector<hipEvent_t> ev_feed; // "chunk i of a streamed block is uploaded and packed"
     int32_t *d_slice_cnt = nullptr;  // [64] list lengths of the top-up slices (slim workspaces)
+    uint8_t *sd_list_img = nullptr; int64_t sd_list_rows = 0;  // scoredist top-up: operand image of the listed queries (dist_sd.hip)
     // scratch of the clustered fast path's cluster-major distance pass (select.hip), grown on demand
     int32_t *cl_ints = nullptr; int64_t cl_ints_cap = 0;
     int2 *cl_items = nullptr; int64_t cl_items_cap = 0;
@@ -311,7 +312,9 @@ void sd_table_codes(const double *blosum20x20, uint8_t *codes);
 int sd_steps(int L);                // 128-value K steps of the operand images
 bool sd_gemm_usable(const apples_ctx *ctx);
 int launch_sd_expand(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_img, hipStream_t st,
-                     const int32_t *d_src_row, int64_t row0, bool query, float *d_nv);
+                     const int32_t *d_src_row, int64_t row0, bool query, float *d_nv, const int32_t *d_n = nullptr);
+int launch_sd_topup(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist, const int32_t *qcount,
+                    uint8_t *img, double *lbrows, double *out_rows);
 int launch_sd_filter(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);
 int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, int32_t *seg_slot,
                     int32_t *seg_cnt);

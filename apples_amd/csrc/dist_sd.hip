@@ -49,8 +49,10 @@ __device__ __forceinline__ v16f_t sd_mfma(const v4i_t &a, const v4i_t &b, const 
 __global__ __launch_bounds__(APPLES_TPB) void k_sd_expand(const uint8_t *__restrict__ raw, int64_t n, int L, int NB,
                                                           uint4 *__restrict__ out, int64_t n_img,
                                                           const int32_t *__restrict__ src_row, int64_t row0,
-                                                          const uint8_t *__restrict__ tq4, float *__restrict__ nv) {
+                                                          const uint8_t *__restrict__ tq4, float *__restrict__ nv,
+                                                          const int32_t *__restrict__ n_dev) {
     const int64_t idx = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;  // one thread per (row, step, chunk)
+    if (n_dev) n = n_img = *n_dev;  // listed rows: the list's length lives on the device (nothing beyond it is written)
     if (idx >= n_img * NB * 4) return;
     const int c = (int)(idx & 3);
     const int64_t rb = idx >> 2;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_expand(const uint8_t *__restr
     const int64_t ar = row0 + q, tile = ar >> 8;
     const int rr = (int)(ar & 255), sw = (rr >> 2) & 3;
     out[(tile * NB + b) * 1024 + rr * 4 + (c ^ sw)] = make_uint4(w[0], w[1], w[2], w[3]);
-    if (b == 0 && c == 0) {
+    if (nv && b == 0 && c == 0) {
         int cnt = -1;
         if (q < n) {
             cnt = 0;
@@ -89,11 +91,20 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_expand(const uint8_t *__restr
 }
 
 // R = (NB - 2) % 3: the shape of the main loop's tail, fixed per launch (as k_jc69_gemm)
-template <int R>
+// ROWS: the bounds themselves, for a list of queries (the top-up path): the query image holds the listed queries in list
+// order, *qcount of them; acc of (list entry r, slot) goes to row qlist[r] of `rows` (floats, row stride in doubles)
+template <int R, bool ROWS>
 __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ rf4, const uint8_t *__restrict__ qf4,
                                                     int64_t qrow0, int64_t slots_pad, int NB, int64_t nq, int TQ, int TR,
                                                     const float *__restrict__ nvr, const float *__restrict__ nvq, float k4c,
-                                                    int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt) {
+                                                    int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
+                                                    const int32_t *__restrict__ qlist, const int32_t *__restrict__ qcount,
+                                                    double *__restrict__ rows, int64_t row_stride) {
+    if (ROWS) {
+        nq = *qcount;
+        TQ = (int)((nq + SD_T - 1) / SD_T);
+        if (TQ == 0) return;
+    }
     constexpr int QT = SD_T, AI = QT * 64, GEN = AI + SD_IMG;
     __shared__ __attribute__((aligned(1024))) uint8_t lds[3 * GEN];
 #define Aq(g) (lds + (g) * GEN)
@@ -238,6 +249,34 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
             step(b + 2, 2, false, true);
             step(b + 3, 0, false, false);
         }
+        int64_t nl = l + stride, nqt = 0, nrt = 0;
+        bool have = false;
+        for (; nl < l_end; nl += stride) {
+            tile_at(nl, nqt, nrt);
+            if (nrt < TR) { have = true; break; }
+        }
+        // C layout of the 32x32 tiles: column (reference slot) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+        if (ROWS) {
+            // the next tile's first two steps: after the last barrier nobody reads LDS any more
+            if (have) {
+                set_tile(nqt, nrt);
+                dma(0, 0, 0); dma(0, 0, 1);
+                dma(1, 1, 0); dma(1, 1, 1);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int64_t qbase = q0 + wq * 64 + i * 32 + 4 * fh;
+                const int rem = (int)(nq - qbase < 32 ? nq - qbase : 32);
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const int cx = (x & 3) + 8 * (x >> 2);
+                    if (cx >= rem) continue;
+                    float *row = reinterpret_cast<float *>(rows + (int64_t)qlist[qbase + cx] * row_stride) + r0 + wr * 128 + fr;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) row[j * 32] = acc[i][j][x];
+                }
+            }
+        } else {
         // the thresholds of this tile's rows and columns, then the next tile's first two steps: after the last barrier
         // nobody reads LDS any more.  Loads complete in order, so the counted wait below leaves the 8 pieces in flight.
         float cq[2][16], cr[4];
@@ -252,12 +291,6 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) cr[j] = nvr[r0 + wr * 128 + j * 32 + fr] * k4c;
-        int64_t nl = l + stride, nqt = 0, nrt = 0;
-        bool have = false;
-        for (; nl < l_end; nl += stride) {
-            tile_at(nl, nqt, nrt);
-            if (nrt < TR) { have = true; break; }
-        }
         if (have) {
             __builtin_amdgcn_sched_barrier(0);
             set_tile(nqt, nrt);
@@ -268,7 +301,6 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
-        // C layout of the 32x32 tiles: column (reference slot) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
         // A pair is a candidate when acc <= 4 c (1 + 1e-6) min(nv of its query, nv of its reference row)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -299,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
                 }
             }
         }
+        }
         if (!have) break;
         l = nl; qt = nqt; rt = nrt;
     }
@@ -311,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
 __device__ __forceinline__ double sd_pair_exact(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
                                                 int64_t slots_pad, int64_t slot, const uint8_t *__restrict__ qrow,
                                                 const uint16_t *__restrict__ qmask, int n16, const char *Tb, int L,
-                                                double overlap) {
+                                                double overlap, double *ratio = nullptr) {
     double tot = 0.0;
     uint32_t valid = 0;
     uint4 rw = *reinterpret_cast<const uint4 *>(refa + slot * 16);
@@ -337,6 +370,7 @@ __device__ __forceinline__ double sd_pair_exact(const uint8_t *__restrict__ refa
         for (int k = 0; k < 16; ++k) tot += v[k];
     }
     if (valid == 0 || (double)valid / (double)L < overlap) return -1.0;
+    if (ratio) *ratio = tot / (double)valid;
     const double r1 = 1 - tot / (double)valid;
     if (0 >= r1) return -1.0;
     return -log(r1) * 1.3;
@@ -419,6 +453,130 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restri
     }
 }
 
+// The top-up rule (apples/Reference.py:144-152) for a listed query without its full row: the `-b` nearest references by
+// exact distance are among those whose LOWER BOUND does not exceed the `-b`-th smallest exact value.  Input: the query's row
+// of bounds (k_sd_gemm<ROWS>: acc = 4 x the bound of tot).  key = acc / 4 / min(valid sites of the query, of the row) <=
+// tot / valid = x, and d grows with x.  (1) a histogram of the keys gives t0 with at least `-b` + 8 keys below it; those
+// references are evaluated exactly (as k_scoredist would: same bits); (2) X = a bin edge at or above the `-b`-th smallest
+// exact x among them, an upper bound of the true `-b`-th smallest x; (3) every other reference with key <= X is evaluated
+// too.  Whatever was not evaluated has x > X: it cannot be among the `-b` nearest, nor inside the threshold (a listed query
+// has fewer than `-b` references there).  Output: row r of `out` (r = list position) with the exact distances of the evaluated
+// references and -1 (= missing) everywhere else -- k_select's top-up rule on it selects what it would select on the full row.
+// Fewer than `-b` valid distances among the first set: everything is evaluated.
+#define SDT_BINS 4096
+#define SDT_SCALE 2048.0
+__global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
+                                                         const uint8_t *__restrict__ qa, const uint16_t *__restrict__ qm,
+                                                         const double *__restrict__ table, int64_t n_slots, int64_t slots_pad,
+                                                         int Lpad, int L, double overlap, const int32_t *__restrict__ qlist,
+                                                         const int32_t *__restrict__ qcount, const double *__restrict__ lbrows,
+                                                         int64_t row_stride, const float *__restrict__ nvr,
+                                                         const float *__restrict__ nvq, int64_t qrow0, int baseobs,
+                                                         double *__restrict__ out_rows) {
+    constexpr int TPB = APPLES_TPB, NW = TPB / 64;
+    __shared__ double T[21 * 21];
+    __shared__ int hist[SDT_BINS];
+    __shared__ int sh_w[NW];
+    __shared__ int sh_bin;
+    __shared__ int wqueue[NW][128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 21 * 21; i += TPB) T[i] = table[i];
+    const char *Tb = reinterpret_cast<const char *>(T);
+    const int n16 = Lpad / 16;
+    const int n_list = *qcount;
+    const double INF = __longlong_as_double(0x7ff0000000000000LL);
+    for (int r = blockIdx.x; r < n_list; r += gridDim.x) {
+        const int64_t q = __builtin_amdgcn_readfirstlane(qlist[r]);
+        const float *lb = reinterpret_cast<const float *>(lbrows + q * row_stride);
+        double *out = out_rows + (int64_t)r * row_stride;
+        const uint8_t *qrow = qa + q * (int64_t)Lpad;
+        const uint16_t *qmask = qm + q * (int64_t)n16;
+        const float nq_ = nvq[qrow0 + q];
+        auto key_of = [&](int64_t slot) -> double {
+            const float nr = nvr[slot];
+            const float vub = nr < nq_ ? nr : nq_;
+            return vub > 0.f ? (double)lb[slot] * 0.25 / (double)vub : INF;
+        };
+        auto bin_of = [&](double x) -> int { return x >= (double)(SDT_BINS - 1) / SDT_SCALE ? SDT_BINS - 1 : (int)(x * SDT_SCALE); };
+        // smallest bin whose cumulative count reaches `need` (SDT_BINS if the total does not)
+        auto find_bin = [&](int need) -> int {
+            __syncthreads();  // hist is complete
+            constexpr int PER = SDT_BINS / TPB;
+            int local = 0;
+            for (int k = 0; k < PER; ++k) local += hist[tid * PER + k];
+            int incl = local;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) sh_w[w] = incl;
+            if (tid == 0) sh_bin = SDT_BINS;
+            __syncthreads();
+            int base = 0;
+            for (int k = 0; k < w; ++k) base += sh_w[k];
+            int cum = base + incl - local;  // count below this thread's bins
+            if (cum < need && cum + local >= need) {
+                for (int k = 0; k < PER; ++k) {
+                    cum += hist[tid * PER + k];
+                    if (cum >= need) { sh_bin = tid * PER + k; break; }
+                }
+            }
+            __syncthreads();
+            return sh_bin;
+        };
+        // exact distances of the references with lo < key <= hi, streamed through per-wavefront queues; with_hist: the valid ones'
+        // ratios are counted into hist
+        auto eval_range = [&](double lo, double hi, bool with_hist) {
+            int head = 0, count = 0;  // wave-uniform ring of 128 slots
+            auto drain = [&](int n) {
+                if (lane < n) {
+                    const int slot = wqueue[w][(head + lane) & 127];
+                    double x = 0.0;
+                    const double d = sd_pair_exact(refa, refm, slots_pad, slot, qrow, qmask, n16, Tb, L, overlap, &x);
+                    out[slot] = d;
+                    if (with_hist && d >= 0) atomicAdd(&hist[bin_of(x)], 1);
+                }
+                head = (head + n) & 127;
+                count -= n;
+            };
+            for (int64_t s0 = (int64_t)w * 64; s0 < n_slots; s0 += TPB) {
+                const int64_t slot = s0 + lane;
+                bool take = false;
+                if (slot < n_slots) {
+                    const double k = key_of(slot);
+                    take = k > lo && k <= hi;
+                }
+                const unsigned long long m = __ballot(take);
+                if (m) {
+                    if (take) wqueue[w][(head + count + __popcll(m & ((1ull << lane) - 1ull))) & 127] = (int)slot;
+                    count += __popcll(m);
+                    if (count >= 64) drain(64);
+                }
+            }
+            if (count > 0) drain(count);
+        };
+        // the row starts as "everything missing"; the histogram empty
+        for (int64_t s = tid; s < slots_pad; s += TPB) out[s] = -1.0;
+        for (int i = tid; i < SDT_BINS; i += TPB) hist[i] = 0;
+        __syncthreads();
+        for (int64_t s = tid; s < n_slots; s += TPB) {
+            const double k = key_of(s);
+            if (k < INF) atomicAdd(&hist[bin_of(k)], 1);
+        }
+        const int b0 = find_bin(baseobs + 8);
+        const double t0 = b0 >= SDT_BINS - 1 ? INF : (double)(b0 + 1) / SDT_SCALE;
+        for (int i = tid; i < SDT_BINS; i += TPB) hist[i] = 0;
+        __syncthreads();
+        eval_range(-1.0, t0, true);
+        if (t0 < INF) {
+            const int b1 = find_bin(baseobs);
+            const double X = b1 >= SDT_BINS - 1 ? INF : (double)(b1 + 1) / SDT_SCALE * (1.0 + 1e-9);
+            if (X > t0) eval_range(t0, X, false);
+        }
+        __syncthreads();  // (hist, the queues and sh_bin are reused by the next list entry)
+    }
+}
+
 }  // namespace
 
 // fp4 codes of the rounded-down table: code of the largest v in {0, .5, 1, 1.5, 2, 3, 4, 6} with v / 4 <= T[a][b]
@@ -440,13 +598,13 @@ bool sd_gemm_usable(const apples_ctx *ctx) {
 }
 
 int launch_sd_expand(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_img, hipStream_t st,
-                     const int32_t *d_src_row, int64_t row0, bool query, float *d_nv) {
+                     const int32_t *d_src_row, int64_t row0, bool query, float *d_nv, const int32_t *d_n) {
     if (n_img <= 0) return 0;
     const int NB = sd_steps(ctx->aln.L);
     const int64_t total = n_img * NB * 4;
     hipLaunchKernelGGL(k_sd_expand, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0, st ? st : ctx->stream,
                        d_raw, n, ctx->aln.L, NB, reinterpret_cast<uint4 *>(d_out), n_img, d_src_row, row0,
-                       query ? ctx->sd_tq4 : (const uint8_t *)nullptr, d_nv);
+                       query ? ctx->sd_tq4 : (const uint8_t *)nullptr, d_nv, d_n);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -468,9 +626,10 @@ int launch_sd_filter(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t 
     float k4c = (float)(4.0 * c * (1.0 + 1e-6));
     k4c = std::nextafterf(k4c, INFINITY);
     const int R = (NB - 2) % 3;
-#define SD_LAUNCH(R_)                                                                                              \
-    hipLaunchKernelGGL((k_sd_gemm<R_>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, a.sd_ref4, qb.sd_q4, q0,  \
-                       a.slots_pad, NB, nq, TQ, TR, a.sd_nvr, qb.sd_nvq, k4c, seg_slot, seg_cnt)
+#define SD_LAUNCH(R_)                                                                                                     \
+    hipLaunchKernelGGL((k_sd_gemm<R_, false>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, a.sd_ref4, qb.sd_q4, q0,  \
+                       a.slots_pad, NB, nq, TQ, TR, a.sd_nvr, qb.sd_nvq, k4c, seg_slot, seg_cnt, (const int32_t *)nullptr, \
+                       (const int32_t *)nullptr, (double *)nullptr, (int64_t)0)
     if (R == 0) SD_LAUNCH(0); else if (R == 1) SD_LAUNCH(1); else SD_LAUNCH(2);
 #undef SD_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
@@ -485,6 +644,38 @@ int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t n
     hipLaunchKernelGGL(k_sd_exact, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask,
                        qb.aa_idx + q0 * Lpad, qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L,
                        ctx->params.overlap_frac, ctx->params.filt_threshold, seg_d, seg_slot, seg_cnt);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// The top-up path of the fused route for the queries on a device list (entries relative to q0): their operand image in list
+// order (scratch `img`, room for nq_max rows), their rows of bounds on the matrix cores (into the listed queries' own rows of
+// `lbrows`, which the selection has consumed), then k_sd_topup: row r of out_rows = what k_select needs of list entry r's
+// full row.
+int launch_sd_topup(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist, const int32_t *qcount,
+                    uint8_t *img, double *lbrows, double *out_rows) {
+    if (nq_max == 0) return 0;
+    const DevAlign &a = ctx->aln;
+    const int NB = sd_steps(a.L), Lpad = (a.L + 15) / 16 * 16;
+    if (launch_sd_expand(ctx, qb.raw + q0 * a.L, nq_max, img, nq_max, ctx->stream, qlist, 0, true, nullptr, qcount)) return 1;
+    const int TR = (int)(a.slots_pad / SD_T);
+    if (ctx->n_cu == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->n_cu = prop.multiProcessorCount;
+    }
+    const int64_t grid = std::max(8, ctx->n_cu / 8 * 8);
+    const int R = (NB - 2) % 3;
+#define SD_LAUNCH(R_)                                                                                                     \
+    hipLaunchKernelGGL((k_sd_gemm<R_, true>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, a.sd_ref4, img, (int64_t)0, \
+                       a.slots_pad, NB, nq_max, 0, TR, a.sd_nvr, (const float *)nullptr, 0.f, (int32_t *)nullptr,        \
+                       (int32_t *)nullptr, qlist, qcount, lbrows, a.slots_pad)
+    if (R == 0) SD_LAUNCH(0); else if (R == 1) SD_LAUNCH(1); else SD_LAUNCH(2);
+#undef SD_LAUNCH
+    const unsigned wgs = (unsigned)std::min<int64_t>(nq_max, (int64_t)ctx->n_cu * 8);
+    hipLaunchKernelGGL(k_sd_topup, dim3(wgs), dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask, qb.aa_idx + q0 * Lpad,
+                       qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L, ctx->params.overlap_frac,
+                       qlist, qcount, lbrows, a.slots_pad, a.sd_nvr, qb.sd_nvq, q0, ctx->params.base_observation, out_rows);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
