@@ -418,13 +418,18 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // one-hot operand image of the reference rows for the matrix-core filter of the fused pass (dist_sd.hip): 10 bytes per
         // site and slot (253 MB at 50 000 x 500)
-        if (a.all_singleton && !(ctx->dbg & APPLES_DBG_NO_SD_GEMM) && sd_steps(a.L) >= 2) {
+        if (a.all_singleton && !(ctx->dbg & APPLES_DBG_NO_SD_GEMM) && sd_steps(a.L) >= 2 && a.L <= 8192 &&
+            a.slots_pad <= 524288) {  // (the evaluating kernels stage a query row and the segment counts' prefix in LDS)
             uint8_t codes[400];
             sd_table_codes(kBlosum45, codes);
             if (dev_upload(ctx, &ctx->sd_tq4, codes, 400)) return 1;
             if (dev_alloc(ctx, &a.sd_ref4, a.slots_pad * (int64_t)sd_steps(a.L) * 64)) return 1;
             if (dev_alloc(ctx, &a.sd_nvr, a.slots_pad)) return 1;
             if (launch_sd_expand(ctx, a.raw, a.n_rows, a.sd_ref4, a.slots_pad, ctx->stream, a.d_slot_row, 0, false, a.sd_nvr)) return 1;
+            a.aa_Lrow = (int32_t)round_up(a.L, 64);
+            if (dev_alloc(ctx, &a.aa_rows, a.slots_pad * (int64_t)a.aa_Lrow)) return 1;
+            if (dev_alloc(ctx, &a.aa_mrows, a.slots_pad * (int64_t)(a.aa_Lrow / 16))) return 1;
+            if (launch_sd_rows(ctx)) return 1;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (codes is on the stack)
         }
     } else {
@@ -1176,12 +1181,13 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 // segments closed up in place (dist_sd.hip)
                 HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (w.stride / 64) * sizeof(int32_t), front));
                 if (launch_sd_filter(ctx, qb, q0, nq, w.seg_slot, w.seg_cnt)) return 1;
-                if (launch_sd_exact(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt)) return 1;
+                if (launch_sd_exact(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt, w.n_obs)) return 1;
             } else if (launch_scoredist_fused(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt, nullptr)) return 1;
             HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;
             SelectArgs sa = select_args_alignment(ctx, qb, q0);
             sa.seg_lut = nullptr;
+            if (qb.sd_q4 && sd_gemm_usable(ctx)) sa.seg_surv = w.n_obs;  // (k_sd_exact left the survivor counts where k_select_fast puts the observed counts)
             if (launch_select_fast(ctx, sa, nq)) return 1;
             // the queries that need the top-up rule: full rows for the listed queries only (row r of dist_slow = list
             // entry r), a slice of the list at a time, then the general selection over those rows
@@ -1464,7 +1470,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

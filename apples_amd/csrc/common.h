@@ -127,6 +127,9 @@ struct DevAlign {
     int64_t reps_pad = 0;
     uint8_t *aa_idx = nullptr;    // scoredist: [Lpad16/16][slots_pad][16] residue index * 8 (0..152, 160 = gap)
     uint16_t *aa_mask = nullptr;  // scoredist: [Lpad16/16][slots_pad] bit k = site 16*s16+k is not a gap
+    uint8_t *aa_rows = nullptr;   // scoredist, beside sd_ref4: the same residue bytes slot-major, [slots_pad][aa_Lrow] (dist_sd.hip:sd_eval64)
+    uint16_t *aa_mrows = nullptr; // ... and the gap masks, [slots_pad][aa_Lrow / 16]
+    int32_t aa_Lrow = 0;          // bytes per row of aa_rows: L rounded up to a multiple of 64
     uint8_t *sd_ref4 = nullptr;   // scoredist, singleton clusters: one-hot fp4 operand image of the reference rows (dist_sd.hip),
                                   // [slots_pad / 256][steps][1024 chunks of 16 B], 20 values per site
     float *sd_nvr = nullptr;      // [slots_pad] sites of the row that are not gaps (-1: no row in the slot)
@@ -315,9 +318,10 @@ int launch_sd_expand(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *
                      const int32_t *d_src_row, int64_t row0, bool query, float *d_nv, const int32_t *d_n = nullptr);
 int launch_sd_topup(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist, const int32_t *qcount,
                     uint8_t *img, double *lbrows, double *out_rows);
+int launch_sd_rows(apples_ctx *ctx);
 int launch_sd_filter(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);
-int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, int32_t *seg_slot,
-                    int32_t *seg_cnt);
+int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, const int32_t *seg_slot,
+                    const int32_t *seg_cnt, int32_t *n_surv);
 // select.hip
 struct SelectArgs {
     const double *dist;       // [nq][stride]
@@ -337,6 +341,8 @@ struct SelectArgs {
     // fused fast path (k_jc69 MODE 1 -> k_select_fast)
     const int32_t *seg_slot, *seg_cnt;  // [nq][stride], [nq][stride/64]
     const double *seg_lut;              // non-null: seg_slot holds position << 26 | valid << 13 | mism, distances are seg_lut[...]
+    const int32_t *seg_surv;            // non-null (dist_sd.hip): the segments hold CANDIDATES, the ones that failed marked by a negative
+                                        // distance; seg_surv[query] = how many passed
     const int32_t *node_level;          // tree level by node id
     int32_t *slow_list, *slow_count;    // queries that need the top-up rule
     int32_t *slow_hint;                 // [list position] or nullptr: what the listing kernel already knows about the query -- its

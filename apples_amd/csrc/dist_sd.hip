@@ -339,35 +339,74 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
 #undef Br
 }
 
-// exact scoredist of (the block's query, reference slot), the arithmetic of k_scoredist (dist.hip): sites left to right in
-// fp64, the 21 x 21 table (zero gap row / column) in LDS at Tb; the query's residues are workgroup-uniform
-__device__ __forceinline__ double sd_pair_exact(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
-                                                int64_t slots_pad, int64_t slot, const uint8_t *__restrict__ qrow,
-                                                const uint16_t *__restrict__ qmask, int n16, const char *Tb, int L,
-                                                double overlap, double *ratio = nullptr) {
+// Exact scoredist of (the workgroup's query, this lane's reference slot) for the 64 lanes of a wavefront together: the
+// arithmetic of k_scoredist (dist.hip) -- sites left to right in fp64, the 21 x 21 table (zero gap row / column) in LDS at Tb
+// -- so the same bits.  The rows come from the slot-major copy (DevAlign::aa_rows: Lrow bytes per slot, Lrow a multiple of
+// 64, the bytes past the alignment are gaps): a pair's 16-byte pieces would otherwise be Lpad / 16 separate cache-line
+// requests (that form was bound by requests, not by lookups: 5.9 ms per C4 pass).  Here four lanes fetch one slot's 64-byte
+// piece (one request per sector), the pieces are staged in the wavefront's own LDS area (80-byte stride: conflict-free
+// 16-byte reads) and every lane reads its own slot's bytes back; the next piece is on its way meanwhile.  All 64 lanes call
+// (a lane without a pair passes any valid slot and drops the result).  The query's row and masks are staged in LDS by the
+// caller (lq, lqm) and come back as scalars: one broadcast read + readfirstlane per 16 sites, where a scalar memory load
+// per 16 sites had every wavefront wait for the scalar cache between its short bursts of lookups.
+#define SDE_PIECE 64
+#define SDE_STRIDE 80
+#define SDE_WBUF (64 * SDE_STRIDE)  // bytes of LDS per wavefront
+__device__ __forceinline__ double sd_eval64(const uint8_t *__restrict__ rrows, const uint16_t *__restrict__ mrows, int Lrow,
+                                            int slot, uint8_t *wbuf, int *wslot, const uint8_t *lq, const uint16_t *lqm,
+                                            int n16, const char *Tb, int L, double overlap, double *ratio = nullptr) {
+    const int lane = threadIdx.x & 63, sub = lane & 3, grp = lane >> 2;
+    __builtin_amdgcn_wave_barrier();
+    wslot[lane] = slot;
+    __builtin_amdgcn_wave_barrier();
+    // (scalars, not arrays, and an unconditional prefetch: an array carried through the loop went to scratch memory, with
+    // every load waited for at once)
+    const uint8_t *src0 = rrows + (int64_t)wslot[grp] * Lrow + sub * 16, *src1 = rrows + (int64_t)wslot[16 + grp] * Lrow + sub * 16;
+    const uint8_t *src2 = rrows + (int64_t)wslot[32 + grp] * Lrow + sub * 16, *src3 = rrows + (int64_t)wslot[48 + grp] * Lrow + sub * 16;
+    const uint16_t *mrow = mrows + (int64_t)slot * (Lrow / 16);
+    const int npiece = Lrow / SDE_PIECE;
+    uint4 n0 = *reinterpret_cast<const uint4 *>(src0), n1 = *reinterpret_cast<const uint4 *>(src1);
+    uint4 n2 = *reinterpret_cast<const uint4 *>(src2), n3 = *reinterpret_cast<const uint4 *>(src3);
+    uint2 nm = *reinterpret_cast<const uint2 *>(mrow);  // the piece's four 16-bit gap masks
+    uint8_t *wdst = wbuf + grp * SDE_STRIDE + sub * 16;
     double tot = 0.0;
     uint32_t valid = 0;
-    uint4 rw = *reinterpret_cast<const uint4 *>(refa + slot * 16);
-    uint32_t rmask = refm[slot];
-    for (int s16 = 0; s16 < n16; ++s16) {
-        const uint4 cw = rw;
-        const uint32_t cm = rmask;
-        if (s16 + 1 < n16) {  // the next block's gather leaves before this block's sixteen lookups
-            rw = *reinterpret_cast<const uint4 *>(refa + ((int64_t)(s16 + 1) * slots_pad + slot) * 16);
-            rmask = refm[(int64_t)(s16 + 1) * slots_pad + slot];
-        }
-        const uint4 qw = *reinterpret_cast<const uint4 *>(qrow + s16 * 16);
-        valid += __popc(cm & (uint32_t)qmask[s16]);
-        const uint32_t rr[4] = {cw.x, cw.y, cw.z, cw.w}, qq[4] = {qw.x, qw.y, qw.z, qw.w};
-        double v[16];
+    for (int c = 0; c < npiece; ++c) {
+        __builtin_amdgcn_wave_barrier();  // (the previous piece has been read by every lane: LDS operations of a wavefront complete in order)
+        *reinterpret_cast<uint4 *>(wdst) = n0;
+        *reinterpret_cast<uint4 *>(wdst + 16 * SDE_STRIDE) = n1;
+        *reinterpret_cast<uint4 *>(wdst + 32 * SDE_STRIDE) = n2;
+        *reinterpret_cast<uint4 *>(wdst + 48 * SDE_STRIDE) = n3;
+        const uint2 cm = nm;
+        const int cn = c + 1 < npiece ? c + 1 : c;  // (the last round fetches its own piece again: nobody reads it)
+        n0 = *reinterpret_cast<const uint4 *>(src0 + cn * SDE_PIECE);
+        n1 = *reinterpret_cast<const uint4 *>(src1 + cn * SDE_PIECE);
+        n2 = *reinterpret_cast<const uint4 *>(src2 + cn * SDE_PIECE);
+        n3 = *reinterpret_cast<const uint4 *>(src3 + cn * SDE_PIECE);
+        nm = *reinterpret_cast<const uint2 *>(mrow + cn * 4);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint32_t r8 = (rr[k >> 2] >> (8 * (k & 3))) & 0xffu;
-            const uint32_t qr = ((qq[k >> 2] >> (8 * (k & 3))) & 0xffu) * 168u;  // 21 columns * 8 bytes
-            v[k] = *reinterpret_cast<const double *>(Tb + qr + r8);
-        }
+        for (int s = 0; s < 4; ++s) {
+            const int s16 = c * 4 + s;
+            if (s16 < n16) {  // (wave-uniform: the query row ends with the alignment)
+                const uint4 cw = *reinterpret_cast<const uint4 *>(wbuf + lane * SDE_STRIDE + s * 16);
+                const uint4 qw = *reinterpret_cast<const uint4 *>(lq + s16 * 16);
+                const uint32_t rmask = ((s & 2 ? cm.y : cm.x) >> (16 * (s & 1))) & 0xffffu;
+                valid += __popc(rmask & (uint32_t)__builtin_amdgcn_readfirstlane((int)lqm[s16]));
+                const uint32_t rr[4] = {cw.x, cw.y, cw.z, cw.w};
+                const uint32_t qq[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)qw.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)qw.y),
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)qw.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)qw.w)};
+                double v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) tot += v[k];
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t r8 = (rr[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                    const uint32_t qr = ((qq[k >> 2] >> (8 * (k & 3))) & 0xffu) * 168u;  // 21 columns * 8 bytes
+                    v[k] = *reinterpret_cast<const double *>(Tb + qr + r8);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) tot += v[k];
+            }
+        }
     }
     if (valid == 0 || (double)valid / (double)L < overlap) return -1.0;
     if (ratio) *ratio = tot / (double)valid;
@@ -376,87 +415,123 @@ __device__ __forceinline__ double sd_pair_exact(const uint8_t *__restrict__ refa
     return -log(r1) * 1.3;
 }
 
-// candidates -> survivors, in place (see the head of the file).  One workgroup per query; the segments are walked in
-// chunks of 256, a chunk's candidates as one flat list, 256 at a time.
-__global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
-                                                         const uint8_t *__restrict__ qa, const uint16_t *__restrict__ qm,
+// slot-major copy of the packed reference rows for sd_eval64: rows[slot][Lrow] = residue index * 8 (160 = gap, also past the
+// alignment), mrows[slot][Lrow / 16] = 16-bit gap masks
+__global__ __launch_bounds__(APPLES_TPB) void k_sd_rows(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
+                                                        int64_t slots_pad, int n16, int Lrow, uint8_t *__restrict__ rows,
+                                                        uint16_t *__restrict__ mrows) {
+    const int64_t slot = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    const int s16 = blockIdx.y;
+    if (slot >= slots_pad) return;
+    uint4 v = make_uint4(0xa0a0a0a0u, 0xa0a0a0a0u, 0xa0a0a0a0u, 0xa0a0a0a0u);
+    uint16_t m = 0;
+    if (s16 < n16) {
+        v = *reinterpret_cast<const uint4 *>(refa + ((int64_t)s16 * slots_pad + slot) * 16);
+        m = refm[(int64_t)s16 * slots_pad + slot];
+    }
+    *reinterpret_cast<uint4 *>(rows + slot * (int64_t)Lrow + s16 * 16) = v;
+    mrows[slot * (int64_t)(Lrow / 16) + s16] = m;
+}
+
+// candidates -> survivors (see the head of the file).  One workgroup per query: the exclusive prefix of the segments' candidate
+// counts goes to LDS once (the candidates are then one flat list in slot order), and from there the four wavefronts work
+// on their own: a wavefront takes the next 64 candidates from a counter in LDS, evaluates them (sd_eval64) and writes each
+// distance over its candidate's entry of seg_d -- -1 where the pair fails 0 <= d <= thr.  Nothing is moved: k_select_fast
+// skips the entries with d < 0, and takes the number of survivors (what decides "enough inside the threshold or top-up
+// rule") from n_surv[query].  (Closing the segments up in place took a barrier per round of 256 and a scan per 256
+// segments: 5.4 ms per C4 pass against 1.5 for this form.)
+__global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restrict__ rrows, const uint16_t *__restrict__ mrows,
+                                                         int Lrow, const uint8_t *__restrict__ qa, const uint16_t *__restrict__ qm,
                                                          const double *__restrict__ table, int64_t n_slots, int64_t slots_pad,
                                                          int Lpad, int L, double overlap, double thr,
-                                                         double *__restrict__ seg_d, int32_t *__restrict__ seg_slot,
-                                                         int32_t *__restrict__ seg_cnt) {
+                                                         double *__restrict__ seg_d, const int32_t *__restrict__ seg_slot,
+                                                         const int32_t *__restrict__ seg_cnt, int32_t *__restrict__ n_surv) {
     constexpr int TPB = APPLES_TPB, NW = TPB / 64;
     __shared__ double T[21 * 21];
-    __shared__ int sh_pref[TPB + 1];
     __shared__ int sh_w[NW];
-    __shared__ uint8_t sh_keep[TPB * 64];
+    __shared__ int sh_next;
+    __shared__ __attribute__((aligned(16))) uint8_t sh_wbuf[NW][SDE_WBUF];
+    __shared__ int sh_wslot[NW][64];
+    extern __shared__ __attribute__((aligned(16))) uint8_t sh_dyn[];  // the query's row (Lpad bytes), its masks, the prefix [n_seg + 1]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < 21 * 21; i += TPB) T[i] = table[i];
     const char *Tb = reinterpret_cast<const char *>(T);
     const int64_t q = blockIdx.x;
     const int n16 = Lpad / 16;
-    const int64_t n_seg = slots_pad >> 6;
-    int32_t *cnt = seg_cnt + q * n_seg;
-    int32_t *sslot = seg_slot + q * slots_pad;
+    const int n_seg = (int)(slots_pad >> 6);
+    uint8_t *sh_q = sh_dyn;
+    uint16_t *sh_qm = reinterpret_cast<uint16_t *>(sh_dyn + Lpad);
+    int *pref = reinterpret_cast<int *>(sh_dyn + (Lpad + Lpad / 8 + 15) / 16 * 16);
+    for (int i = tid; i < n16; i += TPB) {
+        *reinterpret_cast<uint4 *>(sh_q + i * 16) = *reinterpret_cast<const uint4 *>(qa + q * (int64_t)Lpad + i * 16);
+        sh_qm[i] = qm[q * (int64_t)n16 + i];
+    }
+    const int32_t *cnt = seg_cnt + q * (int64_t)n_seg;
+    const int32_t *sslot = seg_slot + q * slots_pad;
     double *sd = seg_d + q * slots_pad;
-    const uint8_t *qrow = qa + q * (int64_t)Lpad;
-    const uint16_t *qmask = qm + q * (int64_t)n16;
-    for (int64_t s0 = 0; s0 < n_seg; s0 += TPB) {
-        const int64_t sg = s0 + tid;
-        const int my = sg < n_seg ? cnt[sg] : 0;
-        // exclusive prefix of the chunk's counts
-        int incl = my;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
+    // exclusive prefix of the counts (coalesced in, summed out of LDS: k_select_fast's form)
+    const int K = (n_seg + TPB - 1) / TPB;
+    const int s_lo = tid * K, s_hi = s_lo + K < n_seg ? s_lo + K : n_seg;
+    for (int s = tid; s < n_seg; s += TPB) pref[s] = cnt[s];
+    __syncthreads();
+    int local = 0;
+    for (int s = s_lo; s < s_hi; ++s) { const int v = pref[s]; pref[s] = local; local += v; }
+    int incl = local;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) sh_w[w] = incl;
+    if (tid == 0) sh_next = 0;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int k = 0; k < NW; ++k) {
+        if (k < w) base += sh_w[k];
+        total += sh_w[k];
+    }
+    const int at = base + incl - local;
+    for (int s = s_lo; s < s_hi; ++s) pref[s] += at;
+    if (tid == 0) pref[n_seg] = total;
+    __syncthreads();
+    int kept = 0;
+    for (;;) {
+        int e0 = 0;
+        if (lane == 0) e0 = atomicAdd(&sh_next, 64);
+        e0 = __builtin_amdgcn_readfirstlane(e0);
+        if (e0 >= total) break;
+        const int e = e0 + lane;
+        const bool in = e < total;
+        int lo = 0, hi = n_seg + 1;  // last segment whose prefix <= e (empty segments share a prefix: the last one wins, and holds e)
+        const int ee = in ? e : 0;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pref[mid] <= ee) lo = mid; else hi = mid;
         }
-        __syncthreads();  // (the previous chunk is done with sh_pref / sh_keep; first chunk: the table is written)
-        if (lane == 63) sh_w[w] = incl;
-        __syncthreads();
-        int base = 0, chunk_total = 0;
-        for (int k = 0; k < NW; ++k) {
-            if (k < w) base += sh_w[k];
-            chunk_total += sh_w[k];
+        const int64_t src = (int64_t)lo * 64 + (ee - pref[lo]);
+        const int slot = sslot[src];
+        const bool ok = in && slot < n_slots;
+        const double d = sd_eval64(rrows, mrows, Lrow, ok ? slot : 0, sh_wbuf[w], sh_wslot[w], sh_q, sh_qm, n16, Tb, L, overlap);
+        if (in) {
+            const bool keep = ok && d >= 0 && d <= thr;
+            sd[src] = keep ? d : -1.0;
+            kept += keep ? 1 : 0;
         }
-        sh_pref[tid] = base + incl - my;
-        if (tid == 0) sh_pref[TPB] = chunk_total;
-        __syncthreads();
-        for (int e0 = 0; e0 < chunk_total; e0 += TPB) {  // (block-uniform)
-            const int e = e0 + tid;
-            const bool in = e < chunk_total;
-            int lo = 0, slot = 0, first = 0;
-            bool keep = false, last = false;
-            double d = -1.0;
-            if (in) {
-                int hi = TPB;  // last segment whose prefix <= e (empty segments share a prefix: the last one wins, and holds e)
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sh_pref[mid] <= e) lo = mid; else hi = mid;
-                }
-                first = sh_pref[lo];
-                last = e + 1 == sh_pref[lo + 1];
-                slot = sslot[(s0 + lo) * 64 + (e - first)];
-                if (slot < n_slots) d = sd_pair_exact(refa, refm, slots_pad, slot, qrow, qmask, n16, Tb, L, overlap);
-                keep = d >= 0 && d <= thr;
-                sh_keep[e] = keep ? 1 : 0;
-            }
-            __syncthreads();  // this round's candidates are read and judged: survivors may now move left
-            if (in && (keep || last)) {
-                int pos = 0;
-                for (int k = first; k < e; ++k) pos += sh_keep[k];
-                if (keep) {
-                    sslot[(s0 + lo) * 64 + pos] = slot;
-                    sd[(s0 + lo) * 64 + pos] = d;
-                }
-                if (last) cnt[s0 + lo] = pos + (keep ? 1 : 0);
-            }
-        }
+    }
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_down(kept, o, 64);
+    __syncthreads();  // (sh_w is free)
+    if (lane == 0) sh_w[w] = kept;
+    __syncthreads();
+    if (tid == 0) {
+        int s = 0;
+        for (int k = 0; k < NW; ++k) s += sh_w[k];
+        n_surv[q] = s;
     }
 }
 
 // The top-up rule (apples/Reference.py:144-152) for a listed query without its full row: the `-b` nearest references by
 // exact distance are among those whose LOWER BOUND does not exceed the `-b`-th smallest exact value.  Input: the query's row
 // of bounds (k_sd_gemm<ROWS>: acc = 4 x the bound of tot).  key = acc / 4 / min(valid sites of the query, of the row) <=
-// tot / valid = x, and d grows with x.  (1) a histogram of the keys gives t0 with at least `-b` + 8 keys below it; those
+// tot / valid = x (kept in single precision, within 2e-7: the comparisons carry a margin of 1e-6), and d grows with x.  (1) a histogram of the keys gives t0 with at least `-b` + 8 keys below it; those
 // references are evaluated exactly (as k_scoredist would: same bits); (2) X = a bin edge at or above the `-b`-th smallest
 // exact x among them, an upper bound of the true `-b`-th smallest x; (3) every other reference with key <= X is evaluated
 // too.  Whatever was not evaluated has x > X: it cannot be among the `-b` nearest, nor inside the threshold (a listed query
@@ -465,11 +540,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restri
 // Fewer than `-b` valid distances among the first set: everything is evaluated.
 #define SDT_BINS 4096
 #define SDT_SCALE 2048.0
-__global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restrict__ refa, const uint16_t *__restrict__ refm,
-                                                         const uint8_t *__restrict__ qa, const uint16_t *__restrict__ qm,
+__global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restrict__ rrows, const uint16_t *__restrict__ mrows,
+                                                         int Lrow, const uint8_t *__restrict__ qa, const uint16_t *__restrict__ qm,
                                                          const double *__restrict__ table, int64_t n_slots, int64_t slots_pad,
                                                          int Lpad, int L, double overlap, const int32_t *__restrict__ qlist,
-                                                         const int32_t *__restrict__ qcount, const double *__restrict__ lbrows,
+                                                         const int32_t *__restrict__ qcount, double *lbrows,
                                                          int64_t row_stride, const float *__restrict__ nvr,
                                                          const float *__restrict__ nvq, int64_t qrow0, int baseobs,
                                                          double *__restrict__ out_rows) {
@@ -479,24 +554,26 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restri
     __shared__ int sh_w[NW];
     __shared__ int sh_bin;
     __shared__ int wqueue[NW][128];
+    __shared__ __attribute__((aligned(16))) uint8_t sh_wbuf[NW][SDE_WBUF];
+    __shared__ int sh_wslot[NW][64];
+    extern __shared__ __attribute__((aligned(16))) uint8_t sh_q[];  // the query's row (Lpad bytes), then its masks
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < 21 * 21; i += TPB) T[i] = table[i];
     const char *Tb = reinterpret_cast<const char *>(T);
     const int n16 = Lpad / 16;
+    uint16_t *sh_qm = reinterpret_cast<uint16_t *>(sh_q + Lpad);
     const int n_list = *qcount;
     const double INF = __longlong_as_double(0x7ff0000000000000LL);
     for (int r = blockIdx.x; r < n_list; r += gridDim.x) {
         const int64_t q = __builtin_amdgcn_readfirstlane(qlist[r]);
-        const float *lb = reinterpret_cast<const float *>(lbrows + q * row_stride);
+        float *lb = reinterpret_cast<float *>(lbrows + q * row_stride);
         double *out = out_rows + (int64_t)r * row_stride;
-        const uint8_t *qrow = qa + q * (int64_t)Lpad;
-        const uint16_t *qmask = qm + q * (int64_t)n16;
+        for (int i = tid; i < n16; i += TPB) {  // (the previous list entry's last use lies behind its closing barrier)
+            *reinterpret_cast<uint4 *>(sh_q + i * 16) = *reinterpret_cast<const uint4 *>(qa + q * (int64_t)Lpad + i * 16);
+            sh_qm[i] = qm[q * (int64_t)n16 + i];
+        }
         const float nq_ = nvq[qrow0 + q];
-        auto key_of = [&](int64_t slot) -> double {
-            const float nr = nvr[slot];
-            const float vub = nr < nq_ ? nr : nq_;
-            return vub > 0.f ? (double)lb[slot] * 0.25 / (double)vub : INF;
-        };
+        float *keys = lb;  // the row of bounds becomes the row of keys in place (pass A below)
         auto bin_of = [&](double x) -> int { return x >= (double)(SDT_BINS - 1) / SDT_SCALE ? SDT_BINS - 1 : (int)(x * SDT_SCALE); };
         // smallest bin whose cumulative count reaches `need` (SDT_BINS if the total does not)
         auto find_bin = [&](int need) -> int {
@@ -529,40 +606,57 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restri
         auto eval_range = [&](double lo, double hi, bool with_hist) {
             int head = 0, count = 0;  // wave-uniform ring of 128 slots
             auto drain = [&](int n) {
+                const int slot = lane < n ? wqueue[w][(head + lane) & 127] : 0;
+                double x = 0.0;
+                const double d = sd_eval64(rrows, mrows, Lrow, slot, sh_wbuf[w], sh_wslot[w], sh_q, sh_qm, n16, Tb, L, overlap, &x);
                 if (lane < n) {
-                    const int slot = wqueue[w][(head + lane) & 127];
-                    double x = 0.0;
-                    const double d = sd_pair_exact(refa, refm, slots_pad, slot, qrow, qmask, n16, Tb, L, overlap, &x);
                     out[slot] = d;
                     if (with_hist && d >= 0) atomicAdd(&hist[bin_of(x)], 1);
                 }
                 head = (head + n) & 127;
                 count -= n;
             };
-            for (int64_t s0 = (int64_t)w * 64; s0 < n_slots; s0 += TPB) {
-                const int64_t slot = s0 + lane;
-                bool take = false;
-                if (slot < n_slots) {
-                    const double k = key_of(slot);
-                    take = k > lo && k <= hi;
-                }
-                const unsigned long long m = __ballot(take);
-                if (m) {
-                    if (take) wqueue[w][(head + count + __popcll(m & ((1ull << lane) - 1ull))) & 127] = (int)slot;
-                    count += __popcll(m);
-                    if (count >= 64) drain(64);
+            // a wavefront streams blocks of 256 keys (four per lane), the next block's load leaving before this one is looked at
+            const float flo = (float)lo, fhi = (float)hi;
+            const int64_t step = (int64_t)NW * 256;
+            int64_t s0 = (int64_t)w * 256 + lane * 4;
+            float4 nxt = s0 < slots_pad ? *reinterpret_cast<const float4 *>(keys + s0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (; s0 - lane * 4 < n_slots; s0 += step) {
+                const float4 cur = nxt;
+                if (s0 + step < slots_pad) nxt = *reinterpret_cast<const float4 *>(keys + s0 + step);
+                const float kk[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool take = s0 + j < n_slots && kk[j] > flo && kk[j] <= fhi;
+                    const unsigned long long m = __ballot(take);
+                    if (m) {
+                        if (take) wqueue[w][(head + count + __popcll(m & ((1ull << lane) - 1ull))) & 127] = (int)(s0 + j);
+                        count += __popcll(m);
+                        if (count >= 64) drain(64);
+                    }
                 }
             }
             if (count > 0) drain(count);
         };
         // the row starts as "everything missing"; the histogram empty
-        for (int64_t s = tid; s < slots_pad; s += TPB) out[s] = -1.0;
+        for (int64_t s = (int64_t)tid * 2; s < slots_pad; s += TPB * 2) *reinterpret_cast<double2 *>(out + s) = make_double2(-1.0, -1.0);
         for (int i = tid; i < SDT_BINS; i += TPB) hist[i] = 0;
         __syncthreads();
-        for (int64_t s = tid; s < n_slots; s += TPB) {
-            const double k = key_of(s);
-            if (k < INF) atomicAdd(&hist[bin_of(k)], 1);
+        // pass A: key = bound / 4 / min(valid sites of the query, of the row) in single precision (within 2e-7 of the quotient:
+        // the tests below carry a margin of 1e-6), written over the bound; +inf where no pair can be valid
+        for (int64_t s = (int64_t)tid * 4; s < slots_pad; s += TPB * 4) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(lb + s), n4 = *reinterpret_cast<const float4 *>(nvr + s);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w};
+            float kk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float vub = nn[j] < nq_ ? nn[j] : nq_;
+                kk[j] = (s + j < n_slots && vub > 0.f) ? bb[j] * 0.25f / vub : __int_as_float(0x7f800000);
+                if (kk[j] < __int_as_float(0x7f800000)) atomicAdd(&hist[bin_of((double)kk[j])], 1);
+            }
+            *reinterpret_cast<float4 *>(keys + s) = make_float4(kk[0], kk[1], kk[2], kk[3]);
         }
+        __threadfence_block();
         const int b0 = find_bin(baseobs + 8);
         const double t0 = b0 >= SDT_BINS - 1 ? INF : (double)(b0 + 1) / SDT_SCALE;
         for (int i = tid; i < SDT_BINS; i += TPB) hist[i] = 0;
@@ -570,7 +664,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restri
         eval_range(-1.0, t0, true);
         if (t0 < INF) {
             const int b1 = find_bin(baseobs);
-            const double X = b1 >= SDT_BINS - 1 ? INF : (double)(b1 + 1) / SDT_SCALE * (1.0 + 1e-9);
+            const double X = b1 >= SDT_BINS - 1 ? INF : (double)(b1 + 1) / SDT_SCALE * (1.0 + 1e-6);
             if (X > t0) eval_range(t0, X, false);
         }
         __syncthreads();  // (hist, the queues and sh_bin are reused by the next list entry)
@@ -636,14 +730,15 @@ int launch_sd_filter(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t 
     return 0;
 }
 
-int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, int32_t *seg_slot,
-                    int32_t *seg_cnt) {
+int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, const int32_t *seg_slot,
+                    const int32_t *seg_cnt, int32_t *n_surv) {
     if (nq == 0) return 0;
     const DevAlign &a = ctx->aln;
     const int Lpad = (a.L + 15) / 16 * 16;
-    hipLaunchKernelGGL(k_sd_exact, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask,
+    const size_t dyn = (size_t)((Lpad + Lpad / 8 + 15) / 16 * 16) + ((size_t)(a.slots_pad >> 6) + 1) * sizeof(int);
+    hipLaunchKernelGGL(k_sd_exact, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow,
                        qb.aa_idx + q0 * Lpad, qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L,
-                       ctx->params.overlap_frac, ctx->params.filt_threshold, seg_d, seg_slot, seg_cnt);
+                       ctx->params.overlap_frac, ctx->params.filt_threshold, seg_d, seg_slot, seg_cnt, n_surv);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -673,9 +768,19 @@ int launch_sd_topup(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t n
     if (R == 0) SD_LAUNCH(0); else if (R == 1) SD_LAUNCH(1); else SD_LAUNCH(2);
 #undef SD_LAUNCH
     const unsigned wgs = (unsigned)std::min<int64_t>(nq_max, (int64_t)ctx->n_cu * 8);
-    hipLaunchKernelGGL(k_sd_topup, dim3(wgs), dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask, qb.aa_idx + q0 * Lpad,
+    hipLaunchKernelGGL(k_sd_topup, dim3(wgs), dim3(APPLES_TPB), (size_t)(Lpad + Lpad / 8), ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow, qb.aa_idx + q0 * Lpad,
                        qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L, ctx->params.overlap_frac,
                        qlist, qcount, lbrows, a.slots_pad, a.sd_nvr, qb.sd_nvq, q0, ctx->params.base_observation, out_rows);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// slot-major copy of the packed reference rows (what sd_eval64 reads); a.aa_rows / a.aa_mrows allocated by the caller
+int launch_sd_rows(apples_ctx *ctx) {
+    const DevAlign &a = ctx->aln;
+    const int Lpad = (a.L + 15) / 16 * 16;
+    hipLaunchKernelGGL(k_sd_rows, dim3((unsigned)(a.slots_pad / APPLES_TPB), (unsigned)(a.aa_Lrow / 16)), dim3(APPLES_TPB), 0, ctx->stream,
+                       a.aa_idx, a.aa_mask, a.slots_pad, Lpad / 16, a.aa_Lrow, a.aa_rows, a.aa_mrows);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -429,7 +429,8 @@ __global__ __launch_bounds__(TPB) void k_select_fast(SelectArgs a) {
         for (int64_t s = tid; s < n_seg; s += TPB) c += cnt[s];
         total = block_sum<NW>(c, sh_i);
     }
-    if (total < a.baseobs) {
+    if ((a.seg_surv ? a.seg_surv[q] : total) < a.baseobs) {
+        __syncthreads();  // (seg_surv may be n_obs itself: every thread has read it)
         if (tid == 0) {
             a.slow_list[atomicAdd(a.slow_count, 1)] = (int32_t)q;
             a.n_obs[q] = 0;
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(TPB) void k_select_fast(SelectArgs a) {
         } else {
             d = sd[src];
         }
-        if (slot == self) return 0;
+        if (slot == self || (a.seg_surv && d < 0)) return 0;
         ++n_total;
         node = a.slot_node[slot];
         lv = a.slot_level[slot];  // (beside the node: the per-level offsets below need no second pass over the list)
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(TPB) void k_select_fast(SelectArgs a) {
             for (int u = 0; u < EF; ++u) {
                 if (e0 + u * TPB >= total) break;  // (block-uniform)
                 int emit = 0;
-                if (in_[u] && slot_[u] != self) {  // own row dropped, first zero noted
+                if (in_[u] && slot_[u] != self && !(a.seg_surv && d_[u] < 0)) {  // own row dropped, first zero noted
                     ++n_total;
                     if (d_[u] == 0) {
                         const int ri = a.slot_rep[slot_[u]];
