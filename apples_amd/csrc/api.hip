@@ -425,7 +425,8 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
             if (dev_upload(ctx, &ctx->sd_tq4, codes, 400)) return 1;
             if (dev_alloc(ctx, &a.sd_ref4, a.slots_pad * (int64_t)sd_steps(a.L) * 64)) return 1;
             if (dev_alloc(ctx, &a.sd_nvr, a.slots_pad)) return 1;
-            if (launch_sd_expand(ctx, a.raw, a.n_rows, a.sd_ref4, a.slots_pad, ctx->stream, a.d_slot_row, 0, false, a.sd_nvr)) return 1;
+            if (launch_sd_expand(ctx, a.raw, a.n_rows, a.sd_ref4, a.slots_pad, ctx->stream, a.d_slot_row, 0, false, a.sd_nvr, nullptr,
+                                 a.aa_mask, a.slots_pad)) return 1;
             a.aa_Lrow = (int32_t)round_up(a.L, 64);
             if (dev_alloc(ctx, &a.aa_rows, a.slots_pad * (int64_t)a.aa_Lrow)) return 1;
             if (dev_alloc(ctx, &a.aa_mrows, a.slots_pad * (int64_t)(a.aa_Lrow / 16))) return 1;
@@ -790,7 +791,8 @@ int fill_block(apples_ctx *ctx, QueryBlock *qb, const uint8_t *queries, int64_t 
         if (qb->sd_q4) {
             const int64_t n_img = round_up(qb->n_pad, 256) + 256;
             const bool last = q0 + nq >= qb->n;  // the last chunk also zeroes the image's padding rows
-            if (launch_sd_expand(ctx, qb->raw + q0 * a.L, nq, qb->sd_q4, last ? n_img - q0 : nq, st, nullptr, q0, true, qb->sd_nvq)) return 1;
+            if (launch_sd_expand(ctx, qb->raw + q0 * a.L, nq, qb->sd_q4, last ? n_img - q0 : nq, st, nullptr, q0, true, qb->sd_nvq, nullptr,
+                                 qb->aa_mask + q0 * (Lpad / 16), 0)) return 1;
         }
         return 0;
     }

@@ -315,7 +315,8 @@ void sd_table_codes(const double *blosum20x20, uint8_t *codes);
 int sd_steps(int L);                // 128-value K steps of the operand images
 bool sd_gemm_usable(const apples_ctx *ctx);
 int launch_sd_expand(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_img, hipStream_t st,
-                     const int32_t *d_src_row, int64_t row0, bool query, float *d_nv, const int32_t *d_n = nullptr);
+                     const int32_t *d_src_row, int64_t row0, bool query, float *d_nv, const int32_t *d_n = nullptr,
+                     const uint16_t *d_mask = nullptr, int64_t ref_stride = 0);
 int launch_sd_topup(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist, const int32_t *qcount,
                     uint8_t *img, double *lbrows, double *out_rows);
 int launch_sd_rows(apples_ctx *ctx);

@@ -20,6 +20,7 @@
 //
 // Queries left with fewer than `-b` survivors take the top-up rule on full rows (k_scoredist listed mode), as before.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -51,6 +52,19 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_expand(const uint8_t *__restr
                                                           const int32_t *__restrict__ src_row, int64_t row0,
                                                           const uint8_t *__restrict__ tq4, float *__restrict__ nv,
                                                           const int32_t *__restrict__ n_dev) {
+    // two values per byte and 20 per site: a byte never straddles sites, so the image is a byte table look-up -- rowb[v][h] =
+    // values 2 h, 2 h + 1 of the row of residue v (row 20 = a gap: zeros)
+    __shared__ uint8_t rowb[21 * 10];
+    for (int i = threadIdx.x; i < 210; i += APPLES_TPB) {
+        const int v = i / 10, a = (i - v * 10) * 2;
+        uint32_t lo = 0, hi = 0;
+        if (v < 20) {
+            lo = tq4 ? tq4[v * 20 + a] : (v == a ? 2u : 0u);
+            hi = tq4 ? tq4[v * 20 + a + 1] : (v == a + 1 ? 2u : 0u);
+        }
+        rowb[i] = (uint8_t)(lo | (hi << 4));
+    }
+    __syncthreads();
     const int64_t idx = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;  // one thread per (row, step, chunk)
     if (n_dev) n = n_img = *n_dev;  // listed rows: the list's length lives on the device (nothing beyond it is written)
     if (idx >= n_img * NB * 4) return;
@@ -59,35 +73,39 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_expand(const uint8_t *__restr
     const int b = (int)(rb % NB);
     const int64_t q = rb / NB;
     uint32_t w[4] = {0, 0, 0, 0};
-    const uint8_t *row = nullptr;
     if (q < n) {
-        row = raw + (src_row ? (int64_t)src_row[q] : q) * (int64_t)L;
+        const uint8_t *row = raw + (src_row ? (int64_t)src_row[q] : q) * (int64_t)L;
         const int k0 = b * 128 + c * 32;
-        int s = k0 / 20, a = k0 - s * 20;
-        uint32_t v = s < L ? aa_index(row[s]) : 20u;
+        int s = k0 / 20, h = (k0 - s * 20) >> 1;
+        // the chunk's 16 bytes lie in at most three sites
+        uint32_t v3[3];
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            uint32_t nib = 0;
-            if (v < 20u) nib = tq4 ? tq4[v * 20u + a] : (v == (uint32_t)a ? 2u : 0u);
-            w[e >> 3] |= nib << (4 * (e & 7));
-            if (++a == 20) {
-                a = 0;
-                ++s;
-                v = s < L ? aa_index(row[s]) : 20u;
-            }
+        for (int i = 0; i < 3; ++i) v3[i] = s + i < L ? aa_index(row[s + i]) : 20u;
+        int si = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t v = si == 0 ? v3[0] : (si == 1 ? v3[1] : v3[2]);
+            w[j >> 2] |= (uint32_t)rowb[v * 10 + h] << (8 * (j & 3));
+            if (++h == 10) { h = 0; ++si; }
         }
     }
     const int64_t ar = row0 + q, tile = ar >> 8;
     const int rr = (int)(ar & 255), sw = (rr >> 2) & 3;
     out[(tile * NB + b) * 1024 + rr * 4 + (c ^ sw)] = make_uint4(w[0], w[1], w[2], w[3]);
-    if (nv && b == 0 && c == 0) {
-        int cnt = -1;
-        if (q < n) {
-            cnt = 0;
-            for (int s = 0; s < L; ++s) cnt += row[s] != (uint8_t)'-';
-        }
-        nv[ar] = (float)cnt;
+}
+
+// sites of a row that are not gaps, from the 16-bit gap masks the packing kernel left (query layout [row][n16], reference
+// layout [n16][slots_pad]); -1 for the image's padding rows (no pair with them may pass the filter)
+__global__ __launch_bounds__(APPLES_TPB) void k_sd_nv(const uint16_t *__restrict__ mask, int64_t n, int64_t n_img, int n16,
+                                                      int64_t ref_stride, float *__restrict__ nv) {
+    const int64_t r = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    if (r >= n_img) return;
+    int cnt = -1;
+    if (r < n) {
+        cnt = 0;
+        for (int s = 0; s < n16; ++s) cnt += __popc((uint32_t)(ref_stride ? mask[(int64_t)s * ref_stride + r] : mask[r * n16 + s]));
     }
+    nv[r] = (float)cnt;
 }
 
 // R = (NB - 2) % 3: the shape of the main loop's tail, fixed per launch (as k_jc69_gemm)
@@ -354,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
 #define SDE_WBUF (64 * SDE_STRIDE)  // bytes of LDS per wavefront
 __device__ __forceinline__ double sd_eval64(const uint8_t *__restrict__ rrows, const uint16_t *__restrict__ mrows, int Lrow,
                                             int slot, uint8_t *wbuf, int *wslot, const uint8_t *lq, const uint16_t *lqm,
-                                            int n16, const char *Tb, int L, double overlap, double *ratio = nullptr) {
+                                            int n16, const char *Tb, int L, double overlap, double *ratio = nullptr, int dbg = 0) {
     const int lane = threadIdx.x & 63, sub = lane & 3, grp = lane >> 2;
     __builtin_amdgcn_wave_barrier();
     wslot[lane] = slot;
@@ -378,7 +396,7 @@ __device__ __forceinline__ double sd_eval64(const uint8_t *__restrict__ rrows, c
         *reinterpret_cast<uint4 *>(wdst + 32 * SDE_STRIDE) = n2;
         *reinterpret_cast<uint4 *>(wdst + 48 * SDE_STRIDE) = n3;
         const uint2 cm = nm;
-        const int cn = c + 1 < npiece ? c + 1 : c;  // (the last round fetches its own piece again: nobody reads it)
+        const int cn = (dbg & 1) ? 0 : (c + 1 < npiece ? c + 1 : c);  // (the last round fetches its own piece again: nobody reads it)
         n0 = *reinterpret_cast<const uint4 *>(src0 + cn * SDE_PIECE);
         n1 = *reinterpret_cast<const uint4 *>(src1 + cn * SDE_PIECE);
         n2 = *reinterpret_cast<const uint4 *>(src2 + cn * SDE_PIECE);
@@ -388,7 +406,7 @@ __device__ __forceinline__ double sd_eval64(const uint8_t *__restrict__ rrows, c
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int s16 = c * 4 + s;
-            if (s16 < n16) {  // (wave-uniform: the query row ends with the alignment)
+            if (s16 < n16 && !(dbg & 2)) {  // (wave-uniform: the query row ends with the alignment)
                 const uint4 cw = *reinterpret_cast<const uint4 *>(wbuf + lane * SDE_STRIDE + s * 16);
                 const uint4 qw = *reinterpret_cast<const uint4 *>(lq + s16 * 16);
                 const uint32_t rmask = ((s & 2 ? cm.y : cm.x) >> (16 * (s & 1))) & 0xffffu;
@@ -445,7 +463,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restri
                                                          const double *__restrict__ table, int64_t n_slots, int64_t slots_pad,
                                                          int Lpad, int L, double overlap, double thr,
                                                          double *__restrict__ seg_d, const int32_t *__restrict__ seg_slot,
-                                                         const int32_t *__restrict__ seg_cnt, int32_t *__restrict__ n_surv) {
+                                                         const int32_t *__restrict__ seg_cnt, int32_t *__restrict__ n_surv, int dbg) {
     constexpr int TPB = APPLES_TPB, NW = TPB / 64;
     __shared__ double T[21 * 21];
     __shared__ int sh_w[NW];
@@ -510,7 +528,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restri
         const int64_t src = (int64_t)lo * 64 + (ee - pref[lo]);
         const int slot = sslot[src];
         const bool ok = in && slot < n_slots;
-        const double d = sd_eval64(rrows, mrows, Lrow, ok ? slot : 0, sh_wbuf[w], sh_wslot[w], sh_q, sh_qm, n16, Tb, L, overlap);
+        const double d = sd_eval64(rrows, mrows, Lrow, ok ? slot : 0, sh_wbuf[w], sh_wslot[w], sh_q, sh_qm, n16, Tb, L, overlap, nullptr, dbg);
         if (in) {
             const bool keep = ok && d >= 0 && d <= thr;
             sd[src] = keep ? d : -1.0;
@@ -691,14 +709,20 @@ bool sd_gemm_usable(const apples_ctx *ctx) {
     return ctx->aln.sd_ref4 != nullptr && ctx->params.filt_threshold <= SD_GEMM_MAX_THRESHOLD;
 }
 
+// d_mask / ref_stride: the rows' gap masks (k_pack_aa; ref_stride = slots_pad for the reference layout, 0 for the query
+// layout) when d_nv is wanted
 int launch_sd_expand(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_img, hipStream_t st,
-                     const int32_t *d_src_row, int64_t row0, bool query, float *d_nv, const int32_t *d_n) {
+                     const int32_t *d_src_row, int64_t row0, bool query, float *d_nv, const int32_t *d_n, const uint16_t *d_mask,
+                     int64_t ref_stride) {
     if (n_img <= 0) return 0;
     const int NB = sd_steps(ctx->aln.L);
     const int64_t total = n_img * NB * 4;
     hipLaunchKernelGGL(k_sd_expand, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0, st ? st : ctx->stream,
                        d_raw, n, ctx->aln.L, NB, reinterpret_cast<uint4 *>(d_out), n_img, d_src_row, row0,
                        query ? ctx->sd_tq4 : (const uint8_t *)nullptr, d_nv, d_n);
+    if (d_nv)
+        hipLaunchKernelGGL(k_sd_nv, dim3((unsigned)((n_img + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0, st ? st : ctx->stream,
+                           d_mask, n, n_img, (ctx->aln.L + 15) / 16, ref_stride, d_nv + row0);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -736,9 +760,10 @@ int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t n
     const DevAlign &a = ctx->aln;
     const int Lpad = (a.L + 15) / 16 * 16;
     const size_t dyn = (size_t)((Lpad + Lpad / 8 + 15) / 16 * 16) + ((size_t)(a.slots_pad >> 6) + 1) * sizeof(int);
+    static const int sd_dbg = getenv("APPLES_SD_DBG") ? atoi(getenv("APPLES_SD_DBG")) : 0;  // timing experiments only (wrong results)
     hipLaunchKernelGGL(k_sd_exact, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow,
                        qb.aa_idx + q0 * Lpad, qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L,
-                       ctx->params.overlap_frac, ctx->params.filt_threshold, seg_d, seg_slot, seg_cnt, n_surv);
+                       ctx->params.overlap_frac, ctx->params.filt_threshold, seg_d, seg_slot, seg_cnt, n_surv, sd_dbg);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
