@@ -1131,7 +1131,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             sa.lvl_slots = a.lvl_slots;
             {   // scratch of the cluster-major distance pass: per-cluster counters, the (query, offset) lists, the tile table
                 const bool big_form = a.n_reps > SELECT_CLUSTERS_ACC_CAP && a.n_reps <= SELECT_CLUSTERS_BIG_CAP &&
-                                      !getenv("APPLES_NO_CLUSTER_BIG");  // (diagnostic knob: queries beyond ACC_CAP clusters to the general route)
+                                      !(ctx->dbg & APPLES_DBG_NO_CLUSTER_BIG);  // (diagnostic switch: queries beyond ACC_CAP clusters to the general route)
                 const int64_t n_ints = 3 * (int64_t)a.n_reps + 8 + SELECT_CLUSTERS_BIG_LIST + 8,
                               n_items = nq * SELECT_CLUSTERS_ACC_CAP + (big_form ? std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps : 0),
                               n_tiles = n_items / SELECT_CLUSTERS_MIN_TILE + a.n_reps + 1;
@@ -1159,7 +1159,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             if (launch_select_clusters(ctx, sa, nq)) return 1;
             // queries whose accepted clusters hold fewer than -b valid distances: the top-up rule over the representatives
             // (phase 4 of k_select_clusters); what that cannot hold: full rows + general selection
-            static const bool no_listed = getenv("APPLES_NO_CLUSTER_TOPUP") != nullptr;  // diagnostic knob: everything through the general route
+            const bool no_listed = (ctx->dbg & APPLES_DBG_NO_CLUSTER_TOPUP) != 0;  // diagnostic switch: everything through the general route
             int32_t *fwd_list = w.slow_list + 2 * w.batch, *fwd_count = w.cls_count + 20;
             if (!no_listed) {
                 sa.rep_panel = a.rep_packed; sa.slow2_list = fwd_list; sa.slow2_count = fwd_count;
@@ -1194,7 +1194,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             // the queries that need the top-up rule: full rows for the listed queries only (row r of dist_slow = list
             // entry r), a slice of the list at a time, then the general selection over those rows
             sa.dist = w.dist_slow;
-            static const bool no_sd_topup = getenv("APPLES_NO_SD_TOPUP") != nullptr;  // diagnostic knob: full rows for the listed queries
+            const bool no_sd_topup = (ctx->dbg & APPLES_DBG_NO_SD_TOPUP) != 0;  // diagnostic switch: full rows for the listed queries
             const bool lb_topup = qb.sd_q4 && sd_gemm_usable(ctx) && !no_sd_topup && w.dist_rows >= nq;
             if (lb_topup && ctx->sd_list_rows < w.batch) {
                 dev_free(ctx->sd_list_img); ctx->sd_list_img = nullptr; ctx->sd_list_rows = 0;
@@ -1224,7 +1224,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             sa.seg_lut = nullptr;
             // top-up path for the queries k_select_fast listed: full rows + per-segment minima (in the
             // rows of the fused buffers, which k_select_fast has consumed), then the `-b` nearest
-            static const bool no_topup = getenv("APPLES_NO_TOPUP_KERNEL") != nullptr;  // diagnostic knob
+            const bool no_topup = (ctx->dbg & APPLES_DBG_NO_TOPUP_KERNEL) != 0;  // diagnostic switch
             // (short rows are cheaper to stream twice than to rank: 2 x `-b` block arg-min rounds)
             static const int64_t topup_min = getenv("APPLES_TOPUP_MIN_ROWS") ? atoll(getenv("APPLES_TOPUP_MIN_ROWS")) : 40000;
             const bool topup = !no_topup && ctx->params.base_observation <= 256 && ctx->aln.n_refs >= topup_min;
@@ -1305,13 +1305,16 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
     };
     ctx->device = device;
     ctx->params = *params;
-    ctx->dbg = params->debug;
+    ctx->dbg = params->debug & APPLES_DBG_ALL;  // (bits this build does not know are ignored: a caller built against a newer header)
     {
         static const struct { const char *env; uint32_t bit; } knobs[] = {
             {"APPLES_NO_FUSE", APPLES_DBG_NO_FUSE}, {"APPLES_SWEEP_SCAN", APPLES_DBG_SWEEP_SCAN}, {"APPLES_NODE_MAP", APPLES_DBG_NODE_MAP},
             {"APPLES_SWEEP_MERGE", APPLES_DBG_SWEEP_MERGE}, {"APPLES_NO_SWEEP_MERGE", APPLES_DBG_NO_SWEEP_MERGE},
             {"APPLES_NO_DIST_GEMM", APPLES_DBG_NO_DIST_GEMM}, {"APPLES_NO_SWEEP_LEAN", APPLES_DBG_NO_SWEEP_LEAN},
-            {"APPLES_NO_SD_GEMM", APPLES_DBG_NO_SD_GEMM}};
+            {"APPLES_NO_SD_GEMM", APPLES_DBG_NO_SD_GEMM}, {"APPLES_CLUSTER_BY_QUERY", APPLES_DBG_CLUSTER_BY_QUERY},
+            {"APPLES_NO_CLUSTER_TOPUP", APPLES_DBG_NO_CLUSTER_TOPUP}, {"APPLES_NO_STREAM_SELECT", APPLES_DBG_NO_STREAM_SELECT},
+            {"APPLES_NO_TOPUP_KERNEL", APPLES_DBG_NO_TOPUP_KERNEL}, {"APPLES_NO_CLUSTER_BIG", APPLES_DBG_NO_CLUSTER_BIG},
+            {"APPLES_NO_SD_TOPUP", APPLES_DBG_NO_SD_TOPUP}};
         for (const auto &k : knobs)
             if (getenv(k.env)) ctx->dbg |= k.bit;
     }

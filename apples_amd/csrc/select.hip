@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist(SelectArgs a) {
 int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
     const size_t dyn = (size_t)((a.n_members + 63) >> 6) * 10;  // the slot bitmap and its 16-bit in-run prefixes (runs of 16 words: 262 144 slots)
-    const bool by_query = getenv("APPLES_CLUSTER_BY_QUERY") != nullptr;  // diagnostic knob: phase 0 alone (read per launch: tests cross the two forms in one process)
+    const bool by_query = (ctx->dbg & APPLES_DBG_CLUSTER_BY_QUERY) != 0;  // diagnostic switch: phase 0 alone
     if (by_query || !a.cl_count) {
         hipLaunchKernelGGL(k_select_clusters<0>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
@@ -1729,7 +1729,7 @@ int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     unsigned grid = a.qcount ? (unsigned)std::min<int64_t>(nq, 512) : (unsigned)nq;
     SelectArgs b = a;
     b.n_rows_plain = nq;
-    static const bool no_stream = getenv("APPLES_NO_STREAM_SELECT") != nullptr;  // diagnostic knob
+    const bool no_stream = (ctx->dbg & APPLES_DBG_NO_STREAM_SELECT) != 0;  // diagnostic switch
     if (a.all_singleton && !a.gather && !no_stream) {  // singleton clusters, rows in slot order: barrier-free streaming form
         // one workgroup per row up to 4 per CU, then rows in turn (C5: 1.70 ms per 4 096 rows against 1.85-1.9 with one
         // workgroup per row); APPLES_STREAM_GRID: tuning knob

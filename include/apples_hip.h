@@ -92,6 +92,13 @@ typedef struct {
 #define APPLES_DBG_NO_DIST_GEMM  32u  /* fused distance pass through the bit-plane-fed MFMA kernel, no reference image */
 #define APPLES_DBG_NO_SWEEP_LEAN 64u  /* level loop of sweep.hip where sweep_lean.hip would run */
 #define APPLES_DBG_NO_SD_GEMM    128u /* scoredist: the fused pass evaluates every pair (k_scoredist), no matrix-core filter */
+#define APPLES_DBG_CLUSTER_BY_QUERY 256u  /* clustered route: a thread per (query, member) pair (phase 0 of k_select_clusters) */
+#define APPLES_DBG_NO_CLUSTER_TOPUP 512u  /* clustered route: its listed queries through full rows + general selection */
+#define APPLES_DBG_NO_STREAM_SELECT 1024u /* singleton rows / -d tables: general selection kernel instead of the streaming one */
+#define APPLES_DBG_NO_TOPUP_KERNEL 2048u  /* JC69 top-up list: general selection over the full rows, no segment minima */
+#define APPLES_DBG_NO_CLUSTER_BIG 4096u   /* clustered route: queries beyond 512 accepted clusters to the general route */
+#define APPLES_DBG_NO_SD_TOPUP   8192u    /* scoredist top-up list: full rows (k_scoredist listed), no lower-bound rows */
+#define APPLES_DBG_ALL           16383u   /* every defined switch; other bits of apples_params.debug are ignored */
 
 /* One placement = the p row runquery returns, [edge_num, likelihood(error), 1, distal, pendant]
  * (apples/Algorithm.py:98-101, apples/PoolQueryWorker.py:36-37,74,88,119-125). */

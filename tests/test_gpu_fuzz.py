@@ -1,0 +1,164 @@
+"""Differential fuzz of the routes through the hot path, inside `pytest -m gpu` (round 3's scripts/*_fuzz.py, which found
+the one real selection bug of that round -- a query identical to two members of one cluster, `k_select`'s first-zero
+bookkeeping -- lived outside the suite).  Every test draws random configurations from a fixed seed (backbone size,
+alignment length, gap rate, threshold, -b, method, device batch size, ...) and requires byte-identical placements between
+routes that share no distance, selection or sweep code, crossed inside one process through `apples_params.debug`; the
+small backbones also against the C oracle (what the reference computes: apples/Reference.py:138-154,
+apples/PoolQueryWorker.py:63-98).  Two seeds x 40 configurations per family."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+from oracle_c import COracle  # noqa: E402
+
+from apples_amd import synth, treecluster  # noqa: E402
+from apples_amd.engine import Engine, jc69_lut  # noqa: E402
+from apples_amd.fasta import Alignment  # noqa: E402
+from apples_amd.reference import ReducedReference  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+NTHREADS = len(os.sched_getaffinity(0))
+NCFG = 40
+
+
+def _place(routes, make, queries, place='place_sequences'):
+    """placements per route: make(debug) -> Engine"""
+    out = {}
+    for name, dbg in routes:
+        e = make(dbg)
+        out[name] = getattr(e, place)(*queries) if isinstance(queries, tuple) else getattr(e, place)(queries)
+        e.close()
+    return out
+
+
+def _diff(a, b):
+    bad = np.nonzero([x.tobytes() != y.tobytes() for x, y in zip(a, b)])[0]
+    return '%d rows differ, first %s: %s / %s' % (len(bad), bad[:5], a[bad[0]] if len(bad) else '', b[bad[0]] if len(bad) else '')
+
+
+@pytest.mark.parametrize('seed', [1, 9])
+def test_clustered_routes_agree(seed):
+    """The command line's default route (clustered references, consensus representatives): fused default (cluster-major member
+    distances, phase 4 for the listed queries) / a thread per (query, member) pair / the listed queries through full rows /
+    full rows + general selection for every query.  Seed 1 is the stream that exposed the round-3 `k_select` fault."""
+    rng = np.random.default_rng(seed)
+    routes = (('default', ()), ('by_query', ('cluster_by_query',)), ('no_topup', ('no_cluster_topup',)), ('no_fuse', ('no_fuse',)))
+    checked = 0
+    for c in range(NCFG):  # (seed 1, first 30 configurations: the round-3 script run that found the fault)
+        n = int(rng.choice([60, 257, 600, 1500, 5000, 12000])); L = int(rng.integers(40, 2047)); nq = int(rng.integers(1, 900))
+        gap = float(rng.choice([0.0, 0.05, 0.3, 0.6])); thr = float(rng.choice([0.0, 0.02, 0.2, 0.5, 1.2])); b = int(rng.choice([3, 25, 200]))
+        mb = int(rng.choice([0, 0, 32, 96, 160, 512])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
+        diam = float(rng.choice([0.01, 0.05, 0.24, 0.4, 0.8]))
+        d = synth.make_dataset(n, L, nq, gap_rate=gap, seed_tree=200 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])))
+        nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
+        ca = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, diam)).cluster_arrays()
+        out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method=m, threshold=thr, baseobs=b,
+                                                max_batch=mb, debug=dbg), d.query_seqs)
+        tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s diam %g' % (seed, c, n, L, nq, gap, thr, b, mb, m, diam)
+        for k in ('by_query', 'no_topup', 'no_fuse'):
+            assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
+        if n <= 1500:
+            co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method=m, criterion='MLSE', threshold=thr, baseobs=b,
+                         lut=jc69_lut(L, 0.001), threads=NTHREADS)
+            want = co.place_sequences(d.query_seqs)
+            assert want.tobytes() == out['default'].tobytes(), '%s: default vs C oracle: %s' % (tag, _diff(out['default'], want))
+            checked += 1
+    assert checked >= 5
+
+
+@pytest.mark.parametrize('seed', [3, 10])
+def test_singleton_jc69_routes_agree(seed):
+    """Singleton clusters, JC69: GEMM-form fused pass + lean / bit sweep (default) against the bit-plane-fed matrix-core kernel
+    with merged level lists, and against full rows + general selection with the node map: no distance, selection or
+    sweep code in common; small backbones also against the C oracle."""
+    rng = np.random.default_rng(seed)
+    routes = (('default', ()), ('no_gemm', ('no_dist_gemm', 'sweep_merge')), ('no_fuse', ('no_fuse', 'node_map')),
+              ('no_topup', ('no_topup_kernel', 'no_sweep_lean')))
+    checked = 0
+    for c in range(NCFG):
+        n = int(rng.choice([40, 257, 600, 1500, 5000, 20000])); L = int(rng.integers(20, 2047)); nq = int(rng.integers(1, 700))
+        gap = float(rng.choice([0.0, 0.05, 0.3, 0.6])); thr = float(rng.choice([0.05, 0.2, 0.5, 1.2])); b = int(rng.choice([3, 25, 200]))
+        mb = int(rng.choice([0, 0, 32, 96, 160, 512])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
+        d = synth.make_dataset(n, L, nq, gap_rate=gap, seed_tree=100 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])))
+        nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
+        out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, method=m, threshold=thr, baseobs=b, max_batch=mb, debug=dbg),
+                     d.query_seqs)
+        tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s' % (seed, c, n, L, nq, gap, thr, b, mb, m)
+        for k in ('no_gemm', 'no_fuse', 'no_topup'):
+            assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
+        if n <= 1500:
+            co = COracle(d.tree, d.ref_seqs, nodes, method=m, criterion='MLSE', threshold=thr, baseobs=b, lut=jc69_lut(L, 0.001),
+                         threads=NTHREADS)
+            want = co.place_sequences(d.query_seqs)
+            assert want.tobytes() == out['default'].tobytes(), '%s: default vs C oracle: %s' % (tag, _diff(out['default'], want))
+            checked += 1
+    assert checked >= 5
+
+
+@pytest.mark.parametrize('seed', [4, 11])
+def test_scoredist_routes_agree(seed):
+    """scoredist, singleton clusters: matrix-core lower-bound filter + exact candidates + lower-bound top-up (default) against
+    every pair with the early exit (no filter), against the filter with full rows for the top-up list, and against full
+    rows + general selection; small backbones also against the C oracle (edges, flags and counts equal, lengths to 1e-9:
+    the reference's own summation order is BLAS-internal)."""
+    rng = np.random.default_rng(seed)
+    routes = (('default', ()), ('every_pair', ('no_sd_gemm',)), ('rows_topup', ('no_sd_topup',)), ('no_fuse', ('no_fuse',)))
+    checked = 0
+    for c in range(NCFG):
+        n = int(rng.choice([40, 257, 600, 1500, 5000, 20000])); L = int(rng.integers(7, 1200)); nq = int(rng.integers(1, 700))
+        gap = float(rng.choice([0.0, 0.05, 0.3, 0.6])); thr = float(rng.choice([0.03, 0.1, 0.2, 0.24, 0.5])); b = int(rng.choice([3, 25, 200]))
+        mb = int(rng.choice([0, 0, 32, 96, 160, 512])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
+        d = synth.make_dataset(n, L, nq, protein=True, gap_rate=gap, seed_tree=400 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])))
+        q = d.query_seqs.copy()
+        if nq > 6:
+            q[3] = d.ref_seqs[11 % n]          # an exact match
+            q[4] = ord('-')                    # nothing observed
+            q[5, ::2] = ord('x')               # symbols outside the alphabet count as 'A' (apples/distance.py:418-678)
+        nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
+        out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, protein=True, method=m, threshold=thr, baseobs=b,
+                                                max_batch=mb, debug=dbg), q)
+        tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s' % (seed, c, n, L, nq, gap, thr, b, mb, m)
+        for k in ('every_pair', 'rows_topup', 'no_fuse'):
+            assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
+        if n <= 1500:
+            co = COracle(d.tree, d.ref_seqs, nodes, protein=True, method=m, criterion='MLSE', threshold=thr, baseobs=b, threads=NTHREADS)
+            want = co.place_sequences(q)
+            got = out['default']
+            for f in ('edge', 'flags', 'n_obs', 'n_valid'):
+                assert np.array_equal(got[f], want[f]), '%s: %s differs from the C oracle' % (tag, f)
+            for f in ('error', 'distal', 'pendant'):
+                np.testing.assert_allclose(got[f], want[f], rtol=1e-9, atol=1e-15, err_msg='%s: %s' % (tag, f))
+            checked += 1
+    assert checked >= 5
+
+
+@pytest.mark.parametrize('seed', [1, 5])
+def test_distance_table_routes_against_c_oracle(seed):
+    """-d input (apples/PoolQueryWorker.py:44-59): odd and even numbers of columns (rows then start 8- or 16-byte aligned, which
+    picks the loads of the selection kernels), columns in random order, columns that are not tree leaves, negative and zero
+    entries, ties; streaming selection (default), general selection and the level-loop sweep, all byte for byte against the
+    C oracle."""
+    rng = np.random.default_rng(seed)
+    routes = (('default', ()), ('no_stream', ('no_stream_select',)), ('no_lean', ('no_sweep_lean', 'no_topup_kernel')))
+    for c in range(NCFG):
+        n = int(rng.choice([33, 64, 257, 1000, 4097, 20001])); nq = int(rng.integers(1, 200))
+        thr = float(rng.choice([0.0, 0.05, 0.2, 1.0])); b = int(rng.choice([3, 25, 200])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
+        d = synth.make_dataset(n, 8, nq, seed_tree=300 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])))
+        nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
+        D = synth.noisy_distance_rows(d.tree, d.query_leaf, d.query_pendant, list(range(nq)), seed_noise=c)
+        perm = rng.permutation(n); D = np.ascontiguousarray(D[:, perm]); cols = nodes[perm].copy()
+        off = rng.random(n) < float(rng.choice([0.0, 0.02, 0.3])); cols[off] = -1               # columns that are not tree leaves
+        neg = rng.random(D.shape) < float(rng.choice([0.0, 0.01])); D[neg] = -1.0               # invalid entries
+        zer = rng.random(D.shape) < float(rng.choice([0.0, 0.0005])); D[zer] = 0.0              # exact matches (also outside the tree)
+        tie = rng.random(D.shape) < 0.01; D[tie] = np.round(D[tie], 2)                          # ties
+        want = COracle(d.tree, method=m, criterion='MLSE', threshold=thr, baseobs=b, threads=NTHREADS).place_distances(D, cols)
+        out = _place(routes, lambda dbg: Engine(d.tree, None, method=m, criterion='MLSE', threshold=thr, baseobs=b, debug=dbg),
+                     (D, cols), place='place_distances')
+        tag = 'seed %d cfg %d: n %d nq %d thr %g b %d %s off-tree %d' % (seed, c, n, nq, thr, b, m, int(off.sum()))
+        for k in out:
+            assert out[k].tobytes() == want.tobytes(), '%s: %s vs C oracle: %s' % (tag, k, _diff(out[k], want))
