@@ -1071,18 +1071,33 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     hipEvent_t *ev = ctx->ev_pool.data() + 2;
     hipEvent_t e_start = ctx->ev_pool[0], e_stop = ctx->ev_pool[1];
     if (n_sub == 0) feed = nullptr;  // an empty block: nothing to upload, nothing to place
+    // A chunk of a host buffer travels in two pieces where the distance pass can start on the first (the matrix-core passes
+    // take any range of query rows): the first quarter is on the device and under way while the rest is still on the bus
+    // (a 12 500-query chunk of config 3: 0.22 ms of copy + 0.08 ms of packing in front of 3.6 ms of GEMM).  head(nq) = rows of
+    // the first piece (nq: one piece).
+    const bool split_feed = feed && fused && !cfused && !pipelined && ((sfused && qb.sd_q4 && sd_gemm_usable(ctx)) ||
+                                                                        (!sfused && fused_counts_format(ctx, qb) && dist_gemm_usable(ctx)));
+    auto head = [&](int64_t nq) -> int64_t { return split_feed && nq >= 4096 ? round_up(nq / 4, 256) : nq; };
+    auto feed_chunk = [&](int64_t i) -> int {  // upload + pack sub-batch i on stream2, an event behind each piece
+        const int64_t q0 = i * step, nq = std::min(step, qb.n - q0), h = head(nq);
+        if (fill_block(ctx, &qb, feed->host, q0, h, ctx->stream2)) return 1;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_feed[2 * i], ctx->stream2));
+        if (h < nq && fill_block(ctx, &qb, feed->host, q0 + h, nq - h, ctx->stream2)) return 1;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_feed[2 * i + 1], ctx->stream2));
+        return 0;
+    };
     if (feed) {
-        while (ctx->ev_feed.size() < (size_t)n_sub) {
+        while (ctx->ev_feed.size() < (size_t)n_sub * 2) {
             hipEvent_t e;
             HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->ev_feed.push_back(e);
         }
-        if (fill_block(ctx, &qb, feed->host, 0, std::min(step, qb.n), ctx->stream2)) return 1;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_feed[0], ctx->stream2));
+        if (feed_chunk(0)) return 1;
     }
     HIP_TRY(ctx, hipEventRecord(e_start, front));
     if (pipelined) HIP_TRY(ctx, hipStreamWaitEvent(back, e_start, 0));
     int launches = 0;
+    bool sd_filter_timed = false;
     // The queries on the top-up / slow list get full distance rows; a slim workspace holds rows for a slice of the batch
     // only: the list's length comes to the host (one short wait per batch) and the list is walked in slices of that many
     // queries.  fn(list, count pointer, entries at most) runs the listed distance pass + selection for one slice.
@@ -1115,7 +1130,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         if (pipelined && i > 0) swap_bufs(w);  // host view: w.* now names buffer set `set`
         if (pipelined && i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_back[set], 0));  // set free again
         hipEvent_t *e = &ev[(size_t)i * 6];
-        if (feed) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[i], 0));  // chunk i is on the device
+        const int64_t nh = feed ? head(nq) : nq;  // rows of the chunk's first piece
+        if (feed) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[2 * i + (nh < nq ? 0 : 1)], 0));  // chunk i (its first piece) is on the device
         HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), front));  // every counter of the batch
         if (cfused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
@@ -1182,7 +1198,14 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 // lower bounds on the matrix cores -> candidates per segment -> exact distances of the candidates, the
                 // segments closed up in place (dist_sd.hip)
                 HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (w.stride / 64) * sizeof(int32_t), front));
-                if (launch_sd_filter(ctx, qb, q0, nq, w.seg_slot, w.seg_cnt)) return 1;
+                if (launch_sd_filter(ctx, qb, q0, nh, w.seg_slot, w.seg_cnt)) return 1;
+                if (nh < nq) {  // the rest of the chunk has arrived meanwhile
+                    HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[2 * i + 1], 0));
+                    if (launch_sd_filter(ctx, qb, q0 + nh, nq - nh, w.seg_slot + nh * w.stride, w.seg_cnt + nh * (w.stride / 64))) return 1;
+                    ++launches;
+                }
+                HIP_TRY(ctx, hipEventRecord(e[5], front));
+                sd_filter_timed = true;
                 if (launch_sd_exact(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt, w.n_obs)) return 1;
             } else if (launch_scoredist_fused(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt, nullptr)) return 1;
             HIP_TRY(ctx, hipEventRecord(e[1], front));
@@ -1215,7 +1238,13 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
             if (fused_counts_format(ctx, qb))  // the matrix-core kernel writes only the non-empty segments' counts
                 HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (w.stride / 64) * sizeof(int32_t), front));
-            if (launch_counts_fused(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, w.seg_slot, w.seg_cnt)) return 1;
+            if (launch_counts_fused(ctx, qb, q0, nh, dist_tile_for(nq), w.dist, w.seg_slot, w.seg_cnt)) return 1;
+            if (nh < nq) {  // the rest of the chunk has arrived meanwhile (split_feed: the GEMM form, packed survivors in seg_slot alone)
+                HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[2 * i + 1], 0));
+                if (launch_counts_fused(ctx, qb, q0 + nh, nq - nh, dist_tile_for(nq), w.dist, w.seg_slot + nh * w.stride,
+                                        w.seg_cnt + nh * (w.stride / 64))) return 1;
+                ++launches;
+            }
             HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;
             SelectArgs sa = select_args_alignment(ctx, qb, q0);
@@ -1259,11 +1288,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         if (run_sweep(ctx, qb.out + q0, nq, back)) return 1;
         HIP_TRY(ctx, hipEventRecord(e[4], back));
         if (pipelined) HIP_TRY(ctx, hipEventRecord(ctx->ev_back[set], back));
-        if (feed && i + 1 < n_sub) {  // the next chunk travels while this sub-batch's kernels run
-            const int64_t q1 = (i + 1) * step;
-            if (fill_block(ctx, &qb, feed->host, q1, std::min(step, qb.n - q1), ctx->stream2)) return 1;
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_feed[i + 1], ctx->stream2));
-        }
+        if (feed && i + 1 < n_sub && feed_chunk(i + 1)) return 1;  // the next chunk travels while this sub-batch's kernels run
     }
     if (pipelined) {
         HIP_TRY(ctx, hipEventRecord(e_stop, back));
@@ -1277,6 +1302,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         hipEvent_t *e = &ev[(size_t)i * 6];
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e[0], e[1]); ctx->t_ms[APPLES_T_DIST] += ms;
+        if (sd_filter_timed) (void)hipEventElapsedTime(&ms, e[0], e[5]);
+        ctx->t_ms[APPLES_T_FILTER] += ms;
         (void)hipEventElapsedTime(&ms, e[1], e[2]); ctx->t_ms[APPLES_T_SELECT] += ms;
         (void)hipEventElapsedTime(&ms, e[3], e[4]); ctx->t_ms[APPLES_T_SWEEP] += ms;
     }
@@ -1293,6 +1320,9 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
 extern "C" {
 
 const char *apples_last_error(const apples_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+uint32_t apples_abi_version(void) { return APPLES_ABI_VERSION; }
+size_t apples_params_size(void) { return sizeof(apples_params); }
 
 int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, const apples_params *params, int device,
                       apples_ctx **out) {
@@ -1984,7 +2014,7 @@ int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n) {
 
 const char *apples_describe(apples_ctx *ctx) {
     hipDeviceProp_t prop;
-    char buf[1024];
+    char buf[1280];
     const char *name = "?";
     int cus = 0;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) { name = prop.name; cus = prop.multiProcessorCount; }
@@ -1993,7 +2023,8 @@ const char *apples_describe(apples_ctx *ctx) {
              "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"n_rows\": %lld, "
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
              "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\", "
-             "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld, \"sweep_layout\": \"%s\", \"cluster_fused\": %d}",
+             "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld, \"sweep_layout\": \"%s\", \"cluster_fused\": %d, "
+             "\"scoredist_filter\": %d, \"scoredist_image_bytes\": %lld}",
              name, cus, ctx->tree.n_nodes, ctx->tree.height, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
              (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
@@ -2007,7 +2038,10 @@ const char *apples_describe(apples_ctx *ctx) {
              ctx->tree.scan ? "scan" : (ctx->ws.small.lean || (ctx->ws.batch == 0 && sweep_lean_layout(ctx->tree, false))) ? "lean"
              : sweep_merge_lists(ctx->tree) ? "merge" : sweep_bits_in_lds(ctx->tree) ? "bits" : "map",
              // clustered references with the panels of the fast path (representatives for the matrix-core pass, members cluster-major)
-             (!a.all_singleton && a.rep_packed && a.packed_rm && ctx->params.model == APPLES_JC69 && !(ctx->dbg & APPLES_DBG_NO_FUSE)) ? 1 : 0);
+             (!a.all_singleton && a.rep_packed && a.packed_rm && ctx->params.model == APPLES_JC69 && !(ctx->dbg & APPLES_DBG_NO_FUSE)) ? 1 : 0,
+             // scoredist: the fused pass filters on the matrix cores (dist_sd.hip) at the present threshold
+             (ctx->params.model == APPLES_SCOREDIST && sd_gemm_usable(ctx) && !(ctx->dbg & APPLES_DBG_NO_FUSE)) ? 1 : 0,
+             (long long)(a.sd_ref4 ? a.slots_pad * (int64_t)sd_steps(a.L) * 64 : 0));
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

@@ -20,7 +20,7 @@ F_EXACT, F_INSUFFICIENT, F_MISPLACED, F_PENDANT_INT, F_ZERO_NOT_IN_TREE, F_DEGEN
 DBG = {'no_fuse': 1, 'sweep_scan': 2, 'node_map': 4, 'sweep_merge': 8, 'no_sweep_merge': 16, 'no_dist_gemm': 32, 'no_sweep_lean': 64,
        'no_sd_gemm': 128, 'cluster_by_query': 256, 'no_cluster_topup': 512, 'no_stream_select': 1024, 'no_topup_kernel': 2048,
        'no_cluster_big': 4096, 'no_sd_topup': 8192}
-T_PACK, T_DIST, T_SELECT, T_SWEEP, T_TOTAL, T_DIST_LAUNCHES, T_COUNT = range(7)
+T_PACK, T_DIST, T_SELECT, T_SWEEP, T_TOTAL, T_DIST_LAUNCHES, T_FILTER, T_COUNT = range(8)
 
 PLACEMENT_DTYPE = np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'), ('distal', '<f8'),
                             ('pendant', '<f8'), ('n_obs', '<i4'), ('n_valid', '<i4')], align=True)
@@ -29,7 +29,8 @@ EXPORTS = ['apples_ctx_create', 'apples_ctx_destroy', 'apples_last_error', 'appl
            'apples_place_from_sequences', 'apples_place_from_distances', 'apples_sweep_edges', 'apples_place_sequences_streamed',
            'apples_queries_upload', 'apples_table_upload', 'apples_queries_free', 'apples_place_resident', 'apples_fetch_placements',
            'apples_distances_resident', 'apples_placements_device_ptr', 'apples_last_timing', 'apples_describe',
-           'apples_backbone_lengths']
+           'apples_backbone_lengths', 'apples_abi_version', 'apples_params_size']
+ABI_VERSION = 4  # include/apples_hip.h APPLES_ABI_VERSION
 
 
 class _Tree(C.Structure):
@@ -86,6 +87,13 @@ def load_library():
     lib.apples_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.apples_backbone_lengths.argtypes = [C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_void_p]
+    # the mirror structs here must be the library's: a library built from another header is refused, not guessed at
+    lib.apples_abi_version.restype = C.c_uint32
+    lib.apples_params_size.restype = C.c_size_t
+    if lib.apples_abi_version() != ABI_VERSION or lib.apples_params_size() != C.sizeof(_Params):
+        raise RuntimeError('libapples_hip.so has ABI %d / apples_params of %d bytes; this engine.py expects %d / %d: rebuild '
+                           '(`python -m apples_amd.build --force`)' % (lib.apples_abi_version(), lib.apples_params_size(),
+                                                                        ABI_VERSION, C.sizeof(_Params)))
     _lib = lib
     return lib
 
@@ -245,7 +253,7 @@ class Engine:
         ms = np.zeros(T_COUNT)
         self.lib.apples_last_timing(self.ctx, _ptr(ms), T_COUNT)
         return {'pack_ms': ms[T_PACK], 'dist_ms': ms[T_DIST], 'select_ms': ms[T_SELECT], 'sweep_ms': ms[T_SWEEP],
-                'total_ms': ms[T_TOTAL], 'dist_launches': int(ms[T_DIST_LAUNCHES])}
+                'total_ms': ms[T_TOTAL], 'dist_launches': int(ms[T_DIST_LAUNCHES]), 'filter_ms': ms[T_FILTER]}
 
     def _queries(self, queries):
         """uint8[Q, L] with L = the reference alignment's length.  The reference fails loudly on a query

@@ -65,6 +65,8 @@ def rank_environment(rank, world, port, base=None):
     env = dict(os.environ if base is None else base)
     env.update({'RANK': str(rank), 'LOCAL_RANK': str(rank), 'WORLD_SIZE': str(world), 'LOCAL_WORLD_SIZE': str(world),
                 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
+                # names the job in the side channel's greeting (apples_amd/rccl.py): two jobs on one port pair stay apart
+                'APPLES_JOB_NONCE': env.get('APPLES_JOB_NONCE') or str((os.getpid() << 20) ^ (time.time_ns() & 0xfffffffffff)),
                 # dmabuf IPC: what the host driver supports (RCCL needs it between processes)
                 'HSA_ENABLE_IPC_MODE_LEGACY': env.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')})
     return env
@@ -84,9 +86,24 @@ def launch(n_ranks, script, argv, timeout=None, stdout=None, stderr=None):
         else [sys.executable, script]
     port = free_port()
     procs = []
+
+    # `timeout 600 python bench.py --gpus 8` and harness kills deliver SIGTERM / SIGHUP: without a handler the interpreter dies at
+    # once, the `finally` below never runs and the ranks stay behind holding their GPUs (blocked in a rendezvous or a
+    # collective).  The handlers turn the signal into an exception; the previous ones come back when launch() returns.
+    def _stop(signum, _frame):
+        raise SystemExit(128 + signum)
+
+    previous = {}
+    for sig in (signal.SIGTERM, signal.SIGHUP):
+        try:
+            previous[sig] = signal.signal(sig, _stop)
+        except (ValueError, OSError):  # not the main thread: the caller owns signal handling
+            pass
+    base = dict(os.environ)
+    base['APPLES_JOB_NONCE'] = rank_environment(0, n_ranks, port)['APPLES_JOB_NONCE']  # one nonce for every rank of the job
     try:
         for r in range(n_ranks):
-            procs.append(subprocess.Popen(cmd + list(argv), env=rank_environment(r, n_ranks, port),
+            procs.append(subprocess.Popen(cmd + list(argv), env=rank_environment(r, n_ranks, port, base),
                                           stdout=(stdout if r == 0 else (stderr or sys.stderr)), stderr=stderr))
         deadline = None if not timeout else time.time() + float(timeout)
         rc = 0
@@ -121,3 +138,5 @@ def launch(n_ranks, script, argv, timeout=None, stdout=None, stderr=None):
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
+        for sig, h in previous.items():
+            signal.signal(sig, h)

@@ -51,7 +51,9 @@ class SideChannel:
         self.peers = []   # rank 0: sockets of ranks 1..world-1, by rank
         self.sock = None  # other ranks: socket to rank 0
         self.blob = blob
-        hello = struct.pack('<8sii', b'APPLESRV', self.world, base)
+        # the greeting names the job: world size, base port and the launcher's nonce (APPLES_JOB_NONCE, apples_amd/launcher.py), so
+        # that two jobs sharing MASTER_PORT and world size do not take each other's ranks
+        hello = struct.pack('<8siiq', b'APPLESRV', self.world, base, int(os.environ.get('APPLES_JOB_NONCE', '0') or 0))
         if self.world == 1:
             return
         if self.rank == 0:
@@ -99,10 +101,11 @@ class SideChannel:
                         continue
                     try:
                         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                        s.settimeout(timeout)
+                        s.settimeout(3.0)  # a foreign listener that accepts and stays silent costs seconds, not the whole deadline
                         s.sendall(hello + struct.pack('<i', self.rank))
                         if self._recv(s, len(hello)) != hello:
                             raise RuntimeError('not rank 0 of this job')
+                        s.settimeout(timeout)  # ours: the blob may take as long as rank 0 needs to gather everybody
                         n = struct.unpack('<i', self._recv(s, 4))[0]
                         self.blob = self._recv(s, n) if n else b''
                         self.sock = s

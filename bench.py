@@ -226,7 +226,7 @@ def hbm_point(ref_seqs, queries, device, seconds=5.0, min_packed_bytes=1100 << 2
                            'for every query' % (info['packed_bytes'] >> 20)}
 
 
-def strong_scaling_proxy(eng, queries, ms_full, parts=8, reps=3):
+def strong_scaling_proxy(eng, queries, ms_full, parts=8, reps=3, device=0):
     """What a single GPU can say about BASELINE config 3's 1 -> 8 GPU curve: the `parts` contiguous shards of the one
     query set (apples_amd/distributed.py:shard_bounds, what rank r of an 8-GPU job places) timed one after the other,
     host buffer -> placements in host memory like the step itself.  The 8-GPU step ends when its slowest rank does
@@ -243,11 +243,33 @@ def strong_scaling_proxy(eng, queries, ms_full, parts=8, reps=3):
             dt = (time.perf_counter() - t0) * 1e3
             best = dt if best is None else min(best, dt)
         ms.append(best)
+    # the end-of-run gather as far as one GPU can measure it: the torch-free RCCL path (apples_amd/rccl.py, world size 1: a
+    # grouped ncclSend / ncclRecv to self + the copy to the host) on the whole job's 40-byte structs -- what rank 0 of an
+    # 8-GPU job receives and brings to the host; the other ranks' sends travel over seven xGMI links at once
+    gather_ms = None
+    try:
+        from apples_amd.rccl import Comm
+        h, n = eng.place_sequences_streamed(queries)
+        comm = Comm(0, 1, device)
+        g = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            comm.gather_to_host(eng.placements_device_ptr(h), [n * 40])
+            g.append((time.perf_counter() - t0) * 1e3)
+        comm.close()
+        eng.free_queries(h)
+        gather_ms = min(g)
+    except Exception as e:  # no librccl on this host: say so in the line
+        gather_note = 'gather not measured here: %s' % e
+    worst = max(ms) + (gather_ms or 0.0)
     return {'parts': parts, 'queries_per_shard': [b - a for a, b in shard_bounds(len(queries), parts)],
             'ms_shard': ms, 'ms_shard_max': max(ms), 'ms_shard_mean': float(np.mean(ms)), 'ms_full_set': ms_full,
-            'predicted_speedup_at_%d' % parts: ms_full / max(ms),
-            'note': 'shards of the one query set timed one by one on this GPU (best of %d, host buffer -> host); prediction = '
-                    'full-set step / slowest shard; the end-of-run gather (40 B per query) is not included' % reps}
+            'gather_ms': gather_ms,
+            'predicted_speedup_at_%d' % parts: ms_full / worst,
+            'note': 'A PREDICTION, not a measurement (this pool has one-GPU boxes): shards of the one query set timed one by one '
+                    'on this GPU (best of %d, host buffer -> host); predicted speed-up = full-set step / (slowest shard + gather_ms); '
+                    'gather_ms = %s' % (reps, 'world-1 RCCL self-gather of all %d placement structs + copy to the host, best of 5'
+                                        % len(queries) if gather_ms is not None else gather_note)}
 
 
 def clustered_leg(ds, nodes, queries, thr, method, device, steps=3):
@@ -278,6 +300,115 @@ def clustered_leg(ds, nodes, queries, thr, method, device, steps=3):
             'clustering_and_consensus_s': t_clusters,
             'note': 'same tree, reference and queries through max-diameter clusters at 1.2 x -f with consensus representatives '
                     '(the route run_apples.py takes by default); host buffer -> placements in host memory'}
+
+
+def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_step, placements, info, filter_ms=None):
+    """`roofline` of the dominant kernel (what bounds each kernel and its algorithmic bytes / operations
+    per unit): algorithmic work per launch / HIP-event time per launch."""
+    placed = placements['n_valid'] > 0
+    # algorithmic bytes per step (SURVEY 8d): distance N_rows*(L+8)+L per query; sweep 332*V per query
+    dist_bytes = nq * (rows * (L + 8) + L)
+    sweep_bytes = 332.0 * float(np.sum(placements['n_valid'][placed] + 1))
+    kernels = {'lsq_sweep': (sweep_bytes, per_step['sweep_ms'])}
+    if table:  # the -d filter reads every table value once
+        kernels['table_select'] = (nq * rows * 8.0, per_step['select_ms'])
+    else:
+        kernels['jc69_distance' if not protein else 'scoredist_distance'] = (dist_bytes, per_step['dist_ms'])
+    dom = max(kernels, key=lambda k: kernels[k][1])
+    n_launch = max(launches_per_step, 1)
+    achieved = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9 if kernels[dom][1] > 0 else 0.0
+    traffic, traffic_commit = load_traffic(workload, dom)
+    roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_measured_at_commit': traffic_commit,
+                'launches_per_step': n_launch, 'avg_launch_ms': kernels[dom][1] / n_launch,
+                'algorithmic_bytes_per_launch': kernels[dom][0] / n_launch,
+                'per_kernel_ms_per_step': per_step,
+                'all_kernels_GBps': {k: (v[0] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in kernels.items()}}
+    if dom == 'jc69_distance' and info.get('code_planes') == 2 and info.get('all_singleton') and \
+            not os.environ.get('APPLES_NO_DIST_MFMA') and not os.environ.get('APPLES_NO_FUSE'):
+        # the tiled pair counts run on the matrix cores (fp4 operands, 4 MACs per site and pair:
+        # DESIGN.md section 4): price them against the dense fp4 MFMA peak, 2 ops per MAC
+        ops = 2.0 * 4.0 * nq * rows * 32.0 * ((L + 31) // 32)
+        tops = ops / (kernels[dom][1] * 1e-3) / 1e12
+        roofline.update({'bound': 'mfma', 'achieved': tops, 'peak': MFMA_F4_PEAK_TOPS, 'unit': 'TFLOP/s',
+                         'frac': tops / MFMA_F4_PEAK_TOPS, 'algorithmic_ops_per_launch': ops / n_launch,
+                         'hbm_algorithmic_GBps': achieved})
+    elif dom == 'scoredist_distance' and info.get('scoredist_filter') and filter_ms:
+        # the fused scoredist pass = a lower bound of every pair's table sum on the matrix cores (fp4 operands, 20 values per
+        # site: dist_sd.hip) + the exact evaluation of the ~1 % of the pairs that survive it; the dominant kernel is the
+        # matrix-core filter: 2 x 20 L operations per pair in 128-value steps, priced against the dense fp4 peak
+        steps = (20 * L + 127) // 128
+        pad = (rows + 255) // 256 * 256
+        ops = 2.0 * nq * pad * steps * 128.0
+        tops = ops / (filter_ms * 1e-3) / 1e12
+        roofline.update({'bound': 'mfma', 'kernel': 'scoredist_filter_gemm', 'achieved': tops, 'peak': MFMA_F4_PEAK_TOPS, 'unit': 'TFLOP/s',
+                         'frac': tops / MFMA_F4_PEAK_TOPS, 'algorithmic_ops_per_launch': ops / n_launch,
+                         'avg_launch_ms': filter_ms / n_launch, 'hbm_algorithmic_GBps': achieved,
+                         'note': 'dist_ms = filter (filter_ms) + exact evaluation of its candidates; the table look-ups the '
+                                 'reference makes for every pair (8 B x 20 x L x pairs from LDS: the round-3 bound) are made for the candidates only'})
+        roofline['traffic'], roofline['traffic_measured_at_commit'] = load_traffic(workload, 'scoredist_filter_gemm')
+    elif dom == 'scoredist_distance':
+        # one 8-byte table read from LDS per site and pair (DESIGN.md section 4): the LDS read rate bounds it
+        lds = 8.0 * nq * rows * L / (kernels[dom][1] * 1e-3) / 1e9
+        roofline.update({'bound': 'lds', 'achieved': lds, 'peak': LDS_PEAK_GBS, 'frac': lds / LDS_PEAK_GBS,
+                         'hbm_algorithmic_GBps': achieved})
+    return roofline
+
+
+def other_workload(name, device, steps=3, ds=None):
+    """A compact leg of another BASELINE config for the driver's line: `steps` timed passes (host buffers -> placements in
+    host memory; config 5: the table block resident), per-kernel HIP-event times, the dominant kernel's roofline.  No CPU leg."""
+    from apples_amd import synth
+    from apples_amd.engine import Engine
+    n_leaves, L, Q, protein, method, thr = WORKLOADS[name]
+    table = name == 'c5'
+    if ds is None or table:
+        ds_ = synth.make_dataset(n_leaves, L if not table else 4, Q, protein=protein) if ds is None else ds
+    else:
+        ds_ = ds
+    nodes = np.array([ds_.tree.name_to_node[n] for n in ds_.ref_names], np.int32)
+    if table:
+        index = synth.TreeIndex(ds_.tree)
+        rs = np.random.default_rng(3)
+        q_leaf = rs.integers(0, n_leaves, size=Q)
+        q_pend = rs.exponential(0.01, size=Q)
+        D = synth.fast_distance_rows(ds_.tree, index, q_leaf, q_pend, list(range(Q)), seed_noise=7)
+        eng = Engine(ds_.tree, None, method=method, criterion='MLSE', threshold=thr, baseobs=25, device=device)
+        handle, _ = eng.upload_table(D, nodes)
+
+        def step():
+            eng.place_resident(handle)
+            return eng.fetch(handle, Q)
+    else:
+        eng = Engine(ds_.tree, ds_.ref_seqs, nodes, protein=protein, method=method, criterion='MLSE', threshold=thr, baseobs=25,
+                     overlap=0.001, device=device)
+        queries = np.ascontiguousarray(ds_.query_seqs[:Q])
+
+        def step():
+            return eng.place_sequences(queries)
+    try:
+        out = step()
+        ph = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0, 'filter_ms': 0.0}
+        launches = 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+            tm = eng.timing()
+            for k in ph:
+                ph[k] += tm[k]
+            launches += tm['dist_launches']
+        dt = (time.perf_counter() - t0) / steps
+        info = eng.describe()
+    finally:
+        eng.close()
+    per = {k: ph[k] / steps for k in ('dist_ms', 'select_ms', 'sweep_ms')}
+    rf = roofline_of(name, Q, n_leaves if table else info['n_rows'], L, protein, table, per, launches / steps, out, info,
+                     filter_ms=ph['filter_ms'] / steps)
+    return {'value': Q / dt, 'unit': 'queries/s', 'ms_per_step': dt * 1e3, 'steps': steps, 'queries': Q,
+            'timed': 'table block resident -> placements in host memory' if table else 'host byte arrays -> placements in host memory',
+            'per_kernel_ms_per_step': per,
+            'roofline': {k: rf[k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'traffic') if k in rf},
+            'mean_observed': float(np.mean(out['n_obs'])), 'placed': int((out['n_valid'] > 0).sum())}
 
 
 def load_traffic(workload, kernel):
@@ -439,7 +570,7 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    phases = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0}
+    phases = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0, 'filter_ms': 0.0}
     launches = 0
     out = None
     for _ in range(args.steps):
@@ -487,46 +618,16 @@ def main():
         rows = eng.n_rows if not table else n_leaves
         placed = mine['n_valid'] > 0
         mean_v = float(np.mean(mine['n_valid'][placed] + 1)) if placed.any() else 0.0
-        per_step = {k: v / args.steps for k, v in phases.items()}
-        # algorithmic bytes per step: distance N_rows*(L+8)+L per query; sweep 332*V per query
-        dist_bytes = nq * (rows * (L + 8) + L)
-        sweep_bytes = 332.0 * float(np.sum(mine['n_valid'][placed] + 1))
-        kernels = {'lsq_sweep': (sweep_bytes, per_step['sweep_ms'])}
-        if table:  # the -d filter reads every table value once
-            kernels['table_select'] = (nq * rows * 8.0, per_step['select_ms'])
-        else:
-            kernels['jc69_distance' if not protein else 'scoredist_distance'] = (dist_bytes, per_step['dist_ms'])
-        dom = max(kernels, key=lambda k: kernels[k][1])
-        n_launch = max(launches / args.steps, 1)
-        achieved = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9 if kernels[dom][1] > 0 else 0.0
-        traffic, traffic_commit = load_traffic(args.workload, dom)
-        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_measured_at_commit': traffic_commit,
-                    'launches_per_step': n_launch, 'avg_launch_ms': kernels[dom][1] / n_launch,
-                    'algorithmic_bytes_per_launch': kernels[dom][0] / n_launch,
-                    'per_kernel_ms_per_step': per_step,
-                    'all_kernels_GBps': {k: (v[0] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in kernels.items()}}
+        per_step = {k: v / args.steps for k, v in phases.items() if k != 'filter_ms'}
         info = eng.describe()
-        if dom == 'jc69_distance' and info.get('code_planes') == 2 and info.get('all_singleton') and \
-                not os.environ.get('APPLES_NO_DIST_MFMA') and not os.environ.get('APPLES_NO_FUSE'):
-            # the tiled pair counts run on the matrix cores (fp4 operands, 4 MACs per site and pair:
-            # DESIGN.md section 4): price them against the dense fp4 MFMA peak, 2 ops per MAC
-            ops = 2.0 * 4.0 * nq * rows * 32.0 * ((L + 31) // 32)
-            tops = ops / (kernels[dom][1] * 1e-3) / 1e12
-            roofline.update({'bound': 'mfma', 'achieved': tops, 'peak': MFMA_F4_PEAK_TOPS, 'unit': 'TFLOP/s',
-                             'frac': tops / MFMA_F4_PEAK_TOPS, 'algorithmic_ops_per_launch': ops / n_launch,
-                             'hbm_algorithmic_GBps': achieved})
-        elif dom == 'scoredist_distance':
-            # one 8-byte table read from LDS per site and pair: the LDS read rate bounds it
-            lds = 8.0 * nq * rows * L / (kernels[dom][1] * 1e-3) / 1e9
-            roofline.update({'bound': 'lds', 'achieved': lds, 'peak': LDS_PEAK_GBS, 'frac': lds / LDS_PEAK_GBS,
-                             'hbm_algorithmic_GBps': achieved})
+        roofline = roofline_of(args.workload, nq, rows, L, protein, table, per_step, launches / args.steps, mine, info,
+                               filter_ms=phases['filter_ms'] / args.steps)
         stream = proxy = None
         if world == 1 and not table and not protein and not clustered:
             stream = distance_stream_point(eng, ds, L)
         extras = world == 1 and not args.no_extras and not use_dist
         if extras and args.workload == 'c3':
-            proxy = strong_scaling_proxy(eng, queries, ms_per_step)
+            proxy = strong_scaling_proxy(eng, queries, ms_per_step, device=local_rank)
         cpu = None
         if world == 1 and not args.no_cpu and not clustered:
             cpu = cpu_baseline_table(ds, D, method, thr) if table else cpu_baseline(ds, protein, method, thr)
@@ -566,6 +667,10 @@ def main():
             line['clustered'] = clustered_leg(ds, nodes, queries, thr, method, local_rank)
         if extras and not table and not protein:
             line['roofline_hbm_point'] = hbm_point(ds.ref_seqs, queries, local_rank)
+        if extras and args.workload == 'c3':
+            # the other BASELINE configs, so that the driver's own run sees them (config 5 on config 3's tree: the same backbone)
+            line['other_workloads'] = {'c2': other_workload('c2', local_rank), 'c4': other_workload('c4', local_rank),
+                                       'c5': other_workload('c5', local_rank, ds=ds)}
         final_line = json.dumps(line)
     if comm is not None:
         comm.barrier()

@@ -120,6 +120,15 @@ typedef struct {
                                          reference raises KeyError (PoolQueryWorker.py:74) */
 #define APPLES_F_DEGENERATE  32u  /* >=3 distances but fewer than two of them on tree leaves */
 
+/* ABI of this header: bumped whenever a struct above grows or an entry point changes (4 = apples_params.debug with the
+ * switches up to APPLES_DBG_ALL).  apples_params has no size field: a caller must zero-initialise it (memset / = {0}) and
+ * be built against the header of the library it loads -- check apples_abi_version() == APPLES_ABI_VERSION and
+ * apples_params_size() == sizeof(apples_params) once at start-up, as apples_amd/engine.py does.  Bits of `debug` beyond
+ * APPLES_DBG_ALL are ignored. */
+#define APPLES_ABI_VERSION 4u
+uint32_t apples_abi_version(void);
+size_t apples_params_size(void);
+
 /* Build a context on HIP device `device`: uploads the tree, packs the alignment into the
  * bit-plane layout, allocates workspaces.  `aln` may be NULL for a distance-table-only context
  * (run_apples.py -d).  Replaces prepareTree + ReducedReference construction state that
@@ -194,7 +203,10 @@ int apples_distances_resident(apples_ctx *ctx, int64_t handle, int32_t query_til
 /* Per-kernel device time of the most recent apples_place_* / apples_distances* call, measured
  * with HIP events on the context's stream.  ms[APPLES_T_*]; n = number of entries filled. */
 enum { APPLES_T_PACK = 0, APPLES_T_DIST = 1, APPLES_T_SELECT = 2, APPLES_T_SWEEP = 3, APPLES_T_TOTAL = 4,
-       APPLES_T_DIST_LAUNCHES = 5, APPLES_T_COUNT = 6 };
+       APPLES_T_DIST_LAUNCHES = 5,
+       APPLES_T_FILTER = 6, /* the part of APPLES_T_DIST spent in the matrix-core pass proper (scoredist: the lower-bound filter,
+                               before the exact evaluation of its candidates; otherwise equal to APPLES_T_DIST) */
+       APPLES_T_COUNT = 7 };
 int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n);
 
 /* Introspection: device name, packed layout, workspace sizes (JSON text, owned by ctx). */

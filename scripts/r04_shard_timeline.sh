@@ -9,12 +9,16 @@ import csv, glob, re, json
 k = glob.glob("/tmp/tl_trace/*/*kernel_trace.csv")[0]
 rows = [("K", re.search(r"(k_[a-zA-Z0-9_]+|__amd_rocclr_[a-zA-Z]+)", r["Kernel_Name"]).group(1) if re.search(r"(k_[a-zA-Z0-9_]+|__amd_rocclr_[a-zA-Z]+)", r["Kernel_Name"]) else r["Kernel_Name"][:30], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(k))]
 for m in glob.glob("/tmp/tl_trace/*/*memory_copy_trace.csv"):
-    for r in csv.DictReader(open(m)):
-        rows.append(("C", r.get("Direction", "copy") + " " + r.get("Size", ""), int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    rd = csv.DictReader(open(m))
+    print("copy trace columns:", rd.fieldnames)
+    for r in rd:
+        size = next((r[c] for c in r if "ize" in c or "ytes" in c), "")
+        rows.append(("C", (r.get("Direction") or r.get("Kind") or "copy") + " " + str(size), int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 rows.sort(key=lambda r: r[2])
-# the last step: from the last host-to-device copy of query bytes (12.5 MB) on
+# the steps: from every host-to-device copy of the query bytes (12.5 MB) on
 big = [i for i, r in enumerate(rows) if r[0] == "C" and "12500000" in r[1]]
-i0 = big[-4] if len(big) >= 4 else big[-1]   # the resident leg re-uploads: take the last step of the timed loop heuristically
+if not big:
+    big = [i for i, r in enumerate(rows) if "k_pack_rows" in r[1]]
 d = json.load(open("/tmp/tl_bench.json"))
 print("bench ms_per_step", d["ms_per_step"], "resident", d["resident"]["ms_per_step"], d["resident"]["per_kernel_ms_per_step"])
 for s in big[-6:]:

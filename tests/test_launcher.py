@@ -16,6 +16,9 @@ if mode == 'fail' and rank == 1:
     sys.exit(7)
 if mode == 'fail' and rank != 1:
     time.sleep(60)       # must be stopped by the launcher, not run to its end
+if mode == 'hang':
+    open(os.environ['STUB_PIDS'], 'a').write('%d\n' % os.getpid())
+    time.sleep(120)      # the launcher is terminated from outside: its ranks must go with it
 print(json.dumps({'rank': rank, 'local_rank': int(os.environ['LOCAL_RANK']), 'world': int(os.environ['WORLD_SIZE']),
                   'addr': os.environ['MASTER_ADDR'], 'port': int(os.environ['MASTER_PORT']), 'argv': sys.argv[1:],
                   'ipc': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}), flush=True)
@@ -61,6 +64,35 @@ def test_launcher_failed_rank_stops_the_others(tmp_path):
     assert r.returncode == 7
     assert 'rank 1 ended with status 7' in r.stderr
     assert time.time() - t0 < 30
+
+
+def test_terminating_the_launcher_takes_the_ranks_down(tmp_path):
+    """`timeout N python bench.py --gpus 8` ends the parent with SIGTERM: the ranks must not stay behind with their GPUs."""
+    import signal
+    import time
+    stub = tmp_path / 'stub_rank.py'
+    stub.write_text(STUB)
+    pids = tmp_path / 'pids'
+    env = dict(os.environ)
+    env.pop('RANK', None)
+    env.pop('WORLD_SIZE', None)
+    env.update({'APPLES_LAUNCH_DEVICE_COUNT': '3', 'APPLES_LAUNCH_RANK_CMD': json.dumps([sys.executable, str(stub)]),
+                'STUB_MODE': 'hang', 'STUB_PIDS': str(pids)})
+    p = subprocess.Popen([sys.executable, BENCH, '--gpus', '3'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t0 = time.time()
+    while time.time() - t0 < 60 and (not pids.exists() or len(pids.read_text().split()) < 3):
+        time.sleep(0.1)
+    ranks = [int(x) for x in pids.read_text().split()]
+    assert len(ranks) == 3
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=30)
+    assert p.returncode == 128 + signal.SIGTERM
+    t1 = time.time()
+    alive = ranks
+    while alive and time.time() - t1 < 15:
+        alive = [r for r in alive if os.path.exists('/proc/%d' % r) and open('/proc/%d/stat' % r).read().split()[2] != 'Z']
+        time.sleep(0.1)
+    assert not alive, 'ranks left behind: %s' % alive
 
 
 def test_defaults_strong_for_c3_and_torch_free_gather():
