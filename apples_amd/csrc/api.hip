@@ -643,6 +643,13 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         int64_t b = want_batch;
         if (ctx->params.max_batch > 0) b = std::min(b, (int64_t)ctx->params.max_batch);
         b = std::min(b, capq);
+        if (sweep_lean_layout(t, need_xe || w.big.xe != nullptr)) {
+            // sweep_lean.hip's pool cursor is a 32-bit counter that every query of the batch adds its share to, whether the pool
+            // still has room or not: the batch's requests together must stay below 2^32 (the largest share: lean_query_cap of
+            // the routing threshold, 3 n + 1 027 entries; 167 000 queries at the default threshold)
+            const int64_t share = 3 * std::min<int64_t>(std::max<int64_t>(members, w.obs_cap), big_threshold(ctx)) + 1028;
+            b = std::min<int64_t>(b, (int64_t)(0xffffffffll / share) / 32 * 32 - 32);
+        }
         return round_up(std::max<int64_t>(b, 1), 32);
     };
     batch = size_batch();

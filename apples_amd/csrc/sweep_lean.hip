@@ -503,13 +503,11 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh) {
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
         // the query's share of the pool (one atomic add per query); out of pool = the workgroup-sized teams take it
         const int qcap = lean_query_cap(n);
-        // (a pool that has run dry is not asked again: the cursor then stays within the pool's size plus what the teams in
-        // flight added at once, far from wrapping a 32-bit counter however many queries the batch holds)
+        // (32-bit cursor: ensure_workspace keeps batch x the largest share below 2^32, so the sum of every query's request cannot
+        // wrap it; asking the cursor first -- a load of the one line every team's atomic add goes to -- doubled the sweep's time
+        // at 50 000 queries per batch)
         unsigned int off0 = 0;
-        if (lane == 0) {
-            const unsigned int cur = __hip_atomic_load(a.pool_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            off0 = (int64_t)cur + qcap > a.lean_cap1 ? 0xffffffffu : atomicAdd(a.pool_cursor, (unsigned int)qcap);
-        }
+        if (lane == 0) off0 = atomicAdd(a.pool_cursor, (unsigned int)qcap);
         const int64_t off = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)off0);
         int32_t *grp_off = a.grp_off + q * (int64_t)(T.height + 4);
         if (off + qcap > a.lean_cap1) {

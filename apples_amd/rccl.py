@@ -149,6 +149,25 @@ class SideChannel:
             self.sock = None
 
 
+class _StdoutToStderr:
+    """While active, file descriptor 1 points at file descriptor 2: the collective library writes a version banner to the C
+    stdout when a communicator comes up, and a caller whose stdout is ONE JSON line (bench.py) must not carry it."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 class Comm:
     """One RCCL communicator over the ranks of one node + the TCP side channel through rank 0."""
 
@@ -173,7 +192,8 @@ class Comm:
                 raise RuntimeError('rendezvous delivered %d bytes in place of the 128-byte communicator id' % len(self.side.blob))
             C.memmove(C.byref(uid), self.side.blob, 128)
         self.comm = C.c_void_p()
-        self._check(self.nccl.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        with _StdoutToStderr():
+            self._check(self.nccl.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
         self._recv_buf = C.c_void_p()
         self._recv_cap = 0
 
