@@ -516,6 +516,18 @@ int big_threshold(const apples_ctx *ctx) {
     return ctx->tree.scan ? std::min(v, SCAN_LDS_LEAVES_SMALL) : v;
 }
 
+// ... for the device batch under way: a small batch (a shard of a multi-GPU job, a -d block) routes from half the count.  Its
+// wavefront-sized teams have three or four queries each, so their kernels' time is the longest query's, and a query of 8 000
+// observed leaves takes a wavefront about four times as long as a workgroup-sized team (measured at config 3, host -> host:
+// 12 500 queries 7.15 -> 6.80 ms, sweep 2.40 -> 2.11; the full 100 000, in batches of 25 000, 48.7 -> 49.1: the cut stays where
+// it was there).  Never above the count the workspace was sized with.
+int route_threshold(const apples_ctx *ctx) {
+    const int v = big_threshold(ctx);
+    static const bool fixed = getenv("APPLES_BIG_THRESHOLD") != nullptr;  // (the knob fixes the cut for every batch size)
+    if (fixed || ctx->tree.scan || v != LEAN_BIG_THRESHOLD) return v;
+    return ctx->cur_batch_queries > 0 && ctx->cur_batch_queries <= 16384 ? v / 2 : v;
+}
+
 void free_sweep(Workspace::Sweep &sw) {
     dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.ent); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
     dev_free(sw.ent_f); dev_free(sw.ent_i); dev_free(sw.leaf_g); dev_free(sw.meta); dev_free(sw.lean); dev_free(sw.lean_leaf); dev_free(sw.lean_meta);
@@ -877,7 +889,7 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.n_obs = w.n_obs;
     s.cnt_gt = ctx->tree.scan ? nullptr : w.cnt_gt;  // (the scan sweep takes its leaves in node-id order and needs no per-level offsets)
     s.out = qb.out + q0;
-    s.big_threshold = big_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+    s.big_threshold = route_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
     s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;  // (what run_sweep's launch_big will run)
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     s.seg_slot = w.seg_slot; s.seg_cnt = w.seg_cnt; s.node_level = ctx->tree.level;
@@ -906,7 +918,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
     static const int dbg = getenv("APPLES_SWEEP_DEBUG_PHASE") ? atoi(getenv("APPLES_SWEEP_DEBUG_PHASE")) : 0;
     s.debug_phase = dbg;
-    s.work_list = nullptr; s.work_count = nullptr; s.big_threshold = big_threshold(ctx);
+    s.work_list = nullptr; s.work_count = nullptr; s.big_threshold = route_threshold(ctx);
     s.cls_list = nullptr; s.cls_count = nullptr; s.cls_stride = w.batch; s.cursor = w.cls_count + 4;
     s.overflow_list = w.overflow_list; s.overflow_count = w.overflow_count;
     s.out = out;
@@ -1137,6 +1149,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         if (pipelined && i > 0) swap_bufs(w);  // host view: w.* now names buffer set `set`
         if (pipelined && i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_back[set], 0));  // set free again
         hipEvent_t *e = &ev[(size_t)i * 6];
+        ctx->cur_batch_queries = nq;  // (route_threshold)
         const int64_t nh = feed ? head(nq) : nq;  // rows of the chunk's first piece
         if (feed) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[2 * i + (nh < nq ? 0 : 1)], 0));  // chunk i (its first piece) is on the device
         HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), front));  // every counter of the batch
@@ -1747,6 +1760,7 @@ static int setup_columns(apples_ctx *ctx, int64_t n_cols, const int32_t *col_nod
 static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, int64_t n_cols, const int32_t *d_self,
                            apples_placement *d_out, PhaseTimer &pt) {
     Workspace &w = ctx->ws;
+    ctx->cur_batch_queries = nq;  // (route_threshold)
     SelectArgs s{};
     s.dist = d_rows; s.stride = n_cols; s.gather = nullptr;  // rows were permuted into slot order
     s.slot_node = ctx->d_col_node; s.slot_level = ctx->d_col_level; s.slot_rep = ctx->d_col_perm;
@@ -1757,7 +1771,7 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.n_obs = w.n_obs;
     s.cnt_gt = ctx->tree.scan ? nullptr : w.cnt_gt;
     s.out = d_out;
-    s.big_threshold = big_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
+    s.big_threshold = route_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
     s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), ctx->stream));  // every counter of the batch

@@ -248,6 +248,7 @@ struct apples_ctx {
     int64_t jc_lut_len = 0;
     GemmThreshold gemm_thr;
     int n_cu = 0;  // compute units of the device (dist_gemm.hip's persistent grid)
+    int64_t cur_batch_queries = 0;  // queries of the device batch under way (api.hip:route_threshold)
     int32_t *jc_mmax = nullptr;  // [L+1] largest mismatch count with 0 <= lut <= threshold, per valid count
     double *blosum = nullptr;  // 21x21 table (row/col 20 = gap -> 0)
     uint8_t *sd_tq4 = nullptr; // [20][20] fp4 codes of the table rounded down to the grid {0, .5, 1, 1.5, 2, 3, 4, 6} / 4 (dist_sd.hip)

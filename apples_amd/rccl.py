@@ -196,6 +196,10 @@ class Comm:
             self._check(self.nccl.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
         self._recv_buf = C.c_void_p()
         self._recv_cap = 0
+        self._host = C.c_void_p()
+        self._host_cap = 0
+        self.hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+        self.hip.hipHostFree.argtypes = [C.c_void_p]
 
     # ------------------------------------------------------------------ helpers
     def _check(self, rc, what):
@@ -218,7 +222,8 @@ class Comm:
     # ------------------------------------------------------------------ the gather
     def gather_to_host(self, dev_ptr, sizes):
         """dev_ptr: this rank's device buffer of sizes[rank] bytes.  One grouped send/recv to rank 0, which
-        returns the concatenation (in rank order) as bytes; the other ranks return None."""
+        returns the concatenation (in rank order) as a bytes-like view of the communicator's page-locked buffer (valid
+        until the next gather; `bytes(view)` copies); the other ranks return None."""
         total = int(sum(sizes))
         if self.rank == 0 and total > self._recv_cap:
             if self._recv_buf:
@@ -238,9 +243,16 @@ class Comm:
         self._check_hip(self.hip.hipDeviceSynchronize(), 'hipDeviceSynchronize')
         if self.rank != 0:
             return None
-        host = C.create_string_buffer(max(total, 1))
-        self._check_hip(self.hip.hipMemcpy(host, self._recv_buf, total, 2), 'hipMemcpy')  # 2 = device to host
-        return host.raw[:total]
+        # into a page-locked buffer that lives with the communicator (a pageable destination is staged through the driver's own
+        # bounce buffer: 4 MB took 0.26 ms in place of 0.08); the caller gets a view of it, valid until the next gather
+        if total > self._host_cap:
+            if self._host:
+                self.hip.hipHostFree(self._host)
+            self._host = C.c_void_p()
+            self._check_hip(self.hip.hipHostMalloc(C.byref(self._host), max(total, 1), 0), 'hipHostMalloc')
+            self._host_cap = total
+        self._check_hip(self.hip.hipMemcpy(self._host, self._recv_buf, total, 2), 'hipMemcpy')  # 2 = device to host
+        return memoryview((C.c_char * total).from_address(self._host.value)).cast('B') if total else memoryview(b'')
 
     def close(self):
         if getattr(self, 'comm', None):
@@ -249,4 +261,8 @@ class Comm:
         if self._recv_buf:
             self.hip.hipFree(self._recv_buf)
             self._recv_buf = C.c_void_p()
+        if self._host:
+            self.hip.hipHostFree(self._host)
+            self._host = C.c_void_p()
+            self._host_cap = 0
         self.side.close()

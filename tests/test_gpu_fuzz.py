@@ -129,10 +129,18 @@ def test_scoredist_routes_agree(seed):
             co = COracle(d.tree, d.ref_seqs, nodes, protein=True, method=m, criterion='MLSE', threshold=thr, baseobs=b, threads=NTHREADS)
             want = co.place_sequences(q)
             got = out['default']
-            for f in ('edge', 'flags', 'n_obs', 'n_valid'):
+            for f in ('n_obs', 'n_valid'):
                 assert np.array_equal(got[f], want[f]), '%s: %s differs from the C oracle' % (tag, f)
+            # the distances carry the device's log, the oracle's libm's: one unit in the last place apart now and then, which
+            # decides between edges whose residuals are mathematically equal (edges meeting at a node, a pendant of zero: SURVEY
+            # H1).  Such a row is accepted when the two residuals agree to 1e-9; there must be few of them
+            same = got['edge'] == want['edge']
+            tie = ~same
+            assert tie.sum() <= max(1, len(got) // 50), '%s: %d edges differ from the C oracle' % (tag, tie.sum())
+            np.testing.assert_allclose(got['error'][tie], want['error'][tie], rtol=1e-9, atol=1e-15, err_msg='%s: tied rows' % tag)
+            assert np.array_equal(got['flags'][same], want['flags'][same]), '%s: flags' % tag
             for f in ('error', 'distal', 'pendant'):
-                np.testing.assert_allclose(got[f], want[f], rtol=1e-9, atol=1e-15, err_msg='%s: %s' % (tag, f))
+                np.testing.assert_allclose(got[f][same], want[f][same], rtol=1e-9, atol=1e-15, err_msg='%s: %s' % (tag, f))
             checked += 1
     assert checked >= 5
 
