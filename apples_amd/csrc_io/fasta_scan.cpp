@@ -1,5 +1,9 @@
 // FASTA/FASTQ scanner behind include/apples_io.h (reader semantics of apples/fasta2dic.py:4-39).
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "apples_io.h"
 
@@ -85,4 +89,111 @@ extern "C" int apples_fasta_scan(const uint8_t *data, int64_t n_bytes, const uin
     }
     *n_records = rec;
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same for the common shape -- plain FASTA, "\n" line ends -- in one threaded pass over the file image (at
+// 200 000 x 1 000 the line-by-line scanner above, run twice for the count and the fill, took 0.7 s; the whole GPU pass over the
+// file's 100 000 queries takes 0.05 s).  Phase 1, by byte ranges: the offsets of the record headers = '>' at a line start
+// (memchr for the line ends); anything the reader above treats specially -- a '\r', a line starting with '@' or '+' -- makes
+// the caller take the general scanner.  Phase 2, by record ranges: name ranges, and the sequence lines copied through the
+// translation table straight into their rows (memchr per line, 16 bytes of table look-ups per unrolled round).
+// Returns 0; 3 = not the plain shape (nothing written that the caller may use); 1 / 2 as apples_fasta_scan.  *length is taken
+// from the first record.  rows == NULL: records and length only.
+extern "C" int apples_fasta_scan_mt(const uint8_t *data, int64_t n_bytes, const uint8_t *translate, uint8_t *rows, int64_t n_rows,
+                                    int64_t *n_records, int64_t *length, int64_t *name_off, int32_t *name_len,
+                                    int64_t *bad_record, int64_t *bad_length, int32_t n_threads) {
+    if (n_bytes <= 0) { *n_records = 0; return 0; }
+    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    T = std::max(1, std::min(T, 64));
+    if (n_bytes < (1 << 20)) T = 1;
+    // phase 1: header offsets per byte range (a line start = offset 0 or the byte after a '\n')
+    std::vector<std::vector<int64_t>> starts(T);
+    std::atomic<int> odd{0};
+    auto index = [&](int t) {
+        const int64_t lo = n_bytes * t / T, hi = n_bytes * (t + 1) / T;
+        std::vector<int64_t> &out = starts[t];
+        if (memchr(data + lo, '\r', (size_t)(hi - lo))) { odd = 1; return; }
+        int64_t p = lo;
+        if (p > 0) {  // first line start inside the range
+            const uint8_t *q = (const uint8_t *)memchr(data + p - 1, '\n', (size_t)(hi - p + 1));
+            if (!q) return;
+            p = (q - data) + 1;
+        }
+        while (p < hi) {
+            const uint8_t c = data[p];
+            if (c == '>') out.push_back(p);
+            else if (c == '@' || c == '+') { odd = 1; return; }
+            const uint8_t *q = (const uint8_t *)memchr(data + p, '\n', (size_t)(n_bytes - p));
+            if (!q) break;
+            p = (q - data) + 1;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(index, t);
+        index(0);
+        for (auto &x : th) x.join();
+    }
+    if (odd) return 3;
+    // (a lone '>' as the file's unterminated last line ends a sequence but opens no record: the reader's `l[:-1]` leaves nothing of it)
+    if (data[n_bytes - 1] == '>' && (n_bytes == 1 || data[n_bytes - 2] == '\n')) return 3;
+    std::vector<int64_t> rec;
+    for (auto &v : starts) rec.insert(rec.end(), v.begin(), v.end());
+    const int64_t n = (int64_t)rec.size();
+    *n_records = n;
+    if (n == 0) return 0;
+    rec.push_back(n_bytes);
+    // sequence length of one record (lines lose their last byte: the '\n', or the last character of an unterminated last line)
+    auto walk = [&](int64_t r, uint8_t *row, int64_t L, int64_t *noff, int32_t *nlen) -> int64_t {
+        const uint8_t *p = data + rec[r], *end = data + rec[r + 1];
+        const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+        const uint8_t *he = q ? q : (end > p ? end - 1 : end);  // header line without its last byte
+        if (noff) {
+            const uint8_t *nb = p + 1, *ne = nb;
+            while (ne < he && *ne != ' ') ++ne;
+            if (nb > he) nb = ne = he;
+            *noff = nb - data;
+            *nlen = (int32_t)(ne - nb);
+        }
+        int64_t len = 0;
+        p = q ? q + 1 : end;
+        while (p < end) {
+            q = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+            const uint8_t *le = q ? q : end - 1;
+            const int64_t k = le - p;
+            if (row && len + k <= L) {
+                uint8_t *d = row + len;
+                int64_t i = 0;
+                for (; i + 16 <= k; i += 16)
+                    for (int j = 0; j < 16; ++j) d[i + j] = translate[p[i + j]];
+                for (; i < k; ++i) d[i] = translate[p[i]];
+            }
+            len += k;
+            p = q ? q + 1 : end;
+        }
+        return len;
+    };
+    const int64_t L = walk(0, nullptr, 0, nullptr, nullptr);
+    *length = L;
+    if (!rows) return 0;
+    if (n > n_rows) return 2;
+    std::atomic<int64_t> first_bad{n};
+    std::vector<int64_t> bad_len(T, 0), bad_at(T, n);
+    auto fill = [&](int t) {
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        for (int64_t r = lo; r < hi; ++r) {
+            const int64_t len = walk(r, rows + r * L, L, name_off + r, name_len + r);
+            if (len != L && bad_at[t] == n) { bad_at[t] = r; bad_len[t] = len; }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(fill, t);
+        fill(0);
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < T; ++t)
+        if (bad_at[t] < n) { *bad_record = bad_at[t]; *bad_length = bad_len[t]; return 1; }
+    return 0;
 }

@@ -12,6 +12,8 @@ Instead of ``{name: ndarray('S1')}`` the build keeps one dense ``uint8[N, L]``
 matrix plus a name list (dict semantics: a repeated name keeps its first
 position and the last sequence).
 """
+import os
+
 import numpy as np
 
 
@@ -130,6 +132,9 @@ def _load_io():
             lib.apples_fasta_scan.restype = ctypes.c_int
             lib.apples_fasta_scan.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                               ctypes.c_int64] + [ctypes.c_void_p] * 6
+            if hasattr(lib, 'apples_fasta_scan_mt'):
+                lib.apples_fasta_scan_mt.restype = ctypes.c_int
+                lib.apples_fasta_scan_mt.argtypes = lib.apples_fasta_scan.argtypes + [ctypes.c_int32]
             if hasattr(lib, 'apples_newick_scan'):
                 lib.apples_newick_scan.restype = ctypes.c_int
                 lib.apples_newick_scan.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64] + \
@@ -159,16 +164,27 @@ def read_alignment(path, prot_flag, mask_flag):
     bad = ctypes.c_int64(-1)
     bad_len = ctypes.c_int64(0)
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    lib.apples_fasta_scan(ptr(data), data.size, ptr(tab), None, 0, ctypes.byref(n_rec), ctypes.byref(length),
-                          None, None, ctypes.byref(bad), ctypes.byref(bad_len))
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else 0
+
+    def scan(rows, n_rows, off, ln):
+        # plain FASTA with "\n" line ends: the threaded scanner; anything else (FASTQ, "\r", ...): the general one
+        rc = 3
+        if hasattr(lib, 'apples_fasta_scan_mt'):
+            rc = lib.apples_fasta_scan_mt(ptr(data), data.size, ptr(tab), rows, n_rows, ctypes.byref(n_rec), ctypes.byref(length),
+                                          off, ln, ctypes.byref(bad), ctypes.byref(bad_len), min(threads, 32))
+        if rc == 3:
+            rc = lib.apples_fasta_scan(ptr(data), data.size, ptr(tab), rows, n_rows, ctypes.byref(n_rec), ctypes.byref(length),
+                                       off, ln, ctypes.byref(bad), ctypes.byref(bad_len))
+        return rc
+
+    scan(None, 0, None, None)
     n, L = n_rec.value, length.value
     if n == 0:
         return Alignment([], np.zeros((0, 0), dtype=np.uint8))
     mat = np.empty((n, L), dtype=np.uint8)
     off = np.empty(n, dtype=np.int64)
     ln = np.empty(n, dtype=np.int32)
-    rc = lib.apples_fasta_scan(ptr(data), data.size, ptr(tab), ptr(mat), n, ctypes.byref(n_rec), ctypes.byref(length),
-                               ptr(off), ptr(ln), ctypes.byref(bad), ctypes.byref(bad_len))
+    rc = scan(ptr(mat), n, ptr(off), ptr(ln))
     raw = data.tobytes() if n < 64 else memoryview(data)
     names = [bytes(raw[o:o + k]).decode() for o, k in zip(off.tolist(), ln.tolist())]
     if rc != 0 or len(set(names)) != n:

@@ -212,8 +212,50 @@ def _len_str(x):
     return str(float(x))
 
 
+def _extended_newick_native(tree):
+    """The same through libapples_io.so (apples_extended_newick), or None: library missing, labels that are not plain strings."""
+    from .fasta import _load_io
+    lib = _load_io()
+    if lib is None or not hasattr(lib, 'apples_extended_newick'):
+        return None
+    import ctypes
+    n = tree.n_nodes
+    labs = tree.labels
+    try:
+        parts = [b'' if x is None else x.encode() for x in labs]
+    except AttributeError:
+        return None
+    llen = np.fromiter((-1 if x is None else len(b) for x, b in zip(labs, parts)), dtype=np.int32, count=n)
+    loff = np.zeros(n, dtype=np.int64)
+    np.cumsum(np.maximum(llen[:-1], 0), out=loff[1:])
+    blob = b''.join(parts)
+    cap = 64 + 40 * n + len(blob)
+    out = ctypes.create_string_buffer(cap)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.apples_extended_newick.restype = ctypes.c_int64
+    lib.apples_extended_newick.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p,
+                                           ctypes.c_int64]
+    el = np.ascontiguousarray(tree.edge_len, dtype=np.float64)
+    hl = np.ascontiguousarray(tree.has_len, dtype=np.uint8)
+    co = np.ascontiguousarray(tree.child_off, dtype=np.int32)
+    ci = np.ascontiguousarray(tree.child_idx, dtype=np.int32)
+    k = lib.apples_extended_newick(n, ptr(co), ptr(ci), int(tree.root), ptr(el), ptr(hl), blob, ptr(loff), ptr(llen), out, cap)
+    if k < 0:
+        return None
+    s = out.raw[:k].decode()
+    return ('[&R] %s;' % s) if tree.is_rooted else ('%s;' % s)
+
+
 def extended_newick(tree):
     """Newick with ``{edge_index}`` after every non-root node (apples/jutil.py:22-96)."""
+    s = _extended_newick_native(tree)
+    if s is not None:
+        return s
+    return _extended_newick_py(tree)
+
+
+def _extended_newick_py(tree):
     n = tree.n_nodes
     off = tree.child_off.tolist()
     idx = tree.child_idx.tolist()

@@ -7,7 +7,8 @@ import threading
 
 import numpy as np
 
-from .engine import (Engine, placement_rows, F_EXACT, F_INSUFFICIENT, F_MISPLACED, F_ZERO_NOT_IN_TREE, F_DEGENERATE)
+from .engine import (Engine, placement_rows, F_EXACT, F_INSUFFICIENT, F_MISPLACED, F_ZERO_NOT_IN_TREE, F_DEGENERATE,
+                     F_PENDANT_INT)
 
 
 def _shards(n, parts):
@@ -76,7 +77,7 @@ class QueryWorker:
         # the entry runquery deletes: query name is a backbone leaf and names a reference row (:63-66)
         self_rows = np.array([aln.index.get(n, -1) if n in self.tree.name_to_node else -1 for n in names], np.int32)
         out = self._run_sharded(len(names), lambda eng, lo, hi: eng.place_sequences(seqs[lo:hi], self_rows[lo:hi]))
-        return self._rows(names, out) if rows else self._to_jplace(names, out)
+        return self._rows(names, out, arrays=rows == 'arrays') if rows else self._to_jplace(names, out)
 
     # ------------------------------------------------------------------ distance-table input
     def run_distances(self, names, cols, D, rows=False):
@@ -84,10 +85,10 @@ class QueryWorker:
         col_index = {c: i for i, c in enumerate(cols)}
         self_cols = np.array([col_index.get(n, -1) if n in self.tree.name_to_node else -1 for n in names], np.int32)
         out = self._run_sharded(len(names), lambda eng, lo, hi: eng.place_distances(D[lo:hi], col_nodes, self_cols[lo:hi]))
-        return self._rows(names, out) if rows else self._to_jplace(names, out)
+        return self._rows(names, out, arrays=rows == 'arrays') if rows else self._to_jplace(names, out)
 
     # ------------------------------------------------------------------ result assembly
-    def _rows(self, names, out):
+    def _rows(self, names, out, arrays=False):
         """(names as printed, jplace p rows): the branches of runquery that are visible in the output
         (PoolQueryWorker.py:63-70,83-88,119-130), flags first so that the common case stays vectorised."""
         flags = out['flags']
@@ -105,7 +106,8 @@ class QueryWorker:
             if flags[i] & F_ZERO_NOT_IN_TREE:
                 raise KeyError('query %s has a zero distance to a reference that is not a leaf of the backbone tree' % names[i])
             raise ValueError('query %s: fewer than two of its observed references are leaves of the backbone tree' % names[i])
-        rows = placement_rows(out)
+        rows = None if arrays else placement_rows(out)
+        edge = out['edge'].copy() if arrays else None
         for i in np.nonzero(flags & F_INSUFFICIENT)[0]:
             sys.stderr.write('Taxon {} cannot be placed. At least three non-infinity distances '
                              'should be observed to place a taxon. '
@@ -114,11 +116,21 @@ class QueryWorker:
         for i in mis:
             ignored = ''
             if self.options.exclude_intplace:
-                rows[i][0] = -1
+                if arrays:
+                    edge[i] = -1
+                else:
+                    rows[i][0] = -1
                 ignored = ' Consequently, this sequence is ignored (no output).'
             logging.warning('Best placement for query sequence %s has zero pendant edge length and placed at an '
                             'internal node with a non-zero least squares error. This is a potential misplacement.%s'
                             % (names[i], ignored))
+        if arrays:
+            # the p rows as columns (what apples_amd/jplace.py's native writer takes): kind 1 = [edge, 0, 1, 0, 0], 2 = the
+            # pendant is the clamped int 0, 0 = five numbers as they are (engine.placement_rows)
+            kind = np.where((flags & (F_EXACT | F_INSUFFICIENT | F_DEGENERATE)) != 0, 1,
+                            np.where((flags & F_PENDANT_INT) != 0, 2, 0)).astype(np.uint8)
+            return names, {'edge': edge, 'error': np.ascontiguousarray(out['error']), 'distal': np.ascontiguousarray(out['distal']),
+                           'pendant': np.ascontiguousarray(out['pendant']), 'kind': kind}
         return names, rows
 
     def _to_jplace(self, names, out):

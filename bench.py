@@ -497,6 +497,11 @@ def main():
     # strong: one set of Q queries, rank r takes the contiguous block shard_bounds gives it
     ds = synth.make_dataset(n_leaves, L if not table else 4, Q, protein=protein, seed_query=3 if strong else 3 + rank)
     lo, hi = shard_bounds(Q, world)[rank] if strong else (0, Q)
+    if os.environ.get('APPLES_BENCH_SHARD'):
+        # experiment only (never the reported line): this process places shard k of the 8-GPU job's split of the workload's query set
+        ds = synth.make_dataset(n_leaves, L if not table else 4, WORKLOADS[args.workload][2], protein=protein, seed_query=3)
+        lo, hi = shard_bounds(WORKLOADS[args.workload][2], 8)[int(os.environ['APPLES_BENCH_SHARD'])]
+        Q = hi - lo
     queries = np.ascontiguousarray(ds.query_seqs[lo:hi])
     if os.environ.get('APPLES_BENCH_TREE_ORDER'):
         # experiment only (never the reported line): the block's queries in the tree order of their true sister leaves,

@@ -26,6 +26,13 @@ int apples_fasta_scan(const uint8_t *data, int64_t n_bytes, const uint8_t *trans
                       uint8_t *rows, int64_t n_rows, int64_t *n_records, int64_t *length,
                       int64_t *name_off, int32_t *name_len, int64_t *bad_record, int64_t *bad_length);
 
+/* The same in one threaded pass for the plain shape (FASTA only, "\n" line ends: no '\r' anywhere, no line starting with '@' or
+ * '+'): headers indexed by byte ranges, records filled by record ranges, memchr per line.  Returns 3 when the input is not of that
+ * shape (the caller then runs apples_fasta_scan); otherwise as apples_fasta_scan.  n_threads <= 0: one per hardware thread. */
+int apples_fasta_scan_mt(const uint8_t *data, int64_t n_bytes, const uint8_t *translate /*[256]*/, uint8_t *rows, int64_t n_rows,
+                         int64_t *n_records, int64_t *length, int64_t *name_off, int32_t *name_len, int64_t *bad_record,
+                         int64_t *bad_length, int32_t n_threads);
+
 /* apples_newick_scan replaces the token loop of the Newick reader (apples_amd/tree.py:parse_newick;
  * reader contract: SURVEY.md Appendix B, for apples/prepareTree.py:24-36 and apples/util.py:57-88)
  * for backbones of 10^5..10^6 leaves.  `text` is the tree string after the optional [&R]/[&U]
@@ -68,6 +75,25 @@ int apples_max_clusters(int32_t n_nodes, const int32_t *child_off, const int32_t
 int apples_dismat_scan(const uint8_t *data, int64_t n_bytes, double *out, int64_t n_tags_cap, int64_t n_rows_cap,
                        int64_t *n_tags, int64_t *n_rows, int64_t *tag_off, int32_t *tag_len, int64_t *name_off,
                        int32_t *name_len);
+
+/* jplace placement rows as text (csrc_io/jplace_format.cpp): the bytes json.dumps(sort_keys=True, indent=4) gives for the
+ * reference's per-query dicts {"n": [name], "p": [[edge, likelihood, 1, distal, pendant]]} (run_apples.py:106-118,
+ * apples/PoolQueryWorker.py:36-37), numbers spelled as Python's repr spells them.  kind[i]: 0 = floats; 1 = [edge, 0, 1, 0, 0];
+ * 2 = floats with the pendant as the int 0.  keep[i] == 0 rows are skipped; first != 0: the first row written opens the
+ * "placements" list.  Names are copied verbatim between quotes (the caller checks that json.dumps would not escape them).
+ * Returns the bytes written into out[cap], -1 if cap is too small (512 + name bytes per kept row is always enough). */
+int64_t apples_jplace_rows(const uint8_t *names, const int64_t *name_off, const int32_t *name_len, int64_t n, const int32_t *edge,
+                           const double *err, const double *distal, const double *pendant, const uint8_t *kind,
+                           const uint8_t *keep, int first, char *out, int64_t cap);
+/* The jplace tree string without its closing ';' (apples/jutil.py:22-96): Newick with "{edge_index}" after every node but the
+ * root; nodes numbered in left-to-right post-order, children in file order (CSR), labels as byte ranges of `labels`
+ * (label_len < 0: none).  Returns the bytes written, -1 if cap is too small (24 + 40 per node + the labels' bytes is enough),
+ * -2 when a branch length is an integral value beyond 2^63 (the caller's own formatter prints those). */
+int64_t apples_extended_newick(int32_t n_nodes, const int32_t *child_off, const int32_t *child_idx, int32_t root,
+                               const double *edge_len, const uint8_t *has_len, const uint8_t *labels, const int64_t *label_off,
+                               const int32_t *label_len, char *out, int64_t cap);
+/* repr(float) of Python into out (at most 32 bytes); returns its length */
+int64_t apples_format_double(double x, char *out);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import numpy as np
 
 from apples_amd.dismat import read_dismat as read_distance_table, read_dismat_binary, read_dismat_py  # noqa: F401
 from apples_amd.fasta import read_alignment
-from apples_amd.jplace import iter_text, keep_mask
+from apples_amd.jplace import iter_text, keep_mask, write_native
 from apples_amd.options import options_config
 from apples_amd.reference import ReducedReference, read_treecluster
 from apples_amd.tree import extended_newick, read_tree
@@ -75,7 +75,7 @@ def main(argv=None):
         names, cols, D = read_distance_table(options.dist_fp)  # text (native scanner) or .npz
         worker = QueryWorker(tree, options, None, devices)
         startq = time.time()
-        out_names, rows = worker.run_distances(names, cols, D, rows=True)
+        out_names, rows = worker.run_distances(names, cols, D, rows='arrays')
     else:
         start = time.time()
         ref = reference.aln if reference is not None else read_alignment(options.ref_fp, options.protein_seqs, False)  # reference rows are never masked
@@ -111,19 +111,26 @@ def main(argv=None):
             qnames, qseqs = [ext.names[i] for i in keep], ext.seqs[keep]
         worker = QueryWorker(tree, options, reference, devices)
         startq = time.time()
-        out_names, rows = worker.run_sequences(qnames, qseqs, rows=True)
+        out_names, rows = worker.run_sequences(qnames, qseqs, rows='arrays')
     logging.info('[%s] Processed all queries in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - startq))
     worker.close()
 
     # join_jplace + json.dumps(sort_keys=True, indent=4) of the reference (run_apples.py:106-118), streamed
-    keep = keep_mask([r[0] for r in rows])
-    text = iter_text(((n, r) for n, r, k in zip(out_names, rows, keep) if k), newick,
-                     sys.argv if argv is None else ['run_apples.py'] + list(argv))
-    f = open(options.output_fp, 'w') if options.output_fp else sys.stdout
-    for piece in text:
-        f.write(piece)
+    invocation = sys.argv if argv is None else ['run_apples.py'] + list(argv)
+    fb = open(options.output_fp, 'wb') if options.output_fp else sys.stdout.buffer
+    if not write_native(fb, out_names, rows, newick, invocation):
+        # a name json.dumps would escape, or no native library: the same text from Python
+        from apples_amd.engine import F_EXACT, F_INSUFFICIENT, F_DEGENERATE  # noqa: F401
+        prow = [[int(e), 0, 1, 0, 0] if k == 1 else [int(e), float(er), 1, float(d), 0 if k == 2 else float(pe)]
+                for e, er, d, pe, k in zip(rows['edge'].tolist(), rows['error'].tolist(), rows['distal'].tolist(),
+                                           rows['pendant'].tolist(), rows['kind'].tolist())]
+        keep = keep_mask([r[0] for r in prow])
+        for piece in iter_text(((n, r) for n, r, k in zip(out_names, prow, keep) if k), newick, invocation):
+            fb.write(piece.encode())
     if options.output_fp:
-        f.close()
+        fb.close()
+    else:
+        fb.flush()
     logging.warning('[%s] APPLES finished in %.3f seconds.' % (time.strftime('%H:%M:%S'), time.time() - startb))
 
 

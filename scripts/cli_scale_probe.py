@@ -17,7 +17,9 @@ open(os.path.join(tmp, 'tree.nwk'), 'w').write(d.newick + '\n')
 wf(os.path.join(tmp, 'ref.fa'), d.ref_names, d.ref_seqs)
 wf(os.path.join(tmp, 'query.fa'), d.query_names, d.query_seqs)
 out = os.path.join(tmp, 'out.jplace')
+import time as _t
 for clusters in (['--no-clusters'], []):
+    _t.sleep(8)  # the previous process's 96 GiB of batch buffers are scrubbed by the driver after it exits: a run started at once waits for that (4 s)
     t = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_apples.py'), '-s', os.path.join(tmp, 'ref.fa'), '-q',
                         os.path.join(tmp, 'query.fa'), '-t', os.path.join(tmp, 'tree.nwk'), '-o', out, '-D'] + clusters,

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/tl_trace
-timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl_trace -- python3 $R/bench.py --no-cpu --no-extras --queries 12500 --steps 3 --warmup 2 "$@" > /tmp/tl_bench.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl_trace -- python3 $R/bench.py --no-cpu --no-extras --queries 12500 --steps 3 --warmup 2 --scaling weak "$@" > /tmp/tl_bench.json 2>/dev/null
 python3 - <<PY
 import csv, glob, re, json
 k = glob.glob("/tmp/tl_trace/*/*kernel_trace.csv")[0]
@@ -21,7 +21,7 @@ if not big:
     big = [i for i, r in enumerate(rows) if "k_pack_rows" in r[1]]
 d = json.load(open("/tmp/tl_bench.json"))
 print("bench ms_per_step", d["ms_per_step"], "resident", d["resident"]["ms_per_step"], d["resident"]["per_kernel_ms_per_step"])
-for s in big[-6:]:
+for s in big[-2:-1]:
     t0 = rows[s][2]
     print("---- step starting at the copy of the query bytes")
     for r in rows[s:s + 40]:

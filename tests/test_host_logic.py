@@ -267,6 +267,66 @@ def test_native_fasta_scan_matches_record_reader(case, tmp_path):
                 assert np.array_equal(want.seqs, got.seqs)
 
 
+@pytest.mark.parametrize('tail', ['newline', 'none', 'blank'])
+def test_threaded_fasta_scan_on_a_file_of_several_megabytes(tail, tmp_path):
+    """The threaded scanner (apples_fasta_scan_mt: headers indexed by byte ranges, records filled by record ranges) against the
+    general one and the record reader on a 3 MB file: ragged line widths, blank lines inside records, junk before the first
+    header, descriptions after the name, lower case and odd symbols, with and without a final newline."""
+    import ctypes
+    from apples_amd import build, fasta
+    build.build_io(verbose=False)
+    fasta._io_lib = None
+    lib = fasta._load_io()
+    rng = np.random.default_rng(5)
+    L, n = 1500, 2000
+    alpha = np.frombuffer(b'ACGTacgtNnU-*?', dtype=np.uint8)
+    seqs = alpha[rng.integers(0, len(alpha), size=(n, L))]
+    parts = [b'junk line\n\n']
+    for i in range(n):
+        parts.append(b'>s%d some description %d\n' % (i, i))
+        at = 0
+        while at < L:
+            w = int(rng.integers(1, 200))
+            parts.append(seqs[i, at:at + w].tobytes() + b'\n')
+            at += w
+            if rng.random() < 0.02:
+                parts.append(b'\n')
+    blob = b''.join(parts)
+    if tail == 'none':
+        blob = blob[:-1] + b'G'      # the last line unterminated: it loses its last character, the 'G'
+    elif tail == 'blank':
+        blob += b'\n\n'
+    path = str(tmp_path / 'big.fa')
+    with open(path, 'wb') as f:
+        f.write(blob)
+    assert len(blob) > (1 << 20)
+    want = fasta._read_alignment_py(path, False, False)
+    got = fasta.read_alignment(path, False, False)
+    assert want.names == got.names and np.array_equal(want.seqs, got.seqs)
+    # the threaded entry point itself, seven threads, against the general scanner's rows
+    data = np.frombuffer(blob, dtype=np.uint8)
+    tab = fasta._translation(False, True)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    outs = []
+    for fn, extra in ((lib.apples_fasta_scan_mt, (7,)), (lib.apples_fasta_scan, ())):
+        n_rec, length, bad, bad_len = ctypes.c_int64(0), ctypes.c_int64(L), ctypes.c_int64(-1), ctypes.c_int64(0)
+        mat = np.zeros((n, L), np.uint8)
+        off = np.zeros(n, np.int64)
+        ln = np.zeros(n, np.int32)
+        rc = fn(ptr(data), data.size, ptr(tab), ptr(mat), n, ctypes.byref(n_rec), ctypes.byref(length), ptr(off), ptr(ln),
+                ctypes.byref(bad), ctypes.byref(bad_len), *extra)
+        assert rc == 0 and n_rec.value == n
+        outs.append((mat, off, ln))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    # not the plain shape: the threaded scanner declines
+    for odd in (blob.replace(b'\n>s7 ', b'\r\n>s7 ', 1), blob + b'\n+\n', blob + b'\n>'):
+        d2 = np.frombuffer(odd, dtype=np.uint8)
+        n_rec, length, bad, bad_len = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(-1), ctypes.c_int64(0)
+        assert lib.apples_fasta_scan_mt(ptr(d2), d2.size, ptr(tab), None, 0, ctypes.byref(n_rec), ctypes.byref(length), None, None,
+                                        ctypes.byref(bad), ctypes.byref(bad_len), 7) == 3
+
+
 def test_binary_distance_table_equals_text_reader(tmp_path):
     """The .npz form of a -d table gives run_apples.py the same names, columns and values as the
     text form (run_apples.py:43-54), repeated column names included."""
