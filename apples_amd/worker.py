@@ -21,6 +21,11 @@ class QueryWorker:
     """State injected once (PoolQueryWorker.set_class_attributes, PoolQueryWorker.py:17-24)."""
 
     def __init__(self, tree, options, reference=None, devices=(0,)):
+        # A one-shot run keeps its device batch buffers small: beyond a few tens of GiB the allocation itself takes seconds
+        # (the driver hands out scrubbed memory: 2 - 4 s for the 96 GiB a resident context would take at 200 000 references, every
+        # run, against 0.1 s for 24 GiB), which no batch size wins back on one pass over the queries (scripts/r04_cli_batch_exp.sh)
+        import os
+        os.environ.setdefault('APPLES_BATCH_GIB', '24')
         self.tree = tree
         self.options = options
         self.reference = reference

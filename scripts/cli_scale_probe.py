@@ -17,16 +17,20 @@ open(os.path.join(tmp, 'tree.nwk'), 'w').write(d.newick + '\n')
 wf(os.path.join(tmp, 'ref.fa'), d.ref_names, d.ref_seqs)
 wf(os.path.join(tmp, 'query.fa'), d.query_names, d.query_seqs)
 out = os.path.join(tmp, 'out.jplace')
-import time as _t
+# every configuration three times, a pause before each: a process that starts right after another one has exited waits for the
+# driver to scrub that one's device memory (seconds for tens of GiB; scripts/r04_cli_batch_exp.sh), which says nothing about this one
 for clusters in (['--no-clusters'], []):
-    _t.sleep(8)  # the previous process's 96 GiB of batch buffers are scrubbed by the driver after it exits: a run started at once waits for that (4 s)
-    t = time.time()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_apples.py'), '-s', os.path.join(tmp, 'ref.fa'), '-q',
-                        os.path.join(tmp, 'query.fa'), '-t', os.path.join(tmp, 'tree.nwk'), '-o', out, '-D'] + clusters,
-                       capture_output=True, text=True)
-    wall = time.time() - t
-    assert r.returncode == 0, r.stderr[-2000:]
+    walls = []
+    for rep in range(3):
+        time.sleep(6)
+        t = time.time()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_apples.py'), '-s', os.path.join(tmp, 'ref.fa'), '-q',
+                            os.path.join(tmp, 'query.fa'), '-t', os.path.join(tmp, 'tree.nwk'), '-o', out, '-D', '--debug'] + clusters,
+                           capture_output=True, text=True)
+        walls.append(time.time() - t)
+        assert r.returncode == 0, r.stderr[-2000:]
+        phases = [l.split('] ', 1)[-1] for l in r.stderr.strip().splitlines() if 'seconds' in l]
+        print('  run %d: wall %.2f s | %s' % (rep, walls[-1], ' | '.join(phases)[:400]), flush=True)
     j = json.load(open(out))
-    print('clusters' if not clusters else 'no clusters', 'wall %.2f s' % wall, 'placements', len(j['placements']),
-          'bytes', os.path.getsize(out))
-    print('  ' + ' | '.join(l.split('] ', 1)[-1] for l in r.stderr.strip().splitlines() if 'seconds' in l)[:600])
+    print('clusters' if not clusters else 'no clusters', 'wall best of 3 %.2f s (%s)' % (min(walls), ', '.join('%.2f' % w for w in walls)),
+          'placements', len(j['placements']), 'bytes', os.path.getsize(out), flush=True)
