@@ -1,6 +1,7 @@
 // Max-diameter tree clustering behind include/apples_io.h: the sweep of apples_amd/treecluster.py
 // (the TreeCluster "max" method the reference runs as an external tool, apples/Reference.py:87-88),
 // statement for statement, on the tree's CSR arrays.
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <deque>
@@ -102,5 +103,52 @@ extern "C" int apples_max_clusters(int32_t n_nodes, const int32_t *child_off, co
     }
     if (n > 0) close(cut(root));
     *n_clusters = n_cl;
+    return 0;
+}
+
+// Consensus rows of the multi-member clusters (apples/PoolRepresentativeWorker.py:17-85): per column the most frequent symbol of the
+// alphabet among the members' rows, ties to the first in alphabet order, symbols outside the alphabet not counted (a column with
+// none of them: the alphabet's first symbol, as numpy's argmax of zeros).  Cluster c = rows member_row[member_off[c] ..
+// member_off[c + 1]) of `seqs` ([n_rows][L] bytes); out = [n_clusters][L].  Threads take clusters in turn.
+#include <atomic>
+#include <thread>
+
+extern "C" int apples_consensus(const uint8_t *seqs, int64_t L, const int32_t *member_row, const int64_t *member_off,
+                                int64_t n_clusters, const uint8_t *alphabet, int32_t n_alpha, uint8_t *out, int32_t n_threads) {
+    if (n_alpha <= 0 || n_alpha > 32) return 1;
+    uint8_t lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = 255;
+    for (int a = n_alpha - 1; a >= 0; --a) lut[alphabet[a]] = (uint8_t)a;
+    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    T = std::max(1, std::min<int>(T, 64));
+    if (n_clusters < 64) T = 1;
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        std::vector<uint32_t> cnt((size_t)n_alpha * L);
+        for (;;) {
+            const int64_t c = next.fetch_add(1);
+            if (c >= n_clusters) break;
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (int64_t m = member_off[c]; m < member_off[c + 1]; ++m) {
+                const uint8_t *row = seqs + (int64_t)member_row[m] * L;
+                for (int64_t s = 0; s < L; ++s) {
+                    const uint8_t a = lut[row[s]];
+                    if (a != 255) ++cnt[(size_t)a * L + s];
+                }
+            }
+            uint8_t *o = out + c * L;
+            for (int64_t s = 0; s < L; ++s) {
+                int best = 0;
+                uint32_t bc = cnt[s];
+                for (int a = 1; a < n_alpha; ++a)
+                    if (cnt[(size_t)a * L + s] > bc) { bc = cnt[(size_t)a * L + s]; best = a; }
+                o[s] = alphabet[best];
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
     return 0;
 }

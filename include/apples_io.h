@@ -62,6 +62,12 @@ int apples_max_clusters(int32_t n_nodes, const int32_t *child_off, const int32_t
                         const double *edge_len, int32_t root, double threshold, int32_t *leaf_order,
                         int32_t *cluster_end, int32_t *n_clusters);
 
+/* Consensus rows of multi-member clusters (apples/PoolRepresentativeWorker.py:17-85): per column the most frequent symbol of
+ * `alphabet` among the cluster's rows (member_row[member_off[c] .. member_off[c + 1]) of seqs[n_rows][L]), ties to the first in
+ * alphabet order, other symbols not counted.  out = [n_clusters][L].  Returns 0. */
+int apples_consensus(const uint8_t *seqs, int64_t L, const int32_t *member_row, const int64_t *member_off, int64_t n_clusters,
+                     const uint8_t *alphabet, int32_t n_alpha, uint8_t *out, int32_t n_threads);
+
 /* apples_dismat_scan replaces the per-value Python of the reference's distance-table reader
  * (run_apples.py:43-54 read_dismat) for tables of 10^8 and more values.  `data` is the file image.
  * Reader semantics kept: universal newlines; the header line is right-stripped and split on white

@@ -38,7 +38,7 @@ def test_io_library_builds_and_exports_every_symbol():
     from apples_amd import build
     lib = ctypes.CDLL(build.build_io(verbose=False))
     syms = _declared_symbols('apples_io.h')
-    assert syms == ['apples_dismat_scan', 'apples_extended_newick', 'apples_fasta_scan', 'apples_fasta_scan_mt', 'apples_format_double',
+    assert syms == ['apples_consensus', 'apples_dismat_scan', 'apples_extended_newick', 'apples_fasta_scan', 'apples_fasta_scan_mt', 'apples_format_double',
                     'apples_jplace_rows', 'apples_max_clusters', 'apples_newick_scan']
     for s in syms:
         assert hasattr(lib, s), 'missing export %s' % s
