@@ -174,12 +174,17 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
         for (int k = 0; k < 2; ++k) {
             const uint8_t *src = part == 0 ? (qtile + b * SD_IMG) + doff[k] : (rtile + b * SD_IMG + k * 1024) + roff;
             uint8_t *dst = part == 0 ? Aq(g) + (wv * 2 + k) * 1024 : Br(g) + (wv * 2 + k) * 1024;
+#ifndef SD_NO_DMA  // (timing experiments: scripts/r04_sd_parts_exp.sh)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+#endif
         }
     };
     v4i_t fa[2][2], fb[2][4];  // fragment sets: [0] the step's first K half, [1] its second
     auto load_frags = [&](int g, int h) __attribute__((always_inline)) {
+#ifdef SD_NO_FRAGS
+        if (g >= 0) return;
+#endif
         const uint8_t *A = Aq(g) + arow + coff[h], *B = Br(g) + brow + coff[h];
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[h][i] = *reinterpret_cast<const v4i_t *>(A + i * 32 * 64);
@@ -273,6 +278,17 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
             tile_at(nl, nqt, nrt);
             if (nrt < TR) { have = true; break; }
         }
+#ifdef SD_SKIP_EPILOGUE
+        {   // timing experiment: main loop only (every accumulator stays live)
+            float s = 0;
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int x = 0; x < 16; ++x) s += acc[i][j][x];
+            if (s == 123456.f) seg_cnt[0] = 1;
+            if (have) { set_tile(nqt, nrt); dma(0, 0, 0); dma(0, 0, 1); dma(1, 1, 0); dma(1, 1, 1); }
+            if (!have) break;
+            l = nl; qt = nqt; rt = nrt;
+            continue;
+        }
+#endif
         // C layout of the 32x32 tiles: column (reference slot) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
         if (ROWS) {
             // the next tile's first two steps: after the last barrier nobody reads LDS any more
