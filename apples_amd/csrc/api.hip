@@ -1757,8 +1757,10 @@ static int setup_columns(apples_ctx *ctx, int64_t n_cols, const int32_t *col_nod
 
 // selection (table rule) + sweep over nq rows of a device-resident table in slot order; d_self = per-query own
 // column as a slot index or -1
+// `pipe` (run_table_block's pipelined form): the selection on the context's stream between pipe[0] and pipe[1], the sweep on
+// the back stream (stream3) behind `ready`, between pipe[2] and pipe[3]; no phase timer
 static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, int64_t n_cols, const int32_t *d_self,
-                           apples_placement *d_out, PhaseTimer &pt) {
+                           apples_placement *d_out, PhaseTimer &pt, hipEvent_t *pipe = nullptr, hipEvent_t ready = nullptr) {
     Workspace &w = ctx->ws;
     ctx->cur_batch_queries = nq;  // (route_threshold)
     SelectArgs s{};
@@ -1775,6 +1777,17 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), ctx->stream));  // every counter of the batch
+    if (pipe) {
+        HIP_TRY(ctx, hipEventRecord(pipe[0], ctx->stream));
+        if (launch_select(ctx, s, nq)) return 1;
+        HIP_TRY(ctx, hipEventRecord(pipe[1], ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ready, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ready, 0));
+        HIP_TRY(ctx, hipEventRecord(pipe[2], ctx->stream3));
+        if (run_sweep(ctx, d_out, nq, ctx->stream3)) return 1;
+        HIP_TRY(ctx, hipEventRecord(pipe[3], ctx->stream3));
+        return 0;
+    }
     pt.flush();
     pt.begin(APPLES_T_SELECT);
     if (launch_select(ctx, s, nq)) return 1;
@@ -1869,19 +1882,43 @@ static int run_table_block(apples_ctx *ctx, QueryBlock &qb) {
                    "placed on this context): upload the table again";
         return 1;
     }
-    if (ensure_workspace(ctx, qb.n_cols, qb.n_cols, qb.n, false, false, hybrid)) return 1;
+    // APPLES_TABLE_PIPELINE=k (an experiment, off by default): the block as a pipeline of k sub-batches with two sets of batch
+    // buffers, the selection of sub-batch i + 1 -- a stream over the table, bound by HBM -- beside the sweep of sub-batch i, which
+    // waits on memory round trips.  Measured: a sweep takes about as long for 2 048 rows as for 4 096 (its
+    // longest queries decide), so k sweeps cost more than the overlap returns.
+    static const int n_pipe = getenv("APPLES_TABLE_PIPELINE") ? atoi(getenv("APPLES_TABLE_PIPELINE")) : 0;  // sub-batches; 0 / 1: off
+    const bool pipelined = n_pipe > 1 && !hybrid && !ctx->tree.scan && qb.n >= 2048;
+    int64_t want = qb.n;
+    if (pipelined) want = round_up((qb.n + n_pipe - 1) / n_pipe, 32);
+    if (ensure_workspace(ctx, qb.n_cols, qb.n_cols, want, false, false, hybrid, false, pipelined)) return 1;
     Workspace &w = ctx->ws;
+    const int64_t step = pipelined ? std::min<int64_t>(w.batch, want) : w.batch;
+    const int64_t n_sub = (qb.n + step - 1) / step;
     PhaseTimer pt{ctx};
-    while (ctx->ev_pool.size() < 2) {  // timing events live with the context
+    while (ctx->ev_pool.size() < (size_t)(2 + (pipelined ? 4 * n_sub : 0))) {  // timing events live with the context
         hipEvent_t e;
         HIP_TRY(ctx, hipEventCreate(&e));
         ctx->ev_pool.push_back(e);
     }
     hipEvent_t e_start = ctx->ev_pool[0], e_stop = ctx->ev_pool[1];
     HIP_TRY(ctx, hipEventRecord(e_start, ctx->stream));
-    for (int64_t q0 = 0; q0 < qb.n; q0 += w.batch) {
-        int64_t nq = std::min(w.batch, qb.n - q0);
-        if (run_table_batch(ctx, qb.table + q0 * qb.n_cols, nq, qb.n_cols, qb.self_slot + q0, qb.out + q0, pt)) return 1;
+    for (int64_t i = 0; i < n_sub; ++i) {
+        const int64_t q0 = i * step, nq = std::min(step, qb.n - q0);
+        if (!pipelined) {
+            if (run_table_batch(ctx, qb.table + q0 * qb.n_cols, nq, qb.n_cols, qb.self_slot + q0, qb.out + q0, pt)) return 1;
+            continue;
+        }
+        const int set = (int)(i & 1);
+        if (i > 0) swap_bufs(w);  // host view: w.* now names buffer set `set`
+        if (i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_back[set], 0));  // the sweep that read this set is done
+        if (run_table_batch(ctx, qb.table + q0 * qb.n_cols, nq, qb.n_cols, qb.self_slot + q0, qb.out + q0, pt,
+                            ctx->ev_pool.data() + 2 + 4 * i, ctx->ev_front[set])) return 1;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_back[set], ctx->stream3));
+    }
+    if (pipelined) {
+        if ((n_sub & 1) == 0) swap_bufs(w);  // leave the host view on set 0
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_bigfree, ctx->stream3));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_bigfree, 0));
     }
     HIP_TRY(ctx, hipEventRecord(e_stop, ctx->stream));
     HIP_TRY(ctx, hipEventSynchronize(e_stop));
@@ -1889,6 +1926,14 @@ static int run_table_block(apples_ctx *ctx, QueryBlock &qb) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e_start, e_stop);
     for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = pt.acc[i];
+    if (pipelined)
+        for (int64_t i = 0; i < n_sub; ++i) {  // each kernel family's own time; the two overlap, so they add up to more than the total
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, ctx->ev_pool[2 + 4 * i], ctx->ev_pool[2 + 4 * i + 1]);
+            (void)hipEventElapsedTime(&b, ctx->ev_pool[2 + 4 * i + 2], ctx->ev_pool[2 + 4 * i + 3]);
+            ctx->t_ms[APPLES_T_SELECT] += a;
+            ctx->t_ms[APPLES_T_SWEEP] += b;
+        }
     ctx->t_ms[APPLES_T_TOTAL] = ms;
     return 0;
 }

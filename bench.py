@@ -355,12 +355,14 @@ def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_st
     return roofline
 
 
-def other_workload(name, device, steps=3, ds=None):
+def other_workload(name, device, steps=3, ds=None, queries=0):
     """A compact leg of another BASELINE config for the driver's line: `steps` timed passes (host buffers -> placements in
     host memory; config 5: the table block resident), per-kernel HIP-event times, the dominant kernel's roofline.  No CPU leg."""
     from apples_amd import synth
     from apples_amd.engine import Engine
     n_leaves, L, Q, protein, method, thr = WORKLOADS[name]
+    if queries:
+        Q = queries
     table = name == 'c5'
     if ds is None or table:
         ds_ = synth.make_dataset(n_leaves, L if not table else 4, Q, protein=protein) if ds is None else ds
@@ -372,7 +374,10 @@ def other_workload(name, device, steps=3, ds=None):
         rs = np.random.default_rng(3)
         q_leaf = rs.integers(0, n_leaves, size=Q)
         q_pend = rs.exponential(0.01, size=Q)
-        D = synth.fast_distance_rows(ds_.tree, index, q_leaf, q_pend, list(range(Q)), seed_noise=7)
+        D = np.empty((Q, n_leaves))
+        for lo in range(0, Q, 2048):  # (block by block: the generator's temporaries stay small)
+            hi = min(Q, lo + 2048)
+            D[lo:hi] = synth.fast_distance_rows(ds_.tree, index, q_leaf, q_pend, list(range(lo, hi)), seed_noise=7 + lo)
         eng = Engine(ds_.tree, None, method=method, criterion='MLSE', threshold=thr, baseobs=25, device=device)
         handle, _ = eng.upload_table(D, nodes)
 
@@ -675,7 +680,9 @@ def main():
         if extras and args.workload == 'c3':
             # the other BASELINE configs, so that the driver's own run sees them (config 5 on config 3's tree: the same backbone)
             line['other_workloads'] = {'c2': other_workload('c2', local_rank), 'c4': other_workload('c4', local_rank),
-                                       'c5': other_workload('c5', local_rank, ds=ds)}
+                                       'c5': other_workload('c5', local_rank, ds=ds),
+                                       # config 5 as one rank of its 8-GPU job holds it: 12 500 of the 100 000 rows (20 GB) resident
+                                       'c5_shard_12500_rows': other_workload('c5', local_rank, ds=ds, queries=12500)}
         final_line = json.dumps(line)
     if comm is not None:
         comm.barrier()

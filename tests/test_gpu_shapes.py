@@ -142,6 +142,40 @@ def test_c5_shape_200k_column_distance_table_bme():
     assert got[7]['flags'] & F_EXACT and got[6]['flags'] & F_INSUFFICIENT
 
 
+def test_c5_one_shard_of_eight_12500_rows_resident():
+    """Config 5 as one rank of the 8-GPU job sees it: 12 500 of the 100 000 table rows (20 GB of fp64) resident, placed as a
+    pipeline of sub-batches (selection of one beside the sweep of the one before, two sets of batch buffers).  512 rows -- the
+    special ones, the extremes, a strided set -- byte for byte against the C oracle; the first 3 000 rows through the host-buffer
+    entry point (one stream, other batch cuts): identical bytes."""
+    nq = 12500
+    d = synth.make_dataset(200000, 8, nq)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ix = synth.TreeIndex(d.tree)
+    D = np.empty((nq, 200000))
+    for lo in range(0, nq, 2500):  # (block by block: the generator's temporaries stay small)
+        D[lo:lo + 2500] = synth.fast_distance_rows(d.tree, ix, d.query_leaf, d.query_pendant, list(range(lo, lo + 2500)), seed_noise=7 + lo)
+    D[5, ::3] = -1.0
+    D[6, :] = -1.0
+    D[7, 123456] = 0.0
+    D[9000, 1::2] = -1.0
+    eng = Engine(d.tree, None, method='BME')
+    h, n = eng.upload_table(D, nodes)
+    eng.place_resident(h)
+    got = eng.fetch(h, n)
+    eng.place_resident(h)                       # a second pass over the same resident block: same bytes
+    assert eng.fetch(h, n).tobytes() == got.tobytes()
+    eng.free_queries(h)
+    eng.close()
+    e1 = Engine(d.tree, None, method='BME', max_batch=1024)
+    assert e1.place_distances(D[:3000], nodes).tobytes() == got[:3000].tobytes()
+    e1.close()
+    sample = np.unique(np.concatenate([np.arange(16), [9000], _sample(got, nq, extremes=24, strided=460)]))
+    assert len(sample) >= 480
+    want = COracle(d.tree, method='BME', threads=NTHREADS).place_distances(np.ascontiguousarray(D[sample]), nodes)
+    assert got[sample].tobytes() == want.tobytes()
+    assert got[7]['flags'] & F_EXACT and got[6]['flags'] & F_INSUFFICIENT
+
+
 def test_resident_table_is_refused_after_the_column_layout_changed():
     """A resident -d block was permuted with the column order of its upload; placing another table
     with different columns of the same number replaces that order.  The old block must be refused,
