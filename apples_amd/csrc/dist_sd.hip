@@ -529,6 +529,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restri
     __syncthreads();
     int kept = 0;
     for (;;) {
+        if (dbg & 4) break;  // (timing experiments: the set-up alone)
         int e0 = 0;
         if (lane == 0) e0 = atomicAdd(&sh_next, 64);
         e0 = __builtin_amdgcn_readfirstlane(e0);
@@ -544,6 +545,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restri
         const int64_t src = (int64_t)lo * 64 + (ee - pref[lo]);
         const int slot = sslot[src];
         const bool ok = in && slot < n_slots;
+        if (dbg & 8) { if (in) sd[src] = (double)slot; continue; }  // (timing experiments: no evaluation)
         const double d = sd_eval64(rrows, mrows, Lrow, ok ? slot : 0, sh_wbuf[w], sh_wslot[w], sh_q, sh_qm, n16, Tb, L, overlap, nullptr, dbg);
         if (in) {
             const bool keep = ok && d >= 0 && d <= thr;
