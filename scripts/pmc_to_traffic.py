@@ -11,7 +11,8 @@ import json, os, subprocess, sys
 d, workload = sys.argv[1], sys.argv[2]
 out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_summary.json')
 summ = json.loads(subprocess.check_output([sys.executable, os.path.join(os.path.dirname(__file__), 'pmc_summary.py'), d]))
-names = {'k_jc69_gemm': 'jc69_distance', 'k_jc69_mfma': 'jc69_distance', 'k_jc69': 'jc69_distance', 'k_scoredist': 'scoredist_distance', 'k_select_fast': 'select_fast',
+names = {'k_jc69_gemm': 'jc69_distance', 'k_jc69_mfma': 'jc69_distance', 'k_jc69': 'jc69_distance', 'k_scoredist': 'scoredist_distance', 'k_sd_gemm': 'scoredist_filter_gemm', 'k_sd_exact': 'scoredist_exact', 'k_sd_topup': 'scoredist_topup',
+         'k_select_fast': 'select_fast',
          'k_select_stream': 'table_select' if workload == 'c5' else 'select', 'k_select_clusters': 'select_clusters', 'k_cluster_dist': 'cluster_dist', 'k_select': 'select',
          'k_sweep_mixed': 'lsq_sweep', 'k_sweep<': 'lsq_sweep', 'k_lean_up': 'lsq_sweep_up', 'k_lean_down': 'lsq_sweep_down',
          'k_sweep_lean_big': 'lsq_sweep_big'}
