@@ -332,7 +332,10 @@ def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_st
         tops = ops / (kernels[dom][1] * 1e-3) / 1e12
         roofline.update({'bound': 'mfma', 'achieved': tops, 'peak': MFMA_F4_PEAK_TOPS, 'unit': 'TFLOP/s',
                          'frac': tops / MFMA_F4_PEAK_TOPS, 'algorithmic_ops_per_launch': ops / n_launch,
-                         'hbm_algorithmic_GBps': achieved})
+                         'hbm_algorithmic_GBps': achieved,
+                         'launch_note': 'a device batch that comes from a host buffer is two launches (its first quarter, while the rest '
+                                        'is still on the bus, then the rest): avg_launch_ms is the mean over both; the resident pass '
+                                        'launches whole batches, and a kernel trace of this command averages over all of them'})
     elif dom == 'scoredist_distance' and info.get('scoredist_filter') and filter_ms:
         # the fused scoredist pass = a lower bound of every pair's table sum on the matrix cores (fp4 operands, 20 values per
         # site: dist_sd.hip) + the exact evaluation of the ~1 % of the pairs that survive it; the dominant kernel is the
