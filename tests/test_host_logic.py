@@ -637,3 +637,90 @@ def test_native_distance_table_values_equal_python_float_on_random_spellings(tmp
         f.write('q ' + ' '.join(vals) + '\n')
     _, _, G = dismat.read_dismat(str(p))
     assert np.array_equal(G[0], np.array([float(v) for v in vals]))
+
+
+def test_native_jplace_rows_equal_the_python_writer():
+    """apples_jplace_rows (include/apples_io.h) against apples_amd.jplace.iter_text, itself byte-identical to the reference's
+    json.dumps(sort_keys=True, indent=4) (run_apples.py:116): floats spelled as Python's repr, the three row kinds, dropped rows,
+    the first-result quirk of join_jplace (apples/jutil.py:11-18), names that need escaping (the native writer declines)."""
+    import io
+    import json
+    from apples_amd import build, fasta, jplace
+    build.build_io(verbose=False)
+    fasta._io_lib = None
+    rng = np.random.default_rng(1)
+    n = 3000
+    names = ['q%d' % i for i in range(n)]
+    edge = rng.integers(-1, 1000, size=n).astype(np.int32)
+    kind = rng.integers(0, 3, size=n).astype(np.uint8)
+    err = rng.random(n) * 10.0 ** rng.integers(-25, 20, size=n)
+    err[:8] = [0.0, -0.0, 1e16, 1e-4, 9.999e-5, 123456789012345680.0, 5e-324, 1.7976931348623157e308]
+    dist = rng.random(n)
+    pend = rng.random(n) * 1e-5
+    for first_edge in (-1, 7):
+        edge[0] = first_edge
+        cols = {'edge': edge, 'error': err, 'distal': dist, 'pendant': pend, 'kind': kind}
+        rows = [[int(e), 0, 1, 0, 0] if k == 1 else [int(e), float(a), 1, float(b), 0 if k == 2 else float(c)]
+                for e, a, b, c, k in zip(edge, err, dist, pend, kind)]
+        keep = jplace.keep_mask([r[0] for r in rows])
+        want = ''.join(jplace.iter_text(((nm, r) for nm, r, k in zip(names, rows, keep) if k), '(a{0},b{1});', ['run', 'a b']))
+        f = io.BytesIO()
+        assert jplace.write_native(f, names, cols, '(a{0},b{1});', ['run', 'a b'])
+        assert f.getvalue().decode() == want
+        assert json.loads(want)['version'] == 3
+    one = {k: v[:1] for k, v in cols.items()}
+    for bad in ('a"b', 'a\\b', 'caf\u00e9', 'tab\there'):
+        assert not jplace.write_native(io.BytesIO(), [bad], one, 't', ['x'])
+    f = io.BytesIO()
+    assert jplace.write_native(f, [], {k: v[:0] for k, v in cols.items()}, 't', ['x'])
+    assert f.getvalue().decode() == ''.join(jplace.iter_text([], 't', ['x']))
+
+
+def test_native_float_spelling_is_pythons():
+    import ctypes
+    import json
+    import random
+    import struct
+    from apples_amd import build, fasta
+    build.build_io(verbose=False)
+    fasta._io_lib = None
+    lib = fasta._load_io()
+    lib.apples_format_double.restype = ctypes.c_int64
+    lib.apples_format_double.argtypes = [ctypes.c_double, ctypes.c_char_p]
+    buf = ctypes.create_string_buffer(64)
+    rng = random.Random(7)
+    vals = [0.0, -0.0, 1.0, 1e16, 9999999999999998.0, 1e-4, 9.999e-5, 1e22, 5e-324, 0.1, 1 / 3, 100.0, 1e-5, float('nan'), float('inf'), float('-inf')]
+    vals += [struct.unpack('d', struct.pack('Q', rng.getrandbits(64)))[0] for _ in range(50000)]
+    vals += [rng.random() * 10 ** rng.randint(-8, 20) for _ in range(20000)]
+    for v in vals:
+        k = lib.apples_format_double(v, buf)
+        assert buf.raw[:k].decode() == json.dumps(v), repr(v)
+
+
+def test_native_extended_newick_and_consensus_equal_python():
+    """apples_extended_newick against the Python formatter (apples/jutil.py:22-96: integral lengths as ints, others as str(float),
+    no length where the input had none, quoted labels as parsed) and apples_consensus against the numpy restatement of
+    apples/PoolRepresentativeWorker.py:17-85 (ties to the first symbol in alphabet order, other symbols not counted)."""
+    from apples_amd import build, fasta, reference, synth
+    from apples_amd import tree as T
+    build.build_io(verbose=False)
+    fasta._io_lib = None
+    for nw in ('((A:0.1,B:2):3,(C:1e-7,(D:0.25,E)x:-0.5)y:17,F:5e-324)r;', '[&R] (a,b,(c,d)e);', 'A;', "('a b':1,'c''d':2.50):0;",
+               '((a:1.0,b:nan):inf,c:-0.0);', synth.random_tree_newick(3000)):
+        t = T.parse_newick(nw)
+        assert T._extended_newick_native(t) == T._extended_newick_py(t)
+    big = T.parse_newick('((A:0.1,B:2):3,C:1e22);')   # an integral length beyond 2^63: left to Python
+    assert T._extended_newick_native(big) is None and T.extended_newick(big) == T._extended_newick_py(big)
+    rng = np.random.default_rng(2)
+    for protein in (False, True):
+        alpha = np.frombuffer(b'ACGT-NX*acgt' if not protein else b'ACDEFGHIKLMNPQRSTVWY-XBZ*', np.uint8)
+        seqs = alpha[rng.integers(0, len(alpha), size=(2000, 131))]
+        mrow = list(rng.permutation(2000))
+        groups, at = [], 0
+        while at < 2000:
+            k = int(rng.integers(1, 60))
+            groups.append((at, min(2000, at + k)))
+            at += k
+        got = reference._consensus_rows(seqs, mrow, groups, protein)
+        want = np.array([reference.consensus(seqs[mrow[a:b]], protein) for a, b in groups], np.uint8)
+        assert np.array_equal(got, want)
