@@ -415,7 +415,9 @@ def other_workload(name, device, steps=3, ds=None, queries=0):
     return {'value': Q / dt, 'unit': 'queries/s', 'ms_per_step': dt * 1e3, 'steps': steps, 'queries': Q,
             'timed': 'table block resident -> placements in host memory' if table else 'host byte arrays -> placements in host memory',
             'per_kernel_ms_per_step': per,
-            'roofline': {k: rf[k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'traffic') if k in rf},
+            # (the committed counter passes are of the workload's own size: no traffic figure for another number of queries)
+            'roofline': {k: (None if k == 'traffic' and queries else rf[k])
+                         for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'traffic') if k in rf},
             'mean_observed': float(np.mean(out['n_obs'])), 'placed': int((out['n_valid'] > 0).sum())}
 
 

@@ -24,6 +24,9 @@ from apples_amd.reference import ReducedReference  # noqa: E402
 pytestmark = pytest.mark.gpu
 NTHREADS = len(os.sched_getaffinity(0))
 NCFG = 40
+# APPLES_FUZZ_SEEDS="20-59": extra seeds for every family (a fuzz campaign outside the suite's two fixed ones)
+_extra = os.environ.get('APPLES_FUZZ_SEEDS', '')
+EXTRA_SEEDS = list(range(int(_extra.split('-')[0]), int(_extra.split('-')[1]) + 1)) if '-' in _extra else []
 
 
 def _place(routes, make, queries, place='place_sequences'):
@@ -41,7 +44,7 @@ def _diff(a, b):
     return '%d rows differ, first %s: %s / %s' % (len(bad), bad[:5], a[bad[0]] if len(bad) else '', b[bad[0]] if len(bad) else '')
 
 
-@pytest.mark.parametrize('seed', [1, 9])
+@pytest.mark.parametrize('seed', [1, 9] + EXTRA_SEEDS)
 def test_clustered_routes_agree(seed):
     """The command line's default route (clustered references, consensus representatives): fused default (cluster-major member
     distances, phase 4 for the listed queries) / a thread per (query, member) pair / the listed queries through full rows /
@@ -71,7 +74,7 @@ def test_clustered_routes_agree(seed):
     assert checked >= 5
 
 
-@pytest.mark.parametrize('seed', [3, 10])
+@pytest.mark.parametrize('seed', [3, 10] + EXTRA_SEEDS)
 def test_singleton_jc69_routes_agree(seed):
     """Singleton clusters, JC69: GEMM-form fused pass + lean / bit sweep (default) against the bit-plane-fed matrix-core kernel
     with merged level lists, and against full rows + general selection with the node map: no distance, selection or
@@ -100,7 +103,7 @@ def test_singleton_jc69_routes_agree(seed):
     assert checked >= 5
 
 
-@pytest.mark.parametrize('seed', [4, 11])
+@pytest.mark.parametrize('seed', [4, 11] + EXTRA_SEEDS)
 def test_scoredist_routes_agree(seed):
     """scoredist, singleton clusters: matrix-core lower-bound filter + exact candidates + lower-bound top-up (default) against
     every pair with the early exit (no filter), against the filter with full rows for the top-up list, and against full
@@ -145,7 +148,7 @@ def test_scoredist_routes_agree(seed):
     assert checked >= 5
 
 
-@pytest.mark.parametrize('seed', [1, 5])
+@pytest.mark.parametrize('seed', [1, 5] + EXTRA_SEEDS)
 def test_distance_table_routes_against_c_oracle(seed):
     """-d input (apples/PoolQueryWorker.py:44-59): odd and even numbers of columns (rows then start 8- or 16-byte aligned, which
     picks the loads of the selection kernels), columns in random order, columns that are not tree leaves, negative and zero
