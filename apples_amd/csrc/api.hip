@@ -418,10 +418,11 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // one-hot operand image of the reference rows for the matrix-core filter of the fused pass (dist_sd.hip): 10 bytes per
         // site and slot (253 MB at 50 000 x 500)
-        if (a.all_singleton && !(ctx->dbg & APPLES_DBG_NO_SD_GEMM) && sd_steps(a.L) >= 2 && a.L <= 8192 &&
-            a.slots_pad <= 524288) {  // (the evaluating kernels stage a query row and the segment counts' prefix in LDS)
+        if (a.all_singleton && !(ctx->dbg & APPLES_DBG_NO_SD_GEMM) && sd_steps(a.L) >= 2 && a.L <= 4096 &&
+            a.slots_pad <= 458752) {  // (the evaluating kernels stage a query row and the segment counts' prefix in LDS: 64 KB per workgroup)
+            a.sd_fp6 = (ctx->dbg & APPLES_DBG_SD_FP6) != 0;  // (off by default: DESIGN.md section 5)
             uint8_t codes[400];
-            sd_table_codes(kBlosum45, codes);
+            sd_table_codes(kBlosum45, codes, a.sd_fp6);
             if (dev_upload(ctx, &ctx->sd_tq4, codes, 400)) return 1;
             if (dev_alloc(ctx, &a.sd_ref4, a.slots_pad * (int64_t)sd_steps(a.L) * 64)) return 1;
             if (dev_alloc(ctx, &a.sd_nvr, a.slots_pad)) return 1;
@@ -783,7 +784,7 @@ int alloc_block(apples_ctx *ctx, int64_t n, const int32_t *self_row, int planes,
         HIP_TRY(ctx, hipMemsetAsync(qb->aa_mask, 0, (size_t)qb->n_pad * (Lpad / 16) * 2, st));
         if (a.sd_ref4) {  // operand image for the matrix-core filter (dist_sd.hip), tiled like the reference's
             const int64_t n_img = round_up(qb->n_pad, 256) + 256;  // a sub-batch may start at any multiple of 32
-            if (blk_alloc(ctx, &qb->sd_q4, n_img * sd_steps(a.L) * 64)) return 1;
+            if (blk_alloc(ctx, &qb->sd_q4, sd_query_image_bytes(ctx, n_img))) return 1;
             if (blk_alloc(ctx, &qb->sd_nvq, n_img)) return 1;
         }
     } else {
@@ -1243,7 +1244,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             const bool lb_topup = qb.sd_q4 && sd_gemm_usable(ctx) && !no_sd_topup && w.dist_rows >= nq;
             if (lb_topup && ctx->sd_list_rows < w.batch) {
                 dev_free(ctx->sd_list_img); ctx->sd_list_img = nullptr; ctx->sd_list_rows = 0;
-                if (dev_alloc(ctx, &ctx->sd_list_img, round_up(w.batch, 256) * sd_steps(a.L) * 64)) return 1;
+                if (dev_alloc(ctx, &ctx->sd_list_img, sd_query_image_bytes(ctx, round_up(w.batch, 256)))) return 1;
                 ctx->sd_list_rows = w.batch;
             }
             if (for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
@@ -1366,7 +1367,7 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
             {"APPLES_NO_SD_GEMM", APPLES_DBG_NO_SD_GEMM}, {"APPLES_CLUSTER_BY_QUERY", APPLES_DBG_CLUSTER_BY_QUERY},
             {"APPLES_NO_CLUSTER_TOPUP", APPLES_DBG_NO_CLUSTER_TOPUP}, {"APPLES_NO_STREAM_SELECT", APPLES_DBG_NO_STREAM_SELECT},
             {"APPLES_NO_TOPUP_KERNEL", APPLES_DBG_NO_TOPUP_KERNEL}, {"APPLES_NO_CLUSTER_BIG", APPLES_DBG_NO_CLUSTER_BIG},
-            {"APPLES_NO_SD_TOPUP", APPLES_DBG_NO_SD_TOPUP}};
+            {"APPLES_NO_SD_TOPUP", APPLES_DBG_NO_SD_TOPUP}, {"APPLES_SD_FP6", APPLES_DBG_SD_FP6}};
         for (const auto &k : knobs)
             if (getenv(k.env)) ctx->dbg |= k.bit;
     }

@@ -133,6 +133,7 @@ struct DevAlign {
     uint8_t *sd_ref4 = nullptr;   // scoredist, singleton clusters: one-hot fp4 operand image of the reference rows (dist_sd.hip),
                                   // [slots_pad / 256][steps][1024 chunks of 16 B], 20 values per site
     float *sd_nvr = nullptr;      // [slots_pad] sites of the row that are not gaps (-1: no row in the slot)
+    bool sd_fp6 = false;          // the query images hold fp6 table values (24 bytes per 32), not fp4 (APPLES_DBG_SD_FP6; default fp4)
     int32_t *slot_node = nullptr; // [n_refs] tree node or -1
     int32_t *slot_level = nullptr;// [n_refs] level or -1
     int32_t *lvl_slots = nullptr; // [height + 2] entry l + 1: slots with a level above l (slots are sorted by level, deepest first); null
@@ -312,7 +313,8 @@ int launch_scoredist_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, i
                             const int32_t *qcount, double *d_dist);
 // dist_sd.hip: the fused scoredist pass as a lower bound on the matrix cores + exact evaluation of the candidates
 #define SD_GEMM_MAX_THRESHOLD 0.25  // -f beyond this: too many pairs pass for a filter to pay (full rows instead)
-void sd_table_codes(const double *blosum20x20, uint8_t *codes);
+void sd_table_codes(const double *blosum20x20, uint8_t *codes, bool fp6);
+int64_t sd_query_image_bytes(const apples_ctx *ctx, int64_t rows256);  // bytes of a query operand image of that many rows
 int sd_steps(int L);                // 128-value K steps of the operand images
 bool sd_gemm_usable(const apples_ctx *ctx);
 int launch_sd_expand(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *d_out, int64_t n_img, hipStream_t st,

@@ -33,12 +33,18 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 #define SD_STRIP 4           // reference tiles per strip
 #endif
 #define SD_IMG (SD_T * 64)   // bytes of one tile-step image: 256 rows x 128 fp4 values
+#define SD_IMG6 (SD_T * 96)  // ... x 128 fp6 values: the fp4-shaped part (16 bytes of each lane's 24) + 8 KB of [chunk][row] 8-byte tails
 
 namespace {
 
 __device__ __forceinline__ v16f_t sd_mfma(const v4i_t &a, const v4i_t &b, const v16f_t &c) {
     const v8i_t a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0, 0, 0);  // fp4 x fp4, unscaled
+}
+// the query side as fp6 (e2m3: 32 values = 192 bits per lane, the matrix cores' fp4 rate), the one-hot side fp4
+__device__ __forceinline__ v16f_t sd_mfma6(const v4i_t &a, const int2 &a2, const v4i_t &b, const v16f_t &c) {
+    const v8i_t a8 = {a[0], a[1], a[2], a[3], a2.x, a2.y, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 2, 4, 0, 0, 0, 0);
 }
 
 // rows -> operand image.  K index of (site s, residue a) = 20 s + a; a step is 128 K values, chunk c of a row its
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_expand(const uint8_t *__restr
                                                           uint4 *__restrict__ out, int64_t n_img,
                                                           const int32_t *__restrict__ src_row, int64_t row0,
                                                           const uint8_t *__restrict__ tq4, float *__restrict__ nv,
-                                                          const int32_t *__restrict__ n_dev) {
+                                                          const int32_t *__restrict__ n_dev, int fp6) {
     // two values per byte and 20 per site: a byte never straddles sites, so the image is a byte table look-up -- rowb[v][h] =
     // values 2 h, 2 h + 1 of the row of residue v (row 20 = a gap: zeros)
     __shared__ uint8_t rowb[21 * 10];
@@ -72,6 +78,31 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_expand(const uint8_t *__restr
     const int64_t rb = idx >> 2;
     const int b = (int)(rb % NB);
     const int64_t q = rb / NB;
+    if (fp6) {
+        // 32 six-bit codes per chunk (value e at bits 6 e .. 6 e + 5 of the lane's 192): the first 128 bits where the fp4 chunk would
+        // lie, the last 64 in the tile-step's tail area [chunk][row]
+        uint32_t w6[6] = {0, 0, 0, 0, 0, 0};
+        if (q < n) {
+            const uint8_t *row = raw + (src_row ? (int64_t)src_row[q] : q) * (int64_t)L;
+            const int k0 = b * 128 + c * 32;
+            int s = k0 / 20, a = k0 - s * 20;
+            uint32_t v = s < L ? aa_index(row[s]) : 20u;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const uint32_t code = v < 20u ? tq4[v * 20u + a] : 0u;
+                const int bit = 6 * e;
+                w6[bit >> 5] |= code << (bit & 31);
+                if ((bit & 31) > 26) w6[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                if (++a == 20) { a = 0; ++s; v = s < L ? aa_index(row[s]) : 20u; }
+            }
+        }
+        const int64_t ar = row0 + q, tile = ar >> 8;
+        const int rr = (int)(ar & 255), sw = (rr >> 2) & 3;
+        uint8_t *ts = reinterpret_cast<uint8_t *>(out) + (tile * NB + b) * (int64_t)SD_IMG6;
+        reinterpret_cast<uint4 *>(ts)[rr * 4 + (c ^ sw)] = make_uint4(w6[0], w6[1], w6[2], w6[3]);
+        reinterpret_cast<uint2 *>(ts + SD_IMG)[c * 256 + rr] = make_uint2(w6[4], w6[5]);
+        return;
+    }
     uint32_t w[4] = {0, 0, 0, 0};
     if (q < n) {
         const uint8_t *row = raw + (src_row ? (int64_t)src_row[q] : q) * (int64_t)L;
@@ -111,7 +142,12 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_nv(const uint16_t *__restrict
 // R = (NB - 2) % 3: the shape of the main loop's tail, fixed per launch (as k_jc69_gemm)
 // ROWS: the bounds themselves, for a list of queries (the top-up path): the query image holds the listed queries in list
 // order, *qcount of them; acc of (list entry r, slot) goes to row qlist[r] of `rows` (floats, row stride in doubles)
-template <int R, bool ROWS>
+// F6 (APPLES_DBG_SD_FP6, off by default): the query image holds fp6 values (SD_IMG6 bytes per tile-step), 24 bytes per lane and
+// MFMA: the table rounded down to the e2m3 grid keeps 0.955 of tot where the fp4 grid keeps 0.83, which halves the candidates
+// (k_sd_exact 4.2 -> 1.9 ms per C4 pass) -- and costs the filter more than that: 10.5 -> 13.6 ms (a quarter more bytes through
+// an LDS-DMA path that already takes a third of the kernel, the mixed fp6 x fp4 instruction 7 % slower in a bare loop,
+// 256 registers).  Same bytes out; kept as the measured alternative.
+template <int R, bool ROWS, bool F6>
 __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ rf4, const uint8_t *__restrict__ qf4,
                                                     int64_t qrow0, int64_t slots_pad, int NB, int64_t nq, int TQ, int TR,
                                                     const float *__restrict__ nvr, const float *__restrict__ nvq, float k4c,
@@ -123,10 +159,11 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
         TQ = (int)((nq + SD_T - 1) / SD_T);
         if (TQ == 0) return;
     }
-    constexpr int QT = SD_T, AI = QT * 64, GEN = AI + SD_IMG;
+    constexpr int QT = SD_T, AI = QT * 64, A2 = F6 ? QT * 32 : 0, GEN = AI + A2 + SD_IMG, QIMG = F6 ? SD_IMG6 : SD_IMG;
     __shared__ __attribute__((aligned(1024))) uint8_t lds[3 * GEN];
 #define Aq(g) (lds + (g) * GEN)
-#define Br(g) (lds + (g) * GEN + AI)
+#define A2q(g) (lds + (g) * GEN + AI)
+#define Br(g) (lds + (g) * GEN + AI + A2)
     // persistent workgroups, one per CU: XCD x takes the strips x, x + 8, ... of SD_STRIP reference tiles; within the XCD the
     // tiles (query tile major, the strip's reference tiles inside) are dealt round-robin to its workgroups
     const int xcd = blockIdx.x & 7;
@@ -148,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
     // DMA roles (dist_gemm.hip): a tile-step image is 16 pieces of 1 KB; this wavefront moves pieces 2 wv, 2 wv + 1 of the
     // query image and of the reference image.  The query tile starts at image row qrow0 + q0, a multiple of 32: its rows
     // may lie in two image tiles.
-    uint32_t doff[2];
+    uint32_t doff[3];
     const uint8_t *qtile, *rtile;
     auto set_tile = [&](int64_t qt_, int64_t rt_) __attribute__((always_inline)) {
         const int64_t qabs = qrow0 + qt_ * QT;
@@ -156,9 +193,13 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int row = (wv * 2 + k) * 16 + (lane >> 2), slot = lane & 3, ar = qin + row;
-            doff[k] = (uint32_t)(((ar >> 8) * NB * 1024 + (ar & 255) * 4 + slot) * 16);
+            doff[k] = (uint32_t)((ar >> 8) * NB * QIMG + (ar & 255) * 64 + slot * 16);
         }
-        qtile = qf4 + (qabs >> 8) * (int64_t)NB * SD_IMG;
+        if (F6) {  // this wavefront's piece of the 8-byte tails: chunk wv >> 1, rows (wv & 1) * 128 + 2 lane, + 1 (one image tile: qin is even)
+            const int ar = qin + (wv & 1) * 128 + 2 * lane;
+            doff[2] = (uint32_t)((ar >> 8) * NB * QIMG + SD_IMG + ((wv >> 1) * 256 + (ar & 255)) * 8);
+        }
+        qtile = qf4 + (qabs >> 8) * (int64_t)NB * QIMG;
         rtile = rf4 + rt_ * (int64_t)NB * SD_IMG;
     };
     set_tile(qt, rt);
@@ -171,9 +212,10 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
     v16f_t acc[2][4];
     auto dma = [&](int b, int g, int part) __attribute__((always_inline)) {  // part 0: query pieces, 1: reference pieces
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const uint8_t *src = part == 0 ? (qtile + b * SD_IMG) + doff[k] : (rtile + b * SD_IMG + k * 1024) + roff;
-            uint8_t *dst = part == 0 ? Aq(g) + (wv * 2 + k) * 1024 : Br(g) + (wv * 2 + k) * 1024;
+        for (int k = 0; k < (F6 ? 3 : 2); ++k) {
+            if (k == 2 && part != 0) continue;
+            const uint8_t *src = part == 0 ? (qtile + b * QIMG) + doff[k] : (rtile + b * SD_IMG + k * 1024) + roff;
+            uint8_t *dst = part == 0 ? (k == 2 ? A2q(g) + wv * 1024 : Aq(g) + (wv * 2 + k) * 1024) : Br(g) + (wv * 2 + k) * 1024;
 #ifndef SD_NO_DMA  // (timing experiments: scripts/r04_sd_parts_exp.sh)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -181,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
         }
     };
     v4i_t fa[2][2], fb[2][4];  // fragment sets: [0] the step's first K half, [1] its second
+    int2 fa2[2][2];            // fp6: the last 64 bits of the query side's 192
     auto load_frags = [&](int g, int h) __attribute__((always_inline)) {
 #ifdef SD_NO_FRAGS
         if (g >= 0) return;
@@ -188,6 +231,11 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
         const uint8_t *A = Aq(g) + arow + coff[h], *B = Br(g) + brow + coff[h];
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[h][i] = *reinterpret_cast<const v4i_t *>(A + i * 32 * 64);
+        if (F6) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                fa2[h][i] = *reinterpret_cast<const int2 *>(A2q(g) + ((h * 2 + fh) * 256 + wq * 64 + i * 32 + fr) * 8);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[h][j] = *reinterpret_cast<const v4i_t *>(B + j * 32 * 64);
     };
@@ -195,7 +243,8 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = sd_mfma(fa[h][i], fb[h][j], acc[i][j]);
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = F6 ? sd_mfma6(fa[h][i], fa2[h][i], fb[h][j], acc[i][j]) : sd_mfma(fa[h][i], fb[h][j], acc[i][j]);
     };
     // One step = 128 K values = 2 sections of 8 MFMAs per wavefront, generation g = step % 3.  Entry: set 0 holds the
     // first half's fragments (read after the previous barrier).  Section 0: the second half's fragments are requested, the
@@ -210,14 +259,15 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (k == 1 || k == 4) {
+            if (k < (F6 ? 8 : 6)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (k == 1 || k == 4 || (F6 && k == 6)) {
                 __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (feed) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        if (feed && F6) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if (feed) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -227,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (k < (F6 ? 8 : 6)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (k == 1 || k == 4) {
                 __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -330,7 +380,8 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
             set_tile(nqt, nrt);
             dma(0, 0, 0); dma(0, 0, 1);
             dma(1, 1, 0); dma(1, 1, 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (F6) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -370,6 +421,7 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
         l = nl; qt = nqt; rt = nrt;
     }
 #undef Aq
+#undef A2q
 #undef Br
 }
 
@@ -710,14 +762,27 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restri
 }  // namespace
 
 // fp4 codes of the rounded-down table: code of the largest v in {0, .5, 1, 1.5, 2, 3, 4, 6} with v / 4 <= T[a][b]
-void sd_table_codes(const double *blosum20x20, uint8_t *codes /* [20][20] */) {
+// fp6: the same on the e2m3 grid (code = exponent << 3 | mantissa: m / 8 for exponent 0, 2^(e - 1) (1 + m / 8) above: 0 .. 7.5)
+void sd_table_codes(const double *blosum20x20, uint8_t *codes /* [20][20] */, bool fp6) {
     static const double grid[8] = {0, 0.5, 1, 1.5, 2, 3, 4, 6};
     for (int i = 0; i < 400; ++i) {
         int c = 0;
-        for (int k = 0; k < 8; ++k)
-            if (grid[k] / 4.0 <= blosum20x20[i]) c = k;
+        if (fp6) {
+            for (int k = 0; k < 32; ++k) {
+                const int e = k >> 3, m = k & 7;
+                const double v = e == 0 ? m / 8.0 : std::ldexp(1.0 + m / 8.0, e - 1);
+                if (v / 4.0 <= blosum20x20[i]) c = k;  // (the grid grows with the code)
+            }
+        } else {
+            for (int k = 0; k < 8; ++k)
+                if (grid[k] / 4.0 <= blosum20x20[i]) c = k;
+        }
         codes[i] = (uint8_t)c;
     }
+}
+
+int64_t sd_query_image_bytes(const apples_ctx *ctx, int64_t rows256) {  // rows256: image rows, a multiple of 256
+    return rows256 / 256 * sd_steps(ctx->aln.L) * (int64_t)(ctx->aln.sd_fp6 ? SD_IMG6 : SD_IMG);
 }
 
 int sd_steps(int L) { return (20 * L + 127) / 128; }
@@ -737,7 +802,7 @@ int launch_sd_expand(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *
     const int64_t total = n_img * NB * 4;
     hipLaunchKernelGGL(k_sd_expand, dim3((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0, st ? st : ctx->stream,
                        d_raw, n, ctx->aln.L, NB, reinterpret_cast<uint4 *>(d_out), n_img, d_src_row, row0,
-                       query ? ctx->sd_tq4 : (const uint8_t *)nullptr, d_nv, d_n);
+                       query ? ctx->sd_tq4 : (const uint8_t *)nullptr, d_nv, d_n, query && ctx->aln.sd_fp6 ? 1 : 0);
     if (d_nv)
         hipLaunchKernelGGL(k_sd_nv, dim3((unsigned)((n_img + APPLES_TPB - 1) / APPLES_TPB)), dim3(APPLES_TPB), 0, st ? st : ctx->stream,
                            d_mask, n, n_img, (ctx->aln.L + 15) / 16, ref_stride, d_nv + row0);
@@ -762,11 +827,12 @@ int launch_sd_filter(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t 
     float k4c = (float)(4.0 * c * (1.0 + 1e-6));
     k4c = std::nextafterf(k4c, INFINITY);
     const int R = (NB - 2) % 3;
-#define SD_LAUNCH(R_)                                                                                                     \
-    hipLaunchKernelGGL((k_sd_gemm<R_, false>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, a.sd_ref4, qb.sd_q4, q0,  \
-                       a.slots_pad, NB, nq, TQ, TR, a.sd_nvr, qb.sd_nvq, k4c, seg_slot, seg_cnt, (const int32_t *)nullptr, \
+#define SD_LAUNCH(R_, F6_)                                                                                                     \
+    hipLaunchKernelGGL((k_sd_gemm<R_, false, F6_>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, a.sd_ref4, qb.sd_q4, q0,  \
+                       a.slots_pad, NB, nq, TQ, TR, a.sd_nvr, qb.sd_nvq, k4c, seg_slot, seg_cnt, (const int32_t *)nullptr,      \
                        (const int32_t *)nullptr, (double *)nullptr, (int64_t)0)
-    if (R == 0) SD_LAUNCH(0); else if (R == 1) SD_LAUNCH(1); else SD_LAUNCH(2);
+    if (a.sd_fp6) { if (R == 0) SD_LAUNCH(0, true); else if (R == 1) SD_LAUNCH(1, true); else SD_LAUNCH(2, true); }
+    else { if (R == 0) SD_LAUNCH(0, false); else if (R == 1) SD_LAUNCH(1, false); else SD_LAUNCH(2, false); }
 #undef SD_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -804,11 +870,12 @@ int launch_sd_topup(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t n
     }
     const int64_t grid = std::max(8, ctx->n_cu / 8 * 8);
     const int R = (NB - 2) % 3;
-#define SD_LAUNCH(R_)                                                                                                     \
-    hipLaunchKernelGGL((k_sd_gemm<R_, true>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, a.sd_ref4, img, (int64_t)0, \
-                       a.slots_pad, NB, nq_max, 0, TR, a.sd_nvr, (const float *)nullptr, 0.f, (int32_t *)nullptr,        \
+#define SD_LAUNCH(R_, F6_)                                                                                                     \
+    hipLaunchKernelGGL((k_sd_gemm<R_, true, F6_>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, a.sd_ref4, img, (int64_t)0, \
+                       a.slots_pad, NB, nq_max, 0, TR, a.sd_nvr, (const float *)nullptr, 0.f, (int32_t *)nullptr,             \
                        (int32_t *)nullptr, qlist, qcount, lbrows, a.slots_pad)
-    if (R == 0) SD_LAUNCH(0); else if (R == 1) SD_LAUNCH(1); else SD_LAUNCH(2);
+    if (a.sd_fp6) { if (R == 0) SD_LAUNCH(0, true); else if (R == 1) SD_LAUNCH(1, true); else SD_LAUNCH(2, true); }
+    else { if (R == 0) SD_LAUNCH(0, false); else if (R == 1) SD_LAUNCH(1, false); else SD_LAUNCH(2, false); }
 #undef SD_LAUNCH
     const unsigned wgs = (unsigned)std::min<int64_t>(nq_max, (int64_t)ctx->n_cu * 8);
     hipLaunchKernelGGL(k_sd_topup, dim3(wgs), dim3(APPLES_TPB), (size_t)(Lpad + Lpad / 8), ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow, qb.aa_idx + q0 * Lpad,

@@ -18,14 +18,18 @@ __global__ __launch_bounds__(512, 2) void k(const int *__restrict__ in, float *_
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) b[i][j] = in[(tid * 16 + i * 4 + j + 77) & 0xffff];
     for (int i = 0; i < 2; ++i) for (int j = 4; j < 8; ++j) a[i][j] = 0;
     for (int i = 0; i < 4; ++i) for (int j = 4; j < 8; ++j) b[i][j] = 0;
-    if (SHAPE == 32) {
+    if (SHAPE == 32 || SHAPE == 326) {
+        // (SHAPE 326: the first operand as fp6 -- 6 of its 8 dwords in use -- against fp4: the mixed form of dist_sd.hip's F6 filter)
+        if (SHAPE == 326) for (int i = 0; i < 2; ++i) { a[i][4] = a[i][0] ^ 0x1111; a[i][5] = a[i][1] ^ 0x2222; }
         v16f acc[2][4];
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
         for (int it = 0; it < iters; ++it)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[i][j], 4, 4, 0, 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = SHAPE == 326 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[i][j], 2, 4, 0, 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[i][j], 4, 4, 0, 0, 0, 0);
         float s = 0;
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int x = 0; x < 16; ++x) s += acc[i][j][x];
         out[tid] = s;
@@ -54,18 +58,19 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int waves = 0; waves < 2; ++waves) {
         const int threads = waves ? 512 : 256;
-        for (int shape : {32, 16, 32, 16}) {
+        for (int shape : {32, 16, 326, 32, 16, 326}) {
             // iters: 32x32x64: 8 MFMAs per iteration x 131072 FLOP; 16x16x128: 32 MFMAs x 65536 FLOP
-            const int iters = shape == 32 ? 40000 : 10000;
+            const int iters = shape != 16 ? 40000 : 10000;
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0);
                 if (shape == 32) hipLaunchKernelGGL(k<32>, dim3(256), dim3(threads), 0, 0, in, out, iters);
+                else if (shape == 326) hipLaunchKernelGGL(k<326>, dim3(256), dim3(threads), 0, 0, in, out, iters);
                 else hipLaunchKernelGGL(k<16>, dim3(256), dim3(threads), 0, 0, in, out, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
             }
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            const double flop = (double)256 * (threads / 64) * iters * (shape == 32 ? 8 * 131072.0 : 32 * 65536.0);
-            printf("%d wave(s) per SIMD, shape %s: %.2f ms, %.0f TFLOP/s\n", threads / 256, shape == 32 ? "32x32x64 " : "16x16x128", ms, flop / ms / 1e9);
+            const double flop = (double)256 * (threads / 64) * iters * (shape != 16 ? 8 * 131072.0 : 32 * 65536.0);
+            printf("%d wave(s) per SIMD, shape %s: %.2f ms, %.0f TFLOP/s\n", threads / 256, shape == 32 ? "32x32x64 fp4 x fp4" : (shape == 326 ? "32x32x64 fp6 x fp4" : "16x16x128 fp4 x fp4"), ms, flop / ms / 1e9);
         }
     }
     return 0;

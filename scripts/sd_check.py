@@ -15,7 +15,7 @@ def routes(N, L, Q, thr=0.2, b=25, seed=3, max_batch=0):
         q[4] = ord('-')
     nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
     outs = {}
-    for name, dbg in (('gemm', ()), ('early', ('no_sd_gemm',)), ('nofuse', ('no_fuse',))):
+    for name, dbg in (('gemm', ()), ('gemm_fp6', ('sd_fp6',)), ('early', ('no_sd_gemm',)), ('nofuse', ('no_fuse',))):
         e = Engine(d.tree, d.ref_seqs, nodes, protein=True, method='FM', threshold=thr, baseobs=b, debug=dbg, max_batch=max_batch)
         t0 = time.perf_counter()
         outs[name] = e.place_sequences(q)
@@ -23,9 +23,9 @@ def routes(N, L, Q, thr=0.2, b=25, seed=3, max_batch=0):
         tm = e.timing()
         e.close()
         print('  %-7s %.1f ms  dist %.2f select %.2f sweep %.2f' % (name, dt * 1e3, tm['dist_ms'], tm['select_ms'], tm['sweep_ms']), flush=True)
-    ok = outs['gemm'].tobytes() == outs['nofuse'].tobytes() and outs['early'].tobytes() == outs['nofuse'].tobytes()
+    ok = all(outs[k].tobytes() == outs['nofuse'].tobytes() for k in ('gemm', 'gemm_fp6', 'early'))
     if not ok:
-        for k in ('gemm', 'early'):
+        for k in ('gemm', 'gemm_fp6', 'early'):
             bad = np.nonzero([a.tobytes() != b_.tobytes() for a, b_ in zip(outs[k], outs['nofuse'])])[0]
             print('  MISMATCH', k, len(bad), bad[:10])
             for i in bad[:3]:

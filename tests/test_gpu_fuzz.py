@@ -105,12 +105,12 @@ def test_singleton_jc69_routes_agree(seed):
 
 @pytest.mark.parametrize('seed', [4, 11] + EXTRA_SEEDS)
 def test_scoredist_routes_agree(seed):
-    """scoredist, singleton clusters: matrix-core lower-bound filter + exact candidates + lower-bound top-up (default) against
-    every pair with the early exit (no filter), against the filter with full rows for the top-up list, and against full
+    """scoredist, singleton clusters: matrix-core lower-bound filter (fp4 table values) + exact candidates + lower-bound top-up
+    (default) against the same with fp6 table values, against every pair with the early exit (no filter), against the filter with full rows for the top-up list, and against full
     rows + general selection; small backbones also against the C oracle (edges, flags and counts equal, lengths to 1e-9:
     the reference's own summation order is BLAS-internal)."""
     rng = np.random.default_rng(seed)
-    routes = (('default', ()), ('every_pair', ('no_sd_gemm',)), ('rows_topup', ('no_sd_topup',)), ('no_fuse', ('no_fuse',)))
+    routes = (('default', ()), ('fp6', ('sd_fp6',)), ('every_pair', ('no_sd_gemm',)), ('rows_topup', ('no_sd_topup',)), ('no_fuse', ('no_fuse',)))
     checked = 0
     for c in range(NCFG):
         n = int(rng.choice([40, 257, 600, 1500, 5000, 20000])); L = int(rng.integers(7, 1200)); nq = int(rng.integers(1, 700))
@@ -126,7 +126,7 @@ def test_scoredist_routes_agree(seed):
         out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, protein=True, method=m, threshold=thr, baseobs=b,
                                                 max_batch=mb, debug=dbg), q)
         tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s' % (seed, c, n, L, nq, gap, thr, b, mb, m)
-        for k in ('every_pair', 'rows_topup', 'no_fuse'):
+        for k in ('fp6', 'every_pair', 'rows_topup', 'no_fuse'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
             co = COracle(d.tree, d.ref_seqs, nodes, protein=True, method=m, criterion='MLSE', threshold=thr, baseobs=b, threads=NTHREADS)
