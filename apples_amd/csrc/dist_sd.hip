@@ -433,8 +433,9 @@ __global__ __launch_bounds__(512, 2) void k_sd_gemm(const uint8_t *__restrict__ 
 // piece (one request per sector), the pieces are staged in the wavefront's own LDS area (80-byte stride: conflict-free
 // 16-byte reads) and every lane reads its own slot's bytes back; the next piece is on its way meanwhile.  All 64 lanes call
 // (a lane without a pair passes any valid slot and drops the result).  The query's row and masks are staged in LDS by the
-// caller (lq, lqm) and come back as scalars: one broadcast read + readfirstlane per 16 sites, where a scalar memory load
-// per 16 sites had every wavefront wait for the scalar cache between its short bursts of lookups.
+// caller (lq: per site the byte offset of its table row, residue index x 168, as 16-bit values; lqm: the masks): two broadcast
+// reads per 16 sites, where a scalar memory load per 16 sites had every wavefront wait for the scalar cache between its short
+// bursts of look-ups, and scalars by readfirstlane two scalar operations per site.
 #define SDE_PIECE 64
 #define SDE_STRIDE 80
 #define SDE_WBUF (64 * SDE_STRIDE)  // bytes of LDS per wavefront
@@ -476,17 +477,18 @@ __device__ __forceinline__ double sd_eval64(const uint8_t *__restrict__ rrows, c
             const int s16 = c * 4 + s;
             if (s16 < n16 && !(dbg & 2)) {  // (wave-uniform: the query row ends with the alignment)
                 const uint4 cw = *reinterpret_cast<const uint4 *>(wbuf + lane * SDE_STRIDE + s * 16);
-                const uint4 qw = *reinterpret_cast<const uint4 *>(lq + s16 * 16);
+                // the query's table-row offsets (residue index x 168 bytes) come ready-made as 16-bit values, 16 per site block
+                // (two broadcast reads): the look-up's address is then ONE vector add with a word and a byte selected
+                const uint4 qw0 = *reinterpret_cast<const uint4 *>(lq + s16 * 32), qw1 = *reinterpret_cast<const uint4 *>(lq + s16 * 32 + 16);
                 const uint32_t rmask = ((s & 2 ? cm.y : cm.x) >> (16 * (s & 1))) & 0xffffu;
-                valid += __popc(rmask & (uint32_t)__builtin_amdgcn_readfirstlane((int)lqm[s16]));
+                valid += __popc(rmask & (uint32_t)lqm[s16]);
                 const uint32_t rr[4] = {cw.x, cw.y, cw.z, cw.w};
-                const uint32_t qq[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)qw.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)qw.y),
-                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)qw.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)qw.w)};
+                const uint32_t qq[8] = {qw0.x, qw0.y, qw0.z, qw0.w, qw1.x, qw1.y, qw1.z, qw1.w};
                 double v[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const uint32_t r8 = (rr[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                    const uint32_t qr = ((qq[k >> 2] >> (8 * (k & 3))) & 0xffu) * 168u;  // 21 columns * 8 bytes
+                    const uint32_t qr = (qq[k >> 1] >> (16 * (k & 1))) & 0xffffu;
                     v[k] = *reinterpret_cast<const double *>(Tb + qr + r8);
                 }
 #pragma unroll
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restri
     __shared__ int sh_next;
     __shared__ __attribute__((aligned(16))) uint8_t sh_wbuf[NW][SDE_WBUF];
     __shared__ int sh_wslot[NW][64];
-    extern __shared__ __attribute__((aligned(16))) uint8_t sh_dyn[];  // the query's row (Lpad bytes), its masks, the prefix [n_seg + 1]
+    extern __shared__ __attribute__((aligned(16))) uint8_t sh_dyn[];  // the query's table-row offsets (2 Lpad bytes), its masks, the prefix [n_seg + 1]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < 21 * 21; i += TPB) T[i] = table[i];
     const char *Tb = reinterpret_cast<const char *>(T);
@@ -546,12 +548,10 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restri
     const int n16 = Lpad / 16;
     const int n_seg = (int)(slots_pad >> 6);
     uint8_t *sh_q = sh_dyn;
-    uint16_t *sh_qm = reinterpret_cast<uint16_t *>(sh_dyn + Lpad);
-    int *pref = reinterpret_cast<int *>(sh_dyn + (Lpad + Lpad / 8 + 15) / 16 * 16);
-    for (int i = tid; i < n16; i += TPB) {
-        *reinterpret_cast<uint4 *>(sh_q + i * 16) = *reinterpret_cast<const uint4 *>(qa + q * (int64_t)Lpad + i * 16);
-        sh_qm[i] = qm[q * (int64_t)n16 + i];
-    }
+    uint16_t *sh_qm = reinterpret_cast<uint16_t *>(sh_dyn + 2 * Lpad);
+    int *pref = reinterpret_cast<int *>(sh_dyn + (2 * Lpad + Lpad / 8 + 15) / 16 * 16);
+    for (int i = tid; i < Lpad; i += TPB) reinterpret_cast<uint16_t *>(sh_q)[i] = (uint16_t)(qa[q * (int64_t)Lpad + i] * 168u);
+    for (int i = tid; i < n16; i += TPB) sh_qm[i] = qm[q * (int64_t)n16 + i];
     const int32_t *cnt = seg_cnt + q * (int64_t)n_seg;
     const int32_t *sslot = seg_slot + q * slots_pad;
     double *sd = seg_d + q * slots_pad;
@@ -644,22 +644,21 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restri
     __shared__ int wqueue[NW][128];
     __shared__ __attribute__((aligned(16))) uint8_t sh_wbuf[NW][SDE_WBUF];
     __shared__ int sh_wslot[NW][64];
-    extern __shared__ __attribute__((aligned(16))) uint8_t sh_q[];  // the query's row (Lpad bytes), then its masks
+    extern __shared__ __attribute__((aligned(16))) uint8_t sh_q[];  // the query's table-row offsets (2 Lpad bytes), then its masks
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < 21 * 21; i += TPB) T[i] = table[i];
     const char *Tb = reinterpret_cast<const char *>(T);
     const int n16 = Lpad / 16;
-    uint16_t *sh_qm = reinterpret_cast<uint16_t *>(sh_q + Lpad);
+    uint16_t *sh_qm = reinterpret_cast<uint16_t *>(sh_q + 2 * Lpad);
     const int n_list = *qcount;
     const double INF = __longlong_as_double(0x7ff0000000000000LL);
     for (int r = blockIdx.x; r < n_list; r += gridDim.x) {
         const int64_t q = __builtin_amdgcn_readfirstlane(qlist[r]);
         float *lb = reinterpret_cast<float *>(lbrows + q * row_stride);
         double *out = out_rows + (int64_t)r * row_stride;
-        for (int i = tid; i < n16; i += TPB) {  // (the previous list entry's last use lies behind its closing barrier)
-            *reinterpret_cast<uint4 *>(sh_q + i * 16) = *reinterpret_cast<const uint4 *>(qa + q * (int64_t)Lpad + i * 16);
-            sh_qm[i] = qm[q * (int64_t)n16 + i];
-        }
+        // (the previous list entry's last use lies behind its closing barrier)
+        for (int i = tid; i < Lpad; i += TPB) reinterpret_cast<uint16_t *>(sh_q)[i] = (uint16_t)(qa[q * (int64_t)Lpad + i] * 168u);
+        for (int i = tid; i < n16; i += TPB) sh_qm[i] = qm[q * (int64_t)n16 + i];
         const float nq_ = nvq[qrow0 + q];
         float *keys = lb;  // the row of bounds becomes the row of keys in place (pass A below)
         auto bin_of = [&](double x) -> int { return x >= (double)(SDT_BINS - 1) / SDT_SCALE ? SDT_BINS - 1 : (int)(x * SDT_SCALE); };
@@ -843,7 +842,7 @@ int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t n
     if (nq == 0) return 0;
     const DevAlign &a = ctx->aln;
     const int Lpad = (a.L + 15) / 16 * 16;
-    const size_t dyn = (size_t)((Lpad + Lpad / 8 + 15) / 16 * 16) + ((size_t)(a.slots_pad >> 6) + 1) * sizeof(int);
+    const size_t dyn = (size_t)((2 * Lpad + Lpad / 8 + 15) / 16 * 16) + ((size_t)(a.slots_pad >> 6) + 1) * sizeof(int);
     static const int sd_dbg = getenv("APPLES_SD_DBG") ? atoi(getenv("APPLES_SD_DBG")) : 0;  // timing experiments only (wrong results)
     hipLaunchKernelGGL(k_sd_exact, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow,
                        qb.aa_idx + q0 * Lpad, qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L,
@@ -878,7 +877,7 @@ int launch_sd_topup(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t n
     else { if (R == 0) SD_LAUNCH(0, false); else if (R == 1) SD_LAUNCH(1, false); else SD_LAUNCH(2, false); }
 #undef SD_LAUNCH
     const unsigned wgs = (unsigned)std::min<int64_t>(nq_max, (int64_t)ctx->n_cu * 8);
-    hipLaunchKernelGGL(k_sd_topup, dim3(wgs), dim3(APPLES_TPB), (size_t)(Lpad + Lpad / 8), ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow, qb.aa_idx + q0 * Lpad,
+    hipLaunchKernelGGL(k_sd_topup, dim3(wgs), dim3(APPLES_TPB), (size_t)(2 * Lpad + Lpad / 8), ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow, qb.aa_idx + q0 * Lpad,
                        qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L, ctx->params.overlap_frac,
                        qlist, qcount, lbrows, a.slots_pad, a.sd_nvr, qb.sd_nvq, q0, ctx->params.base_observation, out_rows);
     HIP_TRY(ctx, hipGetLastError());
