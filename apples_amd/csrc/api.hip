@@ -98,6 +98,7 @@ const double kBlosum45[400] = {
 int upload_tree(apples_ctx *ctx, const apples_tree *t) {
     DevTree &d = ctx->tree;
     d.dbg = ctx->dbg;
+    d.lean_small = ctx->params.criterion != APPLES_HYBRID;
     d.n_nodes = t->n_nodes;
     int h = 0;
     for (int i = 0; i < t->n_nodes; ++i) h = std::max(h, t->level[i]);

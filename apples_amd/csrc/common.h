@@ -72,6 +72,7 @@ struct DevTree {
     // the merged level lists (sweep.hip:merge_parents, sweep_lean.hip) need node ids in left-to-right post-order and observed
     // leaves that are distinct nodes; a tree or an alignment / table that does not comply gets the node map or the node bits
     bool merge_ok = false;
+    bool lean_small = false;  // criterion other than HYBRID: a small tree, too, takes the merged lists + lean sweep (sweep.hip:sweep_merge_lists)
     uint32_t dbg = 0;  // APPLES_DBG_* switches of the context (apples_params.debug | environment), fixed at creation
     int32_t *parent = nullptr;
     double *edge_len = nullptr;

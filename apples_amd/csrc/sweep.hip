@@ -878,7 +878,13 @@ bool sweep_merge_lists(const DevTree &t) {
     // SWEEP_MERGE = the merge layout also where the node bits would fit in LDS (tests run it on small trees)
     const bool off = (t.dbg & APPLES_DBG_NO_SWEEP_MERGE) != 0, force = (t.dbg & APPLES_DBG_SWEEP_MERGE) != 0;
     if (off || t.scan || !t.merge_ok || (t.dbg & APPLES_DBG_NODE_MAP)) return false;
-    return force || (size_t)4 * t.bm_words * 12 > 40 * 1024;
+    if (force || (size_t)4 * t.bm_words * 12 > 40 * 1024) return true;
+    // ... and from 2 048 nodes up wherever sweep_lean.hip can serve the tree: its sweep beats the level loop over node bits in
+    // LDS by 4-13 % (BASELINE config 2's shape at 1 000 / 2 000 / 5 000 / 10 000 / 20 000 leaves: sweep 0.78 -> 0.75, 1.00 -> 0.96,
+    // 1.22 -> 1.15, 1.40 -> 1.28, 1.52 -> 1.32 ms; at 500 leaves the node bits win, 0.72 against 0.79:
+    // profiles/r04_small_tree_sweep_exp.txt).  HYBRID keeps the node bits on such trees (its per-edge records need the level loop).
+    return t.n_nodes >= 2048 && t.lean_small && t.max_children <= 2 && t.height + 2 <= LEAN_MAX_LEVELS && t.pe != nullptr &&
+           !(t.dbg & APPLES_DBG_NO_SWEEP_LEAN);
 }
 
 // sweep_lean.hip serves the wavefront-sized teams of a big binary tree (merge layout, no polytomies, no per-edge
@@ -890,7 +896,7 @@ bool sweep_lean_layout(const DevTree &t, bool per_edge_records) {
 
 bool sweep_bits_in_lds(const DevTree &t) {
     if (t.dbg & APPLES_DBG_NODE_MAP) return false;  // test knob: exercise the big-tree layout on a small tree
-    if ((t.dbg & APPLES_DBG_SWEEP_MERGE) && !t.scan && t.merge_ok && !(t.dbg & APPLES_DBG_NO_SWEEP_MERGE)) return false;  // (forced merge layout)
+    if (sweep_merge_lists(t)) return false;  // (merged lists: forced, or chosen for a tree the lean sweep serves)
     // (a big tree whose numbering the merged lists cannot take keeps the tagged node map)
     return (size_t)4 * t.bm_words * 12 <= 40 * 1024;
 }

@@ -500,6 +500,8 @@ def main():
     n_leaves, L, Q, protein, method, thr = WORKLOADS[args.workload]
     if args.queries:
         Q = args.queries
+    if os.environ.get('APPLES_BENCH_LEAVES'):  # experiment only (never the reported line): another backbone size for the workload
+        n_leaves = int(os.environ['APPLES_BENCH_LEAVES'])
     table = args.workload == 'c5'
     clustered = args.workload == 'c3-clustered'
     strong = args.scaling == 'strong'

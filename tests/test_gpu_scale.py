@@ -70,8 +70,10 @@ def test_all_observed_stress_and_batching(c2, layout, monkeypatch):
         monkeypatch.setenv('APPLES_SWEEP_SCAN', '1')
     if layout == 'map':
         monkeypatch.setenv('APPLES_NODE_MAP', '1')
-    if layout in ('merge', 'lean'):  # big trees' layouts, forced on a small one: merged level lists inside the level
-        monkeypatch.setenv('APPLES_SWEEP_MERGE', '1')  # loop, or (binary trees, the default there) the three-pass lean form
+    if layout == 'bits':  # (a binary tree of 2 048 nodes or more takes the lean form by default)
+        monkeypatch.setenv('APPLES_NO_SWEEP_MERGE', '1')
+    if layout in ('merge', 'lean'):  # merged level lists inside the level loop, or (binary trees, the default from 2 048
+        monkeypatch.setenv('APPLES_SWEEP_MERGE', '1')  # nodes up) the three-pass lean form
     if layout == 'merge':
         monkeypatch.setenv('APPLES_NO_SWEEP_LEAN', '1')
     nthreads = len(os.sched_getaffinity(0))
@@ -181,7 +183,7 @@ def test_debug_switches_cross_the_routes_inside_one_process(c2):
     d, nodes = c2
     outs = {}
     for dbg in ((), ('no_fuse',), ('node_map',), ('sweep_merge',), ('sweep_merge', 'no_sweep_lean'), ('no_dist_gemm',), ('sweep_scan',),
-                ('no_fuse', 'sweep_merge'), ('no_dist_gemm', 'node_map')):
+                ('no_fuse', 'sweep_merge'), ('no_dist_gemm', 'node_map'), ('no_sweep_merge',), ('no_sweep_lean',)):
         eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS', debug=dbg)
         info = eng.describe()
         if 'sweep_scan' in dbg:
@@ -190,8 +192,10 @@ def test_debug_switches_cross_the_routes_inside_one_process(c2):
             assert info['sweep_layout'] == ('merge' if 'no_sweep_lean' in dbg else 'lean')
         elif 'node_map' in dbg:
             assert info['sweep_layout'] == 'map'
+        elif 'no_sweep_merge' in dbg or 'no_sweep_lean' in dbg:
+            assert info['sweep_layout'] == 'bits'  # (the node bits of 20 000 nodes fit in LDS)
         else:
-            assert info['sweep_layout'] == 'bits'
+            assert info['sweep_layout'] == 'lean'  # binary tree, 2 048 nodes or more
         assert ('gemm' in info['fused_distance_pass']) == ('no_dist_gemm' not in dbg)
         outs[dbg] = eng.place_sequences(d.query_seqs[:768]).tobytes()
         eng.close()
