@@ -529,7 +529,7 @@ int route_threshold(const apples_ctx *ctx) {
     if (fixed || ctx->tree.scan || v != LEAN_BIG_THRESHOLD) return v;
     // (13 312: the clustered route's batches of 14 300 queries with 3 100 observed leaves each lose by the lower cut -- sweep 35.6 ->
     // 37.8 ms per pass, the workgroup-sized teams flooded -- and stay with the higher one)
-    return ctx->cur_batch_queries > 0 && ctx->cur_batch_queries <= 13312 ? v / 2 : v;
+    return ctx->cur_batch_queries > 0 && ctx->cur_batch_queries <= LEAN_SMALL_BATCH ? v / 2 : v;
 }
 
 void free_sweep(Workspace::Sweep &sw) {
@@ -1053,6 +1053,12 @@ struct Feeder {
     const uint8_t *host;
 };
 
+// the back stream of the pipeline experiments, made on first use
+int back_stream(apples_ctx *ctx) {
+    if (!ctx->stream3) HIP_TRY(ctx, hipStreamCreate(&ctx->stream3));
+    return 0;
+}
+
 int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     const DevAlign &a = ctx->aln;
     bool hybrid = ctx->params.criterion == APPLES_HYBRID;
@@ -1083,6 +1089,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     if (!pipelined && n_sub > 1) step = std::min(step, round_up((qb.n + n_sub - 1) / n_sub, 32));  // equal sub-batches
     // (the GEMM-form distance pass reads whole contiguous kilobytes when a sub-batch starts on a 256-row image tile)
     if (!pipelined && n_sub > 1 && step >= 2048 && dist_gemm_usable(ctx) && round_up(step, 256) <= w.batch) step = round_up(step, 256);
+    if (pipelined && back_stream(ctx)) return 1;
     hipStream_t front = ctx->stream, back = pipelined ? ctx->stream3 : ctx->stream;
     // timing events come from a pool that lives with the context (creating and destroying a dozen
     // events per call costs host time inside every pass)
@@ -1378,9 +1385,12 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         return fail();
     }
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return fail(); }
-    // stream2 is spare; stream3 is the back stream of the APPLES_PIPELINE experiment
+    // Three streams and nothing on the null stream: the runtime spreads a process's streams over four hardware queues
+    // (GPU_MAX_HW_QUEUES) and two streams on one queue run their kernels one after the other (scripts/stream_queue_probe.hip);
+    // the sweep's launches side by side need queues of their own.  stream3 (the pipeline experiments' back stream) is made
+    // when an experiment asks for it (back_stream).
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
-        hipStreamCreate(&ctx->stream3) != hipSuccess || hipStreamCreate(&ctx->stream_big) != hipSuccess ||
+        hipStreamCreate(&ctx->stream_big) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_front[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_front[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_back[0], hipEventDisableTiming) != hipSuccess ||
@@ -1393,11 +1403,11 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
     for (int i = 0; i < 8; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return fail(); }
     if (tree->n_nodes < 2) { ctx->err = "tree needs at least two nodes"; return fail(); }
-    if (dev_alloc(ctx, &ctx->d_exotic, 1) || hipMemset(ctx->d_exotic, 0, sizeof(int)) != hipSuccess) return fail();
+    if (dev_alloc(ctx, &ctx->d_exotic, 1) || hipMemsetAsync(ctx->d_exotic, 0, sizeof(int), ctx->stream) != hipSuccess) return fail();
     if (getenv("APPLES_SCAN_PROFILE"))
-        if (dev_alloc(ctx, &ctx->scan_prof, 8) || hipMemset(ctx->scan_prof, 0, 64) != hipSuccess) return fail();
+        if (dev_alloc(ctx, &ctx->scan_prof, 8) || hipMemsetAsync(ctx->scan_prof, 0, 64, ctx->stream) != hipSuccess) return fail();
     if (getenv("APPLES_LEAN_PROFILE"))
-        if (dev_alloc(ctx, &ctx->lean_prof, 16) || hipMemset(ctx->lean_prof, 0, 128) != hipSuccess) return fail();
+        if (dev_alloc(ctx, &ctx->lean_prof, 16) || hipMemsetAsync(ctx->lean_prof, 0, 128, ctx->stream) != hipSuccess) return fail();
     if (upload_tree(ctx, tree)) return fail();
     if (aln) {
         if (setup_alignment(ctx, tree, aln)) return fail();
@@ -1723,7 +1733,8 @@ static int setup_columns(apples_ctx *ctx, int64_t n_cols, const int32_t *col_nod
                 std::equal(col_node, col_node + n_cols, ctx->h_col_node.begin());
     if (same) return 0;
     std::vector<int32_t> level(t.n_nodes);
-    HIP_TRY(ctx, hipMemcpy(level.data(), t.level, (size_t)t.n_nodes * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpyAsync(level.data(), t.level, (size_t)t.n_nodes * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int64_t c = 0; c < n_cols; ++c)
         if (col_node[c] >= t.n_nodes) { ctx->err = "col_node out of range"; return 1; }
     if (ctx->tree.merge_ok) {  // two columns on one tree leaf: no merged level lists (the workspace is laid out again)
@@ -1894,6 +1905,7 @@ static int run_table_block(apples_ctx *ctx, QueryBlock &qb) {
     const bool pipelined = n_pipe > 1 && !hybrid && !ctx->tree.scan && qb.n >= 2048;
     int64_t want = qb.n;
     if (pipelined) want = round_up((qb.n + n_pipe - 1) / n_pipe, 32);
+    if (pipelined && back_stream(ctx)) return 1;
     if (ensure_workspace(ctx, qb.n_cols, qb.n_cols, want, false, false, hybrid, false, pipelined)) return 1;
     Workspace &w = ctx->ws;
     const int64_t step = pipelined ? std::min<int64_t>(w.batch, want) : w.batch;

@@ -473,6 +473,7 @@ int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int t
 // sweep_lean.hip: the three-pass form for big binary trees (wavefront-sized teams over the size-class queues)
 #define LEAN_BYTES_PER_NODE 100  // T0 T1 T2 E DD (16 B each), D N (8 B each), K (4 B)
 #define LEAN_BYTES_PER_LEAF 12   // per observed leaf: edge length, parent
+#define LEAN_SMALL_BATCH 13312    // device batches up to this many queries: routing cut halved (api.hip:route_threshold), 512-thread routed teams
 #define LEAN_BIG_THRESHOLD 8192  // observed leaves above which a query goes to the lean sweep's workgroup-sized teams
 #define LEAN_MAX_LEVELS 256      // per-level offsets of a query in LDS: trees up to 254 levels
 bool sweep_lean_layout(const DevTree &t, bool per_edge_records);

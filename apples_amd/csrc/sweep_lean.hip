@@ -960,7 +960,15 @@ __global__ __launch_bounds__(APPLES_TPB, LEAN_DOWN_WAVES) void k_lean_down(Sweep
 // workgroup-sized teams over a device-side list (routed or overflow queries); a.lean = the big teams' field arrays
 int launch_sweep_lean_big(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st) {
     if (nq == 0) return 0;
-    static const int team = getenv("APPLES_LEAN_BIG_TEAM") ? atoi(getenv("APPLES_LEAN_BIG_TEAM")) : 256;  // tuning knob
+    // Team size: 256 threads, and 512 in a small device batch (a shard of a multi-GPU job, a -d block: the batches route_threshold
+    // lowers the routing cut for).  There the routed queries are a launch of their own length -- config 3's 12 500-query shards
+    // with a 34 000-leaf query: this kernel 2.74 -> 1.61 ms, the sweep 2.75 -> 2.24, the shard 7.65 -> 7.05 ms; a shard without such
+    // a query 6.86 -> 6.91 (profiles/r04_shard_bigteam_exp.txt) -- while in the big batches of a full pass the wavefront-sized teams'
+    // kernels beside it are as long as it is either way (no change at config 3, 35.8 -> 37.2 ms on the clustered route: half as many
+    // teams per compute unit).  512-thread teams for the few largest queries only, in a launch of their own beside a launch of
+    // 256-thread teams, measured worse than either (2.86 / 2.57 ms on the two shards).  APPLES_LEAN_BIG_TEAM: tuning knob.
+    static const int team_env = getenv("APPLES_LEAN_BIG_TEAM") ? atoi(getenv("APPLES_LEAN_BIG_TEAM")) : 0;
+    const int team = team_env > 0 ? team_env : (ctx->cur_batch_queries > 0 && ctx->cur_batch_queries <= LEAN_SMALL_BATCH ? 512 : 256);
     const dim3 grid((unsigned)std::min<int64_t>(nq, wgs));
     if (team == 512) launch_lean_big_t<512>(a, nq, grid, st);
     else launch_lean_big_t<256>(a, nq, grid, st);

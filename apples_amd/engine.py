@@ -61,6 +61,11 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('libapples_hip.so is not built (%s); run `python -m apples_amd.build`. '
                            'The APPLES hot path has no CPU fallback.' % LIB_PATH)
+    # the sweep runs its launches side by side on streams of their own; the HIP runtime gives a process four hardware queues
+    # by default and lets further streams share them, serialised (csrc/api.hip:apples_ctx_create, scripts/stream_queue_probe.hip).
+    # Room for other users of the process (read when the runtime starts: no effect if something has initialised HIP already,
+    # none if the user set it)
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     lib = C.CDLL(LIB_PATH)
     lib.apples_last_error.restype = C.c_char_p
     lib.apples_last_error.argtypes = [C.c_void_p]
