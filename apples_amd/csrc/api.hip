@@ -598,7 +598,7 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
         char *p = nullptr;
         if (dev_alloc(ctx, &p, sw.lean_cap1 * LEAN_BYTES_PER_NODE)) return 1;
         sw.lean = p;
-        if (dev_alloc(ctx, &p, sw.teams * sw.lean_leaf1 * LEAN_BYTES_PER_LEAF)) return 1;
+        if (dev_alloc(ctx, &p, 2 * sw.teams * sw.lean_leaf1 * LEAN_BYTES_PER_LEAF)) return 1;  // (x 2: run_sweep_second's teams)
         sw.lean_leaf = p;
         if (dev_alloc(ctx, &sw.grp_off, batch * (int64_t)(t.height + 4))) return 1;
         if (dev_alloc(ctx, &sw.lean_meta, batch)) return 1;
@@ -710,12 +710,14 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         }
         if (dev_alloc(ctx, &w.route_list, 3 * batch)) return 1;
         if (dev_alloc(ctx, &w.overflow_list, batch)) return 1;
-        if (dev_alloc(ctx, &w.cls_list, 8 * batch)) return 1;  // four size classes, then the largest class once more in four
+        if (dev_alloc(ctx, &w.cls_list, 16 * batch)) return 1;  // four size classes, then the largest class once more in four; all of it
+                                                                // a second time for the overlapped top-up chain (run_sweep_second)
         // one block for every per-batch counter, cleared by one memset: [0..3] size-class counts,
         // [4..6] the sweep launches' work cursors, [7] the lean sweep's pool cursor, [8] routed, [9] top-up list, [10] overflow,
         // [11] the lean top-down kernel's cursor, [12..14] routed queries by size class, [16..19] the largest size class of the
         // small teams split four ways (sweep_lean.hip takes the longest jobs first), [20] what the clustered route's top-up phase forwards
-        if (dev_alloc(ctx, &w.cls_count, 32)) return 1;
+        // [32..63] the same for the second set of queues
+        if (dev_alloc(ctx, &w.cls_count, 64)) return 1;
         w.route_count = w.cls_count + 8;
         w.slow_count = w.cls_count + 9;
         w.overflow_count = w.cls_count + 10;
@@ -980,7 +982,9 @@ int run_scan(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st)
 // full-size scratch for the queries whose induced subtree did not fit (usually none).
 // `st` = the stream the small-team sweep (and the final overflow launch) runs on; the caller has
 // made `st` wait for the selection kernel of this batch.
-int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st = nullptr) {
+// `part`: 0 = all of it; 1 = everything but the closing launch for the overflow list and 2 = that launch alone (run_block's
+// overlapped top-up chain appends to the list between the two; the caller has cleared the list's counter)
+int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st = nullptr, int part = 0) {
     Workspace &w = ctx->ws;
     if (!st) st = ctx->stream;
     if (ctx->tree.scan) return run_scan(ctx, out, nq, st);
@@ -1004,12 +1008,14 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     b.work_count = w.route_count;
     b.route_classes = (w.big.lean && !b.keep_edges) ? 1 : 0;  // (as the selection kernels filed them: select_args_alignment)
     const bool can_overflow = w.small.cap < ctx->tree.n_nodes || w.small.lean_leaf != nullptr;  // (pool: a query may ask for more than its share)
-    if (can_overflow) HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), st));
+    if (can_overflow && part == 0) HIP_TRY(ctx, hipMemsetAsync(w.overflow_count, 0, sizeof(int32_t), st));
     SweepArgs sm = sweep_args(ctx, w.small, out, false);
     sm.cls_list = w.cls_list;  // size-class queues written by the selection kernels, largest first
     sm.cls_count = w.cls_count;
     sm.cursor = w.cls_count + 4;
-    if (w.small.lean && !sm.keep_edges) {
+    if (part == 2) {
+        // (nothing of the first part to launch)
+    } else if (w.small.lean && !sm.keep_edges) {
         // big binary trees: the wavefront-sized teams run sweep_lean.hip; the queries routed to workgroup-sized teams
         // (many observed leaves: the longest jobs) run beside them.  Their launch goes first and on this stream, the lean
         // kernel on a second stream behind an event: its persistent workgroups would otherwise take every slot of the
@@ -1026,13 +1032,36 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     } else if (launch_sweep_mixed(ctx, sm, b, nq, w.small.wgs, w.big.wgs, st)) return 1;
     // whatever did not fit a small team's scratch (usually nothing; nothing at all when that scratch
     // holds the whole tree: the overflow test in the kernel is `cap < n_nodes && ...`)
-    if (!can_overflow) return 0;
+    if (!can_overflow || part == 1) return 0;
     b.work_list = w.overflow_list;
     b.work_count = w.overflow_count;
     b.route_classes = 0;
     b.cursor = w.cls_count + 6;
     return launch_big(b, st);
 }
+
+// The top-up chain's own sweep (run_block): the wavefront-sized teams of sweep_lean.hip over the SECOND set of size-class
+// queues (what the chain's selection kernels enlisted), with per-leaf scratch of their own, on `st` beside the batch's main
+// sweep.  Pool, per-query records and the overflow list are the main sweep's (atomic cursors).
+int run_sweep_second(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st) {
+    Workspace &w = ctx->ws;
+    SweepArgs sm = sweep_args(ctx, w.small, out, false);
+    sm.cls_list = w.cls_list + 8 * w.batch;
+    sm.cls_count = w.cls_count + 32;
+    sm.cursor = w.cls_count + 32 + 4;
+    sm.lean_leaf = reinterpret_cast<char *>(w.small.lean_leaf) + w.small.teams * w.small.lean_leaf1 * LEAN_BYTES_PER_LEAF;
+    SweepArgs down = sm;
+    down.cursor = w.cls_count + 32 + 11;
+    return launch_sweep_lean(ctx, sm, down, nq, st);
+}
+
+// every launch_* below reads ctx->stream when it is called: a chain of them on another stream for the length of a scope
+struct StreamScope {
+    apples_ctx *ctx;
+    hipStream_t saved;
+    StreamScope(apples_ctx *c, hipStream_t s) : ctx(c), saved(c->stream) { c->stream = s; }
+    ~StreamScope() { ctx->stream = saved; }
+};
 
 int dist_tile_for(int64_t nq) {
     static const int forced = getenv("APPLES_DIST_TILE") ? atoi(getenv("APPLES_DIST_TILE")) : 0;  // tuning knob
@@ -1163,7 +1192,44 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         ctx->cur_batch_queries = nq;  // (route_threshold)
         const int64_t nh = feed ? head(nq) : nq;  // rows of the chunk's first piece
         if (feed) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[2 * i + (nh < nq ? 0 : 1)], 0));  // chunk i (its first piece) is on the device
-        HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), front));  // every counter of the batch
+        HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 64 * sizeof(int32_t), front));  // every counter of the batch
+        // The top-up chain -- full rows (or rows of bounds) for the queries k_select_fast listed, their selection -- runs BESIDE the
+        // sweep of the queries k_select_fast placed on its own: on stream2, its selection kernels filing into the second set of
+        // size-class queues, which a second launch of the wavefront-sized teams serves (run_sweep_second); what would be routed to
+        // workgroup-sized teams goes to the overflow list, whose launch closes the batch.  chain() = the chain's launches (they
+        // read ctx->stream, redirected for the scope).  Sets swept_here when the batch's sweep has been launched in here.
+        // Small device batches only (a shard of a multi-GPU job): there the chain's short launches find idle compute units beside
+        // the sweep (two of config 3's 12 500-query shards: 6.99 -> 6.79 and 7.02 -> 6.92 ms); in a full-size batch the sweep's
+        // persistent workgroups hold every slot until their queues are empty, the chain runs after them all the same and the two
+        // sweeps get in each other's way (config 3: 48.1 -> 49.7 ms, config 4: 23.0 -> 23.6).
+        bool swept_here = false;
+        auto overlapped = [&](SelectArgs &sa, auto chain) -> int {
+            const bool on = !pipelined && !hybrid && !(ctx->dbg & APPLES_DBG_NO_TOPUP_OVERLAP) && !ctx->tree.scan && w.small.lean &&
+                            w.small.lean_leaf && w.big.lean && nq <= LEAN_SMALL_BATCH;
+            if (!on) {
+                if (chain()) return 1;
+                HIP_TRY(ctx, hipEventRecord(e[2], front));
+                return 0;
+            }
+            HIP_TRY(ctx, hipEventRecord(e[2], front));  // (the selection phase of the timers: k_select_fast alone)
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_top[0], front));
+            HIP_TRY(ctx, hipEventRecord(e[3], front));
+            if (run_sweep(ctx, qb.out + q0, nq, front, 1)) return 1;
+            {
+                StreamScope scope(ctx, ctx->stream2);
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_top[0], 0));
+                sa.cls_list = w.cls_list + 8 * w.batch; sa.cls_count = w.cls_count + 32;
+                sa.overflow_list = w.overflow_list; sa.overflow_count = w.overflow_count; sa.route_classes = 0;
+                if (chain()) return 1;
+                if (run_sweep_second(ctx, qb.out + q0, nq, ctx->stream2)) return 1;
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_top[1], ctx->stream2));
+            }
+            HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_top[1], 0));
+            if (run_sweep(ctx, qb.out + q0, nq, front, 2)) return 1;
+            HIP_TRY(ctx, hipEventRecord(e[4], front));
+            swept_here = true;
+            return 0;
+        };
         if (cfused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
             HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (a.reps_pad / 64) * sizeof(int32_t), front));
@@ -1255,16 +1321,17 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 if (dev_alloc(ctx, &ctx->sd_list_img, sd_query_image_bytes(ctx, round_up(w.batch, 256)))) return 1;
                 ctx->sd_list_rows = w.batch;
             }
-            if (for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
-                    // rows of lower bounds on the matrix cores (into the listed queries' rows of w.dist: k_select_fast is done
-                    // with them), exact distances only where the `-b` nearest can be (dist_sd.hip:k_sd_topup); else full rows
-                    if (lb_topup ? launch_sd_topup(ctx, qb, q0, n_max, lst, cntp, ctx->sd_list_img, w.dist, w.dist_slow)
-                                 : launch_scoredist_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow)) return 1;
-                    sa.qlist = lst;
-                    sa.qcount = cntp;
-                    return launch_select(ctx, sa, n_max);
+            if (overlapped(sa, [&]() -> int {
+                    return for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
+                        // rows of lower bounds on the matrix cores (into the listed queries' rows of w.dist: k_select_fast is done
+                        // with them), exact distances only where the `-b` nearest can be (dist_sd.hip:k_sd_topup); else full rows
+                        if (lb_topup ? launch_sd_topup(ctx, qb, q0, n_max, lst, cntp, ctx->sd_list_img, w.dist, w.dist_slow)
+                                     : launch_scoredist_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow)) return 1;
+                        sa.qlist = lst;
+                        sa.qcount = cntp;
+                        return launch_select(ctx, sa, n_max);
+                    });
                 })) return 1;
-            HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else if (fused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
             if (fused_counts_format(ctx, qb))  // the matrix-core kernel writes only the non-empty segments' counts
@@ -1291,14 +1358,15 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             sa.dist = w.dist_slow;
             sa.segmin_d = w.dist;
             sa.segmin_i = w.seg_slot;
-            if (for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
-                    if (launch_counts_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow, topup ? w.dist : nullptr,
-                                             topup ? w.seg_slot : nullptr)) return 1;
-                    sa.qlist = lst;
-                    sa.qcount = cntp;
-                    return topup ? launch_select_topup(ctx, sa, n_max) : launch_select(ctx, sa, n_max);
+            if (overlapped(sa, [&]() -> int {
+                    return for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
+                        if (launch_counts_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow, topup ? w.dist : nullptr,
+                                                 topup ? w.seg_slot : nullptr)) return 1;
+                        sa.qlist = lst;
+                        sa.qcount = cntp;
+                        return topup ? launch_select_topup(ctx, sa, n_max) : launch_select(ctx, sa, n_max);
+                    });
                 })) return 1;
-            HIP_TRY(ctx, hipEventRecord(e[2], front));
         } else {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
             if (ctx->params.model == APPLES_SCOREDIST) {
@@ -1315,9 +1383,11 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_front[set], front));
             HIP_TRY(ctx, hipStreamWaitEvent(back, ctx->ev_front[set], 0));
         }
-        HIP_TRY(ctx, hipEventRecord(e[3], back));
-        if (run_sweep(ctx, qb.out + q0, nq, back)) return 1;
-        HIP_TRY(ctx, hipEventRecord(e[4], back));
+        if (!swept_here) {
+            HIP_TRY(ctx, hipEventRecord(e[3], back));
+            if (run_sweep(ctx, qb.out + q0, nq, back)) return 1;
+            HIP_TRY(ctx, hipEventRecord(e[4], back));
+        }
         if (pipelined) HIP_TRY(ctx, hipEventRecord(ctx->ev_back[set], back));
         if (feed && i + 1 < n_sub && feed_chunk(i + 1)) return 1;  // the next chunk travels while this sub-batch's kernels run
     }
@@ -1375,7 +1445,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
             {"APPLES_NO_SD_GEMM", APPLES_DBG_NO_SD_GEMM}, {"APPLES_CLUSTER_BY_QUERY", APPLES_DBG_CLUSTER_BY_QUERY},
             {"APPLES_NO_CLUSTER_TOPUP", APPLES_DBG_NO_CLUSTER_TOPUP}, {"APPLES_NO_STREAM_SELECT", APPLES_DBG_NO_STREAM_SELECT},
             {"APPLES_NO_TOPUP_KERNEL", APPLES_DBG_NO_TOPUP_KERNEL}, {"APPLES_NO_CLUSTER_BIG", APPLES_DBG_NO_CLUSTER_BIG},
-            {"APPLES_NO_SD_TOPUP", APPLES_DBG_NO_SD_TOPUP}, {"APPLES_SD_FP6", APPLES_DBG_SD_FP6}};
+            {"APPLES_NO_SD_TOPUP", APPLES_DBG_NO_SD_TOPUP}, {"APPLES_SD_FP6", APPLES_DBG_SD_FP6},
+            {"APPLES_NO_TOPUP_OVERLAP", APPLES_DBG_NO_TOPUP_OVERLAP}};
         for (const auto &k : knobs)
             if (getenv(k.env)) ctx->dbg |= k.bit;
     }
@@ -1399,6 +1470,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         hipEventCreateWithFlags(&ctx->ev_cl[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_cl[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_sel, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_top[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_top[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return fail(); }
     for (int i = 0; i < 8; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return fail(); }
@@ -1557,6 +1630,8 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     if (ctx->stream_big) (void)hipStreamDestroy(ctx->stream_big);
     if (ctx->ev_sel) (void)hipEventDestroy(ctx->ev_sel);
     if (ctx->ev_big) (void)hipEventDestroy(ctx->ev_big);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->ev_top[i]) (void)hipEventDestroy(ctx->ev_top[i]);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1791,7 +1866,7 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.big_threshold = route_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
     s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
-    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), ctx->stream));  // every counter of the batch
+    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 64 * sizeof(int32_t), ctx->stream));  // every counter of the batch
     if (pipe) {
         HIP_TRY(ctx, hipEventRecord(pipe[0], ctx->stream));
         if (launch_select(ctx, s, nq)) return 1;
@@ -1974,7 +2049,7 @@ static int sweep_edges_scan(apples_ctx *ctx, const int32_t *obs_node, const doub
     HIP_TRY(ctx, hipMemcpy(w.obs_node, s_node.data(), (size_t)n_obs * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.obs_dist, s_dist.data(), (size_t)n_obs * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.n_obs, &n_obs, 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 64 * sizeof(int32_t), ctx->stream));
     ScanArgs sa = scan_args(ctx, w.big, d_out, true, true);
     sa.overflow_list = nullptr; sa.overflow_count = nullptr;
     if (launch_scan(ctx, sa, 1, 1, 256, ctx->stream)) { dev_free(d_out); return 1; }
@@ -2035,7 +2110,7 @@ int apples_sweep_edges(apples_ctx *ctx, const int32_t *obs_node, const double *o
     HIP_TRY(ctx, hipMemcpy(w.obs_dist, s_dist.data(), (size_t)n_obs * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.cnt_gt, cg.data(), cg.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(w.n_obs, &n_obs, 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 32 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 64 * sizeof(int32_t), ctx->stream));
     if (launch_sweep(ctx, sweep_args(ctx, w.big, d_out, true), 1, 1, 256)) { dev_free(d_out); return 1; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     apples_placement res;

@@ -235,6 +235,7 @@ struct apples_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // spare
     hipEvent_t ev_sel = nullptr, ev_big = nullptr;
+    hipEvent_t ev_top[2] = {nullptr, nullptr};  // run_block's overlapped top-up chain: k_select_fast done / chain and its sweep done
     hipStream_t stream3 = nullptr;   // back stream: sweeps of batch i while the front stream works on batch i+1
     hipStream_t stream_big = nullptr; // the workgroup-sized sweep teams of a batch, beside sweep_lean.hip's wavefront-sized ones
     hipEvent_t ev_front[2] = {}, ev_back[2] = {}, ev_bigfree = nullptr;

@@ -390,10 +390,10 @@ def other_workload(name, device, steps=3, ds=None, queries=0):
     else:
         eng = Engine(ds_.tree, ds_.ref_seqs, nodes, protein=protein, method=method, criterion='MLSE', threshold=thr, baseobs=25,
                      overlap=0.001, device=device)
-        queries = np.ascontiguousarray(ds_.query_seqs[:Q])
+        qarr = np.ascontiguousarray(ds_.query_seqs[:Q])
 
         def step():
-            return eng.place_sequences(queries)
+            return eng.place_sequences(qarr)
     try:
         out = step()
         ph = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0, 'filter_ms': 0.0}

@@ -99,7 +99,8 @@ typedef struct {
 #define APPLES_DBG_NO_CLUSTER_BIG 4096u   /* clustered route: queries beyond 512 accepted clusters to the general route */
 #define APPLES_DBG_NO_SD_TOPUP   8192u    /* scoredist top-up list: full rows (k_scoredist listed), no lower-bound rows */
 #define APPLES_DBG_SD_FP6        16384u   /* scoredist filter: query-side table values as fp6 (half the candidates, a slower filter: measured slower in all) */
-#define APPLES_DBG_ALL           32767u   /* every defined switch; other bits of apples_params.debug are ignored */
+#define APPLES_DBG_NO_TOPUP_OVERLAP 32768u /* the top-up chain of a device batch (full rows + selection of the listed queries) before the sweep, not beside it */
+#define APPLES_DBG_ALL           65535u   /* every defined switch; other bits of apples_params.debug are ignored */
 
 /* One placement = the p row runquery returns, [edge_num, likelihood(error), 1, distal, pendant]
  * (apples/Algorithm.py:98-101, apples/PoolQueryWorker.py:36-37,74,88,119-125). */

@@ -78,10 +78,11 @@ def test_clustered_routes_agree(seed):
 def test_singleton_jc69_routes_agree(seed):
     """Singleton clusters, JC69: GEMM-form fused pass + lean / bit sweep (default) against the bit-plane-fed matrix-core kernel
     with merged level lists, and against full rows + general selection with the node map: no distance, selection or
-    sweep code in common; small backbones also against the C oracle."""
+    sweep code in common; the default (top-up chain beside the sweep, from 2 048 nodes) against the chain before the sweep;
+    small backbones also against the C oracle."""
     rng = np.random.default_rng(seed)
     routes = (('default', ()), ('no_gemm', ('no_dist_gemm', 'sweep_merge')), ('no_fuse', ('no_fuse', 'node_map')),
-              ('no_topup', ('no_topup_kernel', 'no_sweep_lean')))
+              ('no_topup', ('no_topup_kernel', 'no_sweep_lean')), ('serial_topup', ('no_topup_overlap',)))
     checked = 0
     for c in range(NCFG):
         n = int(rng.choice([40, 257, 600, 1500, 5000, 20000])); L = int(rng.integers(20, 2047)); nq = int(rng.integers(1, 700))
@@ -92,7 +93,7 @@ def test_singleton_jc69_routes_agree(seed):
         out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, method=m, threshold=thr, baseobs=b, max_batch=mb, debug=dbg),
                      d.query_seqs)
         tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s' % (seed, c, n, L, nq, gap, thr, b, mb, m)
-        for k in ('no_gemm', 'no_fuse', 'no_topup'):
+        for k in ('no_gemm', 'no_fuse', 'no_topup', 'serial_topup'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
             co = COracle(d.tree, d.ref_seqs, nodes, method=m, criterion='MLSE', threshold=thr, baseobs=b, lut=jc69_lut(L, 0.001),
@@ -110,7 +111,8 @@ def test_scoredist_routes_agree(seed):
     rows + general selection; small backbones also against the C oracle (edges, flags and counts equal, lengths to 1e-9:
     the reference's own summation order is BLAS-internal)."""
     rng = np.random.default_rng(seed)
-    routes = (('default', ()), ('fp6', ('sd_fp6',)), ('every_pair', ('no_sd_gemm',)), ('rows_topup', ('no_sd_topup',)), ('no_fuse', ('no_fuse',)))
+    routes = (('default', ()), ('fp6', ('sd_fp6',)), ('every_pair', ('no_sd_gemm',)), ('rows_topup', ('no_sd_topup',)), ('no_fuse', ('no_fuse',)),
+              ('serial_topup', ('no_topup_overlap',)))
     checked = 0
     for c in range(NCFG):
         n = int(rng.choice([40, 257, 600, 1500, 5000, 20000])); L = int(rng.integers(7, 1200)); nq = int(rng.integers(1, 700))
@@ -126,7 +128,7 @@ def test_scoredist_routes_agree(seed):
         out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, protein=True, method=m, threshold=thr, baseobs=b,
                                                 max_batch=mb, debug=dbg), q)
         tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s' % (seed, c, n, L, nq, gap, thr, b, mb, m)
-        for k in ('fp6', 'every_pair', 'rows_topup', 'no_fuse'):
+        for k in ('fp6', 'every_pair', 'rows_topup', 'no_fuse', 'serial_topup'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
             co = COracle(d.tree, d.ref_seqs, nodes, protein=True, method=m, criterion='MLSE', threshold=thr, baseobs=b, threads=NTHREADS)
