@@ -524,8 +524,11 @@ int big_threshold(const apples_ctx *ctx) {
 // 12 500 queries 7.15 -> 6.80 ms, sweep 2.40 -> 2.11; the full 100 000, in batches of 25 000, 48.7 -> 49.1: the cut stays where
 // it was there).  Never above the count the workspace was sized with.
 int route_threshold(const apples_ctx *ctx) {
-    const int v = big_threshold(ctx);
+    int v = big_threshold(ctx);
     static const bool fixed = getenv("APPLES_BIG_THRESHOLD") != nullptr;  // (the knob fixes the cut for every batch size)
+    // (a workspace regrown with per-edge records -- a HYBRID pass, apples_sweep_edges -- stays with the level loop for later
+    // MLSE / ME passes too: its cut, not the lean sweep's the tree would be eligible for)
+    if (!fixed && !ctx->tree.scan && ctx->ws.batch > 0 && !ctx->ws.small.lean) v = std::min(v, 4096);
     if (fixed || ctx->tree.scan || v != LEAN_BIG_THRESHOLD) return v;
     // (13 312: the clustered route's batches of 14 300 queries with 3 100 observed leaves each lose by the lower cut -- sweep 35.6 ->
     // 37.8 ms per pass, the workgroup-sized teams flooded -- and stay with the higher one)

@@ -226,7 +226,7 @@ def hbm_point(ref_seqs, queries, device, seconds=5.0, min_packed_bytes=1100 << 2
                            'for every query' % (info['packed_bytes'] >> 20)}
 
 
-def strong_scaling_proxy(eng, queries, ms_full, parts=8, reps=3, device=0):
+def strong_scaling_proxy(eng, queries, ms_full, parts=8, reps=3, device=0, full=None):
     """What a single GPU can say about BASELINE config 3's 1 -> 8 GPU curve: the `parts` contiguous shards of the one
     query set (apples_amd/distributed.py:shard_bounds, what rank r of an 8-GPU job places) timed one after the other,
     host buffer -> placements in host memory like the step itself.  The 8-GPU step ends when its slowest rank does
@@ -239,9 +239,13 @@ def strong_scaling_proxy(eng, queries, ms_full, parts=8, reps=3, device=0):
         best = None
         for _ in range(reps):
             t0 = time.perf_counter()
-            eng.place_sequences(block)
+            got = eng.place_sequences(block)
             dt = (time.perf_counter() - t0) * 1e3
             best = dt if best is None else min(best, dt)
+        # (a shard is a small device batch: lower routing cut, 512-thread routed teams, the top-up chain beside the sweep --
+        # other routes than the full set's batches took, the same bytes)
+        if full is not None and got.tobytes() != full[lo:hi].tobytes():
+            raise SystemExit('bench: shard [%d, %d) placed on its own differs from the same queries in the full set' % (lo, hi))
         ms.append(best)
     # the end-of-run gather as far as one GPU can measure it: the torch-free RCCL path (apples_amd/rccl.py, world size 1: a
     # grouped ncclSend / ncclRecv to self + the copy to the host) on the whole job's 40-byte structs -- what rank 0 of an
@@ -264,7 +268,7 @@ def strong_scaling_proxy(eng, queries, ms_full, parts=8, reps=3, device=0):
     worst = max(ms) + (gather_ms or 0.0)
     return {'parts': parts, 'queries_per_shard': [b - a for a, b in shard_bounds(len(queries), parts)],
             'ms_shard': ms, 'ms_shard_max': max(ms), 'ms_shard_mean': float(np.mean(ms)), 'ms_full_set': ms_full,
-            'gather_ms': gather_ms,
+            'gather_ms': gather_ms, 'shards_equal_full_set': full is not None,
             'predicted_speedup_at_%d' % parts: ms_full / worst,
             'note': 'A PREDICTION, not a measurement (this pool has one-GPU boxes): shards of the one query set timed one by one '
                     'on this GPU (best of %d, host buffer -> host); predicted speed-up = full-set step / (slowest shard + gather_ms); '
@@ -644,7 +648,7 @@ def main():
             stream = distance_stream_point(eng, ds, L)
         extras = world == 1 and not args.no_extras and not use_dist
         if extras and args.workload == 'c3':
-            proxy = strong_scaling_proxy(eng, queries, ms_per_step, device=local_rank)
+            proxy = strong_scaling_proxy(eng, queries, ms_per_step, device=local_rank, full=mine)
         cpu = None
         if world == 1 and not args.no_cpu and not clustered:
             cpu = cpu_baseline_table(ds, D, method, thr) if table else cpu_baseline(ds, protein, method, thr)

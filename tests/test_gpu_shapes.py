@@ -51,6 +51,10 @@ def test_c3_shape_200k_leaves_100k_queries():
     eng.place_resident(h)
     assert eng.fetch(h, n).tobytes() == got.tobytes()
     eng.free_queries(h)
+    # rank 1's share of an 8-GPU job placed on its own: ONE small device batch (routing cut halved, 512-thread routed teams,
+    # the top-up chain beside the sweep) against the same queries inside the full set's batches of 25 000
+    shard = eng.place_sequences(d.query_seqs[12500:25000])
+    assert shard.tobytes() == got[12500:25000].tobytes()
     eng.close()
     # >= 1 024 queries byte for byte against the C oracle (round 3 compared 72 of the 100 000)
     sample = _sample(got, nq, extremes=32, strided=1000)
