@@ -718,7 +718,8 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         // one block for every per-batch counter, cleared by one memset: [0..3] size-class counts,
         // [4..6] the sweep launches' work cursors, [7] the lean sweep's pool cursor, [8] routed, [9] top-up list, [10] overflow,
         // [11] the lean top-down kernel's cursor, [12..14] routed queries by size class, [16..19] the largest size class of the
-        // small teams split four ways (sweep_lean.hip takes the longest jobs first), [20] what the clustered route's top-up phase forwards
+        // small teams split four ways (sweep_lean.hip takes the longest jobs first), [20] what the clustered route's top-up phase forwards,
+        // [21] k_select_stream's row cursor
         // [32..63] the same for the second set of queues
         if (dev_alloc(ctx, &w.cls_count, 64)) return 1;
         w.route_count = w.cls_count + 8;
@@ -901,6 +902,7 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     s.big_threshold = route_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
     s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;  // (what run_sweep's launch_big will run)
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
+    s.row_cursor = w.cls_count + 21;
     s.seg_slot = w.seg_slot; s.seg_cnt = w.seg_cnt; s.node_level = ctx->tree.level;
     s.slow_list = w.slow_list; s.slow_count = w.slow_count; s.qlist = nullptr; s.qcount = nullptr;
     s.slow_hint = nullptr; s.qhint = nullptr;
@@ -1221,7 +1223,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             {
                 StreamScope scope(ctx, ctx->stream2);
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_top[0], 0));
-                sa.cls_list = w.cls_list + 8 * w.batch; sa.cls_count = w.cls_count + 32;
+                sa.cls_list = w.cls_list + 8 * w.batch; sa.cls_count = w.cls_count + 32; sa.row_cursor = w.cls_count + 32 + 21;
                 sa.overflow_list = w.overflow_list; sa.overflow_count = w.overflow_count; sa.route_classes = 0;
                 if (chain()) return 1;
                 if (run_sweep_second(ctx, qb.out + q0, nq, ctx->stream2)) return 1;
@@ -1449,7 +1451,7 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
             {"APPLES_NO_CLUSTER_TOPUP", APPLES_DBG_NO_CLUSTER_TOPUP}, {"APPLES_NO_STREAM_SELECT", APPLES_DBG_NO_STREAM_SELECT},
             {"APPLES_NO_TOPUP_KERNEL", APPLES_DBG_NO_TOPUP_KERNEL}, {"APPLES_NO_CLUSTER_BIG", APPLES_DBG_NO_CLUSTER_BIG},
             {"APPLES_NO_SD_TOPUP", APPLES_DBG_NO_SD_TOPUP}, {"APPLES_SD_FP6", APPLES_DBG_SD_FP6},
-            {"APPLES_NO_TOPUP_OVERLAP", APPLES_DBG_NO_TOPUP_OVERLAP}};
+            {"APPLES_NO_TOPUP_OVERLAP", APPLES_DBG_NO_TOPUP_OVERLAP}, {"APPLES_STREAM_THIRD_PASS", APPLES_DBG_STREAM_THIRD_PASS}};
         for (const auto &k : knobs)
             if (getenv(k.env)) ctx->dbg |= k.bit;
     }
@@ -1869,6 +1871,7 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.big_threshold = route_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
     s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
+    s.row_cursor = w.cls_count + 21;
     HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 64 * sizeof(int32_t), ctx->stream));  // every counter of the batch
     if (pipe) {
         HIP_TRY(ctx, hipEventRecord(pipe[0], ctx->stream));

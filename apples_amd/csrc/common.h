@@ -358,6 +358,8 @@ struct SelectArgs {
     int64_t cls_stride;
     int big_threshold;                  // n_obs above this -> straight to the big-team sweep list
     int32_t *overflow_list, *overflow_count;
+    int32_t *row_cursor;                // k_select_stream: the next row to hand out (cleared by launch_select), or nullptr = rows dealt out in advance
+    int third_pass;                     // k_select_stream: a third pass over a row that needs the top-up rule instead of the merge in LDS (diagnostic)
     int route_classes;                  // the routed queries go to three lists by size (each cls_stride long, counts at overflow_count[4..6]):
                                         // sweep_lean.hip's workgroup-sized teams take the largest first
     // listed mode of k_select: block r handles query qlist[r] with distances in row r (rows_by_query: in row qlist[r])

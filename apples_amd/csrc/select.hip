@@ -1201,9 +1201,11 @@ int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
 #ifndef STREAM_WAVES
 #define STREAM_WAVES 4
 #endif
+#define STREAM_MERGE_CAP 1280  // `-b` up to which the top-up rule's entries are merged in LDS (half of the four queues: 4 x STREAM_QUEUE / 2)
 #define STREAM_QUEUE ((SU2_LOADS > 4 ? SU2_LOADS : 4) * 128 + 128)  // candidates a wavefront queues before it looks at them (one
                                                                      // round of loads adds at most SU x 128, or 8 x 64 with 8-byte loads)
 // (4 wavefronts per SIMD: the streaming pass wants its loads in flight, not registers)
+static_assert(4 * STREAM_QUEUE >= 2 * STREAM_MERGE_CAP, "the merge's two halves live in the four queues");
 __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(SelectArgs a) {
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
@@ -1225,7 +1227,16 @@ __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(Sele
     // quarters aligned to 64 slots
     const int64_t per = ((nm + 4 * WAVE - 1) / (4 * WAVE)) * WAVE;
     const int64_t w_lo = std::min<int64_t>(nm, per * wv), w_hi = std::min<int64_t>(nm, per * (wv + 1));
-    for (int64_t r = blockIdx.x; r < n_list; r += gridDim.x) {
+    // (a.row_cursor: rows handed out one at a time instead of dealt out in advance -- a tuning knob, see launch_select)
+    __shared__ int sh_row;
+    for (int64_t r = blockIdx.x;; r += gridDim.x) {
+        if (a.row_cursor) {
+            if (tid == 0) sh_row = atomicAdd(a.row_cursor, 1);
+            __syncthreads();
+            r = sh_row;
+            // (the row's closing barrier keeps thread 0's next write behind this read)
+        }
+        if (r >= n_list) break;
         const int64_t q = a.qlist ? a.qlist[r] : r;
         const double *row = a.dist + (a.rows_by_query ? q : r) * a.stride;
         const int self = a.self_slot ? a.self_slot[q] : -1;
@@ -1237,6 +1248,7 @@ __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(Sele
         int n_total = 0, thr_cnt = 0, n_emit = 0;
         int z_i = 0x7fffffff, z_node = -2;
         double z_d = INF_D;
+        bool merged = false;  // the top-up rule's entries were merged into the list without another pass over the row
         for (int round = 0; round < 2; ++round) {
             n_total = 0; thr_cnt = 0; z_i = 0x7fffffff; z_node = -2; z_d = INF_D;
             int wbase = 0;  // keepers this wavefront has written (wave-uniform)
@@ -1365,6 +1377,13 @@ __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(Sele
                 constexpr int KL = 4;
                 double cd[KL];
                 int ci[KL];
+                int cs[KL];  // the slots of the cached keys
+                // what the rule takes is noted as it is taken (the queues of the streaming pass are idle: their upper half), so
+                // that the row need not be streamed a third time to collect it
+                int *const mx_s = &sh_qs[0][0] + STREAM_MERGE_CAP;
+                double *const mx_d = &sh_qd[0][0] + STREAM_MERGE_CAP;
+                const bool direct = late_node && a.baseobs <= STREAM_MERGE_CAP && !a.third_pass;
+                int n_x = 0;
                 int head = 0, filled = 0;
                 bool more = true;
                 auto refill = [&](double lo_d, int lo_i) {
@@ -1392,8 +1411,8 @@ __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(Sele
                             int pos = filled < KL ? filled : KL;
                             while (pos > 0 && key_lt(d, i, cd[pos - 1], ci[pos - 1])) --pos;
                             if (pos < KL) {
-                                for (int k = (filled < KL ? filled : KL - 1); k > pos; --k) { cd[k] = cd[k - 1]; ci[k] = ci[k - 1]; }
-                                cd[pos] = d; ci[pos] = i;
+                                for (int k = (filled < KL ? filled : KL - 1); k > pos; --k) { cd[k] = cd[k - 1]; ci[k] = ci[k - 1]; cs[k] = cs[k - 1]; }
+                                cd[pos] = d; ci[pos] = i; cs[pos] = (int)s;
                                 if (filled < KL) ++filled;
                             }
                         }
@@ -1408,11 +1427,48 @@ __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(Sele
                     const int mine = bi;
                     block_argmin3(bd, bi, bj, sh_d, sh_i, sh_j);
                     if (bi == 0x7fffffff) break;
-                    if (mine == bi && head < filled) ++head;
+                    if (mine == bi && head < filled) {
+                        if (direct) { mx_s[n_x] = cs[head]; mx_d[n_x] = cd[head]; }  // (n_x < baseobs <= STREAM_MERGE_CAP)
+                        ++head;
+                    }
+                    ++n_x;
                     cut_d = bd; cut_i = bi;
                     ++have;
                 }
-                if (cut_i >= 0) continue;  // stream again with the cut
+                if (cut_i >= 0 && !direct) continue;  // stream again with the cut
+                if (cut_i >= 0) {
+                    // The second pass would keep what the first kept plus every key in (threshold, cut]: exactly the n_x entries
+                    // taken above (keys are distinct: one per slot), the query's own slot aside.  Fewer than 2 x baseobs entries
+                    // in all: the first pass's four pieces and the new entries go through LDS, every entry finds its place
+                    // by counting the smaller slots, and the list is written closed up.
+                    int *const m_s = &sh_qs[0][0];
+                    double *const m_d = &sh_qd[0][0];
+                    __syncthreads();  // (mx_* written; sh_wcnt published by block_sum above)
+                    int tot0 = 0;
+                    for (int k = 0; k < 4; ++k) {
+                        const int cnt = sh_wcnt[k];
+                        const int64_t src = std::min<int64_t>(nm, per * k);
+                        for (int c = tid; c < cnt; c += APPLES_TPB) { m_s[tot0 + c] = o_node[src + c]; m_d[tot0 + c] = o_dist[src + c]; }
+                        tot0 += cnt;
+                    }
+                    __syncthreads();
+                    const int total = tot0 + n_x;
+                    int dropped = 0;
+                    for (int j = 0; j < n_x; ++j) dropped += mx_s[j] == self;
+                    for (int e = tid; e < total; e += APPLES_TPB) {
+                        const int s_e = e < tot0 ? m_s[e] : mx_s[e - tot0];
+                        if (e >= tot0 && s_e == self) continue;
+                        const double d_e = e < tot0 ? m_d[e] : mx_d[e - tot0];
+                        int rank = 0;
+                        for (int f = 0; f < tot0; ++f) rank += m_s[f] < s_e;
+                        for (int f = 0; f < n_x; ++f) rank += mx_s[f] < s_e && mx_s[f] != self;
+                        o_node[rank] = s_e;  // (slots for now: late_node; they become nodes in the row's tail below)
+                        o_dist[rank] = d_e;
+                    }
+                    n_emit = total - dropped;
+                    if (tid == 0) n_total += n_x - dropped;
+                    merged = true;
+                }
             }
             break;
         }
@@ -1421,8 +1477,8 @@ __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(Sele
         int cnts[4], pre[4];
         int acc = 0;
         for (int k = 0; k < 4; ++k) { cnts[k] = sh_wcnt[k]; pre[k] = acc; acc += cnts[k]; }
-        n_emit = acc;
-        for (int k = 1; k < 4; ++k) {
+        if (!merged) n_emit = acc;
+        for (int k = 1; k < 4 && !merged; ++k) {
             const int64_t src = std::min<int64_t>(nm, per * k);
             if (src == pre[k]) continue;
             for (int c0 = 0; c0 < cnts[k]; c0 += APPLES_TPB) {  // moving down: read, barrier, write
@@ -1735,6 +1791,13 @@ int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         // workgroup per row); APPLES_STREAM_GRID: tuning knob
         static const int cap = getenv("APPLES_STREAM_GRID") ? atoi(getenv("APPLES_STREAM_GRID")) : 1024;
         if (cap > 0) grid = std::min<unsigned>(grid, (unsigned)cap);
+        b.third_pass = (ctx->dbg & APPLES_DBG_STREAM_THIRD_PASS) ? 1 : 0;  // diagnostic switch
+        // rows dealt out in advance (row r to workgroup r mod grid) unless APPLES_STREAM_DYNAMIC_ROWS hands them out one at a time:
+        // measured on config 5, selection 1.80 -> 1.90 ms for 4 096 rows and 4.55 -> 4.47 for 12 500 (the atomic and its barrier
+        // per row against a better balance of the rows that are streamed twice); off
+        static const bool dynamic_rows = getenv("APPLES_STREAM_DYNAMIC_ROWS") != nullptr;  // tuning knob
+        if (!dynamic_rows) b.row_cursor = nullptr;
+        if (b.row_cursor) HIP_TRY(ctx, hipMemsetAsync(b.row_cursor, 0, sizeof(int32_t), ctx->stream));
         hipLaunchKernelGGL(k_select_stream, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);
     }
     else {

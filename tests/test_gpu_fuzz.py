@@ -157,7 +157,8 @@ def test_distance_table_routes_against_c_oracle(seed):
     entries, ties; streaming selection (default), general selection and the level-loop sweep, all byte for byte against the
     C oracle."""
     rng = np.random.default_rng(seed)
-    routes = (('default', ()), ('no_stream', ('no_stream_select',)), ('no_lean', ('no_sweep_lean', 'no_topup_kernel')))
+    routes = (('default', ()), ('no_stream', ('no_stream_select',)), ('no_lean', ('no_sweep_lean', 'no_topup_kernel')),
+              ('third_pass', ('stream_third_pass',)))
     for c in range(NCFG):
         n = int(rng.choice([33, 64, 257, 1000, 4097, 20001])); nq = int(rng.integers(1, 200))
         thr = float(rng.choice([0.0, 0.05, 0.2, 1.0])); b = int(rng.choice([3, 25, 200])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
