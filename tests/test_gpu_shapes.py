@@ -55,6 +55,9 @@ def test_c3_shape_200k_leaves_100k_queries():
     # the top-up chain beside the sweep) against the same queries inside the full set's batches of 25 000
     shard = eng.place_sequences(d.query_seqs[12500:25000])
     assert shard.tobytes() == got[12500:25000].tobytes()
+    h, n = eng.place_sequences_streamed(d.query_seqs[87500:])  # (what a rank of `bench.py --gpus 8` calls: placements left on the device)
+    assert eng.fetch(h, n).tobytes() == got[87500:].tobytes()
+    eng.free_queries(h)
     eng.close()
     # >= 1 024 queries byte for byte against the C oracle (round 3 compared 72 of the 100 000)
     sample = _sample(got, nq, extremes=32, strided=1000)
