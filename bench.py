@@ -65,6 +65,10 @@ WORKLOADS = {
     # the command line's default route at C3 size: max-diameter clusters at 1.2 x -f with consensus
     # representatives (apples/Reference.py:84-157) instead of all-singleton clusters
     'c3-clustered': (200000, 1000, 100000, False, 'OLS', 0.2),
+    # SURVEY 8d's stress variant: -f 1e9, every leaf observed (V = 2 N - 2 nodes swept per query: the worst case for both
+    # kernel families); C3's shape on a bounded sample of its queries
+    'c2-all': (10000, 1000, 10000, False, 'OLS', 1e9),
+    'c3-all': (200000, 1000, 2048, False, 'OLS', 1e9),
 }
 MFMA_F4_PEAK_TOPS = 10000.0  # dense fp4 peak at the nominal clock, /opt/skills/guides/MI355X_MICROARCH.md, matrix cores table
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
@@ -693,7 +697,10 @@ def main():
             line['other_workloads'] = {'c2': other_workload('c2', local_rank), 'c4': other_workload('c4', local_rank),
                                        'c5': other_workload('c5', local_rank, ds=ds),
                                        # config 5 as one rank of its 8-GPU job holds it: 12 500 of the 100 000 rows (20 GB) resident
-                                       'c5_shard_12500_rows': other_workload('c5', local_rank, ds=ds, queries=12500)}
+                                       'c5_shard_12500_rows': other_workload('c5', local_rank, ds=ds, queries=12500),
+                                       # SURVEY 8d's stress variant at config 3's shape: -f 1e9, every leaf observed, V = 2 N - 2 swept
+                                       # nodes per query (133 MB of algorithmic sweep bytes each), on the first 2 048 queries
+                                       'c3_all_observed_2048_queries': other_workload('c3-all', local_rank, ds=ds)}
         final_line = json.dumps(line)
     if comm is not None:
         comm.barrier()
