@@ -1195,7 +1195,9 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         if (pipelined && i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_back[set], 0));  // set free again
         hipEvent_t *e = &ev[(size_t)i * 6];
         ctx->cur_batch_queries = nq;  // (route_threshold)
-        const int64_t nh = feed ? head(nq) : nq;  // rows of the chunk's first piece
+        // rows of the chunk's first piece.  Only the first chunk is still on the bus when its kernels could start: chunk i + 1
+        // travels while batch i runs and is there, whole, when its turn comes -- one launch then, not two
+        const int64_t nh = (feed && i == 0) ? head(nq) : nq;
         if (feed) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[2 * i + (nh < nq ? 0 : 1)], 0));  // chunk i (its first piece) is on the device
         HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 64 * sizeof(int32_t), front));  // every counter of the batch
         // The top-up chain -- full rows (or rows of bounds) for the queries k_select_fast listed, their selection -- runs BESIDE the
