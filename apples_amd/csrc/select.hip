@@ -1195,18 +1195,19 @@ int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
 // a contiguous quarter of the slots, compacts its keepers with ballots into the start of its own
 // quarter of the output, and the four sparse pieces are then closed up.  If fewer than `baseobs`
 // entries pass the threshold the top-up rule computes a (d, i) cut and the row is streamed again.
-#ifndef SU2_LOADS
-#define SU2_LOADS 4
-#endif
 #ifndef STREAM_WAVES
 #define STREAM_WAVES 4
 #endif
-#define STREAM_MERGE_CAP 1280  // `-b` up to which the top-up rule's entries are merged in LDS (half of the four queues: 4 x STREAM_QUEUE / 2)
-#define STREAM_QUEUE ((SU2_LOADS > 4 ? SU2_LOADS : 4) * 128 + 128)  // candidates a wavefront queues before it looks at them (one
-                                                                     // round of loads adds at most SU x 128, or 8 x 64 with 8-byte loads)
-// (4 wavefronts per SIMD: the streaming pass wants its loads in flight, not registers)
-static_assert(4 * STREAM_QUEUE >= 2 * STREAM_MERGE_CAP, "the merge's two halves live in the four queues");
-__global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(SelectArgs a) {
+#define STREAM_MERGE_CAP 1280  // `-b` up to which the top-up rule's entries are merged in LDS (half of the four queues of the smaller form)
+// SU2 = 16-byte loads in flight per lane.  4 with 640-entry queues (30 KB: four workgroups per CU) for blocks of a few thousand
+// rows; 8 with 1 152-entry queues (54 KB: two workgroups per CU -- fewer, deeper streams) from 8 192 rows on: config 5's 12 500-row
+// shard 4.37 -> 4.00 ms (5.0 TB/s), its 4 096-row block 1.76 -> 1.97 the other way (scripts/r04_stream_su_exp.sh).  A queue holds a
+// whole round of loads (at most SU x 128 candidates, or 8 x 64 with 8-byte loads) + 128; a smaller queue looked at mid-round was
+// measured too: the extra branch costs more than the occupancy brings (scripts/r04_stream_su_exp2.sh).
+template <int SU2>
+__global__ __launch_bounds__(APPLES_TPB, SU2 > 4 ? 2 : STREAM_WAVES) void k_select_stream(SelectArgs a) {  // (the deep form's LDS lets a CU hold two)
+    constexpr int STREAM_QUEUE = (SU2 > 4 ? SU2 : 4) * 128 + 128;  // candidates a wavefront queues before it looks at them
+    static_assert(4 * STREAM_QUEUE >= 2 * STREAM_MERGE_CAP, "the merge's two halves live in the four queues");
     __shared__ int sh_i[8];
     __shared__ int sh_j[8];
     __shared__ double sh_d[8];
@@ -1223,7 +1224,7 @@ __global__ __launch_bounds__(APPLES_TPB, STREAM_WAVES) void k_select_stream(Sele
     // there are none (or this is not a table) it is looked up for the entries that are kept
     const bool early_node = table && !a.cols_all_in_tree;
     const bool late_node = a.cols_all_in_tree != 0;  // (table or alignment: no slot without a tree leaf)
-    constexpr int SU1 = 8, SU2 = SU2_LOADS;  // independent load instructions per lane in flight (8-byte / 16-byte loads)
+    constexpr int SU1 = 8;  // independent load instructions per lane in flight with 8-byte loads (SU2: with 16-byte loads)
     // quarters aligned to 64 slots
     const int64_t per = ((nm + 4 * WAVE - 1) / (4 * WAVE)) * WAVE;
     const int64_t w_lo = std::min<int64_t>(nm, per * wv), w_hi = std::min<int64_t>(nm, per * (wv + 1));
@@ -1798,7 +1799,10 @@ int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         static const bool dynamic_rows = getenv("APPLES_STREAM_DYNAMIC_ROWS") != nullptr;  // tuning knob
         if (!dynamic_rows) b.row_cursor = nullptr;
         if (b.row_cursor) HIP_TRY(ctx, hipMemsetAsync(b.row_cursor, 0, sizeof(int32_t), ctx->stream));
-        hipLaunchKernelGGL(k_select_stream, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);
+        static const int su_env = getenv("APPLES_STREAM_SU") ? atoi(getenv("APPLES_STREAM_SU")) : 0;  // tuning knob: 4 or 8
+        const bool deep = su_env ? su_env == 8 : (!a.qcount && nq >= 8192);
+        if (deep) hipLaunchKernelGGL(k_select_stream<8>, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);
+        else hipLaunchKernelGGL(k_select_stream<4>, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);
     }
     else {
         // clustered rows: the representatives' distances in LDS where they fit (48 KB: 6 144 of them)
