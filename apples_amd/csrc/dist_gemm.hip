@@ -70,6 +70,10 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
     // strips x, x + 8, ... of GM_STRIP reference tiles, and within the XCD the tiles (query tile major, the strip's
     // reference tiles inside) are dealt round-robin to its workgroups, so that the 32 tiles in flight on an XCD are 8
     // consecutive query tiles x one strip.
+    // (Whole strips dealt round the XCDs leave the first XCDs a strip more than the last -- 100 reference tiles against 96 at
+    // config 3, 28 against 24 at config 4.  An eighth of the tiles per XCD, to within one tile, was measured on one box against
+    // this: config 3's pass 27.2 -> 28.4 ms, config 4's 14.6 -> 14.5: the eight XCDs then stream regions a fixed 25 MB apart, and
+    // an XCD that finishes early hands its share of the power budget to the others anyway.)
     const int xcd = blockIdx.x & 7;
     const int64_t per_strip = (int64_t)TQ * GM_STRIP, stride = gridDim.x >> 3;
     const int64_t l_end = (((TR + GM_STRIP - 1) / GM_STRIP + 7) / 8) * per_strip;
