@@ -1325,17 +1325,32 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             const bool lb_topup = qb.sd_q4 && sd_gemm_usable(ctx) && !no_sd_topup && w.dist_rows >= nq;
             if (lb_topup && ctx->sd_list_rows < w.batch) {
                 dev_free(ctx->sd_list_img); ctx->sd_list_img = nullptr; ctx->sd_list_rows = 0;
+                dev_free(ctx->sd_list_ints); ctx->sd_list_ints = nullptr;
                 if (dev_alloc(ctx, &ctx->sd_list_img, sd_query_image_bytes(ctx, round_up(w.batch, 256)))) return 1;
+                if (dev_alloc(ctx, &ctx->sd_list_ints, 2 * w.batch + 1)) return 1;
                 ctx->sd_list_rows = w.batch;
             }
+            // compact lists of the evaluated references for the selection (dist_sd.hip:k_sd_topup<true>) instead of rows of
+            // n_slots values; what a compact row cannot hold goes through the row form afterwards
+            const bool compact = lb_topup && !(ctx->dbg & APPLES_DBG_NO_SD_COMPACT);
+            int32_t *c_len = compact ? ctx->sd_list_ints : nullptr, *c_count2 = compact ? ctx->sd_list_ints + w.batch : nullptr,
+                    *c_list2 = compact ? ctx->sd_list_ints + w.batch + 1 : nullptr;
             if (overlapped(sa, [&]() -> int {
                     return for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
                         // rows of lower bounds on the matrix cores (into the listed queries' rows of w.dist: k_select_fast is done
                         // with them), exact distances only where the `-b` nearest can be (dist_sd.hip:k_sd_topup); else full rows
-                        if (lb_topup ? launch_sd_topup(ctx, qb, q0, n_max, lst, cntp, ctx->sd_list_img, w.dist, w.dist_slow)
+                        if (lb_topup ? launch_sd_topup(ctx, qb, q0, n_max, lst, cntp, ctx->sd_list_img, w.dist, w.dist_slow, c_len, c_list2, c_count2)
                                      : launch_scoredist_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow)) return 1;
                         sa.qlist = lst;
                         sa.qcount = cntp;
+                        if (!compact) return launch_select(ctx, sa, n_max);
+                        sa.row_len = c_len; sa.row_cap = sd_compact_cap(ctx);
+                        if (launch_select(ctx, sa, n_max)) return 1;
+                        // ... and the queries whose lists did not fit (usually none: the launches find an empty list)
+                        sa.row_len = nullptr; sa.row_cap = 0;
+                        if (launch_sd_topup_rows_again(ctx, qb, q0, n_max, c_list2, c_count2, w.dist, w.dist_slow)) return 1;
+                        sa.qlist = c_list2;
+                        sa.qcount = c_count2;
                         return launch_select(ctx, sa, n_max);
                     });
                 })) return 1;
@@ -1453,7 +1468,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
             {"APPLES_NO_CLUSTER_TOPUP", APPLES_DBG_NO_CLUSTER_TOPUP}, {"APPLES_NO_STREAM_SELECT", APPLES_DBG_NO_STREAM_SELECT},
             {"APPLES_NO_TOPUP_KERNEL", APPLES_DBG_NO_TOPUP_KERNEL}, {"APPLES_NO_CLUSTER_BIG", APPLES_DBG_NO_CLUSTER_BIG},
             {"APPLES_NO_SD_TOPUP", APPLES_DBG_NO_SD_TOPUP}, {"APPLES_SD_FP6", APPLES_DBG_SD_FP6},
-            {"APPLES_NO_TOPUP_OVERLAP", APPLES_DBG_NO_TOPUP_OVERLAP}, {"APPLES_STREAM_THIRD_PASS", APPLES_DBG_STREAM_THIRD_PASS}};
+            {"APPLES_NO_TOPUP_OVERLAP", APPLES_DBG_NO_TOPUP_OVERLAP}, {"APPLES_STREAM_THIRD_PASS", APPLES_DBG_STREAM_THIRD_PASS},
+            {"APPLES_NO_SD_COMPACT", APPLES_DBG_NO_SD_COMPACT}, {"APPLES_SD_COMPACT_TINY", APPLES_DBG_SD_COMPACT_TINY}};
         for (const auto &k : knobs)
             if (getenv(k.env)) ctx->dbg |= k.bit;
     }
@@ -1619,7 +1635,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

@@ -266,6 +266,7 @@ struct apples_ctx {
     std::vector<hipEvent_t> ev_feed; // "chunk i of a streamed block is uploaded and packed"
     int32_t *d_slice_cnt = nullptr;  // [64] list lengths of the top-up slices (slim workspaces)
     uint8_t *sd_list_img = nullptr; int64_t sd_list_rows = 0;  // scoredist top-up: operand image of the listed queries (dist_sd.hip)
+    int32_t *sd_list_ints = nullptr;  // ... [sd_list_rows] compact row lengths, [1] count of list2, [sd_list_rows] list2
     // scratch of the clustered fast path's cluster-major distance pass (select.hip), grown on demand
     int32_t *cl_ints = nullptr; int64_t cl_ints_cap = 0;
     int2 *cl_items = nullptr; int64_t cl_items_cap = 0;
@@ -323,7 +324,11 @@ int launch_sd_expand(apples_ctx *ctx, const uint8_t *d_raw, int64_t n, uint8_t *
                      const int32_t *d_src_row, int64_t row0, bool query, float *d_nv, const int32_t *d_n = nullptr,
                      const uint16_t *d_mask = nullptr, int64_t ref_stride = 0);
 int launch_sd_topup(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist, const int32_t *qcount,
-                    uint8_t *img, double *lbrows, double *out_rows);
+                    uint8_t *img, double *lbrows, double *out_rows, int32_t *len = nullptr, int32_t *list2 = nullptr,
+                    int32_t *count2 = nullptr);
+int launch_sd_topup_rows_again(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
+                               const int32_t *qcount, double *lbrows, double *out_rows);
+int sd_compact_cap(const apples_ctx *ctx);  // entries a compact row of launch_sd_topup holds
 int launch_sd_rows(apples_ctx *ctx);
 int launch_sd_filter(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);
 int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, const int32_t *seg_slot,
@@ -358,6 +363,10 @@ struct SelectArgs {
     int64_t cls_stride;
     int big_threshold;                  // n_obs above this -> straight to the big-team sweep list
     int32_t *overflow_list, *overflow_count;
+    // k_select_stream on compact rows (dist_sd.hip:k_sd_topup<true>): row r holds row_len[r] distances in slot order and, from
+    // double `row_cap` on, their slots as 32-bit integers; row_len[r] < 0: not this launch's row.  nullptr: rows of n_members values
+    const int32_t *row_len;
+    int row_cap;
     int32_t *row_cursor;                // k_select_stream: the next row to hand out (cleared by launch_select), or nullptr = rows dealt out in advance
     int third_pass;                     // k_select_stream: a third pass over a row that needs the top-up rule instead of the merge in LDS (diagnostic)
     int route_classes;                  // the routed queries go to three lists by size (each cls_stride long, counts at overflow_count[4..6]):

@@ -626,8 +626,16 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_exact(const uint8_t *__restri
 // has fewer than `-b` references there).  Output: row r of `out` (r = list position) with the exact distances of the evaluated
 // references and -1 (= missing) everywhere else -- k_select's top-up rule on it selects what it would select on the full row.
 // Fewer than `-b` valid distances among the first set: everything is evaluated.
+// COMPACT: the evaluated references leave as a short list instead of a row of n_slots values -- row r of `out` then holds
+// len[r] distances (slot order) followed, from double `cap` on, by their slots as 32-bit integers (k_select_stream's compact
+// rows); a query that evaluates more than `cap` references gets len[r] = -1 and goes on list2 for the row form of this
+// kernel (keys_ready: its row of bounds holds the keys already).  The row form writes 8 n_slots bytes per query and the
+// selection reads them back: 2.0 of config 4's 22.9 ms for 11 % of its queries.
 #define SDT_BINS 4096
 #define SDT_SCALE 2048.0
+#define SDT_CAP 512  // entries of a compact row at most (6 KB of LDS).  k_sd_topup<true> per config 4 pass with 4 096 / 2 048 / 1 024 / 512 / 256
+                     // entries: 2.40 / 1.50 / 1.30 / 0.99 / 0.96 ms (the lists' LDS decides how many workgroups a CU holds); the row form: 1.52
+template <bool COMPACT>
 __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restrict__ rrows, const uint16_t *__restrict__ mrows,
                                                          int Lrow, const uint8_t *__restrict__ qa, const uint16_t *__restrict__ qm,
                                                          const double *__restrict__ table, int64_t n_slots, int64_t slots_pad,
@@ -635,10 +643,14 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restri
                                                          const int32_t *__restrict__ qcount, double *lbrows,
                                                          int64_t row_stride, const float *__restrict__ nvr,
                                                          const float *__restrict__ nvq, int64_t qrow0, int baseobs,
-                                                         double *__restrict__ out_rows) {
+                                                         double *__restrict__ out_rows, int cap, int32_t *__restrict__ len,
+                                                         int32_t *__restrict__ list2, int32_t *__restrict__ count2, int keys_ready) {
     constexpr int TPB = APPLES_TPB, NW = TPB / 64;
     __shared__ double T[21 * 21];
     __shared__ int hist[SDT_BINS];
+    __shared__ int c_s[COMPACT ? SDT_CAP : 1];     // compact form: the evaluated references' slots ...
+    __shared__ double c_d[COMPACT ? SDT_CAP : 1];  // ... and distances, in the order they were evaluated
+    __shared__ int sh_cn;
     __shared__ int sh_w[NW];
     __shared__ int sh_bin;
     __shared__ int wqueue[NW][128];
@@ -696,10 +708,17 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restri
                 const int slot = lane < n ? wqueue[w][(head + lane) & 127] : 0;
                 double x = 0.0;
                 const double d = sd_eval64(rrows, mrows, Lrow, slot, sh_wbuf[w], sh_wslot[w], sh_q, sh_qm, n16, Tb, L, overlap, &x);
-                if (lane < n) {
+                if (COMPACT) {  // (missing distances are simply absent from the list)
+                    const bool keep = lane < n && d >= 0;
+                    const unsigned long long km = __ballot(keep);
+                    int at = 0;
+                    if (lane == 0 && km) at = atomicAdd(&sh_cn, __popcll(km));
+                    at = __shfl(at, 0, 64) + __popcll(km & ((1ull << lane) - 1ull));
+                    if (keep && at < cap) { c_s[at] = slot; c_d[at] = d; }
+                } else if (lane < n) {
                     out[slot] = d;
-                    if (with_hist && d >= 0) atomicAdd(&hist[bin_of(x)], 1);
                 }
+                if (lane < n && with_hist && d >= 0) atomicAdd(&hist[bin_of(x)], 1);
                 head = (head + n) & 127;
                 count -= n;
             };
@@ -725,9 +744,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restri
             }
             if (count > 0) drain(count);
         };
-        // the row starts as "everything missing"; the histogram empty
-        for (int64_t s = (int64_t)tid * 2; s < slots_pad; s += TPB * 2) *reinterpret_cast<double2 *>(out + s) = make_double2(-1.0, -1.0);
+        // the row starts as "everything missing" (row form); the histogram empty
+        if (!COMPACT)
+            for (int64_t s = (int64_t)tid * 2; s < slots_pad; s += TPB * 2) *reinterpret_cast<double2 *>(out + s) = make_double2(-1.0, -1.0);
         for (int i = tid; i < SDT_BINS; i += TPB) hist[i] = 0;
+        if (tid == 0) sh_cn = 0;
         __syncthreads();
         // pass A: key = bound / 4 / min(valid sites of the query, of the row) in single precision (within 2e-7 of the quotient:
         // the tests below carry a margin of 1e-6), written over the bound; +inf where no pair can be valid
@@ -738,10 +759,10 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float vub = nn[j] < nq_ ? nn[j] : nq_;
-                kk[j] = (s + j < n_slots && vub > 0.f) ? bb[j] * 0.25f / vub : __int_as_float(0x7f800000);
+                kk[j] = keys_ready ? bb[j] : ((s + j < n_slots && vub > 0.f) ? bb[j] * 0.25f / vub : __int_as_float(0x7f800000));
                 if (kk[j] < __int_as_float(0x7f800000)) atomicAdd(&hist[bin_of((double)kk[j])], 1);
             }
-            *reinterpret_cast<float4 *>(keys + s) = make_float4(kk[0], kk[1], kk[2], kk[3]);
+            if (!keys_ready) *reinterpret_cast<float4 *>(keys + s) = make_float4(kk[0], kk[1], kk[2], kk[3]);
         }
         __threadfence_block();
         const int b0 = find_bin(baseobs + 8);
@@ -754,7 +775,25 @@ __global__ __launch_bounds__(APPLES_TPB) void k_sd_topup(const uint8_t *__restri
             const double X = b1 >= SDT_BINS - 1 ? INF : (double)(b1 + 1) / SDT_SCALE * (1.0 + 1e-6);
             if (X > t0) eval_range(t0, X, false);
         }
-        __syncthreads();  // (hist, the queues and sh_bin are reused by the next list entry)
+        __syncthreads();  // (hist, the queues and sh_bin are reused by the next list entry; sh_cn and the list are complete)
+        if (COMPACT) {
+            const int n = sh_cn;
+            if (n > cap) {  // too many for a compact row: the row form takes this query
+                if (tid == 0) { len[r] = -1; list2[atomicAdd(count2, 1)] = (int32_t)q; }
+            } else {
+                // slot order: an entry's place = the number of entries with a smaller slot (slots are distinct)
+                int32_t *out_s = reinterpret_cast<int32_t *>(out + cap);
+                for (int e = tid; e < n; e += TPB) {
+                    const int se = c_s[e];
+                    int rank = 0;
+                    for (int f = 0; f < n; ++f) rank += c_s[f] < se;
+                    out[rank] = c_d[e];
+                    out_s[rank] = se;
+                }
+                if (tid == 0) len[r] = n;
+            }
+            __syncthreads();  // (the list is free for the next entry)
+        }
     }
 }
 
@@ -855,8 +894,30 @@ int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t n
 // order (scratch `img`, room for nq_max rows), their rows of bounds on the matrix cores (into the listed queries' own rows of
 // `lbrows`, which the selection has consumed), then k_sd_topup: row r of out_rows = what k_select needs of list entry r's
 // full row.
+// compact rows hold `cap` entries: SDT_CAP, or what two thirds of a row's 8 n_slots bytes hold (12 bytes per entry)
+int sd_compact_cap(const apples_ctx *ctx) {
+    if (ctx->dbg & APPLES_DBG_SD_COMPACT_TINY) return 16;  // diagnostic switch: nearly every listed query overflows into the row form
+    return (int)std::min<int64_t>(SDT_CAP, ctx->aln.slots_pad * 2 / 3 / 64 * 64);
+}
+
+// k_sd_topup alone for a device list whose rows of bounds hold keys already (the queries a compact pass could not hold): row form
+int launch_sd_topup_rows_again(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
+                               const int32_t *qcount, double *lbrows, double *out_rows) {
+    if (nq_max == 0) return 0;
+    const DevAlign &a = ctx->aln;
+    const int Lpad = (a.L + 15) / 16 * 16;
+    const unsigned wgs = (unsigned)std::min<int64_t>(nq_max, (int64_t)ctx->n_cu * 8);
+    hipLaunchKernelGGL(k_sd_topup<false>, dim3(wgs), dim3(APPLES_TPB), (size_t)(2 * Lpad + Lpad / 8), ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow,
+                       qb.aa_idx + q0 * Lpad, qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L,
+                       ctx->params.overlap_frac, qlist, qcount, lbrows, a.slots_pad, a.sd_nvr, qb.sd_nvq, q0, ctx->params.base_observation,
+                       out_rows, 0, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, 1);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// `len` != nullptr: compact rows (len[r] entries in row r of out_rows, -1 = on list2 / count2 for launch_sd_topup_rows_again)
 int launch_sd_topup(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist, const int32_t *qcount,
-                    uint8_t *img, double *lbrows, double *out_rows) {
+                    uint8_t *img, double *lbrows, double *out_rows, int32_t *len, int32_t *list2, int32_t *count2) {
     if (nq_max == 0) return 0;
     const DevAlign &a = ctx->aln;
     const int NB = sd_steps(a.L), Lpad = (a.L + 15) / 16 * 16;
@@ -877,9 +938,18 @@ int launch_sd_topup(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t n
     else { if (R == 0) SD_LAUNCH(0, false); else if (R == 1) SD_LAUNCH(1, false); else SD_LAUNCH(2, false); }
 #undef SD_LAUNCH
     const unsigned wgs = (unsigned)std::min<int64_t>(nq_max, (int64_t)ctx->n_cu * 8);
-    hipLaunchKernelGGL(k_sd_topup, dim3(wgs), dim3(APPLES_TPB), (size_t)(2 * Lpad + Lpad / 8), ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow, qb.aa_idx + q0 * Lpad,
-                       qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L, ctx->params.overlap_frac,
-                       qlist, qcount, lbrows, a.slots_pad, a.sd_nvr, qb.sd_nvq, q0, ctx->params.base_observation, out_rows);
+    if (len) {
+        HIP_TRY(ctx, hipMemsetAsync(count2, 0, sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(k_sd_topup<true>, dim3(wgs), dim3(APPLES_TPB), (size_t)(2 * Lpad + Lpad / 8), ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow,
+                           qb.aa_idx + q0 * Lpad, qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L,
+                           ctx->params.overlap_frac, qlist, qcount, lbrows, a.slots_pad, a.sd_nvr, qb.sd_nvq, q0,
+                           ctx->params.base_observation, out_rows, sd_compact_cap(ctx), len, list2, count2, 0);
+    } else {
+        hipLaunchKernelGGL(k_sd_topup<false>, dim3(wgs), dim3(APPLES_TPB), (size_t)(2 * Lpad + Lpad / 8), ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow,
+                           qb.aa_idx + q0 * Lpad, qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L,
+                           ctx->params.overlap_frac, qlist, qcount, lbrows, a.slots_pad, a.sd_nvr, qb.sd_nvq, q0,
+                           ctx->params.base_observation, out_rows, 0, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, 0);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

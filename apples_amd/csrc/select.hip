@@ -1217,7 +1217,6 @@ __global__ __launch_bounds__(APPLES_TPB, SU2 > 4 ? 2 : STREAM_WAVES) void k_sele
     __shared__ double sh_qd[APPLES_TPB / WAVE][STREAM_QUEUE];  // ... and distance
     const int64_t n_list = a.qcount ? (int64_t)*a.qcount : a.n_rows_plain;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    const int64_t nm = a.n_members;
     const double thr = a.thr;
     const bool table = a.table_mode != 0;
     // A row's node is needed while streaming only to skip table columns that are not tree leaves; if
@@ -1225,9 +1224,6 @@ __global__ __launch_bounds__(APPLES_TPB, SU2 > 4 ? 2 : STREAM_WAVES) void k_sele
     const bool early_node = table && !a.cols_all_in_tree;
     const bool late_node = a.cols_all_in_tree != 0;  // (table or alignment: no slot without a tree leaf)
     constexpr int SU1 = 8;  // independent load instructions per lane in flight with 8-byte loads (SU2: with 16-byte loads)
-    // quarters aligned to 64 slots
-    const int64_t per = ((nm + 4 * WAVE - 1) / (4 * WAVE)) * WAVE;
-    const int64_t w_lo = std::min<int64_t>(nm, per * wv), w_hi = std::min<int64_t>(nm, per * (wv + 1));
     // (a.row_cursor: rows handed out one at a time instead of dealt out in advance -- a tuning knob, see launch_select)
     __shared__ int sh_row;
     for (int64_t r = blockIdx.x;; r += gridDim.x) {
@@ -1240,6 +1236,13 @@ __global__ __launch_bounds__(APPLES_TPB, SU2 > 4 ? 2 : STREAM_WAVES) void k_sele
         if (r >= n_list) break;
         const int64_t q = a.qlist ? a.qlist[r] : r;
         const double *row = a.dist + (a.rows_by_query ? q : r) * a.stride;
+        // a compact row: nm of the reference's values, entry s belongs to slot rs[s] (slots ascending); else entry s = slot s
+        const int32_t *rs = a.row_len ? reinterpret_cast<const int32_t *>(row + a.row_cap) : nullptr;
+        if (a.row_len && a.row_len[r] < 0) continue;  // (block-uniform: this query's list did not fit; another launch has its row)
+        const int64_t nm = a.row_len ? a.row_len[r] : a.n_members;
+        // quarters aligned to 64 entries
+        const int64_t per = ((nm + 4 * WAVE - 1) / (4 * WAVE)) * WAVE;
+        const int64_t w_lo = std::min<int64_t>(nm, per * wv), w_hi = std::min<int64_t>(nm, per * (wv + 1));
         const int self = a.self_slot ? a.self_slot[q] : -1;
         int32_t *o_node = a.obs_node + q * a.obs_cap;
         double *o_dist = a.obs_dist + q * a.obs_cap;
@@ -1268,7 +1271,8 @@ __global__ __launch_bounds__(APPLES_TPB, SU2 > 4 ? 2 : STREAM_WAVES) void k_sele
                     int node = 0;
                     double d = 0;
                     if (i < q_n) {
-                        const int64_t s = w_lo + sh_qs[wv][i];
+                        const int64_t e_ = w_lo + sh_qs[wv][i];
+                        const int64_t s = rs ? rs[e_] : e_;  // the entry's slot
                         d = sh_qd[wv][i];
                         bool ok = true;
                         if (early_node) { node = a.slot_node[s]; ok = node >= 0; }
@@ -1399,9 +1403,10 @@ __global__ __launch_bounds__(APPLES_TPB, SU2 > 4 ? 2 : STREAM_WAVES) void k_sele
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const int64_t s = s0 + u * APPLES_TPB;
+                            const int64_t e_ = s0 + u * APPLES_TPB;
                             const double d = dd[u];
                             if (!(d >= 0 && d > thr) || d < lo_d) continue;
+                            const int64_t s = rs ? rs[e_] : e_;  // the entry's slot
                             if (early_node && a.slot_node[s] < 0) continue;
                             // the index decides ties only: beyond the cut and beyond the cache's last key it is not needed
                             const bool fits = filled < KL || d <= cd[KL - 1];

@@ -112,7 +112,7 @@ def test_scoredist_routes_agree(seed):
     the reference's own summation order is BLAS-internal)."""
     rng = np.random.default_rng(seed)
     routes = (('default', ()), ('fp6', ('sd_fp6',)), ('every_pair', ('no_sd_gemm',)), ('rows_topup', ('no_sd_topup',)), ('no_fuse', ('no_fuse',)),
-              ('serial_topup', ('no_topup_overlap',)))
+              ('serial_topup', ('no_topup_overlap',)), ('row_lists', ('no_sd_compact',)), ('tiny_lists', ('sd_compact_tiny',)))
     checked = 0
     for c in range(NCFG):
         n = int(rng.choice([40, 257, 600, 1500, 5000, 20000])); L = int(rng.integers(7, 1200)); nq = int(rng.integers(1, 700))
@@ -128,7 +128,7 @@ def test_scoredist_routes_agree(seed):
         out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, protein=True, method=m, threshold=thr, baseobs=b,
                                                 max_batch=mb, debug=dbg), q)
         tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s' % (seed, c, n, L, nq, gap, thr, b, mb, m)
-        for k in ('fp6', 'every_pair', 'rows_topup', 'no_fuse', 'serial_topup'):
+        for k in ('fp6', 'every_pair', 'rows_topup', 'no_fuse', 'serial_topup', 'row_lists', 'tiny_lists'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
             co = COracle(d.tree, d.ref_seqs, nodes, protein=True, method=m, criterion='MLSE', threshold=thr, baseobs=b, threads=NTHREADS)
