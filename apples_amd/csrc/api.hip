@@ -1142,21 +1142,35 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     const bool split_feed = feed && fused && !cfused && !pipelined && ((sfused && qb.sd_q4 && sd_gemm_usable(ctx)) ||
                                                                         (!sfused && fused_counts_format(ctx, qb) && dist_gemm_usable(ctx)));
     auto head = [&](int64_t nq) -> int64_t { return split_feed && nq >= 4096 ? round_up(nq / 4, 256) : nq; };
-    auto feed_chunk = [&](int64_t i) -> int {  // upload + pack sub-batch i on stream2, an event behind each piece
+    // upload + pack sub-batch i on stream2, an event behind each piece.  The copy of a pageable host buffer holds the calling
+    // thread until the bytes are on their way: the first chunk's second piece is therefore sent (feed_rest) only after the
+    // kernels of its first piece have been launched -- sent right behind the first piece, nothing reached the main stream before
+    // the whole chunk had gone (config 2's timeline: the distance pass started 0.2 ms after its first piece was ready).
+    bool rest_pending = false;
+    auto feed_head = [&](int64_t i) -> int {
         const int64_t q0 = i * step, nq = std::min(step, qb.n - q0), h = head(nq);
         if (fill_block(ctx, &qb, feed->host, q0, h, ctx->stream2)) return 1;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_feed[2 * i], ctx->stream2));
-        if (h < nq && fill_block(ctx, &qb, feed->host, q0 + h, nq - h, ctx->stream2)) return 1;
+        rest_pending = h < nq;
+        if (!rest_pending) HIP_TRY(ctx, hipEventRecord(ctx->ev_feed[2 * i + 1], ctx->stream2));
+        return 0;
+    };
+    auto feed_rest = [&](int64_t i) -> int {
+        if (!rest_pending) return 0;
+        const int64_t q0 = i * step, nq = std::min(step, qb.n - q0), h = head(nq);
+        rest_pending = false;
+        if (fill_block(ctx, &qb, feed->host, q0 + h, nq - h, ctx->stream2)) return 1;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_feed[2 * i + 1], ctx->stream2));
         return 0;
     };
+    auto feed_chunk = [&](int64_t i) -> int { return feed_head(i) || feed_rest(i); };
     if (feed) {
         while (ctx->ev_feed.size() < (size_t)n_sub * 2) {
             hipEvent_t e;
             HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->ev_feed.push_back(e);
         }
-        if (feed_chunk(0)) return 1;
+        if (feed_head(0)) return 1;
     }
     HIP_TRY(ctx, hipEventRecord(e_start, front));
     if (pipelined) HIP_TRY(ctx, hipStreamWaitEvent(back, e_start, 0));
@@ -1303,7 +1317,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 // segments closed up in place (dist_sd.hip)
                 HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (w.stride / 64) * sizeof(int32_t), front));
                 if (launch_sd_filter(ctx, qb, q0, nh, w.seg_slot, w.seg_cnt)) return 1;
-                if (nh < nq) {  // the rest of the chunk has arrived meanwhile
+                if (nh < nq) {  // the rest of the chunk travels meanwhile
+                    if (feed_rest(i)) return 1;
                     HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[2 * i + 1], 0));
                     if (launch_sd_filter(ctx, qb, q0 + nh, nq - nh, w.seg_slot + nh * w.stride, w.seg_cnt + nh * (w.stride / 64))) return 1;
                     ++launches;
@@ -1359,7 +1374,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             if (fused_counts_format(ctx, qb))  // the matrix-core kernel writes only the non-empty segments' counts
                 HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (w.stride / 64) * sizeof(int32_t), front));
             if (launch_counts_fused(ctx, qb, q0, nh, dist_tile_for(nq), w.dist, w.seg_slot, w.seg_cnt)) return 1;
-            if (nh < nq) {  // the rest of the chunk has arrived meanwhile (split_feed: the GEMM form, packed survivors in seg_slot alone)
+            if (nh < nq) {  // the rest of the chunk travels meanwhile (split_feed: the GEMM form, packed survivors in seg_slot alone)
+                if (feed_rest(i)) return 1;
                 HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[2 * i + 1], 0));
                 if (launch_counts_fused(ctx, qb, q0 + nh, nq - nh, dist_tile_for(nq), w.dist, w.seg_slot + nh * w.stride,
                                         w.seg_cnt + nh * (w.stride / 64))) return 1;
@@ -1405,6 +1421,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_front[set], front));
             HIP_TRY(ctx, hipStreamWaitEvent(back, ctx->ev_front[set], 0));
         }
+        if (feed && feed_rest(i)) return 1;  // (a route that did not ask for the second piece itself: nothing left behind)
         if (!swept_here) {
             HIP_TRY(ctx, hipEventRecord(e[3], back));
             if (run_sweep(ctx, qb.out + q0, nq, back)) return 1;
