@@ -22,11 +22,14 @@ _TOKEN = re.compile(r"\(|\)|,|;|:|'(?:[^']|'')*'|\[[^\]]*\]|[^(),:;\[\]']+")
 class Tree:
     """Array form of the backbone tree.  All arrays have length ``n_nodes``."""
 
-    def __init__(self, parent, edge_len, has_len, labels, child_off, child_idx, level, is_rooted):
+    def __init__(self, parent, edge_len, has_len, labels, child_off, child_idx, level, is_rooted, label_src=None):
         self.parent = parent  # int32, -1 for the root
         self.edge_len = edge_len  # float64, 0.0 where has_len is False
         self.has_len = has_len  # bool: edge length present in the Newick
-        self.labels = labels  # list[str|None]
+        # labels: list[str|None], or None with label_src = (text, offset[n], length[n]: -1 = no label) -- the labels as slices of the
+        # Newick text they were scanned from, cut into strings only when somebody asks (a 200 000-leaf backbone: 0.12 s of 0.35)
+        self._labels = labels
+        self._label_src = label_src
         self.child_off = child_off  # int32[n_nodes+1]
         self.child_idx = child_idx  # int32[n_nodes-1], file order
         self.level = level  # int32
@@ -37,9 +40,26 @@ class Tree:
         self.is_leaf = nchild == 0
         self.leaves = np.nonzero(self.is_leaf)[0].astype(np.int32)  # ascending id == left-to-right
         # leaf label -> node id (apples/prepareTree.py:32-34; later duplicates overwrite)
-        self.name_to_node = {}
-        for v in self.leaves:
-            self.name_to_node[labels[v]] = int(v)
+        if labels is None:
+            text, lo, ll = label_src
+            a, k = lo[self.leaves], ll[self.leaves]
+            if (k < 0).any():  # (a leaf without a label: the key is None, as labels[v] would be)
+                self.name_to_node = {(text[o:o + n] if n >= 0 else None): v
+                                     for o, n, v in zip(a.tolist(), k.tolist(), self.leaves.tolist())}
+            else:
+                self.name_to_node = dict(zip([text[o:e] for o, e in zip(a.tolist(), (a + k).tolist())], self.leaves.tolist()))
+        else:
+            self.name_to_node = {}
+            for v in self.leaves:
+                self.name_to_node[labels[v]] = int(v)
+
+    @property
+    def labels(self):
+        """list[str|None], one per node."""
+        if self._labels is None:
+            text, lo, ll = self._label_src
+            self._labels = [text[o:o + k] if k >= 0 else None for o, k in zip(lo.tolist(), ll.tolist())]
+        return self._labels
 
     @property
     def n_leaves(self):
@@ -122,6 +142,12 @@ def _scan_py(text):
     return np.array(t_parent, dtype=np.int64), np.array(t_depth, dtype=np.int64), size, t_label, lens, given
 
 
+class _LabelSlices:
+    """Per-node labels in creation order as (offset, length) into the scanned text (length -1 = none)."""
+    def __init__(self, text, off, length):
+        self.text, self.off, self.length = text, off, length
+
+
 def _scan_native(text):
     """The same through libapples_io.so (include/apples_io.h: apples_newick_scan), or None when the
     library is missing, the text is not plain ASCII, or the scanner met something it leaves to
@@ -144,10 +170,15 @@ def _scan_native(text):
     if rc != 0:
         return None
     n = n.value
-    loff = loff[:n].tolist(); llen = llen[:n].tolist()
-    labels = [text[o:o + k] if k >= 0 else None for o, k in zip(loff, llen)]
-    for k in np.nonzero(lq[:n])[0].tolist():
-        labels[k] = labels[k].replace("''", "'")
+    # labels stay slices of the text (Tree.labels cuts them on demand) unless a quoted one holds a doubled quote to undo
+    quoted = np.nonzero(lq[:n])[0].tolist()
+    if any("''" in text[loff[k]:loff[k] + llen[k]] for k in quoted):
+        lo = loff[:n].tolist(); ll = llen[:n].tolist()
+        labels = [text[o:o + k] if k >= 0 else None for o, k in zip(lo, ll)]
+        for k in quoted:
+            labels[k] = labels[k].replace("''", "'")
+    else:
+        labels = _LabelSlices(text, loff[:n].copy(), llen[:n].copy())
     st = st[:n]
     lens = np.where(st == 1, val[:n], np.nan)
     try:
@@ -185,9 +216,15 @@ def parse_newick(text):
     has_len = np.zeros(n, dtype=bool)
     edge_len[post[given]] = lens[given]
     has_len[post] = given
-    labels = [None] * n
-    for p, lab in zip(post.tolist(), t_label):
-        labels[p] = lab
+    label_src = None
+    if isinstance(t_label, _LabelSlices):
+        lo = np.empty(n, dtype=np.int64); ll = np.empty(n, dtype=np.int32)
+        lo[post] = t_label.off; ll[post] = t_label.length
+        labels, label_src = None, (t_label.text, lo, ll)
+    else:
+        labels = [None] * n
+        for p, lab in zip(post.tolist(), t_label):
+            labels[p] = lab
     nchild = np.bincount(parent[parent >= 0], minlength=n)
     child_off = np.zeros(n + 1, dtype=np.int32)
     child_off[1:] = np.cumsum(nchild)
@@ -197,7 +234,7 @@ def parse_newick(text):
     child_idx = post[order].astype(np.int32) if n > 1 else np.empty(0, dtype=np.int32)
     level = np.zeros(n, dtype=np.int32)
     level[post] = pre_depth  # BFS depth (apples/util.py:72-88)
-    return Tree(parent, edge_len, has_len, labels, child_off, child_idx, level, is_rooted)
+    return Tree(parent, edge_len, has_len, labels, child_off, child_idx, level, is_rooted, label_src=label_src)
 
 
 def read_tree(path):
@@ -220,16 +257,24 @@ def _extended_newick_native(tree):
         return None
     import ctypes
     n = tree.n_nodes
-    labs = tree.labels
-    try:
-        parts = [b'' if x is None else x.encode() for x in labs]
-    except AttributeError:
-        return None
-    llen = np.fromiter((-1 if x is None else len(b) for x, b in zip(labs, parts)), dtype=np.int32, count=n)
-    loff = np.zeros(n, dtype=np.int64)
-    np.cumsum(np.maximum(llen[:-1], 0), out=loff[1:])
-    blob = b''.join(parts)
-    cap = 64 + 40 * n + len(blob)
+    src = getattr(tree, '_label_src', None)
+    if src is not None and getattr(tree, '_labels', None) is None:
+        # the labels are slices of the (ASCII) text the tree was scanned from: that text is the blob
+        blob = src[0].encode('ascii')
+        loff = np.ascontiguousarray(src[1], dtype=np.int64)
+        llen = np.ascontiguousarray(src[2], dtype=np.int32)
+        cap = 64 + 40 * n + int(np.maximum(llen, 0).sum())
+    else:
+        labs = tree.labels
+        try:
+            parts = [b'' if x is None else x.encode() for x in labs]
+        except AttributeError:
+            return None
+        llen = np.fromiter((-1 if x is None else len(b) for x, b in zip(labs, parts)), dtype=np.int32, count=n)
+        loff = np.zeros(n, dtype=np.int64)
+        np.cumsum(np.maximum(llen[:-1], 0), out=loff[1:])
+        blob = b''.join(parts)
+        cap = 64 + 40 * n + len(blob)
     out = ctypes.create_string_buffer(cap)
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     lib.apples_extended_newick.restype = ctypes.c_int64

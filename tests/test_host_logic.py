@@ -403,7 +403,7 @@ def _same_tree(a, b):
         return a[1:] == b[1:]
     x, y = a[1], b[1]
     return (np.array_equal(x.parent, y.parent) and np.array_equal(x.edge_len, y.edge_len, equal_nan=True)
-            and np.array_equal(x.has_len, y.has_len) and x.labels == y.labels
+            and np.array_equal(x.has_len, y.has_len) and x.name_to_node == y.name_to_node and x.labels == y.labels
             and np.array_equal(x.child_off, y.child_off) and np.array_equal(x.child_idx, y.child_idx)
             and np.array_equal(x.level, y.level) and x.is_rooted == y.is_rooted)
 
