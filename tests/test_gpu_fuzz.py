@@ -107,8 +107,9 @@ def test_singleton_jc69_routes_agree(seed):
 @pytest.mark.parametrize('seed', [4, 11] + EXTRA_SEEDS)
 def test_scoredist_routes_agree(seed):
     """scoredist, singleton clusters: matrix-core lower-bound filter (fp4 table values) + exact candidates + lower-bound top-up
-    (default) against the same with fp6 table values, against every pair with the early exit (no filter), against the filter with full rows for the top-up list, and against full
-    rows + general selection; small backbones also against the C oracle (edges, flags and counts equal, lengths to 1e-9:
+    (default) against the same with fp6 table values, against every pair with the early exit (no filter), against the filter with full rows for the top-up list, against full
+    rows + general selection, against the top-up chain before the sweep, and against the top-up's row form for every listed query / for
+    nearly every one (compact lists of 16 entries: the hand-over to the row form); small backbones also against the C oracle (edges, flags and counts equal, lengths to 1e-9:
     the reference's own summation order is BLAS-internal)."""
     rng = np.random.default_rng(seed)
     routes = (('default', ()), ('fp6', ('sd_fp6',)), ('every_pair', ('no_sd_gemm',)), ('rows_topup', ('no_sd_topup',)), ('no_fuse', ('no_fuse',)),
