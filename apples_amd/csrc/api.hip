@@ -435,6 +435,10 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
             if (launch_sd_rows(ctx)) return 1;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (codes is on the stack)
         }
+        // clustered reference (the default route of -p): the representatives' rows in representative order for the fused selection
+        // by representatives (select.hip: k_select_clusters around k_cluster_dist_sd)
+        if (!a.all_singleton && a.n_refs <= SELECT_CLUSTERS_MAX_SLOTS && !getenv("APPLES_NO_CLUSTER_FUSE"))
+            if (launch_build_cluster_panels_aa(ctx)) return 1;
     } else {
         int *d_exotic = nullptr;
         if (dev_alloc(ctx, &d_exotic, 1)) return 1;
@@ -657,7 +661,8 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         int64_t budget_gib = 96;
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_gib = std::max<int64_t>(8, std::min<int64_t>(96, (int64_t)(fr >> 30) * 2 / 5));
-        if (const char *e = getenv("APPLES_BATCH_GIB")) budget_gib = std::max<int64_t>(1, atoll(e));  // tuning knob
+        if (ctx->params.batch_gib > 0) budget_gib = std::min<int64_t>(budget_gib, ctx->params.batch_gib);  // the caller's cap only lowers it
+        if (const char *e = getenv("APPLES_BATCH_GIB")) budget_gib = std::max<int64_t>(1, atoll(e));  // tuning knob (experiments: replaces both)
         capq = std::max<int64_t>(32, ((need_alt ? budget_gib / 2 : budget_gib) << 30) / std::max<int64_t>(per_q, 1));
         int64_t b = want_batch;
         if (ctx->params.max_batch > 0) b = std::min(b, (int64_t)ctx->params.max_batch);
@@ -1103,11 +1108,14 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     // clustered references: the matrix-core pass runs over the representatives only, k_select_clusters expands
     // the accepted clusters (needs the panels of setup_alignment, the tabulated distances and their integer
     // threshold form)
-    const bool cfused = !no_fuse && !a.all_singleton && ctx->params.model == APPLES_JC69 && a.rep_packed && a.packed_rm &&
-                        fused_counts_format(ctx, qb);
+    // (scoredist contexts, csd: full rows of the distances to the representatives in place of the matrix-core pass, k_cluster_dist_sd
+    // for the members)
+    const bool csd = !no_fuse && !a.all_singleton && ctx->params.model == APPLES_SCOREDIST && a.aa_rep_idx;
+    const bool cfused = csd || (!no_fuse && !a.all_singleton && ctx->params.model == APPLES_JC69 && a.rep_packed && a.packed_rm &&
+                                fused_counts_format(ctx, qb));
     // scoredist with singleton clusters: threshold compaction in the distance kernel's epilogue as well
     const bool sfused = !no_fuse && a.all_singleton && ctx->params.model == APPLES_SCOREDIST;
-    const bool fused = !no_fuse && (((a.all_singleton || cfused) && ctx->params.model == APPLES_JC69) || sfused);
+    const bool fused = !no_fuse && (((a.all_singleton || cfused) && ctx->params.model == APPLES_JC69) || sfused || csd);
     const bool pipelined = n_pipe > 1 && qb.n >= 1024;
     int64_t want = qb.n;
     if (pipelined) want = round_up((qb.n + n_pipe - 1) / n_pipe, 32);
@@ -1175,7 +1183,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     HIP_TRY(ctx, hipEventRecord(e_start, front));
     if (pipelined) HIP_TRY(ctx, hipStreamWaitEvent(back, e_start, 0));
     int launches = 0;
-    bool sd_filter_timed = false;
+    std::vector<char> sd_filter_timed((size_t)n_sub, 0);  // per sub-batch: e[5] was recorded (the scoredist filter ran there)
     // The queries on the top-up / slow list get full distance rows; a slim workspace holds rows for a slice of the batch
     // only: the list's length comes to the host (one short wait per batch) and the list is walked in slices of that many
     // queries.  fn(list, count pointer, entries at most) runs the listed distance pass + selection for one slice.
@@ -1253,13 +1261,28 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         };
         if (cfused) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
-            HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (a.reps_pad / 64) * sizeof(int32_t), front));
-            if (launch_counts_reps(ctx, qb, q0, nq, w.seg_slot, w.seg_cnt)) return 1;
+            if (csd) {
+                if (ctx->sd_rep_d_cap < w.batch * a.reps_pad) {
+                    dev_free(ctx->sd_rep_d); ctx->sd_rep_d = nullptr; ctx->sd_rep_d_cap = 0;
+                    if (dev_alloc(ctx, &ctx->sd_rep_d, w.batch * a.reps_pad)) return 1;
+                    ctx->sd_rep_d_cap = w.batch * a.reps_pad;
+                }
+                if (launch_scoredist_reps(ctx, qb, q0, nq, ctx->sd_rep_d, w.seg_slot, w.seg_cnt)) return 1;  // (writes every segment's count)
+            } else {
+                HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (a.reps_pad / 64) * sizeof(int32_t), front));
+                if (launch_counts_reps(ctx, qb, q0, nq, w.seg_slot, w.seg_cnt)) return 1;
+            }
             HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;
             SelectArgs sa = select_args_alignment(ctx, qb, q0);
             sa.seg_lut = ctx->jc_lut;
-            sa.packed_rm = a.packed_rm; sa.qpacked = qb.packed + q0 * a.G * 3; sa.G = a.G; sa.L = a.L;
+            if (csd) {
+                const int Lpad = (a.L + 15) / 16 * 16;
+                sa.seg_lut = nullptr; sa.rep_dist = ctx->sd_rep_d;
+                sa.aa_idx = a.aa_idx; sa.aa_mask = a.aa_mask; sa.q_aa = qb.aa_idx + q0 * Lpad; sa.q_aam = qb.aa_mask + q0 * (Lpad / 16);
+                sa.Lpad = Lpad; sa.table = ctx->blosum;
+            }
+            sa.packed_rm = a.packed_rm; sa.qpacked = csd ? nullptr : qb.packed + q0 * a.G * 3; sa.G = a.G; sa.L = a.L;
             sa.overlap = ctx->params.overlap_frac; sa.rep_stride = a.reps_pad; sa.tmp_d = w.dist;
             sa.slow_hint = w.slow_list + w.batch;
             sa.lvl_slots = a.lvl_slots;
@@ -1293,7 +1316,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             if (launch_select_clusters(ctx, sa, nq)) return 1;
             // queries whose accepted clusters hold fewer than -b valid distances: the top-up rule over the representatives
             // (phase 4 of k_select_clusters); what that cannot hold: full rows + general selection
-            const bool no_listed = (ctx->dbg & APPLES_DBG_NO_CLUSTER_TOPUP) != 0;  // diagnostic switch: everything through the general route
+            // (scoredist: no phase 4 yet -- its listed queries take the general route)
+            const bool no_listed = csd || (ctx->dbg & APPLES_DBG_NO_CLUSTER_TOPUP) != 0;  // diagnostic switch: everything through the general route
             int32_t *fwd_list = w.slow_list + 2 * w.batch, *fwd_count = w.cls_count + 20;
             if (!no_listed) {
                 sa.rep_panel = a.rep_packed; sa.slow2_list = fwd_list; sa.slow2_count = fwd_count;
@@ -1303,7 +1327,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             sa.seg_lut = nullptr;
             sa.dist = w.dist_slow;
             if (for_slow_slices(nq, [&](const int32_t *lst, const int32_t *cntp, int64_t n_max) -> int {
-                    if (launch_counts_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow, nullptr, nullptr)) return 1;
+                    if (csd ? launch_scoredist_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow)
+                            : launch_counts_listed(ctx, qb, q0, n_max, lst, cntp, w.dist_slow, nullptr, nullptr)) return 1;
                     sa.qlist = lst;
                     sa.qcount = cntp;
                     sa.qhint = no_listed ? lst + w.batch : nullptr;
@@ -1324,7 +1349,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                     ++launches;
                 }
                 HIP_TRY(ctx, hipEventRecord(e[5], front));
-                sd_filter_timed = true;
+                sd_filter_timed[(size_t)i] = 1;
                 if (launch_sd_exact(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt, w.n_obs)) return 1;
             } else if (launch_scoredist_fused(ctx, qb, q0, nq, w.dist, w.seg_slot, w.seg_cnt, nullptr)) return 1;
             HIP_TRY(ctx, hipEventRecord(e[1], front));
@@ -1442,8 +1467,11 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         hipEvent_t *e = &ev[(size_t)i * 6];
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e[0], e[1]); ctx->t_ms[APPLES_T_DIST] += ms;
-        if (sd_filter_timed) (void)hipEventElapsedTime(&ms, e[0], e[5]);
-        ctx->t_ms[APPLES_T_FILTER] += ms;
+        if (sd_filter_timed[(size_t)i]) {  // (a sub-batch without the filter adds nothing: T_FILTER = 0 means no filter ran)
+            float fms = 0;
+            (void)hipEventElapsedTime(&fms, e[0], e[5]);
+            ctx->t_ms[APPLES_T_FILTER] += fms;
+        }
         (void)hipEventElapsedTime(&ms, e[1], e[2]); ctx->t_ms[APPLES_T_SELECT] += ms;
         (void)hipEventElapsedTime(&ms, e[3], e[4]); ctx->t_ms[APPLES_T_SWEEP] += ms;
     }
@@ -1646,13 +1674,13 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     ctx->blk_cache.clear();
     dev_free(ctx->d_exotic);
     dev_free(ctx->d_slice_cnt);
-    dev_free(ctx->cl_ints); dev_free(ctx->cl_items); dev_free(ctx->cl_tiles);
+    dev_free(ctx->cl_ints); dev_free(ctx->cl_items); dev_free(ctx->cl_tiles); dev_free(ctx->sd_rep_d);
     for (auto &e : ctx->ev_feed) (void)hipEventDestroy(e);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);
@@ -2236,7 +2264,8 @@ const char *apples_describe(apples_ctx *ctx) {
              ctx->tree.scan ? "scan" : (ctx->ws.small.lean || (ctx->ws.batch == 0 && sweep_lean_layout(ctx->tree, false))) ? "lean"
              : sweep_merge_lists(ctx->tree) ? "merge" : sweep_bits_in_lds(ctx->tree) ? "bits" : "map",
              // clustered references with the panels of the fast path (representatives for the matrix-core pass, members cluster-major)
-             (!a.all_singleton && a.rep_packed && a.packed_rm && ctx->params.model == APPLES_JC69 && !(ctx->dbg & APPLES_DBG_NO_FUSE)) ? 1 : 0,
+             (!a.all_singleton && !(ctx->dbg & APPLES_DBG_NO_FUSE) &&
+              ((a.rep_packed && a.packed_rm && ctx->params.model == APPLES_JC69) || (a.aa_rep_idx && ctx->params.model == APPLES_SCOREDIST))) ? 1 : 0,
              // scoredist: the fused pass filters on the matrix cores (dist_sd.hip) at the present threshold
              (ctx->params.model == APPLES_SCOREDIST && sd_gemm_usable(ctx) && !(ctx->dbg & APPLES_DBG_NO_FUSE)) ? 1 : 0,
              (long long)(a.sd_ref4 ? a.slots_pad * (int64_t)sd_steps(a.L) * 64 : 0));

@@ -126,6 +126,10 @@ struct DevAlign {
     uint4 *packed_rm = nullptr;   // the member rows cluster by cluster, interleaved per plane word (dist.hip:k_cluster_major): [n_refs * G*3]
     uint4 *rep_packed = nullptr;  // [G][3][reps_pad] the representatives' rows, in representative order
     int64_t reps_pad = 0;
+    // ... and of scoredist contexts (the default route of -p): the representatives' rows in representative order, in the layout
+    // of aa_idx / aa_mask with reps_pad in place of slots_pad (what k_scoredist runs over in place of every slot)
+    uint8_t *aa_rep_idx = nullptr;   // [Lpad16/16][reps_pad][16]
+    uint16_t *aa_rep_mask = nullptr; // [Lpad16/16][reps_pad]
     uint8_t *aa_idx = nullptr;    // scoredist: [Lpad16/16][slots_pad][16] residue index * 8 (0..152, 160 = gap)
     uint16_t *aa_mask = nullptr;  // scoredist: [Lpad16/16][slots_pad] bit k = site 16*s16+k is not a gap
     uint8_t *aa_rows = nullptr;   // scoredist, beside sd_ref4: the same residue bytes slot-major, [slots_pad][aa_Lrow] (dist_sd.hip:sd_eval64)
@@ -271,6 +275,7 @@ struct apples_ctx {
     int32_t *cl_ints = nullptr; int64_t cl_ints_cap = 0;
     int2 *cl_items = nullptr; int64_t cl_items_cap = 0;
     int4 *cl_tiles = nullptr; int64_t cl_tiles_cap = 0;
+    double *sd_rep_d = nullptr; int64_t sd_rep_d_cap = 0;  // scoredist: [batch][reps_pad] the queries' distances to every representative
     unsigned long long *scan_prof = nullptr;  // APPLES_SCAN_PROFILE: per-phase cycle sums of the scan sweep
     unsigned long long *lean_prof = nullptr;  // APPLES_LEAN_PROFILE: the same for sweep_lean.hip's wavefront-sized teams
     // -d path: column layout cache
@@ -312,6 +317,11 @@ int launch_scoredist(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t 
                      uint32_t *d_counts);
 int launch_scoredist_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, int32_t *seg_slot,
                            int32_t *seg_cnt, double *full_rows);
+int launch_build_cluster_panels_aa(apples_ctx *ctx);  // scoredist: the representatives' rows in representative order
+// scoredist of queries q0.. to every representative: full rows of reps_pad values (rep_d), then the survivors 0 <= d <= threshold
+// per 64-representative segment as k_select_clusters reads them (position << 26 in seg_slot, counts in seg_cnt)
+int launch_scoredist_reps(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *rep_d, int32_t *seg_slot,
+                          int32_t *seg_cnt);
 int launch_scoredist_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
                             const int32_t *qcount, double *d_dist);
 // dist_sd.hip: the fused scoredist pass as a lower bound on the matrix cores + exact evaluation of the candidates
@@ -393,6 +403,12 @@ struct SelectArgs {
     // and where it forwards what it cannot serve (then full rows + k_select)
     const uint4 *rep_panel; int32_t *slow2_list, *slow2_count;
     int32_t *big_list, *big_count;  // queries with more than ACC_CAP accepted clusters: served by the phases' second form (CAP = BIG_CAP)
+    // scoredist contexts on that path (k_cluster_dist_sd, phase 4): the representatives' distances come as full rows (the survivors
+    // in seg_slot carry their position only), the members' from the packed residue bytes
+    const double *rep_dist;   // [nq][rep_stride] or nullptr (JC69: seg_lut)
+    const uint8_t *aa_idx; const uint16_t *aa_mask;   // DevAlign's, row stride `stride`
+    const uint8_t *q_aa; const uint16_t *q_aam;       // the batch's queries: QueryBlock::aa_idx / aa_mask from its first query on
+    int Lpad; const double *table;                    // 21 x 21
     int rep_cache;            // k_select, clustered rows: representatives whose distances are staged in LDS (set by the launcher; 0 = none)
     int64_t n_rows_plain;     // k_select / k_select_stream without a list: rows to select (set by the launcher; the grid may be smaller)
 };

@@ -846,6 +846,71 @@ int launch_scoredist_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, in
     return 0;
 }
 
+// ---- clustered references, scoredist (the default route of `-p`): the distances to the representatives alone, then the
+// survivors in the form k_select_clusters reads
+__global__ __launch_bounds__(APPLES_TPB) void k_gather_reps_aa(const uint8_t *__restrict__ idx, const uint16_t *__restrict__ mask,
+                                                               int64_t slots_pad, const int32_t *__restrict__ rep_slot,
+                                                               int64_t n_reps, int64_t reps_pad, uint8_t *__restrict__ oidx,
+                                                               uint16_t *__restrict__ omask) {
+    const int64_t j = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    const int64_t s16 = blockIdx.y;
+    if (j >= n_reps) return;
+    const int64_t slot = rep_slot[j];
+    reinterpret_cast<uint4 *>(oidx)[s16 * reps_pad + j] = reinterpret_cast<const uint4 *>(idx)[s16 * slots_pad + slot];
+    omask[s16 * reps_pad + j] = mask[s16 * slots_pad + slot];
+}
+
+int launch_build_cluster_panels_aa(apples_ctx *ctx) {
+    DevAlign &a = ctx->aln;
+    const int64_t n16 = (a.L + 15) / 16;
+    a.reps_pad = (a.n_reps + 255) / 256 * 256;
+    if (a.aa_rep_idx) (void)hipFree(a.aa_rep_idx);
+    if (a.aa_rep_mask) (void)hipFree(a.aa_rep_mask);
+    a.aa_rep_idx = nullptr; a.aa_rep_mask = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&a.aa_rep_idx, (size_t)n16 * a.reps_pad * 16));
+    HIP_TRY(ctx, hipMemsetAsync(a.aa_rep_idx, 160, (size_t)n16 * a.reps_pad * 16, ctx->stream));  // (padding rows: gaps)
+    HIP_TRY(ctx, hipMalloc((void **)&a.aa_rep_mask, (size_t)n16 * a.reps_pad * 2));
+    HIP_TRY(ctx, hipMemsetAsync(a.aa_rep_mask, 0, (size_t)n16 * a.reps_pad * 2, ctx->stream));
+    hipLaunchKernelGGL(k_gather_reps_aa, dim3((unsigned)((a.n_reps + APPLES_TPB - 1) / APPLES_TPB), (unsigned)n16), dim3(APPLES_TPB), 0,
+                       ctx->stream, a.aa_idx, a.aa_mask, a.slots_pad, a.rep_slot, a.n_reps, a.reps_pad, a.aa_rep_idx, a.aa_rep_mask);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// the representatives with 0 <= d <= thr of every query, per 64-representative segment: position << 26 (the packed word of the
+// JC69 passes without its counts: k_select_clusters takes the distance from the row) and the segment's count
+__global__ __launch_bounds__(APPLES_TPB) void k_sd_rep_survivors(const double *__restrict__ rep_d, int64_t n_reps, int64_t reps_pad,
+                                                                 double thr, int32_t *__restrict__ seg_slot,
+                                                                 int32_t *__restrict__ seg_cnt) {
+    const int64_t q = blockIdx.x;
+    const int64_t j = (int64_t)blockIdx.y * APPLES_TPB + threadIdx.x;  // (the grid covers reps_pad)
+    const int lane = threadIdx.x & 63;
+    const double d = j < n_reps ? rep_d[q * reps_pad + j] : -1.0;
+    const bool keep = d >= 0 && d <= thr;
+    const unsigned long long m = __ballot(keep);
+    const int64_t seg = j >> 6;
+    if (keep) seg_slot[q * reps_pad + seg * 64 + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)((uint32_t)lane << 26);
+    if (lane == 0) seg_cnt[q * (reps_pad >> 6) + seg] = __popcll(m);
+}
+
+int launch_scoredist_reps(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *rep_d, int32_t *seg_slot,
+                          int32_t *seg_cnt) {
+    if (nq == 0) return 0;
+    const DevAlign &a = ctx->aln;
+    int Lpad = (a.L + 15) / 16 * 16;
+    constexpr int TQ = 8;
+    hipLaunchKernelGGL((k_scoredist<TQ, 0>), dim3((unsigned)((nq + TQ - 1) / TQ), (unsigned)(a.reps_pad / APPLES_TPB)),
+                       dim3(APPLES_TPB), 0, ctx->stream, a.aa_rep_idx, a.aa_rep_mask, qb.aa_idx + q0 * Lpad,
+                       qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, rep_d, (uint32_t *)nullptr, a.n_reps, a.reps_pad, Lpad, a.L, nq,
+                       ctx->params.overlap_frac, 0.0, 0.0, (int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr);
+    hipLaunchKernelGGL(k_sd_rep_survivors, dim3((unsigned)nq, (unsigned)(a.reps_pad / APPLES_TPB)), dim3(APPLES_TPB), 0, ctx->stream,
+                       rep_d, a.n_reps, a.reps_pad, ctx->params.filt_threshold, seg_slot, seg_cnt);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 // full rows for a device-side list of queries of the block starting at q0 (MODE 2): row r of d_dist = query qlist[r]; the grid
 // covers at most nq_max list entries and tiles beyond *qcount exit at once
 int launch_scoredist_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,

@@ -886,8 +886,8 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
                     if (d == 0) {
                         // (rare: the representative's own distance is looked up again among the survivors of its segment)
                         const int rep = sh_rep[lo], mp = m - sh_off[lo];
-                        double drep = PHASE == 4 ? reprow[rep] : 0.0;
-                        for (int k = 0; PHASE != 4 && k < cnt[rep >> 6]; ++k) {
+                        double drep = PHASE == 4 ? reprow[rep] : (a.rep_dist ? a.rep_dist[q * a.rep_stride + rep] : 0.0);
+                        for (int k = 0; PHASE != 4 && !a.rep_dist && k < cnt[rep >> 6]; ++k) {
                             const uint32_t pk = (uint32_t)sslot[(int64_t)(rep >> 6) * 64 + k];
                             if ((int)(pk >> 26) == (rep & 63)) {
                                 const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
@@ -1097,10 +1097,94 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist(SelectArgs a) {
     }
 }
 
+// The same tiles for scoredist contexts (-p with clusters): the exact distance of every (member, query) pair of a tile with the
+// arithmetic of k_scoredist (dist.hip: fp64, sites left to right, the 21 x 21 table in LDS -- the same bits).  A wavefront takes
+// 64 members of the cluster x TQ of the tile's queries at a time: the queries are wave-uniform (their residues select table
+// rows by scalar arithmetic, all lanes of a look-up index one 21-entry row: conflict-free), a member's 16 residues of a site
+// block are unpacked once for the TQ queries.
+template <int TQ>
+__global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist_sd(SelectArgs a) {
+    __shared__ double T[21 * 21];
+    __shared__ int sh_q[64], sh_o[64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 21 * 21; i += APPLES_TPB) T[i] = a.table[i];
+    const char *Tb = reinterpret_cast<const char *>(T);
+    const int n16 = a.Lpad / 16;
+    const int n_tiles = *a.cl_ntiles;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int4 tile = a.cl_tiles[t];
+        const int c = tile.x, nqt = tile.z;
+        const int mb = a.rep_moff[c], sz = a.rep_moff[c + 1] - mb;
+        __syncthreads();  // the previous tile's last readers of sh_q / sh_o (first tile: T is written)
+        if (tid < nqt) {
+            const int2 it = a.cl_items[tile.y + tid];
+            sh_q[tid] = it.x; sh_o[tid] = it.y;
+        }
+        __syncthreads();
+        const int MC = (sz + 63) >> 6, QG = (nqt + TQ - 1) / TQ;
+        for (int item = wv; item < MC * QG; item += APPLES_TPB / 64) {  // (wave-uniform)
+            const int mc = item % MC, qg = item / MC;
+            const int m = mc * 64 + lane;
+            const bool act = m < sz;
+            const int64_t slot = a.mem_slot[mb + (act ? m : 0)];
+            int64_t qi[TQ];
+#pragma unroll
+            for (int k = 0; k < TQ; ++k) qi[k] = __builtin_amdgcn_readfirstlane(sh_q[qg * TQ + k < nqt ? qg * TQ + k : qg * TQ]);
+            double tot[TQ];
+            uint32_t nv[TQ];
+#pragma unroll
+            for (int k = 0; k < TQ; ++k) { tot[k] = 0.0; nv[k] = 0; }
+            for (int s16 = 0; s16 < n16; ++s16) {
+                const uint4 rw = *reinterpret_cast<const uint4 *>(a.aa_idx + ((int64_t)s16 * a.stride + slot) * 16);
+                const uint32_t rmask = a.aa_mask[(int64_t)s16 * a.stride + slot];
+                uint32_t r8[16];
+                const uint32_t rr[4] = {rw.x, rw.y, rw.z, rw.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) r8[k] = (rr[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                uint32_t qv[TQ][4];
+#pragma unroll
+                for (int k = 0; k < TQ; ++k) {
+                    const uint4 qw = *reinterpret_cast<const uint4 *>(a.q_aa + qi[k] * (int64_t)a.Lpad + s16 * 16);
+                    qv[k][0] = qw.x; qv[k][1] = qw.y; qv[k][2] = qw.z; qv[k][3] = qw.w;
+                    nv[k] += __popc(rmask & (uint32_t)a.q_aam[qi[k] * (int64_t)n16 + s16]);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    double v[TQ];
+#pragma unroll
+                    for (int x = 0; x < TQ; ++x) {
+                        const uint32_t qrow = ((qv[x][k >> 2] >> (8 * (k & 3))) & 0xffu) * 168u;
+                        v[x] = *reinterpret_cast<const double *>(Tb + qrow + r8[k]);
+                    }
+#pragma unroll
+                    for (int x = 0; x < TQ; ++x) tot[x] += v[x];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TQ; ++k) {
+                const int j = qg * TQ + k;
+                if (j < nqt && act) {
+                    const uint32_t valid = nv[k];
+                    double d;
+                    if (valid == 0 || (double)valid / (double)a.L < a.overlap) d = -1.0;
+                    else {
+                        const double r1 = 1 - tot[k] / (double)valid;
+                        if (0 >= r1) d = -1.0;
+                        else d = -log(r1) * 1.3;
+                    }
+                    a.tmp_d[qi[k] * a.stride + sh_o[j] + m] = d;
+                }
+            }
+        }
+    }
+}
+
 int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
     const size_t dyn = (size_t)((a.n_members + 63) >> 6) * 10;  // the slot bitmap and its 16-bit in-run prefixes (runs of 16 words: 262 144 slots)
-    const bool by_query = (ctx->dbg & APPLES_DBG_CLUSTER_BY_QUERY) != 0;  // diagnostic switch: phase 0 alone
+    const bool sd = a.aa_idx != nullptr;  // scoredist context: k_cluster_dist_sd computes the member distances (no by-query form)
+    const bool by_query = (ctx->dbg & APPLES_DBG_CLUSTER_BY_QUERY) != 0 && !sd;  // diagnostic switch: phase 0 alone
+    if (sd && !a.cl_count) { ctx->err = "scoredist cluster route without its tile scratch"; return 1; }
     if (by_query || !a.cl_count) {
         hipLaunchKernelGGL(k_select_clusters<0>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
@@ -1124,7 +1208,8 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         ctx->n_cu = prop.multiProcessorCount;
     }
     static const int per_cu = getenv("APPLES_CLUSTER_WGS") ? atoi(getenv("APPLES_CLUSTER_WGS")) : 8;  // tuning knob
-    hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
+    if (sd) hipLaunchKernelGGL(k_cluster_dist_sd<4>, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
     // the second form's last phase beside the first's, on the spare stream: a hundred-odd workgroups of 1 024 threads (their
     // rounds of member lookups are what such a workgroup takes: a quarter of the rounds of 256 threads) leave the chip idle
     if (big) {

@@ -96,6 +96,8 @@ def launch(n_ranks, script, argv, timeout=None, stdout=None, stderr=None):
     previous = {}
     for sig in (signal.SIGTERM, signal.SIGHUP):
         try:
+            if signal.getsignal(sig) == signal.SIG_IGN:  # `nohup python bench.py --gpus 8 &`: a hang-up stays ignored
+                continue
             previous[sig] = signal.signal(sig, _stop)
         except (ValueError, OSError):  # not the main thread: the caller owns signal handling
             pass
@@ -128,6 +130,8 @@ def launch(n_ranks, script, argv, timeout=None, stdout=None, stderr=None):
                 time.sleep(0.05)
         return rc
     finally:
+        for sig in previous:  # a second signal must not cut the clean-up short and leave ranks behind
+            signal.signal(sig, signal.SIG_IGN)
         for p in procs:   # by exact PID, never by pattern
             if p.poll() is None:
                 p.send_signal(signal.SIGTERM)

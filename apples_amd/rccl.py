@@ -80,17 +80,22 @@ class SideChannel:
                     if self._recv(conn, len(hello)) != hello:
                         raise RuntimeError('not a rank of this job')
                     r = struct.unpack('<i', self._recv(conn, 4))[0]
-                    if not 0 < r < self.world or r in got:
+                    if not 0 < r < self.world:
                         raise RuntimeError('unexpected rank %d' % r)
+                    # the echo goes out at once: the client's short timeout guards only this exchange, however far apart the
+                    # ranks arrive (the blob follows once everybody is in)
+                    conn.sendall(hello)
                 except (RuntimeError, OSError):
                     conn.close()
                     continue
                 conn.settimeout(timeout)
+                if r in got:  # the same rank again: its first connection is dead (it gave up on it and came back)
+                    got[r].close()
                 got[r] = conn
             srv.close()
             self.peers = [got[r] for r in range(1, self.world)]
             for conn in self.peers:
-                conn.sendall(hello + struct.pack('<i', len(blob or b'')) + bytes(blob or b''))
+                conn.sendall(struct.pack('<i', len(blob or b'')) + bytes(blob or b''))
         else:
             deadline = time.time() + timeout
             while self.sock is None:

@@ -23,9 +23,9 @@ class QueryWorker:
     def __init__(self, tree, options, reference=None, devices=(0,)):
         # A one-shot run keeps its device batch buffers small: beyond a few tens of GiB the allocation itself takes seconds
         # (the driver hands out scrubbed memory: 2 - 4 s for the 96 GiB a resident context would take at 200 000 references, every
-        # run, against 0.1 s for 24 GiB), which no batch size wins back on one pass over the queries (scripts/r04_cli_batch_exp.sh)
-        import os
-        os.environ.setdefault('APPLES_BATCH_GIB', '24')
+        # run, against 0.1 s for 24 GiB), which no batch size wins back on one pass over the queries (scripts/r04_cli_batch_exp.sh).
+        # A cap of this worker's contexts (apples_params.batch_gib: min(cap, what free memory allows)), not of the process
+        self.batch_gib = 24
         self.tree = tree
         self.options = options
         self.reference = reference
@@ -39,7 +39,8 @@ class QueryWorker:
             o = self.options
             kw = dict(protein=o.protein_seqs, method=o.method_name, criterion=o.criterion_name,
                       negative=bool(o.negative_branch), threshold=o.filt_threshold,
-                      baseobs=o.base_observation_threshold, overlap=o.minimum_alignment_overlap, device=device)
+                      baseobs=o.base_observation_threshold, overlap=o.minimum_alignment_overlap, device=device,
+                      batch_gib=self.batch_gib)
             if self.reference is not None:
                 aln = self.reference.eng_aln  # the clustered rows (every row, unless -s holds more than the tree)
                 nodes = np.array([self.tree.name_to_node.get(n, -1) for n in aln.names], np.int32)

@@ -256,6 +256,7 @@ def strong_scaling_proxy(eng, queries, ms_full, parts=8, reps=3, device=0, full=
     # grouped ncclSend / ncclRecv to self + the copy to the host) on the whole job's 40-byte structs -- what rank 0 of an
     # 8-GPU job receives and brings to the host; the other ranks' sends travel over seven xGMI links at once
     gather_ms = None
+    h = comm = None
     try:
         from apples_amd.rccl import Comm
         h, n = eng.place_sequences_streamed(queries)
@@ -265,11 +266,14 @@ def strong_scaling_proxy(eng, queries, ms_full, parts=8, reps=3, device=0, full=
             t0 = time.perf_counter()
             comm.gather_to_host(eng.placements_device_ptr(h), [n * 40])
             g.append((time.perf_counter() - t0) * 1e3)
-        comm.close()
-        eng.free_queries(h)
         gather_ms = min(g)
     except Exception as e:  # no librccl on this host: say so in the line
         gather_note = 'gather not measured here: %s' % e
+    finally:  # whatever happened: the resident block and the communicator do not stay behind to skew the legs that follow
+        if comm is not None:
+            comm.close()
+        if h is not None:
+            eng.free_queries(h)
     worst = max(ms) + (gather_ms or 0.0)
     return {'parts': parts, 'queries_per_shard': [b - a for a, b in shard_bounds(len(queries), parts)],
             'ms_shard': ms, 'ms_shard_max': max(ms), 'ms_shard_mean': float(np.mean(ms)), 'ms_full_set': ms_full,

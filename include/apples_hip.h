@@ -82,6 +82,10 @@ typedef struct {
      * process.  0 = the measured-best defaults.  The environment variables of the same names (APPLES_NO_FUSE ...) set
      * the same bits for a whole process. */
     uint32_t debug;
+    /* Cap of the device batch buffers in GiB; 0 = none.  The library sizes them from free memory (at most 96 GiB or 40 % of
+     * what is free); the cap only ever lowers that: min(cap, free-memory budget).  A one-shot command-line run sets 24 (beyond
+     * a few tens of GiB the allocation itself takes seconds, apples_amd/worker.py). */
+    int32_t batch_gib;
 } apples_params;
 
 #define APPLES_DBG_NO_FUSE       1u   /* full distance rows + general selection instead of the fused epilogue */
@@ -126,11 +130,11 @@ typedef struct {
 #define APPLES_F_DEGENERATE  32u  /* >=3 distances but fewer than two of them on tree leaves */
 
 /* ABI of this header: bumped whenever a struct above grows or an entry point changes (4 = apples_params.debug with the
- * switches up to APPLES_DBG_ALL).  apples_params has no size field: a caller must zero-initialise it (memset / = {0}) and
+ * switches up to APPLES_DBG_ALL; 5 = apples_params.batch_gib).  apples_params has no size field: a caller must zero-initialise it (memset / = {0}) and
  * be built against the header of the library it loads -- check apples_abi_version() == APPLES_ABI_VERSION and
  * apples_params_size() == sizeof(apples_params) once at start-up, as apples_amd/engine.py does.  Bits of `debug` beyond
  * APPLES_DBG_ALL are ignored. */
-#define APPLES_ABI_VERSION 4u
+#define APPLES_ABI_VERSION 5u
 uint32_t apples_abi_version(void);
 size_t apples_params_size(void);
 
@@ -209,8 +213,9 @@ int apples_distances_resident(apples_ctx *ctx, int64_t handle, int32_t query_til
  * with HIP events on the context's stream.  ms[APPLES_T_*]; n = number of entries filled. */
 enum { APPLES_T_PACK = 0, APPLES_T_DIST = 1, APPLES_T_SELECT = 2, APPLES_T_SWEEP = 3, APPLES_T_TOTAL = 4,
        APPLES_T_DIST_LAUNCHES = 5,
-       APPLES_T_FILTER = 6, /* the part of APPLES_T_DIST spent in the matrix-core pass proper (scoredist: the lower-bound filter,
-                               before the exact evaluation of its candidates; otherwise equal to APPLES_T_DIST) */
+       APPLES_T_FILTER = 6, /* scoredist: the part of APPLES_T_DIST spent in the matrix-core lower-bound filter, before the
+                               exact evaluation of its candidates, summed over the device batches the filter ran in; 0 = no
+                               filter ran (every other route) */
        APPLES_T_COUNT = 7 };
 int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n);
 

@@ -502,6 +502,42 @@ def g9():
         run(tfp, ffp, protein, 'g9_fasttree_%s.nwk' % name)
 
 
+# ============================================================================= G10 the default protein route
+def g10():
+    """-p with clusters (apples/Reference.py:117-157 over scoredist, apples/PoolRepresentativeWorker.py:33-58 with the
+    21-symbol alphabet): consensus rows, observed dicts in order, placements, and one whole run of the reference's
+    run_apples.py -p consuming this repo's cluster table.  Inputs: tests/prot_cases.py (seeded; the tests regenerate them)."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    import prot_cases
+    tmp = tempfile.mkdtemp()
+    ref_fp, qry_fp, tree_fp = prot_cases.write_case(tmp)
+    tree, n2n, newick = prepare_tree(tree_fp)
+    refs = ref_fasta2dic(ref_fp, True, False)
+    qs = ref_fasta2dic(qry_fp, True, False)
+    reps_cl = clade_clusters(tree, refs, True, prot_cases.CLADE_MIN, prot_cases.CLADE_MAX)
+    out = {'clade_clusters': reps_to_json(reps_cl), 'cases': [], 'placements': [], 'tree': newick}
+    for label, reps in (('singleton', None), ('clades', reps_cl)):
+        for f, b in prot_cases.SELECTION_PARAMS:
+            r = make_reference(refs, True, f, b, reps)
+            for qn in list(qs)[:6]:
+                obs = r.get_obs_dist(qs[qn], qn, 0.001)
+                out['cases'].append({'clusters': label, 'f': f, 'b': b, 'query': qn,
+                                     'obs': [[k, float(v)] for k, v in obs.items()]})
+    queries = [(k, v, None) for k, v in qs.items()]
+    for m, c, neg in (('FM', 'MLSE', False), ('OLS', 'MLSE', False), ('BME', 'MLSE', False), ('BE', 'MLSE', False),
+                      ('FM', 'ME', False), ('FM', 'HYBRID', False), ('FM', 'MLSE', True), ('OLS', 'HYBRID', True)):
+        for f, b in prot_cases.SELECTION_PARAMS[:2]:
+            res = run_queries(make_reference(refs, True, f, b, reps_cl), options(m, c, neg, f, b), n2n, queries)
+            out['placements'].append({'m': m, 'c': c, 'n': neg, 'f': f, 'b': b, 'clusters': 'clades', 'p': placements_of(res)})
+    with open(os.path.join(HERE, 'g10_prot_clustered.json'), 'w') as f:  # (one case per line: the observed dicts are long)
+        f.write('{' + ',\n'.join('%s: %s' % (json.dumps(k), json.dumps(v) if not isinstance(v, list) else
+                                             '[\n' + ',\n'.join(json.dumps(x) for x in v) + '\n]') for k, v in out.items()) + '}\n')
+    g7({'prot_default': ['-p', '-s', ref_fp, '-q', qry_fp, '-t', tree_fp, '-D', '-T', '2'],
+        'prot_OLS_f01_b5': ['-p', '-s', ref_fp, '-q', qry_fp, '-t', tree_fp, '-m', 'OLS', '-f', '0.1', '-b', '5', '-D', '-T', '2']},
+       rename={ref_fp: 'prot_ref.fa', qry_fp: 'prot_query.fa', tree_fp: 'prot_backbone.nwk'})
+
+
 def g7(runs=None, rename=None):
     """Run the reference's own run_apples.py end to end (treeswift stand-in registered above, and
     a stub TreeCluster.py on PATH that labels every leaf '-1' = all-singleton clusters)."""
@@ -570,7 +606,7 @@ def g7(runs=None, rename=None):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
     for w in which:
         print('generating', w, flush=True)
         globals()[w]()

@@ -41,3 +41,11 @@ def assert_prow(got, want, rel=1e-6, err_abs=1e-9, ctx=''):
     assert isinstance(got[4], int) == isinstance(want[4], int), '%s pendant type %r vs %r' % (ctx, got[4], want[4])
     assert isinstance(got[1], int) == isinstance(want[1], int), '%s err type %r vs %r' % (ctx, got[1], want[1])
     assert isinstance(got[3], int) == isinstance(want[3], int), '%s distal type %r vs %r' % (ctx, got[3], want[3])
+
+
+def prow_is_tie(got, want, rel=1e-9):
+    """The tie class of SURVEY H1: edges that meet at a node have mathematically equal residuals there, so which of them wins is
+    decided by the last bit of the distances -- and scoredist's are reproducible only to 1e-15 (BLAS summation order, device log).
+    True when the two rows name different edges but the same residual and the same pendant length."""
+    return (got[0] != want[0] and got[0] >= 0 and want[0] >= 0 and
+            math.isclose(got[1], want[1], rel_tol=rel, abs_tol=1e-15) and math.isclose(got[4], want[4], rel_tol=rel, abs_tol=1e-12))

@@ -23,13 +23,22 @@ RUNS = {
                            '--no-clusters'],
     'dist_default': ['-d', 'dist.mat', '-t', 'backbone.nwk', '-T', '2'],
     'small_BME': ['-d', 'small_dist.mat', '-t', 'small_backbone.nwk', '-m', 'BME', '-T', '1'],
+    # -p on its default route (clusters of this repo's table, consensus of the 21-symbol alphabet); inputs: tests/prot_cases.py
+    'prot_default': ['-p', '-s', 'prot_ref.fa', '-q', 'prot_query.fa', '-t', 'prot_backbone.nwk', '-D', '-T', '2'],
+    'prot_OLS_f01_b5': ['-p', '-s', 'prot_ref.fa', '-q', 'prot_query.fa', '-t', 'prot_backbone.nwk', '-m', 'OLS', '-f', '0.1',
+                        '-b', '5', '-D', '-T', '2'],
 }
 
 
 @pytest.mark.parametrize('label', sorted(RUNS))
 def test_cli_matches_reference_jplace(label, tmp_path):
-    args = [a if a.startswith('-') or not os.path.exists(os.path.join(DATA, a)) else os.path.join(DATA, a)
-            for a in RUNS[label]]
+    if label.startswith('prot_'):
+        import prot_cases
+        made = {os.path.basename(p): p for p in prot_cases.write_case(str(tmp_path))}
+        args = [made.get(a, a) for a in RUNS[label]]
+    else:
+        args = [a if a.startswith('-') or not os.path.exists(os.path.join(DATA, a)) else os.path.join(DATA, a)
+                for a in RUNS[label]]
     out = tmp_path / 'out.jplace'
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_apples.py')] + args + ['-o', str(out)],
                        capture_output=True, text=True, timeout=600)

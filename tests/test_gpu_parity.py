@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import DATA, GOLD, ROOT, assert_prow, load_json, read_dismat
+from helpers import DATA, GOLD, ROOT, assert_prow, load_json, prow_is_tie, read_dismat
 
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import apples_oracle as orc  # noqa: E402
@@ -185,6 +185,74 @@ def test_placements_clustered_reference_golden(c1):
         eng.set_options(method='OLS', threshold=case['f'], baseobs=case['b'])
         p = eng.place_sequences(qry.seqs[qry.index[case['query']]][None, :])[0]
         assert p['n_obs'] == len(case['obs']), case
+    eng.close()
+
+
+def _cluster_arrays(reps, ref):
+    """(consensus rows, rep_row, member_off, member_row) of a fixture's representative list [{cons, members}]"""
+    cons, rep_row, moff, mrow = [], [], [0], []
+    for r in reps:
+        if len(r['members']) == 1 and ref.seqs[ref.index[r['members'][0]]].tobytes().decode() == r['cons']:
+            rep_row.append(ref.index[r['members'][0]])
+        else:
+            rep_row.append(len(ref) + len(cons))
+            cons.append(np.frombuffer(r['cons'].encode(), np.uint8))
+        mrow += [ref.index[m] for m in r['members']]
+        moff.append(len(mrow))
+    return np.array(cons, np.uint8).reshape(-1, ref.length), rep_row, moff, mrow
+
+
+@pytest.mark.parametrize('route', ['default', 'no_fuse'])
+def test_protein_clustered_reference_golden(route, tmp_path):
+    """The command line's default protein route, -p with clusters: scoredist to consensus representatives of the 21-symbol
+    alphabet, members of the accepted clusters, the top-up rule (apples/Reference.py:117-157, apples/PoolRepresentativeWorker.py:33-58)
+    against what the reference itself returned for the same clusters (g10): placements for 4 methods, 3 criteria, -n, two
+    (f, b) pairs, and the size of every observed dict."""
+    import prot_cases
+    from apples_amd.reference import consensus
+    ref_fp, qry_fp, tree_fp = prot_cases.write_case(str(tmp_path))
+    tree = read_tree(tree_fp)
+    ref = read_alignment(ref_fp, True, False)
+    qry = read_alignment(qry_fp, True, False)
+    nodes = np.array([tree.name_to_node.get(n, -1) for n in ref.names], np.int32)
+    g = load_json('g10_prot_clustered.json')
+    # the consensus rows this build forms are the reference's
+    for r in g['clade_clusters']:
+        if len(r['members']) > 1:
+            assert consensus(ref.seqs[[ref.index[m] for m in r['members']]], True).tobytes().decode() == r['cons']
+    eng = Engine(tree, ref.seqs, nodes, clusters=_cluster_arrays(g['clade_clusters'], ref), protein=True,
+                 debug=() if route == 'default' else (route,))
+    info = eng.describe()
+    assert info['all_singleton'] == 0
+    if route == 'default':
+        assert info['cluster_fused'] == 1, info
+    ties = 0
+    for case in g['placements']:
+        eng.set_options(method=case['m'], criterion=case['c'], negative=case['n'], threshold=case['f'], baseobs=case['b'])
+        for row, w in zip(_rows(eng, qry.seqs), case['p']):
+            if prow_is_tie(row, w['p']):  # (another of the edges that meet at the attachment point: same residual, same pendant)
+                ties += 1
+                continue
+            assert_prow(row, w['p'], ctx='prot clades %s/%s/n=%s/f=%s %s' % (case['m'], case['c'], case['n'], case['f'], w['n']))
+    print('protein clustered golden (%s): %d tie-class rows of %d' % (route, ties, 24 * len(g['placements'])))
+    assert ties <= 4
+    n = 0
+    for case in g['cases']:
+        if case['clusters'] != 'clades':
+            continue
+        eng.set_options(method='FM', criterion='MLSE', negative=False, threshold=case['f'], baseobs=case['b'])
+        p = eng.place_sequences(qry.seqs[qry.index[case['query']]][None, :])[0]
+        assert p['n_obs'] == len(case['obs']), (case['query'], case['f'], case['b'])
+        n += 1
+    assert n == 24
+    eng.close()
+    # singleton clusters on the same inputs (the dict sizes of g10's singleton cases)
+    eng = Engine(tree, ref.seqs, nodes, protein=True, debug=() if route == 'default' else (route,))
+    for case in g['cases']:
+        if case['clusters'] == 'singleton':
+            eng.set_options(threshold=case['f'], baseobs=case['b'])
+            p = eng.place_sequences(qry.seqs[qry.index[case['query']]][None, :])[0]
+            assert p['n_obs'] == len(case['obs']), (case['query'], case['f'], case['b'])
     eng.close()
 
 

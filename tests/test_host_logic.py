@@ -81,6 +81,29 @@ def test_consensus_matches_reference_fixture():
     assert consensus(arr, False).tobytes() == b'AAA'
 
 
+def test_protein_consensus_matches_reference_fixture(tmp_path):
+    """The 21-symbol alphabet of apples/PoolRepresentativeWorker.py:33-58 (A C D E ... Y -: alphabetical, not a2i's
+    order) against rows the reference's own _find_representative(prot_flag=True) produced (g10), numpy and native."""
+    import prot_cases
+    from apples_amd.reference import _consensus_rows
+    ref_fp, _, _ = prot_cases.write_case(str(tmp_path))
+    ref = read_alignment(ref_fp, True, False)
+    reps = [r for r in load_json('g10_prot_clustered.json')['clade_clusters'] if len(r['members']) > 1]
+    assert len(reps) > 50
+    mrow, groups = [], []
+    for r in reps:
+        rows = [ref.index[m] for m in r['members']]
+        assert consensus(ref.seqs[rows], True).tobytes().decode() == r['cons']
+        groups.append((len(mrow), len(mrow) + len(rows)))
+        mrow += rows
+    native = _consensus_rows(ref.seqs, np.array(mrow, np.int32), groups, True)
+    assert [bytes(x).decode() for x in native] == [r['cons'] for r in reps]
+    assert any('-' in r['cons'] for r in reps)  # a gap can win a column
+    # ties go to the first symbol in A C D E F G H I K L M N P Q R S T V W Y - order; other symbols are not counted
+    arr = np.frombuffer(b'RC*x' b'CR*x', np.uint8).reshape(2, 4)
+    assert consensus(arr, True).tobytes() == b'CCAA'
+
+
 def test_reduced_reference_from_treecluster_file(tmp_path):
     ref = read_alignment(os.path.join(DATA, 'ref.fa'), False, False)
     names = ref.names

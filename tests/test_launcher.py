@@ -183,3 +183,35 @@ def test_side_channel_rendezvous_skips_a_foreign_listener():
     for r, blob, m, m2 in got:
         assert blob == b'id' * 64, (r, blob)
         assert m == 12.0 and m2 == 0.0
+
+
+def _side_rank_late(rank, world, port, q, delay):
+    import time
+    time.sleep(delay)
+    _side_rank(rank, world, port, q)
+
+
+def test_side_channel_rendezvous_with_ranks_arriving_seconds_apart():
+    """Ranks that reach rank 0 more than the client's 3-second greeting timeout apart (round 4's advisor finding: rank 0 used to
+    echo the greeting only once everybody was in, an early rank gave up on its connection and its retry was refused as a
+    duplicate).  The echo now goes out as each rank is accepted; a rank that does come back replaces its dead connection."""
+    import multiprocessing as mp
+    from apples_amd.launcher import free_port
+    port = free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_side_rank_late, args=(r, world, port, q, d)) for r, d in ((0, 0.0), (1, 0.0), (2, 4.5))]
+    try:
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=60) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.terminate()
+    assert [g[0] for g in got] == [0, 1, 2]
+    for r, blob, m, m2 in got:
+        assert blob == b'id' * 64, (r, blob)
+        assert m == 12.0 and m2 == 0.0

@@ -234,3 +234,43 @@ def test_g6_synthetic_dmat(m):
         obs = orc.valid_dists(dict(zip(d.ref_names, D[i].tolist())), d.tree.name_to_node, g['b'], g['f'])
         r = orc.runquery(d.tree, qn, obs, m)
         assert_prow(r['placements'][0]['p'][0], g['p'][i]['p'], ctx='dmat %s %s' % (m, qn))
+
+
+# ----------------------------------------------------------------------------- G10: -p with clusters
+@pytest.fixture(scope='module')
+def prot(tmp_path_factory):
+    import prot_cases
+    ref_fp, qry_fp, tree_fp = prot_cases.write_case(str(tmp_path_factory.mktemp('prot')))
+    return read_tree(tree_fp), read_alignment(ref_fp, True, False), read_alignment(qry_fp, True, False)
+
+
+def test_g10_protein_selection(prot):
+    """get_obs_dist over scoredist with consensus representatives (apples/Reference.py:117-157): the observed dict in
+    insertion order, singleton and clade clusters."""
+    tree, ref, qry = prot
+    g = load_json('g10_prot_clustered.json')
+    assert extended_newick(tree) == g['tree']
+    rows = {n: ref.seqs[i] for i, n in enumerate(ref.names)}
+    reps_single = [(ref.seqs[i], [n]) for i, n in enumerate(ref.names)]
+    reps_clades = _reps_from_json(g['clade_clusters'])
+    for case in g['cases']:
+        reps = reps_single if case['clusters'] == 'singleton' else reps_clades
+        q = qry.seqs[qry.index[case['query']]]
+        for fn in (orc.scoredist, orc.scoredist_sequential):
+            obs = orc.get_obs_dist(q, reps, rows, fn, case['f'], case['b'], 0.001)
+            assert list(obs) == [k for k, _ in case['obs']], case['query']
+            np.testing.assert_allclose(list(obs.values()), [v for _, v in case['obs']], rtol=1e-12, atol=1e-15)
+    assert any(v == 0 and np.signbit(v) for case in g['cases'] for _, v in case['obs'])  # the duplicate row's -0.0
+
+
+def test_g10_protein_placements(prot):
+    tree, ref, qry = prot
+    g = load_json('g10_prot_clustered.json')
+    rows = {n: ref.seqs[i] for i, n in enumerate(ref.names)}
+    reps = _reps_from_json(g['clade_clusters'])
+    for case in g['placements']:
+        res = []
+        for n, s in zip(qry.names, qry.seqs):
+            obs = orc.get_obs_dist(s, reps, rows, orc.scoredist, case['f'], case['b'], 0.001)
+            res.append(orc.runquery(tree, n, obs, case['m'], case['c'], case['n']))
+        _check(res, case['p'], 'prot %s/%s/n=%s/f=%s' % (case['m'], case['c'], case['n'], case['f']))
