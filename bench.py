@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the APPLES per-query hot path on MI355X (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5|c3-clustered|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5|c3-clustered|c4-clustered|small]
                     [--scaling weak|strong] [--no-cpu] [--queries Q]
 
 Default workload = BASELINE.json config 3, the one the targets are quoted on: synthetic 200 k-leaf
@@ -65,6 +65,8 @@ WORKLOADS = {
     # the command line's default route at C3 size: max-diameter clusters at 1.2 x -f with consensus
     # representatives (apples/Reference.py:84-157) instead of all-singleton clusters
     'c3-clustered': (200000, 1000, 100000, False, 'OLS', 0.2),
+    # ... and at C4's: the default route of `-p` (scoredist to consensus representatives of the 21-symbol alphabet)
+    'c4-clustered': (50000, 500, 50000, True, 'FM', 0.2),
     # SURVEY 8d's stress variant: -f 1e9, every leaf observed (V = 2 N - 2 nodes swept per query: the worst case for both
     # kernel families); C3's shape on a bounded sample of its queries
     'c2-all': (10000, 1000, 10000, False, 'OLS', 1e9),
@@ -382,6 +384,7 @@ def other_workload(name, device, steps=3, ds=None, queries=0):
     if queries:
         Q = queries
     table = name == 'c5'
+    clustered = name.endswith('-clustered')  # the command line's default route: clusters + consensus representatives
     if ds is None or table:
         ds_ = synth.make_dataset(n_leaves, L if not table else 4, Q, protein=protein) if ds is None else ds
     else:
@@ -403,8 +406,8 @@ def other_workload(name, device, steps=3, ds=None, queries=0):
             eng.place_resident(handle)
             return eng.fetch(handle, Q)
     else:
-        eng = Engine(ds_.tree, ds_.ref_seqs, nodes, protein=protein, method=method, criterion='MLSE', threshold=thr, baseobs=25,
-                     overlap=0.001, device=device)
+        eng = Engine(ds_.tree, ds_.ref_seqs, nodes, clusters=make_clusters(ds_, thr, protein) if clustered else None, protein=protein,
+                     method=method, criterion='MLSE', threshold=thr, baseobs=25, overlap=0.001, device=device)
         qarr = np.ascontiguousarray(ds_.query_seqs[:Q])
 
         def step():
@@ -433,7 +436,8 @@ def other_workload(name, device, steps=3, ds=None, queries=0):
             # (the committed counter passes are of the workload's own size: no traffic figure for another number of queries)
             'roofline': {k: (None if k == 'traffic' and queries else rf[k])
                          for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'traffic') if k in rf},
-            'mean_observed': float(np.mean(out['n_obs'])), 'placed': int((out['n_valid'] > 0).sum())}
+            'mean_observed': float(np.mean(out['n_obs'])), 'placed': int((out['n_valid'] > 0).sum()),
+            **({'n_reps': int(info['n_reps']), 'cluster_fused': int(info.get('cluster_fused', 0))} if clustered else {})}
 
 
 def load_traffic(workload, kernel):
@@ -451,13 +455,13 @@ def load_traffic(workload, kernel):
         return None, None
 
 
-def make_clusters(ds, threshold):
+def make_clusters(ds, threshold, protein=False):
     """Clusters + consensus rows of the command line's default route (run_apples.py: max-diameter
-    clusters at 1.2 x -f, apples/Reference.py:87)."""
+    clusters at 1.2 x -f, apples/Reference.py:87; the consensus over the alphabet of apples/PoolRepresentativeWorker.py:33-58)."""
     from apples_amd import treecluster
     from apples_amd.fasta import Alignment
     from apples_amd.reference import ReducedReference
-    ref = ReducedReference(Alignment(ds.ref_names, ds.ref_seqs), False, treecluster.grouped(ds.tree, threshold * 1.2))
+    ref = ReducedReference(Alignment(ds.ref_names, ds.ref_seqs), bool(protein), treecluster.grouped(ds.tree, threshold * 1.2))
     return ref.cluster_arrays()
 
 
@@ -518,7 +522,7 @@ def main():
     if os.environ.get('APPLES_BENCH_LEAVES'):  # experiment only (never the reported line): another backbone size for the workload
         n_leaves = int(os.environ['APPLES_BENCH_LEAVES'])
     table = args.workload == 'c5'
-    clustered = args.workload == 'c3-clustered'
+    clustered = args.workload.endswith('-clustered')
     strong = args.scaling == 'strong'
     # every rank holds the same backbone + reference.  weak: rank-specific blocks of Q queries (own seed);
     # strong: one set of Q queries, rank r takes the contiguous block shard_bounds gives it
@@ -544,7 +548,7 @@ def main():
                                      seed_noise=7 if strong else 7 + rank)
         eng = Engine(ds.tree, None, method=method, criterion='MLSE', threshold=thr, baseobs=25, device=local_rank)
     else:
-        eng = Engine(ds.tree, ds.ref_seqs, nodes, clusters=make_clusters(ds, thr) if clustered else None, protein=protein,
+        eng = Engine(ds.tree, ds.ref_seqs, nodes, clusters=make_clusters(ds, thr, protein) if clustered else None, protein=protein,
                      method=method, criterion='MLSE', threshold=thr, baseobs=25, overlap=0.001, device=local_rank)
     nq = hi - lo
     timed = args.timed or ('resident' if table else 'host')
@@ -702,6 +706,8 @@ def main():
         if extras and args.workload == 'c3':
             # the other BASELINE configs, so that the driver's own run sees them (config 5 on config 3's tree: the same backbone)
             line['other_workloads'] = {'c2': other_workload('c2', local_rank), 'c4': other_workload('c4', local_rank),
+                                       # config 4's inputs through the default route of `-p`: clusters at 1.2 x -f, consensus representatives
+                                       'c4_clustered': other_workload('c4-clustered', local_rank),
                                        'c5': other_workload('c5', local_rank, ds=ds),
                                        # config 5 as one rank of its 8-GPU job holds it: 12 500 of the 100 000 rows (20 GB) resident
                                        'c5_shard_12500_rows': other_workload('c5', local_rank, ds=ds, queries=12500),

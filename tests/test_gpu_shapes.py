@@ -116,6 +116,61 @@ def test_c4_shape_50k_leaves_L500_protein_fm():
         np.testing.assert_allclose(g[f], want[f], rtol=1e-9, atol=1e-15, err_msg=f)
 
 
+def test_c4_shape_clustered_default_protein_route():
+    """Config 4's inputs through the command line's default route for -p (max-diameter clusters at 1.2 x -f, consensus
+    representatives of the 21-symbol alphabet; apples/Reference.py:84-157): the fused route (distances to the representatives
+    alone, cluster-major member distances) on all 50 000 queries; 256 + sampled queries against the C oracle (edges, flags and
+    counts identical, lengths to 1e-9), the first 6 000 also through full rows + general selection (round 4's route): same bytes."""
+    from apples_amd import treecluster
+    from apples_amd.fasta import Alignment
+    from apples_amd.reference import ReducedReference
+    nq = 50000
+    d = synth.make_dataset(50000, 500, nq, protein=True)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ca = ReducedReference(Alignment(d.ref_names, d.ref_seqs), True, treecluster.grouped(d.tree, 0.2 * 1.2)).cluster_arrays()
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, protein=True, method='FM')
+    info = eng.describe()
+    assert info['all_singleton'] == 0 and info['cluster_fused'] == 1 and 500 < info['n_reps'] < 5000, info
+    got = eng.place_sequences(d.query_seqs)
+    eng.close()
+    e2 = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, protein=True, method='FM', debug=('no_fuse',))
+    assert e2.describe()['cluster_fused'] == 0
+    other = e2.place_sequences(d.query_seqs[:6000])
+    e2.close()
+    assert other.tobytes() == got[:6000].tobytes()
+    sample = _sample(got, nq, extremes=16, strided=240)
+    assert len(sample) >= 256
+    co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, protein=True, method='FM', threads=NTHREADS)
+    want = co.place_sequences(d.query_seqs[sample])
+    g = got[sample]
+    for f in ('edge', 'flags', 'n_obs', 'n_valid'):
+        assert np.array_equal(g[f], want[f]), f
+    for f in ('error', 'distal', 'pendant'):
+        np.testing.assert_allclose(g[f], want[f], rtol=1e-9, atol=1e-15, err_msg=f)
+
+
+def test_c3_shape_other_criteria_and_negative_branches():
+    """Config 3's backbone with -c ME / HYBRID and with -n (apples/Algorithm.py:76-101, apples/util.py:32-50): 4 096 queries
+    placed, a sample of 256 + byte for byte against the C oracle.  ME rides the lean sweep's kernels, HYBRID the level loop with
+    per-edge records (sweep.hip) -- the route with no large-shape evidence before round 5."""
+    nq = 4096
+    d = synth.make_dataset(200000, 1000, nq)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    lut = jc69_lut(1000, 0.001)
+    for criterion, negative in (('ME', False), ('HYBRID', False), ('MLSE', True), ('HYBRID', True)):
+        eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS', criterion=criterion, negative=negative)
+        got = eng.place_sequences(d.query_seqs)
+        layout = eng.describe()['sweep_layout']
+        eng.close()
+        assert (layout == 'lean') == (criterion != 'HYBRID'), (criterion, layout)
+        sample = _sample(got, nq, extremes=16, strided=240)
+        assert len(sample) >= 256
+        co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', criterion=criterion, negative=negative, lut=lut, threads=NTHREADS)
+        want = co.place_sequences(d.query_seqs[sample])
+        assert np.array_equal(got[sample]['edge'], want['edge']), (criterion, negative)
+        assert got[sample].tobytes() == want.tobytes(), (criterion, negative)
+
+
 def test_c5_shape_200k_column_distance_table_bme():
     """Config 5: -d input, 200 000 columns, BME.  The bench's block: 4 096 table rows (6.5 GB) resident, rows with
     missing values, an exact hit, a row with nothing observed; 256 rows (the special ones, the extremes and a strided
