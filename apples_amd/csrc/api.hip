@@ -307,6 +307,114 @@ std::vector<int32_t> level_order(const int32_t *node, int64_t n, const std::vect
     return idx;
 }
 
+// Clade blocks of a clustered reference (DevAlign::blk_*): whole subtrees of the backbone whose leaves are all members of one
+// cluster.  A query that accepts the cluster observes every leaf of the block (apples/Reference.py:146-152), so inside the block
+// the induced subtree (apples/Subtree.py:23-43) is the block itself, the same for every such query: its sweep runs on a static
+// schedule (sweep_lean.hip: k_blocks_up / k_blocks_down) and the per-query merged lists see the block's root as one leaf.
+// Needs node ids in post-order (children before parents, a subtree = a contiguous id range); blocks are binary inside.
+int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_t> &level, const std::vector<int32_t> &slot_node,
+                 const std::vector<int32_t> &slot_rep, const std::vector<int32_t> &slot_mpos, const std::vector<int32_t> &rep_moff) {
+    DevAlign &a = ctx->aln;
+    a.n_blocks = 0;
+    a.n_e = 0;
+    if (a.all_singleton || !ctx->tree.merge_ok || ctx->tree.scan || (ctx->dbg & APPLES_DBG_NO_BLOCKS)) return 0;
+    const int n = t->n_nodes;
+    std::vector<int32_t> node_slot(n, -1), pure(n, -1), nleaf(n, 0), first(n, 0);
+    for (int64_t s = 0; s < a.n_refs; ++s)
+        if (slot_node[s] >= 0) node_slot[slot_node[s]] = (int32_t)s;
+    for (int v = 0; v < n; ++v) {
+        const int c0 = t->child_off[v], c1 = t->child_off[v + 1];
+        first[v] = v;
+        if (c0 == c1) {
+            pure[v] = node_slot[v] >= 0 ? slot_rep[node_slot[v]] : -1;
+            nleaf[v] = 1;
+            continue;
+        }
+        int p = -2, nl = 0;
+        for (int k = c0; k < c1; ++k) {
+            const int c = t->child_idx[k];
+            if (c >= v) return 0;  // not a post-order numbering: no blocks
+            first[v] = std::min(first[v], first[c]);
+            nl += nleaf[c];
+            if (pure[c] < 0) p = -1;
+            else if (p == -2) p = pure[c];
+            else if (p != pure[c]) p = -1;
+        }
+        nleaf[v] = nl;
+        pure[v] = (c1 - c0 == 2 && p >= 0 && v - first[v] + 1 == 2 * nl - 1) ? p : -1;
+    }
+    std::vector<std::vector<int32_t>> by_rep((size_t)a.n_reps);
+    int n_blocks = 0;
+    for (int v = 0; v < n; ++v)
+        if (pure[v] >= 0 && nleaf[v] >= 2 && (t->parent[v] < 0 || pure[t->parent[v]] < 0)) { by_rep[pure[v]].push_back(v); ++n_blocks; }
+    // (the selection's bitmap over emission indices: 4 096 words of LDS at most, k_select_clusters)
+    int64_t n_leaf_slots = 0;
+    for (int64_t s = 0; s < a.n_refs; ++s) n_leaf_slots += slot_node[s] >= 0 ? 1 : 0;
+    if (n_blocks == 0 || n_leaf_slots + n_blocks > 262144) return 0;
+    std::vector<int4> rec_i;
+    std::vector<double2> rec_e;
+    std::vector<int32_t> rep_soff((size_t)a.n_reps + 1, 0), mem_block((size_t)rep_moff[a.n_reps], -1), blk_root, blk_rslot, blk_nodes, slot_of(n, -1);
+    for (int64_t c = 0; c < a.n_reps; ++c) {
+        rep_soff[c] = (int32_t)rec_i.size();
+        int sc = 0;
+        for (int u : by_rep[c]) {
+            const int b = (int)blk_root.size();
+            bool first_leaf = true;
+            for (int v = first[u]; v <= u; ++v) {
+                if (t->child_off[v] == t->child_off[v + 1]) {
+                    mem_block[rep_moff[c] + slot_mpos[node_slot[v]]] = (b << 1) | (first_leaf ? 1 : 0);  // (one member speaks for the block where it is counted)
+                    first_leaf = false;
+                    continue;
+                }
+                slot_of[v] = sc++;
+                const int l = t->child_idx[t->child_off[v]], r = t->child_idx[t->child_off[v] + 1];
+                auto ref = [&](int k) { return slot_of[k] >= 0 ? slot_of[k] : -(slot_mpos[node_slot[k]] + 1); };
+                rec_i.push_back(make_int4(ref(l), ref(r), l, r));
+                rec_e.push_back(make_double2(t->edge_len[l], t->edge_len[r]));
+            }
+            blk_root.push_back(u);
+            blk_rslot.push_back(slot_of[u]);
+            blk_nodes.push_back(2 * nleaf[u] - 2);
+        }
+    }
+    rep_soff[a.n_reps] = (int32_t)rec_i.size();
+    // emission order: tree-leaf slots and block roots by (level, deepest first; node id)
+    struct Ent { int32_t lvl, node, kind, idx; };
+    std::vector<Ent> ents;
+    for (int64_t s = 0; s < a.n_refs; ++s)
+        if (slot_node[s] >= 0) ents.push_back({level[slot_node[s]], slot_node[s], 0, (int32_t)s});
+    for (int b = 0; b < n_blocks; ++b) ents.push_back({level[blk_root[b]], blk_root[b], 1, b});
+    std::sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) { return x.lvl != y.lvl ? x.lvl > y.lvl : x.node < y.node; });
+    const int H = ctx->tree.height;
+    std::vector<int32_t> e_of_slot((size_t)a.n_refs, -1), e_of_blk((size_t)n_blocks, -1), e_node(ents.size()), lvl_e((size_t)H + 2, 0);
+    for (size_t e = 0; e < ents.size(); ++e) {
+        if (ents[e].lvl > H || ents[e].lvl < 0) return 0;
+        (ents[e].kind ? e_of_blk[ents[e].idx] : e_of_slot[ents[e].idx]) = (int32_t)e;
+        e_node[e] = ents[e].node;
+        ++lvl_e[ents[e].lvl];  // for now: entries AT level l
+    }
+    for (int l = H, above = 0; l >= -1; --l) {  // entry l + 1 = entries above level l
+        const int at = l >= 0 ? lvl_e[l] : 0;
+        lvl_e[l + 1] = above;
+        above += at;
+    }
+    if (dev_upload(ctx, &a.blk_rec_i, rec_i.data(), (int64_t)rec_i.size())) return 1;
+    if (dev_upload(ctx, &a.blk_rec_e, rec_e.data(), (int64_t)rec_e.size())) return 1;
+    if (dev_upload(ctx, &a.rep_soff, rep_soff.data(), (int64_t)rep_soff.size())) return 1;
+    if (dev_upload(ctx, &a.mem_block, mem_block.data(), (int64_t)mem_block.size())) return 1;
+    if (dev_upload(ctx, &a.blk_root, blk_root.data(), n_blocks)) return 1;
+    if (dev_upload(ctx, &a.blk_rslot, blk_rslot.data(), n_blocks)) return 1;
+    if (dev_upload(ctx, &a.blk_nodes, blk_nodes.data(), n_blocks)) return 1;
+    if (dev_upload(ctx, &a.e_of_slot, e_of_slot.data(), a.n_refs)) return 1;
+    if (dev_upload(ctx, &a.e_of_blk, e_of_blk.data(), n_blocks)) return 1;
+    if (dev_upload(ctx, &a.e_node, e_node.data(), (int64_t)e_node.size())) return 1;
+    if (dev_upload(ctx, &a.lvl_e, lvl_e.data(), (int64_t)lvl_e.size())) return 1;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the vectors are locals)
+    a.n_blocks = n_blocks;
+    a.n_e = (int64_t)ents.size();
+    return 0;
+}
+
 int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignment *al) {
     DevAlign &a = ctx->aln;
     a.n_rows = al->n_rows;
@@ -397,6 +505,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
     if (dev_upload(ctx, &a.rep_slot, rep_slot.data(), a.n_reps)) return 1;
     if (dev_upload(ctx, &a.rep_moff, rep_moff.data(), a.n_reps + 1)) return 1;
     if (dev_upload(ctx, &a.mem_slot, mem_slot.data(), (int64_t)mem_slot.size())) return 1;
+    if (build_blocks(ctx, t, level, slot_node, slot_rep, slot_mpos, rep_moff)) return 1;
 
     // the rows go to the device as the caller holds them (one copy, no re-ordered staging buffer on the
     // host); the packing kernels gather them into slot order through d_slot_row
@@ -925,6 +1034,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.lean = sw.lean; s.lean_cap1 = sw.lean_cap1; s.lean_leaf1 = sw.lean_leaf1;
     s.lean_leaf = sw.lean_leaf; s.lean_teams = sw.teams; s.lean_meta = sw.lean_meta; s.pool_cursor = (unsigned int *)(w.cls_count + 7);
     s.prof = ctx->lean_prof;
+    s.blk_pool = ctx->blk_active ? ctx->blk_pool : nullptr;  // (clade blocks in this device batch's observation lists: run_block)
     s.map_bits = 1;
     while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
     if (const char *e = getenv("APPLES_MAP_BITS")) s.map_bits = std::min(30, std::max(s.map_bits, atoi(e)));  // test knob: few tags, early wrap
@@ -1313,6 +1423,46 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 sa.big_list = big_form ? sa.cl_ntiles + 8 : nullptr;
                 sa.cl_items = ctx->cl_items; sa.cl_tiles = ctx->cl_tiles; sa.cl_tiles_cap = ctx->cl_tiles_cap;
             }
+            // clade blocks (build_blocks): the sweep inside whole subtrees of one cluster on a static schedule, cluster-major
+            // (sweep_lean.hip: k_blocks_up before the selection's last phase, k_blocks_down + k_blocks_finish after the sweep above
+            // them).  With the lean sweep only (MLSE / ME on a big binary tree): its kernels know a block root among the leaves.
+            ctx->blk_active = a.n_blocks > 0 && !hybrid && !pipelined && !ctx->tree.scan && w.small.lean && w.small.lean_leaf && w.big.lean;
+            if (ctx->blk_active) {
+                const int64_t n_items = nq * SELECT_CLUSTERS_ACC_CAP + std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps;
+                const int64_t n_ints = 2 * n_items + 3 * w.batch + 16, n_tiles = n_items / 64 + a.n_reps + 1;
+                if (n_ints > ctx->blk_ints_cap) {
+                    dev_free(ctx->blk_ints); ctx->blk_ints = nullptr; ctx->blk_ints_cap = 0;
+                    if (dev_alloc(ctx, &ctx->blk_ints, n_ints)) return 1;
+                    ctx->blk_ints_cap = n_ints;
+                }
+                if (n_tiles > ctx->blk_tiles_cap) {
+                    dev_free(ctx->blk_tiles); ctx->blk_tiles = nullptr; ctx->blk_tiles_cap = 0;
+                    if (dev_alloc(ctx, &ctx->blk_tiles, n_tiles)) return 1;
+                    ctx->blk_tiles_cap = n_tiles;
+                }
+                if (!ctx->blk_pool) {
+                    // the tuples of the blocks' internal nodes, 48 bytes per (query, node): room for every query of a batch observing an
+                    // eighth of the reference, 16 GiB or a third of the free memory at most; a tile that finds no room goes without
+                    // blocks (k_cluster_tiles).  APPLES_BLK_POOL_MB: test knob (a pool that runs dry)
+                    size_t fr = 0, tot = 0;
+                    int64_t bytes = std::min<int64_t>((int64_t)16 << 30, w.batch * a.n_refs * 6);
+                    if (hipMemGetInfo(&fr, &tot) == hipSuccess) bytes = std::min<int64_t>(bytes, (int64_t)(fr / 3));
+                    if (const char *e = getenv("APPLES_BLK_POOL_MB")) bytes = (int64_t)atoll(e) << 20;
+                    bytes = std::max<int64_t>(bytes, 1 << 20);
+                    if (dev_alloc(ctx, &ctx->blk_pool, bytes / 8)) return 1;
+                    ctx->blk_pool_cap = bytes / 8;
+                }
+                int32_t *bi = ctx->blk_ints;
+                sa.item_sbase = bi; sa.q_item = bi + n_items; sa.q_items = reinterpret_cast<int2 *>(bi + 2 * n_items);
+                sa.q_blk = bi + 2 * n_items + 2 * w.batch; sa.q_item_cursor = bi + 2 * n_items + 3 * w.batch; sa.blk_ntiles = sa.q_item_cursor + 2;
+                HIP_TRY(ctx, hipMemsetAsync(bi + 2 * n_items, 0, (size_t)(3 * w.batch + 16) * sizeof(int32_t), front));
+                sa.blk_rec_i = a.blk_rec_i; sa.blk_rec_e = a.blk_rec_e; sa.rep_soff = a.rep_soff; sa.mem_block = a.mem_block;
+                sa.blk_root = a.blk_root; sa.blk_rslot = a.blk_rslot; sa.blk_nodes = a.blk_nodes;
+                sa.e_of_slot = a.e_of_slot; sa.e_of_blk = a.e_of_blk; sa.e_node = a.e_node; sa.lvl_e = a.lvl_e; sa.n_e = a.n_e;
+                sa.blk_pool = ctx->blk_pool; sa.blk_pool_cap = ctx->blk_pool_cap;
+                sa.blk_tiles = ctx->blk_tiles; sa.blk_tiles_cap = ctx->blk_tiles_cap;
+                sa.method = ctx->params.method;
+            }
             if (launch_select_clusters(ctx, sa, nq)) return 1;
             // queries whose accepted clusters hold fewer than -b valid distances: the top-up rule over the representatives
             // (phase 4 of k_select_clusters); what that cannot hold: full rows + general selection
@@ -1450,8 +1600,22 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         if (!swept_here) {
             HIP_TRY(ctx, hipEventRecord(e[3], back));
             if (run_sweep(ctx, qb.out + q0, nq, back)) return 1;
+            if (cfused && ctx->blk_active) {  // the top-down pass inside the clade blocks, then the better of the two placements
+                const int64_t n_items = nq * SELECT_CLUSTERS_ACC_CAP + std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps;
+                int32_t *bi = ctx->blk_ints;
+                BlockArgs b{};
+                b.tiles = ctx->blk_tiles; b.n_tiles = bi + 2 * n_items + 3 * w.batch + 2; b.items = ctx->cl_items;
+                b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.mem_slot = a.mem_slot;
+                b.self_slot = qb.self_slot + q0; b.tmp_d = w.dist; b.stride = a.slots_pad; b.pool = ctx->blk_pool;
+                b.item_sbase = bi; b.q_item = bi + n_items; b.q_items = reinterpret_cast<const int2 *>(bi + 2 * n_items);
+                b.q_blk = bi + 2 * n_items + 2 * w.batch; b.cursor = bi + 2 * n_items + 3 * w.batch + 1;
+                b.method = ctx->params.method; b.criterion = ctx->params.criterion; b.negative = ctx->params.negative_branch;
+                b.out = qb.out + q0; b.nq = nq;
+                if (launch_blocks_down(ctx, b, back)) return 1;
+            }
             HIP_TRY(ctx, hipEventRecord(e[4], back));
         }
+        ctx->blk_active = false;
         if (pipelined) HIP_TRY(ctx, hipEventRecord(ctx->ev_back[set], back));
         if (feed && i + 1 < n_sub && feed_chunk(i + 1)) return 1;  // the next chunk travels while this sub-batch's kernels run
     }
@@ -1514,7 +1678,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
             {"APPLES_NO_TOPUP_KERNEL", APPLES_DBG_NO_TOPUP_KERNEL}, {"APPLES_NO_CLUSTER_BIG", APPLES_DBG_NO_CLUSTER_BIG},
             {"APPLES_NO_SD_TOPUP", APPLES_DBG_NO_SD_TOPUP}, {"APPLES_SD_FP6", APPLES_DBG_SD_FP6},
             {"APPLES_NO_TOPUP_OVERLAP", APPLES_DBG_NO_TOPUP_OVERLAP}, {"APPLES_STREAM_THIRD_PASS", APPLES_DBG_STREAM_THIRD_PASS},
-            {"APPLES_NO_SD_COMPACT", APPLES_DBG_NO_SD_COMPACT}, {"APPLES_SD_COMPACT_TINY", APPLES_DBG_SD_COMPACT_TINY}};
+            {"APPLES_NO_SD_COMPACT", APPLES_DBG_NO_SD_COMPACT}, {"APPLES_SD_COMPACT_TINY", APPLES_DBG_SD_COMPACT_TINY},
+            {"APPLES_NO_BLOCKS", APPLES_DBG_NO_BLOCKS}};
         for (const auto &k : knobs)
             if (getenv(k.env)) ctx->dbg |= k.bit;
     }
@@ -1674,13 +1839,13 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     ctx->blk_cache.clear();
     dev_free(ctx->d_exotic);
     dev_free(ctx->d_slice_cnt);
-    dev_free(ctx->cl_ints); dev_free(ctx->cl_items); dev_free(ctx->cl_tiles); dev_free(ctx->sd_rep_d);
+    dev_free(ctx->cl_ints); dev_free(ctx->cl_items); dev_free(ctx->cl_tiles); dev_free(ctx->sd_rep_d); dev_free(ctx->blk_pool); dev_free(ctx->blk_ints); dev_free(ctx->blk_tiles);
     for (auto &e : ctx->ev_feed) (void)hipEventDestroy(e);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.rep_soff); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);
@@ -2250,7 +2415,7 @@ const char *apples_describe(apples_ctx *ctx) {
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
              "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\", "
              "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld, \"sweep_layout\": \"%s\", \"cluster_fused\": %d, "
-             "\"scoredist_filter\": %d, \"scoredist_image_bytes\": %lld}",
+             "\"scoredist_filter\": %d, \"scoredist_image_bytes\": %lld, \"cluster_blocks\": %d}",
              name, cus, ctx->tree.n_nodes, ctx->tree.height, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
              (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
@@ -2268,7 +2433,9 @@ const char *apples_describe(apples_ctx *ctx) {
               ((a.rep_packed && a.packed_rm && ctx->params.model == APPLES_JC69) || (a.aa_rep_idx && ctx->params.model == APPLES_SCOREDIST))) ? 1 : 0,
              // scoredist: the fused pass filters on the matrix cores (dist_sd.hip) at the present threshold
              (ctx->params.model == APPLES_SCOREDIST && sd_gemm_usable(ctx) && !(ctx->dbg & APPLES_DBG_NO_FUSE)) ? 1 : 0,
-             (long long)(a.sd_ref4 ? a.slots_pad * (int64_t)sd_steps(a.L) * 64 : 0));
+             (long long)(a.sd_ref4 ? a.slots_pad * (int64_t)sd_steps(a.L) * 64 : 0),
+             // clade blocks of a clustered reference (build_blocks): whole subtrees of one cluster, swept on a static schedule
+             (int)a.n_blocks);
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

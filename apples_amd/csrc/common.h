@@ -139,6 +139,28 @@ struct DevAlign {
                                   // [slots_pad / 256][steps][1024 chunks of 16 B], 20 values per site
     float *sd_nvr = nullptr;      // [slots_pad] sites of the row that are not gaps (-1: no row in the slot)
     bool sd_fp6 = false;          // the query images hold fp6 table values (24 bytes per 32), not fp4 (APPLES_DBG_SD_FP6; default fp4)
+    // Clade blocks of a clustered reference (sweep_lean.hip: k_blocks_up / k_blocks_down): a block = a whole subtree of the
+    // backbone all of whose leaves are members of one cluster (at least two leaves, binary inside).  A query that accepts the
+    // cluster observes every leaf of the block (apples/Reference.py:146-152 keeps every member with a valid distance), so the
+    // induced subtree inside the block is the block itself: its S / R passes run on a static schedule, cluster-major, with the
+    // queries in the lanes, and the per-query merged sweep sees the block's root as one leaf that carries a tuple.
+    int32_t n_blocks = 0;
+    int4 *blk_rec_i = nullptr;    // per internal node of the clusters' blocks, cluster by cluster, a cluster's blocks by root id, a block's
+                                  // internal nodes in post-order ("slot" = index inside the cluster): {left, right, node id of left, of right};
+                                  // left / right >= 0: the child's slot, < 0: a leaf, member position -(x + 1) of the cluster's flat member list
+    double2 *blk_rec_e = nullptr; // ... and the edge lengths of the two children
+    int32_t *rep_soff = nullptr;  // [n_reps + 1] first record of every cluster (records = internal nodes of its blocks)
+    int32_t *mem_block = nullptr; // [members] block of the member (index into blk_*) x 2 + (1: the block's first leaf), -1: none
+    int32_t *blk_root = nullptr;  // [n_blocks] root node
+    int32_t *blk_rslot = nullptr; // [n_blocks] slot of the root inside its cluster
+    int32_t *blk_nodes = nullptr; // [n_blocks] nodes strictly below the root (2 x leaves - 2)
+    // emission order of the clustered fast path with blocks: tree-leaf slots and block roots together, by level (deepest first),
+    // then node id -- what the level-sorted observation list of the sweep wants
+    int32_t *e_of_slot = nullptr; // [n_refs] emission index of a slot (-1: not a tree leaf)
+    int32_t *e_of_blk = nullptr;  // [n_blocks]
+    int32_t *e_node = nullptr;    // [n_e] node of an emission index
+    int32_t *lvl_e = nullptr;     // [height + 2] entry l + 1: emission indices with a level above l
+    int64_t n_e = 0;
     int32_t *slot_node = nullptr; // [n_refs] tree node or -1
     int32_t *slot_level = nullptr;// [n_refs] level or -1
     int32_t *lvl_slots = nullptr; // [height + 2] entry l + 1: slots with a level above l (slots are sorted by level, deepest first); null
@@ -275,6 +297,10 @@ struct apples_ctx {
     int32_t *cl_ints = nullptr; int64_t cl_ints_cap = 0;
     int2 *cl_items = nullptr; int64_t cl_items_cap = 0;
     int4 *cl_tiles = nullptr; int64_t cl_tiles_cap = 0;
+    bool blk_active = false;   // the device batch under way names block roots in its observation lists (run_block)
+    double *blk_pool = nullptr; int64_t blk_pool_cap = 0;   // clade blocks: the batch's tuples, [tile][slot][6][64 lanes] doubles
+    int32_t *blk_ints = nullptr; int64_t blk_ints_cap = 0;  // ... per item: storage base (-1: no blocks for it); per query: {first, count} of its items; the items
+    int4 *blk_tiles = nullptr; int64_t blk_tiles_cap = 0;   // ... tiles of up to 64 items of one cluster: {cluster, first item, items, storage base / 64}
     double *sd_rep_d = nullptr; int64_t sd_rep_d_cap = 0;  // scoredist: [batch][reps_pad] the queries' distances to every representative
     unsigned long long *scan_prof = nullptr;  // APPLES_SCAN_PROFILE: per-phase cycle sums of the scan sweep
     unsigned long long *lean_prof = nullptr;  // APPLES_LEAN_PROFILE: the same for sweep_lean.hip's wavefront-sized teams
@@ -409,6 +435,19 @@ struct SelectArgs {
     const uint8_t *aa_idx; const uint16_t *aa_mask;   // DevAlign's, row stride `stride`
     const uint8_t *q_aa; const uint16_t *q_aam;       // the batch's queries: QueryBlock::aa_idx / aa_mask from its first query on
     int Lpad; const double *table;                    // 21 x 21
+    // clade blocks (DevAlign::blk_*): k_cluster_tiles also cuts every cluster's items into tiles of up to 64 for the block kernels,
+    // phase 2 notes every query's items, k_blocks_up leaves the blocks' S tuples in the pool, phase 3 emits block roots
+    const int4 *blk_rec_i; const double2 *blk_rec_e; const int32_t *rep_soff, *mem_block, *blk_root, *blk_rslot, *blk_nodes;
+    const int32_t *e_of_slot, *e_of_blk, *e_node, *lvl_e; int64_t n_e;
+    double *blk_pool; int64_t blk_pool_cap;  // (doubles)
+    int4 *blk_tiles; int64_t blk_tiles_cap; int32_t *blk_ntiles;
+    int32_t *q_blk;           // [nq] 1: the query's observation list names block roots (k_blocks_down / k_blocks_finish serve it)
+    int32_t *item_sbase;      // [items] first slot of the item's tile in blk_pool x 64 + the item's lane (slot s, component x, lane l at
+                              // ((base + s) * 6 + x) * 64 + l); -1: no blocks for the item
+    int2 *q_items;            // [nq] {first entry of q_item, accepted clusters}
+    int32_t *q_item;          // [items] the queries' items, a query's in the order of its accepted clusters
+    int32_t *q_item_cursor;   // [1]
+    int method;               // (k_blocks_up)
     int rep_cache;            // k_select, clustered rows: representatives whose distances are staged in LDS (set by the launcher; 0 = none)
     int64_t n_rows_plain;     // k_select / k_select_stream without a list: rows to select (set by the launcher; the grid may be smaller)
 };
@@ -452,6 +491,8 @@ struct SweepArgs {
     int64_t lean_teams;       // ... for this many teams
     int4 *lean_meta;          // [batch] per query: {offset in the pool, number of level groups G (-1: not swept here), internal nodes, -}
     unsigned int *pool_cursor; // next free pool entry (cleared per batch)
+    double *blk_pool;          // clade blocks: an observed "leaf" whose distance is a boxed index (lean_is_block) is a block root, its tuple at
+                               // blk_pool[index + x * 64] (S after k_blocks_up; the top-down pass leaves lift(R) there for k_blocks_down)
     unsigned long long *prof; // diagnostic (APPLES_LEAN_PROFILE): [16] cycles and step counts per phase summed over teams, or nullptr
     int64_t lean_cap1, lean_leaf1;
     int map_bits;             // payload bits of a map entry; the tag sits above them
@@ -472,6 +513,23 @@ struct SweepArgs {
     int32_t *overflow_count;
     apples_placement *out;
 };
+// clade blocks (sweep_lean.hip: k_blocks_up / k_blocks_down / k_blocks_finish; DevAlign::blk_* for the static part)
+struct BlockArgs {
+    const int4 *tiles; const int32_t *n_tiles;  // {cluster, first item, items (<= 64), first slot of the tile's tuples in the pool or -1}
+    const int2 *items;                          // (query, where the cluster's members start in the query's flat member list)
+    const int4 *rec_i; const double2 *rec_e; const int32_t *rep_soff, *rep_moff, *mem_slot;
+    const int32_t *self_slot;                   // [nq] the queries' own rows as slots, or nullptr
+    const double *tmp_d; int64_t stride;        // the queries' rows of member distances
+    double *pool;                               // [slot][6][64 lanes]; a tile's slot 0: the lanes' best edges inside the blocks (key, x1, x2,
+                                                // err, e, (x1 is the int 0, edge)), its slots 1 ..: the tuples of the cluster's block-internal nodes
+    int32_t *item_sbase;                        // [items] first slot x 64 + lane, -1: the item goes without blocks
+    const int32_t *q_blk; const int2 *q_items; const int32_t *q_item;
+    int32_t *cursor;
+    int method, criterion, negative;
+    apples_placement *out; int64_t nq;
+};
+int launch_blocks_up(apples_ctx *ctx, const BlockArgs &a, hipStream_t st);
+int launch_blocks_down(apples_ctx *ctx, const BlockArgs &a, hipStream_t st);
 // sweep_scan.hip
 struct ScanArgs {
     const int4 *leaf_info; const AncRec *anc; const uint8_t *rmq;

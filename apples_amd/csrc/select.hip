@@ -649,6 +649,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     __shared__ int sh_rep[ACC_CAP];
     __shared__ int sh_off[ACC_CAP + 1];
     __shared__ int sh_mb[ACC_CAP];  // first member (index into mem_slot / the cluster-major panel) of every accepted cluster
+    __shared__ int sh_sb[PHASE == 3 ? ACC_CAP : 1];  // clade blocks: where the tuples of the cluster's blocks are for this query (first slot x 64 + lane), -1: no blocks
     __shared__ int sh_znode, sh_nacc;
     if (PHASE == 4) {
         // phase 4: a workgroup per entry of the slow list, up to the grid (the launcher does not know the list's length and a
@@ -666,7 +667,9 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     const int tid = threadIdx.x;
     const int G = a.G;
     const int64_t nm = a.n_members;
-    const int n_words = (int)((nm + 63) >> 6);
+    // (with clade blocks the bitmap is over emission indices: tree-leaf slots and block roots in level order)
+    const bool blk_space = PHASE == 3 && a.e_of_slot != nullptr;
+    const int n_words = (int)(((blk_space ? a.n_e : nm) + 63) >> 6);
     uint16_t *pre = reinterpret_cast<uint16_t *>(dyn_bits + n_words);
     double *reprow = reinterpret_cast<double *>(dyn_bits + n_words + (n_words + 3) / 4);  // phase 4: the query's distance to every representative
     const int self = a.self_slot ? a.self_slot[q] : -1;
@@ -787,14 +790,31 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     }
     __syncthreads();
     if (PHASE == 2) {  // the query joins the lists of its clusters (in whatever order the additions land: every pair is on its own)
+        if (a.q_items) {  // clade blocks: which items are this query's, in the order of its accepted clusters
+            if (tid == 0) { sh_znode = atomicAdd(a.q_item_cursor, n_acc); a.q_items[q] = make_int2(sh_znode, n_acc); }
+            __syncthreads();
+        }
         for (int k = tid; k < n_acc; k += TPB) {
             const int c = sh_rep[k];
-            a.cl_items[a.cl_start[c] + atomicAdd(&a.cl_fill[c], 1)] = make_int2((int)q, sh_off[k]);
+            const int item = a.cl_start[c] + atomicAdd(&a.cl_fill[c], 1);
+            a.cl_items[item] = make_int2((int)q, sh_off[k]);
+            if (a.q_items) { a.q_item[sh_znode + k] = item; a.item_sbase[item] = -1; }  // (no blocks until k_blocks_up says otherwise: a cluster without any has no tile)
         }
         return;
     }
     int M = sh_off[n_acc];
     int n_acc_all = n_acc;  // (phase 4: grows with the clusters the top-up rule accepts)
+    bool use_blk = false;   // this query's observation list names block roots (workgroup-uniform)
+    if (PHASE == 3 && blk_space) {
+        const int2 qi = a.q_items[q];
+        int any = 0;
+        for (int k = tid; k < n_acc; k += TPB) {
+            const int sb = k < qi.y ? a.item_sbase[a.q_item[qi.x + k]] : -1;
+            sh_sb[k] = sb;
+            any |= sb >= 0;
+        }
+        use_blk = __syncthreads_or(any) != 0;
+    }
     if (PHASE == 4) {
         // ---- the members' distances (a thread per member), then Reference.py:144-152: while fewer than `-b` valid member
         // distances are in, the representative with the next smallest (distance, index) beyond the threshold brings its cluster
@@ -850,7 +870,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
         }
         return lo;
     };
-    int n_total = 0, obs_cnt = 0;
+    int n_total = 0, obs_cnt = 0, blk_extra = 0;
     double z_d = INF_D;
     int z_i = 0x7fffffff, z_p = 0x7fffffff, z_node = -2;
     for (int m0 = 0; m0 < M; m0 += TPB * E) {
@@ -900,7 +920,15 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
                     }
                     if (node >= 0) {
                         keep = d;
-                        atomicOr(&dyn_bits[slot >> 6], 1ull << (slot & 63));
+                        int es = slot;
+                        if (blk_space) {
+                            es = a.e_of_slot[slot];
+                            if (use_blk && sh_sb[lo] >= 0) {  // a member of a block: the block's root stands for it
+                                const int mbk = a.mem_block[sh_mb[lo] + (m - sh_off[lo])];
+                                if (mbk >= 0) es = a.e_of_blk[mbk >> 1];
+                            }
+                        }
+                        atomicOr(&dyn_bits[es >> 6], 1ull << (es & 63));
                     }
                 }
             }
@@ -911,15 +939,31 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     if (PHASE != 4 && obs < a.baseobs) { to_slow(obs); return; }  // the reference would pop further clusters (Reference.py:146): phase 4 did
     // ---- ranks of the slot bitmap: a thread counts its run of 16 words, one scan over the threads
     int n_emit;
-    {
+    auto ranks = [&]() {
         int c = 0;
         for (int k = 0; k < 16; ++k) {
             const int w = tid * 16 + k;
             if (w < n_words) { pre[w] = (uint16_t)c; c += __popcll(dyn_bits[w]); }
         }
         sh_base[tid] = block_excl_scan_int<NW>(c, sh_i, &n_emit);
+        __syncthreads();
+    };
+    ranks();
+    if (PHASE == 3 && use_blk && n_emit < 2) {
+        // every observed leaf inside one block (or nothing left to observe): the block's root would be the only entry of the list
+        // and the induced subtree's root lies inside the block -- this query goes without blocks, its leaves one by one
+        use_blk = false;
+        for (int i = tid; i < n_words; i += TPB) dyn_bits[i] = 0;
+        __syncthreads();
+        for (int m = tid; m < M; m += TPB) {
+            if (!(tmp[m] >= 0)) continue;  // (pass 1 left the distance of what it keeps, -2 elsewhere)
+            const int lo = cluster_of(m);
+            const int es = a.e_of_slot[a.mem_slot[sh_mb[lo] + (m - sh_off[lo])]];
+            atomicOr(&dyn_bits[es >> 6], 1ull << (es & 63));
+        }
+        __syncthreads();
+        ranks();
     }
-    __syncthreads();
     auto rank_of = [&](int slot) -> int {  // emitted members in the slots below `slot`
         const int w = slot >> 6;
         if (w >= n_words) return n_emit;
@@ -945,12 +989,31 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e)
             if (d_[e] >= 0) {
-                const int pos = rank_of(slot_[e]);
-                o_node[pos] = node_[e];
-                o_dist[pos] = d_[e];
+                int es = slot_[e], node = node_[e];
+                double dd = d_[e];
+                if (blk_space) {
+                    es = a.e_of_slot[slot_[e]];
+                    const int m = m0 + e * TPB + tid, lo = cluster_of(m);
+                    if (use_blk && sh_sb[lo] >= 0) {
+                        const int mbk = a.mem_block[sh_mb[lo] + (m - sh_off[lo])];
+                        if (mbk >= 0) {  // (every member of the block writes the same entry)
+                            const int b = mbk >> 1;
+                            es = a.e_of_blk[b];
+                            node = a.blk_root[b];
+                            // the "distance" of a block root: where its tuple is (sweep_lean.hip:lean_is_block), a boxed index into the pool
+                            const long long at = ((long long)(sh_sb[lo] >> 6) + 1 + a.blk_rslot[b]) * 384 + (sh_sb[lo] & 63);
+                            dd = __longlong_as_double((long long)0xFFF8000000000000ull | at);
+                            if (mbk & 1) blk_extra += a.blk_nodes[b];  // (its first member counts the nodes below the root once)
+                        }
+                    }
+                }
+                const int pos = rank_of(es);
+                o_node[pos] = node;
+                o_dist[pos] = dd;
             }
     }
     n_total = block_sum<NW>(n_total, sh_i);  // (its barriers also publish the emission)
+    if (PHASE == 3 && blk_space) blk_extra = use_blk ? block_sum<NW>(blk_extra, sh_i) : 0;
     double zd = z_d; int zi = z_i, zp = z_p;
     block_argmin3<NW>(zd, zi, zp, sh_d, sh_i, sh_j);
     if (tid == 0) sh_znode = -2;
@@ -960,7 +1023,9 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     // per-level offsets into the level-sorted list (the sweep's cnt_gt): cg[l + 1] = entries above level l = the emitted members
     // in the slots above level l (slots are sorted by level, deepest first; lvl_slots[l + 1] = how many slots those are)
     int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
-    if (cg && a.lvl_slots) {
+    if (cg && blk_space) {
+        for (int i = tid; i < a.height + 2; i += TPB) cg[i] = rank_of(a.lvl_e[i]);
+    } else if (cg && a.lvl_slots) {
         for (int i = tid; i < a.height + 2; i += TPB) cg[i] = rank_of(a.lvl_slots[i]);
     } else {
         for (int i = tid; cg && i <= n_emit; i += TPB) {
@@ -987,6 +1052,8 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
             p.edge = -1;
             ne = 0;
         }
+        // (n_valid: the nodes strictly inside the emitted blocks; the sweep adds its own count to it)
+        if (PHASE == 3 && blk_space && ne > 0) { p.n_valid = blk_extra; a.q_blk[q] = use_blk ? 1 : 0; }
         a.out[q] = p;
         a.n_obs[q] = ne;
         enlist(a, q, ne);
@@ -1005,7 +1072,7 @@ __device__ __forceinline__ int cluster_tile_queries(int sz) {
 __global__ __launch_bounds__(CL_TILES_TPB) void k_cluster_tiles(SelectArgs a) {
     __shared__ int sh_i[CL_TILES_TPB / WAVE];
     const int tid = threadIdx.x;
-    int item_base = 0, tile_base = 0;
+    int item_base = 0, tile_base = 0, btile_base = 0, bslot_base = 0;
     for (int64_t c0 = 0; c0 < a.n_reps; c0 += CL_TILES_TPB) {
         const int64_t c = c0 + tid;
         const int cnt = c < a.n_reps ? a.cl_count[c] : 0;
@@ -1022,10 +1089,28 @@ __global__ __launch_bounds__(CL_TILES_TPB) void k_cluster_tiles(SelectArgs a) {
         }
         item_base += tot_i;
         tile_base += tot_t;
+        if (a.blk_tiles) {
+            // clade blocks: the cluster's items once more in tiles of up to 64 (a lane of k_blocks_up / k_blocks_down = an item), each
+            // with room in the pool for the tuples of the cluster's block-internal nodes (ns slots of 6 x 64 doubles); a tile the
+            // pool cannot hold gets no storage (base -1: its items go without blocks)
+            const int ns = c < a.n_reps ? a.rep_soff[c + 1] - a.rep_soff[c] : 0;
+            const int nb = ns > 0 ? (cnt + 63) / 64 : 0;
+            int tot_b, tot_s;
+            const int at_b = btile_base + block_excl_scan_int<CL_TILES_TPB / WAVE>(nb, sh_i, &tot_b);
+            // (ns + 1 slots per tile: the first holds the lanes' best edges inside the blocks, k_blocks_down -> k_blocks_finish)
+            const int at_s = bslot_base + block_excl_scan_int<CL_TILES_TPB / WAVE>(nb * (ns + 1), sh_i, &tot_s);
+            for (int k = 0; k < nb; ++k)
+                if (at_b + k < a.blk_tiles_cap)
+                    a.blk_tiles[at_b + k] = make_int4((int)c, at_i + k * 64, cnt - k * 64 < 64 ? cnt - k * 64 : 64,
+                                                      (int64_t)(at_s + (k + 1) * (ns + 1)) * 384 <= a.blk_pool_cap ? at_s + k * (ns + 1) : -1);
+            btile_base += tot_b;
+            bslot_base += tot_s;
+        }
     }
     if (tid == 0) {
         a.cl_start[a.n_reps] = item_base;
         *a.cl_ntiles = tile_base < a.cl_tiles_cap ? tile_base : (int)a.cl_tiles_cap;  // (the cap is the proven upper bound: never hit)
+        if (a.blk_tiles) *a.blk_ntiles = btile_base < a.blk_tiles_cap ? btile_base : (int)a.blk_tiles_cap;
     }
 }
 
@@ -1181,7 +1266,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist_sd(SelectArgs a) {
 
 int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
-    const size_t dyn = (size_t)((a.n_members + 63) >> 6) * 10;  // the slot bitmap and its 16-bit in-run prefixes (runs of 16 words: 262 144 slots)
+    // the slot bitmap and its 16-bit in-run prefixes (runs of 16 words: 262 144 slots); with clade blocks over emission indices
+    const size_t dyn = (size_t)(((a.e_of_slot ? std::max(a.n_e, a.n_members) : a.n_members) + 63) >> 6) * 10;
     const bool sd = a.aa_idx != nullptr;  // scoredist context: k_cluster_dist_sd computes the member distances (no by-query form)
     const bool by_query = (ctx->dbg & APPLES_DBG_CLUSTER_BY_QUERY) != 0 && !sd;  // diagnostic switch: phase 0 alone
     if (sd && !a.cl_count) { ctx->err = "scoredist cluster route without its tile scratch"; return 1; }
@@ -1210,6 +1296,13 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     static const int per_cu = getenv("APPLES_CLUSTER_WGS") ? atoi(getenv("APPLES_CLUSTER_WGS")) : 8;  // tuning knob
     if (sd) hipLaunchKernelGGL(k_cluster_dist_sd<4>, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
     else hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
+    if (a.blk_tiles) {  // clade blocks: the S tuples inside them, before the last phase names their roots in the observation lists
+        BlockArgs b{};
+        b.tiles = a.blk_tiles; b.n_tiles = a.blk_ntiles; b.items = a.cl_items; b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e;
+        b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.mem_slot = a.mem_slot; b.self_slot = a.self_slot; b.tmp_d = a.tmp_d;
+        b.stride = a.stride; b.pool = a.blk_pool; b.item_sbase = a.item_sbase; b.cursor = a.q_item_cursor + 1; b.method = a.method;
+        if (launch_blocks_up(ctx, b, ctx->stream)) return 1;
+    }
     // the second form's last phase beside the first's, on the spare stream: a hundred-odd workgroups of 1 024 threads (their
     // rounds of member lookups are what such a workgroup takes: a quarter of the rounds of 256 threads) leave the chip idle
     if (big) {

@@ -78,7 +78,14 @@ struct LeanTeam {
     int32_t *K;             // node id
     double *LE;             // per observed leaf: edge length ...
     int32_t *LP;            // ... and parent (pe gathered once, up front)
+    double *BP;             // clade blocks: the pool of their tuples (SweepArgs::blk_pool), or nullptr
 };
+
+// An observed "leaf" that is the root of a clade block (DevAlign::blk_*, select.hip phase 3): its distance is a boxed index -- a
+// negative quiet NaN whose low bits say where the block's tuple is in the pool (component x at index + 64 x): S after k_blocks_up;
+// the top-down pass leaves lift(R) over the root's edge there, which k_blocks_down takes on into the block.
+__device__ __forceinline__ bool lean_is_block(double dist) { return ((unsigned)__double2hiint(dist) & 0xfff80000u) == 0xfff80000u; }
+__device__ __forceinline__ long long lean_block_at(double dist) { return __double_as_longlong(dist) & 0x0007ffffffffffffLL; }
 
 __device__ __forceinline__ LeanTeam lean_team(void *base, int64_t team, int64_t cap1, int64_t leaf1) {
     char *p = reinterpret_cast<char *>(base) + team * (cap1 * LEAN_BYTES_PER_NODE + leaf1 * LEAN_BYTES_PER_LEAF);
@@ -93,6 +100,7 @@ __device__ __forceinline__ LeanTeam lean_team(void *base, int64_t team, int64_t 
     t.K = reinterpret_cast<int32_t *>(p); p += cap1 * 4;
     t.LE = reinterpret_cast<double *>(p); p += leaf1 * 8;
     t.LP = reinterpret_cast<int32_t *>(p);
+    t.BP = nullptr;
     return t;
 }
 
@@ -113,6 +121,7 @@ __device__ __forceinline__ LeanTeam lean_pool_view(void *pool, int64_t n, int64_
     char *l = reinterpret_cast<char *>(leaf) + team * leaf1 * LEAN_BYTES_PER_LEAF;
     t.LE = reinterpret_cast<double *>(l);
     t.LP = reinterpret_cast<int32_t *>(l + leaf1 * 8);
+    t.BP = nullptr;
     return t;
 }
 
@@ -216,7 +225,15 @@ __device__ __forceinline__ void kid_tuple(int kd, double dist, const LeanTeam &t
         a = t.T0[ki]; b = t.T1[ki]; c = t.T2[ki];
     }
     S[0] = a.x; S[1] = a.y; S[2] = b.x; S[3] = b.y; S[4] = c.x; S[5] = c.y;
-    if (kd <= 0) leaf_tuple<M>(dist, S);
+    if (kd <= 0) {
+        if (t.BP && lean_is_block(dist)) {  // the root of a clade block: its tuple waits in the pool
+            const double *bp = t.BP + lean_block_at(dist);
+#pragma unroll
+            for (int x = 0; x < 6; ++x) S[x] = bp[x * 64];
+        } else {
+            leaf_tuple<M>(dist, S);
+        }
+    }
 }
 
 // S tuple of a node from its entry (apples/OLS.py:25-44: children in file order)
@@ -282,7 +299,7 @@ template <int M>
 __device__ __forceinline__ void lean_td_kid(const LeanTeam &t, const double *Sk, const double *Ss, const double *plift, double ek,
                                             double es, int kd, int kn, int nk, bool is_lca, double coef, int negative,
                                             int criterion, const double *lds_pow, double2 (*hand)[WAVE], int hand_base,
-                                            LeanBest &best) {
+                                            LeanBest &best, double ddk = 0.0) {
     constexpr bool BME = (M == APPLES_BME);
     double acc[6];
 #pragma unroll
@@ -311,6 +328,12 @@ __device__ __forceinline__ void lean_td_kid(const LeanTeam &t, const double *Sk,
             t.T1[kd - 1] = make_double2(u[2], u[3]);
             t.T2[kd - 1] = make_double2(u[4], u[5]);
         }
+    } else if (t.BP && lean_is_block(ddk)) {  // the root of a clade block: lift(R) over its edge replaces its S in the pool (k_blocks_down)
+        double u[6];
+        lift<M>(acc, ek, u);
+        double *bp = t.BP + lean_block_at(ddk);
+#pragma unroll
+        for (int x = 0; x < 6; ++x) bp[x * 64] = u[x];
     }
     const double key = (criterion == APPLES_ME) ? r.x1 : r.err;
     if (key < best.key || (key == best.key && kn < best.v)) {
@@ -342,14 +365,15 @@ __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, const i
     double Sk[6], Ss[6];  // the child in hand and its sibling
     kid_tuple<M>(d.x, dd.x, t, nullptr, false, 0, Sk);
     kid_tuple<M>(d.y, dd.y, t, nullptr, false, 0, Ss);
-    double ek = e.x, es = e.y;
+    double ek = e.x, es = e.y, ddk = dd.x, dds = dd.y;
     int kd = d.x, ks = d.y, kn = nd.x, ksn = nd.y;
 #pragma unroll 1
     for (int z = 0; z < nk; ++z) {
-        lean_td_kid<M>(t, Sk, Ss, plift, ek, es, kd, kn, nk, is_lca, coef, negative, criterion, lds_pow, hand_out, out_base, best);
+        lean_td_kid<M>(t, Sk, Ss, plift, ek, es, kd, kn, nk, is_lca, coef, negative, criterion, lds_pow, hand_out, out_base, best, ddk);
 #pragma unroll
         for (int x = 0; x < 6; ++x) { const double w = Sk[x]; Sk[x] = Ss[x]; Ss[x] = w; }
         { const double w = ek; ek = es; es = w; }
+        { const double w = ddk; ddk = dds; dds = w; }
         { const int w = kd; kd = ks; ks = w; }
         { const int w = kn; kn = ksn; ksn = w; }
     }
@@ -412,23 +436,24 @@ __device__ __forceinline__ void lean_td_pairs(const LeanTeam &t, int g0, int ng,
     __builtin_amdgcn_wave_barrier();  // (every lane's reads of the hand-over precede the stores of this step)
     if (mine)
         lean_td_kid<M>(t, Sk, Ss, plift, z ? e.y : e.x, z ? e.x : e.y, z ? d.y : d.x, z ? nd.y : nd.x, nk, is_lca, coef, negative,
-                       criterion, lds_pow, hand_out, out_base, best);
+                       criterion, lds_pow, hand_out, out_base, best, z ? dd.y : dd.x);
 }
 
 // the query's placement from the team's winner (apples/Algorithm.py:92-101); `mine` = this lane holds the winning edge
 __device__ __forceinline__ void lean_write_placement(apples_placement *out, int64_t q, int V, int win, bool mine, bool lane0,
                                                      const LeanBest &best) {
+    // (n_valid: the selection kernel left the nodes inside the query's clade blocks there -- 0 without blocks)
     if (win == 0x7fffffff) {
         if (lane0) {
             apples_placement pl = out[q];
-            pl.n_valid = V;
+            pl.n_valid += V;
             pl.edge = -1;
             pl.flags |= APPLES_F_DEGENERATE | APPLES_F_PENDANT_INT;
             out[q] = pl;
         }
     } else if (mine) {
         apples_placement pl = out[q];
-        pl.n_valid = V;
+        pl.n_valid += V;
         pl.edge = win;
         pl.error = best.err;
         pl.distal = best.e - best.x2;
@@ -515,7 +540,8 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh) {
             continue;
         }
         const int64_t cap = qcap - 1;
-        const LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, off, a.lean_leaf, team, a.lean_leaf1);
+        LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, off, a.lean_leaf, team, a.lean_leaf1);
+        t.BP = a.blk_pool;
         LEAN_TICK(0);
 
         // ------------------------------------------------------------ up front: the per-level offsets into LDS; parent and
@@ -689,7 +715,8 @@ __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
         const int G = meta.y, VI = meta.z;
         if (G < 0) continue;  // handed to the workgroup-sized teams by the bottom-up kernel
         const int V = VI + n;  // Subtree.num_nodes
-        const LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, meta.x & 0xffffffffll, nullptr, 0, 0);
+        LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, meta.x & 0xffffffffll, nullptr, 0, 0);
+        t.BP = a.blk_pool;
         const int32_t *grp_off = a.grp_off + q * (int64_t)(T.height + 4);
         LEAN_TICK(0);
         LeanBest best;
@@ -858,7 +885,8 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
     const double *lds_pow = sh.pow;
     const DevTree &T = a.tree;
     const int4 *__restrict__ pe = reinterpret_cast<const int4 *>(T.pe);
-    const LeanTeam t = lean_team(a.lean, blockIdx.x, a.lean_cap1, a.lean_leaf1);
+    LeanTeam t = lean_team(a.lean, blockIdx.x, a.lean_cap1, a.lean_leaf1);
+    t.BP = a.blk_pool;
     int32_t *grp_off = a.grp_off + (int64_t)blockIdx.x * (T.height + 4);
     // work: a device-side list, or (routed queries) three lists by size class, largest first
     const int r0 = a.route_classes ? a.work_count[4] : 0, r1 = a.route_classes ? a.work_count[5] : 0;
@@ -955,7 +983,222 @@ __global__ __launch_bounds__(APPLES_TPB, LEAN_DOWN_WAVES) void k_lean_down(Sweep
     lean_down_loop<M>(a, sh);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Clade blocks (DevAlign::blk_*): the part of the sweep that lies inside whole subtrees of one cluster.  A tile = up to 64
+// of the queries that accepted one cluster; a wavefront takes a tile, a lane = a query, and walks the internal nodes of the
+// cluster's blocks on the static schedule of their records -- bottom-up in post-order (k_blocks_up: all_S_values,
+// apples/OLS.py:12-44 ...), top-down in reverse (k_blocks_down: all_R_values, placement_per_edge, error_per_edge, the
+// running arg-min of apples/Algorithm.py:74-91).  The structure (children, edge lengths) is wave-uniform: scalar loads; the
+// tuples live in the pool as [slot][component][lane] -- a wavefront's loads and stores are whole 512-byte rows; the
+// distances of the blocks' leaves are the member distances the cluster-major distance pass left in the queries' rows.
+// Arithmetic and order are node_S's and lean_td_kid's: every valid child in file order, the parent term last.
+__device__ __forceinline__ void blk_load(const double *p, double *S) {
+#pragma unroll
+    for (int x = 0; x < 6; ++x) S[x] = p[x * 64];
+}
+__device__ __forceinline__ void blk_store(double *p, const double *S) {
+#pragma unroll
+    for (int x = 0; x < 6; ++x) p[x * 64] = S[x];
+}
+
+template <int M>
+__global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
+    constexpr bool BME = (M == APPLES_BME);
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int n_tiles = *a.n_tiles;
+    while (true) {
+        int tq = 0;
+        if (lane == 0) tq = atomicAdd(a.cursor, 1);
+        const int ti = __builtin_amdgcn_readfirstlane(tq);
+        if (ti >= n_tiles) break;
+        const int4 tile = a.tiles[ti];
+        const int c = tile.x, nqt = tile.z;
+        const bool in = lane < nqt;
+        const int item = tile.y + (in ? lane : 0);
+        const int2 it = a.items[item];
+        if (tile.w < 0) {  // no room in the pool: the tile's queries take these leaves one by one
+            if (in) a.item_sbase[item] = -1;
+            continue;
+        }
+        const int64_t q = it.x;
+        const double *dbase = a.tmp_d + q * a.stride + it.y;
+        const int self = a.self_slot ? a.self_slot[q] : -1;
+        const int rb = a.rep_soff[c], ns = a.rep_soff[c + 1] - rb, mb = a.rep_moff[c];
+        double *pool = a.pool + ((int64_t)tile.w + 1) * 384 + lane;  // (slot 0 of the tile: the lanes' best edges, k_blocks_down)
+        bool regular = true;
+        for (int j = 0; j < ns; ++j) {
+            const int4 ri = a.rec_i[rb + j];
+            const double2 re = a.rec_e[rb + j];
+            double S0[6], S1[6], u[6], r[6];
+            if (ri.x >= 0) blk_load(pool + (int64_t)ri.x * 384, S0);
+            else {
+                const int mp = -ri.x - 1;
+                const double D = dbase[mp];
+                if (D < 0 || a.mem_slot[mb + mp] == self) regular = false;  // a member the reference drops (Reference.py:150) or the query's own row
+                leaf_tuple<M>(D, S0);
+            }
+            if (ri.y >= 0) blk_load(pool + (int64_t)ri.y * 384, S1);
+            else {
+                const int mp = -ri.y - 1;
+                const double D = dbase[mp];
+                if (D < 0 || a.mem_slot[mb + mp] == self) regular = false;
+                leaf_tuple<M>(D, S1);
+            }
+            const double coef = BME ? 1.0 / (double)2 : 1.0;  // apples/BME.py:20: both children are valid
+            lift<M>(S0, re.x, u);
+#pragma unroll
+            for (int x = 0; x < 6; ++x) r[x] = 0;
+#pragma unroll
+            for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
+            lift<M>(S1, re.y, u);
+#pragma unroll
+            for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
+            blk_store(pool + (int64_t)j * 384, r);
+        }
+        if (in) a.item_sbase[item] = regular ? tile.w * 64 + lane : -1;
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(APPLES_TPB) void k_blocks_down(BlockArgs a) {
+    constexpr bool BME = (M == APPLES_BME);
+    __shared__ double sh_pow[384 + 256];
+    for (int i = threadIdx.x; i < 384; i += APPLES_TPB) sh_pow[i] = (&kPowLogTab[0][0])[i];
+    for (int i = threadIdx.x; i < 256; i += APPLES_TPB) sh_pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
+    __syncthreads();
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int n_tiles = *a.n_tiles;
+    while (true) {
+        int tq = 0;
+        if (lane == 0) tq = atomicAdd(a.cursor, 1);
+        const int ti = __builtin_amdgcn_readfirstlane(tq);
+        if (ti >= n_tiles) break;
+        const int4 tile = a.tiles[ti];
+        if (tile.w < 0) continue;
+        const int c = tile.x, nqt = tile.z;
+        const bool in = lane < nqt;
+        const int item = tile.y + (in ? lane : 0);
+        const int2 it = a.items[item];
+        const int64_t q = it.x;
+        // (a lane whose query goes without blocks -- a member it drops, its own row, a top-up or exact-match query -- computes on
+        // whatever the pool holds and writes nothing that is read)
+        const bool mine = in && a.item_sbase[item] >= 0 && a.q_blk[q] == 1;
+        if (__ballot(mine) == 0ull) continue;
+        const double *dbase = a.tmp_d + q * a.stride + it.y;
+        const int rb = a.rep_soff[c], ns = a.rep_soff[c + 1] - rb;
+        double *pool = a.pool + ((int64_t)tile.w + 1) * 384 + lane;
+        LeanBest best;
+        lean_best_init(best);
+        const double coef = BME ? 1.0 / (double)(1 + 2 - 1) : 1.0;  // apples/BME.py:36-37: the node is not the LCA, one valid sibling
+        for (int j = ns - 1; j >= 0; --j) {
+            const int4 ri = a.rec_i[rb + j];
+            const double2 re = a.rec_e[rb + j];
+            double plift[6], S0[6], S1[6];
+            blk_load(pool + (int64_t)j * 384, plift);  // lift(R) of this node over its own edge: from its parent's step (a root: from the sweep above)
+            if (ri.x >= 0) blk_load(pool + (int64_t)ri.x * 384, S0); else leaf_tuple<M>(dbase[-ri.x - 1], S0);
+            if (ri.y >= 0) blk_load(pool + (int64_t)ri.y * 384, S1); else leaf_tuple<M>(dbase[-ri.y - 1], S1);
+            auto kid = [&](const double *Sk, const double *Ss, double ek, double es, int kd, int kn) __attribute__((always_inline)) {
+                double acc[6], u[6];
+#pragma unroll
+                for (int x = 0; x < 6; ++x) acc[x] = 0;
+                lift<M>(Ss, es, u);  // the one valid sibling (apples/OLS.py:59-69)
+#pragma unroll
+                for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * u[x] : u[x];
+#pragma unroll
+                for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];  // parent term last (apples/OLS.py:70-80)
+                const Sol r = solve_edge<M>(Sk, acc, ek, a.negative, sh_pow);
+                if (kd >= 0) {  // an internal child: lift(R) over its edge replaces its S (both S tuples are in registers)
+                    lift<M>(acc, ek, u);
+                    blk_store(pool + (int64_t)kd * 384, u);
+                }
+                const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
+                if (key < best.key || (key == best.key && kn < best.v)) {
+                    best.key = key; best.v = kn; best.x1 = r.x1; best.x2 = r.x2; best.err = r.err; best.x1_int = r.x1_int; best.e = ek;
+                }
+            };
+            kid(S0, S1, re.x, re.y, ri.x, ri.z);
+            kid(S1, S0, re.y, re.x, ri.y, ri.w);
+        }
+        if (in) {  // slot 0 of the tile: key, x1, x2, err, e, (x1 is the int 0, edge)
+            double *b = a.pool + (int64_t)tile.w * 384 + lane;
+            b[0] = mine ? best.key : INF_D; b[64] = best.x1; b[128] = best.x2; b[192] = best.err; b[256] = best.e;
+            b[320] = __hiloint2double(best.x1_int, best.v);
+        }
+    }
+}
+
+// the query's placement = the better of what the sweep above the blocks found and the best edge inside its blocks
+// (apples/Algorithm.py:74-101: smallest key, ties to the smaller edge_index).  A wavefront per query.
+__global__ __launch_bounds__(APPLES_TPB) void k_blocks_finish(BlockArgs a) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t q = (int64_t)blockIdx.x * (APPLES_TPB / WAVE) + threadIdx.x / WAVE;
+    if (q >= a.nq || a.q_blk[q] != 1) return;
+    const int2 qi = a.q_items[q];
+    double key = INF_D;
+    int v = 0x7fffffff, at = -1;
+    for (int k = lane; k < qi.y; k += WAVE) {
+        const int sb = a.item_sbase[a.q_item[qi.x + k]];
+        if (sb < 0) continue;
+        const double *b = a.pool + (int64_t)(sb >> 6) * 384 + (sb & 63);
+        const double k2 = b[0];
+        const int v2 = __double2loint(b[320]);
+        if (k2 < key || (k2 == key && v2 < v)) { key = k2; v = v2; at = sb; }
+    }
+    const int my_v = v;
+    double wkey = key;
+    int win = v;
+    team_argmin<WAVE>(wkey, win, nullptr, nullptr);
+    if (win == 0x7fffffff || my_v != win || at < 0) return;  // (edge ids are distinct: one lane holds the winner)
+    apples_placement pl = a.out[q];
+    const double ukey = pl.edge < 0 ? INF_D : (a.criterion == APPLES_ME ? pl.pendant : pl.error);
+    if (!(wkey < ukey || (wkey == ukey && win < pl.edge))) return;
+    const double *b = a.pool + (int64_t)(at >> 6) * 384 + (at & 63);
+    const double x1 = b[64], x2 = b[128], err = b[192], e = b[256];
+    pl.edge = win;
+    pl.error = err;
+    pl.distal = e - x2;
+    pl.pendant = x1;
+    pl.flags = 0;
+    if (__double2hiint(b[320])) pl.flags |= APPLES_F_PENDANT_INT;
+    if (x1 == 0 && err > 0 && (x2 == 0 || x2 == e)) pl.flags |= APPLES_F_MISPLACED;
+    a.out[q] = pl;
+}
+
 }  // namespace
+
+// clade blocks: S tuples of the blocks of every (query, accepted cluster) item, before the selection's last phase names the
+// block roots in the observation lists
+int launch_blocks_up(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
+    const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    const dim3 grid((unsigned)(cus * 4)), block(APPLES_TPB);
+    HIP_TRY(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int32_t), st));
+    switch (a.method) {
+        case APPLES_FM: hipLaunchKernelGGL((k_blocks_up<APPLES_FM>), grid, block, 0, st, a); break;
+        case APPLES_BME: hipLaunchKernelGGL((k_blocks_up<APPLES_BME>), grid, block, 0, st, a); break;
+        case APPLES_BE: hipLaunchKernelGGL((k_blocks_up<APPLES_BE>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((k_blocks_up<APPLES_OLS>), grid, block, 0, st, a); break;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ... and after the sweep above the blocks: the top-down pass inside them, then the queries' placements
+int launch_blocks_down(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
+    const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    const dim3 grid((unsigned)(cus * 3)), block(APPLES_TPB);
+    HIP_TRY(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int32_t), st));
+    switch (a.method) {
+        case APPLES_FM: hipLaunchKernelGGL((k_blocks_down<APPLES_FM>), grid, block, 0, st, a); break;
+        case APPLES_BME: hipLaunchKernelGGL((k_blocks_down<APPLES_BME>), grid, block, 0, st, a); break;
+        case APPLES_BE: hipLaunchKernelGGL((k_blocks_down<APPLES_BE>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((k_blocks_down<APPLES_OLS>), grid, block, 0, st, a); break;
+    }
+    if (!getenv("APPLES_BLK_SKIP_FINISH"))  // (debug)
+    hipLaunchKernelGGL(k_blocks_finish, dim3((unsigned)((a.nq + APPLES_TPB / WAVE - 1) / (APPLES_TPB / WAVE))), block, 0, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
 
 // workgroup-sized teams over a device-side list (routed or overflow queries); a.lean = the big teams' field arrays
 int launch_sweep_lean_big(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st) {

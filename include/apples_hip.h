@@ -107,7 +107,8 @@ typedef struct {
 #define APPLES_DBG_STREAM_THIRD_PASS 65536u /* k_select_stream: a row that needs the top-up rule is streamed a third time instead of the merge in LDS */
 #define APPLES_DBG_NO_SD_COMPACT  131072u  /* scoredist top-up: rows of n_slots values for the selection instead of compact lists */
 #define APPLES_DBG_SD_COMPACT_TINY 262144u /* ... compact lists of 16 entries: nearly every listed query overflows into the row form */
-#define APPLES_DBG_ALL           524287u  /* every defined switch; other bits of apples_params.debug are ignored */
+#define APPLES_DBG_NO_BLOCKS     524288u  /* clustered route: no clade blocks (every observed leaf goes through the per-query merged sweep) */
+#define APPLES_DBG_ALL           1048575u /* every defined switch; other bits of apples_params.debug are ignored */
 
 /* One placement = the p row runquery returns, [edge_num, likelihood(error), 1, distal, pendant]
  * (apples/Algorithm.py:98-101, apples/PoolQueryWorker.py:36-37,74,88,119-125). */
