@@ -750,17 +750,24 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
 // `slim`: the fused matrix-core path writes no full distance rows for the batch -- only the queries on the top-up
 // list get them -- so dist and dist_slow hold a slice of the batch (an eighth) and the list is walked in slices:
 // a query then costs 4 + 2 bytes per reference slot instead of 20, and a C3 pass needs 4 device batches, not 7.
+// `seg_stride` > 0 (the clustered fused route): its survivors are representatives, rows of seg_stride = reps_pad entries, and
+// only what its top-up phase forwards takes a full row -- seg_slot / seg_cnt are that narrow and dist_slow holds a slice; dist
+// (the queries' rows of member distances) stays whole.  6.4 -> 4.2 MB per query at 200 000 references: five device batches
+// for config 3's 100 000 queries, not seven (every kernel of the route has a tail of a few hundred microseconds per batch).
 int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t want_batch, bool need_dist,
-                     bool need_counts, bool need_xe, bool need_fused = false, bool need_alt = false, bool slim = false) {
+                     bool need_counts, bool need_xe, bool need_fused = false, bool need_alt = false, bool slim = false,
+                     int64_t seg_stride = 0) {
     Workspace &w = ctx->ws;
     const DevTree &t = ctx->tree;
     int64_t batch = want_batch;
     if (ctx->params.max_batch > 0) batch = std::min(batch, (int64_t)ctx->params.max_batch);
     static const bool no_slim = getenv("APPLES_NO_SLIM_BATCH") != nullptr;  // diagnostic knob
     slim = slim && need_fused && !need_counts && !need_alt && !no_slim;
+    const bool cslim = seg_stride > 0 && seg_stride < stride && need_fused && !need_counts && !need_alt && !slim && !no_slim;
     int64_t per_q = stride * 8 + members * 12 + (int64_t)(t.height + 2) * 4 + (need_counts ? stride * 4 : 0) +
                     (need_fused ? stride * 12 + stride / 16 : 0);
     if (slim) per_q = stride * 4 + stride / 16 + stride * 2 + members * 12 + (int64_t)(t.height + 2) * 4;
+    if (cslim) per_q = stride * 8 + stride + seg_stride * 4 + seg_stride / 16 + members * 12 + (int64_t)(t.height + 2) * 4;
     // batch buffers: up to 96 GiB, at most 40 % of what is free on the card (288 GB HBM3E; bigger
     // batches amortise the sweep's tail: at 200 k leaves 16 k-query batches are 13 % faster than 5 k).
     // Allocating them is not free: with 160 GiB a resident C3 pass is another 4 % faster, but a one-shot
@@ -788,17 +795,18 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     batch = size_batch();
     bool regrow = batch > w.batch || members > w.obs_cap || stride > w.stride || (need_counts && !w.counts) ||
                   (need_xe && !w.big.xe) || (need_dist && !w.dist) || (need_fused && !w.seg_slot) || (need_alt && !w.has_alt) ||
-                  (!slim && w.dist_rows < w.batch);  // full rows wanted where only a slice exists (run_block steps by w.batch)
+                  (!slim && !cslim && w.dist_rows < w.batch);  // full rows wanted where only a slice exists (run_block steps by w.batch)
     if (!regrow) return 0;
     if (!ctx->blk_cache.empty()) {  // cached block buffers count as used in hipMemGetInfo: give them back, then size the batch
         for (auto &c : ctx->blk_cache) dev_free(c.second);
         ctx->blk_cache.clear();
         batch = size_batch();
     }
-    if (slim == w.slim || !w.slim) batch = std::max(batch, w.batch);
+    if ((slim == w.slim || !w.slim) && (cslim == w.cslim || !w.cslim)) batch = std::max(batch, w.batch);
     if (!slim) batch = std::min(batch, std::max<int64_t>(capq, 32));  // (a slim workspace's batch would not fit with full rows)
     batch = round_up(std::max<int64_t>(batch, 1), 32);
-    const int64_t drows = slim ? std::min(batch, std::max<int64_t>(2048, batch / 8)) : batch;
+    const int64_t drows = (slim || cslim) ? std::min(batch, std::max<int64_t>(2048, batch / 8)) : batch;
+    const int64_t seg_w = cslim ? seg_stride : std::max<int64_t>(stride, 1);  // entries of a row of seg_slot
     int64_t obs_cap = std::max(members, w.obs_cap);
     stride = std::max(stride, w.stride);
     bool xe = need_xe || w.big.xe != nullptr, had_counts = w.counts != nullptr;
@@ -809,9 +817,10 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     w.obs_cap = obs_cap;
     w.stride = stride;
     w.slim = slim;
+    w.cslim = cslim;
     w.dist_rows = drows;
     for (int set = 0; set < (alt ? 2 : 1); ++set) {
-        if (dev_alloc(ctx, &w.dist, drows * std::max<int64_t>(stride, 1))) return 1;
+        if (dev_alloc(ctx, &w.dist, (cslim ? batch : drows) * std::max<int64_t>(stride, 1))) return 1;
         if (need_counts || had_counts)
             if (dev_alloc(ctx, &w.counts, batch * std::max<int64_t>(stride, 1))) return 1;
         if (dev_alloc(ctx, &w.obs_node, batch * obs_cap)) return 1;
@@ -819,8 +828,8 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         if (dev_alloc(ctx, &w.cnt_gt, batch * (int64_t)(t.height + 2))) return 1;
         if (dev_alloc(ctx, &w.n_obs, batch)) return 1;
         if (fused) {
-            if (dev_alloc(ctx, &w.seg_slot, batch * std::max<int64_t>(stride, 1))) return 1;
-            if (dev_alloc(ctx, &w.seg_cnt, batch * std::max<int64_t>(stride / 64, 1))) return 1;
+            if (dev_alloc(ctx, &w.seg_slot, batch * seg_w)) return 1;
+            if (dev_alloc(ctx, &w.seg_cnt, batch * std::max<int64_t>(seg_w / 64, 1))) return 1;
             if (dev_alloc(ctx, &w.dist_slow, drows * std::max<int64_t>(stride, 1))) return 1;
             if (dev_alloc(ctx, &w.slow_list, 3 * batch)) return 1;  // the list, what is known about its entries (SelectArgs.slow_hint), and the
                                                                     // list of what the clustered route's phase 4 forwards to the general selection
@@ -1234,7 +1243,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     // against 69.2 -- lists of 3 126 observed leaves per query outgrow the Infinity Cache in the bigger batches -- and the
     // selection kernel's load schedule suffered from the second home of the distances: 4.0 against 2.6 ms per batch)
     const bool slim = fused && a.all_singleton && fused_counts_format(ctx, qb) && !pipelined;
-    if (ensure_workspace(ctx, a.n_refs, a.slots_pad, want, true, false, hybrid, fused, pipelined, slim)) return 1;
+    if (ensure_workspace(ctx, a.n_refs, a.slots_pad, want, true, false, hybrid, fused, pipelined, slim,
+                         (cfused && !pipelined && !(ctx->dbg & APPLES_DBG_NO_CLUSTER_TOPUP)) ? a.reps_pad : 0)) return 1;
     Workspace &w = ctx->ws;
     int64_t step = pipelined ? std::min<int64_t>(w.batch, want) : w.batch;
     const int64_t n_sub = (qb.n + step - 1) / step;
@@ -1431,7 +1441,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 const int64_t n_items = nq * SELECT_CLUSTERS_ACC_CAP + std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps;
                 const int64_t n_ints = 2 * n_items + 3 * w.batch + 16, n_tiles = n_items / 64 + a.n_reps + 1;
                 if (n_ints > ctx->blk_ints_cap) {
-                    dev_free(ctx->blk_ints); ctx->blk_ints = nullptr; ctx->blk_ints_cap = 0;
+                    dev_free(ctx->blk_ints); ctx->blk_ints = nullptr; ctx->blk_ints_cap = 0; ctx->blk_counters = nullptr;
                     if (dev_alloc(ctx, &ctx->blk_ints, n_ints)) return 1;
                     ctx->blk_ints_cap = n_ints;
                 }
@@ -1455,6 +1465,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 int32_t *bi = ctx->blk_ints;
                 sa.item_sbase = bi; sa.q_item = bi + n_items; sa.q_items = reinterpret_cast<int2 *>(bi + 2 * n_items);
                 sa.q_blk = bi + 2 * n_items + 2 * w.batch; sa.q_item_cursor = bi + 2 * n_items + 3 * w.batch; sa.blk_ntiles = sa.q_item_cursor + 2;
+                ctx->blk_counters = sa.q_item_cursor;  // (apples_describe: items and tiles of the last device batch)
                 HIP_TRY(ctx, hipMemsetAsync(bi + 2 * n_items, 0, (size_t)(3 * w.batch + 16) * sizeof(int32_t), front));
                 sa.blk_rec_i = a.blk_rec_i; sa.blk_rec_e = a.blk_rec_e; sa.rep_soff = a.rep_soff; sa.mem_block = a.mem_block;
                 sa.blk_root = a.blk_root; sa.blk_rslot = a.blk_rslot; sa.blk_nodes = a.blk_nodes;
@@ -1605,7 +1616,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 int32_t *bi = ctx->blk_ints;
                 BlockArgs b{};
                 b.tiles = ctx->blk_tiles; b.n_tiles = bi + 2 * n_items + 3 * w.batch + 2; b.items = ctx->cl_items;
-                b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.mem_slot = a.mem_slot;
+                b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos;
                 b.self_slot = qb.self_slot + q0; b.tmp_d = w.dist; b.stride = a.slots_pad; b.pool = ctx->blk_pool;
                 b.item_sbase = bi; b.q_item = bi + n_items; b.q_items = reinterpret_cast<const int2 *>(bi + 2 * n_items);
                 b.q_blk = bi + 2 * n_items + 2 * w.batch; b.cursor = bi + 2 * n_items + 3 * w.batch + 1;
@@ -2405,17 +2416,20 @@ int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n) {
 
 const char *apples_describe(apples_ctx *ctx) {
     hipDeviceProp_t prop;
-    char buf[1280];
+    char buf[1536];
     const char *name = "?";
     int cus = 0;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) { name = prop.name; cus = prop.multiProcessorCount; }
     const DevAlign &a = ctx->aln;
+    int32_t blk_cnt[3] = {0, 0, 0};  // clade blocks, the last device batch: (query, cluster) items, -, tiles
+    if (ctx->blk_counters && hipStreamSynchronize(ctx->stream) == hipSuccess)
+        (void)hipMemcpy(blk_cnt, ctx->blk_counters, sizeof blk_cnt, hipMemcpyDeviceToHost);
     snprintf(buf, sizeof buf,
              "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"n_rows\": %lld, "
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
              "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\", "
              "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld, \"sweep_layout\": \"%s\", \"cluster_fused\": %d, "
-             "\"scoredist_filter\": %d, \"scoredist_image_bytes\": %lld, \"cluster_blocks\": %d}",
+             "\"scoredist_filter\": %d, \"scoredist_image_bytes\": %lld, \"cluster_blocks\": %d, \"block_items_last_batch\": %d, \"block_tiles_last_batch\": %d}",
              name, cus, ctx->tree.n_nodes, ctx->tree.height, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
              (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
@@ -2435,7 +2449,7 @@ const char *apples_describe(apples_ctx *ctx) {
              (ctx->params.model == APPLES_SCOREDIST && sd_gemm_usable(ctx) && !(ctx->dbg & APPLES_DBG_NO_FUSE)) ? 1 : 0,
              (long long)(a.sd_ref4 ? a.slots_pad * (int64_t)sd_steps(a.L) * 64 : 0),
              // clade blocks of a clustered reference (build_blocks): whole subtrees of one cluster, swept on a static schedule
-             (int)a.n_blocks);
+             (int)a.n_blocks, (int)blk_cnt[0], (int)blk_cnt[2]);
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

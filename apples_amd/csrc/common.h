@@ -208,6 +208,7 @@ struct Workspace {
     int64_t batch = 0;            // queries per device batch
     int64_t dist_rows = 0;        // rows of dist / dist_slow: `batch`, or a slice of it (slim: only listed queries use full rows)
     bool slim = false;
+    bool cslim = false;           // clustered fused route: seg_slot / seg_cnt rows of reps_pad entries, dist_slow a slice, dist whole
     int64_t stride = 0;           // row stride of dist/counts
     double *dist = nullptr;       // [batch][slots_pad] fp64 distances in slot order
     uint32_t *counts = nullptr;   // [batch][slots_pad] (mism<<16|valid), only when requested
@@ -298,6 +299,7 @@ struct apples_ctx {
     int2 *cl_items = nullptr; int64_t cl_items_cap = 0;
     int4 *cl_tiles = nullptr; int64_t cl_tiles_cap = 0;
     bool blk_active = false;   // the device batch under way names block roots in its observation lists (run_block)
+    int32_t *blk_counters = nullptr;  // [3] inside blk_ints: items, work cursor, tiles of the last device batch
     double *blk_pool = nullptr; int64_t blk_pool_cap = 0;   // clade blocks: the batch's tuples, [tile][slot][6][64 lanes] doubles
     int32_t *blk_ints = nullptr; int64_t blk_ints_cap = 0;  // ... per item: storage base (-1: no blocks for it); per query: {first, count} of its items; the items
     int4 *blk_tiles = nullptr; int64_t blk_tiles_cap = 0;   // ... tiles of up to 64 items of one cluster: {cluster, first item, items, storage base / 64}
@@ -517,7 +519,7 @@ struct SweepArgs {
 struct BlockArgs {
     const int4 *tiles; const int32_t *n_tiles;  // {cluster, first item, items (<= 64), first slot of the tile's tuples in the pool or -1}
     const int2 *items;                          // (query, where the cluster's members start in the query's flat member list)
-    const int4 *rec_i; const double2 *rec_e; const int32_t *rep_soff, *rep_moff, *mem_slot;
+    const int4 *rec_i; const double2 *rec_e; const int32_t *rep_soff, *rep_moff, *slot_rep, *slot_mpos;
     const int32_t *self_slot;                   // [nq] the queries' own rows as slots, or nullptr
     const double *tmp_d; int64_t stride;        // the queries' rows of member distances
     double *pool;                               // [slot][6][64 lanes]; a tile's slot 0: the lanes' best edges inside the blocks (key, x1, x2,

@@ -874,15 +874,20 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     double z_d = INF_D;
     int z_i = 0x7fffffff, z_p = 0x7fffffff, z_node = -2;
     for (int m0 = 0; m0 < M; m0 += TPB * E) {
-        int lo_[E], slot_[E], node_[E];
+        int lo_[E], slot_[E], node_[E], mbk_[E];
         double d_[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int m = m0 + e * TPB + tid;
-            lo_[e] = -1; slot_[e] = 0; d_[e] = -1.0;
+            lo_[e] = -1; slot_[e] = 0; d_[e] = -1.0; mbk_[e] = -1;
             if (m < M) {
                 const int lo = cluster_of(m), mp = m - sh_off[lo], mb = sh_mb[lo];
                 lo_[e] = lo;
+                // clade blocks: a member of a block whose tuples k_blocks_up has formed for this query -- every leaf of the block is
+                // a tree leaf with a distance > 0 and none is the query's own row (else the cluster's item has no blocks): it is
+                // counted, its block's first leaf marks the root, and nothing of its own is looked up
+                if (PHASE == 3 && use_blk && sh_sb[lo] >= 0) mbk_[e] = a.mem_block[mb + mp];
+                if (mbk_[e] >= 0) { d_[e] = 1.0; continue; }
                 slot_[e] = a.mem_slot[mb + mp];  // (on its way with the member's distance / words below: neither waits for the other)
                 if (PHASE >= 3) d_[e] = tmp[m];  // k_cluster_dist (phase 4: the block above) left it there
                 else d_[e] = by_query(a.packed_rm + (int64_t)mb * (G * 3) + mp, sh_off[lo + 1] - sh_off[lo]);
@@ -890,7 +895,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < E; ++e)  // (the node of every listed member: cheaper asked for than waited for)
-            node_[e] = lo_[e] >= 0 ? a.slot_node[slot_[e]] : -1;
+            node_[e] = lo_[e] < 0 ? -1 : (mbk_[e] >= 0 ? 0 : a.slot_node[slot_[e]]);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int m = m0 + e * TPB + tid;
@@ -900,7 +905,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
             double keep = -2.0;  // not emitted
             if (!(d < 0)) {      // Reference.py:150: `if not dm < 0`
                 ++obs_cnt;
-                if (slot != self) {
+                if (slot != self || mbk_[e] >= 0) {
                     ++n_total;
                     const int node = node_[e];
                     if (d == 0) {
@@ -920,19 +925,19 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
                     }
                     if (node >= 0) {
                         keep = d;
-                        int es = slot;
-                        if (blk_space) {
-                            es = a.e_of_slot[slot];
-                            if (use_blk && sh_sb[lo] >= 0) {  // a member of a block: the block's root stands for it
-                                const int mbk = a.mem_block[sh_mb[lo] + (m - sh_off[lo])];
-                                if (mbk >= 0) es = a.e_of_blk[mbk >> 1];
+                        if (mbk_[e] >= 0) {  // the block's root stands for its leaves: its first leaf marks it
+                            if (mbk_[e] & 1) {
+                                const int es = a.e_of_blk[mbk_[e] >> 1];
+                                atomicOr(&dyn_bits[es >> 6], 1ull << (es & 63));
                             }
+                        } else {
+                            const int es = blk_space ? a.e_of_slot[slot] : slot;
+                            atomicOr(&dyn_bits[es >> 6], 1ull << (es & 63));
                         }
-                        atomicOr(&dyn_bits[es >> 6], 1ull << (es & 63));
                     }
                 }
             }
-            tmp[m] = keep;
+            if (mbk_[e] < 0) tmp[m] = keep;  // (a block's leaf: its distance stays as it is)
         }
     }
     const int obs = block_sum<NW>(obs_cnt, sh_i);
@@ -971,41 +976,40 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     };
     // ---- pass 2: emission in slot order
     for (int m0 = 0; m0 < M; m0 += TPB * E) {
-        int slot_[E];
+        int slot_[E], mbk_[E], lo_[E];
         double d_[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int m = m0 + e * TPB + tid;
-            slot_[e] = -1; d_[e] = -2.0;
+            slot_[e] = -1; d_[e] = -2.0; mbk_[e] = -1; lo_[e] = 0;
             if (m < M) {
                 const int lo = cluster_of(m);
+                lo_[e] = lo;
+                if (PHASE == 3 && use_blk && sh_sb[lo] >= 0) mbk_[e] = a.mem_block[sh_mb[lo] + (m - sh_off[lo])];
+                if (mbk_[e] >= 0) { d_[e] = (mbk_[e] & 1) ? 1.0 : -2.0; continue; }  // (the block's first leaf writes the block's entry)
                 d_[e] = tmp[m];
                 slot_[e] = a.mem_slot[sh_mb[lo] + (m - sh_off[lo])];
             }
         }
         int node_[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) node_[e] = slot_[e] >= 0 ? a.slot_node[slot_[e]] : -1;
+        for (int e = 0; e < E; ++e) node_[e] = (slot_[e] >= 0 && mbk_[e] < 0) ? a.slot_node[slot_[e]] : -1;
 #pragma unroll
         for (int e = 0; e < E; ++e)
             if (d_[e] >= 0) {
-                int es = slot_[e], node = node_[e];
+                int es, node = node_[e];
                 double dd = d_[e];
-                if (blk_space) {
-                    es = a.e_of_slot[slot_[e]];
-                    const int m = m0 + e * TPB + tid, lo = cluster_of(m);
-                    if (use_blk && sh_sb[lo] >= 0) {
-                        const int mbk = a.mem_block[sh_mb[lo] + (m - sh_off[lo])];
-                        if (mbk >= 0) {  // (every member of the block writes the same entry)
-                            const int b = mbk >> 1;
-                            es = a.e_of_blk[b];
-                            node = a.blk_root[b];
-                            // the "distance" of a block root: where its tuple is (sweep_lean.hip:lean_is_block), a boxed index into the pool
-                            const long long at = ((long long)(sh_sb[lo] >> 6) + 1 + a.blk_rslot[b]) * 384 + (sh_sb[lo] & 63);
-                            dd = __longlong_as_double((long long)0xFFF8000000000000ull | at);
-                            if (mbk & 1) blk_extra += a.blk_nodes[b];  // (its first member counts the nodes below the root once)
-                        }
-                    }
+                if (mbk_[e] >= 0) {
+                    if (!(mbk_[e] & 1)) continue;  // (the block's first leaf writes the block's entry)
+                    const int b = mbk_[e] >> 1, sb = sh_sb[lo_[e]];
+                    es = a.e_of_blk[b];
+                    node = a.blk_root[b];
+                    // the "distance" of a block root: where its tuple is (sweep_lean.hip:lean_is_block), a boxed index into the pool
+                    const long long at = ((long long)(sb >> 6) + 1 + a.blk_rslot[b]) * 384 + (sb & 63);
+                    dd = __longlong_as_double((long long)0xFFF8000000000000ull | at);
+                    blk_extra += a.blk_nodes[b];  // (the nodes below the root, once)
+                } else {
+                    es = blk_space ? a.e_of_slot[slot_[e]] : slot_[e];
                 }
                 const int pos = rank_of(es);
                 o_node[pos] = node;
@@ -1097,12 +1101,14 @@ __global__ __launch_bounds__(CL_TILES_TPB) void k_cluster_tiles(SelectArgs a) {
             const int nb = ns > 0 ? (cnt + 63) / 64 : 0;
             int tot_b, tot_s;
             const int at_b = btile_base + block_excl_scan_int<CL_TILES_TPB / WAVE>(nb, sh_i, &tot_b);
-            // (ns + 1 slots per tile: the first holds the lanes' best edges inside the blocks, k_blocks_down -> k_blocks_finish)
-            const int at_s = bslot_base + block_excl_scan_int<CL_TILES_TPB / WAVE>(nb * (ns + 1), sh_i, &tot_s);
+            // (slots per tile: the first holds the lanes' best edges inside the blocks, k_blocks_down -> k_blocks_finish; ns for the
+            // tuples; then the members' distances once more as [member][lane], six rows to a slot: what the walks read whole rows of)
+            const int ts = c < a.n_reps ? 1 + ns + (a.rep_moff[c + 1] - a.rep_moff[c] + 5) / 6 : 0;
+            const int at_s = bslot_base + block_excl_scan_int<CL_TILES_TPB / WAVE>(nb * ts, sh_i, &tot_s);
             for (int k = 0; k < nb; ++k)
                 if (at_b + k < a.blk_tiles_cap)
                     a.blk_tiles[at_b + k] = make_int4((int)c, at_i + k * 64, cnt - k * 64 < 64 ? cnt - k * 64 : 64,
-                                                      (int64_t)(at_s + (k + 1) * (ns + 1)) * 384 <= a.blk_pool_cap ? at_s + k * (ns + 1) : -1);
+                                                      (int64_t)(at_s + (k + 1) * ts) * 384 <= a.blk_pool_cap ? at_s + k * ts : -1);
             btile_base += tot_b;
             bslot_base += tot_s;
         }
@@ -1299,7 +1305,7 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (a.blk_tiles) {  // clade blocks: the S tuples inside them, before the last phase names their roots in the observation lists
         BlockArgs b{};
         b.tiles = a.blk_tiles; b.n_tiles = a.blk_ntiles; b.items = a.cl_items; b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e;
-        b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.mem_slot = a.mem_slot; b.self_slot = a.self_slot; b.tmp_d = a.tmp_d;
+        b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos; b.self_slot = a.self_slot; b.tmp_d = a.tmp_d;
         b.stride = a.stride; b.pool = a.blk_pool; b.item_sbase = a.item_sbase; b.cursor = a.q_item_cursor + 1; b.method = a.method;
         if (launch_blocks_up(ctx, b, ctx->stream)) return 1;
     }

@@ -1002,10 +1002,30 @@ __device__ __forceinline__ void blk_store(double *p, const double *S) {
     for (int x = 0; x < 6; ++x) p[x * 64] = S[x];
 }
 
+// What a step of the walks reads besides its record: the distances of the node's leaf children, the tuple of an internal child
+// that is not the node before (bottom-up: only a left child can be) and, top-down, the node's own lift(R) where the step before
+// did not form it.  All of it is requested ONE STEP AHEAD and UNCONDITIONALLY (what a node does not need comes from slot 0 /
+// member 0 and is dropped): the loads of a step are then a fixed number, the wait before their use is a counted one that leaves
+// the step's own stores and the next step's loads in flight.  (First form: loads where needed, waited for where used -- every
+// step then drained the memory queue, stores included, 8 us per step: the kernel was a queue of round trips.)  The records
+// come through a per-wavefront window in LDS (one coalesced load per 128 nodes): reading them costs no place in that queue.
+#define BLK_WIN 128
+struct BlkOps {
+    double d0, d1;
+    double p0[6], p1[6], pl[6];
+};
+struct BlkWin {
+    int4 ri[APPLES_TPB / WAVE][BLK_WIN];
+    double2 re[APPLES_TPB / WAVE][BLK_WIN];
+};
+
 template <int M>
 __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
     constexpr bool BME = (M == APPLES_BME);
-    const int lane = threadIdx.x & (WAVE - 1);
+    __shared__ BlkWin win;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    int4 *w_ri = win.ri[wv];
+    double2 *w_re = win.re[wv];
     const int n_tiles = *a.n_tiles;
     while (true) {
         int tq = 0;
@@ -1023,38 +1043,85 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
         }
         const int64_t q = it.x;
         const double *dbase = a.tmp_d + q * a.stride + it.y;
+        // the query's own row as a member position of this cluster (-1: not in it): a block that holds it is not whole
+        // (apples/PoolQueryWorker.py:63-66 deletes the entry)
         const int self = a.self_slot ? a.self_slot[q] : -1;
-        const int rb = a.rep_soff[c], ns = a.rep_soff[c + 1] - rb, mb = a.rep_moff[c];
+        const int self_mp = (self >= 0 && a.slot_rep[self] == c) ? a.slot_mpos[self] : -1;
+        const int rb = a.rep_soff[c], ns = a.rep_soff[c + 1] - rb;
         double *pool = a.pool + ((int64_t)tile.w + 1) * 384 + lane;  // (slot 0 of the tile: the lanes' best edges, k_blocks_down)
+        // the members' distances as [member][lane] behind the tuples: a lane reads its query's row eight values (a sector) at a
+        // time here, and the walks then read a leaf's distance as one 512-byte row for the wavefront -- read leaf by leaf from
+        // the queries' rows a visit cost 64 sectors for 64 values, half of all the bytes the walks moved
+        double *dT = pool + (int64_t)ns * 384;
+        const int sz = a.rep_moff[c + 1] - a.rep_moff[c];
+        for (int m0 = 0; m0 < sz; m0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = dbase[m0 + k < sz ? m0 + k : sz - 1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (m0 + k < sz) dT[(int64_t)(m0 + k) * 64] = v[k];
+        }
         bool regular = true;
-        for (int j = 0; j < ns; ++j) {
-            const int4 ri = a.rec_i[rb + j];
-            const double2 re = a.rec_e[rb + j];
-            double S0[6], S1[6], u[6], r[6];
-            if (ri.x >= 0) blk_load(pool + (int64_t)ri.x * 384, S0);
-            else {
-                const int mp = -ri.x - 1;
-                const double D = dbase[mp];
-                if (D < 0 || a.mem_slot[mb + mp] == self) regular = false;  // a member the reference drops (Reference.py:150) or the query's own row
-                leaf_tuple<M>(D, S0);
+        // (what a node does not need is read from one place, the same for every lane: a sector, not a row)
+        auto fetch = [&](const int4 &ri, int j, BlkOps &o) __attribute__((always_inline)) {
+            o.d0 = dT[(int64_t)(ri.x < 0 ? -ri.x - 1 : 0) * 64];
+            o.d1 = dT[(int64_t)(ri.y < 0 ? -ri.y - 1 : 0) * 64];
+#ifdef BLK_EXP_NO_LOAD
+            blk_load(a.pool, o.p0);
+#else
+            blk_load((ri.x >= 0 && ri.x != j - 1) ? pool + (int64_t)ri.x * 384 : a.pool, o.p0);
+#endif
+        };
+        double r[6] = {0, 0, 0, 0, 0, 0};  // the tuple of the node before: in post-order an internal right child (or an internal left child beside a
+                                            // leaf) is the node just formed -- it does not come back from the pool
+        for (int w0 = 0; w0 < ns; w0 += BLK_WIN) {
+            const int wn = ns - w0 < BLK_WIN ? ns - w0 : BLK_WIN;
+            __builtin_amdgcn_wave_barrier();  // (the window's last readers)
+            for (int k = lane; k < wn; k += WAVE) { w_ri[k] = a.rec_i[rb + w0 + k]; w_re[k] = a.rec_e[rb + w0 + k]; }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            // two operand sets in turn (a step uses one and requests the next node's into the other): copying a set would wait for
+            // the loads it had just requested -- the first form did, and a step cost a memory round trip again
+            auto step = [&](int k, const BlkOps &o, BlkOps &o1) __attribute__((always_inline)) {
+                const int j = w0 + k;
+                const int4 ri = w_ri[k];
+                const double2 re = w_re[k];
+                fetch(w_ri[k + 1 < wn ? k + 1 : k], j + 1, o1);  // the next node's operands (its slots lie below j: written)
+                double S0[6], S1[6], L0[6], L1[6], u[6];
+                leaf_tuple<M>(o.d0, L0);
+                leaf_tuple<M>(o.d1, L1);
+                const bool leaf0 = ri.x < 0, leaf1 = ri.y < 0, prev0 = ri.x == j - 1;
+#pragma unroll
+                for (int x = 0; x < 6; ++x) {
+                    S0[x] = leaf0 ? L0[x] : (prev0 ? r[x] : o.p0[x]);
+                    S1[x] = leaf1 ? L1[x] : r[x];  // (an internal right child is the node before)
+                }
+                // a member the reference drops (Reference.py:150), the query's own row, or an exact match (the selection's
+                // bookkeeping of PoolQueryWorker.py:72-75 wants its leaf): the cluster's item goes without blocks
+                if ((leaf0 && (!(o.d0 > 0) || -ri.x - 1 == self_mp)) || (leaf1 && (!(o.d1 > 0) || -ri.y - 1 == self_mp))) regular = false;
+                const double coef = BME ? 1.0 / (double)2 : 1.0;  // apples/BME.py:20: both children are valid
+                lift<M>(S0, re.x, u);
+#pragma unroll
+                for (int x = 0; x < 6; ++x) r[x] = 0;
+#pragma unroll
+                for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
+                lift<M>(S1, re.y, u);
+#pragma unroll
+                for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
+#ifdef BLK_EXP_NO_STORE  // (timing experiments: scripts/r05_blk_parts_exp.sh)
+                if (r[0] == 123456.789) blk_store(pool + (int64_t)j * 384, r);
+#else
+                blk_store(pool + (int64_t)j * 384, r);
+#endif
+            };
+            BlkOps oa, ob;
+            fetch(w_ri[0], w0, oa);
+            int k = 0;
+            for (; k + 2 <= wn; k += 2) {
+                step(k, oa, ob);
+                step(k + 1, ob, oa);
             }
-            if (ri.y >= 0) blk_load(pool + (int64_t)ri.y * 384, S1);
-            else {
-                const int mp = -ri.y - 1;
-                const double D = dbase[mp];
-                if (D < 0 || a.mem_slot[mb + mp] == self) regular = false;
-                leaf_tuple<M>(D, S1);
-            }
-            const double coef = BME ? 1.0 / (double)2 : 1.0;  // apples/BME.py:20: both children are valid
-            lift<M>(S0, re.x, u);
-#pragma unroll
-            for (int x = 0; x < 6; ++x) r[x] = 0;
-#pragma unroll
-            for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
-            lift<M>(S1, re.y, u);
-#pragma unroll
-            for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
-            blk_store(pool + (int64_t)j * 384, r);
+            if (k < wn) step(k, oa, ob);
         }
         if (in) a.item_sbase[item] = regular ? tile.w * 64 + lane : -1;
     }
@@ -1064,10 +1131,13 @@ template <int M>
 __global__ __launch_bounds__(APPLES_TPB) void k_blocks_down(BlockArgs a) {
     constexpr bool BME = (M == APPLES_BME);
     __shared__ double sh_pow[384 + 256];
+    __shared__ BlkWin win;
     for (int i = threadIdx.x; i < 384; i += APPLES_TPB) sh_pow[i] = (&kPowLogTab[0][0])[i];
     for (int i = threadIdx.x; i < 256; i += APPLES_TPB) sh_pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
     __syncthreads();
-    const int lane = threadIdx.x & (WAVE - 1);
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    int4 *w_ri = win.ri[wv];
+    double2 *w_re = win.re[wv];
     const int n_tiles = *a.n_tiles;
     while (true) {
         int tq = 0;
@@ -1085,40 +1155,77 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_down(BlockArgs a) {
         // whatever the pool holds and writes nothing that is read)
         const bool mine = in && a.item_sbase[item] >= 0 && a.q_blk[q] == 1;
         if (__ballot(mine) == 0ull) continue;
-        const double *dbase = a.tmp_d + q * a.stride + it.y;
         const int rb = a.rep_soff[c], ns = a.rep_soff[c + 1] - rb;
         double *pool = a.pool + ((int64_t)tile.w + 1) * 384 + lane;
+        const double *dT = pool + (int64_t)ns * 384;  // the members' distances as [member][lane] (k_blocks_up)
         LeanBest best;
         lean_best_init(best);
         const double coef = BME ? 1.0 / (double)(1 + 2 - 1) : 1.0;  // apples/BME.py:36-37: the node is not the LCA, one valid sibling
-        for (int j = ns - 1; j >= 0; --j) {
-            const int4 ri = a.rec_i[rb + j];
-            const double2 re = a.rec_e[rb + j];
-            double plift[6], S0[6], S1[6];
-            blk_load(pool + (int64_t)j * 384, plift);  // lift(R) of this node over its own edge: from its parent's step (a root: from the sweep above)
-            if (ri.x >= 0) blk_load(pool + (int64_t)ri.x * 384, S0); else leaf_tuple<M>(dbase[-ri.x - 1], S0);
-            if (ri.y >= 0) blk_load(pool + (int64_t)ri.y * 384, S1); else leaf_tuple<M>(dbase[-ri.y - 1], S1);
-            auto kid = [&](const double *Sk, const double *Ss, double ek, double es, int kd, int kn) __attribute__((always_inline)) {
-                double acc[6], u[6];
+        auto fetch = [&](const int4 &ri, int j, bool chained, BlkOps &o) __attribute__((always_inline)) {
+            o.d0 = dT[(int64_t)(ri.x < 0 ? -ri.x - 1 : 0) * 64];
+            o.d1 = dT[(int64_t)(ri.y < 0 ? -ri.y - 1 : 0) * 64];
+            blk_load(chained ? a.pool : pool + (int64_t)j * 384, o.pl);  // (what a node does not need: one place for every lane, a sector)
+            blk_load(ri.x >= 0 ? pool + (int64_t)ri.x * 384 : a.pool, o.p0);
+            blk_load(ri.y >= 0 ? pool + (int64_t)ri.y * 384 : a.pool, o.p1);
+        };
+        double nxt[6] = {0, 0, 0, 0, 0, 0};  // lift(R) of node j - 1 where this step forms it (j - 1 is then a child of j): it does not go through the pool
+        bool have = false;                  // (wave-uniform)
+        for (int w1 = ns; w1 > 0; w1 -= BLK_WIN) {  // windows from the top: nodes [w0, w1)
+            const int w0 = w1 > BLK_WIN ? w1 - BLK_WIN : 0, wn = w1 - w0;
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < wn; k += WAVE) { w_ri[k] = a.rec_i[rb + w0 + k]; w_re[k] = a.rec_e[rb + w0 + k]; }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            auto step = [&](int k, const BlkOps &o, BlkOps &o1) __attribute__((always_inline)) {
+                const int j = w0 + k;
+                const int4 ri = w_ri[k];
+                const double2 re = w_re[k];
+                // the next node's operands: its own lift(R) (unless this step forms it: then what comes is not used), its children's
+                // tuples (slots below j - 1: this step writes none of them -- an internal child of j that is not j - 1 roots another subtree)
+                fetch(w_ri[k > 0 ? k - 1 : 0], k > 0 ? j - 1 : j, ri.x == j - 1 || ri.y == j - 1, o1);
+                double plift[6], S0[6], S1[6], L0[6], L1[6];
+                leaf_tuple<M>(o.d0, L0);
+                leaf_tuple<M>(o.d1, L1);
+                const bool leaf0 = ri.x < 0, leaf1 = ri.y < 0;
 #pragma unroll
-                for (int x = 0; x < 6; ++x) acc[x] = 0;
-                lift<M>(Ss, es, u);  // the one valid sibling (apples/OLS.py:59-69)
-#pragma unroll
-                for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * u[x] : u[x];
-#pragma unroll
-                for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];  // parent term last (apples/OLS.py:70-80)
-                const Sol r = solve_edge<M>(Sk, acc, ek, a.negative, sh_pow);
-                if (kd >= 0) {  // an internal child: lift(R) over its edge replaces its S (both S tuples are in registers)
-                    lift<M>(acc, ek, u);
-                    blk_store(pool + (int64_t)kd * 384, u);
+                for (int x = 0; x < 6; ++x) {
+                    plift[x] = have ? nxt[x] : o.pl[x];  // from its parent's step (a root: from the sweep above)
+                    S0[x] = leaf0 ? L0[x] : o.p0[x];
+                    S1[x] = leaf1 ? L1[x] : o.p1[x];
                 }
-                const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
-                if (key < best.key || (key == best.key && kn < best.v)) {
-                    best.key = key; best.v = kn; best.x1 = r.x1; best.x2 = r.x2; best.err = r.err; best.x1_int = r.x1_int; best.e = ek;
-                }
+                auto kid = [&](const double *Sk, const double *Ss, double ek, double es, int kd, int kn) __attribute__((always_inline)) {
+                    double acc[6], u[6];
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) acc[x] = 0;
+                    lift<M>(Ss, es, u);  // the one valid sibling (apples/OLS.py:59-69)
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * u[x] : u[x];
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];  // parent term last (apples/OLS.py:70-80)
+                    const Sol r = solve_edge<M>(Sk, acc, ek, a.negative, sh_pow);
+                    if (kd >= 0) {  // an internal child: lift(R) over its edge replaces its S (both S tuples are in registers)
+                        lift<M>(acc, ek, u);
+                        if (kd == j - 1) {  // the next node of the walk
+#pragma unroll
+                            for (int x = 0; x < 6; ++x) nxt[x] = u[x];
+                        } else blk_store(pool + (int64_t)kd * 384, u);
+                    }
+                    const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
+                    if (key < best.key || (key == best.key && kn < best.v)) {
+                        best.key = key; best.v = kn; best.x1 = r.x1; best.x2 = r.x2; best.err = r.err; best.x1_int = r.x1_int; best.e = ek;
+                    }
+                };
+                kid(S0, S1, re.x, re.y, ri.x, ri.z);
+                kid(S1, S0, re.y, re.x, ri.y, ri.w);
+                have = ri.x == j - 1 || ri.y == j - 1;
             };
-            kid(S0, S1, re.x, re.y, ri.x, ri.z);
-            kid(S1, S0, re.y, re.x, ri.y, ri.w);
+            BlkOps oa, ob;
+            fetch(w_ri[wn - 1], w1 - 1, have, oa);
+            int k = wn - 1;
+            for (; k >= 1; k -= 2) {
+                step(k, oa, ob);
+                step(k - 1, ob, oa);
+            }
+            if (k == 0) step(0, oa, ob);
         }
         if (in) {  // slot 0 of the tile: key, x1, x2, err, e, (x1 is the int 0, edge)
             double *b = a.pool + (int64_t)tile.w * 384 + lane;
@@ -1171,7 +1278,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_finish(BlockArgs a) {
 // block roots in the observation lists
 int launch_blocks_up(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
     const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    const dim3 grid((unsigned)(cus * 4)), block(APPLES_TPB);
+    const dim3 grid((unsigned)(cus * 6)), block(APPLES_TPB);  // (74 registers: six wavefronts per SIMD)
     HIP_TRY(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int32_t), st));
     switch (a.method) {
         case APPLES_FM: hipLaunchKernelGGL((k_blocks_up<APPLES_FM>), grid, block, 0, st, a); break;
@@ -1186,7 +1293,7 @@ int launch_blocks_up(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
 // ... and after the sweep above the blocks: the top-down pass inside them, then the queries' placements
 int launch_blocks_down(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
     const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    const dim3 grid((unsigned)(cus * 3)), block(APPLES_TPB);
+    const dim3 grid((unsigned)(cus * 2)), block(APPLES_TPB);  // (186 registers: two wavefronts per SIMD)
     HIP_TRY(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int32_t), st));
     switch (a.method) {
         case APPLES_FM: hipLaunchKernelGGL((k_blocks_down<APPLES_FM>), grid, block, 0, st, a); break;

@@ -437,7 +437,8 @@ def other_workload(name, device, steps=3, ds=None, queries=0):
             'roofline': {k: (None if k == 'traffic' and queries else rf[k])
                          for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'traffic') if k in rf},
             'mean_observed': float(np.mean(out['n_obs'])), 'placed': int((out['n_valid'] > 0).sum()),
-            **({'n_reps': int(info['n_reps']), 'cluster_fused': int(info.get('cluster_fused', 0))} if clustered else {})}
+            **({'n_reps': int(info['n_reps']), 'cluster_fused': int(info.get('cluster_fused', 0)),
+                'cluster_blocks': int(info.get('cluster_blocks', 0))} if clustered else {})}
 
 
 def load_traffic(workload, kernel):
