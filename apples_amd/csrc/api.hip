@@ -546,7 +546,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         }
         // clustered reference (the default route of -p): the representatives' rows in representative order for the fused selection
         // by representatives (select.hip: k_select_clusters around k_cluster_dist_sd)
-        if (!a.all_singleton && a.n_refs <= SELECT_CLUSTERS_MAX_SLOTS && !getenv("APPLES_NO_CLUSTER_FUSE"))
+        if (!a.all_singleton && a.n_refs <= SELECT_CLUSTERS_MAX_SLOTS && !(ctx->dbg & APPLES_DBG_NO_FUSE))
             if (launch_build_cluster_panels_aa(ctx)) return 1;
     } else {
         int *d_exotic = nullptr;
@@ -579,7 +579,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         }
         // clustered reference on the ACGT- fast path: panels for the fused selection by representatives
         if (!a.all_singleton && a.planes == 2 && a.n_refs <= SELECT_CLUSTERS_MAX_SLOTS && a.G <= 64 &&
-            !getenv("APPLES_NO_CLUSTER_FUSE") && dist_mfma_enabled())
+            !(ctx->dbg & APPLES_DBG_NO_FUSE) && dist_mfma_enabled())
             if (launch_build_cluster_panels(ctx)) return 1;
     }
     return 0;

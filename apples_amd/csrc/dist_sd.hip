@@ -18,7 +18,8 @@
 //     sites left to right, the same table in LDS: the same bits), applies the real test 0 <= d <= f and closes the
 //     segments up in place.  k_select_fast then sees what k_scoredist<MODE 1> would have written.
 //
-// Queries left with fewer than `-b` survivors take the top-up rule on full rows (k_scoredist listed mode), as before.
+// Queries left with fewer than `-b` survivors take the top-up rule on rows of the same lower bounds (k_sd_gemm<ROWS>) with exact
+// distances only where the `-b` nearest can be (k_sd_topup below); full rows (k_scoredist listed mode) behind APPLES_DBG_NO_SD_TOPUP.
 #include <cmath>
 #include <cstdlib>
 

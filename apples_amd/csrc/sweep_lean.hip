@@ -1301,7 +1301,6 @@ int launch_blocks_down(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
         case APPLES_BE: hipLaunchKernelGGL((k_blocks_down<APPLES_BE>), grid, block, 0, st, a); break;
         default: hipLaunchKernelGGL((k_blocks_down<APPLES_OLS>), grid, block, 0, st, a); break;
     }
-    if (!getenv("APPLES_BLK_SKIP_FINISH"))  // (debug)
     hipLaunchKernelGGL(k_blocks_finish, dim3((unsigned)((a.nq + APPLES_TPB / WAVE - 1) / (APPLES_TPB / WAVE))), block, 0, st, a);
     HIP_TRY(ctx, hipGetLastError());
     return 0;

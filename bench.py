@@ -44,6 +44,7 @@ os.environ.setdefault('OPENBLAS_NUM_THREADS', '1')
 os.environ.setdefault('MKL_NUM_THREADS', '1')
 
 import argparse  # noqa: E402
+import zlib  # noqa: E402
 import json  # noqa: E402
 import sys  # noqa: E402
 import time  # noqa: E402
@@ -686,6 +687,8 @@ def main():
                        'n_ref': n_leaves, 'L': L, 'queries_this_rank': nq, 'queries_total': total_q, 'method': method,
                        'mean_observed': float(np.mean(mine['n_obs'])), 'mean_swept_nodes': mean_v,
                        'placed': int(placed.sum()), 'parallelism': 'query-sharded x%d' % world,
+                       # every placement struct of the job as rank 0 holds them after the gather (strong scaling: the same bytes at any N)
+                       'placements_crc32': zlib.crc32(np.ascontiguousarray(out).tobytes()),
                        'gather': ('librccl via ctypes (no PyTorch)' if comm is not None else 'torch.distributed nccl') if use_dist else None},
             'roofline': roofline,
             'resident': {'value': world * nq / (dt_res / args.steps), 'ms_per_step': res_ms, 'unit': 'queries/s',

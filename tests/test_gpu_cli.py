@@ -125,6 +125,34 @@ def test_bench_multi_rank_path_on_one_gpu(scaling):
     assert line['config']['placed'] > 0
 
 
+def _device_count():
+    import ctypes
+    try:
+        hip = ctypes.CDLL('libamdhip64.so')
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+def test_bench_two_ranks_when_two_gpus():
+    """`bench.py --gpus 2` the way a user starts it (apples_amd/launcher.py: one process per GPU, the grouped ncclSend / ncclRecv
+    of apples_amd/rccl.py between two real peers) against the same job on one rank: the same placement bytes on rank 0.
+    Arms itself on the first box with two devices; this pool's boxes have one (skipped there)."""
+    if _device_count() < 2:
+        pytest.skip('needs two visible GPUs')
+    crc = {}
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '1', '--workload',
+                            'small', '--no-cpu', '--no-extras', '--scaling', 'strong', '--gather', 'rccl'],
+                           capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line['n_gpus'] == n and line['config']['queries_total'] == 2048
+        crc[n] = line['config']['placements_crc32']
+    assert crc[1] == crc[2]
+
+
 def test_cli_reference_alignment_with_rows_beyond_the_tree(tmp_path):
     """-s holds three rows that are not backbone leaves, -x the extended alignment: the reference
     (fixture g7_cli_aln_superset.jplace, written by its own run_apples.py) never compares those rows

@@ -510,3 +510,35 @@ def test_top_up_list_walked_in_slices(c2_full):
     co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', threshold=0.01, baseobs=30, lut=jc69_lut(1000, 0.001),
                  threads=len(os.sched_getaffinity(0)))
     assert got[sample].tobytes() == co.place_sequences(d.query_seqs[sample]).tobytes()
+
+
+def test_clade_blocks_with_a_pool_that_runs_dry_and_with_own_rows(monkeypatch):
+    """The clustered route's clade blocks (whole subtrees of one cluster swept on a static schedule, sweep_lean.hip: k_blocks_up /
+    k_blocks_down): a pool of 1 MB holds the tuples of a few tiles only -- the others' queries take those leaves one by one --,
+    every query is a backbone leaf's own sequence once (its row is deleted, apples/PoolQueryWorker.py:63-66: the block that holds
+    it is not whole), and a few queries equal a reference row (exact match inside a block).  Same bytes as without blocks."""
+    from apples_amd import treecluster
+    from apples_amd.fasta import Alignment
+    from apples_amd.reference import ReducedReference
+    d = synth.make_dataset(6000, 400, 700)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ca = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, 0.24)).cluster_arrays()
+    q = d.query_seqs.copy()
+    self_rows = np.full(len(q), -1, np.int32)
+    q[100:400] = d.ref_seqs[1000:1300]
+    self_rows[100:400] = np.arange(1000, 1300)       # leave-one-out: the query is this reference row
+    q[400:410] = d.ref_seqs[2000:2010]               # exact matches
+    want = None
+    for pool_mb, dbg in ((None, ('no_blocks',)), (None, ()), ('1', ())):
+        if pool_mb:
+            monkeypatch.setenv('APPLES_BLK_POOL_MB', pool_mb)
+        eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='FM', debug=dbg)
+        got = eng.place_sequences(q, self_rows)
+        info = eng.describe()
+        eng.close()
+        assert (info['cluster_blocks'] > 0) == (dbg == ())
+        if want is None:
+            want = got
+        else:
+            assert got.tobytes() == want.tobytes(), (pool_mb, dbg)
+    assert (want['flags'][400:410] & 1).all()  # F_EXACT

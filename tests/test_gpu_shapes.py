@@ -297,7 +297,7 @@ def test_exotic_symbols_in_a_later_chunk_of_a_streamed_block():
 
 
 def test_scan_sweep_at_c3_shape_and_on_a_deep_tree(monkeypatch):
-    """The scan formulation of the sweep (APPLES_SWEEP_SCAN=1: id-sorted leaves, Euler-tour lowest common
+    """The scan formulation of the sweep (the sweep_scan switch: id-sorted leaves, Euler-tour lowest common
     ancestors, prefix counts instead of a node map) returns the level loop's bytes at the 200 000-leaf
     shape; a tree deeper than its 254-level tables (a caterpillar) quietly keeps the level loop."""
     from apples_amd.tree import parse_newick
@@ -307,8 +307,7 @@ def test_scan_sweep_at_c3_shape_and_on_a_deep_tree(monkeypatch):
     assert eng.describe()['sweep'] == 'levels'
     want = eng.place_sequences(d.query_seqs)
     eng.close()
-    monkeypatch.setenv('APPLES_SWEEP_SCAN', '1')
-    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS', debug=('sweep_scan',))
     assert eng.describe()['sweep'] == 'scan'
     got = eng.place_sequences(d.query_seqs)
     eng.close()
@@ -369,8 +368,7 @@ def test_clustered_route_fused_by_representatives_against_c_oracle(thr, b, monke
     got = eng.place_sequences(q)
     eng.close()
     assert got.tobytes() == want.tobytes()
-    monkeypatch.setenv('APPLES_NO_CLUSTER_FUSE', '1')
-    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', threshold=thr, baseobs=b)
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', threshold=thr, baseobs=b, debug=('no_fuse',))
     unfused = eng.place_sequences(q, self_rows)
     eng.close()
     assert unfused.tobytes() == want.tobytes()
@@ -386,8 +384,7 @@ def test_clustered_route_at_c3_shape(monkeypatch):
     eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS')
     got = eng.place_sequences(d.query_seqs)
     eng.close()
-    monkeypatch.setenv('APPLES_NO_CLUSTER_FUSE', '1')
-    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS')
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', debug=('no_fuse',))
     unfused = eng.place_sequences(d.query_seqs[:600])
     eng.close()
     assert unfused.tobytes() == got[:600].tobytes()
@@ -401,9 +398,8 @@ def test_clustered_route_at_c3_shape(monkeypatch):
 def test_scoredist_fused_threshold_compaction_equals_full_rows(thr, b):
     """scoredist with singleton clusters keeps, like JC69, only the entries inside the threshold in the
     distance kernel's epilogue; queries that need the top-up rule get full rows (listed mode).  Same bytes as
-    the unfused route (APPLES_NO_FUSE=1: full rows + general selection); edges and counts equal to the C
+    the unfused route (the no_fuse switch: full rows + general selection); edges and counts equal to the C
     oracle's, lengths within 1e-9."""
-    import subprocess
     d = synth.make_dataset(5000, 300, 900, protein=True)
     q = d.query_seqs.copy()
     q[3] = d.ref_seqs[11]
@@ -412,16 +408,10 @@ def test_scoredist_fused_threshold_compaction_equals_full_rows(thr, b):
     eng = Engine(d.tree, d.ref_seqs, nodes, protein=True, method='FM', threshold=thr, baseobs=b)
     got = eng.place_sequences(q)
     eng.close()
-    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
-            "from apples_amd import synth\nfrom apples_amd.engine import Engine\n"
-            "d = synth.make_dataset(5000, 300, 900, protein=True)\n"
-            "q = d.query_seqs.copy(); q[3] = d.ref_seqs[11]; q[4] = ord('-')\n"
-            "nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)\n"
-            "e = Engine(d.tree, d.ref_seqs, nodes, protein=True, method='FM', threshold=%r, baseobs=%d)\n"
-            "sys.stdout.buffer.write(e.place_sequences(q).tobytes())\n" % (ROOT, thr, b))
-    r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=dict(os.environ, APPLES_NO_FUSE='1'), timeout=900)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
-    assert r.stdout == got.tobytes()
+    e2 = Engine(d.tree, d.ref_seqs, nodes, protein=True, method='FM', threshold=thr, baseobs=b, debug=('no_fuse',))
+    unfused = e2.place_sequences(q)
+    e2.close()
+    assert unfused.tobytes() == got.tobytes()
     want = COracle(d.tree, d.ref_seqs, nodes, protein=True, method='FM', threshold=thr, baseobs=b, threads=NTHREADS).place_sequences(q)
     for f in ('edge', 'flags', 'n_obs', 'n_valid'):
         assert np.array_equal(got[f], want[f]), f
