@@ -1477,8 +1477,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             if (launch_select_clusters(ctx, sa, nq)) return 1;
             // queries whose accepted clusters hold fewer than -b valid distances: the top-up rule over the representatives
             // (phase 4 of k_select_clusters); what that cannot hold: full rows + general selection
-            // (scoredist: no phase 4 yet -- its listed queries take the general route)
-            const bool no_listed = csd || (ctx->dbg & APPLES_DBG_NO_CLUSTER_TOPUP) != 0;  // diagnostic switch: everything through the general route
+            const bool no_listed = (ctx->dbg & APPLES_DBG_NO_CLUSTER_TOPUP) != 0;  // diagnostic switch: everything through the general route
             int32_t *fwd_list = w.slow_list + 2 * w.batch, *fwd_count = w.cls_count + 20;
             if (!no_listed) {
                 sa.rep_panel = a.rep_packed; sa.slow2_list = fwd_list; sa.slow2_count = fwd_count;

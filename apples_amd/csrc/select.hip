@@ -646,6 +646,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     __shared__ int sh_j[NW < 8 ? 8 : NW];
     __shared__ double sh_d[NW < 8 ? 8 : NW];
     __shared__ uint4 sh_q[(PHASE == 0 || PHASE == 4) ? 64 * 3 : 1];
+    __shared__ double sh_T[PHASE == 4 ? 21 * 21 : 1];  // scoredist contexts: the table (phase 4 forms member distances itself)
     __shared__ int sh_rep[ACC_CAP];
     __shared__ int sh_off[ACC_CAP + 1];
     __shared__ int sh_mb[ACC_CAP];  // first member (index into mem_slot / the cluster-major panel) of every accepted cluster
@@ -688,13 +689,44 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
         if (tid == 0) a.slow2_list[atomicAdd(a.slow2_count, 1)] = (int32_t)q;
     };
     if (PHASE == 4 && (a.qhint[blockIdx.x] < 0 || !a.rep_cache)) { forward(); return; }
-    if (PHASE == 0 || PHASE == 4) {
+    const bool sd = PHASE == 4 && a.aa_idx != nullptr;  // scoredist context
+    if ((PHASE == 0 || PHASE == 4) && !sd) {
         // the query's packed words (tile layout of pack.hip: [(q/16)*G + g][q%16][plane])
         for (int i = tid; i < G * 3; i += TPB) {
             const int g = i / 3, pl = i % 3;
             sh_q[i] = a.qpacked[(((q >> 4) * G + g) * 16 + (q & 15)) * 3 + pl];
         }
     }
+    if (sd)
+        for (int i = tid; i < 21 * 21; i += TPB) sh_T[i] = a.table[i];
+    // scoredist of the query and the reference row in `slot`: the arithmetic of k_scoredist (dist.hip: fp64, sites left to right,
+    // the table in LDS -- the same bits); the query's residues are the same for every lane (one table row per site)
+    auto sd_dist = [&](int64_t slot) -> double {
+        const char *Tb = reinterpret_cast<const char *>(sh_T);
+        const int n16 = a.Lpad / 16;
+        double tot = 0.0;
+        uint32_t nv = 0;
+        for (int s16 = 0; s16 < n16; ++s16) {
+            const uint4 rw = *reinterpret_cast<const uint4 *>(a.aa_idx + ((int64_t)s16 * a.stride + slot) * 16);
+            const uint32_t rmask = a.aa_mask[(int64_t)s16 * a.stride + slot];
+            const uint4 qw = *reinterpret_cast<const uint4 *>(a.q_aa + q * (int64_t)a.Lpad + s16 * 16);
+            nv += __popc(rmask & (uint32_t)a.q_aam[q * (int64_t)n16 + s16]);
+            const uint32_t rr[4] = {rw.x, rw.y, rw.z, rw.w}, qq[4] = {qw.x, qw.y, qw.z, qw.w};
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t r8 = (rr[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                const uint32_t qrow = ((qq[k >> 2] >> (8 * (k & 3))) & 0xffu) * 168u;
+                v[k] = *reinterpret_cast<const double *>(Tb + qrow + r8);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tot += v[k];
+        }
+        if (nv == 0 || (double)nv / (double)a.L < a.overlap) return -1.0;
+        const double r1 = 1 - tot / (double)nv;
+        if (0 >= r1) return -1.0;
+        return -log(r1) * 1.3;
+    };
     if (PHASE == 0 || PHASE >= 3)
         for (int i = tid; i < n_words; i += TPB) dyn_bits[i] = 0;
     // a member's (or representative's) distance from its words: word (g, plane) at base[(g * 3 + plane) * stride] -- the
@@ -728,7 +760,8 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
         __syncthreads();  // sh_q
         for (int64_t j0 = 0; j0 < a.n_reps; j0 += TPB) {
             const int64_t j = j0 + tid;
-            const double d = j < a.n_reps ? by_query(a.rep_panel + j, a.rep_stride) : -1.0;
+            // (scoredist: the full rows of the representative pass hold them)
+            const double d = j < a.n_reps ? (sd ? a.rep_dist[q * a.rep_stride + j] : by_query(a.rep_panel + j, a.rep_stride)) : -1.0;
             if (j < a.n_reps) reprow[j] = d;
             const int in = j < a.n_reps && d >= 0 && d <= a.thr;
             int tot;
@@ -825,7 +858,8 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
                 const int mid = (lo + hi) >> 1;
                 if (sh_off[mid] <= m) lo = mid; else hi = mid;
             }
-            const double d = by_query(a.packed_rm + (int64_t)sh_mb[lo] * (G * 3) + (m - sh_off[lo]), sh_off[lo + 1] - sh_off[lo]);
+            const double d = sd ? sd_dist(a.mem_slot[sh_mb[lo] + (m - sh_off[lo])])
+                                : by_query(a.packed_rm + (int64_t)sh_mb[lo] * (G * 3) + (m - sh_off[lo]), sh_off[lo + 1] - sh_off[lo]);
             tmp[m] = d;
             c += !(d < 0);
         }
@@ -849,7 +883,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
             if (tid == 0) { sh_rep[n_acc_all] = bi; sh_mb[n_acc_all] = mb0; sh_off[n_acc_all + 1] = M + sz; }
             c = 0;
             for (int mp = tid; mp < sz; mp += TPB) {
-                const double d = by_query(a.packed_rm + (int64_t)mb0 * (G * 3) + mp, sz);
+                const double d = sd ? sd_dist(a.mem_slot[mb0 + mp]) : by_query(a.packed_rm + (int64_t)mb0 * (G * 3) + mp, sz);
                 tmp[M + mp] = d;
                 c += !(d < 0);
             }
