@@ -1439,7 +1439,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             ctx->blk_active = a.n_blocks > 0 && !hybrid && !pipelined && !ctx->tree.scan && w.small.lean && w.small.lean_leaf && w.big.lean;
             if (ctx->blk_active) {
                 const int64_t n_items = nq * SELECT_CLUSTERS_ACC_CAP + std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps;
-                const int64_t n_ints = 2 * n_items + 3 * w.batch + 16, n_tiles = n_items / 64 + a.n_reps + 1;
+                const int64_t n_ints = 3 * n_items + 3 * w.batch + 16 + a.n_reps, n_tiles = n_items / 64 + a.n_reps + 1;
                 if (n_ints > ctx->blk_ints_cap) {
                     dev_free(ctx->blk_ints); ctx->blk_ints = nullptr; ctx->blk_ints_cap = 0; ctx->blk_counters = nullptr;
                     if (dev_alloc(ctx, &ctx->blk_ints, n_ints)) return 1;
@@ -1470,6 +1470,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 sa.blk_rec_i = a.blk_rec_i; sa.blk_rec_e = a.blk_rec_e; sa.rep_soff = a.rep_soff; sa.mem_block = a.mem_block;
                 sa.blk_root = a.blk_root; sa.blk_rslot = a.blk_rslot; sa.blk_nodes = a.blk_nodes;
                 sa.e_of_slot = a.e_of_slot; sa.e_of_blk = a.e_of_blk; sa.e_node = a.e_node; sa.lvl_e = a.lvl_e; sa.n_e = a.n_e;
+                sa.item_bad = bi + 2 * n_items + 3 * w.batch + 16; sa.cl_bbase = sa.item_bad + n_items;
                 sa.blk_pool = ctx->blk_pool; sa.blk_pool_cap = ctx->blk_pool_cap;
                 sa.blk_tiles = ctx->blk_tiles; sa.blk_tiles_cap = ctx->blk_tiles_cap;
                 sa.method = ctx->params.method;
@@ -1609,6 +1610,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         if (feed && feed_rest(i)) return 1;  // (a route that did not ask for the second piece itself: nothing left behind)
         if (!swept_here) {
             HIP_TRY(ctx, hipEventRecord(e[3], back));
+            if (cfused && ctx->blk_active) HIP_TRY(ctx, hipStreamWaitEvent(back, ctx->ev_blk[1], 0));  // the blocks' tuples (k_blocks_up on stream_big)
             if (run_sweep(ctx, qb.out + q0, nq, back)) return 1;
             if (cfused && ctx->blk_active) {  // the top-down pass inside the clade blocks, then the better of the two placements
                 const int64_t n_items = nq * SELECT_CLUSTERS_ACC_CAP + std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps;
@@ -1617,7 +1619,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 b.tiles = ctx->blk_tiles; b.n_tiles = bi + 2 * n_items + 3 * w.batch + 2; b.items = ctx->cl_items;
                 b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos;
                 b.self_slot = qb.self_slot + q0; b.tmp_d = w.dist; b.stride = a.slots_pad; b.pool = ctx->blk_pool;
-                b.item_sbase = bi; b.q_item = bi + n_items; b.q_items = reinterpret_cast<const int2 *>(bi + 2 * n_items);
+                b.item_sbase = bi; b.item_bad = bi + 2 * n_items + 3 * w.batch + 16;
+                b.q_item = bi + n_items; b.q_items = reinterpret_cast<const int2 *>(bi + 2 * n_items);
                 b.q_blk = bi + 2 * n_items + 2 * w.batch; b.cursor = bi + 2 * n_items + 3 * w.batch + 1;
                 b.method = ctx->params.method; b.criterion = ctx->params.criterion; b.negative = ctx->params.negative_branch;
                 b.out = qb.out + q0; b.nq = nq;
@@ -1712,6 +1715,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         hipEventCreateWithFlags(&ctx->ev_bigfree, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_cl[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_cl[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_blk[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_blk[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_sel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_top[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_top[1], hipEventDisableTiming) != hipSuccess ||
@@ -1869,6 +1874,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     }
     if (ctx->ev_bigfree) (void)hipEventDestroy(ctx->ev_bigfree);
     for (auto &e : ctx->ev_cl) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_blk) if (e) (void)hipEventDestroy(e);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream_big) (void)hipStreamDestroy(ctx->stream_big);
     if (ctx->ev_sel) (void)hipEventDestroy(ctx->ev_sel);

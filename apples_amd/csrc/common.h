@@ -267,6 +267,7 @@ struct apples_ctx {
     hipStream_t stream_big = nullptr; // the workgroup-sized sweep teams of a batch, beside sweep_lean.hip's wavefront-sized ones
     hipEvent_t ev_front[2] = {}, ev_back[2] = {}, ev_bigfree = nullptr;
     hipEvent_t ev_cl[2] = {};        // clustered fast path: the few-query second form of its last phase runs beside the first on stream2
+    hipEvent_t ev_blk[2] = {};       // clade blocks: k_blocks_up runs on stream_big beside the selection's last phase (distances ready / tuples ready)
     std::string err;
     std::string desc;
     apples_params params{};
@@ -445,7 +446,10 @@ struct SelectArgs {
     int4 *blk_tiles; int64_t blk_tiles_cap; int32_t *blk_ntiles;
     int32_t *q_blk;           // [nq] 1: the query's observation list names block roots (k_blocks_down / k_blocks_finish serve it)
     int32_t *item_sbase;      // [items] first slot of the item's tile in blk_pool x 64 + the item's lane (slot s, component x, lane l at
-                              // ((base + s) * 6 + x) * 64 + l); -1: no blocks for the item
+                              // ((base + s) * 6 + x) * 64 + l); -1: no room in the pool / no blocks in the cluster (phase 2)
+    int32_t *item_bad;        // [items] 1: a member the reference drops, the query's own row or an exact match among the cluster's
+                              // members -- the item goes without blocks (k_cluster_dist)
+    int32_t *cl_bbase;        // [n_reps] first slot of the cluster's tiles in the pool, -1: the cluster has no blocks (k_cluster_tiles)
     int2 *q_items;            // [nq] {first entry of q_item, accepted clusters}
     int32_t *q_item;          // [items] the queries' items, a query's in the order of its accepted clusters
     int32_t *q_item_cursor;   // [1]
@@ -524,7 +528,7 @@ struct BlockArgs {
     const double *tmp_d; int64_t stride;        // the queries' rows of member distances
     double *pool;                               // [slot][6][64 lanes]; a tile's slot 0: the lanes' best edges inside the blocks (key, x1, x2,
                                                 // err, e, (x1 is the int 0, edge)), its slots 1 ..: the tuples of the cluster's block-internal nodes
-    int32_t *item_sbase;                        // [items] first slot x 64 + lane, -1: the item goes without blocks
+    const int32_t *item_sbase, *item_bad;       // [items] first slot x 64 + lane (-1: none); 1: the item goes without blocks
     const int32_t *q_blk; const int2 *q_items; const int32_t *q_item;
     int32_t *cursor;
     int method, criterion, negative;

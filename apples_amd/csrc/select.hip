@@ -829,9 +829,17 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
         }
         for (int k = tid; k < n_acc; k += TPB) {
             const int c = sh_rep[k];
-            const int item = a.cl_start[c] + atomicAdd(&a.cl_fill[c], 1);
+            const int pos = atomicAdd(&a.cl_fill[c], 1), item = a.cl_start[c] + pos;
             a.cl_items[item] = make_int2((int)q, sh_off[k]);
-            if (a.q_items) { a.q_item[sh_znode + k] = item; a.item_sbase[item] = -1; }  // (no blocks until k_blocks_up says otherwise: a cluster without any has no tile)
+            if (a.q_items) {
+                // where the tuples of the cluster's blocks will be for this query: tile pos / 64 of the cluster, lane pos % 64
+                // (k_cluster_tiles: 1 + ns + ceil(size / 6) slots per tile from the cluster's base; -1: no blocks, no room)
+                const int bb = a.cl_bbase[c], ns = a.rep_soff[c + 1] - a.rep_soff[c];
+                const int ts = 1 + ns + (a.rep_moff[c + 1] - a.rep_moff[c] + 5) / 6, tb = bb + (pos >> 6) * ts;
+                a.q_item[sh_znode + k] = item;
+                a.item_sbase[item] = (bb >= 0 && (int64_t)(tb + ts) * 384 <= a.blk_pool_cap) ? tb * 64 + (pos & 63) : -1;
+                a.item_bad[item] = 0;
+            }
         }
         return;
     }
@@ -842,7 +850,11 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
         const int2 qi = a.q_items[q];
         int any = 0;
         for (int k = tid; k < n_acc; k += TPB) {
-            const int sb = k < qi.y ? a.item_sbase[a.q_item[qi.x + k]] : -1;
+            int sb = -1;
+            if (k < qi.y) {
+                const int item = a.q_item[qi.x + k];
+                sb = a.item_bad[item] ? -1 : a.item_sbase[item];
+            }
             sh_sb[k] = sb;
             any |= sb >= 0;
         }
@@ -1139,6 +1151,7 @@ __global__ __launch_bounds__(CL_TILES_TPB) void k_cluster_tiles(SelectArgs a) {
             // tuples; then the members' distances once more as [member][lane], six rows to a slot: what the walks read whole rows of)
             const int ts = c < a.n_reps ? 1 + ns + (a.rep_moff[c + 1] - a.rep_moff[c] + 5) / 6 : 0;
             const int at_s = bslot_base + block_excl_scan_int<CL_TILES_TPB / WAVE>(nb * ts, sh_i, &tot_s);
+            if (c < a.n_reps) a.cl_bbase[c] = ns > 0 ? at_s : -1;  // (phase 2 derives every item's place from it)
             for (int k = 0; k < nb; ++k)
                 if (at_b + k < a.blk_tiles_cap)
                     a.blk_tiles[at_b + k] = make_int4((int)c, at_i + k * 64, cnt - k * 64 < 64 ? cnt - k * 64 : 64,
@@ -1214,8 +1227,12 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist(SelectArgs a) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int j = jl + k * QL;
-                    if (j < nqt)
-                        a.tmp_d[(int64_t)sh_q[j] * a.stride + sh_o[j] + mc0 + ml] = a.seg_lut[(int64_t)nv[k] * (nv[k] + 1) / 2 + nmis[k]];
+                    if (j < nqt) {
+                        const double d = a.seg_lut[(int64_t)nv[k] * (nv[k] + 1) / 2 + nmis[k]];
+                        a.tmp_d[(int64_t)sh_q[j] * a.stride + sh_o[j] + mc0 + ml] = d;
+                        // clade blocks: a member the reference drops, an exact match or the query's own row -- the item goes without
+                        if (a.item_bad && (!(d > 0) || (a.self_slot && a.mem_slot[mb + mc0 + ml] == a.self_slot[sh_q[j]]))) a.item_bad[tile.y + j] = 1;
+                    }
                 }
             }
         }
@@ -1298,6 +1315,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist_sd(SelectArgs a) {
                         else d = -log(r1) * 1.3;
                     }
                     a.tmp_d[qi[k] * a.stride + sh_o[j] + m] = d;
+                    if (a.item_bad && (!(d > 0) || (a.self_slot && slot == a.self_slot[qi[k]]))) a.item_bad[tile.y + j] = 1;  // (as k_cluster_dist)
                 }
             }
         }
@@ -1340,8 +1358,14 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         BlockArgs b{};
         b.tiles = a.blk_tiles; b.n_tiles = a.blk_ntiles; b.items = a.cl_items; b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e;
         b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos; b.self_slot = a.self_slot; b.tmp_d = a.tmp_d;
-        b.stride = a.stride; b.pool = a.blk_pool; b.item_sbase = a.item_sbase; b.cursor = a.q_item_cursor + 1; b.method = a.method;
-        if (launch_blocks_up(ctx, b, ctx->stream)) return 1;
+        b.stride = a.stride; b.pool = a.blk_pool; b.item_sbase = a.item_sbase; b.item_bad = a.item_bad; b.cursor = a.q_item_cursor + 1; b.method = a.method;
+        // ... on the sweep's side stream, beside the last phase (a bandwidth-bound kernel beside a latency-bound one: 1.3 of the 1.8 ms
+        // of a 20 000-query batch at config 3's size disappear).  Which items go without blocks is k_cluster_dist's finding
+        // (item_bad), where their tuples will be phase 2's arithmetic: the last phase needs nothing of this kernel
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[0], ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_big, ctx->ev_blk[0], 0));
+        if (launch_blocks_up(ctx, b, ctx->stream_big)) return 1;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[1], ctx->stream_big));
     }
     // the second form's last phase beside the first's, on the spare stream: a hundred-odd workgroups of 1 024 threads (their
     // rounds of member lookups are what such a workgroup takes: a quarter of the rounds of 256 threads) leave the chip idle

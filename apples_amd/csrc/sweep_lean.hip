@@ -1037,16 +1037,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
         const bool in = lane < nqt;
         const int item = tile.y + (in ? lane : 0);
         const int2 it = a.items[item];
-        if (tile.w < 0) {  // no room in the pool: the tile's queries take these leaves one by one
-            if (in) a.item_sbase[item] = -1;
-            continue;
-        }
+        if (tile.w < 0) continue;  // no room in the pool: the tile's queries take these leaves one by one (phase 2 told them)
+        // (which of the tile's items go without blocks -- a member the reference drops, an exact match, the query's own row -- is
+        // k_cluster_dist's finding, item_bad: this kernel forms every lane's tuples, so that it can run beside the selection's last phase)
         const int64_t q = it.x;
         const double *dbase = a.tmp_d + q * a.stride + it.y;
-        // the query's own row as a member position of this cluster (-1: not in it): a block that holds it is not whole
-        // (apples/PoolQueryWorker.py:63-66 deletes the entry)
-        const int self = a.self_slot ? a.self_slot[q] : -1;
-        const int self_mp = (self >= 0 && a.slot_rep[self] == c) ? a.slot_mpos[self] : -1;
         const int rb = a.rep_soff[c], ns = a.rep_soff[c + 1] - rb;
         double *pool = a.pool + ((int64_t)tile.w + 1) * 384 + lane;  // (slot 0 of the tile: the lanes' best edges, k_blocks_down)
         // the members' distances as [member][lane] behind the tuples: a lane reads its query's row eight values (a sector) at a
@@ -1062,7 +1057,6 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
             for (int k = 0; k < 8; ++k)
                 if (m0 + k < sz) dT[(int64_t)(m0 + k) * 64] = v[k];
         }
-        bool regular = true;
         // (what a node does not need is read from one place, the same for every lane: a sector, not a row)
         auto fetch = [&](const int4 &ri, int j, BlkOps &o) __attribute__((always_inline)) {
             o.d0 = dT[(int64_t)(ri.x < 0 ? -ri.x - 1 : 0) * 64];
@@ -1096,9 +1090,6 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
                     S0[x] = leaf0 ? L0[x] : (prev0 ? r[x] : o.p0[x]);
                     S1[x] = leaf1 ? L1[x] : r[x];  // (an internal right child is the node before)
                 }
-                // a member the reference drops (Reference.py:150), the query's own row, or an exact match (the selection's
-                // bookkeeping of PoolQueryWorker.py:72-75 wants its leaf): the cluster's item goes without blocks
-                if ((leaf0 && (!(o.d0 > 0) || -ri.x - 1 == self_mp)) || (leaf1 && (!(o.d1 > 0) || -ri.y - 1 == self_mp))) regular = false;
                 const double coef = BME ? 1.0 / (double)2 : 1.0;  // apples/BME.py:20: both children are valid
                 lift<M>(S0, re.x, u);
 #pragma unroll
@@ -1123,7 +1114,6 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
             }
             if (k < wn) step(k, oa, ob);
         }
-        if (in) a.item_sbase[item] = regular ? tile.w * 64 + lane : -1;
     }
 }
 
@@ -1153,7 +1143,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_down(BlockArgs a) {
         const int64_t q = it.x;
         // (a lane whose query goes without blocks -- a member it drops, its own row, a top-up or exact-match query -- computes on
         // whatever the pool holds and writes nothing that is read)
-        const bool mine = in && a.item_sbase[item] >= 0 && a.q_blk[q] == 1;
+        const bool mine = in && a.item_sbase[item] >= 0 && !a.item_bad[item] && a.q_blk[q] == 1;
         if (__ballot(mine) == 0ull) continue;
         const int rb = a.rep_soff[c], ns = a.rep_soff[c + 1] - rb;
         double *pool = a.pool + ((int64_t)tile.w + 1) * 384 + lane;
@@ -1245,8 +1235,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_finish(BlockArgs a) {
     double key = INF_D;
     int v = 0x7fffffff, at = -1;
     for (int k = lane; k < qi.y; k += WAVE) {
-        const int sb = a.item_sbase[a.q_item[qi.x + k]];
-        if (sb < 0) continue;
+        const int item = a.q_item[qi.x + k], sb = a.item_sbase[item];
+        if (sb < 0 || a.item_bad[item]) continue;
         const double *b = a.pool + (int64_t)(sb >> 6) * 384 + (sb & 63);
         const double k2 = b[0];
         const int v2 = __double2loint(b[320]);
@@ -1278,7 +1268,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_finish(BlockArgs a) {
 // block roots in the observation lists
 int launch_blocks_up(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
     const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    const dim3 grid((unsigned)(cus * 6)), block(APPLES_TPB);  // (74 registers: six wavefronts per SIMD)
+    static const int per_cu = getenv("APPLES_BLK_UP_WGS") ? atoi(getenv("APPLES_BLK_UP_WGS")) : 6;  // tuning knob (82 registers: up to five or six wavefronts per SIMD)
+    const dim3 grid((unsigned)(cus * std::max(per_cu, 1))), block(APPLES_TPB);
     HIP_TRY(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int32_t), st));
     switch (a.method) {
         case APPLES_FM: hipLaunchKernelGGL((k_blocks_up<APPLES_FM>), grid, block, 0, st, a); break;
