@@ -496,9 +496,46 @@ __device__ __forceinline__ int64_t lean_queue_at(const SweepArgs &a, const LeanQ
 // needs more than this goes to the workgroup-sized teams.
 __device__ __forceinline__ int lean_query_cap(int n) { return (3 * n + 128 + min(22 * n, 896) + 3) & ~3; }
 
-// Bottom-up kernel of the wavefront-sized teams: level lists and S tuples of one query after the other, into the pool
+// The top-down pass of ONE query of a wavefront-sized team (all_R_values, placement_per_edge, error_per_edge, the arg-min of
+// apples/Algorithm.py:74-91) from what its bottom-up pass left: the pool offset, the number of level groups G and of internal
+// nodes VI, the groups' offsets.  `stage`: the wavefront's LDS area for tuples on their way to a level of at most 64 nodes.
 template <int M>
-__device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh) {
+__device__ __forceinline__ void lean_down_one(const SweepArgs &a, const double *lds_pow, double2 (*stage)[WAVE], int64_t q, int n,
+                                              int64_t off, int G, int VI, int lane) {
+    const DevTree &T = a.tree;
+    const int V = VI + n;  // Subtree.num_nodes
+    LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, off, nullptr, 0, 0);
+    t.BP = a.blk_pool;
+    const int32_t *grp_off = a.grp_off + q * (int64_t)(T.height + 4);
+    LeanBest best;
+    lean_best_init(best);
+    bool hand_in = false;  // this level's lifted R tuples wait in LDS (handed over by the level above)
+    for (int g = G; g >= 1; --g) {
+        const int g0 = grp_off[g], g1 = grp_off[g + 1], k0 = grp_off[g - 1];
+        const int ng = g1 - g0;
+        const bool hand_out = g0 - k0 <= WAVE;  // the children's level has at most 64 nodes: their tuples go through LDS
+        if (ng <= 32) {
+            lean_td_pairs<M>(t, g0, ng, VI, lane, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
+                             hand_out ? stage : nullptr, k0, best);
+        } else {
+            lean_td_chunks<M, false>(t, g0, g1, lane, WAVE, VI, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
+                              hand_out ? stage : nullptr, k0, best);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        hand_in = hand_out;
+    }
+    const int my_best = best.v;
+    double wkey = best.key;
+    int win = best.v;
+    team_argmin<WAVE>(wkey, win, nullptr, nullptr);
+    lean_write_placement(a.out, q, V, win, my_best == win, lane == 0, best);
+}
+
+// Bottom-up kernel of the wavefront-sized teams: level lists and S tuples of one query after the other, into the pool.
+// FUSED (k_lean_both, APPLES_LEAN_FUSED=1): the team runs the query's top-down pass right behind its bottom-up pass -- one launch
+// and one tail per device batch instead of two; measured slower (register spills: launch_sweep_lean), not the default.
+template <int M, bool FUSED = false>
+__device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double *lds_pow = nullptr) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
     LeanWave &L = sh.w[wave];
@@ -676,6 +713,10 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh) {
         }
         // internal valid nodes: base; the LCA's entry sits at that index.  What the top-down kernel needs of this query:
         if (lane == 0) { grp_off[G] = base; grp_off[G + 1] = base + 1; a.lean_meta[q] = make_int4((int)off, G, base, 0); }
+        if (FUSED) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the group offsets and the entries: this wavefront's own writes)
+            if (a.debug_phase != 1) lean_down_one<M>(a, lds_pow, stage, q, n, off, G, base, lane);
+        }
         if (prof) {
             if (lane == 0) {
                 for (int k = 0; k < 4; ++k) { atomicAdd(a.prof + k, pc[k]); pc[k] = 0; }
@@ -714,6 +755,7 @@ __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
         const int4 meta = a.lean_meta[q];
         const int G = meta.y, VI = meta.z;
         if (G < 0) continue;  // handed to the workgroup-sized teams by the bottom-up kernel
+        if (!prof) { lean_down_one<M>(a, lds_pow, stage, q, n, meta.x & 0xffffffffll, G, VI, lane); continue; }
         const int V = VI + n;  // Subtree.num_nodes
         LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, meta.x & 0xffffffffll, nullptr, 0, 0);
         t.BP = a.blk_pool;
@@ -972,6 +1014,20 @@ template <int M>
 __global__ __launch_bounds__(APPLES_TPB, LEAN_UP_WAVES) void k_lean_up(SweepArgs a) {
     __shared__ LeanUpShared sh;
     lean_up_loop<M>(a, sh);
+}
+
+struct LeanBothShared {
+    LeanUpShared up;
+    double pow[384 + 256];  // libm pow tables (sweep_math.h)
+};
+
+template <int M>
+__global__ __launch_bounds__(APPLES_TPB, LEAN_UP_WAVES) void k_lean_both(SweepArgs a) {
+    __shared__ LeanBothShared sh;
+    for (int i = threadIdx.x; i < 384; i += APPLES_TPB) sh.pow[i] = (&kPowLogTab[0][0])[i];
+    for (int i = threadIdx.x; i < 256; i += APPLES_TPB) sh.pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
+    __syncthreads();
+    lean_up_loop<M, true>(a, sh.up, sh.pow);
 }
 
 template <int M>
@@ -1329,6 +1385,21 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
     const dim3 gu((unsigned)std::min<int64_t>(need, wg_up > 0 ? wg_up : cus * LEAN_UP_WAVES * 3 / 2));
     const dim3 gd((unsigned)std::min<int64_t>(need, wg_down > 0 ? wg_down : cus * LEAN_DOWN_WAVES * 3 / 2));
     if ((int64_t)gu.x * 4 > up.lean_teams) { ctx->err = "lean sweep: more bottom-up teams than per-leaf scratch"; return 1; }
+    // APPLES_LEAN_FUSED=1: one kernel for both passes of a query (k_lean_both), the team's top-down pass right behind its bottom-up
+    // pass.  Measured SLOWER than the two kernels in every workload (round 5, scripts/r05_run8.sh: config 3's sweep 15.6 -> 16.7 ms,
+    // config 5's block 1.31 -> 1.44, config 4 2.77 -> 3.05): at three wavefronts per SIMD the fused body spills 85 vector registers
+    // where the bottom-up kernel alone spills 19 and the top-down kernel 8, and the launch it saves is worth less than that.
+    static const bool fused = getenv("APPLES_LEAN_FUSED") != nullptr;  // experiment knob
+    if (fused && !up.prof && up.debug_phase != 1) {
+        switch (up.method) {
+            case APPLES_FM: hipLaunchKernelGGL((k_lean_both<APPLES_FM>), gu, block, 0, st, up); break;
+            case APPLES_BME: hipLaunchKernelGGL((k_lean_both<APPLES_BME>), gu, block, 0, st, up); break;
+            case APPLES_BE: hipLaunchKernelGGL((k_lean_both<APPLES_BE>), gu, block, 0, st, up); break;
+            default: hipLaunchKernelGGL((k_lean_both<APPLES_OLS>), gu, block, 0, st, up); break;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
     switch (up.method) {
         case APPLES_FM: hipLaunchKernelGGL((k_lean_up<APPLES_FM>), gu, block, 0, st, up); break;
         case APPLES_BME: hipLaunchKernelGGL((k_lean_up<APPLES_BME>), gu, block, 0, st, up); break;
