@@ -714,7 +714,7 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
         char *p = nullptr;
         if (dev_alloc(ctx, &p, sw.lean_cap1 * LEAN_BYTES_PER_NODE)) return 1;
         sw.lean = p;
-        if (dev_alloc(ctx, &p, 2 * sw.teams * sw.lean_leaf1 * LEAN_BYTES_PER_LEAF)) return 1;  // (x 2: run_sweep_second's teams)
+        if (dev_alloc(ctx, &p, 3 * sw.teams * sw.lean_leaf1 * LEAN_BYTES_PER_LEAF)) return 1;  // (x 3: run_sweep_second's teams, the second half's of a small batch)
         sw.lean_leaf = p;
         if (dev_alloc(ctx, &sw.grp_off, batch * (int64_t)(t.height + 4))) return 1;
         if (dev_alloc(ctx, &sw.lean_meta, batch)) return 1;
@@ -1155,7 +1155,14 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_big, ctx->ev_sel, 0));
         SweepArgs down = sm;
         down.cursor = w.cls_count + 11;
-        if (launch_sweep_lean(ctx, sm, down, nq, ctx->stream_big)) return 1;
+        // APPLES_LEAN_HALVES=1: a small device batch takes its queue in two halves, the first half's top-down kernel beside the second
+        // half's bottom-up kernel.  Measured SLOWER (round 5, profiles/r05_lean_halves_exp.txt: config 3's 12 500-query shards 6.6 - 6.8 ->
+        // 7.0 - 7.3 ms, config 5's block 3.28 -> 3.74, config 2 2.38 -> 2.77): four short launches have four tails.  Off by default.
+        static const bool want_halves = getenv("APPLES_LEAN_HALVES") != nullptr;  // experiment knob
+        const bool halves = want_halves && nq <= LEAN_SMALL_BATCH && nq >= 2048;
+        if (halves && !ctx->stream3) HIP_TRY(ctx, hipStreamCreate(&ctx->stream3));
+        if (launch_sweep_lean(ctx, sm, down, nq, ctx->stream_big, halves ? w.cls_count + 22 : nullptr, halves ? ctx->stream3 : nullptr,
+                              ctx->ev_half)) return 1;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_big, ctx->stream_big));
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_big, 0));
     } else if (launch_sweep_mixed(ctx, sm, b, nq, w.small.wgs, w.big.wgs, st)) return 1;
@@ -1715,6 +1722,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         hipEventCreateWithFlags(&ctx->ev_bigfree, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_cl[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_cl[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_half[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_half[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_blk[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_blk[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_sel, hipEventDisableTiming) != hipSuccess ||
@@ -1875,6 +1884,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     if (ctx->ev_bigfree) (void)hipEventDestroy(ctx->ev_bigfree);
     for (auto &e : ctx->ev_cl) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_blk) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_half) if (e) (void)hipEventDestroy(e);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream_big) (void)hipStreamDestroy(ctx->stream_big);
     if (ctx->ev_sel) (void)hipEventDestroy(ctx->ev_sel);

@@ -267,6 +267,7 @@ struct apples_ctx {
     hipStream_t stream_big = nullptr; // the workgroup-sized sweep teams of a batch, beside sweep_lean.hip's wavefront-sized ones
     hipEvent_t ev_front[2] = {}, ev_back[2] = {}, ev_bigfree = nullptr;
     hipEvent_t ev_cl[2] = {};        // clustered fast path: the few-query second form of its last phase runs beside the first on stream2
+    hipEvent_t ev_half[2] = {};      // the lean sweep of a small device batch in two halves (launch_sweep_lean)
     hipEvent_t ev_blk[2] = {};       // clade blocks: k_blocks_up runs on stream_big beside the selection's last phase (distances ready / tuples ready)
     std::string err;
     std::string desc;
@@ -515,6 +516,7 @@ struct SweepArgs {
     const int32_t *cls_count; // [4] class counts
     int64_t cls_stride;
     int32_t *cursor;          // dynamic work queue: teams take the next entry with one atomic add
+    int w_mod, w_rem;         // sweep_lean.hip's wavefront-sized teams: this launch takes the queue entries w with w % w_mod == w_rem (0, 0: all)
     int32_t *overflow_list;   // queries whose subtree exceeded `cap`
     int32_t *overflow_count;
     apples_placement *out;
@@ -569,7 +571,8 @@ int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int t
 #define LEAN_BIG_THRESHOLD 8192  // observed leaves above which a query goes to the lean sweep's workgroup-sized teams
 #define LEAN_MAX_LEVELS 256      // per-level offsets of a query in LDS: trees up to 254 levels
 bool sweep_lean_layout(const DevTree &t, bool per_edge_records);
-int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &down, int64_t nq, hipStream_t st);
+int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &down, int64_t nq, hipStream_t st, int32_t *halves = nullptr,
+                      hipStream_t side = nullptr, hipEvent_t *ev = nullptr);
 int sweep_lean_up_teams(const apples_ctx *ctx);
 int launch_sweep_lean_big(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, hipStream_t st);
 int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs &big, int64_t nq, int wgs, int n_big,

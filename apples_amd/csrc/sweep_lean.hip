@@ -555,7 +555,8 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
         // dynamic scheduling: one atomic add per query, broadcast to the wavefront
         int wq = 0;
         if (lane == 0) wq = atomicAdd(a.cursor, 1);
-        const int64_t w = __builtin_amdgcn_readfirstlane(wq);  // (scalar: the query's pointers and counts then live in SGPRs)
+        int64_t w = __builtin_amdgcn_readfirstlane(wq);  // (scalar: the query's pointers and counts then live in SGPRs)
+        if (a.w_mod > 1) w = w * a.w_mod + a.w_rem;     // (this launch's share of the queue: launch_sweep_lean's halves)
         if (w >= n_work) break;
         const int64_t q = lean_queue_at(a, qu, w);
         const int n = a.n_obs[q];
@@ -747,7 +748,8 @@ __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
     while (true) {
         int wq = 0;
         if (lane == 0) wq = atomicAdd(a.cursor, 1);
-        const int64_t w = __builtin_amdgcn_readfirstlane(wq);  // (scalar: the query's pointers and counts then live in SGPRs)
+        int64_t w = __builtin_amdgcn_readfirstlane(wq);  // (scalar: the query's pointers and counts then live in SGPRs)
+        if (a.w_mod > 1) w = w * a.w_mod + a.w_rem;
         if (w >= qu.n_work) break;
         const int64_t q = lean_queue_at(a, qu, w);
         const int n = a.n_obs[q];
@@ -1375,7 +1377,8 @@ int launch_sweep_lean_big(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int w
 // wavefront-sized teams over the size-class queues of one device batch: the bottom-up kernel, then (unless the timing
 // knob says bottom-up only) the top-down kernel, each a persistent grid of the workgroups its registers let a CU hold
 // (x 1.5: a second round shortens the tail).  `up` / `down` differ in their work cursor only.
-int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &down, int64_t nq, hipStream_t st) {
+int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &down, int64_t nq, hipStream_t st, int32_t *halves,
+                      hipStream_t side, hipEvent_t *ev) {
     if (nq == 0) return 0;
     const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
     static const int wg_up = getenv("APPLES_LEAN_UP_WGS") ? atoi(getenv("APPLES_LEAN_UP_WGS")) : 0;      // tuning knobs
@@ -1400,20 +1403,47 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     }
-    switch (up.method) {
-        case APPLES_FM: hipLaunchKernelGGL((k_lean_up<APPLES_FM>), gu, block, 0, st, up); break;
-        case APPLES_BME: hipLaunchKernelGGL((k_lean_up<APPLES_BME>), gu, block, 0, st, up); break;
-        case APPLES_BE: hipLaunchKernelGGL((k_lean_up<APPLES_BE>), gu, block, 0, st, up); break;
-        default: hipLaunchKernelGGL((k_lean_up<APPLES_OLS>), gu, block, 0, st, up); break;
-    }
-    if (up.debug_phase != 1) {
-        switch (down.method) {
-            case APPLES_FM: hipLaunchKernelGGL((k_lean_down<APPLES_FM>), gd, block, 0, st, down); break;
-            case APPLES_BME: hipLaunchKernelGGL((k_lean_down<APPLES_BME>), gd, block, 0, st, down); break;
-            case APPLES_BE: hipLaunchKernelGGL((k_lean_down<APPLES_BE>), gd, block, 0, st, down); break;
-            default: hipLaunchKernelGGL((k_lean_down<APPLES_OLS>), gd, block, 0, st, down); break;
+    auto launch_up = [&](const SweepArgs &x, hipStream_t s_) {
+        switch (x.method) {
+            case APPLES_FM: hipLaunchKernelGGL((k_lean_up<APPLES_FM>), gu, block, 0, s_, x); break;
+            case APPLES_BME: hipLaunchKernelGGL((k_lean_up<APPLES_BME>), gu, block, 0, s_, x); break;
+            case APPLES_BE: hipLaunchKernelGGL((k_lean_up<APPLES_BE>), gu, block, 0, s_, x); break;
+            default: hipLaunchKernelGGL((k_lean_up<APPLES_OLS>), gu, block, 0, s_, x); break;
         }
+    };
+    auto launch_down = [&](const SweepArgs &x, hipStream_t s_) {
+        switch (x.method) {
+            case APPLES_FM: hipLaunchKernelGGL((k_lean_down<APPLES_FM>), gd, block, 0, s_, x); break;
+            case APPLES_BME: hipLaunchKernelGGL((k_lean_down<APPLES_BME>), gd, block, 0, s_, x); break;
+            case APPLES_BE: hipLaunchKernelGGL((k_lean_down<APPLES_BE>), gd, block, 0, s_, x); break;
+            default: hipLaunchKernelGGL((k_lean_down<APPLES_OLS>), gd, block, 0, s_, x); break;
+        }
+    };
+    // A small device batch (a shard of a multi-GPU job, a -d block) leaves most of the chip idle during either kernel -- a team has
+    // three or four queries and a launch lasts as long as its longest: the queue is then taken in two halves (entries of even and
+    // of odd index: both get their share of every size class), and the top-down kernel of the first half runs on `side` beside
+    // the bottom-up kernel of the second.  halves = the two extra work cursors (cleared with the batch's counters), or nullptr.
+    if (halves && side && up.debug_phase != 1 && !up.prof) {
+        SweepArgs u0 = up, u1 = up, d0 = down, d1 = down;
+        u0.w_mod = u1.w_mod = d0.w_mod = d1.w_mod = 2;
+        u1.w_rem = d1.w_rem = 1;
+        u1.cursor = halves; d1.cursor = halves + 1;
+        // (the second bottom-up launch needs per-leaf scratch of its own: the teams of the two launches are alive together)
+        // (the THIRD set of the workspace: the second belongs to the overlapped top-up chain's sweep, api.hip:run_sweep_second)
+        u1.lean_leaf = reinterpret_cast<char *>(up.lean_leaf) + 2 * up.lean_teams * up.lean_leaf1 * LEAN_BYTES_PER_LEAF;
+        launch_up(u0, st);
+        HIP_TRY(ctx, hipEventRecord(ev[0], st));
+        HIP_TRY(ctx, hipStreamWaitEvent(side, ev[0], 0));
+        launch_down(d0, side);
+        HIP_TRY(ctx, hipEventRecord(ev[1], side));
+        launch_up(u1, st);
+        launch_down(d1, st);
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ev[1], 0));
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
     }
+    launch_up(up, st);
+    if (up.debug_phase != 1) launch_down(down, st);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
