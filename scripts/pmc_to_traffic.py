@@ -14,6 +14,7 @@ summ = json.loads(subprocess.check_output([sys.executable, os.path.join(os.path.
 names = {'k_jc69_gemm': 'jc69_distance', 'k_jc69_mfma': 'jc69_distance', 'k_jc69': 'jc69_distance', 'k_scoredist': 'scoredist_distance', 'k_sd_gemm': 'scoredist_filter_gemm', 'k_sd_exact': 'scoredist_exact', 'k_sd_topup': 'scoredist_topup',
          'k_select_fast': 'select_fast',
          'k_select_stream': 'table_select' if workload == 'c5' else 'select', 'k_select_clusters': 'select_clusters', 'k_cluster_dist': 'cluster_dist', 'k_select': 'select',
+         'k_blocks_up': 'blocks_up', 'k_blocks_down': 'blocks_down',
          'k_sweep_mixed': 'lsq_sweep', 'k_sweep<': 'lsq_sweep', 'k_lean_up': 'lsq_sweep_up', 'k_lean_down': 'lsq_sweep_down',
          'k_sweep_lean_big': 'lsq_sweep_big'}
 res = {}
@@ -26,7 +27,7 @@ for k, v in summ.items():
     if key == 'lsq_sweep' and '64>' not in k and v['mean_ns_under_pmc'] < 1e5:
         continue
     fetch, write = v['FETCH_SIZE'] * 1024, v['WRITE_SIZE'] * 1024
-    streaming = not key.startswith('lsq_sweep')
+    streaming = not key.startswith('lsq_sweep')  # (the block kernels read and write whole 512-byte rows: streaming)
     e = {'kernel': k, 'fetch_bytes_raw': fetch, 'write_bytes': write,
          'hbm_bytes_per_launch': (2 * fetch if streaming else fetch) + write,
          'fetch_correction': 'x2 (wide coalesced streaming reads)' if streaming else 'raw (scattered / short runs: uncalibrated; x2 would give %d)' % (2 * fetch + write),
@@ -37,10 +38,10 @@ for k, v in summ.items():
         res[key] = e
 # sweep_lean.hip runs a device batch's sweep as three kernels (bottom-up, top-down, workgroup-sized teams: the last one's
 # figures are the mean over its dispatches, half of which are empty overflow launches -> doubled): one figure for the batch
-parts = [res[k] for k in ('lsq_sweep_up', 'lsq_sweep_down') if k in res]
+parts = [res[k] for k in ('lsq_sweep_up', 'lsq_sweep_down', 'blocks_down') if k in res]  # (clustered route: the sweep phase's timer holds k_blocks_down too)
 if parts and 'lsq_sweep' not in res:
     big = res.get('lsq_sweep_big')
-    res['lsq_sweep'] = {'kernel': 'k_lean_up + k_lean_down + k_sweep_lean_big (per device batch)',
+    res['lsq_sweep'] = {'kernel': 'k_lean_up + k_lean_down + k_sweep_lean_big' + (' + k_blocks_down' if 'blocks_down' in res else '') + ' (per device batch)',
                         'hbm_bytes_per_launch': sum(p_['hbm_bytes_per_launch'] for p_ in parts) + (2 * big['hbm_bytes_per_launch'] if big else 0),
                         'mean_ns_under_pmc': sum(p_['mean_ns_under_pmc'] for p_ in parts) + (2 * big['mean_ns_under_pmc'] if big else 0),
                         'fetch_correction': 'raw', 'note': 'serialised under the counter passes; the three run side by side in the bench'}

@@ -19,8 +19,9 @@ stats c2 --workload c2 --steps 10 --warmup 3
 stats c4 --workload c4 --steps 3 --warmup 1
 stats c5 --workload c5 --steps 5 --warmup 2
 stats c3_clustered --workload c3-clustered --steps 3 --warmup 1
+stats c4_clustered --workload c4-clustered --steps 3 --warmup 1
 cd $R
-for W in c3 c2 c4 c5 c3-clustered; do
+for W in c3 c2 c4 c5 c3-clustered c4-clustered; do
   # (the whole workload: the launch shape -- queries per device batch -- must be the bench's own)
   bash scripts/pmc_traffic_passes.sh $TAG/pmc_$W --workload $W --no-extras --steps 1 --warmup 1 > /dev/null 2>&1
   python scripts/pmc_to_traffic.py gpurun_out/$TAG/pmc_$W $W $OUT/pmc_traffic.json > /dev/null
@@ -39,5 +40,7 @@ python bench.py --workload c2 --steps 20 --warmup 5 2> $OUT/bench_c2.log | tail 
 python bench.py --workload c4 --steps 3 --warmup 1 2> $OUT/bench_c4.log | tail -1 > $OUT/bench_c4.json
 python bench.py --workload c5 --steps 5 --warmup 2 2> $OUT/bench_c5.log | tail -1 > $OUT/bench_c5.json
 python bench.py --workload c3-clustered --steps 3 --warmup 1 --no-cpu 2> $OUT/bench_c3cl.log | tail -1 > $OUT/bench_c3cl.json
-for f in c3 c2 c4 c5 c3cl; do python3 -c "
+python bench.py --workload c4-clustered --steps 3 --warmup 1 --no-cpu 2> $OUT/bench_c4cl.log | tail -1 > $OUT/bench_c4cl.json
+python scripts/r05_hybrid_probe.py > $OUT/hybrid_c3.json 2> $OUT/hybrid_c3.log
+for f in c3 c2 c4 c5 c3cl c4cl; do python3 -c "
 import json; d=json.load(open('$OUT/bench_$f.json')); print('$f', round(d['value']), round(d['ms_per_step'],2), d['roofline']['kernel'], round(d['roofline']['frac'],3), d['roofline'].get('traffic'), d['resident']['per_kernel_ms_per_step'], d.get('cpu_baseline') and round(d['cpu_baseline']['value'],1))"; done
