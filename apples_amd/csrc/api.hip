@@ -401,6 +401,10 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
     if (dev_upload(ctx, &a.blk_rec_i, rec_i.data(), (int64_t)rec_i.size())) return 1;
     if (dev_upload(ctx, &a.blk_rec_e, rec_e.data(), (int64_t)rec_e.size())) return 1;
     if (dev_upload(ctx, &a.rep_soff, rep_soff.data(), (int64_t)rep_soff.size())) return 1;
+    std::vector<int32_t> cl_order((size_t)a.n_reps);
+    std::iota(cl_order.begin(), cl_order.end(), 0);
+    std::stable_sort(cl_order.begin(), cl_order.end(), [&](int32_t x, int32_t y) { return rep_soff[x + 1] - rep_soff[x] > rep_soff[y + 1] - rep_soff[y]; });
+    if (dev_upload(ctx, &a.cl_order, cl_order.data(), a.n_reps)) return 1;
     if (dev_upload(ctx, &a.mem_block, mem_block.data(), (int64_t)mem_block.size())) return 1;
     if (dev_upload(ctx, &a.blk_root, blk_root.data(), n_blocks)) return 1;
     if (dev_upload(ctx, &a.blk_rslot, blk_rslot.data(), n_blocks)) return 1;
@@ -1262,7 +1266,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     hipStream_t front = ctx->stream, back = pipelined ? ctx->stream3 : ctx->stream;
     // timing events come from a pool that lives with the context (creating and destroying a dozen
     // events per call costs host time inside every pass)
-    while (ctx->ev_pool.size() < (size_t)n_sub * 6 + 2) {
+    while (ctx->ev_pool.size() < (size_t)n_sub * 8 + 2) {
         hipEvent_t e;
         HIP_TRY(ctx, hipEventCreate(&e));
         ctx->ev_pool.push_back(e);
@@ -1310,7 +1314,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     HIP_TRY(ctx, hipEventRecord(e_start, front));
     if (pipelined) HIP_TRY(ctx, hipStreamWaitEvent(back, e_start, 0));
     int launches = 0;
-    std::vector<char> sd_filter_timed((size_t)n_sub, 0);  // per sub-batch: e[5] was recorded (the scoredist filter ran there)
+    std::vector<char> sd_filter_timed((size_t)n_sub, 0), blk_timed((size_t)n_sub, 0);  // per sub-batch: e[5] was recorded (the scoredist filter ran there)
     // The queries on the top-up / slow list get full distance rows; a slim workspace holds rows for a slice of the batch
     // only: the list's length comes to the host (one short wait per batch) and the list is walked in slices of that many
     // queries.  fn(list, count pointer, entries at most) runs the listed distance pass + selection for one slice.
@@ -1342,7 +1346,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
         const int set = (int)(i & 1);
         if (pipelined && i > 0) swap_bufs(w);  // host view: w.* now names buffer set `set`
         if (pipelined && i >= 2) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_back[set], 0));  // set free again
-        hipEvent_t *e = &ev[(size_t)i * 6];
+        hipEvent_t *e = &ev[(size_t)i * 8];
         ctx->cur_batch_queries = nq;  // (route_threshold)
         // rows of the chunk's first piece.  Only the first chunk is still on the bus when its kernels could start: chunk i + 1
         // travels while batch i runs and is there, whole, when its turn comes -- one launch then, not two
@@ -1474,7 +1478,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 sa.q_blk = bi + 2 * n_items + 2 * w.batch; sa.q_item_cursor = bi + 2 * n_items + 3 * w.batch; sa.blk_ntiles = sa.q_item_cursor + 2;
                 ctx->blk_counters = sa.q_item_cursor;  // (apples_describe: items and tiles of the last device batch)
                 HIP_TRY(ctx, hipMemsetAsync(bi + 2 * n_items, 0, (size_t)(3 * w.batch + 16) * sizeof(int32_t), front));
-                sa.blk_rec_i = a.blk_rec_i; sa.blk_rec_e = a.blk_rec_e; sa.rep_soff = a.rep_soff; sa.mem_block = a.mem_block;
+                sa.blk_rec_i = a.blk_rec_i; sa.blk_rec_e = a.blk_rec_e; sa.rep_soff = a.rep_soff; sa.mem_block = a.mem_block; sa.cl_order = a.cl_order;
                 sa.blk_root = a.blk_root; sa.blk_rslot = a.blk_rslot; sa.blk_nodes = a.blk_nodes;
                 sa.e_of_slot = a.e_of_slot; sa.e_of_blk = a.e_of_blk; sa.e_node = a.e_node; sa.lvl_e = a.lvl_e; sa.n_e = a.n_e;
                 sa.item_bad = bi + 2 * n_items + 3 * w.batch + 16; sa.cl_bbase = sa.item_bad + n_items;
@@ -1482,7 +1486,10 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 sa.blk_tiles = ctx->blk_tiles; sa.blk_tiles_cap = ctx->blk_tiles_cap;
                 sa.method = ctx->params.method;
             }
+            ctx->ev_blk_time[0] = ctx->blk_active ? e[6] : nullptr;  // (k_blocks_up's timer: launch_select_clusters records the two events
+            ctx->ev_blk_time[1] = ctx->blk_active ? e[7] : nullptr;  // where it launches the kernel and clears the first)
             if (launch_select_clusters(ctx, sa, nq)) return 1;
+            blk_timed[(size_t)i] = ctx->blk_active && ctx->ev_blk_time[0] == nullptr;
             // queries whose accepted clusters hold fewer than -b valid distances: the top-up rule over the representatives
             // (phase 4 of k_select_clusters); what that cannot hold: full rows + general selection
             const bool no_listed = (ctx->dbg & APPLES_DBG_NO_CLUSTER_TOPUP) != 0;  // diagnostic switch: everything through the general route
@@ -1648,8 +1655,13 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     HIP_TRY(ctx, hipEventSynchronize(e_stop));
     for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = 0;
     for (int64_t i = 0; i < n_sub; ++i) {
-        hipEvent_t *e = &ev[(size_t)i * 6];
+        hipEvent_t *e = &ev[(size_t)i * 8];
         float ms = 0;
+        if (blk_timed[(size_t)i]) {
+            float bms = 0;
+            (void)hipEventElapsedTime(&bms, e[6], e[7]);
+            ctx->t_ms[APPLES_T_BLOCKS] += bms;
+        }
         (void)hipEventElapsedTime(&ms, e[0], e[1]); ctx->t_ms[APPLES_T_DIST] += ms;
         if (sd_filter_timed[(size_t)i]) {  // (a sub-batch without the filter adds nothing: T_FILTER = 0 means no filter ran)
             float fms = 0;
@@ -1869,7 +1881,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.rep_soff); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.rep_soff); dev_free(a.cl_order); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

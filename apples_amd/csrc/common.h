@@ -150,6 +150,7 @@ struct DevAlign {
                                   // left / right >= 0: the child's slot, < 0: a leaf, member position -(x + 1) of the cluster's flat member list
     double2 *blk_rec_e = nullptr; // ... and the edge lengths of the two children
     int32_t *rep_soff = nullptr;  // [n_reps + 1] first record of every cluster (records = internal nodes of its blocks)
+    int32_t *cl_order = nullptr;  // [n_reps] the clusters by falling number of records
     int32_t *mem_block = nullptr; // [members] block of the member (index into blk_*) x 2 + (1: the block's first leaf), -1: none
     int32_t *blk_root = nullptr;  // [n_blocks] root node
     int32_t *blk_rslot = nullptr; // [n_blocks] slot of the root inside its cluster
@@ -267,6 +268,7 @@ struct apples_ctx {
     hipStream_t stream_big = nullptr; // the workgroup-sized sweep teams of a batch, beside sweep_lean.hip's wavefront-sized ones
     hipEvent_t ev_front[2] = {}, ev_back[2] = {}, ev_bigfree = nullptr;
     hipEvent_t ev_cl[2] = {};        // clustered fast path: the few-query second form of its last phase runs beside the first on stream2
+    hipEvent_t ev_blk_time[2] = {};  // timing events around k_blocks_up for the device batch under way (run_block's pool)
     hipEvent_t ev_half[2] = {};      // the lean sweep of a small device batch in two halves (launch_sweep_lean)
     hipEvent_t ev_blk[2] = {};       // clade blocks: k_blocks_up runs on stream_big beside the selection's last phase (distances ready / tuples ready)
     std::string err;
@@ -450,6 +452,7 @@ struct SelectArgs {
                               // ((base + s) * 6 + x) * 64 + l); -1: no room in the pool / no blocks in the cluster (phase 2)
     int32_t *item_bad;        // [items] 1: a member the reference drops, the query's own row or an exact match among the cluster's
                               // members -- the item goes without blocks (k_cluster_dist)
+    const int32_t *cl_order;  // [n_reps] the clusters by falling number of block-internal nodes (k_cluster_tiles walks them in this order), or nullptr
     int32_t *cl_bbase;        // [n_reps] first slot of the cluster's tiles in the pool, -1: the cluster has no blocks (k_cluster_tiles)
     int2 *q_items;            // [nq] {first entry of q_item, accepted clusters}
     int32_t *q_item;          // [items] the queries' items, a query's in the order of its accepted clusters

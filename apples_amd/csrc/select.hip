@@ -1124,7 +1124,9 @@ __global__ __launch_bounds__(CL_TILES_TPB) void k_cluster_tiles(SelectArgs a) {
     const int tid = threadIdx.x;
     int item_base = 0, tile_base = 0, btile_base = 0, bslot_base = 0;
     for (int64_t c0 = 0; c0 < a.n_reps; c0 += CL_TILES_TPB) {
-        const int64_t c = c0 + tid;
+        // (clade blocks: the clusters in the order of their walks' lengths, longest first -- the tiles of the block kernels are
+        // taken in table order, and a launch's floor is its longest walk: started first it lies beside the others, not behind them)
+        const int64_t c = c0 + tid < a.n_reps ? (a.cl_order ? a.cl_order[c0 + tid] : c0 + tid) : a.n_reps;
         const int cnt = c < a.n_reps ? a.cl_count[c] : 0;
         const int T = c < a.n_reps ? cluster_tile_queries(a.rep_moff[c + 1] - a.rep_moff[c]) : 1;
         const int nt = (cnt + T - 1) / T;
@@ -1364,7 +1366,10 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         // (item_bad), where their tuples will be phase 2's arithmetic: the last phase needs nothing of this kernel
         HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[0], ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_big, ctx->ev_blk[0], 0));
+        const bool timed = ctx->ev_blk_time[0] && ctx->ev_blk_time[1];
+        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[0], ctx->stream_big));
         if (launch_blocks_up(ctx, b, ctx->stream_big)) return 1;
+        if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[1], ctx->stream_big)); ctx->ev_blk_time[0] = nullptr; }  // (recorded: run_block reads them)
         HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[1], ctx->stream_big));
     }
     // the second form's last phase beside the first's, on the spare stream: a hundred-odd workgroups of 1 024 threads (their

@@ -301,7 +301,7 @@ def clustered_leg(ds, nodes, queries, thr, method, device, steps=3):
                  threshold=thr, baseobs=25, overlap=0.001, device=device)
     try:
         out = eng.place_sequences(queries)
-        ph = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0}
+        ph = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0, 'blocks_ms': 0.0}
         t0 = time.perf_counter()
         for _ in range(steps):
             out = eng.place_sequences(queries)
@@ -315,9 +315,11 @@ def clustered_leg(ds, nodes, queries, thr, method, device, steps=3):
     return {'value': len(queries) / dt, 'unit': 'queries/s', 'ms_per_step': dt * 1e3, 'steps': steps,
             'per_kernel_ms_per_step': {k: v / steps for k, v in ph.items()}, 'n_reps': int(info['n_reps']),
             'mean_observed': float(np.mean(out['n_obs'])), 'placed': int((out['n_valid'] > 0).sum()),
+            'cluster_blocks': int(info.get('cluster_blocks', 0)), 'device_batch': int(info['batch']),
             'clustering_and_consensus_s': t_clusters,
             'note': 'same tree, reference and queries through max-diameter clusters at 1.2 x -f with consensus representatives '
-                    '(the route run_apples.py takes by default); host buffer -> placements in host memory'}
+                    '(the route run_apples.py takes by default); host buffer -> placements in host memory.  blocks_ms = k_blocks_up (the '
+                    'sweep inside the clade blocks, bottom-up), which runs beside the last phase of select_ms; k_blocks_down is in sweep_ms'}
 
 
 def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_step, placements, info, filter_ms=None):
@@ -327,7 +329,9 @@ def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_st
     # algorithmic bytes per step: distance N_rows*(L+8)+L per query; sweep 332*V per query
     dist_bytes = nq * (rows * (L + 8) + L)
     sweep_bytes = 332.0 * float(np.sum(placements['n_valid'][placed] + 1))
-    kernels = {'lsq_sweep': (sweep_bytes, per_step['sweep_ms'])}
+    # (clustered route with clade blocks: the sweep inside the blocks starts in k_blocks_up, which runs beside the selection's last
+    # phase -- its own timer, blocks_ms; k_blocks_down is inside sweep_ms)
+    kernels = {'lsq_sweep': (sweep_bytes, per_step['sweep_ms'] + per_step.get('blocks_ms', 0.0))}
     if table:  # the -d filter reads every table value once
         kernels['table_select'] = (nq * rows * 8.0, per_step['select_ms'])
     else:
@@ -342,6 +346,10 @@ def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_st
                 'algorithmic_bytes_per_launch': kernels[dom][0] / n_launch,
                 'per_kernel_ms_per_step': per_step,
                 'all_kernels_GBps': {k: (v[0] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in kernels.items()}}
+    if dom == 'lsq_sweep' and per_step.get('blocks_ms', 0.0) > 0:
+        roofline['note'] = ('clustered route with clade blocks: time = sweep_ms + blocks_ms (k_blocks_up runs beside the selection); the '
+                            'algorithmic figure is SURVEY 8d\'s 332 B per swept node, the block kernels move ~190 B per block-internal node '
+                            '(tuples of [slot][component][lane] rows shared structure): a fraction above 1 means fewer bytes moved, see traffic')
     if dom == 'jc69_distance' and info.get('code_planes') == 2 and info.get('all_singleton') and \
             not os.environ.get('APPLES_NO_DIST_MFMA') and not os.environ.get('APPLES_NO_FUSE'):
         # the tiled pair counts run on the matrix cores (fp4 operands, 4 MACs per site and pair:
@@ -415,7 +423,7 @@ def other_workload(name, device, steps=3, ds=None, queries=0):
             return eng.place_sequences(qarr)
     try:
         out = step()
-        ph = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0, 'filter_ms': 0.0}
+        ph = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0, 'filter_ms': 0.0, 'blocks_ms': 0.0}
         launches = 0
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -429,6 +437,8 @@ def other_workload(name, device, steps=3, ds=None, queries=0):
     finally:
         eng.close()
     per = {k: ph[k] / steps for k in ('dist_ms', 'select_ms', 'sweep_ms')}
+    if ph['blocks_ms'] > 0:
+        per['blocks_ms'] = ph['blocks_ms'] / steps
     rf = roofline_of(name, Q, n_leaves if table else info['n_rows'], L, protein, table, per, launches / steps, out, info,
                      filter_ms=ph['filter_ms'] / steps)
     return {'value': Q / dt, 'unit': 'queries/s', 'ms_per_step': dt * 1e3, 'steps': steps, 'queries': Q,
@@ -608,7 +618,7 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    phases = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0, 'filter_ms': 0.0}
+    phases = {'dist_ms': 0.0, 'select_ms': 0.0, 'sweep_ms': 0.0, 'filter_ms': 0.0, 'blocks_ms': 0.0}
     launches = 0
     out = None
     for _ in range(args.steps):
@@ -656,7 +666,7 @@ def main():
         rows = eng.n_rows if not table else n_leaves
         placed = mine['n_valid'] > 0
         mean_v = float(np.mean(mine['n_valid'][placed] + 1)) if placed.any() else 0.0
-        per_step = {k: v / args.steps for k, v in phases.items() if k != 'filter_ms'}
+        per_step = {k: v / args.steps for k, v in phases.items() if k != 'filter_ms' and (k != 'blocks_ms' or v > 0)}
         info = eng.describe()
         roofline = roofline_of(args.workload, nq, rows, L, protein, table, per_step, launches / args.steps, mine, info,
                                filter_ms=phases['filter_ms'] / args.steps)

@@ -131,11 +131,11 @@ typedef struct {
 #define APPLES_F_DEGENERATE  32u  /* >=3 distances but fewer than two of them on tree leaves */
 
 /* ABI of this header: bumped whenever a struct above grows or an entry point changes (4 = apples_params.debug with the
- * switches up to APPLES_DBG_ALL; 5 = apples_params.batch_gib).  apples_params has no size field: a caller must zero-initialise it (memset / = {0}) and
+ * switches up to APPLES_DBG_ALL; 5 = apples_params.batch_gib; 6 = APPLES_T_BLOCKS, APPLES_DBG_NO_BLOCKS).  apples_params has no size field: a caller must zero-initialise it (memset / = {0}) and
  * be built against the header of the library it loads -- check apples_abi_version() == APPLES_ABI_VERSION and
  * apples_params_size() == sizeof(apples_params) once at start-up, as apples_amd/engine.py does.  Bits of `debug` beyond
  * APPLES_DBG_ALL are ignored. */
-#define APPLES_ABI_VERSION 5u
+#define APPLES_ABI_VERSION 6u
 uint32_t apples_abi_version(void);
 size_t apples_params_size(void);
 
@@ -217,7 +217,9 @@ enum { APPLES_T_PACK = 0, APPLES_T_DIST = 1, APPLES_T_SELECT = 2, APPLES_T_SWEEP
        APPLES_T_FILTER = 6, /* scoredist: the part of APPLES_T_DIST spent in the matrix-core lower-bound filter, before the
                                exact evaluation of its candidates, summed over the device batches the filter ran in; 0 = no
                                filter ran (every other route) */
-       APPLES_T_COUNT = 7 };
+       APPLES_T_BLOCKS = 7, /* clustered route with clade blocks: k_blocks_up (it runs on a side stream beside the selection's last
+                               phase, so APPLES_T_SELECT covers it too; k_blocks_down is part of APPLES_T_SWEEP); 0 otherwise */
+       APPLES_T_COUNT = 8 };
 int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n);
 
 /* Introspection: device name, packed layout, workspace sizes (JSON text, owned by ctx). */
