@@ -350,12 +350,14 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
     // (the selection's bitmap over emission indices: 4 096 words of LDS at most, k_select_clusters)
     int64_t n_leaf_slots = 0;
     for (int64_t s = 0; s < a.n_refs; ++s) n_leaf_slots += slot_node[s] >= 0 ? 1 : 0;
-    if (n_blocks == 0 || n_leaf_slots + n_blocks > 262144) return 0;
+    if (n_blocks == 0 || n_leaf_slots + n_blocks > 262144 || n >= (1 << 30)) return 0;
     std::vector<int4> rec_i;
     std::vector<double2> rec_e;
+    std::vector<double> stat_plain, stat_bme;  // per record: the first three components of the node's S tuple (OLS / BE / FM; BME)
     std::vector<int32_t> rep_soff((size_t)a.n_reps + 1, 0), mem_block((size_t)rep_moff[a.n_reps], -1), blk_root, blk_rslot, blk_nodes, slot_of(n, -1);
     for (int64_t c = 0; c < a.n_reps; ++c) {
         rep_soff[c] = (int32_t)rec_i.size();
+        const int64_t rc = c;
         int sc = 0;
         for (int u : by_rep[c]) {
             const int b = (int)blk_root.size();
@@ -369,8 +371,31 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
                 slot_of[v] = sc++;
                 const int l = t->child_idx[t->child_off[v]], r = t->child_idx[t->child_off[v] + 1];
                 auto ref = [&](int k) { return slot_of[k] >= 0 ? slot_of[k] : -(slot_mpos[node_slot[k]] + 1); };
-                rec_i.push_back(make_int4(ref(l), ref(r), l, r));
+                rec_i.push_back(make_int4(ref(l), ref(r), l, v == u ? (r | (1 << 30)) : r));  // (bit 30 of the right child's id: the record is a block's root)
                 rec_e.push_back(make_double2(t->edge_len[l], t->edge_len[r]));
+                // The components of the node's S tuple that do not depend on the query: inside a block every leaf is observed, so the
+                // count and the path-length sums are the same for every query (OLS / BME: S, Sd, Sd2; BE: S, Sd; FM: S -- the first
+                // components of the tuples, sweep_math.h).  Formed here with node_S's operations in node_S's order (lift, then 0 + first
+                // child + second child; BME: each child's share times 1 / 2), so they carry the bits the device would form: the block
+                // kernels neither store nor load them (sweep_lean.hip).  This file is compiled with -ffp-contract=off like the kernels.
+                for (int bme = 0; bme < 2; ++bme) {
+                    std::vector<double> &st = bme ? stat_bme : stat_plain;
+                    double acc[3] = {0, 0, 0};
+                    const int kids[2] = {l, r};
+                    for (int k = 0; k < 2; ++k) {
+                        const int c = kids[k];
+                        double s0 = 1, s1 = 0, s2 = 0;  // a leaf's tuple starts (1, 0, 0, ...) for every method
+                        if (slot_of[c] >= 0) { const double *sc = &st[(size_t)(rep_soff[rc] + slot_of[c]) * 3]; s0 = sc[0]; s1 = sc[1]; s2 = sc[2]; }
+                        const double e = t->edge_len[c];
+                        double u[3];
+                        u[0] = s0;
+                        u[1] = s0 * e + s1;
+                        u[2] = s0 * e * e + s2 + 2 * e * s1;
+                        const double coef = 1.0 / (double)2;
+                        for (int x = 0; x < 3; ++x) acc[x] += bme ? coef * u[x] : u[x];
+                    }
+                    st.push_back(acc[0]); st.push_back(acc[1]); st.push_back(acc[2]);
+                }
             }
             blk_root.push_back(u);
             blk_rslot.push_back(slot_of[u]);
@@ -400,6 +425,8 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
     }
     if (dev_upload(ctx, &a.blk_rec_i, rec_i.data(), (int64_t)rec_i.size())) return 1;
     if (dev_upload(ctx, &a.blk_rec_e, rec_e.data(), (int64_t)rec_e.size())) return 1;
+    if (dev_upload(ctx, &a.blk_stat[0], stat_plain.data(), (int64_t)stat_plain.size())) return 1;
+    if (dev_upload(ctx, &a.blk_stat[1], stat_bme.data(), (int64_t)stat_bme.size())) return 1;
     if (dev_upload(ctx, &a.rep_soff, rep_soff.data(), (int64_t)rep_soff.size())) return 1;
     std::vector<int32_t> cl_order((size_t)a.n_reps);
     std::iota(cl_order.begin(), cl_order.end(), 0);
@@ -1478,7 +1505,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 sa.q_blk = bi + 2 * n_items + 2 * w.batch; sa.q_item_cursor = bi + 2 * n_items + 3 * w.batch; sa.blk_ntiles = sa.q_item_cursor + 2;
                 ctx->blk_counters = sa.q_item_cursor;  // (apples_describe: items and tiles of the last device batch)
                 HIP_TRY(ctx, hipMemsetAsync(bi + 2 * n_items, 0, (size_t)(3 * w.batch + 16) * sizeof(int32_t), front));
-                sa.blk_rec_i = a.blk_rec_i; sa.blk_rec_e = a.blk_rec_e; sa.rep_soff = a.rep_soff; sa.mem_block = a.mem_block; sa.cl_order = a.cl_order;
+                sa.blk_rec_i = a.blk_rec_i; sa.blk_rec_e = a.blk_rec_e; sa.blk_stat = a.blk_stat[ctx->params.method == APPLES_BME ? 1 : 0]; sa.rep_soff = a.rep_soff; sa.mem_block = a.mem_block; sa.cl_order = a.cl_order;
                 sa.blk_root = a.blk_root; sa.blk_rslot = a.blk_rslot; sa.blk_nodes = a.blk_nodes;
                 sa.e_of_slot = a.e_of_slot; sa.e_of_blk = a.e_of_blk; sa.e_node = a.e_node; sa.lvl_e = a.lvl_e; sa.n_e = a.n_e;
                 sa.item_bad = bi + 2 * n_items + 3 * w.batch + 16; sa.cl_bbase = sa.item_bad + n_items;
@@ -1631,7 +1658,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 int32_t *bi = ctx->blk_ints;
                 BlockArgs b{};
                 b.tiles = ctx->blk_tiles; b.n_tiles = bi + 2 * n_items + 3 * w.batch + 2; b.items = ctx->cl_items;
-                b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos;
+                b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.stat = a.blk_stat[ctx->params.method == APPLES_BME ? 1 : 0]; b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos;
                 b.self_slot = qb.self_slot + q0; b.tmp_d = w.dist; b.stride = a.slots_pad; b.pool = ctx->blk_pool;
                 b.item_sbase = bi; b.item_bad = bi + 2 * n_items + 3 * w.batch + 16;
                 b.q_item = bi + n_items; b.q_items = reinterpret_cast<const int2 *>(bi + 2 * n_items);
@@ -1881,7 +1908,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.rep_soff); dev_free(a.cl_order); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.blk_stat[0]); dev_free(a.blk_stat[1]); dev_free(a.rep_soff); dev_free(a.cl_order); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

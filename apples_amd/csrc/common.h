@@ -149,6 +149,8 @@ struct DevAlign {
                                   // internal nodes in post-order ("slot" = index inside the cluster): {left, right, node id of left, of right};
                                   // left / right >= 0: the child's slot, < 0: a leaf, member position -(x + 1) of the cluster's flat member list
     double2 *blk_rec_e = nullptr; // ... and the edge lengths of the two children
+    double *blk_stat[2] = {nullptr, nullptr};  // ... and [record][3] the first three components of the node's S tuple, which do not depend on the
+                                  // query inside a block (api.hip:build_blocks): [0] OLS / BE / FM, [1] BME
     int32_t *rep_soff = nullptr;  // [n_reps + 1] first record of every cluster (records = internal nodes of its blocks)
     int32_t *cl_order = nullptr;  // [n_reps] the clusters by falling number of records
     int32_t *mem_block = nullptr; // [members] block of the member (index into blk_*) x 2 + (1: the block's first leaf), -1: none
@@ -443,7 +445,7 @@ struct SelectArgs {
     int Lpad; const double *table;                    // 21 x 21
     // clade blocks (DevAlign::blk_*): k_cluster_tiles also cuts every cluster's items into tiles of up to 64 for the block kernels,
     // phase 2 notes every query's items, k_blocks_up leaves the blocks' S tuples in the pool, phase 3 emits block roots
-    const int4 *blk_rec_i; const double2 *blk_rec_e; const int32_t *rep_soff, *mem_block, *blk_root, *blk_rslot, *blk_nodes;
+    const int4 *blk_rec_i; const double2 *blk_rec_e; const double *blk_stat; const int32_t *rep_soff, *mem_block, *blk_root, *blk_rslot, *blk_nodes;
     const int32_t *e_of_slot, *e_of_blk, *e_node, *lvl_e; int64_t n_e;
     double *blk_pool; int64_t blk_pool_cap;  // (doubles)
     int4 *blk_tiles; int64_t blk_tiles_cap; int32_t *blk_ntiles;
@@ -528,7 +530,7 @@ struct SweepArgs {
 struct BlockArgs {
     const int4 *tiles; const int32_t *n_tiles;  // {cluster, first item, items (<= 64), first slot of the tile's tuples in the pool or -1}
     const int2 *items;                          // (query, where the cluster's members start in the query's flat member list)
-    const int4 *rec_i; const double2 *rec_e; const int32_t *rep_soff, *rep_moff, *slot_rep, *slot_mpos;
+    const int4 *rec_i; const double2 *rec_e; const double *stat; const int32_t *rep_soff, *rep_moff, *slot_rep, *slot_mpos;
     const int32_t *self_slot;                   // [nq] the queries' own rows as slots, or nullptr
     const double *tmp_d; int64_t stride;        // the queries' rows of member distances
     double *pool;                               // [slot][6][64 lanes]; a tile's slot 0: the lanes' best edges inside the blocks (key, x1, x2,

@@ -1358,7 +1358,7 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     else hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
     if (a.blk_tiles) {  // clade blocks: the S tuples inside them, before the last phase names their roots in the observation lists
         BlockArgs b{};
-        b.tiles = a.blk_tiles; b.n_tiles = a.blk_ntiles; b.items = a.cl_items; b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e;
+        b.tiles = a.blk_tiles; b.n_tiles = a.blk_ntiles; b.items = a.cl_items; b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.stat = a.blk_stat;
         b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos; b.self_slot = a.self_slot; b.tmp_d = a.tmp_d;
         b.stride = a.stride; b.pool = a.blk_pool; b.item_sbase = a.item_sbase; b.item_bad = a.item_bad; b.cursor = a.q_item_cursor + 1; b.method = a.method;
         // ... on the sweep's side stream, beside the last phase (a bandwidth-bound kernel beside a latency-bound one: 1.3 of the 1.8 ms

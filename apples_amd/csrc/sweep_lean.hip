@@ -1051,6 +1051,23 @@ __global__ __launch_bounds__(APPLES_TPB, LEAN_DOWN_WAVES) void k_lean_down(Sweep
 // tuples live in the pool as [slot][component][lane] -- a wavefront's loads and stores are whole 512-byte rows; the
 // distances of the blocks' leaves are the member distances the cluster-major distance pass left in the queries' rows.
 // Arithmetic and order are node_S's and lean_td_kid's: every valid child in file order, the parent term last.
+// The first NS components of an S tuple inside a block do not depend on the query (every leaf of the block is observed: the count
+// and the path-length sums are the block's own): OLS / BME S, Sd, Sd2; BE S, Sd; FM S.  The host formed them with node_S's
+// operations (api.hip:build_blocks, BlockArgs::stat): the walks store and load the other components only.
+template <int M>
+struct BlkStat {
+    static constexpr int NS = (M == APPLES_OLS || M == APPLES_BME) ? 3 : (M == APPLES_BE ? 2 : 1);
+};
+template <int NS>
+__device__ __forceinline__ void blk_load_dyn(const double *p, double *S) {
+#pragma unroll
+    for (int x = NS; x < 6; ++x) S[x] = p[x * 64];
+}
+template <int NS>
+__device__ __forceinline__ void blk_store_dyn(double *p, const double *S) {
+#pragma unroll
+    for (int x = NS; x < 6; ++x) p[x * 64] = S[x];
+}
 __device__ __forceinline__ void blk_load(const double *p, double *S) {
 #pragma unroll
     for (int x = 0; x < 6; ++x) S[x] = p[x * 64];
@@ -1070,7 +1087,7 @@ __device__ __forceinline__ void blk_store(double *p, const double *S) {
 #define BLK_WIN 128
 struct BlkOps {
     double d0, d1;
-    double p0[6], p1[6], pl[6];
+    double p0[6], p1[6], pl[6];  // (p0 / p1: the query-independent components come from the static table, the others from the pool)
 };
 struct BlkWin {
     int4 ri[APPLES_TPB / WAVE][BLK_WIN];
@@ -1116,13 +1133,17 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
                 if (m0 + k < sz) dT[(int64_t)(m0 + k) * 64] = v[k];
         }
         // (what a node does not need is read from one place, the same for every lane: a sector, not a row)
+        constexpr int NS = BlkStat<M>::NS;
+        const double *stat = a.stat + (int64_t)rb * 3;
         auto fetch = [&](const int4 &ri, int j, BlkOps &o) __attribute__((always_inline)) {
             o.d0 = dT[(int64_t)(ri.x < 0 ? -ri.x - 1 : 0) * 64];
             o.d1 = dT[(int64_t)(ri.y < 0 ? -ri.y - 1 : 0) * 64];
+#pragma unroll
+            for (int x = 0; x < NS; ++x) o.p0[x] = stat[(ri.x >= 0 ? ri.x : 0) * 3 + x];  // (the same address for every lane)
 #ifdef BLK_EXP_NO_LOAD
-            blk_load(a.pool, o.p0);
+            blk_load_dyn<NS>(a.pool, o.p0);
 #else
-            blk_load((ri.x >= 0 && ri.x != j - 1) ? pool + (int64_t)ri.x * 384 : a.pool, o.p0);
+            blk_load_dyn<NS>((ri.x >= 0 && ri.x != j - 1) ? pool + (int64_t)ri.x * 384 : a.pool, o.p0);
 #endif
         };
         double r[6] = {0, 0, 0, 0, 0, 0};  // the tuple of the node before: in post-order an internal right child (or an internal left child beside a
@@ -1160,7 +1181,13 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
 #ifdef BLK_EXP_NO_STORE  // (timing experiments: scripts/r05_blk_parts_exp.sh)
                 if (r[0] == 123456.789) blk_store(pool + (int64_t)j * 384, r);
 #else
-                blk_store(pool + (int64_t)j * 384, r);
+                // the query's components of the tuple; the others only for a block's root (the sweep above the blocks reads a whole
+                // tuple there) -- for every other node they go to the tile's slot 0, which nobody reads before k_blocks_down fills
+                // it: one hot row, and the step's stores stay a fixed number (the counted waits)
+                blk_store_dyn<NS>(pool + (int64_t)j * 384, r);
+                double *sp = (ri.w >> 30) ? pool + (int64_t)j * 384 : pool - 384;
+#pragma unroll
+                for (int x = 0; x < NS; ++x) sp[x * 64] = r[x];
 #endif
             };
             BlkOps oa, ob;
@@ -1209,12 +1236,19 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_down(BlockArgs a) {
         LeanBest best;
         lean_best_init(best);
         const double coef = BME ? 1.0 / (double)(1 + 2 - 1) : 1.0;  // apples/BME.py:36-37: the node is not the LCA, one valid sibling
+        constexpr int NS = BlkStat<M>::NS;
+        const double *stat = a.stat + (int64_t)rb * 3;
         auto fetch = [&](const int4 &ri, int j, bool chained, BlkOps &o) __attribute__((always_inline)) {
             o.d0 = dT[(int64_t)(ri.x < 0 ? -ri.x - 1 : 0) * 64];
             o.d1 = dT[(int64_t)(ri.y < 0 ? -ri.y - 1 : 0) * 64];
             blk_load(chained ? a.pool : pool + (int64_t)j * 384, o.pl);  // (what a node does not need: one place for every lane, a sector)
-            blk_load(ri.x >= 0 ? pool + (int64_t)ri.x * 384 : a.pool, o.p0);
-            blk_load(ri.y >= 0 ? pool + (int64_t)ri.y * 384 : a.pool, o.p1);
+#pragma unroll
+            for (int x = 0; x < NS; ++x) {  // the children's query-independent components (the same address for every lane)
+                o.p0[x] = stat[(ri.x >= 0 ? ri.x : 0) * 3 + x];
+                o.p1[x] = stat[(ri.y >= 0 ? ri.y : 0) * 3 + x];
+            }
+            blk_load_dyn<NS>(ri.x >= 0 ? pool + (int64_t)ri.x * 384 : a.pool, o.p0);
+            blk_load_dyn<NS>(ri.y >= 0 ? pool + (int64_t)ri.y * 384 : a.pool, o.p1);
         };
         double nxt[6] = {0, 0, 0, 0, 0, 0};  // lift(R) of node j - 1 where this step forms it (j - 1 is then a child of j): it does not go through the pool
         bool have = false;                  // (wave-uniform)
@@ -1263,7 +1297,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_down(BlockArgs a) {
                     }
                 };
                 kid(S0, S1, re.x, re.y, ri.x, ri.z);
-                kid(S1, S0, re.y, re.x, ri.y, ri.w);
+                kid(S1, S0, re.y, re.x, ri.y, ri.w & 0x3fffffff);  // (bit 30: the record is a block's root)
                 have = ri.x == j - 1 || ri.y == j - 1;
             };
             BlkOps oa, ob;
