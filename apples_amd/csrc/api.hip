@@ -403,6 +403,16 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
         }
     }
     rep_soff[a.n_reps] = (int32_t)rec_i.size();
+    // per cluster: its blocks (numbered cluster by cluster: [rep_boff[c], rep_boff[c + 1])) and its members outside every block
+    // (positions in the cluster's member list), for the selection's short form of the last phase (select.hip)
+    std::vector<int32_t> rep_boff((size_t)a.n_reps + 1, 0), rep_loff((size_t)a.n_reps + 1, 0), loose_mp;
+    for (int64_t c = 0; c < a.n_reps; ++c) {
+        rep_boff[c + 1] = rep_boff[c] + (int32_t)by_rep[c].size();
+        for (int m = rep_moff[c]; m < rep_moff[c + 1]; ++m)
+            if (mem_block[m] < 0) loose_mp.push_back(m - rep_moff[c]);
+        rep_loff[c + 1] = (int32_t)loose_mp.size();
+    }
+    if (loose_mp.empty()) loose_mp.push_back(0);
     // emission order: tree-leaf slots and block roots by (level, deepest first; node id)
     struct Ent { int32_t lvl, node, kind, idx; };
     std::vector<Ent> ents;
@@ -433,6 +443,9 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
     std::stable_sort(cl_order.begin(), cl_order.end(), [&](int32_t x, int32_t y) { return rep_soff[x + 1] - rep_soff[x] > rep_soff[y + 1] - rep_soff[y]; });
     if (dev_upload(ctx, &a.cl_order, cl_order.data(), a.n_reps)) return 1;
     if (dev_upload(ctx, &a.mem_block, mem_block.data(), (int64_t)mem_block.size())) return 1;
+    if (dev_upload(ctx, &a.rep_boff, rep_boff.data(), (int64_t)rep_boff.size())) return 1;
+    if (dev_upload(ctx, &a.rep_loff, rep_loff.data(), (int64_t)rep_loff.size())) return 1;
+    if (dev_upload(ctx, &a.loose_mp, loose_mp.data(), (int64_t)loose_mp.size())) return 1;
     if (dev_upload(ctx, &a.blk_root, blk_root.data(), n_blocks)) return 1;
     if (dev_upload(ctx, &a.blk_rslot, blk_rslot.data(), n_blocks)) return 1;
     if (dev_upload(ctx, &a.blk_nodes, blk_nodes.data(), n_blocks)) return 1;
@@ -1507,6 +1520,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 HIP_TRY(ctx, hipMemsetAsync(bi + 2 * n_items, 0, (size_t)(3 * w.batch + 16) * sizeof(int32_t), front));
                 sa.blk_rec_i = a.blk_rec_i; sa.blk_rec_e = a.blk_rec_e; sa.blk_stat = a.blk_stat[ctx->params.method == APPLES_BME ? 1 : 0]; sa.rep_soff = a.rep_soff; sa.mem_block = a.mem_block; sa.cl_order = a.cl_order;
                 sa.blk_root = a.blk_root; sa.blk_rslot = a.blk_rslot; sa.blk_nodes = a.blk_nodes;
+                sa.rep_boff = a.rep_boff; sa.rep_loff = a.rep_loff; sa.loose_mp = a.loose_mp;
                 sa.e_of_slot = a.e_of_slot; sa.e_of_blk = a.e_of_blk; sa.e_node = a.e_node; sa.lvl_e = a.lvl_e; sa.n_e = a.n_e;
                 sa.item_bad = bi + 2 * n_items + 3 * w.batch + 16; sa.cl_bbase = sa.item_bad + n_items;
                 sa.blk_pool = ctx->blk_pool; sa.blk_pool_cap = ctx->blk_pool_cap;
@@ -1908,7 +1922,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.blk_stat[0]); dev_free(a.blk_stat[1]); dev_free(a.rep_soff); dev_free(a.cl_order); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_boff); dev_free(a.rep_loff); dev_free(a.loose_mp); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.blk_stat[0]); dev_free(a.blk_stat[1]); dev_free(a.rep_soff); dev_free(a.cl_order); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

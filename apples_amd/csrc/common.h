@@ -153,6 +153,8 @@ struct DevAlign {
                                   // query inside a block (api.hip:build_blocks): [0] OLS / BE / FM, [1] BME
     int32_t *rep_soff = nullptr;  // [n_reps + 1] first record of every cluster (records = internal nodes of its blocks)
     int32_t *cl_order = nullptr;  // [n_reps] the clusters by falling number of records
+    int32_t *rep_boff = nullptr, *rep_loff = nullptr, *loose_mp = nullptr;  // [n_reps + 1] the clusters' blocks (numbered cluster by cluster), [n_reps + 1] + list:
+                                  // their members outside every block (positions in the cluster's member list)
     int32_t *mem_block = nullptr; // [members] block of the member (index into blk_*) x 2 + (1: the block's first leaf), -1: none
     int32_t *blk_root = nullptr;  // [n_blocks] root node
     int32_t *blk_rslot = nullptr; // [n_blocks] slot of the root inside its cluster
@@ -447,6 +449,7 @@ struct SelectArgs {
     // phase 2 notes every query's items, k_blocks_up leaves the blocks' S tuples in the pool, phase 3 emits block roots
     const int4 *blk_rec_i; const double2 *blk_rec_e; const double *blk_stat; const int32_t *rep_soff, *mem_block, *blk_root, *blk_rslot, *blk_nodes;
     const int32_t *e_of_slot, *e_of_blk, *e_node, *lvl_e; int64_t n_e;
+    const int32_t *rep_boff, *rep_loff, *loose_mp;  // (the short form of the last phase)
     double *blk_pool; int64_t blk_pool_cap;  // (doubles)
     int4 *blk_tiles; int64_t blk_tiles_cap; int32_t *blk_ntiles;
     int32_t *q_blk;           // [nq] 1: the query's observation list names block roots (k_blocks_down / k_blocks_finish serve it)

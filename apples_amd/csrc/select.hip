@@ -860,6 +860,111 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
         }
         use_blk = __syncthreads_or(any) != 0;
     }
+    // ---- clade blocks, the short form of this phase.  When every accepted cluster that has blocks has them for this query, the
+    // observation list is a hundred-odd entries -- the clusters' block roots and their few members outside every block -- and needs
+    // neither the bitmap over every emission index nor a look at every member: a thread per accepted cluster writes its entries
+    // into a short list in LDS (the bitmap's memory: it is not used), the entries are ranked by counting, and the per-level offsets
+    // are counts over the list.  Anything else -- a cluster whose item goes without blocks, an exact match or the query's own row
+    // among the members outside the blocks, more than SHORT_CAP entries, fewer than two -- takes the general form below.
+    constexpr int SHORT_CAP = 1024;
+    if (PHASE == 3 && !LISTED && use_blk) {
+        double *f_val = reinterpret_cast<double *>(dyn_bits);
+        int *f_key = reinterpret_cast<int *>(f_val + SHORT_CAP), *f_node = f_key + SHORT_CAP, *f_off = f_node + SHORT_CAP;  // f_off[ACC_CAP + 1]
+        // entries each cluster may write (its blocks + its members outside them); a cluster with blocks must have them here
+        int ok = 1, carry = 0;
+        for (int k0 = 0; k0 < n_acc; k0 += TPB) {
+            const int k = k0 + tid;
+            int cnt_k = 0;
+            if (k < n_acc) {
+                const int c = sh_rep[k];
+                if (a.rep_soff[c + 1] > a.rep_soff[c] && sh_sb[k] < 0) ok = 0;
+                cnt_k = a.rep_boff[c + 1] - a.rep_boff[c] + a.rep_loff[c + 1] - a.rep_loff[c];
+            }
+            int tot;
+            const int off = carry + block_excl_scan_int<NW>(cnt_k, sh_i, &tot);
+            if (k < n_acc) f_off[k] = off;
+            carry += tot;
+        }
+        const int n_slots_f = carry;
+        if (__syncthreads_and(ok) && n_slots_f <= SHORT_CAP) {
+            int obs_c = 0, tot_c = 0, extra_c = 0, slow = 0;
+            for (int k = tid; k < n_acc; k += TPB) {
+                const int c = sh_rep[k], sb = sh_sb[k], mb = sh_mb[k];
+                int at = f_off[k];
+                const int l0 = a.rep_loff[c], l1 = a.rep_loff[c + 1];
+                const int in_blocks = (sh_off[k + 1] - sh_off[k]) - (l1 - l0);  // (every one of them observed: k_cluster_dist found none to drop)
+                obs_c += in_blocks;
+                tot_c += in_blocks;
+                for (int b = a.rep_boff[c]; b < a.rep_boff[c + 1]; ++b, ++at) {
+                    f_key[at] = a.e_of_blk[b];
+                    f_node[at] = a.blk_root[b];
+                    const long long pl = ((long long)(sb >> 6) + 1 + a.blk_rslot[b]) * 384 + (sb & 63);
+                    f_val[at] = __longlong_as_double((long long)0xFFF8000000000000ull | pl);
+                    extra_c += a.blk_nodes[b];
+                }
+                for (int l = l0; l < l1; ++l, ++at) {  // a member outside every block: Reference.py:150, PoolQueryWorker.py:63-75 one by one
+                    const int mp = a.loose_mp[l], slot = a.mem_slot[mb + mp];
+                    const double d = tmp[sh_off[k] + mp];
+                    f_key[at] = 0x7fffffff;  // (no entry unless it is observed below)
+                    if (d < 0) continue;
+                    ++obs_c;
+                    if (slot == self) continue;
+                    ++tot_c;
+                    if (d == 0) { slow = 1; continue; }  // an exact match: the general form keeps that book
+                    const int node = a.slot_node[slot];
+                    if (node < 0) continue;
+                    f_key[at] = a.e_of_slot[slot];
+                    f_node[at] = node;
+                    f_val[at] = d;
+                }
+            }
+            const int obs_s = block_sum<NW>(obs_c, sh_i);
+            const int tot_s = block_sum<NW>(tot_c, sh_i);
+            const int extra_s = block_sum<NW>(extra_c, sh_i);
+            int ne_c = 0;
+            for (int i = tid; i < n_slots_f; i += TPB) ne_c += f_key[i] != 0x7fffffff;
+            const int ne = block_sum<NW>(ne_c, sh_i);
+            if (!__syncthreads_or(slow) && ne >= 2) {
+                if (obs_s < a.baseobs) { to_slow(obs_s); return; }  // the reference would pop further clusters (Reference.py:146)
+                // rank by counting (the keys are distinct emission indices), then the list in level order
+                for (int i = tid; i < n_slots_f; i += TPB) {
+                    const int key = f_key[i];
+                    if (key == 0x7fffffff) continue;
+                    int r = 0;
+                    for (int j = 0; j < n_slots_f; ++j) r += f_key[j] < key;
+                    o_node[r] = f_node[i];
+                    o_dist[r] = f_val[i];
+                }
+                int32_t *cgf = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
+                for (int i = tid; cgf && i < a.height + 2; i += TPB) {  // entries above level i - 1: emission indices below lvl_e[i]
+                    const int lim = a.lvl_e[i];
+                    int r = 0;
+                    for (int j = 0; j < n_slots_f; ++j) r += f_key[j] < lim;
+                    cgf[i] = r;
+                }
+                if (tid == 0) {
+                    apples_placement p;
+                    p.edge = 0; p.flags = 0; p.error = 0.0; p.distal = 0.0; p.pendant = 0.0; p.n_obs = tot_s; p.n_valid = extra_s;
+                    int nee = ne;
+                    if (tot_s <= 2) {  // (PoolQueryWorker.py:97-98; cannot be with two entries of which one is a block, kept for the form's sake)
+                        p.flags = APPLES_F_INSUFFICIENT | APPLES_F_PENDANT_INT;
+                        p.edge = -1;
+                        p.n_valid = 0;
+                        nee = 0;
+                    }
+                    a.q_blk[q] = nee > 0 ? 1 : 0;
+                    a.out[q] = p;
+                    a.n_obs[q] = nee;
+                    enlist(a, q, nee);
+                }
+                return;
+            }
+        }
+        // the general form after all: the bitmap's memory as it expects it (the list's offsets, at least, were written into it)
+        __syncthreads();
+        for (int i = tid; i < n_words; i += TPB) dyn_bits[i] = 0;
+        __syncthreads();
+    }
     if (PHASE == 4) {
         // ---- the members' distances (a thread per member), then Reference.py:144-152: while fewer than `-b` valid member
         // distances are in, the representative with the next smallest (distance, index) beyond the threshold brings its cluster
@@ -1327,7 +1432,8 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist_sd(SelectArgs a) {
 int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (nq == 0) return 0;
     // the slot bitmap and its 16-bit in-run prefixes (runs of 16 words: 262 144 slots); with clade blocks over emission indices
-    const size_t dyn = (size_t)(((a.e_of_slot ? std::max(a.n_e, a.n_members) : a.n_members) + 63) >> 6) * 10;
+    size_t dyn = (size_t)(((a.e_of_slot ? std::max(a.n_e, a.n_members) : a.n_members) + 63) >> 6) * 10;
+    if (a.e_of_slot) dyn = std::max<size_t>(dyn, 1024 * 16 + (SELECT_CLUSTERS_ACC_CAP + 1) * 4);  // (the short form's list lives in the bitmap's memory)
     const bool sd = a.aa_idx != nullptr;  // scoredist context: k_cluster_dist_sd computes the member distances (no by-query form)
     const bool by_query = (ctx->dbg & APPLES_DBG_CLUSTER_BY_QUERY) != 0 && !sd;  // diagnostic switch: phase 0 alone
     if (sd && !a.cl_count) { ctx->err = "scoredist cluster route without its tile scratch"; return 1; }
@@ -1364,13 +1470,15 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         // ... on the sweep's side stream, beside the last phase (a bandwidth-bound kernel beside a latency-bound one: 1.3 of the 1.8 ms
         // of a 20 000-query batch at config 3's size disappear).  Which items go without blocks is k_cluster_dist's finding
         // (item_bad), where their tuples will be phase 2's arithmetic: the last phase needs nothing of this kernel
+        static const bool serial = getenv("APPLES_BLK_SERIAL") != nullptr;  // experiment knob: k_blocks_up before the last phase, on the main stream
+        hipStream_t bs = serial ? ctx->stream : ctx->stream_big;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[0], ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_big, ctx->ev_blk[0], 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_blk[0], 0));
         const bool timed = ctx->ev_blk_time[0] && ctx->ev_blk_time[1];
-        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[0], ctx->stream_big));
-        if (launch_blocks_up(ctx, b, ctx->stream_big)) return 1;
-        if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[1], ctx->stream_big)); ctx->ev_blk_time[0] = nullptr; }  // (recorded: run_block reads them)
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[1], ctx->stream_big));
+        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[0], bs));
+        if (launch_blocks_up(ctx, b, bs)) return 1;
+        if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[1], bs)); ctx->ev_blk_time[0] = nullptr; }  // (recorded: run_block reads them)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[1], bs));
     }
     // the second form's last phase beside the first's, on the spare stream: a hundred-odd workgroups of 1 024 threads (their
     // rounds of member lookups are what such a workgroup takes: a quarter of the rounds of 256 threads) leave the chip idle
