@@ -98,7 +98,7 @@ const double kBlosum45[400] = {
 int upload_tree(apples_ctx *ctx, const apples_tree *t) {
     DevTree &d = ctx->tree;
     d.dbg = ctx->dbg;
-    d.lean_small = ctx->params.criterion != APPLES_HYBRID;
+    d.lean_small = ctx->params.criterion != APPLES_HYBRID || !(ctx->dbg & APPLES_DBG_HYBRID_RECORDS);
     d.n_nodes = t->n_nodes;
     int h = 0;
     for (int i = 0; i < t->n_nodes; ++i) h = std::max(h, t->level[i]);
@@ -664,13 +664,21 @@ int repack_to_bytes(apples_ctx *ctx) {  // a query block carries symbols beyond 
     return 0;
 }
 
+// HYBRID (apples/Algorithm.py:76-82) needs every edge's solution once the sweep is through: the lean sweep keeps them in its
+// entries and ranks them itself (sweep_lean.hip:lean_hybrid_pick); the level loop and the scan sweep write per-edge records
+// (Workspace::Sweep::xe).  True = this context's HYBRID passes take the records.  APPLES_DBG_HYBRID_RECORDS: on every tree.
+bool hybrid_records(const apples_ctx *ctx) {
+    if (ctx->params.criterion != APPLES_HYBRID) return false;
+    return (ctx->dbg & APPLES_DBG_HYBRID_RECORDS) || !sweep_lean_layout(ctx->tree, false);
+}
+
 // observed-leaf count above which a query goes straight to a workgroup-sized sweep team
 int big_threshold(const apples_ctx *ctx) {
     static const int env = getenv("APPLES_BIG_THRESHOLD") ? atoi(getenv("APPLES_BIG_THRESHOLD")) : 0;
     // the lean sweep's wavefront-sized teams are the efficient ones and take their queue largest first, finely graded
     // (C3 sweep 15.8 / 15.8 / 16.7 / 18.7 ms at 4 096 / 8 192 / 12 288 / 16 384, the clustered route's 38.4 / 35.5 / 35.1 / 36.0);
     // the level loop's cut was measured at 4 096
-    const int v = env > 0 ? env : (sweep_lean_layout(ctx->tree, ctx->params.criterion == APPLES_HYBRID) ? LEAN_BIG_THRESHOLD : 4096);
+    const int v = env > 0 ? env : (sweep_lean_layout(ctx->tree, hybrid_records(ctx)) ? LEAN_BIG_THRESHOLD : 4096);
     // scan sweep: a wavefront-sized team keeps the per-leaf state of at most SCAN_LDS_LEAVES_SMALL leaves in LDS
     return ctx->tree.scan ? std::min(v, SCAN_LDS_LEAVES_SMALL) : v;
 }
@@ -1067,7 +1075,7 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     s.cnt_gt = ctx->tree.scan ? nullptr : w.cnt_gt;  // (the scan sweep takes its leaves in node-id order and needs no per-level offsets)
     s.out = qb.out + q0;
     s.big_threshold = route_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
-    s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;  // (what run_sweep's launch_big will run)
+    s.route_classes = (w.big.lean && !hybrid_records(ctx)) ? 1 : 0;  // (what run_sweep's launch_big will run)
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     s.row_cursor = w.cls_count + 21;
     s.seg_slot = w.seg_slot; s.seg_cnt = w.seg_cnt; s.node_level = ctx->tree.level;
@@ -1094,7 +1102,9 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.cap = sw.cap;
     s.leaf_cap = sw.leaf_cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
-    s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
+    // (HYBRID on a level-loop workspace -- a tree the lean sweep does not serve, or one regrown with records for apples_sweep_edges --
+    // ranks the per-edge records; the lean sweep ranks what it keeps in its entries)
+    s.keep_edges = (keep_edges || (ctx->params.criterion == APPLES_HYBRID && (hybrid_records(ctx) || !sw.lean))) ? 1 : 0;
     static const int dbg = getenv("APPLES_SWEEP_DEBUG_PHASE") ? atoi(getenv("APPLES_SWEEP_DEBUG_PHASE")) : 0;
     s.debug_phase = dbg;
     s.work_list = nullptr; s.work_count = nullptr; s.big_threshold = route_threshold(ctx);
@@ -1114,7 +1124,7 @@ ScanArgs scan_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placement
     s.cap = sw.cap; s.leaf_cap = sw.leaf_cap;
     s.lds_leaves = big ? SCAN_LDS_LEAVES_BIG : SCAN_LDS_LEAVES_SMALL;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
-    s.keep_edges = (keep_edges || ctx->params.criterion == APPLES_HYBRID) ? 1 : 0;
+    s.keep_edges = (keep_edges || hybrid_records(ctx)) ? 1 : 0;
     s.big_threshold = big_threshold(ctx);
     s.work_list = nullptr; s.work_count = nullptr; s.cls_list = nullptr; s.cls_count = nullptr; s.cls_stride = w.batch;
     s.cursor = w.cls_count + 4;
@@ -1270,7 +1280,7 @@ int back_stream(apples_ctx *ctx) {
 
 int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
     const DevAlign &a = ctx->aln;
-    bool hybrid = ctx->params.criterion == APPLES_HYBRID;
+    const bool hybrid = hybrid_records(ctx);  // (HYBRID on the lean sweep is a pass like any other)
     // fused path: threshold compaction in the distance kernel's epilogue; only queries that need
     // the top-up rule get full distance rows
     const bool no_fuse = (ctx->dbg & APPLES_DBG_NO_FUSE) != 0;  // diagnostic switch
@@ -1487,7 +1497,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
             // clade blocks (build_blocks): the sweep inside whole subtrees of one cluster on a static schedule, cluster-major
             // (sweep_lean.hip: k_blocks_up before the selection's last phase, k_blocks_down + k_blocks_finish after the sweep above
             // them).  With the lean sweep only (MLSE / ME on a big binary tree): its kernels know a block root among the leaves.
-            ctx->blk_active = a.n_blocks > 0 && !hybrid && !pipelined && !ctx->tree.scan && w.small.lean && w.small.lean_leaf && w.big.lean;
+            ctx->blk_active = a.n_blocks > 0 && ctx->params.criterion != APPLES_HYBRID && !pipelined && !ctx->tree.scan && w.small.lean && w.small.lean_leaf && w.big.lean;
             if (ctx->blk_active) {
                 const int64_t n_items = nq * SELECT_CLUSTERS_ACC_CAP + std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps;
                 const int64_t n_ints = 3 * n_items + 3 * w.batch + 16 + a.n_reps, n_tiles = n_items / 64 + a.n_reps + 1;
@@ -1752,7 +1762,7 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
             {"APPLES_NO_SD_TOPUP", APPLES_DBG_NO_SD_TOPUP}, {"APPLES_SD_FP6", APPLES_DBG_SD_FP6},
             {"APPLES_NO_TOPUP_OVERLAP", APPLES_DBG_NO_TOPUP_OVERLAP}, {"APPLES_STREAM_THIRD_PASS", APPLES_DBG_STREAM_THIRD_PASS},
             {"APPLES_NO_SD_COMPACT", APPLES_DBG_NO_SD_COMPACT}, {"APPLES_SD_COMPACT_TINY", APPLES_DBG_SD_COMPACT_TINY},
-            {"APPLES_NO_BLOCKS", APPLES_DBG_NO_BLOCKS}};
+            {"APPLES_NO_BLOCKS", APPLES_DBG_NO_BLOCKS}, {"APPLES_HYBRID_RECORDS", APPLES_DBG_HYBRID_RECORDS}};
         for (const auto &k : knobs)
             if (getenv(k.env)) ctx->dbg |= k.bit;
     }
@@ -2176,7 +2186,7 @@ static int run_table_batch(apples_ctx *ctx, const double *d_rows, int64_t nq, in
     s.cnt_gt = ctx->tree.scan ? nullptr : w.cnt_gt;
     s.out = d_out;
     s.big_threshold = route_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
-    s.route_classes = (w.big.lean && ctx->params.criterion != APPLES_HYBRID) ? 1 : 0;
+    s.route_classes = (w.big.lean && !hybrid_records(ctx)) ? 1 : 0;
     s.cls_list = w.cls_list; s.cls_count = w.cls_count; s.cls_stride = w.batch;
     s.row_cursor = w.cls_count + 21;
     HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 64 * sizeof(int32_t), ctx->stream));  // every counter of the batch
@@ -2209,7 +2219,7 @@ int apples_place_from_distances(apples_ctx *ctx, const double *dist, int64_t n_q
     const std::vector<int32_t> &perm = ctx->h_col_perm;
     std::vector<int32_t> col_slot(n_cols);
     for (int64_t s = 0; s < n_cols; ++s) col_slot[perm[s]] = (int32_t)s;
-    bool hybrid = ctx->params.criterion == APPLES_HYBRID;
+    const bool hybrid = hybrid_records(ctx);
     if (ensure_workspace(ctx, n_cols, n_cols, n_queries, true, false, hybrid)) return 1;
     Workspace &w = ctx->ws;
     apples_placement *d_out = nullptr;
@@ -2279,7 +2289,7 @@ int apples_table_upload(apples_ctx *ctx, const double *dist, int64_t n_queries, 
 }
 
 static int run_table_block(apples_ctx *ctx, QueryBlock &qb) {
-    bool hybrid = ctx->params.criterion == APPLES_HYBRID;
+    const bool hybrid = hybrid_records(ctx);
     if (qb.n_cols != ctx->dcols || qb.col_gen != ctx->col_gen) {
         ctx->err = "the column layout changed since this table was uploaded (another table with different columns was "
                    "placed on this context): upload the table again";

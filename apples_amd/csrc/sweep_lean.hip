@@ -24,8 +24,9 @@
 //     memory round trip in the step.
 //
 // Team = one wavefront per query (four per workgroup, no s_barrier).  Queries with many observed leaves are routed to
-// sweep.hip's workgroup-sized teams as before; so are trees with polytomies or more than LEAN_MAX_LEVELS - 2 levels, the
-// HYBRID criterion and per-edge inspection (the launcher decides).  Arithmetic: sweep_math.h, shared with sweep.hip --
+// sweep.hip's workgroup-sized teams as before; so are trees with polytomies or more than LEAN_MAX_LEVELS - 2 levels and
+// per-edge inspection (the launcher decides).  The HYBRID criterion keeps every edge's solution in the entries' tuple slots and
+// ranks them after the top-down pass (lean_hybrid_pick).  Arithmetic: sweep_math.h, shared with sweep.hip --
 // same expressions in the same order, so placements are bit-identical to the level loop's.
 #include <algorithm>
 #include <cstdlib>
@@ -286,6 +287,10 @@ struct LeanBest {
     int v, x1_int;
 };
 
+// HYBRID's per-edge records: a pendant length that is Python's int 0 (apples/util.py:36-50, Sol::x1_int) is stored as this NaN (no
+// arithmetic produces its payload)
+#define LEAN_BOXED_INT0 0x7ff8ab5e00000001LL
+
 __device__ __forceinline__ void lean_best_init(LeanBest &b) {
     b.key = INF_D; b.v = 0x7fffffff; b.x1 = b.x2 = b.err = b.e = 0; b.x1_int = 0;
 }
@@ -295,11 +300,14 @@ __device__ __forceinline__ void lean_best_init(LeanBest &b) {
 // evaluates its residual (error_per_edge); an internal child receives lift(R) over its own edge -- what it will add for
 // each of its own children -- in its tuple slot, or through LDS (`hand`) when its level has at most 64 nodes.
 // Sk / ek / kd / kn: the child's S tuple, edge length, descriptor, node id; Ss / es: the sibling's (nk > 1 only).
-template <int M>
+// HY (the HYBRID criterion, apples/Algorithm.py:76-82): nothing is compared here; the edge's error, x_1 and x_2 go into half `rz` of
+// the tuple slots of its parent's entry `ridx` (dead by now: the entry's S went into its own parent's step, its lifted R was read
+// when this step began), for lean_hybrid_pick.
+template <int M, bool HY = false>
 __device__ __forceinline__ void lean_td_kid(const LeanTeam &t, const double *Sk, const double *Ss, const double *plift, double ek,
                                             double es, int kd, int kn, int nk, bool is_lca, double coef, int negative,
                                             int criterion, const double *lds_pow, double2 (*hand)[WAVE], int hand_base,
-                                            LeanBest &best, double ddk = 0.0) {
+                                            LeanBest &best, double ddk = 0.0, int ridx = 0, int rz = 0) {
     constexpr bool BME = (M == APPLES_BME);
     double acc[6];
 #pragma unroll
@@ -335,6 +343,12 @@ __device__ __forceinline__ void lean_td_kid(const LeanTeam &t, const double *Sk,
 #pragma unroll
         for (int x = 0; x < 6; ++x) bp[x * 64] = u[x];
     }
+    if (HY) {
+        reinterpret_cast<double *>(t.T0 + ridx)[rz] = r.err;
+        reinterpret_cast<double *>(t.T1 + ridx)[rz] = r.x1_int ? __longlong_as_double(LEAN_BOXED_INT0) : r.x1;
+        reinterpret_cast<double *>(t.T2 + ridx)[rz] = r.x2;
+        return;
+    }
     const double key = (criterion == APPLES_ME) ? r.x1 : r.err;
     if (key < best.key || (key == best.key && kn < best.v)) {
         best.key = key; best.v = kn; best.x1 = r.x1; best.x2 = r.x2; best.err = r.err; best.x1_int = r.x1_int; best.e = ek;
@@ -351,7 +365,7 @@ __device__ __forceinline__ void lean_own_plift(const LeanTeam &t, int idx, const
 
 // Top-down step of one internal node, both children in turn (the two swap roles in between): a rolled loop keeps one
 // 2x2 solve's worth of temporaries live, which is what decides how many wavefronts a SIMD holds.
-template <int M>
+template <int M, bool HY = false>
 __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, const int2 d, const int2 nd, const double2 e, const double2 dd,
                                              bool is_lca, int negative, int criterion,
                                              const double *lds_pow, const double2 (*hand_in)[WAVE], int in_pos,
@@ -369,7 +383,7 @@ __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, const i
     int kd = d.x, ks = d.y, kn = nd.x, ksn = nd.y;
 #pragma unroll 1
     for (int z = 0; z < nk; ++z) {
-        lean_td_kid<M>(t, Sk, Ss, plift, ek, es, kd, kn, nk, is_lca, coef, negative, criterion, lds_pow, hand_out, out_base, best, ddk);
+        lean_td_kid<M, HY>(t, Sk, Ss, plift, ek, es, kd, kn, nk, is_lca, coef, negative, criterion, lds_pow, hand_out, out_base, best, ddk, idx, z);
 #pragma unroll
         for (int x = 0; x < 6; ++x) { const double w = Sk[x]; Sk[x] = Ss[x]; Ss[x] = w; }
         { const double w = ek; ek = es; es = w; }
@@ -383,7 +397,7 @@ __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, const i
 // lean_S_chunks) -- for the workgroup-sized teams, which wait on memory; the wavefront-sized teams' top-down kernel is
 // bound by instruction issue at three wavefronts per SIMD, and the registers of the look-ahead (spilled there) cost it
 // more than the round trip (measured: 6.9 against 5.0 ms per C3 pass)
-template <int M, bool AHEAD>
+template <int M, bool AHEAD, bool HY = false>
 __device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi, int first, int stride, int VI, int negative,
                                                int criterion, const double *lds_pow, const double2 (*hand_in)[WAVE],
                                                double2 (*hand_out)[WAVE], int out_base, LeanBest &best) {
@@ -392,7 +406,7 @@ __device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi
     double2 e = make_double2(0, 0), dd = make_double2(0, 0);
     if (!AHEAD) {
         for (; idx < hi; idx += stride) {
-            lean_td_node<M>(t, idx, t.D[idx], t.N[idx], t.E[idx], t.DD[idx], idx == VI, negative, criterion, lds_pow, hand_in, idx - lo,
+            lean_td_node<M, HY>(t, idx, t.D[idx], t.N[idx], t.E[idx], t.DD[idx], idx == VI, negative, criterion, lds_pow, hand_in, idx - lo,
                             hand_out, out_base, best);
             __builtin_amdgcn_wave_barrier();
         }
@@ -404,7 +418,7 @@ __device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi
         int2 d2 = make_int2(0, 0), nd2 = make_int2(0, 0);
         double2 e2 = make_double2(0, 0), dd2 = make_double2(0, 0);
         if (nidx < hi) { d2 = t.D[nidx]; nd2 = t.N[nidx]; e2 = t.E[nidx]; dd2 = t.DD[nidx]; }
-        lean_td_node<M>(t, idx, d, nd, e, dd, idx == VI, negative, criterion, lds_pow, hand_in, idx - lo, hand_out, out_base, best);
+        lean_td_node<M, HY>(t, idx, d, nd, e, dd, idx == VI, negative, criterion, lds_pow, hand_in, idx - lo, hand_out, out_base, best);
         __builtin_amdgcn_wave_barrier();
         idx = nidx; d = d2; nd = nd2; e = e2; dd = dd2;
     }
@@ -412,7 +426,7 @@ __device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi
 
 // The same for a level of at most 32 nodes, one lane per (node, child): lanes 0-31 take the first valid children of
 // nodes g0 .. g0 + 31, lanes 32-63 the second: the 2x2 solve and the residual run once per level step, not twice.
-template <int M>
+template <int M, bool HY = false>
 __device__ __forceinline__ void lean_td_pairs(const LeanTeam &t, int g0, int ng, int VI, int lane, int negative, int criterion,
                                               const double *lds_pow, const double2 (*hand_in)[WAVE], double2 (*hand_out)[WAVE],
                                               int out_base, LeanBest &best) {
@@ -435,8 +449,8 @@ __device__ __forceinline__ void lean_td_pairs(const LeanTeam &t, int g0, int ng,
     }
     __builtin_amdgcn_wave_barrier();  // (every lane's reads of the hand-over precede the stores of this step)
     if (mine)
-        lean_td_kid<M>(t, Sk, Ss, plift, z ? e.y : e.x, z ? e.x : e.y, z ? d.y : d.x, z ? nd.y : nd.x, nk, is_lca, coef, negative,
-                       criterion, lds_pow, hand_out, out_base, best, z ? dd.y : dd.x);
+        lean_td_kid<M, HY>(t, Sk, Ss, plift, z ? e.y : e.x, z ? e.x : e.y, z ? d.y : d.x, z ? nd.y : nd.x, nk, is_lca, coef, negative,
+                           criterion, lds_pow, hand_out, out_base, best, z ? dd.y : dd.x, idx, z);
 }
 
 // the query's placement from the team's winner (apples/Algorithm.py:92-101); `mine` = this lane holds the winning edge
@@ -465,6 +479,95 @@ __device__ __forceinline__ void lean_write_placement(apples_placement *out, int6
     }
 }
 
+
+// HYBRID (apples/Algorithm.py:76-82): heapq.nsmallest(floor(log2(num_nodes))) of the valid edges by error -- stable, so ties go to
+// the earlier edge in post-order = the smaller edge index -- then the first minimum of x_1 among those in that order.  The records
+// are what lean_td_kid<HY> left in the entries [lo, hi) (T0: the two children's errors, T1: x_1, T2: x_2; D, N, E as the bottom-up
+// pass wrote them).  One round per rank: every lane offers the smallest (error, edge) of its entries beyond the last one taken, the
+// team's arg-min takes it, and the lane that owns it keeps it if its x_1 beats what the lane kept before (a later rank never
+// replaces an equal x_1, and a first rank whose x_1 is a NaN keeps the place as it does under Python's min: key -inf here).  The
+// team's arg-min over (x_1 kept, rank) then names the winner.  A NaN error is never taken (sweep.hip's HYBRID: the same rule).
+// `argmin(key, id)`: the team's lexicographic arg-min, result in every lane.  Returns 0x7fffffff when there is no edge at all;
+// `mine` = this lane holds the winner (its record in `best`).
+template <class ArgMin>
+__device__ __forceinline__ int lean_hybrid_pick(const LeanTeam &t, int lo, int hi, int V, int first, int stride, ArgMin &&argmin,
+                                                LeanBest &best, bool &mine) {
+    const int kk = 31 - __clz(V);
+    double last_e = -INF_D;
+    int last_v = -1;
+    double keep_x1 = INF_D;
+    int keep_rank = 0x7fffffff;
+    lean_best_init(best);
+    // a lane's KL smallest (error, edge) beyond the last one taken, sorted, and where they are (2 x entry + child); `more`: the
+    // lane has others beyond those.  A lane offers the head of its list; when the list runs dry and there are more, it scans its
+    // entries again from the team's last pick on (what lies before that has been taken: a lane's smaller keys were offered first).
+    // floor(log2(num_nodes)) ranks over 64 or more lanes: the second scan is rare, so the ranking costs one pass over the entries.
+    constexpr int KL = 4;
+    double ce[KL];
+    int cv[KL], cat[KL];
+    int filled = 0, head = 0;
+    bool more = true;
+    auto refill = [&]() {
+        filled = 0; head = 0;
+        int seen = 0;
+        auto offer = [&](double e, int v, int at) {
+            const bool after = (e > last_e) || (e == last_e && v > last_v);
+            if (!after) return;  // (a NaN error is never after anything)
+            ++seen;
+            int pos = filled < KL ? filled : KL;
+#pragma unroll
+            for (int k = KL - 1; k >= 0; --k)
+                if (k < filled && (e < ce[k] || (e == ce[k] && v < cv[k]))) pos = k;
+            if (pos >= KL) return;
+#pragma unroll
+            for (int k = KL - 1; k > 0; --k)
+                if (k > pos && k <= filled) { ce[k] = ce[k - 1]; cv[k] = cv[k - 1]; cat[k] = cat[k - 1]; }
+#pragma unroll
+            for (int k = 0; k < KL; ++k)
+                if (k == pos) { ce[k] = e; cv[k] = v; cat[k] = at; }
+            if (filled < KL) ++filled;
+        };
+        for (int idx = lo + first; idx < hi; idx += stride) {
+            const int2 d = t.D[idx], nd = t.N[idx];
+            const double2 er = t.T0[idx];
+            offer(er.x, nd.x, 2 * idx);
+            if (d.y != 0) offer(er.y, nd.y, 2 * idx + 1);
+        }
+        more = seen > filled;
+    };
+    for (int r = 0; r < kk; ++r) {
+        if (head == filled && more) refill();
+        double ke = INF_D;
+        int kv = 0x7fffffff, at = -1;
+#pragma unroll
+        for (int k = 0; k < KL; ++k)
+            if (k == head && k < filled) { ke = ce[k]; kv = cv[k]; at = cat[k]; }
+        const int my_v = kv;
+        argmin(ke, kv);
+        if (kv == 0x7fffffff) break;
+        last_e = ke; last_v = kv;
+        if (my_v == kv && at >= 0) {  // (edge indices are distinct: one owner)
+            ++head;
+            const int idx = at >> 1, z = at & 1;
+            double x1 = reinterpret_cast<const double *>(t.T1 + idx)[z];
+            const bool boxed = __double_as_longlong(x1) == LEAN_BOXED_INT0;
+            if (boxed) x1 = 0;
+            const double kx = (r == 0 && !(x1 == x1)) ? -INF_D : x1;
+            if (r == 0 || kx < keep_x1) {
+                keep_x1 = kx; keep_rank = r;
+                best.v = kv; best.x1 = x1; best.x1_int = boxed ? 1 : 0; best.err = ke;
+                best.x2 = reinterpret_cast<const double *>(t.T2 + idx)[z];
+                best.e = reinterpret_cast<const double *>(t.E + idx)[z];
+            }
+        }
+    }
+    const int my_rank = keep_rank;
+    double wk = keep_x1;
+    int wr = keep_rank;
+    argmin(wk, wr);
+    mine = wr != 0x7fffffff && my_rank == wr;
+    return wr == 0x7fffffff ? 0x7fffffff : 0;
+}
 
 // The size-class queues of a batch (written by the selection kernels): entry w -> query, largest first: the four parts
 // of the largest class (lists 4..7, counts at cls_count[16..19]), then classes 1..3
@@ -499,7 +602,7 @@ __device__ __forceinline__ int lean_query_cap(int n) { return (3 * n + 128 + min
 // The top-down pass of ONE query of a wavefront-sized team (all_R_values, placement_per_edge, error_per_edge, the arg-min of
 // apples/Algorithm.py:74-91) from what its bottom-up pass left: the pool offset, the number of level groups G and of internal
 // nodes VI, the groups' offsets.  `stage`: the wavefront's LDS area for tuples on their way to a level of at most 64 nodes.
-template <int M>
+template <int M, bool HY = false>
 __device__ __forceinline__ void lean_down_one(const SweepArgs &a, const double *lds_pow, double2 (*stage)[WAVE], int64_t q, int n,
                                               int64_t off, int G, int VI, int lane) {
     const DevTree &T = a.tree;
@@ -515,14 +618,21 @@ __device__ __forceinline__ void lean_down_one(const SweepArgs &a, const double *
         const int ng = g1 - g0;
         const bool hand_out = g0 - k0 <= WAVE;  // the children's level has at most 64 nodes: their tuples go through LDS
         if (ng <= 32) {
-            lean_td_pairs<M>(t, g0, ng, VI, lane, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
-                             hand_out ? stage : nullptr, k0, best);
+            lean_td_pairs<M, HY>(t, g0, ng, VI, lane, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
+                                 hand_out ? stage : nullptr, k0, best);
         } else {
-            lean_td_chunks<M, false>(t, g0, g1, lane, WAVE, VI, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
-                              hand_out ? stage : nullptr, k0, best);
+            lean_td_chunks<M, false, HY>(t, g0, g1, lane, WAVE, VI, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
+                                         hand_out ? stage : nullptr, k0, best);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         hand_in = hand_out;
+    }
+    if (HY) {
+        bool mine = false;
+        const int none = lean_hybrid_pick(t, grp_off[1], grp_off[G + 1], V, lane, WAVE,
+                                          [](double &d, int &i) { team_argmin<WAVE>(d, i, nullptr, nullptr); }, best, mine);
+        lean_write_placement(a.out, q, V, mine ? best.v : none, mine, lane == 0, best);
+        return;
     }
     const int my_best = best.v;
     double wkey = best.key;
@@ -733,7 +843,7 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
 // Top-down kernel of the wavefront-sized teams: a node forms R for each valid child (all_R_values), solves it
 // (placement_per_edge) and evaluates its residual (error_per_edge); an internal child's tuple becomes lift(R) over its own
 // edge; then the query's arg-min (apples/Algorithm.py:74-91)
-template <int M>
+template <int M, bool HY = false>
 __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
@@ -742,7 +852,7 @@ __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
     const DevTree &T = a.tree;
     const LeanQueue qu = lean_queue(a);
     unsigned long long pc[7] = {0, 0, 0, 0, 0, 0, 0}, pn[4] = {0, 0, 0, 0}, tk = 0;
-    const bool prof = a.prof != nullptr;
+    const bool prof = a.prof != nullptr && !HY;  // (the cycle counters cover the MLSE / ME form)
 #define LEAN_TICK(slot) do { if (prof) { const unsigned long long now_ = __builtin_readcyclecounter(); pc[slot] += now_ - tk; tk = now_; } } while (0)
     if (prof) tk = __builtin_readcyclecounter();
     while (true) {
@@ -757,7 +867,7 @@ __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
         const int4 meta = a.lean_meta[q];
         const int G = meta.y, VI = meta.z;
         if (G < 0) continue;  // handed to the workgroup-sized teams by the bottom-up kernel
-        if (!prof) { lean_down_one<M>(a, lds_pow, stage, q, n, meta.x & 0xffffffffll, G, VI, lane); continue; }
+        if (!prof) { lean_down_one<M, HY>(a, lds_pow, stage, q, n, meta.x & 0xffffffffll, G, VI, lane); continue; }
         const int V = VI + n;  // Subtree.num_nodes
         LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, meta.x & 0xffffffffll, nullptr, 0, 0);
         t.BP = a.blk_pool;
@@ -923,7 +1033,7 @@ __device__ __forceinline__ void lean_argmin_wg(double &d, int &i, LeanBigShared<
     }
 }
 
-template <int M, int TEAM>
+template <int M, int TEAM, bool HY = false>
 __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM> &sh) {
     const int tid = threadIdx.x;
     const double *lds_pow = sh.pow;
@@ -980,8 +1090,16 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
         lean_best_init(best);
         for (int g = G; g >= 1; --g) {
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
-            lean_td_chunks<M, true>(t, g0, g1, tid, TEAM, VI, a.negative, a.criterion, lds_pow, nullptr, nullptr, 0, best);
+            lean_td_chunks<M, true, HY>(t, g0, g1, tid, TEAM, VI, a.negative, a.criterion, lds_pow, nullptr, nullptr, 0, best);
             __syncthreads();
+        }
+        if (HY) {
+            bool mine = false;
+            const int none = lean_hybrid_pick(t, grp_off[1], VI + 1, V, tid, TEAM,
+                                              [&sh](double &d, int &i) { lean_argmin_wg<TEAM>(d, i, sh); }, best, mine);
+            lean_write_placement(a.out, q, V, mine ? best.v : none, mine, tid == 0, best);
+            __syncthreads();
+            continue;
         }
         const int my_best = best.v;
         double wkey = best.key;
@@ -992,18 +1110,27 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
     }
 }
 
-template <int M, int TEAM>
+template <int M, int TEAM, bool HY = false>
 __global__ __launch_bounds__(TEAM, TEAM / 256 * 2 > 2 ? 2 : TEAM / 256 * 2) void k_sweep_lean_big(SweepArgs a, int64_t nq) {
     __shared__ LeanBigShared<TEAM> sh;
     for (int i = threadIdx.x; i < 384; i += TEAM) sh.pow[i] = (&kPowLogTab[0][0])[i];
     for (int i = threadIdx.x; i < 256; i += TEAM) sh.pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
     __syncthreads();
-    lean_big_loop<M, TEAM>(a, nq, sh);
+    lean_big_loop<M, TEAM, HY>(a, nq, sh);
 }
 
 template <int TEAM>
 void launch_lean_big_t(const SweepArgs &a, int64_t nq, dim3 grid, hipStream_t st) {
     const dim3 block(TEAM);
+    if (a.criterion == APPLES_HYBRID) {
+        switch (a.method) {
+            case APPLES_FM: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_FM, TEAM, true>), grid, block, 0, st, a, nq); break;
+            case APPLES_BME: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BME, TEAM, true>), grid, block, 0, st, a, nq); break;
+            case APPLES_BE: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BE, TEAM, true>), grid, block, 0, st, a, nq); break;
+            default: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_OLS, TEAM, true>), grid, block, 0, st, a, nq); break;
+        }
+        return;
+    }
     switch (a.method) {
         case APPLES_FM: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_FM, TEAM>), grid, block, 0, st, a, nq); break;
         case APPLES_BME: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BME, TEAM>), grid, block, 0, st, a, nq); break;
@@ -1032,13 +1159,13 @@ __global__ __launch_bounds__(APPLES_TPB, LEAN_UP_WAVES) void k_lean_both(SweepAr
     lean_up_loop<M, true>(a, sh.up, sh.pow);
 }
 
-template <int M>
+template <int M, bool HY = false>
 __global__ __launch_bounds__(APPLES_TPB, LEAN_DOWN_WAVES) void k_lean_down(SweepArgs a) {
     __shared__ LeanDownShared sh;
     for (int i = threadIdx.x; i < 384; i += APPLES_TPB) sh.pow[i] = (&kPowLogTab[0][0])[i];
     for (int i = threadIdx.x; i < 256; i += APPLES_TPB) sh.pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
     __syncthreads();
-    lean_down_loop<M>(a, sh);
+    lean_down_loop<M, HY>(a, sh);
 }
 
 
@@ -1427,7 +1554,7 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
     // config 5's block 1.31 -> 1.44, config 4 2.77 -> 3.05): at three wavefronts per SIMD the fused body spills 85 vector registers
     // where the bottom-up kernel alone spills 19 and the top-down kernel 8, and the launch it saves is worth less than that.
     static const bool fused = getenv("APPLES_LEAN_FUSED") != nullptr;  // experiment knob
-    if (fused && !up.prof && up.debug_phase != 1) {
+    if (fused && !up.prof && up.debug_phase != 1 && up.criterion != APPLES_HYBRID) {
         switch (up.method) {
             case APPLES_FM: hipLaunchKernelGGL((k_lean_both<APPLES_FM>), gu, block, 0, st, up); break;
             case APPLES_BME: hipLaunchKernelGGL((k_lean_both<APPLES_BME>), gu, block, 0, st, up); break;
@@ -1446,6 +1573,15 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
         }
     };
     auto launch_down = [&](const SweepArgs &x, hipStream_t s_) {
+        if (x.criterion == APPLES_HYBRID) {  // (per-edge records in the entries' dead tuple slots + lean_hybrid_pick)
+            switch (x.method) {
+                case APPLES_FM: hipLaunchKernelGGL((k_lean_down<APPLES_FM, true>), gd, block, 0, s_, x); break;
+                case APPLES_BME: hipLaunchKernelGGL((k_lean_down<APPLES_BME, true>), gd, block, 0, s_, x); break;
+                case APPLES_BE: hipLaunchKernelGGL((k_lean_down<APPLES_BE, true>), gd, block, 0, s_, x); break;
+                default: hipLaunchKernelGGL((k_lean_down<APPLES_OLS, true>), gd, block, 0, s_, x); break;
+            }
+            return;
+        }
         switch (x.method) {
             case APPLES_FM: hipLaunchKernelGGL((k_lean_down<APPLES_FM>), gd, block, 0, s_, x); break;
             case APPLES_BME: hipLaunchKernelGGL((k_lean_down<APPLES_BME>), gd, block, 0, s_, x); break;

@@ -19,7 +19,7 @@ F_EXACT, F_INSUFFICIENT, F_MISPLACED, F_PENDANT_INT, F_ZERO_NOT_IN_TREE, F_DEGEN
 # apples_params.debug (include/apples_hip.h APPLES_DBG_*): alternative routes to the same placements, fixed at context creation
 DBG = {'no_fuse': 1, 'sweep_scan': 2, 'node_map': 4, 'sweep_merge': 8, 'no_sweep_merge': 16, 'no_dist_gemm': 32, 'no_sweep_lean': 64,
        'no_sd_gemm': 128, 'cluster_by_query': 256, 'no_cluster_topup': 512, 'no_stream_select': 1024, 'no_topup_kernel': 2048,
-       'no_cluster_big': 4096, 'no_sd_topup': 8192, 'sd_fp6': 16384, 'no_topup_overlap': 32768, 'stream_third_pass': 65536, 'no_sd_compact': 131072, 'sd_compact_tiny': 262144, 'no_blocks': 524288}
+       'no_cluster_big': 4096, 'no_sd_topup': 8192, 'sd_fp6': 16384, 'no_topup_overlap': 32768, 'stream_third_pass': 65536, 'no_sd_compact': 131072, 'sd_compact_tiny': 262144, 'no_blocks': 524288, 'hybrid_records': 1048576}
 T_PACK, T_DIST, T_SELECT, T_SWEEP, T_TOTAL, T_DIST_LAUNCHES, T_FILTER, T_BLOCKS, T_COUNT = range(9)
 
 PLACEMENT_DTYPE = np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'), ('distal', '<f8'),
@@ -30,7 +30,7 @@ EXPORTS = ['apples_ctx_create', 'apples_ctx_destroy', 'apples_last_error', 'appl
            'apples_queries_upload', 'apples_table_upload', 'apples_queries_free', 'apples_place_resident', 'apples_fetch_placements',
            'apples_distances_resident', 'apples_placements_device_ptr', 'apples_last_timing', 'apples_describe',
            'apples_backbone_lengths', 'apples_abi_version', 'apples_params_size']
-ABI_VERSION = 6  # include/apples_hip.h APPLES_ABI_VERSION
+ABI_VERSION = 7  # include/apples_hip.h APPLES_ABI_VERSION
 
 
 class _Tree(C.Structure):

@@ -151,8 +151,9 @@ def test_c4_shape_clustered_default_protein_route():
 
 def test_c3_shape_other_criteria_and_negative_branches():
     """Config 3's backbone with -c ME / HYBRID and with -n (apples/Algorithm.py:76-101, apples/util.py:32-50): 4 096 queries
-    placed, a sample of 256 + byte for byte against the C oracle.  ME rides the lean sweep's kernels, HYBRID the level loop with
-    per-edge records (sweep.hip) -- the route with no large-shape evidence before round 5."""
+    placed, a sample of 256 + byte for byte against the C oracle.  All of them ride the lean sweep's kernels (HYBRID: every edge's
+    solution kept in the entries, ranked after the top-down pass); HYBRID is crossed, all 4 096 queries byte for byte, with the
+    level loop over per-edge records (sweep.hip, the `hybrid_records` switch: the form of rounds 1 - 4), for OLS and for FM."""
     nq = 4096
     d = synth.make_dataset(200000, 1000, nq)
     nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
@@ -162,13 +163,25 @@ def test_c3_shape_other_criteria_and_negative_branches():
         got = eng.place_sequences(d.query_seqs)
         layout = eng.describe()['sweep_layout']
         eng.close()
-        assert (layout == 'lean') == (criterion != 'HYBRID'), (criterion, layout)
+        assert layout == 'lean', (criterion, layout)
         sample = _sample(got, nq, extremes=16, strided=240)
         assert len(sample) >= 256
         co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', criterion=criterion, negative=negative, lut=lut, threads=NTHREADS)
         want = co.place_sequences(d.query_seqs[sample])
         assert np.array_equal(got[sample]['edge'], want['edge']), (criterion, negative)
         assert got[sample].tobytes() == want.tobytes(), (criterion, negative)
+        if criterion == 'HYBRID':
+            for method in ('OLS', 'FM') if not negative else ('OLS',):
+                e1 = Engine(d.tree, d.ref_seqs, nodes, method=method, criterion='HYBRID', negative=negative)
+                a = e1.place_sequences(d.query_seqs)
+                e1.close()
+                e2 = Engine(d.tree, d.ref_seqs, nodes, method=method, criterion='HYBRID', negative=negative, debug=('hybrid_records',))
+                b = e2.place_sequences(d.query_seqs)
+                assert e2.describe()['sweep_layout'] != 'lean'
+                e2.close()
+                assert a.tobytes() == b.tobytes(), (method, negative, int((a['edge'] != b['edge']).sum()))
+                if method == 'OLS':
+                    assert a.tobytes() == got.tobytes()
 
 
 def test_c5_shape_200k_column_distance_table_bme():
