@@ -826,9 +826,12 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     // command-line run of the same size pays 1.1 to 3.4 s more for the allocation.
     int64_t capq = 0;
     auto size_batch = [&]() {
+        // (half of what is free, 144 GiB at most: on an empty 288-GB device the clustered route's 100 000 queries at 200 000
+        // references are then four device batches, not five -- 36.0 -> 34.4 ms; the other workloads do not move:
+        // profiles/r05_batch_gib_exp.txt)
         int64_t budget_gib = 96;
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_gib = std::max<int64_t>(8, std::min<int64_t>(96, (int64_t)(fr >> 30) * 2 / 5));
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_gib = std::max<int64_t>(8, std::min<int64_t>(144, (int64_t)(fr >> 30) / 2));
         if (ctx->params.batch_gib > 0) budget_gib = std::min<int64_t>(budget_gib, ctx->params.batch_gib);  // the caller's cap only lowers it
         if (const char *e = getenv("APPLES_BATCH_GIB")) budget_gib = std::max<int64_t>(1, atoll(e));  // tuning knob (experiments: replaces both)
         capq = std::max<int64_t>(32, ((need_alt ? budget_gib / 2 : budget_gib) << 30) / std::max<int64_t>(per_q, 1));

@@ -82,7 +82,7 @@ typedef struct {
      * process.  0 = the measured-best defaults.  The environment variables of the same names (APPLES_NO_FUSE ...) set
      * the same bits for a whole process. */
     uint32_t debug;
-    /* Cap of the device batch buffers in GiB; 0 = none.  The library sizes them from free memory (at most 96 GiB or 40 % of
+    /* Cap of the device batch buffers in GiB; 0 = none.  The library sizes them from free memory (at most 144 GiB or half of
      * what is free); the cap only ever lowers that: min(cap, free-memory budget).  A one-shot command-line run sets 24 (beyond
      * a few tens of GiB the allocation itself takes seconds, apples_amd/worker.py). */
     int32_t batch_gib;
