@@ -1462,24 +1462,31 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     static const int per_cu = getenv("APPLES_CLUSTER_WGS") ? atoi(getenv("APPLES_CLUSTER_WGS")) : 8;  // tuning knob
     if (sd) hipLaunchKernelGGL(k_cluster_dist_sd<4>, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
     else hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
-    if (a.blk_tiles) {  // clade blocks: the S tuples inside them, before the last phase names their roots in the observation lists
+    // clade blocks: the S tuples inside them (k_blocks_up), on the sweep's side stream beside the last phase, which names their
+    // roots in the observation lists (a bandwidth-bound kernel beside a latency-bound one).  Which items go without blocks is
+    // k_cluster_dist's finding (item_bad), where their tuples will be phase 2's arithmetic: the last phase needs nothing of this kernel
+    auto blocks_up = [&]() -> int {
+        if (!a.blk_tiles) return 0;
         BlockArgs b{};
         b.tiles = a.blk_tiles; b.n_tiles = a.blk_ntiles; b.items = a.cl_items; b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.stat = a.blk_stat;
         b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos; b.self_slot = a.self_slot; b.tmp_d = a.tmp_d;
         b.stride = a.stride; b.pool = a.blk_pool; b.item_sbase = a.item_sbase; b.item_bad = a.item_bad; b.cursor = a.q_item_cursor + 1; b.method = a.method;
-        // ... on the sweep's side stream, beside the last phase (a bandwidth-bound kernel beside a latency-bound one: 1.3 of the 1.8 ms
-        // of a 20 000-query batch at config 3's size disappear).  Which items go without blocks is k_cluster_dist's finding
-        // (item_bad), where their tuples will be phase 2's arithmetic: the last phase needs nothing of this kernel
-        static const bool serial = getenv("APPLES_BLK_SERIAL") != nullptr;  // experiment knob: k_blocks_up before the last phase, on the main stream
+        static const bool serial = getenv("APPLES_BLK_SERIAL") != nullptr;  // experiment knob: k_blocks_up on the main stream
         hipStream_t bs = serial ? ctx->stream : ctx->stream_big;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[0], ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_blk[0], 0));
         const bool timed = ctx->ev_blk_time[0] && ctx->ev_blk_time[1];
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[0], bs));
         if (launch_blocks_up(ctx, b, bs)) return 1;
         if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[1], bs)); ctx->ev_blk_time[0] = nullptr; }  // (recorded: run_block reads them)
         HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[1], bs));
-    }
+        return 0;
+    };
+    // APPLES_BLK_FIRST: k_blocks_up's persistent workgroups enter before the last phase's (experiment knob; the default lets the
+    // last phase's short workgroups in first: the persistent ones find their places as those retire, and both kernels run side
+    // by side from the start -- the other way round the last phase waits for places the persistent workgroups never give back)
+    static const bool blocks_first = getenv("APPLES_BLK_FIRST") != nullptr;
+    if (a.blk_tiles) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[0], ctx->stream));
+    if (blocks_first && blocks_up()) return 1;
     // the second form's last phase beside the first's, on the spare stream: a hundred-odd workgroups of 1 024 threads (their
     // rounds of member lookups are what such a workgroup takes: a quarter of the rounds of 256 threads) leave the chip idle
     if (big) {
@@ -1489,6 +1496,7 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_cl[1], ctx->stream2));
     }
     hipLaunchKernelGGL(k_select_clusters<3>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
+    if (!blocks_first && blocks_up()) return 1;
     if (big) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cl[1], 0));
     HIP_TRY(ctx, hipGetLastError());
     return 0;

@@ -1329,8 +1329,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
     }
 }
 
+#ifndef BLK_DOWN_WAVES
+#define BLK_DOWN_WAVES 2  // wavefronts per SIMD k_blocks_down is compiled for (186 registers unconstrained)
+#endif
 template <int M>
-__global__ __launch_bounds__(APPLES_TPB) void k_blocks_down(BlockArgs a) {
+__global__ __launch_bounds__(APPLES_TPB, BLK_DOWN_WAVES) void k_blocks_down(BlockArgs a) {
     constexpr bool BME = (M == APPLES_BME);
     __shared__ double sh_pow[384 + 256];
     __shared__ BlkWin win;
@@ -1487,8 +1490,12 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_finish(BlockArgs a) {
 // block roots in the observation lists
 int launch_blocks_up(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
     const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    static const int per_cu = getenv("APPLES_BLK_UP_WGS") ? atoi(getenv("APPLES_BLK_UP_WGS")) : 6;  // tuning knob (82 registers: up to five or six wavefronts per SIMD)
-    const dim3 grid((unsigned)(cus * std::max(per_cu, 1))), block(APPLES_TPB);
+    // tuning knob (82 registers: up to five or six wavefronts per SIMD -- but the kernel is bound by its pool traffic, not by the
+    // wavefronts in flight: 6 / 4 / 3 / 2 workgroups per CU give 34.6 / 34.7 / 34.3 / 33.7 ms on config 3's clustered pass,
+    // profiles/r05_blk_order_exp.txt, and the fewer there are the more room the selection's last phase has beside them)
+    static const int per_cu = getenv("APPLES_BLK_UP_WGS") ? atoi(getenv("APPLES_BLK_UP_WGS")) : 1;
+    static const int total = getenv("APPLES_BLK_UP_GRID") ? atoi(getenv("APPLES_BLK_UP_GRID")) : 0;  // experiment knob: the grid itself
+    const dim3 grid((unsigned)(total > 0 ? total : cus * std::max(per_cu, 1))), block(APPLES_TPB);
     HIP_TRY(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int32_t), st));
     switch (a.method) {
         case APPLES_FM: hipLaunchKernelGGL((k_blocks_up<APPLES_FM>), grid, block, 0, st, a); break;
@@ -1503,7 +1510,8 @@ int launch_blocks_up(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
 // ... and after the sweep above the blocks: the top-down pass inside them, then the queries' placements
 int launch_blocks_down(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
     const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    const dim3 grid((unsigned)(cus * 2)), block(APPLES_TPB);  // (186 registers: two wavefronts per SIMD)
+    static const int per_cu = getenv("APPLES_BLK_DOWN_WGS") ? atoi(getenv("APPLES_BLK_DOWN_WGS")) : BLK_DOWN_WAVES;  // tuning knob (186 registers: two wavefronts per SIMD)
+    const dim3 grid((unsigned)(cus * std::min(std::max(per_cu, 1), BLK_DOWN_WAVES))), block(APPLES_TPB);
     HIP_TRY(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int32_t), st));
     switch (a.method) {
         case APPLES_FM: hipLaunchKernelGGL((k_blocks_down<APPLES_FM>), grid, block, 0, st, a); break;
