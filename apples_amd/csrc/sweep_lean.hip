@@ -1363,8 +1363,20 @@ __global__ __launch_bounds__(APPLES_TPB, BLK_DOWN_WAVES) void k_blocks_down(Bloc
         const int rb = a.rep_soff[c], ns = a.rep_soff[c + 1] - rb;
         double *pool = a.pool + ((int64_t)tile.w + 1) * 384 + lane;
         const double *dT = pool + (int64_t)ns * 384;  // the members' distances as [member][lane] (k_blocks_up)
+        // The lane's running best starts from what the sweep above the blocks found for the query (k_blocks_finish keeps the smaller
+        // of the two anyway: smallest key, ties to the smaller edge index), so that an edge's residual with the reference's bits --
+        // two libm squares, a third of this kernel's arithmetic -- is formed only where it could matter: MLSE takes the residual
+        // with plain squares first, and unless that minus its proven slack (sweep_math.h:edge_residual) lies above the lane's best
+        // the edge cannot win; ME needs the residual of an edge only when its x_1 wins.  The branch is the wavefront's: one lane
+        // that needs the exact value sends all 64 through it (measured with plain squares everywhere, results then differ in the last
+        // place: 2.42 -> 1.66 ms per launch, profiles/r05_plain_sq_exp.txt).
         LeanBest best;
         lean_best_init(best);
+        bool found = false;
+        if (mine) {
+            const apples_placement up = a.out[q];
+            if (up.edge >= 0) { best.key = a.criterion == APPLES_ME ? up.pendant : up.error; best.v = up.edge; }
+        }
         const double coef = BME ? 1.0 / (double)(1 + 2 - 1) : 1.0;  // apples/BME.py:36-37: the node is not the LCA, one valid sibling
         constexpr int NS = BlkStat<M>::NS;
         const double *stat = a.stat + (int64_t)rb * 3;
@@ -1413,7 +1425,15 @@ __global__ __launch_bounds__(APPLES_TPB, BLK_DOWN_WAVES) void k_blocks_down(Bloc
                     for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * u[x] : u[x];
 #pragma unroll
                     for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];  // parent term last (apples/OLS.py:70-80)
-                    const Sol r = solve_edge<M>(Sk, acc, ek, a.negative, sh_pow);
+                    Sol r = solve_x<M>(Sk, acc, ek, a.negative);
+                    bool need;
+                    if (a.criterion == APPLES_ME) {
+                        need = mine && (r.x1 < best.key || (r.x1 == best.key && kn < best.v));
+                    } else {
+                        double mag;
+                        const double lower = edge_residual<M, false>(Sk, acc, ek, r.x1, r.x2, nullptr, &mag);
+                        need = mine && !(lower - 0x1p-40 * mag > best.key);  // (a NaN anywhere: the exact evaluation decides)
+                    }
                     if (kd >= 0) {  // an internal child: lift(R) over its edge replaces its S (both S tuples are in registers)
                         lift<M>(acc, ek, u);
                         if (kd == j - 1) {  // the next node of the walk
@@ -1421,9 +1441,13 @@ __global__ __launch_bounds__(APPLES_TPB, BLK_DOWN_WAVES) void k_blocks_down(Bloc
                             for (int x = 0; x < 6; ++x) nxt[x] = u[x];
                         } else blk_store(pool + (int64_t)kd * 384, u);
                     }
-                    const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
-                    if (key < best.key || (key == best.key && kn < best.v)) {
-                        best.key = key; best.v = kn; best.x1 = r.x1; best.x2 = r.x2; best.err = r.err; best.x1_int = r.x1_int; best.e = ek;
+                    if (__ballot(need) != 0ull) {
+                        r.err = edge_residual<M, true>(Sk, acc, ek, r.x1, r.x2, sh_pow);
+                        const double key = (a.criterion == APPLES_ME) ? r.x1 : r.err;
+                        if (need && (key < best.key || (key == best.key && kn < best.v))) {
+                            best.key = key; best.v = kn; best.x1 = r.x1; best.x2 = r.x2; best.err = r.err; best.x1_int = r.x1_int; best.e = ek;
+                            found = true;
+                        }
                     }
                 };
                 kid(S0, S1, re.x, re.y, ri.x, ri.z);
@@ -1441,7 +1465,7 @@ __global__ __launch_bounds__(APPLES_TPB, BLK_DOWN_WAVES) void k_blocks_down(Bloc
         }
         if (in) {  // slot 0 of the tile: key, x1, x2, err, e, (x1 is the int 0, edge)
             double *b = a.pool + (int64_t)tile.w * 384 + lane;
-            b[0] = mine ? best.key : INF_D; b[64] = best.x1; b[128] = best.x2; b[192] = best.err; b[256] = best.e;
+            b[0] = (mine && found) ? best.key : INF_D; b[64] = best.x1; b[128] = best.x2; b[192] = best.err; b[256] = best.e;
             b[320] = __hiloint2double(best.x1_int, best.v);
         }
     }

@@ -61,6 +61,9 @@ __device__ __forceinline__ void lift(const double *s, double e, double *t) {
 __device__ __forceinline__ double pow2_libm(double x, const double *tab) {
     const double ax = fabs(x);
     if (!(ax >= 0x1p-500 && ax <= 0x1p500)) return x * x;
+#ifdef SWEEP_EXP_PLAIN_SQ  // (timing experiment: plain squares, results differ in the last place: scripts/r05_plain_sq_exp.sh)
+    return x * x;
+#endif
     const unsigned long long ix = (unsigned long long)__double_as_longlong(ax);
     const unsigned long long tmp = ix - 0x3fe6955500000000ULL;
     const int i = (int)((tmp >> 45) & 127);
@@ -114,8 +117,9 @@ struct Sol {
     int x1_int;
 };
 
+// placement_per_edge (apples/OLS.py:82-119 ..., util.py:6-54): x_1, x_2 of one edge; `err` is left unset
 template <int M>
-__device__ __forceinline__ Sol solve_edge(const double *S, const double *R, double e, int negative, const double *pow_tab) {
+__device__ __forceinline__ Sol solve_x(const double *S, const double *R, double e, int negative) {
     // which tuple slots play which role (apples/OLS.py:90-96, FM.py:86-92, BE.py:61-67, BME.py:64-70)
     constexpr int IA = (M == APPLES_OLS || M == APPLES_BME) ? 0 : 5;                     // a_11 = R? + S?
     constexpr int IC = (M == APPLES_OLS || M == APPLES_BME) ? 5 : (M == APPLES_FM ? 4 : 0);  // RD / R1_D / R
@@ -134,6 +138,7 @@ __device__ __forceinline__ Sol solve_edge(const double *S, const double *R, doub
     r.x1 = r.x1n;
     r.x2 = r.x2n;
     r.x1_int = 0;
+    r.err = 0;
     if (!negative) {
         // the branch table of apples/util.py:32-50, evaluated in its order with strict comparisons; the three branches that
         // divide all divide by a_11 (a_22 is the same number), so the quotient is formed once for whichever numerator the
@@ -162,24 +167,41 @@ __device__ __forceinline__ Sol solve_edge(const double *S, const double *R, doub
             r.x2 = e;
         }
     }
-    // error_per_edge (apples/OLS.py:121-128, FM.py:117-124, BE.py:73-80, BME.py:76-83)
+    return r;
+}
+
+// error_per_edge (apples/OLS.py:121-128, FM.py:117-124, BE.py:73-80, BME.py:76-83) at (x_1, x_2).  EXACT: the reference's bits
+// (`x ** 2` is libm pow there: pow2_libm).  !EXACT: plain squares -- a bound, not a result: with *mag = the sum of the
+// terms' magnitudes, |exact - this| <= 2^-49 mag (pow2_libm(x) and x * x are both within one unit in the last place of x^2: the
+// two products of the C term differ by at most 2^-51 of their magnitudes + roundings, and the three additions behind C round
+// partial sums that are bounded by mag: 6 x 2^-53 mag between the two evaluations); callers use 2^-40 mag.
+template <int M, bool EXACT>
+__device__ __forceinline__ double edge_residual(const double *S, const double *R, double e, double x1, double x2, const double *pow_tab,
+                                                double *mag = nullptr) {
     constexpr int JA = (M == APPLES_FM) ? 0 : 4;
     constexpr int JB = (M == APPLES_OLS || M == APPLES_BME) ? 1 : 2;
     constexpr int JC = (M == APPLES_OLS || M == APPLES_BME) ? 0 : 5;
     constexpr int JD = (M == APPLES_OLS || M == APPLES_BME) ? 5 : (M == APPLES_FM ? 4 : 0);
     constexpr int JE = (M == APPLES_OLS || M == APPLES_BME) ? 3 : 1;
     constexpr int JF = (M == APPLES_OLS || M == APPLES_BME) ? 2 : 3;
-    double x1 = r.x1, x2 = r.x2;
     double up = x1 + x2;      // path through the parent side
     double dn = e + x1 - x2;  // path through the child side
     double A = R[JA] + S[JA];
     double B = 2 * up * R[JB] + 2 * dn * S[JB];
     // `x ** 2` is libm pow in the reference: same bits here
-    double C = pow2_libm(up, pow_tab) * R[JC] + pow2_libm(dn, pow_tab) * S[JC];
+    const double cu = (EXACT ? pow2_libm(up, pow_tab) : up * up) * R[JC], cd = (EXACT ? pow2_libm(dn, pow_tab) : dn * dn) * S[JC];
+    double C = cu + cd;
     double Dd = -2 * up * R[JD] - 2 * dn * S[JD];
     double E = -2 * R[JE] - 2 * S[JE];
     double F = R[JF] + S[JF];
-    r.err = A + B + C + Dd + E + F;
+    if (!EXACT && mag) *mag = fabs(A) + fabs(B) + fabs(cu) + fabs(cd) + fabs(Dd) + fabs(E) + fabs(F);
+    return A + B + C + Dd + E + F;
+}
+
+template <int M>
+__device__ __forceinline__ Sol solve_edge(const double *S, const double *R, double e, int negative, const double *pow_tab) {
+    Sol r = solve_x<M>(S, R, e, negative);
+    r.err = edge_residual<M, true>(S, R, e, r.x1, r.x2, pow_tab);
     return r;
 }
 
