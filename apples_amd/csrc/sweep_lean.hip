@@ -1280,6 +1280,14 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
             __builtin_amdgcn_wave_barrier();  // (the window's last readers)
             for (int k = lane; k < wn; k += WAVE) { w_ri[k] = a.rec_i[rb + w0 + k]; w_re[k] = a.rec_e[rb + w0 + k]; }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            // the query-independent components of the blocks' roots in this window (the host's values, the same bits the walk forms:
+            // build_blocks): stored here, outside the steps, whose stores stay a fixed number (the counted waits) -- until round 5's
+            // end every step stored them, into a dummy row for the nodes that are no roots: a third of the kernel's stores
+            for (int k = 0; k < wn; ++k) {
+                if (!(w_ri[k].w >> 30)) continue;  // (wave-uniform)
+#pragma unroll
+                for (int x = 0; x < NS; ++x) pool[(int64_t)(w0 + k) * 384 + x * 64] = stat[(w0 + k) * 3 + x];
+            }
             // two operand sets in turn (a step uses one and requests the next node's into the other): copying a set would wait for
             // the loads it had just requested -- the first form did, and a step cost a memory round trip again
             auto step = [&](int k, const BlkOps &o, BlkOps &o1) __attribute__((always_inline)) {
@@ -1308,13 +1316,9 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
 #ifdef BLK_EXP_NO_STORE  // (timing experiments: scripts/r05_blk_parts_exp.sh)
                 if (r[0] == 123456.789) blk_store(pool + (int64_t)j * 384, r);
 #else
-                // the query's components of the tuple; the others only for a block's root (the sweep above the blocks reads a whole
-                // tuple there) -- for every other node they go to the tile's slot 0, which nobody reads before k_blocks_down fills
-                // it: one hot row, and the step's stores stay a fixed number (the counted waits)
+                // the query's components of the tuple (the others: the window loop below stores them for a block's root, where the
+                // sweep above the blocks reads a whole tuple; nobody reads them anywhere else)
                 blk_store_dyn<NS>(pool + (int64_t)j * 384, r);
-                double *sp = (ri.w >> 30) ? pool + (int64_t)j * 384 : pool - 384;
-#pragma unroll
-                for (int x = 0; x < NS; ++x) sp[x * 64] = r[x];
 #endif
             };
             BlkOps oa, ob;
