@@ -1467,6 +1467,8 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 sa.Lpad = Lpad; sa.table = ctx->blosum;
             }
             sa.packed_rm = a.packed_rm; sa.qpacked = csd ? nullptr : qb.packed + q0 * a.G * 3; sa.G = a.G; sa.L = a.L;
+            // the member distances of accepted clusters on the matrix cores (k_cluster_dist_mfma) unless APPLES_DBG_NO_CLUSTER_MFMA
+            sa.cl_mfma = (!csd && !(ctx->dbg & APPLES_DBG_NO_CLUSTER_MFMA)) ? 1 : 0;
             sa.overlap = ctx->params.overlap_frac; sa.rep_stride = a.reps_pad; sa.tmp_d = w.dist;
             sa.slow_hint = w.slow_list + w.batch;
             sa.lvl_slots = a.lvl_slots;
@@ -1765,7 +1767,8 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
             {"APPLES_NO_SD_TOPUP", APPLES_DBG_NO_SD_TOPUP}, {"APPLES_SD_FP6", APPLES_DBG_SD_FP6},
             {"APPLES_NO_TOPUP_OVERLAP", APPLES_DBG_NO_TOPUP_OVERLAP}, {"APPLES_STREAM_THIRD_PASS", APPLES_DBG_STREAM_THIRD_PASS},
             {"APPLES_NO_SD_COMPACT", APPLES_DBG_NO_SD_COMPACT}, {"APPLES_SD_COMPACT_TINY", APPLES_DBG_SD_COMPACT_TINY},
-            {"APPLES_NO_BLOCKS", APPLES_DBG_NO_BLOCKS}, {"APPLES_HYBRID_RECORDS", APPLES_DBG_HYBRID_RECORDS}};
+            {"APPLES_NO_BLOCKS", APPLES_DBG_NO_BLOCKS}, {"APPLES_HYBRID_RECORDS", APPLES_DBG_HYBRID_RECORDS},
+            {"APPLES_NO_CLUSTER_MFMA", APPLES_DBG_NO_CLUSTER_MFMA}};
         for (const auto &k : knobs)
             if (getenv(k.env)) ctx->dbg |= k.bit;
     }

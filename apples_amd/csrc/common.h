@@ -426,6 +426,7 @@ struct SelectArgs {
     // clustered fast path (k_select_clusters): survivors among the representatives come in seg_slot/seg_cnt with
     // row stride rep_stride; member rows are read row-major, the query's words from its packed tile
     const uint4 *packed_rm; const uint4 *qpacked; int G; int L; double overlap; int64_t rep_stride;
+    int cl_mfma;                        // the member distances of accepted clusters on the matrix cores (k_cluster_dist_mfma), not by bit counts (k_cluster_dist)
     double *tmp_d;            // [nq][stride] member distances before the ordered emission
     int flat_pref;            // k_select_fast: the segment counts' prefix fits LDS (set by the launcher)
     // cluster-major member distances (k_select_clusters phases 1-3 around k_cluster_tiles / k_cluster_dist): per cluster the

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "jc69_f4.h"
 
 #define WAVE 64
 
@@ -1233,7 +1234,7 @@ __global__ __launch_bounds__(CL_TILES_TPB) void k_cluster_tiles(SelectArgs a) {
         // taken in table order, and a launch's floor is its longest walk: started first it lies beside the others, not behind them)
         const int64_t c = c0 + tid < a.n_reps ? (a.cl_order ? a.cl_order[c0 + tid] : c0 + tid) : a.n_reps;
         const int cnt = c < a.n_reps ? a.cl_count[c] : 0;
-        const int T = c < a.n_reps ? cluster_tile_queries(a.rep_moff[c + 1] - a.rep_moff[c]) : 1;
+        const int T = c < a.n_reps ? (a.cl_mfma ? 64 : cluster_tile_queries(a.rep_moff[c + 1] - a.rep_moff[c])) : 1;  // (k_cluster_dist_mfma: 64 queries)
         const int nt = (cnt + T - 1) / T;
         int tot_i, tot_t;
         const int at_i = item_base + block_excl_scan_int<CL_TILES_TPB / WAVE>(cnt, sh_i, &tot_i);
@@ -1334,7 +1335,11 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist(SelectArgs a) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int j = jl + k * QL;
+#ifdef CL_EXP_NO_EPILOGUE
+                    if (j < nqt && nv[k] == 0x7fffffffu) {
+#else
                     if (j < nqt) {
+#endif
                         const double d = a.seg_lut[(int64_t)nv[k] * (nv[k] + 1) / 2 + nmis[k]];
                         a.tmp_d[(int64_t)sh_q[j] * a.stride + sh_o[j] + mc0 + ml] = d;
                         // clade blocks: a member the reference drops, an exact match or the query's own row -- the item goes without
@@ -1342,6 +1347,172 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist(SelectArgs a) {
                     }
                 }
             }
+        }
+    }
+}
+
+// The same on the matrix cores (the default): a wavefront = a tile of up to 64 queries x 64 of the cluster's members at a time, the
+// pair counts as in k_jc69_mfma (dist.hip: acc1 = sum t.t over three components, acc2 = valid; mism = (3 valid - acc1) / 4, exact
+// in the f32 accumulators) -- four v_mfma_f32_32x32x64_f8f6f4 per 32 x 32 block of pairs and 64-site block where k_cluster_dist
+// spends ~ 240 vector instructions per pair and keeps the vector pipes 70 % busy (profiles/r05_blk_sq_counters.txt).  Both
+// operands come as bit planes (3 bits per site: the queries' packed rows, the cluster-major member panel; lanes along the rows) and
+// are expanded to fp4 nibbles into the wavefront's own LDS images (expand_quarter, the same encoding on both sides; no workgroup
+// barrier: a workgroup is one wavefront).  (Fed
+// from the queries' pre-expanded fp4 images instead -- 16 bits per site -- the kernel was bound by L2 traffic and slower than the
+// bit counts: 3.9 against 1.3 ms per batch.)  A 32 x 32 block with no query or no member in it is skipped.  Same counts, same table
+// look-up: the same bits as k_cluster_dist.
+#ifndef CLM_WAVES
+#define CLM_WAVES 2  // wavefronts per SIMD k_cluster_dist_mfma is compiled for
+#endif
+__global__ __launch_bounds__(WAVE, CLM_WAVES) void k_cluster_dist_mfma(SelectArgs a) {
+    // the images of one 64-site block, piece-major: piece (component c, quarter k) of row r -- 8 bytes, 16 sites -- at [c * 4 + k][r].  A lane
+    // expands its own row (it holds the row's plane words), so a store instruction writes 64 consecutive pieces and a fragment read
+    // 32 consecutive ones: no bank conflicts either way (row-major images as in k_jc69_mfma cost this kernel four-way conflicts on
+    // every store of the expansion, and the LDS was what it waited for)
+    // Only t1 and t2 go through LDS: t3 is t1 with the sign flipped where t2 is negative and the validity operand is t1 with the sign
+    // bits cleared -- two bit operations per fragment register (as dist_gemm.hip), half the LDS traffic, which is what bounds the loop
+    __shared__ uint2 Aq[8][64];  // the tile's queries
+    __shared__ uint2 Bm[8][64];  // 64 members
+    __shared__ int sh_q[64], sh_o[64], sh_self[64];
+    const int lane = threadIdx.x;
+    const int G = a.G;
+    const int n_tiles = *a.cl_ntiles;
+    auto expand_row = [&](uint2 (*img)[64], uint32_t m, uint32_t c0, uint32_t c1, int half) {  // one 32-site word: quarters 2 half, 2 half + 1 (expand_quarter's arithmetic)
+        const uint32_t K2 = 0x22222222u, K8 = 0x88888888u;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t mm = m >> (2 * k), a0 = c0 >> (2 * k), a1 = c1 >> (2 * k);
+            const uint32_t v0 = (mm << 1) & K2, v1 = mm & K2;
+            const int q = 2 * half + k;
+            img[0 + q][lane] = make_uint2(((a1 << 3) & K8) | v0, ((a1 << 2) & K8) | v1);
+            img[4 + q][lane] = make_uint2(((a0 << 3) & K8) | v0, ((a0 << 2) & K8) | v1);
+        }
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int4 tile = a.cl_tiles[t];
+        const int c = tile.x, nqt = tile.z;
+        const int mb = a.rep_moff[c], sz = a.rep_moff[c + 1] - mb;
+        __builtin_amdgcn_wave_barrier();  // (the previous tile's readers of sh_q / sh_o)
+        {
+            const int2 it = a.cl_items[tile.y + (lane < nqt ? lane : 0)];
+            sh_q[lane] = it.x; sh_o[lane] = it.y;
+            sh_self[lane] = a.self_slot ? a.self_slot[it.x] : -2;  // (-2: no member's slot; my_slot is -1 without the check)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int64_t myq = sh_q[lane];
+        const uint4 *qsrc = a.qpacked + ((myq >> 4) * G * 16 + (myq & 15)) * 3;  // group g, plane pl at ((g * 16) * 3 + pl) beyond this
+        const bool qi1 = nqt > 32;
+        for (int mc0 = 0; mc0 < sz; mc0 += 64) {
+            const int msz = sz - mc0 < 64 ? sz - mc0 : 64;
+            const bool mj1 = msz > 32;
+            const int ml = lane < msz ? lane : msz - 1;  // (lanes beyond the chunk repeat its last member: computed, not written)
+            const uint4 *rsrc = a.packed_rm + (int64_t)mb * (G * 3) + mc0 + ml;
+            v16f_t s1[2][2], s2[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) { s1[i][j][x] = 0.f; s2[i][j][x] = 0.f; }
+            uint4 qm, q0, q1, pm, p0, p1;
+            auto fetch = [&](int g, uint4 &am, uint4 &a0, uint4 &a1, uint4 &bm, uint4 &b0, uint4 &b1) {
+                const uint4 *qp = qsrc + (int64_t)g * 48;
+                am = qp[0]; a0 = qp[1]; a1 = qp[2];
+                const uint4 *rp = rsrc + (int64_t)(g * 3) * sz;
+                bm = rp[0]; b0 = rp[sz]; b1 = rp[2 * (int64_t)sz];
+            };
+            fetch(0, qm, q0, q1, pm, p0, p1);
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    // planes -> the images (the previous block's fragment reads are behind us: one wavefront, program order)
+                    expand_row(Aq, y ? qm.z : qm.x, y ? q0.z : q0.x, y ? q1.z : q1.x, 0);
+                    expand_row(Aq, y ? qm.w : qm.y, y ? q0.w : q0.y, y ? q1.w : q1.y, 1);
+                    expand_row(Bm, y ? pm.z : pm.x, y ? p0.z : p0.x, y ? p1.z : p1.x, 0);
+                    expand_row(Bm, y ? pm.w : pm.y, y ? p0.w : p0.y, y ? p1.w : p1.y, 1);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    {
+                        v4i_t fa[2][2], fb[2][2];  // [t1 | t2][row block]
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {  // sites 32 fh .. 32 fh + 31 of the block: pieces 2 fh and 2 fh + 1
+                                const uint2 a0 = Aq[cc * 4 + 2 * fh][i * 32 + fr], a1 = Aq[cc * 4 + 2 * fh + 1][i * 32 + fr];
+                                const uint2 b0 = Bm[cc * 4 + 2 * fh][i * 32 + fr], b1 = Bm[cc * 4 + 2 * fh + 1][i * 32 + fr];
+                                fa[cc][i] = v4i_t{(int)a0.x, (int)a0.y, (int)a1.x, (int)a1.y};
+                                fb[cc][i] = v4i_t{(int)b0.x, (int)b0.y, (int)b1.x, (int)b1.y};
+                            }
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {  // t1, t2, then t3 and v in t2's and t1's registers
+                            if (cc == 2) {
+#pragma unroll
+                                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        fa[1][i][e] = fa[0][i][e] ^ (fa[1][i][e] & (int)0x88888888u);
+                                        fb[1][i][e] = fb[0][i][e] ^ (fb[1][i][e] & (int)0x88888888u);
+                                    }
+                            }
+                            if (cc == 3) {
+#pragma unroll
+                                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { fa[0][i][e] &= 0x77777777; fb[0][i][e] &= 0x77777777; }
+                            }
+                            const int set = (cc == 0 || cc == 3) ? 0 : 1;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    if ((i == 1 && !qi1) || (j == 1 && !mj1)) continue;  // (wave-uniform)
+                                    if (cc < 3) s1[i][j] = mfma_f4(fa[set][i], fb[set][j], s1[i][j]);
+                                    else s2[i][j] = mfma_f4(fa[set][i], fb[set][j], s2[i][j]);
+                                }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // (the next group's plane words, once this group's are expanded.  A second set requested a group ahead was measured:
+                // 0.95 against 0.88 ms per launch -- its 24 registers spill at two wavefronts per SIMD; one wavefront per SIMD without
+                // spills 1.17, three 2.59: profiles/r05_cluster_dist_exp.txt)
+                if (g + 1 < G) fetch(g + 1, qm, q0, q1, pm, p0, p1);
+            }
+            // C layout of the 32 x 32 blocks: column (member) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+            // A block's 16 table look-ups per lane leave together, then its 16 stores (a look-up behind a store would wait for it:
+            // the compiler cannot tell the table from the rows)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if ((i == 1 && !qi1) || (j == 1 && !mj1)) continue;
+                    const int m = j * 32 + fr;
+                    const bool m_in = m < msz;
+                    const int my_slot = (a.item_bad && a.self_slot) ? a.mem_slot[mb + mc0 + (m_in ? m : 0)] : -1;
+                    double d[16];
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) {
+                        const int nv = (int)s2[i][j][x], nmis = (3 * nv - (int)s1[i][j][x]) >> 2;
+#ifdef CL_EXP_NO_EPILOGUE  // (timing experiment: the main loop alone)
+                        d[x] = (double)(nv + nmis);
+#else
+                        d[x] = a.seg_lut[(int64_t)nv * (nv + 1) / 2 + nmis];
+#endif
+                    }
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) {
+                        const int jq = i * 32 + (x & 3) + 8 * (x >> 2) + 4 * fh;
+#ifdef CL_EXP_NO_EPILOGUE
+                        if (jq < nqt && m_in && d[x] == -12345.0) {
+#else
+                        if (jq < nqt && m_in) {
+#endif
+                            a.tmp_d[(int64_t)sh_q[jq] * a.stride + sh_o[jq] + mc0 + m] = d[x];
+                            // clade blocks: a member the reference drops, an exact match or the query's own row -- the item goes without
+                            if (a.item_bad && (!(d[x] > 0) || my_slot == sh_self[jq])) a.item_bad[tile.y + jq] = 1;
+                        }
+                    }
+                }
         }
     }
 }
@@ -1461,6 +1632,7 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     }
     static const int per_cu = getenv("APPLES_CLUSTER_WGS") ? atoi(getenv("APPLES_CLUSTER_WGS")) : 8;  // tuning knob
     if (sd) hipLaunchKernelGGL(k_cluster_dist_sd<4>, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
+    else if (a.cl_mfma) hipLaunchKernelGGL(k_cluster_dist_mfma, dim3((unsigned)(ctx->n_cu * 4 * CLM_WAVES)), dim3(WAVE), 0, ctx->stream, a);  // (18 KB of LDS per wavefront: eight per CU)
     else hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
     // clade blocks: the S tuples inside them (k_blocks_up), on the sweep's side stream beside the last phase, which names their
     // roots in the observation lists (a bandwidth-bound kernel beside a latency-bound one).  Which items go without blocks is

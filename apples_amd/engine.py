@@ -19,7 +19,7 @@ F_EXACT, F_INSUFFICIENT, F_MISPLACED, F_PENDANT_INT, F_ZERO_NOT_IN_TREE, F_DEGEN
 # apples_params.debug (include/apples_hip.h APPLES_DBG_*): alternative routes to the same placements, fixed at context creation
 DBG = {'no_fuse': 1, 'sweep_scan': 2, 'node_map': 4, 'sweep_merge': 8, 'no_sweep_merge': 16, 'no_dist_gemm': 32, 'no_sweep_lean': 64,
        'no_sd_gemm': 128, 'cluster_by_query': 256, 'no_cluster_topup': 512, 'no_stream_select': 1024, 'no_topup_kernel': 2048,
-       'no_cluster_big': 4096, 'no_sd_topup': 8192, 'sd_fp6': 16384, 'no_topup_overlap': 32768, 'stream_third_pass': 65536, 'no_sd_compact': 131072, 'sd_compact_tiny': 262144, 'no_blocks': 524288, 'hybrid_records': 1048576}
+       'no_cluster_big': 4096, 'no_sd_topup': 8192, 'sd_fp6': 16384, 'no_topup_overlap': 32768, 'stream_third_pass': 65536, 'no_sd_compact': 131072, 'sd_compact_tiny': 262144, 'no_blocks': 524288, 'hybrid_records': 1048576, 'no_cluster_mfma': 2097152}
 T_PACK, T_DIST, T_SELECT, T_SWEEP, T_TOTAL, T_DIST_LAUNCHES, T_FILTER, T_BLOCKS, T_COUNT = range(9)
 
 PLACEMENT_DTYPE = np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'), ('distal', '<f8'),

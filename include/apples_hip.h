@@ -109,7 +109,8 @@ typedef struct {
 #define APPLES_DBG_SD_COMPACT_TINY 262144u /* ... compact lists of 16 entries: nearly every listed query overflows into the row form */
 #define APPLES_DBG_NO_BLOCKS     524288u  /* clustered route: no clade blocks (every observed leaf goes through the per-query merged sweep) */
 #define APPLES_DBG_HYBRID_RECORDS 1048576u /* -c HYBRID: per-edge records + the level loop on every tree (the form of rounds 1 - 4), not the lean sweep's ranking */
-#define APPLES_DBG_ALL           2097151u /* every defined switch; other bits of apples_params.debug are ignored */
+#define APPLES_DBG_NO_CLUSTER_MFMA 2097152u /* clustered route, JC69: the member distances of accepted clusters by bit counts (k_cluster_dist), not on the matrix cores */
+#define APPLES_DBG_ALL           4194303u /* every defined switch; other bits of apples_params.debug are ignored */
 
 /* One placement = the p row runquery returns, [edge_num, likelihood(error), 1, distal, pendant]
  * (apples/Algorithm.py:98-101, apples/PoolQueryWorker.py:36-37,74,88,119-125). */
@@ -132,7 +133,7 @@ typedef struct {
 #define APPLES_F_DEGENERATE  32u  /* >=3 distances but fewer than two of them on tree leaves */
 
 /* ABI of this header: bumped whenever a struct above grows or an entry point changes (4 = apples_params.debug with the
- * switches up to APPLES_DBG_ALL; 5 = apples_params.batch_gib; 6 = APPLES_T_BLOCKS, APPLES_DBG_NO_BLOCKS; 7 = APPLES_DBG_HYBRID_RECORDS).  apples_params has no size field: a caller must zero-initialise it (memset / = {0}) and
+ * switches up to APPLES_DBG_ALL; 5 = apples_params.batch_gib; 6 = APPLES_T_BLOCKS, APPLES_DBG_NO_BLOCKS; 7 = APPLES_DBG_HYBRID_RECORDS, APPLES_DBG_NO_CLUSTER_MFMA).  apples_params has no size field: a caller must zero-initialise it (memset / = {0}) and
  * be built against the header of the library it loads -- check apples_abi_version() == APPLES_ABI_VERSION and
  * apples_params_size() == sizeof(apples_params) once at start-up, as apples_amd/engine.py does.  Bits of `debug` beyond
  * APPLES_DBG_ALL are ignored. */

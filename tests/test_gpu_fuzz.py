@@ -61,11 +61,12 @@ def test_clustered_routes_agree(seed):
     distances, phase 4 for the listed queries, the sweep inside whole subtrees of one cluster on the static schedule of the clade
     blocks) / a thread per (query, member) pair / the listed queries through full rows / full rows + general selection for every
     query / no clade blocks (every observed leaf through the per-query merged sweep) / -c HYBRID through the level loop's per-edge
-    records instead of the lean sweep's ranking (a no-op for the other criteria).  Seed 1 is the stream that exposed the
+    records instead of the lean sweep's ranking (a no-op for the other criteria) / the member distances of accepted clusters by bit
+    counts instead of the matrix cores.  Seed 1 is the stream that exposed the
     round-3 `k_select` fault."""
     rng = np.random.default_rng(seed)
     routes = (('default', ()), ('by_query', ('cluster_by_query',)), ('no_topup', ('no_cluster_topup',)), ('no_fuse', ('no_fuse',)),
-              ('no_blocks', ('no_blocks',)), ('hybrid_records', ('hybrid_records',)))
+              ('no_blocks', ('no_blocks',)), ('hybrid_records', ('hybrid_records',)), ('no_cluster_mfma', ('no_cluster_mfma',)))
     checked = 0
     for c in range(NCFG):  # (seed 1, first 30 configurations: the round-3 script run that found the fault)
         n = int(rng.choice([60, 257, 600, 1500, 5000, 12000])); L = int(rng.integers(40, 2047)); nq = int(rng.integers(1, 900))
@@ -80,7 +81,7 @@ def test_clustered_routes_agree(seed):
                                                 threshold=thr, baseobs=b, max_batch=mb, debug=dbg), d.query_seqs)
         tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s diam %g' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit,
                                                                                           ' -n' if neg else '', diam)
-        for k in ('by_query', 'no_topup', 'no_fuse', 'no_blocks', 'hybrid_records'):
+        for k in ('by_query', 'no_topup', 'no_fuse', 'no_blocks', 'hybrid_records', 'no_cluster_mfma'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
             co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method=m, criterion=crit, negative=neg, threshold=thr, baseobs=b,

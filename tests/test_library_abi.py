@@ -96,10 +96,10 @@ def test_params_struct_layout_matches_header(tmp_path):
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "apples_hip.h"\n'
                    'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(apples_params), offsetof(apples_params, filt_threshold), '
                    'offsetof(apples_params, jc_lut), offsetof(apples_params, max_batch), offsetof(apples_params, debug), offsetof(apples_params, batch_gib)); '
-                   'printf("%u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u\\n", APPLES_DBG_NO_FUSE, APPLES_DBG_SWEEP_SCAN, APPLES_DBG_NODE_MAP, APPLES_DBG_SWEEP_MERGE, '
+                   'printf("%u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u %u\\n", APPLES_DBG_NO_FUSE, APPLES_DBG_SWEEP_SCAN, APPLES_DBG_NODE_MAP, APPLES_DBG_SWEEP_MERGE, '
                    'APPLES_DBG_NO_SWEEP_MERGE, APPLES_DBG_NO_DIST_GEMM, APPLES_DBG_NO_SWEEP_LEAN, APPLES_DBG_NO_SD_GEMM, APPLES_DBG_CLUSTER_BY_QUERY, '
                    'APPLES_DBG_NO_CLUSTER_TOPUP, APPLES_DBG_NO_STREAM_SELECT, APPLES_DBG_NO_TOPUP_KERNEL, APPLES_DBG_NO_CLUSTER_BIG, '
-                   'APPLES_DBG_NO_SD_TOPUP, APPLES_DBG_SD_FP6, APPLES_DBG_NO_TOPUP_OVERLAP, APPLES_DBG_STREAM_THIRD_PASS, APPLES_DBG_NO_SD_COMPACT, APPLES_DBG_SD_COMPACT_TINY, APPLES_DBG_NO_BLOCKS, APPLES_DBG_HYBRID_RECORDS, APPLES_DBG_ALL); return 0; }\n')
+                   'APPLES_DBG_NO_SD_TOPUP, APPLES_DBG_SD_FP6, APPLES_DBG_NO_TOPUP_OVERLAP, APPLES_DBG_STREAM_THIRD_PASS, APPLES_DBG_NO_SD_COMPACT, APPLES_DBG_SD_COMPACT_TINY, APPLES_DBG_NO_BLOCKS, APPLES_DBG_HYBRID_RECORDS, APPLES_DBG_NO_CLUSTER_MFMA, APPLES_DBG_ALL); return 0; }\n')
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     out = subprocess.check_output([str(exe)], text=True).split('\n')
@@ -109,6 +109,6 @@ def test_params_struct_layout_matches_header(tmp_path):
     assert (P.filt_threshold.offset, P.jc_lut.offset, P.max_batch.offset, P.debug.offset, P.batch_gib.offset) == (o_thr, o_lut, o_mb, o_dbg, o_gib)
     bits = list(map(int, out[1].split()))
     names = ('no_fuse', 'sweep_scan', 'node_map', 'sweep_merge', 'no_sweep_merge', 'no_dist_gemm', 'no_sweep_lean', 'no_sd_gemm',
-             'cluster_by_query', 'no_cluster_topup', 'no_stream_select', 'no_topup_kernel', 'no_cluster_big', 'no_sd_topup', 'sd_fp6', 'no_topup_overlap', 'stream_third_pass', 'no_sd_compact', 'sd_compact_tiny', 'no_blocks', 'hybrid_records')
+             'cluster_by_query', 'no_cluster_topup', 'no_stream_select', 'no_topup_kernel', 'no_cluster_big', 'no_sd_topup', 'sd_fp6', 'no_topup_overlap', 'stream_third_pass', 'no_sd_compact', 'sd_compact_tiny', 'no_blocks', 'hybrid_records', 'no_cluster_mfma')
     assert bits[:-1] == [engine.DBG[k] for k in names]
     assert bits[-1] == sum(engine.DBG.values()) and len(engine.DBG) == len(names)  # APPLES_DBG_ALL = every switch
