@@ -1634,33 +1634,9 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (sd) hipLaunchKernelGGL(k_cluster_dist_sd<4>, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
     else if (a.cl_mfma) hipLaunchKernelGGL(k_cluster_dist_mfma, dim3((unsigned)(ctx->n_cu * 4 * CLM_WAVES)), dim3(WAVE), 0, ctx->stream, a);  // (18 KB of LDS per wavefront: eight per CU)
     else hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
-    // clade blocks: the S tuples inside them (k_blocks_up), on the sweep's side stream beside the last phase, which names their
-    // roots in the observation lists (a bandwidth-bound kernel beside a latency-bound one).  Which items go without blocks is
-    // k_cluster_dist's finding (item_bad), where their tuples will be phase 2's arithmetic: the last phase needs nothing of this kernel
-    auto blocks_up = [&]() -> int {
-        if (!a.blk_tiles) return 0;
-        BlockArgs b{};
-        b.tiles = a.blk_tiles; b.n_tiles = a.blk_ntiles; b.items = a.cl_items; b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.stat = a.blk_stat;
-        b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos; b.self_slot = a.self_slot; b.tmp_d = a.tmp_d;
-        b.stride = a.stride; b.pool = a.blk_pool; b.item_sbase = a.item_sbase; b.item_bad = a.item_bad; b.cursor = a.q_item_cursor + 1; b.method = a.method;
-        static const bool serial = getenv("APPLES_BLK_SERIAL") != nullptr;  // experiment knob: k_blocks_up on the main stream
-        hipStream_t bs = serial ? ctx->stream : ctx->stream_big;
-        HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_blk[0], 0));
-        const bool timed = ctx->ev_blk_time[0] && ctx->ev_blk_time[1];
-        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[0], bs));
-        if (launch_blocks_up(ctx, b, bs)) return 1;
-        if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[1], bs)); ctx->ev_blk_time[0] = nullptr; }  // (recorded: run_block reads them)
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[1], bs));
-        return 0;
-    };
-    // APPLES_BLK_FIRST: k_blocks_up's persistent workgroups enter before the last phase's (experiment knob; the default lets the
-    // last phase's short workgroups in first: the persistent ones find their places as those retire, and both kernels run side
-    // by side from the start -- the other way round the last phase waits for places the persistent workgroups never give back)
-    static const bool blocks_first = getenv("APPLES_BLK_FIRST") != nullptr;
-    if (a.blk_tiles) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[0], ctx->stream));
-    if (blocks_first && blocks_up()) return 1;
     // the second form's last phase beside the first's, on the spare stream: a hundred-odd workgroups of 1 024 threads (their
     // rounds of member lookups are what such a workgroup takes: a quarter of the rounds of 256 threads) leave the chip idle
+    if (a.blk_tiles) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[0], ctx->stream));
     if (big) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_cl[0], ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_cl[0], 0));
@@ -1668,7 +1644,24 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_cl[1], ctx->stream2));
     }
     hipLaunchKernelGGL(k_select_clusters<3>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
-    if (!blocks_first && blocks_up()) return 1;
+    // clade blocks: the S tuples inside them (k_blocks_up), on the sweep's side stream beside the last phase, which names their
+    // roots in the observation lists.  Which items go without blocks is k_cluster_dist's finding (item_bad), where their tuples will
+    // be is phase 2's arithmetic: the last phase needs nothing of this kernel.  Launched AFTER the last phase: that one's short
+    // workgroups get in first and the persistent ones of k_blocks_up find their places as those retire; the other way round, or
+    // both on one stream, the pass is 0.3 - 0.5 ms longer (profiles/r05_blk_order_exp.txt)
+    if (a.blk_tiles) {
+        BlockArgs bb{};
+        bb.tiles = a.blk_tiles; bb.n_tiles = a.blk_ntiles; bb.items = a.cl_items; bb.rec_i = a.blk_rec_i; bb.rec_e = a.blk_rec_e; bb.stat = a.blk_stat;
+        bb.rep_soff = a.rep_soff; bb.rep_moff = a.rep_moff; bb.slot_rep = a.slot_rep; bb.slot_mpos = a.slot_mpos; bb.self_slot = a.self_slot; bb.tmp_d = a.tmp_d;
+        bb.stride = a.stride; bb.pool = a.blk_pool; bb.item_sbase = a.item_sbase; bb.item_bad = a.item_bad; bb.cursor = a.q_item_cursor + 1; bb.method = a.method;
+        hipStream_t bs = ctx->stream_big;
+        HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_blk[0], 0));
+        const bool timed = ctx->ev_blk_time[0] && ctx->ev_blk_time[1];
+        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[0], bs));
+        if (launch_blocks_up(ctx, bb, bs)) return 1;
+        if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[1], bs)); ctx->ev_blk_time[0] = nullptr; }  // (recorded: run_block reads them)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[1], bs));
+    }
     if (big) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cl[1], 0));
     HIP_TRY(ctx, hipGetLastError());
     return 0;

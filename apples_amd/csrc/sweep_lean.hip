@@ -1521,9 +1521,9 @@ int launch_blocks_up(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
     // tuning knob (82 registers: up to five or six wavefronts per SIMD -- but the kernel is bound by its pool traffic, not by the
     // wavefronts in flight: 6 / 4 / 3 / 2 workgroups per CU give 34.6 / 34.7 / 34.3 / 33.7 ms on config 3's clustered pass,
     // profiles/r05_blk_order_exp.txt, and the fewer there are the more room the selection's last phase has beside them)
+    // then one per CU (32.6 against 33.5 ms at two; a grid of 64 / 128 / 192 workgroups: 46.2 / 35.7 / 32.4 ms)
     static const int per_cu = getenv("APPLES_BLK_UP_WGS") ? atoi(getenv("APPLES_BLK_UP_WGS")) : 1;
-    static const int total = getenv("APPLES_BLK_UP_GRID") ? atoi(getenv("APPLES_BLK_UP_GRID")) : 0;  // experiment knob: the grid itself
-    const dim3 grid((unsigned)(total > 0 ? total : cus * std::max(per_cu, 1))), block(APPLES_TPB);
+    const dim3 grid((unsigned)(cus * std::max(per_cu, 1))), block(APPLES_TPB);
     HIP_TRY(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int32_t), st));
     switch (a.method) {
         case APPLES_FM: hipLaunchKernelGGL((k_blocks_up<APPLES_FM>), grid, block, 0, st, a); break;
@@ -1538,8 +1538,9 @@ int launch_blocks_up(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
 // ... and after the sweep above the blocks: the top-down pass inside them, then the queries' placements
 int launch_blocks_down(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
     const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    static const int per_cu = getenv("APPLES_BLK_DOWN_WGS") ? atoi(getenv("APPLES_BLK_DOWN_WGS")) : BLK_DOWN_WAVES;  // tuning knob (186 registers: two wavefronts per SIMD)
-    const dim3 grid((unsigned)(cus * std::min(std::max(per_cu, 1), BLK_DOWN_WAVES))), block(APPLES_TPB);
+    // (193 registers: two wavefronts per SIMD; one workgroup per CU instead of two: the sweep phase 15.2 -> 18.7 ms; compiled for
+    // three with 23 registers spilled: 16.5, profiles/r05_blk_order_exp.txt)
+    const dim3 grid((unsigned)(cus * BLK_DOWN_WAVES)), block(APPLES_TPB);
     HIP_TRY(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int32_t), st));
     switch (a.method) {
         case APPLES_FM: hipLaunchKernelGGL((k_blocks_down<APPLES_FM>), grid, block, 0, st, a); break;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # k_blocks_up beside the last phase of the clustered selection: which of the two is launched first, on one stream or two, and how
-# many persistent workgroups per CU k_blocks_up gets.  usage on the GPU box: bash scripts/r05_blk_order_exp.sh
+# many persistent workgroups per CU k_blocks_up gets.  (APPLES_BLK_FIRST / APPLES_BLK_SERIAL: knobs of the library up to commit 27f4222.)
+# usage on the GPU box: bash scripts/r05_blk_order_exp.sh
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/r05_blk_order.txt
 : > $OUT
