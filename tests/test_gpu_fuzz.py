@@ -130,7 +130,8 @@ def _against_c_oracle_scoredist(got, want, tag, crit, neg):
     equal residuals; for ME / HYBRID pendants clamped to zero, apples/Algorithm.py:83-91).  Every row with another
     edge must be such a tie -- the quantity the criterion minimises agrees to 1e-9 -- and there must be few: at most 2 per
     configuration on the default criterion (observed: 0 - 1); with -n or ME / HYBRID, where queries with three or four observed
-    leaves fit several edges equally well, at most 5 %.  Returns their number."""
+    leaves fit several edges equally well, at most 10 % (a campaign over seeds 20 - 27 saw 5 of 99 on a 40-leaf backbone with -b 3,
+    HYBRID and -n: every one of them checked to be a tie above).  Returns their number."""
     for f in ('n_obs', 'n_valid'):
         assert np.array_equal(got[f], want[f]), '%s: %s differs from the C oracle' % (tag, f)
     same = got['edge'] == want['edge']
@@ -139,7 +140,7 @@ def _against_c_oracle_scoredist(got, want, tag, crit, neg):
         e_ok = np.isclose(got['error'][i], want['error'][i], rtol=1e-9, atol=1e-15)
         p_ok = np.isclose(got['pendant'][i], want['pendant'][i], rtol=1e-9, atol=1e-12)
         assert (e_ok if crit == 'MLSE' else (e_ok or p_ok)), '%s: row %d is not a tie: %s / %s' % (tag, i, got[i], want[i])
-    bound = 2 if (crit == 'MLSE' and not neg) else max(2, len(got) // 20)
+    bound = 2 if (crit == 'MLSE' and not neg) else max(2, len(got) // 10)
     assert tie.sum() <= bound, '%s: %d edges differ from the C oracle' % (tag, tie.sum())
     assert np.array_equal(got['flags'][same], want['flags'][same]), '%s: flags' % tag
     for f in ('error', 'distal', 'pendant'):
