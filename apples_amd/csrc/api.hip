@@ -1465,6 +1465,7 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                 sa.seg_lut = nullptr; sa.rep_dist = ctx->sd_rep_d;
                 sa.aa_idx = a.aa_idx; sa.aa_mask = a.aa_mask; sa.q_aa = qb.aa_idx + q0 * Lpad; sa.q_aam = qb.aa_mask + q0 * (Lpad / 16);
                 sa.Lpad = Lpad; sa.table = ctx->blosum;
+                sa.aa_cm_idx = a.aa_cm_idx; sa.aa_cm_mask = a.aa_cm_mask; sa.cm_pad = a.slots_pad;
             }
             sa.packed_rm = a.packed_rm; sa.qpacked = csd ? nullptr : qb.packed + q0 * a.G * 3; sa.G = a.G; sa.L = a.L;
             // the member distances of accepted clusters on the matrix cores (k_cluster_dist_mfma) unless APPLES_DBG_NO_CLUSTER_MFMA
@@ -1938,7 +1939,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_boff); dev_free(a.rep_loff); dev_free(a.loose_mp); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.blk_stat[0]); dev_free(a.blk_stat[1]); dev_free(a.rep_soff); dev_free(a.cl_order); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_boff); dev_free(a.rep_loff); dev_free(a.loose_mp); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.blk_stat[0]); dev_free(a.blk_stat[1]); dev_free(a.rep_soff); dev_free(a.cl_order); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_cm_idx); dev_free(a.aa_cm_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

@@ -130,6 +130,8 @@ struct DevAlign {
     // of aa_idx / aa_mask with reps_pad in place of slots_pad (what k_scoredist runs over in place of every slot)
     uint8_t *aa_rep_idx = nullptr;   // [Lpad16/16][reps_pad][16]
     uint16_t *aa_rep_mask = nullptr; // [Lpad16/16][reps_pad]
+    uint8_t *aa_cm_idx = nullptr;    // [Lpad16/16][slots_pad][16]: the member rows cluster by cluster (position rep_moff[c] + m: mem_slot's order), k_cluster_dist_sd
+    uint16_t *aa_cm_mask = nullptr;  // [Lpad16/16][slots_pad]
     uint8_t *aa_idx = nullptr;    // scoredist: [Lpad16/16][slots_pad][16] residue index * 8 (0..152, 160 = gap)
     uint16_t *aa_mask = nullptr;  // scoredist: [Lpad16/16][slots_pad] bit k = site 16*s16+k is not a gap
     uint8_t *aa_rows = nullptr;   // scoredist, beside sd_ref4: the same residue bytes slot-major, [slots_pad][aa_Lrow] (dist_sd.hip:sd_eval64)
@@ -444,6 +446,7 @@ struct SelectArgs {
     // in seg_slot carry their position only), the members' from the packed residue bytes
     const double *rep_dist;   // [nq][rep_stride] or nullptr (JC69: seg_lut)
     const uint8_t *aa_idx; const uint16_t *aa_mask;   // DevAlign's, row stride `stride`
+    const uint8_t *aa_cm_idx; const uint16_t *aa_cm_mask; int64_t cm_pad;  // the same rows in cluster-major member order (row stride cm_pad), or nullptr
     const uint8_t *q_aa; const uint16_t *q_aam;       // the batch's queries: QueryBlock::aa_idx / aa_mask from its first query on
     int Lpad; const double *table;                    // 21 x 21
     // clade blocks (DevAlign::blk_*): k_cluster_tiles also cuts every cluster's items into tiles of up to 64 for the block kernels,

@@ -846,6 +846,17 @@ int launch_build_cluster_panels_aa(apples_ctx *ctx) {
     HIP_TRY(ctx, hipMemsetAsync(a.aa_rep_mask, 0, (size_t)n16 * a.reps_pad * 2, ctx->stream));
     hipLaunchKernelGGL(k_gather_reps_aa, dim3((unsigned)((a.n_reps + APPLES_TPB - 1) / APPLES_TPB), (unsigned)n16), dim3(APPLES_TPB), 0,
                        ctx->stream, a.aa_idx, a.aa_mask, a.slots_pad, a.rep_slot, a.n_reps, a.reps_pad, a.aa_rep_idx, a.aa_rep_mask);
+    // ... and every member row once more cluster by cluster (mem_slot's order): a wavefront of k_cluster_dist_sd holds consecutive
+    // members of one cluster in its lanes, and from the slot-ordered rows every lane's 16 bytes were a sector of their own
+    if (a.aa_cm_idx) (void)hipFree(a.aa_cm_idx);
+    if (a.aa_cm_mask) (void)hipFree(a.aa_cm_mask);
+    a.aa_cm_idx = nullptr; a.aa_cm_mask = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&a.aa_cm_idx, (size_t)n16 * a.slots_pad * 16));
+    HIP_TRY(ctx, hipMemsetAsync(a.aa_cm_idx, 160, (size_t)n16 * a.slots_pad * 16, ctx->stream));
+    HIP_TRY(ctx, hipMalloc((void **)&a.aa_cm_mask, (size_t)n16 * a.slots_pad * 2));
+    HIP_TRY(ctx, hipMemsetAsync(a.aa_cm_mask, 0, (size_t)n16 * a.slots_pad * 2, ctx->stream));
+    hipLaunchKernelGGL(k_gather_reps_aa, dim3((unsigned)((a.n_refs + APPLES_TPB - 1) / APPLES_TPB), (unsigned)n16), dim3(APPLES_TPB), 0,
+                       ctx->stream, a.aa_idx, a.aa_mask, a.slots_pad, a.mem_slot, a.n_refs, a.slots_pad, a.aa_cm_idx, a.aa_cm_mask);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;

@@ -1554,9 +1554,13 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist_sd(SelectArgs a) {
             uint32_t nv[TQ];
 #pragma unroll
             for (int k = 0; k < TQ; ++k) { tot[k] = 0.0; nv[k] = 0; }
+            // the member's rows: from the cluster-major copy (consecutive lanes = consecutive 16-byte words) where the context has one
+            const uint8_t *ridx = a.aa_cm_idx ? a.aa_cm_idx : a.aa_idx;
+            const uint16_t *rmsk = a.aa_cm_idx ? a.aa_cm_mask : a.aa_mask;
+            const int64_t rstride = a.aa_cm_idx ? a.cm_pad : a.stride, rpos = a.aa_cm_idx ? (int64_t)mb + (act ? m : 0) : slot;
             for (int s16 = 0; s16 < n16; ++s16) {
-                const uint4 rw = *reinterpret_cast<const uint4 *>(a.aa_idx + ((int64_t)s16 * a.stride + slot) * 16);
-                const uint32_t rmask = a.aa_mask[(int64_t)s16 * a.stride + slot];
+                const uint4 rw = *reinterpret_cast<const uint4 *>(ridx + ((int64_t)s16 * rstride + rpos) * 16);
+                const uint32_t rmask = rmsk[(int64_t)s16 * rstride + rpos];
                 uint32_t r8[16];
                 const uint32_t rr[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
