@@ -2510,12 +2510,12 @@ const char *apples_describe(apples_ctx *ctx) {
     if (ctx->blk_counters && hipStreamSynchronize(ctx->stream) == hipSuccess)
         (void)hipMemcpy(blk_cnt, ctx->blk_counters, sizeof blk_cnt, hipMemcpyDeviceToHost);
     snprintf(buf, sizeof buf,
-             "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"n_rows\": %lld, "
+             "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"max_children\": %d, \"n_rows\": %lld, "
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
              "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\", "
              "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld, \"sweep_layout\": \"%s\", \"cluster_fused\": %d, "
              "\"scoredist_filter\": %d, \"scoredist_image_bytes\": %lld, \"cluster_blocks\": %d, \"block_items_last_batch\": %d, \"block_tiles_last_batch\": %d}",
-             name, cus, ctx->tree.n_nodes, ctx->tree.height, (long long)a.n_rows, (long long)a.n_refs,
+             name, cus, ctx->tree.n_nodes, ctx->tree.height, ctx->tree.max_children, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
              (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
              (long long)ctx->ws.small.cap, ctx->ws.big.wgs, ctx->jc_lut ? 1 : 0, ctx->tree.scan ? "scan" : "levels",

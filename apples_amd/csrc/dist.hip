@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "libm_log.h"
 
 __device__ __forceinline__ double jc69_from_counts(uint32_t mism, uint32_t valid, int L, double overlap,
                                                    const double *__restrict__ lut) {
@@ -22,7 +23,7 @@ __device__ __forceinline__ double jc69_from_counts(uint32_t mism, uint32_t valid
     if (p - 2.220446049250313e-16 < 0) return 0.0;
     double loc = 1 - (4 * p / 3);
     if (0 >= loc) return -1.0;
-    return -0.75 * log(loc);
+    return -0.75 * log_libm(loc);
 }
 
 // popcount with the instruction's own accumulate operand (D = popc(S0) + S1); hipcc otherwise emits
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_scoredist(const uint8_t *__restr
             else {
                 double r1 = 1 - tot[t] / (double)valid;
                 if (0 >= r1) d = -1.0;
-                else d = -log(r1) * 1.3;
+                else d = -log_libm(r1) * 1.3;
             }
             if (MODE == 1) {
                 // (a query dropped from the site loop has no pair left that can pass; the pairs of the others whose sums
@@ -909,5 +910,35 @@ int launch_scoredist_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, i
                        qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, d_dist, (uint32_t *)nullptr, a.n_rows, a.slots_pad, Lpad, a.L,
                        nq_max, ctx->params.overlap_frac, 0.0, 0.0, (int32_t *)nullptr, (int32_t *)nullptr, qlist, qcount);
     HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- diagnostic: the kernels' logarithm on an array (include/apples_hip.h: apples_device_log) ------------------------------
+namespace {
+__global__ void k_log_array(const double *__restrict__ x, double *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = log_libm(x[i]);
+}
+}  // namespace
+
+extern "C" int apples_device_log(int device, const double *x, int64_t n, double *out) {
+    if (n <= 0) return 0;
+    double *d_x = nullptr, *d_o = nullptr;
+    auto fail = [&](const char *what, hipError_t e) {
+        g_create_error = std::string("apples_device_log: ") + what + ": " + hipGetErrorString(e);
+        if (d_x) (void)hipFree(d_x);
+        if (d_o) (void)hipFree(d_o);
+        return 1;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipMalloc(&d_x, (size_t)n * 8)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&d_o, (size_t)n * 8)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMemcpy(d_x, x, (size_t)n * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+    hipLaunchKernelGGL(k_log_array, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d_x, d_o, n);
+    if ((e = hipGetLastError()) != hipSuccess) return fail("launch", e);
+    if ((e = hipMemcpy(out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost)) != hipSuccess) return fail("hipMemcpy", e);
+    (void)hipFree(d_x);
+    (void)hipFree(d_o);
     return 0;
 }

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "libm_log.h"
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v8i_t __attribute__((ext_vector_type(8)));
@@ -501,7 +502,7 @@ __device__ __forceinline__ double sd_eval64(const uint8_t *__restrict__ rrows, c
     if (ratio) *ratio = tot / (double)valid;
     const double r1 = 1 - tot / (double)valid;
     if (0 >= r1) return -1.0;
-    return -log(r1) * 1.3;
+    return -log_libm(r1) * 1.3;
 }
 
 // slot-major copy of the packed reference rows for sd_eval64: rows[slot][Lrow] = residue index * 8 (160 = gap, also past the

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "libm_log.h"
 #include "jc69_f4.h"
 
 #define WAVE 64
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
         if (nv == 0 || (double)nv / (double)a.L < a.overlap) return -1.0;
         const double r1 = 1 - tot / (double)nv;
         if (0 >= r1) return -1.0;
-        return -log(r1) * 1.3;
+        return -log_libm(r1) * 1.3;
     };
     if (PHASE == 0 || PHASE >= 3)
         for (int i = tid; i < n_words; i += TPB) dyn_bits[i] = 0;
@@ -1594,7 +1595,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist_sd(SelectArgs a) {
                     else {
                         const double r1 = 1 - tot[k] / (double)valid;
                         if (0 >= r1) d = -1.0;
-                        else d = -log(r1) * 1.3;
+                        else d = -log_libm(r1) * 1.3;
                     }
                     a.tmp_d[qi[k] * a.stride + sh_o[j] + m] = d;
                     if (a.item_bad && (!(d > 0) || (a.self_slot && slot == a.self_slot[qi[k]]))) a.item_bad[tile.y + j] = 1;  // (as k_cluster_dist)

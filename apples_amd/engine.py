@@ -28,7 +28,7 @@ PLACEMENT_DTYPE = np.dtype([('edge', '<i4'), ('flags', '<u4'), ('error', '<f8'),
 EXPORTS = ['apples_ctx_create', 'apples_ctx_destroy', 'apples_last_error', 'apples_set_params', 'apples_distances',
            'apples_place_from_sequences', 'apples_place_from_distances', 'apples_sweep_edges', 'apples_place_sequences_streamed',
            'apples_queries_upload', 'apples_table_upload', 'apples_queries_free', 'apples_place_resident', 'apples_fetch_placements',
-           'apples_distances_resident', 'apples_placements_device_ptr', 'apples_last_timing', 'apples_describe',
+           'apples_distances_resident', 'apples_placements_device_ptr', 'apples_last_timing', 'apples_describe', 'apples_device_log',
            'apples_backbone_lengths', 'apples_abi_version', 'apples_params_size']
 ABI_VERSION = 7  # include/apples_hip.h APPLES_ABI_VERSION
 
@@ -93,6 +93,7 @@ def load_library():
     lib.apples_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.apples_backbone_lengths.argtypes = [C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_void_p]
+    lib.apples_device_log.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     # the mirror structs here must be the library's: a library built from another header is refused, not guessed at
     lib.apples_abi_version.restype = C.c_uint32
     lib.apples_params_size.restype = C.c_size_t
@@ -149,6 +150,16 @@ def backbone_lengths(parent, children, leaf_row, rows, protein, device=0, site_c
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_log(x, device=0):
+    """The distance kernels' logarithm on an array of positive doubles (apples_device_log: libm's log bit for bit)."""
+    lib = load_library()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    if lib.apples_device_log(int(device), _ptr(x), x.size, _ptr(out)) != 0:
+        raise RuntimeError(lib.apples_last_error(None).decode())
+    return out
 
 
 class Engine:

@@ -19,8 +19,9 @@ NT = np.frombuffer(b'ACGT', dtype=np.uint8)
 AA = np.frombuffer(b'ARNDCQEGHILKMFPSTWYV', dtype=np.uint8)
 
 
-def random_tree_newick(n_leaves, seed=1, mean_len=0.01):
-    """Random-join binary tree as a Newick string (iterative, O(N))."""
+def random_tree_newick(n_leaves, seed=1, mean_len=0.01, spine=0):
+    """Random-join binary tree as a Newick string (iterative, O(N)).  spine > 0: the joining stops at spine + 1
+    subtrees, which are hung on a caterpillar of `spine` nodes (the deep-backbone shape: more than `spine` levels)."""
     rng = np.random.default_rng(seed)
     # node table: children of internal nodes; leaves 0..n-1
     left = []
@@ -29,13 +30,20 @@ def random_tree_newick(n_leaves, seed=1, mean_len=0.01):
     nxt = n_leaves
     picks = rng.random(2 * n_leaves)
     pi = 0
-    while len(roots) > 1:
+    while len(roots) > 1 + max(int(spine), 0):
         i = int(picks[pi] * len(roots)); pi += 1
         roots[i], roots[-1] = roots[-1], roots[i]
         a = roots.pop()
         j = int(picks[pi] * len(roots)); pi += 1
         roots[j], roots[-1] = roots[-1], roots[j]
         b = roots.pop()
+        left.append(a)
+        right.append(b)
+        roots.append(nxt)
+        nxt += 1
+    while len(roots) > 1:  # the caterpillar: (subtree, (subtree, (... (subtree, subtree))))
+        b = roots.pop()
+        a = roots.pop()
         left.append(a)
         right.append(b)
         roots.append(nxt)
@@ -68,6 +76,65 @@ def random_tree_newick(n_leaves, seed=1, mean_len=0.01):
     return ''.join(out)
 
 
+def reshape_newick(tree, kind, seed=11, frac=0.01):
+    """The same backbone with another shape, as Newick text (same leaves in the same left-to-right order, same root
+    distances of the leaves): what real inputs look like beside the strictly binary random-join tree --
+    * 'unrooted': the root's first internal child is dissolved into the root (a root trifurcation: what FastTree prints and
+      what the reference's own example backbones have);
+    * 'polytomies': a fraction `frac` of the internal non-root nodes is dissolved into their parents (seeded)."""
+    n = tree.n_nodes
+    kids = [list(map(int, tree.children(v))) for v in range(n)]
+    lens = np.array(tree.edge_len, dtype=np.float64)
+    labels = tree.labels
+    root = tree.root
+    gone = np.zeros(n, bool)
+    if kind == 'unrooted':
+        for c in kids[root]:
+            if kids[c]:
+                gone[c] = True
+                break
+    elif kind == 'polytomies':
+        rng = np.random.default_rng(seed)
+        internal = np.array([v for v in range(n) if kids[v] and v != root])
+        gone[internal[rng.random(len(internal)) < frac]] = True
+    else:
+        raise ValueError(kind)
+    out = []
+    stack = [(root, 0, 0.0)]  # node, next child, length inherited from dissolved ancestors
+    while stack:
+        v, k, add = stack.pop()
+        if not kids[v]:
+            out.append('%s:%.6f' % (labels[v], lens[v] + add))
+            continue
+        if gone[v]:  # its children take its place (and its length)
+            for c in reversed(kids[v]):
+                stack.append((c, 0, add + lens[v]))
+            continue
+        if k == 0:
+            out.append('(')
+            stack.append((v, 1, add))
+            # the children in file order, a marker between them
+            seq = []
+            for c in kids[v]:
+                seq.append((c, 0, 0.0))
+            for item in reversed(seq):
+                stack.append(item)
+        else:
+            out.append(')' if v == root else '):%.6f' % (lens[v] + add))
+    # commas: between consecutive siblings = wherever a token that ends a subtree is followed by one that starts one
+    text = []
+    for i, tok in enumerate(out):
+        if i and out[i - 1] != '(' and not tok.startswith(')'):
+            text.append(',')
+        text.append(tok)
+    text.append(';')
+    return ''.join(text)
+
+
+def reshape_tree(tree, kind, seed=11, frac=0.01):
+    return parse_newick(reshape_newick(tree, kind, seed, frac))
+
+
 def _sub_prob(t, n_states):
     k = n_states / (n_states - 1.0)
     return (1.0 - 1.0 / n_states) * (1.0 - np.exp(-k * t))
@@ -89,12 +156,12 @@ class SynthData:
 
 
 def make_dataset(n_leaves, length, n_queries, protein=False, seed_tree=1, seed_aln=5, seed_query=3,
-                 gap_rate=0.05, mean_len=0.01):
+                 gap_rate=0.05, mean_len=0.01, spine=0):
     """Returns an object with: newick, tree, ref_names, ref_seqs uint8[N,L] (rows in
     leaf order), query_names, query_seqs uint8[Q,L], query_leaf (true sister leaf)."""
     alphabet = AA if protein else NT
     ns = len(alphabet)
-    newick = random_tree_newick(n_leaves, seed_tree, mean_len)
+    newick = random_tree_newick(n_leaves, seed_tree, mean_len, spine)
     tree = parse_newick(newick)
     rng = np.random.default_rng(seed_aln)
     n = tree.n_nodes

@@ -384,9 +384,45 @@ def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_st
     return roofline
 
 
-def other_workload(name, device, steps=3, ds=None, queries=0):
+def variant_dataset(ds, variant, n_leaves, L, Q, protein):
+    """Config 3's inputs in the shapes real inputs have beside the strictly binary, shallow, ACGT--only synthetic set:
+    'unrooted' (the same tree with its root trifurcated: what FastTree prints and what both of the reference's example
+    backbones look like), 'polytomies' (1 % of the internal nodes dissolved into their parents), 'deep' (the random-join
+    subtrees hung on a caterpillar spine of 400 nodes: more than 254 levels; its own alignment), 'dots' (one `.` per 1 000
+    sites in 5 % of the reference rows and one query with a `?`: bytes beyond ACGT-, ordinary symbols to
+    apples/distance.py:733-737), 'L4000' (every row four times over: the same distances from four times the sites),
+    '300k' (300 000 leaves: its own alignment)."""
+    import copy
+    from apples_amd import synth
+    if variant == 'deep':
+        return synth.make_dataset(n_leaves, L, Q, protein=protein, spine=400)
+    if variant == '300k':
+        return synth.make_dataset(300000, L, Q, protein=protein)
+    d = copy.copy(ds if ds is not None else synth.make_dataset(n_leaves, L, Q, protein=protein))
+    if variant in ('unrooted', 'polytomies'):
+        d.newick = synth.reshape_newick(d.tree, variant)
+        d.tree = synth.parse_newick(d.newick)
+    elif variant == 'dots':
+        rng = np.random.default_rng(17)
+        d.ref_seqs = d.ref_seqs.copy()
+        rows = np.nonzero(rng.random(len(d.ref_seqs)) < 0.05)[0]
+        for k in range((L + 999) // 1000):
+            lo, hi = 1000 * k, min(L, 1000 * (k + 1))
+            d.ref_seqs[rows, rng.integers(lo, hi, size=len(rows))] = ord('.')
+        d.query_seqs = d.query_seqs.copy()
+        d.query_seqs[0, int(rng.integers(0, L))] = ord('?')
+    elif variant == 'L4000':
+        d.ref_seqs = np.ascontiguousarray(np.tile(d.ref_seqs, (1, 4)))
+        d.query_seqs = np.ascontiguousarray(np.tile(d.query_seqs[:Q], (1, 4)))
+    elif variant:
+        raise ValueError(variant)
+    return d
+
+
+def other_workload(name, device, steps=3, ds=None, queries=0, variant=None, prepared=False):
     """A compact leg of another BASELINE config for the driver's line: `steps` timed passes (host buffers -> placements in
-    host memory; config 5: the table block resident), per-kernel HIP-event times, the dominant kernel's roofline.  No CPU leg."""
+    host memory; config 5: the table block resident), per-kernel HIP-event times, the dominant kernel's roofline.  No CPU leg.
+    variant: see variant_dataset (config 3's size in the shapes the fast routes used to refuse)."""
     from apples_amd import synth
     from apples_amd.engine import Engine
     n_leaves, L, Q, protein, method, thr = WORKLOADS[name]
@@ -394,7 +430,10 @@ def other_workload(name, device, steps=3, ds=None, queries=0):
         Q = queries
     table = name == 'c5'
     clustered = name.endswith('-clustered')  # the command line's default route: clusters + consensus representatives
-    if ds is None or table:
+    if variant:  # (prepared: ds already is the variant's dataset)
+        ds_ = ds if prepared else variant_dataset(ds, variant, n_leaves, L, Q, protein)
+        n_leaves, L = len(ds_.ref_names), ds_.ref_seqs.shape[1]
+    elif ds is None or table:
         ds_ = synth.make_dataset(n_leaves, L if not table else 4, Q, protein=protein) if ds is None else ds
     else:
         ds_ = ds
@@ -449,7 +488,11 @@ def other_workload(name, device, steps=3, ds=None, queries=0):
                          for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'traffic') if k in rf},
             'mean_observed': float(np.mean(out['n_obs'])), 'placed': int((out['n_valid'] > 0).sum()),
             **({'n_reps': int(info['n_reps']), 'cluster_fused': int(info.get('cluster_fused', 0)),
-                'cluster_blocks': int(info.get('cluster_blocks', 0))} if clustered else {})}
+                'cluster_blocks': int(info.get('cluster_blocks', 0))} if clustered else {}),
+            # which route served it (apples_describe): the legs of the other input shapes are there to show this
+            **({'variant': variant,
+                'route': {k: info.get(k) for k in ('sweep_layout', 'fused_distance_pass', 'code_planes', 'cluster_fused', 'cluster_blocks',
+                                                   'height', 'max_children', 'n_rows', 'length', 'batch')}} if variant else {})}
 
 
 def load_traffic(workload, kernel):
@@ -728,6 +771,17 @@ def main():
                                        # SURVEY 8d's stress variant at config 3's shape: -f 1e9, every leaf observed, V = 2 N - 2 swept
                                        # nodes per query (133 MB of algorithmic sweep bytes each), on the first 2 048 queries
                                        'c3_all_observed_2048_queries': other_workload('c3-all', local_rank, ds=ds)}
+            # config 3's size in the shapes real inputs have (variant_dataset), each with the route that served it, singleton
+            # clusters and the command line's default route
+            shapes = {}
+            for v in ('unrooted', 'polytomies', 'deep', 'dots', 'L4000'):
+                dv = variant_dataset(ds, v, n_leaves, L, 25000 if v == 'L4000' else Q, protein)
+                shapes['c3-' + v] = other_workload('c3', local_rank, ds=dv, variant=v, prepared=True, queries=25000 if v == 'L4000' else 0)
+                if v in ('unrooted', 'polytomies', 'deep'):
+                    shapes['c3-%s-clustered' % v] = other_workload('c3-clustered', local_rank, ds=dv, variant=v, prepared=True)
+                del dv
+            shapes['c3-clustered-300k'] = other_workload('c3-clustered', local_rank, variant='300k')
+            line['other_shapes'] = shapes
         final_line = json.dumps(line)
     if comm is not None:
         comm.barrier()

@@ -241,6 +241,11 @@ int apples_backbone_lengths(int device, int32_t n_nodes, const int32_t *parent, 
                             const int32_t *child_idx, const int32_t *leaf_row, const uint8_t *rows,
                             int64_t n_rows, int32_t length, int protein, int64_t site_chunk, double *out_len);
 
+/* Diagnostic, no context needed: out[i] = the logarithm the distance kernels take (csrc/libm_log.h: GNU libm's double log
+ * restated bit for bit -- the `np.log` of apples/distance.py:715,745 as the C oracle evaluates it), x[i] positive and normal.
+ * tests/test_gpu_parity.py compares it with the host's libm on millions of arguments.  Errors: apples_last_error(NULL). */
+int apples_device_log(int device, const double *x, int64_t n, double *out);
+
 #ifdef __cplusplus
 }
 #endif

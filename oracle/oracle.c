@@ -90,6 +90,11 @@ double orc_scoredist(const uint8_t *a, const uint8_t *b, int L, double overlap, 
     return -log(r) * 1.3;
 }
 
+/* libm's log over an array: what the device's restatement of it (apples_amd/csrc/libm_log.h) is compared with */
+void orc_log_array(const double *x, double *out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = log(x[i]);
+}
+
 /* one query against n_rows rows -> dist[n_rows] */
 void orc_distance_row(const uint8_t *query, const uint8_t *rows, int64_t n_rows, int L, int model, double overlap,
                       const double *lut, const double *blosum400, double *dist) {

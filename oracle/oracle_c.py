@@ -134,3 +134,12 @@ class COracle:
         self.lib.orc_sweep_edges(C.byref(self.t), _p(on), _p(od), C.c_int(len(on)), C.c_int(m), C.c_int(c), C.c_int(ng),
                                  _p(valid), _p(S), _p(R), _p(x), _p(err), _p(lca), _p(out))
         return dict(valid=valid.astype(bool), S=S, R=R, x=x, err=err, lca=int(lca[0]), placement=out[0])
+
+
+def libm_log_array(x):
+    """libm's log of every element (the host routine the C oracle's distances go through)."""
+    lib = load()
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    lib.orc_log_array(_p(x), _p(out), C.c_int64(x.size))
+    return out

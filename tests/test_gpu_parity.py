@@ -82,8 +82,37 @@ def test_jc69_device_log_without_table(c1):
     e = Engine(tree, ref.seqs, nodes, method='OLS', use_lut=False)
     _, dist = e.distances(qry.seqs, want_counts=False)
     g = np.load(os.path.join(GOLD, 'g1_jc69_data.npz'))
-    np.testing.assert_allclose(dist, g['dist'], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(dist, g['dist'], rtol=1e-12, atol=0)  # (the fixture carries numpy's log: its SIMD form on some CPUs)
     e.close()
+    # the device's log is libm's bit for bit (csrc/libm_log.h): the C oracle, which calls libm, gives the same bytes
+    want = COracle(tree, ref.seqs, nodes).distances(qry.seqs)
+    assert dist.tobytes() == want.tobytes()
+
+
+def test_device_log_is_libm_log_bit_for_bit():
+    """csrc/libm_log.h against the host's libm on a million arguments per family: uniform in (0, 1), around 1 on both sides of
+    the routine's branch cut at 1 - 2^-4, random mantissas with exponents 2^-59 .. 1, JC69-shaped 1 - 4 m / (3 v) and scoredist-shaped
+    1 - tot / valid (apples/distance.py:715,745).  The host side is ctypes on libm.so.6: the routine the C oracle links."""
+    import ctypes
+    from apples_amd.engine import device_log
+    libm = ctypes.CDLL('libm.so.6')
+    libm.log.restype = ctypes.c_double
+    libm.log.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    v = rng.integers(1, 4097, size=n).astype(np.float64)
+    m = np.floor(rng.random(n) * (v + 1))
+    fam = [rng.random(n), 1.0 - rng.random(n) * 0.13, 1.0 + rng.random(n) * 0.07,
+           np.ldexp(1.0 + rng.random(n), -rng.integers(0, 60, size=n)), 1 - (4 * (m / v) / 3), 1 - (rng.random(n) * 1.8 * v) / v,
+           np.array([1.0, 0.9375, np.nextafter(0.9375, 0), np.nextafter(1.0, 0), np.nextafter(1.0, 2), 1 + 0x1.09p-4,
+                     np.nextafter(1 + 0x1.09p-4, 0), 0.5, 2.0 ** -52, 2.0 ** -1000])]
+    x = np.concatenate(fam)
+    x = np.ascontiguousarray(x[x > 0])
+    got = device_log(x)
+    want = np.array([libm.log(float(t)) for t in x[::37]])  # (ctypes call per value: a strided sample of the million ...)
+    assert got[::37].tobytes() == want.tobytes()
+    from oracle_c import libm_log_array                      # ... and every one of them through the C oracle's loop over libm's log
+    assert got.tobytes() == libm_log_array(x).tobytes()
 
 
 def test_scoredist_against_golden():
