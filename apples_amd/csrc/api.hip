@@ -104,7 +104,12 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
     for (int i = 0; i < t->n_nodes; ++i) h = std::max(h, t->level[i]);
     d.height = h;
     d.max_children = 0;
-    for (int i = 0; i < t->n_nodes; ++i) d.max_children = std::max(d.max_children, t->child_off[i + 1] - t->child_off[i]);
+    d.poly_kids = 0;
+    for (int i = 0; i < t->n_nodes; ++i) {
+        const int nc = t->child_off[i + 1] - t->child_off[i];
+        d.max_children = std::max(d.max_children, nc);
+        if (nc > 2) d.poly_kids += nc;
+    }
     if (dev_upload(ctx, &d.parent, t->parent, t->n_nodes)) return 1;
     if (dev_upload(ctx, &d.edge_len, t->edge_len, t->n_nodes)) return 1;
     if (dev_upload(ctx, &d.child_off, t->child_off, t->n_nodes + 1)) return 1;
@@ -700,6 +705,9 @@ int route_threshold(const apples_ctx *ctx) {
     return ctx->cur_batch_queries > 0 && ctx->cur_batch_queries <= LEAN_SMALL_BATCH ? v / 2 : v;
 }
 
+// ints per query / team of the lean sweep's group offsets: height + 4, and once more for the child records' offsets on a tree with polytomies
+static int64_t lean_grp_stride(const DevTree &t) { return (int64_t)(t.height + 4) * ((t.max_children > 2 || getenv("APPLES_LEAN_FORCE_POLY")) ? 2 : 1); }
+
 void free_sweep(Workspace::Sweep &sw) {
     dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.ent); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
     dev_free(sw.ent_f); dev_free(sw.ent_i); dev_free(sw.leaf_g); dev_free(sw.meta); dev_free(sw.lean); dev_free(sw.lean_leaf); dev_free(sw.lean_meta);
@@ -768,17 +776,19 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
         sw.lean = p;
         if (dev_alloc(ctx, &p, 3 * sw.teams * sw.lean_leaf1 * LEAN_BYTES_PER_LEAF)) return 1;  // (x 3: run_sweep_second's teams, the second half's of a small batch)
         sw.lean_leaf = p;
-        if (dev_alloc(ctx, &sw.grp_off, batch * (int64_t)(t.height + 4))) return 1;
+        if (dev_alloc(ctx, &sw.grp_off, batch * lean_grp_stride(t))) return 1;
         if (dev_alloc(ctx, &sw.lean_meta, batch)) return 1;
         return 0;
     }
     if (sweep_lean_layout(t, xe)) {  // sweep_lean.hip, workgroup-sized teams: field arrays in place of ent and A
-        sw.lean_cap1 = round_up(cap + 1, 4);
+        // (a tree with polytomies: a team's child records live in its entry slots from the top down -- at most one per child of a
+        // polytomy, DevTree::poly_kids)
+        sw.lean_cap1 = round_up(cap + 1 + t.poly_kids, 4);
         sw.lean_leaf1 = round_up(std::max<int64_t>(leaf_cap, 4), 4);
         char *p = nullptr;
         if (dev_alloc(ctx, &p, sw.teams * (sw.lean_cap1 * LEAN_BYTES_PER_NODE + sw.lean_leaf1 * LEAN_BYTES_PER_LEAF))) return 1;
         sw.lean = p;
-        if (dev_alloc(ctx, &sw.grp_off, sw.teams * (int64_t)(t.height + 4))) return 1;
+        if (dev_alloc(ctx, &sw.grp_off, sw.teams * lean_grp_stride(t))) return 1;
         return 0;
     }
     if (sweep_merge_lists(t)) {
@@ -930,7 +940,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     }
     if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, t.scan ? 0 : std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold(ctx))), xe, batch)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
-    int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 4 + (sweep_lean_layout(t, xe) ? members * LEAN_BYTES_PER_LEAF : 0);
+    int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 8 + (sweep_lean_layout(t, xe) ? members * LEAN_BYTES_PER_LEAF + t.poly_kids * LEAN_BYTES_PER_NODE : 0);
     int64_t big_max = getenv("APPLES_SWEEP_BIG_WGS") ? atoi(getenv("APPLES_SWEEP_BIG_WGS")) : 512;
     int wgs_big = (int)std::min<int64_t>(big_max, std::max<int64_t>(4, ((int64_t)24 << 30) / std::max<int64_t>(per_wg, 1)));
     wgs_big = (int)std::min<int64_t>(wgs_big, batch);
@@ -1094,6 +1104,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.tree = ctx->tree;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
     s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
+    s.grp_stride = (int)lean_grp_stride(ctx->tree);
     s.map = sw.map; s.map_ver = sw.ver; s.order = sw.order; s.ent = sw.ent;
     s.lean = sw.lean; s.lean_cap1 = sw.lean_cap1; s.lean_leaf1 = sw.lean_leaf1;
     s.lean_leaf = sw.lean_leaf; s.lean_teams = sw.teams; s.lean_meta = sw.lean_meta; s.pool_cursor = (unsigned int *)(w.cls_count + 7);

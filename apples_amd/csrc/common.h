@@ -69,6 +69,7 @@ struct DevTree {
     int32_t n_nodes = 0;
     int32_t height = 0;  // max level
     int32_t max_children = 0;
+    int64_t poly_kids = 0;  // children of the nodes with more than two (sweep_lean.hip: the child records a full-size team may need)
     // the merged level lists (sweep.hip:merge_parents, sweep_lean.hip) need node ids in left-to-right post-order and observed
     // leaves that are distinct nodes; a tree or an alignment / table that does not comply gets the node map or the node bits
     bool merge_ok = false;
@@ -501,6 +502,7 @@ struct SweepArgs {
     DevTree tree;
     const int32_t *obs_node; const double *obs_dist; int64_t obs_cap; const int32_t *cnt_gt; const int32_t *n_obs;
     int32_t *grp_off; void *A, *B; double *xe;
+    int grp_stride;           // sweep_lean.hip: ints per query / team in grp_off (height + 4; twice that on a tree with polytomies: the child records' offsets)
     uint32_t *map;            // big trees: [teams][n_nodes] tagged node map; nullptr = node bits in LDS
     uint32_t *map_ver;        // [teams] version tags of the maps
     int32_t *order;           // [teams][cap+1]
@@ -581,7 +583,7 @@ int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int t
 #define LEAN_BYTES_PER_LEAF 12   // per observed leaf: edge length, parent
 #define LEAN_SMALL_BATCH 13312    // device batches up to this many queries: routing cut halved (api.hip:route_threshold), 512-thread routed teams
 #define LEAN_BIG_THRESHOLD 8192  // observed leaves above which a query goes to the lean sweep's workgroup-sized teams
-#define LEAN_MAX_LEVELS 256      // per-level offsets of a query in LDS: trees up to 254 levels
+#define LEAN_MAX_LEVELS 256      // per-level offsets of a query in LDS: a window of this many levels (deeper trees: it follows the walk)
 bool sweep_lean_layout(const DevTree &t, bool per_edge_records);
 int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &down, int64_t nq, hipStream_t st, int32_t *halves = nullptr,
                       hipStream_t side = nullptr, hipEvent_t *ev = nullptr);

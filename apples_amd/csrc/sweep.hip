@@ -883,15 +883,14 @@ bool sweep_merge_lists(const DevTree &t) {
     // LDS by 4-13 % (BASELINE config 2's shape at 1 000 / 2 000 / 5 000 / 10 000 / 20 000 leaves: sweep 0.78 -> 0.75, 1.00 -> 0.96,
     // 1.22 -> 1.15, 1.40 -> 1.28, 1.52 -> 1.32 ms; at 500 leaves the node bits win, 0.72 against 0.79:
     // profiles/r04_small_tree_sweep_exp.txt).  HYBRID keeps the node bits on such trees (its per-edge records need the level loop).
-    return t.n_nodes >= 2048 && t.lean_small && t.max_children <= 2 && t.height + 2 <= LEAN_MAX_LEVELS && t.pe != nullptr &&
-           !(t.dbg & APPLES_DBG_NO_SWEEP_LEAN);
+    return t.n_nodes >= 2048 && t.lean_small && t.pe != nullptr && !(t.dbg & APPLES_DBG_NO_SWEEP_LEAN);
 }
 
-// sweep_lean.hip serves the wavefront-sized teams of a big binary tree (merge layout, no polytomies, no per-edge
-// records -- HYBRID and inspection keep the level loop above).  APPLES_NO_SWEEP_LEAN: the level loop everywhere.
+// sweep_lean.hip serves the teams of a big tree in the merge layout (any number of children per node since round 6 -- child
+// records, lean_poly_S / lean_poly_td -- and any height: the per-level offsets are a window in LDS), without per-edge
+// records -- inspection keeps the level loop above.  APPLES_NO_SWEEP_LEAN: the level loop everywhere.
 bool sweep_lean_layout(const DevTree &t, bool per_edge_records) {
-    return sweep_merge_lists(t) && t.max_children <= 2 && t.height + 2 <= LEAN_MAX_LEVELS && !per_edge_records && t.pe != nullptr &&
-           !(t.dbg & APPLES_DBG_NO_SWEEP_LEAN);
+    return sweep_merge_lists(t) && !per_edge_records && t.pe != nullptr && !(t.dbg & APPLES_DBG_NO_SWEEP_LEAN);
 }
 
 bool sweep_bits_in_lds(const DevTree &t) {

@@ -24,8 +24,9 @@
 //     memory round trip in the step.
 //
 // Team = one wavefront per query (four per workgroup, no s_barrier).  Queries with many observed leaves are routed to
-// sweep.hip's workgroup-sized teams as before; so are trees with polytomies or more than LEAN_MAX_LEVELS - 2 levels and
-// per-edge inspection (the launcher decides).  The HYBRID criterion keeps every edge's solution in the entries' tuple slots and
+// workgroup-sized teams (k_sweep_lean_big below); per-edge inspection keeps sweep.hip's level loop (the launcher decides).
+// Trees with polytomies run the PL instances of the kernels (child records, lean_poly_S / lean_poly_td); trees of more than
+// LEAN_MAX_LEVELS - 2 levels keep a window of the per-level offsets in LDS.  The HYBRID criterion keeps every edge's solution in the entries' tuple slots and
 // ranks them after the top-down pass (lean_hybrid_pick).  Arithmetic: sweep_math.h, shared with sweep.hip --
 // same expressions in the same order, so placements are bit-identical to the level loop's.
 #include <algorithm>
@@ -88,6 +89,28 @@ struct LeanTeam {
 __device__ __forceinline__ bool lean_is_block(double dist) { return ((unsigned)__double2hiint(dist) & 0xfff80000u) == 0xfff80000u; }
 __device__ __forceinline__ long long lean_block_at(double dist) { return __double_as_longlong(dist) & 0x0007ffffffffffffLL; }
 
+// ---- polytomies (template parameter PL; a binary tree's kernels carry none of this) ---------------------------------------
+// A node with more than two valid children in a query's subtree (apples/OLS.py:36,59 loop over any number of children; a
+// root trifurcation is what every unrooted Newick has).  Its entry keeps the first two as ever; the merge step that meets a
+// third child appends CHILD RECORDS for all of them -- one per valid child, in file order -- to the top end of the query's
+// entry range, growing downward: record x of the query sits in entry slot `xtop - x` and reuses the slot's fields,
+//   D = (child's descriptor, position: 0, 1, 2, then 3 for every later one)   N = (child's node id, the polytomy's entry)
+//   E = (child's edge length, its observed distance; after the top-down pass under HYBRID: x_2)
+//   T0..T2 = a copy of the child's S tuple (lean_poly_S), so that the top-down pass may overwrite the child's own slot
+//   DD = HYBRID's per-edge record (error, x_1)
+// The S tuple of such a node is summed over the records in order after the level's binary step (lean_poly_S; BME's
+// 1 / #valid children, apples/BME.py:19-20), which also marks the entry: D = (first record, LEAN_POLY_SELF | children).
+// Top-down, the binary steps skip marked entries and lean_poly_td forms every child's R from ALL its siblings in file order,
+// then the parent term (apples/OLS.py:59-80; BME: 1 / (nonroot + #valid siblings), apples/BME.py:36-38) -- O(children^2)
+// like the reference.  A polytomy's own lift(R) always travels through its tuple slot, never through the LDS hand-over: its
+// descriptor in its parent's entry and its key in the level list carry LEAN_POLY_KID so that the parent knows.
+#define LEAN_POLY_KID 0x40000000
+#define LEAN_POLY_SELF 0x20000000
+#define LEAN_DESC_MASK 0x1fffffff
+template <bool PL> __device__ __forceinline__ int lean_desc_idx(int kd) { return PL ? (kd & LEAN_DESC_MASK) : kd; }
+template <bool PL> __device__ __forceinline__ int lean_key_node(int k) { return PL ? (k & ~LEAN_POLY_KID) : k; }
+__device__ __forceinline__ bool lean_is_poly_entry(const int2 d) { return d.y > 0 && (d.y & LEAN_POLY_SELF) != 0 && (d.y & LEAN_POLY_KID) == 0; }
+
 __device__ __forceinline__ LeanTeam lean_team(void *base, int64_t team, int64_t cap1, int64_t leaf1) {
     char *p = reinterpret_cast<char *>(base) + team * (cap1 * LEAN_BYTES_PER_NODE + leaf1 * LEAN_BYTES_PER_LEAF);
     LeanTeam t;
@@ -132,6 +155,51 @@ __device__ __forceinline__ double shfl_down_f64(double v, int delta) {
 
 __device__ __forceinline__ double pe_len(const int4 &r) { return __hiloint2double(r.w, r.z); }
 
+// What a merge step knows about its runs of siblings (PL), as lane masks from the mask of the runs' first keys alone (scalar
+// bit operations: nothing per lane): `extra` = the third and later keys of their runs, `xfirst` = exactly the third keys,
+// `third` = the first keys of runs that have a third key inside this step.  A run that began in the step before: `ccnt` = how
+// many of its keys that step saw (capped at 3); its keys here are the non-first lanes from lane 0 on.
+struct LeanRunMasks {
+    unsigned long long extra, xfirst, third;
+};
+__device__ __forceinline__ LeanRunMasks lean_run_masks(unsigned long long fm, int tot, int ccnt) {
+    const unsigned long long act = tot >= 64 ? ~0ull : ((1ull << tot) - 1ull);
+    const unsigned long long nf = ~fm & act;  // keys that continue a run
+    LeanRunMasks r;
+    // a key behind another continuing key is at least its run's third; lane 0 continues the carried run: third or later from two carried keys on
+    r.extra = (nf & (nf << 1)) | ((nf & 1ull) && ccnt >= 2 ? 1ull : 0ull);
+    // exactly the third: two lanes behind a first key -- or, in the carried run, where carried keys + lanes before make two
+    r.xfirst = (r.extra & (fm << 2)) | ((nf & 1ull) && ccnt == 2 ? 1ull : 0ull) | ((nf & 3ull) == 3ull && ccnt == 1 ? 2ull : 0ull);
+    r.third = fm & (nf >> 1) & (nf >> 2);
+    return r;
+}
+struct LeanRun {
+    bool extra, xfirst;
+};
+
+// the child records of this step's third-and-later siblings (PL): `en` = the entry of the lane's run, `xc` = records so far;
+// returns how many records the step added (three for a run's third key: the first two children's records are filled in by lean_poly_S)
+__device__ __forceinline__ int lean_poly_records(const LeanTeam &t, int xtop, int xc, const LeanRun &run, int en, int par, int desc,
+                                                 int key, double e, double dist, int lane) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long m3 = __ballot(run.xfirst), m1 = __ballot(run.extra && !run.xfirst);
+    if (run.extra) {
+        const int x0 = xc + 3 * __popcll(m3 & below) + __popcll(m1 & below);
+        const int x = run.xfirst ? x0 + 2 : x0;
+        t.D[xtop - x] = make_int2(desc, run.xfirst ? 2 : 3);
+        t.N[xtop - x] = make_int2(key, en);
+        t.E[xtop - x] = make_double2(e, dist);
+        if (run.xfirst) {
+            t.D[xtop - x0] = make_int2(0, 0);
+            t.N[xtop - x0] = make_int2(-1, en);
+            t.D[xtop - x0 - 1] = make_int2(0, 1);
+            t.N[xtop - x0 - 1] = make_int2(-1, en);
+            t.K[en] = par | LEAN_POLY_KID;
+        }
+    }
+    return 3 * __popcll(m3) + __popcll(m1);
+}
+
 // One level of the lists, general form (any sizes): merge by node id the parents of this level's internal nodes
 // (K[base .. base + nA), sorted) and of its observed leaves (o_node[lo .. lo + nB), sorted): the next level's list, sorted
 // (sweep.hip:merge_parents -- the same merge-path step of 64 keys through two LDS windows).  The entry of a parent names
@@ -139,11 +207,13 @@ __device__ __forceinline__ double pe_len(const int4 &r) { return __hiloint2doubl
 // have at most two keys; a run cut by the end of a step is completed by the next step's first key, which patches the
 // entry -- so how far a step advances in the two lists is known right after its search, and the next step's windows are
 // requested before this step's gather is waited for: one memory round trip per 64 keys, not two.
+// PL: runs of any length; the third and later keys of a run become child records (above), `xc` counts them.
 // Returns the number of entries written from next_base on.
+template <bool PL>
 __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, const int32_t *__restrict__ o_node,
                                           const double *__restrict__ o_dist, int lo, int nB, int next_base,
-                                          const int4 *__restrict__ pe, int *mk_a, int *mk_b, int lane) {
-    int out = 0, ia = 0, ib = 0, carry = -2;
+                                          const int4 *__restrict__ pe, int *mk_a, int *mk_b, int lane, int xtop, int &xc) {
+    int out = 0, ia = 0, ib = 0, carry = -2, ccnt = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
     int wk_a = lane < nA ? t.K[base + lane] : 0x7fffffff, wk_b = lane < nB ? o_node[lo + lane] : 0x7fffffff;
     while (ia < nA || ib < nB) {
@@ -156,13 +226,14 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
         int i_lo = max(0, lane - wb), i_hi = min(lane, wa);  // i = keys of the first window among the lane smallest
         while (i_lo < i_hi) {
             const int i = (i_lo + i_hi) >> 1;
-            if (mk_a[i] < mk_b[lane - 1 - i]) i_lo = i + 1; else i_hi = i;
+            if (lean_key_node<PL>(mk_a[i]) < mk_b[lane - 1 - i]) i_lo = i + 1; else i_hi = i;
         }
         const int i = i_lo, j = lane - i_lo;
-        const int ka = i < wa ? mk_a[i] : 0x7fffffff, kb = j < wb ? mk_b[j] : 0x7fffffff;
+        const int kaf = i < wa ? mk_a[i] : 0x7fffffff;  // (PL: a polytomy's key carries LEAN_POLY_KID)
+        const int ka = i < wa ? lean_key_node<PL>(kaf) : 0x7fffffff, kb = j < wb ? mk_b[j] : 0x7fffffff;
         const bool from_a = ka < kb;
         const int key = from_a ? ka : kb;
-        const int desc = from_a ? base + ia + i + 1 : -(lo + ib + j) - 2;
+        const int desc = from_a ? ((base + ia + i + 1) | (PL ? (kaf & LEAN_POLY_KID) : 0)) : -(lo + ib + j) - 2;
         const int ca = __popcll(__ballot(active && from_a));
         const int nia = ia + ca, nib = ib + tot - ca;
         wk_a = nia + lane < nA ? t.K[base + nia + lane] : 0x7fffffff;  // the next step's windows
@@ -187,19 +258,38 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
         const double next_e = shfl_down_f64(e, 1), next_dist = shfl_down_f64(dist, 1);
         const bool two = lane + 1 < tot && !next_first;
         const unsigned long long fm = __ballot(first);
+        LeanRun run = {false, false};
+        bool third = false;  // (PL) the run this lane begins has a third key inside this step
+        LeanRunMasks rm = {0, 0, 0};
+        if (PL) {
+            rm = lean_run_masks(fm, tot, ccnt);
+            run.extra = (rm.extra >> lane) & 1ull;
+            run.xfirst = (rm.xfirst >> lane) & 1ull;
+            third = (rm.third >> lane) & 1ull;
+        }
         if (first) {
             const int at = next_base + out + __popcll(fm & below);
-            t.K[at] = par;
+            t.K[at] = (PL && third) ? (par | LEAN_POLY_KID) : par;
             t.D[at] = make_int2(desc, two ? next_desc : 0);
             t.N[at] = make_int2(key, two ? next_key : -1);
             t.E[at] = make_double2(e, two ? next_e : 0.0);
             t.DD[at] = make_double2(dist, two ? next_dist : 0.0);
-        } else if (lane == 0 && active) {  // the second child of the previous step's last entry
+        } else if (lane == 0 && active && !(PL && run.extra)) {  // the second child of the previous step's last entry
             const int at = next_base + out - 1;
             reinterpret_cast<int *>(t.D + at)[1] = desc;
             reinterpret_cast<int *>(t.N + at)[1] = key;
             reinterpret_cast<double *>(t.E + at)[1] = e;
             reinterpret_cast<double *>(t.DD + at)[1] = dist;
+        }
+        if (PL) {
+            if (rm.extra != 0ull) {  // (never on a binary tree)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the mark on K follows the entry's own store)
+                const int en = next_base + out + __popcll(fm & (below | (1ull << lane))) - 1;
+                xc += lean_poly_records(t, xtop, xc, run, en, par, desc, key, e, dist, lane);
+            }
+            // how many keys of the last run this step saw (capped at 3), for the lanes 0..2 of the next step
+            const int lastfirst = fm ? 63 - __clzll(fm) : -1;
+            ccnt = lastfirst >= 0 ? min(tot - lastfirst, 3) : min(ccnt + tot, 3);
         }
         carry = __shfl(par, tot - 1, WAVE);
         ia = nia;
@@ -214,15 +304,15 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
 // rebuilt from its distance.  The loads from the arrays are unconditional (a leaf child or no child reads entry 0 and
 // drops it): no branch stands between the loads of a node's two children and of its own tuple, so they all leave together
 // and a step waits for one round trip, not for one per child.
-template <int M>
+template <int M, bool PL = false>
 __device__ __forceinline__ void kid_tuple(int kd, double dist, const LeanTeam &t, const double2 (*stage)[WAVE], bool staged,
                                           int stage_base, double *S) {
     double2 a, b, c;
     if (staged) {  // (wave-uniform)
-        const int p = kd > 0 ? kd - 1 - stage_base : 0;
+        const int p = kd > 0 ? lean_desc_idx<PL>(kd) - 1 - stage_base : 0;
         a = stage[0][p]; b = stage[1][p]; c = stage[2][p];
     } else {
-        const int ki = kd > 0 ? kd - 1 : 0;
+        const int ki = kd > 0 ? lean_desc_idx<PL>(kd) - 1 : 0;
         a = t.T0[ki]; b = t.T1[ki]; c = t.T2[ki];
     }
     S[0] = a.x; S[1] = a.y; S[2] = b.x; S[3] = b.y; S[4] = c.x; S[5] = c.y;
@@ -238,14 +328,14 @@ __device__ __forceinline__ void kid_tuple(int kd, double dist, const LeanTeam &t
 }
 
 // S tuple of a node from its entry (apples/OLS.py:25-44: children in file order)
-template <int M>
+template <int M, bool PL = false>
 __device__ __forceinline__ void node_S(const int2 d, const double2 e, const double2 dd, const LeanTeam &t,
                                        const double2 (*stage)[WAVE], bool staged, int kid_base, double *r) {
     constexpr bool BME = (M == APPLES_BME);
     const double coef = BME ? 1.0 / (double)(d.y != 0 ? 2 : 1) : 1.0;  // apples/BME.py:20
     double S0[6], S1[6], u[6];
-    kid_tuple<M>(d.x, dd.x, t, stage, staged, kid_base, S0);
-    kid_tuple<M>(d.y, dd.y, t, stage, staged, kid_base, S1);  // (no second child: a dummy that is not used)
+    kid_tuple<M, PL>(d.x, dd.x, t, stage, staged, kid_base, S0);
+    kid_tuple<M, PL>(d.y, dd.y, t, stage, staged, kid_base, S1);  // (no second child: a dummy that is not used)
     lift<M>(S0, e.x, u);
 #pragma unroll
     for (int x = 0; x < 6; ++x) r[x] = 0;
@@ -260,7 +350,7 @@ __device__ __forceinline__ void node_S(const int2 d, const double2 e, const doub
 
 // S tuples of the entries [lo, hi), `stride` lanes apart (a level of more than one chunk): the entries of the next chunk
 // are requested before this chunk's children are waited for, so a chunk costs one memory round trip, not two
-template <int M>
+template <int M, bool PL = false>
 __device__ __forceinline__ void lean_S_chunks(const LeanTeam &t, int lo, int hi, int first, int stride,
                                               const double2 (*stage)[WAVE], bool staged, int kid_base) {
     int idx = lo + first;
@@ -273,7 +363,7 @@ __device__ __forceinline__ void lean_S_chunks(const LeanTeam &t, int lo, int hi,
         double2 e2 = make_double2(0, 0), dd2 = make_double2(0, 0);
         if (nidx < hi) { d2 = t.D[nidx]; e2 = t.E[nidx]; dd2 = t.DD[nidx]; }
         double r[6];
-        node_S<M>(d, e, dd, t, stage, staged, kid_base, r);
+        node_S<M, PL>(d, e, dd, t, stage, staged, kid_base, r);
         t.T0[idx] = make_double2(r[0], r[1]);
         t.T1[idx] = make_double2(r[2], r[3]);
         t.T2[idx] = make_double2(r[4], r[5]);
@@ -303,7 +393,7 @@ __device__ __forceinline__ void lean_best_init(LeanBest &b) {
 // HY (the HYBRID criterion, apples/Algorithm.py:76-82): nothing is compared here; the edge's error, x_1 and x_2 go into half `rz` of
 // the tuple slots of its parent's entry `ridx` (dead by now: the entry's S went into its own parent's step, its lifted R was read
 // when this step began), for lean_hybrid_pick.
-template <int M, bool HY = false>
+template <int M, bool HY = false, bool PL = false>
 __device__ __forceinline__ void lean_td_kid(const LeanTeam &t, const double *Sk, const double *Ss, const double *plift, double ek,
                                             double es, int kd, int kn, int nk, bool is_lca, double coef, int negative,
                                             int criterion, const double *lds_pow, double2 (*hand)[WAVE], int hand_base,
@@ -326,15 +416,16 @@ __device__ __forceinline__ void lean_td_kid(const LeanTeam &t, const double *Sk,
     if (kd > 0) {
         double u[6];
         lift<M>(acc, ek, u);
-        if (hand) {
-            const int p = kd - 1 - hand_base;
+        const int ki = lean_desc_idx<PL>(kd) - 1;
+        if (hand && !(PL && (kd & LEAN_POLY_KID))) {  // (a polytomy takes its lift(R) from its tuple slot: lean_poly_td)
+            const int p = ki - hand_base;
             hand[0][p] = make_double2(u[0], u[1]);
             hand[1][p] = make_double2(u[2], u[3]);
             hand[2][p] = make_double2(u[4], u[5]);
         } else {
-            t.T0[kd - 1] = make_double2(u[0], u[1]);
-            t.T1[kd - 1] = make_double2(u[2], u[3]);
-            t.T2[kd - 1] = make_double2(u[4], u[5]);
+            t.T0[ki] = make_double2(u[0], u[1]);
+            t.T1[ki] = make_double2(u[2], u[3]);
+            t.T2[ki] = make_double2(u[4], u[5]);
         }
     } else if (t.BP && lean_is_block(ddk)) {  // the root of a clade block: lift(R) over its edge replaces its S in the pool (k_blocks_down)
         double u[6];
@@ -365,25 +456,26 @@ __device__ __forceinline__ void lean_own_plift(const LeanTeam &t, int idx, const
 
 // Top-down step of one internal node, both children in turn (the two swap roles in between): a rolled loop keeps one
 // 2x2 solve's worth of temporaries live, which is what decides how many wavefronts a SIMD holds.
-template <int M, bool HY = false>
+template <int M, bool HY = false, bool PL = false>
 __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, const int2 d, const int2 nd, const double2 e, const double2 dd,
                                              bool is_lca, int negative, int criterion,
                                              const double *lds_pow, const double2 (*hand_in)[WAVE], int in_pos,
                                              double2 (*hand_out)[WAVE], int out_base, LeanBest &best) {
     constexpr bool BME = (M == APPLES_BME);
+    if (PL && lean_is_poly_entry(d)) return;  // (lean_poly_td serves it)
     const int nk = d.y != 0 ? 2 : 1;
     // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
     const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
     double plift[6];
     lean_own_plift(t, idx, hand_in, in_pos, plift);  // (the LCA has none: what it reads there is not used)
     double Sk[6], Ss[6];  // the child in hand and its sibling
-    kid_tuple<M>(d.x, dd.x, t, nullptr, false, 0, Sk);
-    kid_tuple<M>(d.y, dd.y, t, nullptr, false, 0, Ss);
+    kid_tuple<M, PL>(d.x, dd.x, t, nullptr, false, 0, Sk);
+    kid_tuple<M, PL>(d.y, dd.y, t, nullptr, false, 0, Ss);
     double ek = e.x, es = e.y, ddk = dd.x, dds = dd.y;
     int kd = d.x, ks = d.y, kn = nd.x, ksn = nd.y;
 #pragma unroll 1
     for (int z = 0; z < nk; ++z) {
-        lean_td_kid<M, HY>(t, Sk, Ss, plift, ek, es, kd, kn, nk, is_lca, coef, negative, criterion, lds_pow, hand_out, out_base, best, ddk, idx, z);
+        lean_td_kid<M, HY, PL>(t, Sk, Ss, plift, ek, es, kd, kn, nk, is_lca, coef, negative, criterion, lds_pow, hand_out, out_base, best, ddk, idx, z);
 #pragma unroll
         for (int x = 0; x < 6; ++x) { const double w = Sk[x]; Sk[x] = Ss[x]; Ss[x] = w; }
         { const double w = ek; ek = es; es = w; }
@@ -397,7 +489,7 @@ __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, const i
 // lean_S_chunks) -- for the workgroup-sized teams, which wait on memory; the wavefront-sized teams' top-down kernel is
 // bound by instruction issue at three wavefronts per SIMD, and the registers of the look-ahead (spilled there) cost it
 // more than the round trip (measured: 6.9 against 5.0 ms per C3 pass)
-template <int M, bool AHEAD, bool HY = false>
+template <int M, bool AHEAD, bool HY = false, bool PL = false>
 __device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi, int first, int stride, int VI, int negative,
                                                int criterion, const double *lds_pow, const double2 (*hand_in)[WAVE],
                                                double2 (*hand_out)[WAVE], int out_base, LeanBest &best) {
@@ -406,8 +498,8 @@ __device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi
     double2 e = make_double2(0, 0), dd = make_double2(0, 0);
     if (!AHEAD) {
         for (; idx < hi; idx += stride) {
-            lean_td_node<M, HY>(t, idx, t.D[idx], t.N[idx], t.E[idx], t.DD[idx], idx == VI, negative, criterion, lds_pow, hand_in, idx - lo,
-                            hand_out, out_base, best);
+            lean_td_node<M, HY, PL>(t, idx, t.D[idx], t.N[idx], t.E[idx], t.DD[idx], idx == VI, negative, criterion, lds_pow, hand_in, idx - lo,
+                                    hand_out, out_base, best);
             __builtin_amdgcn_wave_barrier();
         }
         return;
@@ -418,7 +510,7 @@ __device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi
         int2 d2 = make_int2(0, 0), nd2 = make_int2(0, 0);
         double2 e2 = make_double2(0, 0), dd2 = make_double2(0, 0);
         if (nidx < hi) { d2 = t.D[nidx]; nd2 = t.N[nidx]; e2 = t.E[nidx]; dd2 = t.DD[nidx]; }
-        lean_td_node<M, HY>(t, idx, d, nd, e, dd, idx == VI, negative, criterion, lds_pow, hand_in, idx - lo, hand_out, out_base, best);
+        lean_td_node<M, HY, PL>(t, idx, d, nd, e, dd, idx == VI, negative, criterion, lds_pow, hand_in, idx - lo, hand_out, out_base, best);
         __builtin_amdgcn_wave_barrier();
         idx = nidx; d = d2; nd = nd2; e = e2; dd = dd2;
     }
@@ -426,7 +518,7 @@ __device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi
 
 // The same for a level of at most 32 nodes, one lane per (node, child): lanes 0-31 take the first valid children of
 // nodes g0 .. g0 + 31, lanes 32-63 the second: the 2x2 solve and the residual run once per level step, not twice.
-template <int M, bool HY = false>
+template <int M, bool HY = false, bool PL = false>
 __device__ __forceinline__ void lean_td_pairs(const LeanTeam &t, int g0, int ng, int VI, int lane, int negative, int criterion,
                                               const double *lds_pow, const double2 (*hand_in)[WAVE], double2 (*hand_out)[WAVE],
                                               int out_base, LeanBest &best) {
@@ -441,16 +533,215 @@ __device__ __forceinline__ void lean_td_pairs(const LeanTeam &t, int g0, int ng,
     const int nk = d.y != 0 ? 2 : 1;
     const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
     double plift[6], Sk[6], Ss[6];
-    const bool mine = act && z < nk;
+    const bool mine = act && z < nk && !(PL && lean_is_poly_entry(d));  // (a polytomy: lean_poly_td)
     if (mine) {
         lean_own_plift(t, idx, hand_in, i, plift);
-        kid_tuple<M>(z ? d.y : d.x, z ? dd.y : dd.x, t, nullptr, false, 0, Sk);
-        kid_tuple<M>(z ? d.x : d.y, z ? dd.x : dd.y, t, nullptr, false, 0, Ss);
+        kid_tuple<M, PL>(z ? d.y : d.x, z ? dd.y : dd.x, t, nullptr, false, 0, Sk);
+        kid_tuple<M, PL>(z ? d.x : d.y, z ? dd.x : dd.y, t, nullptr, false, 0, Ss);
     }
     __builtin_amdgcn_wave_barrier();  // (every lane's reads of the hand-over precede the stores of this step)
     if (mine)
-        lean_td_kid<M, HY>(t, Sk, Ss, plift, z ? e.y : e.x, z ? e.x : e.y, z ? d.y : d.x, z ? nd.y : nd.x, nk, is_lca, coef, negative,
-                           criterion, lds_pow, hand_out, out_base, best, z ? dd.y : dd.x, idx, z);
+        lean_td_kid<M, HY, PL>(t, Sk, Ss, plift, z ? e.y : e.x, z ? e.x : e.y, z ? d.y : d.x, z ? nd.y : nd.x, nk, is_lca, coef, negative,
+                               criterion, lds_pow, hand_out, out_base, best, z ? dd.y : dd.x, idx, z);
+}
+
+// Polytomies, bottom-up (PL): the S tuples of the nodes whose child records lie in [xlo, xhi) -- the records a level's merge
+// added -- after the level's binary step (which formed something from their first two children alone).  A lane per node: the
+// first two children's records are filled in from the entry, every child's S tuple is copied into its record, the node's
+// tuple is their sum in file order (apples/OLS.py:36-44; BME: each share times 1 / #valid children, apples/BME.py:19-20) and
+// replaces what the binary step left (in the LDS stage too when the level is staged); the entry is marked.  Children's
+// tuples come from the arrays (every level's are stored there as well as staged).
+#ifndef LEAN_EXP_NO_FIX
+#define LEAN_EXP_NO_FIX 0
+#endif
+// The two polytomy passes are real calls, and their call sites hand them COPIES of what they take by reference (the team's
+// pointers, the running best) and park the lane state that must survive in LDS: inlined, their registers (a node's children
+// in flight together) came on top of the level loops' own and the hot paths of a tree without a single polytomy spilled --
+// forced onto config 3's binary tree the PL kernels took 20.9 ms where the plain ones take 15.3 (profiles/r06_poly_exp.txt).
+#ifndef LEAN_POLY_INLINE
+#define LEAN_POLY_INLINE __noinline__
+#endif
+#define LEAN_POLY_REG 4  // children a polytomy's lane keeps in registers (all their loads in flight together); more: one by one
+template <int M>
+__device__ LEAN_POLY_INLINE void lean_poly_S(const LeanTeam &t, int xtop, int xlo, int xhi, int first, int stride,
+                                         double2 (*stage)[WAVE], int stage_base) {
+    constexpr bool BME = (M == APPLES_BME);
+#pragma unroll 1
+    for (int x = xlo + first; x < xhi; x += stride) {
+        // round 1: is this a node's first record, its entry, how many children (the positions of the records behind it)
+        const int p0 = t.D[xtop - x].y, en = t.N[xtop - x].y;
+        int pj[LEAN_POLY_REG + 1];
+#pragma unroll
+        for (int j = 2; j <= LEAN_POLY_REG; ++j) pj[j] = t.D[xtop - min(x + j, xhi - 1)].y;
+        if (p0 != 0) continue;  // (a node begins at its position-0 record)
+        int m = 2;
+#pragma unroll
+        for (int j = 2; j <= LEAN_POLY_REG; ++j)
+            if (m == j && x + j < xhi && pj[j] >= 2) m = j + 1;
+        if (m > LEAN_POLY_REG)
+            while (x + m < xhi && t.D[xtop - x - m].y >= 2) ++m;
+        // round 2: the first two children from the entry, the others' records
+        const int2 ed = t.D[en], ekn = t.N[en];
+        const double2 ee = t.E[en], edd = t.DD[en];
+        int kd[LEAN_POLY_REG];
+        double2 ke[LEAN_POLY_REG];
+#pragma unroll
+        for (int j = 2; j < LEAN_POLY_REG; ++j) { const int s = xtop - x - min(j, m - 1); kd[j] = t.D[s].x; ke[j] = t.E[s]; }
+        kd[0] = ed.x; kd[1] = ed.y; ke[0] = make_double2(ee.x, edd.x); ke[1] = make_double2(ee.y, edd.y);
+        t.D[xtop - x] = make_int2(ed.x, 0); t.N[xtop - x] = make_int2(ekn.x, en); t.E[xtop - x] = ke[0];
+        t.D[xtop - x - 1] = make_int2(ed.y, 1); t.N[xtop - x - 1] = make_int2(ekn.y, en); t.E[xtop - x - 1] = ke[1];
+        const double coef = BME ? 1.0 / (double)m : 1.0;
+        double r[6] = {0, 0, 0, 0, 0, 0};
+        // round 3: the children's tuples, all requested together (kid_tuple's loads are unconditional)
+        double S[LEAN_POLY_REG][6];
+#pragma unroll
+        for (int j = 0; j < LEAN_POLY_REG; ++j) kid_tuple<M, true>(j < m ? kd[j] : 0, ke[j < m ? j : 0].y, t, nullptr, false, 0, S[j]);
+#pragma unroll
+        for (int j = 0; j < LEAN_POLY_REG; ++j) {
+            if (j < m) {
+                const int s = xtop - x - j;
+                t.T0[s] = make_double2(S[j][0], S[j][1]); t.T1[s] = make_double2(S[j][2], S[j][3]); t.T2[s] = make_double2(S[j][4], S[j][5]);
+                double u[6];
+                lift<M>(S[j], ke[j].x, u);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) r[c] += BME ? coef * u[c] : u[c];
+            }
+        }
+#pragma unroll 1
+        for (int j = LEAN_POLY_REG; j < m; ++j) {  // (a polytomy of more than LEAN_POLY_REG children: the rest one by one)
+            const int s = xtop - x - j;
+            const int dj = t.D[s].x;
+            const double2 ej = t.E[s];
+            double Sj[6], u[6];
+            kid_tuple<M, true>(dj, ej.y, t, nullptr, false, 0, Sj);
+            t.T0[s] = make_double2(Sj[0], Sj[1]); t.T1[s] = make_double2(Sj[2], Sj[3]); t.T2[s] = make_double2(Sj[4], Sj[5]);
+            lift<M>(Sj, ej.x, u);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) r[c] += BME ? coef * u[c] : u[c];
+        }
+        t.T0[en] = make_double2(r[0], r[1]); t.T1[en] = make_double2(r[2], r[3]); t.T2[en] = make_double2(r[4], r[5]);
+        if (stage) {
+            const int p = en - stage_base;
+            stage[0][p] = make_double2(r[0], r[1]); stage[1][p] = make_double2(r[2], r[3]); stage[2][p] = make_double2(r[4], r[5]);
+        }
+        t.D[en] = make_int2(x, LEAN_POLY_SELF | m);
+    }
+}
+
+// Polytomies, top-down (PL): the nodes whose child records lie in [xlo, xhi), after the level's binary step skipped them.  A
+// lane per node; for every child in file order its R = every other valid child's lifted S in file order, then the node's own
+// lifted R (apples/OLS.py:59-80; BME: all of it times 1 / (nonroot + #valid siblings), apples/BME.py:36-38), the 2x2 solve and
+// the residual as lean_td_kid; an internal child's lift(R) goes where lean_td_kid would put it (the children's S tuples are
+// the copies in the records: the child's own slot is free to take it).  Up to LEAN_POLY_REG children: their records and
+// their lifted tuples (coefficient applied: what every sibling's sum adds, the same bits each time) stay in registers.
+template <int M, bool HY>
+__device__ __forceinline__ void lean_poly_edge(const LeanTeam &t, int s, const double *Sk, const double *acc, double ek, double ddk, int kd,
+                                               int kn, int negative, int criterion, const double *lds_pow, double2 (*hand)[WAVE],
+                                               int hand_base, LeanBest &best) {
+    const Sol r = solve_edge<M>(Sk, acc, ek, negative, lds_pow);
+    if (kd > 0) {
+        double u[6];
+        lift<M>(acc, ek, u);
+        const int ki = (kd & LEAN_DESC_MASK) - 1;
+        if (hand && !(kd & LEAN_POLY_KID)) {
+            const int p = ki - hand_base;
+            hand[0][p] = make_double2(u[0], u[1]); hand[1][p] = make_double2(u[2], u[3]); hand[2][p] = make_double2(u[4], u[5]);
+        } else {
+            t.T0[ki] = make_double2(u[0], u[1]); t.T1[ki] = make_double2(u[2], u[3]); t.T2[ki] = make_double2(u[4], u[5]);
+        }
+    } else if (t.BP && lean_is_block(ddk)) {  // the root of a clade block (as lean_td_kid)
+        double u[6];
+        lift<M>(acc, ek, u);
+        double *bp = t.BP + lean_block_at(ddk);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bp[k * 64] = u[k];
+    }
+    if (HY) {  // the edge's record for lean_hybrid_pick: (error, x_1) in DD, x_2 in place of the distance
+        t.DD[s] = make_double2(r.err, r.x1_int ? __longlong_as_double(LEAN_BOXED_INT0) : r.x1);
+        t.E[s] = make_double2(ek, r.x2);
+    } else {
+        const double key = (criterion == APPLES_ME) ? r.x1 : r.err;
+        if (key < best.key || (key == best.key && kn < best.v)) {
+            best.key = key; best.v = kn; best.x1 = r.x1; best.x2 = r.x2; best.err = r.err; best.x1_int = r.x1_int; best.e = ek;
+        }
+    }
+}
+
+template <int M, bool HY>
+__device__ LEAN_POLY_INLINE void lean_poly_td(const LeanTeam &t, int xtop, int xlo, int xhi, int first, int stride, int VI, int negative,
+                                          int criterion, const double *lds_pow, double2 (*hand)[WAVE], int hand_base, LeanBest &best) {
+    constexpr bool BME = (M == APPLES_BME);
+#pragma unroll 1
+    for (int x = xlo + first; x < xhi; x += stride) {
+        const int p0 = t.D[xtop - x].y, en = t.N[xtop - x].y;
+        if (p0 != 0) continue;
+        const int m = t.D[en].y & LEAN_DESC_MASK;
+        const bool is_lca = en == VI;
+        double plift[6];
+        lean_own_plift(t, en, nullptr, 0, plift);  // (the LCA has none: not used)
+        const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + m - 1) : 1.0;
+        if (m <= LEAN_POLY_REG) {
+            double S[LEAN_POLY_REG][6], U[LEAN_POLY_REG][6];
+            double2 ed[LEAN_POLY_REG];
+            int kd[LEAN_POLY_REG], kn[LEAN_POLY_REG];
+#pragma unroll
+            for (int j = 0; j < LEAN_POLY_REG; ++j) {  // (every record's loads in flight together; beyond m: the last one again, not used)
+                const int s = xtop - x - min(j, m - 1);
+                const double2 a = t.T0[s], b = t.T1[s], c = t.T2[s];
+                S[j][0] = a.x; S[j][1] = a.y; S[j][2] = b.x; S[j][3] = b.y; S[j][4] = c.x; S[j][5] = c.y;
+                ed[j] = t.E[s]; kd[j] = t.D[s].x; kn[j] = t.N[s].x;
+            }
+#pragma unroll
+            for (int j = 0; j < LEAN_POLY_REG; ++j) {
+                double u[6];
+                lift<M>(S[j], ed[j].x, u);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) U[j][k] = BME ? coef * u[k] : u[k];
+            }
+#pragma unroll
+            for (int i = 0; i < LEAN_POLY_REG; ++i) {
+                if (i < m) {
+                    double acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < LEAN_POLY_REG; ++j)
+                        if (j != i && j < m) {
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) acc[k] += U[j][k];
+                        }
+                    if (!is_lca) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) acc[k] += BME ? coef * plift[k] : plift[k];
+                    }
+                    lean_poly_edge<M, HY>(t, xtop - x - i, S[i], acc, ed[i].x, ed[i].y, kd[i], kn[i], negative, criterion, lds_pow, hand, hand_base, best);
+                }
+            }
+            continue;
+        }
+#pragma unroll 1
+        for (int i = 0; i < m; ++i) {
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+            for (int j = 0; j < m; ++j) {
+                if (j == i) continue;
+                const int s = xtop - x - j;
+                const double2 a = t.T0[s], b = t.T1[s], c = t.T2[s];
+                const double Sj[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+                double u[6];
+                lift<M>(Sj, t.E[s].x, u);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) acc[k] += BME ? coef * u[k] : u[k];
+            }
+            if (!is_lca) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) acc[k] += BME ? coef * plift[k] : plift[k];
+            }
+            const int s = xtop - x - i;
+            const double2 a = t.T0[s], b = t.T1[s], c = t.T2[s];
+            const double Sk[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+            const double2 ed = t.E[s];
+            lean_poly_edge<M, HY>(t, s, Sk, acc, ed.x, ed.y, t.D[s].x, t.N[s].x, negative, criterion, lds_pow, hand, hand_base, best);
+        }
+    }
 }
 
 // the query's placement from the team's winner (apples/Algorithm.py:92-101); `mine` = this lane holds the winning edge
@@ -489,9 +780,11 @@ __device__ __forceinline__ void lean_write_placement(apples_placement *out, int6
 // team's arg-min over (x_1 kept, rank) then names the winner.  A NaN error is never taken (sweep.hip's HYBRID: the same rule).
 // `argmin(key, id)`: the team's lexicographic arg-min, result in every lane.  Returns 0x7fffffff when there is no edge at all;
 // `mine` = this lane holds the winner (its record in `best`).
+// xn > 0 (polytomies): the edges below a polytomy have their records in the query's child records [0, xn) (lean_poly_td), the
+// marked entries themselves hold none.
 template <class ArgMin>
 __device__ __forceinline__ int lean_hybrid_pick(const LeanTeam &t, int lo, int hi, int V, int first, int stride, ArgMin &&argmin,
-                                                LeanBest &best, bool &mine) {
+                                                LeanBest &best, bool &mine, int xtop = 0, int xn = 0) {
     const int kk = 31 - __clz(V);
     double last_e = -INF_D;
     int last_v = -1;
@@ -529,10 +822,12 @@ __device__ __forceinline__ int lean_hybrid_pick(const LeanTeam &t, int lo, int h
         };
         for (int idx = lo + first; idx < hi; idx += stride) {
             const int2 d = t.D[idx], nd = t.N[idx];
+            if (xn > 0 && lean_is_poly_entry(d)) continue;
             const double2 er = t.T0[idx];
             offer(er.x, nd.x, 2 * idx);
             if (d.y != 0) offer(er.y, nd.y, 2 * idx + 1);
         }
+        for (int x = first; x < xn; x += stride) offer(t.DD[xtop - x].x, t.N[xtop - x].x, LEAN_POLY_KID | x);
         more = seen > filled;
     };
     for (int r = 0; r < kk; ++r) {
@@ -548,16 +843,17 @@ __device__ __forceinline__ int lean_hybrid_pick(const LeanTeam &t, int lo, int h
         last_e = ke; last_v = kv;
         if (my_v == kv && at >= 0) {  // (edge indices are distinct: one owner)
             ++head;
-            const int idx = at >> 1, z = at & 1;
-            double x1 = reinterpret_cast<const double *>(t.T1 + idx)[z];
+            const bool rec = (at & LEAN_POLY_KID) != 0;  // (a child record of a polytomy)
+            const int idx = rec ? xtop - (at & ~LEAN_POLY_KID) : at >> 1, z = rec ? 1 : at & 1;
+            double x1 = rec ? t.DD[idx].y : reinterpret_cast<const double *>(t.T1 + idx)[z];
             const bool boxed = __double_as_longlong(x1) == LEAN_BOXED_INT0;
             if (boxed) x1 = 0;
             const double kx = (r == 0 && !(x1 == x1)) ? -INF_D : x1;
             if (r == 0 || kx < keep_x1) {
                 keep_x1 = kx; keep_rank = r;
                 best.v = kv; best.x1 = x1; best.x1_int = boxed ? 1 : 0; best.err = ke;
-                best.x2 = reinterpret_cast<const double *>(t.T2 + idx)[z];
-                best.e = reinterpret_cast<const double *>(t.E + idx)[z];
+                best.x2 = rec ? t.E[idx].y : reinterpret_cast<const double *>(t.T2 + idx)[z];
+                best.e = reinterpret_cast<const double *>(t.E + idx)[rec ? 0 : z];
             }
         }
     }
@@ -602,14 +898,18 @@ __device__ __forceinline__ int lean_query_cap(int n) { return (3 * n + 128 + min
 // The top-down pass of ONE query of a wavefront-sized team (all_R_values, placement_per_edge, error_per_edge, the arg-min of
 // apples/Algorithm.py:74-91) from what its bottom-up pass left: the pool offset, the number of level groups G and of internal
 // nodes VI, the groups' offsets.  `stage`: the wavefront's LDS area for tuples on their way to a level of at most 64 nodes.
-template <int M, bool HY = false>
+// PL (polytomies): xn = the query's child records (in its entry range from the top down), the records of group g's nodes at
+// [xoff[g], xoff[g + 1]) with xoff = the second half of the query's group offsets.
+template <int M, bool HY = false, bool PL = false>
 __device__ __forceinline__ void lean_down_one(const SweepArgs &a, const double *lds_pow, double2 (*stage)[WAVE], int64_t q, int n,
-                                              int64_t off, int G, int VI, int lane) {
+                                              int64_t off, int G, int VI, int lane, int xn = 0) {
     const DevTree &T = a.tree;
     const int V = VI + n;  // Subtree.num_nodes
     LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, off, nullptr, 0, 0);
     t.BP = a.blk_pool;
-    const int32_t *grp_off = a.grp_off + q * (int64_t)(T.height + 4);
+    const int32_t *grp_off = a.grp_off + q * (int64_t)a.grp_stride;
+    const int32_t *xoff = grp_off + (T.height + 4);
+    const int xtop = lean_query_cap(n) - 1;
     LeanBest best;
     lean_best_init(best);
     bool hand_in = false;  // this level's lifted R tuples wait in LDS (handed over by the level above)
@@ -618,11 +918,21 @@ __device__ __forceinline__ void lean_down_one(const SweepArgs &a, const double *
         const int ng = g1 - g0;
         const bool hand_out = g0 - k0 <= WAVE;  // the children's level has at most 64 nodes: their tuples go through LDS
         if (ng <= 32) {
-            lean_td_pairs<M, HY>(t, g0, ng, VI, lane, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
-                                 hand_out ? stage : nullptr, k0, best);
+            lean_td_pairs<M, HY, PL>(t, g0, ng, VI, lane, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
+                                     hand_out ? stage : nullptr, k0, best);
         } else {
-            lean_td_chunks<M, false, HY>(t, g0, g1, lane, WAVE, VI, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
-                                         hand_out ? stage : nullptr, k0, best);
+            lean_td_chunks<M, false, HY, PL>(t, g0, g1, lane, WAVE, VI, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
+                                             hand_out ? stage : nullptr, k0, best);
+        }
+        if (PL && xn > 0) {
+            const int x0 = xoff[g], x1 = xoff[g + 1];
+            if (x1 > x0) {  // this level's polytomies (the binary step has read its hand-over: the stage is free to take theirs)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                const LeanTeam tc = t;
+                LeanBest b2 = best;  // (a copy: the call takes a reference, and `best` itself stays in registers)
+                lean_poly_td<M, HY>(tc, xtop, x0, x1, lane, WAVE, VI, a.negative, a.criterion, lds_pow, hand_out ? stage : nullptr, k0, b2);
+                best = b2;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         hand_in = hand_out;
@@ -630,7 +940,7 @@ __device__ __forceinline__ void lean_down_one(const SweepArgs &a, const double *
     if (HY) {
         bool mine = false;
         const int none = lean_hybrid_pick(t, grp_off[1], grp_off[G + 1], V, lane, WAVE,
-                                          [](double &d, int &i) { team_argmin<WAVE>(d, i, nullptr, nullptr); }, best, mine);
+                                          [](double &d, int &i) { team_argmin<WAVE>(d, i, nullptr, nullptr); }, best, mine, xtop, PL ? xn : 0);
         lean_write_placement(a.out, q, V, mine ? best.v : none, mine, lane == 0, best);
         return;
     }
@@ -644,7 +954,9 @@ __device__ __forceinline__ void lean_down_one(const SweepArgs &a, const double *
 // Bottom-up kernel of the wavefront-sized teams: level lists and S tuples of one query after the other, into the pool.
 // FUSED (k_lean_both, APPLES_LEAN_FUSED=1): the team runs the query's top-down pass right behind its bottom-up pass -- one launch
 // and one tail per device batch instead of two; measured slower (register spills: launch_sweep_lean), not the default.
-template <int M, bool FUSED = false>
+// PL: the tree has polytomies (child records, lean_poly_S).  Trees of more than LEAN_MAX_LEVELS - 2 levels: the per-level
+// offsets sit in LDS as a window of LEAN_MAX_LEVELS that follows the walk upward.
+template <int M, bool FUSED = false, bool PL = false>
 __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double *lds_pow = nullptr) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
@@ -682,7 +994,8 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
         unsigned int off0 = 0;
         if (lane == 0) off0 = atomicAdd(a.pool_cursor, (unsigned int)qcap);
         const int64_t off = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)off0);
-        int32_t *grp_off = a.grp_off + q * (int64_t)(T.height + 4);
+        int32_t *grp_off = a.grp_off + q * (int64_t)a.grp_stride;
+        int32_t *xoff = grp_off + (T.height + 4);  // (PL) child records before each group's
         if (off + qcap > a.lean_cap1) {
             if (lane == 0) { a.lean_meta[q] = make_int4(0, -1, 0, 0); a.overflow_list[atomicAdd(a.overflow_count, 1)] = (int32_t)q; }
             continue;
@@ -694,7 +1007,11 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
 
         // ------------------------------------------------------------ up front: the per-level offsets into LDS; parent and
         // edge length of every observed leaf (independent gathers, all in flight together) into the team's arrays
-        for (int i = lane; i < T.height + 2; i += WAVE) L.cg[i] = cg[i];
+        // (a deep tree: the window [wlo, wlo + LEAN_MAX_LEVELS) of the offsets, reloaded when the walk leaves it below)
+        const bool deep = T.height + 2 > LEAN_MAX_LEVELS;
+        int wlo = 0;
+        if (deep) wlo = max(0, T.level[o_node[0]] + 2 - LEAN_MAX_LEVELS);
+        for (int i = lane; i < min(T.height + 2 - wlo, LEAN_MAX_LEVELS); i += WAVE) L.cg[i] = cg[wlo + i];
         for (int j0 = 0; j0 < n; j0 += 4 * WAVE) {
             int4 r[4];
 #pragma unroll
@@ -722,22 +1039,24 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
         int2 cD = make_int2(0, 0), cN = make_int2(0, 0);
         double2 cE = make_double2(0, 0), cDD = make_double2(0, 0);
         double pf_e = 0;
-        int lo = L.cg[lvl + 1], hi = L.cg[lvl];  // observed leaves of this level: obs[lo, hi)
+        int lo = L.cg[lvl + 1 - wlo], hi = L.cg[lvl - wlo];  // observed leaves of this level: obs[lo, hi)
         int n_leaf = hi - lo;
+        const int xtop = qcap - 1;  // (PL) child records: entry slots from the top of the query's range down
+        int xc = 0, xg = 0;         // ... how many there are, and how many there were before the current list's
         int lw_node = 0, lw_par = 0;
         double lw_e = 0, lw_dist = 0;
         if (n_leaf <= WAVE && lane < n_leaf) { lw_node = o_node[lo + lane]; lw_par = t.LP[lo + lane]; lw_e = t.LE[lo + lane]; lw_dist = o_dist[lo + lane]; }
         LEAN_TICK(1);
         while (true) {
             if (n_par + n_leaf == 1 && hi == n) break;  // one node left in the frontier: the LCA (Subtree.py:36-43), entry `base`
-            if ((int64_t)base + 2 * (int64_t)n_par + n_leaf > cap) { overflow = true; break; }
-            if (lane == 0) grp_off[G] = base;
+            if ((int64_t)base + 2 * (int64_t)n_par + n_leaf + (PL ? (int64_t)xc + n_par + n_leaf : 0) > cap) { overflow = true; break; }
+            if (lane == 0) { grp_off[G] = base; if (PL) xoff[G + 1] = xc; }
             const int next_base = base + n_par;
             // ---- S tuples of this level's internal nodes
             if (n_par > 0 && n_par <= WAVE) {
                 double r[6];
                 if (lane < n_par) {
-                    node_S<M>(cD, cE, cDD, t, stage, prev_staged, kid_base, r);
+                    node_S<M, PL>(cD, cE, cDD, t, stage, prev_staged, kid_base, r);
                     t.T0[base + lane] = make_double2(r[0], r[1]);
                     t.T1[base + lane] = make_double2(r[2], r[3]);
                     t.T2[base + lane] = make_double2(r[4], r[5]);
@@ -749,12 +1068,26 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
                     stage[2][lane] = make_double2(r[4], r[5]);
                 }
             } else if (n_par > WAVE) {
-                lean_S_chunks<M>(t, base, next_base, lane, WAVE, stage, prev_staged, kid_base);
+                lean_S_chunks<M, PL>(t, base, next_base, lane, WAVE, stage, prev_staged, kid_base);
             }
+            if (PL && xc > xg && !LEAN_EXP_NO_FIX) {  // this list's polytomies: their tuples over all their children (never on a binary tree)
+                // (the lane state the next steps need waits in the merge windows, which are free here: nothing but scalars lives
+                // across the call)
+                L.ka[lane] = cK; L.pa[lane] = pf_par; L.ea[lane] = pf_e;
+                L.kb[lane] = lw_node; L.pb[lane] = lw_par; L.eb[lane] = lw_e; L.db[lane] = lw_dist;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                const LeanTeam tc = t;
+                lean_poly_S<M>(tc, xtop, xg, xc, lane, WAVE, n_par <= WAVE ? stage : nullptr, base);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                cK = L.ka[lane]; pf_par = L.pa[lane]; pf_e = L.ea[lane];
+                lw_node = L.kb[lane]; lw_par = L.pb[lane]; lw_e = L.eb[lane]; lw_dist = L.db[lane];
+                __builtin_amdgcn_wave_barrier();
+            }
+            xg = xc;
             // ---- the next level's list
             int merged;
             if (n_par <= WAVE && n_par + n_leaf <= WAVE) {
-                if (lane < n_par) { L.ka[lane] = cK; L.pa[lane] = pf_par; L.ea[lane] = pf_e; }
+                if (lane < n_par) { L.ka[lane] = cK; L.pa[lane] = pf_par; L.ea[lane] = pf_e; }  // (PL: cK may carry LEAN_POLY_KID)
                 if (lane < n_leaf) { L.kb[lane] = lw_node; L.pb[lane] = lw_par; L.eb[lane] = lw_e; L.db[lane] = lw_dist; }
                 __builtin_amdgcn_wave_barrier();
                 const int tot = n_par + n_leaf;
@@ -762,13 +1095,14 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
                 int i_lo = max(0, lane - n_leaf), i_hi = min(lane, n_par);  // i = keys of the list among the lane smallest
                 while (i_lo < i_hi) {
                     const int i = (i_lo + i_hi) >> 1;
-                    if (L.ka[i] < L.kb[lane - 1 - i]) i_lo = i + 1; else i_hi = i;
+                    if (lean_key_node<PL>(L.ka[i]) < L.kb[lane - 1 - i]) i_lo = i + 1; else i_hi = i;
                 }
                 const int i = i_lo, j = lane - i_lo;
-                const int ka = i < n_par ? L.ka[i] : 0x7fffffff, kb = j < n_leaf ? L.kb[j] : 0x7fffffff;
+                const int kaf = i < n_par ? L.ka[i] : 0x7fffffff;
+                const int ka = i < n_par ? lean_key_node<PL>(kaf) : 0x7fffffff, kb = j < n_leaf ? L.kb[j] : 0x7fffffff;
                 const bool from_a = ka < kb;
                 const int key = from_a ? ka : kb;
-                const int desc = from_a ? base + i + 1 : -(lo + j) - 2;
+                const int desc = from_a ? ((base + i + 1) | (PL ? (kaf & LEAN_POLY_KID) : 0)) : -(lo + j) - 2;
                 int par = -3;
                 double e = 0, dist = 0;
                 if (active) {
@@ -783,17 +1117,31 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
                 const bool two = lane + 1 < tot && !next_first;
                 const unsigned long long fm = __ballot(first);
                 merged = __popcll(fm);
+                LeanRun run = {false, false};
+                int kflag = 0;  // (PL) the run this lane begins has a third key: the node is a polytomy
+                LeanRunMasks rm = {0, 0, 0};
+                if (PL) {
+                    rm = lean_run_masks(fm, tot, 0);
+                    run.extra = (rm.extra >> lane) & 1ull;
+                    run.xfirst = (rm.xfirst >> lane) & 1ull;
+                    kflag = ((rm.third >> lane) & 1ull) ? LEAN_POLY_KID : 0;
+                }
                 if (first) {
                     const int c = __popcll(fm & below);
                     const int2 eD = make_int2(desc, two ? next_desc : 0), eN = make_int2(key, two ? next_key : -1);
                     const double2 eE = make_double2(e, two ? next_e : 0.0), eDD = make_double2(dist, two ? next_dist : 0.0);
-                    L.oK[c] = par; L.oD[c] = eD; L.oN[c] = eN; L.oE[c] = eE; L.oDD[c] = eDD;
-                    t.K[next_base + c] = par; t.D[next_base + c] = eD; t.N[next_base + c] = eN; t.E[next_base + c] = eE; t.DD[next_base + c] = eDD;
+                    L.oK[c] = par | kflag; L.oD[c] = eD; L.oN[c] = eN; L.oE[c] = eE; L.oDD[c] = eDD;
+                    t.K[next_base + c] = par | kflag; t.D[next_base + c] = eD; t.N[next_base + c] = eN; t.E[next_base + c] = eE; t.DD[next_base + c] = eDD;
+                }
+                if (PL && rm.extra != 0ull) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    const int en = next_base + __popcll(fm & (below | (1ull << lane))) - 1;
+                    xc += lean_poly_records(t, xtop, xc, run, en, par, desc, key, e, dist, lane);
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (lane < merged) { cK = L.oK[lane]; cD = L.oD[lane]; cN = L.oN[lane]; cE = L.oE[lane]; cDD = L.oDD[lane]; }
             } else {
-                merged = lean_merge(t, base, n_par, o_node, o_dist, lo, n_leaf, next_base, pe, L.ka, L.kb, lane);
+                merged = lean_merge<PL>(t, base, n_par, o_node, o_dist, lo, n_leaf, next_base, pe, L.ka, L.kb, lane, xtop, xc);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (merged <= WAVE && lane < merged) {
                     cK = t.K[next_base + lane]; cD = t.D[next_base + lane]; cN = t.N[next_base + lane];
@@ -802,7 +1150,7 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
             }
             // {parent, edge length} of the new list's keys: on the way while the next step computes its S tuples
             if (merged <= WAVE && lane < merged) {
-                const int4 r = pe[cK];
+                const int4 r = pe[lean_key_node<PL>(cK)];
                 pf_par = r.x;
                 pf_e = pe_len(r);
             }
@@ -813,7 +1161,13 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
             n_par = merged;
             ++G;
             --lvl;
-            lo = L.cg[lvl + 1]; hi = L.cg[lvl];
+            if (deep && lvl < wlo) {  // (the walk left the window: the next LEAN_MAX_LEVELS levels up)
+                wlo = max(0, lvl + 2 - LEAN_MAX_LEVELS);
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < min(T.height + 2 - wlo, LEAN_MAX_LEVELS); i += WAVE) L.cg[i] = cg[wlo + i];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            lo = L.cg[lvl + 1 - wlo]; hi = L.cg[lvl - wlo];
             n_leaf = hi - lo;
             if (n_leaf <= WAVE && lane < n_leaf) { lw_node = o_node[lo + lane]; lw_par = t.LP[lo + lane]; lw_e = t.LE[lo + lane]; lw_dist = o_dist[lo + lane]; }
         }
@@ -823,10 +1177,18 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
             continue;
         }
         // internal valid nodes: base; the LCA's entry sits at that index.  What the top-down kernel needs of this query:
-        if (lane == 0) { grp_off[G] = base; grp_off[G + 1] = base + 1; a.lean_meta[q] = make_int4((int)off, G, base, 0); }
+        if (PL && xc > xg && !LEAN_EXP_NO_FIX) {  // the LCA is a polytomy (a root trifurcation): its children's tuples into their records
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const LeanTeam tc = t;
+            lean_poly_S<M>(tc, xtop, xg, xc, lane, WAVE, nullptr, 0);
+        }
+        if (lane == 0) {
+            grp_off[G] = base; grp_off[G + 1] = base + 1; a.lean_meta[q] = make_int4((int)off, G, base, xc);
+            if (PL) xoff[G + 1] = xc;
+        }
         if (FUSED) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the group offsets and the entries: this wavefront's own writes)
-            if (a.debug_phase != 1) lean_down_one<M>(a, lds_pow, stage, q, n, off, G, base, lane);
+            if (a.debug_phase != 1) lean_down_one<M, false, PL>(a, lds_pow, stage, q, n, off, G, base, lane, xc);
         }
         if (prof) {
             if (lane == 0) {
@@ -843,7 +1205,7 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
 // Top-down kernel of the wavefront-sized teams: a node forms R for each valid child (all_R_values), solves it
 // (placement_per_edge) and evaluates its residual (error_per_edge); an internal child's tuple becomes lift(R) over its own
 // edge; then the query's arg-min (apples/Algorithm.py:74-91)
-template <int M, bool HY = false>
+template <int M, bool HY = false, bool PL = false>
 __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
@@ -852,7 +1214,7 @@ __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
     const DevTree &T = a.tree;
     const LeanQueue qu = lean_queue(a);
     unsigned long long pc[7] = {0, 0, 0, 0, 0, 0, 0}, pn[4] = {0, 0, 0, 0}, tk = 0;
-    const bool prof = a.prof != nullptr && !HY;  // (the cycle counters cover the MLSE / ME form)
+    const bool prof = a.prof != nullptr && !HY && !PL;  // (the cycle counters cover the MLSE / ME form on binary trees)
 #define LEAN_TICK(slot) do { if (prof) { const unsigned long long now_ = __builtin_readcyclecounter(); pc[slot] += now_ - tk; tk = now_; } } while (0)
     if (prof) tk = __builtin_readcyclecounter();
     while (true) {
@@ -867,11 +1229,11 @@ __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
         const int4 meta = a.lean_meta[q];
         const int G = meta.y, VI = meta.z;
         if (G < 0) continue;  // handed to the workgroup-sized teams by the bottom-up kernel
-        if (!prof) { lean_down_one<M, HY>(a, lds_pow, stage, q, n, meta.x & 0xffffffffll, G, VI, lane); continue; }
+        if (!prof) { lean_down_one<M, HY, PL>(a, lds_pow, stage, q, n, meta.x & 0xffffffffll, G, VI, lane, meta.w); continue; }
         const int V = VI + n;  // Subtree.num_nodes
         LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, meta.x & 0xffffffffll, nullptr, 0, 0);
         t.BP = a.blk_pool;
-        const int32_t *grp_off = a.grp_off + q * (int64_t)(T.height + 4);
+        const int32_t *grp_off = a.grp_off + q * (int64_t)a.grp_stride;
         LEAN_TICK(0);
         LeanBest best;
         lean_best_init(best);
@@ -923,17 +1285,18 @@ struct LeanBigShared {
     int m_par[TEAM], m_desc[TEAM], m_key[TEAM];    // what a step's lanes tell their neighbours
     double m_e[TEAM], m_dist[TEAM];
     int mcnt[2][TEAM / WAVE];
+    int xcnt[2][TEAM / WAVE];                      // (polytomies) a step's third / later siblings per wavefront
     double d[TEAM / WAVE];
     int i[TEAM / WAVE];
     int w;
 };
 
-template <int TEAM>
+template <int TEAM, bool PL>
 __device__ __forceinline__ int lean_merge_wg(const LeanTeam &t, int base, int nA, const int32_t *__restrict__ o_node,
                                              const double *__restrict__ o_dist, int lo, int nB, int next_base,
-                                             const int4 *__restrict__ pe, LeanBigShared<TEAM> &sh) {
+                                             const int4 *__restrict__ pe, LeanBigShared<TEAM> &sh, int xtop, int &xc) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    int out = 0, ia = 0, ib = 0, carry = -2;
+    int out = 0, ia = 0, ib = 0, carry = -2, ccnt = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
     int wk_a = tid < nA ? t.K[base + tid] : 0x7fffffff, wk_b = tid < nB ? o_node[lo + tid] : 0x7fffffff;
     while (ia < nA || ib < nB) {
@@ -946,13 +1309,14 @@ __device__ __forceinline__ int lean_merge_wg(const LeanTeam &t, int base, int nA
         int i_lo = max(0, tid - wb), i_hi = min(tid, wa);
         while (i_lo < i_hi) {
             const int i = (i_lo + i_hi) >> 1;
-            if (sh.ka[i] < sh.kb[tid - 1 - i]) i_lo = i + 1; else i_hi = i;
+            if (lean_key_node<PL>(sh.ka[i]) < sh.kb[tid - 1 - i]) i_lo = i + 1; else i_hi = i;
         }
         const int i = i_lo, j = tid - i_lo;
-        const int ka = i < wa ? sh.ka[i] : 0x7fffffff, kb = j < wb ? sh.kb[j] : 0x7fffffff;
+        const int kaf = i < wa ? sh.ka[i] : 0x7fffffff;  // (PL: a polytomy's key carries LEAN_POLY_KID)
+        const int ka = i < wa ? lean_key_node<PL>(kaf) : 0x7fffffff, kb = j < wb ? sh.kb[j] : 0x7fffffff;
         const bool from_a = ka < kb;
         const int key = from_a ? ka : kb;
-        const int desc = from_a ? base + ia + i + 1 : -(lo + ib + j) - 2;
+        const int desc = from_a ? ((base + ia + i + 1) | (PL ? (kaf & LEAN_POLY_KID) : 0)) : -(lo + ib + j) - 2;
         const unsigned long long am = __ballot(active && from_a);
         if (lane == 0) sh.mcnt[1][wave] = __popcll(am);
         __syncthreads();  // (the windows are read: the next step may overwrite them after its own first barrier)
@@ -982,21 +1346,62 @@ __device__ __forceinline__ int lean_merge_wg(const LeanTeam &t, int base, int nA
         const unsigned long long fm = __ballot(first);
         if (lane == 0) sh.mcnt[0][wave] = __popcll(fm);
         const int last_par = sh.m_par[tot - 1];
+        // (PL) the lane's place in its run of siblings, as lean_run_of with the neighbours in LDS
+        bool extra = false, xfirst = false, third = false;
+        unsigned long long m3 = 0, m1 = 0;
+        int ncc = 0;
+        if (PL) {
+            const bool c = carry == par;
+            const bool s1 = tid >= 1 ? sh.m_par[tid - 1] == par : (c && ccnt >= 1);
+            const bool s2 = s1 && (tid >= 2 ? sh.m_par[tid - 2] == par : (c && ccnt >= 2 - tid));
+            const bool s3 = s2 && (tid >= 3 ? sh.m_par[tid - 3] == par : (c && ccnt >= 3 - tid));
+            extra = active && s2;
+            xfirst = extra && !s3;
+            third = first && tid + 2 < tot && sh.m_par[tid + 2] == par;
+            m3 = __ballot(xfirst);
+            m1 = __ballot(extra && !xfirst);
+            if (lane == 0) { sh.xcnt[0][wave] = __popcll(m3); sh.xcnt[1][wave] = __popcll(m1); }
+            // keys of the step's last run (capped at 3; with the carried ones when the whole step belongs to the run before)
+            const bool a1 = tot >= 2 && sh.m_par[tot - 2] == last_par, a2 = a1 && tot >= 3 && sh.m_par[tot - 3] == last_par;
+            ncc = a2 ? 3 : (a1 ? 2 : 1);
+            if (ncc == tot && carry == last_par) ncc = min(ncc + ccnt, 3);
+        }
         __syncthreads();
-        int before = 0, total = 0;
+        int before = 0, total = 0, xb3 = 0, xb1 = 0, xt3 = 0, xt1 = 0;
 #pragma unroll
         for (int w = 0; w < TEAM / WAVE; ++w) {
             if (w < wave) before += sh.mcnt[0][w];
             total += sh.mcnt[0][w];
+            if (PL) {
+                if (w < wave) { xb3 += sh.xcnt[0][w]; xb1 += sh.xcnt[1][w]; }
+                xt3 += sh.xcnt[0][w]; xt1 += sh.xcnt[1][w];
+            }
         }
+        if (PL && extra) {  // a child record (lean_poly_records, with the counts of the wavefronts before)
+            const int en = next_base + out + before + __popcll(fm & (below | (1ull << lane))) - 1;
+            const int x0 = xc + 3 * (xb3 + __popcll(m3 & below)) + xb1 + __popcll(m1 & below);
+            const int x = xfirst ? x0 + 2 : x0;
+            t.D[xtop - x] = make_int2(desc, xfirst ? 2 : 3);
+            t.N[xtop - x] = make_int2(key, en);
+            t.E[xtop - x] = make_double2(e, dist);
+            if (xfirst) {
+                t.D[xtop - x0] = make_int2(0, 0);
+                t.N[xtop - x0] = make_int2(-1, en);
+                t.D[xtop - x0 - 1] = make_int2(0, 1);
+                t.N[xtop - x0 - 1] = make_int2(-1, en);
+                // (the entry's own store of its key: this step's carries the mark already -- `third` -- an earlier step's is long done)
+                t.K[en] = par | LEAN_POLY_KID;
+            }
+        }
+        if (PL) { xc += 3 * xt3 + xt1; ccnt = ncc; }
         if (first) {
             const int at = next_base + out + before + __popcll(fm & below);
-            t.K[at] = par;
+            t.K[at] = (PL && third) ? (par | LEAN_POLY_KID) : par;
             t.D[at] = make_int2(desc, two ? sh.m_desc[tid + 1] : 0);
             t.N[at] = make_int2(key, two ? sh.m_key[tid + 1] : -1);
             t.E[at] = make_double2(e, two ? sh.m_e[tid + 1] : 0.0);
             t.DD[at] = make_double2(dist, two ? sh.m_dist[tid + 1] : 0.0);
-        } else if (tid == 0 && active) {  // the second child of the previous step's last entry
+        } else if (tid == 0 && active && !(PL && extra)) {  // the second child of the previous step's last entry
             const int at = next_base + out - 1;
             reinterpret_cast<int *>(t.D + at)[1] = desc;
             reinterpret_cast<int *>(t.N + at)[1] = key;
@@ -1033,7 +1438,7 @@ __device__ __forceinline__ void lean_argmin_wg(double &d, int &i, LeanBigShared<
     }
 }
 
-template <int M, int TEAM, bool HY = false>
+template <int M, int TEAM, bool HY = false, bool PL = false>
 __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM> &sh) {
     const int tid = threadIdx.x;
     const double *lds_pow = sh.pow;
@@ -1041,7 +1446,10 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
     const int4 *__restrict__ pe = reinterpret_cast<const int4 *>(T.pe);
     LeanTeam t = lean_team(a.lean, blockIdx.x, a.lean_cap1, a.lean_leaf1);
     t.BP = a.blk_pool;
-    int32_t *grp_off = a.grp_off + (int64_t)blockIdx.x * (T.height + 4);
+    int32_t *grp_off = a.grp_off + (int64_t)blockIdx.x * a.grp_stride;
+    int32_t *xoff = grp_off + (T.height + 4);  // (PL) child records before each group's
+    const int xtop = (int)a.lean_cap1 - 1;     // (PL) child records: the team's entry slots from the top down
+    const bool deep = T.height + 2 > LEAN_MAX_LEVELS;  // the per-level offsets in LDS as a window that follows the walk
     // work: a device-side list, or (routed queries) three lists by size class, largest first
     const int r0 = a.route_classes ? a.work_count[4] : 0, r1 = a.route_classes ? a.work_count[5] : 0;
     const int64_t n_work = a.route_classes ? (int64_t)r0 + r1 + a.work_count[6] : (a.work_count ? *a.work_count : nq);
@@ -1059,23 +1467,36 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
         const int32_t *o_node = a.obs_node + q * a.obs_cap;
         const double *o_dist = a.obs_dist + q * a.obs_cap;
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
-        for (int i = tid; i < T.height + 2; i += TEAM) sh.cg[i] = cg[i];
+        const int lvl_first = T.level[o_node[0]];
+        int wlo = deep ? max(0, lvl_first + 2 - LEAN_MAX_LEVELS) : 0;
+        for (int i = tid; i < min(T.height + 2 - wlo, LEAN_MAX_LEVELS); i += TEAM) sh.cg[i] = cg[wlo + i];
         for (int j = tid; j < n; j += TEAM) {
             const int4 r = pe[o_node[j]];
             t.LP[j] = r.x;
             t.LE[j] = pe_len(r);
         }
-        const int lvl_first = T.level[o_node[0]];
         __syncthreads();
-        int lvl = lvl_first, base = 0, n_par = 0, G = 0;
+        int lvl = lvl_first, base = 0, n_par = 0, G = 0, xc = 0, xg = 0;
         while (true) {
-            const int lo = sh.cg[lvl + 1], hi = sh.cg[lvl];
+            if (deep && lvl < wlo) {  // (the walk left the window: the next LEAN_MAX_LEVELS levels up)
+                wlo = max(0, lvl + 2 - LEAN_MAX_LEVELS);
+                __syncthreads();
+                for (int i = tid; i < min(T.height + 2 - wlo, LEAN_MAX_LEVELS); i += TEAM) sh.cg[i] = cg[wlo + i];
+                __syncthreads();
+            }
+            const int lo = sh.cg[lvl + 1 - wlo], hi = sh.cg[lvl - wlo];
             const int n_leaf = hi - lo;
             if (n_par + n_leaf == 1 && hi == n) break;  // the LCA (Subtree.py:36-43), entry `base`
-            if (tid == 0) grp_off[G] = base;
+            if (tid == 0) { grp_off[G] = base; if (PL) xoff[G + 1] = xc; }
             const int next_base = base + n_par;
-            lean_S_chunks<M>(t, base, next_base, tid, TEAM, nullptr, false, 0);  // S tuples of this level (the level below's are complete)
-            const int merged = lean_merge_wg<TEAM>(t, base, n_par, o_node, o_dist, lo, n_leaf, next_base, pe, sh);
+            lean_S_chunks<M, PL>(t, base, next_base, tid, TEAM, nullptr, false, 0);  // S tuples of this level (the level below's are complete)
+            if (PL && xc > xg) {  // this list's polytomies: their tuples over all their children
+                __syncthreads();
+                const LeanTeam tc = t;
+                lean_poly_S<M>(tc, xtop, xg, xc, tid, TEAM, nullptr, 0);
+            }
+            xg = xc;
+            const int merged = lean_merge_wg<TEAM, PL>(t, base, n_par, o_node, o_dist, lo, n_leaf, next_base, pe, sh, xtop, xc);
             __syncthreads();
             base = next_base;
             n_par = merged;
@@ -1083,20 +1504,34 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
             --lvl;
         }
         const int VI = base, V = base + n;
-        if (tid == 0) { grp_off[G] = VI; grp_off[G + 1] = VI + 1; }
+        if (PL && xc > xg) {  // the LCA is a polytomy: its children's tuples into their records
+            __syncthreads();
+            const LeanTeam tc = t;
+            lean_poly_S<M>(tc, xtop, xg, xc, tid, TEAM, nullptr, 0);
+        }
+        if (tid == 0) { grp_off[G] = VI; grp_off[G + 1] = VI + 1; if (PL) xoff[G + 1] = xc; }
         __syncthreads();
         if (a.debug_phase == 1) continue;
         LeanBest best;
         lean_best_init(best);
         for (int g = G; g >= 1; --g) {
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
-            lean_td_chunks<M, true, HY>(t, g0, g1, tid, TEAM, VI, a.negative, a.criterion, lds_pow, nullptr, nullptr, 0, best);
+            lean_td_chunks<M, true, HY, PL>(t, g0, g1, tid, TEAM, VI, a.negative, a.criterion, lds_pow, nullptr, nullptr, 0, best);
+            if (PL && xc > 0) {
+                const int x0 = xoff[g], x1 = xoff[g + 1];
+                if (x1 > x0) {
+                    const LeanTeam tc = t;
+                    LeanBest b2 = best;
+                    lean_poly_td<M, HY>(tc, xtop, x0, x1, tid, TEAM, VI, a.negative, a.criterion, lds_pow, nullptr, 0, b2);
+                    best = b2;
+                }
+            }
             __syncthreads();
         }
         if (HY) {
             bool mine = false;
             const int none = lean_hybrid_pick(t, grp_off[1], VI + 1, V, tid, TEAM,
-                                              [&sh](double &d, int &i) { lean_argmin_wg<TEAM>(d, i, sh); }, best, mine);
+                                              [&sh](double &d, int &i) { lean_argmin_wg<TEAM>(d, i, sh); }, best, mine, xtop, PL ? xc : 0);
             lean_write_placement(a.out, q, V, mine ? best.v : none, mine, tid == 0, best);
             __syncthreads();
             continue;
@@ -1110,39 +1545,42 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
     }
 }
 
-template <int M, int TEAM, bool HY = false>
+template <int M, int TEAM, bool HY = false, bool PL = false>
 __global__ __launch_bounds__(TEAM, TEAM / 256 * 2 > 2 ? 2 : TEAM / 256 * 2) void k_sweep_lean_big(SweepArgs a, int64_t nq) {
     __shared__ LeanBigShared<TEAM> sh;
     for (int i = threadIdx.x; i < 384; i += TEAM) sh.pow[i] = (&kPowLogTab[0][0])[i];
     for (int i = threadIdx.x; i < 256; i += TEAM) sh.pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
     __syncthreads();
-    lean_big_loop<M, TEAM, HY>(a, nq, sh);
+    lean_big_loop<M, TEAM, HY, PL>(a, nq, sh);
+}
+
+template <int TEAM, bool HY, bool PL>
+void launch_lean_big_m(const SweepArgs &a, int64_t nq, dim3 grid, hipStream_t st) {
+    const dim3 block(TEAM);
+    switch (a.method) {
+        case APPLES_FM: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_FM, TEAM, HY, PL>), grid, block, 0, st, a, nq); break;
+        case APPLES_BME: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BME, TEAM, HY, PL>), grid, block, 0, st, a, nq); break;
+        case APPLES_BE: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BE, TEAM, HY, PL>), grid, block, 0, st, a, nq); break;
+        default: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_OLS, TEAM, HY, PL>), grid, block, 0, st, a, nq); break;
+    }
 }
 
 template <int TEAM>
 void launch_lean_big_t(const SweepArgs &a, int64_t nq, dim3 grid, hipStream_t st) {
-    const dim3 block(TEAM);
+    const bool poly = a.tree.max_children > 2 || getenv("APPLES_LEAN_FORCE_POLY") != nullptr;  // (the kernels for trees with polytomies: child records, lean_poly_S / lean_poly_td; the knob: timing experiments on binary trees)
     if (a.criterion == APPLES_HYBRID) {
-        switch (a.method) {
-            case APPLES_FM: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_FM, TEAM, true>), grid, block, 0, st, a, nq); break;
-            case APPLES_BME: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BME, TEAM, true>), grid, block, 0, st, a, nq); break;
-            case APPLES_BE: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BE, TEAM, true>), grid, block, 0, st, a, nq); break;
-            default: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_OLS, TEAM, true>), grid, block, 0, st, a, nq); break;
-        }
-        return;
-    }
-    switch (a.method) {
-        case APPLES_FM: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_FM, TEAM>), grid, block, 0, st, a, nq); break;
-        case APPLES_BME: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BME, TEAM>), grid, block, 0, st, a, nq); break;
-        case APPLES_BE: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_BE, TEAM>), grid, block, 0, st, a, nq); break;
-        default: hipLaunchKernelGGL((k_sweep_lean_big<APPLES_OLS, TEAM>), grid, block, 0, st, a, nq); break;
+        if (poly) launch_lean_big_m<TEAM, true, true>(a, nq, grid, st);
+        else launch_lean_big_m<TEAM, true, false>(a, nq, grid, st);
+    } else {
+        if (poly) launch_lean_big_m<TEAM, false, true>(a, nq, grid, st);
+        else launch_lean_big_m<TEAM, false, false>(a, nq, grid, st);
     }
 }
 
-template <int M>
+template <int M, bool PL = false>
 __global__ __launch_bounds__(APPLES_TPB, LEAN_UP_WAVES) void k_lean_up(SweepArgs a) {
     __shared__ LeanUpShared sh;
-    lean_up_loop<M>(a, sh);
+    lean_up_loop<M, false, PL>(a, sh);
 }
 
 struct LeanBothShared {
@@ -1159,13 +1597,13 @@ __global__ __launch_bounds__(APPLES_TPB, LEAN_UP_WAVES) void k_lean_both(SweepAr
     lean_up_loop<M, true>(a, sh.up, sh.pow);
 }
 
-template <int M, bool HY = false>
+template <int M, bool HY = false, bool PL = false>
 __global__ __launch_bounds__(APPLES_TPB, LEAN_DOWN_WAVES) void k_lean_down(SweepArgs a) {
     __shared__ LeanDownShared sh;
     for (int i = threadIdx.x; i < 384; i += APPLES_TPB) sh.pow[i] = (&kPowLogTab[0][0])[i];
     for (int i = threadIdx.x; i < 256; i += APPLES_TPB) sh.pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
     __syncthreads();
-    lean_down_loop<M, HY>(a, sh);
+    lean_down_loop<M, HY, PL>(a, sh);
 }
 
 
@@ -1591,7 +2029,7 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
     // config 5's block 1.31 -> 1.44, config 4 2.77 -> 3.05): at three wavefronts per SIMD the fused body spills 85 vector registers
     // where the bottom-up kernel alone spills 19 and the top-down kernel 8, and the launch it saves is worth less than that.
     static const bool fused = getenv("APPLES_LEAN_FUSED") != nullptr;  // experiment knob
-    if (fused && !up.prof && up.debug_phase != 1 && up.criterion != APPLES_HYBRID) {
+    if (fused && !up.prof && up.debug_phase != 1 && up.criterion != APPLES_HYBRID && up.tree.max_children <= 2) {
         switch (up.method) {
             case APPLES_FM: hipLaunchKernelGGL((k_lean_both<APPLES_FM>), gu, block, 0, st, up); break;
             case APPLES_BME: hipLaunchKernelGGL((k_lean_both<APPLES_BME>), gu, block, 0, st, up); break;
@@ -1601,7 +2039,19 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     }
+    // (the kernels for trees with polytomies; the knob: timing experiments on binary trees -- 1: both kernels, 2: bottom-up only, 3: top-down only)
+    const int force = getenv("APPLES_LEAN_FORCE_POLY") ? atoi(getenv("APPLES_LEAN_FORCE_POLY")) : 0;
+    const bool poly_up = up.tree.max_children > 2 || force == 1 || force == 2, poly = up.tree.max_children > 2 || force == 1 || force == 3;
     auto launch_up = [&](const SweepArgs &x, hipStream_t s_) {
+        if (poly_up) {
+            switch (x.method) {
+                case APPLES_FM: hipLaunchKernelGGL((k_lean_up<APPLES_FM, true>), gu, block, 0, s_, x); break;
+                case APPLES_BME: hipLaunchKernelGGL((k_lean_up<APPLES_BME, true>), gu, block, 0, s_, x); break;
+                case APPLES_BE: hipLaunchKernelGGL((k_lean_up<APPLES_BE, true>), gu, block, 0, s_, x); break;
+                default: hipLaunchKernelGGL((k_lean_up<APPLES_OLS, true>), gu, block, 0, s_, x); break;
+            }
+            return;
+        }
         switch (x.method) {
             case APPLES_FM: hipLaunchKernelGGL((k_lean_up<APPLES_FM>), gu, block, 0, s_, x); break;
             case APPLES_BME: hipLaunchKernelGGL((k_lean_up<APPLES_BME>), gu, block, 0, s_, x); break;
@@ -1610,6 +2060,24 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
         }
     };
     auto launch_down = [&](const SweepArgs &x, hipStream_t s_) {
+        if (poly) {
+            if (x.criterion == APPLES_HYBRID) {
+                switch (x.method) {
+                    case APPLES_FM: hipLaunchKernelGGL((k_lean_down<APPLES_FM, true, true>), gd, block, 0, s_, x); break;
+                    case APPLES_BME: hipLaunchKernelGGL((k_lean_down<APPLES_BME, true, true>), gd, block, 0, s_, x); break;
+                    case APPLES_BE: hipLaunchKernelGGL((k_lean_down<APPLES_BE, true, true>), gd, block, 0, s_, x); break;
+                    default: hipLaunchKernelGGL((k_lean_down<APPLES_OLS, true, true>), gd, block, 0, s_, x); break;
+                }
+            } else {
+                switch (x.method) {
+                    case APPLES_FM: hipLaunchKernelGGL((k_lean_down<APPLES_FM, false, true>), gd, block, 0, s_, x); break;
+                    case APPLES_BME: hipLaunchKernelGGL((k_lean_down<APPLES_BME, false, true>), gd, block, 0, s_, x); break;
+                    case APPLES_BE: hipLaunchKernelGGL((k_lean_down<APPLES_BE, false, true>), gd, block, 0, s_, x); break;
+                    default: hipLaunchKernelGGL((k_lean_down<APPLES_OLS, false, true>), gd, block, 0, s_, x); break;
+                }
+            }
+            return;
+        }
         if (x.criterion == APPLES_HYBRID) {  // (per-edge records in the entries' dead tuple slots + lean_hybrid_pick)
             switch (x.method) {
                 case APPLES_FM: hipLaunchKernelGGL((k_lean_down<APPLES_FM, true>), gd, block, 0, s_, x); break;

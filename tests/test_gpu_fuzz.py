@@ -50,6 +50,22 @@ def _crit(seed, c):
     return str(r.choice(CRITERIA)), bool(r.integers(0, 2))
 
 
+def _shaped(seed, c, n, make):
+    """The backbone's shape for configuration c, drawn apart from the configuration stream: the strictly binary random-join tree
+    (a third of the configurations), the same tree unrooted (a root trifurcation), with a share of its internal nodes dissolved
+    into their parents (polytomies of any degree, apples/OLS.py:36,59), hung on a caterpillar spine (more than 254 levels from
+    600 leaves on: the window of the lean sweep's per-level offsets), or both.  make(spine) -> dataset; returns (dataset, tag)."""
+    r = np.random.default_rng([seed, c, 78])
+    kind = str(r.choice(['binary', 'binary', 'unrooted', 'polytomies', 'deep', 'deep+polytomies']))
+    frac = float(r.choice([0.02, 0.1, 0.4]))
+    d = make(int(min(290, n // 2)) if kind.startswith('deep') else 0)
+    if kind == 'unrooted':
+        d.tree = synth.reshape_tree(d.tree, 'unrooted')
+    elif kind.endswith('polytomies'):
+        d.tree = synth.reshape_tree(d.tree, 'polytomies', seed=1000 * seed + c, frac=frac)
+    return d, ' shape %s%s' % (kind, ' %g' % frac if kind.endswith('polytomies') else '')
+
+
 def _diff(a, b):
     bad = np.nonzero([x.tobytes() != y.tobytes() for x, y in zip(a, b)])[0]
     return '%d rows differ, first %s: %s / %s' % (len(bad), bad[:5], a[bad[0]] if len(bad) else '', b[bad[0]] if len(bad) else '')
@@ -73,13 +89,13 @@ def test_clustered_routes_agree(seed):
         gap = float(rng.choice([0.0, 0.05, 0.3, 0.6])); thr = float(rng.choice([0.0, 0.02, 0.2, 0.5, 1.2])); b = int(rng.choice([3, 25, 200]))
         mb = int(rng.choice([0, 0, 32, 96, 160, 512])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
         diam = float(rng.choice([0.01, 0.05, 0.24, 0.4, 0.8]))
-        d = synth.make_dataset(n, L, nq, gap_rate=gap, seed_tree=200 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])))
+        d, shp = _shaped(seed, c, n, lambda spine: synth.make_dataset(n, L, nq, gap_rate=gap, seed_tree=200 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])), spine=spine))
         nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
         ca = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, diam)).cluster_arrays()
         crit, neg = _crit(seed, c)
         out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method=m, criterion=crit, negative=neg,
                                                 threshold=thr, baseobs=b, max_batch=mb, debug=dbg), d.query_seqs)
-        tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s diam %g' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit,
+        tag = shp + ' seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s diam %g' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit,
                                                                                           ' -n' if neg else '', diam)
         for k in ('by_query', 'no_topup', 'no_fuse', 'no_blocks', 'hybrid_records', 'no_cluster_mfma'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
@@ -106,12 +122,12 @@ def test_singleton_jc69_routes_agree(seed):
         n = int(rng.choice([40, 257, 600, 1500, 5000, 20000])); L = int(rng.integers(20, 2047)); nq = int(rng.integers(1, 700))
         gap = float(rng.choice([0.0, 0.05, 0.3, 0.6])); thr = float(rng.choice([0.05, 0.2, 0.5, 1.2])); b = int(rng.choice([3, 25, 200]))
         mb = int(rng.choice([0, 0, 32, 96, 160, 512])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
-        d = synth.make_dataset(n, L, nq, gap_rate=gap, seed_tree=100 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])))
+        d, shp = _shaped(seed, c, n, lambda spine: synth.make_dataset(n, L, nq, gap_rate=gap, seed_tree=100 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])), spine=spine))
         nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
         crit, neg = _crit(seed, c)
         out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, method=m, criterion=crit, negative=neg, threshold=thr,
                                                 baseobs=b, max_batch=mb, debug=dbg), d.query_seqs)
-        tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit, ' -n' if neg else '')
+        tag = shp + ' seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit, ' -n' if neg else '')
         for k in ('no_gemm', 'no_fuse', 'no_topup', 'serial_topup'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
@@ -147,7 +163,7 @@ def test_scoredist_routes_agree(seed):
         n = int(rng.choice([40, 257, 600, 1500, 5000, 20000])); L = int(rng.integers(7, 1200)); nq = int(rng.integers(1, 700))
         gap = float(rng.choice([0.0, 0.05, 0.3, 0.6])); thr = float(rng.choice([0.03, 0.1, 0.2, 0.24, 0.5])); b = int(rng.choice([3, 25, 200]))
         mb = int(rng.choice([0, 0, 32, 96, 160, 512])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
-        d = synth.make_dataset(n, L, nq, protein=True, gap_rate=gap, seed_tree=400 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])))
+        d, shp = _shaped(seed, c, n, lambda spine: synth.make_dataset(n, L, nq, protein=True, gap_rate=gap, seed_tree=400 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])), spine=spine))
         q = d.query_seqs.copy()
         if nq > 6:
             q[3] = d.ref_seqs[11 % n]          # an exact match
@@ -157,7 +173,7 @@ def test_scoredist_routes_agree(seed):
         crit, neg = _crit(seed, c)
         out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, protein=True, method=m, criterion=crit, negative=neg,
                                                 threshold=thr, baseobs=b, max_batch=mb, debug=dbg), q)
-        tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit, ' -n' if neg else '')
+        tag = shp + ' seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit, ' -n' if neg else '')
         for k in ('fp6', 'every_pair', 'rows_topup', 'no_fuse', 'serial_topup', 'row_lists', 'tiny_lists'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
@@ -185,7 +201,7 @@ def test_clustered_scoredist_routes_agree(seed):
         gap = float(rng.choice([0.0, 0.05, 0.3, 0.6])); thr = float(rng.choice([0.0, 0.03, 0.1, 0.2, 0.24, 0.5])); b = int(rng.choice([3, 25, 200]))
         mb = int(rng.choice([0, 0, 32, 96, 160, 512])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
         diam = float(rng.choice([0.01, 0.05, 0.24, 0.4, 0.8]))
-        d = synth.make_dataset(n, L, nq, protein=True, gap_rate=gap, seed_tree=500 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])))
+        d, shp = _shaped(seed, c, n, lambda spine: synth.make_dataset(n, L, nq, protein=True, gap_rate=gap, seed_tree=500 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])), spine=spine))
         q = d.query_seqs.copy()
         if nq > 6:
             q[3] = d.ref_seqs[11 % n]          # an exact match (-0.0 from scoredist)
@@ -196,7 +212,7 @@ def test_clustered_scoredist_routes_agree(seed):
         crit, neg = _crit(seed, c)
         out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, clusters=ca, protein=True, method=m, criterion=crit,
                                                 negative=neg, threshold=thr, baseobs=b, max_batch=mb, debug=dbg), q)
-        tag = 'seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s diam %g' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit,
+        tag = shp + ' seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s diam %g' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit,
                                                                                           ' -n' if neg else '', diam)
         for k in ('no_topup', 'no_big', 'no_fuse', 'no_blocks'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
@@ -221,7 +237,7 @@ def test_distance_table_routes_against_c_oracle(seed):
     for c in range(NCFG):
         n = int(rng.choice([33, 64, 257, 1000, 4097, 20001])); nq = int(rng.integers(1, 200))
         thr = float(rng.choice([0.0, 0.05, 0.2, 1.0])); b = int(rng.choice([3, 25, 200])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
-        d = synth.make_dataset(n, 8, nq, seed_tree=300 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])))
+        d, shp = _shaped(seed, c, n, lambda spine: synth.make_dataset(n, 8, nq, seed_tree=300 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])), spine=spine))
         nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
         D = synth.noisy_distance_rows(d.tree, d.query_leaf, d.query_pendant, list(range(nq)), seed_noise=c)
         perm = rng.permutation(n); D = np.ascontiguousarray(D[:, perm]); cols = nodes[perm].copy()
@@ -233,6 +249,6 @@ def test_distance_table_routes_against_c_oracle(seed):
         want = COracle(d.tree, method=m, criterion=crit, negative=neg, threshold=thr, baseobs=b, threads=NTHREADS).place_distances(D, cols)
         out = _place(routes, lambda dbg: Engine(d.tree, None, method=m, criterion=crit, negative=neg, threshold=thr, baseobs=b, debug=dbg),
                      (D, cols), place='place_distances')
-        tag = 'seed %d cfg %d: n %d nq %d thr %g b %d %s %s%s off-tree %d' % (seed, c, n, nq, thr, b, m, crit, ' -n' if neg else '', int(off.sum()))
+        tag = shp + ' seed %d cfg %d: n %d nq %d thr %g b %d %s %s%s off-tree %d' % (seed, c, n, nq, thr, b, m, crit, ' -n' if neg else '', int(off.sum()))
         for k in out:
             assert out[k].tobytes() == want.tobytes(), '%s: %s vs C oracle: %s' % (tag, k, _diff(out[k], want))

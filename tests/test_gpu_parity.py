@@ -85,6 +85,7 @@ def test_jc69_device_log_without_table(c1):
     np.testing.assert_allclose(dist, g['dist'], rtol=1e-12, atol=0)  # (the fixture carries numpy's log: its SIMD form on some CPUs)
     e.close()
     # the device's log is libm's bit for bit (csrc/libm_log.h): the C oracle, which calls libm, gives the same bytes
+    from oracle_c import COracle
     want = COracle(tree, ref.seqs, nodes).distances(qry.seqs)
     assert dist.tobytes() == want.tobytes()
 
@@ -104,8 +105,8 @@ def test_device_log_is_libm_log_bit_for_bit():
     m = np.floor(rng.random(n) * (v + 1))
     fam = [rng.random(n), 1.0 - rng.random(n) * 0.13, 1.0 + rng.random(n) * 0.07,
            np.ldexp(1.0 + rng.random(n), -rng.integers(0, 60, size=n)), 1 - (4 * (m / v) / 3), 1 - (rng.random(n) * 1.8 * v) / v,
-           np.array([1.0, 0.9375, np.nextafter(0.9375, 0), np.nextafter(1.0, 0), np.nextafter(1.0, 2), 1 + 0x1.09p-4,
-                     np.nextafter(1 + 0x1.09p-4, 0), 0.5, 2.0 ** -52, 2.0 ** -1000])]
+           np.array([1.0, 0.9375, np.nextafter(0.9375, 0), np.nextafter(1.0, 0), np.nextafter(1.0, 2), float.fromhex('0x1.109p+0'),
+                     np.nextafter(float.fromhex('0x1.109p+0'), 0), 0.5, 2.0 ** -52, 2.0 ** -1000])]
     x = np.concatenate(fam)
     x = np.ascontiguousarray(x[x > 0])
     got = device_log(x)
@@ -481,7 +482,8 @@ def test_random_trees_per_edge_bit_parity_with_c_oracle(layout, monkeypatch):
 
 
 def test_both_sweep_layouts_agree_on_polytomies(monkeypatch):
-    """The sweep knows which nodes are in a query's subtree either from a bit space in LDS (small
+    """The sweep knows which nodes are in a query's subtree from merged level lists without tree records (the lean sweep: the
+    default from 2 048 nodes, polytomies through child records), from a bit space in LDS (small
     trees) or from a tagged node map in global scratch (big trees).  Same polytomous tree, same
     observed sets, every method, HYBRID included (it looks nodes up again after the sweep): the two
     layouts must return the same bytes."""
@@ -497,10 +499,13 @@ def test_both_sweep_layouts_agree_on_polytomies(monkeypatch):
     cols = leaves.astype(np.int32)
     for m, c in (('OLS', 'MLSE'), ('BME', 'HYBRID'), ('FM', 'ME'), ('BE', 'HYBRID')):
         outs = []
-        for layout in ('bits', 'map', 'scan', 'merge'):
+        for layout in ('lean', 'bits', 'map', 'scan', 'merge'):
             monkeypatch.delenv('APPLES_NODE_MAP', raising=False)
             monkeypatch.delenv('APPLES_SWEEP_SCAN', raising=False)
             monkeypatch.delenv('APPLES_SWEEP_MERGE', raising=False)
+            monkeypatch.delenv('APPLES_NO_SWEEP_LEAN', raising=False)
+            if layout != 'lean':  # (the default on this tree since round 6: the lean sweep's child records for its 77 polytomies)
+                monkeypatch.setenv('APPLES_NO_SWEEP_LEAN', '1')
             if layout == 'scan':
                 monkeypatch.setenv('APPLES_SWEEP_SCAN', '1')
             if layout == 'map':
@@ -511,7 +516,8 @@ def test_both_sweep_layouts_agree_on_polytomies(monkeypatch):
             assert eng.describe()['sweep_layout'] == layout
             outs.append(eng.place_distances(D, cols))
             eng.close()
-        assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes() == outs[3].tobytes(), (m, c)
+        assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes() == outs[3].tobytes() == outs[4].tobytes(), (m, c)
+    monkeypatch.delenv('APPLES_NO_SWEEP_LEAN', raising=False)
     monkeypatch.delenv('APPLES_NODE_MAP', raising=False)
     monkeypatch.delenv('APPLES_SWEEP_SCAN', raising=False)
     monkeypatch.delenv('APPLES_SWEEP_MERGE', raising=False)

@@ -443,3 +443,46 @@ def test_empty_query_block():
     eng.free_queries(h)
     assert len(eng.place_sequences(d.query_seqs)) == 4
     eng.close()
+
+
+@pytest.mark.parametrize('shape', ['unrooted', 'polytomies', 'deep'])
+def test_c3_backbone_in_the_shapes_real_trees_have(shape):
+    """Config 3's backbone as real inputs come (bench.py: variant_dataset): unrooted (a root trifurcation: what FastTree prints,
+    what both of the reference's example backbones have), 1 % of the internal nodes dissolved into polytomies
+    (apples/OLS.py:36,59 loop over any number of children), hung on a caterpillar spine of 400 (427 levels).  Until round 6
+    each of them fell off the lean sweep (and the clade blocks) onto the level loop.  Checked on 8 192 queries, singleton
+    clusters and the command line's default route: the route taken (`sweep_layout`, `cluster_blocks`), the level loop's bytes
+    (`no_sweep_lean`; clustered: `no_blocks`), 64 + sampled queries byte for byte against the C oracle."""
+    import bench
+    nq = 8192
+    base = synth.make_dataset(200000, 1000, nq, spine=400 if shape == 'deep' else 0)
+    d = base if shape == 'deep' else bench.variant_dataset(base, shape, 200000, 1000, nq, False)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    info = eng.describe()
+    assert info['sweep_layout'] == 'lean', info
+    assert (info['max_children'] > 2) == (shape != 'deep') and (info['height'] > 254) == (shape == 'deep'), info
+    got = eng.place_sequences(d.query_seqs)
+    eng.close()
+    e2 = Engine(d.tree, d.ref_seqs, nodes, method='OLS', debug=('no_sweep_lean',))
+    assert e2.describe()['sweep_layout'] != 'lean'
+    other = e2.place_sequences(d.query_seqs)
+    e2.close()
+    assert other.tobytes() == got.tobytes()
+    sample = _sample(got, nq, extremes=8, strided=56)
+    co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', lut=jc69_lut(1000, 0.001), threads=NTHREADS)
+    assert co.place_sequences(d.query_seqs[sample]).tobytes() == got[sample].tobytes()
+    # the command line's default route: clusters + consensus representatives, clade blocks
+    ca = bench.make_clusters(d, 0.2)
+    e3 = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS')
+    i3 = e3.describe()
+    assert i3['sweep_layout'] == 'lean' and i3['cluster_fused'] == 1 and i3['cluster_blocks'] > 1000, i3
+    gc = e3.place_sequences(d.query_seqs)
+    e3.close()
+    e4 = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', debug=('no_blocks', 'no_sweep_lean'))
+    oc = e4.place_sequences(d.query_seqs)
+    e4.close()
+    assert oc.tobytes() == gc.tobytes()
+    sample = _sample(gc, nq, extremes=8, strided=56)
+    cc = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', lut=jc69_lut(1000, 0.001), threads=NTHREADS)
+    assert cc.place_sequences(d.query_seqs[sample]).tobytes() == gc[sample].tobytes()
