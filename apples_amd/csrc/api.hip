@@ -464,6 +464,8 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
     return 0;
 }
 
+int ensure_packed8(apples_ctx *ctx);
+
 int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignment *al) {
     DevAlign &a = ctx->aln;
     a.n_rows = al->n_rows;
@@ -605,10 +607,42 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         int64_t words = (int64_t)a.G * 3 * a.slots_pad;
         if (dev_alloc(ctx, &a.packed, words)) return 1;
         HIP_TRY(ctx, hipMemsetAsync(a.packed, 0, (size_t)words * sizeof(uint4), ctx->stream));
-        if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 2, a.packed, a.slots_pad, false, d_exotic, nullptr, a.d_slot_row)) return 1;
+        // bytes beyond ACGT- in a singleton context whose fused pass runs on the matrix cores: the 2-plane rows and the fp4 images
+        // keep them as gaps, the 8-plane form comes beside them (DevAlign::ex_ok)
+        a.ex_ok = a.all_singleton && dist_mfma_enabled() && a.L < 8192;
+        int32_t *d_row_bad = nullptr;
+        if (a.ex_ok) {
+            if (dev_alloc(ctx, &d_row_bad, a.slots_pad)) return 1;
+            HIP_TRY(ctx, hipMemsetAsync(d_row_bad, 0, (size_t)a.slots_pad * sizeof(int32_t), ctx->stream));
+        }
+        if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 2, a.packed, a.slots_pad, false, d_exotic, nullptr, a.d_slot_row, d_row_bad)) return 1;
         int exotic = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&exotic, d_exotic, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (exotic && a.ex_ok) {
+            // which slots, which sites (from the caller's rows: only the flagged rows are read again), and the 8-plane form
+            std::vector<int32_t> bad((size_t)a.n_rows), off((size_t)a.n_rows + 1, 0);
+            HIP_TRY(ctx, hipMemcpy(bad.data(), d_row_bad, (size_t)a.n_rows * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::vector<uint16_t> sites;
+            a.ex_max = 0;
+            for (int64_t s = 0; s < a.n_rows; ++s) {
+                if (bad[s]) {
+                    const uint8_t *row = al->rows + (int64_t)a.slot_row[s] * a.L;
+                    for (int i = 0; i < a.L; ++i) {
+                        const uint8_t b = row[i];
+                        if (b != '-' && b != 'A' && b != 'C' && b != 'G' && b != 'T') sites.push_back((uint16_t)i);
+                    }
+                }
+                off[s + 1] = (int32_t)sites.size();
+                a.ex_max = std::max(a.ex_max, off[s + 1] - off[s]);
+            }
+            if (sites.empty()) sites.push_back(0);
+            if (dev_upload(ctx, &a.ex_off, off.data(), (int64_t)off.size())) return 1;
+            if (dev_upload(ctx, &a.ex_site, sites.data(), (int64_t)sites.size())) return 1;
+            if (ensure_packed8(ctx)) return 1;
+            exotic = 0;
+        }
+        dev_free(d_row_bad);
         if (exotic) {  // symbols beyond ACGT-: keep the raw byte in 8 planes
             dev_free(a.packed);
             a.planes = 8;
@@ -631,6 +665,27 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
             !(ctx->dbg & APPLES_DBG_NO_FUSE) && dist_mfma_enabled())
             if (launch_build_cluster_panels(ctx)) return 1;
     }
+    return 0;
+}
+
+// the reference rows once more in the 8-plane form, beside the 2-plane rows of a context that keeps bytes beyond ACGT- as gaps there
+// (DevAlign::ex_ok): built with the first such byte, in the reference or in a query block
+int ensure_packed8(apples_ctx *ctx) {
+    DevAlign &a = ctx->aln;
+    if (a.packed8 || a.planes == 8) return 0;
+    const int64_t words = (int64_t)a.G * 9 * a.slots_pad;
+    if (dev_alloc(ctx, &a.packed8, words)) return 1;
+    HIP_TRY(ctx, hipMemsetAsync(a.packed8, 0, (size_t)words * sizeof(uint4), ctx->stream));
+    if (launch_pack_rows(ctx, a.raw, a.n_rows, a.L, 8, a.packed8, a.slots_pad, false, nullptr, nullptr, a.d_slot_row)) return 1;
+    // query blocks that exist already: their 8-plane form as well (what exact8_rows asks for)
+    for (auto &qb : ctx->blocks) {
+        if (!qb.live || qb.table || qb.planes != 2 || qb.packed8 || !qb.raw) continue;
+        const int64_t w = qb.n_pad * a.G * 9;
+        if (blk_alloc(ctx, &qb.packed8, w)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(qb.packed8, 0, (size_t)w * sizeof(uint4), ctx->stream));
+        if (launch_pack_rows(ctx, qb.raw, qb.n, a.L, 8, qb.packed8, 0, true, nullptr)) return 1;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -860,7 +915,9 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     batch = size_batch();
     bool regrow = batch > w.batch || members > w.obs_cap || stride > w.stride || (need_counts && !w.counts) ||
                   (need_xe && !w.big.xe) || (need_dist && !w.dist) || (need_fused && !w.seg_slot) || (need_alt && !w.has_alt) ||
-                  (!slim && !cslim && w.dist_rows < w.batch);  // full rows wanted where only a slice exists (run_block steps by w.batch)
+                  // full rows wanted where only a slice exists (run_block steps by w.batch) -- unless the whole block fits the slice
+                  // (a slim workspace serves the few queries of an exact8 block as it is: no regrowing back and forth)
+                  (!slim && !cslim && w.dist_rows < std::min(w.batch, round_up(std::max<int64_t>(want_batch, 1), 32)));
     if (!regrow) return 0;
     if (!ctx->blk_cache.empty()) {  // cached block buffers count as used in hipMemGetInfo: give them back, then size the batch
         for (auto &c : ctx->blk_cache) dev_free(c.second);
@@ -952,6 +1009,8 @@ void free_block(apples_ctx *ctx, QueryBlock *qb) {
     blk_free(ctx, qb->table); blk_free(ctx, qb->raw); blk_free(ctx, qb->packed); blk_free(ctx, qb->qf4);
     blk_free(ctx, qb->aa_idx); blk_free(ctx, qb->aa_mask); blk_free(ctx, qb->self_slot); blk_free(ctx, qb->out);
     blk_free(ctx, qb->sd_q4); blk_free(ctx, qb->sd_nvq);
+    blk_free(ctx, qb->packed8); blk_free(ctx, qb->q_ex); blk_free(ctx, qb->ex_idx);
+    if (qb->ex_block) { free_block(ctx, qb->ex_block); delete qb->ex_block; }
     *qb = QueryBlock();
 }
 
@@ -987,6 +1046,15 @@ int alloc_block(apples_ctx *ctx, int64_t n, const int32_t *self_row, int planes,
         int64_t w = qb->n_pad * a.G * (planes + 1);
         if (blk_alloc(ctx, &qb->packed, w)) return 1;
         HIP_TRY(ctx, hipMemsetAsync(qb->packed, 0, (size_t)w * sizeof(uint4), st));
+        if (planes == 2 && a.ex_ok) {  // which queries carry a byte beyond ACGT- (k_pack_rows<2>); the 8-plane form where the context keeps one
+            if (blk_alloc(ctx, &qb->q_ex, qb->n_pad)) return 1;
+            HIP_TRY(ctx, hipMemsetAsync(qb->q_ex, 0, (size_t)qb->n_pad * sizeof(int32_t), st));
+            if (a.packed8) {
+                const int64_t w8 = qb->n_pad * a.G * 9;
+                if (blk_alloc(ctx, &qb->packed8, w8)) return 1;
+                HIP_TRY(ctx, hipMemsetAsync(qb->packed8, 0, (size_t)w8 * sizeof(uint4), st));
+            }
+        }
         if (planes == 2 && dist_mfma_enabled()) {  // fp4 operand image for the matrix-core distance kernel
             const int64_t n128 = round_up(qb->n_pad, 256) + 256;  // a sub-batch may start at any multiple of 32
             if (blk_alloc(ctx, &qb->qf4, n128 * a.G * 256)) return 1;
@@ -1014,7 +1082,8 @@ int fill_block(apples_ctx *ctx, QueryBlock *qb, const uint8_t *queries, int64_t 
         return 0;
     }
     if (launch_pack_rows(ctx, qb->raw + q0 * a.L, nq, a.L, qb->planes, qb->packed + q0 * a.G * (qb->planes + 1), 0, true,
-                         ctx->d_exotic, st)) return 1;
+                         ctx->d_exotic, st, nullptr, qb->q_ex ? qb->q_ex + q0 : nullptr)) return 1;
+    if (qb->packed8 && launch_pack_rows(ctx, qb->raw + q0 * a.L, nq, a.L, 8, qb->packed8 + q0 * a.G * 9, 0, true, nullptr, st)) return 1;
     if (qb->qf4) {
         const int64_t n128 = round_up(qb->n_pad, 256) + 256;
         const bool last = q0 + nq >= qb->n;  // the last chunk also zeroes the image's padding rows
@@ -1037,6 +1106,49 @@ int take_exotic(apples_ctx *ctx, hipStream_t st, int *exotic) {
     return 0;
 }
 
+int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t *self_row, QueryBlock *qb);
+
+// A packed 2-plane block of an ex_ok context whose queries carry bytes beyond ACGT- (the context's flag said so): the reference's
+// 8-plane form comes into being, the block gets its own, and the queries concerned are placed by the 8-plane kernels -- a few of
+// them: as a block of their own (ex_block: placed behind the main pass, whose placements for them are overwritten); many (more
+// than a twentieth of the block): the whole block (exact8: no matrix-core pass for it).  `queries` / `self_row`: the caller's.
+int exotic_queries(apples_ctx *ctx, QueryBlock *qb, const uint8_t *queries, const int32_t *self_row) {
+    DevAlign &a = ctx->aln;
+    if (ensure_packed8(ctx)) return 1;
+    if (!qb->packed8) {
+        const int64_t w8 = qb->n_pad * a.G * 9;
+        if (blk_alloc(ctx, &qb->packed8, w8)) return 1;
+        HIP_TRY(ctx, hipMemsetAsync(qb->packed8, 0, (size_t)w8 * sizeof(uint4), ctx->stream));
+        if (launch_pack_rows(ctx, qb->raw, qb->n, a.L, 8, qb->packed8, 0, true, nullptr)) return 1;
+    }
+    std::vector<int32_t> flag((size_t)qb->n), idx;
+    HIP_TRY(ctx, hipMemcpyAsync(flag.data(), qb->q_ex, (size_t)qb->n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < qb->n; ++i)
+        if (flag[i]) idx.push_back((int32_t)i);
+    if (idx.empty()) return 0;
+    if ((int64_t)idx.size() > std::min<int64_t>(std::max<int64_t>(16, qb->n / 20), 2048)) { qb->exact8 = true; return 0; }
+    std::vector<uint8_t> rows(idx.size() * (size_t)a.L);
+    std::vector<int32_t> self(idx.size(), -1);
+    for (size_t k = 0; k < idx.size(); ++k) {
+        memcpy(rows.data() + k * (size_t)a.L, queries + (int64_t)idx[k] * a.L, (size_t)a.L);
+        if (self_row) self[k] = self_row[idx[k]];
+    }
+    if (qb->ex_block) { free_block(ctx, qb->ex_block); delete qb->ex_block; qb->ex_block = nullptr; }
+    blk_free(ctx, qb->ex_idx); qb->ex_idx = nullptr;
+    qb->ex_block = new QueryBlock();
+    if (alloc_block(ctx, (int64_t)idx.size(), self_row ? self.data() : nullptr, 2, qb->ex_block, ctx->stream)) return 1;
+    if (fill_block(ctx, qb->ex_block, rows.data(), 0, (int64_t)idx.size(), ctx->stream)) return 1;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (rows is a local)
+    int dummy = 0;
+    if (take_exotic(ctx, ctx->stream, &dummy)) return 1;  // (the flag these rows raised again)
+    qb->ex_block->exact8 = true;
+    qb->ex_block->live = true;
+    if (blk_alloc(ctx, &qb->ex_idx, (int64_t)idx.size())) return 1;
+    HIP_TRY(ctx, hipMemcpy(qb->ex_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
 // whole block at once on the context's stream (apples_queries_upload)
 int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t *self_row, QueryBlock *qb) {
     DevAlign &a = ctx->aln;
@@ -1047,6 +1159,10 @@ int make_block(apples_ctx *ctx, const uint8_t *queries, int64_t n, const int32_t
         int exotic = 0;
         if (take_exotic(ctx, ctx->stream, &exotic)) return 1;
         if (!(exotic && qb->planes == 2)) break;
+        if (a.ex_ok) {  // the context keeps its matrix-core forms: the queries with such bytes take the 8-plane forms
+            if (exotic_queries(ctx, qb, queries, self_row)) return 1;
+            break;
+        }
         free_block(ctx, qb);  // symbols beyond ACGT-: widen the reference, pack again with 8 planes
         if (repack_to_bytes(ctx)) return 1;
     }
@@ -1292,7 +1408,35 @@ int back_stream(apples_ctx *ctx) {
     return 0;
 }
 
+int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed);
+
+__global__ void k_scatter_placements(apples_placement *__restrict__ out, const apples_placement *__restrict__ src,
+                                     const int32_t *__restrict__ idx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[idx[i]] = src[i];
+}
+
+// the block's queries with bytes beyond ACGT- (QueryBlock::ex_block, exotic_queries) through the 8-plane kernels, their
+// placements over what the main pass left for them; the timers add up
+int run_ex_block(apples_ctx *ctx, QueryBlock &qb) {
+    if (!qb.ex_block) return 0;
+    double t0[APPLES_T_COUNT];
+    for (int i = 0; i < APPLES_T_COUNT; ++i) t0[i] = ctx->t_ms[i];
+    QueryBlock &x = *qb.ex_block;
+    if (run_block_main(ctx, x, nullptr)) return 1;
+    hipLaunchKernelGGL(k_scatter_placements, dim3((unsigned)((x.n + 255) / 256)), dim3(256), 0, ctx->stream, qb.out, x.out, qb.ex_idx, x.n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] += t0[i];
+    return 0;
+}
+
 int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
+    if (run_block_main(ctx, qb, feed)) return 1;
+    return run_ex_block(ctx, qb);
+}
+
+int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
     const DevAlign &a = ctx->aln;
     const bool hybrid = hybrid_records(ctx);  // (HYBRID on the lean sweep is a pass like any other)
     // fused path: threshold compaction in the distance kernel's epilogue; only queries that need
@@ -1649,11 +1793,23 @@ int run_block(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed = nullptr) {
                                         w.seg_cnt + nh * (w.stride / 64))) return 1;
                 ++launches;
             }
+            // reference rows with bytes beyond ACGT- (the matrix-core pass took them for gaps): the survivors' exact counts
+            // reference rows with bytes beyond ACGT- (the matrix-core pass took them for gaps): k_select_fast counts those sites for the
+            // survivors on such rows and tests them once more (APPLES_EXOTIC_FIX_KERNEL: the same as a pass of its own, diagnostic)
+            const bool exfix = fused_counts_format(ctx, qb) && (a.ex_off != nullptr || ctx->jc_mmax_true != nullptr);
+            static const bool ex_kernel = getenv("APPLES_EXOTIC_FIX_KERNEL") != nullptr;
+            if (exfix && ex_kernel && launch_exotic_fix(ctx, qb, q0, nq, w.seg_slot, w.seg_cnt, w.n_obs)) return 1;
             HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;
             SelectArgs sa = select_args_alignment(ctx, qb, q0);
             sa.seg_lut = fused_counts_format(ctx, qb) ? ctx->jc_lut : nullptr;
+            if (exfix && ex_kernel) sa.seg_surv = w.n_obs;  // (k_exotic_fix left the survivor counts where k_select_fast puts the observed counts)
+            if (exfix && !ex_kernel) {
+                sa.ex_off = a.ex_off; sa.ex_site = a.ex_site; sa.ex_mmax = ctx->jc_mmax_true ? ctx->jc_mmax_true : ctx->jc_mmax;
+                sa.ex_all = ctx->jc_mmax_true ? 1 : 0; sa.q_raw = qb.raw + q0 * (int64_t)a.L; sa.L = a.L;
+            }
             if (launch_select_fast(ctx, sa, nq)) return 1;
+            sa.seg_surv = nullptr; sa.ex_mmax = nullptr;
             sa.seg_lut = nullptr;
             // top-up path for the queries k_select_fast listed: full rows + per-segment minima (in the
             // rows of the fused buffers, which k_select_fast has consumed), then the `-b` nearest
@@ -1894,6 +2050,23 @@ int apples_set_params(apples_ctx *ctx, const apples_params *params) {
                     if (!(row[m] >= 0 && row[m] <= params->filt_threshold)) monotone = false;
                 mmax[v] = last;
             }
+            dev_free(ctx->jc_mmax_true);
+            ctx->jc_mmax_true = nullptr;
+            if (monotone && ctx->aln.ex_max > 0) {
+                // reference rows with bytes beyond ACGT- (counted as gaps by the matrix-core pass): a pair's true counts are (valid + k,
+                // mism + k), 0 <= k <= ex_max, so the pass must keep (valid, mism) whenever SOME k passes: mmaxF[v] = max_k (mmax[v + k] - k).
+                // It differs from the rule only at the low end, where -V could keep the smaller count out; k_exotic_fix then tests
+                // every survivor against the rule itself.
+                std::vector<int32_t> mf(mmax);
+                bool loosened = false;
+                for (int64_t v = 0; v <= L; ++v)
+                    for (int64_t k = 1; k <= ctx->aln.ex_max && v + k <= L; ++k)
+                        if (mmax[v + k] >= 0 && mmax[v + k] - (int32_t)k > mf[v]) { mf[v] = mmax[v + k] - (int32_t)k; loosened = true; }
+                if (loosened) {
+                    if (dev_upload(ctx, &ctx->jc_mmax_true, mmax.data(), L + 1)) return 1;
+                    mmax = mf;
+                }
+            }
             if (monotone && dev_upload(ctx, &ctx->jc_mmax, mmax.data(), L + 1)) return 1;
             ctx->gemm_thr = monotone ? gemm_threshold(mmax, params->filt_threshold) : GemmThreshold();
         }
@@ -1952,7 +2125,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevAlign &a = ctx->aln;
     dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_boff); dev_free(a.rep_loff); dev_free(a.loose_mp); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.blk_stat[0]); dev_free(a.blk_stat[1]); dev_free(a.rep_soff); dev_free(a.cl_order); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_cm_idx); dev_free(a.aa_cm_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
-    dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
+    dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->jc_mmax_true); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);
     for (int i = 0; i < 8; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -2043,7 +2216,13 @@ int apples_place_sequences_streamed(apples_ctx *ctx, const uint8_t *queries, int
     int rc = run_block(ctx, qb, &feed);
     int exotic = 0;
     if (!rc && ctx->params.model != APPLES_SCOREDIST) rc = take_exotic(ctx, ctx->stream2, &exotic);
-    if (!rc && exotic && planes == 2) {
+    if (!rc && exotic && planes == 2 && ctx->aln.ex_ok) {
+        // a query carried a symbol beyond ACGT-, which the pass took for a gap: those queries once more through the 8-plane
+        // kernels (a few: a block of their own; many: the whole block) -- the context keeps its matrix-core forms
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        rc = exotic_queries(ctx, &qb, queries, self_row);
+        if (!rc) rc = qb.exact8 ? run_block(ctx, qb) : run_ex_block(ctx, qb);
+    } else if (!rc && exotic && planes == 2) {
         // a query carried a symbol beyond ACGT-: the 2-plane images are not valid for it.  Rare: widen
         // the reference to raw bytes and run the block again from a whole-block upload
         free_block(ctx, &qb);
@@ -2512,7 +2691,7 @@ int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n) {
 
 const char *apples_describe(apples_ctx *ctx) {
     hipDeviceProp_t prop;
-    char buf[1536];
+    char buf[2048];
     const char *name = "?";
     int cus = 0;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) { name = prop.name; cus = prop.multiProcessorCount; }
@@ -2525,7 +2704,8 @@ const char *apples_describe(apples_ctx *ctx) {
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
              "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\", "
              "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld, \"sweep_layout\": \"%s\", \"cluster_fused\": %d, "
-             "\"scoredist_filter\": %d, \"scoredist_image_bytes\": %lld, \"cluster_blocks\": %d, \"block_items_last_batch\": %d, \"block_tiles_last_batch\": %d}",
+             "\"scoredist_filter\": %d, \"scoredist_image_bytes\": %lld, \"cluster_blocks\": %d, \"block_items_last_batch\": %d, \"block_tiles_last_batch\": %d, "
+             "\"exotic_symbols_as_gaps\": %d, \"exotic_sites_max_per_row\": %d, \"eight_plane_copy\": %d}",
              name, cus, ctx->tree.n_nodes, ctx->tree.height, ctx->tree.max_children, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
              (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
@@ -2545,7 +2725,10 @@ const char *apples_describe(apples_ctx *ctx) {
              (ctx->params.model == APPLES_SCOREDIST && sd_gemm_usable(ctx) && !(ctx->dbg & APPLES_DBG_NO_FUSE)) ? 1 : 0,
              (long long)(a.sd_ref4 ? a.slots_pad * (int64_t)sd_steps(a.L) * 64 : 0),
              // clade blocks of a clustered reference (build_blocks): whole subtrees of one cluster, swept on a static schedule
-             (int)a.n_blocks, (int)blk_cnt[0], (int)blk_cnt[2]);
+             (int)a.n_blocks, (int)blk_cnt[0], (int)blk_cnt[2],
+             // bytes beyond ACGT- (DevAlign::ex_ok): the context keeps them as gaps in its 2-plane rows and fp4 images; the most such
+             // sites in one reference row; the 8-plane copy exists (built with the first such byte, in the reference or in a query)
+             a.ex_ok ? 1 : 0, (int)a.ex_max, a.packed8 ? 1 : 0);
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

@@ -123,6 +123,17 @@ struct DevAlign {
     int32_t *d_slot_row = nullptr;// [n_rows] slot -> caller's row (the packing kernels gather through it)
     uint4 *packed = nullptr;      // [G][planes+1][slots_pad] uint4 = 4 consecutive 32-site words
     uint8_t *ref_f4 = nullptr;    // [slots_pad][2G][4][32 B] fp4 operand image of the reference (dist_gemm.hip), ACGT- singleton contexts
+    // Bytes beyond ACGT- (`.`, `?`, `*`: ordinary symbols to apples/distance.py:733-737) in a singleton JC69 context: the 2-plane
+    // rows and the fp4 images hold them AS GAPS, so that the matrix-core passes stay what they are; exactness comes back through
+    //   * packed8: the same rows once more in the 8-plane form (the raw byte), for everything that writes full rows (the listed /
+    //     top-up pass, apples_distances, the unfused route) and for query blocks that carry such bytes themselves (QueryBlock::exact8);
+    //   * ex_off / ex_site: per slot the sites that hold such a byte -- k_exotic_fix adds them back to the counts of the fused
+    //     pass's survivors (a site where the row has such a byte and the query a letter is valid and a mismatch).
+    bool ex_ok = false;           // the context takes this route (singleton clusters, JC69, matrix-core passes enabled, L < 8192)
+    uint4 *packed8 = nullptr;     // [G][9][slots_pad]; built with the first such byte, in the reference or in a query block
+    int32_t *ex_off = nullptr;    // [n_rows + 1] CSR over slots, or nullptr: the reference rows hold no such byte
+    uint16_t *ex_site = nullptr;  // [ex_off[n_rows]] sites, ascending per slot
+    int32_t ex_max = 0;           // most such sites in one row
     // clustered references (fused selection by representatives, select.hip k_select_clusters):
     uint4 *packed_rm = nullptr;   // the member rows cluster by cluster, interleaved per plane word (dist.hip:k_cluster_major): [n_refs * G*3]
     uint4 *rep_packed = nullptr;  // [G][3][reps_pad] the representatives' rows, in representative order
@@ -188,6 +199,11 @@ struct QueryBlock {
     int64_t n_cols = 0;
     uint8_t *raw = nullptr;       // [n*L]
     uint4 *packed = nullptr;      // [n_pad/16][G][16][planes+1] uint4
+    uint4 *packed8 = nullptr;     // the 8-plane form beside a 2-plane `packed` (DevAlign::packed8 exists: exact full rows), or nullptr
+    int32_t *q_ex = nullptr;      // [n_pad] 1: the query carries a byte beyond ACGT- (k_pack_rows<2>)
+    bool exact8 = false;          // the block's fused pass runs on the 8-plane forms (its queries carry such bytes): no matrix cores
+    QueryBlock *ex_block = nullptr;  // the block's few queries with such bytes once more as an exact8 block of their own ...
+    int32_t *ex_idx = nullptr;       // ... and which queries they are [ex_block->n] (run_block places them last and copies the structs over)
     uint8_t *qf4 = nullptr;       // fp4 operand image for the matrix-core distance kernels: [n_pad128][2G][4][32 B] (t1, t2, t3, v) for
                                   // k_jc69_mfma; beside a reference image (DevAlign::ref_f4) the compact tiled form of dist_gemm.hip
     uint8_t *aa_idx = nullptr;    // [n_pad][Lpad16] residue index (20 = gap)
@@ -291,6 +307,8 @@ struct apples_ctx {
     int n_cu = 0;  // compute units of the device (dist_gemm.hip's persistent grid)
     int64_t cur_batch_queries = 0;  // queries of the device batch under way (api.hip:route_threshold)
     int32_t *jc_mmax = nullptr;  // [L+1] largest mismatch count with 0 <= lut <= threshold, per valid count
+    int32_t *jc_mmax_true = nullptr;  // jc_mmax is the FILTER's table where the reference holds bytes beyond ACGT- (a pair's counts may still
+                                      // grow by up to ex_max: set_params); this is the rule itself, what k_exotic_fix tests.  nullptr: jc_mmax is
     double *blosum = nullptr;  // 21x21 table (row/col 20 = gap -> 0)
     uint8_t *sd_tq4 = nullptr; // [20][20] fp4 codes of the table rounded down to the grid {0, .5, 1, 1.5, 2, 3, 4, 6} / 4 (dist_sd.hip)
     Workspace ws;
@@ -346,7 +364,7 @@ extern thread_local std::string g_create_error;
 // pack.hip
 int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, int planes, uint4 *d_out,
                      int64_t slots_pad, bool query_layout, int *d_exotic, hipStream_t st = nullptr,
-                     const int32_t *d_src_row = nullptr);
+                     const int32_t *d_src_row = nullptr, int32_t *d_row_bad = nullptr);
 int launch_pack_aa(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, uint8_t *d_out, uint16_t *d_mask,
                    int64_t slots_pad, bool query_layout, hipStream_t st = nullptr, const int32_t *d_src_row = nullptr);
 // dist.hip
@@ -403,6 +421,12 @@ struct SelectArgs {
     const double *seg_lut;              // non-null: seg_slot holds position << 26 | valid << 13 | mism, distances are seg_lut[...]
     const int32_t *seg_surv;            // non-null (dist_sd.hip): the segments hold CANDIDATES, the ones that failed marked by a negative
                                         // distance; seg_surv[query] = how many passed
+    // k_select_fast behind a matrix-core pass over reference rows with bytes beyond ACGT- (DevAlign::ex_off): the survivors on such
+    // rows get those sites counted (valid and mismatching under a letter of the query) and 0 <= d <= threshold tested once more
+    const int32_t *ex_off; const uint16_t *ex_site;  // CSR over slots
+    const int32_t *ex_mmax;             // non-null: do it; the rule's own table (apples_ctx::jc_mmax_true, or jc_mmax where the pass's was not loosened)
+    int ex_all;                         // the pass's table was loosened: every survivor is tested again, not only those on such rows
+    const uint8_t *q_raw;               // the batch's queries as bytes ([nq][L])
     const int32_t *node_level;          // tree level by node id
     int32_t *slow_list, *slow_count;    // queries that need the top-up rule
     int32_t *slow_hint;                 // [list position] or nullptr: what the listing kernel already knows about the query -- its
@@ -497,6 +521,11 @@ int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64
                         int32_t *seg_slot, int32_t *seg_cnt);
 int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
                          const int32_t *qcount, double *d_dist, double *segmin_d, int32_t *segmin_i);
+// the fused matrix-core pass's survivors (packed words in seg_slot) on reference rows with bytes beyond ACGT-: exact counts, the
+// threshold once more, n_surv[query] = how many stay (k_select_fast: SelectArgs::seg_surv)
+int launch_exotic_fix(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, const int32_t *seg_cnt,
+                      int32_t *n_surv);  // (diagnostic form: api.hip does the same inside k_select_fast)
+bool exact8_rows(const apples_ctx *ctx, const QueryBlock &qb);  // the bit-plane kernels take the 8-plane forms for this block
 // sweep.hip
 struct SweepArgs {
     DevTree tree;

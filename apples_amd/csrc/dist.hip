@@ -232,7 +232,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_expand_queries_f4(const uint8_t 
             const int site = (b * 2 + x) * 32 + 4 * i + j;
             if (site >= L) break;
             const uint32_t c = raw[src * (int64_t)L + site];
-            if (c == (uint32_t)'-') continue;
+            if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) continue;  // a gap, or a byte beyond ACGT- (as k_pack_rows<2>: a gap here)
             const uint32_t code = (c >> 1) & 3u;  // as k_pack_rows<2>
             v |= 0x2u << (4 * i);
             t1 |= (0x2u | ((code & 2u) << 2)) << (4 * i);
@@ -492,18 +492,20 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
                              uint32_t *d_counts, int32_t *seg_slot, int32_t *seg_cnt, const int32_t *qlist,
                              const int32_t *qcount, double *segmin_d = nullptr, int32_t *segmin_i = nullptr) {
     const DevAlign &a = ctx->aln;
-    const uint4 *qp = qb.packed + q0 * a.G * (P + 1);  // q0 is a multiple of 32: whole 16-query tiles
+    // (P = 8 beside 2-plane forms: the 8-plane copies of a context with bytes beyond ACGT-, exact8_rows)
+    const uint4 *refp = (P == 8 && a.planes == 2) ? a.packed8 : a.packed;
+    const uint4 *qp = ((P == 8 && qb.planes == 2) ? qb.packed8 : qb.packed) + q0 * a.G * (P + 1);  // q0 is a multiple of 32: whole 16-query tiles
     const double *lut = ctx->jc_lut;
     dim3 block(APPLES_TPB);
     static const bool use_asm = getenv("APPLES_NO_BCNT_ASM") == nullptr;  // tuning knob (default: accumulate form)
     static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
-    const int32_t *mmax = no_mmax ? nullptr : ctx->jc_mmax;
+    const int32_t *mmax = no_mmax ? nullptr : (ctx->jc_mmax_true ? ctx->jc_mmax_true : ctx->jc_mmax);  // (the rule itself: these kernels count exactly)
 #define LAUNCH(TQ)                                                                                                   \
     if (use_asm) LAUNCH2(TQ, true); else LAUNCH2(TQ, false)
 #define LAUNCH2(TQ, A)                                                                                               \
     hipLaunchKernelGGL((k_jc69<P, TQ, MODE, A>), dim3((unsigned)(a.slots_pad / APPLES_TPB),                          \
                        (unsigned)(MODE == 2 ? std::min<int64_t>((nq + TQ - 1) / TQ, 64) : (nq + TQ - 1) / TQ)),         \
-                       block, 0, ctx->stream, a.packed, qp, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,   \
+                       block, 0, ctx->stream, refp, qp, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,   \
                        ctx->params.overlap_frac, lut, ctx->params.filt_threshold, seg_slot, seg_cnt, qlist, qcount, mmax,    \
                        a.slot_rep, segmin_d, segmin_i)
     if (tile >= 32) LAUNCH(32);
@@ -519,7 +521,13 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
 // slots and distances
 bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb) {
     static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
-    return qb.qf4 && ctx->aln.planes == 2 && ctx->jc_lut && ctx->jc_mmax && !no_mmax && ctx->aln.L < 8192;  // 13-bit counts
+    return qb.qf4 && !qb.exact8 && ctx->aln.planes == 2 && ctx->jc_lut && ctx->jc_mmax && !no_mmax && ctx->aln.L < 8192;  // 13-bit counts
+}
+
+// the bit-plane kernels read the 8-plane forms for this block: the context's own layout, or the copies a context with bytes
+// beyond ACGT- keeps beside its 2-plane rows (exact full rows; a block whose queries carry such bytes: its fused pass too)
+bool exact8_rows(const apples_ctx *ctx, const QueryBlock &qb) {
+    return ctx->aln.planes == 8 || (ctx->aln.packed8 != nullptr && qb.packed8 != nullptr);
 }
 
 bool dist_mfma_enabled() {
@@ -616,9 +624,9 @@ int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq,
     // Full rows stay with the bit-plane kernel: with 8 bytes out per pair and a table lookup per pair the
     // matrix-core form is slower here (0.64 against 0.58 ms at C2 size).  APPLES_DIST_MFMA_ROWS=1 routes
     // tiles of 16 and more queries to it anyway (tests compare its counts with the bytewise definition).
-    if (qb.qf4 && !ctx->aln.ref_f4 && ctx->aln.planes == 2 && tile >= 16 && getenv("APPLES_DIST_MFMA_ROWS"))
+    if (qb.qf4 && !ctx->aln.ref_f4 && ctx->aln.planes == 2 && !ctx->aln.packed8 && tile >= 16 && getenv("APPLES_DIST_MFMA_ROWS"))
         return launch_mfma<0>(ctx, qb, q0, nq, d_dist, d_counts, nullptr, nullptr);
-    if (ctx->aln.planes == 2) launch_jc69_tile<2, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
+    if (!exact8_rows(ctx, qb)) launch_jc69_tile<2, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     else launch_jc69_tile<8, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -631,7 +639,7 @@ int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64
     if (fused_counts_format(ctx, qb))
         return dist_gemm_usable(ctx) ? launch_counts_gemm(ctx, qb, q0, nq, seg_slot, seg_cnt)
                                      : launch_mfma<1>(ctx, qb, q0, nq, seg_d, nullptr, seg_slot, seg_cnt);
-    if (ctx->aln.planes == 2) launch_jc69_tile<2, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
+    if (!exact8_rows(ctx, qb)) launch_jc69_tile<2, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
     else launch_jc69_tile<8, 1>(ctx, qb, q0, nq, tile, seg_d, nullptr, seg_slot, seg_cnt, nullptr, nullptr);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -642,7 +650,7 @@ int launch_counts_fused(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64
 int launch_counts_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq_max, const int32_t *qlist,
                          const int32_t *qcount, double *d_dist, double *segmin_d, int32_t *segmin_i) {
     if (nq_max == 0) return 0;
-    if (ctx->aln.planes == 2) launch_jc69_tile<2, 2>(ctx, qb, q0, nq_max, 8, d_dist, nullptr, nullptr, nullptr, qlist, qcount, segmin_d, segmin_i);
+    if (!exact8_rows(ctx, qb)) launch_jc69_tile<2, 2>(ctx, qb, q0, nq_max, 8, d_dist, nullptr, nullptr, nullptr, qlist, qcount, segmin_d, segmin_i);
     else launch_jc69_tile<8, 2>(ctx, qb, q0, nq_max, 8, d_dist, nullptr, nullptr, nullptr, qlist, qcount, segmin_d, segmin_i);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -909,6 +917,69 @@ int launch_scoredist_listed(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, i
                        dim3(APPLES_TPB), 0, ctx->stream, a.aa_idx, a.aa_mask, qb.aa_idx + q0 * Lpad,
                        qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, d_dist, (uint32_t *)nullptr, a.n_rows, a.slots_pad, Lpad, a.L,
                        nq_max, ctx->params.overlap_frac, 0.0, 0.0, (int32_t *)nullptr, (int32_t *)nullptr, qlist, qcount);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- bytes beyond ACGT- in the reference rows of a matrix-core context (DevAlign::ex_off) ------------------------------------
+// The fused pass counted them as gaps.  For a pair (query of letters and gaps, row) every site where the row holds such a byte and
+// the query a letter is a valid site and a mismatch (apples/distance.py:733-737: the bytes differ), so the pair's counts are
+// (valid + k, mism + k) with k = the row's such sites under the query's letters -- which can only make the pair fail: every true
+// survivor is among the pass's survivors (its table, ctx->jc_mmax, is loosened by ex_max valid sites at its lower end, where the
+// overlap rule -V could let a pair in that the smaller count kept out: set_params).  A workgroup per query walks its survivors,
+// recounts the ones on such rows from the query's raw bytes, tests 0 <= d <= threshold on the integers (the rule's own table) and
+// rewrites the packed word -- valid 0 for a pair that fails: the table says -1 there and k_select_fast (SelectArgs::seg_surv) drops it.
+namespace {
+#ifndef WAVE
+#define WAVE 64
+#endif
+__global__ __launch_bounds__(APPLES_TPB) void k_exotic_fix(int32_t *__restrict__ seg_slot, const int32_t *__restrict__ seg_cnt, int64_t stride,
+                                                          const uint8_t *__restrict__ qraw, int L, const int32_t *__restrict__ ex_off,
+                                                          const uint16_t *__restrict__ ex_site, const int32_t *__restrict__ mmax,
+                                                          int retest_all, int32_t *__restrict__ n_surv) {
+    __shared__ int sh_cnt[APPLES_TPB / WAVE];
+    const int64_t q = blockIdx.x;
+    const int64_t n_seg = stride >> 6;
+    const uint8_t *row = qraw + q * (int64_t)L;
+    int kept = 0;
+    for (int64_t s = threadIdx.x; s < n_seg; s += APPLES_TPB) {
+        const int c = seg_cnt[q * n_seg + s];
+        int32_t *w = seg_slot + q * stride + s * 64;
+        for (int k = 0; k < c; ++k) {
+            const uint32_t pk = (uint32_t)w[k];
+            const int64_t slot = s * 64 + (pk >> 26);
+            int valid = (int)((pk >> 13) & 0x1fffu), mism = (int)(pk & 0x1fffu);
+            const int e0 = ex_off ? ex_off[slot] : 0, e1 = ex_off ? ex_off[slot + 1] : 0;
+            if (e1 > e0) {
+                int add = 0;
+                for (int e = e0; e < e1; ++e) {
+                    const uint8_t b = row[ex_site[e]];
+                    add += (b == 'A' || b == 'C' || b == 'G' || b == 'T') ? 1 : 0;
+                }
+                valid += add; mism += add;
+            } else if (!retest_all) { ++kept; continue; }
+            if (mism <= mmax[valid]) { ++kept; w[k] = (int32_t)((pk & 0xfc000000u) | ((uint32_t)valid << 13) | (uint32_t)mism); }
+            else w[k] = (int32_t)(pk & 0xfc000000u);
+        }
+    }
+    for (int o = WAVE / 2; o > 0; o >>= 1) kept += __shfl_down(kept, o, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) sh_cnt[threadIdx.x / WAVE] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < APPLES_TPB / WAVE; ++i) t += sh_cnt[i];
+        n_surv[q] = t;
+    }
+}
+}  // namespace
+
+int launch_exotic_fix(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, const int32_t *seg_cnt,
+                      int32_t *n_surv) {
+    if (nq == 0) return 0;
+    const DevAlign &a = ctx->aln;
+    hipLaunchKernelGGL(k_exotic_fix, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, seg_slot, seg_cnt, a.slots_pad,
+                       qb.raw + q0 * (int64_t)a.L, a.L, a.ex_off, a.ex_site, ctx->jc_mmax_true ? ctx->jc_mmax_true : ctx->jc_mmax,
+                       ctx->jc_mmax_true ? 1 : 0, n_surv);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -3,7 +3,10 @@
 // Bit-plane layout (JC69 path): sites are cut into 32-site words, 4 words form a group g.
 // Per row: a gap plane M (bit = site is not '-') and P code planes.  P = 2 is the ACGT fast
 // path (code = (byte >> 1) & 3: A=0 C=1 T=2 G=3); P = 8 keeps the raw byte, so "any other byte
-// is an ordinary symbol" (distance.py:733 compares bytes) holds for every input.
+// is an ordinary symbol" (distance.py:733 compares bytes) holds for every input.  In the 2-plane form a
+// byte beyond ACGT- is packed AS A GAP and reported (the context's flag, the row's flag): what is then missing
+// from a pair's counts is added back exactly for the pairs that matter (dist.hip: k_exotic_fix) or the row takes
+// the 8-plane form as well (api.hip: exotic rows and queries).
 //   reference rows : packed[(g*(P+1) + plane) * slots_pad + slot]   (uint4; a wave reads 1 KiB)
 //   query rows     : packed[(((q/16)*G + g)*16 + q%16) * (P+1) + plane]   (uint4; wave-uniform reads:
 //                    for one word group the 16 queries of a tile are contiguous, so several
@@ -13,7 +16,8 @@
 template <int P>
 __global__ __launch_bounds__(APPLES_TPB) void k_pack_rows(const uint8_t *__restrict__ raw, int64_t n_rows, int L, int G,
                                                           uint4 *__restrict__ out, int64_t slots_pad, int query_layout,
-                                                          int *__restrict__ exotic, const int32_t *__restrict__ src_row) {
+                                                          int *__restrict__ exotic, const int32_t *__restrict__ src_row,
+                                                          int32_t *__restrict__ row_bad) {
     int64_t row = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
     int g = blockIdx.y;
     if (row >= n_rows) return;
@@ -35,10 +39,14 @@ __global__ __launch_bounds__(APPLES_TPB) void k_pack_rows(const uint8_t *__restr
             if (site >= L) break;
             uint32_t b = src[site];
             uint32_t nd = (b != (uint32_t)'-');
+            if (P == 2) {
+                const uint32_t ok = (b == 'A' || b == 'C' || b == 'G' || b == 'T');
+                bad |= nd & !ok;
+                nd = ok;  // (a byte beyond ACGT-: a gap here, and reported)
+            }
             m[k] |= nd << i;
             if (P == 2) {
                 uint32_t code = (b >> 1) & 3u;
-                bad |= nd & !(b == 'A' || b == 'C' || b == 'G' || b == 'T');
                 c[0][k] |= ((code & 1u) & nd) << i;
                 c[1][k] |= ((code >> 1) & nd) << i;
             } else {
@@ -47,7 +55,10 @@ __global__ __launch_bounds__(APPLES_TPB) void k_pack_rows(const uint8_t *__restr
             }
         }
     }
-    if (bad) atomicOr(exotic, 1);
+    if (bad) {
+        if (exotic) atomicOr(exotic, 1);
+        if (row_bad) row_bad[row] = 1;
+    }
     if (query_layout) {
         uint4 *dst = out + (((row >> 4) * G + g) * 16 + (row & 15)) * (P + 1);
         dst[0] = make_uint4(m[0], m[1], m[2], m[3]);
@@ -62,17 +73,18 @@ __global__ __launch_bounds__(APPLES_TPB) void k_pack_rows(const uint8_t *__restr
 }
 
 int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, int planes, uint4 *d_out,
-                     int64_t slots_pad, bool query_layout, int *d_exotic, hipStream_t st, const int32_t *d_src_row) {
+                     int64_t slots_pad, bool query_layout, int *d_exotic, hipStream_t st, const int32_t *d_src_row,
+                     int32_t *d_row_bad) {
     if (n_rows == 0) return 0;
     if (!st) st = ctx->stream;
     int G = ctx->aln.G;
     dim3 grid((unsigned)((n_rows + APPLES_TPB - 1) / APPLES_TPB), (unsigned)G);
     if (planes == 2)
         hipLaunchKernelGGL(k_pack_rows<2>, grid, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, G, d_out, slots_pad,
-                           query_layout ? 1 : 0, d_exotic, d_src_row);
+                           query_layout ? 1 : 0, d_exotic, d_src_row, d_row_bad);
     else
         hipLaunchKernelGGL(k_pack_rows<8>, grid, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, G, d_out, slots_pad,
-                           query_layout ? 1 : 0, d_exotic, d_src_row);
+                           query_layout ? 1 : 0, d_exotic, d_src_row, (int32_t *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

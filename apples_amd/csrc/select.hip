@@ -431,6 +431,9 @@ __global__ __launch_bounds__(TPB) void k_select_fast(SelectArgs a) {
         for (int64_t s = tid; s < n_seg; s += TPB) c += cnt[s];
         total = block_sum<NW>(c, sh_i);
     }
+    // (reference rows with bytes beyond ACGT-, a.ex_off / a.ex_mmax: a survivor may still fail once those sites are counted -- the
+    // walk below recounts it -- so fewer than `baseobs` survivors is known for sure only at the end; with fewer than that to begin
+    // with the answer is here already)
     if ((a.seg_surv ? a.seg_surv[q] : total) < a.baseobs) {
         __syncthreads();  // (seg_surv may be n_obs itself: every thread has read it)
         if (tid == 0) {
@@ -442,16 +445,35 @@ __global__ __launch_bounds__(TPB) void k_select_fast(SelectArgs a) {
     int32_t *o_node = a.obs_node + q * a.obs_cap;
     double *o_dist = a.obs_dist + q * a.obs_cap;
     int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
-    int base = 0, n_total = 0;
+    int base = 0, n_total = 0, n_drop = 0;
     int z_i = 0x7fffffff, z_node = -2;
+    const bool exm = a.ex_mmax != nullptr;  // the survivors' counts once more where the row holds bytes beyond ACGT- (below)
+    const uint8_t *qrow = exm ? a.q_raw + q * (int64_t)a.L : nullptr;
+    // A reference row with bytes beyond ACGT-, which the matrix-core pass took for gaps: every such site under a letter of the
+    // query is a valid site and a mismatch (apples/distance.py:733-737: the bytes differ; a query with such bytes itself is not
+    // served here, api.hip:exotic_queries), so the pair's counts are (valid + k, mism + k) -- it can only fail now: 0 <= d <=
+    // threshold once more on the integers, the rule's own table (the pass's was loosened at its lower end where -V could have
+    // kept the smaller count out: then every survivor is tested again, ex_all).  False: the pair is no survivor.
+    auto recount = [&](int slot, long long &valid, long long &mism) -> bool {
+        const int e0 = a.ex_off ? a.ex_off[slot] : 0, e1 = a.ex_off ? a.ex_off[slot + 1] : 0;
+        if (e1 == e0 && !a.ex_all) return true;
+        int add = 0;
+        for (int e = e0; e < e1; ++e) {
+            const uint8_t b = qrow[a.ex_site[e]];
+            add += (b == 'A' || b == 'C' || b == 'G' || b == 'T') ? 1 : 0;
+        }
+        valid += add; mism += add;
+        return mism <= a.ex_mmax[valid];
+    };
     // one survivor: entry `off` of segment `seg` -> (slot, distance), own row dropped, first zero noted
     auto take = [&](int64_t seg, int off, int &node, double &d, int &lv) -> int {
         const int64_t src = seg * 64 + off;
         int slot = sslot[src];
         if (a.seg_lut) {  // the matrix-core distance pass leaves position | valid | mism; same table, same bits
             const uint32_t pk = (uint32_t)slot;
-            const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
+            long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
             slot = (int)(seg * 64 + (pk >> 26));
+            if (exm && !recount(slot, valid, mism)) { ++n_drop; return 0; }
             d = a.seg_lut[valid * (valid + 1) / 2 + mism];
         } else {
             d = sd[src];
@@ -513,8 +535,9 @@ __global__ __launch_bounds__(TPB) void k_select_fast(SelectArgs a) {
                 slot_[u] = raw_[u];
                 if (a.seg_lut) {  // the matrix-core distance pass leaves position | valid | mism; same table, same bits
                     const uint32_t pk = (uint32_t)raw_[u];
-                    const long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
+                    long long valid = (pk >> 13) & 0x1fffu, mism = pk & 0x1fffu;
                     slot_[u] = (int)(seg_[u] * 64 + (pk >> 26));
+                    if (exm && in_[u] && !recount(slot_[u], valid, mism)) { in_[u] = false; ++n_drop; }
                     d_[u] = a.seg_lut[in_[u] ? valid * (valid + 1) / 2 + mism : 0];
                 }
                 const int sl = in_[u] ? slot_[u] : 0;
@@ -564,6 +587,18 @@ __global__ __launch_bounds__(TPB) void k_select_fast(SelectArgs a) {
     }
     }
     n_total = block_sum<NW>(n_total, sh_i);
+    if (exm) {  // survivors that failed with their rows' other bytes counted: fewer than `baseobs` left after all -> the top-up rule's list
+        __syncthreads();
+        n_drop = block_sum<NW>(n_drop, sh_i);
+        if (total - n_drop < a.baseobs) {
+            if (tid == 0) {
+                a.slow_list[atomicAdd(a.slow_count, 1)] = (int32_t)q;
+                a.n_obs[q] = 0;
+            }
+            return;
+        }
+        __syncthreads();
+    }
     double zd = 0; int zi = z_i, zp = 0;
     block_argmin3<NW>(zd, zi, zp, sh_d, sh_i, sh_j);
     __shared__ int sh_znode;

@@ -124,6 +124,21 @@ def test_singleton_jc69_routes_agree(seed):
         mb = int(rng.choice([0, 0, 32, 96, 160, 512])); m = str(rng.choice(['OLS', 'FM', 'BME', 'BE']))
         d, shp = _shaped(seed, c, n, lambda spine: synth.make_dataset(n, L, nq, gap_rate=gap, seed_tree=100 + c, mean_len=float(rng.choice([0.003, 0.01, 0.05])), spine=spine))
         nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
+        # bytes beyond ACGT- (ordinary symbols to apples/distance.py:733-737), drawn apart from the configuration stream: none / a `.`
+        # in a few reference rows and a `?` in one query / such bytes in most rows and many queries, runs of them at the rows' ends
+        rx = np.random.default_rng([seed, c, 79])
+        ex = int(rx.integers(0, 4))
+        if ex >= 2:
+            d.ref_seqs = d.ref_seqs.copy(); d.query_seqs = d.query_seqs.copy()
+            rows = np.nonzero(rx.random(n) < (0.05 if ex == 2 else 0.8))[0]
+            d.ref_seqs[rows, rx.integers(0, L, size=len(rows))] = ord('.')
+            d.query_seqs[int(rx.integers(0, nq)), int(rx.integers(0, L))] = ord('?')
+            if ex == 3:
+                for i in rows[::3]:
+                    d.ref_seqs[i, :int(rx.integers(0, L // 4 + 1))] = ord('.')
+                for i in range(0, nq, 3):
+                    d.query_seqs[i, L - int(rx.integers(0, L // 4 + 1)):] = ord(str(rx.choice(['.', '*'])))
+            shp += ' exotic %d' % ex
         crit, neg = _crit(seed, c)
         out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, method=m, criterion=crit, negative=neg, threshold=thr,
                                                 baseobs=b, max_batch=mb, debug=dbg), d.query_seqs)

@@ -53,22 +53,25 @@ def test_jc69_edge_cases_and_byte_symbols():
     a, b = g['a'], g['b']
     tree = read_tree(os.path.join(DATA, 'small_backbone.nwk'))
     for V, key in ((0.001, 'jc69_V0.001'), (0.5, 'jc69_V0.5')):
-        # rows of `b` act as the reference; '*' and '?' force the 8-plane raw-byte layout
+        # rows of `b` act as the reference; '*' and '?' are ordinary symbols (apples/distance.py:733): the context keeps its
+        # 2-plane rows (such bytes as gaps there) and an 8-plane copy, which full rows come from
         e = Engine(tree, b, np.full(len(b), -1, np.int32), method='OLS', overlap=V)
-        assert e.describe()['code_planes'] == 8
+        info = e.describe()
+        assert info['code_planes'] == 2 and info['eight_plane_copy'] == 1 and info['exotic_sites_max_per_row'] > 0, info
         counts, dist = e.distances(a)
         for i in range(len(a)):
             assert tuple(counts[i, i]) == orc.pair_counts(a[i], b[i])
             w = g[key][i]
             assert (dist[i, i] == w) or abs(dist[i, i] - w) <= 1e-6 * abs(w)
         e.close()
-    # ACGT- only -> 2-plane fast path; a later query block with '*' widens the context lazily
+    # ACGT- only -> 2-plane fast path; a later query block with '*' brings the 8-plane copy into being, the context stays as it is
     keep = [i for i in range(len(b)) if not (set(b[i].tobytes()) - set(b'ACGT-'))]
     e = Engine(tree, b[keep], np.full(len(keep), -1, np.int32), method='OLS')
     assert e.describe()['code_planes'] == 2
     c1_, d1 = e.distances(a[:8])      # rows 0..7 of `a` are plain
+    assert e.describe()['eight_plane_copy'] == 0
     c2_, d2 = e.distances(a[8:10])    # row 8 carries '*'
-    assert e.describe()['code_planes'] == 8
+    assert e.describe()['code_planes'] == 2 and e.describe()['eight_plane_copy'] == 1
     c3_, d3 = e.distances(a[:8])
     assert np.array_equal(c1_, c3_) and np.array_equal(d1, d3)
     for qi in range(8, 10):

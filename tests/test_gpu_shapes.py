@@ -290,9 +290,10 @@ def test_query_matrix_of_another_length_is_refused():
 
 def test_exotic_symbols_in_a_later_chunk_of_a_streamed_block():
     """apples_place_from_sequences streams the caller's buffer chunk by chunk; a symbol beyond ACGT-
-    in a later chunk is only seen after earlier chunks ran on the 2-plane images.  The call must then
-    widen the reference to raw bytes and give the same answer as a context that saw such a symbol from
-    the start ("any other byte is an ordinary symbol", apples/distance.py:733)."""
+    in a later chunk is only seen after earlier chunks ran on the 2-plane images, which took it for a gap.  The
+    call must then place those queries once more through the 8-plane kernels ("any other byte is an ordinary
+    symbol", apples/distance.py:733) -- and since round 6 the context keeps its matrix-core forms (one `*` used to
+    re-pack it to 8 planes for good)."""
     d = synth.make_dataset(1500, 200, 400)
     nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
     q = d.query_seqs.copy()
@@ -301,11 +302,63 @@ def test_exotic_symbols_in_a_later_chunk_of_a_streamed_block():
     eng = Engine(d.tree, d.ref_seqs, nodes, method='OLS', max_batch=64)
     assert eng.describe()['code_planes'] == 2
     got = eng.place_sequences(q)
-    assert eng.describe()['code_planes'] == 8
-    eng.close()
+    info = eng.describe()
+    assert info['code_planes'] == 2 and info['eight_plane_copy'] == 1 and info['fused_distance_pass'].startswith('fp4'), info
     co = COracle(d.tree, d.ref_seqs, nodes, method='OLS', lut=jc69_lut(200, 0.001), threads=NTHREADS)
     want = co.place_sequences(q)
     assert got.tobytes() == want.tobytes()
+    # the same block resident (the flags are known before the pass), and a block where most queries carry such bytes (the whole
+    # block through the 8-plane kernels)
+    h, n = eng.upload_queries(q)
+    eng.place_resident(h)
+    assert eng.fetch(h, n).tobytes() == want.tobytes()
+    eng.free_queries(h)
+    q2 = d.query_seqs.copy()
+    q2[::2, 5] = ord('.')
+    q2[1::4, 190:] = ord('?')
+    got2 = eng.place_sequences(q2)
+    assert got2.tobytes() == co.place_sequences(q2).tobytes()
+    assert eng.place_sequences(q).tobytes() == want.tobytes()  # (and the fast route again afterwards)
+    eng.close()
+
+
+def test_exotic_symbols_in_the_reference_rows_stay_on_the_matrix_cores():
+    """Reference rows with bytes beyond ACGT- (`.` as a gap character is ordinary in SILVA / ARB exports; apples/distance.py:733-737
+    compares them as bytes): the fused pass keeps running on the matrix cores with such bytes as gaps, k_exotic_fix gives the
+    survivors on those rows their exact counts, full rows (top-up, apples_distances) come from the 8-plane copy.  Sparse (one `.`
+    per 1 000 sites in 5 % of the rows: bench.py's c3-dots), dense (every row, runs of `.` at both ends), and under -V 0.5, where the
+    smaller valid count of the gap form could have kept a pair out; queries with such bytes among them.  Byte for byte against the
+    C oracle, and equal to the route without the matrix-core pass."""
+    rng = np.random.default_rng(21)
+    for n, L, nq, V, dense in ((3000, 1000, 700, 0.001, False), (1500, 300, 500, 0.001, True), (1200, 400, 300, 0.5, True), (40000, 500, 600, 0.001, False)):
+        d = synth.make_dataset(n, L, nq, gap_rate=0.3 if V > 0.1 else 0.05)
+        nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
+        ref = d.ref_seqs.copy()
+        if dense:
+            for i in range(n):
+                a, b = rng.integers(0, L // 6, size=2)
+                ref[i, :a] = ord('.'); ref[i, L - b:] = ord('.')
+                ref[i, rng.integers(0, L, size=3)] = ord('?')
+        else:
+            rows = np.nonzero(rng.random(n) < 0.05)[0]
+            ref[rows, rng.integers(0, L, size=len(rows))] = ord('.')
+        q = d.query_seqs.copy()
+        q[0, 7] = ord('?')
+        q[5, :40] = ord('.')
+        q[6] = ref[11]          # an exact match of a row with such bytes
+        eng = Engine(d.tree, ref, nodes, method='OLS', overlap=V)
+        info = eng.describe()
+        assert info['code_planes'] == 2 and info['eight_plane_copy'] == 1 and info['fused_distance_pass'].startswith('fp4'), info
+        got = eng.place_sequences(q)
+        counts, dist = eng.distances(q[:16])
+        eng.close()
+        co = COracle(d.tree, ref, nodes, method='OLS', overlap=V, lut=jc69_lut(L, V), threads=NTHREADS)
+        want = co.place_sequences(q)
+        assert got.tobytes() == want.tobytes(), (n, L, V, dense, int((got['edge'] != want['edge']).sum()))
+        assert dist.tobytes() == co.distances(q[:16])[:, :n].tobytes()
+        e2 = Engine(d.tree, ref, nodes, method='OLS', overlap=V, debug=('no_fuse',))
+        assert e2.place_sequences(q).tobytes() == got.tobytes()
+        e2.close()
 
 
 def test_scan_sweep_at_c3_shape_and_on_a_deep_tree(monkeypatch):
