@@ -355,7 +355,7 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
     // (the selection's bitmap over emission indices: 4 096 words of LDS at most, k_select_clusters)
     int64_t n_leaf_slots = 0;
     for (int64_t s = 0; s < a.n_refs; ++s) n_leaf_slots += slot_node[s] >= 0 ? 1 : 0;
-    if (n_blocks == 0 || n_leaf_slots + n_blocks > 262144 || n >= (1 << 30)) return 0;
+    if (n_blocks == 0 || n_leaf_slots + n_blocks > SELECT_CLUSTERS_MAX_SLOTS || n >= (1 << 30)) return 0;
     std::vector<int4> rec_i;
     std::vector<double2> rec_e;
     std::vector<double> stat_plain, stat_bme;  // per record: the first three components of the node's S tuple (OLS / BE / FM; BME)
@@ -1994,7 +1994,7 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
 static GemmThreshold gemm_threshold(const std::vector<int32_t> &mmax, double f) {
     GemmThreshold g;
     const int L = (int)mmax.size() - 1;
-    if (L > GEMM_MAX_L) return g;
+    if (L > GEMM_MAX_L13) return g;  // (longer alignments: the 2^12 form tests through the table)
     int vmin = 0;
     while (vmin <= L && mmax[vmin] < 0) ++vmin;
     for (int v = vmin; v <= L; ++v)

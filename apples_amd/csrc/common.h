@@ -111,7 +111,8 @@ struct GemmThreshold {
     float slope = 0.f, off = 0.f, vmin8 = 0.f;
     bool ok = false;
 };
-#define GEMM_MAX_L 2046  // the merged accumulator decodes exactly while valid <= 2046
+#define GEMM_MAX_L13 2046  // the merged accumulator with the validity sum at 2^13 decodes exactly while valid <= 2046 ...
+#define GEMM_MAX_L 4092    // ... and at 2^12, by the congruence of dist_gemm.hip's header, while valid <= 4092
 
 struct DevAlign {
     int64_t n_rows = 0, n_refs = 0, n_reps = 0;
@@ -504,7 +505,7 @@ int launch_select_clusters_listed(apples_ctx *ctx, const SelectArgs &a, int64_t 
 #define SELECT_CLUSTERS_MIN_TILE 16   // fewest queries a full tile of k_cluster_dist holds
 #define SELECT_CLUSTERS_BIG_CAP 5120  // ... and on its second form, for the few queries beyond ACC_CAP (one workgroup per CU: 60 KB of lists)
 #define SELECT_CLUSTERS_BIG_LIST 1024 // queries a batch may send to that form (more: the general route)
-#define SELECT_CLUSTERS_MAX_SLOTS 229376
+#define SELECT_CLUSTERS_MAX_SLOTS 524288  // k_select_clusters' bitmap: 256 threads x runs of 32 words (80 KB of LDS at that size; 229 376 until round 6)
 int launch_counts_reps(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);
 int launch_build_cluster_panels(apples_ctx *ctx);  // listed queries, needs segmin_d/segmin_i; baseobs <= 256
 int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const int32_t *perm, int64_t nq, int64_t n_cols);

@@ -18,6 +18,12 @@
 //   * persistent workgroups walk the tile grid in strips of 4 reference tiles per XCD.
 // Output format is that of k_jc69_mfma<1> (threshold on the integers, ballot compaction per 64-slot segment, one
 // packed word per survivor); the epilogue decodes on packed fp32 pairs and tests a host-verified linear threshold.
+//
+// Alignments of 2 047 to 4 092 sites (VS = 12, round 6): the validity sum rides at 2^12, acc = sum t.t + 4096 valid = 4099 valid -
+// 4 mism, still below 2^24.  The two fields overlap now (sum t.t reaches 3 valid > 4096), but the pair decodes all the same:
+// 0 <= mism <= valid puts valid into [acc / 4099, acc / 4095], an interval narrower than 4 while valid < 4099, and 4 mism = 4099
+// valid - acc makes 3 valid = acc (mod 4), i.e. valid = 3 acc (mod 4): exactly one count in the interval.  Integer decode, the
+// threshold through the table in LDS (a pass of 63 steps per tile pays for it: the epilogue is a few percent of the tile).
 #include "common.h"
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -42,10 +48,20 @@ __device__ __forceinline__ v16f_t mfma_f4(const v4i_t &a, const v4i_t &b, const 
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0, 0, 0);  // fp4 x fp4, unscaled
 }
 
+template <int VS>
 __device__ __forceinline__ v16f_t mfma_f4_v(const v4i_t &a, const v4i_t &b, const v16f_t &c) {
     const v8i_t a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
-    // E8M0 scales: 127 + 13 on the first operand, 127 (= 1.0) on the second
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 127 + GM_VSHIFT, 0, 127);
+    // E8M0 scales: 127 + VS on the first operand, 127 (= 1.0) on the second
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 127 + VS, 0, 127);
+}
+
+// acc -> (valid, 4 mism) of the VS = 12 form (the file's header): valid = the count in [acc / 4099, acc / 4095] with valid = 3 acc (mod 4)
+__device__ __forceinline__ void decode12(float S, int &valid, int &mism4) {
+    const int A = (int)S;
+    int v = (A + 4098) / 4099;
+    v += (3 * A - v) & 3;
+    valid = v;
+    mism4 = 4099 * v - A;
 }
 
 // R = (NB - 2) % 3: the shape of the main loop's tail, fixed per launch (a run-time choice between the three tails
@@ -53,7 +69,7 @@ __device__ __forceinline__ v16f_t mfma_f4_v(const v4i_t &a, const v4i_t &b, cons
 // QT = query rows per workgroup tile: 256 (eight wavefronts, one workgroup per CU) or 128 (four wavefronts, two
 // workgroups per CU: one's epilogue and barrier stalls run beside the other's MFMAs, for half as much reuse of the
 // reference image per byte moved)
-template <bool LIN, int R, int QT>
+template <bool LIN, int R, int QT, int VS = GM_VSHIFT>
 __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *__restrict__ rf4, const uint8_t *__restrict__ qf4,
                                                       int64_t qrow0, int64_t slots_pad, int NB, int64_t nq, int L, int TQ, int TR,
                                                       int32_t *__restrict__ seg_slot, int32_t *__restrict__ seg_cnt,
@@ -62,7 +78,9 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
     // queue before unrelated reads): three generations -- the QT query rows of one 64-site step (64 bytes each:
     // t1, t2), the 256 reference slots behind them -- and, for the table form of the threshold, the table
     constexpr int AI = QT * 64, GEN = AI + GM_IMG, NW = QT / 32, PB = 16 / NW;  // A image, generation, wavefronts, B pieces per wavefront
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[3 * GEN + (LIN ? 0 : 2048 * 4)];
+    constexpr int NTAB = VS == 12 ? 4096 : 2048;  // entries of the threshold table (valid counts the form can carry)
+    static_assert(VS == GM_VSHIFT || (VS == 12 && !LIN), "the 2^12 form decodes on integers and tests through the table");
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[3 * GEN + (LIN ? 0 : NTAB * 4)];
 #define Aq(g) (lds + (g) * GEN)
 #define Br(g) (lds + (g) * GEN + AI)
     float *mm_lds = reinterpret_cast<float *>(lds + 3 * GEN);
@@ -91,7 +109,7 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wq = wv >> 1, wr = wv & 1;
     if (!LIN)
-        for (int i = tid; i < 2048; i += QT * 2) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
+        for (int i = tid; i < NTAB; i += QT * 2) mm_lds[i] = i <= L ? (float)(4 * mmax[i]) : -4.f;
     // DMA roles: a tile-step image is 1024 16-byte chunks = 16 pieces of 1 KB, stored in HBM exactly as it lies in
     // LDS (k_expand_queries_f4, compact form): row r's four chunks (t1 and t2, two 32-site words each) at 4 r, chunk c
     // in slot c ^ ((r >> 2) & 3), so that with the 64-byte stride the 16 lanes of a ds_read_b128 group cover all 16
@@ -154,7 +172,7 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = valid ? mfma_f4_v(fa[set][i], fb[set][j], acc[i][j]) : mfma_f4(fa[set][i], fb[set][j], acc[i][j]);
+                acc[i][j] = valid ? mfma_f4_v<VS>(fa[set][i], fb[set][j], acc[i][j]) : mfma_f4(fa[set][i], fb[set][j], acc[i][j]);
     };
     auto make_t3 = [&](int s1, int s2) __attribute__((always_inline)) {  // set s2 (t2) -> t3 = t1 ^ sign(t2)
 #pragma unroll
@@ -361,9 +379,15 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const float S = acc[i][2 * s + j][x];
-                    const float valid = __builtin_floorf((S + 2047.f) * (1.f / 8192.f));
-                    const float mism4 = __builtin_fmaf(valid, 8195.f, -S);
-                    keepbits |= (mism4 <= mm_lds[(int)valid] ? 1u : 0u) << (x * 2 + j);
+                    if (VS == 12) {
+                        int v, m4;
+                        decode12(S, v, m4);
+                        keepbits |= ((float)m4 <= mm_lds[v] ? 1u : 0u) << (x * 2 + j);
+                    } else {
+                        const float valid = __builtin_floorf((S + 2047.f) * (1.f / 8192.f));
+                        const float mism4 = __builtin_fmaf(valid, 8195.f, -S);
+                        keepbits |= (mism4 <= mm_lds[(int)valid] ? 1u : 0u) << (x * 2 + j);
+                    }
                 }
             if (__ballot(keepbits != 0) == 0ull) continue;  // no survivor among these 32 queries x 64 slots
             const int64_t seg = (r0 + wr * 128 + s * 64) >> 6;
@@ -380,14 +404,16 @@ __global__ __launch_bounds__(QT * 2, 256 / QT) void k_jc69_gemm(const uint8_t *_
                 int32_t *row = row0 + (int64_t)cx * slots_pad;
                 if (k0) {
                     const float S = acc[i][2 * s][x];
-                    const int valid = (int)__builtin_floorf((S + 2047.f) * (1.f / 8192.f));
-                    const int mism = (8195 * valid - (int)S) >> 2;
+                    int valid, mism;
+                    if (VS == 12) { decode12(S, valid, mism); mism >>= 2; }
+                    else { valid = (int)__builtin_floorf((S + 2047.f) * (1.f / 8192.f)); mism = (8195 * valid - (int)S) >> 2; }
                     row[__popc(lo & below)] = (int32_t)(((uint32_t)fr << 26) | ((uint32_t)valid << 13) | (uint32_t)mism);
                 }
                 if (k1) {
                     const float S = acc[i][2 * s + 1][x];
-                    const int valid = (int)__builtin_floorf((S + 2047.f) * (1.f / 8192.f));
-                    const int mism = (8195 * valid - (int)S) >> 2;
+                    int valid, mism;
+                    if (VS == 12) { decode12(S, valid, mism); mism >>= 2; }
+                    else { valid = (int)__builtin_floorf((S + 2047.f) * (1.f / 8192.f)); mism = (8195 * valid - (int)S) >> 2; }
                     row[__popc(lo) + __popc(hi & below)] = (int32_t)(((uint32_t)(32 + fr) << 26) | ((uint32_t)valid << 13) | (uint32_t)mism);
                 }
                 if (fr == 0 && in) cnt0[(int64_t)cx * n_seg] = __popc(lo) + __popc(hi);
@@ -428,6 +454,16 @@ int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
     static const bool table = getenv("APPLES_GEMM_TABLE") != nullptr;  // diagnostic knob: threshold through the LDS table
     const bool lin = ctx->gemm_thr.ok && !table;
     const int R = (a.G * 2 - 2) % 3;
+    if (a.L > GEMM_MAX_L13) {  // 2 047 .. 4 092 sites: the validity sum at 2^12, integer decode, the threshold through the table
+#define GM_LAUNCH12(R_, QT_)                                                                                         \
+    hipLaunchKernelGGL((k_jc69_gemm<false, R_, QT_, 12>), dim3((unsigned)grid), dim3(QT_ * 2), 0, ctx->stream, a.ref_f4, \
+                       qb.qf4, q0, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt, ctx->jc_mmax, ctx->gemm_thr)
+        if (QT == 256) { if (R == 0) GM_LAUNCH12(0, 256); else if (R == 1) GM_LAUNCH12(1, 256); else GM_LAUNCH12(2, 256); }
+        else { if (R == 0) GM_LAUNCH12(0, 128); else if (R == 1) GM_LAUNCH12(1, 128); else GM_LAUNCH12(2, 128); }
+#undef GM_LAUNCH12
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
 #define GM_LAUNCH(LIN_, R_, QT_)                                                                                     \
     hipLaunchKernelGGL((k_jc69_gemm<LIN_, R_, QT_>), dim3((unsigned)grid), dim3(QT_ * 2), 0, ctx->stream, a.ref_f4,  \
                        qb.qf4, q0, a.slots_pad, a.G * 2, nq, a.L, TQ, TR, seg_slot, seg_cnt,                         \

@@ -1130,12 +1130,14 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     }
     const int obs = block_sum<NW>(obs_cnt, sh_i);
     if (PHASE != 4 && obs < a.baseobs) { to_slow(obs); return; }  // the reference would pop further clusters (Reference.py:146): phase 4 did
-    // ---- ranks of the slot bitmap: a thread counts its run of 16 words, one scan over the threads
+    // ---- ranks of the slot bitmap: a thread counts its run of 16 words (of 32 beyond 16 TPB words: 262 144 slots at 256
+    // threads), one scan over the threads
     int n_emit;
+    const int rsh = n_words > TPB * 16 ? 5 : 4;
     auto ranks = [&]() {
         int c = 0;
-        for (int k = 0; k < 16; ++k) {
-            const int w = tid * 16 + k;
+        for (int k = 0; k < (1 << rsh); ++k) {
+            const int w = (tid << rsh) + k;
             if (w < n_words) { pre[w] = (uint16_t)c; c += __popcll(dyn_bits[w]); }
         }
         sh_base[tid] = block_excl_scan_int<NW>(c, sh_i, &n_emit);
@@ -1160,7 +1162,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     auto rank_of = [&](int slot) -> int {  // emitted members in the slots below `slot`
         const int w = slot >> 6;
         if (w >= n_words) return n_emit;
-        return sh_base[w >> 4] + (int)pre[w] + __popcll(dyn_bits[w] & ((1ull << (slot & 63)) - 1ull));
+        return sh_base[w >> rsh] + (int)pre[w] + __popcll(dyn_bits[w] & ((1ull << (slot & 63)) - 1ull));
     };
     // ---- pass 2: emission in slot order
     for (int m0 = 0; m0 < M; m0 += TPB * E) {
@@ -1647,6 +1649,12 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (a.e_of_slot) dyn = std::max<size_t>(dyn, 1024 * 16 + (SELECT_CLUSTERS_ACC_CAP + 1) * 4);  // (the short form's list lives in the bitmap's memory)
     const bool sd = a.aa_idx != nullptr;  // scoredist context: k_cluster_dist_sd computes the member distances (no by-query form)
     const bool by_query = (ctx->dbg & APPLES_DBG_CLUSTER_BY_QUERY) != 0 && !sd;  // diagnostic switch: phase 0 alone
+    if (dyn > 48 * 1024) {  // (beyond the default allowance of dynamic LDS -- references of more than ~300 000 slots; per device, so asked for at every launch)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<3, SELECT_CLUSTERS_BIG_CAP, true, 1024>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    }
     if (sd && !a.cl_count) { ctx->err = "scoredist cluster route without its tile scratch"; return 1; }
     if (by_query || !a.cl_count) {
         hipLaunchKernelGGL(k_select_clusters<0>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
@@ -1716,7 +1724,11 @@ int launch_select_clusters_listed(apples_ctx *ctx, const SelectArgs &a, int64_t 
     SelectArgs b = a;
     const size_t n_words = (size_t)((a.n_members + 63) >> 6);
     b.rep_cache = a.n_reps <= 8192 ? 1 : 0;
-    const size_t dyn = (n_words + (n_words + 3) / 4 + (b.rep_cache ? (size_t)a.n_reps : 0)) * 8;
+    size_t dyn = (n_words + (n_words + 3) / 4 + (b.rep_cache ? (size_t)a.n_reps : 0)) * 8;
+    if (dyn > 150 * 1024) {  // (a compute unit has 160 KB: without the row of representatives the phase forwards its queries to the general route)
+        b.rep_cache = 0;
+        dyn = (n_words + (n_words + 3) / 4) * 8;
+    }
     if (dyn > 48 * 1024)  // (beyond the default allowance of dynamic LDS; per device, so asked for at every launch)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     hipLaunchKernelGGL(k_select_clusters<4>, dim3((unsigned)std::min<int64_t>(nq_max, 1024)), dim3(APPLES_TPB), dyn, ctx->stream, b);

@@ -2025,7 +2025,7 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
     const dim3 gd((unsigned)std::min<int64_t>(need, wg_down > 0 ? wg_down : cus * LEAN_DOWN_WAVES * 3 / 2));
     if ((int64_t)gu.x * 4 > up.lean_teams) { ctx->err = "lean sweep: more bottom-up teams than per-leaf scratch"; return 1; }
     // APPLES_LEAN_FUSED=1: one kernel for both passes of a query (k_lean_both), the team's top-down pass right behind its bottom-up
-    // pass.  Measured SLOWER than the two kernels in every workload (round 5, scripts/r05_run8.sh: config 3's sweep 15.6 -> 16.7 ms,
+    // pass.  Measured SLOWER than the two kernels in every workload (round 5, profiles/r05_lean_fused_exp.txt: config 3's sweep 15.6 -> 16.7 ms,
     // config 5's block 1.31 -> 1.44, config 4 2.77 -> 3.05): at three wavefronts per SIMD the fused body spills 85 vector registers
     // where the bottom-up kernel alone spills 19 and the top-down kernel 8, and the launch it saves is worth less than that.
     static const bool fused = getenv("APPLES_LEAN_FUSED") != nullptr;  // experiment knob

@@ -222,7 +222,10 @@ def hbm_point(ref_seqs, queries, device, seconds=5.0, min_packed_bytes=1100 << 2
     med = float(np.median(ms))
     moved = n * (info['packed_bytes'] + info['n_rows'] * 8.0)
     gbs = moved / (med * 1e-3) / 1e9
-    return {'kernel': 'k_jc69 (bit planes), query tile 1, full fp64 rows out', 'rows': int(info['n_rows']), 'L': int(L),
+    return {'kernel': 'k_jc69 (bit planes), query tile 1, full fp64 rows out', 'what': 'DELIVERED bandwidth (bytes the kernel moves / time): '
+            'FETCH_SIZE counts Infinity-Cache hits and the 256 queries of a launch march over the same reference together, so this is not '
+            'a pure HBM figure (the guide\'s measured-achievable HBM rate is ~6.3 TB/s)',
+            'rows': int(info['n_rows']), 'L': int(L),
             'queries_per_launch': int(n), 'launches': len(ms), 'continuous_kernel_seconds': float(sum(ms) * 1e-3),
             'wall_seconds': wall, 'ms_per_launch_median': med, 'us_per_query': med * 1e3 / n,
             'packed_reference_bytes': int(info['packed_bytes']), 'bytes_moved_per_launch': moved,
@@ -336,16 +339,36 @@ def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_st
         kernels['table_select'] = (nq * rows * 8.0, per_step['select_ms'])
     else:
         kernels['jc69_distance' if not protein else 'scoredist_distance'] = (dist_bytes, per_step['dist_ms'])
-    dom = max(kernels, key=lambda k: kernels[k][1])
-    n_launch = max(launches_per_step, 1)
+    # (the overlapped part of a phase is not its own: k_blocks_up runs beside the selection's last phase and its time is inside
+    # select_ms too -- it never makes the sweep the dominant kernel by itself)
+    dom = max(kernels, key=lambda k: kernels[k][1] - (per_step.get('blocks_ms', 0.0) if k == 'lsq_sweep' else 0.0))
     achieved = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9 if kernels[dom][1] > 0 else 0.0
     traffic, traffic_commit = load_traffic(workload, dom)
+    # what the numbers of this line can be checked against in profiles/ (rocprofv3 --kernel-trace --stats of this command): the step
+    # is cut into `device_batches` batches of `batch_queries` queries (apples_describe: the workspace's batch; equal batches); the
+    # dominant kernel is launched `kernel_calls_per_step` times per step (the first batch of a host buffer in two pieces) and takes
+    # `dominant_kernel_ms_per_step` in all: the kernel's total time in the trace / the passes traced
+    batch = int(info.get('batch') or 0)
+    n_batches = max(1, -(-nq // batch)) if batch > 0 else 1
     roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_measured_at_commit': traffic_commit,
-                'launches_per_step': n_launch, 'avg_launch_ms': kernels[dom][1] / n_launch,
-                'algorithmic_bytes_per_launch': kernels[dom][0] / n_launch,
+                'traffic_is': 'HBM bytes per launch of the dominant kernel, mean over the launches of the committed counter passes '
+                              '(profiles/pmc_summary.json: separate --pmc runs of this command, FETCH_SIZE corrected as the guide prescribes)',
+                'device_batches': n_batches, 'batch_queries': -(-nq // n_batches),
+                'kernel_calls_per_step': launches_per_step, 'dominant_kernel_ms_per_step': kernels[dom][1],
+                'algorithmic_bytes_per_step': kernels[dom][0],
                 'per_kernel_ms_per_step': per_step,
                 'all_kernels_GBps': {k: (v[0] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for k, v in kernels.items()}}
+    # the sweep against HBM both ways: SURVEY 8d's algorithmic 332 B per swept node, and what the counters saw it move
+    sw_bytes, _ = load_traffic(workload, 'lsq_sweep')
+    sweep_t = kernels['lsq_sweep'][1]
+    if sweep_t > 0:
+        roofline['sweep_hbm'] = {'algorithmic_GBps': kernels['lsq_sweep'][0] / (sweep_t * 1e-3) / 1e9,
+                                 'algorithmic_frac': kernels['lsq_sweep'][0] / (sweep_t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 'counter_bytes_per_device_batch': sw_bytes,
+                                 'counter_GBps': (sw_bytes * n_batches / (sweep_t * 1e-3) / 1e9) if sw_bytes else None,
+                                 'counter_frac': (sw_bytes * n_batches / (sweep_t * 1e-3) / 1e9 / HBM_PEAK_GBS) if sw_bytes else None,
+                                 'note': 'counter figure = HBM bytes of one device batch\'s sweep kernels (committed PMC passes) x device_batches / sweep_ms'}
     if dom == 'lsq_sweep' and per_step.get('blocks_ms', 0.0) > 0:
         roofline['note'] = ('clustered route with clade blocks: time = sweep_ms + blocks_ms (k_blocks_up runs beside the selection); the '
                             'algorithmic figure is SURVEY 8d\'s 332 B per swept node, the block kernels move ~190 B per block-internal node '
@@ -357,11 +380,12 @@ def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_st
         ops = 2.0 * 4.0 * nq * rows * 32.0 * ((L + 31) // 32)
         tops = ops / (kernels[dom][1] * 1e-3) / 1e12
         roofline.update({'bound': 'mfma', 'achieved': tops, 'peak': MFMA_F4_PEAK_TOPS, 'unit': 'TFLOP/s',
-                         'frac': tops / MFMA_F4_PEAK_TOPS, 'algorithmic_ops_per_launch': ops / n_launch,
+                         'frac': tops / MFMA_F4_PEAK_TOPS, 'algorithmic_ops_per_step': ops,
+                         'executed_vs_survey_ops': 'executed fp4 operations = 2 x 4 components x 32-site words: 4.1 x SURVEY 8d\'s 2 L byte-operations per pair '
+                                                   '(three tetrahedron components + validity: the smallest exact bilinear form of the two counts)',
                          'hbm_algorithmic_GBps': achieved,
-                         'launch_note': 'a device batch that comes from a host buffer is two launches (its first quarter, while the rest '
-                                        'is still on the bus, then the rest): avg_launch_ms is the mean over both; the resident pass '
-                                        'launches whole batches, and a kernel trace of this command averages over all of them'})
+                         'launch_note': 'the first device batch of a host buffer is two launches (its first quarter, while the rest is still on the '
+                                        'bus, then the rest); the resident pass launches whole batches'})
     elif dom == 'scoredist_distance' and info.get('scoredist_filter') and filter_ms:
         # the fused scoredist pass = a lower bound of every pair's table sum on the matrix cores (fp4 operands, 20 values per
         # site: dist_sd.hip) + the exact evaluation of the ~1 % of the pairs that survive it; the dominant kernel is the
@@ -371,8 +395,8 @@ def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_st
         ops = 2.0 * nq * pad * steps * 128.0
         tops = ops / (filter_ms * 1e-3) / 1e12
         roofline.update({'bound': 'mfma', 'kernel': 'scoredist_filter_gemm', 'achieved': tops, 'peak': MFMA_F4_PEAK_TOPS, 'unit': 'TFLOP/s',
-                         'frac': tops / MFMA_F4_PEAK_TOPS, 'algorithmic_ops_per_launch': ops / n_launch,
-                         'avg_launch_ms': filter_ms / n_launch, 'hbm_algorithmic_GBps': achieved,
+                         'frac': tops / MFMA_F4_PEAK_TOPS, 'algorithmic_ops_per_step': ops,
+                         'dominant_kernel_ms_per_step': filter_ms, 'hbm_algorithmic_GBps': achieved,
                          'note': 'dist_ms = filter (filter_ms) + exact evaluation of its candidates; the table look-ups the '
                                  'reference makes for every pair (8 B x 20 x L x pairs from LDS: the round-3 bound) are made for the candidates only'})
         roofline['traffic'], roofline['traffic_measured_at_commit'] = load_traffic(workload, 'scoredist_filter_gemm')
@@ -485,7 +509,8 @@ def other_workload(name, device, steps=3, ds=None, queries=0, variant=None, prep
             'per_kernel_ms_per_step': per,
             # (the committed counter passes are of the workload's own size: no traffic figure for another number of queries)
             'roofline': {k: (None if k == 'traffic' and queries else rf[k])
-                         for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'traffic') if k in rf},
+                         for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'dominant_kernel_ms_per_step', 'kernel_calls_per_step',
+                                   'device_batches', 'batch_queries', 'traffic') if k in rf},
             'mean_observed': float(np.mean(out['n_obs'])), 'placed': int((out['n_valid'] > 0).sum()),
             **({'n_reps': int(info['n_reps']), 'cluster_fused': int(info.get('cluster_fused', 0)),
                 'cluster_blocks': int(info.get('cluster_blocks', 0))} if clustered else {}),

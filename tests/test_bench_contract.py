@@ -35,7 +35,8 @@ def test_roofline_of_prices_the_matrix_core_distance_pass_against_the_fp4_peak()
     ops = 2.0 * 4.0 * nq * rows * 1024  # four components per site, sites padded to whole 32-site words
     assert r['kernel'] == 'jc69_distance' and r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 10000.0
     assert abs(r['achieved'] - ops / 27.4e-3 / 1e12) < 1e-6 and abs(r['frac'] - r['achieved'] / 10000.0) < 1e-12
-    assert r['launches_per_step'] == 5 and abs(r['avg_launch_ms'] - 27.4 / 5) < 1e-12
+    assert r['kernel_calls_per_step'] == 5 and abs(r['dominant_kernel_ms_per_step'] - 27.4) < 1e-12 and r['device_batches'] >= 1
+    assert abs(r['sweep_hbm']['algorithmic_GBps'] - 332.0 * 2400 * nq / 15.3e-3 / 1e9) < 1e-3
     # SURVEY 8d's byte figures ride along: N (L + 8) + L per query, 332 V per query
     assert abs(r['hbm_algorithmic_GBps'] - nq * (rows * (L + 8.0) + L) / 27.4e-3 / 1e9) < 1e-3
     assert abs(r['all_kernels_GBps']['lsq_sweep'] - 332.0 * 2400 * nq / 15.3e-3 / 1e9) < 1e-3

@@ -459,10 +459,11 @@ def test_exact_matches_among_the_members_of_one_cluster(no_fuse, monkeypatch):
     assert got.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize('L', [4097, 8190])
+@pytest.mark.parametrize('L', [2047, 2050, 3001, 4000, 4092, 4093, 4097, 8190])
 def test_long_alignments_through_the_fused_matrix_core_pass(L):
     """The fused distance pass packs (valid, mism) into 13-bit fields and counts in f32
-    accumulators over 64-site fp4 blocks: alignments just past 4 096 sites (odd number of blocks,
+    accumulators over 64-site fp4 blocks: alignments on both sides of the GEMM form's two limits (2 046 sites with the validity
+    sum at 2^13, 4 092 at 2^12), just past 4 096 sites (odd number of blocks,
     ragged last word) and just below the 8 192 limit of the packed format, with heavy gaps so that
     the overlap rule and short valid counts occur.  Placements identical to the C oracle's."""
     d = synth.make_dataset(600, L, 300, seed_tree=11, seed_aln=12, seed_query=13)
@@ -478,10 +479,19 @@ def test_long_alignments_through_the_fused_matrix_core_pass(L):
                  threads=len(os.sched_getaffinity(0)))
     want = co.place_sequences(qry)
     eng = Engine(d.tree, ref, nodes, method='OLS', criterion='MLSE')
-    assert eng.describe()['code_planes'] == 2
+    info = eng.describe()
+    assert info['code_planes'] == 2
+    # up to 4 092 sites the pass is the plain fp4 GEMM over the pre-expanded images (2 047 .. 4 092: the validity sum at 2^12 and the
+    # congruence decode of dist_gemm.hip, round 6); longer alignments keep the bit-plane-fed matrix-core kernel
+    assert info['fused_distance_pass'].startswith('fp4 gemm' if L <= 4092 else 'fp4 mfma'), info
     got = eng.place_sequences(qry)
     _compare(got, want, co, d, nodes, 'long alignment L=%d' % L)
     eng.close()
+    if L <= 4092:  # ... and the same bytes from the bit-plane-fed kernel
+        e2 = Engine(d.tree, ref, nodes, method='OLS', criterion='MLSE', debug=('no_dist_gemm',))
+        assert e2.describe()['fused_distance_pass'].startswith('fp4 mfma')
+        assert e2.place_sequences(qry).tobytes() == got.tobytes()
+        e2.close()
 
 
 def test_top_up_list_walked_in_slices(c2_full):

@@ -539,3 +539,27 @@ def test_c3_backbone_in_the_shapes_real_trees_have(shape):
     sample = _sample(gc, nq, extremes=8, strided=56)
     cc = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', lut=jc69_lut(1000, 0.001), threads=NTHREADS)
     assert cc.place_sequences(d.query_seqs[sample]).tobytes() == gc[sample].tobytes()
+
+
+def test_clustered_route_beyond_229376_slots():
+    """The command line's default route on a reference of more than 229 376 rows (k_select_clusters' bitmap over the slots held that
+    many until round 6; 524 288 now: runs of 32 words per thread): 270 000 leaves x L 300, clusters + consensus representatives,
+    clade blocks.  The fused route's bytes against full rows + general selection on 3 000 queries, 64 + sampled ones against the C
+    oracle."""
+    import bench
+    nq = 3000
+    d = synth.make_dataset(270000, 300, nq)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ca = bench.make_clusters(d, 0.2)
+    eng = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS')
+    info = eng.describe()
+    assert info['n_refs'] == 270000 and info['cluster_fused'] == 1 and info['cluster_blocks'] > 1000 and info['sweep_layout'] == 'lean', info
+    got = eng.place_sequences(d.query_seqs)
+    eng.close()
+    e2 = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', debug=('no_fuse',))
+    assert e2.describe()['cluster_fused'] == 0
+    assert e2.place_sequences(d.query_seqs[:1000]).tobytes() == got[:1000].tobytes()
+    e2.close()
+    sample = _sample(got, nq, extremes=8, strided=56)
+    cc = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', lut=jc69_lut(300, 0.001), threads=NTHREADS)
+    assert cc.place_sequences(d.query_seqs[sample]).tobytes() == got[sample].tobytes()
