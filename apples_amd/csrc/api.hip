@@ -885,7 +885,8 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
                     (need_fused ? stride * 12 + stride / 16 : 0);
     if (slim) per_q = stride * 4 + stride / 16 + stride * 2 + members * 12 + (int64_t)(t.height + 2) * 4;
     if (cslim) per_q = stride * 8 + stride + seg_stride * 4 + seg_stride / 16 + members * 12 + (int64_t)(t.height + 2) * 4;
-    // batch buffers: up to 96 GiB, at most 40 % of what is free on the card (288 GB HBM3E; bigger
+    // batch buffers: up to 144 GiB, at most half of what is free on the card (288 GB HBM3E; the clade blocks' pool, sized afterwards
+    // from what is then free -- a third of it, 16 GiB at most -- and the scoredist rows of representatives come on top; bigger
     // batches amortise the sweep's tail: at 200 k leaves 16 k-query batches are 13 % faster than 5 k).
     // Allocating them is not free: with 160 GiB a resident C3 pass is another 4 % faster, but a one-shot
     // command-line run of the same size pays 1.1 to 3.4 s more for the allocation.
@@ -1681,9 +1682,14 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
                     if (hipMemGetInfo(&fr, &tot) == hipSuccess) bytes = std::min<int64_t>(bytes, (int64_t)(fr / 3));
                     if (const char *e = getenv("APPLES_BLK_POOL_MB")) bytes = (int64_t)atoll(e) << 20;
                     bytes = std::max<int64_t>(bytes, 1 << 20);
-                    if (dev_alloc(ctx, &ctx->blk_pool, bytes / 8)) return 1;
-                    ctx->blk_pool_cap = bytes / 8;
+                    // (another context on the device may have taken the memory meanwhile -- two ranks on one GPU size themselves from
+                    // the same hipMemGetInfo: then this context goes without blocks, it does not fail)
+                    if (dev_alloc(ctx, &ctx->blk_pool, bytes / 8)) { ctx->blk_pool = nullptr; ctx->err.clear(); (void)hipGetLastError(); ctx->blk_active = false; }
+                    else ctx->blk_pool_cap = bytes / 8;
                 }
+            }
+            if (ctx->blk_active) {
+                const int64_t n_items = nq * SELECT_CLUSTERS_ACC_CAP + std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps;
                 int32_t *bi = ctx->blk_ints;
                 sa.item_sbase = bi; sa.q_item = bi + n_items; sa.q_items = reinterpret_cast<int2 *>(bi + 2 * n_items);
                 sa.q_blk = bi + 2 * n_items + 2 * w.batch; sa.q_item_cursor = bi + 2 * n_items + 3 * w.batch; sa.blk_ntiles = sa.q_item_cursor + 2;

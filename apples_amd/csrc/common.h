@@ -609,6 +609,10 @@ bool sweep_merge_lists(const DevTree &t);  // big binary trees, wavefront-sized 
 bool sweep_bits_in_lds(const DevTree &t);  // the sweep's node bits fit in LDS (else: tagged node map in global scratch)
 int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int team, hipStream_t stream = nullptr);
 // sweep_lean.hip: the three-pass form for big binary trees (wavefront-sized teams over the size-class queues)
+// An observed "leaf" that is the root of a clade block travels through the observation list as a boxed index into the blocks' pool:
+// a negative quiet NaN with the tag 0b101 under the quiet bit (no arithmetic produces that payload: the default NaN has none) and
+// the index in the low 48 bits (select.hip boxes, sweep_lean.hip:lean_is_block tests the whole 16-bit prefix)
+#define APPLES_BLOCK_BOX 0xFFFD000000000000ull
 #define LEAN_BYTES_PER_NODE 100  // T0 T1 T2 E DD (16 B each), D N (8 B each), K (4 B)
 #define LEAN_BYTES_PER_LEAF 12   // per observed leaf: edge length, parent
 #define LEAN_SMALL_BATCH 13312    // device batches up to this many queries: routing cut halved (api.hip:route_threshold), 512-thread routed teams

@@ -936,7 +936,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
                     f_key[at] = a.e_of_blk[b];
                     f_node[at] = a.blk_root[b];
                     const long long pl = ((long long)(sb >> 6) + 1 + a.blk_rslot[b]) * 384 + (sb & 63);
-                    f_val[at] = __longlong_as_double((long long)0xFFF8000000000000ull | pl);
+                    f_val[at] = __longlong_as_double((long long)APPLES_BLOCK_BOX | pl);
                     extra_c += a.blk_nodes[b];
                 }
                 for (int l = l0; l < l1; ++l, ++at) {  // a member outside every block: Reference.py:150, PoolQueryWorker.py:63-75 one by one
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
                     node = a.blk_root[b];
                     // the "distance" of a block root: where its tuple is (sweep_lean.hip:lean_is_block), a boxed index into the pool
                     const long long at = ((long long)(sb >> 6) + 1 + a.blk_rslot[b]) * 384 + (sb & 63);
-                    dd = __longlong_as_double((long long)0xFFF8000000000000ull | at);
+                    dd = __longlong_as_double((long long)APPLES_BLOCK_BOX | at);
                     blk_extra += a.blk_nodes[b];  // (the nodes below the root, once)
                 } else {
                     es = blk_space ? a.e_of_slot[slot_[e]] : slot_[e];

@@ -30,6 +30,7 @@
 // ranks them after the top-down pass (lean_hybrid_pick).  Arithmetic: sweep_math.h, shared with sweep.hip --
 // same expressions in the same order, so placements are bit-identical to the level loop's.
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "common.h"
@@ -69,6 +70,9 @@ struct LeanDownShared {
     double pow[384 + 256];  // libm pow tables (sweep_math.h)
     double2 stage[APPLES_TPB / WAVE][3][WAVE];  // per wavefront: lifted R tuples on their way to a level of at most 64 nodes
 };
+struct LeanDownSharedPL : LeanDownShared {
+    double pu[APPLES_TPB / WAVE][6][WAVE];  // per wavefront: a polytomy's children's lifted tuples (lean_poly_td)
+};
 
 // per-team scratch: one array per field, `cap1` entries each (cap1 a multiple of 4), then two per observed leaf
 struct LeanTeam {
@@ -84,10 +88,10 @@ struct LeanTeam {
 };
 
 // An observed "leaf" that is the root of a clade block (DevAlign::blk_*, select.hip phase 3): its distance is a boxed index -- a
-// negative quiet NaN whose low bits say where the block's tuple is in the pool (component x at index + 64 x): S after k_blocks_up;
+// negative quiet NaN with a tag (common.h: APPLES_BLOCK_BOX) whose low 48 bits say where the block's tuple is in the pool (component x at index + 64 x): S after k_blocks_up;
 // the top-down pass leaves lift(R) over the root's edge there, which k_blocks_down takes on into the block.
-__device__ __forceinline__ bool lean_is_block(double dist) { return ((unsigned)__double2hiint(dist) & 0xfff80000u) == 0xfff80000u; }
-__device__ __forceinline__ long long lean_block_at(double dist) { return __double_as_longlong(dist) & 0x0007ffffffffffffLL; }
+__device__ __forceinline__ bool lean_is_block(double dist) { return ((unsigned)__double2hiint(dist) & 0xffff0000u) == (unsigned)(APPLES_BLOCK_BOX >> 32); }
+__device__ __forceinline__ long long lean_block_at(double dist) { return __double_as_longlong(dist) & 0x0000ffffffffffffLL; }
 
 // ---- polytomies (template parameter PL; a binary tree's kernels carry none of this) ---------------------------------------
 // A node with more than two valid children in a query's subtree (apples/OLS.py:36,59 loop over any number of children; a
@@ -177,14 +181,96 @@ struct LeanRun {
     bool extra, xfirst;
 };
 
+// The two polytomy passes are real calls, and their call sites hand them COPIES of what they take by reference (the team's
+// pointers, the running best) and park the lane state that must survive in LDS: inlined, their registers (a node's children
+// in flight together) came on top of the level loops' own and the hot paths of a tree without a single polytomy spilled --
+// forced onto config 3's binary tree the PL kernels took 20.9 ms where the plain ones take 15.3 (profiles/r06_poly_exp.txt).
+#ifndef LEAN_POLY_INLINE
+#define LEAN_POLY_INLINE __noinline__
+#endif
+template <int M, bool PL>
+__device__ __forceinline__ void kid_tuple(int kd, double dist, const LeanTeam &t, const double2 (*stage)[WAVE], bool staged,
+                                          int stage_base, double *S);
+
+// Polytomies whose whole run of sibling keys lies inside ONE merge step (nearly all of them: a run is cut only where a level of
+// more than 64 keys happens to break inside it) are finished right there (PL).  The m lanes of the run hold the node's children:
+// each loads its child's S tuple (final: the level below is complete), writes the child's record -- position -1 - j, which the
+// later pass over the records takes for "done" --, lifts the tuple; the node's tuple is their sum in file order, handed from lane
+// to lane (m - 1 rounds of shuffles; BME: every share times 1 / m, apples/BME.py:19-20), and the run's last lane stores it in the
+// node's tuple slot, where the next level step picks it up instead of forming a tuple from the entry's first two children.  The
+// run's first lane marks the entry (D = (first record, LEAN_POLY_SELF | m)).  fm: the step's first keys, third: the first keys of
+// runs with a third key in the step (lean_run_masks), ebase: the entry of the step's first run head.
+// Returns the records written; pm = the lanes served; head = this lane begins such a run (x0 / m: its first record, its children).
+#ifndef LEAN_POLY_FAST_INLINE
+#define LEAN_POLY_FAST_INLINE __forceinline__
+#endif
+template <int M>
+__device__ LEAN_POLY_FAST_INLINE int lean_poly_fast(const LeanTeam &t, int xtop, int xc, unsigned long long fm, unsigned long long third, int tot,
+                                              bool last_step, int ebase, int desc, int key, double e, double dist,
+                                              const double2 (*stage)[WAVE], bool staged, int stage_base, int lane,
+                                              unsigned long long extra, unsigned long long xfirst,
+                                              unsigned long long &pm, bool &head, int &x0, int &m) {
+    constexpr bool BME = (M == APPLES_BME);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long hb = fm & (below | (1ull << lane));  // run heads at or below this lane
+    bool in = false;
+    int hl = 0, end = 0;
+    if (lane < tot && hb != 0ull) {
+        hl = 63 - __clzll((long long)hb);
+        const unsigned long long above = hl == 63 ? 0ull : (fm & ~((2ull << hl) - 1ull));
+        end = above != 0ull ? __ffsll((long long)above) - 1 : tot;
+        // (a run that reaches the end of a step that is not the level's last may go on in the next one: the records' pass serves it)
+        in = ((third >> hl) & 1ull) != 0ull && (end < tot || last_step);
+    }
+#ifdef LEAN_EXP_NO_FAST
+    in = false;  // (experiment: every polytomy through the records' pass)
+#endif
+    pm = __ballot(in);
+    head = false; x0 = 0; m = 0;
+    if (pm == 0ull) return 0;
+    const int pos = lane - hl;
+    m = end - hl;
+    // (records go out in lane order, these and the ones of lean_poly_records together: a run that a step's end cut keeps its
+    // records in one piece -- its lanes of the next step come first there)
+    const unsigned long long s3 = xfirst & ~pm, s1 = extra & ~xfirst & ~pm;
+    const int x = xc + __popcll(pm & below) + 3 * __popcll(s3 & below) + __popcll(s1 & below);
+    x0 = x - pos;
+    head = in && pos == 0;
+    const int en = ebase + __popcll(hb) - 1;
+    double S[6], u[6], acc[6];
+    kid_tuple<M, true>(in ? desc : 0, dist, t, stage, staged, stage_base, S);
+    if (in) {
+        const int s = xtop - x;
+        t.D[s] = make_int2(desc, -1 - pos);
+        t.N[s] = make_int2(key, en);
+        t.E[s] = make_double2(e, dist);
+        t.T0[s] = make_double2(S[0], S[1]); t.T1[s] = make_double2(S[2], S[3]); t.T2[s] = make_double2(S[4], S[5]);
+    }
+    const double coef = BME ? 1.0 / (double)(m > 0 ? m : 1) : 1.0;
+    lift<M>(S, e, u);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { u[c] = BME ? coef * u[c] : u[c]; acc[c] = 0.0 + u[c]; }  // (the reference starts every sum at 0)
+    for (int k = 1; __ballot(in && pos >= k) != 0ull; ++k) {  // lane of position k: the sum so far (from the lane before) + its own share
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double pv = __hiloint2double(__shfl_up(__double2hiint(acc[c]), 1, WAVE), __shfl_up(__double2loint(acc[c]), 1, WAVE));
+            if (in && pos == k) acc[c] = pv + u[c];
+        }
+    }
+    if (in && pos == m - 1) {
+        t.T0[en] = make_double2(acc[0], acc[1]); t.T1[en] = make_double2(acc[2], acc[3]); t.T2[en] = make_double2(acc[4], acc[5]);
+    }
+    return __popcll(pm);
+}
+
 // the child records of this step's third-and-later siblings (PL): `en` = the entry of the lane's run, `xc` = records so far;
 // returns how many records the step added (three for a run's third key: the first two children's records are filled in by lean_poly_S)
 __device__ __forceinline__ int lean_poly_records(const LeanTeam &t, int xtop, int xc, const LeanRun &run, int en, int par, int desc,
-                                                 int key, double e, double dist, int lane) {
+                                                 int key, double e, double dist, int lane, unsigned long long pm = 0ull) {
     const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned long long m3 = __ballot(run.xfirst), m1 = __ballot(run.extra && !run.xfirst);
     if (run.extra) {
-        const int x0 = xc + 3 * __popcll(m3 & below) + __popcll(m1 & below);
+        const int x0 = xc + 3 * __popcll(m3 & below) + __popcll(m1 & below) + __popcll(pm & below);  // (pm: lean_poly_fast's lanes, same order)
         const int x = run.xfirst ? x0 + 2 : x0;
         t.D[xtop - x] = make_int2(desc, run.xfirst ? 2 : 3);
         t.N[xtop - x] = make_int2(key, en);
@@ -209,10 +295,11 @@ __device__ __forceinline__ int lean_poly_records(const LeanTeam &t, int xtop, in
 // requested before this step's gather is waited for: one memory round trip per 64 keys, not two.
 // PL: runs of any length; the third and later keys of a run become child records (above), `xc` counts them.
 // Returns the number of entries written from next_base on.
-template <bool PL>
+// (`xs`: the records left to lean_poly_S, i.e. of runs that a step's end cut)
+template <int M, bool PL>
 __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, const int32_t *__restrict__ o_node,
                                           const double *__restrict__ o_dist, int lo, int nB, int next_base,
-                                          const int4 *__restrict__ pe, int *mk_a, int *mk_b, int lane, int xtop, int &xc) {
+                                          const int4 *__restrict__ pe, int *mk_a, int *mk_b, int lane, int xtop, int &xc, int &xs) {
     int out = 0, ia = 0, ib = 0, carry = -2, ccnt = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
     int wk_a = lane < nA ? t.K[base + lane] : 0x7fffffff, wk_b = lane < nB ? o_node[lo + lane] : 0x7fffffff;
@@ -261,16 +348,32 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
         LeanRun run = {false, false};
         bool third = false;  // (PL) the run this lane begins has a third key inside this step
         LeanRunMasks rm = {0, 0, 0};
+        bool fhead = false;  // (PL) ... and lies inside the step altogether: finished here (lean_poly_fast)
+        int fx0 = 0, fm_ = 0, nfast = 0;
+        unsigned long long pmf = 0ull;
         if (PL) {
             rm = lean_run_masks(fm, tot, ccnt);
+            third = (rm.third >> lane) & 1ull;
+            if (rm.third != 0ull) {  // (never on a binary tree)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the level below's tuples: this wavefront's own stores)
+                {   // (copies: the call takes references, and what the hot path reads stays in registers)
+                    const LeanTeam tc = t;
+                    unsigned long long pm_ = 0ull;
+                    bool h_ = false;
+                    int a_ = 0, b_ = 0;
+                    nfast = lean_poly_fast<M>(tc, xtop, xc, fm, rm.third, tot, nia >= nA && nib >= nB, next_base + out, desc, key, e, dist,
+                                              nullptr, false, 0, lane, rm.extra, rm.xfirst, pm_, h_, a_, b_);
+                    pmf = pm_; fhead = h_; fx0 = a_; fm_ = b_;
+                }
+                rm.extra &= ~pmf; rm.xfirst &= ~pmf;
+            }
             run.extra = (rm.extra >> lane) & 1ull;
             run.xfirst = (rm.xfirst >> lane) & 1ull;
-            third = (rm.third >> lane) & 1ull;
         }
         if (first) {
             const int at = next_base + out + __popcll(fm & below);
             t.K[at] = (PL && third) ? (par | LEAN_POLY_KID) : par;
-            t.D[at] = make_int2(desc, two ? next_desc : 0);
+            t.D[at] = (PL && fhead) ? make_int2(fx0, LEAN_POLY_SELF | fm_) : make_int2(desc, two ? next_desc : 0);
             t.N[at] = make_int2(key, two ? next_key : -1);
             t.E[at] = make_double2(e, two ? next_e : 0.0);
             t.DD[at] = make_double2(dist, two ? next_dist : 0.0);
@@ -285,8 +388,10 @@ __device__ __forceinline__ int lean_merge(const LeanTeam &t, int base, int nA, c
             if (rm.extra != 0ull) {  // (never on a binary tree)
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the mark on K follows the entry's own store)
                 const int en = next_base + out + __popcll(fm & (below | (1ull << lane))) - 1;
-                xc += lean_poly_records(t, xtop, xc, run, en, par, desc, key, e, dist, lane);
+                const int added = lean_poly_records(t, xtop, xc, run, en, par, desc, key, e, dist, lane, pmf);
+                xc += added; xs += added;
             }
+            xc += nfast;
             // how many keys of the last run this step saw (capped at 3), for the lanes 0..2 of the next step
             const int lastfirst = fm ? 63 - __clzll(fm) : -1;
             ccnt = lastfirst >= 0 ? min(tot - lastfirst, 3) : min(ccnt + tot, 3);
@@ -362,11 +467,13 @@ __device__ __forceinline__ void lean_S_chunks(const LeanTeam &t, int lo, int hi,
         int2 d2 = make_int2(0, 0);
         double2 e2 = make_double2(0, 0), dd2 = make_double2(0, 0);
         if (nidx < hi) { d2 = t.D[nidx]; e2 = t.E[nidx]; dd2 = t.DD[nidx]; }
-        double r[6];
-        node_S<M, PL>(d, e, dd, t, stage, staged, kid_base, r);
-        t.T0[idx] = make_double2(r[0], r[1]);
-        t.T1[idx] = make_double2(r[2], r[3]);
-        t.T2[idx] = make_double2(r[4], r[5]);
+        if (!(PL && lean_is_poly_entry(d))) {  // (a marked polytomy: lean_poly_fast left its tuple in the slot)
+            double r[6];
+            node_S<M, PL>(d, e, dd, t, stage, staged, kid_base, r);
+            t.T0[idx] = make_double2(r[0], r[1]);
+            t.T1[idx] = make_double2(r[2], r[3]);
+            t.T2[idx] = make_double2(r[4], r[5]);
+        }
         idx = nidx; d = d2; e = e2; dd = dd2;
     }
 }
@@ -454,15 +561,20 @@ __device__ __forceinline__ void lean_own_plift(const LeanTeam &t, int idx, const
     plift[0] = p0.x; plift[1] = p0.y; plift[2] = p1.x; plift[3] = p1.y; plift[4] = p2.x; plift[5] = p2.y;
 }
 
+template <int M, bool HY>
+__device__ __forceinline__ void lean_poly_td(const LeanTeam &t, int xtop, unsigned long long pmask, int my_en, int my_x, int my_m, int VI,
+                                             int negative, int criterion, const double *lds_pow, double2 (*hand)[WAVE], int hand_base,
+                                             double (*pu)[WAVE], LeanBest &best, int lane);
+
 // Top-down step of one internal node, both children in turn (the two swap roles in between): a rolled loop keeps one
 // 2x2 solve's worth of temporaries live, which is what decides how many wavefronts a SIMD holds.
 template <int M, bool HY = false, bool PL = false>
 __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, const int2 d, const int2 nd, const double2 e, const double2 dd,
                                              bool is_lca, int negative, int criterion,
                                              const double *lds_pow, const double2 (*hand_in)[WAVE], int in_pos,
-                                             double2 (*hand_out)[WAVE], int out_base, LeanBest &best) {
+                                             double2 (*hand_out)[WAVE], int out_base, LeanBest &best, int &p_x, int &p_m) {
     constexpr bool BME = (M == APPLES_BME);
-    if (PL && lean_is_poly_entry(d)) return;  // (lean_poly_td serves it)
+    if (PL && lean_is_poly_entry(d)) { p_x = d.x; p_m = d.y & LEAN_DESC_MASK; return; }  // (lean_poly_td serves it: its first record, its children)
     const int nk = d.y != 0 ? 2 : 1;
     // apples/BME.py:36-37: 1 / (nonroot + #valid siblings)
     const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + nk - 1) : 1.0;
@@ -492,26 +604,43 @@ __device__ __forceinline__ void lean_td_node(const LeanTeam &t, int idx, const i
 template <int M, bool AHEAD, bool HY = false, bool PL = false>
 __device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi, int first, int stride, int VI, int negative,
                                                int criterion, const double *lds_pow, const double2 (*hand_in)[WAVE],
-                                               double2 (*hand_out)[WAVE], int out_base, LeanBest &best) {
+                                               double2 (*hand_out)[WAVE], int out_base, LeanBest &best, int xtop = 0,
+                                               double (*pu)[WAVE] = nullptr) {
     int idx = lo + first;
     int2 d = make_int2(0, 0), nd = make_int2(0, 0);
     double2 e = make_double2(0, 0), dd = make_double2(0, 0);
     if (!AHEAD) {
-        for (; idx < hi; idx += stride) {
-            lean_td_node<M, HY, PL>(t, idx, t.D[idx], t.N[idx], t.E[idx], t.DD[idx], idx == VI, negative, criterion, lds_pow, hand_in, idx - lo,
-                                    hand_out, out_base, best);
+        // (the loop runs to the wavefront's common end: a lane beyond the level idles through the polytomies' call, which is the wavefront's)
+        const int rounds = (hi - lo + stride - 1) / stride;
+        for (int k = 0; k < rounds; ++k, idx += stride) {
+            int p_x = 0, p_m = 0;
+            if (idx < hi)
+                lean_td_node<M, HY, PL>(t, idx, t.D[idx], t.N[idx], t.E[idx], t.DD[idx], idx == VI, negative, criterion, lds_pow, hand_in, idx - lo,
+                                        hand_out, out_base, best, p_x, p_m);
             __builtin_amdgcn_wave_barrier();
+            if (PL) {
+                const unsigned long long pmask = __ballot(p_m > 0);
+                if (pmask != 0ull) lean_poly_td<M, HY>(t, xtop, pmask, idx, p_x, p_m, VI, negative, criterion, lds_pow, hand_out, out_base, pu, best, first & (WAVE - 1));
+            }
         }
         return;
     }
     if (idx < hi) { d = t.D[idx]; nd = t.N[idx]; e = t.E[idx]; dd = t.DD[idx]; }
-    while (idx < hi) {
+    // (PL: the wavefront stays together to its last lane's last entry -- a polytomy's step is the whole wavefront's)
+    while (PL ? __ballot(idx < hi) != 0ull : idx < hi) {
+        const bool on = idx < hi;
         const int nidx = idx + stride;
         int2 d2 = make_int2(0, 0), nd2 = make_int2(0, 0);
         double2 e2 = make_double2(0, 0), dd2 = make_double2(0, 0);
         if (nidx < hi) { d2 = t.D[nidx]; nd2 = t.N[nidx]; e2 = t.E[nidx]; dd2 = t.DD[nidx]; }
-        lean_td_node<M, HY, PL>(t, idx, d, nd, e, dd, idx == VI, negative, criterion, lds_pow, hand_in, idx - lo, hand_out, out_base, best);
+        int p_x = 0, p_m = 0;
+        if (!PL || on)
+            lean_td_node<M, HY, PL>(t, idx, d, nd, e, dd, idx == VI, negative, criterion, lds_pow, hand_in, idx - lo, hand_out, out_base, best, p_x, p_m);
         __builtin_amdgcn_wave_barrier();
+        if (PL) {  // (a workgroup-sized team: every wavefront serves its own lanes' polytomies, no barrier inside)
+            const unsigned long long pmask = __ballot(p_m > 0);
+            if (pmask != 0ull) lean_poly_td<M, HY>(t, xtop, pmask, idx, p_x, p_m, VI, negative, criterion, lds_pow, hand_out, out_base, pu, best, first & (WAVE - 1));
+        }
         idx = nidx; d = d2; nd = nd2; e = e2; dd = dd2;
     }
 }
@@ -521,7 +650,7 @@ __device__ __forceinline__ void lean_td_chunks(const LeanTeam &t, int lo, int hi
 template <int M, bool HY = false, bool PL = false>
 __device__ __forceinline__ void lean_td_pairs(const LeanTeam &t, int g0, int ng, int VI, int lane, int negative, int criterion,
                                               const double *lds_pow, const double2 (*hand_in)[WAVE], double2 (*hand_out)[WAVE],
-                                              int out_base, LeanBest &best) {
+                                              int out_base, LeanBest &best, int xtop = 0, double (*pu)[WAVE] = nullptr) {
     constexpr bool BME = (M == APPLES_BME);
     const int i = lane & 31, z = lane >> 5;
     const int idx = g0 + i;
@@ -543,6 +672,11 @@ __device__ __forceinline__ void lean_td_pairs(const LeanTeam &t, int g0, int ng,
     if (mine)
         lean_td_kid<M, HY, PL>(t, Sk, Ss, plift, z ? e.y : e.x, z ? e.x : e.y, z ? d.y : d.x, z ? nd.y : nd.x, nk, is_lca, coef, negative,
                                criterion, lds_pow, hand_out, out_base, best, z ? dd.y : dd.x, idx, z);
+    if (PL) {  // this level's polytomies (lanes 0-31 own the entries)
+        const bool pol = act && z == 0 && lean_is_poly_entry(d);
+        const unsigned long long pmask = __ballot(pol);
+        if (pmask != 0ull) lean_poly_td<M, HY>(t, xtop, pmask, idx, d.x, d.y & LEAN_DESC_MASK, VI, negative, criterion, lds_pow, hand_out, out_base, pu, best, lane);
+    }
 }
 
 // Polytomies, bottom-up (PL): the S tuples of the nodes whose child records lie in [xlo, xhi) -- the records a level's merge
@@ -553,13 +687,6 @@ __device__ __forceinline__ void lean_td_pairs(const LeanTeam &t, int g0, int ng,
 // tuples come from the arrays (every level's are stored there as well as staged).
 #ifndef LEAN_EXP_NO_FIX
 #define LEAN_EXP_NO_FIX 0
-#endif
-// The two polytomy passes are real calls, and their call sites hand them COPIES of what they take by reference (the team's
-// pointers, the running best) and park the lane state that must survive in LDS: inlined, their registers (a node's children
-// in flight together) came on top of the level loops' own and the hot paths of a tree without a single polytomy spilled --
-// forced onto config 3's binary tree the PL kernels took 20.9 ms where the plain ones take 15.3 (profiles/r06_poly_exp.txt).
-#ifndef LEAN_POLY_INLINE
-#define LEAN_POLY_INLINE __noinline__
 #endif
 #define LEAN_POLY_REG 4  // children a polytomy's lane keeps in registers (all their loads in flight together); more: one by one
 template <int M>
@@ -667,79 +794,69 @@ __device__ __forceinline__ void lean_poly_edge(const LeanTeam &t, int s, const d
     }
 }
 
+// The polytomies of a top-down step, one after the other, each by the whole wavefront: lane j takes child j (its record: the copy
+// of its S tuple, its edge, descriptor, node id), lifts the tuple (coefficient applied) and leaves it in LDS (`pu`, [6][64]); then
+// its R = every OTHER child's share in file order + the node's own lifted R, the 2x2 solve and the residual (lean_poly_edge), the
+// lane's running best as in the binary steps.  pmask: the lanes whose entry of this step is a marked polytomy (my_en / my_x /
+// my_m: the entry, its first record, its children).  More than 64 children: in rounds of 64, the others' shares from the records
+// each time.  Inline: its registers are those of a binary step (one child, one solve per lane).
 template <int M, bool HY>
-__device__ LEAN_POLY_INLINE void lean_poly_td(const LeanTeam &t, int xtop, int xlo, int xhi, int first, int stride, int VI, int negative,
-                                          int criterion, const double *lds_pow, double2 (*hand)[WAVE], int hand_base, LeanBest &best) {
+__device__ __forceinline__ void lean_poly_td(const LeanTeam &t, int xtop, unsigned long long pmask, int my_en, int my_x, int my_m, int VI,
+                                             int negative, int criterion, const double *lds_pow, double2 (*hand)[WAVE], int hand_base,
+                                             double (*pu)[WAVE], LeanBest &best, int lane) {
     constexpr bool BME = (M == APPLES_BME);
-#pragma unroll 1
-    for (int x = xlo + first; x < xhi; x += stride) {
-        const int p0 = t.D[xtop - x].y, en = t.N[xtop - x].y;
-        if (p0 != 0) continue;
-        const int m = t.D[en].y & LEAN_DESC_MASK;
+    while (pmask != 0ull) {  // (wave-uniform)
+        const int src = __ffsll((long long)pmask) - 1;
+        pmask &= pmask - 1ull;
+        const int en = __shfl(my_en, src, WAVE), x = __shfl(my_x, src, WAVE), m = __shfl(my_m, src, WAVE);
         const bool is_lca = en == VI;
-        double plift[6];
-        lean_own_plift(t, en, nullptr, 0, plift);  // (the LCA has none: not used)
         const double coef = BME ? 1.0 / (double)((is_lca ? 0 : 1) + m - 1) : 1.0;
-        if (m <= LEAN_POLY_REG) {
-            double S[LEAN_POLY_REG][6], U[LEAN_POLY_REG][6];
-            double2 ed[LEAN_POLY_REG];
-            int kd[LEAN_POLY_REG], kn[LEAN_POLY_REG];
-#pragma unroll
-            for (int j = 0; j < LEAN_POLY_REG; ++j) {  // (every record's loads in flight together; beyond m: the last one again, not used)
-                const int s = xtop - x - min(j, m - 1);
-                const double2 a = t.T0[s], b = t.T1[s], c = t.T2[s];
-                S[j][0] = a.x; S[j][1] = a.y; S[j][2] = b.x; S[j][3] = b.y; S[j][4] = c.x; S[j][5] = c.y;
-                ed[j] = t.E[s]; kd[j] = t.D[s].x; kn[j] = t.N[s].x;
-            }
-#pragma unroll
-            for (int j = 0; j < LEAN_POLY_REG; ++j) {
-                double u[6];
-                lift<M>(S[j], ed[j].x, u);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) U[j][k] = BME ? coef * u[k] : u[k];
-            }
-#pragma unroll
-            for (int i = 0; i < LEAN_POLY_REG; ++i) {
-                if (i < m) {
-                    double acc[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int j = 0; j < LEAN_POLY_REG; ++j)
-                        if (j != i && j < m) {
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) acc[k] += U[j][k];
-                        }
-                    if (!is_lca) {
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) acc[k] += BME ? coef * plift[k] : plift[k];
-                    }
-                    lean_poly_edge<M, HY>(t, xtop - x - i, S[i], acc, ed[i].x, ed[i].y, kd[i], kn[i], negative, criterion, lds_pow, hand, hand_base, best);
-                }
-            }
-            continue;
-        }
+        double plift[6];
+        lean_own_plift(t, en, nullptr, 0, plift);  // (every lane the same address; the LCA has none: not used)
 #pragma unroll 1
-        for (int i = 0; i < m; ++i) {
+        for (int c0 = 0; c0 < m; c0 += WAVE) {
+            const int j = c0 + lane;
+            const bool act = j < m;
+            const int s = xtop - x - (act ? j : 0);
+            const double2 a0 = t.T0[s], a1 = t.T1[s], a2 = t.T2[s];
+            const double Sk[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+            const double2 ed = t.E[s];
+            const int kd = t.D[s].x, kn = t.N[s].x;
             double acc[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-            for (int j = 0; j < m; ++j) {
-                if (j == i) continue;
-                const int s = xtop - x - j;
-                const double2 a = t.T0[s], b = t.T1[s], c = t.T2[s];
-                const double Sj[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+            if (m <= WAVE) {
                 double u[6];
-                lift<M>(Sj, t.E[s].x, u);
+                lift<M>(Sk, ed.x, u);
+                __builtin_amdgcn_wave_barrier();  // (the shares of the polytomy before: read)
+                if (act) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) acc[k] += BME ? coef * u[k] : u[k];
+                    for (int k = 0; k < 6; ++k) pu[k][lane] = BME ? coef * u[k] : u[k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                for (int jj = 0; jj < m; ++jj) {  // (uniform bound; the lane skips its own child)
+                    if (jj != j) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) acc[k] += pu[k][jj];
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int jj = 0; jj < m; ++jj) {
+                    const int s2 = xtop - x - jj;
+                    const double2 b0 = t.T0[s2], b1 = t.T1[s2], b2 = t.T2[s2];
+                    const double Sj[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+                    double u[6];
+                    lift<M>(Sj, t.E[s2].x, u);
+                    if (jj != j) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) acc[k] += BME ? coef * u[k] : u[k];
+                    }
+                }
             }
             if (!is_lca) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) acc[k] += BME ? coef * plift[k] : plift[k];
             }
-            const int s = xtop - x - i;
-            const double2 a = t.T0[s], b = t.T1[s], c = t.T2[s];
-            const double Sk[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
-            const double2 ed = t.E[s];
-            lean_poly_edge<M, HY>(t, s, Sk, acc, ed.x, ed.y, t.D[s].x, t.N[s].x, negative, criterion, lds_pow, hand, hand_base, best);
+            if (act) lean_poly_edge<M, HY>(t, s, Sk, acc, ed.x, ed.y, kd, kn, negative, criterion, lds_pow, hand, hand_base, best);
         }
     }
 }
@@ -902,13 +1019,12 @@ __device__ __forceinline__ int lean_query_cap(int n) { return (3 * n + 128 + min
 // [xoff[g], xoff[g + 1]) with xoff = the second half of the query's group offsets.
 template <int M, bool HY = false, bool PL = false>
 __device__ __forceinline__ void lean_down_one(const SweepArgs &a, const double *lds_pow, double2 (*stage)[WAVE], int64_t q, int n,
-                                              int64_t off, int G, int VI, int lane, int xn = 0) {
+                                              int64_t off, int G, int VI, int lane, int xn = 0, double (*pu)[WAVE] = nullptr) {
     const DevTree &T = a.tree;
     const int V = VI + n;  // Subtree.num_nodes
     LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, off, nullptr, 0, 0);
     t.BP = a.blk_pool;
     const int32_t *grp_off = a.grp_off + q * (int64_t)a.grp_stride;
-    const int32_t *xoff = grp_off + (T.height + 4);
     const int xtop = lean_query_cap(n) - 1;
     LeanBest best;
     lean_best_init(best);
@@ -919,20 +1035,10 @@ __device__ __forceinline__ void lean_down_one(const SweepArgs &a, const double *
         const bool hand_out = g0 - k0 <= WAVE;  // the children's level has at most 64 nodes: their tuples go through LDS
         if (ng <= 32) {
             lean_td_pairs<M, HY, PL>(t, g0, ng, VI, lane, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
-                                     hand_out ? stage : nullptr, k0, best);
+                                     hand_out ? stage : nullptr, k0, best, xtop, pu);
         } else {
             lean_td_chunks<M, false, HY, PL>(t, g0, g1, lane, WAVE, VI, a.negative, a.criterion, lds_pow, hand_in ? stage : nullptr,
-                                             hand_out ? stage : nullptr, k0, best);
-        }
-        if (PL && xn > 0) {
-            const int x0 = xoff[g], x1 = xoff[g + 1];
-            if (x1 > x0) {  // this level's polytomies (the binary step has read its hand-over: the stage is free to take theirs)
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                const LeanTeam tc = t;
-                LeanBest b2 = best;  // (a copy: the call takes a reference, and `best` itself stays in registers)
-                lean_poly_td<M, HY>(tc, xtop, x0, x1, lane, WAVE, VI, a.negative, a.criterion, lds_pow, hand_out ? stage : nullptr, k0, b2);
-                best = b2;
-            }
+                                             hand_out ? stage : nullptr, k0, best, xtop, pu);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         hand_in = hand_out;
@@ -1042,7 +1148,8 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
         int lo = L.cg[lvl + 1 - wlo], hi = L.cg[lvl - wlo];  // observed leaves of this level: obs[lo, hi)
         int n_leaf = hi - lo;
         const int xtop = qcap - 1;  // (PL) child records: entry slots from the top of the query's range down
-        int xc = 0, xg = 0;         // ... how many there are, and how many there were before the current list's
+        int xc = 0, xg = 0, xsl = 0;  // ... how many there are, how many there were before the current list's, and how many of the
+                                      // current list's are left to lean_poly_S (runs that a merge step's end cut)
         int lw_node = 0, lw_par = 0;
         double lw_e = 0, lw_dist = 0;
         if (n_leaf <= WAVE && lane < n_leaf) { lw_node = o_node[lo + lane]; lw_par = t.LP[lo + lane]; lw_e = t.LE[lo + lane]; lw_dist = o_dist[lo + lane]; }
@@ -1055,11 +1162,22 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
             // ---- S tuples of this level's internal nodes
             if (n_par > 0 && n_par <= WAVE) {
                 double r[6];
+                // (PL) a polytomy's tuple is in its slot already (lean_poly_fast; one that a step's end cut: lean_poly_S below) -- its lane
+                // forms nothing from the entry (marked: no descriptors there) and picks the tuple up
+                const bool ispoly = PL && lane < n_par && (cK & LEAN_POLY_KID) != 0;
                 if (lane < n_par) {
-                    node_S<M, PL>(cD, cE, cDD, t, stage, prev_staged, kid_base, r);
-                    t.T0[base + lane] = make_double2(r[0], r[1]);
-                    t.T1[base + lane] = make_double2(r[2], r[3]);
-                    t.T2[base + lane] = make_double2(r[4], r[5]);
+                    node_S<M, PL>(ispoly ? make_int2(0, 0) : cD, cE, cDD, t, stage, prev_staged, kid_base, r);
+                    if (!ispoly) {
+                        t.T0[base + lane] = make_double2(r[0], r[1]);
+                        t.T1[base + lane] = make_double2(r[2], r[3]);
+                        t.T2[base + lane] = make_double2(r[4], r[5]);
+                    }
+                }
+                if (PL && __ballot(ispoly) != 0ull) {  // (never on a binary tree)
+                    if (ispoly) {
+                        const double2 a0 = t.T0[base + lane], a1 = t.T1[base + lane], a2 = t.T2[base + lane];
+                        r[0] = a0.x; r[1] = a0.y; r[2] = a1.x; r[3] = a1.y; r[4] = a2.x; r[5] = a2.y;
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();  // (every lane's reads of the stage precede these stores)
                 if (lane < n_par) {
@@ -1070,7 +1188,7 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
             } else if (n_par > WAVE) {
                 lean_S_chunks<M, PL>(t, base, next_base, lane, WAVE, stage, prev_staged, kid_base);
             }
-            if (PL && xc > xg && !LEAN_EXP_NO_FIX) {  // this list's polytomies: their tuples over all their children (never on a binary tree)
+            if (PL && xsl > 0 && !LEAN_EXP_NO_FIX) {  // this list's polytomies that a merge step's end cut: their tuples over all their children
                 // (the lane state the next steps need waits in the merge windows, which are free here: nothing but scalars lives
                 // across the call)
                 L.ka[lane] = cK; L.pa[lane] = pf_par; L.ea[lane] = pf_e;
@@ -1083,7 +1201,7 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
                 lw_node = L.kb[lane]; lw_par = L.pb[lane]; lw_e = L.eb[lane]; lw_dist = L.db[lane];
                 __builtin_amdgcn_wave_barrier();
             }
-            xg = xc;
+            xg = xc; xsl = 0;
             // ---- the next level's list
             int merged;
             if (n_par <= WAVE && n_par + n_leaf <= WAVE) {
@@ -1117,31 +1235,34 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
                 const bool two = lane + 1 < tot && !next_first;
                 const unsigned long long fm = __ballot(first);
                 merged = __popcll(fm);
-                LeanRun run = {false, false};
                 int kflag = 0;  // (PL) the run this lane begins has a third key: the node is a polytomy
-                LeanRunMasks rm = {0, 0, 0};
+                bool fhead = false;
+                int fx0 = 0, fm_ = 0;
                 if (PL) {
-                    rm = lean_run_masks(fm, tot, 0);
-                    run.extra = (rm.extra >> lane) & 1ull;
-                    run.xfirst = (rm.xfirst >> lane) & 1ull;
+                    const LeanRunMasks rm = lean_run_masks(fm, tot, 0);
                     kflag = ((rm.third >> lane) & 1ull) ? LEAN_POLY_KID : 0;
+                    if (rm.third != 0ull) {  // (never on a binary tree) every run lies inside this one step: finished here
+                        const LeanTeam tc = t;
+                        unsigned long long pm_ = 0ull;
+                        bool h_ = false;
+                        int a_ = 0, b_ = 0;
+                        xc += lean_poly_fast<M>(tc, xtop, xc, fm, rm.third, tot, true, next_base, desc, key, e, dist, stage, n_par > 0, base, lane,
+                                                0ull, 0ull, pm_, h_, a_, b_);
+                        fhead = h_; fx0 = a_; fm_ = b_;
+                    }
                 }
                 if (first) {
                     const int c = __popcll(fm & below);
-                    const int2 eD = make_int2(desc, two ? next_desc : 0), eN = make_int2(key, two ? next_key : -1);
+                    const int2 eD = (PL && fhead) ? make_int2(fx0, LEAN_POLY_SELF | fm_) : make_int2(desc, two ? next_desc : 0);
+                    const int2 eN = make_int2(key, two ? next_key : -1);
                     const double2 eE = make_double2(e, two ? next_e : 0.0), eDD = make_double2(dist, two ? next_dist : 0.0);
                     L.oK[c] = par | kflag; L.oD[c] = eD; L.oN[c] = eN; L.oE[c] = eE; L.oDD[c] = eDD;
                     t.K[next_base + c] = par | kflag; t.D[next_base + c] = eD; t.N[next_base + c] = eN; t.E[next_base + c] = eE; t.DD[next_base + c] = eDD;
                 }
-                if (PL && rm.extra != 0ull) {
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    const int en = next_base + __popcll(fm & (below | (1ull << lane))) - 1;
-                    xc += lean_poly_records(t, xtop, xc, run, en, par, desc, key, e, dist, lane);
-                }
                 __builtin_amdgcn_wave_barrier();
                 if (lane < merged) { cK = L.oK[lane]; cD = L.oD[lane]; cN = L.oN[lane]; cE = L.oE[lane]; cDD = L.oDD[lane]; }
             } else {
-                merged = lean_merge<PL>(t, base, n_par, o_node, o_dist, lo, n_leaf, next_base, pe, L.ka, L.kb, lane, xtop, xc);
+                merged = lean_merge<M, PL>(t, base, n_par, o_node, o_dist, lo, n_leaf, next_base, pe, L.ka, L.kb, lane, xtop, xc, xsl);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (merged <= WAVE && lane < merged) {
                     cK = t.K[next_base + lane]; cD = t.D[next_base + lane]; cN = t.N[next_base + lane];
@@ -1177,7 +1298,7 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
             continue;
         }
         // internal valid nodes: base; the LCA's entry sits at that index.  What the top-down kernel needs of this query:
-        if (PL && xc > xg && !LEAN_EXP_NO_FIX) {  // the LCA is a polytomy (a root trifurcation): its children's tuples into their records
+        if (PL && xsl > 0 && !LEAN_EXP_NO_FIX) {  // the LCA is a polytomy that a merge step's end cut: its children's tuples into their records
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             const LeanTeam tc = t;
             lean_poly_S<M>(tc, xtop, xg, xc, lane, WAVE, nullptr, 0);
@@ -1206,7 +1327,7 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
 // (placement_per_edge) and evaluates its residual (error_per_edge); an internal child's tuple becomes lift(R) over its own
 // edge; then the query's arg-min (apples/Algorithm.py:74-91)
 template <int M, bool HY = false, bool PL = false>
-__device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
+__device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh, double (*pu)[WAVE] = nullptr) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
     const double *lds_pow = sh.pow;
@@ -1229,7 +1350,7 @@ __device__ void lean_down_loop(const SweepArgs &a, LeanDownShared &sh) {
         const int4 meta = a.lean_meta[q];
         const int G = meta.y, VI = meta.z;
         if (G < 0) continue;  // handed to the workgroup-sized teams by the bottom-up kernel
-        if (!prof) { lean_down_one<M, HY, PL>(a, lds_pow, stage, q, n, meta.x & 0xffffffffll, G, VI, lane, meta.w); continue; }
+        if (!prof) { lean_down_one<M, HY, PL>(a, lds_pow, stage, q, n, meta.x & 0xffffffffll, G, VI, lane, meta.w, pu); continue; }
         const int V = VI + n;  // Subtree.num_nodes
         LeanTeam t = lean_pool_view(a.lean, a.lean_cap1, meta.x & 0xffffffffll, nullptr, 0, 0);
         t.BP = a.blk_pool;
@@ -1286,6 +1407,7 @@ struct LeanBigShared {
     double m_e[TEAM], m_dist[TEAM];
     int mcnt[2][TEAM / WAVE];
     int xcnt[2][TEAM / WAVE];                      // (polytomies) a step's third / later siblings per wavefront
+    double pu[TEAM / WAVE][6][WAVE];               // (polytomies) per wavefront: a polytomy's children's lifted tuples (lean_poly_td)
     double d[TEAM / WAVE];
     int i[TEAM / WAVE];
     int w;
@@ -1516,16 +1638,7 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
         lean_best_init(best);
         for (int g = G; g >= 1; --g) {
             const int g0 = grp_off[g], g1 = grp_off[g + 1];
-            lean_td_chunks<M, true, HY, PL>(t, g0, g1, tid, TEAM, VI, a.negative, a.criterion, lds_pow, nullptr, nullptr, 0, best);
-            if (PL && xc > 0) {
-                const int x0 = xoff[g], x1 = xoff[g + 1];
-                if (x1 > x0) {
-                    const LeanTeam tc = t;
-                    LeanBest b2 = best;
-                    lean_poly_td<M, HY>(tc, xtop, x0, x1, tid, TEAM, VI, a.negative, a.criterion, lds_pow, nullptr, 0, b2);
-                    best = b2;
-                }
-            }
+            lean_td_chunks<M, true, HY, PL>(t, g0, g1, tid, TEAM, VI, a.negative, a.criterion, lds_pow, nullptr, nullptr, 0, best, xtop, sh.pu[tid / WAVE]);
             __syncthreads();
         }
         if (HY) {
@@ -1599,11 +1712,12 @@ __global__ __launch_bounds__(APPLES_TPB, LEAN_UP_WAVES) void k_lean_both(SweepAr
 
 template <int M, bool HY = false, bool PL = false>
 __global__ __launch_bounds__(APPLES_TPB, LEAN_DOWN_WAVES) void k_lean_down(SweepArgs a) {
-    __shared__ LeanDownShared sh;
+    __shared__ typename std::conditional<PL, LeanDownSharedPL, LeanDownShared>::type sh;
     for (int i = threadIdx.x; i < 384; i += APPLES_TPB) sh.pow[i] = (&kPowLogTab[0][0])[i];
     for (int i = threadIdx.x; i < 256; i += APPLES_TPB) sh.pow[384 + i] = __longlong_as_double((long long)kExpTab[i]);
     __syncthreads();
-    lean_down_loop<M, HY, PL>(a, sh);
+    if constexpr (PL) lean_down_loop<M, HY, PL>(a, sh, sh.pu[threadIdx.x / WAVE]);
+    else lean_down_loop<M, HY, PL>(a, sh);
 }
 
 
