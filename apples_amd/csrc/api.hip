@@ -98,6 +98,7 @@ const double kBlosum45[400] = {
 int upload_tree(apples_ctx *ctx, const apples_tree *t) {
     DevTree &d = ctx->tree;
     d.dbg = ctx->dbg;
+    d.force_poly = (int32_t)knob(ctx, "APPLES_LEAN_FORCE_POLY", 0);
     d.lean_small = ctx->params.criterion != APPLES_HYBRID || !(ctx->dbg & APPLES_DBG_HYBRID_RECORDS);
     d.n_nodes = t->n_nodes;
     int h = 0;
@@ -225,7 +226,7 @@ int upload_tree(apples_ctx *ctx, const apples_tree *t) {
         int64_t total = 0;
         for (int i = 0; i < n; ++i)
             if (t->child_off[i + 1] == t->child_off[i]) total += t->level[i] + 1;
-        static const int64_t max_entries = getenv("APPLES_SCAN_TABLE_MAX") ? atoll(getenv("APPLES_SCAN_TABLE_MAX")) : ((int64_t)200 << 20);
+        const int64_t max_entries = (int64_t)knob(ctx, "APPLES_SCAN_TABLE_MAX", ((int64_t)200 << 20));
         if (postorder && total <= max_entries) {
             std::vector<int4> info(n);
             std::vector<AncRec> anc((size_t)total);
@@ -609,7 +610,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         HIP_TRY(ctx, hipMemsetAsync(a.packed, 0, (size_t)words * sizeof(uint4), ctx->stream));
         // bytes beyond ACGT- in a singleton context whose fused pass runs on the matrix cores: the 2-plane rows and the fp4 images
         // keep them as gaps, the 8-plane form comes beside them (DevAlign::ex_ok)
-        a.ex_ok = a.all_singleton && dist_mfma_enabled() && a.L < 8192;
+        a.ex_ok = a.all_singleton && dist_mfma_enabled(ctx) && a.L < 8192;
         int32_t *d_row_bad = nullptr;
         if (a.ex_ok) {
             if (dev_alloc(ctx, &d_row_bad, a.slots_pad)) return 1;
@@ -654,7 +655,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         }
         dev_free(d_exotic);
         // pre-expanded reference image for the GEMM form of the fused pass (dist_gemm.hip): 2 bytes per site
-        if (a.all_singleton && a.planes == 2 && a.L <= GEMM_MAX_L && dist_mfma_enabled() && !(ctx->dbg & APPLES_DBG_NO_DIST_GEMM)) {
+        if (a.all_singleton && a.planes == 2 && a.L <= GEMM_MAX_L && dist_mfma_enabled(ctx) && !(ctx->dbg & APPLES_DBG_NO_DIST_GEMM)) {
             // (the image's own allocation marks the context's fp4 images as compact: 64 bytes per 64-site block)
             if (dev_alloc(ctx, &a.ref_f4, a.slots_pad * (int64_t)a.G * 128)) return 1;
             if (launch_expand_queries_f4(ctx, a.raw, a.n_rows, a.ref_f4, a.slots_pad, ctx->stream, a.d_slot_row)) return 1;
@@ -662,7 +663,7 @@ int setup_alignment(apples_ctx *ctx, const apples_tree *t, const apples_alignmen
         }
         // clustered reference on the ACGT- fast path: panels for the fused selection by representatives
         if (!a.all_singleton && a.planes == 2 && a.n_refs <= SELECT_CLUSTERS_MAX_SLOTS && a.G <= 64 &&
-            !(ctx->dbg & APPLES_DBG_NO_FUSE) && dist_mfma_enabled())
+            !(ctx->dbg & APPLES_DBG_NO_FUSE) && dist_mfma_enabled(ctx))
             if (launch_build_cluster_panels(ctx)) return 1;
     }
     return 0;
@@ -734,7 +735,7 @@ bool hybrid_records(const apples_ctx *ctx) {
 
 // observed-leaf count above which a query goes straight to a workgroup-sized sweep team
 int big_threshold(const apples_ctx *ctx) {
-    static const int env = getenv("APPLES_BIG_THRESHOLD") ? atoi(getenv("APPLES_BIG_THRESHOLD")) : 0;
+    const int env = (int)knob(ctx, "APPLES_BIG_THRESHOLD", 0);
     // the lean sweep's wavefront-sized teams are the efficient ones and take their queue largest first, finely graded
     // (C3 sweep 15.8 / 15.8 / 16.7 / 18.7 ms at 4 096 / 8 192 / 12 288 / 16 384, the clustered route's 38.4 / 35.5 / 35.1 / 36.0);
     // the level loop's cut was measured at 4 096
@@ -750,7 +751,7 @@ int big_threshold(const apples_ctx *ctx) {
 // it was there).  Never above the count the workspace was sized with.
 int route_threshold(const apples_ctx *ctx) {
     int v = big_threshold(ctx);
-    static const bool fixed = getenv("APPLES_BIG_THRESHOLD") != nullptr;  // (the knob fixes the cut for every batch size)
+    const bool fixed = knob_on(ctx, "APPLES_BIG_THRESHOLD");  // (the knob fixes the cut for every batch size)
     // (a workspace regrown with per-edge records -- a HYBRID pass, apples_sweep_edges -- stays with the level loop for later
     // MLSE / ME passes too: its cut, not the lean sweep's the tree would be eligible for)
     if (!fixed && !ctx->tree.scan && ctx->ws.batch > 0 && !ctx->ws.small.lean) v = std::min(v, 4096);
@@ -761,7 +762,7 @@ int route_threshold(const apples_ctx *ctx) {
 }
 
 // ints per query / team of the lean sweep's group offsets: height + 4, and once more for the child records' offsets on a tree with polytomies
-static int64_t lean_grp_stride(const DevTree &t) { return (int64_t)(t.height + 4) * ((t.max_children > 2 || getenv("APPLES_LEAN_FORCE_POLY")) ? 2 : 1); }
+static int64_t lean_grp_stride(const DevTree &t) { return (int64_t)(t.height + 4) * ((t.max_children > 2 || t.force_poly) ? 2 : 1); }
 
 void free_sweep(Workspace::Sweep &sw) {
     dev_free(sw.map); dev_free(sw.ver); dev_free(sw.order); dev_free(sw.ent); dev_free(sw.grp_off); dev_free(sw.A); dev_free(sw.B); dev_free(sw.xe);
@@ -878,7 +879,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     const DevTree &t = ctx->tree;
     int64_t batch = want_batch;
     if (ctx->params.max_batch > 0) batch = std::min(batch, (int64_t)ctx->params.max_batch);
-    static const bool no_slim = getenv("APPLES_NO_SLIM_BATCH") != nullptr;  // diagnostic knob
+    const bool no_slim = knob_on(ctx, "APPLES_NO_SLIM_BATCH");  // diagnostic knob
     slim = slim && need_fused && !need_counts && !need_alt && !no_slim;
     const bool cslim = seg_stride > 0 && seg_stride < stride && need_fused && !need_counts && !need_alt && !slim && !no_slim;
     int64_t per_q = stride * 8 + members * 12 + (int64_t)(t.height + 2) * 4 + (need_counts ? stride * 4 : 0) +
@@ -899,7 +900,7 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_gib = std::max<int64_t>(8, std::min<int64_t>(144, (int64_t)(fr >> 30) / 2));
         if (ctx->params.batch_gib > 0) budget_gib = std::min<int64_t>(budget_gib, ctx->params.batch_gib);  // the caller's cap only lowers it
-        if (const char *e = getenv("APPLES_BATCH_GIB")) budget_gib = std::max<int64_t>(1, atoll(e));  // tuning knob (experiments: replaces both)
+        if (knob_on(ctx, "APPLES_BATCH_GIB")) budget_gib = std::max<int64_t>(1, knob(ctx, "APPLES_BATCH_GIB", 0));  // tuning knob (experiments: replaces both)
         capq = std::max<int64_t>(32, ((need_alt ? budget_gib / 2 : budget_gib) << 30) / std::max<int64_t>(per_q, 1));
         int64_t b = want_batch;
         if (ctx->params.max_batch > 0) b = std::min(b, (int64_t)ctx->params.max_batch);
@@ -981,25 +982,25 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     // (2 048 teams are resident at two wavefronts per SIMD; 3 072 measured best at both 10 k and 200 k leaves)
     int64_t teams = (t.scan || sweep_bits_in_lds(t) || sweep_merge_lists(t)) ? 3072 : std::min<int64_t>(3072, std::max<int64_t>(64, ((int64_t)8 << 30) / (4 * nn)));
     teams = std::min<int64_t>(teams, round_up(batch, 4));
-    if (const char *e = getenv("APPLES_SWEEP_TEAMS")) teams = std::max(4, atoi(e));  // tuning knob
+    if (knob_on(ctx, "APPLES_SWEEP_TEAMS")) teams = std::max<int64_t>(4, knob(ctx, "APPLES_SWEEP_TEAMS", 0));  // tuning knob
     int wgs_small = (int)std::max<int64_t>(1, teams / 4);
     int64_t per_node = t.scan ? 120 + (xe ? 144 : 0) : 68 + (sweep_merge_lists(t) ? 12 : 0) + (t.max_children > 2 ? 48 : 0) + (xe ? 2 * 144 : 0);
     if (sweep_lean_layout(t, xe)) per_node = LEAN_BYTES_PER_NODE + 4;
     const bool lean_pool = sweep_lean_layout(t, xe);
     int64_t cap = std::min<int64_t>(nn, std::max<int64_t>(1024, ((int64_t)16 << 30) / ((int64_t)wgs_small * 4 * per_node)));
-    if (const char *e = getenv("APPLES_SWEEP_CAP")) cap = std::min<int64_t>(cap, std::max<int64_t>(64, atoll(e)));  // test knob: small teams overflow early
+    if (knob_on(ctx, "APPLES_SWEEP_CAP")) cap = std::min<int64_t>(cap, std::max<int64_t>(64, knob(ctx, "APPLES_SWEEP_CAP", 0)));  // test knob: small teams overflow early
     if (lean_pool) {
         // the batch's pool: what its queries ask for at 3 entries per observed leaf, within 12 GiB (queries beyond the
         // pool go to the workgroup-sized teams); APPLES_LEAN_POOL_MB: test knob
         int64_t want = batch * (3 * std::min<int64_t>(members, big_threshold(ctx)) + 1028);  // (sweep_lean.hip:lean_query_cap)
         int64_t pool = std::min<int64_t>(want, ((int64_t)12 << 30) / LEAN_BYTES_PER_NODE);
-        if (const char *e = getenv("APPLES_LEAN_POOL_MB")) pool = std::max<int64_t>(1024, (atoll(e) << 20) / LEAN_BYTES_PER_NODE);
+        if (knob_on(ctx, "APPLES_LEAN_POOL_MB")) pool = std::max<int64_t>(1024, ((int64_t)knob(ctx, "APPLES_LEAN_POOL_MB", 0) << 20) / LEAN_BYTES_PER_NODE);
         cap = std::min<int64_t>(pool, 0x7ffffff0ll);
     }
     if (alloc_sweep(ctx, w.small, wgs_small, 4, cap, t.scan ? 0 : std::min<int64_t>(members, std::max<int64_t>(cap, big_threshold(ctx))), xe, batch)) return 1;
     // big teams: one workgroup per query with full-size scratch (~24 GiB in total)
     int64_t per_wg = nn * (4 + per_node) + (t.height + 4) * 8 + (sweep_lean_layout(t, xe) ? members * LEAN_BYTES_PER_LEAF + t.poly_kids * LEAN_BYTES_PER_NODE : 0);
-    int64_t big_max = getenv("APPLES_SWEEP_BIG_WGS") ? atoi(getenv("APPLES_SWEEP_BIG_WGS")) : 512;
+    int64_t big_max = knob(ctx, "APPLES_SWEEP_BIG_WGS", 512);
     int wgs_big = (int)std::min<int64_t>(big_max, std::max<int64_t>(4, ((int64_t)24 << 30) / std::max<int64_t>(per_wg, 1)));
     wgs_big = (int)std::min<int64_t>(wgs_big, batch);
     if (alloc_sweep(ctx, w.big, wgs_big, 1, nn, members, xe, batch)) return 1;
@@ -1056,7 +1057,7 @@ int alloc_block(apples_ctx *ctx, int64_t n, const int32_t *self_row, int planes,
                 HIP_TRY(ctx, hipMemsetAsync(qb->packed8, 0, (size_t)w8 * sizeof(uint4), st));
             }
         }
-        if (planes == 2 && dist_mfma_enabled()) {  // fp4 operand image for the matrix-core distance kernel
+        if (planes == 2 && dist_mfma_enabled(ctx)) {  // fp4 operand image for the matrix-core distance kernel
             const int64_t n128 = round_up(qb->n_pad, 256) + 256;  // a sub-batch may start at any multiple of 32
             if (blk_alloc(ctx, &qb->qf4, n128 * a.G * 256)) return 1;
         }
@@ -1229,14 +1230,14 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     s.blk_pool = ctx->blk_active ? ctx->blk_pool : nullptr;  // (clade blocks in this device batch's observation lists: run_block)
     s.map_bits = 1;
     while ((1u << s.map_bits) <= 2u * ((uint32_t)ctx->tree.n_nodes + 2u)) ++s.map_bits;
-    if (const char *e = getenv("APPLES_MAP_BITS")) s.map_bits = std::min(30, std::max(s.map_bits, atoi(e)));  // test knob: few tags, early wrap
+    if (knob_on(ctx, "APPLES_MAP_BITS")) s.map_bits = std::min(30, std::max(s.map_bits, (int)knob(ctx, "APPLES_MAP_BITS", 0)));  // test knob: few tags, early wrap
     s.cap = sw.cap;
     s.leaf_cap = sw.leaf_cap;
     s.method = ctx->params.method; s.criterion = ctx->params.criterion; s.negative = ctx->params.negative_branch;
     // (HYBRID on a level-loop workspace -- a tree the lean sweep does not serve, or one regrown with records for apples_sweep_edges --
     // ranks the per-edge records; the lean sweep ranks what it keeps in its entries)
     s.keep_edges = (keep_edges || (ctx->params.criterion == APPLES_HYBRID && (hybrid_records(ctx) || !sw.lean))) ? 1 : 0;
-    static const int dbg = getenv("APPLES_SWEEP_DEBUG_PHASE") ? atoi(getenv("APPLES_SWEEP_DEBUG_PHASE")) : 0;
+    const int dbg = (int)knob(ctx, "APPLES_SWEEP_DEBUG_PHASE", 0);
     s.debug_phase = dbg;
     s.work_list = nullptr; s.work_count = nullptr; s.big_threshold = route_threshold(ctx);
     s.cls_list = nullptr; s.cls_count = nullptr; s.cls_stride = w.batch; s.cursor = w.cls_count + 4;
@@ -1268,7 +1269,7 @@ ScanArgs scan_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placement
 // the same launch structure as run_sweep below, for the scan formulation (sweep_scan.hip)
 int run_scan(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st) {
     Workspace &w = ctx->ws;
-    static const int small_team = getenv("APPLES_SWEEP_TEAM") ? atoi(getenv("APPLES_SWEEP_TEAM")) : 64;  // tuning knob
+    const int small_team = (int)knob(ctx, "APPLES_SWEEP_TEAM", 64);  // tuning knob
     ScanArgs b = scan_args(ctx, w.big, out, false, true);
     b.overflow_list = nullptr;  // a big team's scratch holds the whole tree and any number of leaves
     b.overflow_count = nullptr;
@@ -1302,7 +1303,7 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
     Workspace &w = ctx->ws;
     if (!st) st = ctx->stream;
     if (ctx->tree.scan) return run_scan(ctx, out, nq, st);
-    static const int small_team = getenv("APPLES_SWEEP_TEAM") ? atoi(getenv("APPLES_SWEEP_TEAM")) : 64;  // tuning knob
+    const int small_team = (int)knob(ctx, "APPLES_SWEEP_TEAM", 64);  // tuning knob
     SweepArgs b = sweep_args(ctx, w.big, out, false);
     b.overflow_list = nullptr;  // a big team's scratch holds the whole tree: it cannot overflow
     b.overflow_count = nullptr;
@@ -1343,7 +1344,7 @@ int run_sweep(apples_ctx *ctx, apples_placement *out, int64_t nq, hipStream_t st
         // APPLES_LEAN_HALVES=1: a small device batch takes its queue in two halves, the first half's top-down kernel beside the second
         // half's bottom-up kernel.  Measured SLOWER (round 5, profiles/r05_lean_halves_exp.txt: config 3's 12 500-query shards 6.6 - 6.8 ->
         // 7.0 - 7.3 ms, config 5's block 3.28 -> 3.74, config 2 2.38 -> 2.77): four short launches have four tails.  Off by default.
-        static const bool want_halves = getenv("APPLES_LEAN_HALVES") != nullptr;  // experiment knob
+        const bool want_halves = knob_on(ctx, "APPLES_LEAN_HALVES");  // experiment knob
         const bool halves = want_halves && nq <= LEAN_SMALL_BATCH && nq >= 2048;
         if (halves && !ctx->stream3) HIP_TRY(ctx, hipStreamCreate(&ctx->stream3));
         if (launch_sweep_lean(ctx, sm, down, nq, ctx->stream_big, halves ? w.cls_count + 22 : nullptr, halves ? ctx->stream3 : nullptr,
@@ -1384,8 +1385,8 @@ struct StreamScope {
     ~StreamScope() { ctx->stream = saved; }
 };
 
-int dist_tile_for(int64_t nq) {
-    static const int forced = getenv("APPLES_DIST_TILE") ? atoi(getenv("APPLES_DIST_TILE")) : 0;  // tuning knob
+int dist_tile_for(const apples_ctx *ctx, int64_t nq) {
+    const int forced = (int)knob(ctx, "APPLES_DIST_TILE", 0);  // tuning knob
     if (forced > 0) return forced;
     // 16 queries per reference pass: 32 accumulators + 12 reference words stay within 96 VGPRs
     // (5 waves/SIMD); 32 queries per pass spill the epilogue to 150 VGPRs and run slower
@@ -1443,7 +1444,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
     // fused path: threshold compaction in the distance kernel's epilogue; only queries that need
     // the top-up rule get full distance rows
     const bool no_fuse = (ctx->dbg & APPLES_DBG_NO_FUSE) != 0;  // diagnostic switch
-    static const int n_pipe = getenv("APPLES_PIPELINE") ? atoi(getenv("APPLES_PIPELINE")) : 1;  // >1: measured slower (sweep and distance kernels contend), kept as a knob
+    const int n_pipe = (int)knob(ctx, "APPLES_PIPELINE", 1);  // >1: measured slower (sweep and distance kernels contend), kept as a knob
     // clustered references: the matrix-core pass runs over the representatives only, k_select_clusters expands
     // the accepted clusters (needs the panels of setup_alignment, the tabulated distances and their integer
     // threshold form)
@@ -1680,7 +1681,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
                     size_t fr = 0, tot = 0;
                     int64_t bytes = std::min<int64_t>((int64_t)16 << 30, w.batch * a.n_refs * 6);
                     if (hipMemGetInfo(&fr, &tot) == hipSuccess) bytes = std::min<int64_t>(bytes, (int64_t)(fr / 3));
-                    if (const char *e = getenv("APPLES_BLK_POOL_MB")) bytes = (int64_t)atoll(e) << 20;
+                    if (knob_on(ctx, "APPLES_BLK_POOL_MB")) bytes = (int64_t)knob(ctx, "APPLES_BLK_POOL_MB", 0) << 20;
                     bytes = std::max<int64_t>(bytes, 1 << 20);
                     // (another context on the device may have taken the memory meanwhile -- two ranks on one GPU size themselves from
                     // the same hipMemGetInfo: then this context goes without blocks, it does not fail)
@@ -1791,11 +1792,11 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
             HIP_TRY(ctx, hipEventRecord(e[0], front));
             if (fused_counts_format(ctx, qb))  // the matrix-core kernel writes only the non-empty segments' counts
                 HIP_TRY(ctx, hipMemsetAsync(w.seg_cnt, 0, (size_t)nq * (w.stride / 64) * sizeof(int32_t), front));
-            if (launch_counts_fused(ctx, qb, q0, nh, dist_tile_for(nq), w.dist, w.seg_slot, w.seg_cnt)) return 1;
+            if (launch_counts_fused(ctx, qb, q0, nh, dist_tile_for(ctx, nq), w.dist, w.seg_slot, w.seg_cnt)) return 1;
             if (nh < nq) {  // the rest of the chunk travels meanwhile (split_feed: the GEMM form, packed survivors in seg_slot alone)
                 if (feed_rest(i)) return 1;
                 HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[2 * i + 1], 0));
-                if (launch_counts_fused(ctx, qb, q0 + nh, nq - nh, dist_tile_for(nq), w.dist, w.seg_slot + nh * w.stride,
+                if (launch_counts_fused(ctx, qb, q0 + nh, nq - nh, dist_tile_for(ctx, nq), w.dist, w.seg_slot + nh * w.stride,
                                         w.seg_cnt + nh * (w.stride / 64))) return 1;
                 ++launches;
             }
@@ -1803,7 +1804,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
             // reference rows with bytes beyond ACGT- (the matrix-core pass took them for gaps): k_select_fast counts those sites for the
             // survivors on such rows and tests them once more (APPLES_EXOTIC_FIX_KERNEL: the same as a pass of its own, diagnostic)
             const bool exfix = fused_counts_format(ctx, qb) && (a.ex_off != nullptr || ctx->jc_mmax_true != nullptr);
-            static const bool ex_kernel = getenv("APPLES_EXOTIC_FIX_KERNEL") != nullptr;
+            const bool ex_kernel = knob_on(ctx, "APPLES_EXOTIC_FIX_KERNEL");
             if (exfix && ex_kernel && launch_exotic_fix(ctx, qb, q0, nq, w.seg_slot, w.seg_cnt, w.n_obs)) return 1;
             HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;
@@ -1821,7 +1822,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
             // rows of the fused buffers, which k_select_fast has consumed), then the `-b` nearest
             const bool no_topup = (ctx->dbg & APPLES_DBG_NO_TOPUP_KERNEL) != 0;  // diagnostic switch
             // (short rows are cheaper to stream twice than to rank: 2 x `-b` block arg-min rounds)
-            static const int64_t topup_min = getenv("APPLES_TOPUP_MIN_ROWS") ? atoll(getenv("APPLES_TOPUP_MIN_ROWS")) : 40000;
+            const int64_t topup_min = (int64_t)knob(ctx, "APPLES_TOPUP_MIN_ROWS", 40000);
             const bool topup = !no_topup && ctx->params.base_observation <= 256 && ctx->aln.n_refs >= topup_min;
             sa.dist = w.dist_slow;
             sa.segmin_d = w.dist;
@@ -1840,7 +1841,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
             if (ctx->params.model == APPLES_SCOREDIST) {
                 if (launch_scoredist(ctx, qb, q0, nq, w.dist, nullptr)) return 1;
             } else {
-                if (launch_counts(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, nullptr)) return 1;
+                if (launch_counts(ctx, qb, q0, nq, dist_tile_for(ctx, nq), w.dist, nullptr)) return 1;
             }
             HIP_TRY(ctx, hipEventRecord(e[1], front));
             ++launches;
@@ -1946,6 +1947,31 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         for (const auto &k : knobs)
             if (getenv(k.env)) ctx->dbg |= k.bit;
     }
+    {   // the tuning / experiment / test knobs of this context: the process environment's APPLES_* variables, then apples_params.knobs
+        // over them ("NAME=value;NAME=value", the APPLES_ prefix optional, a bare NAME = 1).  Read here and nowhere else.
+        extern char **environ;
+        auto put = [&](const std::string &kv) {
+            if (kv.empty()) return;
+            const size_t eq = kv.find('=');
+            std::string name = kv.substr(0, eq);
+            if (name.rfind("APPLES_", 0) != 0) name = "APPLES_" + name;
+            const std::string val = eq == std::string::npos ? "1" : kv.substr(eq + 1);
+            ctx->knobs[name] = val.empty() ? 1 : atoll(val.c_str());
+        };
+        for (char **e = environ; e && *e; ++e)
+            if (strncmp(*e, "APPLES_", 7) == 0) put(*e);
+        if (params->knobs) {
+            std::string all(params->knobs);
+            size_t at = 0;
+            while (at <= all.size()) {
+                const size_t semi = all.find(';', at);
+                put(all.substr(at, semi == std::string::npos ? std::string::npos : semi - at));
+                if (semi == std::string::npos) break;
+                at = semi + 1;
+            }
+        }
+        ctx->params.knobs = nullptr;  // (the caller's string is not kept)
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         ctx->err = "no HIP device available: the APPLES hot path needs an MI355X (there is no CPU fallback)";
@@ -1977,9 +2003,9 @@ int apples_ctx_create(const apples_tree *tree, const apples_alignment *aln, cons
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { ctx->err = "hipEventCreate failed"; return fail(); }
     if (tree->n_nodes < 2) { ctx->err = "tree needs at least two nodes"; return fail(); }
     if (dev_alloc(ctx, &ctx->d_exotic, 1) || hipMemsetAsync(ctx->d_exotic, 0, sizeof(int), ctx->stream) != hipSuccess) return fail();
-    if (getenv("APPLES_SCAN_PROFILE"))
+    if (knob_on(ctx, "APPLES_SCAN_PROFILE"))
         if (dev_alloc(ctx, &ctx->scan_prof, 8) || hipMemsetAsync(ctx->scan_prof, 0, 64, ctx->stream) != hipSuccess) return fail();
-    if (getenv("APPLES_LEAN_PROFILE"))
+    if (knob_on(ctx, "APPLES_LEAN_PROFILE"))
         if (dev_alloc(ctx, &ctx->lean_prof, 16) || hipMemsetAsync(ctx->lean_prof, 0, 128, ctx->stream) != hipSuccess) return fail();
     if (upload_tree(ctx, tree)) return fail();
     if (aln) {
@@ -2032,6 +2058,7 @@ int apples_set_params(apples_ctx *ctx, const apples_params *params) {
     if (ctx->has_aln && params->model != model) { ctx->err = "the distance model is fixed at context creation"; return 1; }
     ctx->params = *params;
     ctx->params.debug = ctx->dbg;  // (the switches are fixed at creation)
+    ctx->params.knobs = nullptr;   // (so are the knobs: read once, apples_ctx_create)
     ctx->params.jc_lut = nullptr;
     if (params->jc_lut && params->jc_lut_len > 0) {
         int64_t L = ctx->has_aln ? ctx->aln.L : 0;
@@ -2268,7 +2295,7 @@ int apples_distances_resident(apples_ctx *ctx, int64_t handle, int32_t query_til
         if (ctx->params.model == APPLES_SCOREDIST) {
             if (launch_scoredist(ctx, qb, q0, nq, w.dist, nullptr)) return 1;
         } else {
-            if (launch_counts(ctx, qb, q0, nq, query_tile > 0 ? query_tile : dist_tile_for(nq), w.dist, nullptr)) return 1;
+            if (launch_counts(ctx, qb, q0, nq, query_tile > 0 ? query_tile : dist_tile_for(ctx, nq), w.dist, nullptr)) return 1;
         }
         pt.end(APPLES_T_DIST);
         ++launches;
@@ -2296,7 +2323,7 @@ int apples_distances(apples_ctx *ctx, const uint8_t *queries, int64_t n_queries,
     for (int64_t q0 = 0; !rc && q0 < qb.n; q0 += w.batch) {
         int64_t nq = std::min(w.batch, qb.n - q0);
         if (ctx->params.model == APPLES_SCOREDIST) rc = launch_scoredist(ctx, qb, q0, nq, w.dist, out_counts ? w.counts : nullptr);
-        else rc = launch_counts(ctx, qb, q0, nq, dist_tile_for(nq), w.dist, out_counts ? w.counts : nullptr);
+        else rc = launch_counts(ctx, qb, q0, nq, dist_tile_for(ctx, nq), w.dist, out_counts ? w.counts : nullptr);
         if (rc) break;
         hd.resize((size_t)nq * a.slots_pad);
         if (hipMemcpyAsync(hd.data(), w.dist, hd.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "copy back failed"; rc = 1; break; }
@@ -2502,7 +2529,7 @@ static int run_table_block(apples_ctx *ctx, QueryBlock &qb) {
     // buffers, the selection of sub-batch i + 1 -- a stream over the table, bound by HBM -- beside the sweep of sub-batch i, which
     // waits on memory round trips.  Measured: a sweep takes about as long for 2 048 rows as for 4 096 (its
     // longest queries decide), so k sweeps cost more than the overlap returns.
-    static const int n_pipe = getenv("APPLES_TABLE_PIPELINE") ? atoi(getenv("APPLES_TABLE_PIPELINE")) : 0;  // sub-batches; 0 / 1: off
+    const int n_pipe = (int)knob(ctx, "APPLES_TABLE_PIPELINE", 0);  // sub-batches; 0 / 1: off
     const bool pipelined = n_pipe > 1 && !hybrid && !ctx->tree.scan && qb.n >= 2048;
     int64_t want = qb.n;
     if (pipelined) want = round_up((qb.n + n_pipe - 1) / n_pipe, 32);
@@ -2718,7 +2745,7 @@ const char *apples_describe(apples_ctx *ctx) {
              (long long)ctx->ws.small.cap, ctx->ws.big.wgs, ctx->jc_lut ? 1 : 0, ctx->tree.scan ? "scan" : "levels",
              // which kernel the fused pass of ACGT- query blocks runs on (dist_gemm.hip / dist.hip k_jc69_mfma / k_jc69 or k_scoredist)
              dist_gemm_usable(ctx) ? (ctx->gemm_thr.ok ? "fp4 gemm, linear threshold" : "fp4 gemm, threshold table")
-                                   : (a.planes == 2 && dist_mfma_enabled() ? "fp4 mfma, bit-plane fed" : "valu"),
+                                   : (a.planes == 2 && dist_mfma_enabled(ctx) ? "fp4 mfma, bit-plane fed" : "valu"),
              (long long)(a.ref_f4 ? a.slots_pad * (int64_t)a.G * 128 : 0),
              // how the level-loop sweep knows a query's subtree: merged level lists / node bits in LDS / tagged node map
              // (lean: sweep_lean.hip on big binary trees -- the workspace decides; before there is one, what a plain MLSE / ME pass will get)

@@ -69,6 +69,7 @@ struct DevTree {
     int32_t n_nodes = 0;
     int32_t height = 0;  // max level
     int32_t max_children = 0;
+    int32_t force_poly = 0;  // experiment knob APPLES_LEAN_FORCE_POLY: the polytomy-capable kernels on a binary tree (1 both, 2 bottom-up, 3 top-down)
     int64_t poly_kids = 0;  // children of the nodes with more than two (sweep_lean.hip: the child records a full-size team may need)
     // the merged level lists (sweep.hip:merge_parents, sweep_lean.hip) need node ids in left-to-right post-order and observed
     // leaves that are distinct nodes; a tree or an alignment / table that does not comply gets the node map or the node bits
@@ -284,6 +285,10 @@ struct Workspace {
 
 struct apples_ctx {
     int device = 0;
+    // tuning / experiment / test knobs (NAME -> value): apples_params.knobs ("NAME=value;NAME=value") over the process environment's
+    // APPLES_* variables, both read ONCE, at context creation -- two contexts of one process may differ in every one of them, and no
+    // launcher keeps a function-local static of its own any more (round 6; DESIGN.md lists them)
+    std::unordered_map<std::string, long long> knobs;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // spare
     hipEvent_t ev_sel = nullptr, ev_big = nullptr;
@@ -351,6 +356,13 @@ struct apples_ctx {
 };
 
 extern thread_local std::string g_create_error;
+
+// a knob's value (`def` where it is not set) / whether it is set at all
+inline long long knob(const apples_ctx *ctx, const char *name, long long def) {
+    const auto it = ctx->knobs.find(name);
+    return it == ctx->knobs.end() ? def : it->second;
+}
+inline bool knob_on(const apples_ctx *ctx, const char *name) { return ctx->knobs.find(name) != ctx->knobs.end(); }
 
 #define HIP_TRY(ctx, call)                                                                            \
     do {                                                                                              \
@@ -509,7 +521,7 @@ int launch_select_clusters_listed(apples_ctx *ctx, const SelectArgs &a, int64_t 
 int launch_counts_reps(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);
 int launch_build_cluster_panels(apples_ctx *ctx);  // listed queries, needs segmin_d/segmin_i; baseobs <= 256
 int launch_permute_cols(apples_ctx *ctx, const double *in, double *out, const int32_t *perm, int64_t nq, int64_t n_cols);
-bool dist_mfma_enabled();
+bool dist_mfma_enabled(const apples_ctx *ctx);
 bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb);
 // (contexts with a reference image keep compact, tiled images: d_out is then the image's base and row0 the image row
 // of d_raw's first row)

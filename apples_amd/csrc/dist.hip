@@ -497,8 +497,8 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
     const uint4 *qp = ((P == 8 && qb.planes == 2) ? qb.packed8 : qb.packed) + q0 * a.G * (P + 1);  // q0 is a multiple of 32: whole 16-query tiles
     const double *lut = ctx->jc_lut;
     dim3 block(APPLES_TPB);
-    static const bool use_asm = getenv("APPLES_NO_BCNT_ASM") == nullptr;  // tuning knob (default: accumulate form)
-    static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
+    const bool use_asm = !knob_on(ctx, "APPLES_NO_BCNT_ASM");  // tuning knob (default: accumulate form)
+    const bool no_mmax = knob_on(ctx, "APPLES_NO_MMAX");
     const int32_t *mmax = no_mmax ? nullptr : (ctx->jc_mmax_true ? ctx->jc_mmax_true : ctx->jc_mmax);  // (the rule itself: these kernels count exactly)
 #define LAUNCH(TQ)                                                                                                   \
     if (use_asm) LAUNCH2(TQ, true); else LAUNCH2(TQ, false)
@@ -520,7 +520,7 @@ static void launch_jc69_tile(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, 
 // the fused pass runs on the matrix cores and leaves packed (position, valid, mism) words instead of
 // slots and distances
 bool fused_counts_format(const apples_ctx *ctx, const QueryBlock &qb) {
-    static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
+    const bool no_mmax = knob_on(ctx, "APPLES_NO_MMAX");
     return qb.qf4 && !qb.exact8 && ctx->aln.planes == 2 && ctx->jc_lut && ctx->jc_mmax && !no_mmax && ctx->aln.L < 8192;  // 13-bit counts
 }
 
@@ -530,8 +530,8 @@ bool exact8_rows(const apples_ctx *ctx, const QueryBlock &qb) {
     return ctx->aln.planes == 8 || (ctx->aln.packed8 != nullptr && qb.packed8 != nullptr);
 }
 
-bool dist_mfma_enabled() {
-    static const bool off = getenv("APPLES_NO_DIST_MFMA") != nullptr;  // diagnostic knob: bit-plane VALU kernel everywhere
+bool dist_mfma_enabled(const apples_ctx *ctx) {
+    const bool off = knob_on(ctx, "APPLES_NO_DIST_MFMA");  // diagnostic knob: bit-plane VALU kernel everywhere
     return !off;
 }
 
@@ -550,7 +550,7 @@ template <int MODE>
 static int launch_mfma(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *d_dist, uint32_t *d_counts,
                        int32_t *seg_slot, int32_t *seg_cnt) {
     const DevAlign &a = ctx->aln;
-    static const bool no_mmax = getenv("APPLES_NO_MMAX") != nullptr;
+    const bool no_mmax = knob_on(ctx, "APPLES_NO_MMAX");
     dim3 grid((unsigned)(a.slots_pad / 128), (unsigned)((nq + MF_QT - 1) / MF_QT));
     hipLaunchKernelGGL((k_jc69_mfma<MODE>), grid, dim3(MF_TPB), 0, ctx->stream, a.packed,
                        qb.qf4 + q0 * (int64_t)a.G * 256, d_dist, d_counts, a.n_rows, a.slots_pad, a.G, nq, a.L,
@@ -624,7 +624,7 @@ int launch_counts(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq,
     // Full rows stay with the bit-plane kernel: with 8 bytes out per pair and a table lookup per pair the
     // matrix-core form is slower here (0.64 against 0.58 ms at C2 size).  APPLES_DIST_MFMA_ROWS=1 routes
     // tiles of 16 and more queries to it anyway (tests compare its counts with the bytewise definition).
-    if (qb.qf4 && !ctx->aln.ref_f4 && ctx->aln.planes == 2 && !ctx->aln.packed8 && tile >= 16 && getenv("APPLES_DIST_MFMA_ROWS"))
+    if (qb.qf4 && !ctx->aln.ref_f4 && ctx->aln.planes == 2 && !ctx->aln.packed8 && tile >= 16 && knob_on(ctx, "APPLES_DIST_MFMA_ROWS"))
         return launch_mfma<0>(ctx, qb, q0, nq, d_dist, d_counts, nullptr, nullptr);
     if (!exact8_rows(ctx, qb)) launch_jc69_tile<2, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);
     else launch_jc69_tile<8, 0>(ctx, qb, q0, nq, tile, d_dist, d_counts, nullptr, nullptr, nullptr, nullptr);

@@ -438,7 +438,7 @@ int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
     const DevAlign &a = ctx->aln;
     // tuning knob: 128 = two four-wavefront workgroups per CU (measured at C3: 30.8 ms against 29.4 -- what the second
     // workgroup hides of the first one's epilogue and barrier stalls costs more in DMA traffic)
-    static const int qt_env = getenv("APPLES_GEMM_QT") ? atoi(getenv("APPLES_GEMM_QT")) : 256;
+    const int qt_env = (int)knob(ctx, "APPLES_GEMM_QT", 256);
     const int QT = qt_env == 128 ? 128 : 256;
     const int TQ = (int)((nq + QT - 1) / QT), TR = (int)(a.slots_pad / GM_T);
     // persistent workgroups: as many as the CUs hold (the kernel's LDS and registers allow 256 / QT per CU), a
@@ -448,10 +448,10 @@ int launch_counts_gemm(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
         ctx->n_cu = prop.multiProcessorCount;
     }
-    static const int cus = getenv("APPLES_GEMM_CUS") ? atoi(getenv("APPLES_GEMM_CUS")) : 0;  // experiment: leave CUs to a concurrent sweep
-    static const int per_cu = getenv("APPLES_GEMM_WGS_PER_CU") ? atoi(getenv("APPLES_GEMM_WGS_PER_CU")) : 0;  // experiment: one four-wavefront workgroup per CU (QT = 128)
+    const int cus = (int)knob(ctx, "APPLES_GEMM_CUS", 0);  // experiment: leave CUs to a concurrent sweep
+    const int per_cu = (int)knob(ctx, "APPLES_GEMM_WGS_PER_CU", 0);  // experiment: one four-wavefront workgroup per CU (QT = 128)
     const int64_t grid = std::max(8, (cus > 0 ? std::min(cus, ctx->n_cu) : ctx->n_cu) / 8 * 8) * (per_cu > 0 ? std::min(per_cu, 256 / QT) : 256 / QT);
-    static const bool table = getenv("APPLES_GEMM_TABLE") != nullptr;  // diagnostic knob: threshold through the LDS table
+    const bool table = knob_on(ctx, "APPLES_GEMM_TABLE");  // diagnostic knob: threshold through the LDS table
     const bool lin = ctx->gemm_thr.ok && !table;
     const int R = (a.G * 2 - 2) % 3;
     if (a.L > GEMM_MAX_L13) {  // 2 047 .. 4 092 sites: the validity sum at 2^12, integer decode, the threshold through the table

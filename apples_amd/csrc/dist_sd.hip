@@ -884,7 +884,7 @@ int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t n
     const DevAlign &a = ctx->aln;
     const int Lpad = (a.L + 15) / 16 * 16;
     const size_t dyn = (size_t)((2 * Lpad + Lpad / 8 + 15) / 16 * 16) + ((size_t)(a.slots_pad >> 6) + 1) * sizeof(int);
-    static const int sd_dbg = getenv("APPLES_SD_DBG") ? atoi(getenv("APPLES_SD_DBG")) : 0;  // timing experiments only (wrong results)
+    const int sd_dbg = (int)knob(ctx, "APPLES_SD_DBG", 0);  // timing experiments only (wrong results)
     hipLaunchKernelGGL(k_sd_exact, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a.aa_rows, a.aa_mrows, a.aa_Lrow,
                        qb.aa_idx + q0 * Lpad, qb.aa_mask + q0 * (Lpad / 16), ctx->blosum, a.n_rows, a.slots_pad, Lpad, a.L,
                        ctx->params.overlap_frac, ctx->params.filt_threshold, seg_d, seg_slot, seg_cnt, n_surv, sd_dbg);

@@ -1678,7 +1678,7 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
         ctx->n_cu = prop.multiProcessorCount;
     }
-    static const int per_cu = getenv("APPLES_CLUSTER_WGS") ? atoi(getenv("APPLES_CLUSTER_WGS")) : 8;  // tuning knob
+    const int per_cu = (int)knob(ctx, "APPLES_CLUSTER_WGS", 8);  // tuning knob
     if (sd) hipLaunchKernelGGL(k_cluster_dist_sd<4>, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
     else if (a.cl_mfma) hipLaunchKernelGGL(k_cluster_dist_mfma, dim3((unsigned)(ctx->n_cu * 4 * CLM_WAVES)), dim3(WAVE), 0, ctx->stream, a);  // (18 KB of LDS per wavefront: eight per CU)
     else hipLaunchKernelGGL(k_cluster_dist, dim3((unsigned)(ctx->n_cu * std::max(per_cu, 1))), dim3(APPLES_TPB), 0, ctx->stream, a);
@@ -1761,7 +1761,7 @@ int launch_select_fast(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     b.flat_pref = n_seg <= 16384 ? 1 : 0;
     // (APPLES_SELECT_FAST_TPB=128: two wavefronts per query and 16 workgroups per CU -- measured slower, 4.7 against 4.1 ms per C3
     // pass: the rounds' barriers and scans cost more than the extra workgroups in flight bring)
-    static const int tpb = getenv("APPLES_SELECT_FAST_TPB") ? atoi(getenv("APPLES_SELECT_FAST_TPB")) : 256;
+    const int tpb = (int)knob(ctx, "APPLES_SELECT_FAST_TPB", 256);
     const size_t dyn = b.flat_pref ? (size_t)(n_seg + 1) * sizeof(int) : 0;
     if (tpb == 128) hipLaunchKernelGGL(k_select_fast<128>, dim3((unsigned)nq), dim3(128), dyn, ctx->stream, b);
     else hipLaunchKernelGGL(k_select_fast<256>, dim3((unsigned)nq), dim3(256), dyn, ctx->stream, b);
@@ -2375,16 +2375,16 @@ int launch_select(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (a.all_singleton && !a.gather && !no_stream) {  // singleton clusters, rows in slot order: barrier-free streaming form
         // one workgroup per row up to 4 per CU, then rows in turn (C5: 1.70 ms per 4 096 rows against 1.85-1.9 with one
         // workgroup per row); APPLES_STREAM_GRID: tuning knob
-        static const int cap = getenv("APPLES_STREAM_GRID") ? atoi(getenv("APPLES_STREAM_GRID")) : 1024;
+        const int cap = (int)knob(ctx, "APPLES_STREAM_GRID", 1024);
         if (cap > 0) grid = std::min<unsigned>(grid, (unsigned)cap);
         b.third_pass = (ctx->dbg & APPLES_DBG_STREAM_THIRD_PASS) ? 1 : 0;  // diagnostic switch
         // rows dealt out in advance (row r to workgroup r mod grid) unless APPLES_STREAM_DYNAMIC_ROWS hands them out one at a time:
         // measured on config 5, selection 1.80 -> 1.90 ms for 4 096 rows and 4.55 -> 4.47 for 12 500 (the atomic and its barrier
         // per row against a better balance of the rows that are streamed twice); off
-        static const bool dynamic_rows = getenv("APPLES_STREAM_DYNAMIC_ROWS") != nullptr;  // tuning knob
+        const bool dynamic_rows = knob_on(ctx, "APPLES_STREAM_DYNAMIC_ROWS");  // tuning knob
         if (!dynamic_rows) b.row_cursor = nullptr;
         if (b.row_cursor) HIP_TRY(ctx, hipMemsetAsync(b.row_cursor, 0, sizeof(int32_t), ctx->stream));
-        static const int su_env = getenv("APPLES_STREAM_SU") ? atoi(getenv("APPLES_STREAM_SU")) : 0;  // tuning knob: 4 or 8
+        const int su_env = (int)knob(ctx, "APPLES_STREAM_SU", 0);  // tuning knob: 4 or 8
         const bool deep = su_env ? su_env == 8 : (!a.qcount && nq >= 8192);
         if (deep) hipLaunchKernelGGL(k_select_stream<8>, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);
         else hipLaunchKernelGGL(k_select_stream<4>, dim3(grid), dim3(APPLES_TPB), 0, ctx->stream, b);

@@ -912,7 +912,7 @@ int launch_sweep_mixed(apples_ctx *ctx, const SweepArgs &small, const SweepArgs 
     dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(need, std::min<int64_t>(n_big, nq)), wgs)), block(APPLES_TPB);
     if (n_big > (int)grid.x) n_big = (int)grid.x;
     // (APPLES_SWEEP_LDS_PAD: occupancy experiments -- extra dynamic LDS per workgroup limits how many are resident per CU)
-    static const size_t lds_pad = getenv("APPLES_SWEEP_LDS_PAD") ? (size_t)atol(getenv("APPLES_SWEEP_LDS_PAD")) : 0;
+    const size_t lds_pad = (size_t)knob(ctx, "APPLES_SWEEP_LDS_PAD", 0);
     const size_t dyn = dyn_lds_bytes(small.tree, 4) + lds_pad;
     switch (small.method) {
         case APPLES_FM: hipLaunchKernelGGL((k_sweep_mixed<APPLES_FM>), grid, block, dyn, st, small, big, nq, n_big); break;

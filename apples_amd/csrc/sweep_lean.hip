@@ -1680,7 +1680,7 @@ void launch_lean_big_m(const SweepArgs &a, int64_t nq, dim3 grid, hipStream_t st
 
 template <int TEAM>
 void launch_lean_big_t(const SweepArgs &a, int64_t nq, dim3 grid, hipStream_t st) {
-    const bool poly = a.tree.max_children > 2 || getenv("APPLES_LEAN_FORCE_POLY") != nullptr;  // (the kernels for trees with polytomies: child records, lean_poly_S / lean_poly_td; the knob: timing experiments on binary trees)
+    const bool poly = a.tree.max_children > 2 || a.tree.force_poly != 0;  // (the kernels for trees with polytomies: child records, lean_poly_S / lean_poly_td; the knob: timing experiments on binary trees)
     if (a.criterion == APPLES_HYBRID) {
         if (poly) launch_lean_big_m<TEAM, true, true>(a, nq, grid, st);
         else launch_lean_big_m<TEAM, true, false>(a, nq, grid, st);
@@ -2074,7 +2074,7 @@ int launch_blocks_up(apples_ctx *ctx, const BlockArgs &a, hipStream_t st) {
     // wavefronts in flight: 6 / 4 / 3 / 2 workgroups per CU give 34.6 / 34.7 / 34.3 / 33.7 ms on config 3's clustered pass,
     // profiles/r05_blk_order_exp.txt, and the fewer there are the more room the selection's last phase has beside them)
     // then one per CU (32.6 against 33.5 ms at two; a grid of 64 / 128 / 192 workgroups: 46.2 / 35.7 / 32.4 ms)
-    static const int per_cu = getenv("APPLES_BLK_UP_WGS") ? atoi(getenv("APPLES_BLK_UP_WGS")) : 1;
+    const int per_cu = (int)knob(ctx, "APPLES_BLK_UP_WGS", 1);
     const dim3 grid((unsigned)(cus * std::max(per_cu, 1))), block(APPLES_TPB);
     HIP_TRY(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int32_t), st));
     switch (a.method) {
@@ -2115,7 +2115,7 @@ int launch_sweep_lean_big(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int w
     // kernels beside it are as long as it is either way (no change at config 3, 35.8 -> 37.2 ms on the clustered route: half as many
     // teams per compute unit).  512-thread teams for the few largest queries only, in a launch of their own beside a launch of
     // 256-thread teams, measured worse than either (2.86 / 2.57 ms on the two shards).  APPLES_LEAN_BIG_TEAM: tuning knob.
-    static const int team_env = getenv("APPLES_LEAN_BIG_TEAM") ? atoi(getenv("APPLES_LEAN_BIG_TEAM")) : 0;
+    const int team_env = (int)knob(ctx, "APPLES_LEAN_BIG_TEAM", 0);
     const int team = team_env > 0 ? team_env : (ctx->cur_batch_queries > 0 && ctx->cur_batch_queries <= LEAN_SMALL_BATCH ? 512 : 256);
     const dim3 grid((unsigned)std::min<int64_t>(nq, wgs));
     if (team == 512) launch_lean_big_t<512>(a, nq, grid, st);
@@ -2131,8 +2131,8 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
                       hipStream_t side, hipEvent_t *ev) {
     if (nq == 0) return 0;
     const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    static const int wg_up = getenv("APPLES_LEAN_UP_WGS") ? atoi(getenv("APPLES_LEAN_UP_WGS")) : 0;      // tuning knobs
-    static const int wg_down = getenv("APPLES_LEAN_DOWN_WGS") ? atoi(getenv("APPLES_LEAN_DOWN_WGS")) : 0;
+    const int wg_up = (int)knob(ctx, "APPLES_LEAN_UP_WGS", 0);      // tuning knobs
+    const int wg_down = (int)knob(ctx, "APPLES_LEAN_DOWN_WGS", 0);
     const int64_t need = (nq + 3) / 4;
     const dim3 block(APPLES_TPB);
     const dim3 gu((unsigned)std::min<int64_t>(need, wg_up > 0 ? wg_up : cus * LEAN_UP_WAVES * 3 / 2));
@@ -2142,7 +2142,7 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
     // pass.  Measured SLOWER than the two kernels in every workload (round 5, profiles/r05_lean_fused_exp.txt: config 3's sweep 15.6 -> 16.7 ms,
     // config 5's block 1.31 -> 1.44, config 4 2.77 -> 3.05): at three wavefronts per SIMD the fused body spills 85 vector registers
     // where the bottom-up kernel alone spills 19 and the top-down kernel 8, and the launch it saves is worth less than that.
-    static const bool fused = getenv("APPLES_LEAN_FUSED") != nullptr;  // experiment knob
+    const bool fused = knob_on(ctx, "APPLES_LEAN_FUSED");  // experiment knob
     if (fused && !up.prof && up.debug_phase != 1 && up.criterion != APPLES_HYBRID && up.tree.max_children <= 2) {
         switch (up.method) {
             case APPLES_FM: hipLaunchKernelGGL((k_lean_both<APPLES_FM>), gu, block, 0, st, up); break;
@@ -2154,7 +2154,7 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
         return 0;
     }
     // (the kernels for trees with polytomies; the knob: timing experiments on binary trees -- 1: both kernels, 2: bottom-up only, 3: top-down only)
-    const int force = getenv("APPLES_LEAN_FORCE_POLY") ? atoi(getenv("APPLES_LEAN_FORCE_POLY")) : 0;
+    const int force = (int)knob(ctx, "APPLES_LEAN_FORCE_POLY", 0);
     const bool poly_up = up.tree.max_children > 2 || force == 1 || force == 2, poly = up.tree.max_children > 2 || force == 1 || force == 3;
     auto launch_up = [&](const SweepArgs &x, hipStream_t s_) {
         if (poly_up) {
@@ -2240,6 +2240,6 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
 // bottom-up teams the workspace must hold per-leaf scratch for
 int sweep_lean_up_teams(const apples_ctx *ctx) {
     const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    const int wg_up = getenv("APPLES_LEAN_UP_WGS") ? atoi(getenv("APPLES_LEAN_UP_WGS")) : 0;
+    const int wg_up = (int)knob(ctx, "APPLES_LEAN_UP_WGS", 0);
     return 4 * (wg_up > 0 ? wg_up : cus * LEAN_UP_WAVES * 3 / 2);
 }

@@ -30,7 +30,7 @@ EXPORTS = ['apples_ctx_create', 'apples_ctx_destroy', 'apples_last_error', 'appl
            'apples_queries_upload', 'apples_table_upload', 'apples_queries_free', 'apples_place_resident', 'apples_fetch_placements',
            'apples_distances_resident', 'apples_placements_device_ptr', 'apples_last_timing', 'apples_describe', 'apples_device_log',
            'apples_backbone_lengths', 'apples_abi_version', 'apples_params_size']
-ABI_VERSION = 7  # include/apples_hip.h APPLES_ABI_VERSION
+ABI_VERSION = 8  # include/apples_hip.h APPLES_ABI_VERSION
 
 
 class _Tree(C.Structure):
@@ -48,7 +48,7 @@ class _Params(C.Structure):
     _fields_ = [('model', C.c_int32), ('method', C.c_int32), ('criterion', C.c_int32), ('negative_branch', C.c_int32),
                 ('filt_threshold', C.c_double), ('base_observation', C.c_int32), ('overlap_frac', C.c_double),
                 ('jc_lut', C.c_void_p), ('jc_lut_len', C.c_int64), ('max_batch', C.c_int64), ('debug', C.c_uint32),
-                ('batch_gib', C.c_int32)]
+                ('batch_gib', C.c_int32), ('knobs', C.c_char_p)]
 
 
 _lib = None
@@ -169,11 +169,13 @@ class Engine:
 
     def __init__(self, tree, ref_seqs=None, ref_nodes=None, clusters=None, protein=False, method='FM',
                  criterion='MLSE', negative=False, threshold=0.2, baseobs=25, overlap=0.001, device=0,
-                 use_lut=True, max_batch=0, debug=(), batch_gib=0):
+                 use_lut=True, max_batch=0, debug=(), batch_gib=0, knobs=None):
         """tree: apples_amd.tree.Tree.  ref_seqs: uint8[N, L] (None for a distance-table context).
         ref_nodes: int32[N] tree leaf of each row (-1 = not in tree).  clusters: None (all
         singletons) or (cons_rows uint8[C, L], rep_row int32[R], member_off int32[R+1], member_row).
-        batch_gib: cap of the device batch buffers (0 = sized from free memory alone; the cap only lowers that)."""
+        batch_gib: cap of the device batch buffers (0 = sized from free memory alone; the cap only lowers that).
+        knobs: {name: value} tuning / test knobs of this context alone (apples_params.knobs; the process environment's
+        APPLES_* variables give the same knobs to every context)."""
         self.lib = load_library()
         self.tree = tree
         self._keep = []
@@ -214,6 +216,7 @@ class Engine:
         self.use_lut = bool(use_lut)
         self.max_batch = int(max_batch)
         self.batch_gib = int(batch_gib)
+        self.knobs = ';'.join('%s=%d' % (k, int(v)) for k, v in (knobs or {}).items()).encode() or None
         self.debug = sum(DBG[k] for k in debug) if not isinstance(debug, int) else int(debug)
         self._opts = dict(method=method, criterion=criterion, negative=negative, threshold=threshold, baseobs=baseobs,
                           overlap=overlap)
@@ -238,6 +241,7 @@ class Engine:
         p.max_batch = self.max_batch
         p.debug = self.debug
         p.batch_gib = self.batch_gib
+        p.knobs = self.knobs
         self._lut = None
         if not self.protein and self.use_lut and 0 < self.length <= self.LUT_MAX_LEN:
             self._lut = jc69_lut(self.length, float(o['overlap']))

@@ -331,6 +331,10 @@ def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_st
     placed = placements['n_valid'] > 0
     # algorithmic bytes per step: distance N_rows*(L+8)+L per query; sweep 332*V per query
     dist_bytes = nq * (rows * (L + 8) + L)
+    if info.get('cluster_fused'):
+        # the clustered route's pairs are (query, representative) and (query, member of an accepted cluster) -- what
+        # apples/Reference.py:138-152 computes: pricing it by N_rows pairs per query would report work nobody asks for
+        dist_bytes = nq * ((float(info.get('n_reps') or 0) + float(np.mean(placements['n_obs']))) * (L + 8) + L)
     sweep_bytes = 332.0 * float(np.sum(placements['n_valid'][placed] + 1))
     # (clustered route with clade blocks: the sweep inside the blocks starts in k_blocks_up, which runs beside the selection's last
     # phase -- its own timer, blocks_ms; k_blocks_down is inside sweep_ms)

@@ -86,6 +86,11 @@ typedef struct {
      * what is free); the cap only ever lowers that: min(cap, free-memory budget).  A one-shot command-line run sets 24 (beyond
      * a few tens of GiB the allocation itself takes seconds, apples_amd/worker.py). */
     int32_t batch_gib;
+    /* Tuning, experiment and test knobs of THIS context, "NAME=value;NAME=value" (the APPLES_ prefix optional, a bare NAME means 1),
+     * or NULL.  Read once, at apples_ctx_create, over the process environment's APPLES_* variables (which give the same knobs to
+     * every context of a process); apples_set_params ignores it.  The library keeps no other hidden state: two contexts of one
+     * process may differ in every knob.  The names and defaults: DESIGN.md, "Knobs". */
+    const char *knobs;
 } apples_params;
 
 #define APPLES_DBG_NO_FUSE       1u   /* full distance rows + general selection instead of the fused epilogue */
@@ -133,11 +138,11 @@ typedef struct {
 #define APPLES_F_DEGENERATE  32u  /* >=3 distances but fewer than two of them on tree leaves */
 
 /* ABI of this header: bumped whenever a struct above grows or an entry point changes (4 = apples_params.debug with the
- * switches up to APPLES_DBG_ALL; 5 = apples_params.batch_gib; 6 = APPLES_T_BLOCKS, APPLES_DBG_NO_BLOCKS; 7 = APPLES_DBG_HYBRID_RECORDS, APPLES_DBG_NO_CLUSTER_MFMA).  apples_params has no size field: a caller must zero-initialise it (memset / = {0}) and
+ * switches up to APPLES_DBG_ALL; 5 = apples_params.batch_gib; 6 = APPLES_T_BLOCKS, APPLES_DBG_NO_BLOCKS; 7 = APPLES_DBG_HYBRID_RECORDS, APPLES_DBG_NO_CLUSTER_MFMA; 8 = apples_params.knobs, apples_device_log).  apples_params has no size field: a caller must zero-initialise it (memset / = {0}) and
  * be built against the header of the library it loads -- check apples_abi_version() == APPLES_ABI_VERSION and
  * apples_params_size() == sizeof(apples_params) once at start-up, as apples_amd/engine.py does.  Bits of `debug` beyond
  * APPLES_DBG_ALL are ignored. */
-#define APPLES_ABI_VERSION 7u
+#define APPLES_ABI_VERSION 8u
 uint32_t apples_abi_version(void);
 size_t apples_params_size(void);
 

@@ -552,3 +552,18 @@ def test_clade_blocks_with_a_pool_that_runs_dry_and_with_own_rows(monkeypatch):
         else:
             assert got.tobytes() == want.tobytes(), (pool_mb, dbg)
     assert (want['flags'][400:410] & 1).all()  # F_EXACT
+
+
+def test_knobs_are_per_context_not_per_process(c2_full):
+    """apples_params.knobs: the library's tuning / test knobs are read once per context (over the process environment), not kept
+    in function-local statics -- two contexts of one process differ in them (no hidden globals).  A context whose
+    small sweep teams overflow early and whose lean pool runs dry beside a default one: different workspaces, the same bytes."""
+    d, nodes = c2_full
+    q = d.query_seqs[:2000]
+    e1 = Engine(d.tree, d.ref_seqs, nodes, method='OLS', knobs={'SWEEP_CAP': 64, 'APPLES_LEAN_POOL_MB': 1, 'TOPUP_MIN_ROWS': 1})
+    e2 = Engine(d.tree, d.ref_seqs, nodes, method='OLS')
+    a, b = e1.place_sequences(q), e2.place_sequences(q)
+    i1, i2 = e1.describe(), e2.describe()
+    e1.close(); e2.close()
+    assert a.tobytes() == b.tobytes()
+    assert i1['sweep_team_cap'] != i2['sweep_team_cap'], (i1['sweep_team_cap'], i2['sweep_team_cap'])
