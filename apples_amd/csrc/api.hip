@@ -317,7 +317,13 @@ std::vector<int32_t> level_order(const int32_t *node, int64_t n, const std::vect
 // cluster.  A query that accepts the cluster observes every leaf of the block (apples/Reference.py:146-152), so inside the block
 // the induced subtree (apples/Subtree.py:23-43) is the block itself, the same for every such query: its sweep runs on a static
 // schedule (sweep_lean.hip: k_blocks_up / k_blocks_down) and the per-query merged lists see the block's root as one leaf.
-// Needs node ids in post-order (children before parents, a subtree = a contiguous id range); blocks are binary inside.
+// Needs node ids in post-order (children before parents, a subtree = a contiguous id range).  Inside a block a node may have up
+// to BLK_MAX_DEG children (round 6; binary until then: a polytomy cut its block into its children's).  A node of m > 2 children is a
+// chain of m - 1 records, each right behind the subtree of its right operand: (c0, c1), then (the chain so far, c_j) with no edge on
+// the left -- bottom-up that is the reference's sum in file order, ((u0 + u1) + u2) + ..., on the binary walk as it is (lifting the
+// partial sum over a zero edge and adding it to 0 leaves its bits: the sums start at +0.0 and are never -0.0); the chain's last
+// record is the node itself and also lists ALL its children (blk_pk_*) for the top-down walk, where every child's R is the sum
+// over all its siblings in file order (k_blocks_down's polytomy step), the chain's other records being skipped there.
 int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_t> &level, const std::vector<int32_t> &slot_node,
                  const std::vector<int32_t> &slot_rep, const std::vector<int32_t> &slot_mpos, const std::vector<int32_t> &rep_moff) {
     DevAlign &a = ctx->aln;
@@ -325,7 +331,7 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
     a.n_e = 0;
     if (a.all_singleton || !ctx->tree.merge_ok || ctx->tree.scan || (ctx->dbg & APPLES_DBG_NO_BLOCKS)) return 0;
     const int n = t->n_nodes;
-    std::vector<int32_t> node_slot(n, -1), pure(n, -1), nleaf(n, 0), first(n, 0);
+    std::vector<int32_t> node_slot(n, -1), pure(n, -1), nleaf(n, 0), first(n, 0), nn(n, 1);
     for (int64_t s = 0; s < a.n_refs; ++s)
         if (slot_node[s] >= 0) node_slot[slot_node[s]] = (int32_t)s;
     for (int v = 0; v < n; ++v) {
@@ -336,18 +342,20 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
             nleaf[v] = 1;
             continue;
         }
-        int p = -2, nl = 0;
+        int p = -2, nl = 0, nv = 1;
         for (int k = c0; k < c1; ++k) {
             const int c = t->child_idx[k];
             if (c >= v) return 0;  // not a post-order numbering: no blocks
             first[v] = std::min(first[v], first[c]);
             nl += nleaf[c];
+            nv += nn[c];
             if (pure[c] < 0) p = -1;
             else if (p == -2) p = pure[c];
             else if (p != pure[c]) p = -1;
         }
         nleaf[v] = nl;
-        pure[v] = (c1 - c0 == 2 && p >= 0 && v - first[v] + 1 == 2 * nl - 1) ? p : -1;
+        nn[v] = nv;
+        pure[v] = (c1 - c0 >= 2 && c1 - c0 <= BLK_MAX_DEG && p >= 0 && v - first[v] + 1 == nv) ? p : -1;
     }
     std::vector<std::vector<int32_t>> by_rep((size_t)a.n_reps);
     int n_blocks = 0;
@@ -356,11 +364,14 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
     // (the selection's bitmap over emission indices: 4 096 words of LDS at most, k_select_clusters)
     int64_t n_leaf_slots = 0;
     for (int64_t s = 0; s < a.n_refs; ++s) n_leaf_slots += slot_node[s] >= 0 ? 1 : 0;
-    if (n_blocks == 0 || n_leaf_slots + n_blocks > SELECT_CLUSTERS_MAX_SLOTS || n >= (1 << 30)) return 0;
+    if (n_blocks == 0 || n_leaf_slots + n_blocks > SELECT_CLUSTERS_MAX_SLOTS || n >= BLK_NODE_MASK) return 0;
     std::vector<int4> rec_i;
-    std::vector<double2> rec_e;
+    std::vector<double2> rec_e, rec_c;  // rec_c: BME's coefficients of the two operands (1 / children; 1 for a chain's partial sum)
+    std::vector<int2> rec_p;           // per record: (first entry of pk_*, children) for a polytomy's last record, else (0, 0)
+    std::vector<int2> pk_i;            // a polytomy's children in file order: (slot or -(member position + 1), node id) ...
+    std::vector<double> pk_e;          // ... and their edge lengths
     std::vector<double> stat_plain, stat_bme;  // per record: the first three components of the node's S tuple (OLS / BE / FM; BME)
-    std::vector<int32_t> rep_soff((size_t)a.n_reps + 1, 0), mem_block((size_t)rep_moff[a.n_reps], -1), blk_root, blk_rslot, blk_nodes, slot_of(n, -1);
+    std::vector<int32_t> rep_soff((size_t)a.n_reps + 1, 0), mem_block((size_t)rep_moff[a.n_reps], -1), blk_root, blk_rslot, blk_nodes, slot_of(n, -1), chain_slot(n, -1);
     for (int64_t c = 0; c < a.n_reps; ++c) {
         rep_soff[c] = (int32_t)rec_i.size();
         const int64_t rc = c;
@@ -368,44 +379,73 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
         for (int u : by_rep[c]) {
             const int b = (int)blk_root.size();
             bool first_leaf = true;
-            for (int v = first[u]; v <= u; ++v) {
-                if (t->child_off[v] == t->child_off[v + 1]) {
-                    mem_block[rep_moff[c] + slot_mpos[node_slot[v]]] = (b << 1) | (first_leaf ? 1 : 0);  // (one member speaks for the block where it is counted)
-                    first_leaf = false;
-                    continue;
-                }
-                slot_of[v] = sc++;
-                const int l = t->child_idx[t->child_off[v]], r = t->child_idx[t->child_off[v] + 1];
+            // one record: (left operand, right operand) -> slot sc; `lpart`: the left operand is the chain's partial sum (no edge, no node)
+            auto emit = [&](int l, bool lpart, int lslot, int r, int m, bool is_root, bool is_top, int self_node) {
                 auto ref = [&](int k) { return slot_of[k] >= 0 ? slot_of[k] : -(slot_mpos[node_slot[k]] + 1); };
-                rec_i.push_back(make_int4(ref(l), ref(r), l, v == u ? (r | (1 << 30)) : r));  // (bit 30 of the right child's id: the record is a block's root)
-                rec_e.push_back(make_double2(t->edge_len[l], t->edge_len[r]));
-                // The components of the node's S tuple that do not depend on the query: inside a block every leaf is observed, so the
-                // count and the path-length sums are the same for every query (OLS / BME: S, Sd, Sd2; BE: S, Sd; FM: S -- the first
-                // components of the tuples, sweep_math.h).  Formed here with node_S's operations in node_S's order (lift, then 0 + first
-                // child + second child; BME: each child's share times 1 / 2), so they carry the bits the device would form: the block
-                // kernels neither store nor load them (sweep_lean.hip).  This file is compiled with -ffp-contract=off like the kernels.
+                const int here = sc++;
+                const int lref = lpart ? lslot : ref(l);
+                int w = r;
+                if (is_root) w |= BLK_F_ROOT;
+                if (is_top && m > 2) w |= BLK_F_POLY;
+                if (!is_top) w |= BLK_F_PART;  // (a chain's inner record: not a node)
+                rec_i.push_back(make_int4(lref, ref(r), lpart ? (int)BLK_F_NOEDGE : l, w));
+                rec_e.push_back(make_double2(lpart ? 0.0 : t->edge_len[l], t->edge_len[r]));
+                rec_c.push_back(make_double2(lpart ? 1.0 : 1.0 / (double)m, 1.0 / (double)m));
+                rec_p.push_back(make_int2(0, 0));
+                // the query-independent components (S, Sd, Sd2 of OLS / BME; sweep_math.h) with node_S's operations in node_S's order:
+                // lift, then 0 + left + right; BME: each share times its coefficient.  (This file is compiled with -ffp-contract=off.)
                 for (int bme = 0; bme < 2; ++bme) {
                     std::vector<double> &st = bme ? stat_bme : stat_plain;
                     double acc[3] = {0, 0, 0};
-                    const int kids[2] = {l, r};
                     for (int k = 0; k < 2; ++k) {
-                        const int c = kids[k];
+                        const bool part = k == 0 && lpart;
+                        const int cs = k == 0 ? (lpart ? lslot : slot_of[l]) : slot_of[r];
                         double s0 = 1, s1 = 0, s2 = 0;  // a leaf's tuple starts (1, 0, 0, ...) for every method
-                        if (slot_of[c] >= 0) { const double *sc = &st[(size_t)(rep_soff[rc] + slot_of[c]) * 3]; s0 = sc[0]; s1 = sc[1]; s2 = sc[2]; }
-                        const double e = t->edge_len[c];
+                        if (cs >= 0) { const double *q = &st[(size_t)(rep_soff[rc] + cs) * 3]; s0 = q[0]; s1 = q[1]; s2 = q[2]; }
+                        const double e = part ? 0.0 : t->edge_len[k == 0 ? l : r];
                         double u[3];
                         u[0] = s0;
                         u[1] = s0 * e + s1;
                         u[2] = s0 * e * e + s2 + 2 * e * s1;
-                        const double coef = 1.0 / (double)2;
+                        const double coef = part ? 1.0 : 1.0 / (double)m;
                         for (int x = 0; x < 3; ++x) acc[x] += bme ? coef * u[x] : u[x];
                     }
                     st.push_back(acc[0]); st.push_back(acc[1]); st.push_back(acc[2]);
                 }
+                (void)self_node;
+                return here;
+            };
+            for (int v = first[u]; v <= u; ++v) {
+                if (t->child_off[v] == t->child_off[v + 1]) {
+                    mem_block[rep_moff[c] + slot_mpos[node_slot[v]]] = (b << 1) | (first_leaf ? 1 : 0);  // (one member speaks for the block where it is counted)
+                    first_leaf = false;
+                }
+                // v (a leaf, or an internal node whose own last record went out when its last child was done) is complete: if it is
+                // the j-th child (j >= 1) of its parent, the parent's record over (what came before, v) follows right here
+                if (v == u) break;
+                const int par = t->parent[v];
+                const int pc0 = t->child_off[par], m = t->child_off[par + 1] - pc0;
+                int j = 0;
+                while (t->child_idx[pc0 + j] != v) ++j;
+                if (j == 0) continue;
+                const bool top = j == m - 1;
+                const int here = emit(t->child_idx[pc0], j > 1, chain_slot[par], v, m, top && par == u, top, par);
+                chain_slot[par] = here;
+                if (top) {
+                    slot_of[par] = here;
+                    if (m > 2) {  // every child of the polytomy, for the top-down walk
+                        rec_p.back() = make_int2((int)pk_i.size(), m);
+                        for (int k = 0; k < m; ++k) {
+                            const int ck = t->child_idx[pc0 + k];
+                            pk_i.push_back(make_int2(slot_of[ck] >= 0 ? slot_of[ck] : -(slot_mpos[node_slot[ck]] + 1), ck));
+                            pk_e.push_back(t->edge_len[ck]);
+                        }
+                    }
+                }
             }
             blk_root.push_back(u);
             blk_rslot.push_back(slot_of[u]);
-            blk_nodes.push_back(2 * nleaf[u] - 2);
+            blk_nodes.push_back(nn[u] - 1);
         }
     }
     rep_soff[a.n_reps] = (int32_t)rec_i.size();
@@ -441,6 +481,11 @@ int build_blocks(apples_ctx *ctx, const apples_tree *t, const std::vector<int32_
     }
     if (dev_upload(ctx, &a.blk_rec_i, rec_i.data(), (int64_t)rec_i.size())) return 1;
     if (dev_upload(ctx, &a.blk_rec_e, rec_e.data(), (int64_t)rec_e.size())) return 1;
+    if (dev_upload(ctx, &a.blk_rec_c, rec_c.data(), (int64_t)rec_c.size())) return 1;
+    if (dev_upload(ctx, &a.blk_rec_p, rec_p.data(), (int64_t)rec_p.size())) return 1;
+    if (pk_i.empty()) { pk_i.push_back(make_int2(0, 0)); pk_e.push_back(0.0); }
+    if (dev_upload(ctx, &a.blk_pk_i, pk_i.data(), (int64_t)pk_i.size())) return 1;
+    if (dev_upload(ctx, &a.blk_pk_e, pk_e.data(), (int64_t)pk_e.size())) return 1;
     if (dev_upload(ctx, &a.blk_stat[0], stat_plain.data(), (int64_t)stat_plain.size())) return 1;
     if (dev_upload(ctx, &a.blk_stat[1], stat_bme.data(), (int64_t)stat_bme.size())) return 1;
     if (dev_upload(ctx, &a.rep_soff, rep_soff.data(), (int64_t)rep_soff.size())) return 1;
@@ -1696,7 +1741,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
                 sa.q_blk = bi + 2 * n_items + 2 * w.batch; sa.q_item_cursor = bi + 2 * n_items + 3 * w.batch; sa.blk_ntiles = sa.q_item_cursor + 2;
                 ctx->blk_counters = sa.q_item_cursor;  // (apples_describe: items and tiles of the last device batch)
                 HIP_TRY(ctx, hipMemsetAsync(bi + 2 * n_items, 0, (size_t)(3 * w.batch + 16) * sizeof(int32_t), front));
-                sa.blk_rec_i = a.blk_rec_i; sa.blk_rec_e = a.blk_rec_e; sa.blk_stat = a.blk_stat[ctx->params.method == APPLES_BME ? 1 : 0]; sa.rep_soff = a.rep_soff; sa.mem_block = a.mem_block; sa.cl_order = a.cl_order;
+                sa.blk_rec_i = a.blk_rec_i; sa.blk_rec_e = a.blk_rec_e; sa.blk_rec_c = a.blk_rec_c; sa.blk_stat = a.blk_stat[ctx->params.method == APPLES_BME ? 1 : 0]; sa.rep_soff = a.rep_soff; sa.mem_block = a.mem_block; sa.cl_order = a.cl_order;
                 sa.blk_root = a.blk_root; sa.blk_rslot = a.blk_rslot; sa.blk_nodes = a.blk_nodes;
                 sa.rep_boff = a.rep_boff; sa.rep_loff = a.rep_loff; sa.loose_mp = a.loose_mp;
                 sa.e_of_slot = a.e_of_slot; sa.e_of_blk = a.e_of_blk; sa.e_node = a.e_node; sa.lvl_e = a.lvl_e; sa.n_e = a.n_e;
@@ -1862,7 +1907,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
                 int32_t *bi = ctx->blk_ints;
                 BlockArgs b{};
                 b.tiles = ctx->blk_tiles; b.n_tiles = bi + 2 * n_items + 3 * w.batch + 2; b.items = ctx->cl_items;
-                b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.stat = a.blk_stat[ctx->params.method == APPLES_BME ? 1 : 0]; b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos;
+                b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.rec_c = a.blk_rec_c; b.rec_p = a.blk_rec_p; b.pk_i = a.blk_pk_i; b.pk_e = a.blk_pk_e; b.stat = a.blk_stat[ctx->params.method == APPLES_BME ? 1 : 0]; b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos;
                 b.self_slot = qb.self_slot + q0; b.tmp_d = w.dist; b.stride = a.slots_pad; b.pool = ctx->blk_pool;
                 b.item_sbase = bi; b.item_bad = bi + 2 * n_items + 3 * w.batch + 16;
                 b.q_item = bi + n_items; b.q_items = reinterpret_cast<const int2 *>(bi + 2 * n_items);
@@ -2156,7 +2201,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     DevTree &t = ctx->tree;
     dev_free(t.parent); dev_free(t.edge_len); dev_free(t.child_off); dev_free(t.child_idx); dev_free(t.level); dev_free(t.rec); dev_free(t.lvlw); dev_free(t.lnode); dev_free(t.rec_l); dev_free(t.npos); dev_free(t.pe); dev_free(t.leaf_info); dev_free(t.anc); dev_free(t.rmq);
     DevAlign &a = ctx->aln;
-    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_boff); dev_free(a.rep_loff); dev_free(a.loose_mp); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.blk_stat[0]); dev_free(a.blk_stat[1]); dev_free(a.rep_soff); dev_free(a.cl_order); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_cm_idx); dev_free(a.aa_cm_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
+    dev_free(a.raw); dev_free(a.d_slot_row); dev_free(a.packed); dev_free(a.ref_f4); dev_free(a.rep_boff); dev_free(a.rep_loff); dev_free(a.loose_mp); dev_free(a.blk_rec_i); dev_free(a.blk_rec_e); dev_free(a.blk_rec_c); dev_free(a.blk_rec_p); dev_free(a.blk_pk_i); dev_free(a.blk_pk_e); dev_free(a.blk_stat[0]); dev_free(a.blk_stat[1]); dev_free(a.rep_soff); dev_free(a.cl_order); dev_free(a.mem_block); dev_free(a.blk_root); dev_free(a.blk_rslot); dev_free(a.blk_nodes); dev_free(a.e_of_slot); dev_free(a.e_of_blk); dev_free(a.e_node); dev_free(a.lvl_e); dev_free(a.rep_packed); dev_free(a.packed_rm); dev_free(a.aa_rep_idx); dev_free(a.aa_rep_mask); dev_free(a.aa_cm_idx); dev_free(a.aa_cm_mask); dev_free(a.aa_idx); dev_free(a.aa_mask); dev_free(a.sd_ref4); dev_free(a.sd_nvr); dev_free(a.aa_rows); dev_free(a.aa_mrows); dev_free(ctx->sd_tq4); dev_free(ctx->sd_list_img); dev_free(ctx->sd_list_ints); dev_free(a.slot_node); dev_free(a.slot_level); dev_free(a.lvl_slots);
     dev_free(a.slot_rep); dev_free(a.slot_mpos); dev_free(a.rep_slot); dev_free(a.rep_moff); dev_free(a.mem_slot);
     dev_free(ctx->jc_lut); dev_free(ctx->jc_mmax); dev_free(ctx->jc_mmax_true); dev_free(ctx->blosum); dev_free(ctx->d_col_perm); dev_free(ctx->d_col_node);
     dev_free(ctx->d_col_level);

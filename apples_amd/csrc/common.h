@@ -165,6 +165,13 @@ struct DevAlign {
                                   // internal nodes in post-order ("slot" = index inside the cluster): {left, right, node id of left, of right};
                                   // left / right >= 0: the child's slot, < 0: a leaf, member position -(x + 1) of the cluster's flat member list
     double2 *blk_rec_e = nullptr; // ... and the edge lengths of the two children
+    // (round 6) a node of up to BLK_MAX_DEG children inside a block = a chain of records (api.hip:build_blocks): the flags in the
+    // fourth component of blk_rec_i (BLK_F_*), BME's coefficients of a record's two operands, and for the chain's last record -- the
+    // node itself -- all its children once more for the top-down walk
+    double2 *blk_rec_c = nullptr; // [record] BME: coefficient of the left / right operand (1 / #children; 1 for the chain's partial sum)
+    int2 *blk_rec_p = nullptr;    // [record] (first entry of blk_pk_*, children) where BLK_F_POLY is set
+    int2 *blk_pk_i = nullptr;     // a polytomy's children in file order: (slot, or -(member position + 1) for a leaf; node id)
+    double *blk_pk_e = nullptr;   // ... their edge lengths
     double *blk_stat[2] = {nullptr, nullptr};  // ... and [record][3] the first three components of the node's S tuple, which do not depend on the
                                   // query inside a block (api.hip:build_blocks): [0] OLS / BE / FM, [1] BME
     int32_t *rep_soff = nullptr;  // [n_reps + 1] first record of every cluster (records = internal nodes of its blocks)
@@ -489,7 +496,7 @@ struct SelectArgs {
     int Lpad; const double *table;                    // 21 x 21
     // clade blocks (DevAlign::blk_*): k_cluster_tiles also cuts every cluster's items into tiles of up to 64 for the block kernels,
     // phase 2 notes every query's items, k_blocks_up leaves the blocks' S tuples in the pool, phase 3 emits block roots
-    const int4 *blk_rec_i; const double2 *blk_rec_e; const double *blk_stat; const int32_t *rep_soff, *mem_block, *blk_root, *blk_rslot, *blk_nodes;
+    const int4 *blk_rec_i; const double2 *blk_rec_e; const double2 *blk_rec_c; const double *blk_stat; const int32_t *rep_soff, *mem_block, *blk_root, *blk_rslot, *blk_nodes;
     const int32_t *e_of_slot, *e_of_blk, *e_node, *lvl_e; int64_t n_e;
     const int32_t *rep_boff, *rep_loff, *loose_mp;  // (the short form of the last phase)
     double *blk_pool; int64_t blk_pool_cap;  // (doubles)
@@ -582,6 +589,7 @@ struct BlockArgs {
     const int4 *tiles; const int32_t *n_tiles;  // {cluster, first item, items (<= 64), first slot of the tile's tuples in the pool or -1}
     const int2 *items;                          // (query, where the cluster's members start in the query's flat member list)
     const int4 *rec_i; const double2 *rec_e; const double *stat; const int32_t *rep_soff, *rep_moff, *slot_rep, *slot_mpos;
+    const double2 *rec_c; const int2 *rec_p; const int2 *pk_i; const double *pk_e;  // (polytomies inside blocks: DevAlign::blk_rec_c ...)
     const int32_t *self_slot;                   // [nq] the queries' own rows as slots, or nullptr
     const double *tmp_d; int64_t stride;        // the queries' rows of member distances
     double *pool;                               // [slot][6][64 lanes]; a tile's slot 0: the lanes' best edges inside the blocks (key, x1, x2,
@@ -625,6 +633,14 @@ int launch_sweep(apples_ctx *ctx, const SweepArgs &a, int64_t nq, int wgs, int t
 // a negative quiet NaN with the tag 0b101 under the quiet bit (no arithmetic produces that payload: the default NaN has none) and
 // the index in the low 48 bits (select.hip boxes, sweep_lean.hip:lean_is_block tests the whole 16-bit prefix)
 #define APPLES_BLOCK_BOX 0xFFFD000000000000ull
+// clade blocks: flags in the fourth component of a record (DevAlign::blk_rec_i) above the right child's node id; the third component
+// of a chain's inner / last record whose left operand is the partial sum: BLK_F_NOEDGE
+#define BLK_MAX_DEG 5              // children of a node inside a block (more: the block is cut there, as every polytomy was until round 6)
+#define BLK_F_ROOT 0x40000000      // the record is a block's root
+#define BLK_F_POLY 0x20000000      // the record is a node of more than two children (its chain's last record): blk_rec_p names them all
+#define BLK_F_PART 0x10000000      // the record is an inner record of a chain: a partial sum, not a node
+#define BLK_NODE_MASK 0x0fffffff   // node ids below
+#define BLK_F_NOEDGE 0x0fffffff    // "node id" of a left operand that is a partial sum
 #define LEAN_BYTES_PER_NODE 100  // T0 T1 T2 E DD (16 B each), D N (8 B each), K (4 B)
 #define LEAN_BYTES_PER_LEAF 12   // per observed leaf: edge length, parent
 #define LEAN_SMALL_BATCH 13312    // device batches up to this many queries: routing cut halved (api.hip:route_threshold), 512-thread routed teams

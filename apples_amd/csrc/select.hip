@@ -1699,7 +1699,7 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     // both on one stream, the pass is 0.3 - 0.5 ms longer (profiles/r05_blk_order_exp.txt)
     if (a.blk_tiles) {
         BlockArgs bb{};
-        bb.tiles = a.blk_tiles; bb.n_tiles = a.blk_ntiles; bb.items = a.cl_items; bb.rec_i = a.blk_rec_i; bb.rec_e = a.blk_rec_e; bb.stat = a.blk_stat;
+        bb.tiles = a.blk_tiles; bb.n_tiles = a.blk_ntiles; bb.items = a.cl_items; bb.rec_i = a.blk_rec_i; bb.rec_e = a.blk_rec_e; bb.rec_c = a.blk_rec_c; bb.stat = a.blk_stat;
         bb.rep_soff = a.rep_soff; bb.rep_moff = a.rep_moff; bb.slot_rep = a.slot_rep; bb.slot_mpos = a.slot_mpos; bb.self_slot = a.self_slot; bb.tmp_d = a.tmp_d;
         bb.stride = a.stride; bb.pool = a.blk_pool; bb.item_sbase = a.item_sbase; bb.item_bad = a.item_bad; bb.cursor = a.q_item_cursor + 1; bb.method = a.method;
         hipStream_t bs = ctx->stream_big;

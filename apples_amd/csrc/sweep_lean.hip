@@ -1772,14 +1772,20 @@ struct BlkWin {
     int4 ri[APPLES_TPB / WAVE][BLK_WIN];
     double2 re[APPLES_TPB / WAVE][BLK_WIN];
 };
+struct BlkWinC {  // (BME bottom-up: the records' coefficients too -- a node of m children inside a block weighs them 1 / m)
+    double2 rc[APPLES_TPB / WAVE][BLK_WIN];
+};
 
 template <int M>
 __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
     constexpr bool BME = (M == APPLES_BME);
     __shared__ BlkWin win;
+    __shared__ typename std::conditional<BME, BlkWinC, int>::type winc;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     int4 *w_ri = win.ri[wv];
     double2 *w_re = win.re[wv];
+    double2 *w_rc = nullptr;
+    if constexpr (BME) w_rc = winc.rc[wv];
     const int n_tiles = *a.n_tiles;
     while (true) {
         int tq = 0;
@@ -1830,13 +1836,16 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
         for (int w0 = 0; w0 < ns; w0 += BLK_WIN) {
             const int wn = ns - w0 < BLK_WIN ? ns - w0 : BLK_WIN;
             __builtin_amdgcn_wave_barrier();  // (the window's last readers)
-            for (int k = lane; k < wn; k += WAVE) { w_ri[k] = a.rec_i[rb + w0 + k]; w_re[k] = a.rec_e[rb + w0 + k]; }
+            for (int k = lane; k < wn; k += WAVE) {
+                w_ri[k] = a.rec_i[rb + w0 + k]; w_re[k] = a.rec_e[rb + w0 + k];
+                if (BME) w_rc[k] = a.rec_c[rb + w0 + k];
+            }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             // the query-independent components of the blocks' roots in this window (the host's values, the same bits the walk forms:
             // build_blocks): stored here, outside the steps, whose stores stay a fixed number (the counted waits) -- until round 5's
             // end every step stored them, into a dummy row for the nodes that are no roots: a third of the kernel's stores
             for (int k = 0; k < wn; ++k) {
-                if (!(w_ri[k].w >> 30)) continue;  // (wave-uniform)
+                if (!(w_ri[k].w & BLK_F_ROOT)) continue;  // (wave-uniform)
 #pragma unroll
                 for (int x = 0; x < NS; ++x) pool[(int64_t)(w0 + k) * 384 + x * 64] = stat[(w0 + k) * 3 + x];
             }
@@ -1856,15 +1865,18 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
                     S0[x] = leaf0 ? L0[x] : (prev0 ? r[x] : o.p0[x]);
                     S1[x] = leaf1 ? L1[x] : r[x];  // (an internal right child is the node before)
                 }
-                const double coef = BME ? 1.0 / (double)2 : 1.0;  // apples/BME.py:20: both children are valid
+                // apples/BME.py:20: every child is valid here: 1 / #children each (1 / 2 on a binary node; a chain record of a node of
+                // m children: 1 / m, and 1 for the chain's partial sum on the left: api.hip:build_blocks)
+                double2 coef = make_double2(1.0, 1.0);
+                if (BME) coef = w_rc[k];
                 lift<M>(S0, re.x, u);
 #pragma unroll
                 for (int x = 0; x < 6; ++x) r[x] = 0;
 #pragma unroll
-                for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
+                for (int x = 0; x < 6; ++x) r[x] += BME ? coef.x * u[x] : u[x];
                 lift<M>(S1, re.y, u);
 #pragma unroll
-                for (int x = 0; x < 6; ++x) r[x] += BME ? coef * u[x] : u[x];
+                for (int x = 0; x < 6; ++x) r[x] += BME ? coef.y * u[x] : u[x];
 #ifdef BLK_EXP_NO_STORE  // (timing experiments: scripts/r05_blk_parts_exp.sh)
                 if (r[0] == 123456.789) blk_store(pool + (int64_t)j * 384, r);
 #else
@@ -1961,7 +1973,12 @@ __global__ __launch_bounds__(APPLES_TPB, BLK_DOWN_WAVES) void k_blocks_down(Bloc
                 const double2 re = w_re[k];
                 // the next node's operands: its own lift(R) (unless this step forms it: then what comes is not used), its children's
                 // tuples (slots below j - 1: this step writes none of them -- an internal child of j that is not j - 1 roots another subtree)
-                fetch(w_ri[k > 0 ? k - 1 : 0], k > 0 ? j - 1 : j, ri.x == j - 1 || ri.y == j - 1, o1);
+                // (round 6: a chain's inner record -- a partial sum, not a node -- does nothing on the way down; the chain's last record,
+                // a node of more than two children, forms every child's R itself, below: of its children only the last can be j - 1)
+                const bool part = (ri.w & BLK_F_PART) != 0, poly = (ri.w & BLK_F_POLY) != 0;  // (wave-uniform)
+                const bool forms_next = !part && (poly ? ri.y == j - 1 : (ri.x == j - 1 || ri.y == j - 1));
+                fetch(w_ri[k > 0 ? k - 1 : 0], k > 0 ? j - 1 : j, forms_next, o1);
+                if (part) { have = false; return; }
                 double plift[6], S0[6], S1[6], L0[6], L1[6];
                 leaf_tuple<M>(o.d0, L0);
                 leaf_tuple<M>(o.d1, L1);
@@ -1972,15 +1989,11 @@ __global__ __launch_bounds__(APPLES_TPB, BLK_DOWN_WAVES) void k_blocks_down(Bloc
                     S0[x] = leaf0 ? L0[x] : o.p0[x];
                     S1[x] = leaf1 ? L1[x] : o.p1[x];
                 }
-                auto kid = [&](const double *Sk, const double *Ss, double ek, double es, int kd, int kn) __attribute__((always_inline)) {
-                    double acc[6], u[6];
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) acc[x] = 0;
-                    lift<M>(Ss, es, u);  // the one valid sibling (apples/OLS.py:59-69)
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * u[x] : u[x];
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];  // parent term last (apples/OLS.py:70-80)
+                // the edge above one child from its R (`acc`): solve, the lazy residual, lift(R) to an internal child
+                // (defer: an internal child's lift(R) goes there instead of its slot -- the polytomy step, whose children's S tuples must
+                // stay in the pool until every sibling has read them)
+                auto kid_acc = [&](const double *Sk, const double *acc, double ek, int kd, int kn, double *defer) __attribute__((always_inline)) {
+                    double u[6];
                     Sol r = solve_x<M>(Sk, acc, ek, a.negative);
                     bool need;
                     if (a.criterion == APPLES_ME) {
@@ -1992,7 +2005,10 @@ __global__ __launch_bounds__(APPLES_TPB, BLK_DOWN_WAVES) void k_blocks_down(Bloc
                     }
                     if (kd >= 0) {  // an internal child: lift(R) over its edge replaces its S (both S tuples are in registers)
                         lift<M>(acc, ek, u);
-                        if (kd == j - 1) {  // the next node of the walk
+                        if (defer) {
+#pragma unroll
+                            for (int x = 0; x < 6; ++x) defer[x] = u[x];
+                        } else if (kd == j - 1) {  // the next node of the walk
 #pragma unroll
                             for (int x = 0; x < 6; ++x) nxt[x] = u[x];
                         } else blk_store(pool + (int64_t)kd * 384, u);
@@ -2006,9 +2022,72 @@ __global__ __launch_bounds__(APPLES_TPB, BLK_DOWN_WAVES) void k_blocks_down(Bloc
                         }
                     }
                 };
+                auto kid = [&](const double *Sk, const double *Ss, double ek, double es, int kd, int kn) __attribute__((always_inline)) {
+                    double acc[6], u[6];
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) acc[x] = 0;
+                    lift<M>(Ss, es, u);  // the one valid sibling (apples/OLS.py:59-69)
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * u[x] : u[x];
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) acc[x] += BME ? coef * plift[x] : plift[x];  // parent term last (apples/OLS.py:70-80)
+                    kid_acc(Sk, acc, ek, kd, kn, nullptr);
+                };
+                if (poly) {
+                    // a node of m > 2 children (all of them observed, the node not the LCA): child i's R = every other child's lifted S in
+                    // file order, then the node's own lifted R (apples/OLS.py:59-80; BME: all times 1 / m, apples/BME.py:36-38).  Rare:
+                    // the children's tuples are fetched here, one at a time, again for every sibling (m <= BLK_MAX_DEG)
+                    const int2 pp = a.rec_p[rb + j];
+                    const double cf = BME ? 1.0 / (double)pp.y : 1.0;
+                    auto child = [&](int c, double *S) __attribute__((always_inline)) {
+                        const int ref = a.pk_i[pp.x + c].x;
+                        if (ref >= 0) {
+#pragma unroll
+                            for (int x = 0; x < NS; ++x) S[x] = stat[ref * 3 + x];
+                            blk_load_dyn<NS>(pool + (int64_t)ref * 384, S);
+                        } else {
+                            leaf_tuple<M>(dT[(int64_t)(-ref - 1) * 64], S);
+                        }
+                    };
+                    // (the children's lift(R) wait in registers until every child has read its siblings' S tuples from the pool)
+                    double U[BLK_MAX_DEG][6];
+                    int KD[BLK_MAX_DEG];
+#pragma unroll
+                    for (int i = 0; i < BLK_MAX_DEG; ++i) {
+                        KD[i] = -1;
+                        if (i < pp.y) {  // (wave-uniform)
+                            double acc[6] = {0, 0, 0, 0, 0, 0}, Sk[6], u[6];
+#pragma unroll 1
+                            for (int c = 0; c < pp.y; ++c) {
+                                if (c == i) continue;
+                                child(c, Sk);
+                                lift<M>(Sk, a.pk_e[pp.x + c], u);
+#pragma unroll
+                                for (int x = 0; x < 6; ++x) acc[x] += BME ? cf * u[x] : u[x];
+                            }
+#pragma unroll
+                            for (int x = 0; x < 6; ++x) acc[x] += BME ? cf * plift[x] : plift[x];
+                            child(i, Sk);
+                            const int2 ki = a.pk_i[pp.x + i];
+                            KD[i] = ki.x;
+                            kid_acc(Sk, acc, a.pk_e[pp.x + i], ki.x, ki.y, U[i]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < BLK_MAX_DEG; ++i) {
+                        if (KD[i] >= 0) {  // (wave-uniform)
+                            if (KD[i] == j - 1) {
+#pragma unroll
+                                for (int x = 0; x < 6; ++x) nxt[x] = U[i][x];
+                            } else blk_store(pool + (int64_t)KD[i] * 384, U[i]);
+                        }
+                    }
+                    have = forms_next;
+                    return;
+                }
                 kid(S0, S1, re.x, re.y, ri.x, ri.z);
-                kid(S1, S0, re.y, re.x, ri.y, ri.w & 0x3fffffff);  // (bit 30: the record is a block's root)
-                have = ri.x == j - 1 || ri.y == j - 1;
+                kid(S1, S0, re.y, re.x, ri.y, ri.w & BLK_NODE_MASK);  // (the bits above: BLK_F_*)
+                have = forms_next;
             };
             BlkOps oa, ob;
             fetch(w_ri[wn - 1], w1 - 1, have, oa);
