@@ -72,12 +72,96 @@ __global__ __launch_bounds__(APPLES_TPB) void k_pack_rows(const uint8_t *__restr
     }
 }
 
+// The same packing with the lanes along the SITES (round 6): a thread = one 32-site word of one row, consecutive threads =
+// consecutive words, rows back to back -- a wavefront reads 2 KB of consecutive row bytes (k_pack_rows above reads a row per
+// thread: 64 rows, 64 cache lines per load instruction; 0.86 ms per 33 000 queries of 1 000 sites, 0.8 of them overhead) and the
+// four threads of a word group hand their words to the first, which stores the planes' uint4s.  Needs 4 | threads per row.
+template <int P>
+__global__ __launch_bounds__(APPLES_TPB) void k_pack_rows_w(const uint8_t *__restrict__ raw, int64_t n_rows, int L, int G,
+                                                            uint4 *__restrict__ out, int64_t slots_pad, int query_layout,
+                                                            int *__restrict__ exotic, const int32_t *__restrict__ src_row,
+                                                            int32_t *__restrict__ row_bad) {
+    const int64_t idx = (int64_t)blockIdx.x * APPLES_TPB + threadIdx.x;
+    const int W4 = G * 4;  // words per row, padded to whole groups
+    const int64_t row = idx / W4;
+    const int w = (int)(idx - row * W4);
+    const bool on = row < n_rows;
+    uint32_t m = 0, c[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) c[p] = 0;
+    int bad = 0;
+    if (on && w * 32 < L) {
+        const uint8_t *src = raw + (src_row ? (int64_t)src_row[row] : row) * (int64_t)L + w * 32;
+        const int nb = min(32, L - w * 32);
+        uint32_t bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (nb == 32 && ((reinterpret_cast<uintptr_t>(src) & 3) == 0)) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bytes[k] = reinterpret_cast<const uint32_t *>(src)[k];
+        } else {
+            for (int i = 0; i < nb; ++i) bytes[i >> 2] |= (uint32_t)src[i] << (8 * (i & 3));
+            for (int i = nb; i < 32; ++i) bytes[i >> 2] |= (uint32_t)'-' << (8 * (i & 3));  // (beyond the row: gaps)
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t b = (bytes[i >> 2] >> (8 * (i & 3))) & 0xffu;
+            uint32_t nd = (b != (uint32_t)'-');
+            if (P == 2) {
+                const uint32_t ok = (b == 'A' || b == 'C' || b == 'G' || b == 'T');
+                bad |= nd & !ok;
+                nd = ok;  // (a byte beyond ACGT-: a gap here, and reported)
+            }
+            m |= nd << i;
+            if (P == 2) {
+                const uint32_t code = (b >> 1) & 3u;
+                c[0] |= ((code & 1u) & nd) << i;
+                c[1] |= ((code >> 1) & nd) << i;
+            } else {
+#pragma unroll
+                for (int p = 0; p < P; ++p) c[p] |= (((b >> p) & 1u) & nd) << i;
+            }
+        }
+    }
+    if (bad) {
+        if (exotic) atomicOr(exotic, 1);
+        if (row_bad) row_bad[row] = 1;
+    }
+    // words k = 0..3 of a group sit in four consecutive lanes (W4 is a multiple of 4, so a group never straddles rows or wavefronts)
+    uint4 pm, pc[P];
+    pm = make_uint4(m, __shfl_down(m, 1, 64), __shfl_down(m, 2, 64), __shfl_down(m, 3, 64));
+#pragma unroll
+    for (int p = 0; p < P; ++p) pc[p] = make_uint4(c[p], __shfl_down(c[p], 1, 64), __shfl_down(c[p], 2, 64), __shfl_down(c[p], 3, 64));
+    if (!on || (w & 3) != 0) return;
+    const int g = w >> 2;
+    if (query_layout) {
+        uint4 *dst = out + (((row >> 4) * G + g) * 16 + (row & 15)) * (P + 1);
+        dst[0] = pm;
+#pragma unroll
+        for (int p = 0; p < P; ++p) dst[1 + p] = pc[p];
+    } else {
+        out[((int64_t)g * (P + 1) + 0) * slots_pad + row] = pm;
+#pragma unroll
+        for (int p = 0; p < P; ++p) out[((int64_t)g * (P + 1) + 1 + p) * slots_pad + row] = pc[p];
+    }
+}
+
 int launch_pack_rows(apples_ctx *ctx, const uint8_t *d_raw, int64_t n_rows, int L, int planes, uint4 *d_out,
                      int64_t slots_pad, bool query_layout, int *d_exotic, hipStream_t st, const int32_t *d_src_row,
                      int32_t *d_row_bad) {
     if (n_rows == 0) return 0;
     if (!st) st = ctx->stream;
     int G = ctx->aln.G;
+    if (!knob_on(ctx, "APPLES_PACK_BY_ROW")) {  // (the knob: the thread-per-row form of rounds 1 - 5, for comparison)
+        const int64_t total = n_rows * (int64_t)G * 4;
+        const dim3 gw((unsigned)((total + APPLES_TPB - 1) / APPLES_TPB));
+        if (planes == 2)
+            hipLaunchKernelGGL(k_pack_rows_w<2>, gw, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, G, d_out, slots_pad,
+                               query_layout ? 1 : 0, d_exotic, d_src_row, d_row_bad);
+        else
+            hipLaunchKernelGGL(k_pack_rows_w<8>, gw, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, G, d_out, slots_pad,
+                               query_layout ? 1 : 0, d_exotic, d_src_row, (int32_t *)nullptr);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
     dim3 grid((unsigned)((n_rows + APPLES_TPB - 1) / APPLES_TPB), (unsigned)G);
     if (planes == 2)
         hipLaunchKernelGGL(k_pack_rows<2>, grid, dim3(APPLES_TPB), 0, st, d_raw, n_rows, L, G, d_out, slots_pad,

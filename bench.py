@@ -406,7 +406,8 @@ def roofline_of(workload, nq, rows, L, protein, table, per_step, launches_per_st
         roofline['traffic'], roofline['traffic_measured_at_commit'] = load_traffic(workload, 'scoredist_filter_gemm')
     elif dom == 'scoredist_distance':
         # one 8-byte table read from LDS per site and pair: the LDS read rate bounds it
-        lds = 8.0 * nq * rows * L / (kernels[dom][1] * 1e-3) / 1e9
+        pairs = (float(info.get('n_reps') or 0) + float(np.mean(placements['n_obs']))) if info.get('cluster_fused') else rows  # (per query: what the route computes)
+        lds = 8.0 * nq * pairs * L / (kernels[dom][1] * 1e-3) / 1e9
         roofline.update({'bound': 'lds', 'achieved': lds, 'peak': LDS_PEAK_GBS, 'frac': lds / LDS_PEAK_GBS,
                          'hbm_algorithmic_GBps': achieved})
     return roofline

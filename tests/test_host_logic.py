@@ -747,3 +747,35 @@ def test_native_extended_newick_and_consensus_equal_python():
         got = reference._consensus_rows(seqs, mrow, groups, protein)
         want = np.array([reference.consensus(seqs[mrow[a:b]], protein) for a, b in groups], np.uint8)
         assert np.array_equal(got, want)
+
+
+def test_synthetic_backbone_shapes_keep_the_leaves_and_their_root_distances():
+    """apples_amd/synth.py: the shapes bench.py's `other_shapes` legs and the GPU fuzz draw beside the strictly binary random-join
+    tree -- unrooted (the root's first internal child dissolved: a trifurcation), polytomies (a share of the internal nodes dissolved
+    into their parents) and a caterpillar spine (more than `spine` levels).  Same leaves in the same left-to-right order, same root
+    distance of every leaf (the branch lengths print with six decimals, sums of two such numbers print exactly)."""
+    from apples_amd import synth
+    t = synth.parse_newick(synth.random_tree_newick(400, seed=3))
+    assert np.diff(t.child_off).max() == 2
+
+    def root_dist(tr):
+        r = np.zeros(tr.n_nodes)
+        for v in range(tr.n_nodes - 2, -1, -1):
+            r[v] = r[tr.parent[v]] + tr.edge_len[v]
+        return {tr.labels[v]: r[v] for v in tr.leaves}
+
+    base = root_dist(t)
+    u = synth.reshape_tree(t, 'unrooted')
+    assert u.n_nodes == t.n_nodes - 1 and len(u.children(u.root)) == 3 and np.diff(u.child_off).max() == 3
+    p = synth.reshape_tree(t, 'polytomies', seed=5, frac=0.3)
+    assert p.n_nodes < t.n_nodes - 50 and np.diff(p.child_off).max() >= 4
+    for x in (u, p):
+        assert [x.labels[v] for v in x.leaves] == [t.labels[v] for v in t.leaves]
+        rd = root_dist(x)
+        assert max(abs(rd[k] - base[k]) for k in base) < 1e-12
+        assert (np.diff(x.child_off)[~x.is_leaf] >= 2).all()
+    d = synth.make_dataset(900, 40, 5, spine=300)
+    assert d.tree.level.max() > 300 and np.diff(d.tree.child_off).max() == 2 and d.tree.n_leaves == 900
+    # the default generator's stream is what it was (fixtures and benchmark inputs depend on it)
+    import hashlib
+    assert hashlib.sha1(synth.random_tree_newick(50, 1).encode()).hexdigest()[:12] == '51bad92e7a9d'
