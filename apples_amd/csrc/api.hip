@@ -1676,8 +1676,14 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
             sa.slow_hint = w.slow_list + w.batch;
             sa.lvl_slots = a.lvl_slots;
             {   // scratch of the cluster-major distance pass: per-cluster counters, the (query, offset) lists, the tile table
-                const bool big_form = a.n_reps > SELECT_CLUSTERS_ACC_CAP && a.n_reps <= SELECT_CLUSTERS_BIG_CAP &&
+                // (beyond BIG_CAP clusters: the third form, whose offsets take 64 KB of LDS beside the bitmap -- up to the compute unit's 160 KB)
+                const int64_t bitmap_bytes = ((std::max<int64_t>(a.n_e, a.n_refs) + 63) >> 6) * 10;
+                const bool huge_fits = a.n_reps <= SELECT_CLUSTERS_HUGE_CAP && bitmap_bytes + (SELECT_CLUSTERS_HUGE_CAP + 1) * 4 + 6 * 1024 <= 160 * 1024 &&
+                                       !knob_on(ctx, "APPLES_NO_CLUSTER_HUGE");  // (test knob: such references as before)
+                const bool big_form = a.n_reps > SELECT_CLUSTERS_ACC_CAP && (a.n_reps <= SELECT_CLUSTERS_BIG_CAP || huge_fits) &&
                                       !(ctx->dbg & APPLES_DBG_NO_CLUSTER_BIG);  // (diagnostic switch: queries beyond ACC_CAP clusters to the general route)
+                if (big_form && a.n_reps > SELECT_CLUSTERS_BIG_CAP && !ctx->cl_big_scr &&
+                    dev_alloc(ctx, &ctx->cl_big_scr, (int64_t)SELECT_CLUSTERS_BIG_LIST * 3 * SELECT_CLUSTERS_HUGE_CAP)) return 1;
                 const int64_t n_ints = 3 * (int64_t)a.n_reps + 8 + SELECT_CLUSTERS_BIG_LIST + 8,
                               n_items = nq * SELECT_CLUSTERS_ACC_CAP + (big_form ? std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps : 0),
                               n_tiles = n_items / SELECT_CLUSTERS_MIN_TILE + a.n_reps + 1;
@@ -1700,6 +1706,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
                 sa.cl_ntiles = sa.cl_fill + a.n_reps;
                 sa.big_count = big_form ? sa.cl_ntiles + 4 : nullptr;
                 sa.big_list = big_form ? sa.cl_ntiles + 8 : nullptr;
+                sa.big_scr = ctx->cl_big_scr;
                 sa.cl_items = ctx->cl_items; sa.cl_tiles = ctx->cl_tiles; sa.cl_tiles_cap = ctx->cl_tiles_cap;
             }
             // clade blocks (build_blocks): the sweep inside whole subtrees of one cluster on a static schedule, cluster-major
@@ -2195,7 +2202,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     ctx->blk_cache.clear();
     dev_free(ctx->d_exotic);
     dev_free(ctx->d_slice_cnt);
-    dev_free(ctx->cl_ints); dev_free(ctx->cl_items); dev_free(ctx->cl_tiles); dev_free(ctx->sd_rep_d); dev_free(ctx->blk_pool); dev_free(ctx->blk_ints); dev_free(ctx->blk_tiles);
+    dev_free(ctx->cl_ints); dev_free(ctx->cl_items); dev_free(ctx->cl_tiles); dev_free(ctx->cl_big_scr); dev_free(ctx->sd_rep_d); dev_free(ctx->blk_pool); dev_free(ctx->blk_ints); dev_free(ctx->blk_tiles);
     for (auto &e : ctx->ev_feed) (void)hipEventDestroy(e);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;

@@ -340,6 +340,7 @@ struct apples_ctx {
     int32_t *cl_ints = nullptr; int64_t cl_ints_cap = 0;
     int2 *cl_items = nullptr; int64_t cl_items_cap = 0;
     int4 *cl_tiles = nullptr; int64_t cl_tiles_cap = 0;
+    int32_t *cl_big_scr = nullptr;  // k_select_clusters' third form: its lists (SELECT_CLUSTERS_BIG_LIST workgroups x 3 x HUGE_CAP)
     bool blk_active = false;   // the device batch under way names block roots in its observation lists (run_block)
     int32_t *blk_counters = nullptr;  // [3] inside blk_ints: items, work cursor, tiles of the last device batch
     double *blk_pool = nullptr; int64_t blk_pool_cap = 0;   // clade blocks: the batch's tuples, [tile][slot][6][64 lanes] doubles
@@ -487,6 +488,7 @@ struct SelectArgs {
     // and where it forwards what it cannot serve (then full rows + k_select)
     const uint4 *rep_panel; int32_t *slow2_list, *slow2_count;
     int32_t *big_list, *big_count;  // queries with more than ACC_CAP accepted clusters: served by the phases' second form (CAP = BIG_CAP)
+    int32_t *big_scr;  // the third form's lists (CAP = HUGE_CAP): 3 x HUGE_CAP ints per workgroup of its launches
     // scoredist contexts on that path (k_cluster_dist_sd, phase 4): the representatives' distances come as full rows (the survivors
     // in seg_slot carry their position only), the members' from the packed residue bytes
     const double *rep_dist;   // [nq][rep_stride] or nullptr (JC69: seg_lut)
@@ -523,6 +525,7 @@ int launch_select_clusters_listed(apples_ctx *ctx, const SelectArgs &a, int64_t 
 #define SELECT_CLUSTERS_ACC_CAP 512   // accepted clusters per query on the fast path (more: the query takes the general route)
 #define SELECT_CLUSTERS_MIN_TILE 16   // fewest queries a full tile of k_cluster_dist holds
 #define SELECT_CLUSTERS_BIG_CAP 5120  // ... and on its second form, for the few queries beyond ACC_CAP (one workgroup per CU: 60 KB of lists)
+#define SELECT_CLUSTERS_HUGE_CAP 16384 // ... and on the third, for references of more than BIG_CAP clusters: the offsets in LDS (64 KB), the other lists in global scratch
 #define SELECT_CLUSTERS_BIG_LIST 1024 // queries a batch may send to that form (more: the general route)
 #define SELECT_CLUSTERS_MAX_SLOTS 524288  // k_select_clusters' bitmap: 256 threads x runs of 32 words (80 KB of LDS at that size; 229 376 until round 6)
 int launch_counts_reps(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, int32_t *seg_slot, int32_t *seg_cnt);

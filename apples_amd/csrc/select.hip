@@ -684,10 +684,16 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     __shared__ double sh_d[NW < 8 ? 8 : NW];
     __shared__ uint4 sh_q[(PHASE == 0 || PHASE == 4) ? 64 * 3 : 1];
     __shared__ double sh_T[PHASE == 4 ? 21 * 21 : 1];  // scoredist contexts: the table (phase 4 forms member distances itself)
-    __shared__ int sh_rep[ACC_CAP];
+    // (CAP beyond BIG_CAP, the third form: references of more than BIG_CAP clusters -- the offsets, which every member's binary
+    // search reads, stay in LDS; the other three lists are rows of a scratch buffer in global memory, one set per workgroup)
+    constexpr bool GL = CAP > SELECT_CLUSTERS_BIG_CAP;
+    __shared__ int sh_rep_[GL ? 1 : ACC_CAP];
     __shared__ int sh_off[ACC_CAP + 1];
-    __shared__ int sh_mb[ACC_CAP];  // first member (index into mem_slot / the cluster-major panel) of every accepted cluster
-    __shared__ int sh_sb[PHASE == 3 ? ACC_CAP : 1];  // clade blocks: where the tuples of the cluster's blocks are for this query (first slot x 64 + lane), -1: no blocks
+    __shared__ int sh_mb_[GL ? 1 : ACC_CAP];  // first member (index into mem_slot / the cluster-major panel) of every accepted cluster
+    __shared__ int sh_sb_[(PHASE == 3 && !GL) ? ACC_CAP : 1];  // clade blocks: where the tuples of the cluster's blocks are for this query (first slot x 64 + lane), -1: no blocks
+    int *const sh_rep = GL ? a.big_scr + (int64_t)blockIdx.x * 3 * ACC_CAP : sh_rep_;
+    int *const sh_mb = GL ? sh_rep + ACC_CAP : sh_mb_;
+    int *const sh_sb = GL ? sh_rep + 2 * ACC_CAP : sh_sb_;
     __shared__ int sh_znode, sh_nacc;
     if (PHASE == 4) {
         // phase 4: a workgroup per entry of the slow list, up to the grid (the launcher does not know the list's length and a
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     const int n_acc = sh_nacc;
     if (n_acc > ACC_CAP || __syncthreads_or(overflow ? 1 : 0)) {
         // (once, in the first phase: the later ones just leave the query alone)
-        if (PHASE == 1 && !LISTED && a.big_list && a.n_reps <= SELECT_CLUSTERS_BIG_CAP) {  // the second form of the phases takes it
+        if (PHASE == 1 && !LISTED && a.big_list) {  // the second (third) form of the phases takes it
             int at = SELECT_CLUSTERS_BIG_LIST;
             if (tid == 0) {
                 at = atomicAdd(a.big_count, 1);
@@ -1654,6 +1660,8 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<3, SELECT_CLUSTERS_BIG_CAP, true, 1024>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<3, SELECT_CLUSTERS_HUGE_CAP, true, 1024>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     }
     if (sd && !a.cl_count) { ctx->err = "scoredist cluster route without its tile scratch"; return 1; }
     if (by_query || !a.cl_count) {
@@ -1662,17 +1670,19 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         return 0;
     }
     HIP_TRY(ctx, hipMemsetAsync(a.cl_count, 0, (size_t)a.n_reps * sizeof(int32_t), ctx->stream));
-    constexpr int BIG = SELECT_CLUSTERS_BIG_CAP;
-    const bool big = a.big_list != nullptr;
+    constexpr int BIG = SELECT_CLUSTERS_BIG_CAP, HUGE = SELECT_CLUSTERS_HUGE_CAP;
+    const bool big = a.big_list != nullptr, huge = big && a.n_reps > BIG;  // (huge: the lists of the form in a.big_scr)
     SelectArgs b = a;  // the second form: a workgroup per entry of the list phase 1 writes
     b.qlist = a.big_list; b.qcount = a.big_count;
     const dim3 gbig((unsigned)std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST));
     if (big) HIP_TRY(ctx, hipMemsetAsync(a.big_count, 0, sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(k_select_clusters<1>, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
-    if (big) hipLaunchKernelGGL((k_select_clusters<1, BIG, true>), gbig, dim3(APPLES_TPB), 0, ctx->stream, b);
+    if (huge) hipLaunchKernelGGL((k_select_clusters<1, HUGE, true>), gbig, dim3(APPLES_TPB), 0, ctx->stream, b);
+    else if (big) hipLaunchKernelGGL((k_select_clusters<1, BIG, true>), gbig, dim3(APPLES_TPB), 0, ctx->stream, b);
     hipLaunchKernelGGL(k_cluster_tiles, dim3(1), dim3(CL_TILES_TPB), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_select_clusters<2>, dim3((unsigned)nq), dim3(APPLES_TPB), 0, ctx->stream, a);
-    if (big) hipLaunchKernelGGL((k_select_clusters<2, BIG, true>), gbig, dim3(APPLES_TPB), 0, ctx->stream, b);
+    if (huge) hipLaunchKernelGGL((k_select_clusters<2, HUGE, true>), gbig, dim3(APPLES_TPB), 0, ctx->stream, b);
+    else if (big) hipLaunchKernelGGL((k_select_clusters<2, BIG, true>), gbig, dim3(APPLES_TPB), 0, ctx->stream, b);
     if (ctx->n_cu == 0) {
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
@@ -1688,7 +1698,8 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (big) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_cl[0], ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_cl[0], 0));
-        hipLaunchKernelGGL((k_select_clusters<3, BIG, true, 1024>), gbig, dim3(1024), dyn, ctx->stream2, b);
+        if (huge) hipLaunchKernelGGL((k_select_clusters<3, HUGE, true, 1024>), gbig, dim3(1024), dyn, ctx->stream2, b);
+        else hipLaunchKernelGGL((k_select_clusters<3, BIG, true, 1024>), gbig, dim3(1024), dyn, ctx->stream2, b);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_cl[1], ctx->stream2));
     }
     hipLaunchKernelGGL(k_select_clusters<3>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);

@@ -48,6 +48,7 @@ one = engine()
 ref = one.place_sequences(qall)
 print('%s: one context, %d queries: min %.2f ms, median %.2f ms  (batch %s)' % ((name, Q) + timed(lambda: one.place_sequences(qall)) +
                                                                                  (one.describe().get('batch'),)), flush=True)
+one.close()  # (its workspace: half of the device's memory)
 for parts in (2, 3):
     # (each context sizes its batch from the memory that is free when it first runs: a fixed budget keeps them equal)
     engs = [engine(batch_gib=64 if parts == 2 else 44) for _ in range(parts)]

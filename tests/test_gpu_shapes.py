@@ -560,6 +560,14 @@ def test_clustered_route_beyond_229376_slots():
     assert e2.describe()['cluster_fused'] == 0
     assert e2.place_sequences(d.query_seqs[:1000]).tobytes() == got[:1000].tobytes()
     e2.close()
+    # more than 5 120 clusters: the queries that accept more than 512 of them go through the third form of the selection's phases
+    # (k_select_clusters<.., HUGE_CAP>: lists in global scratch) and keep their clade blocks; without it (the knob) they took full
+    # rows and the general selection -- the same bytes either way
+    assert info['n_reps'] > 5120, info
+    e3 = Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', knobs={'APPLES_NO_CLUSTER_HUGE': 1})
+    assert e3.place_sequences(d.query_seqs).tobytes() == got.tobytes()
+    e3.close()
+    assert int(np.max(got['n_obs'])) > 20000  # (such queries are there)
     sample = _sample(got, nq, extremes=8, strided=56)
     cc = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', lut=jc69_lut(300, 0.001), threads=NTHREADS)
     assert cc.place_sequences(d.query_seqs[sample]).tobytes() == got[sample].tobytes()
