@@ -837,7 +837,7 @@ void free_workspace(Workspace &w) {
     dev_free(w.dist); dev_free(w.counts); dev_free(w.obs_node); dev_free(w.obs_dist); dev_free(w.cnt_gt);
     dev_free(w.n_obs); dev_free(w.overflow_list); dev_free(w.route_list);
     dev_free(w.cls_list); dev_free(w.cls_count); dev_free(w.seg_slot); dev_free(w.seg_cnt);
-    dev_free(w.dist_slow); dev_free(w.slow_list);
+    dev_free(w.dist_slow); dev_free(w.slow_list); dev_free(w.row_off);
     free_sweep(w.small);
     free_sweep(w.big);
     w = Workspace();
@@ -919,7 +919,7 @@ int alloc_sweep(apples_ctx *ctx, Workspace::Sweep &sw, int wgs, int teams_per_wg
 // for config 3's 100 000 queries, not seven (every kernel of the route has a tail of a few hundred microseconds per batch).
 int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t want_batch, bool need_dist,
                      bool need_counts, bool need_xe, bool need_fused = false, bool need_alt = false, bool slim = false,
-                     int64_t seg_stride = 0) {
+                     int64_t seg_stride = 0, bool want_ragged = false) {
     Workspace &w = ctx->ws;
     const DevTree &t = ctx->tree;
     int64_t batch = want_batch;
@@ -931,6 +931,17 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
                     (need_fused ? stride * 12 + stride / 16 : 0);
     if (slim) per_q = stride * 4 + stride / 16 + stride * 2 + members * 12 + (int64_t)(t.height + 2) * 4;
     if (cslim) per_q = stride * 8 + stride + seg_stride * 4 + seg_stride / 16 + members * 12 + (int64_t)(t.height + 2) * 4;
+    // ragged rows (common.h, Workspace::ragged): the clustered fused route on the lean sweep, a reference of at least four small rows
+    const int64_t row_small = knob(ctx, "APPLES_RAGGED_SMALL", 16384);  // (test knob: small rows that send many queries to the big ones)
+    const bool ragged = want_ragged && cslim && !need_xe && !w.big.xe && sweep_lean_layout(t, false) && stride >= 4 * row_small && row_small >= 16 &&
+                        !ctx->no_ragged && !knob_on(ctx, "APPLES_NO_RAGGED");
+    int64_t row_big = 0;
+    if (ragged) {
+        // big rows: for a sixteenth of the wanted batch, 1 024 to 8 192 of them (APPLES_RAGGED_BIG: test knob -- a block that runs out)
+        row_big = std::min<int64_t>(8192, std::max<int64_t>(1024, want_batch / 16));
+        if (knob_on(ctx, "APPLES_RAGGED_BIG")) row_big = std::max<int64_t>(1, knob(ctx, "APPLES_RAGGED_BIG", 0));
+        per_q = row_small * 20 + stride + seg_stride * 4 + seg_stride / 16 + (int64_t)(t.height + 2) * 4 + 8;
+    }
     // batch buffers: up to 144 GiB, at most half of what is free on the card (288 GB HBM3E; the clade blocks' pool, sized afterwards
     // from what is then free -- a third of it, 16 GiB at most -- and the scoredist rows of representatives come on top; bigger
     // batches amortise the sweep's tail: at 200 k leaves 16 k-query batches are 13 % faster than 5 k).
@@ -946,10 +957,19 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_gib = std::max<int64_t>(8, std::min<int64_t>(144, (int64_t)(fr >> 30) / 2));
         if (ctx->params.batch_gib > 0) budget_gib = std::min<int64_t>(budget_gib, ctx->params.batch_gib);  // the caller's cap only lowers it
         if (knob_on(ctx, "APPLES_BATCH_GIB")) budget_gib = std::max<int64_t>(1, knob(ctx, "APPLES_BATCH_GIB", 0));  // tuning knob (experiments: replaces both)
-        capq = std::max<int64_t>(32, ((need_alt ? budget_gib / 2 : budget_gib) << 30) / std::max<int64_t>(per_q, 1));
+        // (ragged rows: the big rows come out of the same budget, a quarter of it at most -- a one-shot run's 24 GiB: 1 500 of them
+        // at 200 000 leaves)
+        if (ragged && !knob_on(ctx, "APPLES_RAGGED_BIG"))
+            row_big = std::max<int64_t>(64, std::min<int64_t>(row_big, ((budget_gib << 30) / 4) / (stride * 20) - 1));
+        const int64_t fixed = ragged ? (row_big + 1) * stride * 20 : 0;
+        capq = std::max<int64_t>(32, (((need_alt ? budget_gib / 2 : budget_gib) << 30) - fixed) / std::max<int64_t>(per_q, 1));
         int64_t b = want_batch;
         if (ctx->params.max_batch > 0) b = std::min(b, (int64_t)ctx->params.max_batch);
         b = std::min(b, capq);
+        // (ragged rows: config 3 through clusters at device batches of 100 000 / 50 016 / 33 344 / 25 024 queries: 28.75 / 27.74 /
+        // 28.35 / 28.95 ms per pass, 26.65 / 26.62 / 27.46 / 28.28 of it on the device -- beyond 50 000 the kernels gain nothing more
+        // and a host buffer's first chunk travels with nothing to hide behind; APPLES_RAGGED_BATCH: tuning knob)
+        if (ragged) b = std::min<int64_t>(b, std::max<int64_t>(32, knob(ctx, "APPLES_RAGGED_BATCH", 50016)));
         if (sweep_lean_layout(t, need_xe || w.big.xe != nullptr)) {
             // sweep_lean.hip's pool cursor is a 32-bit counter that every query of the batch adds its share to, whether the pool
             // still has room or not: the batch's requests together must stay below 2^32 (the largest share: lean_query_cap of
@@ -964,14 +984,16 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
                   (need_xe && !w.big.xe) || (need_dist && !w.dist) || (need_fused && !w.seg_slot) || (need_alt && !w.has_alt) ||
                   // full rows wanted where only a slice exists (run_block steps by w.batch) -- unless the whole block fits the slice
                   // (a slim workspace serves the few queries of an exact8 block as it is: no regrowing back and forth)
-                  (!slim && !cslim && w.dist_rows < std::min(w.batch, round_up(std::max<int64_t>(want_batch, 1), 32)));
+                  (!slim && !cslim && w.dist_rows < std::min(w.batch, round_up(std::max<int64_t>(want_batch, 1), 32))) ||
+                  // rows of another shape (every other route indexes q x obs_cap / q x stride)
+                  ragged != w.ragged || (ragged && (row_small != w.row_small || row_big > w.row_big));
     if (!regrow) return 0;
     if (!ctx->blk_cache.empty()) {  // cached block buffers count as used in hipMemGetInfo: give them back, then size the batch
         for (auto &c : ctx->blk_cache) dev_free(c.second);
         ctx->blk_cache.clear();
         batch = size_batch();
     }
-    if ((slim == w.slim || !w.slim) && (cslim == w.cslim || !w.cslim)) batch = std::max(batch, w.batch);
+    if ((slim == w.slim || !w.slim) && (cslim == w.cslim || !w.cslim) && ragged == w.ragged) batch = std::max(batch, w.batch);
     if (!slim) batch = std::min(batch, std::max<int64_t>(capq, 32));  // (a slim workspace's batch would not fit with full rows)
     batch = round_up(std::max<int64_t>(batch, 1), 32);
     const int64_t drows = (slim || cslim) ? std::min(batch, std::max<int64_t>(2048, batch / 8)) : batch;
@@ -988,12 +1010,19 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
     w.slim = slim;
     w.cslim = cslim;
     w.dist_rows = drows;
+    w.ragged = ragged; w.row_small = ragged ? row_small : 0; w.row_big = row_big;
+    const int64_t rag_entries = ragged ? batch * row_small + (row_big + 1) * stride : 0;  // (+ 1: the row the queries share when the big ones run out)
+    if (ragged) {
+        if (dev_alloc(ctx, &w.row_off, batch)) return 1;
+        if (!ctx->d_rag && dev_alloc(ctx, &ctx->d_rag, 2)) return 1;
+        w.dist_rows = std::min<int64_t>(w.dist_rows, rag_entries / std::max<int64_t>(stride, 1));  // (whole rows of `dist`, for whoever counts in them)
+    }
     for (int set = 0; set < (alt ? 2 : 1); ++set) {
-        if (dev_alloc(ctx, &w.dist, (cslim ? batch : drows) * std::max<int64_t>(stride, 1))) return 1;
+        if (dev_alloc(ctx, &w.dist, ragged ? rag_entries : (cslim ? batch : drows) * std::max<int64_t>(stride, 1))) return 1;
         if (need_counts || had_counts)
             if (dev_alloc(ctx, &w.counts, batch * std::max<int64_t>(stride, 1))) return 1;
-        if (dev_alloc(ctx, &w.obs_node, batch * obs_cap)) return 1;
-        if (dev_alloc(ctx, &w.obs_dist, batch * obs_cap)) return 1;
+        if (dev_alloc(ctx, &w.obs_node, ragged ? rag_entries : batch * obs_cap)) return 1;
+        if (dev_alloc(ctx, &w.obs_dist, ragged ? rag_entries : batch * obs_cap)) return 1;
         if (dev_alloc(ctx, &w.cnt_gt, batch * (int64_t)(t.height + 2))) return 1;
         if (dev_alloc(ctx, &w.n_obs, batch)) return 1;
         if (fused) {
@@ -1038,7 +1067,8 @@ int ensure_workspace(apples_ctx *ctx, int64_t members, int64_t stride, int64_t w
         // the batch's pool: what its queries ask for at 3 entries per observed leaf, within 12 GiB (queries beyond the
         // pool go to the workgroup-sized teams); APPLES_LEAN_POOL_MB: test knob
         int64_t want = batch * (3 * std::min<int64_t>(members, big_threshold(ctx)) + 1028);  // (sweep_lean.hip:lean_query_cap)
-        int64_t pool = std::min<int64_t>(want, ((int64_t)12 << 30) / LEAN_BYTES_PER_NODE);
+        // (ragged rows: batches three times as long -- 1 300 entries for a query of the clustered route's hundred-odd entries)
+        int64_t pool = std::min<int64_t>(want, ((int64_t)(ragged ? 32 : 12) << 30) / LEAN_BYTES_PER_NODE);
         if (knob_on(ctx, "APPLES_LEAN_POOL_MB")) pool = std::max<int64_t>(1024, ((int64_t)knob(ctx, "APPLES_LEAN_POOL_MB", 0) << 20) / LEAN_BYTES_PER_NODE);
         cap = std::min<int64_t>(pool, 0x7ffffff0ll);
     }
@@ -1248,6 +1278,10 @@ SelectArgs select_args_alignment(apples_ctx *ctx, const QueryBlock &qb, int64_t 
     s.self_slot = qb.self_slot + q0;
     s.thr = ctx->params.filt_threshold; s.baseobs = ctx->params.base_observation; s.height = ctx->tree.height;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.n_obs = w.n_obs;
+    if (w.ragged) {  // (common.h, Workspace::ragged)
+        s.row_off = w.row_off; s.row_small = w.row_small; s.row_big_base = w.batch * w.row_small; s.row_big_pitch = w.stride; s.row_big_n = (int32_t)w.row_big;
+        s.row_big_cursor = w.cls_count + 22; s.row_fail = ctx->d_rag;
+    }
     s.cnt_gt = ctx->tree.scan ? nullptr : w.cnt_gt;  // (the scan sweep takes its leaves in node-id order and needs no per-level offsets)
     s.out = qb.out + q0;
     s.big_threshold = route_threshold(ctx); s.overflow_list = w.route_list; s.overflow_count = w.route_count;
@@ -1266,6 +1300,7 @@ SweepArgs sweep_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placeme
     SweepArgs s{};
     s.tree = ctx->tree;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.cnt_gt = w.cnt_gt; s.n_obs = w.n_obs;
+    s.row_off = w.ragged ? w.row_off : nullptr;
     s.grp_off = sw.grp_off; s.A = sw.A; s.B = sw.B; s.xe = sw.xe;
     s.grp_stride = (int)lean_grp_stride(ctx->tree);
     s.map = sw.map; s.map_ver = sw.ver; s.order = sw.order; s.ent = sw.ent;
@@ -1297,6 +1332,7 @@ ScanArgs scan_args(apples_ctx *ctx, const Workspace::Sweep &sw, apples_placement
     ScanArgs s{};
     s.leaf_info = t.leaf_info; s.anc = t.anc; s.rmq = t.rmq; s.euler_len = t.euler_len; s.n_nodes = t.n_nodes; s.height = t.height;
     s.obs_node = w.obs_node; s.obs_dist = w.obs_dist; s.obs_cap = w.obs_cap; s.n_obs = w.n_obs;
+    s.row_off = w.ragged ? w.row_off : nullptr;
     s.ent_f = sw.ent_f; s.ent_i = sw.ent_i; s.xe = sw.xe; s.leaf_g = sw.leaf_g; s.meta = sw.meta;
     s.cap = sw.cap; s.leaf_cap = sw.leaf_cap;
     s.lds_leaves = big ? SCAN_LDS_LEAVES_BIG : SCAN_LDS_LEAVES_SMALL;
@@ -1457,6 +1493,12 @@ int back_stream(apples_ctx *ctx) {
 
 int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed);
 
+// ragged rows (common.h, Workspace::ragged): every query of the device batch starts on its small row
+__global__ void k_row_init(int64_t *__restrict__ row_off, int64_t nq, int64_t row_small) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) row_off[q] = q * row_small;
+}
+
 __global__ void k_scatter_placements(apples_placement *__restrict__ out, const apples_placement *__restrict__ src,
                                      const int32_t *__restrict__ idx, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1510,8 +1552,10 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
     // selection kernel's load schedule suffered from the second home of the distances: 4.0 against 2.6 ms per batch)
     const bool slim = fused && a.all_singleton && fused_counts_format(ctx, qb) && !pipelined;
     if (ensure_workspace(ctx, a.n_refs, a.slots_pad, want, true, false, hybrid, fused, pipelined, slim,
-                         (cfused && !pipelined && !(ctx->dbg & APPLES_DBG_NO_CLUSTER_TOPUP)) ? a.reps_pad : 0)) return 1;
+                         (cfused && !pipelined && !(ctx->dbg & APPLES_DBG_NO_CLUSTER_TOPUP)) ? a.reps_pad : 0,
+                         cfused && !pipelined && !hybrid && !(ctx->dbg & APPLES_DBG_CLUSTER_BY_QUERY))) return 1;
     Workspace &w = ctx->ws;
+    if (w.ragged) HIP_TRY(ctx, hipMemsetAsync(ctx->d_rag, 0, 2 * sizeof(int32_t), ctx->stream));
     int64_t step = pipelined ? std::min<int64_t>(w.batch, want) : w.batch;
     const int64_t n_sub = (qb.n + step - 1) / step;
     if (!pipelined && n_sub > 1) step = std::min(step, round_up((qb.n + n_sub - 1) / n_sub, 32));  // equal sub-batches
@@ -1608,6 +1652,10 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
         const int64_t nh = (feed && i == 0) ? head(nq) : nq;
         if (feed) HIP_TRY(ctx, hipStreamWaitEvent(front, ctx->ev_feed[2 * i + (nh < nq ? 0 : 1)], 0));  // chunk i (its first piece) is on the device
         HIP_TRY(ctx, hipMemsetAsync(w.cls_count, 0, 64 * sizeof(int32_t), front));  // every counter of the batch
+        if (w.ragged) {  // every query's rows: the small ones (common.h, Workspace::ragged)
+            hipLaunchKernelGGL(k_row_init, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, front, w.row_off, nq, w.row_small);
+            HIP_TRY(ctx, hipGetLastError());
+        }
         // The top-up chain -- full rows (or rows of bounds) for the queries k_select_fast listed, their selection -- runs BESIDE the
         // sweep of the queries k_select_fast placed on its own: on stream2, its selection kernels filing into the second set of
         // size-class queues, which a second launch of the wavefront-sized teams serves (run_sweep_second); what would be routed to
@@ -1731,7 +1779,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
                     // eighth of the reference, 16 GiB or a third of the free memory at most; a tile that finds no room goes without
                     // blocks (k_cluster_tiles).  APPLES_BLK_POOL_MB: test knob (a pool that runs dry)
                     size_t fr = 0, tot = 0;
-                    int64_t bytes = std::min<int64_t>((int64_t)16 << 30, w.batch * a.n_refs * 6);
+                    int64_t bytes = std::min<int64_t>((int64_t)(w.ragged ? 40 : 16) << 30, w.batch * a.n_refs * 6);  // (ragged rows: batches three times as long)
                     if (hipMemGetInfo(&fr, &tot) == hipSuccess) bytes = std::min<int64_t>(bytes, (int64_t)(fr / 3));
                     if (knob_on(ctx, "APPLES_BLK_POOL_MB")) bytes = (int64_t)knob(ctx, "APPLES_BLK_POOL_MB", 0) << 20;
                     bytes = std::max<int64_t>(bytes, 1 << 20);
@@ -1915,7 +1963,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
                 BlockArgs b{};
                 b.tiles = ctx->blk_tiles; b.n_tiles = bi + 2 * n_items + 3 * w.batch + 2; b.items = ctx->cl_items;
                 b.rec_i = a.blk_rec_i; b.rec_e = a.blk_rec_e; b.rec_c = a.blk_rec_c; b.rec_p = a.blk_rec_p; b.pk_i = a.blk_pk_i; b.pk_e = a.blk_pk_e; b.stat = a.blk_stat[ctx->params.method == APPLES_BME ? 1 : 0]; b.rep_soff = a.rep_soff; b.rep_moff = a.rep_moff; b.slot_rep = a.slot_rep; b.slot_mpos = a.slot_mpos;
-                b.self_slot = qb.self_slot + q0; b.tmp_d = w.dist; b.stride = a.slots_pad; b.pool = ctx->blk_pool;
+                b.self_slot = qb.self_slot + q0; b.tmp_d = w.dist; b.stride = a.slots_pad; b.row_off = w.ragged ? w.row_off : nullptr; b.pool = ctx->blk_pool;
                 b.item_sbase = bi; b.item_bad = bi + 2 * n_items + 3 * w.batch + 16;
                 b.q_item = bi + n_items; b.q_items = reinterpret_cast<const int2 *>(bi + 2 * n_items);
                 b.q_blk = bi + 2 * n_items + 2 * w.batch; b.cursor = bi + 2 * n_items + 3 * w.batch + 1;
@@ -1934,8 +1982,20 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
         HIP_TRY(ctx, hipStreamWaitEvent(front, e_stop, 0));
         if ((n_sub & 1) == 0) swap_bufs(w);  // leave the host view on set 0
     }
+    int32_t rag[2] = {0, 0};
+    if (w.ragged) HIP_TRY(ctx, hipMemcpyAsync(rag, ctx->d_rag, sizeof(rag), hipMemcpyDeviceToHost, front));
     HIP_TRY(ctx, hipEventRecord(e_stop, front));
     HIP_TRY(ctx, hipEventSynchronize(e_stop));
+    if (w.ragged) {
+        HIP_TRY(ctx, hipStreamSynchronize(front));  // (rag is on the stack)
+        if (rag[0]) {
+            // a device batch ran out of big rows (common.h, Workspace::ragged): its queries shared the spare row and their placements
+            // are not to be used.  The block once more with full rows, and full rows for this context from here on (the block is on
+            // the device by now: no feed)
+            ctx->no_ragged = true;
+            return run_block_main(ctx, qb, nullptr);
+        }
+    }
     for (int i = 0; i < APPLES_T_COUNT; ++i) ctx->t_ms[i] = 0;
     for (int64_t i = 0; i < n_sub; ++i) {
         hipEvent_t *e = &ev[(size_t)i * 8];
@@ -2202,7 +2262,7 @@ void apples_ctx_destroy(apples_ctx *ctx) {
     ctx->blk_cache.clear();
     dev_free(ctx->d_exotic);
     dev_free(ctx->d_slice_cnt);
-    dev_free(ctx->cl_ints); dev_free(ctx->cl_items); dev_free(ctx->cl_tiles); dev_free(ctx->cl_big_scr); dev_free(ctx->sd_rep_d); dev_free(ctx->blk_pool); dev_free(ctx->blk_ints); dev_free(ctx->blk_tiles);
+    dev_free(ctx->cl_ints); dev_free(ctx->cl_items); dev_free(ctx->cl_tiles); dev_free(ctx->cl_big_scr); dev_free(ctx->d_rag); dev_free(ctx->sd_rep_d); dev_free(ctx->blk_pool); dev_free(ctx->blk_ints); dev_free(ctx->blk_tiles);
     for (auto &e : ctx->ev_feed) (void)hipEventDestroy(e);
     free_workspace(ctx->ws);
     DevTree &t = ctx->tree;
@@ -2776,7 +2836,7 @@ int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n) {
 
 const char *apples_describe(apples_ctx *ctx) {
     hipDeviceProp_t prop;
-    char buf[2048];
+    char buf[2560];
     const char *name = "?";
     int cus = 0;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) { name = prop.name; cus = prop.multiProcessorCount; }
@@ -2784,13 +2844,17 @@ const char *apples_describe(apples_ctx *ctx) {
     int32_t blk_cnt[3] = {0, 0, 0};  // clade blocks, the last device batch: (query, cluster) items, -, tiles
     if (ctx->blk_counters && hipStreamSynchronize(ctx->stream) == hipSuccess)
         (void)hipMemcpy(blk_cnt, ctx->blk_counters, sizeof blk_cnt, hipMemcpyDeviceToHost);
+    int32_t big_used = 0;  // ragged rows (common.h, Workspace::ragged): the big rows the last device batch handed out
+    if (ctx->ws.ragged && hipStreamSynchronize(ctx->stream) == hipSuccess)
+        (void)hipMemcpy(&big_used, ctx->ws.cls_count + 22, sizeof big_used, hipMemcpyDeviceToHost);
     snprintf(buf, sizeof buf,
              "{\"device\": \"%s\", \"compute_units\": %d, \"n_nodes\": %d, \"height\": %d, \"max_children\": %d, \"n_rows\": %lld, "
              "\"n_refs\": %lld, \"n_reps\": %lld, \"length\": %d, \"code_planes\": %d, \"all_singleton\": %d, "
              "\"packed_bytes\": %lld, \"batch\": %lld, \"sweep_workgroups\": %d, \"sweep_team_cap\": %lld, \"sweep_big_workgroups\": %d, \"jc_lut\": %d, \"sweep\": \"%s\", "
              "\"fused_distance_pass\": \"%s\", \"fp4_reference_image_bytes\": %lld, \"sweep_layout\": \"%s\", \"cluster_fused\": %d, "
              "\"scoredist_filter\": %d, \"scoredist_image_bytes\": %lld, \"cluster_blocks\": %d, \"block_items_last_batch\": %d, \"block_tiles_last_batch\": %d, "
-             "\"exotic_symbols_as_gaps\": %d, \"exotic_sites_max_per_row\": %d, \"eight_plane_copy\": %d}",
+             "\"exotic_symbols_as_gaps\": %d, \"exotic_sites_max_per_row\": %d, \"eight_plane_copy\": %d, "
+             "\"ragged_rows\": %d, \"row_small\": %lld, \"big_rows\": %lld, \"big_rows_last_batch\": %d, \"full_rows_for_good\": %d}",
              name, cus, ctx->tree.n_nodes, ctx->tree.height, ctx->tree.max_children, (long long)a.n_rows, (long long)a.n_refs,
              (long long)a.n_reps, a.L, a.planes, a.all_singleton ? 1 : 0,
              (long long)((int64_t)a.G * (a.planes + 1) * a.slots_pad * 16), (long long)ctx->ws.batch, ctx->ws.small.wgs,
@@ -2813,7 +2877,8 @@ const char *apples_describe(apples_ctx *ctx) {
              (int)a.n_blocks, (int)blk_cnt[0], (int)blk_cnt[2],
              // bytes beyond ACGT- (DevAlign::ex_ok): the context keeps them as gaps in its 2-plane rows and fp4 images; the most such
              // sites in one reference row; the 8-plane copy exists (built with the first such byte, in the reference or in a query)
-             a.ex_ok ? 1 : 0, (int)a.ex_max, a.packed8 ? 1 : 0);
+             a.ex_ok ? 1 : 0, (int)a.ex_max, a.packed8 ? 1 : 0,
+             ctx->ws.ragged ? 1 : 0, (long long)ctx->ws.row_small, (long long)ctx->ws.row_big, (int)big_used, ctx->no_ragged ? 1 : 0);
     ctx->desc = buf;
     return ctx->desc.c_str();
 }

@@ -250,6 +250,16 @@ struct Workspace {
     int32_t *cnt_gt = nullptr;    // [batch][height+2]: #observed leaves with level > l, at index l+1
     int32_t *n_obs = nullptr;     // [batch] emitted observed leaves (tree leaves, self removed)
     int64_t obs_cap = 0;
+    // Ragged rows (the clustered fused route on the lean sweep, round 6).  The observation rows and the rows of member distances
+    // (obs_node / obs_dist / dist) are sized for a query that observes every leaf -- 20 bytes x n_refs per query, 4 MB at 200 000
+    // leaves, which is what bounds the device batch -- where the mean query's flat member list is a few thousand entries.  Ragged:
+    // every query of the batch has a row of `row_small` entries at q x row_small; a query whose list is longer (k_select_clusters
+    // phase 2), or that leaves the fast phases (phase 4, k_select), takes one of `row_big` rows of `stride` entries behind them, handed
+    // out by a cursor (cls_count[22]); row_off[q] = where query q's rows start, in entries.  When the big rows run out the queries share
+    // the last one (garbage, in bounds), cls_count[23] is raised and run_block repeats the block with full rows for good (ctx->no_ragged).
+    bool ragged = false;
+    int64_t row_small = 0, row_big = 0;
+    int64_t *row_off = nullptr;   // [batch]
     // sweep scratch.  Small teams (one wavefront per query): `cap` nodes each; big teams (one
     // workgroup per query, for subtrees beyond cap): n_nodes each.
     struct Sweep {
@@ -342,6 +352,8 @@ struct apples_ctx {
     int4 *cl_tiles = nullptr; int64_t cl_tiles_cap = 0;
     int32_t *cl_big_scr = nullptr;  // k_select_clusters' third form: its lists (SELECT_CLUSTERS_BIG_LIST workgroups x 3 x HUGE_CAP)
     bool blk_active = false;   // the device batch under way names block roots in its observation lists (run_block)
+    int32_t *d_rag = nullptr;  // [2] ragged rows: [0] a batch ran out of big rows
+    bool no_ragged = false;    // a block ran out of big rows once (Workspace::ragged): this context keeps full rows from then on
     int32_t *blk_counters = nullptr;  // [3] inside blk_ints: items, work cursor, tiles of the last device batch
     double *blk_pool = nullptr; int64_t blk_pool_cap = 0;   // clade blocks: the batch's tuples, [tile][slot][6][64 lanes] doubles
     int32_t *blk_ints = nullptr; int64_t blk_ints_cap = 0;  // ... per item: storage base (-1: no blocks for it); per query: {first, count} of its items; the items
@@ -422,6 +434,9 @@ int launch_sd_filter(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t 
 int launch_sd_exact(apples_ctx *ctx, const QueryBlock &qb, int64_t q0, int64_t nq, double *seg_d, const int32_t *seg_slot,
                     const int32_t *seg_cnt, int32_t *n_surv);
 // select.hip
+// where query q's row starts (entries): ragged rows (Workspace::ragged) or q x pitch
+__device__ __forceinline__ int64_t row_start(const int64_t *row_off, int64_t q, int64_t pitch) { return row_off ? row_off[q] : q * pitch; }
+
 struct SelectArgs {
     const double *dist;       // [nq][stride]
     int64_t stride;
@@ -436,6 +451,8 @@ struct SelectArgs {
     int baseobs;
     int height;
     int32_t *obs_node; double *obs_dist; int64_t obs_cap; int32_t *cnt_gt; int32_t *n_obs;
+    // ragged rows (Workspace::ragged): where a query's observation row and its row of member distances start; nullptr: q x obs_cap / q x stride
+    int64_t *row_off; int64_t row_small, row_big_base, row_big_pitch; int32_t row_big_n; int32_t *row_big_cursor, *row_fail;
     apples_placement *out;    // [nq]
     // fused fast path (k_jc69 MODE 1 -> k_select_fast)
     const int32_t *seg_slot, *seg_cnt;  // [nq][stride], [nq][stride/64]
@@ -553,6 +570,7 @@ bool exact8_rows(const apples_ctx *ctx, const QueryBlock &qb);  // the bit-plane
 struct SweepArgs {
     DevTree tree;
     const int32_t *obs_node; const double *obs_dist; int64_t obs_cap; const int32_t *cnt_gt; const int32_t *n_obs;
+    const int64_t *row_off;   // ragged rows (Workspace::ragged) or nullptr
     int32_t *grp_off; void *A, *B; double *xe;
     int grp_stride;           // sweep_lean.hip: ints per query / team in grp_off (height + 4; twice that on a tree with polytomies: the child records' offsets)
     uint32_t *map;            // big trees: [teams][n_nodes] tagged node map; nullptr = node bits in LDS
@@ -595,6 +613,7 @@ struct BlockArgs {
     const double2 *rec_c; const int2 *rec_p; const int2 *pk_i; const double *pk_e;  // (polytomies inside blocks: DevAlign::blk_rec_c ...)
     const int32_t *self_slot;                   // [nq] the queries' own rows as slots, or nullptr
     const double *tmp_d; int64_t stride;        // the queries' rows of member distances
+    const int64_t *row_off;                     // ... ragged (Workspace::ragged) or nullptr
     double *pool;                               // [slot][6][64 lanes]; a tile's slot 0: the lanes' best edges inside the blocks (key, x1, x2,
                                                 // err, e, (x1 is the int 0, edge)), its slots 1 ..: the tuples of the cluster's block-internal nodes
     const int32_t *item_sbase, *item_bad;       // [items] first slot x 64 + lane (-1: none); 1: the item goes without blocks
@@ -611,6 +630,7 @@ struct ScanArgs {
     int32_t euler_len;
     int32_t n_nodes, height;
     const int32_t *obs_node; const double *obs_dist; int64_t obs_cap; const int32_t *n_obs;
+    const int64_t *row_off;   // ragged rows (Workspace::ragged) or nullptr
     double *ent_f; int32_t *ent_i; double *xe; uint16_t *leaf_g; int32_t *meta;
     int64_t cap;              // entries of scratch per team
     int64_t leaf_cap;         // leaves a team's global leaf-state area holds (0: none)

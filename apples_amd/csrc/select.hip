@@ -135,6 +135,19 @@ __device__ __forceinline__ void enlist(const SelectArgs &a, int64_t q, int ne) {
 #ifndef SELECT_E
 #define SELECT_E 8  // slots per thread and round of the compaction pass (their loads are in flight together; 16: no faster)
 #endif
+// Ragged rows (common.h, Workspace::ragged): query q takes one of the big rows -- its flat member list is longer than a small row, or it
+// leaves the fast phases for the top-up rule / the general selection, whose lists may grow to every leaf.  One thread per query.
+// False: none left -- the query is marked (row_off = -1: every later phase leaves it alone, nothing is swept for it) and row_fail is
+// raised: run_block repeats the block with full rows.
+__device__ __forceinline__ bool row_make_big(const SelectArgs &a, int64_t q) {
+    if (!a.row_off || a.row_off[q] >= a.row_big_base) return true;
+    if (a.row_off[q] < 0) return false;
+    const int k = atomicAdd(a.row_big_cursor, 1);
+    if (k >= a.row_big_n) { a.row_off[q] = -1; *a.row_fail = 1; a.n_obs[q] = 0; return false; }
+    a.row_off[q] = a.row_big_base + (int64_t)k * a.row_big_pitch;
+    return true;
+}
+
 template <int TPB>
 __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
     constexpr int NW = TPB / WAVE;
@@ -148,6 +161,13 @@ __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
     for (int64_t r = blockIdx.x; r < n_list; r += gridDim.x) {
     const int64_t q = a.qlist ? a.qlist[r] : r;
     const int tid = threadIdx.x;
+    if (a.row_off) {  // (ragged rows: this selection's list may name every leaf)
+        if (tid == 0) sh_i[0] = row_make_big(a, q) ? 1 : 0;
+        __syncthreads();
+        const int ok = sh_i[0];
+        __syncthreads();
+        if (!ok) continue;
+    }
     const double *row = a.dist + (a.rows_by_query ? q : r) * a.stride;
     const int32_t *gather = a.gather;
     const int64_t nm = a.n_members;
@@ -182,8 +202,8 @@ __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
     double z_d = INF_D;
     int z_i = 0x7fffffff, z_p = 0x7fffffff;
     int64_t z_s = -1;  // the slot of that first zero (its node is looked up once, at the end)
-    int32_t *o_node = a.obs_node + q * a.obs_cap;
-    double *o_dist = a.obs_dist + q * a.obs_cap;
+    int32_t *o_node = a.obs_node + row_start(a.row_off, q, a.obs_cap);
+    double *o_dist = a.obs_dist + row_start(a.row_off, q, a.obs_cap);
     int32_t *cg = a.cnt_gt ? a.cnt_gt + q * (int64_t)(a.height + 2) : nullptr;
     for (int round = 0; round < 2; ++round) {
     // ---- top-up: smallest (d, i) beyond the threshold until baseobs observations -------------------
@@ -717,9 +737,17 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     uint16_t *pre = reinterpret_cast<uint16_t *>(dyn_bits + n_words);
     double *reprow = reinterpret_cast<double *>(dyn_bits + n_words + (n_words + 3) / 4);  // phase 4: the query's distance to every representative
     const int self = a.self_slot ? a.self_slot[q] : -1;
-    int32_t *o_node = a.obs_node + q * a.obs_cap;
-    double *o_dist = a.obs_dist + q * a.obs_cap;
-    double *tmp = a.tmp_d + q * a.stride;
+    if (a.row_off) {
+        if (PHASE == 4) {  // (ragged rows: the top-up rule may add clusters up to every leaf)
+            if (threadIdx.x == 0) sh_znode = row_make_big(a, q) ? 1 : 0;
+            __syncthreads();
+            if (!sh_znode) return;
+            __syncthreads();
+        } else if (PHASE != 1 && a.row_off[q] < 0) return;  // (phase 1 found no big row for it: row_make_big)
+    }
+    int32_t *o_node = a.obs_node + row_start(a.row_off, q, a.obs_cap);
+    double *o_dist = a.obs_dist + row_start(a.row_off, q, a.obs_cap);
+    double *tmp = a.tmp_d + row_start(a.row_off, q, a.stride);
     auto to_slow = [&](int known_obs) {  // known_obs: the observations inside the threshold if they were counted, else -1
         if (tid == 0) {
             const int at = atomicAdd(a.slow_count, 1);
@@ -847,6 +875,16 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
         return;
     }
     if (PHASE == 1) {  // one more query for every accepted cluster
+        if (a.row_off) {  // (ragged rows: a flat member list longer than a small row takes a big one, here, before anything is counted)
+            int mine = 0;
+            for (int k = tid; k < n_acc; k += TPB) mine += a.rep_moff[sh_rep[k] + 1] - a.rep_moff[sh_rep[k]];
+            const int m_all = block_sum<NW>(mine, sh_i);
+            if (m_all > a.row_small) {
+                if (tid == 0) sh_znode = row_make_big(a, q) ? 1 : 0;
+                __syncthreads();
+                if (!sh_znode) return;
+            }
+        }
         for (int k = tid; k < n_acc; k += TPB) atomicAdd(&a.cl_count[sh_rep[k]], 1);
         return;
     }
@@ -1385,7 +1423,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist(SelectArgs a) {
                     if (j < nqt) {
 #endif
                         const double d = a.seg_lut[(int64_t)nv[k] * (nv[k] + 1) / 2 + nmis[k]];
-                        a.tmp_d[(int64_t)sh_q[j] * a.stride + sh_o[j] + mc0 + ml] = d;
+                        a.tmp_d[row_start(a.row_off, sh_q[j], a.stride) + sh_o[j] + mc0 + ml] = d;
                         // clade blocks: a member the reference drops, an exact match or the query's own row -- the item goes without
                         if (a.item_bad && (!(d > 0) || (a.self_slot && a.mem_slot[mb + mc0 + ml] == a.self_slot[sh_q[j]]))) a.item_bad[tile.y + j] = 1;
                     }
@@ -1551,7 +1589,7 @@ __global__ __launch_bounds__(WAVE, CLM_WAVES) void k_cluster_dist_mfma(SelectArg
 #else
                         if (jq < nqt && m_in) {
 #endif
-                            a.tmp_d[(int64_t)sh_q[jq] * a.stride + sh_o[jq] + mc0 + m] = d[x];
+                            a.tmp_d[row_start(a.row_off, sh_q[jq], a.stride) + sh_o[jq] + mc0 + m] = d[x];
                             // clade blocks: a member the reference drops, an exact match or the query's own row -- the item goes without
                             if (a.item_bad && (!(d[x] > 0) || my_slot == sh_self[jq])) a.item_bad[tile.y + jq] = 1;
                         }
@@ -1640,7 +1678,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_cluster_dist_sd(SelectArgs a) {
                         if (0 >= r1) d = -1.0;
                         else d = -log_libm(r1) * 1.3;
                     }
-                    a.tmp_d[qi[k] * a.stride + sh_o[j] + m] = d;
+                    a.tmp_d[row_start(a.row_off, qi[k], a.stride) + sh_o[j] + m] = d;
                     if (a.item_bad && (!(d > 0) || (a.self_slot && slot == a.self_slot[qi[k]]))) a.item_bad[tile.y + j] = 1;  // (as k_cluster_dist)
                 }
             }
@@ -1711,7 +1749,7 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (a.blk_tiles) {
         BlockArgs bb{};
         bb.tiles = a.blk_tiles; bb.n_tiles = a.blk_ntiles; bb.items = a.cl_items; bb.rec_i = a.blk_rec_i; bb.rec_e = a.blk_rec_e; bb.rec_c = a.blk_rec_c; bb.stat = a.blk_stat;
-        bb.rep_soff = a.rep_soff; bb.rep_moff = a.rep_moff; bb.slot_rep = a.slot_rep; bb.slot_mpos = a.slot_mpos; bb.self_slot = a.self_slot; bb.tmp_d = a.tmp_d;
+        bb.rep_soff = a.rep_soff; bb.rep_moff = a.rep_moff; bb.slot_rep = a.slot_rep; bb.slot_mpos = a.slot_mpos; bb.self_slot = a.self_slot; bb.tmp_d = a.tmp_d; bb.row_off = a.row_off;
         bb.stride = a.stride; bb.pool = a.blk_pool; bb.item_sbase = a.item_sbase; bb.item_bad = a.item_bad; bb.cursor = a.q_item_cursor + 1; bb.method = a.method;
         hipStream_t bs = ctx->stream_big;
         HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_blk[0], 0));

@@ -439,9 +439,9 @@ __device__ void sweep_team(const SweepArgs &a, int64_t nq, SweepShared &sh) {
         const int n = a.n_obs[q];
         if (n == 0) continue;
         if (TEAM == WAVE && !a.work_list && !a.cls_list && n > a.big_threshold) continue;  // listed for a workgroup-sized team
-        const int32_t *o_node = a.obs_node + q * a.obs_cap;
+        const int32_t *o_node = a.obs_node + row_start(a.row_off, q, a.obs_cap);
         cur_obs = o_node;
-        const double *o_dist = a.obs_dist + q * a.obs_cap;
+        const double *o_dist = a.obs_dist + row_start(a.row_off, q, a.obs_cap);
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
 
         // ------------------------------------------------------------ bottom-up: mark + S values

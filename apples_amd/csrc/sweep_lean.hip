@@ -1089,8 +1089,8 @@ __device__ void lean_up_loop(const SweepArgs &a, LeanUpShared &sh, const double 
         const int64_t q = lean_queue_at(a, qu, w);
         const int n = a.n_obs[q];
         if (n == 0) continue;
-        const int32_t *o_node = a.obs_node + q * a.obs_cap;
-        const double *o_dist = a.obs_dist + q * a.obs_cap;
+        const int32_t *o_node = a.obs_node + row_start(a.row_off, q, a.obs_cap);
+        const double *o_dist = a.obs_dist + row_start(a.row_off, q, a.obs_cap);
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
         // the query's share of the pool (one atomic add per query); out of pool = the workgroup-sized teams take it
         const int qcap = lean_query_cap(n);
@@ -1586,8 +1586,8 @@ __device__ void lean_big_loop(const SweepArgs &a, int64_t nq, LeanBigShared<TEAM
         else q = a.work_list ? a.work_list[w] : w;
         const int n = a.n_obs[q];
         if (n == 0) continue;
-        const int32_t *o_node = a.obs_node + q * a.obs_cap;
-        const double *o_dist = a.obs_dist + q * a.obs_cap;
+        const int32_t *o_node = a.obs_node + row_start(a.row_off, q, a.obs_cap);
+        const double *o_dist = a.obs_dist + row_start(a.row_off, q, a.obs_cap);
         const int32_t *cg = a.cnt_gt + q * (int64_t)(T.height + 2);
         const int lvl_first = T.level[o_node[0]];
         int wlo = deep ? max(0, lvl_first + 2 - LEAN_MAX_LEVELS) : 0;
@@ -1801,7 +1801,7 @@ __global__ __launch_bounds__(APPLES_TPB) void k_blocks_up(BlockArgs a) {
         // (which of the tile's items go without blocks -- a member the reference drops, an exact match, the query's own row -- is
         // k_cluster_dist's finding, item_bad: this kernel forms every lane's tuples, so that it can run beside the selection's last phase)
         const int64_t q = it.x;
-        const double *dbase = a.tmp_d + q * a.stride + it.y;
+        const double *dbase = a.tmp_d + row_start(a.row_off, q, a.stride) + it.y;
         const int rb = a.rep_soff[c], ns = a.rep_soff[c + 1] - rb;
         double *pool = a.pool + ((int64_t)tile.w + 1) * 384 + lane;  // (slot 0 of the tile: the lanes' best edges, k_blocks_down)
         // the members' distances as [member][lane] behind the tuples: a lane reads its query's row eight values (a sector) at a

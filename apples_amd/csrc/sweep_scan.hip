@@ -168,8 +168,8 @@ __device__ void scan_team(const ScanArgs &a, int64_t nq, ScanShared &sh) {
         const int n = a.n_obs[q];
         if (n == 0) continue;
         if (TEAM == WAVE && !a.work_list && !a.cls_list && n > a.big_threshold) continue;  // listed for a workgroup-sized team
-        const int32_t *o_node = a.obs_node + q * a.obs_cap;
-        const double *o_dist = a.obs_dist + q * a.obs_cap;
+        const int32_t *o_node = a.obs_node + row_start(a.row_off, q, a.obs_cap);
+        const double *o_dist = a.obs_dist + row_start(a.row_off, q, a.obs_cap);
         if (n < 2) continue;
         stamp(0);
         // (a wavefront-sized team always has its leaves in LDS: plain ds_read/ds_write; a workgroup-sized team

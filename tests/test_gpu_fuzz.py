@@ -34,7 +34,10 @@ def _place(routes, make, queries, place='place_sequences'):
     """placements per route: make(debug) -> Engine"""
     out = {}
     for name, dbg in routes:
-        e = make(dbg)
+        if isinstance(dbg, dict):  # (a route by knobs of the context: make(debug, knobs))
+            e = make((), dbg)
+        else:
+            e = make(dbg)
         out[name] = getattr(e, place)(*queries) if isinstance(queries, tuple) else getattr(e, place)(queries)
         e.close()
     return out
@@ -82,7 +85,11 @@ def test_clustered_routes_agree(seed):
     round-3 `k_select` fault."""
     rng = np.random.default_rng(seed)
     routes = (('default', ()), ('by_query', ('cluster_by_query',)), ('no_topup', ('no_cluster_topup',)), ('no_fuse', ('no_fuse',)),
-              ('no_blocks', ('no_blocks',)), ('hybrid_records', ('hybrid_records',)), ('no_cluster_mfma', ('no_cluster_mfma',)))
+              ('no_blocks', ('no_blocks',)), ('hybrid_records', ('hybrid_records',)), ('no_cluster_mfma', ('no_cluster_mfma',)),
+              # ragged rows (csrc/common.h, Workspace::ragged; by default for references of 65 536 rows and more): small rows of 32
+              # entries, so that most queries move to a big row; and two big rows only, so that a device batch runs out of them and
+              # the block is placed once more with full rows
+              ('ragged', {'APPLES_RAGGED_SMALL': 32}), ('ragged_dry', {'APPLES_RAGGED_SMALL': 32, 'APPLES_RAGGED_BIG': 2}))
     checked = 0
     for c in range(NCFG):  # (seed 1, first 30 configurations: the round-3 script run that found the fault)
         n = int(rng.choice([60, 257, 600, 1500, 5000, 12000])); L = int(rng.integers(40, 2047)); nq = int(rng.integers(1, 900))
@@ -93,11 +100,11 @@ def test_clustered_routes_agree(seed):
         nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
         ca = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, diam)).cluster_arrays()
         crit, neg = _crit(seed, c)
-        out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method=m, criterion=crit, negative=neg,
-                                                threshold=thr, baseobs=b, max_batch=mb, debug=dbg), d.query_seqs)
+        out = _place(routes, lambda dbg, knobs=None: Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method=m, criterion=crit, negative=neg,
+                                                            threshold=thr, baseobs=b, max_batch=mb, debug=dbg, knobs=knobs), d.query_seqs)
         tag = shp + ' seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s diam %g' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit,
                                                                                           ' -n' if neg else '', diam)
-        for k in ('by_query', 'no_topup', 'no_fuse', 'no_blocks', 'hybrid_records', 'no_cluster_mfma'):
+        for k in ('by_query', 'no_topup', 'no_fuse', 'no_blocks', 'hybrid_records', 'no_cluster_mfma', 'ragged', 'ragged_dry'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
             co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method=m, criterion=crit, negative=neg, threshold=thr, baseobs=b,
@@ -209,7 +216,7 @@ def test_clustered_scoredist_routes_agree(seed):
     for every query (round 3's route, the only one before round 5); small backbones also against the C oracle."""
     rng = np.random.default_rng(seed)
     routes = (('default', ()), ('no_topup', ('no_cluster_topup',)), ('no_big', ('no_cluster_big',)), ('no_fuse', ('no_fuse',)),
-              ('no_blocks', ('no_blocks',)))
+              ('no_blocks', ('no_blocks',)), ('ragged', {'APPLES_RAGGED_SMALL': 32}), ('ragged_dry', {'APPLES_RAGGED_SMALL': 32, 'APPLES_RAGGED_BIG': 2}))
     checked = ties = 0
     for c in range(NCFG):
         n = int(rng.choice([60, 257, 600, 1500, 5000, 12000])); L = int(rng.integers(7, 1200)); nq = int(rng.integers(1, 700))
@@ -225,11 +232,11 @@ def test_clustered_scoredist_routes_agree(seed):
         nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
         ca = ReducedReference(Alignment(d.ref_names, d.ref_seqs), True, treecluster.grouped(d.tree, diam)).cluster_arrays()
         crit, neg = _crit(seed, c)
-        out = _place(routes, lambda dbg: Engine(d.tree, d.ref_seqs, nodes, clusters=ca, protein=True, method=m, criterion=crit,
-                                                negative=neg, threshold=thr, baseobs=b, max_batch=mb, debug=dbg), q)
+        out = _place(routes, lambda dbg, knobs=None: Engine(d.tree, d.ref_seqs, nodes, clusters=ca, protein=True, method=m, criterion=crit,
+                                                            negative=neg, threshold=thr, baseobs=b, max_batch=mb, debug=dbg, knobs=knobs), q)
         tag = shp + ' seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s diam %g' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit,
                                                                                           ' -n' if neg else '', diam)
-        for k in ('no_topup', 'no_big', 'no_fuse', 'no_blocks'):
+        for k in ('no_topup', 'no_big', 'no_fuse', 'no_blocks', 'ragged', 'ragged_dry'):
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
             co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, protein=True, method=m, criterion=crit, negative=neg, threshold=thr,

@@ -567,3 +567,49 @@ def test_knobs_are_per_context_not_per_process(c2_full):
     e1.close(); e2.close()
     assert a.tobytes() == b.tobytes()
     assert i1['sweep_team_cap'] != i2['sweep_team_cap'], (i1['sweep_team_cap'], i2['sweep_team_cap'])
+
+
+def test_ragged_rows_of_the_clustered_route():
+    """The clustered fused route's rows (csrc/common.h, Workspace::ragged): observation rows and rows of member distances sized for a
+    query that observes every leaf are what bounds its device batch (20 B x leaves per query); from 65 536 reference rows on every query
+    gets a row of 16 384 entries and only the queries whose flat member list is longer, or that leave the fast phases for the top-up
+    rule / the general selection, take one of a few full-size rows.  80 000 leaves x L 200, self rows, exact matches, queries on the
+    top-up rule: the same bytes with ragged rows (the default here), with small rows of 256 entries and a big row for every query (most take one),
+    with a single big row (the block runs out and is placed once more with full rows, for good), without ragged rows; sampled against
+    the C oracle.  A call of another entry point on the same context (full distance rows) reshapes the workspace and back."""
+    import bench
+    nq = 3000
+    d = synth.make_dataset(80000, 200, nq)
+    nodes = np.array([d.tree.name_to_node[n] for n in d.ref_names], np.int32)
+    ca = bench.make_clusters(d, 0.2)
+    q = d.query_seqs.copy()
+    self_rows = np.full(nq, -1, np.int32)
+    q[100:200] = d.ref_seqs[5000:5100]
+    self_rows[100:200] = np.arange(5000, 5100)   # leave-one-out
+    q[200:210] = d.ref_seqs[9000:9010]           # exact matches
+    q[300:320, ::3] = ord('-')                   # fewer valid sites: more of them on the top-up rule
+    kw = dict(clusters=ca, method='OLS', baseobs=40)
+    eng = Engine(d.tree, d.ref_seqs, nodes, **kw)
+    got = eng.place_sequences(q, self_rows)
+    info = eng.describe()
+    assert info['ragged_rows'] == 1 and info['row_small'] == 16384 and info['full_rows_for_good'] == 0 and info['cluster_blocks'] > 0, info
+    batch_ragged = info['batch']
+    _, dist = eng.distances(q[:4], want_counts=False)   # (another entry point: rows of n_slots distances)
+    assert dist.shape[0] == 4 and dist.shape[1] >= 80000
+    assert eng.place_sequences(q, self_rows).tobytes() == got.tobytes()
+    eng.close()
+    for knobs, expect in (({'APPLES_NO_RAGGED': 1}, dict(ragged_rows=0)), ({'APPLES_RAGGED_SMALL': 256, 'APPLES_RAGGED_BIG': 3100}, dict(ragged_rows=1, row_small=256, full_rows_for_good=0)),
+                          ({'APPLES_RAGGED_SMALL': 256, 'APPLES_RAGGED_BIG': 1}, dict(ragged_rows=0, full_rows_for_good=1))):
+        e = Engine(d.tree, d.ref_seqs, nodes, knobs=knobs, **kw)
+        out = e.place_sequences(q, self_rows)
+        i2 = e.describe()
+        e.close()
+        assert out.tobytes() == got.tobytes(), knobs
+        for k, v in expect.items():
+            assert i2[k] == v, (knobs, k, i2)
+        if expect.get('row_small') == 256:
+            assert i2['big_rows_last_batch'] > 100, i2
+    assert batch_ragged >= nq
+    sample = np.concatenate([np.arange(0, nq, 47), np.arange(100, 110), np.arange(200, 210), np.arange(300, 320)])
+    co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method='OLS', baseobs=40, lut=jc69_lut(200, 0.001), threads=len(os.sched_getaffinity(0)))
+    assert got[sample].tobytes() == co.place_sequences(q[sample], self_rows[sample]).tobytes()
