@@ -137,13 +137,20 @@ __device__ __forceinline__ void enlist(const SelectArgs &a, int64_t q, int ne) {
 #endif
 // Ragged rows (common.h, Workspace::ragged): query q takes one of the big rows -- its flat member list is longer than a small row, or it
 // leaves the fast phases for the top-up rule / the general selection, whose lists may grow to every leaf.  One thread per query.
-// False: none left -- the query is marked (row_off = -1: every later phase leaves it alone, nothing is swept for it) and row_fail is
-// raised: run_block repeats the block with full rows.
-__device__ __forceinline__ bool row_make_big(const SelectArgs &a, int64_t q) {
+// False: none left -- nothing is swept for the query (n_obs = 0) and row_fail is raised: run_block repeats the block with full rows.
+// mark (phase 1 of k_select_clusters, before the query has joined any list): row_off = -1, the later phases leave the query alone.
+// Later callers (phase 4, k_select) leave the row where it is: the query's items are in its clusters' lists by then and
+// k_blocks_up, which may run beside them, reads the member distances of every item through row_off.
+__device__ __forceinline__ bool row_make_big(const SelectArgs &a, int64_t q, bool mark) {
     if (!a.row_off || a.row_off[q] >= a.row_big_base) return true;
     if (a.row_off[q] < 0) return false;
     const int k = atomicAdd(a.row_big_cursor, 1);
-    if (k >= a.row_big_n) { a.row_off[q] = -1; *a.row_fail = 1; a.n_obs[q] = 0; return false; }
+    if (k >= a.row_big_n) {
+        if (mark) a.row_off[q] = -1;
+        *a.row_fail = 1;
+        a.n_obs[q] = 0;
+        return false;
+    }
     a.row_off[q] = a.row_big_base + (int64_t)k * a.row_big_pitch;
     return true;
 }
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(TPB) void k_select(SelectArgs a) {
     const int64_t q = a.qlist ? a.qlist[r] : r;
     const int tid = threadIdx.x;
     if (a.row_off) {  // (ragged rows: this selection's list may name every leaf)
-        if (tid == 0) sh_i[0] = row_make_big(a, q) ? 1 : 0;
+        if (tid == 0) sh_i[0] = row_make_big(a, q, false) ? 1 : 0;
         __syncthreads();
         const int ok = sh_i[0];
         __syncthreads();
@@ -739,7 +746,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     const int self = a.self_slot ? a.self_slot[q] : -1;
     if (a.row_off) {
         if (PHASE == 4) {  // (ragged rows: the top-up rule may add clusters up to every leaf)
-            if (threadIdx.x == 0) sh_znode = row_make_big(a, q) ? 1 : 0;
+            if (threadIdx.x == 0) sh_znode = row_make_big(a, q, false) ? 1 : 0;
             __syncthreads();
             if (!sh_znode) return;
             __syncthreads();
@@ -880,7 +887,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
             for (int k = tid; k < n_acc; k += TPB) mine += a.rep_moff[sh_rep[k] + 1] - a.rep_moff[sh_rep[k]];
             const int m_all = block_sum<NW>(mine, sh_i);
             if (m_all > a.row_small) {
-                if (tid == 0) sh_znode = row_make_big(a, q) ? 1 : 0;
+                if (tid == 0) sh_znode = row_make_big(a, q, true) ? 1 : 0;
                 __syncthreads();
                 if (!sh_znode) return;
             }
@@ -1691,6 +1698,7 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     // the slot bitmap and its 16-bit in-run prefixes (runs of 16 words: 262 144 slots); with clade blocks over emission indices
     size_t dyn = (size_t)(((a.e_of_slot ? std::max(a.n_e, a.n_members) : a.n_members) + 63) >> 6) * 10;
     if (a.e_of_slot) dyn = std::max<size_t>(dyn, 1024 * 16 + (SELECT_CLUSTERS_ACC_CAP + 1) * 4);  // (the short form's list lives in the bitmap's memory)
+    dyn += (size_t)knob(ctx, "APPLES_SELECT_LDS_PAD_KB", 0) * 1024;  // experiment knob: fewer workgroups per CU in the last phase
     const bool sd = a.aa_idx != nullptr;  // scoredist context: k_cluster_dist_sd computes the member distances (no by-query form)
     const bool by_query = (ctx->dbg & APPLES_DBG_CLUSTER_BY_QUERY) != 0 && !sd;  // diagnostic switch: phase 0 alone
     if (dyn > 48 * 1024) {  // (beyond the default allowance of dynamic LDS -- references of more than ~300 000 slots; per device, so asked for at every launch)

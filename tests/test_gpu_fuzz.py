@@ -33,7 +33,12 @@ EXTRA_SEEDS = list(range(int(_extra.split('-')[0]), int(_extra.split('-')[1]) + 
 def _place(routes, make, queries, place='place_sequences'):
     """placements per route: make(debug) -> Engine"""
     out = {}
+    only = os.environ.get('APPLES_FUZZ_ROUTES')  # (chasing a crash: "default,ragged_dry")
     for name, dbg in routes:
+        if only and name not in only.split(','):
+            continue
+        if os.environ.get('APPLES_FUZZ_TRACE'):  # (a campaign's crash: which route of which configuration)
+            print('route', name, file=sys.stderr, flush=True)
         if isinstance(dbg, dict):  # (a route by knobs of the context: make(debug, knobs))
             e = make((), dbg)
         else:
@@ -100,11 +105,17 @@ def test_clustered_routes_agree(seed):
         nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
         ca = ReducedReference(Alignment(d.ref_names, d.ref_seqs), False, treecluster.grouped(d.tree, diam)).cluster_arrays()
         crit, neg = _crit(seed, c)
+        if os.environ.get('APPLES_FUZZ_TRACE'):
+            print('cfg', seed, c, n, L, nq, gap, thr, b, mb, m, crit, neg, diam, shp, file=sys.stderr, flush=True)
+        if os.environ.get('APPLES_FUZZ_ONLY') and c != int(os.environ['APPLES_FUZZ_ONLY']):
+            continue
         out = _place(routes, lambda dbg, knobs=None: Engine(d.tree, d.ref_seqs, nodes, clusters=ca, method=m, criterion=crit, negative=neg,
                                                             threshold=thr, baseobs=b, max_batch=mb, debug=dbg, knobs=knobs), d.query_seqs)
         tag = shp + ' seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s diam %g' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit,
                                                                                           ' -n' if neg else '', diam)
         for k in ('by_query', 'no_topup', 'no_fuse', 'no_blocks', 'hybrid_records', 'no_cluster_mfma', 'ragged', 'ragged_dry'):
+            if k not in out:
+                continue
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
             co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, method=m, criterion=crit, negative=neg, threshold=thr, baseobs=b,
@@ -232,11 +243,17 @@ def test_clustered_scoredist_routes_agree(seed):
         nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
         ca = ReducedReference(Alignment(d.ref_names, d.ref_seqs), True, treecluster.grouped(d.tree, diam)).cluster_arrays()
         crit, neg = _crit(seed, c)
+        if os.environ.get('APPLES_FUZZ_TRACE'):
+            print('cfg', seed, c, n, L, nq, gap, thr, b, mb, m, crit, neg, diam, shp, file=sys.stderr, flush=True)
+        if os.environ.get('APPLES_FUZZ_ONLY') and c != int(os.environ['APPLES_FUZZ_ONLY']):
+            continue
         out = _place(routes, lambda dbg, knobs=None: Engine(d.tree, d.ref_seqs, nodes, clusters=ca, protein=True, method=m, criterion=crit,
                                                             negative=neg, threshold=thr, baseobs=b, max_batch=mb, debug=dbg, knobs=knobs), q)
         tag = shp + ' seed %d cfg %d: n %d L %d nq %d gap %g thr %g b %d batch %d %s %s%s diam %g' % (seed, c, n, L, nq, gap, thr, b, mb, m, crit,
                                                                                           ' -n' if neg else '', diam)
         for k in ('no_topup', 'no_big', 'no_fuse', 'no_blocks', 'ragged', 'ragged_dry'):
+            if k not in out:
+                continue
             assert out[k].tobytes() == out['default'].tobytes(), '%s: default vs %s: %s' % (tag, k, _diff(out['default'], out[k]))
         if n <= 1500:
             co = COracle(d.tree, d.ref_seqs, nodes, clusters=ca, protein=True, method=m, criterion=crit, negative=neg, threshold=thr,
