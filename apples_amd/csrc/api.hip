@@ -1732,7 +1732,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
                                       !(ctx->dbg & APPLES_DBG_NO_CLUSTER_BIG);  // (diagnostic switch: queries beyond ACC_CAP clusters to the general route)
                 if (big_form && a.n_reps > SELECT_CLUSTERS_BIG_CAP && !ctx->cl_big_scr &&
                     dev_alloc(ctx, &ctx->cl_big_scr, (int64_t)SELECT_CLUSTERS_BIG_LIST * 3 * SELECT_CLUSTERS_HUGE_CAP)) return 1;
-                const int64_t n_ints = 3 * (int64_t)a.n_reps + 8 + SELECT_CLUSTERS_BIG_LIST + 8,
+                const int64_t n_ints = 3 * (int64_t)a.n_reps + 8 + SELECT_CLUSTERS_BIG_LIST + 8 + nq + 32,  // (... + the short-form launch's list, its count in front)
                               n_items = nq * SELECT_CLUSTERS_ACC_CAP + (big_form ? std::min<int64_t>(nq, SELECT_CLUSTERS_BIG_LIST) * a.n_reps : 0),
                               n_tiles = n_items / SELECT_CLUSTERS_MIN_TILE + a.n_reps + 1;
                 if (n_ints > ctx->cl_ints_cap) {
@@ -1755,6 +1755,7 @@ int run_block_main(apples_ctx *ctx, QueryBlock &qb, const Feeder *feed) {
                 sa.big_count = big_form ? sa.cl_ntiles + 4 : nullptr;
                 sa.big_list = big_form ? sa.cl_ntiles + 8 : nullptr;
                 sa.big_scr = ctx->cl_big_scr;
+                sa.gen_count = sa.cl_ntiles + 8 + SELECT_CLUSTERS_BIG_LIST + 8; sa.gen_list = sa.gen_count + 8;
                 sa.cl_items = ctx->cl_items; sa.cl_tiles = ctx->cl_tiles; sa.cl_tiles_cap = ctx->cl_tiles_cap;
             }
             // clade blocks (build_blocks): the sweep inside whole subtrees of one cluster on a static schedule, cluster-major

@@ -505,6 +505,7 @@ struct SelectArgs {
     // and where it forwards what it cannot serve (then full rows + k_select)
     const uint4 *rep_panel; int32_t *slow2_list, *slow2_count;
     int32_t *big_list, *big_count;  // queries with more than ACC_CAP accepted clusters: served by the phases' second form (CAP = BIG_CAP)
+    int32_t *gen_list, *gen_count;  // phase 3 with clade blocks: the queries the short-form launch leaves to the general form (k_select_clusters, SHORT_ONLY)
     int32_t *big_scr;  // the third form's lists (CAP = HUGE_CAP): 3 x HUGE_CAP ints per workgroup of its launches
     // scoredist contexts on that path (k_cluster_dist_sd, phase 4): the representatives' distances come as full rows (the survivors
     // in seg_slot carry their position only), the members' from the packed residue bytes

@@ -700,7 +700,11 @@ __device__ __forceinline__ void cluster_count(const uint4 &rm, const uint4 &r0, 
 //   size: observed sets of tens of thousands) are listed by phase 1 and go through the same phases once more with CAP = BIG_CAP,
 //   a workgroup per list entry (LISTED; 60 KB of lists, so one workgroup per CU: a launch of their own keeps that occupancy
 //   and their long rounds away from the other 99 %).
-template <int PHASE, int CAP = SELECT_CLUSTERS_ACC_CAP, bool LISTED = (PHASE == 4), int TPB = APPLES_TPB>
+//   SHORT_ONLY (phase 3 of a context with clade blocks): the launch over all queries serves the short form alone -- 18 KB of dynamic
+//   LDS instead of the bitmap's 33 at 200 000 leaves: five workgroups per CU where the general form has three, and the phase is a
+//   chain of dependent look-ups (its time follows the occupancy: + 1.1 ms per pass with two per CU) -- and lists the queries that need
+//   the general form (a.gen_list), which a LISTED launch takes right behind it.
+template <int PHASE, int CAP = SELECT_CLUSTERS_ACC_CAP, bool LISTED = (PHASE == 4), int TPB = APPLES_TPB, bool SHORT_ONLY = false>
 __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     constexpr int ACC_CAP = CAP, NW = TPB / WAVE;
     extern __shared__ unsigned long long dyn_bits[];  // [n_words] member bits in slot order, then uint16 [n_words]: the set bits before the
@@ -805,7 +809,7 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
         if (0 >= r1) return -1.0;
         return -log_libm(r1) * 1.3;
     };
-    if (PHASE == 0 || PHASE >= 3)
+    if (!SHORT_ONLY && (PHASE == 0 || PHASE >= 3))
         for (int i = tid; i < n_words; i += TPB) dyn_bits[i] = 0;
     // a member's (or representative's) distance from its words: word (g, plane) at base[(g * 3 + plane) * stride] -- the
     // cluster-major panel with the cluster's size as stride (the lanes holding consecutive members read consecutive 16
@@ -954,7 +958,10 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
     // into a short list in LDS (the bitmap's memory: it is not used), the entries are ranked by counting, and the per-level offsets
     // are counts over the list.  Anything else -- a cluster whose item goes without blocks, an exact match or the query's own row
     // among the members outside the blocks, more than SHORT_CAP entries, fewer than two -- takes the general form below.
-    constexpr int SHORT_CAP = 1024;
+#ifndef SELECT_SHORT_ONLY_CAP
+#define SELECT_SHORT_ONLY_CAP 1024  // entries of the short form's list in the SHORT_ONLY launch (experiments: 512 = eight workgroups per CU)
+#endif
+    constexpr int SHORT_CAP = SHORT_ONLY ? SELECT_SHORT_ONLY_CAP : 1024;
     if (PHASE == 3 && !LISTED && use_blk) {
         double *f_val = reinterpret_cast<double *>(dyn_bits);
         int *f_key = reinterpret_cast<int *>(f_val + SHORT_CAP), *f_node = f_key + SHORT_CAP, *f_off = f_node + SHORT_CAP;  // f_off[ACC_CAP + 1]
@@ -1049,9 +1056,15 @@ __global__ __launch_bounds__(TPB) void k_select_clusters(SelectArgs a) {
             }
         }
         // the general form after all: the bitmap's memory as it expects it (the list's offsets, at least, were written into it)
-        __syncthreads();
-        for (int i = tid; i < n_words; i += TPB) dyn_bits[i] = 0;
-        __syncthreads();
+        if (!SHORT_ONLY) {
+            __syncthreads();
+            for (int i = tid; i < n_words; i += TPB) dyn_bits[i] = 0;
+            __syncthreads();
+        }
+    }
+    if (SHORT_ONLY) {  // (this launch has no bitmap: the LISTED launch behind it takes the query)
+        if (tid == 0) a.gen_list[atomicAdd(a.gen_count, 1)] = (int32_t)q;
+        return;
     }
     if (PHASE == 4) {
         // ---- the members' distances (a thread per member), then Reference.py:144-152: while fewer than `-b` valid member
@@ -1704,6 +1717,8 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
     if (dyn > 48 * 1024) {  // (beyond the default allowance of dynamic LDS -- references of more than ~300 000 slots; per device, so asked for at every launch)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<3, SELECT_CLUSTERS_ACC_CAP, true, APPLES_TPB>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<3, SELECT_CLUSTERS_BIG_CAP, true, 1024>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_clusters<3, SELECT_CLUSTERS_HUGE_CAP, true, 1024>),
@@ -1748,6 +1763,14 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         else hipLaunchKernelGGL((k_select_clusters<3, BIG, true, 1024>), gbig, dim3(1024), dyn, ctx->stream2, b);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_cl[1], ctx->stream2));
     }
+    if (a.e_of_slot && a.gen_list && !knob_on(ctx, "APPLES_NO_SHORT_SPLIT")) {  // (SHORT_ONLY, above; the knob: one launch as before, diagnostic)
+        const size_t dyn_short = SELECT_SHORT_ONLY_CAP * 16 + (SELECT_CLUSTERS_ACC_CAP + 1) * 4;
+        SelectArgs g = a;
+        g.qlist = a.gen_list; g.qcount = a.gen_count;
+        HIP_TRY(ctx, hipMemsetAsync(a.gen_count, 0, sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL((k_select_clusters<3, SELECT_CLUSTERS_ACC_CAP, false, APPLES_TPB, true>), dim3((unsigned)nq), dim3(APPLES_TPB), dyn_short, ctx->stream, a);
+        hipLaunchKernelGGL((k_select_clusters<3, SELECT_CLUSTERS_ACC_CAP, true, APPLES_TPB>), dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, g);
+    } else
     hipLaunchKernelGGL(k_select_clusters<3>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
     // clade blocks: the S tuples inside them (k_blocks_up), on the sweep's side stream beside the last phase, which names their
     // roots in the observation lists.  Which items go without blocks is k_cluster_dist's finding (item_bad), where their tuples will
