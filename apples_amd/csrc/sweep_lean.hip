@@ -42,6 +42,11 @@
 #ifndef LEAN_UP_WAVES
 #define LEAN_UP_WAVES 3
 #endif
+#ifndef LEAN_UP_WAVES_PL
+#define LEAN_UP_WAVES_PL 2  // ... of the bottom-up kernel's instantiation for trees with polytomies: its merge keeps more alive -- 368 bytes of
+                            // scratch per lane at three (48 without polytomies); at two, config 3's tree with 1 % polytomies sweeps in 18.95 ms
+                            // against 20.29, unrooted 17.6 against 18.1 (profiles/r06_pl_waves_exp.txt)
+#endif
 #ifndef LEAN_DOWN_WAVES
 #define LEAN_DOWN_WAVES 3
 #endif
@@ -1691,7 +1696,7 @@ void launch_lean_big_t(const SweepArgs &a, int64_t nq, dim3 grid, hipStream_t st
 }
 
 template <int M, bool PL = false>
-__global__ __launch_bounds__(APPLES_TPB, LEAN_UP_WAVES) void k_lean_up(SweepArgs a) {
+__global__ __launch_bounds__(APPLES_TPB, PL ? LEAN_UP_WAVES_PL : LEAN_UP_WAVES) void k_lean_up(SweepArgs a) {
     __shared__ LeanUpShared sh;
     lean_up_loop<M, false, PL>(a, sh);
 }
@@ -2214,7 +2219,8 @@ int launch_sweep_lean(apples_ctx *ctx, const SweepArgs &up, const SweepArgs &dow
     const int wg_down = (int)knob(ctx, "APPLES_LEAN_DOWN_WGS", 0);
     const int64_t need = (nq + 3) / 4;
     const dim3 block(APPLES_TPB);
-    const dim3 gu((unsigned)std::min<int64_t>(need, wg_up > 0 ? wg_up : cus * LEAN_UP_WAVES * 3 / 2));
+    const bool pl_up = up.tree.max_children > 2 || up.tree.force_poly == 1 || up.tree.force_poly == 2;  // (k_lean_up<M, true>)
+    const dim3 gu((unsigned)std::min<int64_t>(need, wg_up > 0 ? wg_up : cus * (pl_up ? LEAN_UP_WAVES_PL : LEAN_UP_WAVES) * 3 / 2));
     const dim3 gd((unsigned)std::min<int64_t>(need, wg_down > 0 ? wg_down : cus * LEAN_DOWN_WAVES * 3 / 2));
     if ((int64_t)gu.x * 4 > up.lean_teams) { ctx->err = "lean sweep: more bottom-up teams than per-leaf scratch"; return 1; }
     // APPLES_LEAN_FUSED=1: one kernel for both passes of a query (k_lean_both), the team's top-down pass right behind its bottom-up
