@@ -3,7 +3,7 @@
 # the workgroups a CU holds (1 024: five; 512: eight; 256: eight, more queries left to the general form)
 #   bash scripts/r06_short_cap_exp.sh > gpurun_out/r06_short_cap_exp.txt
 cd $GRAFT_REPO_ROOT
-for CAP in 1024 512 256; do
+for CAP in ${CAPS:-1024 512 256}; do
   APPLES_EXTRA_HIPCC_FLAGS="-DSELECT_SHORT_ONLY_CAP=$CAP" python -c "
 import os
 os.utime('apples_amd/csrc/select.hip')
