@@ -1763,6 +1763,29 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         else hipLaunchKernelGGL((k_select_clusters<3, BIG, true, 1024>), gbig, dim3(1024), dyn, ctx->stream2, b);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_cl[1], ctx->stream2));
     }
+    // clade blocks: the S tuples inside them (k_blocks_up), on the sweep's side stream beside the last phase, which names their
+    // roots in the observation lists.  Which items go without blocks is k_cluster_dist's finding (item_bad), where their tuples will
+    // be is phase 2's arithmetic: the last phase needs nothing of this kernel.  Launched AFTER the last phase: that one's short
+    // workgroups get in first and the persistent ones of k_blocks_up find their places as those retire; the other way round, or
+    // both on one stream, the pass is 0.3 - 0.5 ms longer (profiles/r05_blk_order_exp.txt)
+    auto launch_blk = [&]() -> int {
+        if (a.blk_tiles) {
+            BlockArgs bb{};
+            bb.tiles = a.blk_tiles; bb.n_tiles = a.blk_ntiles; bb.items = a.cl_items; bb.rec_i = a.blk_rec_i; bb.rec_e = a.blk_rec_e; bb.rec_c = a.blk_rec_c; bb.stat = a.blk_stat;
+            bb.rep_soff = a.rep_soff; bb.rep_moff = a.rep_moff; bb.slot_rep = a.slot_rep; bb.slot_mpos = a.slot_mpos; bb.self_slot = a.self_slot; bb.tmp_d = a.tmp_d; bb.row_off = a.row_off;
+            bb.stride = a.stride; bb.pool = a.blk_pool; bb.item_sbase = a.item_sbase; bb.item_bad = a.item_bad; bb.cursor = a.q_item_cursor + 1; bb.method = a.method;
+            hipStream_t bs = ctx->stream_big;
+            HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_blk[0], 0));
+            const bool timed = ctx->ev_blk_time[0] && ctx->ev_blk_time[1];
+            if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[0], bs));
+            if (launch_blocks_up(ctx, bb, bs)) return 1;
+            if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[1], bs)); ctx->ev_blk_time[0] = nullptr; }  // (recorded: run_block reads them)
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[1], bs));
+        }
+        return 0;
+    };
+    const bool blk_first = knob_on(ctx, "APPLES_BLK_FIRST");  // experiment knob: k_blocks_up ahead of the last phase's launches
+    if (blk_first && launch_blk()) return 1;
     if (a.e_of_slot && a.gen_list && !knob_on(ctx, "APPLES_NO_SHORT_SPLIT")) {  // (SHORT_ONLY, above; the knob: one launch as before, diagnostic)
         const size_t dyn_short = SELECT_SHORT_ONLY_CAP * 16 + (SELECT_CLUSTERS_ACC_CAP + 1) * 4;
         SelectArgs g = a;
@@ -1772,24 +1795,7 @@ int launch_select_clusters(apples_ctx *ctx, const SelectArgs &a, int64_t nq) {
         hipLaunchKernelGGL((k_select_clusters<3, SELECT_CLUSTERS_ACC_CAP, true, APPLES_TPB>), dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, g);
     } else
     hipLaunchKernelGGL(k_select_clusters<3>, dim3((unsigned)nq), dim3(APPLES_TPB), dyn, ctx->stream, a);
-    // clade blocks: the S tuples inside them (k_blocks_up), on the sweep's side stream beside the last phase, which names their
-    // roots in the observation lists.  Which items go without blocks is k_cluster_dist's finding (item_bad), where their tuples will
-    // be is phase 2's arithmetic: the last phase needs nothing of this kernel.  Launched AFTER the last phase: that one's short
-    // workgroups get in first and the persistent ones of k_blocks_up find their places as those retire; the other way round, or
-    // both on one stream, the pass is 0.3 - 0.5 ms longer (profiles/r05_blk_order_exp.txt)
-    if (a.blk_tiles) {
-        BlockArgs bb{};
-        bb.tiles = a.blk_tiles; bb.n_tiles = a.blk_ntiles; bb.items = a.cl_items; bb.rec_i = a.blk_rec_i; bb.rec_e = a.blk_rec_e; bb.rec_c = a.blk_rec_c; bb.stat = a.blk_stat;
-        bb.rep_soff = a.rep_soff; bb.rep_moff = a.rep_moff; bb.slot_rep = a.slot_rep; bb.slot_mpos = a.slot_mpos; bb.self_slot = a.self_slot; bb.tmp_d = a.tmp_d; bb.row_off = a.row_off;
-        bb.stride = a.stride; bb.pool = a.blk_pool; bb.item_sbase = a.item_sbase; bb.item_bad = a.item_bad; bb.cursor = a.q_item_cursor + 1; bb.method = a.method;
-        hipStream_t bs = ctx->stream_big;
-        HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_blk[0], 0));
-        const bool timed = ctx->ev_blk_time[0] && ctx->ev_blk_time[1];
-        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[0], bs));
-        if (launch_blocks_up(ctx, bb, bs)) return 1;
-        if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ev_blk_time[1], bs)); ctx->ev_blk_time[0] = nullptr; }  // (recorded: run_block reads them)
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_blk[1], bs));
-    }
+    if (!blk_first && launch_blk()) return 1;
     if (big) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cl[1], 0));
     HIP_TRY(ctx, hipGetLastError());
     return 0;
