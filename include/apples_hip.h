@@ -229,7 +229,11 @@ enum { APPLES_T_PACK = 0, APPLES_T_DIST = 1, APPLES_T_SELECT = 2, APPLES_T_SWEEP
        APPLES_T_COUNT = 8 };
 int apples_last_timing(const apples_ctx *ctx, double *ms, int32_t n);
 
-/* Introspection: device name, packed layout, workspace sizes (JSON text, owned by ctx). */
+/* Introspection: device name, packed layout, workspace sizes (JSON text, owned by ctx).  Which route a context takes is in here:
+ * "sweep_layout" (lean / merge / bits / map / scan), "fused_distance_pass" (fp4 gemm / fp4 mfma / valu), "code_planes",
+ * "cluster_fused", "cluster_blocks", "max_children", "height", "exotic_symbols_as_gaps" / "eight_plane_copy" (bytes beyond ACGT-),
+ * "batch" (queries per device batch), "ragged_rows" / "row_small" / "big_rows" / "big_rows_last_batch" / "full_rows_for_good" (the
+ * clustered route's observation rows: DESIGN.md section 3). */
 const char *apples_describe(apples_ctx *ctx);
 
 /* Backbone branch lengths on a fixed topology, no context needed: replaces the external call
