@@ -541,6 +541,38 @@ def test_c3_backbone_in_the_shapes_real_trees_have(shape):
     assert cc.place_sequences(d.query_seqs[sample]).tobytes() == gc[sample].tobytes()
 
 
+@pytest.mark.parametrize('method', ['OLS', 'FM', 'BME', 'BE'])
+def test_unrooted_backbones_every_method_and_criterion(method):
+    """An unrooted binary backbone -- a root with three children, the tree's only polytomy: what every tree-building program prints.
+    The lean sweep's kernels for trees with polytomies against the level loop (`no_sweep_lean`) for every method, MLSE / ME / HYBRID,
+    with and without `-n`, singleton and clustered, with root children that are leaves (a three-leaf star, a tiny tree) among the
+    shapes; sampled against the C oracle.  (Round 6 also tried the binary tree's kernels with a step of their own for the root: the
+    same bytes, slower on both kinds of tree -- profiles/r06_root3_ab.txt -- and not kept.)"""
+    import bench
+    for n, nq in ((3, 40), (7, 60), (12000, 3000)):
+        d = synth.make_dataset(n, 300, nq, seed_tree=77 + n)
+        d.tree = synth.reshape_tree(d.tree, 'unrooted')
+        nodes = np.array([d.tree.name_to_node[x] for x in d.ref_names], np.int32)
+        ca = bench.make_clusters(d, 0.2) if n > 100 else None
+        for crit, neg in (('MLSE', False), ('ME', True), ('HYBRID', False)):
+            for clusters in ((None, ca) if ca is not None else (None,)):
+                kw = dict(clusters=clusters, method=method, criterion=crit, negative=neg, threshold=0.3)
+                e = Engine(d.tree, d.ref_seqs, nodes, **kw)
+                info = e.describe()
+                got = e.place_sequences(d.query_seqs)
+                e.close()
+                assert info['max_children'] == 3, info
+                e2 = Engine(d.tree, d.ref_seqs, nodes, debug=('no_sweep_lean', 'no_blocks'), **kw)
+                want = e2.place_sequences(d.query_seqs)
+                e2.close()
+                assert got.tobytes() == want.tobytes(), (n, crit, neg, clusters is not None)
+                if crit != 'HYBRID':
+                    sample = np.arange(0, nq, 7)
+                    co = COracle(d.tree, d.ref_seqs, nodes, clusters=clusters, method=method, criterion=crit, negative=neg, threshold=0.3,
+                                 lut=jc69_lut(300, 0.001), threads=NTHREADS)
+                    assert co.place_sequences(d.query_seqs[sample]).tobytes() == got[sample].tobytes(), (n, crit, neg, clusters is not None)
+
+
 def test_clustered_route_beyond_229376_slots():
     """The command line's default route on a reference of more than 229 376 rows (k_select_clusters' bitmap over the slots held that
     many until round 6; 524 288 now: runs of 32 words per thread): 270 000 leaves x L 300, clusters + consensus representatives,
